@@ -1,0 +1,122 @@
+"""ORACLE -- TEST INFRASTRUCTURE ONLY. ctypes wrapper over oracle/liboracle.so
+(oracle/simple_reference.c)."""
+import ctypes
+import os
+import subprocess
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "liboracle.so")
+    src = os.path.join(_HERE, "simple_reference.c")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["gcc", "-O3", "-march=native", "-shared", "-fPIC",
+                               "-o", so, src, "-lm"])
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = ctypes.CDLL(build())
+        for name in ("oracle_bfs", "oracle_sssp", "oracle_pr", "oracle_cc", "oracle_tc"):
+            getattr(_LIB, name).restype = ctypes.c_double
+        _LIB.oracle_cc_verify.restype = ctypes.c_int
+        _LIB.oracle_bfs_do_stats.restype = ctypes.c_int
+    return _LIB
+
+
+def _p(a, t):
+    return a.ctypes.data_as(ctypes.POINTER(t))
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def bfs(row_ptr, col_ind, src, stop=10000):
+    rp, ci = _i32(row_ptr), _i32(col_ind)
+    n = rp.size - 1
+    depth = np.zeros(n, dtype=np.float32)
+    sd = ctypes.c_int(0)
+    ms = lib().oracle_bfs(n, _p(rp, ctypes.c_int), _p(ci, ctypes.c_int), _p(depth, ctypes.c_float),
+                          int(src), int(stop), ctypes.byref(sd))
+    return depth, sd.value, ms
+
+
+def sssp(row_ptr, col_ind, val, src):
+    rp, ci = _i32(row_ptr), _i32(col_ind)
+    v = np.ascontiguousarray(val, dtype=np.float32)
+    n = rp.size - 1
+    dist = np.zeros(n, dtype=np.float32)
+    sd = ctypes.c_int(0)
+    ms = lib().oracle_sssp(n, _p(rp, ctypes.c_int), _p(ci, ctypes.c_int), _p(v, ctypes.c_float),
+                           _p(dist, ctypes.c_float), int(src), ctypes.byref(sd))
+    return dist, sd.value, ms
+
+
+def pr(row_ptr, col_ind, alpha=0.85, eps=1e-8, max_niter=10):
+    rp, ci = _i32(row_ptr), _i32(col_ind)
+    n = rp.size - 1
+    rank = np.zeros(n, dtype=np.float32)
+    it = ctypes.c_int(0)
+    res = ctypes.c_float(0)
+    ms = lib().oracle_pr(n, _p(rp, ctypes.c_int), _p(ci, ctypes.c_int), _p(rank, ctypes.c_float),
+                         ctypes.c_float(alpha), ctypes.c_float(eps), int(max_niter),
+                         ctypes.byref(it), ctypes.byref(res))
+    return rank, it.value, res.value, ms
+
+
+def cc(row_ptr, col_ind):
+    rp, ci = _i32(row_ptr), _i32(col_ind)
+    n = rp.size - 1
+    label = np.zeros(n, dtype=np.int32)
+    nc = ctypes.c_int(0)
+    ms = lib().oracle_cc(n, _p(rp, ctypes.c_int), _p(ci, ctypes.c_int), _p(label, ctypes.c_int),
+                         ctypes.byref(nc))
+    return label, nc.value, ms
+
+
+def cc_verify(row_ptr, col_ind, label):
+    rp, ci, lb = _i32(row_ptr), _i32(col_ind), _i32(label)
+    nd = ctypes.c_int(0)
+    err = lib().oracle_cc_verify(rp.size - 1, _p(rp, ctypes.c_int), _p(ci, ctypes.c_int),
+                                 _p(lb, ctypes.c_int), ctypes.byref(nd))
+    return err, nd.value
+
+
+def cc_canonical(label):
+    """Canonicalise a component labelling to 'min vertex id in component'."""
+    label = np.asarray(label)
+    first = {}
+    out = np.empty(label.size, dtype=np.int32)
+    order = np.argsort(label, kind="stable")
+    lab_sorted = label[order]
+    starts = np.r_[0, np.nonzero(np.diff(lab_sorted))[0] + 1]
+    mins = np.minimum.reduceat(order, starts)
+    out[order] = np.repeat(mins, np.diff(np.r_[starts, label.size]))
+    return out
+
+
+def tc(row_ptr, col_ind):
+    rp, ci = _i32(row_ptr), _i32(col_ind)
+    nt = ctypes.c_longlong(0)
+    ms = lib().oracle_tc(rp.size - 1, _p(rp, ctypes.c_int), _p(ci, ctypes.c_int), ctypes.byref(nt))
+    return nt.value, ms
+
+
+def bfs_do_stats(csr_ptr, csr_ind, csc_ptr, csc_ind, src, mxvmode=10, switchpoint=0.01,
+                 max_niter=10000, max_levels=100000):
+    a, b, c, d = _i32(csr_ptr), _i32(csr_ind), _i32(csc_ptr), _i32(csc_ind)
+    n = a.size - 1
+    depth = np.zeros(n, dtype=np.float32)
+    stats = np.zeros((max_levels, 6), dtype=np.int64)
+    lv = lib().oracle_bfs_do_stats(n, _p(a, ctypes.c_int), _p(b, ctypes.c_int), _p(c, ctypes.c_int),
+                                   _p(d, ctypes.c_int), int(src), int(mxvmode),
+                                   ctypes.c_float(switchpoint), int(max_niter),
+                                   _p(depth, ctypes.c_float), _p(stats, ctypes.c_longlong),
+                                   int(max_levels))
+    return depth, stats[:min(lv, max_levels)].copy()
