@@ -1,0 +1,232 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json's metric on MI355X: direction-optimised BFS TEPS (+ SpMV
+achieved HBM GB/s) on RMAT scale 22, edge factor 16.
+
+  python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+
+A step = one direction-optimised BFS (algorithm::bfs, --mxvmode 0 --struconly 1
+--opreuse 1 --earlyexit 1, the authors' flag set of run_bfs.sh) from the next source of a
+fixed seeded source list over the RMAT-22 graph already resident in HBM.  value = directed
+stored edges traversed (sum of out-degree over reached vertices) per
+second over the K timed steps, whole job.  At N > 1 the graph is 1-D vertex partitioned
+(graphblast_amd/dist.py) and the same K traversals run cooperatively ("strong" scaling).
+
+Rank 0 prints ONE JSON line.  Extra objects on it:
+  roofline      dominant kernel of the timed region (the pull-step kernel): algorithmic
+                bytes per launch / mean launch duration from HIP events
+                recorded on the library's stream inside the timed steps
+  bfs_total     whole-traversal algorithmic GB/s and the per-level table of one traversal
+  spmv          the generic SpMV kernel (PlusMultiplies, f32) on the same graph: algorithmic
+                8*nnz + 12*n + 4 bytes per launch / HIP-event mean launch time
+  cpu_baseline  the oracle's SimpleReferenceBfs restatement (one host core) on a bounded
+                sample of the same workload (rank 0, N = 1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def level_bytes(levels, n):
+    """push 12 nf + 8 mf + 8 nf'; pull 4 n + 8 nu + 8 mi + 4 nf'."""
+    out = []
+    reached = 1
+    for L in levels:
+        nf, nfn = L["frontier"], L["discovered"]
+        if L["direction"] == "push":
+            b = 12 * nf + 8 * L["frontier_edges"] + 8 * nfn
+        else:
+            nu = n - reached
+            b = 4 * n + 8 * nu + 8 * L["frontier_edges"] + 4 * nfn
+        reached += nfn
+        out.append(b)
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=32)
+    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--scale", type=int, default=22)
+    ap.add_argument("--edge-factor", type=int, default=16)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..."
+                             % (args.gpus, args.gpus))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import graphblast_amd as g
+    from graphblast_amd.graphgen import rmat_edges, finalize_edges, random_sources
+
+    # ---- synthetic input, identical on every rank (seeded), built on the GPU -------------
+    src, dst, n = rmat_edges(args.scale, args.edge_factor, seed=1, device=dev)
+    gr = finalize_edges(src, dst, n, symmetrize=True)
+    del src, dst
+    tptr, tind = gr["csr"]
+    nnz = gr["nnz"]
+    ptr_host = tptr.cpu().numpy()
+    deg = np.diff(ptr_host)
+    sources = [int(np.argmax(deg))] + random_sources(ptr_host, 63, seed=0)
+    workload = "rmat%d_ef%d_sym_do_bfs" % (args.scale, args.edge_factor)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    extra = {}
+    if world == 1:
+        tval = torch.ones(nnz, dtype=torch.float32, device=dev)
+        torch.cuda.synchronize()
+        A = g.Matrix(n, n)
+        info = A.build_device_csr(tptr.data_ptr(), tind.data_ptr(), tval.data_ptr(), nnz, tptr.data_ptr(),
+                                  tind.data_ptr(), tval.data_ptr(), keep=(tptr, tind, tval))
+        assert info == 0, info
+        desc = g.Descriptor()
+        assert desc.loadArgs(mxvmode=0, struconly=1, opreuse=1, earlyexit=1) == 0
+        v = g.Vector(n)
+
+        def run_step(i, profile=1):
+            info, res = g.bfs(v, A, sources[i % len(sources)], desc, fused=True, profile=profile)
+            assert info == 0, info
+            return res
+
+        for i in range(args.warmup):
+            run_step(i)
+        barrier()
+        t0 = time.perf_counter()
+        results = [run_step(i) for i in range(args.steps)]
+        barrier()
+        elapsed = time.perf_counter() - t0
+        edges = sum(r["edges_traversed"] for r in results)
+
+        # ---- roofline of the dominant kernel (pull step), from the timed steps' HIP events
+        used = sorted(set(sources[i % len(sources)] for i in range(args.steps)))
+        inspected = {}
+        for s in used:                      # same deterministic decisions; counts inspected edges
+            inspected[s] = g.bfs(v, A, s, desc, fused=True, profile=3)[1]["per_level"]
+        pull_bytes = pull_ms = push_bytes = push_ms = 0.0
+        npull = npush = 0
+        for i, r in enumerate(results):
+            ref = inspected[sources[i % len(sources)]]
+            lv = [dict(L, frontier_edges=(R["frontier_edges"] if L["direction"] == "pull" else L["frontier_edges"]))
+                  for L, R in zip(r["per_level"], ref)]
+            for L, b in zip(lv, level_bytes(lv, n)):
+                if L["direction"] == "pull":
+                    pull_bytes += b; pull_ms += L["ms"]; npull += 1
+                else:
+                    push_bytes += b; push_ms += L["ms"]; npush += 1
+        tight_ms = sum(r["tight_ms"] for r in results)
+        dom_pull = pull_ms >= push_ms
+        kb, kms, kn = (pull_bytes, pull_ms, npull) if dom_pull else (push_bytes, push_ms, npush)
+        ach = kb / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
+        roofline = {"bound": "hbm", "kernel": "bfs_pull_kernel" if dom_pull else "lb_expand_kernel<BfsPushVisitor>",
+                    "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                    "traffic": None, "launches": kn, "avg_launch_ms": round(kms / max(kn, 1), 5),
+                    "algorithmic_bytes_per_launch": int(kb / max(kn, 1))}
+        one = inspected[sources[0]]
+        ob = level_bytes(one, n)
+        extra["bfs_total"] = {
+            "algorithmic_GBps": round((pull_bytes + push_bytes) / (tight_ms * 1e-3) / 1e9, 2),
+            "frac_of_hbm_peak": round((pull_bytes + push_bytes) / (tight_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "tight_ms_mean": round(tight_ms / args.steps, 4),
+            "graph500_teps": edges / 2 / elapsed,
+            "levels_source0": [dict(dir=L["direction"], nf=L["frontier"], edges=L["frontier_edges"],
+                                    found=L["discovered"], ms=round(L["ms"], 4), bytes=int(b))
+                               for L, b in zip(one, ob)],
+        }
+
+        # ---- generic SpMV kernel on the same graph (the metric's second half)
+        x = torch.rand(n, dtype=torch.float32, device=dev)
+        y = torch.empty(n, dtype=torch.float32, device=dev)
+        torch.cuda.synchronize()
+        for _ in range(3):
+            assert g.k_spmv(A, 0, "PlusMultiplies", x.data_ptr(), None, 0, 0, y.data_ptr()) == 0
+        reps = 20
+        g.timer_start()
+        for _ in range(reps):
+            g.k_spmv(A, 0, "PlusMultiplies", x.data_ptr(), None, 0, 0, y.data_ptr())
+        ms = g.timer_stop() / reps
+        sb = g.k_spmv_bytes(A, 0)
+        extra["spmv"] = {"kernel": "spmv_stream_kernel<PlusMultiplies,f32>", "bound": "hbm",
+                         "algorithmic_bytes_per_launch": sb, "avg_launch_ms": round(ms, 5),
+                         "achieved": round(sb / (ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(sb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "gflops": round(2 * nnz / (ms * 1e-3) / 1e9, 1)}
+
+        # ---- CPU baseline: the oracle's sequential BFS on a bounded sample (checker code,
+        #      timed beside the GPU run; never part of the product path)
+        if not args.no_cpu_baseline:
+            from oracle import simple_reference as sr
+            ind_host = tind.cpu().numpy()
+            nsamp = 3
+            cpu_edges, cpu_ms = 0, 0.0
+            for s in sources[:nsamp]:
+                depth, _, ms_ = sr.bfs(ptr_host, ind_host, s)
+                cpu_edges += int(deg[depth != 0].sum())
+                cpu_ms += ms_
+            extra["cpu_baseline"] = {"value": cpu_edges / (cpu_ms * 1e-3), "unit": "TEPS", "cores": 1, "kind": "port",
+                                     "sample": "SimpleReferenceBfs restatement (oracle/simple_reference.c), %d of the "
+                                               "timed sources on the same RMAT-%d graph, traversal loop only" % (nsamp, args.scale),
+                                     "ms_per_bfs": round(cpu_ms / nsamp, 2)}
+        parallelism = "single"
+    else:
+        from graphblast_amd import dist as gdist
+        part = gdist.Partition1D(n, tptr, tind, rank, world, dev)
+        del tptr, tind
+        for i in range(args.warmup):
+            part.bfs(sources[i % len(sources)])
+        barrier()
+        t0 = time.perf_counter()
+        edges = 0
+        for i in range(args.steps):
+            edges += part.bfs(sources[i % len(sources)])["edges_traversed"]
+        barrier()
+        elapsed = time.perf_counter() - t0
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        roofline = None
+        parallelism = "1d_vertex_partition_x%d" % world
+
+    if rank == 0:
+        line = {
+            "metric": "BFS TEPS (edges/sec) + SpMV achieved HBM GB/s on RMAT-22, 1/2/4/8 MI355X",
+            "value": edges / elapsed, "unit": "TEPS", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": workload, "n": n, "nnz": nnz, "edge_convention": "directed stored edges",
+                       "flags": "mxvmode=0 struconly=1 opreuse=1 earlyexit=1 switchpoint=0.01",
+                       "sources": len(sources), "parallelism": parallelism},
+            "roofline": roofline,
+        }
+        line.update(extra)
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,139 @@
+"""ctypes binding of libgrb_hip.so (include/grb_hip.h).
+
+There is deliberately no fallback: if the HIP library is missing or a call fails, this
+module raises.  The Python layer is plumbing over the C ABI -- the same binding a
+maintainer of the reference would write for any FFI host.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgrb_hip.so")
+
+# graphblas::Info names, types.hpp:28-42
+INFO_NAMES = ["GrB_SUCCESS", "GrB_UNINITIALIZED_OBJECT", "GrB_NULL_POINTER", "GrB_INVALID_VALUE",
+              "GrB_INVALID_INDEX", "GrB_DOMAIN_MISMATCH", "GrB_DIMENSION_MISMATCH",
+              "GrB_OUTPUT_NOT_EMPTY", "GrB_NO_VALUE", "GrB_NOT_IMPLEMENTED", "GrB_OUT_OF_MEMORY",
+              "GrB_INSUFFICIENT_SPACE", "GrB_INVALID_OBJECT", "GrB_INDEX_OUT_OF_BOUNDS", "GrB_PANIC"]
+
+
+class GrbError(RuntimeError):
+    def __init__(self, info, what):
+        self.info = info
+        name = INFO_NAMES[info] if 0 <= info < len(INFO_NAMES) else str(info)
+        super().__init__("%s returned %s" % (what, name))
+
+
+class BfsResult(C.Structure):
+    _fields_ = [("levels", C.c_int), ("tight_ms", C.c_float), ("edges_traversed", C.c_int64),
+                ("reached", C.c_int32)]
+
+
+class AlgoResult(C.Structure):
+    _fields_ = [("iterations", C.c_int), ("tight_ms", C.c_float), ("last_value", C.c_double)]
+
+
+class BfsLevel(C.Structure):
+    _fields_ = [("direction", C.c_int32), ("frontier", C.c_int32), ("frontier_edges", C.c_int64),
+                ("discovered", C.c_int32), ("ms", C.c_float)]
+
+
+_vp, _i, _d, _f = C.c_void_p, C.c_int, C.c_double, C.c_float
+_ip = C.POINTER(C.c_int)
+_SIGS = {
+    "grb_set_stream": [_vp],
+    "grb_device_info": [C.c_char_p, C.c_size_t],
+    "grb_timer_start": [],
+    "grb_timer_stop": [C.POINTER(_f)],
+    "grb_descriptor_new": [C.POINTER(_vp)],
+    "grb_descriptor_free": [_vp],
+    "grb_descriptor_set": [_vp, _i, _i],
+    "grb_descriptor_get": [_vp, _i, _ip],
+    "grb_descriptor_toggle": [_vp, _i],
+    "grb_descriptor_load_defaults": [_vp],
+    "grb_descriptor_set_arg": [_vp, C.c_char_p, _d],
+    "grb_descriptor_get_arg": [_vp, C.c_char_p, C.POINTER(_d)],
+    "grb_descriptor_lastmxv": [_vp, _ip],
+    "grb_vector_new": [C.POINTER(_vp), _i, _i],
+    "grb_vector_free": [_vp],
+    "grb_vector_dup": [_vp, _vp],
+    "grb_vector_clear": [_vp],
+    "grb_vector_size": [_vp, _ip],
+    "grb_vector_nvals": [_vp, _ip],
+    "grb_vector_build_sparse": [_vp, _vp, _vp, _i],
+    "grb_vector_build_dense": [_vp, _vp, _i],
+    "grb_vector_adopt_dense": [_vp, _vp, _i],
+    "grb_vector_adopt_sparse": [_vp, _vp, _vp, _i],
+    "grb_vector_set_element": [_vp, _d, _i],
+    "grb_vector_extract_element": [_vp, C.POINTER(_d), _i],
+    "grb_vector_extract_tuples_sparse": [_vp, _vp, _vp, _ip],
+    "grb_vector_extract_tuples_dense": [_vp, _vp, _ip],
+    "grb_vector_fill": [_vp, _d],
+    "grb_vector_fill_ascending": [_vp, _i],
+    "grb_vector_get_storage": [_vp, _ip],
+    "grb_vector_set_storage": [_vp, _i],
+    "grb_vector_swap": [_vp, _vp],
+    "grb_vector_convert": [_vp, _d, _f, _vp],
+    "grb_vector_sparse2dense": [_vp, _d, _vp],
+    "grb_vector_dense2sparse": [_vp, _d, _vp],
+    "grb_vector_device_ptrs": [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp)],
+    "grb_matrix_new": [C.POINTER(_vp), _i, _i, _i],
+    "grb_matrix_free": [_vp],
+    "grb_matrix_build": [_vp, _vp, _vp, _vp, _i],
+    "grb_matrix_build_csr": [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp],
+    "grb_matrix_adopt_device_csr": [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp],
+    "grb_matrix_nrows": [_vp, _ip],
+    "grb_matrix_ncols": [_vp, _ip],
+    "grb_matrix_nvals": [_vp, _ip],
+    "grb_matrix_host_csr": [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp)],
+    "grb_matrix_host_csc": [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp)],
+    "grb_matrix_set_values": [_vp, _vp],
+    "grb_vxm": [_vp, _vp, _i, _i, _vp, _vp, _vp],
+    "grb_mxv": [_vp, _vp, _i, _i, _vp, _vp, _vp],
+    "grb_eWiseMult": [_vp, _vp, _i, _i, _vp, _vp, _vp],
+    "grb_eWiseAdd": [_vp, _vp, _i, _i, _vp, _vp, _vp],
+    "grb_eWiseAdd_scalar": [_vp, _vp, _i, _i, _vp, _d, _vp],
+    "grb_reduce_vector": [C.POINTER(_d), _i, _i, _vp, _vp],
+    "grb_reduce_matrix_rows": [_vp, _vp, _i, _i, _vp, _vp],
+    "grb_assign": [_vp, _vp, _i, _d, _vp],
+    "grb_bfs": [_vp, _vp, _i, _vp, C.POINTER(BfsResult)],
+    "grb_bfs_fused": [_vp, _vp, _i, _vp, C.POINTER(BfsResult), C.POINTER(BfsLevel), _i, _i],
+    "grb_sssp": [_vp, _vp, _i, _vp, C.POINTER(AlgoResult)],
+    "grb_pr": [_vp, _vp, _f, _f, _vp, C.POINTER(AlgoResult)],
+    "grb_k_spmv": [_vp, _i, _i, _vp, _vp, _i, _i, _vp],
+}
+
+_lib = None
+
+
+def load():
+    """dlopen the library; never silently substitutes anything."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("graphblast_amd: %s not found -- build it with `python -c 'import "
+                          "__graft_entry__ as g; g.build()'` (hipcc, gfx950). There is no CPU "
+                          "fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, args in _SIGS.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = C.c_int
+    lib.grb_version.restype = C.c_char_p
+    lib.grb_version.argtypes = []
+    lib.grb_k_spmv_bytes.restype = C.c_int64
+    lib.grb_k_spmv_bytes.argtypes = [_vp, _i]
+    _lib = lib
+    return lib
+
+
+def check(info, what):
+    if info != 0:
+        raise GrbError(info, what)
+
+
+def call(name, *args):
+    info = getattr(load(), name)(*args)
+    if info != 0:
+        raise GrbError(info, name)

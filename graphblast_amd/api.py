@@ -1,0 +1,407 @@
+"""Host-side mirror of the reference frontend over the C ABI.
+
+Same names, argument order and error behaviour as `graphblas::Vector`,
+`graphblas::Matrix`, `graphblas::Descriptor` (graphblas/{vector,matrix,descriptor}.hpp)
+and the free functions of graphblas/operations.hpp, so a test written against the
+reference reads the same here.  Operations return the `graphblas::Info` code (they do
+not raise) exactly like the reference's functions; container constructors raise on
+allocation failure.  All compute happens in libgrb_hip.so -- this file moves pointers.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import BfsLevel, BfsResult, AlgoResult
+
+# graphblas/types.hpp
+GrB_NULL = None
+GrB_ALL = None
+(GrB_SUCCESS, GrB_UNINITIALIZED_OBJECT, GrB_NULL_POINTER, GrB_INVALID_VALUE, GrB_INVALID_INDEX,
+ GrB_DOMAIN_MISMATCH, GrB_DIMENSION_MISMATCH, GrB_OUTPUT_NOT_EMPTY, GrB_NO_VALUE,
+ GrB_NOT_IMPLEMENTED, GrB_OUT_OF_MEMORY, GrB_INSUFFICIENT_SPACE, GrB_INVALID_OBJECT,
+ GrB_INDEX_OUT_OF_BOUNDS, GrB_PANIC) = range(15)
+GrB_UNKNOWN, GrB_SPARSE, GrB_DENSE = 0, 1, 2
+(GrB_MASK, GrB_OUTP, GrB_INP0, GrB_INP1, GrB_MODE, GrB_TA, GrB_TB, GrB_NT, GrB_MXVMODE, GrB_TOL,
+ GrB_BACKEND) = range(11)
+GrB_SCMP, GrB_REPLACE, GrB_TRAN, GrB_DEFAULT = 0, 1, 2, 3
+GrB_PUSHPULL, GrB_PUSHONLY, GrB_PULLONLY = 10, 11, 12
+
+F32, I32 = 0, 1
+_NP = {F32: np.float32, I32: np.int32}
+
+# graphblas/stddef.hpp:159-172 / :195-213 (order == include/grb_hip.h enums)
+MONOIDS = ["Plus", "Multiplies", "Minimum", "Maximum", "LogicalOr", "LogicalAnd", "Greater",
+           "CustomLess", "NotEqualTo"]
+SEMIRINGS = ["LogicalOrAnd", "PlusMultiplies", "MinimumPlus", "MaximumMultiplies", "PlusDivides",
+             "PlusGreater", "GreaterPlus", "PlusMinus", "PlusLess", "CustomLessPlus",
+             "MinimumMultiplies", "MultipliesMultiplies", "NotEqualToPlus", "MinimumSelectSecond",
+             "PlusNotEqualTo", "CustomLessLess", "MinimumNotEqualTo"]
+
+
+def _monoid_id(op):
+    if isinstance(op, int):
+        return op
+    name = op[:-len("Monoid")] if op.endswith("Monoid") else op
+    return MONOIDS.index(name)
+
+
+def _semiring_id(op):
+    if isinstance(op, int):
+        return op
+    name = op[:-len("Semiring")] if op.endswith("Semiring") else op
+    return SEMIRINGS.index(name)
+
+
+def _h(obj):
+    return None if obj is None else obj._h
+
+
+def _accum(accum):
+    return 0 if accum is None else 1
+
+
+def _dtype_code(dtype):
+    if dtype in (F32, I32):
+        return dtype
+    dt = np.dtype(dtype)
+    if dt == np.float32:
+        return F32
+    if dt == np.int32 or dt == np.bool_:
+        return I32          # Vector<bool> of the reference maps to 4-byte ints
+    raise TypeError("graphblast_amd supports float32 and int32 vectors/matrices")
+
+
+class Descriptor:
+    """graphblas::Descriptor (descriptor.hpp:17-39)."""
+
+    def __init__(self):
+        self._h = C.c_void_p()
+        _lib.call("grb_descriptor_new", C.byref(self._h))
+
+    def __del__(self):
+        try:
+            if self._h:
+                _lib.load().grb_descriptor_free(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def set(self, field, value):
+        return _lib.load().grb_descriptor_set(self._h, field, value)
+
+    def get(self, field):
+        out = C.c_int(0)
+        _lib.call("grb_descriptor_get", self._h, field, C.byref(out))
+        return out.value
+
+    def toggle(self, field):
+        return _lib.load().grb_descriptor_toggle(self._h, field)
+
+    def loadArgs(self, **vm):
+        """Descriptor::loadArgs: parseArgs defaults (util.hpp:39-132), then the given flags."""
+        info = _lib.load().grb_descriptor_load_defaults(self._h)
+        for k, val in vm.items():
+            if info != 0:
+                break
+            info = _lib.load().grb_descriptor_set_arg(self._h, k.encode(), float(val))
+        return info
+
+    def arg(self, name):
+        out = C.c_double(0)
+        _lib.call("grb_descriptor_get_arg", self._h, name.encode(), C.byref(out))
+        return out.value
+
+    @property
+    def lastmxv_(self):
+        out = C.c_int(0)
+        _lib.call("grb_descriptor_lastmxv", self._h, C.byref(out))
+        return out.value
+
+
+class Vector:
+    """graphblas::Vector<T> (vector.hpp:12-66); T in {float32, int32}."""
+
+    def __init__(self, nsize, dtype=np.float32):
+        self.dtype_code = _dtype_code(dtype)
+        self.np_dtype = _NP[self.dtype_code]
+        self._h = C.c_void_p()
+        _lib.call("grb_vector_new", C.byref(self._h), self.dtype_code, int(nsize))
+        self._keep = []
+
+    def __del__(self):
+        try:
+            if self._h:
+                _lib.load().grb_vector_free(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    # -- C API methods --------------------------------------------------------
+    def dup(self, rhs):
+        return _lib.load().grb_vector_dup(self._h, rhs._h)
+
+    def clear(self):
+        return _lib.load().grb_vector_clear(self._h)
+
+    def size(self):
+        out = C.c_int(0)
+        _lib.call("grb_vector_size", self._h, C.byref(out))
+        return out.value
+
+    def nvals(self):
+        out = C.c_int(0)
+        _lib.call("grb_vector_nvals", self._h, C.byref(out))
+        return out.value
+
+    def build(self, *args):
+        """build(indices, values, nvals, dup)  -> sparse;  build(values, nvals) -> dense."""
+        lib = _lib.load()
+        if len(args) >= 3 and args[1] is not None and not np.isscalar(args[1]):
+            idx = np.ascontiguousarray(args[0], dtype=np.int32)
+            val = np.ascontiguousarray(args[1], dtype=self.np_dtype)
+            n = int(args[2])
+            return lib.grb_vector_build_sparse(self._h, idx.ctypes.data, val.ctypes.data, n)
+        val = np.ascontiguousarray(args[0], dtype=self.np_dtype)
+        n = int(args[1]) if len(args) > 1 else val.size
+        return lib.grb_vector_build_dense(self._h, val.ctypes.data, n)
+
+    def build_device(self, d_values_ptr, nvals, d_indices_ptr=None):
+        """build(T* values, nvals) / build(Index*, T*, nvals): adopt device pointers."""
+        lib = _lib.load()
+        if d_indices_ptr is None:
+            return lib.grb_vector_adopt_dense(self._h, d_values_ptr, int(nvals))
+        return lib.grb_vector_adopt_sparse(self._h, d_indices_ptr, d_values_ptr, int(nvals))
+
+    def setElement(self, val, index):
+        return _lib.load().grb_vector_set_element(self._h, float(val), int(index))
+
+    def extractElement(self, index):
+        out = C.c_double(0)
+        info = _lib.load().grb_vector_extract_element(self._h, C.byref(out), int(index))
+        return info, self.np_dtype(out.value)
+
+    def extractTuples(self, n=None, sparse=False):
+        """extractTuples(values, n) (dense; densifies a sparse vector with fill 0) or, with
+        sparse=True, extractTuples(indices, values, n).  Returns (info, ...arrays)."""
+        lib = _lib.load()
+        if sparse:
+            n = self.nvals() if n is None else int(n)
+            idx = np.zeros(max(n, 1), dtype=np.int32)
+            val = np.zeros(max(n, 1), dtype=self.np_dtype)
+            cn = C.c_int(n)
+            info = lib.grb_vector_extract_tuples_sparse(self._h, idx.ctypes.data, val.ctypes.data, C.byref(cn))
+            return info, idx[:n], val[:n]
+        n = self.size() if n is None else int(n)
+        val = np.zeros(max(n, 1), dtype=self.np_dtype)
+        cn = C.c_int(n)
+        info = lib.grb_vector_extract_tuples_dense(self._h, val.ctypes.data, C.byref(cn))
+        return info, val[:n]
+
+    def fill(self, val):
+        return _lib.load().grb_vector_fill(self._h, float(val))
+
+    def fillAscending(self, nvals=0):
+        return _lib.load().grb_vector_fill_ascending(self._h, int(nvals))
+
+    def getStorage(self):
+        out = C.c_int(0)
+        _lib.call("grb_vector_get_storage", self._h, C.byref(out))
+        return out.value
+
+    def setStorage(self, storage):
+        return _lib.load().grb_vector_set_storage(self._h, int(storage))
+
+    def swap(self, rhs):
+        return _lib.load().grb_vector_swap(self._h, rhs._h)
+
+    # backend::Vector methods the reference's tests reach through `#define private public`
+    def convert(self, identity, switchpoint, desc):
+        return _lib.load().grb_vector_convert(self._h, float(identity), float(switchpoint), desc._h)
+
+    def sparse2dense(self, identity, desc=None):
+        return _lib.load().grb_vector_sparse2dense(self._h, float(identity), _h(desc))
+
+    def dense2sparse(self, identity, desc):
+        return _lib.load().grb_vector_dense2sparse(self._h, float(identity), desc._h)
+
+    def device_ptrs(self):
+        a, b, c = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        _lib.call("grb_vector_device_ptrs", self._h, C.byref(a), C.byref(b), C.byref(c))
+        return a.value, b.value, c.value
+
+
+class Matrix:
+    """graphblas::Matrix<T> (matrix.hpp:13-84)."""
+
+    def __init__(self, nrows, ncols, dtype=np.float32):
+        self.dtype_code = _dtype_code(dtype)
+        self.np_dtype = _NP[self.dtype_code]
+        self._h = C.c_void_p()
+        self._nrows, self._ncols = int(nrows), int(ncols)
+        _lib.call("grb_matrix_new", C.byref(self._h), self.dtype_code, self._nrows, self._ncols)
+        self._keep = []
+
+    def __del__(self):
+        try:
+            if self._h:
+                _lib.load().grb_matrix_free(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def build(self, row_indices, col_indices, values, nvals=None, dup=None):
+        r = np.ascontiguousarray(row_indices, dtype=np.int32)
+        c = np.ascontiguousarray(col_indices, dtype=np.int32)
+        v = np.ascontiguousarray(values, dtype=self.np_dtype)
+        n = r.size if nvals is None else int(nvals)
+        return _lib.load().grb_matrix_build(self._h, r.ctypes.data, c.ctypes.data, v.ctypes.data, n)
+
+    def build_csr(self, row_ptr, col_ind, values, csc=None):
+        p = np.ascontiguousarray(row_ptr, dtype=np.int32)
+        i = np.ascontiguousarray(col_ind, dtype=np.int32)
+        v = np.ascontiguousarray(values, dtype=self.np_dtype)
+        if csc is None:
+            return _lib.load().grb_matrix_build_csr(self._h, p.ctypes.data, i.ctypes.data, v.ctypes.data,
+                                                    i.size, None, None, None)
+        cp = np.ascontiguousarray(csc[0], dtype=np.int32)
+        ci = np.ascontiguousarray(csc[1], dtype=np.int32)
+        cv = np.ascontiguousarray(csc[2], dtype=self.np_dtype)
+        return _lib.load().grb_matrix_build_csr(self._h, p.ctypes.data, i.ctypes.data, v.ctypes.data, i.size,
+                                                cp.ctypes.data, ci.ctypes.data, cv.ctypes.data)
+
+    def build_device_csr(self, d_ptr, d_ind, d_val, nvals, d_cptr=None, d_cind=None, d_cval=None, keep=()):
+        """build(row_ptr, col_ind, values, nvals) adopting device pointers; `keep` holds
+        whatever owns that memory (e.g. torch tensors) alive."""
+        self._keep = list(keep)
+        return _lib.load().grb_matrix_adopt_device_csr(self._h, d_ptr, d_ind, d_val, int(nvals), d_cptr, d_cind,
+                                                       d_cval)
+
+    def nrows(self):
+        return self._nrows
+
+    def ncols(self):
+        return self._ncols
+
+    def nvals(self):
+        out = C.c_int(0)
+        _lib.call("grb_matrix_nvals", self._h, C.byref(out))
+        return out.value
+
+    def _host(self, which):
+        p, i, v = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        _lib.call(which, self._h, C.byref(p), C.byref(i), C.byref(v))
+        n = self._nrows if which.endswith("csr") else self._ncols
+        nv = self.nvals()
+        ptr = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_int32)), shape=(n + 1,)).copy()
+        ind = np.ctypeslib.as_array(C.cast(i, C.POINTER(C.c_int32)), shape=(max(nv, 1),))[:nv].copy()
+        raw = np.ctypeslib.as_array(C.cast(v, C.POINTER(C.c_uint32)), shape=(max(nv, 1),))[:nv].copy()
+        return ptr, ind, raw.view(self.np_dtype)
+
+    def host_csr(self):
+        """h_csrRowPtr_, h_csrColInd_, h_csrVal_ (what the CPU oracles read)."""
+        return self._host("grb_matrix_host_csr")
+
+    def host_csc(self):
+        return self._host("grb_matrix_host_csc")
+
+    def set_values(self, csr_values):
+        v = np.ascontiguousarray(csr_values, dtype=self.np_dtype)
+        return _lib.load().grb_matrix_set_values(self._h, v.ctypes.data)
+
+
+# ---- graphblas/operations.hpp ------------------------------------------------------
+def vxm(w, mask, accum, op, u, A, desc):
+    return _lib.load().grb_vxm(_h(w), _h(mask), _accum(accum), _semiring_id(op), _h(u), _h(A), _h(desc))
+
+
+def mxv(w, mask, accum, op, A, u, desc):
+    return _lib.load().grb_mxv(_h(w), _h(mask), _accum(accum), _semiring_id(op), _h(A), _h(u), _h(desc))
+
+
+def eWiseMult(w, mask, accum, op, u, v, desc):
+    return _lib.load().grb_eWiseMult(_h(w), _h(mask), _accum(accum), _semiring_id(op), _h(u), _h(v), _h(desc))
+
+
+def eWiseAdd(w, mask, accum, op, u, v, desc):
+    """eWiseAdd(w, mask, accum, op, u, v | scalar, desc)."""
+    if isinstance(v, Vector):
+        return _lib.load().grb_eWiseAdd(_h(w), _h(mask), _accum(accum), _semiring_id(op), _h(u), _h(v), _h(desc))
+    return _lib.load().grb_eWiseAdd_scalar(_h(w), _h(mask), _accum(accum), _semiring_id(op), _h(u), float(v),
+                                           _h(desc))
+
+
+def reduce(accum, op, u, desc, w=None, mask=None):
+    """reduce(&val, accum, MonoidT, Vector u, desc) -> (info, val)  or, with w given and u a
+    Matrix, reduce(Vector w, mask, accum, MonoidT, Matrix A, desc) -> info."""
+    if isinstance(u, Matrix):
+        return _lib.load().grb_reduce_matrix_rows(_h(w), _h(mask), _accum(accum), _monoid_id(op), _h(u), _h(desc))
+    out = C.c_double(0)
+    info = _lib.load().grb_reduce_vector(C.byref(out), _accum(accum), _monoid_id(op), _h(u), _h(desc))
+    return info, out.value
+
+
+def assign(w, mask, accum, val, indices, nindices, desc):
+    """assign(w, mask, accum, val, GrB_ALL, n, desc)."""
+    if indices is not None:
+        return GrB_NOT_IMPLEMENTED
+    return _lib.load().grb_assign(_h(w), _h(mask), _accum(accum), float(val), _h(desc))
+
+
+# ---- graphblas/algorithm/*.hpp -----------------------------------------------------
+def bfs(v, A, s, desc, fused=False, profile=False, max_levels=4096):
+    """algorithm::bfs. Returns (info, result dict). fused=True runs the device-resident loop."""
+    res = BfsResult()
+    if not fused:
+        info = _lib.load().grb_bfs(_h(v), _h(A), int(s), _h(desc), C.byref(res))
+        return info, dict(levels=res.levels, tight_ms=res.tight_ms)
+    lv = (BfsLevel * max_levels)()
+    info = _lib.load().grb_bfs_fused(_h(v), _h(A), int(s), _h(desc), C.byref(res), lv, max_levels,
+                                     int(profile))
+    n = min(res.levels, max_levels)
+    levels = [dict(direction="pull" if lv[i].direction else "push", frontier=lv[i].frontier,
+                   frontier_edges=lv[i].frontier_edges, discovered=lv[i].discovered, ms=lv[i].ms)
+              for i in range(n)]
+    return info, dict(levels=res.levels, tight_ms=res.tight_ms, edges_traversed=res.edges_traversed,
+                      reached=res.reached, per_level=levels)
+
+
+def sssp(v, A, s, desc):
+    res = AlgoResult()
+    info = _lib.load().grb_sssp(_h(v), _h(A), int(s), _h(desc), C.byref(res))
+    return info, dict(iterations=res.iterations, tight_ms=res.tight_ms, succ=res.last_value)
+
+
+def pr(p, A, alpha, eps, desc):
+    res = AlgoResult()
+    info = _lib.load().grb_pr(_h(p), _h(A), float(alpha), float(eps), _h(desc), C.byref(res))
+    return info, dict(iterations=res.iterations, tight_ms=res.tight_ms, error=res.last_value)
+
+
+# ---- raw kernels / timing -----------------------------------------------------------
+def k_spmv(A, tran, op, d_u, d_mask, scmp, accum, d_w):
+    return _lib.load().grb_k_spmv(_h(A), int(tran), _semiring_id(op), d_u, d_mask, int(scmp), int(accum), d_w)
+
+
+def k_spmv_bytes(A, tran):
+    return int(_lib.load().grb_k_spmv_bytes(_h(A), int(tran)))
+
+
+def timer_start():
+    _lib.call("grb_timer_start")
+
+
+def timer_stop():
+    out = C.c_float(0)
+    _lib.call("grb_timer_stop", C.byref(out))
+    return out.value
+
+
+def set_stream(ptr):
+    _lib.call("grb_set_stream", ptr)
+
+
+def device_info():
+    buf = C.create_string_buffer(256)
+    _lib.call("grb_device_info", buf, 256)
+    return buf.value.decode()

@@ -1,0 +1,103 @@
+// algorithms.hip -- the remaining drivers of graphblas/algorithm/ on the path, written
+// against the C ABI's own operations exactly as the reference writes them against the
+// frontend:  sssp (algorithm/sssp.hpp:15-103)  and  pr (algorithm/pr.hpp:15-94).
+// (bfs lives in ops.hip / bfs_fused.hip.)
+#include <cmath>
+
+#include "common.hpp"
+
+using namespace grb;
+
+namespace {
+struct VecGuard {               // frees temporaries on every exit path
+  std::vector<grb_vector> v;
+  ~VecGuard() { for (grb_vector x : v) grb_vector_free(x); }
+  grb_info make(grb_vector* out, grb_dtype dt, Index n) {
+    grb_info i = grb_vector_new(out, dt, n);
+    if (i == GRB_SUCCESS) v.push_back(*out);
+    return i;
+  }
+};
+}  // namespace
+
+extern "C" {
+
+// Bellman-Ford with frontier filtering; MinimumPlus vxm + CustomLessPlus / MinimumPlus
+// eWiseAdd + masked assign + reduce, as algorithm/sssp.hpp:62-91.
+grb_info grb_sssp(grb_vector v, grb_matrix A, grb_index source, grb_descriptor desc, grb_algo_result* result) {
+  if (!v || !A || !desc) return GRB_UNINITIALIZED_OBJECT;
+  if (source < 0 || source >= A->nrows) return GRB_INVALID_INDEX;
+  const Index n = A->nrows;
+  const double fmax = (double)FLT_MAX;
+  GRB_TRY(grb_vector_fill(v, fmax));
+  GRB_TRY(grb_vector_set_element(v, 0.0, source));
+  VecGuard g;
+  grb_vector f1, f2, m;
+  GRB_TRY(g.make(&f1, GRB_F32, n));
+  GRB_TRY(g.make(&f2, GRB_F32, n));
+  GRB_TRY(g.make(&m, GRB_F32, n));
+  if (desc->desc[GRB_MXVMODE] == GRB_PULLONLY) {
+    GRB_TRY(grb_vector_fill(f1, fmax));
+    GRB_TRY(grb_vector_set_element(f1, 0.0, source));
+  } else {
+    float zero = 0.f;
+    GRB_TRY(grb_vector_build_sparse(f1, &source, &zero, 1));
+  }
+  int iter = 1;
+  grb_index f1_nvals = 1;
+  double succ = 1;
+  float ms = 0.f;
+  GRB_TRY(grb_timer_start());
+  for (; iter <= desc->max_niter; ++iter) {
+    GRB_TRY(grb_vxm(f2, nullptr, GRB_ACCUM_NULL, GRB_MINIMUM_PLUS, f1, A, desc));
+    GRB_TRY(grb_eWiseAdd(m, nullptr, GRB_ACCUM_NULL, GRB_CUSTOM_LESS_PLUS, f2, v, desc));
+    GRB_TRY(grb_eWiseAdd(v, nullptr, GRB_ACCUM_NULL, GRB_MINIMUM_PLUS, v, f2, desc));
+    grb_descriptor_toggle(desc, GRB_MASK);
+    grb_info ai = grb_assign(f2, m, GRB_ACCUM_NULL, fmax, desc);
+    grb_descriptor_toggle(desc, GRB_MASK);
+    GRB_TRY(ai);
+    GRB_TRY(grb_vector_swap(f2, f1));
+    GRB_TRY(grb_vector_nvals(f1, &f1_nvals));
+    GRB_TRY(grb_reduce_vector(&succ, GRB_ACCUM_NULL, GRB_PLUS_MONOID, m, desc));
+    if (f1_nvals == 0 || succ == 0) break;
+  }
+  GRB_TRY(grb_timer_stop(&ms));
+  if (result) { result->iterations = iter; result->tight_ms = ms; result->last_value = succ; }
+  return GRB_SUCCESS;
+}
+
+// PageRank power iteration, algorithm/pr.hpp:60-82: vxm(PlusMultiplies) + eWiseAdd scalar +
+// eWiseMult(PlusMinus) + eWiseAdd(MultipliesMultiplies) + reduce(Plus); error = sqrt(sum).
+grb_info grb_pr(grb_vector p, grb_matrix A, float alpha, float eps, grb_descriptor desc, grb_algo_result* result) {
+  if (!p || !A || !desc) return GRB_UNINITIALIZED_OBJECT;
+  const Index n = A->nrows;
+  GRB_TRY(grb_vector_clear(p));
+  GRB_TRY(grb_vector_fill(p, (double)(1.f / n)));
+  VecGuard g;
+  grb_vector p_prev, p_swap, r, r_temp;
+  GRB_TRY(g.make(&p_prev, GRB_F32, n));
+  GRB_TRY(g.make(&p_swap, GRB_F32, n));
+  GRB_TRY(g.make(&r, GRB_F32, n));
+  GRB_TRY(g.make(&r_temp, GRB_F32, n));
+  GRB_TRY(grb_vector_fill(r, 1.0));
+  int iter = 1;
+  float error = 1.f;
+  float ms = 0.f;
+  GRB_TRY(grb_timer_start());
+  for (; error > eps && iter <= desc->max_niter; ++iter) {
+    GRB_TRY(grb_vector_dup(p_prev, p));
+    GRB_TRY(grb_vxm(p_swap, nullptr, GRB_ACCUM_NULL, GRB_PLUS_MULTIPLIES, p_prev, A, desc));
+    GRB_TRY(grb_eWiseAdd_scalar(p, nullptr, GRB_ACCUM_NULL, GRB_PLUS_MULTIPLIES, p_swap,
+                                (double)((1.f - alpha) / n), desc));
+    GRB_TRY(grb_eWiseMult(r, nullptr, GRB_ACCUM_NULL, GRB_PLUS_MINUS, p, p_prev, desc));
+    GRB_TRY(grb_eWiseAdd(r_temp, nullptr, GRB_ACCUM_NULL, GRB_MULTIPLIES_MULTIPLIES, r, r, desc));
+    double sum = 0;
+    GRB_TRY(grb_reduce_vector(&sum, GRB_ACCUM_NULL, GRB_PLUS_MONOID, r_temp, desc));
+    error = sqrtf((float)sum);
+  }
+  GRB_TRY(grb_timer_stop(&ms));
+  if (result) { result->iterations = iter - 1; result->tight_ms = ms; result->last_value = error; }
+  return GRB_SUCCESS;
+}
+
+}  // extern "C"

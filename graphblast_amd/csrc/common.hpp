@@ -1,0 +1,420 @@
+// common.hpp -- shared declarations of libgrb_hip.so (gfx950 only).
+//
+// Objects behind the opaque handles of include/grb_hip.h, the semiring functor
+// table (graphblas/stddef.hpp restated as compile-time traits so every kernel gets
+// its operators inlined), wavefront/workgroup primitives for 64-lane waves, and the
+// prototypes of the kernel launchers implemented in the *.hip files.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+#include <climits>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <type_traits>
+#include <vector>
+
+#include "grb_hip.h"
+
+namespace grb {
+
+typedef int32_t Index;
+
+constexpr int kWave = 64;          // gfx950 wavefront width
+constexpr int kBlock = 256;        // workgroup size used by every kernel (4 waves)
+constexpr int kWavesPerBlock = kBlock / kWave;
+
+// ----------------------------------------------------------------------------
+// error handling: never exit(); HIP failures become GRB_PANIC with a message.
+#define GRB_HIP_TRY(expr)                                                         \
+  do {                                                                            \
+    hipError_t e__ = (expr);                                                      \
+    if (e__ != hipSuccess) {                                                      \
+      fprintf(stderr, "libgrb_hip: %s failed: %s (%s:%d)\n", #expr,               \
+              hipGetErrorString(e__), __FILE__, __LINE__);                        \
+      return GRB_PANIC;                                                           \
+    }                                                                             \
+  } while (0)
+
+#define GRB_TRY(expr)                                                             \
+  do {                                                                            \
+    grb_info i__ = (expr);                                                        \
+    if (i__ != GRB_SUCCESS) return i__;                                           \
+  } while (0)
+
+// ----------------------------------------------------------------------------
+// Binary operators (graphblas/stddef.hpp:14-138)
+enum BinOp {
+  OP_LOR, OP_LAND, OP_LXOR, OP_EQ, OP_NE, OP_GT, OP_LT, OP_GE, OP_LE,
+  OP_FIRST, OP_SECOND, OP_MIN, OP_MAX, OP_PLUS, OP_MINUS, OP_TIMES, OP_DIV
+};
+
+template <typename T> __host__ __device__ inline T tmin(T a, T b) { return a < b ? a : b; }
+template <typename T> __host__ __device__ inline T tmax(T a, T b) { return a > b ? a : b; }
+template <> __host__ __device__ inline float tmin<float>(float a, float b) { return fminf(a, b); }
+template <> __host__ __device__ inline float tmax<float>(float a, float b) { return fmaxf(a, b); }
+
+template <int OP, typename T>
+__host__ __device__ inline T binop(T a, T b) {
+  if constexpr (OP == OP_LOR)    return (T)((a != (T)0) || (b != (T)0));
+  if constexpr (OP == OP_LAND)   return (T)((a != (T)0) && (b != (T)0));
+  if constexpr (OP == OP_LXOR)   return (T)((a != (T)0) != (b != (T)0));
+  if constexpr (OP == OP_EQ)     return (T)(a == b);
+  if constexpr (OP == OP_NE)     return (T)(a != b);
+  if constexpr (OP == OP_GT)     return (T)(a > b);
+  if constexpr (OP == OP_LT)     return (T)(a < b);
+  if constexpr (OP == OP_GE)     return (T)(a >= b);
+  if constexpr (OP == OP_LE)     return (T)(a <= b);
+  if constexpr (OP == OP_FIRST)  return a;
+  if constexpr (OP == OP_SECOND) return b;
+  if constexpr (OP == OP_MIN)    return tmin<T>(a, b);
+  if constexpr (OP == OP_MAX)    return tmax<T>(a, b);
+  if constexpr (OP == OP_PLUS)   return a + b;
+  if constexpr (OP == OP_MINUS)  return a - b;
+  if constexpr (OP == OP_TIMES)  return a * b;
+  if constexpr (OP == OP_DIV) {
+    if constexpr (std::is_integral<T>::value) {   // integer: guard /0 (UB in C)
+      return b == (T)0 ? (T)0 : (T)(a / b);
+    } else {
+      return a / b;
+    }
+  }
+  return a;
+}
+
+template <typename T> struct Limits;
+template <> struct Limits<float> {
+  __host__ __device__ static float max() { return FLT_MAX; }
+  __host__ __device__ static float min() { return FLT_MIN; }   // numeric_limits<float>::min()
+};
+template <> struct Limits<int> {
+  __host__ __device__ static int max() { return INT_MAX; }
+  __host__ __device__ static int min() { return INT_MIN; }
+};
+
+// Monoids (stddef.hpp:159-172). IDK: 0 zero, 1 one, 2 max(), 3 min().
+template <int M> struct MonoidTraits;
+#define GRB_DEF_MONOID(M, OP, IDK)                                   \
+  template <> struct MonoidTraits<M> {                               \
+    static constexpr int op = OP;                                    \
+    static constexpr int idk = IDK;                                  \
+  };
+GRB_DEF_MONOID(GRB_PLUS_MONOID, OP_PLUS, 0)
+GRB_DEF_MONOID(GRB_MULTIPLIES_MONOID, OP_TIMES, 1)
+GRB_DEF_MONOID(GRB_MINIMUM_MONOID, OP_MIN, 2)
+GRB_DEF_MONOID(GRB_MAXIMUM_MONOID, OP_MAX, 0)
+GRB_DEF_MONOID(GRB_LOGICAL_OR_MONOID, OP_LOR, 0)
+GRB_DEF_MONOID(GRB_LOGICAL_AND_MONOID, OP_LAND, 0)
+GRB_DEF_MONOID(GRB_GREATER_MONOID, OP_GT, 3)
+GRB_DEF_MONOID(GRB_CUSTOM_LESS_MONOID, OP_LT, 2)
+GRB_DEF_MONOID(GRB_NOT_EQUAL_TO_MONOID, OP_NE, 2)
+#undef GRB_DEF_MONOID
+
+template <int M, typename T>
+struct Monoid {
+  static constexpr int op = MonoidTraits<M>::op;
+  __host__ __device__ static T identity() {
+    constexpr int k = MonoidTraits<M>::idk;
+    if constexpr (k == 0) return (T)0;
+    if constexpr (k == 1) return (T)1;
+    if constexpr (k == 2) return Limits<T>::max();
+    return Limits<T>::min();
+  }
+  __host__ __device__ static T add(T a, T b) { return binop<op, T>(a, b); }
+};
+
+// Semirings (stddef.hpp:195-213)
+template <int SR> struct SemiringTraits;
+#define GRB_DEF_SR(SR, MONOID, MUL)                                  \
+  template <> struct SemiringTraits<SR> {                            \
+    static constexpr int monoid = MONOID;                            \
+    static constexpr int mul = MUL;                                  \
+  };
+GRB_DEF_SR(GRB_LOGICAL_OR_AND, GRB_LOGICAL_OR_MONOID, OP_LAND)
+GRB_DEF_SR(GRB_PLUS_MULTIPLIES, GRB_PLUS_MONOID, OP_TIMES)
+GRB_DEF_SR(GRB_MINIMUM_PLUS, GRB_MINIMUM_MONOID, OP_PLUS)
+GRB_DEF_SR(GRB_MAXIMUM_MULTIPLIES, GRB_MAXIMUM_MONOID, OP_TIMES)
+GRB_DEF_SR(GRB_PLUS_DIVIDES, GRB_PLUS_MONOID, OP_DIV)
+GRB_DEF_SR(GRB_PLUS_GREATER, GRB_PLUS_MONOID, OP_GT)
+GRB_DEF_SR(GRB_GREATER_PLUS, GRB_GREATER_MONOID, OP_PLUS)
+GRB_DEF_SR(GRB_PLUS_MINUS, GRB_PLUS_MONOID, OP_MINUS)
+GRB_DEF_SR(GRB_PLUS_LESS, GRB_PLUS_MONOID, OP_LT)
+GRB_DEF_SR(GRB_CUSTOM_LESS_PLUS, GRB_CUSTOM_LESS_MONOID, OP_PLUS)
+GRB_DEF_SR(GRB_MINIMUM_MULTIPLIES, GRB_MINIMUM_MONOID, OP_TIMES)
+GRB_DEF_SR(GRB_MULTIPLIES_MULTIPLIES, GRB_MULTIPLIES_MONOID, OP_TIMES)
+GRB_DEF_SR(GRB_NOT_EQUAL_TO_PLUS, GRB_NOT_EQUAL_TO_MONOID, OP_PLUS)
+GRB_DEF_SR(GRB_MINIMUM_SELECT_SECOND, GRB_MINIMUM_MONOID, OP_SECOND)
+GRB_DEF_SR(GRB_PLUS_NOT_EQUAL_TO, GRB_PLUS_MONOID, OP_NE)
+GRB_DEF_SR(GRB_CUSTOM_LESS_LESS, GRB_CUSTOM_LESS_MONOID, OP_LT)
+GRB_DEF_SR(GRB_MINIMUM_NOT_EQUAL_TO, GRB_MINIMUM_MONOID, OP_NE)
+#undef GRB_DEF_SR
+
+template <int SR, typename T>
+struct Semiring {
+  typedef Monoid<SemiringTraits<SR>::monoid, T> M;
+  static constexpr int monoid = SemiringTraits<SR>::monoid;
+  static constexpr int mulop = SemiringTraits<SR>::mul;
+  __host__ __device__ static T identity() { return M::identity(); }
+  __host__ __device__ static T add(T a, T b) { return M::add(a, b); }
+  __host__ __device__ static T mul(T a, T b) { return binop<mulop, T>(a, b); }
+};
+
+template <int N> struct IntTag { static constexpr int value = N; };
+
+// Runtime (semiring, dtype) -> compile-time dispatch: f(IntTag<SR>{}, T{}).
+template <typename F>
+inline grb_info dispatch_semiring(int sr, int dtype, F&& f) {
+#define GRB_CASE(SR)                                                         \
+  case SR:                                                                   \
+    if (dtype == GRB_F32) return f(IntTag<SR>{}, float{});                   \
+    return f(IntTag<SR>{}, int{});
+  switch (sr) {
+    GRB_CASE(GRB_LOGICAL_OR_AND) GRB_CASE(GRB_PLUS_MULTIPLIES) GRB_CASE(GRB_MINIMUM_PLUS)
+    GRB_CASE(GRB_MAXIMUM_MULTIPLIES) GRB_CASE(GRB_PLUS_DIVIDES) GRB_CASE(GRB_PLUS_GREATER)
+    GRB_CASE(GRB_GREATER_PLUS) GRB_CASE(GRB_PLUS_MINUS) GRB_CASE(GRB_PLUS_LESS)
+    GRB_CASE(GRB_CUSTOM_LESS_PLUS) GRB_CASE(GRB_MINIMUM_MULTIPLIES)
+    GRB_CASE(GRB_MULTIPLIES_MULTIPLIES) GRB_CASE(GRB_NOT_EQUAL_TO_PLUS)
+    GRB_CASE(GRB_MINIMUM_SELECT_SECOND) GRB_CASE(GRB_PLUS_NOT_EQUAL_TO)
+    GRB_CASE(GRB_CUSTOM_LESS_LESS) GRB_CASE(GRB_MINIMUM_NOT_EQUAL_TO)
+    default: return GRB_INVALID_VALUE;
+  }
+#undef GRB_CASE
+}
+
+template <typename F>
+inline grb_info dispatch_monoid(int m, int dtype, F&& f) {
+#define GRB_CASE(M)                                                          \
+  case M:                                                                    \
+    if (dtype == GRB_F32) return f(IntTag<M>{}, float{});                    \
+    return f(IntTag<M>{}, int{});
+  switch (m) {
+    GRB_CASE(GRB_PLUS_MONOID) GRB_CASE(GRB_MULTIPLIES_MONOID) GRB_CASE(GRB_MINIMUM_MONOID)
+    GRB_CASE(GRB_MAXIMUM_MONOID) GRB_CASE(GRB_LOGICAL_OR_MONOID) GRB_CASE(GRB_LOGICAL_AND_MONOID)
+    GRB_CASE(GRB_GREATER_MONOID) GRB_CASE(GRB_CUSTOM_LESS_MONOID) GRB_CASE(GRB_NOT_EQUAL_TO_MONOID)
+    default: return GRB_INVALID_VALUE;
+  }
+#undef GRB_CASE
+}
+
+// Host-side evaluation of a semiring on doubles (identity(), add_op(3,5) probes).
+double semiring_identity(int sr, int dtype);
+double semiring_add(int sr, int dtype, double a, double b);
+double monoid_identity(int m, int dtype);
+int semiring_monoid(int sr);
+
+// ----------------------------------------------------------------------------
+// Wavefront / workgroup primitives (64-lane waves, 256-thread workgroups)
+__device__ inline int lane_id() { return threadIdx.x & (kWave - 1); }
+__device__ inline int wave_id() { return threadIdx.x >> 6; }
+
+template <typename T, typename F>
+__device__ inline T wave_reduce(T v, F f) {
+#pragma unroll
+  for (int o = kWave / 2; o > 0; o >>= 1) v = f(v, __shfl_xor(v, o, kWave));
+  return v;
+}
+
+// Reduce within aligned groups of L lanes (L power of two <= 64).
+template <typename T, typename F>
+__device__ inline T group_reduce(T v, int L, F f) {
+  for (int o = L >> 1; o > 0; o >>= 1) v = f(v, __shfl_xor(v, o, kWave));
+  return v;
+}
+
+// Exclusive prefix sum of one int per thread over a 256-thread workgroup.
+// smem: at least kWavesPerBlock ints. Ends with a barrier, so smem may be reused.
+__device__ inline int block_exclusive_scan(int v, int* smem, int& total) {
+  const int lane = lane_id(), wid = wave_id();
+  int x = v;
+#pragma unroll
+  for (int o = 1; o < kWave; o <<= 1) {
+    int y = __shfl_up(x, o, kWave);
+    if (lane >= o) x += y;
+  }
+  if (lane == kWave - 1) smem[wid] = x;
+  __syncthreads();
+  int wave_off = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < kWavesPerBlock; ++w) {
+    int s = smem[w];
+    if (w < wid) wave_off += s;
+    tot += s;
+  }
+  __syncthreads();
+  total = tot;
+  return wave_off + x - v;
+}
+
+// Mask test of the reference ("castable to true", kernels/assign_dense.hpp:27):
+// passes when (scmp && m == 0) || (!scmp && m != 0). Masks are 4-byte f32 or i32.
+__device__ inline bool mask_nonzero(const void* mask, int mask_f32, Index i) {
+  return mask_f32 ? (reinterpret_cast<const float*>(mask)[i] != 0.f)
+                  : (reinterpret_cast<const int*>(mask)[i] != 0);
+}
+__device__ inline bool mask_pass(const void* mask, int mask_f32, int scmp, Index i) {
+  return mask_nonzero(mask, mask_f32, i) != (scmp != 0);
+}
+
+inline int ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
+// Grid for grid-stride kernels: enough workgroups to fill 256 CUs x 8, never zero.
+inline int stream_grid(long long work_items, int per_block = kBlock) {
+  long long b = (work_items + per_block - 1) / per_block;
+  if (b < 1) b = 1;
+  if (b > 2048) b = 2048;
+  return (int)b;
+}
+
+// ----------------------------------------------------------------------------
+// Library context: stream, grow-only scratch slots, pinned mailbox.
+struct Context {
+  hipStream_t stream = nullptr;
+  static constexpr int kSlots = 12;
+  void* slot[kSlots] = {nullptr};
+  size_t slot_cap[kSlots] = {0};
+  int* h_mail = nullptr;            // pinned host, 64 ints
+  int* d_mail = nullptr;            // device, 64 ints
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  bool inited = false;
+  int num_cu = 256;
+  // push accumulator (scratch slot 5) is kept filled with this identity between calls
+  double acc_identity = 0.0;
+  int acc_dtype = -1;
+  size_t acc_cap = 0;
+};
+Context& ctx();
+grb_info ctx_init();
+// Device scratch of at least `bytes` in slot `i` (contents not preserved on growth).
+grb_info scratch(int i, size_t bytes, void** out);
+// Copy `count` ints from device to host through the pinned mailbox; synchronises.
+grb_info fetch_ints(const int* d_src, int count, int* h_dst);
+
+// ----------------------------------------------------------------------------
+// Objects behind the handles
+struct SpmvBlock {        // one workgroup's share of an SpMV (row-block streaming)
+  int row_start, row_end; // rows [row_start, row_end)
+  int nnz_start, nnz_end; // their nonzeros (or a slice of one long row)
+  int slot;               // -1: whole rows; >=0: partial-result slot of a long row
+};
+
+struct SpmvPlan {         // built once per matrix orientation at build()
+  int nblocks = 0;
+  SpmvBlock* d_blocks = nullptr;
+  int nlong = 0;          // rows longer than one tile, reduced in two steps
+  int* d_long_row = nullptr;
+  int* d_long_slot_ptr = nullptr;
+  int nslots = 0;
+  void* d_partials = nullptr;
+};
+
+struct CsrArrays {
+  Index* ptr = nullptr;   // [n+1]
+  Index* ind = nullptr;   // [nvals]
+  void* val = nullptr;    // [nvals] of dtype
+  Index n = 0;            // number of rows of this orientation
+};
+
+}  // namespace grb
+
+struct grb_descriptor_s {
+  int desc[GRB_NDESCFIELD];
+  // Descriptor::loadArgs fields (backend/cuda/descriptor.hpp:84-122)
+  int mxvmode = 0, niter = 0, max_niter = 0, directed = 0, timing = 0, nthread = 0;
+  int transpose = 0, debug = 0;
+  float switchpoint = 0.f, memusage = 0.f;
+  int dirinfo = 0, struconly = 0, opreuse = 0, endbit = 0, sort = 0, atomic = 0;
+  int earlyexit = 0, fusedmask = 0;
+  int lastmxv = GRB_PUSHONLY;
+};
+
+struct grb_vector_s {
+  int dtype = GRB_F32;
+  grb::Index nsize = 0;
+  grb::Index nvals = 0;           // cached, refreshed by grb_vector_nvals
+  int vec_type = GRB_UNKNOWN;
+  float ratio = 0.f;              // backend::Vector::ratio_
+  // SparseVector
+  grb::Index* s_ind = nullptr;    // [nsize]
+  void* s_val = nullptr;          // [nsize + 1]
+  grb::Index s_nvals = 0;
+  bool s_owned = true;
+  // DenseVector
+  void* d_val = nullptr;          // [nsize]
+  grb::Index d_nnz = 0;
+  bool d_owned = true;
+};
+
+struct grb_matrix_s {
+  int dtype = GRB_F32;
+  grb::Index nrows = 0, ncols = 0, nvals = 0;
+  bool built = false;
+  bool owned = true;
+  // host mirrors (sparse_matrix.hpp:120-132)
+  std::vector<grb::Index> h_csr_ptr, h_csr_ind, h_csc_ptr, h_csc_ind;
+  std::vector<uint32_t> h_csr_val, h_csc_val;   // raw 4-byte values of dtype
+  grb::CsrArrays csr, csc;                       // device
+  grb::SpmvPlan plan_csr, plan_csc;
+};
+
+namespace grb {
+
+// ---- kernel launchers (implemented in the *.hip files) -----------------------
+// elementwise.hip
+grb_info k_fill(int dtype, void* d, double val, Index n);
+grb_info k_fill_ascending(int dtype, void* d, Index n);
+grb_info k_scatter_const(int dtype, void* d_dense, const Index* ind, double val, Index n);
+grb_info k_scatter_vals(int dtype, void* d_dense, const Index* ind, const void* vals, Index n);
+grb_info k_count_nonidentity(int dtype, const void* d, double identity, Index n, Index* count_out);
+// dense -> sparse (flag = val != identity); struconly: indices only. Sorted by index.
+grb_info k_dense2sparse(int dtype, const void* d_dense, double identity, Index n, Index* out_ind,
+                        void* out_val /*nullable*/, Index* nvals_out);
+// prune a sparse (ind, val) list: keep entries with val != prune_val.
+grb_info k_sparse_prune(int dtype, Index* ind, void* val, Index n, double prune_val,
+                        Index* nvals_out);
+grb_info k_assign_dense_mask_dense(int dtype, void* w, Index n, const void* mask, int mask_f32,
+                                   int scmp, double val);
+grb_info k_assign_dense_mask_sparse(int dtype, void* w, const Index* mask_ind, Index mask_nvals,
+                                    double val);
+grb_info k_assign_sparse_mask_dense(int dtype, const Index* w_ind, void* w_val, Index w_nvals,
+                                    const void* mask, int mask_f32, int scmp, double val);
+grb_info k_reduce(int monoid, int dtype, const void* d, Index n, double* out);
+grb_info k_reduce_rows(int monoid, int dtype, const Index* ptr, const void* val, Index nrows,
+                       void* w);
+grb_info k_ewise_add_dense_dense(int sr, int dtype, void* w, const void* u, const void* v, Index n);
+grb_info k_ewise_add_const(int sr, int dtype, void* w, double identity, int reverse, Index n);
+grb_info k_ewise_add_sparse_dense(int sr, int dtype, void* w, const Index* u_ind, const void* u_val,
+                                  const void* v, Index u_nvals);
+grb_info k_ewise_scalar(int sr, int dtype, int use_add, void* w, double val, Index n);
+grb_info k_ewise_mult_dense_dense(int sr, int dtype, void* w, const void* mask, int mask_f32,
+                                  const void* u, const void* v, Index n);
+grb_info k_ewise_mult_dense_dense_spmask(int sr, int dtype, Index* w_ind, void* w_val,
+                                         const Index* m_ind, const void* m_val, int mask_f32,
+                                         Index m_nvals, const void* u, const void* v);
+grb_info k_ewise_mult_sparse_dense(int sr, int dtype, Index* w_ind, void* w_val, const Index* u_ind,
+                                   const void* u_val, Index u_nvals, const void* v, int reverse);
+grb_info k_ewise_mult_sparse_dense_spmask(int sr, int dtype, Index* w_ind, void* w_val,
+                                          const Index* m_ind, const void* m_val, int mask_f32,
+                                          Index m_nvals, const Index* u_ind, const void* u_val,
+                                          Index u_nvals, const void* v, int reverse);
+grb_info k_zero_dense_identity(int dtype, const void* mask, int mask_f32, double identity,
+                               const Index* u_ind, void* u_val, Index n);
+
+// spmv.hip
+grb_info build_spmv_plan(const std::vector<Index>& ptr, Index n, SpmvPlan* plan);
+void free_spmv_plan(SpmvPlan* plan);
+grb_info k_spmv(int sr, int dtype, const CsrArrays& M, const SpmvPlan& plan, const void* u,
+                const void* mask, int mask_f32, int scmp, int accum, void* w);
+grb_info k_spmv_masked_or(int dtype, const CsrArrays& M, const void* u, double identity,
+                          const void* mask, int mask_f32, int scmp, int earlyexit, int opreuse,
+                          void* w);
+
+// spmspv.hip
+grb_info k_spmspv(int sr, int dtype, const CsrArrays& M, Index out_size, int struconly,
+                  const Index* u_ind, const void* u_val, Index u_nvals, const void* mask,
+                  int mask_f32, int use_mask, int keep_when_mask_zero, Index* w_ind, void* w_val,
+                  Index* w_nvals);
+
+}  // namespace grb

@@ -1,0 +1,756 @@
+// objects.hip -- library context and the three containers behind the C ABI:
+// Descriptor (backend/cuda/descriptor.hpp), Vector (backend/cuda/vector.hpp +
+// sparse_vector.hpp + dense_vector.hpp) and Matrix (backend/cuda/sparse_matrix.hpp).
+//
+// MI355X-first differences from the reference containers:
+//  * no per-call cudaThreadSynchronize: everything is stream-ordered; only the calls
+//    whose result is a host value synchronise (nvals of a fresh result, extractTuples,
+//    reduce), through one pinned mailbox;
+//  * fill / fillAscending / sparse2dense run on the device (the reference loops on the
+//    host and copies n*4 bytes over PCIe every time, dense_vector.hpp:311-327);
+//  * scratch is a set of grow-only slots owned by the context (the reference's
+//    Descriptor::resize is malloc-new + D2D copy + free-old, descriptor.hpp:156-192);
+//  * Matrix::build also prepares the row-block plans of the SpMV kernel for both
+//    orientations (CSR for mxv, CSC for vxm-pull).
+#include <algorithm>
+#include <numeric>
+
+#include "common.hpp"
+
+namespace grb {
+
+Context& ctx() {
+  static Context c;
+  return c;
+}
+
+grb_info ctx_init() {
+  Context& c = ctx();
+  if (c.inited) return GRB_SUCCESS;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+    fprintf(stderr, "libgrb_hip: no HIP device visible -- this library has no CPU fallback\n");
+    return GRB_PANIC;
+  }
+  GRB_HIP_TRY(hipHostMalloc((void**)&c.h_mail, 64 * sizeof(int), hipHostMallocDefault));
+  GRB_HIP_TRY(hipMalloc((void**)&c.d_mail, 64 * sizeof(int)));
+  GRB_HIP_TRY(hipMemset(c.d_mail, 0, 64 * sizeof(int)));
+  GRB_HIP_TRY(hipEventCreate(&c.ev0));
+  GRB_HIP_TRY(hipEventCreate(&c.ev1));
+  int dev = 0;
+  GRB_HIP_TRY(hipGetDevice(&dev));
+  hipDeviceProp_t prop;
+  GRB_HIP_TRY(hipGetDeviceProperties(&prop, dev));
+  c.num_cu = prop.multiProcessorCount;
+  c.inited = true;
+  return GRB_SUCCESS;
+}
+
+grb_info scratch(int i, size_t bytes, void** out) {
+  Context& c = ctx();
+  GRB_TRY(ctx_init());
+  if (bytes < 256) bytes = 256;
+  if (c.slot_cap[i] < bytes) {
+    if (c.slot[i]) {
+      // stream-ordered users of the old buffer must finish before it is released
+      GRB_HIP_TRY(hipStreamSynchronize(c.stream));
+      GRB_HIP_TRY(hipFree(c.slot[i]));
+      c.slot[i] = nullptr;
+      c.slot_cap[i] = 0;
+    }
+    size_t cap = bytes + bytes / 4;
+    cap = (cap + 255) & ~(size_t)255;
+    GRB_HIP_TRY(hipMalloc(&c.slot[i], cap));
+    c.slot_cap[i] = cap;
+  }
+  *out = c.slot[i];
+  return GRB_SUCCESS;
+}
+
+grb_info fetch_ints(const int* d_src, int count, int* h_dst) {
+  Context& c = ctx();
+  GRB_HIP_TRY(hipMemcpyAsync(c.h_mail, d_src, sizeof(int) * count, hipMemcpyDeviceToHost, c.stream));
+  GRB_HIP_TRY(hipStreamSynchronize(c.stream));
+  memcpy(h_dst, c.h_mail, sizeof(int) * count);
+  return GRB_SUCCESS;
+}
+
+// ---- host-side semiring probes ------------------------------------------------
+double semiring_identity(int sr, int dtype) {
+  double out = 0;
+  dispatch_semiring(sr, dtype, [&](auto tag, auto t) -> grb_info {
+    using T = decltype(t);
+    out = (double)Semiring<decltype(tag)::value, T>::identity();
+    return GRB_SUCCESS;
+  });
+  return out;
+}
+double semiring_add(int sr, int dtype, double a, double b) {
+  double out = 0;
+  dispatch_semiring(sr, dtype, [&](auto tag, auto t) -> grb_info {
+    using T = decltype(t);
+    out = (double)Semiring<decltype(tag)::value, T>::add((T)a, (T)b);
+    return GRB_SUCCESS;
+  });
+  return out;
+}
+double monoid_identity(int m, int dtype) {
+  double out = 0;
+  dispatch_monoid(m, dtype, [&](auto tag, auto t) -> grb_info {
+    using T = decltype(t);
+    out = (double)Monoid<decltype(tag)::value, T>::identity();
+    return GRB_SUCCESS;
+  });
+  return out;
+}
+int semiring_monoid(int sr) {
+  int out = -1;
+  dispatch_semiring(sr, GRB_F32, [&](auto tag, auto t) -> grb_info {
+    out = SemiringTraits<decltype(tag)::value>::monoid;
+    return GRB_SUCCESS;
+  });
+  return out;
+}
+
+static inline void store_scalar(int dtype, void* dst, double v) {
+  if (dtype == GRB_F32) { float f = (float)v; memcpy(dst, &f, 4); }
+  else { int i = (int)v; memcpy(dst, &i, 4); }
+}
+static inline double load_scalar(int dtype, const void* src) {
+  if (dtype == GRB_F32) { float f; memcpy(&f, src, 4); return (double)f; }
+  int i; memcpy(&i, src, 4); return (double)i;
+}
+
+}  // namespace grb
+
+using namespace grb;
+
+extern "C" {
+
+// =============================================================================== library
+grb_info grb_set_stream(void* hip_stream) {
+  GRB_TRY(ctx_init());
+  ctx().stream = (hipStream_t)hip_stream;
+  return GRB_SUCCESS;
+}
+
+grb_info grb_device_info(char* buf, size_t buflen) {
+  GRB_TRY(ctx_init());
+  int dev = 0;
+  GRB_HIP_TRY(hipGetDevice(&dev));
+  hipDeviceProp_t prop;
+  GRB_HIP_TRY(hipGetDeviceProperties(&prop, dev));
+  snprintf(buf, buflen, "%s:%d:%s", prop.gcnArchName, prop.multiProcessorCount, prop.name);
+  return GRB_SUCCESS;
+}
+
+const char* grb_version(void) { return "graphblast_amd 0.1 (gfx950)"; }
+
+grb_info grb_timer_start(void) {
+  GRB_TRY(ctx_init());
+  GRB_HIP_TRY(hipEventRecord(ctx().ev0, ctx().stream));
+  return GRB_SUCCESS;
+}
+grb_info grb_timer_stop(float* elapsed_ms) {
+  GRB_HIP_TRY(hipEventRecord(ctx().ev1, ctx().stream));
+  GRB_HIP_TRY(hipEventSynchronize(ctx().ev1));
+  GRB_HIP_TRY(hipEventElapsedTime(elapsed_ms, ctx().ev0, ctx().ev1));
+  return GRB_SUCCESS;
+}
+
+// =============================================================================== Descriptor
+grb_info grb_descriptor_new(grb_descriptor* desc) {
+  if (!desc) return GRB_NULL_POINTER;
+  grb_descriptor d = new grb_descriptor_s();
+  // backend/cuda/descriptor.hpp:17-18
+  const int defaults[GRB_NDESCFIELD] = {GRB_DEFAULT, GRB_DEFAULT, GRB_DEFAULT, GRB_DEFAULT, GRB_FIXEDROW,
+                                        32, 32, 128, GRB_PUSHPULL, 16, GRB_HIP};
+  memcpy(d->desc, defaults, sizeof(defaults));
+  *desc = d;
+  return GRB_SUCCESS;
+}
+grb_info grb_descriptor_free(grb_descriptor desc) { delete desc; return GRB_SUCCESS; }
+
+grb_info grb_descriptor_set(grb_descriptor desc, int field, int value) {
+  if (!desc) return GRB_UNINITIALIZED_OBJECT;
+  if (field < 0 || field >= GRB_NDESCFIELD) return GRB_INVALID_VALUE;
+  desc->desc[field] = value;
+  return GRB_SUCCESS;
+}
+grb_info grb_descriptor_get(grb_descriptor desc, int field, int* value) {
+  if (!desc) return GRB_UNINITIALIZED_OBJECT;
+  if (field < 0 || field >= GRB_NDESCFIELD) return GRB_INVALID_VALUE;
+  *value = desc->desc[field];
+  return GRB_SUCCESS;
+}
+// backend/cuda/descriptor.hpp:141-154
+grb_info grb_descriptor_toggle(grb_descriptor desc, int field) {
+  if (!desc) return GRB_UNINITIALIZED_OBJECT;
+  if (field >= 0 && field < 4) {
+    if (desc->desc[field] != GRB_DEFAULT) desc->desc[field] = GRB_DEFAULT;
+    else if (field > 2) desc->desc[field] = GRB_TRAN;
+    else desc->desc[field] = field;      // MASK -> SCMP(0), OUTP -> REPLACE(1), INP0 -> TRAN(2)
+  }
+  return GRB_SUCCESS;
+}
+
+static grb_info desc_apply_modes(grb_descriptor d) {
+  switch (d->mxvmode) {                   // descriptor.hpp:244-256
+    case 0: d->desc[GRB_MXVMODE] = GRB_PUSHPULL; break;
+    case 1: d->desc[GRB_MXVMODE] = GRB_PUSHONLY; break;
+    case 2: d->desc[GRB_MXVMODE] = GRB_PULLONLY; break;
+    default: return GRB_INVALID_VALUE;
+  }
+  switch (d->nthread) {                   // descriptor.hpp:258-280
+    case 32: case 64: case 128: case 256: case 512: case 1024: d->desc[GRB_NT] = d->nthread; break;
+    default: return GRB_INVALID_VALUE;
+  }
+  return GRB_SUCCESS;
+}
+
+// parseArgs defaults, graphblas/util.hpp:39-132
+grb_info grb_descriptor_load_defaults(grb_descriptor d) {
+  if (!d) return GRB_UNINITIALIZED_OBJECT;
+  d->niter = 10; d->max_niter = 10000; d->directed = 0; d->timing = 1; d->transpose = 0;
+  d->mxvmode = 1; d->switchpoint = 0.01f; d->dirinfo = 0; d->struconly = 0; d->opreuse = 0;
+  d->memusage = 1.0f; d->endbit = 1; d->sort = 1; d->atomic = 0; d->earlyexit = 1; d->fusedmask = 1;
+  d->nthread = 128; d->debug = 0;
+  return desc_apply_modes(d);
+}
+
+#define GRB_DESC_ARGS(X)                                                                          \
+  X(mxvmode) X(switchpoint) X(struconly) X(opreuse) X(earlyexit) X(fusedmask) X(sort) X(endbit)   \
+  X(memusage) X(atomic) X(dirinfo) X(nthread) X(max_niter) X(niter) X(timing) X(debug) X(directed) \
+  X(transpose)
+
+grb_info grb_descriptor_set_arg(grb_descriptor d, const char* name, double value) {
+  if (!d || !name) return GRB_UNINITIALIZED_OBJECT;
+#define X(f) if (strcmp(name, #f) == 0) { d->f = (decltype(d->f))value; return desc_apply_modes(d); }
+  GRB_DESC_ARGS(X)
+#undef X
+  return GRB_INVALID_VALUE;
+}
+grb_info grb_descriptor_get_arg(grb_descriptor d, const char* name, double* value) {
+  if (!d || !name || !value) return GRB_UNINITIALIZED_OBJECT;
+#define X(f) if (strcmp(name, #f) == 0) { *value = (double)d->f; return GRB_SUCCESS; }
+  GRB_DESC_ARGS(X)
+#undef X
+  return GRB_INVALID_VALUE;
+}
+grb_info grb_descriptor_lastmxv(grb_descriptor d, int* value) {
+  if (!d) return GRB_UNINITIALIZED_OBJECT;
+  *value = d->lastmxv;
+  return GRB_SUCCESS;
+}
+
+// =============================================================================== Vector
+static grb_info vec_alloc_sparse(grb_vector v) {
+  if (v->nsize > 0 && !v->s_ind) {
+    GRB_HIP_TRY(hipMalloc((void**)&v->s_ind, sizeof(Index) * (size_t)v->nsize));
+    GRB_HIP_TRY(hipMalloc(&v->s_val, 4 * ((size_t)v->nsize + 1)));
+    v->s_owned = true;
+  }
+  return GRB_SUCCESS;
+}
+static grb_info vec_alloc_dense(grb_vector v) {
+  if (v->nsize > 0 && !v->d_val) {
+    GRB_HIP_TRY(hipMalloc(&v->d_val, 4 * (size_t)v->nsize));
+    v->d_owned = true;
+  }
+  return GRB_SUCCESS;
+}
+
+grb_info grb_vector_new(grb_vector* out, grb_dtype dtype, grb_index nsize) {
+  if (!out) return GRB_NULL_POINTER;
+  if (nsize < 0) return GRB_INVALID_VALUE;
+  GRB_TRY(ctx_init());
+  grb_vector v = new grb_vector_s();
+  v->dtype = dtype;
+  v->nsize = nsize;
+  // both representations exist at full size from construction (vector.hpp:30-32)
+  grb_info i = vec_alloc_sparse(v);
+  if (i == GRB_SUCCESS) i = vec_alloc_dense(v);
+  if (i != GRB_SUCCESS) { delete v; return i; }
+  *out = v;
+  return GRB_SUCCESS;
+}
+
+grb_info grb_vector_free(grb_vector v) {
+  if (!v) return GRB_SUCCESS;
+  (void)hipStreamSynchronize(ctx().stream);
+  if (v->s_owned) { if (v->s_ind) (void)hipFree(v->s_ind); if (v->s_val) (void)hipFree(v->s_val); }
+  if (v->d_owned && v->d_val) (void)hipFree(v->d_val);
+  delete v;
+  return GRB_SUCCESS;
+}
+
+grb_info grb_vector_set_storage(grb_vector v, int storage) {
+  if (!v) return GRB_UNINITIALIZED_OBJECT;
+  v->vec_type = storage;
+  if (storage == GRB_SPARSE) return vec_alloc_sparse(v);
+  if (storage == GRB_DENSE) return vec_alloc_dense(v);
+  return GRB_SUCCESS;
+}
+grb_info grb_vector_get_storage(grb_vector v, int* storage) {
+  if (!v) return GRB_UNINITIALIZED_OBJECT;
+  *storage = v->vec_type;
+  return GRB_SUCCESS;
+}
+
+grb_info grb_vector_dup(grb_vector dst, grb_vector src) {
+  if (!dst || !src) return GRB_UNINITIALIZED_OBJECT;
+  if (dst->nsize != src->nsize || dst->dtype != src->dtype) return GRB_DIMENSION_MISMATCH;
+  hipStream_t s = ctx().stream;
+  dst->vec_type = src->vec_type;
+  if (src->vec_type == GRB_SPARSE) {
+    GRB_TRY(vec_alloc_sparse(dst));
+    // the reference copies nsize elements (sparse_vector.hpp:110-113); nvals suffice
+    if (src->s_nvals > 0) {
+      GRB_HIP_TRY(hipMemcpyAsync(dst->s_ind, src->s_ind, 4 * (size_t)src->s_nvals, hipMemcpyDeviceToDevice, s));
+      GRB_HIP_TRY(hipMemcpyAsync(dst->s_val, src->s_val, 4 * (size_t)src->s_nvals, hipMemcpyDeviceToDevice, s));
+    }
+    dst->s_nvals = src->s_nvals;
+    return GRB_SUCCESS;
+  }
+  if (src->vec_type == GRB_DENSE) {
+    GRB_TRY(vec_alloc_dense(dst));
+    if (src->nsize > 0)
+      GRB_HIP_TRY(hipMemcpyAsync(dst->d_val, src->d_val, 4 * (size_t)src->nsize, hipMemcpyDeviceToDevice, s));
+    dst->d_nnz = src->d_nnz;
+    return GRB_SUCCESS;
+  }
+  return GRB_UNINITIALIZED_OBJECT;
+}
+
+grb_info grb_vector_clear(grb_vector v) {
+  if (!v) return GRB_UNINITIALIZED_OBJECT;
+  v->vec_type = GRB_UNKNOWN;          // vector.hpp:105-112
+  v->nvals = 0;
+  v->s_nvals = 0;
+  return k_fill(v->dtype, v->d_val, 0.0, v->nsize);
+}
+
+grb_info grb_vector_size(grb_vector v, grb_index* nsize) {
+  if (!v) return GRB_UNINITIALIZED_OBJECT;
+  *nsize = v->nsize;
+  return GRB_SUCCESS;
+}
+
+// vector.hpp:132-146: sparse -> stored count, dense -> size, unknown -> cached
+grb_info grb_vector_nvals(grb_vector v, grb_index* nvals) {
+  if (!v) return GRB_UNINITIALIZED_OBJECT;
+  if (v->vec_type == GRB_SPARSE) v->nvals = v->s_nvals;
+  else if (v->vec_type == GRB_DENSE) v->nvals = v->nsize;
+  *nvals = v->nvals;
+  return GRB_SUCCESS;
+}
+
+grb_info grb_vector_build_sparse(grb_vector v, const grb_index* indices, const void* values, grb_index nvals) {
+  if (!v) return GRB_UNINITIALIZED_OBJECT;
+  if (nvals > v->nsize) return GRB_PANIC;                  // sparse_vector.hpp:138-142
+  if (v->s_nvals > 0) return GRB_OUTPUT_NOT_EMPTY;
+  v->vec_type = GRB_SPARSE;
+  GRB_TRY(vec_alloc_sparse(v));
+  if (nvals > 0) {
+    GRB_HIP_TRY(hipMemcpyAsync(v->s_ind, indices, 4 * (size_t)nvals, hipMemcpyHostToDevice, ctx().stream));
+    GRB_HIP_TRY(hipMemcpyAsync(v->s_val, values, 4 * (size_t)nvals, hipMemcpyHostToDevice, ctx().stream));
+    GRB_HIP_TRY(hipStreamSynchronize(ctx().stream));       // host buffers may be released by the caller
+  }
+  v->s_nvals = nvals;
+  return GRB_SUCCESS;
+}
+
+grb_info grb_vector_build_dense(grb_vector v, const void* values, grb_index nvals) {
+  if (!v) return GRB_UNINITIALIZED_OBJECT;
+  if (nvals > v->nsize) return GRB_INDEX_OUT_OF_BOUNDS;    // dense_vector.hpp:201-202
+  v->vec_type = GRB_DENSE;
+  GRB_TRY(vec_alloc_dense(v));
+  if (nvals > 0) {
+    GRB_HIP_TRY(hipMemcpyAsync(v->d_val, values, 4 * (size_t)nvals, hipMemcpyHostToDevice, ctx().stream));
+    GRB_HIP_TRY(hipStreamSynchronize(ctx().stream));
+  }
+  return GRB_SUCCESS;
+}
+
+grb_info grb_vector_adopt_dense(grb_vector v, void* d_values, grb_index nvals) {
+  if (!v) return GRB_UNINITIALIZED_OBJECT;
+  (void)hipStreamSynchronize(ctx().stream);
+  if (v->d_owned && v->d_val) (void)hipFree(v->d_val);
+  v->d_val = d_values;
+  v->d_owned = false;
+  v->nsize = nvals;
+  v->vec_type = GRB_DENSE;
+  return GRB_SUCCESS;
+}
+grb_info grb_vector_adopt_sparse(grb_vector v, grb_index* d_indices, void* d_values, grb_index nvals) {
+  if (!v) return GRB_UNINITIALIZED_OBJECT;
+  (void)hipStreamSynchronize(ctx().stream);
+  if (v->s_owned) { if (v->s_ind) (void)hipFree(v->s_ind); if (v->s_val) (void)hipFree(v->s_val); }
+  v->s_ind = d_indices;
+  v->s_val = d_values;
+  v->s_owned = false;
+  v->s_nvals = nvals;
+  v->vec_type = GRB_SPARSE;
+  return GRB_SUCCESS;
+}
+
+grb_info grb_vector_set_element(grb_vector v, double val, grb_index index) {
+  if (!v) return GRB_UNINITIALIZED_OBJECT;
+  if (index < 0 || index >= v->nsize) return GRB_INDEX_OUT_OF_BOUNDS;
+  uint32_t raw;
+  store_scalar(v->dtype, &raw, val);
+  hipStream_t s = ctx().stream;
+  if (v->vec_type == GRB_DENSE) {
+    GRB_HIP_TRY(hipMemcpyAsync((char*)v->d_val + 4 * (size_t)index, &raw, 4, hipMemcpyHostToDevice, s));
+    GRB_HIP_TRY(hipStreamSynchronize(s));
+    return GRB_SUCCESS;
+  }
+  if (v->vec_type == GRB_SPARSE) {           // appended, sparse_vector.hpp:177-185
+    if (v->s_nvals >= v->nsize) return GRB_INDEX_OUT_OF_BOUNDS;
+    GRB_HIP_TRY(hipMemcpyAsync(v->s_ind + v->s_nvals, &index, 4, hipMemcpyHostToDevice, s));
+    GRB_HIP_TRY(hipMemcpyAsync((char*)v->s_val + 4 * (size_t)v->s_nvals, &raw, 4, hipMemcpyHostToDevice, s));
+    GRB_HIP_TRY(hipStreamSynchronize(s));
+    v->s_nvals++;
+    return GRB_SUCCESS;
+  }
+  return GRB_UNINITIALIZED_OBJECT;
+}
+
+grb_info grb_vector_extract_element(grb_vector v, double* val, grb_index index) {
+  if (!v || !val) return GRB_UNINITIALIZED_OBJECT;
+  if (index < 0 || index >= v->nsize) return GRB_INDEX_OUT_OF_BOUNDS;
+  if (v->vec_type != GRB_DENSE) return GRB_NOT_IMPLEMENTED;
+  uint32_t raw = 0;
+  GRB_HIP_TRY(hipMemcpyAsync(&raw, (char*)v->d_val + 4 * (size_t)index, 4, hipMemcpyDeviceToHost, ctx().stream));
+  GRB_HIP_TRY(hipStreamSynchronize(ctx().stream));
+  *val = load_scalar(v->dtype, &raw);
+  return GRB_SUCCESS;
+}
+
+grb_info grb_vector_extract_tuples_sparse(grb_vector v, grb_index* indices, void* values, grb_index* n) {
+  if (!v || !n) return GRB_UNINITIALIZED_OBJECT;
+  if (v->vec_type != GRB_SPARSE) return v->vec_type == GRB_DENSE ? GRB_NOT_IMPLEMENTED : GRB_UNINITIALIZED_OBJECT;
+  if (*n > v->s_nvals) return GRB_UNINITIALIZED_OBJECT;    // sparse_vector.hpp:203-211
+  if (*n < v->s_nvals) return GRB_INSUFFICIENT_SPACE;
+  if (*n > 0) {
+    hipStream_t s = ctx().stream;
+    GRB_HIP_TRY(hipMemcpyAsync(indices, v->s_ind, 4 * (size_t)*n, hipMemcpyDeviceToHost, s));
+    if (values) GRB_HIP_TRY(hipMemcpyAsync(values, v->s_val, 4 * (size_t)*n, hipMemcpyDeviceToHost, s));
+  }
+  GRB_HIP_TRY(hipStreamSynchronize(ctx().stream));
+  return GRB_SUCCESS;
+}
+
+grb_info grb_vector_extract_tuples_dense(grb_vector v, void* values, grb_index* n) {
+  if (!v || !n) return GRB_UNINITIALIZED_OBJECT;
+  if (v->vec_type == GRB_SPARSE) GRB_TRY(grb_vector_sparse2dense(v, 0.0, nullptr));   // vector.hpp:208-217
+  if (v->vec_type != GRB_DENSE) return GRB_UNINITIALIZED_OBJECT;
+  if (*n > v->nsize) return GRB_UNINITIALIZED_OBJECT;      // dense_vector.hpp:255-264
+  if (*n < v->nsize) return GRB_INSUFFICIENT_SPACE;
+  if (*n > 0)
+    GRB_HIP_TRY(hipMemcpyAsync(values, v->d_val, 4 * (size_t)*n, hipMemcpyDeviceToHost, ctx().stream));
+  GRB_HIP_TRY(hipStreamSynchronize(ctx().stream));
+  return GRB_SUCCESS;
+}
+
+grb_info grb_vector_fill(grb_vector v, double val) {
+  if (!v) return GRB_UNINITIALIZED_OBJECT;
+  if (v->vec_type != GRB_DENSE) GRB_TRY(grb_vector_set_storage(v, GRB_DENSE));
+  return k_fill(v->dtype, v->d_val, val, v->nsize);
+}
+grb_info grb_vector_fill_ascending(grb_vector v, grb_index) {
+  if (!v) return GRB_UNINITIALIZED_OBJECT;
+  if (v->vec_type != GRB_DENSE) GRB_TRY(grb_vector_set_storage(v, GRB_DENSE));
+  return k_fill_ascending(v->dtype, v->d_val, v->nsize);
+}
+
+// vector.hpp:428-450: same storage required; size, nvals and ratio_ travel with the contents
+grb_info grb_vector_swap(grb_vector a, grb_vector b) {
+  if (!a || !b) return GRB_UNINITIALIZED_OBJECT;
+  if (a->vec_type != b->vec_type || a->vec_type == GRB_UNKNOWN) return GRB_INVALID_OBJECT;
+  if (a->vec_type == GRB_SPARSE) {
+    std::swap(a->s_ind, b->s_ind);
+    std::swap(a->s_val, b->s_val);
+    std::swap(a->s_nvals, b->s_nvals);
+    std::swap(a->s_owned, b->s_owned);
+  } else {
+    std::swap(a->d_val, b->d_val);
+    std::swap(a->d_nnz, b->d_nnz);
+    std::swap(a->d_owned, b->d_owned);
+  }
+  std::swap(a->nsize, b->nsize);
+  std::swap(a->nvals, b->nvals);
+  std::swap(a->ratio, b->ratio);
+  return GRB_SUCCESS;
+}
+
+// vector.hpp:325-364
+grb_info grb_vector_sparse2dense(grb_vector v, double identity, grb_descriptor desc) {
+  if (!v) return GRB_UNINITIALIZED_OBJECT;
+  if (v->vec_type == GRB_DENSE) return GRB_SUCCESS;
+  if (v->vec_type == GRB_UNKNOWN) return grb_vector_set_storage(v, GRB_DENSE);
+  GRB_TRY(vec_alloc_dense(v));
+  const Index nvals = v->s_nvals;
+  if (!desc || !desc->opreuse) {
+    GRB_TRY(k_fill(v->dtype, v->d_val, identity, v->nsize));
+    if (desc && desc->struconly) GRB_TRY(k_scatter_const(v->dtype, v->d_val, v->s_ind, 1.0, nvals));
+    else GRB_TRY(k_scatter_vals(v->dtype, v->d_val, v->s_ind, v->s_val, nvals));
+  }
+  v->vec_type = GRB_DENSE;
+  v->d_nnz = nvals;
+  return GRB_SUCCESS;
+}
+
+// vector.hpp:366-425
+grb_info grb_vector_dense2sparse(grb_vector v, double identity, grb_descriptor desc) {
+  if (!v || !desc) return GRB_UNINITIALIZED_OBJECT;
+  if (v->vec_type == GRB_SPARSE) return GRB_INVALID_OBJECT;
+  GRB_TRY(vec_alloc_sparse(v));
+  GRB_TRY(vec_alloc_dense(v));
+  Index nv = 0;
+  GRB_TRY(k_dense2sparse(v->dtype, v->d_val, identity, v->nsize, v->s_ind, desc->struconly ? nullptr : v->s_val, &nv));
+  v->s_nvals = nv;
+  v->vec_type = GRB_SPARSE;
+  return GRB_SUCCESS;
+}
+
+// vector.hpp:291-323: the direction-optimisation heuristic
+grb_info grb_vector_convert(grb_vector v, double identity, float switchpoint, grb_descriptor desc) {
+  if (!v || !desc) return GRB_UNINITIALIZED_OBJECT;
+  Index nvals_t = 0, nsize_t = v->nsize;
+  if (v->vec_type == GRB_SPARSE) {
+    nvals_t = v->s_nvals;
+  } else if (v->vec_type == GRB_DENSE) {
+    if (v->nsize == 0) return GRB_INVALID_OBJECT;
+    GRB_TRY(k_count_nonidentity(v->dtype, v->d_val, identity, v->nsize, &nvals_t));
+    v->d_nnz = nvals_t;
+  } else {
+    return GRB_UNINITIALIZED_OBJECT;
+  }
+  const float ratio = (float)nvals_t / (float)nsize_t;
+  if (v->vec_type == GRB_SPARSE) {
+    if (ratio > switchpoint && ratio > v->ratio) GRB_TRY(grb_vector_sparse2dense(v, identity, desc));
+    else v->ratio = ratio;
+  } else {
+    if (ratio <= switchpoint && ratio < v->ratio) GRB_TRY(grb_vector_dense2sparse(v, identity, desc));
+    else v->ratio = ratio;
+  }
+  return GRB_SUCCESS;
+}
+
+grb_info grb_vector_device_ptrs(grb_vector v, grb_index** d_sparse_ind, void** d_sparse_val, void** d_dense_val) {
+  if (!v) return GRB_UNINITIALIZED_OBJECT;
+  if (d_sparse_ind) *d_sparse_ind = v->s_ind;
+  if (d_sparse_val) *d_sparse_val = v->s_val;
+  if (d_dense_val) *d_dense_val = v->d_val;
+  return GRB_SUCCESS;
+}
+
+// =============================================================================== Matrix
+grb_info grb_matrix_new(grb_matrix* out, grb_dtype dtype, grb_index nrows, grb_index ncols) {
+  if (!out) return GRB_NULL_POINTER;
+  if (nrows < 0 || ncols < 0) return GRB_INVALID_VALUE;
+  GRB_TRY(ctx_init());
+  grb_matrix A = new grb_matrix_s();
+  A->dtype = dtype;
+  A->nrows = nrows;
+  A->ncols = ncols;
+  *out = A;
+  return GRB_SUCCESS;
+}
+
+static void matrix_release_device(grb_matrix A) {
+  (void)hipStreamSynchronize(ctx().stream);
+  if (A->owned) {
+    for (CsrArrays* m : {&A->csr, &A->csc}) {
+      if (m->ptr) (void)hipFree(m->ptr);
+      if (m->ind) (void)hipFree(m->ind);
+      if (m->val) (void)hipFree(m->val);
+    }
+  }
+  A->csr = CsrArrays();
+  A->csc = CsrArrays();
+  free_spmv_plan(&A->plan_csr);
+  free_spmv_plan(&A->plan_csc);
+  A->built = false;
+}
+
+grb_info grb_matrix_free(grb_matrix A) {
+  if (!A) return GRB_SUCCESS;
+  matrix_release_device(A);
+  delete A;
+  return GRB_SUCCESS;
+}
+
+static grb_info upload(CsrArrays* d, Index n, Index nvals, const std::vector<Index>& ptr,
+                       const std::vector<Index>& ind, const std::vector<uint32_t>& val) {
+  d->n = n;
+  GRB_HIP_TRY(hipMalloc((void**)&d->ptr, 4 * ((size_t)n + 1)));
+  GRB_HIP_TRY(hipMemcpy(d->ptr, ptr.data(), 4 * ((size_t)n + 1), hipMemcpyHostToDevice));
+  size_t cap = nvals > 0 ? (size_t)nvals : 1;
+  GRB_HIP_TRY(hipMalloc((void**)&d->ind, 4 * cap));
+  GRB_HIP_TRY(hipMalloc(&d->val, 4 * cap));
+  if (nvals > 0) {
+    GRB_HIP_TRY(hipMemcpy(d->ind, ind.data(), 4 * (size_t)nvals, hipMemcpyHostToDevice));
+    GRB_HIP_TRY(hipMemcpy(d->val, val.data(), 4 * (size_t)nvals, hipMemcpyHostToDevice));
+  }
+  return GRB_SUCCESS;
+}
+
+// Sorted (major, minor) compressed build; ties keep input order (util.hpp:501-559).
+static void coo_to_compressed(const grb_index* major, const grb_index* minor, const uint32_t* vals, Index nvals,
+                              Index nmajor, std::vector<Index>* ptr, std::vector<Index>* ind,
+                              std::vector<uint32_t>* val) {
+  std::vector<Index> order((size_t)nvals);
+  std::iota(order.begin(), order.end(), 0);
+  std::stable_sort(order.begin(), order.end(), [&](Index a, Index b) {
+    if (major[a] != major[b]) return major[a] < major[b];
+    return minor[a] < minor[b];
+  });
+  ptr->assign((size_t)nmajor + 1, 0);
+  ind->resize((size_t)nvals);
+  val->resize((size_t)nvals);
+  for (Index i = 0; i < nvals; ++i) (*ptr)[(size_t)major[i] + 1]++;
+  for (Index r = 0; r < nmajor; ++r) (*ptr)[(size_t)r + 1] += (*ptr)[r];
+  for (Index i = 0; i < nvals; ++i) {
+    (*ind)[i] = minor[order[i]];
+    (*val)[i] = vals[order[i]];
+  }
+}
+
+// CSR -> CSC by counting sort (keeps row order inside every column).
+static void transpose_compressed(Index nmajor, Index nminor, const std::vector<Index>& ptr,
+                                 const std::vector<Index>& ind, const std::vector<uint32_t>& val,
+                                 std::vector<Index>* tptr, std::vector<Index>* tind, std::vector<uint32_t>* tval) {
+  const size_t nvals = ind.size();
+  tptr->assign((size_t)nminor + 1, 0);
+  tind->resize(nvals);
+  tval->resize(nvals);
+  for (size_t i = 0; i < nvals; ++i) (*tptr)[(size_t)ind[i] + 1]++;
+  for (Index c = 0; c < nminor; ++c) (*tptr)[(size_t)c + 1] += (*tptr)[c];
+  std::vector<Index> cursor(tptr->begin(), tptr->end() - 1);
+  for (Index r = 0; r < nmajor; ++r)
+    for (Index p = ptr[r]; p < ptr[(size_t)r + 1]; ++p) {
+      Index dst = cursor[ind[p]]++;
+      (*tind)[dst] = r;
+      (*tval)[dst] = val[p];
+    }
+}
+
+static grb_info matrix_finish_build(grb_matrix A) {
+  A->owned = true;
+  GRB_TRY(upload(&A->csr, A->nrows, A->nvals, A->h_csr_ptr, A->h_csr_ind, A->h_csr_val));
+  GRB_TRY(upload(&A->csc, A->ncols, A->nvals, A->h_csc_ptr, A->h_csc_ind, A->h_csc_val));
+  GRB_TRY(build_spmv_plan(A->h_csr_ptr, A->nrows, &A->plan_csr));
+  GRB_TRY(build_spmv_plan(A->h_csc_ptr, A->ncols, &A->plan_csc));
+  A->built = true;
+  return GRB_SUCCESS;
+}
+
+grb_info grb_matrix_build(grb_matrix A, const grb_index* rows, const grb_index* cols, const void* values,
+                          grb_index nvals) {
+  if (!A) return GRB_UNINITIALIZED_OBJECT;
+  if (nvals < 0) return GRB_INVALID_VALUE;
+  for (Index i = 0; i < nvals; ++i)
+    if (rows[i] < 0 || rows[i] >= A->nrows || cols[i] < 0 || cols[i] >= A->ncols) return GRB_INDEX_OUT_OF_BOUNDS;
+  matrix_release_device(A);
+  A->nvals = nvals;
+  const uint32_t* v = (const uint32_t*)values;
+  coo_to_compressed(rows, cols, v, nvals, A->nrows, &A->h_csr_ptr, &A->h_csr_ind, &A->h_csr_val);
+  coo_to_compressed(cols, rows, v, nvals, A->ncols, &A->h_csc_ptr, &A->h_csc_ind, &A->h_csc_val);
+  return matrix_finish_build(A);
+}
+
+grb_info grb_matrix_build_csr(grb_matrix A, const grb_index* csr_ptr, const grb_index* csr_ind, const void* csr_val,
+                              grb_index nvals, const grb_index* csc_ptr, const grb_index* csc_ind,
+                              const void* csc_val) {
+  if (!A || !csr_ptr) return GRB_UNINITIALIZED_OBJECT;
+  matrix_release_device(A);
+  A->nvals = nvals;
+  A->h_csr_ptr.assign(csr_ptr, csr_ptr + A->nrows + 1);
+  A->h_csr_ind.assign(csr_ind, csr_ind + nvals);
+  A->h_csr_val.assign((const uint32_t*)csr_val, (const uint32_t*)csr_val + nvals);
+  if (csc_ptr) {
+    A->h_csc_ptr.assign(csc_ptr, csc_ptr + A->ncols + 1);
+    A->h_csc_ind.assign(csc_ind, csc_ind + nvals);
+    A->h_csc_val.assign((const uint32_t*)csc_val, (const uint32_t*)csc_val + nvals);
+  } else {
+    transpose_compressed(A->nrows, A->ncols, A->h_csr_ptr, A->h_csr_ind, A->h_csr_val, &A->h_csc_ptr,
+                         &A->h_csc_ind, &A->h_csc_val);
+  }
+  return matrix_finish_build(A);
+}
+
+grb_info grb_matrix_adopt_device_csr(grb_matrix A, grb_index* d_csr_ptr, grb_index* d_csr_ind, void* d_csr_val,
+                                     grb_index nvals, grb_index* d_csc_ptr, grb_index* d_csc_ind, void* d_csc_val) {
+  if (!A || !d_csr_ptr) return GRB_UNINITIALIZED_OBJECT;
+  matrix_release_device(A);
+  A->owned = false;
+  A->nvals = nvals;
+  A->csr.ptr = d_csr_ptr; A->csr.ind = d_csr_ind; A->csr.val = d_csr_val; A->csr.n = A->nrows;
+  A->h_csr_ptr.resize((size_t)A->nrows + 1);
+  GRB_HIP_TRY(hipMemcpy(A->h_csr_ptr.data(), d_csr_ptr, 4 * ((size_t)A->nrows + 1), hipMemcpyDeviceToHost));
+  GRB_TRY(build_spmv_plan(A->h_csr_ptr, A->nrows, &A->plan_csr));
+  if (d_csc_ptr) {
+    A->csc.ptr = d_csc_ptr; A->csc.ind = d_csc_ind; A->csc.val = d_csc_val; A->csc.n = A->ncols;
+    A->h_csc_ptr.resize((size_t)A->ncols + 1);
+    GRB_HIP_TRY(hipMemcpy(A->h_csc_ptr.data(), d_csc_ptr, 4 * ((size_t)A->ncols + 1), hipMemcpyDeviceToHost));
+    GRB_TRY(build_spmv_plan(A->h_csc_ptr, A->ncols, &A->plan_csc));
+  }
+  A->h_csr_ind.clear(); A->h_csr_val.clear(); A->h_csc_ind.clear(); A->h_csc_val.clear();
+  A->built = true;
+  return GRB_SUCCESS;
+}
+
+grb_info grb_matrix_nrows(grb_matrix A, grb_index* n) { if (!A) return GRB_UNINITIALIZED_OBJECT; *n = A->nrows; return GRB_SUCCESS; }
+grb_info grb_matrix_ncols(grb_matrix A, grb_index* n) { if (!A) return GRB_UNINITIALIZED_OBJECT; *n = A->ncols; return GRB_SUCCESS; }
+grb_info grb_matrix_nvals(grb_matrix A, grb_index* n) { if (!A) return GRB_UNINITIALIZED_OBJECT; *n = A->nvals; return GRB_SUCCESS; }
+
+static grb_info ensure_host_mirror(grb_matrix A, bool csc) {
+  std::vector<Index>& ind = csc ? A->h_csc_ind : A->h_csr_ind;
+  std::vector<uint32_t>& val = csc ? A->h_csc_val : A->h_csr_val;
+  const CsrArrays& d = csc ? A->csc : A->csr;
+  if ((Index)ind.size() != A->nvals && d.ind) {
+    ind.resize((size_t)A->nvals);
+    val.resize((size_t)A->nvals);
+    if (A->nvals > 0) {
+      GRB_HIP_TRY(hipMemcpy(ind.data(), d.ind, 4 * (size_t)A->nvals, hipMemcpyDeviceToHost));
+      if (d.val) GRB_HIP_TRY(hipMemcpy(val.data(), d.val, 4 * (size_t)A->nvals, hipMemcpyDeviceToHost));
+    }
+  }
+  return GRB_SUCCESS;
+}
+
+grb_info grb_matrix_host_csr(grb_matrix A, const grb_index** ptr, const grb_index** ind, const void** val) {
+  if (!A || !A->built) return GRB_UNINITIALIZED_OBJECT;
+  GRB_TRY(ensure_host_mirror(A, false));
+  if (ptr) *ptr = A->h_csr_ptr.data();
+  if (ind) *ind = A->h_csr_ind.data();
+  if (val) *val = A->h_csr_val.data();
+  return GRB_SUCCESS;
+}
+grb_info grb_matrix_host_csc(grb_matrix A, const grb_index** ptr, const grb_index** ind, const void** val) {
+  if (!A || !A->built) return GRB_UNINITIALIZED_OBJECT;
+  if (!A->csc.ptr) return GRB_NO_VALUE;
+  GRB_TRY(ensure_host_mirror(A, true));
+  if (ptr) *ptr = A->h_csc_ptr.data();
+  if (ind) *ind = A->h_csc_ind.data();
+  if (val) *val = A->h_csc_val.data();
+  return GRB_SUCCESS;
+}
+
+grb_info grb_matrix_set_values(grb_matrix A, const void* csr_val) {
+  if (!A || !A->built || !A->owned) return GRB_UNINITIALIZED_OBJECT;
+  GRB_TRY(ensure_host_mirror(A, false));
+  A->h_csr_val.assign((const uint32_t*)csr_val, (const uint32_t*)csr_val + A->nvals);
+  std::vector<Index> tptr, tind;
+  transpose_compressed(A->nrows, A->ncols, A->h_csr_ptr, A->h_csr_ind, A->h_csr_val, &tptr, &tind, &A->h_csc_val);
+  GRB_HIP_TRY(hipStreamSynchronize(ctx().stream));
+  if (A->nvals > 0) {
+    GRB_HIP_TRY(hipMemcpy(A->csr.val, A->h_csr_val.data(), 4 * (size_t)A->nvals, hipMemcpyHostToDevice));
+    GRB_HIP_TRY(hipMemcpy(A->csc.val, A->h_csc_val.data(), 4 * (size_t)A->nvals, hipMemcpyHostToDevice));
+  }
+  return GRB_SUCCESS;
+}
+
+}  // extern "C"

@@ -1,0 +1,253 @@
+/*
+ * grb_hip.h -- C ABI of libgrb_hip.so, the MI355X (gfx950) backend for the
+ * GraphBLAST mxv/vxm hot path.
+ *
+ * The reference (gunrock/graphblast) has no FFI: its boundary is the C++ template
+ * frontend `graphblas::{Vector,Matrix,Descriptor}` + the free functions of
+ * graphblas/operations.hpp.  This header is that frontend flattened to C: one
+ * opaque handle per frontend class, one entry point per frontend method/operation
+ * on the path, enums in place of the functor template arguments.  Every entry point
+ * cites the reference interface it replaces.  All functions return a grb_info
+ * whose values are `graphblas::Info` (graphblas/types.hpp:28-42); nothing calls
+ * exit().  Plain pointers and sizes only; no C++ or torch types.
+ *
+ * One process drives one GPU (hipSetDevice is the caller's business); all work is
+ * enqueued on the stream set with grb_set_stream (default: the null stream).
+ * Host-visible results (nvals, reduce, extractTuples) synchronise that stream, as
+ * the reference's API does.
+ */
+#ifndef GRB_HIP_H_
+#define GRB_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef int32_t grb_index;                 /* graphblas::Index, types.hpp:18 */
+typedef int grb_info;                      /* graphblas::Info,  types.hpp:28-42 */
+
+enum {
+  GRB_SUCCESS = 0, GRB_UNINITIALIZED_OBJECT, GRB_NULL_POINTER, GRB_INVALID_VALUE,
+  GRB_INVALID_INDEX, GRB_DOMAIN_MISMATCH, GRB_DIMENSION_MISMATCH, GRB_OUTPUT_NOT_EMPTY,
+  GRB_NO_VALUE, GRB_NOT_IMPLEMENTED, GRB_OUT_OF_MEMORY, GRB_INSUFFICIENT_SPACE,
+  GRB_INVALID_OBJECT, GRB_INDEX_OUT_OF_BOUNDS, GRB_PANIC
+};
+
+/* graphblas::Storage, types.hpp:21-23 */
+enum { GRB_UNKNOWN = 0, GRB_SPARSE = 1, GRB_DENSE = 2 };
+
+/* graphblas::Desc_field, types.hpp:44-55 */
+enum { GRB_MASK = 0, GRB_OUTP, GRB_INP0, GRB_INP1, GRB_MODE, GRB_TA, GRB_TB, GRB_NT,
+       GRB_MXVMODE, GRB_TOL, GRB_BACKEND, GRB_NDESCFIELD };
+
+/* graphblas::Desc_value, types.hpp:57-78 (GRB_HIP takes the slot of GrB_CUDA) */
+enum { GRB_SCMP = 0, GRB_REPLACE = 1, GRB_TRAN = 2, GRB_DEFAULT = 3, GRB_FIXEDROW = 6,
+       GRB_PUSHPULL = 10, GRB_PUSHONLY = 11, GRB_PULLONLY = 12, GRB_SEQUENTIAL = 13,
+       GRB_HIP = 14 };
+
+/* Element type of a Vector<T> / Matrix<T>.  The reference instantiates float
+ * (BFS/SSSP/PR) and int (CC/TC). */
+typedef enum { GRB_F32 = 0, GRB_I32 = 1 } grb_dtype;
+
+/* Additive monoids, graphblas/stddef.hpp:159-172 (same order). */
+typedef enum {
+  GRB_PLUS_MONOID = 0, GRB_MULTIPLIES_MONOID, GRB_MINIMUM_MONOID, GRB_MAXIMUM_MONOID,
+  GRB_LOGICAL_OR_MONOID, GRB_LOGICAL_AND_MONOID, GRB_GREATER_MONOID,
+  GRB_CUSTOM_LESS_MONOID, GRB_NOT_EQUAL_TO_MONOID, GRB_N_MONOIDS
+} grb_monoid;
+
+/* Semirings, graphblas/stddef.hpp:195-213 (same order). */
+typedef enum {
+  GRB_LOGICAL_OR_AND = 0, GRB_PLUS_MULTIPLIES, GRB_MINIMUM_PLUS, GRB_MAXIMUM_MULTIPLIES,
+  GRB_PLUS_DIVIDES, GRB_PLUS_GREATER, GRB_GREATER_PLUS, GRB_PLUS_MINUS, GRB_PLUS_LESS,
+  GRB_CUSTOM_LESS_PLUS, GRB_MINIMUM_MULTIPLIES, GRB_MULTIPLIES_MULTIPLIES,
+  GRB_NOT_EQUAL_TO_PLUS, GRB_MINIMUM_SELECT_SECOND, GRB_PLUS_NOT_EQUAL_TO,
+  GRB_CUSTOM_LESS_LESS, GRB_MINIMUM_NOT_EQUAL_TO, GRB_N_SEMIRINGS
+} grb_semiring;
+
+/* `accum` argument: the reference only tests its presence
+ * (typeid(accum).name().size() > 1, backend/cuda/spmv.hpp:34-40). */
+typedef enum { GRB_ACCUM_NULL = 0, GRB_ACCUM_PRESENT = 1 } grb_accum;
+
+typedef struct grb_vector_s*     grb_vector;      /* graphblas::Vector<T>   vector.hpp:12-66 */
+typedef struct grb_matrix_s*     grb_matrix;      /* graphblas::Matrix<T>   matrix.hpp:13-84 */
+typedef struct grb_descriptor_s* grb_descriptor;  /* graphblas::Descriptor  descriptor.hpp:17-39 */
+
+/* ---- library ----------------------------------------------------------------- */
+/* Stream for all subsequent work (a hipStream_t cast to void*; NULL = null stream). */
+grb_info grb_set_stream(void* hip_stream);
+/* "gfx950:<CU count>:<device name>" of the current device, for logs. */
+grb_info grb_device_info(char* buf, size_t buflen);
+const char* grb_version(void);
+/* HIP-event stopwatch on the library stream (backend::GpuTimer, backend/cuda/util.hpp:92-120). */
+grb_info grb_timer_start(void);
+grb_info grb_timer_stop(float* elapsed_ms);
+
+/* ---- Descriptor (graphblas/descriptor.hpp:17-39, backend/cuda/descriptor.hpp) -- */
+grb_info grb_descriptor_new(grb_descriptor* desc);
+grb_info grb_descriptor_free(grb_descriptor desc);
+grb_info grb_descriptor_set(grb_descriptor desc, int field, int value);      /* Descriptor::set    */
+grb_info grb_descriptor_get(grb_descriptor desc, int field, int* value);     /* Descriptor::get    */
+grb_info grb_descriptor_toggle(grb_descriptor desc, int field);              /* Descriptor::toggle */
+/* Descriptor::loadArgs (backend/cuda/descriptor.hpp:207-287): grb_descriptor_load_defaults
+ * applies the parseArgs defaults of graphblas/util.hpp:39-132, grb_descriptor_set_arg one
+ * named CLI flag: mxvmode switchpoint struconly opreuse earlyexit fusedmask sort endbit
+ * memusage atomic dirinfo nthread max_niter niter timing debug directed transpose. */
+grb_info grb_descriptor_load_defaults(grb_descriptor desc);
+grb_info grb_descriptor_set_arg(grb_descriptor desc, const char* name, double value);
+grb_info grb_descriptor_get_arg(grb_descriptor desc, const char* name, double* value);
+/* desc->descriptor_.lastmxv_ : GRB_PUSHONLY or GRB_PULLONLY of the last mxv/vxm. */
+grb_info grb_descriptor_lastmxv(grb_descriptor desc, int* value);
+
+/* ---- Vector (graphblas/vector.hpp:12-66) ------------------------------------- */
+grb_info grb_vector_new(grb_vector* v, grb_dtype dtype, grb_index nsize);    /* Vector(Index)      */
+grb_info grb_vector_free(grb_vector v);
+grb_info grb_vector_dup(grb_vector dst, grb_vector src);                     /* dup / operator=    */
+grb_info grb_vector_clear(grb_vector v);
+grb_info grb_vector_size(grb_vector v, grb_index* nsize);
+grb_info grb_vector_nvals(grb_vector v, grb_index* nvals);
+/* build(indices, values, nvals, dup) -> sparse; host arrays; values are dtype-typed. */
+grb_info grb_vector_build_sparse(grb_vector v, const grb_index* indices, const void* values,
+                                 grb_index nvals);
+/* build(values, nvals) -> dense; host array. */
+grb_info grb_vector_build_dense(grb_vector v, const void* values, grb_index nvals);
+/* build(T* values, nvals) / build(Index*, T*, nvals): adopt caller DEVICE pointers
+ * without ownership (dense_vector.hpp:215-224, sparse_vector.hpp:164-175). */
+grb_info grb_vector_adopt_dense(grb_vector v, void* d_values, grb_index nvals);
+grb_info grb_vector_adopt_sparse(grb_vector v, grb_index* d_indices, void* d_values,
+                                 grb_index nvals);
+grb_info grb_vector_set_element(grb_vector v, double val, grb_index index);
+grb_info grb_vector_extract_element(grb_vector v, double* val, grb_index index);
+/* extractTuples(indices, values, n): sparse vector only; *n must equal nvals. */
+grb_info grb_vector_extract_tuples_sparse(grb_vector v, grb_index* indices, void* values,
+                                          grb_index* n);
+/* extractTuples(values, n): densifies a sparse vector with fill 0 (vector.hpp:208-217);
+ * *n must equal size. */
+grb_info grb_vector_extract_tuples_dense(grb_vector v, void* values, grb_index* n);
+grb_info grb_vector_fill(grb_vector v, double val);
+grb_info grb_vector_fill_ascending(grb_vector v, grb_index nvals);
+grb_info grb_vector_get_storage(grb_vector v, int* storage);
+grb_info grb_vector_set_storage(grb_vector v, int storage);
+grb_info grb_vector_swap(grb_vector a, grb_vector b);
+/* backend::Vector::{convert,sparse2dense,dense2sparse} (backend/cuda/vector.hpp:291-425). */
+grb_info grb_vector_convert(grb_vector v, double identity, float switchpoint, grb_descriptor desc);
+grb_info grb_vector_sparse2dense(grb_vector v, double identity, grb_descriptor desc /*nullable*/);
+grb_info grb_vector_dense2sparse(grb_vector v, double identity, grb_descriptor desc);
+/* Raw device views (sparse_.d_ind_, sparse_.d_val_, dense_.d_val_) for zero-copy
+ * interop (RCCL buffers, torch tensors); valid until the vector is freed or resized. */
+grb_info grb_vector_device_ptrs(grb_vector v, grb_index** d_sparse_ind, void** d_sparse_val,
+                                void** d_dense_val);
+
+/* ---- Matrix (graphblas/matrix.hpp:13-84) ------------------------------------- */
+grb_info grb_matrix_new(grb_matrix* A, grb_dtype dtype, grb_index nrows, grb_index ncols);
+grb_info grb_matrix_free(grb_matrix A);
+/* build(row_indices, col_indices, values, nvals, dup): host COO, sorted internally
+ * (coo2csr + coo2csc, backend/cuda/sparse_matrix.hpp:289-351). */
+grb_info grb_matrix_build(grb_matrix A, const grb_index* row_indices, const grb_index* col_indices,
+                          const void* values, grb_index nvals);
+/* Host CSR in, CSC derived (csr2csc); `csc_*` may be given to skip the transpose. */
+grb_info grb_matrix_build_csr(grb_matrix A, const grb_index* csr_row_ptr, const grb_index* csr_col_ind,
+                              const void* csr_val, grb_index nvals, const grb_index* csc_col_ptr,
+                              const grb_index* csc_row_ind, const void* csc_val);
+/* build(row_ptr, col_ind, values, nvals) adopting DEVICE CSR (+ optional CSC) pointers
+ * without ownership (sparse_matrix.hpp:417-435). */
+grb_info grb_matrix_adopt_device_csr(grb_matrix A, grb_index* d_csr_row_ptr, grb_index* d_csr_col_ind,
+                                     void* d_csr_val, grb_index nvals, grb_index* d_csc_col_ptr,
+                                     grb_index* d_csc_row_ind, void* d_csc_val);
+grb_info grb_matrix_nrows(grb_matrix A, grb_index* nrows);
+grb_info grb_matrix_ncols(grb_matrix A, grb_index* ncols);
+grb_info grb_matrix_nvals(grb_matrix A, grb_index* nvals);
+/* Host mirrors h_csrRowPtr_/h_csrColInd_/h_csrVal_ and h_cscColPtr_/h_cscRowInd_/h_cscVal_
+ * (sparse_matrix.hpp:120-132) that the CPU oracles read (algorithm/bfs.hpp:100-107). */
+grb_info grb_matrix_host_csr(grb_matrix A, const grb_index** row_ptr, const grb_index** col_ind,
+                             const void** val);
+grb_info grb_matrix_host_csc(grb_matrix A, const grb_index** col_ptr, const grb_index** row_ind,
+                             const void** val);
+/* Overwrite the stored values (CSR order; CSC is re-derived): what gsssp.cu:79-86 does
+ * through apply() + syncCpu, and gpr.cu:82-90 through the matrix eWiseMult variants. */
+grb_info grb_matrix_set_values(grb_matrix A, const void* csr_val);
+
+/* ---- Operations (graphblas/operations.hpp) ----------------------------------- */
+/* vxm  operations.hpp:59-87   -> backend/cuda/operations.hpp:80-209  */
+grb_info grb_vxm(grb_vector w, grb_vector mask, grb_accum accum, grb_semiring op, grb_vector u,
+                 grb_matrix A, grb_descriptor desc);
+/* mxv  operations.hpp:97-127  -> backend/cuda/operations.hpp:215-327 */
+grb_info grb_mxv(grb_vector w, grb_vector mask, grb_accum accum, grb_semiring op, grb_matrix A,
+                 grb_vector u, grb_descriptor desc);
+/* eWiseMult (vector x vector)  operations.hpp:137-158 -> backend :331-410 */
+grb_info grb_eWiseMult(grb_vector w, grb_vector mask, grb_accum accum, grb_semiring op, grb_vector u,
+                       grb_vector v, grb_descriptor desc);
+/* eWiseAdd (vector + vector)   operations.hpp:277-298 -> backend :567-627 */
+grb_info grb_eWiseAdd(grb_vector w, grb_vector mask, grb_accum accum, grb_semiring op, grb_vector u,
+                      grb_vector v, grb_descriptor desc);
+/* eWiseAdd (vector + scalar)   operations.hpp:333-352 -> backend :649-699 */
+grb_info grb_eWiseAdd_scalar(grb_vector w, grb_vector mask, grb_accum accum, grb_semiring op,
+                             grb_vector u, double val, grb_descriptor desc);
+/* reduce (vector -> scalar)    operations.hpp:642-660 -> backend :1004-1030; result on host. */
+grb_info grb_reduce_vector(double* val, grb_accum accum, grb_monoid op, grb_vector u,
+                           grb_descriptor desc);
+/* reduce (matrix -> vector, row-wise)  operations.hpp:620-640 -> backend :953-986 */
+grb_info grb_reduce_matrix_rows(grb_vector w, grb_vector mask, grb_accum accum, grb_monoid op,
+                                grb_matrix A, grb_descriptor desc);
+/* assign (constant under mask, GrB_ALL)  operations.hpp:509-530 -> backend :822-860 */
+grb_info grb_assign(grb_vector w, grb_vector mask, grb_accum accum, double val, grb_descriptor desc);
+
+/* ---- Algorithms: the drivers of graphblas/algorithm/{bfs,...}.hpp built on the ops above.
+ * *_fused variants run the same level loop on the device-resident representation
+ * (bitmap frontier, no per-op host round trips) and must return identical results. */
+typedef struct {
+  int      levels;            /* iterations executed                                  */
+  float    tight_ms;          /* HIP-event time of the level loop ("tight", bfs.hpp:42-88) */
+  int64_t  edges_traversed;   /* sum of out-degree over reached vertices (TEPS numerator) */
+  int32_t  reached;           /* vertices with a nonzero label                         */
+} grb_bfs_result;
+
+/* Per-level record, filled when `levels_out` is non-NULL (capacity max_levels). */
+typedef struct {
+  int32_t direction;          /* 0 push (SpMSpV), 1 pull (SpMV): desc lastmxv_          */
+  int32_t frontier;           /* nf: vertices in the input frontier                    */
+  int64_t frontier_edges;     /* push: mf = sum of frontier out-degrees; pull: inspected edges (profile bit 1) */
+  int32_t discovered;         /* vertices labelled by this level                       */
+  float   ms;                 /* HIP-event time of this level (only in profiling mode) */
+} grb_bfs_level;
+
+/* algorithm::bfs (algorithm/bfs.hpp:14-89) op by op through grb_assign/grb_vxm/grb_reduce. */
+grb_info grb_bfs(grb_vector v, grb_matrix A, grb_index source, grb_descriptor desc,
+                 grb_bfs_result* result);
+/* Same result, fused device-resident level loop.  profile bit 0: HIP events around every
+ * level's expansion kernel(s) -> grb_bfs_level.ms (cheap).  profile bit 1: pull levels also
+ * count the edges they inspect (slower kernel variant) -> grb_bfs_level.frontier_edges. */
+grb_info grb_bfs_fused(grb_vector v, grb_matrix A, grb_index source, grb_descriptor desc,
+                       grb_bfs_result* result, grb_bfs_level* levels_out, int max_levels,
+                       int profile);
+
+typedef struct {
+  int    iterations;          /* loop iterations executed                              */
+  float  tight_ms;            /* HIP-event time of the loop                            */
+  double last_value;          /* sssp: last reduce(succ); pr: last residual `error`    */
+} grb_algo_result;
+
+/* algorithm::sssp (algorithm/sssp.hpp:15-103): v = distances, FLT_MAX when unreachable. */
+grb_info grb_sssp(grb_vector v, grb_matrix A, grb_index source, grb_descriptor desc,
+                  grb_algo_result* result);
+/* algorithm::pr (algorithm/pr.hpp:15-94): A must already be the scaled column-stochastic
+ * matrix the driver prepares (example/gpr.cu:67-90). */
+grb_info grb_pr(grb_vector p, grb_matrix A, float alpha, float eps, grb_descriptor desc,
+                grb_algo_result* result);
+
+/* ---- Raw kernels on plain device pointers (micro-benchmarks / multi-GPU shards) --- */
+/* Generic semiring SpMV  w[i] = (+)_j A[i,j] (x) u[j] on this matrix's CSR (tran=0) or
+ * CSC (tran=1) arrays: the kernel behind the pull branch (backend/cuda/spmv.hpp:178-220).
+ * mask may be NULL. */
+grb_info grb_k_spmv(grb_matrix A, int tran, grb_semiring op, const void* d_u, const void* d_mask,
+                    int scmp, int accum, void* d_w);
+/* Algorithmic bytes of one grb_k_spmv launch: 8*nnz + 12*n + 4. */
+int64_t grb_k_spmv_bytes(grb_matrix A, int tran);
+
+#ifdef __cplusplus
+}
+#endif
+#endif  /* GRB_HIP_H_ */

@@ -1,0 +1,255 @@
+"""GPU suite (-m gpu): the algorithm drivers through the C ABI against the C oracle
+(SimpleReference*), on the reference's data files, seeded random graphs and RMAT,
+plus full-size (RMAT-22) checks."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from backends import HipBackend, GOLDEN
+
+pytestmark = pytest.mark.gpu
+F = np.float32
+FLT_MAX = np.finfo(np.float32).max
+
+
+@pytest.fixture(scope="module")
+def hb():
+    return HipBackend()
+
+
+def small_graphs():
+    from graphblast_amd.graphgen import finalize_edges, rmat_edges, grid_edges
+    out = []
+    rng = np.random.default_rng(2)
+    for n, m, sym in ((200, 500, True), (2000, 7000, False), (5000, 9000, True)):
+        out.append(("rand%d" % n, finalize_edges(rng.integers(0, n, m), rng.integers(0, n, m), n, symmetrize=sym)))
+    s, d, n = rmat_edges(14, 16, seed=1)
+    out.append(("rmat14_sym", finalize_edges(s, d, n, symmetrize=True)))
+    out.append(("rmat14_dir", finalize_edges(s, d, n, symmetrize=False)))
+    s, d, n = grid_edges(120, keep=0.7)
+    out.append(("grid120", finalize_edges(s, d, n, symmetrize=True)))
+    return out
+
+
+@pytest.fixture(scope="module")
+def graphs():
+    return small_graphs()
+
+
+def build(hb, g, vals=None):
+    ptr, ind = g["csr"]
+    if vals is None:
+        vals = np.ones(ind.size, dtype=F)
+    A = hb.g.Matrix(g["n"], g["n"])
+    cptr, cind = g["csc"]
+    if vals is not None and not np.all(vals == 1):
+        assert A.build_csr(ptr, ind, vals) == 0          # CSC values derived on the host
+    else:
+        assert A.build_csr(ptr, ind, vals, csc=(cptr, cind, np.ones(cind.size, dtype=F))) == 0
+    return A
+
+
+def first_source(g):
+    return int(np.nonzero(np.diff(g["csr"][0]))[0][0])
+
+
+def test_bfs_known_answers(hb):
+    """data/small graphs: chesapeake depth vector, every mxvmode, op-by-op
+    and fused."""
+    from oracle import simple_reference as sr
+    ka = json.load(open(os.path.join(GOLDEN, "known_answers.json")))
+    g = hb.g
+    for name in ("chesapeake", "test_cc", "test_bc"):
+        A = hb.matrix_from_mtx(name + ".mtx")
+        n = A.nrows()
+        for mode in (0, 1, 2):
+            for struc in (0, 1):
+                for fused in (False, True):
+                    d = hb.descriptor(mxvmode=mode, struconly=struc, opreuse=struc)
+                    v = g.Vector(n)
+                    info, res = g.bfs(v, A, 0, d, fused=fused)
+                    assert info == 0
+                    got = hb.dense_values(v)
+                    assert got.astype(int).tolist() == ka[name]["bfs_depth"], (name, mode, struc, fused)
+
+
+def test_bfs_random_graphs(hb, graphs):
+    """Depth labels bit-exact vs SimpleReferenceBfs; op-by-op == fused; the fused loop's
+    direction trace and per-level counts equal the accounting oracle's."""
+    from oracle import simple_reference as sr
+    g = hb.g
+    for name, gr in graphs:
+        ptr, ind = gr["csr"]
+        cptr, cind = gr["csc"]
+        A = build(hb, gr)
+        n = gr["n"]
+        srcs = [first_source(gr)] + g.graphgen.random_sources(ptr, 1, seed=1)
+        for s in srcs:
+            want, depth_max, _ = sr.bfs(ptr, ind, s)
+            for mode in (0, 1, 2):
+                for sp in (0.01, 0.1):
+                    d = hb.descriptor(mxvmode=mode, switchpoint=sp, struconly=1, opreuse=1)
+                    v1, v2 = g.Vector(n), g.Vector(n)
+                    i1, r1 = g.bfs(v1, A, s, d, fused=False)
+                    i2, r2 = g.bfs(v2, A, s, d, fused=True, profile=3)
+                    assert i1 == 0 and i2 == 0
+                    a, b = hb.dense_values(v1), hb.dense_values(v2)
+                    assert np.array_equal(a, want), (name, s, mode, sp, "op-by-op")
+                    assert np.array_equal(b, want), (name, s, mode, sp, "fused")
+                    _, stats = sr.bfs_do_stats(ptr, ind, cptr, cind, s, mxvmode=10 + mode, switchpoint=sp)
+                    lv = r2["per_level"]
+                    assert len(lv) == len(stats) == r2["levels"], (name, s, mode, sp)
+                    for L, st in zip(lv, stats):
+                        assert (L["direction"] == "pull") == bool(st[0])
+                        assert L["frontier"] == st[1] and L["discovered"] == st[5]
+                        assert L["frontier_edges"] == (st[4] if st[0] else st[2])   # pull: inspected, push: expanded
+                    assert r2["reached"] == int(np.count_nonzero(want))
+                    assert r2["edges_traversed"] == int(np.diff(ptr)[want != 0].sum())
+
+
+def test_bfs_max_niter_cap(hb, graphs):
+    """A frontier discovered by the last allowed iteration is never labelled (bfs.hpp:48-66)."""
+    g = hb.g
+    name, gr = graphs[-1]                      # grid: many levels
+    ptr, ind = gr["csr"]
+    A = build(hb, gr)
+    s = first_source(gr)
+    from oracle import simple_reference as sr
+    full = sr.bfs(ptr, ind, s)[0]
+    for fused in (False, True):
+        for mode in (0, 1, 2):
+            d = hb.descriptor(mxvmode=mode, max_niter=5)
+            v = g.Vector(gr["n"])
+            assert g.bfs(v, A, s, d, fused=fused)[0] == 0
+            got = hb.dense_values(v)
+            assert np.array_equal(got, np.where(full <= 5, full, 0)), (fused, mode)
+
+
+def test_sssp(hb, graphs):
+    """Distances equal lazy Dijkstra (integer weights 1..64: sums exact in f32, so exact;
+    the bar written in BASELINE.md is 1e-5 relative)."""
+    from oracle import simple_reference as sr
+    g = hb.g
+    for name, gr in graphs[:5]:
+        ptr, ind = gr["csr"]
+        rng = np.random.default_rng(3)
+        w = rng.integers(1, 65, ind.size).astype(F)
+        A = build(hb, gr, w)
+        s = first_source(gr)
+        want = sr.sssp(ptr, ind, w, s)[0]
+        for mode in (0, 1, 2):
+            d = hb.descriptor(mxvmode=mode)
+            v = g.Vector(gr["n"])
+            info, res = g.sssp(v, A, s, d)
+            assert info == 0
+            got = hb.dense_values(v)
+            assert np.allclose(got, want, rtol=1e-5, atol=0), (name, mode)
+            assert np.array_equal(got == FLT_MAX, want == FLT_MAX)
+
+
+def test_pagerank(hb, graphs):
+    """algorithm::pr at fixed max_niter vs SimpleReferencePr, <= 1e-5 relative."""
+    from oracle import simple_reference as sr
+    g = hb.g
+    for name, gr in graphs[:4]:
+        ptr, ind = gr["csr"]
+        n = gr["n"]
+        deg = np.diff(ptr).astype(F)
+        rows = np.repeat(np.arange(n), np.diff(ptr))
+        vals = (F(1.0) * F(0.85)) / deg[rows]            # gpr.cu:82-90
+        A = build(hb, gr, vals.astype(F))
+        want = sr.pr(ptr, ind, 0.85, 1e-8, 10)[0]
+        for mode in (1, 2):
+            d = hb.descriptor(mxvmode=mode, max_niter=10)
+            p = g.Vector(n)
+            info, res = g.pr(p, A, 0.85, 1e-8, d)
+            assert info == 0 and res["iterations"] == 10
+            got = hb.dense_values(p)
+            rel = np.abs(got - want) / np.maximum(np.abs(want), 1e-30)
+            assert rel.max() <= 1e-5, (name, mode, rel.max())
+
+
+def test_raw_spmv_kernel_entry(hb, graphs):
+    """grb_k_spmv on plain device pointers (the benchmarked kernel) == mxv result."""
+    import torch
+    g = hb.g
+    name, gr = graphs[3]
+    ptr, ind = gr["csr"]
+    n = gr["n"]
+    rng = np.random.default_rng(0)
+    vals = rng.integers(1, 4, ind.size).astype(F)
+    A = build(hb, gr, vals)
+    u = rng.integers(0, 3, n).astype(F)
+    tu = torch.from_numpy(u).cuda()
+    tw = torch.empty(n, dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    assert g.k_spmv(A, 0, "PlusMultiplies", tu.data_ptr(), None, 0, 0, tw.data_ptr()) == 0
+    torch.cuda.synchronize()
+    want = np.zeros(n, dtype=np.float64)
+    np.add.at(want, np.repeat(np.arange(n), np.diff(ptr)), vals.astype(np.float64) * u[ind])
+    assert np.array_equal(tw.cpu().numpy(), want.astype(F))
+    assert g.k_spmv_bytes(A, 0) == 8 * ind.size + 12 * n + 4
+
+
+def test_full_size_rmat22_bfs_and_spmv(hb):
+    """BASELINE.json's size: RMAT scale 22, edge factor 16, symmetrised (n = 4 194 304,
+    ~1.3e8 stored edges). Fused DO-BFS bit-exact vs SimpleReferenceBfs from 3 sources;
+    size-independent properties: every labelled non-source vertex has a neighbour one level
+    up and no neighbour more than one level away; SpMV linearity and a checksum."""
+    import torch
+    from graphblast_amd.graphgen import rmat_edges, finalize_edges
+    from oracle import simple_reference as sr
+    g = hb.g
+    s_, d_, n = rmat_edges(22, 16, seed=1, device="cuda")
+    gr = finalize_edges(s_, d_, n, symmetrize=True)
+    del s_, d_
+    tptr, tind = gr["csr"]
+    nnz = gr["nnz"]
+    tval = torch.ones(nnz, dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    A = g.Matrix(n, n)
+    assert A.build_device_csr(tptr.data_ptr(), tind.data_ptr(), tval.data_ptr(), nnz, tptr.data_ptr(),
+                              tind.data_ptr(), tval.data_ptr(), keep=(tptr, tind, tval)) == 0
+    ptr, ind = tptr.cpu().numpy(), tind.cpu().numpy()
+    deg = np.diff(ptr)
+    sources = [int(np.argmax(deg))] + g.graphgen.random_sources(ptr, 1, seed=0)
+    rows = np.repeat(np.arange(n, dtype=np.int32), deg)
+    d = hb.descriptor(mxvmode=0, struconly=1, opreuse=1)
+    for s in sources:
+        v = g.Vector(n)
+        info, res = g.bfs(v, A, s, d, fused=True)
+        assert info == 0
+        got = hb.dense_values(v)
+        want = sr.bfs(ptr, ind, s)[0]
+        assert np.array_equal(got, want), s
+        assert res["edges_traversed"] == int(deg[want != 0].sum())
+        if s != sources[0]:
+            continue
+        # property check on the GPU result itself (vectorised over all edges)
+        lr, lc = got[rows], got[ind]
+        both_reached = (lr != 0) & (lc != 0)
+        assert np.all(np.abs(lr[both_reached] - lc[both_reached]) <= 1)
+        assert not np.any((lr != 0) ^ (lc != 0))          # symmetric graph: components are closed
+        up = np.zeros(n, dtype=bool)
+        up[rows[lc == lr - 1]] = True
+        assert np.all(up[(got > 1)])
+    # SpMV at full size: linearity + checksum against the host
+    rng = np.random.default_rng(1)
+    x = rng.integers(0, 3, n).astype(F)
+    y = rng.integers(0, 3, n).astype(F)
+    tx, ty = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
+    w1 = torch.empty(n, dtype=torch.float32, device="cuda")
+    w2 = torch.empty_like(w1)
+    w3 = torch.empty_like(w1)
+    txy = tx + ty
+    torch.cuda.synchronize()
+    assert g.k_spmv(A, 0, "PlusMultiplies", tx.data_ptr(), None, 0, 0, w1.data_ptr()) == 0
+    assert g.k_spmv(A, 0, "PlusMultiplies", ty.data_ptr(), None, 0, 0, w2.data_ptr()) == 0
+    assert g.k_spmv(A, 0, "PlusMultiplies", txy.data_ptr(), None, 0, 0, w3.data_ptr()) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(w1 + w2, w3)                         # integer-valued: exact
+    want = np.add.reduceat(x[ind].astype(np.float64), ptr[:-1][deg > 0])
+    got = w1.cpu().numpy()
+    assert np.array_equal(got[deg > 0], want.astype(F)) and np.all(got[deg == 0] == 0)

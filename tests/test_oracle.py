@@ -1,0 +1,199 @@
+"""CPU suite: pins the ORACLE (oracle/) against the reference's golden vectors.
+Nothing here touches the HIP path."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from backends import OracleBackend, GOLDEN
+import ref_cases
+
+
+@pytest.fixture(scope="module")
+def be():
+    return OracleBackend()
+
+
+def test_reference_unit_cases_on_oracle(be):
+    """Every literal case of test/gvxm.cu, gewiseadd.cu, gewisemult.cu, greduce.cu."""
+    results = ref_cases.run_all(be)
+    assert len(results) > 40
+    for label, got, cor in results:
+        assert got.shape == cor.shape, label
+        assert np.array_equal(got, cor), (label, got, cor)
+
+
+def test_loader_against_reference_mmio():
+    """Banner / size parsing vs the reference's own mmio.hpp (oracle/_ref, recorded in
+    tests/golden/mmio_ref.json)."""
+    from oracle import loader
+    ref = json.load(open(os.path.join(GOLDEN, "mmio_ref.json")))
+    assert len(ref) >= 12
+    for fname, r in ref.items():
+        with open(os.path.join(GOLDEN, "data", fname)) as f:
+            code = loader.read_banner(f.readline())
+            line = f.readline()
+            while line.startswith("%"):
+                line = f.readline()
+            nr, nc, nnz = (int(x) for x in line.split()[:3])
+        assert r["rc_banner"] == 0 and r["rc_size"] == 0
+        assert "".join(code) == r["typecode"], fname
+        assert (nr, nc, nnz) == (r["nrows"], r["ncols"], r["nnz"]), fname
+
+
+def test_loader_known_answers():
+    """Row degrees asserted by test/greduce.cu:65,72; chesapeake size."""
+    from oracle import loader
+    ka = json.load(open(os.path.join(GOLDEN, "known_answers.json")))
+    for name in ("test_cc", "test_bc"):
+        r, c, v, nr, nc, nv = loader.read_mtx(os.path.join(GOLDEN, "data", name + ".mtx"))
+        ptr, ind, val = loader.coo2csr(r, c, v, nr, nc)
+        assert np.diff(ptr).tolist() == ka[name]["row_degrees"]
+        assert np.all(np.diff(ind.astype(np.int64) + np.repeat(np.arange(nr), np.diff(ptr)) * nc) > 0)
+        cp, ci, cv = loader.coo2csc(r, c, v, nr, nc)
+        cp2, ci2, cv2 = loader.csr2csc(ptr, ind, val, nr, nc)
+        assert np.array_equal(cp, cp2) and np.array_equal(ci, ci2) and np.array_equal(cv, cv2)
+    r, c, v, nr, nc, nv = loader.read_mtx(os.path.join(GOLDEN, "data", "chesapeake.mtx"))
+    assert (nr, nv) == (ka["chesapeake"]["n"], ka["chesapeake"]["nnz"])
+    assert not np.any(r == c)
+    # symmetric input was doubled: the edge set equals its transpose
+    assert set(zip(r.tolist(), c.tolist())) == set(zip(c.tolist(), r.tolist()))
+
+
+def test_loader_quirks(tmp_path):
+    """Duplicates and self loops are dropped; values are NOT moved by the compaction
+    (util.hpp:311-323); --directed 2 symmetrises; cache file round trip."""
+    from oracle import loader
+    p = tmp_path / "q.mtx"
+    p.write_text("%%MatrixMarket matrix coordinate real general\n4 4 6\n"
+                 "1 1 9.0\n1 2 1.0\n1 2 2.0\n3 1 3.0\n2 4 4.0\n4 4 5.0\n")
+    r, c, v, nr, nc, nv = loader.read_mtx(str(p), directed=0)
+    assert list(zip(r, c)) == [(0, 1), (1, 3), (2, 0)]
+    assert v.tolist() == [9.0, 1.0, 2.0]          # sorted values truncated, not compacted
+    r2, c2, v2, _, _, nv2 = loader.read_mtx(str(p), directed=2)
+    assert sorted(zip(r2.tolist(), c2.tolist())) == [(0, 1), (0, 2), (1, 0), (1, 3), (2, 0), (3, 1)]
+    ptr, ind, val = loader.coo2csr(r2, c2, np.ones(nv2, dtype=np.float32), nr, nc)
+    cache = loader.cache_name(str(p), True)
+    assert cache.endswith("/.q.mtx.ud.nosl.bin")
+    loader.write_cache(str(tmp_path / "c.bin"), ptr, ind)
+    p3, i3, v3 = loader.read_cache(str(tmp_path / "c.bin"))
+    assert np.array_equal(p3, ptr) and np.array_equal(i3, ind) and np.all(v3 == 1)
+
+
+def test_semiring_table_against_reference_stddef():
+    """identity / add / mul of all 17 semirings x {f32,i32} vs the table printed by the
+    reference's own graphblas/stddef.hpp (tests/golden/semiring_ref.json)."""
+    from oracle.semiring import Semiring
+    ref = json.load(open(os.path.join(GOLDEN, "semiring_ref.json")))
+    assert len(ref) == 34
+    for e in ref:
+        dt = np.float32 if e["dtype"] == "f32" else np.int32
+        sr = Semiring(e["semiring"], dt)
+        assert float(sr.identity()) == pytest.approx(e["identity"], rel=1e-7), e["semiring"]
+        for a, b, want in e["add"]:
+            assert float(sr.add_op(a, b)) == want, (e["semiring"], e["dtype"], "add", a, b)
+        for a, b, want in e["mul"]:
+            got = float(sr.mul_op(a, b))
+            assert got == pytest.approx(want, rel=1e-6), (e["semiring"], e["dtype"], "mul", a, b)
+
+
+def test_simple_reference_known_answers():
+    from oracle import loader, simple_reference as sr
+    ka = json.load(open(os.path.join(GOLDEN, "known_answers.json")))
+    r, c, v, nr, nc, nv = loader.read_mtx(os.path.join(GOLDEN, "data", "chesapeake.mtx"))
+    ptr, ind, val = loader.coo2csr(r, c, v, nr, nc)
+    depth, sd, _ = sr.bfs(ptr, ind, 0)
+    assert depth.astype(int).tolist() == ka["chesapeake"]["bfs_depth"]
+    assert sd == ka["chesapeake"]["bfs_search_depth"]
+    rows = np.repeat(np.arange(nr), np.diff(ptr))
+    low = ind < rows                                   # tril, tri.hpp:21-48
+    lp, li, lv = loader.coo2csr(rows[low], ind[low], val[low], nr, nc)
+    assert sr.tc(lp, li)[0] == ka["chesapeake"]["tc_tril"]
+    assert sr.tc(ptr, ind)[0] == ka["chesapeake"]["tc_full"]
+    for name in ("test_cc", "test_bc"):
+        r, c, v, nr, nc, nv = loader.read_mtx(os.path.join(GOLDEN, "data", name + ".mtx"))
+        ptr, ind, val = loader.coo2csr(r, c, v, nr, nc)
+        assert sr.bfs(ptr, ind, 0)[0].astype(int).tolist() == ka[name]["bfs_depth"]
+
+
+def _rand_graph(n, m, seed, sym=True):
+    rng = np.random.default_rng(seed)
+    from graphblast_amd.graphgen import finalize_edges
+    return finalize_edges(rng.integers(0, n, m), rng.integers(0, n, m), n, symmetrize=sym)
+
+
+def test_simple_reference_vs_scipy():
+    """Independent cross-check of the C oracles (scipy.sparse.csgraph)."""
+    import scipy.sparse as sp
+    from scipy.sparse import csgraph
+    from oracle import simple_reference as sr
+    for seed, sym in ((1, True), (2, False)):
+        g = _rand_graph(500, 1500, seed, sym)
+        ptr, ind = g["csr"]
+        n = g["n"]
+        rng = np.random.default_rng(seed)
+        w = rng.integers(1, 65, ind.size).astype(np.float32)
+        M = sp.csr_matrix((w, ind, ptr), shape=(n, n))
+        d = csgraph.shortest_path(sp.csr_matrix((np.ones(ind.size), ind, ptr), shape=(n, n)), method="D",
+                                  unweighted=True, indices=0)
+        depth = sr.bfs(ptr, ind, 0)[0]
+        want = np.where(np.isinf(d), 0, d + 1)
+        assert np.array_equal(depth, want.astype(np.float32))
+        dist = sr.sssp(ptr, ind, w, 0)[0]
+        dd = csgraph.dijkstra(M, indices=0)
+        fm = np.finfo(np.float32).max
+        assert np.allclose(np.where(dist == fm, np.inf, dist), dd)
+        if sym:
+            nc, lab = csgraph.connected_components(M, directed=False)
+            mine, k, _ = sr.cc(ptr, ind)
+            assert k == nc
+            assert np.array_equal(sr.cc_canonical(mine), sr.cc_canonical(lab))
+            assert sr.cc_verify(ptr, ind, mine) == (0, nc)
+
+
+def test_algorithm_drivers_on_oracle():
+    """algorithm::{bfs,sssp,pr} restated over the oracle ops agree with SimpleReference*
+    for every mxvmode -- i.e. the ops-level oracle and the C oracle pin each other."""
+    from oracle import ops, algorithms, simple_reference as sr
+    g = _rand_graph(300, 900, 5, True)
+    ptr, ind = g["csr"]
+    n = g["n"]
+    rng = np.random.default_rng(3)
+    w = rng.integers(1, 65, ind.size).astype(np.float32)
+    want_bfs = sr.bfs(ptr, ind, 0)[0]
+    want_sssp = sr.sssp(ptr, ind, w, 0)[0]
+    for mode in (0, 1, 2):
+        for struc in (False, True):
+            A = ops.Matrix(n, n)
+            A.build_csr(ptr, ind, np.ones(ind.size, dtype=np.float32))
+            d = ops.Descriptor()
+            d.loadArgs(mxvmode=mode, struconly=struc, opreuse=struc)
+            got, trace = algorithms.bfs(A, 0, d)
+            assert np.array_equal(got, want_bfs), (mode, struc)
+        A = ops.Matrix(n, n)
+        A.build_csr(ptr, ind, w)
+        d = ops.Descriptor()
+        d.loadArgs(mxvmode=mode)
+        got, trace = algorithms.sssp(A, 0, d)
+        assert np.array_equal(got, want_sssp), mode
+    # direction trace of the ops-level BFS == the C accounting oracle
+    A = ops.Matrix(n, n)
+    A.build_csr(ptr, ind, np.ones(ind.size, dtype=np.float32))
+    d = ops.Descriptor()
+    d.loadArgs(mxvmode=0, switchpoint=0.05)
+    got, trace = algorithms.bfs(A, 0, d)
+    depth, stats = sr.bfs_do_stats(ptr, ind, ptr, ind, 0, mxvmode=10, switchpoint=0.05)
+    assert np.array_equal(depth, got)
+    assert [t[0] for t in trace] == ["pull" if s[0] else "push" for s in stats]
+    # PageRank at a fixed iteration count
+    A = ops.Matrix(n, n)
+    A.build_csr(ptr, ind, np.ones(ind.size, dtype=np.float32))
+    algorithms.pr_setup(A, 0.85)
+    d = ops.Descriptor()
+    d.loadArgs(mxvmode=2, max_niter=10)
+    got, errs = algorithms.pr(A, 0.85, 1e-8, d)
+    want = sr.pr(ptr, ind, 0.85, 1e-8, 10)[0]
+    deg = np.diff(ptr)
+    ok = deg > 0
+    assert np.allclose(got, want, rtol=1e-4, atol=1e-7)
