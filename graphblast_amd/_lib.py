@@ -106,11 +106,29 @@ _SIGS = {
 _lib = None
 
 
+def _share_torch_hip_runtime():
+    """PyTorch wheels bundle their own libamdhip64.so (same SONAME as /opt/rocm's).  A process
+    must run ONE HIP runtime for torch tensors, RCCL buffers and this library to share device
+    pointers, and whichever copy is loaded first wins -- so when torch is installed its copy is
+    loaded here first (without importing torch); libgrb_hip.so then binds to it."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        C.CDLL(cand, mode=C.RTLD_GLOBAL)
+
+
 def load():
     """dlopen the library; never silently substitutes anything."""
     global _lib
     if _lib is not None:
         return _lib
+    _share_torch_hip_runtime()
     if not os.path.exists(LIB_PATH):
         raise ImportError("graphblast_amd: %s not found -- build it with `python -c 'import "
                           "__graft_entry__ as g; g.build()'` (hipcc, gfx950). There is no CPU "

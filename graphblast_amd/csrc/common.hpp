@@ -315,6 +315,7 @@ struct CsrArrays {
   Index* ind = nullptr;   // [nvals]
   void* val = nullptr;    // [nvals] of dtype
   Index n = 0;            // number of rows of this orientation
+  Index nvals = 0;        // stored entries
 };
 
 }  // namespace grb
@@ -357,6 +358,7 @@ struct grb_matrix_s {
   std::vector<uint32_t> h_csr_val, h_csc_val;   // raw 4-byte values of dtype
   grb::CsrArrays csr, csc;                       // device
   grb::SpmvPlan plan_csr, plan_csc;
+  unsigned int* d_no_in_edges = nullptr;         // bitmap: CSC column empty (built lazily by bfs_fused)
 };
 
 namespace grb {

@@ -570,6 +570,7 @@ static void matrix_release_device(grb_matrix A) {
   }
   A->csr = CsrArrays();
   A->csc = CsrArrays();
+  if (A->d_no_in_edges) { (void)hipFree(A->d_no_in_edges); A->d_no_in_edges = nullptr; }
   free_spmv_plan(&A->plan_csr);
   free_spmv_plan(&A->plan_csc);
   A->built = false;
@@ -585,6 +586,7 @@ grb_info grb_matrix_free(grb_matrix A) {
 static grb_info upload(CsrArrays* d, Index n, Index nvals, const std::vector<Index>& ptr,
                        const std::vector<Index>& ind, const std::vector<uint32_t>& val) {
   d->n = n;
+  d->nvals = nvals;
   GRB_HIP_TRY(hipMalloc((void**)&d->ptr, 4 * ((size_t)n + 1)));
   GRB_HIP_TRY(hipMemcpy(d->ptr, ptr.data(), 4 * ((size_t)n + 1), hipMemcpyHostToDevice));
   size_t cap = nvals > 0 ? (size_t)nvals : 1;
@@ -687,12 +689,12 @@ grb_info grb_matrix_adopt_device_csr(grb_matrix A, grb_index* d_csr_ptr, grb_ind
   matrix_release_device(A);
   A->owned = false;
   A->nvals = nvals;
-  A->csr.ptr = d_csr_ptr; A->csr.ind = d_csr_ind; A->csr.val = d_csr_val; A->csr.n = A->nrows;
+  A->csr.ptr = d_csr_ptr; A->csr.ind = d_csr_ind; A->csr.val = d_csr_val; A->csr.n = A->nrows; A->csr.nvals = nvals;
   A->h_csr_ptr.resize((size_t)A->nrows + 1);
   GRB_HIP_TRY(hipMemcpy(A->h_csr_ptr.data(), d_csr_ptr, 4 * ((size_t)A->nrows + 1), hipMemcpyDeviceToHost));
   GRB_TRY(build_spmv_plan(A->h_csr_ptr, A->nrows, &A->plan_csr));
   if (d_csc_ptr) {
-    A->csc.ptr = d_csc_ptr; A->csc.ind = d_csc_ind; A->csc.val = d_csc_val; A->csc.n = A->ncols;
+    A->csc.ptr = d_csc_ptr; A->csc.ind = d_csc_ind; A->csc.val = d_csc_val; A->csc.n = A->ncols; A->csc.nvals = nvals;
     A->h_csc_ptr.resize((size_t)A->ncols + 1);
     GRB_HIP_TRY(hipMemcpy(A->h_csc_ptr.data(), d_csc_ptr, 4 * ((size_t)A->ncols + 1), hipMemcpyDeviceToHost));
     GRB_TRY(build_spmv_plan(A->h_csc_ptr, A->ncols, &A->plan_csc));

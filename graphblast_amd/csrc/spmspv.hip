@@ -55,41 +55,31 @@ __device__ inline void atomic_combine(T* addr, T v) {
   }
 }
 
-// ---- 3. per-edge visitor of lb_expand_kernel: mask, multiply, combine
+// ---- 3. per-edge visitor of lb_expand_kernel: mask (peek), multiply + combine (visit)
 template <int SR, typename T, bool kStruc>
 struct SpmspvVisitor {
   const T* val; const T* u_val; const void* mask; int mask_f32, use_mask, keep_when_zero;
   unsigned int* touched; T* acc;
-  __device__ void operator()(Index k, Index /*row*/, Index p, Index dst) const {
+  __device__ bool peek(Index dst) const {
+    if (use_mask && ((mask_nonzero(mask, mask_f32, dst) ? 1 : 0) == keep_when_zero)) return false;
+    if constexpr (kStruc) return !((touched[dst >> 5] >> (dst & 31)) & 1u);   // already recorded
+    return true;
+  }
+  __device__ void visit(Index k, Index p, Index dst) const {
     typedef Semiring<SR, T> S;
-    if (use_mask && ((mask_nonzero(mask, mask_f32, dst) ? 1 : 0) == keep_when_zero)) return;
     const unsigned int bit = 1u << (dst & 31);
     if constexpr (!kStruc) {
       const T a = val[p], x = u_val[k];
       const T ident = S::identity();
       const T prod = (a == ident || x == ident) ? ident : S::mul(a, x);   // kernels/ewisemult.hpp:22-25
       atomic_combine<S::monoid, T>(&acc[dst], prod);
+      if ((touched[dst >> 5] & bit)) return;
     }
-    if (!(touched[dst >> 5] & bit)) atomicOr(&touched[dst >> 5], bit);
+    atomicOr(&touched[dst >> 5], bit);
   }
 };
 
 // ---- 4. ordered bitmap compaction (one word per thread), resets bitmap + accumulator
-__global__ void bitmap_count_kernel(const unsigned int* __restrict__ words, int nwords,
-                                    int* __restrict__ tile_counts) {
-  __shared__ int smem[kWavesPerBlock];
-  int i = blockIdx.x * kBlock + threadIdx.x;
-  int c = i < nwords ? __popc(words[i]) : 0;
-  c = wave_reduce(c, [](int a, int b) { return a + b; });
-  if (lane_id() == 0) smem[wave_id()] = c;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    int t = 0;
-    for (int w = 0; w < kWavesPerBlock; ++w) t += smem[w];
-    tile_counts[blockIdx.x] = t;
-  }
-}
-
 template <typename T, bool kStruc>
 __global__ void bitmap_write_kernel(unsigned int* __restrict__ words, int nwords,
                                     const int* __restrict__ tile_off, T* __restrict__ acc, T identity,
@@ -127,29 +117,27 @@ grb_info k_spmspv(int sr, int dtype, const CsrArrays& M, Index out_size, int str
   const int ntiles = ceil_div(nf, kDegTile);
   const int nwords = ceil_div(out_size, 32);
   const int wtiles = ceil_div(nwords, kBlock);
-  void *p_scan, *p_tiles, *p_bitmap, *p_acc, *p_btiles;
+  void *p_scan, *p_tiles, *p_bitmap, *p_acc, *p_btiles, *p_rs, *p_chunks;
+  const long long max_edges = (long long)M.nvals;
   GRB_TRY(scratch(2, sizeof(int) * (size_t)nf, &p_scan));
+  GRB_TRY(scratch(11, sizeof(int) * (size_t)nf, &p_rs));
   GRB_TRY(scratch(3, sizeof(int) * (size_t)(2 * ntiles + 2), &p_tiles));
-  GRB_TRY(scratch(6, sizeof(int) * (size_t)(2 * wtiles + 2), &p_btiles));
+  GRB_TRY(scratch(6, sizeof(int) * (size_t)(2 * wtiles + 2 + max_edges / kEdgeChunk + 4), &p_btiles));
   // slots 4 (bitmap) and 5 (accumulator) are persistent: kept zero / identity between calls
   size_t old_bitmap_cap = ctx().slot_cap[4];
   GRB_TRY(scratch(4, sizeof(unsigned int) * (size_t)nwords, &p_bitmap));
   if (ctx().slot_cap[4] != old_bitmap_cap)
     GRB_HIP_TRY(hipMemsetAsync(p_bitmap, 0, ctx().slot_cap[4], s));
   int* local_scan = (int*)p_scan;
+  Index* row_start = (Index*)p_rs;
   int* tile_sums = (int*)p_tiles;
   int* tile_off = tile_sums + ntiles;            // ntiles + 1 entries
   int* btile_counts = (int*)p_btiles;
-  int* btile_off = btile_counts + wtiles;
+  int* btile_off = btile_counts + wtiles;        // wtiles + 1 entries
+  Index* chunk_owner = (Index*)(btile_off + wtiles + 2);
   int* d_mail = ctx().d_mail;                    // [0] expanded edges, [1] output count, [2] dropped
-
-  hipLaunchKernelGGL(push_degree_kernel, dim3(ntiles), dim3(kBlock), 0, s, M.ptr, u_ind, nf, local_scan, tile_sums);
-  GRB_HIP_TRY(hipGetLastError());
-  hipLaunchKernelGGL(push_scan_tiles_kernel, dim3(1), dim3(kBlock), 0, s, tile_sums, ntiles, tile_off, d_mail);
-  GRB_HIP_TRY(hipGetLastError());
   GRB_HIP_TRY(hipMemsetAsync(d_mail + 2, 0, sizeof(int), s));
 
-  const int grid = 2048;
   GRB_TRY(dispatch_semiring(sr, dtype, [&](auto tag, auto t) -> grb_info {
     using T = decltype(t);
     constexpr int SR = decltype(tag)::value;
@@ -171,17 +159,16 @@ grb_info k_spmspv(int sr, int dtype, const CsrArrays& M, Index out_size, int str
     if (struconly) {
       SpmspvVisitor<SR, T, true> vis{(const T*)M.val, (const T*)u_val, mask, mask_f32, use_mask,
                                      keep_when_mask_zero, (unsigned int*)p_bitmap, acc};
-      hipLaunchKernelGGL((lb_expand_kernel<SpmspvVisitor<SR, T, true>>), dim3(grid), dim3(kBlock), 0, s, M.ptr,
-                         M.ind, u_ind, nf, local_scan, tile_off, ntiles, vis);
+      GRB_TRY(launch_lb_expand(s, M, u_ind, nf, max_edges, local_scan, row_start, tile_sums, tile_off, chunk_owner,
+                               d_mail, vis));
     } else {
       SpmspvVisitor<SR, T, false> vis{(const T*)M.val, (const T*)u_val, mask, mask_f32, use_mask,
                                       keep_when_mask_zero, (unsigned int*)p_bitmap, acc};
-      hipLaunchKernelGGL((lb_expand_kernel<SpmspvVisitor<SR, T, false>>), dim3(grid), dim3(kBlock), 0, s, M.ptr,
-                         M.ind, u_ind, nf, local_scan, tile_off, ntiles, vis);
+      GRB_TRY(launch_lb_expand(s, M, u_ind, nf, max_edges, local_scan, row_start, tile_sums, tile_off, chunk_owner,
+                               d_mail, vis));
     }
-    GRB_HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(bitmap_count_kernel, dim3(wtiles), dim3(kBlock), 0, s, (const unsigned int*)p_bitmap, nwords,
-                       btile_counts);
+    hipLaunchKernelGGL(bitmap_count_kernel, dim3(wtiles), dim3(kBlock), 0, s, (const unsigned int*)p_bitmap,
+                       (const unsigned int*)nullptr, nwords, btile_counts);
     GRB_HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(push_scan_tiles_kernel, dim3(1), dim3(kBlock), 0, s, btile_counts, wtiles, btile_off,
                        d_mail + 1);
