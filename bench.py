@@ -60,6 +60,8 @@ def main():
     ap.add_argument("--scale", type=int, default=22)
     ap.add_argument("--edge-factor", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--partitioned", action="store_true",
+                    help="use the 1-D partitioned level loop even at N = 1 (debugging the N > 1 path)")
     args = ap.parse_args()
 
     import torch
@@ -98,7 +100,7 @@ def main():
         torch.cuda.synchronize()
 
     extra = {}
-    if world == 1:
+    if world == 1 and not args.partitioned:
         tval = torch.ones(nnz, dtype=torch.float32, device=dev)
         torch.cuda.synchronize()
         A = g.Matrix(n, n)
@@ -205,9 +207,10 @@ def main():
             edges += part.bfs(sources[i % len(sources)])["edges_traversed"]
         barrier()
         elapsed = time.perf_counter() - t0
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
         roofline = None
         parallelism = "1d_vertex_partition_x%d" % world
 

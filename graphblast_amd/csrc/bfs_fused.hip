@@ -28,114 +28,9 @@
 //
 // Labels are the reference's: v[i] = level at which i was discovered, source = 1,
 // unreachable = 0, float32 (bit-exact vs SimpleReferenceBfs, test_bfs.hpp:11-61).
-#include "push_common.hpp"
+#include "bfs_kernels.hpp"
 
 namespace grb {
-
-constexpr int kPullProbe = 4;
-
-struct BfsPushVisitor {
-  unsigned int* visited;
-  float* label;
-  float new_label;
-  __device__ bool peek(Index dst) const { return !((visited[dst >> 5] >> (dst & 31)) & 1u); }
-  __device__ void visit(Index, Index, Index dst) const {
-    const unsigned int bit = 1u << (dst & 31);
-    const unsigned int old = atomicOr(&visited[dst >> 5], bit);
-    if (!(old & bit)) label[dst] = new_label;
-  }
-};
-
-__device__ inline bool bit_set(const unsigned int* __restrict__ bm, Index v) {
-  return (bm[v >> 5] >> (v & 31)) & 1u;
-}
-
-template <bool kCountInspected>
-__global__ __launch_bounds__(kBlock) void bfs_pull_kernel(
-    const Index* __restrict__ ptr, const Index* __restrict__ ind, Index n,
-    const unsigned int* __restrict__ vin, const unsigned int* __restrict__ skip,
-    unsigned int* __restrict__ vout, float* __restrict__ label, float new_label,
-    unsigned long long* __restrict__ inspected_out /* profile only */) {
-  __shared__ unsigned long long blk_inspected;
-  const int lane = lane_id();
-  const Index nchunks = (n + kWave - 1) / kWave;
-  const Index wave_global = (Index)blockIdx.x * kWavesPerBlock + wave_id();
-  const Index nwaves = (Index)gridDim.x * kWavesPerBlock;
-  unsigned long long inspected = 0;
-  if (kCountInspected) {
-    if (threadIdx.x == 0) blk_inspected = 0ull;
-    __syncthreads();
-  }
-  for (Index chunk = wave_global; chunk < nchunks; chunk += nwaves) {
-    const Index v = chunk * kWave + lane;
-    const unsigned int word = vin[(chunk << 1) + (lane >> 5)];
-    // `skip` marks vertices without in-edges: never discoverable, but NOT visited (they may
-    // still be somebody's in-neighbour, so they must not look visited to the hit test)
-    const bool was = ((word | skip[(chunk << 1) + (lane >> 5)]) >> (lane & 31)) & 1u;
-    bool active = (v < n) && !was;
-    unsigned long long act_mask = __ballot(active);
-    if (act_mask == 0ull) {                       // whole chunk already visited / unreachable
-      if (lane == 0) vout[chunk << 1] = word;
-      if (lane == 32) vout[(chunk << 1) + 1] = word;
-      continue;
-    }
-    Index p = 0, e = 0;
-    bool found = false;
-    if (active) {
-      p = ptr[v];
-      e = ptr[v + 1];
-      const Index stop = (e - p > kPullProbe) ? p + kPullProbe : e;
-      for (; p < stop; ++p) {
-        if (kCountInspected) ++inspected;
-        if (bit_set(vin, ind[p])) { found = true; break; }
-      }
-      if (found) p = e;
-    }
-    unsigned long long todo = __ballot(active && p < e);
-    while (todo) {
-      const int src = __ffsll((long long)todo) - 1;
-      todo &= todo - 1;
-      const Index rs = __shfl(p, src, kWave), re = __shfl(e, src, kWave);
-      bool any = false;
-      for (Index q = rs; q < re; q += kWave) {
-        bool h = false;
-        if (q + lane < re) h = bit_set(vin, ind[q + lane]);
-        const unsigned long long hb = __ballot(h);
-        if (kCountInspected && lane == 0) {
-          // early-exit accounting: edges up to and including the first hit
-          Index span = (re - q < kWave) ? re - q : kWave;
-          inspected += hb ? (unsigned long long)__ffsll((long long)hb) : (unsigned long long)span;
-        }
-        if (hb) { any = true; break; }
-      }
-      if (lane == src && any) found = true;
-    }
-    const unsigned long long fb = __ballot(found);
-    if (lane == 0) vout[chunk << 1] = word | (unsigned int)(fb & 0xffffffffull);
-    if (lane == 32) vout[(chunk << 1) + 1] = word | (unsigned int)(fb >> 32);
-    if (found) label[v] = new_label;
-  }
-  if (kCountInspected) {
-    inspected = wave_reduce(inspected, [](unsigned long long a, unsigned long long b) { return a + b; });
-    if (lane == 0) atomicAdd(&blk_inspected, inspected);
-    __syncthreads();
-    if (threadIdx.x == 0 && blk_inspected) atomicAdd(inspected_out, blk_inspected);
-  }
-}
-
-// bit v set  <=>  vertex v has no stored entry in this orientation (ptr[v+1] == ptr[v]);
-// bits >= n of the last words are set too, so padding never looks "unvisited"
-__global__ void bfs_empty_rows_kernel(const Index* __restrict__ ptr, Index n, int nwords,
-                                      unsigned int* __restrict__ out) {
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nwords; i += gridDim.x * blockDim.x) {
-    unsigned int w = 0u;
-    for (int b = 0; b < 32; ++b) {
-      Index v = (Index)i * 32 + b;
-      if (v >= n || ptr[v + 1] == ptr[v]) w |= 1u << b;
-    }
-    out[i] = w;
-  }
-}
 
 __global__ void bfs_seed_kernel(unsigned int* visited, float* label, Index* queue, Index source) {
   if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -150,28 +45,6 @@ __global__ void bfs_seed_kernel(unsigned int* visited, float* label, Index* queu
 __global__ void bfs_unlabel_kernel(float* __restrict__ label, Index n, float bad) {
   for (Index i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
     if (label[i] == bad) label[i] = 0.f;
-}
-
-// TEPS numerator: sum of out-degree over labelled vertices, and their count.
-// Partials per workgroup, spread over 32 slots to keep atomics off a single address.
-__global__ void bfs_tally_kernel(const float* __restrict__ label, const Index* __restrict__ ptr, Index n,
-                                 unsigned long long* __restrict__ out /*[32][2]: edges, reached*/) {
-  __shared__ unsigned long long se[kWavesPerBlock], sr[kWavesPerBlock];
-  unsigned long long edges = 0, reached = 0;
-  for (Index i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    if (label[i] != 0.f) { edges += (unsigned long long)(ptr[i + 1] - ptr[i]); ++reached; }
-  }
-  edges = wave_reduce(edges, [](unsigned long long a, unsigned long long b) { return a + b; });
-  reached = wave_reduce(reached, [](unsigned long long a, unsigned long long b) { return a + b; });
-  if (lane_id() == 0) { se[wave_id()] = edges; sr[wave_id()] = reached; }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    unsigned long long e = 0, r = 0;
-    for (int w = 0; w < kWavesPerBlock; ++w) { e += se[w]; r += sr[w]; }
-    const int slot = blockIdx.x & 31;
-    atomicAdd(&out[slot * 2], e);
-    atomicAdd(&out[slot * 2 + 1], r);
-  }
 }
 
 }  // namespace grb
@@ -196,12 +69,7 @@ extern "C" grb_info grb_bfs_fused(grb_vector v, grb_matrix A, grb_index source, 
   const long long max_chunks = max_edges / kEdgeChunk + 2;
 
   // vertices without in-edges, cached per matrix
-  if (!A->d_no_in_edges) {
-    GRB_HIP_TRY(hipMalloc((void**)&A->d_no_in_edges, 4 * (size_t)nwords));
-    hipLaunchKernelGGL(bfs_empty_rows_kernel, dim3(stream_grid(nwords)), dim3(kBlock), 0, s, A->csc.ptr, n, nwords,
-                       A->d_no_in_edges);
-    GRB_HIP_TRY(hipGetLastError());
-  }
+  GRB_TRY(ensure_empty_rows(&A->d_no_in_edges, A->csc, s));
 
   void *p_va, *p_vb, *p_q, *p_scan, *p_rs, *p_tiles, *p_bt;
   GRB_TRY(scratch(7, 4 * (size_t)nwords, &p_va));
@@ -287,11 +155,12 @@ extern "C" grb_info grb_bfs_fused(grb_vector v, grb_matrix A, grb_index source, 
       GRB_TRY(mark());
       if (count_inspected)
         hipLaunchKernelGGL((bfs_pull_kernel<true>), dim3(grid), dim3(kBlock), 0, s, A->csc.ptr, A->csc.ind, n, vis,
-                           A->d_no_in_edges, vis_alt, label, (float)(iter + 1),
+                           vis, A->d_no_in_edges, vis_alt, 0, label, (float)(iter + 1),
                            reinterpret_cast<unsigned long long*>(d_state + 2));
       else
         hipLaunchKernelGGL((bfs_pull_kernel<false>), dim3(grid), dim3(kBlock), 0, s, A->csc.ptr, A->csc.ind, n, vis,
-                           A->d_no_in_edges, vis_alt, label, (float)(iter + 1), (unsigned long long*)nullptr);
+                           vis, A->d_no_in_edges, vis_alt, 0, label, (float)(iter + 1),
+                           (unsigned long long*)nullptr);
       GRB_HIP_TRY(hipGetLastError());
       GRB_TRY(mark());
       std::swap(vis, vis_alt);       // vis = new set, vis_alt = set before this level

@@ -359,6 +359,7 @@ struct grb_matrix_s {
   grb::CsrArrays csr, csc;                       // device
   grb::SpmvPlan plan_csr, plan_csc;
   unsigned int* d_no_in_edges = nullptr;         // bitmap: CSC column empty (built lazily by bfs_fused)
+  unsigned int* d_empty_csr_rows = nullptr;      // bitmap: CSR row empty (built lazily by bfs_part)
 };
 
 namespace grb {

@@ -1,0 +1,202 @@
+"""1-D vertex-partitioned, multi-GPU direction-optimised BFS.
+
+One process per GPU (torch.distributed; backend "nccl" is RCCL over xGMI, "gloo" on CPU
+for the logic tests).  Rank r owns the vertex range [lo_r, hi_r) -- boundaries on
+multiples of 64, chosen so every rank holds about nnz / P stored edges -- with the
+out-edges (push) and in-edges (pull) of its vertices, a replica of the n-bit visited
+bitmap and the labels of its own vertices.
+
+Per level every rank expands locally (C ABI: grb_bfs_part_pull / grb_bfs_part_push), the
+n/8-byte "new bits" bitmaps are OR-combined with ONE all-gather (each rank sends 512 KiB
+at RMAT-22; xGMI is point-to-point, so an all-gather uses all links at once where a ring
+all-reduce of the same bitmap would be per-link bound), and grb_bfs_part_apply folds the
+result into the replicated state and returns the next frontier size -- the same number on
+every rank, so the push/pull decision (the reference's `convert` rule,
+backend/cuda/vector.hpp:291-323) is taken identically everywhere without another
+collective.  The reference itself has no multi-GPU path.
+
+The orchestration is engine-agnostic: `HipEngine` drives libgrb_hip.so; the CPU logic
+tests plug in a numpy engine (tests/), which is how the N > 1 path is covered without GPUs.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+GRB_PUSHPULL, GRB_PUSHONLY, GRB_PULLONLY = 10, 11, 12
+
+
+def partition_bounds(ptr, world):
+    """nnz-balanced vertex ranges, lower bounds on multiples of 64."""
+    ptr = np.asarray(ptr, dtype=np.int64)
+    n = ptr.size - 1
+    nnz = int(ptr[-1])
+    bounds = [0]
+    for r in range(1, world):
+        v = int(np.searchsorted(ptr, nnz * r // world, side="left"))
+        v = min(n, max(bounds[-1], (v + 32) // 64 * 64))
+        bounds.append(v)
+    bounds.append(n)
+    return bounds
+
+
+def bitmap_words(n):
+    return 2 * ((n + 63) // 64)
+
+
+class HipEngine:
+    """Level steps through the C ABI on device tensors."""
+
+    def __init__(self, n, lo, lptr, lind, dev):
+        import graphblast_amd as g
+        from . import _lib
+        self._lib = _lib.load()
+        self.n, self.lo, self.n_local = n, lo, lptr.numel() - 1
+        self.keep = (lptr, lind)
+        self.A = g.Matrix(self.n_local, n)
+        info = self.A.build_device_csr(lptr.data_ptr(), lind.data_ptr(), None, int(lind.numel()), keep=self.keep)
+        if info != 0:
+            raise RuntimeError("grb_matrix_adopt_device_csr failed: %d" % info)
+        self.work = torch.zeros(bitmap_words(n), dtype=torch.int32, device=dev)
+
+    def pull(self, vis, new_local, label_local, new_label):
+        info = self._lib.grb_bfs_part_pull(self.A._h, self.lo, self.n, vis.data_ptr(), new_local.data_ptr(),
+                                           label_local.data_ptr(), float(new_label))
+        assert info == 0, info
+
+    def push(self, frontier, vis, new_local):
+        info = self._lib.grb_bfs_part_push(self.A._h, self.lo, self.n, frontier.data_ptr(), vis.data_ptr(),
+                                           self.work.data_ptr(), new_local.data_ptr(), None)
+        assert info == 0, info
+
+    def apply(self, new_global, vis, label_local, new_label):
+        out = C.c_int32(0)
+        info = self._lib.grb_bfs_part_apply(new_global.data_ptr(), vis.data_ptr(), self.lo, self.n_local, self.n,
+                                            label_local.data_ptr(), float(new_label), C.byref(out))
+        assert info == 0, info
+        return out.value
+
+    def tally(self, label_local):
+        e, r = C.c_int64(0), C.c_int32(0)
+        info = self._lib.grb_bfs_part_tally(self.A._h, label_local.data_ptr(), C.byref(e), C.byref(r))
+        assert info == 0, info
+        return e.value, r.value
+
+
+class TorchComm:
+    """The collectives of the partitioned BFS over torch.distributed (RCCL / gloo)."""
+
+    def __init__(self, world, nwords, dev):
+        self.world, self.nwords = world, nwords
+        self.gathered = torch.zeros(world * nwords, dtype=torch.int32, device=dev) if world > 1 else None
+
+    def or_combine(self, new_local, new_global):
+        """OR of every rank's new-bits bitmap: one all-gather + local OR."""
+        if self.world == 1:
+            new_global.copy_(new_local)
+            return
+        dist.all_gather_into_tensor(self.gathered, new_local)
+        g = self.gathered.view(self.world, self.nwords)
+        new_global.copy_(g[0])
+        for r in range(1, self.world):
+            new_global.bitwise_or_(g[r])
+
+    def sum_(self, t):
+        if self.world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return t
+
+    def all_gather_padded(self, pad):
+        out = torch.zeros(self.world * pad.numel(), dtype=pad.dtype, device=pad.device)
+        dist.all_gather_into_tensor(out, pad)
+        return out.view(self.world, pad.numel())
+
+
+class Partition1D:
+    def __init__(self, n, tptr, tind, rank, world, dev, engine_cls=HipEngine, mxvmode=GRB_PUSHPULL,
+                 switchpoint=0.01, max_niter=10000, symmetric=True, comm=None):
+        if not symmetric:
+            raise NotImplementedError("directed graphs need a separate in-edge shard; pass the CSC as (tptr, tind)")
+        self.n, self.rank, self.world, self.dev = n, rank, world, dev
+        ptr_host = tptr.cpu().numpy()
+        self.bounds = partition_bounds(ptr_host, world)
+        self.lo, self.hi = self.bounds[rank], self.bounds[rank + 1]
+        e0, e1 = int(ptr_host[self.lo]), int(ptr_host[self.hi])
+        lptr = (tptr[self.lo:self.hi + 1] - e0).to(torch.int32).contiguous()
+        lind = tind[e0:e1].to(torch.int32).contiguous()
+        if lind.numel() == 0:
+            lind = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.engine = engine_cls(n, self.lo, lptr, lind, dev)
+        self.n_local = self.hi - self.lo
+        self.nwords = bitmap_words(n)
+        z = lambda: torch.zeros(self.nwords, dtype=torch.int32, device=dev)
+        self.vis, self.new_local, self.new_global = z(), z(), z()
+        self.comm = comm if comm is not None else TorchComm(world, self.nwords, dev)
+        self.label = torch.zeros(max(self.n_local, 1), dtype=torch.float32, device=dev)
+        self.mxvmode, self.switchpoint, self.max_niter = mxvmode, float(np.float32(switchpoint)), max_niter
+
+    def _combine(self):
+        self.comm.or_combine(self.new_local, self.new_global)
+
+    def bfs(self, source):
+        n = self.n
+        self.vis.zero_()
+        self.label.zero_()
+        self.new_global.zero_()
+        word, bit = source >> 5, source & 31
+        seed = (1 << bit) if bit < 31 else -(1 << 31)
+        self.new_global[word] = seed
+        self.vis[word] = seed
+        if self.lo <= source < self.hi:
+            self.label[source - self.lo] = 1.0
+        f1_dense = self.mxvmode == GRB_PULLONLY
+        ratio_f1 = ratio_f2 = np.float32(0)
+        nf, levels, trace = 1, 0, []
+        it = 1
+        while it <= self.max_niter:
+            if self.mxvmode == GRB_PUSHPULL:                       # vector.hpp:291-323
+                ratio = np.float32(nf) / np.float32(n)
+                if not f1_dense:
+                    if ratio > np.float32(self.switchpoint) and ratio > ratio_f1:
+                        f1_dense = True
+                    else:
+                        ratio_f1 = ratio
+                else:
+                    if ratio <= np.float32(self.switchpoint) and ratio < ratio_f1:
+                        f1_dense = False
+                    else:
+                        ratio_f1 = ratio
+            else:
+                f1_dense = self.mxvmode == GRB_PULLONLY
+            if f1_dense:
+                self.new_local.zero_()
+                self.engine.pull(self.vis, self.new_local, self.label, it + 1)
+            else:
+                self.engine.push(self.new_global, self.vis, self.new_local)
+            self._combine()
+            found = self.engine.apply(self.new_global, self.vis, self.label, it + 1)
+            trace.append(("pull" if f1_dense else "push", nf, found))
+            levels += 1
+            ratio_f1, ratio_f2 = ratio_f2, ratio_f1
+            nf = found
+            if nf == 0:
+                break
+            it += 1
+        if it > self.max_niter and nf > 0:                          # bfs.hpp:48-66: never assigned
+            self.label[self.label == float(self.max_niter + 1)] = 0.0
+        e, r = self.engine.tally(self.label)
+        t = torch.tensor([e, r], dtype=torch.int64, device=self.dev)
+        self.comm.sum_(t)
+        return dict(levels=levels, edges_traversed=int(t[0].item()), reached=int(t[1].item()), trace=trace)
+
+    def gather_labels(self):
+        """Full label vector on every rank (tests / verification only)."""
+        if self.world == 1:
+            return self.label[:self.n_local].clone()
+        sizes = [self.bounds[r + 1] - self.bounds[r] for r in range(self.world)]
+        m = max(sizes)
+        pad = torch.zeros(m, dtype=torch.float32, device=self.dev)
+        pad[:self.n_local] = self.label[:self.n_local]
+        out = self.comm.all_gather_padded(pad)
+        return torch.cat([out[r, :sizes[r]] for r in range(self.world)])

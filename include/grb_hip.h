@@ -224,6 +224,25 @@ grb_info grb_bfs_fused(grb_vector v, grb_matrix A, grb_index source, grb_descrip
                        grb_bfs_result* result, grb_bfs_level* levels_out, int max_levels,
                        int profile);
 
+/* ---- 1-D vertex-partitioned BFS level steps (one process per GPU).
+ * The reference has no multi-GPU code (backend/cuda/descriptor.hpp:242,283-284 parse
+ * --ndevice and ignore it); these follow the single-GPU level loop.  The rank owns
+ * vertices [lo, lo + nrows(A)), lo % 64 == 0; A_out / A_in are nrows x n_global matrices
+ * whose CSR rows are the owned vertices' out- / in-neighbour lists (global ids).  Bitmaps
+ * are 2*ceil(n_global/64) 32-bit words on the device.  The "new bits" bitmaps of all ranks
+ * are OR-combined by the caller (RCCL) between push/pull and apply. */
+grb_info grb_bfs_part_pull(grb_matrix A_in, grb_index lo, grb_index n_global, const uint32_t* d_vis,
+                           uint32_t* d_new /* caller-zeroed; owned word range written */,
+                           float* d_label_local, float new_label);
+grb_info grb_bfs_part_push(grb_matrix A_out, grb_index lo, grb_index n_global, const uint32_t* d_frontier,
+                           const uint32_t* d_vis, uint32_t* d_work /* scratch bitmap */,
+                           uint32_t* d_new /* fully written */, int64_t* expanded_edges_out /* nullable */);
+grb_info grb_bfs_part_apply(const uint32_t* d_new_global, uint32_t* d_vis, grb_index lo, grb_index n_local,
+                            grb_index n_global, float* d_label_local, float new_label,
+                            int32_t* discovered_out);
+grb_info grb_bfs_part_tally(grb_matrix A_out, const float* d_label_local, int64_t* edges_out,
+                            int32_t* reached_out);
+
 typedef struct {
   int    iterations;          /* loop iterations executed                              */
   float  tight_ms;            /* HIP-event time of the loop                            */

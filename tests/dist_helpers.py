@@ -1,0 +1,123 @@
+"""Test-only pieces for the partitioned BFS: a numpy level engine (so the N > 1
+orchestration of graphblast_amd/dist.py runs under gloo on CPU) and an in-process
+thread communicator (so two simulated ranks can drive the real HIP engine on one GPU)."""
+import threading
+
+import numpy as np
+import torch
+
+
+def _bits(t):
+    return t.numpy().view(np.uint32)
+
+
+class NumpyEngine:
+    def __init__(self, n, lo, lptr, lind, dev):
+        self.n, self.lo = n, lo
+        self.ptr = lptr.cpu().numpy().astype(np.int64)
+        self.ind = lind.cpu().numpy().astype(np.int64)
+        self.n_local = self.ptr.size - 1
+        self.rows = np.repeat(np.arange(self.n_local), np.diff(self.ptr))
+
+    @staticmethod
+    def _test(bm, idx):
+        return ((bm[idx >> 5] >> (idx & 31).astype(np.uint32)) & 1).astype(bool)
+
+    @staticmethod
+    def _set(bm, idx):
+        np.bitwise_or.at(bm, idx >> 5, (np.uint32(1) << (idx & 31).astype(np.uint32)))
+
+    def pull(self, vis, new_local, label_local, new_label):
+        v, nl = _bits(vis), _bits(new_local)
+        own = np.arange(self.n_local) + self.lo
+        unvisited = ~self._test(v, own)
+        hit_edge = self._test(v, self.ind[:self.ptr[-1]])
+        any_hit = np.zeros(self.n_local, dtype=bool)
+        np.logical_or.at(any_hit, self.rows, hit_edge)
+        found = np.nonzero(unvisited & any_hit)[0]
+        self._set(nl, found + self.lo)
+        label_local.numpy()[found] = new_label
+
+    def push(self, frontier, vis, new_local):
+        f, v, nl = _bits(frontier), _bits(vis), _bits(new_local)
+        nl[:] = 0
+        own = np.arange(self.n_local) + self.lo
+        fr = np.nonzero(self._test(f, own))[0]
+        if fr.size == 0:
+            return
+        sel = np.isin(self.rows, fr)
+        dst = np.unique(self.ind[:self.ptr[-1]][sel])
+        dst = dst[~self._test(v, dst)]
+        self._set(nl, dst)
+
+    def apply(self, new_global, vis, label_local, new_label):
+        ng, v = _bits(new_global), _bits(vis)
+        fresh = ng & ~v
+        v |= fresh
+        own = np.arange(self.n_local) + self.lo
+        mine = np.nonzero(self._test(fresh, own))[0]
+        label_local.numpy()[mine] = new_label
+        return int(sum(bin(int(x)).count("1") for x in fresh[fresh != 0]))
+
+    def tally(self, label_local):
+        lab = label_local.numpy()[:self.n_local]
+        deg = np.diff(self.ptr)
+        return int(deg[lab != 0].sum()), int(np.count_nonzero(lab))
+
+
+class ThreadComm:
+    """Lock-step communicator for `world` partitions living in threads of one process."""
+
+    class Shared:
+        def __init__(self, world):
+            self.world = world
+            self.barrier = threading.Barrier(world)
+            self.slots = [None] * world
+            self.lock = threading.Lock()          # serialises calls into the C library
+
+    def __init__(self, shared, rank):
+        self.s, self.rank, self.world = shared, rank, shared.world
+
+    def or_combine(self, new_local, new_global):
+        self.s.slots[self.rank] = new_local
+        self.s.barrier.wait()
+        acc = self.s.slots[0].clone()
+        for r in range(1, self.world):
+            acc |= self.s.slots[r]
+        new_global.copy_(acc)
+        self.s.barrier.wait()
+
+    def sum_(self, t):
+        self.s.slots[self.rank] = t.clone()
+        self.s.barrier.wait()
+        tot = sum(self.s.slots[r] for r in range(self.world))
+        self.s.barrier.wait()
+        t.copy_(tot)
+        return t
+
+    def all_gather_padded(self, pad):
+        self.s.slots[self.rank] = pad.clone()
+        self.s.barrier.wait()
+        out = torch.stack([self.s.slots[r] for r in range(self.world)])
+        self.s.barrier.wait()
+        return out
+
+
+def locked_engine(engine_cls, lock):
+    """Wrap an engine class so every level step holds `lock` (the C library's scratch
+    context is per process, not per thread)."""
+    class Locked(engine_cls):
+        def pull(self, *a):
+            with lock:
+                super().pull(*a); torch.cuda.synchronize()
+        def push(self, *a):
+            with lock:
+                super().push(*a); torch.cuda.synchronize()
+        def apply(self, *a):
+            with lock:
+                r = super().apply(*a); torch.cuda.synchronize()
+                return r
+        def tally(self, *a):
+            with lock:
+                return super().tally(*a)
+    return Locked

@@ -1,0 +1,125 @@
+"""N > 1 path: graphblast_amd/dist.py under torch.distributed with the gloo backend,
+world_size 2 and 3, on CPU (numpy level engine), plus -- on the GPU box -- two simulated
+ranks driving the real HIP level steps in one process."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+
+def _graph(seed=1, scale=11, sym=True):
+    from graphblast_amd.graphgen import rmat_edges, finalize_edges
+    s, d, n = rmat_edges(scale, 8, seed=seed)
+    return finalize_edges(s, d, n, symmetrize=sym)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import sys
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        from dist_helpers import NumpyEngine
+        from graphblast_amd.dist import Partition1D
+        gr = _graph()
+        ptr, ind = gr["csr"]
+        tptr, tind = torch.from_numpy(ptr.astype(np.int64)), torch.from_numpy(ind.astype(np.int64))
+        out = []
+        for mode in (10, 11, 12):
+            part = Partition1D(gr["n"], tptr, tind, rank, world, torch.device("cpu"), engine_cls=NumpyEngine,
+                               mxvmode=mode, switchpoint=0.05)
+            for src in (int(np.argmax(np.diff(ptr))), 7):
+                res = part.bfs(src)
+                labels = part.gather_labels().numpy()
+                out.append((mode, src, res["levels"], res["edges_traversed"], res["reached"],
+                            [t[0] for t in res["trace"]], labels.copy()))
+        if rank == 0:
+            q.put(out)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_partitioned_bfs_gloo(world):
+    from oracle import simple_reference as sr
+    gr = _graph()
+    ptr, ind = gr["csr"]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    deg = np.diff(ptr)
+    for mode, src, levels, edges, reached, dirs, labels in out:
+        want = sr.bfs(ptr, ind, src)[0]
+        assert np.array_equal(labels, want), (mode, src)
+        assert edges == int(deg[want != 0].sum()) and reached == int(np.count_nonzero(want))
+        _, stats = sr.bfs_do_stats(ptr, ind, ptr, ind, src, mxvmode=mode, switchpoint=0.05)
+        assert dirs == ["pull" if s[0] else "push" for s in stats], (mode, src)
+        assert levels == len(stats)
+
+
+def test_partition_bounds():
+    from graphblast_amd.dist import partition_bounds
+    gr = _graph(scale=12)
+    ptr = gr["csr"][0]
+    for world in (1, 2, 4, 8):
+        b = partition_bounds(ptr, world)
+        assert b[0] == 0 and b[-1] == gr["n"] and len(b) == world + 1
+        assert all(x % 64 == 0 for x in b[:-1]) and all(b[i] <= b[i + 1] for i in range(world))
+        if world > 1:
+            share = np.diff(ptr[np.array(b)])
+            assert share.max() <= 1.5 * gr["nnz"] / world + 64 * np.diff(ptr).max()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [1, 2, 4])
+def test_partitioned_bfs_hip_engine_simulated_ranks(world):
+    """The real HIP level steps (grb_bfs_part_*) under `world` simulated ranks sharing one
+    GPU: labels bit-exact vs the oracle, direction trace == single-GPU fused loop."""
+    import threading
+    from dist_helpers import ThreadComm, locked_engine
+    from graphblast_amd.dist import Partition1D, HipEngine
+    import graphblast_amd as g
+    from oracle import simple_reference as sr
+    gr = _graph(seed=3, scale=15)
+    ptr, ind = gr["csr"]
+    n = gr["n"]
+    dev = torch.device("cuda", 0)
+    tptr, tind = torch.from_numpy(ptr.astype(np.int64)).to(dev), torch.from_numpy(ind.astype(np.int64)).to(dev)
+    shared = ThreadComm.Shared(world)
+    Eng = locked_engine(HipEngine, shared.lock)
+    with shared.lock:
+        parts = [Partition1D(n, tptr, tind, r, world, dev, engine_cls=Eng, comm=ThreadComm(shared, r),
+                             switchpoint=0.02) for r in range(world)]
+    for src in (int(np.argmax(np.diff(ptr))), 11, 4097):
+        results, labels = [None] * world, [None] * world
+        def run(r):
+            results[r] = parts[r].bfs(src)
+            labels[r] = parts[r].gather_labels().cpu().numpy()
+        ts = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+        [t.start() for t in ts]
+        [t.join(timeout=300) for t in ts]
+        want = sr.bfs(ptr, ind, src)[0]
+        for r in range(world):
+            assert results[r] is not None, "rank %d did not finish" % r
+            assert np.array_equal(labels[r], want), (src, r)
+            assert results[r]["edges_traversed"] == int(np.diff(ptr)[want != 0].sum())
+        _, stats = sr.bfs_do_stats(ptr, ind, ptr, ind, src, mxvmode=10, switchpoint=0.02)
+        assert [t[0] for t in results[0]["trace"]] == ["pull" if s[0] else "push" for s in stats]
