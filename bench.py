@@ -60,6 +60,9 @@ def main():
     ap.add_argument("--scale", type=int, default=22)
     ap.add_argument("--edge-factor", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--edgeswitch", type=float, default=0.02,
+                    help="graphblast_amd extension: also leave push when frontier out-edges > edgeswitch*nnz "
+                         "(0 = the reference's vertex-count rule only)")
     ap.add_argument("--partitioned", action="store_true",
                     help="use the 1-D partitioned level loop even at N = 1 (debugging the N > 1 path)")
     args = ap.parse_args()
@@ -108,7 +111,7 @@ def main():
                                   tind.data_ptr(), tval.data_ptr(), keep=(tptr, tind, tval))
         assert info == 0, info
         desc = g.Descriptor()
-        assert desc.loadArgs(mxvmode=0, struconly=1, opreuse=1, earlyexit=1) == 0
+        assert desc.loadArgs(mxvmode=0, struconly=1, opreuse=1, earlyexit=1, edgeswitch=args.edgeswitch) == 0
         v = g.Vector(n)
 
         def run_step(i, profile=1):
@@ -221,7 +224,7 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload, "n": n, "nnz": nnz, "edge_convention": "directed stored edges",
-                       "flags": "mxvmode=0 struconly=1 opreuse=1 earlyexit=1 switchpoint=0.01",
+                       "flags": "mxvmode=0 struconly=1 opreuse=1 earlyexit=1 switchpoint=0.01 edgeswitch=%g" % args.edgeswitch,
                        "sources": len(sources), "parallelism": parallelism},
             "roofline": roofline,
         }

@@ -134,7 +134,8 @@ extern "C" grb_info grb_bfs_fused(grb_vector v, grb_matrix A, grb_index source, 
     } else {
       f1_dense = (mode == GRB_PULLONLY);
     }
-    GRB_HIP_TRY(hipMemsetAsync(d_state, 0, 4 * sizeof(int), s));
+    if (count_inspected) GRB_HIP_TRY(hipMemsetAsync(d_state + 2, 0, 2 * sizeof(int), s));
+    int mf = -1;
     if (!f1_dense) {
       if (!have_queue) {
         // the frontier is what the previous level discovered: list (vis & ~vis_alt), ordered,
@@ -142,12 +143,25 @@ extern "C" grb_info grb_bfs_fused(grb_vector v, grb_matrix A, grb_index source, 
         hipLaunchKernelGGL(bitmap_list_kernel, dim3(btiles), dim3(kBlock), 0, s, vis, vis_alt, nwords, btile_off,
                            queue);
         GRB_HIP_TRY(hipGetLastError());
+        have_queue = true;
       }
       GRB_TRY(mark());
+      GRB_TRY(lb_prepare(s, A->csr, queue, nf, local_scan, row_start, tile_sums, tile_off, d_state + 1));
+      if (mode == GRB_PUSHPULL && desc->edgeswitch > 0.f && nf >= 32) {
+        // extension: the reference switches on the frontier's VERTEX count only, so a 1 % frontier
+        // that contains the hubs is expanded edge by edge; leave push when its out-edges exceed
+        // edgeswitch * nnz (costs one extra mailbox read on such levels)
+        GRB_TRY(fetch_ints(d_state + 1, 1, &mf));
+        if ((double)mf > (double)desc->edgeswitch * (double)max_edges) {
+          f1_dense = true;
+          if (profile) --used;          // the prepare work is not part of the pull kernel's time
+        }
+      }
+    }
+    if (!f1_dense) {
       GRB_HIP_TRY(hipMemcpyAsync(vis_alt, vis, 4 * (size_t)nwords, hipMemcpyDeviceToDevice, s));
       BfsPushVisitor vis_fn{vis, label, (float)(iter + 1)};
-      GRB_TRY(launch_lb_expand(s, A->csr, queue, nf, max_edges, local_scan, row_start, tile_sums, tile_off,
-                               chunk_owner, d_state + 1, vis_fn));
+      GRB_TRY(lb_run(s, A->csr, nf, max_edges, local_scan, row_start, tile_off, chunk_owner, vis_fn));
       GRB_TRY(mark());
       desc->lastmxv = GRB_PUSHONLY;
     } else {
@@ -174,6 +188,7 @@ extern "C" grb_info grb_bfs_fused(grb_vector v, grb_matrix A, grb_index source, 
     int h[4] = {0, 0, 0, 0};
     GRB_TRY(fetch_ints(d_state, 4, h));
     have_queue = false;
+    if (f1_dense && !count_inspected) { h[2] = h[3] = 0; }
     if (levels_out && levels < max_levels) {
       grb_bfs_level& L = levels_out[levels];
       L.direction = f1_dense ? 1 : 0;

@@ -275,7 +275,9 @@ struct Context {
   static constexpr int kSlots = 12;
   void* slot[kSlots] = {nullptr};
   size_t slot_cap[kSlots] = {0};
-  int* h_mail = nullptr;            // pinned host, 64 ints
+  int* h_mail = nullptr;            // pinned, host-coherent, 64 ints; [63] = published sequence number
+  int* d_hmail = nullptr;           // device-side address of h_mail
+  int mail_seq = 0;
   int* d_mail = nullptr;            // device, 64 ints
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool inited = false;
@@ -328,6 +330,9 @@ struct grb_descriptor_s {
   float switchpoint = 0.f, memusage = 0.f;
   int dirinfo = 0, struconly = 0, opreuse = 0, endbit = 0, sort = 0, atomic = 0;
   int earlyexit = 0, fusedmask = 0;
+  // extension (0 = off = the reference's rule only): fused BFS also leaves push for pull when the
+  // frontier's out-edges exceed edgeswitch * nnz
+  float edgeswitch = 0.f;
   int lastmxv = GRB_PUSHONLY;
 };
 

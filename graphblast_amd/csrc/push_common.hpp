@@ -214,19 +214,24 @@ static __global__ __launch_bounds__(kBlock) void lb_expand_kernel(
   }
 }
 
-// Launch helper: degree + scan + partition + expand on `s`. Scratch: local_scan[nf],
-// row_start[nf], tile_sums/tile_off[2*ntiles+2], chunk_owner[max_chunks+2].
-// *d_total receives the number of expanded edges.
-template <typename V>
-static inline grb_info launch_lb_expand(hipStream_t s, const CsrArrays& M, const Index* u_ind, Index nf,
-                                        long long max_edges, int* local_scan, Index* row_start, int* tile_sums,
-                                        int* tile_off, Index* chunk_owner, int* d_total, V visitor) {
+// Launch helpers. lb_prepare: degree + scan (frontier out-edge total -> *d_total).
+// lb_run: partition + expand. Scratch: local_scan[nf], row_start[nf],
+// tile_sums/tile_off[2*ntiles+2], chunk_owner[max_chunks+2].
+static inline grb_info lb_prepare(hipStream_t s, const CsrArrays& M, const Index* u_ind, Index nf, int* local_scan,
+                                  Index* row_start, int* tile_sums, int* tile_off, int* d_total) {
   const int ntiles = ceil_div(nf, kDegTile);
   hipLaunchKernelGGL(push_degree_kernel, dim3(ntiles), dim3(kBlock), 0, s, M.ptr, u_ind, nf, local_scan, row_start,
                      tile_sums);
   GRB_HIP_TRY(hipGetLastError());
   hipLaunchKernelGGL(push_scan_tiles_kernel, dim3(1), dim3(kBlock), 0, s, tile_sums, ntiles, tile_off, d_total);
   GRB_HIP_TRY(hipGetLastError());
+  return GRB_SUCCESS;
+}
+
+template <typename V>
+static inline grb_info lb_run(hipStream_t s, const CsrArrays& M, Index nf, long long max_edges, int* local_scan,
+                              Index* row_start, int* tile_off, Index* chunk_owner, V visitor) {
+  const int ntiles = ceil_div(nf, kDegTile);
   const long long max_chunks = (max_edges + kEdgeChunk - 1) / kEdgeChunk + 1;
   int pgrid = (int)((max_chunks + kBlock - 1) / kBlock);
   if (pgrid < 1) pgrid = 1;
@@ -240,6 +245,14 @@ static inline grb_info launch_lb_expand(hipStream_t s, const CsrArrays& M, const
                      tile_off, ntiles, chunk_owner, visitor);
   GRB_HIP_TRY(hipGetLastError());
   return GRB_SUCCESS;
+}
+
+template <typename V>
+static inline grb_info launch_lb_expand(hipStream_t s, const CsrArrays& M, const Index* u_ind, Index nf,
+                                        long long max_edges, int* local_scan, Index* row_start, int* tile_sums,
+                                        int* tile_off, Index* chunk_owner, int* d_total, V visitor) {
+  GRB_TRY(lb_prepare(s, M, u_ind, nf, local_scan, row_start, tile_sums, tile_off, d_total));
+  return lb_run(s, M, nf, max_edges, local_scan, row_start, tile_off, chunk_owner, visitor);
 }
 
 // ---- ordered bitmap compaction: indices of the bits set in (a & ~b), one word per thread.

@@ -256,11 +256,12 @@ double oracle_tc(Index nrows, const Index* row_ptr, const Index* col_ind,
  * Pull inspects in-neighbours (csc) of every unvisited vertex in stored order and
  * stops at the first visited one (kernels/spmv.hpp:33-52, earlyexit).
  * stats row per level: [dir(0 push,1 pull), nf, mf, nu, mi, nf_next].
+ * edgeswitch > 0 adds graphblast_amd's optional edge-aware push->pull override.
  * Returns number of levels executed. ---- */
 int oracle_bfs_do_stats(Index n, const Index* csr_ptr, const Index* csr_ind,
                         const Index* csc_ptr, const Index* csc_ind, Index src,
                         int mxvmode, float switchpoint, int max_niter,
-                        float* depth, long long* stats, int max_levels) {
+                        float* depth, long long* stats, int max_levels, float edgeswitch) {
   for (Index i = 0; i < n; ++i) depth[i] = 0.f;
   Index* cur = (Index*)malloc(sizeof(Index) * (size_t)(n > 0 ? n : 1));
   Index* nxt = (Index*)malloc(sizeof(Index) * (size_t)(n > 0 ? n : 1));
@@ -281,6 +282,13 @@ int oracle_bfs_do_stats(Index n, const Index* csr_ptr, const Index* csr_ind,
       }
     } else if (mxvmode == 11) is_dense = 0;
     else is_dense = 1;
+    /* graphblast_amd extension (not in the reference; off when edgeswitch == 0): leave push
+     * when the frontier's out-edges exceed edgeswitch * nnz (csrc/bfs_fused.hip) */
+    if (mxvmode == 10 && !is_dense && edgeswitch > 0.f && nf >= 32) {
+      long long e = 0;
+      for (Index k = 0; k < nf; ++k) e += csr_ptr[cur[k] + 1] - csr_ptr[cur[k]];
+      if ((double)e > (double)edgeswitch * (double)csr_ptr[n]) is_dense = 1;
+    }
     long long mf = 0, nu = 0, mi = 0;
     Index nn = 0;
     if (!is_dense) {

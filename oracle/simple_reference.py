@@ -109,7 +109,7 @@ def tc(row_ptr, col_ind):
 
 
 def bfs_do_stats(csr_ptr, csr_ind, csc_ptr, csc_ind, src, mxvmode=10, switchpoint=0.01,
-                 max_niter=10000, max_levels=100000):
+                 max_niter=10000, max_levels=100000, edgeswitch=0.0):
     a, b, c, d = _i32(csr_ptr), _i32(csr_ind), _i32(csc_ptr), _i32(csc_ind)
     n = a.size - 1
     depth = np.zeros(n, dtype=np.float32)
@@ -118,5 +118,5 @@ def bfs_do_stats(csr_ptr, csr_ind, csc_ptr, csc_ind, src, mxvmode=10, switchpoin
                                    _p(d, ctypes.c_int), int(src), int(mxvmode),
                                    ctypes.c_float(switchpoint), int(max_niter),
                                    _p(depth, ctypes.c_float), _p(stats, ctypes.c_longlong),
-                                   int(max_levels))
+                                   int(max_levels), ctypes.c_float(edgeswitch))
     return depth, stats[:min(lv, max_levels)].copy()

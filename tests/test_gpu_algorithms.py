@@ -109,6 +109,29 @@ def test_bfs_random_graphs(hb, graphs):
                     assert r2["edges_traversed"] == int(np.diff(ptr)[want != 0].sum())
 
 
+def test_bfs_edge_aware_switch(hb, graphs):
+    """Optional extension (descriptor arg `edgeswitch`, off by default): same labels, and the
+    direction trace equals the accounting oracle run with the same rule."""
+    from oracle import simple_reference as sr
+    g = hb.g
+    for name, gr in graphs:
+        ptr, ind = gr["csr"]
+        cptr, cind = gr["csc"]
+        A = build(hb, gr)
+        for s in [first_source(gr)] + g.graphgen.random_sources(ptr, 2, seed=5):
+            want = sr.bfs(ptr, ind, s)[0]
+            for es in (0.001, 0.02, 0.3):
+                d = hb.descriptor(mxvmode=0, struconly=1, opreuse=1, edgeswitch=es)
+                v = g.Vector(gr["n"])
+                info, res = g.bfs(v, A, s, d, fused=True, profile=3)
+                assert info == 0
+                assert np.array_equal(hb.dense_values(v), want), (name, s, es)
+                _, stats = sr.bfs_do_stats(ptr, ind, cptr, cind, s, mxvmode=10, switchpoint=0.01, edgeswitch=es)
+                assert [L["direction"] == "pull" for L in res["per_level"]] == [bool(x[0]) for x in stats], (name, s, es)
+                for L, st in zip(res["per_level"], stats):
+                    assert L["frontier"] == st[1] and L["discovered"] == st[5]
+
+
 def test_bfs_max_niter_cap(hb, graphs):
     """A frontier discovered by the last allowed iteration is never labelled (bfs.hpp:48-66)."""
     g = hb.g
