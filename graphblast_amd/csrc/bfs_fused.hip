@@ -32,11 +32,15 @@
 
 namespace grb {
 
-__global__ void bfs_seed_kernel(unsigned int* visited, float* label, Index* queue, Index source) {
+__global__ void bfs_seed_kernel(unsigned int* visited, float* label, Index* queue, Index source,
+                                const Index* __restrict__ out_ptr, unsigned long long* edges_acc,
+                                unsigned int* ticket) {
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     visited[source >> 5] |= 1u << (source & 31);
     label[source] = 1.f;
     queue[0] = source;
+    *edges_acc = (unsigned long long)(out_ptr[source + 1] - out_ptr[source]);
+    *ticket = 0u;
   }
 }
 
@@ -50,6 +54,26 @@ __global__ void bfs_unlabel_kernel(float* __restrict__ label, Index n, float bad
 }  // namespace grb
 
 using namespace grb;
+
+// TEPS numerator recomputed from the labels (only needed when max_niter cut the search)
+static grb_info bfs_tally_labels(const float* label, const Index* ptr, Index n, int64_t* edges, int32_t* reached) {
+  Context& c = ctx();
+  hipStream_t s = c.stream;
+  void* p_tally;
+  GRB_TRY(scratch(10, 64 * sizeof(unsigned long long), &p_tally));
+  GRB_HIP_TRY(hipMemsetAsync(p_tally, 0, 64 * sizeof(unsigned long long), s));
+  hipLaunchKernelGGL(bfs_tally_kernel, dim3(stream_grid(n, kBlock * 8)), dim3(kBlock), 0, s, label, ptr, n,
+                     (unsigned long long*)p_tally);
+  GRB_HIP_TRY(hipGetLastError());
+  unsigned long long h_tally[64];
+  GRB_HIP_TRY(hipMemcpyAsync(h_tally, p_tally, sizeof(h_tally), hipMemcpyDeviceToHost, s));
+  GRB_HIP_TRY(hipStreamSynchronize(s));
+  unsigned long long e = 0, r = 0;
+  for (int i = 0; i < 32; ++i) { e += h_tally[2 * i]; r += h_tally[2 * i + 1]; }
+  *edges = (int64_t)e;
+  *reached = (int32_t)r;
+  return GRB_SUCCESS;
+}
 
 extern "C" grb_info grb_bfs_fused(grb_vector v, grb_matrix A, grb_index source, grb_descriptor desc,
                                   grb_bfs_result* result, grb_bfs_level* levels_out, int max_levels, int profile) {
@@ -79,7 +103,7 @@ extern "C" grb_info grb_bfs_fused(grb_vector v, grb_matrix A, grb_index source, 
   GRB_TRY(scratch(11, 4 * (size_t)n + 4, &p_rs));
   const int max_tiles = ceil_div(n, kDegTile);
   GRB_TRY(scratch(3, 4 * (size_t)(2 * max_tiles + 2), &p_tiles));
-  GRB_TRY(scratch(6, 4 * (size_t)(2 * btiles + 4 + max_chunks + 2), &p_bt));
+  GRB_TRY(scratch(6, 4 * (size_t)(2 * btiles + 4 + max_chunks + 2) + 8 * (size_t)(btiles + 2), &p_bt));
   unsigned int* vis = (unsigned int*)p_va;            // current visited set
   unsigned int* vis_alt = (unsigned int*)p_vb;        // the set before the last level
   Index* queue = (Index*)p_q;
@@ -90,13 +114,19 @@ extern "C" grb_info grb_bfs_fused(grb_vector v, grb_matrix A, grb_index source, 
   int* btile_counts = (int*)p_bt;
   int* btile_off = btile_counts + btiles;             // btiles + 1 entries
   Index* chunk_owner = (Index*)(btile_off + btiles + 2);
-  int* d_state = c.d_mail + 8;    // [0] discovered (diff count), [1] expanded edges, [2..3] inspected (u64)
+  unsigned long long* btile_deg =
+      (unsigned long long*)(((uintptr_t)(chunk_owner + max_chunks + 2) + 7) & ~(uintptr_t)7);
+  int* d_state = c.d_mail + 8;    // [1] expanded edges, [2..3] inspected (u64)
+  unsigned long long* d_edges_acc = reinterpret_cast<unsigned long long*>(c.d_mail + 40);
+  unsigned int* d_ticket = reinterpret_cast<unsigned int*>(c.d_mail + 44);
 
   GRB_TRY(grb_vector_set_storage(v, GRB_DENSE));
   float* label = (float*)v->d_val;
   GRB_TRY(k_fill(GRB_F32, label, 0.0, n));
   GRB_HIP_TRY(hipMemsetAsync(vis, 0, 4 * (size_t)nwords, s));
-  hipLaunchKernelGGL(bfs_seed_kernel, dim3(1), dim3(64), 0, s, vis, label, queue, source);
+  GRB_HIP_TRY(hipMemsetAsync(d_state, 0, 4 * sizeof(int), s));
+  hipLaunchKernelGGL(bfs_seed_kernel, dim3(1), dim3(64), 0, s, vis, label, queue, source, A->csr.ptr, d_edges_acc,
+                     d_ticket);
   GRB_HIP_TRY(hipGetLastError());
 
   // profile bit 0: HIP events around every level's expansion kernels (cheap, reusable pool)
@@ -121,6 +151,8 @@ extern "C" grb_info grb_bfs_fused(grb_vector v, grb_matrix A, grb_index source, 
   bool have_queue = true;          // queue holds the current frontier (level 1: the source)
   Index nf = 1;
   int iter = 1, levels = 0;
+  uint64_t edges_cum = 0;
+  int64_t reached = 1;
   GRB_HIP_TRY(hipEventRecord(c.ev0, s));
   for (; iter <= desc->max_niter; ++iter) {
     // ---- vxm's direction decision on u = f1 (operations.hpp:131-140, vector.hpp:291-323)
@@ -140,6 +172,9 @@ extern "C" grb_info grb_bfs_fused(grb_vector v, grb_matrix A, grb_index source, 
       if (!have_queue) {
         // the frontier is what the previous level discovered: list (vis & ~vis_alt), ordered,
         // with the tile offsets the count + scan of that level already produced
+        hipLaunchKernelGGL(push_scan_tiles_kernel, dim3(1), dim3(kBlock), 0, s, btile_counts, btiles, btile_off,
+                           d_state);
+        GRB_HIP_TRY(hipGetLastError());
         hipLaunchKernelGGL(bitmap_list_kernel, dim3(btiles), dim3(kBlock), 0, s, vis, vis_alt, nwords, btile_off,
                            queue);
         GRB_HIP_TRY(hipGetLastError());
@@ -180,15 +215,18 @@ extern "C" grb_info grb_bfs_fused(grb_vector v, grb_matrix A, grb_index source, 
       std::swap(vis, vis_alt);       // vis = new set, vis_alt = set before this level
       desc->lastmxv = GRB_PULLONLY;
     }
-    // discovered = |vis & ~vis_alt| ; the tile offsets are kept for a possible queue listing
-    hipLaunchKernelGGL(bitmap_count_kernel, dim3(btiles), dim3(kBlock), 0, s, vis, vis_alt, nwords, btile_counts);
+    // close the level: discovered = |vis & ~vis_alt|, published by the kernel itself
+    const int seq = ++c.mail_seq;
+    hipLaunchKernelGGL(bfs_level_tail_kernel, dim3(btiles), dim3(kBlock), 0, s, vis, vis_alt, nwords, A->csr.ptr, n,
+                       btile_counts, btile_deg, d_ticket, d_state, d_edges_acc, c.d_hgran, seq);
     GRB_HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(push_scan_tiles_kernel, dim3(1), dim3(kBlock), 0, s, btile_counts, btiles, btile_off, d_state);
-    GRB_HIP_TRY(hipGetLastError());
-    int h[4] = {0, 0, 0, 0};
-    GRB_TRY(fetch_ints(d_state, 4, h));
+    unsigned int gv[6];
+    GRB_TRY(wait_granules(seq, count_inspected ? 6 : 4, gv));
+    int h[4] = {(int)gv[0], (int)gv[1], count_inspected ? (int)gv[4] : 0, count_inspected ? (int)gv[5] : 0};
+    edges_cum = ((uint64_t)gv[3] << 32) | gv[2];
+    reached += h[0];
     have_queue = false;
-    if (f1_dense && !count_inspected) { h[2] = h[3] = 0; }
+    if (!(f1_dense && count_inspected)) { h[2] = h[3] = 0; }
     if (levels_out && levels < max_levels) {
       grb_bfs_level& L = levels_out[levels];
       L.direction = f1_dense ? 1 : 0;
@@ -211,19 +249,14 @@ extern "C" grb_info grb_bfs_fused(grb_vector v, grb_matrix A, grb_index source, 
                        (float)(desc->max_niter + 1));
     GRB_HIP_TRY(hipGetLastError());
   }
-  // tally (outside the timed loop): 32 x {edges, reached} partial slots
-  void* p_tally;
-  GRB_TRY(scratch(10, 64 * sizeof(unsigned long long), &p_tally));
-  unsigned long long* d_tally = (unsigned long long*)p_tally;
-  GRB_HIP_TRY(hipMemsetAsync(d_tally, 0, 64 * sizeof(unsigned long long), s));
-  hipLaunchKernelGGL(bfs_tally_kernel, dim3(stream_grid(n, kBlock * 8)), dim3(kBlock), 0, s, label, A->csr.ptr, n,
-                     d_tally);
-  GRB_HIP_TRY(hipGetLastError());
-  unsigned long long h_tally[64];
-  GRB_HIP_TRY(hipMemcpyAsync(h_tally, d_tally, sizeof(h_tally), hipMemcpyDeviceToHost, s));
-  GRB_HIP_TRY(hipStreamSynchronize(s));
-  unsigned long long tot_e = 0, tot_r = 0;
-  for (int i = 0; i < 32; ++i) { tot_e += h_tally[2 * i]; tot_r += h_tally[2 * i + 1]; }
+  GRB_HIP_TRY(hipEventSynchronize(c.ev1));
+  unsigned long long tot_e = edges_cum, tot_r = (unsigned long long)reached;
+  if (hit_cap && nf > 0) {
+    // the unlabelled last frontier is not "reached": recount from the labels
+    int64_t e2 = 0; int32_t r2 = 0;
+    GRB_TRY(bfs_tally_labels(label, A->csr.ptr, n, &e2, &r2));
+    tot_e = (unsigned long long)e2; tot_r = (unsigned long long)r2;
+  }
   float ms = 0.f;
   GRB_HIP_TRY(hipEventElapsedTime(&ms, c.ev0, c.ev1));
   if (result) {

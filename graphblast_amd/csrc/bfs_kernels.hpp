@@ -135,6 +135,77 @@ static __global__ void bfs_tally_kernel(const float* __restrict__ label, const I
   }
 }
 
+// One launch closes a BFS level: discovered = |now & ~before| and the out-degree sum of those
+// vertices, per-tile counts kept for a later ordered queue listing, and -- by the last
+// workgroup to finish -- the level's record written straight into the pinned host mailbox.
+// Inter-workgroup hand-off without fences (CDNA guide, G16 "R1/R2"): partials are agent-scope
+// write-through stores, drained with s_waitcnt before the ticket; the last workgroup reads
+// them with agent-scope (L1-bypassing) loads; the host record is four 8-byte granules
+// {value, seq} -- the data is the flag, so no ordering between them is needed.
+//   granule 0 discovered   1 expanded edges (push)   2 / 3 cumulative out-degree of everything
+//   discovered so far (lo / hi)   4 / 5 inspected edges (profile runs) lo / hi
+static __global__ __launch_bounds__(kBlock) void bfs_level_tail_kernel(
+    const unsigned int* __restrict__ now, const unsigned int* __restrict__ before, int nwords,
+    const Index* __restrict__ out_ptr, Index n, int* tile_counts, unsigned long long* tile_deg,
+    unsigned int* ticket, const int* __restrict__ d_state, unsigned long long* edges_acc,
+    unsigned long long* mail, int seq) {
+  __shared__ int s_cnt[kWavesPerBlock];
+  __shared__ unsigned long long s_deg[kWavesPerBlock];
+  __shared__ int s_last;
+  const int tid = threadIdx.x;
+  const int i = blockIdx.x * kBlock + tid;
+  unsigned int d = (i < nwords) ? (now[i] & ~before[i]) : 0u;
+  int c = __popc(d);
+  unsigned long long deg = 0;
+  while (d) {
+    const int b = __ffs((int)d) - 1;
+    d &= d - 1;
+    const Index v = (Index)i * 32 + b;
+    if (v < n) deg += (unsigned long long)(out_ptr[v + 1] - out_ptr[v]);
+  }
+  c = wave_reduce(c, [](int a, int b) { return a + b; });
+  deg = wave_reduce(deg, [](unsigned long long a, unsigned long long b) { return a + b; });
+  if (lane_id() == 0) { s_cnt[wave_id()] = c; s_deg[wave_id()] = deg; }
+  __syncthreads();
+  if (tid == 0) {
+    int tc = 0;
+    unsigned long long td = 0;
+    for (int w = 0; w < kWavesPerBlock; ++w) { tc += s_cnt[w]; td += s_deg[w]; }
+    __hip_atomic_store(&tile_counts[blockIdx.x], tc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&tile_deg[blockIdx.x], td, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned int t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = (t == gridDim.x - 1) ? 1 : 0;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  int tc = 0;
+  unsigned long long td = 0;
+  for (int j = tid; j < (int)gridDim.x; j += kBlock) {
+    tc += __hip_atomic_load(&tile_counts[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    td += __hip_atomic_load(&tile_deg[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  tc = wave_reduce(tc, [](int a, int b) { return a + b; });
+  td = wave_reduce(td, [](unsigned long long a, unsigned long long b) { return a + b; });
+  __syncthreads();
+  if (lane_id() == 0) { s_cnt[wave_id()] = tc; s_deg[wave_id()] = td; }
+  __syncthreads();
+  if (tid == 0) {
+    int c2 = 0;
+    unsigned long long d2 = 0;
+    for (int w = 0; w < kWavesPerBlock; ++w) { c2 += s_cnt[w]; d2 += s_deg[w]; }
+    const unsigned long long acc = *edges_acc + d2;
+    *edges_acc = acc;
+    __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long tag = (unsigned long long)(unsigned int)seq << 32;
+    const unsigned int vals[6] = {(unsigned int)c2, (unsigned int)d_state[1], (unsigned int)(acc & 0xffffffffull),
+                                  (unsigned int)(acc >> 32), (unsigned int)d_state[2], (unsigned int)d_state[3]};
+#pragma unroll
+    for (int k = 0; k < 6; ++k)
+      __hip_atomic_store(&mail[k], tag | vals[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
 // Lazily built, cached per matrix: bitmap of rows of `M` without entries.
 static inline grb_info ensure_empty_rows(unsigned int** cache, const CsrArrays& M, hipStream_t s) {
   if (*cache) return GRB_SUCCESS;

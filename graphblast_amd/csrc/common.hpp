@@ -278,6 +278,8 @@ struct Context {
   int* h_mail = nullptr;            // pinned, host-coherent, 64 ints; [63] = published sequence number
   int* d_hmail = nullptr;           // device-side address of h_mail
   int mail_seq = 0;
+  unsigned long long* h_gran = nullptr;   // pinned, host-coherent: 8 x {value, seq} granules
+  unsigned long long* d_hgran = nullptr;  // device-side address of h_gran
   int* d_mail = nullptr;            // device, 64 ints
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool inited = false;
@@ -293,6 +295,10 @@ grb_info ctx_init();
 grb_info scratch(int i, size_t bytes, void** out);
 // Copy `count` ints from device to host through the pinned mailbox; synchronises.
 grb_info fetch_ints(const int* d_src, int count, int* h_dst);
+// Host side of an in-kernel mailbox publish: wait until h_mail[63] == seq.
+grb_info wait_mail(int seq);
+// Wait until granules [0, count) of the granule mailbox carry tag `seq`; values -> out.
+grb_info wait_granules(int seq, int count, unsigned int* out);
 
 // ----------------------------------------------------------------------------
 // Objects behind the handles

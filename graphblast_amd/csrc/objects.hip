@@ -36,6 +36,9 @@ grb_info ctx_init() {
   GRB_HIP_TRY(hipHostMalloc((void**)&c.h_mail, 64 * sizeof(int), hipHostMallocMapped | hipHostMallocCoherent));
   memset(c.h_mail, 0, 64 * sizeof(int));
   GRB_HIP_TRY(hipHostGetDevicePointer((void**)&c.d_hmail, c.h_mail, 0));
+  GRB_HIP_TRY(hipHostMalloc((void**)&c.h_gran, 8 * sizeof(unsigned long long), hipHostMallocMapped | hipHostMallocCoherent));
+  memset(c.h_gran, 0, 8 * sizeof(unsigned long long));
+  GRB_HIP_TRY(hipHostGetDevicePointer((void**)&c.d_hgran, c.h_gran, 0));
   GRB_HIP_TRY(hipMalloc((void**)&c.d_mail, 64 * sizeof(int)));
   GRB_HIP_TRY(hipMemset(c.d_mail, 0, 64 * sizeof(int)));
   GRB_HIP_TRY(hipEventCreate(&c.ev0));
@@ -81,18 +84,15 @@ __global__ void publish_kernel(const int* __restrict__ src, int count, int* __re
   if (threadIdx.x == 0) __hip_atomic_store(&mail[63], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-grb_info fetch_ints(const int* d_src, int count, int* h_dst) {
+// Spin until the mailbox shows sequence number `seq` (falls back to a blocking stream wait
+// after 5 ms: long-running predecessor, or a fault that the wait then reports).
+grb_info wait_mail(int seq) {
   Context& c = ctx();
-  if (count > 62) return GRB_INVALID_VALUE;
-  const int seq = ++c.mail_seq;
-  hipLaunchKernelGGL(publish_kernel, dim3(1), dim3(64), 0, c.stream, d_src, count, c.d_hmail, seq);
-  GRB_HIP_TRY(hipGetLastError());
   const auto t0 = std::chrono::steady_clock::now();
   unsigned spins = 0;
   while (__atomic_load_n(&c.h_mail[63], __ATOMIC_ACQUIRE) != seq) {
     if ((++spins & 1023u) == 0 &&
         std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(5)) {
-      // long-running predecessor (or a fault): fall back to a blocking wait
       GRB_HIP_TRY(hipStreamSynchronize(c.stream));
       if (__atomic_load_n(&c.h_mail[63], __ATOMIC_ACQUIRE) != seq) {
         fprintf(stderr, "libgrb_hip: mailbox not published after stream sync\n");
@@ -101,6 +101,40 @@ grb_info fetch_ints(const int* d_src, int count, int* h_dst) {
       break;
     }
   }
+  return GRB_SUCCESS;
+}
+
+grb_info wait_granules(int seq, int count, unsigned int* out) {
+  Context& c = ctx();
+  const auto t0 = std::chrono::steady_clock::now();
+  unsigned spins = 0;
+  bool synced = false;
+  for (;;) {
+    bool ok = true;
+    for (int k = 0; k < count; ++k) {
+      const unsigned long long g = __atomic_load_n(&c.h_gran[k], __ATOMIC_ACQUIRE);
+      if ((int)(g >> 32) != seq) { ok = false; break; }
+      out[k] = (unsigned int)(g & 0xffffffffull);
+    }
+    if (ok) return GRB_SUCCESS;
+    if (synced) {
+      fprintf(stderr, "libgrb_hip: level record not published after stream sync\n");
+      return GRB_PANIC;
+    }
+    if ((++spins & 1023u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(5)) {
+      GRB_HIP_TRY(hipStreamSynchronize(c.stream));
+      synced = true;
+    }
+  }
+}
+
+grb_info fetch_ints(const int* d_src, int count, int* h_dst) {
+  Context& c = ctx();
+  if (count > 62) return GRB_INVALID_VALUE;
+  const int seq = ++c.mail_seq;
+  hipLaunchKernelGGL(publish_kernel, dim3(1), dim3(64), 0, c.stream, d_src, count, c.d_hmail, seq);
+  GRB_HIP_TRY(hipGetLastError());
+  GRB_TRY(wait_mail(seq));
   memcpy(h_dst, c.h_mail, sizeof(int) * count);
   return GRB_SUCCESS;
 }

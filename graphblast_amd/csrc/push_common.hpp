@@ -32,7 +32,8 @@ constexpr int kSegMax = kEdgeChunk;                 // frontier entries staged p
 // ---- degrees + row starts + tile-local exclusive scan
 static __global__ void push_degree_kernel(const Index* __restrict__ ptr, const Index* __restrict__ u_ind, Index nf,
                                           int* __restrict__ local_scan, Index* __restrict__ row_start,
-                                          int* __restrict__ tile_sums) {
+                                          int* __restrict__ tile_sums, int* __restrict__ tile_off,
+                                          int* __restrict__ total_out) {
   __shared__ int smem[kWavesPerBlock];
   const Index base = (Index)blockIdx.x * kDegTile + threadIdx.x * kDegItems;
   int d[kDegItems];
@@ -57,7 +58,14 @@ static __global__ void push_degree_kernel(const Index* __restrict__ ptr, const I
     if (i < nf) local_scan[i] = off;
     off += d[k];
   }
-  if (threadIdx.x == 0) tile_sums[blockIdx.x] = tot;
+  if (threadIdx.x == 0) {
+    tile_sums[blockIdx.x] = tot;
+    if (gridDim.x == 1) {            // one tile: the scan of the tile sums is trivial, skip that launch
+      tile_off[0] = 0;
+      tile_off[1] = tot;
+      *total_out = tot;
+    }
+  }
 }
 
 // Exclusive scan of `ntiles` counts by ONE workgroup; offsets[ntiles] = total = *total_out.
@@ -221,10 +229,12 @@ static inline grb_info lb_prepare(hipStream_t s, const CsrArrays& M, const Index
                                   Index* row_start, int* tile_sums, int* tile_off, int* d_total) {
   const int ntiles = ceil_div(nf, kDegTile);
   hipLaunchKernelGGL(push_degree_kernel, dim3(ntiles), dim3(kBlock), 0, s, M.ptr, u_ind, nf, local_scan, row_start,
-                     tile_sums);
+                     tile_sums, tile_off, d_total);
   GRB_HIP_TRY(hipGetLastError());
-  hipLaunchKernelGGL(push_scan_tiles_kernel, dim3(1), dim3(kBlock), 0, s, tile_sums, ntiles, tile_off, d_total);
-  GRB_HIP_TRY(hipGetLastError());
+  if (ntiles > 1) {
+    hipLaunchKernelGGL(push_scan_tiles_kernel, dim3(1), dim3(kBlock), 0, s, tile_sums, ntiles, tile_off, d_total);
+    GRB_HIP_TRY(hipGetLastError());
+  }
   return GRB_SUCCESS;
 }
 

@@ -23,7 +23,10 @@
 
 namespace grb {
 
-constexpr int kTileNnz = 2048;      // nonzeros staged per workgroup (8 KiB of LDS)
+#ifndef GRB_SPMV_TILE
+#define GRB_SPMV_TILE 2048
+#endif
+constexpr int kTileNnz = GRB_SPMV_TILE;      // nonzeros staged per workgroup (4 B each in LDS)
 constexpr int kMaxRowsPerBlock = 1024;
 constexpr int kLongSlice = 8192;    // slice of a long row reduced by one workgroup
 
