@@ -102,6 +102,9 @@ _SIGS = {
     "grb_bfs_part_push": [_vp, _i, _i, _vp, _vp, _vp, _vp, C.POINTER(C.c_int64)],
     "grb_bfs_part_apply": [_vp, _vp, _i, _i, _i, _vp, _f, C.POINTER(C.c_int32)],
     "grb_bfs_part_tally": [_vp, _vp, C.POINTER(C.c_int64), C.POINTER(C.c_int32)],
+    "grb_assignScatter": [_vp, _vp, _i, _vp, _vp, _vp],
+    "grb_extractGather": [_vp, _vp, _i, _vp, _vp, _vp],
+    "grb_cc": [_vp, _vp, _i, _vp, C.POINTER(AlgoResult)],
     "grb_sssp": [_vp, _vp, _i, _vp, C.POINTER(AlgoResult)],
     "grb_pr": [_vp, _vp, _f, _f, _vp, C.POINTER(AlgoResult)],
     "grb_k_spmv": [_vp, _i, _i, _vp, _vp, _i, _i, _vp],

@@ -350,6 +350,14 @@ def assign(w, mask, accum, val, indices, nindices, desc):
     return _lib.load().grb_assign(_h(w), _h(mask), _accum(accum), float(val), _h(desc))
 
 
+def assignScatter(w, mask, accum, u, indices, desc):
+    return _lib.load().grb_assignScatter(_h(w), _h(mask), _accum(accum), _h(u), _h(indices), _h(desc))
+
+
+def extractGather(w, mask, accum, u, indices, desc):
+    return _lib.load().grb_extractGather(_h(w), _h(mask), _accum(accum), _h(u), _h(indices), _h(desc))
+
+
 # ---- graphblas/algorithm/*.hpp -----------------------------------------------------
 def bfs(v, A, s, desc, fused=False, profile=False, max_levels=4096):
     """algorithm::bfs. Returns (info, result dict). fused=True runs the device-resident loop."""
@@ -378,6 +386,12 @@ def pr(p, A, alpha, eps, desc):
     res = AlgoResult()
     info = _lib.load().grb_pr(_h(p), _h(A), float(alpha), float(eps), _h(desc), C.byref(res))
     return info, dict(iterations=res.iterations, tight_ms=res.tight_ms, error=res.last_value)
+
+
+def cc(v, A, seed, desc):
+    res = AlgoResult()
+    info = _lib.load().grb_cc(_h(v), _h(A), int(seed), _h(desc), C.byref(res))
+    return info, dict(iterations=res.iterations, tight_ms=res.tight_ms, succ=res.last_value)
 
 
 # ---- raw kernels / timing -----------------------------------------------------------

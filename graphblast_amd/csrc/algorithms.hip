@@ -100,4 +100,47 @@ grb_info grb_pr(grb_vector p, grb_matrix A, float alpha, float eps, grb_descript
   return GRB_SUCCESS;
 }
 
+// FastSV connected components, algorithm/cc.hpp:17-136: v = parent vector (component label =
+// smallest vertex id of the component once converged). A is an int matrix (pattern values).
+grb_info grb_cc(grb_vector v, grb_matrix A, int seed, grb_descriptor desc, grb_algo_result* result) {
+  (void)seed;
+  if (!v || !A || !desc) return GRB_UNINITIALIZED_OBJECT;
+  if (v->dtype != GRB_I32 || A->dtype != GRB_I32) return GRB_DOMAIN_MISMATCH;
+  const Index n = A->nrows;
+  VecGuard g;
+  grb_vector diff, parent, parent_temp, grandparent, grandparent_temp, mnp, mnp_temp;
+  for (grb_vector* p : {&diff, &parent, &parent_temp, &grandparent, &grandparent_temp, &mnp, &mnp_temp})
+    GRB_TRY(g.make(p, GRB_I32, n));
+  GRB_TRY(grb_vector_fill_ascending(parent, n));
+  GRB_TRY(grb_vector_dup(mnp, parent));
+  GRB_TRY(grb_vector_dup(mnp_temp, parent));
+  GRB_TRY(grb_vector_dup(grandparent, parent));
+  GRB_TRY(grb_vector_dup(grandparent_temp, parent));
+  int iter = 1;
+  double succ = 0;
+  float ms = 0.f;
+  GRB_TRY(grb_timer_start());
+  for (; iter <= desc->max_niter; ++iter) {
+    GRB_TRY(grb_vector_dup(parent_temp, parent));
+    GRB_TRY(grb_mxv(mnp_temp, nullptr, GRB_ACCUM_NULL, GRB_MINIMUM_SELECT_SECOND, A, grandparent, desc));
+    GRB_TRY(grb_eWiseAdd(mnp, nullptr, GRB_ACCUM_NULL, GRB_MINIMUM_SELECT_SECOND, mnp, mnp_temp, desc));
+    GRB_TRY(grb_assignScatter(parent, nullptr, GRB_ACCUM_NULL, mnp, parent_temp, desc));
+    GRB_TRY(grb_eWiseAdd(parent, nullptr, GRB_ACCUM_NULL, GRB_MINIMUM_PLUS, parent, mnp, desc));
+    GRB_TRY(grb_eWiseAdd(parent, nullptr, GRB_ACCUM_NULL, GRB_MINIMUM_PLUS, parent, parent_temp, desc));
+    GRB_TRY(grb_extractGather(grandparent, nullptr, GRB_ACCUM_NULL, parent, parent, desc));
+    GRB_TRY(grb_eWiseMult(diff, nullptr, GRB_ACCUM_NULL, GRB_MINIMUM_NOT_EQUAL_TO, grandparent_temp, grandparent, desc));
+    GRB_TRY(grb_reduce_vector(&succ, GRB_ACCUM_NULL, GRB_PLUS_MONOID, diff, desc));
+    if (succ == 0) break;
+    GRB_TRY(grb_vector_dup(grandparent_temp, grandparent));
+    grb_descriptor_toggle(desc, GRB_MASK);
+    grb_info ai = grb_assign(grandparent, diff, GRB_ACCUM_NULL, (double)INT_MAX, desc);
+    grb_descriptor_toggle(desc, GRB_MASK);
+    GRB_TRY(ai);
+  }
+  GRB_TRY(grb_vector_dup(v, parent));
+  GRB_TRY(grb_timer_stop(&ms));
+  if (result) { result->iterations = iter; result->tight_ms = ms; result->last_value = succ; }
+  return GRB_SUCCESS;
+}
+
 }  // extern "C"

@@ -416,6 +416,9 @@ grb_info k_ewise_mult_sparse_dense_spmask(int sr, int dtype, Index* w_ind, void*
 grb_info k_zero_dense_identity(int dtype, const void* mask, int mask_f32, double identity,
                                const Index* u_ind, void* u_val, Index n);
 
+grb_info k_scatter_indexed(int dtype, void* w, Index w_n, const int* idx, Index n, const void* u);
+grb_info k_gather_indexed(int dtype, void* w, Index w_n, const int* idx, Index n, const void* u);
+
 // spmv.hip
 grb_info build_spmv_plan(const std::vector<Index>& ptr, Index n, SpmvPlan* plan);
 void free_spmv_plan(SpmvPlan* plan);

@@ -655,4 +655,43 @@ grb_info k_zero_dense_identity(int dtype, const void* mask, int mask_f32, double
   });
 }
 
+// ---------------------------------------------------------------- scatter / gather by index vector
+// w[idx[k]] = u[k]   (scatterIndexedKernel, kernels/scatter.hpp:24-39; racing duplicates: any winner)
+template <typename T>
+__global__ void scatter_indexed_kernel(T* __restrict__ w, Index w_n, const int* __restrict__ idx, Index n,
+                                       const T* __restrict__ u) {
+  for (Index k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
+    const Index i = idx[k];
+    if (i >= 0 && i < w_n) w[i] = u[k];
+  }
+}
+// w[k] = u[idx[k]]   (gatherIndexedKernel, kernels/gather.hpp:9-23)
+template <typename T>
+__global__ void gather_indexed_kernel(T* w, Index w_n, const int* idx, Index n, const T* u) {
+  for (Index k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
+    const Index i = idx[k];
+    if (i >= 0 && i < w_n) w[k] = u[i];
+  }
+}
+grb_info k_scatter_indexed(int dtype, void* w, Index w_n, const int* idx, Index n, const void* u) {
+  if (n <= 0) return GRB_SUCCESS;
+  return dispatch_dtype(dtype, [&](auto t) -> grb_info {
+    using T = decltype(t);
+    hipLaunchKernelGGL(scatter_indexed_kernel<T>, dim3(stream_grid(n)), dim3(kBlock), 0, ctx().stream, (T*)w, w_n, idx,
+                       n, (const T*)u);
+    GRB_LAUNCH_CHECK();
+    return GRB_SUCCESS;
+  });
+}
+grb_info k_gather_indexed(int dtype, void* w, Index w_n, const int* idx, Index n, const void* u) {
+  if (n <= 0) return GRB_SUCCESS;
+  return dispatch_dtype(dtype, [&](auto t) -> grb_info {
+    using T = decltype(t);
+    hipLaunchKernelGGL(gather_indexed_kernel<T>, dim3(stream_grid(n)), dim3(kBlock), 0, ctx().stream, (T*)w, w_n, idx,
+                       n, (const T*)u);
+    GRB_LAUNCH_CHECK();
+    return GRB_SUCCESS;
+  });
+}
+
 }  // namespace grb

@@ -276,6 +276,41 @@ grb_info grb_assign(grb_vector w, grb_vector mask, grb_accum accum, double val, 
   return GRB_SUCCESS;                                       // unknown storage: nothing happens
 }
 
+// backend/cuda/operations.hpp:1170-1253 + scatter.hpp:85-123 / gather.hpp:11-50
+static grb_info scatter_gather(grb_vector w, grb_vector mask, grb_vector u, grb_vector indices, bool gather) {
+  if (!w || !u || !indices) return GRB_UNINITIALIZED_OBJECT;
+  if (mask && mask->nsize != w->nsize) return GRB_DIMENSION_MISMATCH;
+  if (indices->dtype != GRB_I32) return GRB_DOMAIN_MISMATCH;
+  grb_index nindices = 0;
+  GRB_TRY(grb_vector_nvals(indices, &nindices));
+  const int ut = u->vec_type;
+  if (indices->vec_type != ut) GRB_TRY(grb_vector_set_storage(indices, ut));
+  if (w->vec_type != ut) GRB_TRY(grb_vector_set_storage(w, ut));
+  if (mask) return GRB_SUCCESS;                          // masked variants: empty branch in the reference
+  const void* uv;
+  const int* iv;
+  if (ut == GRB_DENSE) { uv = u->d_val; iv = (const int*)indices->d_val; }
+  else if (ut == GRB_SPARSE) {
+    // reference quirk: w is switched to SPARSE storage above but its DENSE buffer is written
+    uv = u->s_val; iv = (const int*)indices->s_val;
+  } else return GRB_SUCCESS;
+  if (gather) return k_gather_indexed(w->dtype, w->d_val, w->nsize, iv, nindices, uv);
+  return k_scatter_indexed(w->dtype, w->d_val, w->nsize, iv, nindices, uv);
+}
+
+grb_info grb_assignScatter(grb_vector w, grb_vector mask, grb_accum accum, grb_vector u, grb_vector indices,
+                           grb_descriptor desc) {
+  (void)accum;
+  if (!desc) return GRB_UNINITIALIZED_OBJECT;
+  return scatter_gather(w, mask, u, indices, false);
+}
+grb_info grb_extractGather(grb_vector w, grb_vector mask, grb_accum accum, grb_vector u, grb_vector indices,
+                           grb_descriptor desc) {
+  (void)accum;
+  if (!desc) return GRB_UNINITIALIZED_OBJECT;
+  return scatter_gather(w, mask, u, indices, true);
+}
+
 // ---- algorithm::bfs op by op (graphblas/algorithm/bfs.hpp:14-89) ------------------
 grb_info grb_bfs(grb_vector v, grb_matrix A, grb_index source, grb_descriptor desc, grb_bfs_result* result) {
   if (!v || !A || !desc) return GRB_UNINITIALIZED_OBJECT;

@@ -646,6 +646,22 @@ Info assign(Vector<W>* w, Vector<M>* mask, BinaryOpT accum, X val, const Vector<
                             desc->handle()));
 }
 
+template <typename W, typename M, typename U, typename I, typename BinaryOpT>
+Info assignScatter(Vector<W>* w, const Vector<M>* mask, BinaryOpT accum, const Vector<U>* u, const Vector<I>* indices,
+                   Descriptor* desc) {
+  if (w == NULL || u == NULL || indices == NULL || desc == NULL) return GrB_UNINITIALIZED_OBJECT;
+  return to_info(grb_assignScatter(GRB_H(w), GRB_H(mask), detail::accum_of(accum), GRB_H(u), GRB_H(indices),
+                                   desc->handle()));
+}
+
+template <typename W, typename M, typename U, typename I, typename BinaryOpT>
+Info extractGather(Vector<W>* w, const Vector<M>* mask, BinaryOpT accum, const Vector<U>* u, const Vector<I>* indices,
+                   Descriptor* desc) {
+  if (w == NULL || u == NULL || indices == NULL || desc == NULL) return GrB_UNINITIALIZED_OBJECT;
+  return to_info(grb_extractGather(GRB_H(w), GRB_H(mask), detail::accum_of(accum), GRB_H(u), GRB_H(indices),
+                                   desc->handle()));
+}
+
 // ---- set-up time matrix operations (host side, as apply() is in the reference:
 // backend/cuda/apply.hpp:102-111 runs only with GrB_BACKEND = GrB_SEQUENTIAL) -----------
 // apply: C = op(A) on the stored values in CSR order (example/gsssp.cu:79-86)

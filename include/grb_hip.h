@@ -195,6 +195,13 @@ grb_info grb_reduce_matrix_rows(grb_vector w, grb_vector mask, grb_accum accum, 
 /* assign (constant under mask, GrB_ALL)  operations.hpp:509-530 -> backend :822-860 */
 grb_info grb_assign(grb_vector w, grb_vector mask, grb_accum accum, double val, grb_descriptor desc);
 
+/* assignScatter  w[indices[k]] = u[k]   operations.hpp:771-790 -> backend :1170-1210 (scatter.hpp:85-123) */
+grb_info grb_assignScatter(grb_vector w, grb_vector mask, grb_accum accum, grb_vector u, grb_vector indices,
+                           grb_descriptor desc);
+/* extractGather  w[k] = u[indices[k]]   operations.hpp:800-815 -> backend :1212-1253 (gather.hpp:11-50) */
+grb_info grb_extractGather(grb_vector w, grb_vector mask, grb_accum accum, grb_vector u, grb_vector indices,
+                           grb_descriptor desc);
+
 /* ---- Algorithms: the drivers of graphblas/algorithm/{bfs,...}.hpp built on the ops above.
  * *_fused variants run the same level loop on the device-resident representation
  * (bitmap frontier, no per-op host round trips) and must return identical results. */
@@ -256,6 +263,9 @@ grb_info grb_sssp(grb_vector v, grb_matrix A, grb_index source, grb_descriptor d
  * matrix the driver prepares (example/gpr.cu:67-90). */
 grb_info grb_pr(grb_vector p, grb_matrix A, float alpha, float eps, grb_descriptor desc,
                 grb_algo_result* result);
+
+/* algorithm::cc (algorithm/cc.hpp:17-136): FastSV; v and A are int; v = parent labels. */
+grb_info grb_cc(grb_vector v, grb_matrix A, int seed, grb_descriptor desc, grb_algo_result* result);
 
 /* ---- Raw kernels on plain device pointers (micro-benchmarks / multi-GPU shards) --- */
 /* Generic semiring SpMV  w[i] = (+)_j A[i,j] (x) u[j] on this matrix's CSR (tran=0) or

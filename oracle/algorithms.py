@@ -109,3 +109,37 @@ def pr(A, alpha, eps, desc):
         trace.append(float(error))
         it += 1
     return p.extractTuples_dense(), trace
+
+
+def cc(A, desc):
+    """algorithm::cc (graphblas/algorithm/cc.hpp:17-136), FastSV on int vectors."""
+    n = A.nrows_
+    I = np.int32
+    mk = lambda: ops.Vector(n, I)
+    diff, parent, parent_temp, grandparent, grandparent_temp, mnp, mnp_temp = (mk() for _ in range(7))
+    parent.fillAscending()
+    for v in (mnp, mnp_temp, grandparent, grandparent_temp):
+        v.dup(parent)
+    mss = Semiring("MinimumSelectSecond", I)
+    mp = Semiring("MinimumPlus", I)
+    mne = Semiring("MinimumNotEqualTo", I)
+    plus = Monoid("Plus", I)
+    it = 1
+    while it <= desc.max_niter_:
+        parent_temp.dup(parent)
+        ops.mxv(mnp_temp, None, None, mss, A, grandparent, desc)
+        ops.eWiseAdd(mnp, None, None, mss, mnp, mnp_temp, desc)
+        ops.assignScatter(parent, None, None, mnp, parent_temp, desc)
+        ops.eWiseAdd(parent, None, None, mp, parent, mnp, desc)
+        ops.eWiseAdd(parent, None, None, mp, parent, parent_temp, desc)
+        ops.extractGather(grandparent, None, None, parent, parent, desc)
+        ops.eWiseMult(diff, None, None, mne, grandparent_temp, grandparent, desc)
+        succ = ops.reduce_vector(plus, diff, desc)
+        if succ == 0:
+            break
+        grandparent_temp.dup(grandparent)
+        desc.toggle(ops.GrB_MASK)
+        ops.assign(grandparent, diff, None, np.iinfo(I).max, desc)
+        desc.toggle(ops.GrB_MASK)
+        it += 1
+    return parent.extractTuples_dense(), it

@@ -666,3 +666,39 @@ def eWiseMult(w, mask, accum, sr, u, v, desc):
     w.s_val[:k] = out
     w.s_nvals = k
     return GrB_SUCCESS
+
+
+# ---------------------------------------------------------------------------
+def _scatter_gather(w, mask, u, indices, gather):
+    """assignScatter / extractGather: backend/cuda/operations.hpp:1170-1253,
+    scatter.hpp:85-123, gather.hpp:11-50, kernels/scatter.hpp:24-39, kernels/gather.hpp:9-23."""
+    nindices = indices.nvals()
+    ut = u.getStorage()
+    if indices.getStorage() != ut:
+        indices.setStorage(ut)
+    if w.getStorage() != ut:
+        w.setStorage(ut)
+    if mask is not None:
+        return GrB_SUCCESS
+    if ut == GrB_DENSE:
+        uv, iv = u.d_val, indices.d_val
+    elif ut == GrB_SPARSE:
+        uv, iv = u.s_val, indices.s_val          # the dense buffer of w is written (reference quirk)
+    else:
+        return GrB_SUCCESS
+    idx = iv[:nindices].astype(np.int64)
+    ok = (idx >= 0) & (idx < w.nsize_)
+    if gather:
+        k = np.nonzero(ok)[0]
+        w.d_val[k] = uv[idx[k]].astype(w.dtype)
+    else:
+        w.d_val[idx[ok]] = uv[:nindices][ok].astype(w.dtype)    # duplicates: last writer wins here
+    return GrB_SUCCESS
+
+
+def assignScatter(w, mask, accum, u, indices, desc):
+    return _scatter_gather(w, mask, u, indices, False)
+
+
+def extractGather(w, mask, accum, u, indices, desc):
+    return _scatter_gather(w, mask, u, indices, True)

@@ -198,6 +198,29 @@ def test_pagerank(hb, graphs):
             assert rel.max() <= 1e-5, (name, mode, rel.max())
 
 
+def test_connected_components(hb, graphs):
+    """algorithm::cc (FastSV): parent labels == smallest vertex id of the component (the
+    canonical form of SimpleReferenceCc's partition); SimpleVerifyCc: no edge crosses labels."""
+    from oracle import simple_reference as sr
+    g = hb.g
+    for name, gr in graphs:
+        if gr["csr"] is not gr["csc"]:
+            continue                                  # CC is defined on the undirected graphs
+        ptr, ind = gr["csr"]
+        n = gr["n"]
+        A = g.Matrix(n, n, np.int32)
+        assert A.build_csr(ptr, ind, np.ones(ind.size, dtype=np.int32)) == 0
+        want, k, _ = sr.cc(ptr, ind)
+        for mode in (0, 1, 2):
+            d = hb.descriptor(mxvmode=mode)
+            v = g.Vector(n, np.int32)
+            info, res = g.cc(v, A, 0, d)
+            assert info == 0
+            got = v.extractTuples()[1]
+            assert np.array_equal(got, sr.cc_canonical(want)), (name, mode)
+            assert sr.cc_verify(ptr, ind, got) == (0, k)
+
+
 def test_raw_spmv_kernel_entry(hb, graphs):
     """grb_k_spmv on plain device pointers (the benchmarked kernel) == mxv result."""
     import torch

@@ -45,3 +45,11 @@ def test_reference_gpr_main(graph):
     out = _run("gpr_ref", "--mxvmode", "2", "--niter", "1", "--max_niter", "10", "--timing", "0",
                os.path.join(DATA, graph))
     assert "INCORRECT" not in out, out[-1500:]
+
+
+@pytest.mark.parametrize("graph", ["chesapeake.mtx", "test_mesh.mtx", "small.mtx"])
+@pytest.mark.parametrize("mode", ["1", "2"])
+def test_reference_gcc_main(graph, mode):
+    out = _run("gcc_ref", "--mxvmode", mode, "--niter", "1", "--timing", "0", os.path.join(DATA, graph))
+    assert "INCORRECT" not in out, out[-1500:]
+    assert "CORRECT" in out, out[-1500:]

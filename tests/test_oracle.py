@@ -197,3 +197,22 @@ def test_algorithm_drivers_on_oracle():
     deg = np.diff(ptr)
     ok = deg > 0
     assert np.allclose(got, want, rtol=1e-5, atol=0)
+
+
+def test_cc_driver_on_oracle():
+    """algorithm::cc (FastSV) over the oracle ops == DFS labelling of SimpleReferenceCc,
+    both canonicalised to the smallest vertex id of the component; SimpleVerifyCc passes."""
+    from oracle import ops, algorithms, simple_reference as sr
+    for seed in (4, 9):
+        g = _rand_graph(400, 500, seed, True)
+        ptr, ind = g["csr"]
+        n = g["n"]
+        want, k, _ = sr.cc(ptr, ind)
+        for mode in (1, 2):
+            A = ops.Matrix(n, n, np.int32)
+            A.build_csr(ptr, ind, np.ones(ind.size, dtype=np.int32))
+            d = ops.Descriptor()
+            d.loadArgs(mxvmode=mode)
+            got, iters = algorithms.cc(A, d)
+            assert np.array_equal(got, sr.cc_canonical(want)), (seed, mode)
+            assert sr.cc_verify(ptr, ind, got) == (0, k)
