@@ -105,6 +105,10 @@ _SIGS = {
     "grb_assignScatter": [_vp, _vp, _i, _vp, _vp, _vp],
     "grb_extractGather": [_vp, _vp, _i, _vp, _vp, _vp],
     "grb_cc": [_vp, _vp, _i, _vp, C.POINTER(AlgoResult)],
+    "grb_mxm": [_vp, _vp, _i, _i, _vp, _vp, _vp],
+    "grb_reduce_matrix_scalar": [C.POINTER(_d), _i, _i, _vp, _vp],
+    "grb_matrix_tril": [_vp, _vp, _vp],
+    "grb_tc": [C.POINTER(C.c_int64), _vp, _vp, _vp, C.POINTER(AlgoResult)],
     "grb_sssp": [_vp, _vp, _i, _vp, C.POINTER(AlgoResult)],
     "grb_pr": [_vp, _vp, _f, _f, _vp, C.POINTER(AlgoResult)],
     "grb_k_spmv": [_vp, _i, _i, _vp, _vp, _i, _i, _vp],

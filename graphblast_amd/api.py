@@ -350,6 +350,20 @@ def assign(w, mask, accum, val, indices, nindices, desc):
     return _lib.load().grb_assign(_h(w), _h(mask), _accum(accum), float(val), _h(desc))
 
 
+def mxm(Cm, mask, accum, op, A, B, desc):
+    return _lib.load().grb_mxm(_h(Cm), _h(mask), _accum(accum), _semiring_id(op), _h(A), _h(B), _h(desc))
+
+
+def tril(Cm, A, desc):
+    return _lib.load().grb_matrix_tril(_h(Cm), _h(A), _h(desc))
+
+
+def reduce_matrix(accum, op, A, desc):
+    out = C.c_double(0)
+    info = _lib.load().grb_reduce_matrix_scalar(C.byref(out), _accum(accum), _monoid_id(op), _h(A), _h(desc))
+    return info, out.value
+
+
 def assignScatter(w, mask, accum, u, indices, desc):
     return _lib.load().grb_assignScatter(_h(w), _h(mask), _accum(accum), _h(u), _h(indices), _h(desc))
 
@@ -392,6 +406,13 @@ def cc(v, A, seed, desc):
     res = AlgoResult()
     info = _lib.load().grb_cc(_h(v), _h(A), int(seed), _h(desc), C.byref(res))
     return info, dict(iterations=res.iterations, tight_ms=res.tight_ms, succ=res.last_value)
+
+
+def tc(A, B, desc):
+    res = AlgoResult()
+    n = C.c_int64(0)
+    info = _lib.load().grb_tc(C.byref(n), _h(A), _h(B), _h(desc), C.byref(res))
+    return info, n.value, dict(tight_ms=res.tight_ms)
 
 
 # ---- raw kernels / timing -----------------------------------------------------------

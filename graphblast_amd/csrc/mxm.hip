@@ -1,0 +1,172 @@
+// mxm.hip -- masked SpGEMM (the triangle-counting path) and the two
+// matrix helpers its driver needs.
+//
+//   grb_mxm        C<mask> = A (+.x) B for the mask's nonzeros only: backend/cuda/spgemm.hpp:22-110
+//                  + kernels/spgemm.hpp:17-79 (spgemmMaskedKernel).  With GrB_INP1 = GrB_TRAN the
+//                  "columns of B" are B's CSR rows, so C[i,j] = (+)_k A[i,k] (x) B[j,k] -- for
+//                  B = A = L this is |N(i) n N(j)| on every edge of L, whose sum is the triangle
+//                  count.  The reference gives a 32-lane warp to every row and binary-searches
+//                  every A entry in the B column; here one 64-lane wave owns a mask row and each
+//                  LANE owns a mask entry: it walks the shorter of (row i of A, column j of B)
+//                  and binary-searches the longer, so work per dot product is
+//                  min(d_i, d_j) * log max(d_i, d_j).  A's own row pointers are used (the
+//                  reference walks A with the MASK's row pointers, kernels/spgemm.hpp:35-36,51-56,
+//                  which is only meaningful when the two share structure -- as they do in tc()).
+//   grb_matrix_tril  lower triangle on the host, as the reference (tri.hpp:21-48, sequential only)
+//   grb_reduce_matrix_scalar  reduce.hpp:81-91
+#include "common.hpp"
+
+namespace grb {
+
+template <int SR, typename T>
+__global__ __launch_bounds__(kBlock) void spgemm_masked_kernel(
+    T* __restrict__ c_val, const Index* __restrict__ m_ptr, const Index* __restrict__ m_ind,
+    const void* __restrict__ m_val, int mask_f32, const Index* __restrict__ a_ptr, const Index* __restrict__ a_ind,
+    const T* __restrict__ a_val, const Index* __restrict__ b_ptr, const Index* __restrict__ b_ind,
+    const T* __restrict__ b_val, Index nrows) {
+  typedef Semiring<SR, T> S;
+  const int lane = lane_id();
+  const Index wave_global = (Index)blockIdx.x * kWavesPerBlock + wave_id();
+  const Index nwaves = (Index)gridDim.x * kWavesPerBlock;
+  for (Index row = wave_global; row < nrows; row += nwaves) {
+    const Index ms = m_ptr[row], me = m_ptr[row + 1];
+    const Index as = a_ptr[row], ae = a_ptr[row + 1];
+    for (Index e = ms + lane; e < me; e += kWave) {
+      T acc = S::identity();
+      if (mask_nonzero(m_val, mask_f32, e)) {
+        const Index col = m_ind[e];
+        const Index bs = b_ptr[col], be = b_ptr[col + 1];
+        const bool a_short = (ae - as) <= (be - bs);
+        const Index* s_ind = a_short ? a_ind : b_ind;   // list walked
+        const Index* l_ind = a_short ? b_ind : a_ind;   // list searched
+        const Index ss = a_short ? as : bs, se = a_short ? ae : be;
+        const Index ls = a_short ? bs : as, le = a_short ? be : ae;
+        Index lo_hint = ls;                              // both lists are sorted: searches only move right
+        for (Index p = ss; p < se; ++p) {
+          const Index key = s_ind[p];
+          Index lo = lo_hint, hi = le;
+          while (lo < hi) {
+            const Index mid = lo + ((hi - lo) >> 1);
+            if (l_ind[mid] < key) lo = mid + 1; else hi = mid;
+          }
+          lo_hint = lo;
+          if (lo < le && l_ind[lo] == key) {
+            const T av = a_short ? a_val[p] : a_val[lo];
+            const T bv = a_short ? b_val[lo] : b_val[p];
+            acc = S::add(S::mul(av, bv), acc);
+          }
+          if (lo >= le) break;
+        }
+      }
+      c_val[e] = acc;
+    }
+  }
+}
+
+}  // namespace grb
+
+using namespace grb;
+
+extern "C" {
+
+grb_info grb_mxm(grb_matrix C, grb_matrix mask, grb_accum accum, grb_semiring op, grb_matrix A, grb_matrix B,
+                 grb_descriptor desc) {
+  (void)accum;
+  if (!C || !A || !B || !desc) return GRB_UNINITIALIZED_OBJECT;
+  if (!A->built || !B->built) return GRB_UNINITIALIZED_OBJECT;
+  if (!mask) return GRB_NOT_IMPLEMENTED;                 // unmasked SpGEMM is a cuSPARSE call in the reference
+  if (!mask->built) return GRB_UNINITIALIZED_OBJECT;
+  if (C == A || C == B || C == mask) return GRB_NOT_IMPLEMENTED;
+  if (A->dtype != B->dtype || C->dtype != A->dtype) return GRB_DOMAIN_MISMATCH;
+  const bool tran_a = desc->desc[GRB_INP0] == GRB_TRAN;
+  const bool tran_b = desc->desc[GRB_INP1] == GRB_TRAN;
+  const CsrArrays& Aa = tran_a ? A->csc : A->csr;
+  const CsrArrays& Bb = tran_b ? B->csr : B->csc;        // "columns of B"
+  if (!Aa.ptr || !Bb.ptr || !mask->csr.ptr) return GRB_INVALID_OBJECT;
+  if (Aa.n != mask->nrows || C->nrows != mask->nrows || C->ncols != mask->ncols) return GRB_DIMENSION_MISMATCH;
+  hipStream_t s = ctx().stream;
+  // C takes the mask's structure (C->dup(&mask->sparse_), spgemm.hpp:78-79)
+  GRB_HIP_TRY(hipStreamSynchronize(s));
+  if (C->owned) {
+    for (CsrArrays* m : {&C->csr, &C->csc}) {
+      if (m->ptr) (void)hipFree(m->ptr);
+      if (m->ind) (void)hipFree(m->ind);
+      if (m->val) (void)hipFree(m->val);
+    }
+  }
+  C->csr = CsrArrays(); C->csc = CsrArrays();
+  free_spmv_plan(&C->plan_csr); free_spmv_plan(&C->plan_csc);
+  C->owned = true;
+  C->nvals = mask->nvals;
+  const size_t cap = mask->nvals > 0 ? (size_t)mask->nvals : 1;
+  GRB_HIP_TRY(hipMalloc((void**)&C->csr.ptr, 4 * ((size_t)mask->nrows + 1)));
+  GRB_HIP_TRY(hipMalloc((void**)&C->csr.ind, 4 * cap));
+  GRB_HIP_TRY(hipMalloc(&C->csr.val, 4 * cap));
+  GRB_HIP_TRY(hipMemcpyAsync(C->csr.ptr, mask->csr.ptr, 4 * ((size_t)mask->nrows + 1), hipMemcpyDeviceToDevice, s));
+  if (mask->nvals > 0)
+    GRB_HIP_TRY(hipMemcpyAsync(C->csr.ind, mask->csr.ind, 4 * (size_t)mask->nvals, hipMemcpyDeviceToDevice, s));
+  C->csr.n = mask->nrows;
+  C->csr.nvals = mask->nvals;
+  C->h_csr_ptr = mask->h_csr_ptr;
+  C->h_csr_ind.clear(); C->h_csr_val.clear();
+  C->h_csc_ptr.clear(); C->h_csc_ind.clear(); C->h_csc_val.clear();
+  C->built = true;
+  if (mask->nvals == 0) return GRB_SUCCESS;
+  const int grid = stream_grid((long long)mask->nrows * kWave, kBlock);
+  return dispatch_semiring(op, A->dtype, [&](auto tag, auto t) -> grb_info {
+    using T = decltype(t);
+    constexpr int SR = decltype(tag)::value;
+    hipLaunchKernelGGL((spgemm_masked_kernel<SR, T>), dim3(grid), dim3(kBlock), 0, s, (T*)C->csr.val, mask->csr.ptr,
+                       mask->csr.ind, mask->csr.val, mask->dtype == GRB_F32, Aa.ptr, Aa.ind, (const T*)Aa.val, Bb.ptr,
+                       Bb.ind, (const T*)Bb.val, mask->nrows);
+    GRB_HIP_TRY(hipGetLastError());
+    return GRB_SUCCESS;
+  });
+}
+
+grb_info grb_reduce_matrix_scalar(double* val, grb_accum accum, grb_monoid op, grb_matrix A, grb_descriptor desc) {
+  (void)accum;
+  if (!val || !A || !desc) return GRB_UNINITIALIZED_OBJECT;
+  if (!A->built) return GRB_UNINITIALIZED_OBJECT;
+  if (desc->struconly) { *val = (double)A->nvals; return GRB_SUCCESS; }    // reduce.hpp:86-87
+  return k_reduce(op, A->dtype, A->csr.val, A->nvals, val);
+}
+
+grb_info grb_matrix_tril(grb_matrix C, grb_matrix A, grb_descriptor desc) {
+  if (!C || !A || !desc) return GRB_UNINITIALIZED_OBJECT;
+  if (!A->built) return GRB_UNINITIALIZED_OBJECT;
+  if (C->nrows != A->nrows || C->ncols != A->ncols) return GRB_DIMENSION_MISMATCH;
+  const grb_index *ptr, *ind;
+  const void* val;
+  GRB_TRY(grb_matrix_host_csr(A, &ptr, &ind, &val));
+  const uint32_t* v = (const uint32_t*)val;
+  std::vector<Index> nptr((size_t)A->nrows + 1, 0), nind;
+  std::vector<uint32_t> nval;
+  for (Index r = 0; r < A->nrows; ++r) {
+    for (Index p = ptr[r]; p < ptr[r + 1]; ++p)
+      if (ind[p] <= r) { nind.push_back(ind[p]); nval.push_back(v[p]); }    // keep row >= col (tri.hpp:33-40)
+    nptr[(size_t)r + 1] = (Index)nind.size();
+  }
+  static const Index kZero = 0;
+  static const uint32_t kZeroV = 0;
+  return grb_matrix_build_csr(C, nptr.data(), nind.empty() ? &kZero : nind.data(), nval.empty() ? &kZeroV : nval.data(),
+                              (Index)nind.size(), nullptr, nullptr, nullptr);
+}
+
+// algorithm::tc (algorithm/tc.hpp:15-54): B = (A x A^T) .* A on the lower triangle, ntris = sum(B)
+grb_info grb_tc(int64_t* ntris, grb_matrix A, grb_matrix B, grb_descriptor desc, grb_algo_result* result) {
+  if (!ntris || !A || !B || !desc) return GRB_UNINITIALIZED_OBJECT;
+  float ms = 0.f;
+  grb_descriptor_toggle(desc, GRB_INP1);
+  grb_info info = grb_timer_start();
+  if (info == GRB_SUCCESS) info = grb_mxm(B, A, GRB_ACCUM_NULL, GRB_PLUS_MULTIPLIES, A, A, desc);
+  double sum = 0;
+  if (info == GRB_SUCCESS) info = grb_reduce_matrix_scalar(&sum, GRB_ACCUM_NULL, GRB_PLUS_MONOID, B, desc);
+  if (info == GRB_SUCCESS) info = grb_timer_stop(&ms);
+  // (the reference leaves GrB_INP1 toggled: tc.hpp:23 has no matching toggle back)
+  *ntris = (int64_t)sum;
+  if (result) { result->iterations = 1; result->tight_ms = ms; result->last_value = sum; }
+  return info;
+}
+
+}  // extern "C"

@@ -541,6 +541,16 @@ class Matrix {
     return GrB_SUCCESS;
   }
   grb_matrix handle() const { return matrix_.h_; }
+  Info refresh_all() {
+    grb_matrix_nvals(matrix_.h_, &matrix_.nvals_);
+    return matrix_.refresh_host();
+  }
+  void refresh_csr_only() {          // result of mxm: CSR only (csc_initialized_ = false in the reference)
+    const void* v = NULL;
+    grb_matrix_nvals(matrix_.h_, &matrix_.nvals_);
+    grb_matrix_host_csr(matrix_.h_, &matrix_.sparse_.h_csrRowPtr_, &matrix_.sparse_.h_csrColInd_, &v);
+    matrix_.sparse_.h_csrVal_ = static_cast<const X*>(v);
+  }
   // Set-up time rewrite of the stored values on the host (CSR order); CSC is re-derived.
   template <typename F>
   Info transform_values(F f) {
@@ -660,6 +670,35 @@ Info extractGather(Vector<W>* w, const Vector<M>* mask, BinaryOpT accum, const V
   if (w == NULL || u == NULL || indices == NULL || desc == NULL) return GrB_UNINITIALIZED_OBJECT;
   return to_info(grb_extractGather(GRB_H(w), GRB_H(mask), detail::accum_of(accum), GRB_H(u), GRB_H(indices),
                                    desc->handle()));
+}
+
+// mxm: masked SpGEMM only (operations.hpp:22-48; unmasked is a cuSPARSE call in the reference)
+template <typename c, typename m, typename a, typename b, typename BinaryOpT, typename SemiringT>
+Info mxm(Matrix<c>* C, const Matrix<m>* mask, BinaryOpT accum, SemiringT op, const Matrix<a>* A, const Matrix<b>* B,
+         Descriptor* desc) {
+  if (C == NULL || A == NULL || B == NULL || desc == NULL) return GrB_UNINITIALIZED_OBJECT;
+  Info i = to_info(grb_mxm(C->handle(), mask ? mask->handle() : static_cast<grb_matrix>(NULL), detail::accum_of(accum),
+                           static_cast<grb_semiring>(SemiringT::grb_id), A->handle(), B->handle(), desc->handle()));
+  if (i == GrB_SUCCESS) C->refresh_csr_only();
+  return i;
+}
+
+template <typename X, typename a, typename BinaryOpT, typename MonoidT>
+Info reduce(X* val, BinaryOpT accum, MonoidT op, const Matrix<a>* A, Descriptor* desc) {
+  if (val == NULL || A == NULL || desc == NULL) return GrB_UNINITIALIZED_OBJECT;
+  double d = 0;
+  Info i = to_info(grb_reduce_matrix_scalar(&d, detail::accum_of(accum), static_cast<grb_monoid>(MonoidT::grb_id),
+                                            A->handle(), desc->handle()));
+  *val = static_cast<X>(d);
+  return i;
+}
+
+template <typename c, typename a>
+Info tril(Matrix<c>* C, Matrix<a>* A, Descriptor* desc) {
+  if (C == NULL || A == NULL || desc == NULL) return GrB_UNINITIALIZED_OBJECT;
+  Info i = to_info(grb_matrix_tril(C->handle(), A->handle(), desc->handle()));
+  if (i == GrB_SUCCESS) i = C->refresh_all();
+  return i;
 }
 
 // ---- set-up time matrix operations (host side, as apply() is in the reference:

@@ -202,6 +202,14 @@ grb_info grb_assignScatter(grb_vector w, grb_vector mask, grb_accum accum, grb_v
 grb_info grb_extractGather(grb_vector w, grb_vector mask, grb_accum accum, grb_vector u, grb_vector indices,
                            grb_descriptor desc);
 
+/* mxm, masked SpGEMM only   operations.hpp:22-48 -> backend :18-78 (spgemm.hpp:22-110) */
+grb_info grb_mxm(grb_matrix C, grb_matrix mask, grb_accum accum, grb_semiring op, grb_matrix A, grb_matrix B,
+                 grb_descriptor desc);
+/* reduce (matrix -> scalar)   operations.hpp:662-680 -> backend :1032-1059 (reduce.hpp:81-91) */
+grb_info grb_reduce_matrix_scalar(double* val, grb_accum accum, grb_monoid op, grb_matrix A, grb_descriptor desc);
+/* tril   operations.hpp:872-886 -> tri.hpp:10-53 (host side, as in the reference) */
+grb_info grb_matrix_tril(grb_matrix C, grb_matrix A, grb_descriptor desc);
+
 /* ---- Algorithms: the drivers of graphblas/algorithm/{bfs,...}.hpp built on the ops above.
  * *_fused variants run the same level loop on the device-resident representation
  * (bitmap frontier, no per-op host round trips) and must return identical results. */
@@ -266,6 +274,9 @@ grb_info grb_pr(grb_vector p, grb_matrix A, float alpha, float eps, grb_descript
 
 /* algorithm::cc (algorithm/cc.hpp:17-136): FastSV; v and A are int; v = parent labels. */
 grb_info grb_cc(grb_vector v, grb_matrix A, int seed, grb_descriptor desc, grb_algo_result* result);
+
+/* algorithm::tc (algorithm/tc.hpp:15-54): A = lower triangle (int), B = buffer matrix. */
+grb_info grb_tc(int64_t* ntris, grb_matrix A, grb_matrix B, grb_descriptor desc, grb_algo_result* result);
 
 /* ---- Raw kernels on plain device pointers (micro-benchmarks / multi-GPU shards) --- */
 /* Generic semiring SpMV  w[i] = (+)_j A[i,j] (x) u[j] on this matrix's CSR (tran=0) or

@@ -143,3 +143,11 @@ def cc(A, desc):
         desc.toggle(ops.GrB_MASK)
         it += 1
     return parent.extractTuples_dense(), it
+
+
+def tc(L, desc):
+    """algorithm::tc (graphblas/algorithm/tc.hpp:15-54) on L = tril(A)."""
+    I = np.int32
+    desc.toggle(ops.GrB_INP1)
+    vals = ops.mxm_masked(L, Semiring("PlusMultiplies", I), L, L, desc)
+    return int(ops.reduce_matrix(Monoid("Plus", I), vals, L.nvals_, desc))

@@ -702,3 +702,48 @@ def assignScatter(w, mask, accum, u, indices, desc):
 
 def extractGather(w, mask, accum, u, indices, desc):
     return _scatter_gather(w, mask, u, indices, True)
+
+
+# ---------------------------------------------------------------------------
+def tril(A):
+    """tril on the host: keep row >= col (backend/cuda/tri.hpp:21-48). Returns a new Matrix."""
+    rows = np.repeat(np.arange(A.nrows_), np.diff(A.csrRowPtr))
+    keep = A.csrColInd <= rows
+    L = Matrix(A.nrows_, A.ncols_, A.dtype)
+    L.build(rows[keep], A.csrColInd[keep], A.csrVal[keep])
+    return L
+
+
+def mxm_masked(mask, sr, A, B, desc):
+    """C<mask> = A (+.x) B on the mask's nonzeros (spgemm.hpp:22-110, kernels/spgemm.hpp:17-79).
+    GrB_INP1 = GrB_TRAN: B's CSR rows play the role of its columns. Returns C's csrVal on the
+    mask's structure."""
+    tran_a = desc.get(GrB_INP0) == GrB_TRAN
+    tran_b = desc.get(GrB_INP1) == GrB_TRAN
+    ap, ai, av, _ = A.arrays(use_csc=tran_a)
+    bp, bi, bv, _ = B.arrays(use_csc=not tran_b)
+    out = np.full(mask.nvals_, sr.identity(), dtype=sr.dtype)
+    mp, mi, mv = mask.csrRowPtr, mask.csrColInd, mask.csrVal
+    for i in range(mask.nrows_):
+        arow = ai[ap[i]:ap[i + 1]]
+        aval = av[ap[i]:ap[i + 1]]
+        for e in range(mp[i], mp[i + 1]):
+            if mv[e] == 0:
+                continue
+            j = mi[e]
+            bcol = bi[bp[j]:bp[j + 1]]
+            bval = bv[bp[j]:bp[j + 1]]
+            common, ia, ib = np.intersect1d(arow, bcol, return_indices=True)
+            acc = sr.identity()
+            for x, y in zip(aval[ia], bval[ib]):
+                acc = sr.add_op(sr.mul_op(x, y), acc)[()]
+            out[e] = acc
+    return out
+
+
+def reduce_matrix(monoid, A_vals, nvals, desc):
+    if desc.struconly():
+        return monoid.dtype(nvals)
+    if nvals == 0:
+        return monoid.identity()
+    return monoid.reduce(A_vals)

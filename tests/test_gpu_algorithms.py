@@ -221,6 +221,42 @@ def test_connected_components(hb, graphs):
             assert sr.cc_verify(ptr, ind, got) == (0, k)
 
 
+def test_triangle_count(hb, graphs):
+    """algorithm::tc = masked SpGEMM (L x L^T) .* L + reduce: chesapeake = 194 (BASELINE.md 4),
+    exact vs SimpleReferenceTc on tril(A) elsewhere; per-edge counts exact vs the oracle mxm."""
+    from oracle import ops as oops, algorithms as oalg, simple_reference as sr
+    g = hb.g
+    A = hb.matrix_from_mtx("chesapeake.mtx", dtype=np.int32)
+    n = A.nrows()
+    d = hb.descriptor()
+    L, B = g.Matrix(n, n, np.int32), g.Matrix(n, n, np.int32)
+    assert g.tril(L, A, d) == 0
+    info, ntris, res = g.tc(L, B, d)
+    assert info == 0 and ntris == 194
+    for name, gr in graphs:
+        if gr["csr"] is not gr["csc"]:
+            continue
+        ptr, ind = gr["csr"]
+        n = gr["n"]
+        A = g.Matrix(n, n, np.int32)
+        assert A.build_csr(ptr, ind, np.ones(ind.size, dtype=np.int32)) == 0
+        d = hb.descriptor()
+        L, B = g.Matrix(n, n, np.int32), g.Matrix(n, n, np.int32)
+        assert g.tril(L, A, d) == 0
+        lp, li, lv = L.host_csr()
+        info, ntris, res = g.tc(L, B, d)
+        assert info == 0 and ntris == sr.tc(lp, li)[0], name
+        if n <= 5000:
+            Lo = oops.Matrix(n, n, np.int32); Lo.build_csr(lp, li, lv)
+            do = oops.Descriptor(); do.loadArgs(); do.toggle(oops.GrB_INP1)
+            from oracle.semiring import Semiring
+            want = oops.mxm_masked(Lo, Semiring("PlusMultiplies", np.int32), Lo, Lo, do)
+            bp, bi, bv = B.host_csr()
+            assert np.array_equal(bp, lp) and np.array_equal(bi, li) and np.array_equal(bv, want), name
+    # error behaviour: unmasked mxm is not implemented (cuSPARSE in the reference)
+    assert g.mxm(B, None, None, "PlusMultiplies", L, L, d) == g.GrB_NOT_IMPLEMENTED
+
+
 def test_raw_spmv_kernel_entry(hb, graphs):
     """grb_k_spmv on plain device pointers (the benchmarked kernel) == mxv result."""
     import torch

@@ -53,3 +53,12 @@ def test_reference_gcc_main(graph, mode):
     out = _run("gcc_ref", "--mxvmode", mode, "--niter", "1", "--timing", "0", os.path.join(DATA, graph))
     assert "INCORRECT" not in out, out[-1500:]
     assert "CORRECT" in out, out[-1500:]
+
+
+@pytest.mark.parametrize("graph", ["chesapeake.mtx", "test_mesh.mtx", "small.mtx"])
+def test_reference_gtc_main(graph):
+    out = _run("gtc_ref", "--niter", "1", "--timing", "0", os.path.join(DATA, graph))
+    assert "INCORRECT" not in out, out[-1500:]
+    assert "CORRECT" in out, out[-1500:]
+    if graph == "chesapeake.mtx":
+        assert "194" in out

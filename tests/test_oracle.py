@@ -216,3 +216,21 @@ def test_cc_driver_on_oracle():
             got, iters = algorithms.cc(A, d)
             assert np.array_equal(got, sr.cc_canonical(want)), (seed, mode)
             assert sr.cc_verify(ptr, ind, got) == (0, k)
+
+
+def test_tc_driver_on_oracle():
+    """algorithm::tc over the oracle ops: chesapeake = 194 (BASELINE.md), == SimpleReferenceTc."""
+    from oracle import ops, algorithms, loader, simple_reference as sr
+    r, c, v, nr, nc, nv = loader.read_mtx(os.path.join(GOLDEN, "data", "chesapeake.mtx"), dtype=np.int32)
+    A = ops.Matrix(nr, nc, np.int32)
+    A.build(r, c, np.ones(nv, dtype=np.int32))
+    L = ops.tril(A)
+    d = ops.Descriptor(); d.loadArgs()
+    assert algorithms.tc(L, d) == 194 == sr.tc(L.csrRowPtr, L.csrColInd)[0]
+    g = _rand_graph(300, 2500, 6, True)
+    ptr, ind = g["csr"]
+    A = ops.Matrix(g["n"], g["n"], np.int32)
+    A.build_csr(ptr, ind, np.ones(ind.size, dtype=np.int32))
+    L = ops.tril(A)
+    d = ops.Descriptor(); d.loadArgs()
+    assert algorithms.tc(L, d) == sr.tc(L.csrRowPtr, L.csrColInd)[0]
