@@ -83,6 +83,48 @@ class HipEngine:
         assert info == 0, info
         return e.value, r.value
 
+    # ---- PageRank shard: rows = in-edges of the owned vertices, values alpha / outdeg(source)
+    def pr_setup(self, vals, dev):
+        import graphblast_amd as g
+        lptr, lind = self.keep
+        self.pr_vals = vals
+        self.Apr = g.Matrix(self.n_local, self.n)
+        info = self.Apr.build_device_csr(lptr.data_ptr(), lind.data_ptr(), vals.data_ptr(), int(vals.numel()),
+                                         keep=(lptr, lind, vals))
+        assert info == 0, info
+        self.g = g
+        self.desc = g.Descriptor()
+        assert self.desc.loadArgs(mxvmode=2) == 0
+        n1 = max(self.n_local, 1)
+        self._buf = {k: torch.zeros(n1, dtype=torch.float32, device=dev) for k in ("r", "r2")}
+        self._vec = {}
+
+    def _adopt(self, key, tensor):
+        v = self._vec.get(key)
+        if v is None:
+            v = self.g.Vector(max(self.n_local, 1))
+            self._vec[key] = v
+        assert v.build_device(tensor.data_ptr(), max(self.n_local, 1)) == 0
+        return v
+
+    def pr_step(self, p_full, y_local, p_old_local, const):
+        """y = A_in p (local rows); y += const; returns sum((y - p_old)^2) over the owned slice.
+        Exactly the op sequence of algorithm/pr.hpp:66-80 on the shard."""
+        g = self.g
+        if self.n_local == 0:
+            return 0.0
+        assert g.k_spmv(self.Apr, 0, "PlusMultiplies", p_full.data_ptr(), None, 0, 0, y_local.data_ptr()) == 0
+        y = self._adopt("y", y_local)
+        po = self._adopt("po", p_old_local)
+        r = self._adopt("r", self._buf["r"])
+        r2 = self._adopt("r2", self._buf["r2"])
+        assert g.eWiseAdd(y, None, None, "PlusMultiplies", y, float(const), self.desc) == 0
+        assert g.eWiseMult(r, None, None, "PlusMinus", y, po, self.desc) == 0
+        assert g.eWiseAdd(r2, None, None, "MultipliesMultiplies", r, r, self.desc) == 0
+        info, val = g.reduce(None, "Plus", r2, self.desc)
+        assert info == 0
+        return float(val)
+
 
 class TorchComm:
     """The collectives of the partitioned BFS over torch.distributed (RCCL / gloo)."""
@@ -127,6 +169,7 @@ class Partition1D:
         lind = tind[e0:e1].to(torch.int32).contiguous()
         if lind.numel() == 0:
             lind = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.lptr, self.lind = lptr, lind
         self.engine = engine_cls(n, self.lo, lptr, lind, dev)
         self.n_local = self.hi - self.lo
         self.nwords = bitmap_words(n)
@@ -189,6 +232,44 @@ class Partition1D:
         t = torch.tensor([e, r], dtype=torch.int64, device=self.dev)
         self.comm.sum_(t)
         return dict(levels=levels, edges_traversed=int(t[0].item()), reached=int(t[1].item()), trace=trace)
+
+    def pagerank(self, deg_full, alpha=0.85, eps=1e-8, max_niter=10):
+        """algorithm::pr (graphblas/algorithm/pr.hpp:15-94) on the 1-D partition: every rank
+        computes its owned slice of p . A from the replicated p (local SpMV over its in-edge
+        shard, values alpha / outdeg), the slices are all-gathered into the next p and the
+        squared residual is all-reduced.  deg_full: out-degree of every vertex (any float tensor
+        of length n on this rank's device)."""
+        n, dev = self.n, self.dev
+        eng = self.engine
+        lptr, lind = self.lptr, self.lind
+        vals = (alpha / deg_full.to(torch.float32)[lind[:int(lptr[-1].item())].long()]).to(torch.float32).contiguous()
+        if vals.numel() == 0:
+            vals = torch.zeros(1, dtype=torch.float32, device=dev)
+        eng.pr_setup(vals, dev)
+        n1 = max(self.n_local, 1)
+        p = torch.full((n,), 1.0 / n, dtype=torch.float32, device=dev)
+        y = torch.zeros(n1, dtype=torch.float32, device=dev)
+        p_old = torch.zeros(n1, dtype=torch.float32, device=dev)
+        sizes = [self.bounds[r + 1] - self.bounds[r] for r in range(self.world)]
+        m = max(max(sizes), 1)
+        pad = torch.zeros(m, dtype=torch.float32, device=dev)
+        const = np.float32((np.float32(1.0) - np.float32(alpha)) / np.float32(n))
+        error, it, errs = 1.0, 0, []
+        while error > eps and it < max_niter:
+            p_old[:self.n_local] = p[self.lo:self.hi]
+            res = eng.pr_step(p, y, p_old, const)
+            t = self.comm.sum_(torch.tensor([res], dtype=torch.float64, device=dev))
+            error = float(np.sqrt(np.float32(t[0].item())))
+            errs.append(error)
+            if self.world == 1:
+                p[self.lo:self.hi] = y[:self.n_local]
+            else:
+                pad[:self.n_local] = y[:self.n_local]
+                out = self.comm.all_gather_padded(pad)
+                for r in range(self.world):
+                    p[self.bounds[r]:self.bounds[r + 1]] = out[r, :sizes[r]]
+            it += 1
+        return p, dict(iterations=it, errors=errs)
 
     def gather_labels(self):
         """Full label vector on every rank (tests / verification only)."""

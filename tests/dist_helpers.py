@@ -59,6 +59,20 @@ class NumpyEngine:
         label_local.numpy()[mine] = new_label
         return int(sum(bin(int(x)).count("1") for x in fresh[fresh != 0]))
 
+    def pr_setup(self, vals, dev):
+        self.pr_vals = vals.cpu().numpy().astype(np.float32)
+
+    def pr_step(self, p_full, y_local, p_old_local, const):
+        p = p_full.numpy()
+        prod = self.pr_vals[:self.ptr[-1]] * p[self.ind[:self.ptr[-1]]]
+        y = np.zeros(self.n_local, dtype=np.float32)
+        np.add.at(y, self.rows, prod)
+        y = (y + np.float32(const)).astype(np.float32)
+        y_local.numpy()[:self.n_local] = y
+        po = p_old_local.numpy()[:self.n_local]
+        r = np.where((y == 0) | (po == 0), np.float32(0), y - po)      # eWiseMult identity short-circuit
+        return float(np.sum((r * r).astype(np.float32), dtype=np.float32))
+
     def tally(self, label_local):
         lab = label_local.numpy()[:self.n_local]
         deg = np.diff(self.ptr)
@@ -120,4 +134,11 @@ def locked_engine(engine_cls, lock):
         def tally(self, *a):
             with lock:
                 return super().tally(*a)
+        def pr_setup(self, *a):
+            with lock:
+                super().pr_setup(*a); torch.cuda.synchronize()
+        def pr_step(self, *a):
+            with lock:
+                r = super().pr_step(*a); torch.cuda.synchronize()
+                return r
     return Locked

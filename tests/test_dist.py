@@ -27,6 +27,7 @@ def _worker(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    ok = False
     try:
         import sys
         sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
@@ -44,8 +45,17 @@ def _worker(rank, world, port, q):
                 labels = part.gather_labels().numpy()
                 out.append((mode, src, res["levels"], res["edges_traversed"], res["reached"],
                             [t[0] for t in res["trace"]], labels.copy()))
+        # PageRank on the partition (config 4 of BASELINE.json at test size)
+        part = Partition1D(gr["n"], tptr, tind, rank, world, torch.device("cpu"), engine_cls=NumpyEngine)
+        deg = torch.from_numpy(np.diff(ptr).astype(np.float32))
+        pvec, info = part.pagerank(deg, alpha=0.85, eps=0.0, max_niter=10)
         if rank == 0:
-            q.put(out)
+            q.put((out, pvec.numpy().copy(), info["iterations"]))
+        ok = True
+    except Exception as exc:                       # fail fast instead of letting the parent time out
+        import traceback
+        q.put(("error", "rank %d: %s" % (rank, traceback.format_exc()), 0))
+        raise
     finally:
         dist.destroy_process_group()
 
@@ -61,7 +71,8 @@ def test_partitioned_bfs_gloo(world):
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    out = q.get(timeout=300)
+    out, pr_vec, pr_iters = q.get(timeout=180)
+    assert not (isinstance(out, str) and out == "error"), pr_vec
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -73,6 +84,12 @@ def test_partitioned_bfs_gloo(world):
         _, stats = sr.bfs_do_stats(ptr, ind, ptr, ind, src, mxvmode=mode, switchpoint=0.05)
         assert dirs == ["pull" if s[0] else "push" for s in stats], (mode, src)
         assert levels == len(stats)
+
+
+    want_pr = sr.pr(ptr, ind, 0.85, 0.0, 10)[0]
+    assert pr_iters == 10
+    rel = np.abs(pr_vec - want_pr) / np.maximum(np.abs(want_pr), 1e-30)
+    assert rel.max() <= 1e-5, rel.max()
 
 
 def test_partition_bounds():
@@ -123,3 +140,17 @@ def test_partitioned_bfs_hip_engine_simulated_ranks(world):
             assert results[r]["edges_traversed"] == int(np.diff(ptr)[want != 0].sum())
         _, stats = sr.bfs_do_stats(ptr, ind, ptr, ind, src, mxvmode=10, switchpoint=0.02)
         assert [t[0] for t in results[0]["trace"]] == ["pull" if s[0] else "push" for s in stats]
+    # PageRank over the same simulated ranks (local SpMV shard + all-gather of the slices)
+    deg = torch.from_numpy(np.diff(ptr).astype(np.float32)).to(dev)
+    pr_out = [None] * world
+    def run_pr(r):
+        pr_out[r] = parts[r].pagerank(deg, alpha=0.85, eps=0.0, max_niter=10)
+    ts = [threading.Thread(target=run_pr, args=(r,)) for r in range(world)]
+    [t.start() for t in ts]
+    [t.join(timeout=300) for t in ts]
+    want_pr = sr.pr(ptr, ind, 0.85, 0.0, 10)[0]
+    for r in range(world):
+        assert pr_out[r] is not None
+        got = pr_out[r][0].cpu().numpy()
+        rel = np.abs(got - want_pr) / np.maximum(np.abs(want_pr), 1e-30)
+        assert rel.max() <= 1e-5 and pr_out[r][1]["iterations"] == 10, (r, rel.max())
