@@ -36,6 +36,20 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8 TB/s spec
 
 
+def pmc_traffic(kernel_key):
+    """HBM bytes per launch from the committed PMC passes (profiles/*/pmc_traffic.json: separate
+    `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this same command), or None."""
+    best = None
+    pdir = os.path.join(ROOT, "profiles")
+    for d in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
+        f = os.path.join(pdir, d, "pmc_traffic.json")
+        if os.path.exists(f):
+            for name, rec in json.load(open(f)).get("kernels", {}).items():
+                if kernel_key in name:
+                    best = rec.get("hbm_bytes_per_launch_raw")
+    return best
+
+
 def level_bytes(levels, n):
     """push 12 nf + 8 mf + 8 nf'; pull 4 n + 8 nu + 8 mi + 4 nf'."""
     out = []
@@ -150,7 +164,8 @@ def main():
         ach = kb / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
         roofline = {"bound": "hbm", "kernel": "bfs_pull_kernel" if dom_pull else "lb_expand_kernel<BfsPushVisitor>",
                     "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-                    "traffic": None, "launches": kn, "avg_launch_ms": round(kms / max(kn, 1), 5),
+                    "traffic": pmc_traffic("bfs_pull_kernel<false>" if dom_pull else "lb_expand_kernel<grb::BfsPushVisitor>"),
+                    "launches": kn, "avg_launch_ms": round(kms / max(kn, 1), 5),
                     "algorithmic_bytes_per_launch": int(kb / max(kn, 1))}
         one = inspected[sources[0]]
         ob = level_bytes(one, n)
@@ -179,7 +194,8 @@ def main():
         extra["spmv"] = {"kernel": "spmv_stream_kernel<PlusMultiplies,f32>", "bound": "hbm",
                          "algorithmic_bytes_per_launch": sb, "avg_launch_ms": round(ms, 5),
                          "achieved": round(sb / (ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(sb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "gflops": round(2 * nnz / (ms * 1e-3) / 1e9, 1)}
+                         "frac": round(sb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                         "traffic": pmc_traffic("spmv_stream_kernel"), "gflops": round(2 * nnz / (ms * 1e-3) / 1e9, 1)}
 
         # ---- CPU baseline: the oracle's sequential BFS on a bounded sample (checker code,
         #      timed beside the GPU run; never part of the product path)
