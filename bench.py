@@ -74,7 +74,7 @@ def main():
     ap.add_argument("--scale", type=int, default=22)
     ap.add_argument("--edge-factor", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--edgeswitch", type=float, default=0.02,
+    ap.add_argument("--edgeswitch", type=float, default=0.08,
                     help="graphblast_amd extension: also leave push when frontier out-edges > edgeswitch*nnz "
                          "(0 = the reference's vertex-count rule only)")
     ap.add_argument("--partitioned", action="store_true",

@@ -316,6 +316,20 @@ struct SpmvPlan {         // built once per matrix orientation at build()
   int* d_long_slot_ptr = nullptr;
   int nslots = 0;
   void* d_partials = nullptr;
+  // wave-tile plan of the hub-packed kernel (spmv.hip)
+  int ntiles = 0;
+  SpmvBlock* d_tiles = nullptr;
+  int t_nlong = 0, t_nslots = 0;
+  int* d_t_long_row = nullptr;
+  int* d_t_long_slot_ptr = nullptr;
+  void* d_t_partials = nullptr;
+  // hub packing, prepared on the device by the first SpMV of this orientation
+  Index nminor = 0;       // length of the input vector
+  bool hub_ready = false;
+  int nhot = 0;           // leading entries of the (packed) input vector staged in LDS
+  Index* d_ind2 = nullptr;   // column ids renamed by descending column count (nullptr: not renamed)
+  Index* d_order = nullptr;  // [nminor] packed position -> original column
+  void* d_u2 = nullptr;      // [nminor] packed copy of the input vector
 };
 
 struct CsrArrays {
@@ -420,9 +434,9 @@ grb_info k_scatter_indexed(int dtype, void* w, Index w_n, const int* idx, Index 
 grb_info k_gather_indexed(int dtype, void* w, Index w_n, const int* idx, Index n, const void* u);
 
 // spmv.hip
-grb_info build_spmv_plan(const std::vector<Index>& ptr, Index n, SpmvPlan* plan);
+grb_info build_spmv_plan(const std::vector<Index>& ptr, Index n, Index nminor, SpmvPlan* plan);
 void free_spmv_plan(SpmvPlan* plan);
-grb_info k_spmv(int sr, int dtype, const CsrArrays& M, const SpmvPlan& plan, const void* u,
+grb_info k_spmv(int sr, int dtype, const CsrArrays& M, SpmvPlan& plan, const void* u,
                 const void* mask, int mask_f32, int scmp, int accum, void* w);
 grb_info k_spmv_masked_or(int dtype, const CsrArrays& M, const void* u, double identity,
                           const void* mask, int mask_f32, int scmp, int earlyexit, int opreuse,

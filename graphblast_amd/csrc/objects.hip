@@ -708,8 +708,8 @@ static grb_info matrix_finish_build(grb_matrix A) {
   A->owned = true;
   GRB_TRY(upload(&A->csr, A->nrows, A->nvals, A->h_csr_ptr, A->h_csr_ind, A->h_csr_val));
   GRB_TRY(upload(&A->csc, A->ncols, A->nvals, A->h_csc_ptr, A->h_csc_ind, A->h_csc_val));
-  GRB_TRY(build_spmv_plan(A->h_csr_ptr, A->nrows, &A->plan_csr));
-  GRB_TRY(build_spmv_plan(A->h_csc_ptr, A->ncols, &A->plan_csc));
+  GRB_TRY(build_spmv_plan(A->h_csr_ptr, A->nrows, A->ncols, &A->plan_csr));
+  GRB_TRY(build_spmv_plan(A->h_csc_ptr, A->ncols, A->nrows, &A->plan_csc));
   A->built = true;
   return GRB_SUCCESS;
 }
@@ -757,12 +757,12 @@ grb_info grb_matrix_adopt_device_csr(grb_matrix A, grb_index* d_csr_ptr, grb_ind
   A->csr.ptr = d_csr_ptr; A->csr.ind = d_csr_ind; A->csr.val = d_csr_val; A->csr.n = A->nrows; A->csr.nvals = nvals;
   A->h_csr_ptr.resize((size_t)A->nrows + 1);
   GRB_HIP_TRY(hipMemcpy(A->h_csr_ptr.data(), d_csr_ptr, 4 * ((size_t)A->nrows + 1), hipMemcpyDeviceToHost));
-  GRB_TRY(build_spmv_plan(A->h_csr_ptr, A->nrows, &A->plan_csr));
+  GRB_TRY(build_spmv_plan(A->h_csr_ptr, A->nrows, A->ncols, &A->plan_csr));
   if (d_csc_ptr) {
     A->csc.ptr = d_csc_ptr; A->csc.ind = d_csc_ind; A->csc.val = d_csc_val; A->csc.n = A->ncols; A->csc.nvals = nvals;
     A->h_csc_ptr.resize((size_t)A->ncols + 1);
     GRB_HIP_TRY(hipMemcpy(A->h_csc_ptr.data(), d_csc_ptr, 4 * ((size_t)A->ncols + 1), hipMemcpyDeviceToHost));
-    GRB_TRY(build_spmv_plan(A->h_csc_ptr, A->ncols, &A->plan_csc));
+    GRB_TRY(build_spmv_plan(A->h_csc_ptr, A->ncols, A->nrows, &A->plan_csc));
   }
   A->h_csr_ind.clear(); A->h_csr_val.clear(); A->h_csc_ind.clear(); A->h_csc_val.clear();
   A->built = true;

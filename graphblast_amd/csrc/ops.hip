@@ -18,7 +18,7 @@ static grb_info spmv_dispatch(grb_vector w, grb_vector mask, grb_accum accum, in
   const bool use_scmp = desc->desc[GRB_MASK] == GRB_SCMP;
   const bool use_tran = desc->desc[GRB_INP0] == GRB_TRAN || desc->desc[GRB_INP1] == GRB_TRAN;
   const CsrArrays& M = use_tran ? A->csc : A->csr;
-  const SpmvPlan& plan = use_tran ? A->plan_csc : A->plan_csr;
+  SpmvPlan& plan = use_tran ? A->plan_csc : A->plan_csr;
   if (!M.ptr) return GRB_INVALID_OBJECT;
   // "functor == 1": add_op(3, 5) == 1 selects the Boolean fused-mask kernel (spmv.hpp:84-96)
   const int functor = (int)semiring_add(op, w->dtype, 3, 5);
@@ -361,7 +361,7 @@ grb_info grb_k_spmv(grb_matrix A, int tran, grb_semiring op, const void* d_u, co
                     int accum, void* d_w) {
   if (!A || !A->built) return GRB_UNINITIALIZED_OBJECT;
   const CsrArrays& M = tran ? A->csc : A->csr;
-  const SpmvPlan& plan = tran ? A->plan_csc : A->plan_csr;
+  SpmvPlan& plan = tran ? A->plan_csc : A->plan_csr;
   if (!M.ptr) return GRB_INVALID_OBJECT;
   return k_spmv(op, A->dtype, M, plan, d_u, d_mask, A->dtype == GRB_F32, scmp, accum, d_w);
 }
