@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgrb_hip.so")
+LIB_PATH = os.environ.get("GRB_HIP_LIB") or os.path.join(_HERE, "libgrb_hip.so")
 
 # graphblas::Info names, types.hpp:28-42
 INFO_NAMES = ["GrB_SUCCESS", "GrB_UNINITIALIZED_OBJECT", "GrB_NULL_POINTER", "GrB_INVALID_VALUE",

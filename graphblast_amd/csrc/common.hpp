@@ -302,32 +302,27 @@ grb_info wait_granules(int seq, int count, unsigned int* out);
 
 // ----------------------------------------------------------------------------
 // Objects behind the handles
-struct SpmvBlock {        // one workgroup's share of an SpMV (row-block streaming)
+struct SpmvBlock {        // one wave tile of an SpMV
   int row_start, row_end; // rows [row_start, row_end)
   int nnz_start, nnz_end; // their nonzeros (or a slice of one long row)
   int slot;               // -1: whole rows; >=0: partial-result slot of a long row
 };
 
 struct SpmvPlan {         // built once per matrix orientation at build()
-  int nblocks = 0;
-  SpmvBlock* d_blocks = nullptr;
+  Index nrows = 0;        // rows of this orientation
+  Index nminor = 0;       // length of the input vector
+  int ntiles = 0;         // wave tiles
+  SpmvBlock* d_tiles = nullptr;
   int nlong = 0;          // rows longer than one tile, reduced in two steps
   int* d_long_row = nullptr;
   int* d_long_slot_ptr = nullptr;
   int nslots = 0;
   void* d_partials = nullptr;
-  // wave-tile plan of the hub-packed kernel (spmv.hip)
-  int ntiles = 0;
-  SpmvBlock* d_tiles = nullptr;
-  int t_nlong = 0, t_nslots = 0;
-  int* d_t_long_row = nullptr;
-  int* d_t_long_slot_ptr = nullptr;
-  void* d_t_partials = nullptr;
   // hub packing, prepared on the device by the first SpMV of this orientation
-  Index nminor = 0;       // length of the input vector
   bool hub_ready = false;
   int nhot = 0;           // leading entries of the (packed) input vector staged in LDS
-  Index* d_ind2 = nullptr;   // column ids renamed by descending column count (nullptr: not renamed)
+  Index npacked = 0;      // columns with at least one reference: the part of u that is packed
+  Index* d_ind2 = nullptr;   // column ids renamed by descending reference count (nullptr: not renamed)
   Index* d_order = nullptr;  // [nminor] packed position -> original column
   void* d_u2 = nullptr;      // [nminor] packed copy of the input vector
 };

@@ -117,7 +117,7 @@ grb_info k_spmspv(int sr, int dtype, const CsrArrays& M, Index out_size, int str
   const int ntiles = ceil_div(nf, kDegTile);
   const int nwords = ceil_div(out_size, 32);
   const int wtiles = ceil_div(nwords, kBlock);
-  void *p_scan, *p_tiles, *p_bitmap, *p_acc, *p_btiles, *p_rs, *p_chunks;
+  void *p_scan, *p_tiles, *p_bitmap, *p_acc, *p_btiles, *p_rs;
   const long long max_edges = (long long)M.nvals;
   GRB_TRY(scratch(2, sizeof(int) * (size_t)nf, &p_scan));
   GRB_TRY(scratch(11, sizeof(int) * (size_t)nf, &p_rs));

@@ -3,14 +3,17 @@
 //  k_spmv            generic semiring SpMV  w[i] = (+)_j A[i,j] (x) u[j]  with the optional
 //                    mask / accum epilogue of backend/cuda/spmv.hpp:178-220.  The reference
 //                    delegates to moderngpu's merge-path SpmvCsrBinary (source not in the
-//                    mount); this is a row-block streaming design instead (the CSR-Adaptive
-//                    idea): rows are grouped at build time into blocks of <= kTileNnz
-//                    nonzeros, one 256-thread workgroup per block streams the block's
-//                    column indices and values with fully coalesced loads, gathers u,
-//                    stages the products in LDS and reduces each row from LDS with a
-//                    per-block lanes-per-row width; rows longer than a tile are cut into
-//                    slices reduced by whole workgroups into a partial array that a tiny
-//                    second kernel folds in a fixed order (deterministic, no atomics).
+//                    mount); this is a different design, built for what bounds the kernel on
+//                    MI355X -- not the 8 B/nonzero matrix stream but the 4 B gathers of u:
+//                      * rows are cut at build time into wave tiles of <= 512 nonzeros and
+//                        <= 64 rows; rows longer than a tile become slices that each produce
+//                        one partial, folded in slice order by a second tiny kernel
+//                        (deterministic, no atomics);
+//                      * the columns are ranked by reference count once per matrix and u is
+//                        packed by that rank on every launch, so the hot values form a dense
+//                        prefix: 32 Ki of them live in LDS, the warm tail stays L2-resident;
+//                      * one persistent 1024-thread workgroup per CU, 16 independent waves,
+//                        each with three tiles in flight (stream / gather / reduce).
 //  k_spmv_masked_or  Boolean pull step with fused mask (kernels/spmv.hpp:10-59, all eight
 //                    <Scmp, EarlyExit, OpReuse> variants): one 64-lane wave owns 64
 //                    consecutive rows, lanes first probe their own row serially (the common
@@ -23,54 +26,36 @@
 
 namespace grb {
 
-#ifndef GRB_SPMV_TILE
-#define GRB_SPMV_TILE 2048
+// tuning knobs of the SpMV kernel (tools/build_spmv_variants.sh builds A/B variants)
+#ifndef GRB_HUB_THREADS
+#define GRB_HUB_THREADS 1024
 #endif
-constexpr int kTileNnz = GRB_SPMV_TILE;      // nonzeros staged per workgroup (4 B each in LDS)
-constexpr int kMaxRowsPerBlock = 1024;
-constexpr int kLongSlice = 8192;    // slice of a long row reduced by one workgroup
-// hub-packed kernel: one 1024-thread workgroup per CU owning all 160 KiB of LDS
-constexpr int kHubThreads = 1024;
+#ifndef GRB_HUB_TILE
+#define GRB_HUB_TILE 512
+#endif
+#ifndef GRB_HUB_HOT
+#define GRB_HUB_HOT 32768
+#endif
+#ifndef GRB_HUB_NT
+#define GRB_HUB_NT 1
+#endif
+constexpr int kHubThreads = GRB_HUB_THREADS;   // one workgroup per CU owning all 160 KiB of LDS
 constexpr int kHubWaves = kHubThreads / kWave;
-constexpr int kWaveTile = 512;      // nonzeros per wave tile (8 per lane), 2 KiB of LDS per wave
-constexpr int kWaveRows = 256;      // rows per wave tile
-constexpr int kHot = 32768;         // leading values of the packed vector kept in LDS (128 KiB)
-
-// ---- plan ---------------------------------------------------------------------------
-// Two tilings of the same row pointer are kept: workgroup tiles of <= kTileNnz nonzeros for
-// the row-block kernel and wave tiles of <= kWaveTile nonzeros / kWaveRows rows for the
-// hub-packed kernel.  A row longer than a tile is cut into slices that each produce one
-// partial, folded in slice order by the finalize kernel (deterministic, no atomics).
-static void cut_tiles(const std::vector<Index>& ptr, Index n, int tile_nnz, int max_rows, int slice,
-                      std::vector<SpmvBlock>* blocks, std::vector<int>* long_row,
-                      std::vector<int>* long_slot_ptr, int* nslots_out) {
-  int nslots = 0;
-  Index r = 0;
-  while (r < n) {
-    Index len = ptr[r + 1] - ptr[r];
-    if (len > tile_nnz) {
-      long_row->push_back(r);
-      long_slot_ptr->push_back(nslots);
-      for (Index s = ptr[r]; s < ptr[r + 1]; s += slice) {
-        Index e = s + slice < ptr[r + 1] ? s + slice : ptr[r + 1];
-        blocks->push_back(SpmvBlock{r, r + 1, s, e, nslots++});
-      }
-      ++r;
-      continue;
-    }
-    Index start = r, nnz = 0;
-    while (r < n && r - start < max_rows) {
-      Index l = ptr[r + 1] - ptr[r];
-      if (l > tile_nnz || nnz + l > tile_nnz) break;
-      nnz += l;
-      ++r;
-    }
-    blocks->push_back(SpmvBlock{start, r, ptr[start], ptr[r], -1});
-  }
-  long_slot_ptr->push_back(nslots);
-  *nslots_out = nslots;
+constexpr int kWaveTile = GRB_HUB_TILE;   // nonzeros per wave tile (8 per lane), 2 KiB of LDS per wave
+constexpr int kWaveRows = 64;       // rows per wave tile: lane r carries the pointers of row r
+constexpr int kHot = GRB_HUB_HOT;   // leading values of the packed vector kept in LDS (128 KiB)
+constexpr int kHubPerCu = 163840 / (4 * kHot + 4 * kHubWaves * kWaveTile);
+static_assert(kHubPerCu >= 1, "SpMV kernel LDS budget");
+template <typename V>
+__device__ inline V stream_load(const V* p) {
+#if GRB_HUB_NT
+  return __builtin_nontemporal_load(p);
+#else
+  return *p;
+#endif
 }
 
+// ---- plan ---------------------------------------------------------------------------
 template <typename V>
 static grb_info to_device(const std::vector<V>& h, V** d) {
   if (h.empty()) return GRB_SUCCESS;
@@ -82,42 +67,48 @@ static grb_info to_device(const std::vector<V>& h, V** d) {
 grb_info build_spmv_plan(const std::vector<Index>& ptr, Index n, Index nminor, SpmvPlan* plan) {
   free_spmv_plan(plan);
   plan->nminor = nminor;
-  {
-    std::vector<SpmvBlock> blocks;
-    std::vector<int> long_row, long_slot_ptr;
-    int nslots = 0;
-    cut_tiles(ptr, n, kTileNnz, kMaxRowsPerBlock, kLongSlice, &blocks, &long_row, &long_slot_ptr, &nslots);
-    plan->nblocks = (int)blocks.size();
-    plan->nlong = (int)long_row.size();
-    plan->nslots = nslots;
-    GRB_TRY(to_device(blocks, &plan->d_blocks));
-    if (plan->nlong) {
-      GRB_TRY(to_device(long_row, &plan->d_long_row));
-      GRB_TRY(to_device(long_slot_ptr, &plan->d_long_slot_ptr));
-      GRB_HIP_TRY(hipMalloc(&plan->d_partials, 4 * (size_t)nslots));
+  plan->nrows = n;
+  std::vector<SpmvBlock> tiles;
+  std::vector<int> long_row, long_slot_ptr;
+  int nslots = 0;
+  Index r = 0;
+  while (r < n) {
+    const Index len = ptr[r + 1] - ptr[r];
+    if (len > kWaveTile) {
+      long_row.push_back(r);
+      long_slot_ptr.push_back(nslots);
+      for (Index s = ptr[r]; s < ptr[r + 1]; s += kWaveTile) {
+        const Index e = s + kWaveTile < ptr[r + 1] ? s + kWaveTile : ptr[r + 1];
+        tiles.push_back(SpmvBlock{r, r + 1, s, e, nslots++});
+      }
+      ++r;
+      continue;
     }
+    const Index start = r;
+    Index nnz = 0;
+    while (r < n && r - start < kWaveRows) {
+      const Index l = ptr[r + 1] - ptr[r];
+      if (nnz + l > kWaveTile) break;
+      nnz += l;
+      ++r;
+    }
+    tiles.push_back(SpmvBlock{start, r, ptr[start], ptr[r], -1});
   }
-  {
-    std::vector<SpmvBlock> tiles;
-    std::vector<int> long_row, long_slot_ptr;
-    int nslots = 0;
-    cut_tiles(ptr, n, kWaveTile, kWaveRows, kWaveTile, &tiles, &long_row, &long_slot_ptr, &nslots);
-    plan->ntiles = (int)tiles.size();
-    plan->t_nlong = (int)long_row.size();
-    plan->t_nslots = nslots;
-    GRB_TRY(to_device(tiles, &plan->d_tiles));
-    if (plan->t_nlong) {
-      GRB_TRY(to_device(long_row, &plan->d_t_long_row));
-      GRB_TRY(to_device(long_slot_ptr, &plan->d_t_long_slot_ptr));
-      GRB_HIP_TRY(hipMalloc(&plan->d_t_partials, 4 * (size_t)nslots));
-    }
+  long_slot_ptr.push_back(nslots);
+  plan->ntiles = (int)tiles.size();
+  plan->nlong = (int)long_row.size();
+  plan->nslots = nslots;
+  GRB_TRY(to_device(tiles, &plan->d_tiles));
+  if (plan->nlong) {
+    GRB_TRY(to_device(long_row, &plan->d_long_row));
+    GRB_TRY(to_device(long_slot_ptr, &plan->d_long_slot_ptr));
+    GRB_HIP_TRY(hipMalloc(&plan->d_partials, 4 * (size_t)nslots));
   }
   return GRB_SUCCESS;
 }
 
 void free_spmv_plan(SpmvPlan* plan) {
-  void* ptrs[] = {plan->d_blocks, plan->d_long_row, plan->d_long_slot_ptr, plan->d_partials,
-                  plan->d_tiles, plan->d_t_long_row, plan->d_t_long_slot_ptr, plan->d_t_partials,
+  void* ptrs[] = {plan->d_tiles, plan->d_long_row, plan->d_long_slot_ptr, plan->d_partials,
                   plan->d_ind2, plan->d_order, plan->d_u2};
   for (void* q : ptrs)
     if (q) (void)hipFree(q);
@@ -187,6 +178,10 @@ static grb_info prepare_hub_packing(const CsrArrays& M, SpmvPlan& plan) {
     plan.nhot = 0;
     return GRB_SUCCESS;
   }
+  // columns nobody references sort last and are never gathered: they need no packing
+  Index nref = m;
+  while (nref > 0 && cnt[order[nref - 1]] == 0) --nref;
+  plan.npacked = nref;
   Index* d_rank = nullptr;
   GRB_TRY(to_device(rank, &d_rank));
   GRB_TRY(to_device(order, &plan.d_order));
@@ -199,6 +194,8 @@ static grb_info prepare_hub_packing(const CsrArrays& M, SpmvPlan& plan) {
   return GRB_SUCCESS;
 }
 
+// Epilogue shared by the SpMV kernels: mask -> identity where the mask FAILS
+// (spmv.hpp:203-212), then optional accumulate with the semiring's add (:213-220).
 template <int SR, typename T>
 __device__ inline void spmv_store(T* w, Index row, T value, const void* mask, int mask_f32, int scmp,
                                   int accum) {
@@ -208,87 +205,27 @@ __device__ inline void spmv_store(T* w, Index row, T value, const void* mask, in
   w[row] = value;
 }
 
+// A matrix without stored entries: every row is the empty sum.
 template <int SR, typename T>
-__global__ __launch_bounds__(kBlock) void spmv_stream_kernel(
-    const SpmvBlock* __restrict__ blocks, const Index* __restrict__ ptr, const Index* __restrict__ ind,
-    const T* __restrict__ val, const T* __restrict__ u, const void* __restrict__ mask, int mask_f32,
-    int scmp, int accum, T* w, T* __restrict__ partials) {
-  typedef Semiring<SR, T> S;
-  __shared__ T prod[kTileNnz];
-  __shared__ T wsum[kWavesPerBlock];
-  const SpmvBlock b = blocks[blockIdx.x];
-  const int tid = threadIdx.x;
-
-  if (b.slot >= 0) {
-    // slice of one long row: every thread folds a strided share, then a block fold
-    T acc = S::identity();
-    for (Index p = b.nnz_start + tid; p < b.nnz_end; p += kBlock)
-      acc = S::add(acc, S::mul(val[p], u[ind[p]]));
-    acc = wave_reduce(acc, [](T a, T c) { return S::add(a, c); });
-    if (lane_id() == 0) wsum[wave_id()] = acc;
-    __syncthreads();
-    if (tid == 0) {
-      T t = wsum[0];
-#pragma unroll
-      for (int k = 1; k < kWavesPerBlock; ++k) t = S::add(t, wsum[k]);
-      partials[b.slot] = t;
-    }
-    return;
-  }
-
-  // ---- stream the block's nonzeros: coalesced (ind, val), gathered u, product -> LDS
-  const int nnz = b.nnz_end - b.nnz_start;
-  constexpr int kPer = kTileNnz / kBlock;   // 8 independent loads in flight per lane
-  Index c[kPer];
-  T a[kPer];
-#pragma unroll
-  for (int k = 0; k < kPer; ++k) {
-    int o = tid + k * kBlock;
-    if (o < nnz) {
-      c[k] = ind[b.nnz_start + o];
-      a[k] = val[b.nnz_start + o];
-    }
-  }
-#pragma unroll
-  for (int k = 0; k < kPer; ++k) {
-    int o = tid + k * kBlock;
-    if (o < nnz) prod[o] = S::mul(a[k], u[c[k]]);
-  }
-  __syncthreads();
-
-  // ---- reduce rows out of LDS with L lanes per row (L adapted to the block's density)
-  const int nrows = b.row_end - b.row_start;
-  int L = 1;
-  {
-    int avg = nrows > 0 ? nnz / nrows : 0;
-    while (L < kWave && L * 4 < avg) L <<= 1;          // ~4 elements per lane
-    while (L < kWave && nrows * L * 2 <= kBlock) L <<= 1;  // few rows: use the idle lanes
-  }
-  const int groups = kBlock / L;
-  const int g = tid / L, l = tid % L;
-  for (int rr = g; rr < ((nrows + groups - 1) / groups) * groups; rr += groups) {
-    T acc = S::identity();
-    if (rr < nrows) {
-      const Index row = b.row_start + rr;
-      const int s = ptr[row] - b.nnz_start, e = ptr[row + 1] - b.nnz_start;
-      for (int i = s + l; i < e; i += L) acc = S::add(acc, prod[i]);
-    }
-    acc = group_reduce(acc, L, [](T x, T y) { return S::add(x, y); });
-    if (rr < nrows && l == 0) spmv_store<SR, T>(w, b.row_start + rr, acc, mask, mask_f32, scmp, accum);
-  }
+__global__ void spmv_empty_kernel(Index n, const void* __restrict__ mask, int mask_f32, int scmp, int accum, T* w) {
+  const Index i = (Index)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) spmv_store<SR, T>(w, i, Semiring<SR, T>::identity(), mask, mask_f32, scmp, accum);
 }
 
+constexpr int kFinalLanes = 16;   // lanes folding the partials of one long row
 template <int SR, typename T>
 __global__ void spmv_long_finalize_kernel(const int* __restrict__ long_row, const int* __restrict__ slot_ptr,
                                           int nlong, const T* __restrict__ partials,
                                           const void* __restrict__ mask, int mask_f32, int scmp, int accum,
                                           T* w) {
   typedef Semiring<SR, T> S;
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= nlong) return;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = t / kFinalLanes, l = t % kFinalLanes;
   T acc = S::identity();
-  for (int s = slot_ptr[i]; s < slot_ptr[i + 1]; ++s) acc = S::add(acc, partials[s]);
-  spmv_store<SR, T>(w, long_row[i], acc, mask, mask_f32, scmp, accum);
+  if (i < nlong)
+    for (int s = slot_ptr[i] + l; s < slot_ptr[i + 1]; s += kFinalLanes) acc = S::add(acc, partials[s]);
+  acc = group_reduce(acc, kFinalLanes, [](T x, T y) { return S::add(x, y); });
+  if (i < nlong && l == 0) spmv_store<SR, T>(w, long_row[i], acc, mask, mask_f32, scmp, accum);
 }
 
 // ---- hub-packed kernel ------------------------------------------------------------------
@@ -299,6 +236,11 @@ __global__ void spmv_long_finalize_kernel(const int* __restrict__ long_row, cons
 //            not push the vector out of L2;
 //   gather   column < nhot from LDS, the rest from global memory (L2 for the warm tail);
 //   reduce   products -> LDS, rows folded with L lanes per row (L adapted to the tile).
+// The streaming part is written without branches (clamped indices instead of predicates:
+// a lane past the end of its tile re-reads the tile's last element and contributes the
+// identity; a lane whose column is hot points its global gather at u[0], which coalesces to
+// one request) so that the sixteen stream loads and eight gathers of a tile are issued back to
+// back and the tile after it is already in flight while this one is reduced.
 template <int SR, typename T>
 __global__ __launch_bounds__(kHubThreads) void spmv_hub_kernel(
     const SpmvBlock* __restrict__ tiles, int ntiles, const Index* __restrict__ ptr,
@@ -314,114 +256,152 @@ __global__ __launch_bounds__(kHubThreads) void spmv_hub_kernel(
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   T* prod = stage[wave];
   constexpr int kPer = kWaveTile / kWave;
-  for (int t = blockIdx.x * kHubWaves + wave; t < ntiles; t += gridDim.x * kHubWaves) {
-    const SpmvBlock b = tiles[t];
-    const int nnz = b.nnz_end - b.nnz_start;
-    Index c[kPer];
-    T a[kPer];
-#pragma unroll
-    for (int k = 0; k < kPer; ++k) {
-      const int o = lane + k * kWave;
-      if (o < nnz) {
-        c[k] = __builtin_nontemporal_load(&ind[b.nnz_start + o]);
-        a[k] = __builtin_nontemporal_load(&val[b.nnz_start + o]);
-      }
-    }
-    if (b.slot >= 0) {                 // slice of a long row: fold in registers
-      T acc = S::identity();
-#pragma unroll
-      for (int k = 0; k < kPer; ++k) {
-        const int o = lane + k * kWave;
-        if (o < nnz) {
-          const T x = (unsigned)c[k] < (unsigned)nhot ? hot[c[k]] : u[c[k]];
-          acc = S::add(acc, S::mul(a[k], x));
-        }
-      }
-      acc = wave_reduce(acc, [](T p, T q) { return S::add(p, q); });
-      if (lane == 0) partials[b.slot] = acc;
-      continue;
-    }
-#pragma unroll
-    for (int k = 0; k < kPer; ++k) {
-      const int o = lane + k * kWave;
-      if (o < nnz) {
-        const T x = (unsigned)c[k] < (unsigned)nhot ? hot[c[k]] : u[c[k]];
-        prod[o] = S::mul(a[k], x);
-      }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    const int nrows = b.row_end - b.row_start;
-    int L = 1;
-    {
-      const int avg = nrows > 0 ? nnz / nrows : 0;
-      while (L < kWave && L * 4 < avg) L <<= 1;
-      while (L < kWave && nrows * L * 2 <= kWave) L <<= 1;
-    }
-    const int groups = kWave / L;
-    const int g = lane / L, l = lane % L;
-    for (int rr = g; rr < ((nrows + groups - 1) / groups) * groups; rr += groups) {
-      T acc = S::identity();
-      if (rr < nrows) {
-        const Index row = b.row_start + rr;
-        const int s = ptr[row] - b.nnz_start, e = ptr[row + 1] - b.nnz_start;
-        for (int i = s + l; i < e; i += L) acc = S::add(acc, prod[i]);
-      }
-      acc = group_reduce(acc, L, [](T x, T y) { return S::add(x, y); });
-      if (rr < nrows && l == 0) spmv_store<SR, T>(w, b.row_start + rr, acc, mask, mask_f32, scmp, accum);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-  }
-}
+  const int stride = gridDim.x * kHubWaves;
+  const int t0 = blockIdx.x * kHubWaves + wave;
+  if (t0 >= ntiles) return;
+  const int count = (ntiles - t0 + stride - 1) / stride;   // tiles of this wave
+  const int t_last = t0 + (count - 1) * stride;
+  const int hot_clamp = nhot > 0 ? nhot - 1 : 0;
+  auto tile_at = [&](int i) { const int t = t0 + i * stride; return tiles[t < t_last ? t : t_last]; };
 
-static bool spmv_use_legacy() {
-  static const bool v = [] { const char* e = getenv("GRB_SPMV_ROWBLOCK"); return e && atoi(e) != 0; }();
-  return v;
+  // Three tiles are in flight per wave: tile i is reduced out of registers/LDS while the
+  // gathers of tile i+1 and the (column, value, row pointer) stream of tile i+2 are
+  // outstanding; the only wait on memory is at the bottom of the loop.
+  SpmvBlock b0, b1, b2;          // reduce stage, gather stage, stream stage
+  T pr[kPer];                    // products of the reduce-stage tile
+  Index rlo0, rhi0;              // its row pointers, lane r holding row r
+  Index c1[kPer], rlo1, rhi1;
+  T a1[kPer];
+
+#define GRB_HUB_STREAM(B, C, A, RLO, RHI)                                  \
+  _Pragma("unroll") for (int k = 0; k < kPer; ++k) {                        \
+    int p = (B).nnz_start + lane + k * kWave;                               \
+    p = p < (B).nnz_end ? p : (B).nnz_end - 1;                              \
+    p = p > 0 ? p : 0;                                                      \
+    (C)[k] = stream_load(&ind[p]);                                          \
+    (A)[k] = stream_load(&val[p]);                                          \
+  }                                                                         \
+  {                                                                         \
+    const int r = (B).row_start + lane;                                     \
+    RLO = ptr[r < (B).row_end ? r : (B).row_end];                           \
+    RHI = ptr[r + 1 < (B).row_end ? r + 1 : (B).row_end];                   \
+  }
+#define GRB_HUB_COLD(C) ((unsigned)(C) >= (unsigned)nhot)
+#define GRB_HUB_LDS_INDEX(C) ((C) < hot_clamp ? (C) : hot_clamp)
+#define GRB_HUB_GATHER(C, XG, XL)                                                                  \
+  _Pragma("unroll") for (int k = 0; k < kPer; ++k) (XG)[k] = u[GRB_HUB_COLD((C)[k]) ? (C)[k] : 0];  \
+  _Pragma("unroll") for (int k = 0; k < kPer; ++k) (XL)[k] = hot[GRB_HUB_LDS_INDEX((C)[k])];
+#define GRB_HUB_PRODUCTS(B, C, A, XG, XL)                                               \
+  _Pragma("unroll") for (int k = 0; k < kPer; ++k) {                                     \
+    const T x = GRB_HUB_COLD((C)[k]) ? (XG)[k] : (XL)[k];                                \
+    pr[k] = lane + k * kWave < (B).nnz_end - (B).nnz_start ? S::mul((A)[k], x) : S::identity(); \
+  }
+
+  b0 = tile_at(0);
+  b1 = tile_at(1);
+  b2 = tile_at(2);
+  {
+    Index c0[kPer];
+    T a0[kPer], xg[kPer], xl[kPer];
+    GRB_HUB_STREAM(b0, c0, a0, rlo0, rhi0)
+    GRB_HUB_GATHER(c0, xg, xl)
+    asm volatile("" ::: "memory");
+    GRB_HUB_STREAM(b1, c1, a1, rlo1, rhi1)
+    asm volatile("" ::: "memory");
+    GRB_HUB_PRODUCTS(b0, c0, a0, xg, xl)
+  }
+  for (int i = 0; i < count; ++i) {
+    // ---- issue: gathers of tile i+1, stream of tile i+2, descriptor of tile i+3
+    T xg[kPer], xl[kPer];
+    Index c2[kPer], rlo2, rhi2;
+    T a2[kPer];
+    GRB_HUB_GATHER(c1, xg, xl)
+    asm volatile("" ::: "memory");
+    GRB_HUB_STREAM(b2, c2, a2, rlo2, rhi2)
+    asm volatile("" ::: "memory");
+    const SpmvBlock b3 = tile_at(i + 3);
+
+    // ---- reduce tile i (no global loads in here unless a mask / accumulate is requested)
+    const int nnz = b0.nnz_end - b0.nnz_start;
+    if (b0.slot >= 0) {                 // slice of a long row: fold in registers
+      T acc = pr[0];
+#pragma unroll
+      for (int k = 1; k < kPer; ++k) acc = S::add(acc, pr[k]);
+      acc = wave_reduce(acc, [](T p, T q) { return S::add(p, q); });
+      if (lane == 0) partials[b0.slot] = acc;
+    } else {
+#pragma unroll
+      for (int k = 0; k < kPer; ++k) prod[lane + k * kWave] = pr[k];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      const int nrows = b0.row_end - b0.row_start;
+      int L = 1;
+      {
+        const int avg = nrows > 0 ? nnz / nrows : 0;
+        while (L < kWave && L * 4 < avg) L <<= 1;
+        while (L < kWave && nrows * L * 2 <= kWave) L <<= 1;
+      }
+      const int groups = kWave / L;
+      const int g = lane / L, l = lane % L;
+      for (int base = 0; base < nrows; base += groups) {
+        const int rr = base + g;        // < 64 always: a tile holds at most kWaveRows rows
+        const int s = __shfl(rlo0, rr, kWave) - b0.nnz_start;
+        const int e = __shfl(rhi0, rr, kWave) - b0.nnz_start;
+        T acc = S::identity();
+        for (int q = s + l; q < e; q += L) acc = S::add(acc, prod[q]);
+        acc = group_reduce(acc, L, [](T p, T q) { return S::add(p, q); });
+        if (rr < nrows && l == 0) spmv_store<SR, T>(w, b0.row_start + rr, acc, mask, mask_f32, scmp, accum);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+
+    // ---- rotate: the gathers of tile i+1 land here
+    GRB_HUB_PRODUCTS(b1, c1, a1, xg, xl)
+    b0 = b1; rlo0 = rlo1; rhi0 = rhi1;
+    b1 = b2; rlo1 = rlo2; rhi1 = rhi2;
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) { c1[k] = c2[k]; a1[k] = a2[k]; }
+    b2 = b3;
+  }
+#undef GRB_HUB_STREAM
+#undef GRB_HUB_GATHER
+#undef GRB_HUB_PRODUCTS
+#undef GRB_HUB_COLD
+#undef GRB_HUB_LDS_INDEX
 }
 
 grb_info k_spmv(int sr, int dtype, const CsrArrays& M, SpmvPlan& plan, const void* u, const void* mask,
                 int mask_f32, int scmp, int accum, void* w) {
-  if (plan.nblocks == 0) return GRB_SUCCESS;
-  if (spmv_use_legacy()) {
-    return dispatch_semiring(sr, dtype, [&](auto tag, auto t) -> grb_info {
-      using T = decltype(t);
-      constexpr int SR = decltype(tag)::value;
-      hipLaunchKernelGGL((spmv_stream_kernel<SR, T>), dim3(plan.nblocks), dim3(kBlock), 0, ctx().stream,
-                         plan.d_blocks, M.ptr, M.ind, (const T*)M.val, (const T*)u, mask, mask_f32, scmp, accum,
-                         (T*)w, (T*)plan.d_partials);
-      GRB_HIP_TRY(hipGetLastError());
-      if (plan.nlong) {
-        hipLaunchKernelGGL((spmv_long_finalize_kernel<SR, T>), dim3(ceil_div(plan.nlong, kBlock)), dim3(kBlock), 0,
-                           ctx().stream, plan.d_long_row, plan.d_long_slot_ptr, plan.nlong,
-                           (const T*)plan.d_partials, mask, mask_f32, scmp, accum, (T*)w);
-        GRB_HIP_TRY(hipGetLastError());
-      }
-      return GRB_SUCCESS;
-    });
-  }
-  if (!plan.hub_ready) GRB_TRY(prepare_hub_packing(M, plan));
+  if (plan.ntiles == 0) return GRB_SUCCESS;
+  if (M.nvals > 0 && !plan.hub_ready) GRB_TRY(prepare_hub_packing(M, plan));
   return dispatch_semiring(sr, dtype, [&](auto tag, auto t) -> grb_info {
     using T = decltype(t);
     constexpr int SR = decltype(tag)::value;
+    if (M.nvals == 0) {
+      hipLaunchKernelGGL((spmv_empty_kernel<SR, T>), dim3(ceil_div(plan.nrows, kBlock)), dim3(kBlock), 0,
+                         ctx().stream, plan.nrows, mask, mask_f32, scmp, accum, (T*)w);
+      GRB_HIP_TRY(hipGetLastError());
+      return GRB_SUCCESS;
+    }
     const Index* ind = M.ind;
     const T* uu = (const T*)u;
     if (plan.d_ind2) {
-      hipLaunchKernelGGL((pack_vector_kernel<T>), dim3(ceil_div(plan.nminor, kBlock)), dim3(kBlock), 0, ctx().stream,
-                         (const T*)u, plan.d_order, plan.nminor, (T*)plan.d_u2);
+      hipLaunchKernelGGL((pack_vector_kernel<T>), dim3(ceil_div(plan.npacked, kBlock)), dim3(kBlock), 0,
+                         ctx().stream, (const T*)u, plan.d_order, plan.npacked, (T*)plan.d_u2);
       ind = plan.d_ind2;
       uu = (const T*)plan.d_u2;
     }
     int grid = ceil_div(plan.ntiles, kHubWaves);
-    if (grid > ctx().num_cu) grid = ctx().num_cu;
+    if (grid > ctx().num_cu * kHubPerCu) grid = ctx().num_cu * kHubPerCu;
     hipLaunchKernelGGL((spmv_hub_kernel<SR, T>), dim3(grid), dim3(kHubThreads), 0, ctx().stream, plan.d_tiles,
                        plan.ntiles, M.ptr, ind, (const T*)M.val, uu, plan.nhot, mask, mask_f32, scmp, accum, (T*)w,
-                       (T*)plan.d_t_partials);
+                       (T*)plan.d_partials);
     GRB_HIP_TRY(hipGetLastError());
-    if (plan.t_nlong) {
-      hipLaunchKernelGGL((spmv_long_finalize_kernel<SR, T>), dim3(ceil_div(plan.t_nlong, kBlock)), dim3(kBlock), 0,
-                         ctx().stream, plan.d_t_long_row, plan.d_t_long_slot_ptr, plan.t_nlong,
-                         (const T*)plan.d_t_partials, mask, mask_f32, scmp, accum, (T*)w);
+    if (plan.nlong) {
+      hipLaunchKernelGGL((spmv_long_finalize_kernel<SR, T>), dim3(ceil_div(plan.nlong * kFinalLanes, kBlock)),
+                         dim3(kBlock), 0, ctx().stream, plan.d_long_row, plan.d_long_slot_ptr, plan.nlong,
+                         (const T*)plan.d_partials, mask, mask_f32, scmp, accum, (T*)w);
       GRB_HIP_TRY(hipGetLastError());
     }
     return GRB_SUCCESS;
