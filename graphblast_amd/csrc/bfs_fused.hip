@@ -55,6 +55,11 @@ __global__ void bfs_unlabel_kernel(float* __restrict__ label, Index n, float bad
 
 using namespace grb;
 
+grb_info bfs_persistent_run(grb_vector v, grb_matrix A, grb_index source, grb_descriptor desc, int profile,
+                            grb_bfs_level* levels_out, int max_levels, int* levels, int* last_dir,
+                            long long* reached, unsigned long long* edges, Index* nf_left, bool* hit_cap,
+                            float* tight_ms);
+
 // TEPS numerator recomputed from the labels (only needed when max_niter cut the search)
 static grb_info bfs_tally_labels(const float* label, const Index* ptr, Index n, int64_t* edges, int32_t* reached) {
   Context& c = ctx();
@@ -94,6 +99,37 @@ extern "C" grb_info grb_bfs_fused(grb_vector v, grb_matrix A, grb_index source, 
 
   // vertices without in-edges, cached per matrix
   GRB_TRY(ensure_empty_rows(&A->d_no_in_edges, A->csc, s));
+  GRB_TRY(ensure_pull_hint(&A->d_pull_hint, A->csc, A->csr.ptr, s));
+
+  static const bool use_persistent = [] { const char* e = getenv("GRB_BFS_PERSISTENT"); return !e || atoi(e) != 0; }();
+  if (use_persistent) {
+    GRB_TRY(grb_vector_set_storage(v, GRB_DENSE));
+    int p_levels = 0, p_dir = 0;
+    long long p_reached = 0;
+    unsigned long long p_edges = 0;
+    Index p_nf = 0;
+    bool p_cap = false;
+    float p_ms = 0.f;
+    GRB_TRY(bfs_persistent_run(v, A, source, desc, profile, levels_out, max_levels, &p_levels, &p_dir, &p_reached,
+                               &p_edges, &p_nf, &p_cap, &p_ms));
+    desc->lastmxv = p_dir ? GRB_PULLONLY : GRB_PUSHONLY;
+    if (p_cap && p_nf > 0) {
+      hipLaunchKernelGGL(bfs_unlabel_kernel, dim3(stream_grid(n)), dim3(kBlock), 0, s, (float*)v->d_val, n,
+                         (float)(desc->max_niter + 1));
+      GRB_HIP_TRY(hipGetLastError());
+      int64_t e2 = 0; int32_t r2 = 0;
+      GRB_TRY(bfs_tally_labels((const float*)v->d_val, A->csr.ptr, n, &e2, &r2));
+      p_edges = (unsigned long long)e2; p_reached = r2;
+    }
+    if (result) {
+      result->levels = p_levels;
+      result->tight_ms = p_ms;
+      result->edges_traversed = (int64_t)p_edges;
+      result->reached = (int32_t)p_reached;
+    }
+    v->d_nnz = (Index)p_reached;
+    return GRB_SUCCESS;
+  }
 
   void *p_va, *p_vb, *p_q, *p_scan, *p_rs, *p_tiles, *p_bt;
   GRB_TRY(scratch(7, 4 * (size_t)nwords, &p_va));
@@ -203,12 +239,14 @@ extern "C" grb_info grb_bfs_fused(grb_vector v, grb_matrix A, grb_index source, 
       const int grid = stream_grid((long long)ceil_div(n, kWave) * kWave, kBlock);
       GRB_TRY(mark());
       if (count_inspected)
+        // accounting runs walk the lists in storage order (no hint) so that the inspected-edge
+        // count is the sequential early-exit count the oracle defines
         hipLaunchKernelGGL((bfs_pull_kernel<true>), dim3(grid), dim3(kBlock), 0, s, A->csc.ptr, A->csc.ind, n, vis,
-                           vis, A->d_no_in_edges, vis_alt, 0, label, (float)(iter + 1),
+                           vis, A->d_no_in_edges, (const Index*)nullptr, vis_alt, 0, label, (float)(iter + 1),
                            reinterpret_cast<unsigned long long*>(d_state + 2));
       else
         hipLaunchKernelGGL((bfs_pull_kernel<false>), dim3(grid), dim3(kBlock), 0, s, A->csc.ptr, A->csc.ind, n, vis,
-                           vis, A->d_no_in_edges, vis_alt, 0, label, (float)(iter + 1),
+                           vis, A->d_no_in_edges, A->d_pull_hint, vis_alt, 0, label, (float)(iter + 1),
                            (unsigned long long*)nullptr);
       GRB_HIP_TRY(hipGetLastError());
       GRB_TRY(mark());

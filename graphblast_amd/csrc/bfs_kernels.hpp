@@ -28,8 +28,8 @@ static __global__ __launch_bounds__(kBlock) void bfs_pull_kernel(
     const Index* __restrict__ ptr, const Index* __restrict__ ind, Index n,
     const unsigned int* __restrict__ vin /* visited bitmap indexed by NEIGHBOUR id */,
     const unsigned int* __restrict__ vin_own /* same bitmap at this row range's own words */,
-    const unsigned int* __restrict__ skip, unsigned int* __restrict__ vout, int only_new,
-    float* __restrict__ label, float new_label,
+    const unsigned int* __restrict__ skip, const Index* __restrict__ hint /* may be null */,
+    unsigned int* __restrict__ vout, int only_new, float* __restrict__ label, float new_label,
     unsigned long long* __restrict__ inspected_out /* profile only */) {
   __shared__ unsigned long long blk_inspected;
   const int lane = lane_id();
@@ -56,7 +56,13 @@ static __global__ __launch_bounds__(kBlock) void bfs_pull_kernel(
     }
     Index p = 0, e = 0;
     bool found = false;
-    if (active) {
+    if (active && hint) {
+      // the in-neighbour most likely to be in an early frontier, kept in a dense side array:
+      // a coalesced 4 B read instead of one adjacency-list cache line per vertex
+      if (kCountInspected) ++inspected;
+      found = bit_set(vin, hint[v]);
+    }
+    if (active && !found) {
       p = ptr[v];
       e = ptr[v + 1];
       const Index stop = (e - p > kPullProbe) ? p + kPullProbe : e;
@@ -204,6 +210,60 @@ static __global__ __launch_bounds__(kBlock) void bfs_level_tail_kernel(
     for (int k = 0; k < 6; ++k)
       __hip_atomic_store(&mail[k], tag | vals[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
+}
+
+// hint[v] = the entry of row v whose own degree (deg_ptr) is largest, -1 for an empty row.
+static __global__ __launch_bounds__(kBlock) void bfs_hint_kernel(
+    const Index* __restrict__ ptr, const Index* __restrict__ ind, Index n, const Index* __restrict__ deg_ptr,
+    Index* __restrict__ hint) {
+  constexpr int kSerial = 16;
+  const int lane = lane_id();
+  const Index nchunks = (n + kWave - 1) / kWave;
+  const Index nwaves = (Index)gridDim.x * kWavesPerBlock;
+  for (Index chunk = (Index)blockIdx.x * kWavesPerBlock + wave_id(); chunk < nchunks; chunk += nwaves) {
+    const Index v = chunk * kWave + lane;
+    Index p = 0, e = 0, best = -1;
+    int best_deg = -1;
+    if (v < n) { p = ptr[v]; e = ptr[v + 1]; }
+    const Index stop = (e - p > kSerial) ? p + kSerial : e;
+    for (; p < stop; ++p) {
+      const Index u = ind[p];
+      const int d = deg_ptr[u + 1] - deg_ptr[u];
+      if (d > best_deg) { best_deg = d; best = u; }
+    }
+    unsigned long long todo = __ballot(p < e);
+    while (todo) {
+      const int src = __ffsll((long long)todo) - 1;
+      todo &= todo - 1;
+      const Index rs = __shfl(p, src, kWave), re = __shfl(e, src, kWave);
+      Index wb = -1;
+      int wd = -1;
+      for (Index q = rs + lane; q < re; q += kWave) {
+        const Index u = ind[q];
+        const int d = deg_ptr[u + 1] - deg_ptr[u];
+        if (d > wd) { wd = d; wb = u; }
+      }
+      for (int o = kWave / 2; o > 0; o >>= 1) {
+        const int od = __shfl_xor(wd, o, kWave);
+        const Index ob = __shfl_xor(wb, o, kWave);
+        if (od > wd || (od == wd && ob < wb)) { wd = od; wb = ob; }
+      }
+      if (lane == src && wd > best_deg) { best_deg = wd; best = wb; }
+    }
+    if (v < n) hint[v] = best;
+  }
+}
+
+// Lazily built, cached per matrix: for every row of `M` its entry of largest degree.
+static inline grb_info ensure_pull_hint(Index** cache, const CsrArrays& M, const Index* deg_ptr, hipStream_t s) {
+  if (*cache) return GRB_SUCCESS;
+  GRB_HIP_TRY(hipMalloc((void**)cache, 4 * (size_t)(M.n > 0 ? M.n : 1)));
+  if (M.n > 0) {
+    hipLaunchKernelGGL(bfs_hint_kernel, dim3(stream_grid((long long)ceil_div(M.n, kWave) * kWave, kBlock)),
+                       dim3(kBlock), 0, s, M.ptr, M.ind, M.n, deg_ptr, *cache);
+    GRB_HIP_TRY(hipGetLastError());
+  }
+  return GRB_SUCCESS;
 }
 
 // Lazily built, cached per matrix: bitmap of rows of `M` without entries.

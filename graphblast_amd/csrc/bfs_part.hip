@@ -80,7 +80,7 @@ grb_info grb_bfs_part_pull(grb_matrix A_in, grb_index lo, grb_index n_global, co
   GRB_TRY(ensure_empty_rows(&A_in->d_empty_csr_rows, A_in->csr, s));
   const int grid = stream_grid((long long)ceil_div(n_local, kWave) * kWave, kBlock);
   hipLaunchKernelGGL((bfs_pull_kernel<false>), dim3(grid), dim3(kBlock), 0, s, A_in->csr.ptr, A_in->csr.ind, n_local,
-                     d_vis, d_vis + lo / 32, A_in->d_empty_csr_rows, d_new + lo / 32, 1, d_label_local, new_label,
+                     d_vis, d_vis + lo / 32, A_in->d_empty_csr_rows, (const Index*)nullptr, d_new + lo / 32, 1, d_label_local, new_label,
                      (unsigned long long*)nullptr);
   GRB_HIP_TRY(hipGetLastError());
   return GRB_SUCCESS;

@@ -1,0 +1,508 @@
+// bfs_persist.hip -- the whole direction-optimised BFS as ONE persistent launch.
+//
+// The level loop of bfs_fused.hip costs five to seven dependent kernel boundaries and one
+// host round trip per level; on RMAT-22 (six levels, 0.2 ms of expansion work) that is half
+// of the traversal.  Here one co-resident grid (one 1024-thread workgroup per CU) runs every
+// level: the direction decision of vxm/convert (operations.hpp:131-140, vector.hpp:291-323)
+// is evaluated redundantly by every workgroup from the level totals, levels are separated by
+// an XCD-hierarchical grid barrier (per-XCD arrival counters -> top counter -> generation
+// word; release before arriving, acquire after leaving), and the host sees one record at the
+// end.  Same labels, same per-level trace as the fused loop.
+//
+//   visited V[2]   bitmaps; pull reads V[cur] and writes V[cur^1] (= old | found), push sets
+//                  bits in V[cur] with atomicOr
+//   frontier F[3]  bitmap of the vertices the previous level discovered, three buffers in
+//                  rotation (read / being written / being cleared)
+//   push           frontier vertices are classified by out-degree: < 16 expanded by the lane
+//                  that found them, 16..511 by a wave (workgroup-local LDS list), >= 512 cut
+//                  into 1024-edge entries of a global list that whole workgroups consume.  The
+//                  number of such vertices is part of the previous level's totals, so the
+//                  extra listing pass (and its barrier) only runs when there are any.
+//   pull           as bfs_pull_kernel (hint probe, serial probes, wave-cooperative finish)
+//   totals         every workgroup writes {discovered, their out-degree sum, inspected, big}
+//                  into its slot; after the barrier every workgroup sums all slots
+#include "bfs_kernels.hpp"
+
+namespace grb {
+
+constexpr int kPThreads = 1024;
+constexpr int kPWaves = kPThreads / kWave;
+constexpr int kSmallDeg = 16;     // below: expanded inline by the discovering lane
+constexpr int kBigDeg = 512;      // from here: split into kBigChunk-edge entries for workgroups
+constexpr int kBigChunk = 1024;
+constexpr int kMedCap = 4096;     // LDS list of medium vertices per workgroup pass
+constexpr unsigned kSpinLimit = 1u << 22;
+
+struct PersistState {               // zeroed by the host before every launch
+  unsigned xcd_count[8][32];        // one 128 B line per counter
+  unsigned top_count[32];
+  unsigned gen[32];
+  unsigned abort_flag[32];
+  unsigned big_count[2][32];
+};
+
+struct PersistArgs {
+  const Index *optr, *oind;         // out-edges (CSR), walked by push
+  const Index *iptr, *iind;         // in-edges (CSC), walked by pull
+  const unsigned int* skip;         // vertices without in-edges
+  const Index* hint;                // best in-neighbour per vertex (nullptr in accounting runs)
+  Index n;
+  long long nnz;
+  Index source;
+  int mode;
+  float switchpoint, edgeswitch;
+  int max_niter;
+  int count_inspected;
+  float* label;
+  unsigned int* V[2];
+  unsigned int* F[3];
+  int2* big_list;
+  int big_cap;
+  unsigned long long* partials;     // [2][grid][4]
+  PersistState* st;
+  grb_bfs_level* rec;
+  int rec_cap;
+  unsigned long long* mail;         // pinned host granules {value, seq}
+  int seq;
+  float ticks_to_ms;
+  unsigned long long* trace;        // optional (GRB_BFS_TRACE): wall-clock stamps of workgroup 0
+};
+
+// ---- grid barrier ---------------------------------------------------------------------
+// Monotonic counters: generation g of a group of m arrivers completes when its counter
+// reaches m * g.  Returns false when the barrier was abandoned (spin bound hit somewhere).
+__device__ inline bool grid_sync(PersistState* st, unsigned& gen) {
+  __shared__ int s_ok;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned g = gen + 1;
+    const unsigned G = gridDim.x;
+    const unsigned x = blockIdx.x & 7u;
+    const unsigned groups = G < 8u ? G : 8u;
+    const unsigned members = (G - x + 7u) / 8u;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    const unsigned a = __hip_atomic_fetch_add(&st->xcd_count[x][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (a + 1u == members * g) {
+      const unsigned b = __hip_atomic_fetch_add(&st->top_count[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (b + 1u == groups * g) __hip_atomic_store(&st->gen[0], g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    unsigned spins = 0;
+    int ok = 1;
+    while (__hip_atomic_load(&st->gen[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < g) {
+      __builtin_amdgcn_s_sleep(2);
+      if (++spins > kSpinLimit ||
+          __hip_atomic_load(&st->abort_flag[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+        __hip_atomic_store(&st->abort_flag[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ok = 0;
+        break;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    s_ok = ok;
+  }
+  __syncthreads();
+  ++gen;
+  return s_ok != 0;
+}
+
+struct LevelCounters {
+  unsigned long long found = 0, deg = 0, inspected = 0, big = 0;
+};
+
+// a vertex was discovered: label it, account for it
+__device__ inline void discovered(const PersistArgs& a, Index v, float new_label, LevelCounters& c) {
+  a.label[v] = new_label;
+  const Index d = a.optr[v + 1] - a.optr[v];
+  ++c.found;
+  c.deg += (unsigned long long)d;
+  if (d >= kBigDeg) ++c.big;
+}
+
+__device__ inline void push_visit(const PersistArgs& a, unsigned int* V, unsigned int* Fn, Index dst,
+                                  float new_label, LevelCounters& c) {
+  const unsigned int bit = 1u << (dst & 31);
+  if (V[dst >> 5] & bit) return;                    // may be stale: the atomic decides
+  const unsigned int old = atomicOr(&V[dst >> 5], bit);
+  if (old & bit) return;
+  atomicOr(&Fn[dst >> 5], bit);
+  discovered(a, dst, new_label, c);
+}
+
+__global__ __launch_bounds__(kPThreads) void bfs_persistent_kernel(PersistArgs a) {
+  __shared__ unsigned long long s_red[kPWaves][4];
+  __shared__ unsigned long long s_tot[4];
+  __shared__ Index s_med[kMedCap];
+  __shared__ int s_nmed;
+  const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
+  const int G = gridDim.x;
+  const long long gtid = (long long)blockIdx.x * kPThreads + tid;
+  const long long gthreads = (long long)G * kPThreads;
+  const Index n = a.n;
+  const int nwords = 2 * ((n + 63) / 64);
+  PersistState* st = a.st;
+  unsigned gen = 0;
+  const unsigned long long t_start = wall_clock64();
+
+  // ---- init: labels, bitmaps, the source
+  for (long long i = gtid; i < n; i += gthreads) a.label[i] = (i == a.source) ? 1.f : 0.f;
+  for (long long i = gtid; i < nwords; i += gthreads) {
+    const unsigned int w = (i == (a.source >> 5)) ? (1u << (a.source & 31)) : 0u;
+    a.V[0][i] = w;
+    a.F[0][i] = w;
+    a.F[1][i] = 0u;
+    a.F[2][i] = 0u;
+  }
+  const Index src_deg = a.optr[a.source + 1] - a.optr[a.source];
+  if (gtid == 0 && src_deg >= kBigDeg) {
+    const int nch = (src_deg + kBigChunk - 1) / kBigChunk;
+    for (int k = 0; k < nch && k < a.big_cap; ++k) a.big_list[k] = make_int2(a.source, k);
+    st->big_count[1][0] = (unsigned)nch;            // level 1 (iter & 1 == 1) reads slot 1
+  }
+  if (!grid_sync(st, gen)) return;
+  int ntrace = 0;
+  auto stamp = [&]() { if (a.trace && gtid == 0 && ntrace < 255) a.trace[1 + ntrace++] = wall_clock64() - t_start; };
+  stamp();
+
+  // ---- level loop (all scalars below are identical in every workgroup)
+  Index nf = 1;
+  unsigned long long mf = (unsigned long long)src_deg;
+  unsigned long long nbig = src_deg >= kBigDeg ? 1 : 0;
+  bool big_listed = true;                           // the source's entries were written above
+  long long reached = 1;
+  unsigned long long edges_cum = mf;
+  bool f1_dense = (a.mode == GRB_PULLONLY);
+  float ratio_f1 = 0.f, ratio_f2 = 0.f;
+  int cur = 0, fcur = 0, levels = 0, last_dir = 0;
+  int iter = 1;
+  for (; iter <= a.max_niter; ++iter) {
+    const unsigned long long t_level = wall_clock64();
+    if (a.mode == GRB_PUSHPULL) {
+      const float ratio = (float)nf / (float)n;
+      if (!f1_dense) {
+        if (ratio > a.switchpoint && ratio > ratio_f1) f1_dense = true; else ratio_f1 = ratio;
+      } else {
+        if (ratio <= a.switchpoint && ratio < ratio_f1) f1_dense = false; else ratio_f1 = ratio;
+      }
+      if (!f1_dense && a.edgeswitch > 0.f && nf >= 32 &&
+          (double)mf > (double)a.edgeswitch * (double)a.nnz)
+        f1_dense = true;
+    } else {
+      f1_dense = (a.mode == GRB_PULLONLY);
+    }
+    const int fnext = (fcur + 1) % 3, fzero = (fcur + 2) % 3;
+    const unsigned int* Fc = a.F[fcur];
+    unsigned int* Fn = a.F[fnext];
+    const float new_label = (float)(iter + 1);
+    LevelCounters c;
+    // the frontier buffer of two levels ahead, and the entry counter of the next level
+    for (long long i = gtid; i < nwords; i += gthreads) a.F[fzero][i] = 0u;
+    if (gtid == 0) st->big_count[(iter + 1) & 1][0] = 0u;
+
+    if (!f1_dense) {
+      // ================= push =================
+      unsigned int* V = a.V[cur];
+      unsigned* bcount = &st->big_count[iter & 1][0];
+      if (nbig > 0 && !big_listed) {
+        // list the >= kBigDeg frontier vertices as 1024-edge entries (wave-aggregated append)
+        for (long long base = 0; base < nwords; base += gthreads) {
+          const long long i = base + gtid;
+          unsigned int w = (i < nwords) ? Fc[i] : 0u;
+          int mine = 0;
+          for (unsigned int t = w; t; t &= t - 1) {
+            const Index v = (Index)i * 32 + (__ffs((int)t) - 1);
+            const Index d = a.optr[v + 1] - a.optr[v];
+            if (d >= kBigDeg) mine += (d + kBigChunk - 1) / kBigChunk;
+          }
+          int incl = mine;
+#pragma unroll
+          for (int o = 1; o < kWave; o <<= 1) {
+            const int y = __shfl_up(incl, o, kWave);
+            if (lane >= o) incl += y;
+          }
+          const int total = __shfl(incl, kWave - 1, kWave);
+          if (total > 0) {
+            unsigned b0 = 0;
+            if (lane == 0) b0 = atomicAdd(bcount, (unsigned)total);
+            b0 = __shfl(b0, 0, kWave);
+            int at = (int)b0 + incl - mine;
+            for (unsigned int t = w; t; t &= t - 1) {
+              const Index v = (Index)i * 32 + (__ffs((int)t) - 1);
+              const Index d = a.optr[v + 1] - a.optr[v];
+              if (d >= kBigDeg)
+                for (int k = 0; k < (d + kBigChunk - 1) / kBigChunk; ++k, ++at)
+                  if (at < a.big_cap) a.big_list[at] = make_int2(v, k);
+            }
+          }
+        }
+        if (!grid_sync(st, gen)) return;
+      }
+      if (nbig > 0) {
+        int nent = (int)__hip_atomic_load(bcount, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (nent > a.big_cap) nent = a.big_cap;
+        for (int e = blockIdx.x; e < nent; e += G) {
+          const int2 ent = a.big_list[e];
+          const Index p = a.optr[ent.x] + ent.y * kBigChunk + tid;
+          if (p < a.optr[ent.x + 1]) push_visit(a, V, Fn, a.oind[p], new_label, c);
+        }
+      }
+      // the rest of the frontier: words interleaved over the workgroups
+      if (tid == 0) s_nmed = 0;
+      __syncthreads();
+      for (long long base = 0; base < nwords; base += gthreads) {
+        const long long i = (base / G + tid) * G + blockIdx.x;      // word index, stride G inside the WG
+        unsigned int w = (i < nwords) ? Fc[i] : 0u;
+        for (; w; w &= w - 1) {
+          const Index v = (Index)i * 32 + (__ffs((int)w) - 1);
+          const Index s = a.optr[v], e = a.optr[v + 1];
+          const Index d = e - s;
+          if (d >= kBigDeg) continue;
+          if (d >= kSmallDeg) {
+            const int slot = atomicAdd(&s_nmed, 1);
+            if (slot < kMedCap) { s_med[slot] = v; continue; }
+          }
+          for (Index p = s; p < e; ++p) push_visit(a, V, Fn, a.oind[p], new_label, c);
+        }
+        __syncthreads();
+        const int nm = s_nmed < kMedCap ? s_nmed : kMedCap;
+        for (int k = wave; k < nm; k += kPWaves) {
+          const Index v = s_med[k];
+          const Index e = a.optr[v + 1];
+          for (Index p = a.optr[v] + lane; p < e; p += kWave) push_visit(a, V, Fn, a.oind[p], new_label, c);
+        }
+        __syncthreads();
+        if (tid == 0) s_nmed = 0;
+        __syncthreads();
+      }
+      last_dir = 0;
+    } else {
+      // ================= pull =================
+      const unsigned int* vin = a.V[cur];
+      unsigned int* vout = a.V[cur ^ 1];
+      const Index* hint = a.count_inspected ? nullptr : a.hint;
+      const Index nchunks = (n + kWave - 1) / kWave;
+      const Index nwaves = (Index)G * kPWaves;
+      for (Index chunk = (Index)blockIdx.x * kPWaves + wave; chunk < nchunks; chunk += nwaves) {
+        const Index v = chunk * kWave + lane;
+        const unsigned int word = vin[(chunk << 1) + (lane >> 5)];
+        const bool was = ((word | a.skip[(chunk << 1) + (lane >> 5)]) >> (lane & 31)) & 1u;
+        const bool active = (v < n) && !was;
+        if (__ballot(active) == 0ull) {
+          if (lane == 0) { vout[chunk << 1] = word; Fn[chunk << 1] = 0u; }
+          if (lane == 32) { vout[(chunk << 1) + 1] = word; Fn[(chunk << 1) + 1] = 0u; }
+          continue;
+        }
+        Index p = 0, e = 0;
+        bool found = false;
+        if (active && hint) found = bit_set(vin, hint[v]);
+        if (active && !found) {
+          p = a.iptr[v];
+          e = a.iptr[v + 1];
+          const Index stop = (e - p > kPullProbe) ? p + kPullProbe : e;
+          for (; p < stop; ++p) {
+            ++c.inspected;
+            if (bit_set(vin, a.iind[p])) { found = true; break; }
+          }
+          if (found) p = e;
+        }
+        unsigned long long todo = __ballot(active && p < e);
+        while (todo) {
+          const int src = __ffsll((long long)todo) - 1;
+          todo &= todo - 1;
+          const Index rs = __shfl(p, src, kWave), re = __shfl(e, src, kWave);
+          bool any = false;
+          for (Index q = rs; q < re; q += kWave) {
+            bool h = false;
+            if (q + lane < re) h = bit_set(vin, a.iind[q + lane]);
+            const unsigned long long hb = __ballot(h);
+            if (lane == 0) {
+              const Index span = (re - q < kWave) ? re - q : kWave;
+              c.inspected += hb ? (unsigned long long)__ffsll((long long)hb) : (unsigned long long)span;
+            }
+            if (hb) { any = true; break; }
+          }
+          if (lane == src && any) found = true;
+        }
+        const unsigned long long fb = __ballot(found);
+        if (lane == 0) { vout[chunk << 1] = word | (unsigned int)(fb & 0xffffffffull); Fn[chunk << 1] = (unsigned int)(fb & 0xffffffffull); }
+        if (lane == 32) { vout[(chunk << 1) + 1] = word | (unsigned int)(fb >> 32); Fn[(chunk << 1) + 1] = (unsigned int)(fb >> 32); }
+        if (found) discovered(a, v, new_label, c);
+      }
+      last_dir = 1;
+    }
+
+    stamp();
+    // ---- level totals
+    auto add = [](unsigned long long x, unsigned long long y) { return x + y; };
+    unsigned long long r0 = wave_reduce(c.found, add), r1 = wave_reduce(c.deg, add);
+    unsigned long long r2 = wave_reduce(c.inspected, add), r3 = wave_reduce(c.big, add);
+    if (lane == 0) { s_red[wave][0] = r0; s_red[wave][1] = r1; s_red[wave][2] = r2; s_red[wave][3] = r3; }
+    __syncthreads();
+    unsigned long long* slots = a.partials + (size_t)(iter & 1) * G * 4;
+    if (tid < 4) {
+      unsigned long long t = 0;
+      for (int w = 0; w < kPWaves; ++w) t += s_red[w][tid];
+      slots[(size_t)blockIdx.x * 4 + tid] = t;
+    }
+    if (!grid_sync(st, gen)) return;
+    stamp();
+    unsigned long long q0 = 0, q1 = 0, q2 = 0, q3 = 0;
+    for (int j = tid; j < G; j += kPThreads) {
+      q0 += slots[(size_t)j * 4 + 0];
+      q1 += slots[(size_t)j * 4 + 1];
+      q2 += slots[(size_t)j * 4 + 2];
+      q3 += slots[(size_t)j * 4 + 3];
+    }
+    q0 = wave_reduce(q0, add); q1 = wave_reduce(q1, add); q2 = wave_reduce(q2, add); q3 = wave_reduce(q3, add);
+    if (lane == 0) { s_red[wave][0] = q0; s_red[wave][1] = q1; s_red[wave][2] = q2; s_red[wave][3] = q3; }
+    __syncthreads();
+    if (tid < 4) {
+      unsigned long long t = 0;
+      for (int w = 0; w < kPWaves; ++w) t += s_red[w][tid];
+      s_tot[tid] = t;
+    }
+    __syncthreads();
+    const unsigned long long tot_found = s_tot[0], tot_deg = s_tot[1], tot_insp = s_tot[2], tot_big = s_tot[3];
+    __syncthreads();
+
+    stamp();
+    if (gtid == 0 && levels < a.rec_cap) {
+      grb_bfs_level& L = a.rec[levels];
+      L.direction = f1_dense ? 1 : 0;
+      L.frontier = nf;
+      L.frontier_edges = f1_dense ? (a.count_inspected ? (int64_t)tot_insp : 0) : (int64_t)mf;
+      L.discovered = (int32_t)tot_found;
+      L.ms = (float)(wall_clock64() - t_level) * a.ticks_to_ms;
+    }
+    ++levels;
+    reached += (long long)tot_found;
+    edges_cum += tot_deg;
+    if (f1_dense) cur ^= 1;
+    fcur = fnext;
+    const float tmp = ratio_f1; ratio_f1 = ratio_f2; ratio_f2 = tmp;
+    nf = (Index)tot_found;
+    mf = tot_deg;
+    nbig = tot_big;
+    big_listed = false;
+    if (nf == 0) break;
+  }
+
+  if (a.trace && gtid == 0) a.trace[0] = (unsigned long long)ntrace;
+  if (gtid == 0) {
+    const unsigned long long tag = (unsigned long long)(unsigned int)a.seq << 32;
+    const float ms = (float)(wall_clock64() - t_start) * a.ticks_to_ms;
+    const unsigned int vals[8] = {(unsigned int)levels, (unsigned int)last_dir, (unsigned int)reached,
+                                  (unsigned int)(edges_cum & 0xffffffffull), (unsigned int)(edges_cum >> 32),
+                                  (unsigned int)nf, (unsigned int)(iter > a.max_niter ? 1 : 0),
+                                  __float_as_uint(ms)};
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      __hip_atomic_store(&a.mail[k], tag | vals[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
+}  // namespace grb
+
+using namespace grb;
+
+// Runs the persistent traversal.  Outputs mirror what the fused loop keeps on the host.
+grb_info bfs_persistent_run(grb_vector v, grb_matrix A, grb_index source, grb_descriptor desc, int profile,
+                            grb_bfs_level* levels_out, int max_levels, int* levels, int* last_dir,
+                            long long* reached, unsigned long long* edges, Index* nf_left, bool* hit_cap,
+                            float* tight_ms) {
+  Context& c = ctx();
+  hipStream_t s = c.stream;
+  const Index n = A->nrows;
+  const int nwords = 2 * ceil_div(n, 64);
+  int wgs_per_cu = 1;
+  if (const char* e = getenv("GRB_BFS_WGS_PER_CU")) wgs_per_cu = atoi(e) >= 2 ? 2 : 1;
+  static int max_per_cu = 0;
+  if (!max_per_cu) {
+    GRB_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&max_per_cu, bfs_persistent_kernel, kPThreads, 0));
+    if (max_per_cu < 1) return GRB_PANIC;
+  }
+  if (wgs_per_cu > max_per_cu) wgs_per_cu = max_per_cu;
+  const int G = c.num_cu * wgs_per_cu;
+  const int rec_cap = 1024;
+  const int big_cap = (int)(A->nvals / kBigDeg) + 2;
+
+  void *p_v0, *p_v1, *p_f, *p_big, *p_part, *p_st, *p_rec;
+  GRB_TRY(scratch(7, 4 * (size_t)nwords, &p_v0));
+  GRB_TRY(scratch(8, 4 * (size_t)nwords, &p_v1));
+  GRB_TRY(scratch(9, 12 * (size_t)nwords, &p_f));
+  GRB_TRY(scratch(2, sizeof(int2) * (size_t)big_cap, &p_big));
+  GRB_TRY(scratch(3, 2 * (size_t)G * 4 * sizeof(unsigned long long), &p_part));
+  GRB_TRY(scratch(6, sizeof(PersistState), &p_st));
+  GRB_TRY(scratch(11, sizeof(grb_bfs_level) * (size_t)rec_cap, &p_rec));
+
+  static float ticks_to_ms = 0.f;
+  if (ticks_to_ms == 0.f) {
+    int khz = 0, dev = 0;
+    GRB_HIP_TRY(hipGetDevice(&dev));
+    GRB_HIP_TRY(hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev));
+    ticks_to_ms = khz > 0 ? 1.0f / (float)khz : 1e-5f;
+  }
+
+  PersistArgs a;
+  a.optr = A->csr.ptr; a.oind = A->csr.ind;
+  a.iptr = A->csc.ptr; a.iind = A->csc.ind;
+  a.skip = A->d_no_in_edges;
+  a.hint = A->d_pull_hint;
+  a.n = n;
+  a.nnz = A->nvals;
+  a.source = source;
+  a.mode = desc->desc[GRB_MXVMODE];
+  a.switchpoint = desc->switchpoint;
+  a.edgeswitch = desc->edgeswitch;
+  a.max_niter = desc->max_niter;
+  a.count_inspected = (profile & 2) ? 1 : 0;
+  a.label = (float*)v->d_val;
+  a.V[0] = (unsigned int*)p_v0; a.V[1] = (unsigned int*)p_v1;
+  a.F[0] = (unsigned int*)p_f; a.F[1] = a.F[0] + nwords; a.F[2] = a.F[1] + nwords;
+  a.big_list = (int2*)p_big;
+  a.big_cap = big_cap;
+  a.partials = (unsigned long long*)p_part;
+  a.st = (PersistState*)p_st;
+  a.rec = (grb_bfs_level*)p_rec;
+  a.rec_cap = rec_cap;
+  a.mail = c.d_hgran;
+  a.seq = ++c.mail_seq;
+  a.ticks_to_ms = ticks_to_ms;
+  static const bool want_trace = getenv("GRB_BFS_TRACE") != nullptr;
+  a.trace = nullptr;
+  if (want_trace) {
+    void* p_tr;
+    GRB_TRY(scratch(10, 256 * sizeof(unsigned long long), &p_tr));
+    a.trace = (unsigned long long*)p_tr;
+  }
+
+  GRB_HIP_TRY(hipMemsetAsync(p_st, 0, sizeof(PersistState), s));
+  hipLaunchKernelGGL(bfs_persistent_kernel, dim3(G), dim3(kPThreads), 0, s, a);
+  GRB_HIP_TRY(hipGetLastError());
+  unsigned int gv[8];
+  GRB_TRY(wait_granules(a.seq, 8, gv));
+  *levels = (int)gv[0];
+  *last_dir = (int)gv[1];
+  *reached = (long long)gv[2];
+  *edges = ((unsigned long long)gv[4] << 32) | gv[3];
+  *nf_left = (Index)gv[5];
+  *hit_cap = gv[6] != 0;
+  float ms;
+  memcpy(&ms, &gv[7], 4);
+  *tight_ms = ms;
+  if (a.trace) {
+    unsigned long long h[256];
+    GRB_HIP_TRY(hipMemcpyAsync(h, a.trace, sizeof(h), hipMemcpyDeviceToHost, s));
+    GRB_HIP_TRY(hipStreamSynchronize(s));
+    fprintf(stderr, "bfs trace (us since kernel start; init, then per level: expanded / barrier / totals):");
+    for (unsigned long long i = 0; i < h[0] && i < 255; ++i) fprintf(stderr, " %.1f", (double)h[1 + i] * ticks_to_ms * 1e3);
+    fprintf(stderr, "\n");
+  }
+  if (levels_out && max_levels > 0) {
+    const int k = *levels < max_levels ? (*levels < rec_cap ? *levels : rec_cap) : max_levels;
+    if (k > 0) {
+      GRB_HIP_TRY(hipMemcpyAsync(levels_out, p_rec, sizeof(grb_bfs_level) * (size_t)k, hipMemcpyDeviceToHost, s));
+      GRB_HIP_TRY(hipStreamSynchronize(s));
+    }
+  }
+  return GRB_SUCCESS;
+}

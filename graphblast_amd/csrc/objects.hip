@@ -636,6 +636,7 @@ static void matrix_release_device(grb_matrix A) {
   A->csc = CsrArrays();
   if (A->d_no_in_edges) { (void)hipFree(A->d_no_in_edges); A->d_no_in_edges = nullptr; }
   if (A->d_empty_csr_rows) { (void)hipFree(A->d_empty_csr_rows); A->d_empty_csr_rows = nullptr; }
+  if (A->d_pull_hint) { (void)hipFree(A->d_pull_hint); A->d_pull_hint = nullptr; }
   free_spmv_plan(&A->plan_csr);
   free_spmv_plan(&A->plan_csc);
   A->built = false;
