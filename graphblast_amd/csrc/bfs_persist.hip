@@ -39,6 +39,7 @@ struct PersistState {               // zeroed by the host before every launch
   unsigned gen[32];
   unsigned abort_flag[32];
   unsigned big_count[2][32];
+  unsigned long long acc[3][8][16]; // level totals, one line per (set, XCD group): found, deg, inspected, big
 };
 
 struct PersistArgs {
@@ -54,11 +55,10 @@ struct PersistArgs {
   int max_niter;
   int count_inspected;
   float* label;
-  unsigned int* V[2];
+  unsigned int* V[2];               // V[0] and F[0..2] are zeroed by the host with the state
   unsigned int* F[3];
   int2* big_list;
   int big_cap;
-  unsigned long long* partials;     // [2][grid][4]
   PersistState* st;
   grb_bfs_level* rec;
   int rec_cap;
@@ -68,11 +68,22 @@ struct PersistArgs {
   unsigned long long* trace;        // optional (GRB_BFS_TRACE): wall-clock stamps of workgroup 0
 };
 
+// Everything one workgroup writes for another to read goes out as an agent-scope
+// write-through store (or an atomic): the data is in memory when the store has completed,
+// which __syncthreads() waits for, so the barrier needs no L2 write-back on the way in --
+// only the L1/L2 invalidate on the way out (CDNA guide G16, recipe R1).  Labels are read by
+// nobody but the host and stay ordinary stores.
+template <typename V>
+__device__ inline void publish(V* p, V v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // ---- grid barrier ---------------------------------------------------------------------
 // Monotonic counters: generation g of a group of m arrivers completes when its counter
 // reaches m * g.  Returns false when the barrier was abandoned (spin bound hit somewhere).
 __device__ inline bool grid_sync(PersistState* st, unsigned& gen) {
   __shared__ int s_ok;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's write-through stores have landed
   __syncthreads();
   if (threadIdx.x == 0) {
     const unsigned g = gen + 1;
@@ -80,7 +91,6 @@ __device__ inline bool grid_sync(PersistState* st, unsigned& gen) {
     const unsigned x = blockIdx.x & 7u;
     const unsigned groups = G < 8u ? G : 8u;
     const unsigned members = (G - x + 7u) / 8u;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     const unsigned a = __hip_atomic_fetch_add(&st->xcd_count[x][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (a + 1u == members * g) {
       const unsigned b = __hip_atomic_fetch_add(&st->top_count[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -89,7 +99,7 @@ __device__ inline bool grid_sync(PersistState* st, unsigned& gen) {
     unsigned spins = 0;
     int ok = 1;
     while (__hip_atomic_load(&st->gen[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < g) {
-      __builtin_amdgcn_s_sleep(2);
+      __builtin_amdgcn_s_sleep(1);
       if (++spins > kSpinLimit ||
           __hip_atomic_load(&st->abort_flag[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
         __hip_atomic_store(&st->abort_flag[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -142,32 +152,22 @@ __global__ __launch_bounds__(kPThreads) void bfs_persistent_kernel(PersistArgs a
   PersistState* st = a.st;
   unsigned gen = 0;
   const unsigned long long t_start = wall_clock64();
-
-  // ---- init: labels, bitmaps, the source
-  for (long long i = gtid; i < n; i += gthreads) a.label[i] = (i == a.source) ? 1.f : 0.f;
-  for (long long i = gtid; i < nwords; i += gthreads) {
-    const unsigned int w = (i == (a.source >> 5)) ? (1u << (a.source & 31)) : 0u;
-    a.V[0][i] = w;
-    a.F[0][i] = w;
-    a.F[1][i] = 0u;
-    a.F[2][i] = 0u;
-  }
-  const Index src_deg = a.optr[a.source + 1] - a.optr[a.source];
-  if (gtid == 0 && src_deg >= kBigDeg) {
-    const int nch = (src_deg + kBigChunk - 1) / kBigChunk;
-    for (int k = 0; k < nch && k < a.big_cap; ++k) a.big_list[k] = make_int2(a.source, k);
-    st->big_count[1][0] = (unsigned)nch;            // level 1 (iter & 1 == 1) reads slot 1
-  }
-  if (!grid_sync(st, gen)) return;
   int ntrace = 0;
   auto stamp = [&]() { if (a.trace && gtid == 0 && ntrace < 255) a.trace[1 + ntrace++] = wall_clock64() - t_start; };
-  stamp();
+
+  // ---- the source.  The bitmaps arrive zeroed; unreached labels are written at the very end,
+  // so the first level starts without a barrier (unless it is a pull, which must see the bit).
+  const Index src_deg = a.optr[a.source + 1] - a.optr[a.source];
+  if (gtid == 0) {
+    atomicOr(&a.V[0][a.source >> 5], 1u << (a.source & 31));
+    a.label[a.source] = 1.f;
+  }
+  if (a.mode == GRB_PULLONLY && !grid_sync(st, gen)) return;
 
   // ---- level loop (all scalars below are identical in every workgroup)
   Index nf = 1;
   unsigned long long mf = (unsigned long long)src_deg;
-  unsigned long long nbig = src_deg >= kBigDeg ? 1 : 0;
-  bool big_listed = true;                           // the source's entries were written above
+  unsigned long long nbig = 0;
   long long reached = 1;
   unsigned long long edges_cum = mf;
   bool f1_dense = (a.mode == GRB_PULLONLY);
@@ -194,84 +194,94 @@ __global__ __launch_bounds__(kPThreads) void bfs_persistent_kernel(PersistArgs a
     unsigned int* Fn = a.F[fnext];
     const float new_label = (float)(iter + 1);
     LevelCounters c;
-    // the frontier buffer of two levels ahead, and the entry counter of the next level
-    for (long long i = gtid; i < nwords; i += gthreads) a.F[fzero][i] = 0u;
-    if (gtid == 0) st->big_count[(iter + 1) & 1][0] = 0u;
+    // recycle: the frontier buffer of two levels ahead, the entry counter and the totals of
+    // the next level (nobody touches them during this one)
+    for (long long i = gtid; i < nwords; i += gthreads) publish(&a.F[fzero][i], 0u);
+    if (gtid == 0) publish(&st->big_count[(iter + 1) & 1][0], 0u);
+    if (blockIdx.x == 0 && tid < 32) publish(&st->acc[(iter + 1) % 3][tid >> 2][tid & 3], 0ull);
 
     if (!f1_dense) {
       // ================= push =================
       unsigned int* V = a.V[cur];
-      unsigned* bcount = &st->big_count[iter & 1][0];
-      if (nbig > 0 && !big_listed) {
-        // list the >= kBigDeg frontier vertices as 1024-edge entries (wave-aggregated append)
-        for (long long base = 0; base < nwords; base += gthreads) {
-          const long long i = base + gtid;
-          unsigned int w = (i < nwords) ? Fc[i] : 0u;
-          int mine = 0;
-          for (unsigned int t = w; t; t &= t - 1) {
-            const Index v = (Index)i * 32 + (__ffs((int)t) - 1);
-            const Index d = a.optr[v + 1] - a.optr[v];
-            if (d >= kBigDeg) mine += (d + kBigChunk - 1) / kBigChunk;
-          }
-          int incl = mine;
-#pragma unroll
-          for (int o = 1; o < kWave; o <<= 1) {
-            const int y = __shfl_up(incl, o, kWave);
-            if (lane >= o) incl += y;
-          }
-          const int total = __shfl(incl, kWave - 1, kWave);
-          if (total > 0) {
-            unsigned b0 = 0;
-            if (lane == 0) b0 = atomicAdd(bcount, (unsigned)total);
-            b0 = __shfl(b0, 0, kWave);
-            int at = (int)b0 + incl - mine;
+      if (iter == 1) {
+        // the frontier is the source alone: its edges spread over the whole grid
+        const Index e = a.optr[a.source + 1];
+        for (long long p = a.optr[a.source] + gtid; p < e; p += gthreads) {
+          const Index dst = a.oind[p];
+          if (dst != a.source) push_visit(a, V, Fn, dst, new_label, c);
+        }
+      } else {
+        unsigned* bcount = &st->big_count[iter & 1][0];
+        if (nbig > 0) {
+          // list the >= kBigDeg frontier vertices as 1024-edge entries (wave-aggregated append)
+          for (long long base = 0; base < nwords; base += gthreads) {
+            const long long i = base + gtid;
+            const unsigned int w = (i < nwords) ? Fc[i] : 0u;
+            int mine = 0;
             for (unsigned int t = w; t; t &= t - 1) {
               const Index v = (Index)i * 32 + (__ffs((int)t) - 1);
               const Index d = a.optr[v + 1] - a.optr[v];
-              if (d >= kBigDeg)
-                for (int k = 0; k < (d + kBigChunk - 1) / kBigChunk; ++k, ++at)
-                  if (at < a.big_cap) a.big_list[at] = make_int2(v, k);
+              if (d >= kBigDeg) mine += (d + kBigChunk - 1) / kBigChunk;
+            }
+            int incl = mine;
+#pragma unroll
+            for (int o = 1; o < kWave; o <<= 1) {
+              const int y = __shfl_up(incl, o, kWave);
+              if (lane >= o) incl += y;
+            }
+            const int total = __shfl(incl, kWave - 1, kWave);
+            if (total > 0) {
+              unsigned b0 = 0;
+              if (lane == 0) b0 = atomicAdd(bcount, (unsigned)total);
+              b0 = __shfl(b0, 0, kWave);
+              int at = (int)b0 + incl - mine;
+              for (unsigned int t = w; t; t &= t - 1) {
+                const Index v = (Index)i * 32 + (__ffs((int)t) - 1);
+                const Index d = a.optr[v + 1] - a.optr[v];
+                if (d >= kBigDeg)
+                  for (int k = 0; k < (d + kBigChunk - 1) / kBigChunk; ++k, ++at)
+                    if (at < a.big_cap) publish(reinterpret_cast<unsigned long long*>(&a.big_list[at]),
+                                                ((unsigned long long)(unsigned)k << 32) | (unsigned)v);
+              }
             }
           }
-        }
-        if (!grid_sync(st, gen)) return;
-      }
-      if (nbig > 0) {
-        int nent = (int)__hip_atomic_load(bcount, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (nent > a.big_cap) nent = a.big_cap;
-        for (int e = blockIdx.x; e < nent; e += G) {
-          const int2 ent = a.big_list[e];
-          const Index p = a.optr[ent.x] + ent.y * kBigChunk + tid;
-          if (p < a.optr[ent.x + 1]) push_visit(a, V, Fn, a.oind[p], new_label, c);
-        }
-      }
-      // the rest of the frontier: words interleaved over the workgroups
-      if (tid == 0) s_nmed = 0;
-      __syncthreads();
-      for (long long base = 0; base < nwords; base += gthreads) {
-        const long long i = (base / G + tid) * G + blockIdx.x;      // word index, stride G inside the WG
-        unsigned int w = (i < nwords) ? Fc[i] : 0u;
-        for (; w; w &= w - 1) {
-          const Index v = (Index)i * 32 + (__ffs((int)w) - 1);
-          const Index s = a.optr[v], e = a.optr[v + 1];
-          const Index d = e - s;
-          if (d >= kBigDeg) continue;
-          if (d >= kSmallDeg) {
-            const int slot = atomicAdd(&s_nmed, 1);
-            if (slot < kMedCap) { s_med[slot] = v; continue; }
+          if (!grid_sync(st, gen)) return;
+          int nent = (int)__hip_atomic_load(bcount, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (nent > a.big_cap) nent = a.big_cap;
+          for (int e = blockIdx.x; e < nent; e += G) {
+            const int2 ent = a.big_list[e];
+            const Index p = a.optr[ent.x] + ent.y * kBigChunk + tid;
+            if (p < a.optr[ent.x + 1]) push_visit(a, V, Fn, a.oind[p], new_label, c);
           }
-          for (Index p = s; p < e; ++p) push_visit(a, V, Fn, a.oind[p], new_label, c);
         }
-        __syncthreads();
-        const int nm = s_nmed < kMedCap ? s_nmed : kMedCap;
-        for (int k = wave; k < nm; k += kPWaves) {
-          const Index v = s_med[k];
-          const Index e = a.optr[v + 1];
-          for (Index p = a.optr[v] + lane; p < e; p += kWave) push_visit(a, V, Fn, a.oind[p], new_label, c);
-        }
-        __syncthreads();
+        // the rest of the frontier: words interleaved over the workgroups
         if (tid == 0) s_nmed = 0;
         __syncthreads();
+        for (long long base = 0; base < nwords; base += gthreads) {
+          const long long i = (base / G + tid) * G + blockIdx.x;      // word index, stride G inside the WG
+          unsigned int w = (i < nwords) ? Fc[i] : 0u;
+          for (; w; w &= w - 1) {
+            const Index v = (Index)i * 32 + (__ffs((int)w) - 1);
+            const Index s = a.optr[v], e = a.optr[v + 1];
+            const Index d = e - s;
+            if (d >= kBigDeg) continue;
+            if (d >= kSmallDeg) {
+              const int slot = atomicAdd(&s_nmed, 1);
+              if (slot < kMedCap) { s_med[slot] = v; continue; }
+            }
+            for (Index p = s; p < e; ++p) push_visit(a, V, Fn, a.oind[p], new_label, c);
+          }
+          __syncthreads();
+          const int nm = s_nmed < kMedCap ? s_nmed : kMedCap;
+          for (int k = wave; k < nm; k += kPWaves) {
+            const Index v = s_med[k];
+            const Index e = a.optr[v + 1];
+            for (Index p = a.optr[v] + lane; p < e; p += kWave) push_visit(a, V, Fn, a.oind[p], new_label, c);
+          }
+          __syncthreads();
+          if (tid == 0) s_nmed = 0;
+          __syncthreads();
+        }
       }
       last_dir = 0;
     } else {
@@ -287,8 +297,10 @@ __global__ __launch_bounds__(kPThreads) void bfs_persistent_kernel(PersistArgs a
         const bool was = ((word | a.skip[(chunk << 1) + (lane >> 5)]) >> (lane & 31)) & 1u;
         const bool active = (v < n) && !was;
         if (__ballot(active) == 0ull) {
-          if (lane == 0) { vout[chunk << 1] = word; Fn[chunk << 1] = 0u; }
-          if (lane == 32) { vout[(chunk << 1) + 1] = word; Fn[(chunk << 1) + 1] = 0u; }
+          if (lane == 0 || lane == 32) {
+            publish(&vout[(chunk << 1) + (lane >> 5)], word);
+            publish(&Fn[(chunk << 1) + (lane >> 5)], 0u);
+          }
           continue;
         }
         Index p = 0, e = 0;
@@ -323,47 +335,41 @@ __global__ __launch_bounds__(kPThreads) void bfs_persistent_kernel(PersistArgs a
           if (lane == src && any) found = true;
         }
         const unsigned long long fb = __ballot(found);
-        if (lane == 0) { vout[chunk << 1] = word | (unsigned int)(fb & 0xffffffffull); Fn[chunk << 1] = (unsigned int)(fb & 0xffffffffull); }
-        if (lane == 32) { vout[(chunk << 1) + 1] = word | (unsigned int)(fb >> 32); Fn[(chunk << 1) + 1] = (unsigned int)(fb >> 32); }
+        if (lane == 0 || lane == 32) {
+          const unsigned int nb = (unsigned int)(lane ? (fb >> 32) : (fb & 0xffffffffull));
+          publish(&vout[(chunk << 1) + (lane >> 5)], word | nb);
+          publish(&Fn[(chunk << 1) + (lane >> 5)], nb);
+        }
         if (found) discovered(a, v, new_label, c);
       }
       last_dir = 1;
     }
 
     stamp();
-    // ---- level totals
+    // ---- level totals: one atomic per value per workgroup into this XCD group's line
     auto add = [](unsigned long long x, unsigned long long y) { return x + y; };
     unsigned long long r0 = wave_reduce(c.found, add), r1 = wave_reduce(c.deg, add);
     unsigned long long r2 = wave_reduce(c.inspected, add), r3 = wave_reduce(c.big, add);
     if (lane == 0) { s_red[wave][0] = r0; s_red[wave][1] = r1; s_red[wave][2] = r2; s_red[wave][3] = r3; }
     __syncthreads();
-    unsigned long long* slots = a.partials + (size_t)(iter & 1) * G * 4;
+    unsigned long long* acc = &st->acc[iter % 3][0][0];
     if (tid < 4) {
       unsigned long long t = 0;
       for (int w = 0; w < kPWaves; ++w) t += s_red[w][tid];
-      slots[(size_t)blockIdx.x * 4 + tid] = t;
+      if (t) __hip_atomic_fetch_add(&acc[(blockIdx.x & 7) * 16 + tid], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (!grid_sync(st, gen)) return;
     stamp();
-    unsigned long long q0 = 0, q1 = 0, q2 = 0, q3 = 0;
-    for (int j = tid; j < G; j += kPThreads) {
-      q0 += slots[(size_t)j * 4 + 0];
-      q1 += slots[(size_t)j * 4 + 1];
-      q2 += slots[(size_t)j * 4 + 2];
-      q3 += slots[(size_t)j * 4 + 3];
-    }
-    q0 = wave_reduce(q0, add); q1 = wave_reduce(q1, add); q2 = wave_reduce(q2, add); q3 = wave_reduce(q3, add);
-    if (lane == 0) { s_red[wave][0] = q0; s_red[wave][1] = q1; s_red[wave][2] = q2; s_red[wave][3] = q3; }
-    __syncthreads();
-    if (tid < 4) {
-      unsigned long long t = 0;
-      for (int w = 0; w < kPWaves; ++w) t += s_red[w][tid];
-      s_tot[tid] = t;
+    if (wave == 0) {
+      unsigned long long q = 0;
+      if (lane < 32) q = __hip_atomic_load(&acc[(lane >> 2) * 16 + (lane & 3)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      q += __shfl_xor(q, 4, kWave);
+      q += __shfl_xor(q, 8, kWave);
+      q += __shfl_xor(q, 16, kWave);
+      if (lane < 4) s_tot[lane] = q;
     }
     __syncthreads();
     const unsigned long long tot_found = s_tot[0], tot_deg = s_tot[1], tot_insp = s_tot[2], tot_big = s_tot[3];
-    __syncthreads();
-
     stamp();
     if (gtid == 0 && levels < a.rec_cap) {
       grb_bfs_level& L = a.rec[levels];
@@ -382,10 +388,16 @@ __global__ __launch_bounds__(kPThreads) void bfs_persistent_kernel(PersistArgs a
     nf = (Index)tot_found;
     mf = tot_deg;
     nbig = tot_big;
-    big_listed = false;
     if (nf == 0) break;
   }
 
+  // ---- labels of everything never reached (V[cur] is final and visible after the last barrier)
+  {
+    const unsigned int* Vf = a.V[cur];
+    for (long long i = gtid; i < n; i += gthreads)
+      if (!((Vf[i >> 5] >> (i & 31)) & 1u)) a.label[i] = 0.f;
+  }
+  stamp();
   if (a.trace && gtid == 0) a.trace[0] = (unsigned long long)ntrace;
   if (gtid == 0) {
     const unsigned long long tag = (unsigned long long)(unsigned int)a.seq << 32;
@@ -425,14 +437,16 @@ grb_info bfs_persistent_run(grb_vector v, grb_matrix A, grb_index source, grb_de
   const int rec_cap = 1024;
   const int big_cap = (int)(A->nvals / kBigDeg) + 2;
 
-  void *p_v0, *p_v1, *p_f, *p_big, *p_part, *p_st, *p_rec;
-  GRB_TRY(scratch(7, 4 * (size_t)nwords, &p_v0));
+  // one allocation, one memset: [state | V0 | F0 | F1 | F2]
+  const size_t st_bytes = (sizeof(PersistState) + 255) & ~(size_t)255;
+  const size_t zero_bytes = st_bytes + 16 * (size_t)nwords;
+  void *p_zero, *p_v1, *p_big, *p_rec;
+  GRB_TRY(scratch(7, zero_bytes, &p_zero));
   GRB_TRY(scratch(8, 4 * (size_t)nwords, &p_v1));
-  GRB_TRY(scratch(9, 12 * (size_t)nwords, &p_f));
   GRB_TRY(scratch(2, sizeof(int2) * (size_t)big_cap, &p_big));
-  GRB_TRY(scratch(3, 2 * (size_t)G * 4 * sizeof(unsigned long long), &p_part));
-  GRB_TRY(scratch(6, sizeof(PersistState), &p_st));
   GRB_TRY(scratch(11, sizeof(grb_bfs_level) * (size_t)rec_cap, &p_rec));
+  void* p_st = p_zero;
+  unsigned int* p_v0 = (unsigned int*)((char*)p_zero + st_bytes);
 
   static float ticks_to_ms = 0.f;
   if (ticks_to_ms == 0.f) {
@@ -456,11 +470,10 @@ grb_info bfs_persistent_run(grb_vector v, grb_matrix A, grb_index source, grb_de
   a.max_niter = desc->max_niter;
   a.count_inspected = (profile & 2) ? 1 : 0;
   a.label = (float*)v->d_val;
-  a.V[0] = (unsigned int*)p_v0; a.V[1] = (unsigned int*)p_v1;
-  a.F[0] = (unsigned int*)p_f; a.F[1] = a.F[0] + nwords; a.F[2] = a.F[1] + nwords;
+  a.V[0] = p_v0; a.V[1] = (unsigned int*)p_v1;
+  a.F[0] = p_v0 + nwords; a.F[1] = a.F[0] + nwords; a.F[2] = a.F[1] + nwords;
   a.big_list = (int2*)p_big;
   a.big_cap = big_cap;
-  a.partials = (unsigned long long*)p_part;
   a.st = (PersistState*)p_st;
   a.rec = (grb_bfs_level*)p_rec;
   a.rec_cap = rec_cap;
@@ -475,7 +488,7 @@ grb_info bfs_persistent_run(grb_vector v, grb_matrix A, grb_index source, grb_de
     a.trace = (unsigned long long*)p_tr;
   }
 
-  GRB_HIP_TRY(hipMemsetAsync(p_st, 0, sizeof(PersistState), s));
+  GRB_HIP_TRY(hipMemsetAsync(p_zero, 0, zero_bytes, s));
   hipLaunchKernelGGL(bfs_persistent_kernel, dim3(G), dim3(kPThreads), 0, s, a);
   GRB_HIP_TRY(hipGetLastError());
   unsigned int gv[8];

@@ -17,5 +17,6 @@ d = g.Descriptor(); d.loadArgs(mxvmode=0, struconly=1, opreuse=1, earlyexit=1, e
 srcs = random_sources(ptr.cpu().numpy(), 4, seed=0)
 v = g.Vector(n)
 for s in srcs + srcs:
-    info, r = g.bfs(v, A, int(s), d, fused=True)
-    print(s, r["levels"], "%.1f us" % (r["tight_ms"] * 1e3))
+    info, r = g.bfs(v, A, int(s), d, fused=True, profile=1)
+    print(s, r["levels"], "%.1f us" % (r["tight_ms"] * 1e3),
+          " ".join("%s:%d>%d:%.0fus" % (L["direction"][:2], L["frontier"], L["discovered"], L["ms"] * 1e3) for L in r["per_level"]))
