@@ -30,6 +30,7 @@ constexpr int kPWaves = kPThreads / kWave;
 constexpr int kSmallDeg = 16;     // below: expanded inline by the discovering lane
 constexpr int kBigDeg = 512;      // from here: split into kBigChunk-edge entries for workgroups
 constexpr int kBigChunk = 1024;
+constexpr int kPullGroup = 16;    // lanes finishing one undecided row in the pull phase
 constexpr int kMedCap = 4096;     // LDS list of medium vertices per workgroup pass
 constexpr unsigned kSpinLimit = 1u << 22;
 
@@ -245,7 +246,9 @@ __global__ __launch_bounds__(kPThreads) void bfs_persistent_kernel(PersistArgs a
               }
             }
           }
+          stamp();
           if (!grid_sync(st, gen)) return;
+          stamp();
           int nent = (int)__hip_atomic_load(bcount, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           if (nent > a.big_cap) nent = a.big_cap;
           for (int e = blockIdx.x; e < nent; e += G) {
@@ -254,6 +257,7 @@ __global__ __launch_bounds__(kPThreads) void bfs_persistent_kernel(PersistArgs a
             if (p < a.optr[ent.x + 1]) push_visit(a, V, Fn, a.oind[p], new_label, c);
           }
         }
+        stamp();
         // the rest of the frontier: words interleaved over the workgroups
         if (tid == 0) s_nmed = 0;
         __syncthreads();
@@ -316,23 +320,38 @@ __global__ __launch_bounds__(kPThreads) void bfs_persistent_kernel(PersistArgs a
           }
           if (found) p = e;
         }
+        // rows not decided by the serial probes: four at a time, 16 lanes on each
         unsigned long long todo = __ballot(active && p < e);
+        const int grp = lane >> 4, gl = lane & 15;
         while (todo) {
-          const int src = __ffsll((long long)todo) - 1;
-          todo &= todo - 1;
-          const Index rs = __shfl(p, src, kWave), re = __shfl(e, src, kWave);
-          bool any = false;
-          for (Index q = rs; q < re; q += kWave) {
-            bool h = false;
-            if (q + lane < re) h = bit_set(vin, a.iind[q + lane]);
-            const unsigned long long hb = __ballot(h);
-            if (lane == 0) {
-              const Index span = (re - q < kWave) ? re - q : kWave;
-              c.inspected += hb ? (unsigned long long)__ffsll((long long)hb) : (unsigned long long)span;
-            }
-            if (hb) { any = true; break; }
+          int mysrc = -1;
+          int srcs[kWave / kPullGroup];     // wave-uniform
+#pragma unroll
+          for (int g = 0; g < kWave / kPullGroup; ++g) {
+            srcs[g] = todo ? __ffsll((long long)todo) - 1 : -1;
+            if (todo) todo &= todo - 1;
+            if (g == grp) mysrc = srcs[g];
           }
-          if (lane == src && any) found = true;
+          const Index rs = __shfl(p, mysrc < 0 ? 0 : mysrc, kWave);
+          Index re = __shfl(e, mysrc < 0 ? 0 : mysrc, kWave);
+          if (mysrc < 0) re = rs;
+          bool done = false, any = false;
+          for (Index q = rs; __any(q < re && !done); q += kPullGroup) {
+            bool h = false;
+            const bool live = q < re && !done;
+            if (live && q + gl < re) h = bit_set(vin, a.iind[q + gl]);
+            const unsigned int hb = (unsigned int)(__ballot(h) >> (grp * kPullGroup)) & ((1u << kPullGroup) - 1u);
+            if (live && gl == 0) {
+              const Index span = (re - q < kPullGroup) ? re - q : kPullGroup;
+              c.inspected += hb ? (unsigned long long)__ffs((int)hb) : (unsigned long long)span;
+            }
+            if (live && hb) { any = true; done = true; }
+          }
+          // the row's owner lane learns the verdict of its group
+          const unsigned long long anyb = __ballot(any && gl == 0);
+#pragma unroll
+          for (int g = 0; g < kWave / kPullGroup; ++g)
+            if (lane == srcs[g] && ((anyb >> (g * kPullGroup)) & 1ull)) found = true;
         }
         const unsigned long long fb = __ballot(found);
         if (lane == 0 || lane == 32) {

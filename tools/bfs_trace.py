@@ -19,4 +19,4 @@ v = g.Vector(n)
 for s in srcs + srcs:
     info, r = g.bfs(v, A, int(s), d, fused=True, profile=1)
     print(s, r["levels"], "%.1f us" % (r["tight_ms"] * 1e3),
-          " ".join("%s:%d>%d:%.0fus" % (L["direction"][:2], L["frontier"], L["discovered"], L["ms"] * 1e3) for L in r["per_level"]))
+          " ".join("%s:%d(%d)>%d:%.0fus" % (L["direction"][:3], L["frontier"], L["frontier_edges"], L["discovered"], L["ms"] * 1e3) for L in r["per_level"]))
