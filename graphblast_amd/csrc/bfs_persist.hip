@@ -25,11 +25,15 @@
 
 namespace grb {
 
+#ifndef GRB_PULL_BLOCK
+#define GRB_PULL_BLOCK 8
+#endif
 constexpr int kPThreads = 1024;
 constexpr int kPWaves = kPThreads / kWave;
 constexpr int kSmallDeg = 16;     // below: expanded inline by the discovering lane
 constexpr int kBigDeg = 512;      // from here: split into kBigChunk-edge entries for workgroups
 constexpr int kBigChunk = 1024;
+constexpr int kPullBlock = GRB_PULL_BLOCK;    // chunks (of 64 vertices) one wave carries through the pull stages together
 constexpr int kPullGroup = 16;    // lanes finishing one undecided row in the pull phase
 constexpr int kMedCap = 4096;     // LDS list of medium vertices per workgroup pass
 constexpr unsigned kSpinLimit = 1u << 22;
@@ -144,6 +148,9 @@ __global__ __launch_bounds__(kPThreads) void bfs_persistent_kernel(PersistArgs a
   __shared__ unsigned long long s_tot[4];
   __shared__ Index s_med[kMedCap];
   __shared__ int s_nmed;
+  __shared__ int2 s_left[kPWaves][kPullBlock * kWave / 2];        // pull leftovers per wave: {next, end}
+  __shared__ unsigned short s_leftid[kPWaves][kPullBlock * kWave / 2];
+  __shared__ unsigned int s_leftfound[kPWaves][2 * kPullBlock];
   const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
   const int G = gridDim.x;
   const long long gtid = (long long)blockIdx.x * kPThreads + tid;
@@ -290,76 +297,163 @@ __global__ __launch_bounds__(kPThreads) void bfs_persistent_kernel(PersistArgs a
       last_dir = 0;
     } else {
       // ================= pull =================
+      // One wave owns a block of 16 chunks = 1024 vertices = 32 bitmap words and runs every
+      // stage for all 16 chunks at once, so a stage costs one memory latency per block instead
+      // of one per chunk:  words -> hint probe -> four serial probes -> leftovers -> outputs.
       const unsigned int* vin = a.V[cur];
       unsigned int* vout = a.V[cur ^ 1];
       const Index* hint = a.count_inspected ? nullptr : a.hint;
       const Index nchunks = (n + kWave - 1) / kWave;
+      const Index nblocks = (nchunks + kPullBlock - 1) / kPullBlock;
       const Index nwaves = (Index)G * kPWaves;
-      for (Index chunk = (Index)blockIdx.x * kPWaves + wave; chunk < nchunks; chunk += nwaves) {
-        const Index v = chunk * kWave + lane;
-        const unsigned int word = vin[(chunk << 1) + (lane >> 5)];
-        const bool was = ((word | a.skip[(chunk << 1) + (lane >> 5)]) >> (lane & 31)) & 1u;
-        const bool active = (v < n) && !was;
-        if (__ballot(active) == 0ull) {
-          if (lane == 0 || lane == 32) {
-            publish(&vout[(chunk << 1) + (lane >> 5)], word);
-            publish(&Fn[(chunk << 1) + (lane >> 5)], 0u);
-          }
+      const unsigned long long lt_mask = (1ull << lane) - 1ull;
+      for (Index blk = (Index)blockIdx.x * kPWaves + wave; blk < nblocks; blk += nwaves) {
+        // ---- stage 0: the block's 32 words; a lane's 16 vertices are vbase + 64 j
+        const Index wi = blk * (2 * kPullBlock) + lane;
+        const bool has_word = lane < 2 * kPullBlock && wi < nwords;
+        unsigned int vw = 0xffffffffu, inact = 0xffffffffu;
+        if (has_word) { vw = vin[wi]; inact = vw | a.skip[wi]; }
+        unsigned int act = 0;
+#pragma unroll
+        for (int j = 0; j < kPullBlock; ++j) {
+          const unsigned int wj = __shfl(inact, 2 * j + (lane >> 5), kWave);
+          act |= ((~wj >> (lane & 31)) & 1u) << j;
+        }
+        if (__ballot(act != 0u) == 0ull) {
+          if (has_word) publish(&vout[wi], vw);
           continue;
         }
-        Index p = 0, e = 0;
-        bool found = false;
-        if (active && hint) found = bit_set(vin, hint[v]);
-        if (active && !found) {
-          p = a.iptr[v];
-          e = a.iptr[v + 1];
-          const Index stop = (e - p > kPullProbe) ? p + kPullProbe : e;
-          for (; p < stop; ++p) {
-            ++c.inspected;
-            if (bit_set(vin, a.iind[p])) { found = true; break; }
-          }
-          if (found) p = e;
-        }
-        // rows not decided by the serial probes: four at a time, 16 lanes on each
-        unsigned long long todo = __ballot(active && p < e);
-        const int grp = lane >> 4, gl = lane & 15;
-        while (todo) {
-          int mysrc = -1;
-          int srcs[kWave / kPullGroup];     // wave-uniform
+        const Index vbase = blk * (kPullBlock * kWave) + lane;
+        unsigned int fnd = 0;
+        // ---- stage 1: the hinted in-neighbour of every active vertex
+        if (hint) {
+          Index hv[kPullBlock];
 #pragma unroll
-          for (int g = 0; g < kWave / kPullGroup; ++g) {
-            srcs[g] = todo ? __ffsll((long long)todo) - 1 : -1;
-            if (todo) todo &= todo - 1;
-            if (g == grp) mysrc = srcs[g];
+          for (int j = 0; j < kPullBlock; ++j) hv[j] = hint[((act >> j) & 1u) ? vbase + kWave * j : 0];
+#pragma unroll
+          for (int j = 0; j < kPullBlock; ++j) {
+            const unsigned int on = (act >> j) & 1u;
+            const unsigned int w = vin[on ? (hv[j] >> 5) : 0];
+            fnd |= (on & (w >> (hv[j] & 31)) & 1u) << j;
           }
-          const Index rs = __shfl(p, mysrc < 0 ? 0 : mysrc, kWave);
-          Index re = __shfl(e, mysrc < 0 ? 0 : mysrc, kWave);
-          if (mysrc < 0) re = rs;
-          bool done = false, any = false;
-          for (Index q = rs; __any(q < re && !done); q += kPullGroup) {
-            bool h = false;
-            const bool live = q < re && !done;
-            if (live && q + gl < re) h = bit_set(vin, a.iind[q + gl]);
-            const unsigned int hb = (unsigned int)(__ballot(h) >> (grp * kPullGroup)) & ((1u << kPullGroup) - 1u);
-            if (live && gl == 0) {
-              const Index span = (re - q < kPullGroup) ? re - q : kPullGroup;
-              c.inspected += hb ? (unsigned long long)__ffs((int)hb) : (unsigned long long)span;
+        }
+        unsigned int und = act & ~fnd;
+        if (__ballot(und != 0u)) {
+          // ---- stage 2: up to kPullProbe serial probes per undecided vertex
+          Index p[kPullBlock], e[kPullBlock];
+#pragma unroll
+          for (int j = 0; j < kPullBlock; ++j) {
+            const Index vj = ((und >> j) & 1u) ? vbase + kWave * j : 0;
+            p[j] = a.iptr[vj];
+            e[j] = a.iptr[vj + 1];
+          }
+#pragma unroll
+          for (int k = 0; k < kPullProbe; ++k) {
+            Index cidx[kPullBlock];
+            unsigned int need = 0;
+#pragma unroll
+            for (int j = 0; j < kPullBlock; ++j) {
+              const unsigned int nd = ((und >> j) & 1u) & (p[j] + k < e[j] ? 1u : 0u);
+              need |= nd << j;
+              cidx[j] = a.iind[nd ? p[j] + k : 0];
             }
-            if (live && hb) { any = true; done = true; }
-          }
-          // the row's owner lane learns the verdict of its group
-          const unsigned long long anyb = __ballot(any && gl == 0);
 #pragma unroll
-          for (int g = 0; g < kWave / kPullGroup; ++g)
-            if (lane == srcs[g] && ((anyb >> (g * kPullGroup)) & 1ull)) found = true;
+            for (int j = 0; j < kPullBlock; ++j) {
+              const unsigned int nd = (need >> j) & 1u;
+              const unsigned int w = vin[nd ? (cidx[j] >> 5) : 0];
+              const unsigned int hit = nd & (w >> (cidx[j] & 31)) & 1u;
+              fnd |= hit << j;
+              und &= ~(hit << j);
+            }
+            c.inspected += (unsigned long long)__popc(need);
+          }
+          // rows with nothing left are decided (not discoverable this level)
+#pragma unroll
+          for (int j = 0; j < kPullBlock; ++j)
+            if (p[j] + kPullProbe >= e[j]) und &= ~(1u << j);
+          // ---- leftovers: queue them in this wave's LDS region, then 16 lanes per row
+          if (__ballot(und != 0u)) {
+            int2* lq = s_left[wave];
+            unsigned int* lf = s_leftfound[wave];
+            if (lane < 2 * kPullBlock) lf[lane] = 0u;
+            const int grp = lane >> 4, gl = lane & 15;
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {      // the queue holds half a block's rows
+              int qn = 0;
+#pragma unroll
+              for (int jj = 0; jj < kPullBlock / 2; ++jj) {
+                const int j = half * (kPullBlock / 2) + jj;
+                const unsigned long long m = __ballot((und >> j) & 1u);
+                if ((und >> j) & 1u) {
+                  const int slot = qn + __popcll(m & lt_mask);
+                  lq[slot] = make_int2(p[j] + kPullProbe, e[j]);
+                  s_leftid[wave][slot] = (unsigned short)(j * kWave + lane);
+                }
+                qn += __popcll(m);
+              }
+              __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+              __builtin_amdgcn_wave_barrier();
+              for (int q0 = 0; q0 < qn; q0 += kWave / kPullGroup) {
+                const int qi = q0 + grp;
+                Index rs = 0, re = 0;
+                int id = 0;
+                if (qi < qn) { const int2 r = lq[qi]; rs = r.x; re = r.y; id = s_leftid[wave][qi]; }
+                bool done = false;
+                for (Index q = rs; __any(q < re && !done); q += kPullGroup) {
+                  bool h = false;
+                  const bool live = q < re && !done;
+                  if (live && q + gl < re) h = bit_set(vin, a.iind[q + gl]);
+                  const unsigned int hb = (unsigned int)(__ballot(h) >> (grp * kPullGroup)) & ((1u << kPullGroup) - 1u);
+                  if (live && gl == 0) {
+                    const Index span = (re - q < kPullGroup) ? re - q : kPullGroup;
+                    c.inspected += hb ? (unsigned long long)__ffs((int)hb) : (unsigned long long)span;
+                  }
+                  if (live && hb) {
+                    done = true;
+                    if (gl == 0) atomicOr(&lf[id >> 5], 1u << (id & 31));
+                  }
+                }
+              }
+              __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+              __builtin_amdgcn_wave_barrier();
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int j = 0; j < kPullBlock; ++j) fnd |= ((lf[2 * j + (lane >> 5)] >> (lane & 31)) & 1u) << j;
+            __builtin_amdgcn_wave_barrier();
+          }
         }
-        const unsigned long long fb = __ballot(found);
-        if (lane == 0 || lane == 32) {
-          const unsigned int nb = (unsigned int)(lane ? (fb >> 32) : (fb & 0xffffffffull));
-          publish(&vout[(chunk << 1) + (lane >> 5)], word | nb);
-          publish(&Fn[(chunk << 1) + (lane >> 5)], nb);
+        // ---- outputs: new words, labels, accounting
+        unsigned int nb = 0;
+#pragma unroll
+        for (int j = 0; j < kPullBlock; ++j) {
+          const unsigned long long fb = __ballot((fnd >> j) & 1u);
+          if ((lane >> 1) == j) nb = (lane & 1) ? (unsigned int)(fb >> 32) : (unsigned int)(fb & 0xffffffffull);
         }
-        if (found) discovered(a, v, new_label, c);
+        if (has_word) {
+          publish(&vout[wi], vw | nb);
+          if (nb) publish(&Fn[wi], nb);
+        }
+        if (__ballot(fnd != 0u)) {
+          Index d0[kPullBlock], d1[kPullBlock];
+#pragma unroll
+          for (int j = 0; j < kPullBlock; ++j) {
+            const bool f = (fnd >> j) & 1u;
+            const Index vj = f ? vbase + kWave * j : 0;
+            d0[j] = a.optr[vj];
+            d1[j] = a.optr[vj + 1];
+            if (f) a.label[vj] = new_label;
+          }
+#pragma unroll
+          for (int j = 0; j < kPullBlock; ++j)
+            if ((fnd >> j) & 1u) {
+              const Index d = d1[j] - d0[j];
+              ++c.found;
+              c.deg += (unsigned long long)d;
+              if (d >= kBigDeg) ++c.big;
+            }
+        }
       }
       last_dir = 1;
     }
