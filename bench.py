@@ -12,10 +12,11 @@ second over the K timed steps, whole job.  At N > 1 the graph is 1-D vertex part
 (graphblast_amd/dist.py) and the same K traversals run cooperatively ("strong" scaling).
 
 Rank 0 prints ONE JSON line.  Extra objects on it:
-  roofline      dominant kernel of the timed region (the pull-step kernel): algorithmic
-                bytes per launch / mean launch duration from HIP events
-                recorded on the library's stream inside the timed steps
-  bfs_total     whole-traversal algorithmic GB/s and the per-level table of one traversal
+  roofline      dominant kernel of the timed region = bfs_persistent_kernel (one launch runs a
+                whole traversal): algorithmic bytes per launch (summed over
+                the levels) / mean launch duration from HIP events recorded on the library's
+                stream in a second pass over the same steps
+  bfs_total     the kernel's own wall-clock time per traversal and the per-level table of one
   spmv          the generic SpMV kernel (PlusMultiplies, f32) on the same graph: algorithmic
                 8*nnz + 12*n + 4 bytes per launch / HIP-event mean launch time
   cpu_baseline  the oracle's SimpleReferenceBfs restatement (one host core) on a bounded
@@ -128,7 +129,7 @@ def main():
         assert desc.loadArgs(mxvmode=0, struconly=1, opreuse=1, earlyexit=1, edgeswitch=args.edgeswitch) == 0
         v = g.Vector(n)
 
-        def run_step(i, profile=1):
+        def run_step(i, profile=0):
             info, res = g.bfs(v, A, sources[i % len(sources)], desc, fused=True, profile=profile)
             assert info == 0, info
             return res
@@ -142,36 +143,29 @@ def main():
         elapsed = time.perf_counter() - t0
         edges = sum(r["edges_traversed"] for r in results)
 
-        # ---- roofline of the dominant kernel (pull step), from the timed steps' HIP events
+        # ---- roofline of the dominant kernel.  The traversal is ONE launch of
+        #      bfs_persistent_kernel; its duration is measured with HIP events on the library's
+        #      stream in a second pass over the same steps (profile bit 0), its algorithmic bytes
+        #      are BASELINE.md's per-level formulas summed over the levels it ran (pull levels
+        #      need the inspected-edge counts of an accounting run, profile bit 1).
+        timed = [run_step(i, profile=1) for i in range(args.steps)]
+        event_ms = sum(r["tight_ms"] for r in timed)
         used = sorted(set(sources[i % len(sources)] for i in range(args.steps)))
-        inspected = {}
-        for s in used:                      # same deterministic decisions; counts inspected edges
-            inspected[s] = g.bfs(v, A, s, desc, fused=True, profile=3)[1]["per_level"]
-        pull_bytes = pull_ms = push_bytes = push_ms = 0.0
-        npull = npush = 0
-        for i, r in enumerate(results):
-            ref = inspected[sources[i % len(sources)]]
-            lv = [dict(L, frontier_edges=(R["frontier_edges"] if L["direction"] == "pull" else L["frontier_edges"]))
-                  for L, R in zip(r["per_level"], ref)]
-            for L, b in zip(lv, level_bytes(lv, n)):
-                if L["direction"] == "pull":
-                    pull_bytes += b; pull_ms += L["ms"]; npull += 1
-                else:
-                    push_bytes += b; push_ms += L["ms"]; npush += 1
+        account = {s: g.bfs(v, A, s, desc, fused=True, profile=3)[1]["per_level"] for s in used}
+        total_bytes = 0.0
+        for i in range(args.steps):
+            lv = account[sources[i % len(sources)]]
+            total_bytes += sum(level_bytes(lv, n))
+        ach = total_bytes / (event_ms * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "kernel": "bfs_persistent_kernel", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                    "traffic": pmc_traffic("bfs_persistent_kernel"), "launches": args.steps,
+                    "avg_launch_ms": round(event_ms / args.steps, 5),
+                    "algorithmic_bytes_per_launch": int(total_bytes / args.steps)}
         tight_ms = sum(r["tight_ms"] for r in results)
-        dom_pull = pull_ms >= push_ms
-        kb, kms, kn = (pull_bytes, pull_ms, npull) if dom_pull else (push_bytes, push_ms, npush)
-        ach = kb / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
-        roofline = {"bound": "hbm", "kernel": "bfs_pull_kernel" if dom_pull else "lb_expand_kernel<BfsPushVisitor>",
-                    "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-                    "traffic": pmc_traffic("bfs_pull_kernel<false>" if dom_pull else "lb_expand_kernel<grb::BfsPushVisitor>"),
-                    "launches": kn, "avg_launch_ms": round(kms / max(kn, 1), 5),
-                    "algorithmic_bytes_per_launch": int(kb / max(kn, 1))}
-        one = inspected[sources[0]]
+        one = account[sources[0]]
         ob = level_bytes(one, n)
         extra["bfs_total"] = {
-            "algorithmic_GBps": round((pull_bytes + push_bytes) / (tight_ms * 1e-3) / 1e9, 2),
-            "frac_of_hbm_peak": round((pull_bytes + push_bytes) / (tight_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
             "tight_ms_mean": round(tight_ms / args.steps, 4),
             "graph500_teps": edges / 2 / elapsed,
             "levels_source0": [dict(dir=L["direction"], nf=L["frontier"], edges=L["frontier_edges"],
@@ -191,11 +185,11 @@ def main():
             g.k_spmv(A, 0, "PlusMultiplies", x.data_ptr(), None, 0, 0, y.data_ptr())
         ms = g.timer_stop() / reps
         sb = g.k_spmv_bytes(A, 0)
-        extra["spmv"] = {"kernel": "spmv_stream_kernel<PlusMultiplies,f32>", "bound": "hbm",
+        extra["spmv"] = {"kernel": "spmv_hub_kernel<PlusMultiplies,f32>", "bound": "hbm",
                          "algorithmic_bytes_per_launch": sb, "avg_launch_ms": round(ms, 5),
                          "achieved": round(sb / (ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(sb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                         "traffic": pmc_traffic("spmv_stream_kernel"), "gflops": round(2 * nnz / (ms * 1e-3) / 1e9, 1)}
+                         "traffic": pmc_traffic("spmv_hub_kernel"), "gflops": round(2 * nnz / (ms * 1e-3) / 1e9, 1)}
 
         # ---- CPU baseline: the oracle's sequential BFS on a bounded sample (checker code,
         #      timed beside the GPU run; never part of the product path)
