@@ -132,6 +132,51 @@ def test_bfs_edge_aware_switch(hb, graphs):
                     assert L["frontier"] == st[1] and L["discovered"] == st[5]
 
 
+def test_bfs_odd_shapes(hb):
+    """Shapes that hit the corners of the one-launch traversal: sizes that are not multiples of
+    64, fewer than four stored entries, an isolated source, a star whose centre is cut into
+    workgroup entries (degree >= 512), a source with a self loop, a two-level tree that makes
+    the second frontier carry the big vertices."""
+    from oracle import simple_reference as sr
+    from graphblast_amd.graphgen import finalize_edges
+    g = hb.g
+    cases = []
+    cases.append(("single", 1, np.zeros(0, np.int64), np.zeros(0, np.int64), [0]))
+    cases.append(("edge", 2, np.array([0]), np.array([1]), [0, 1]))
+    cases.append(("path3", 3, np.array([0, 1]), np.array([1, 2]), [0, 2]))
+    cases.append(("isolated_source", 70, np.arange(1, 69), np.arange(2, 70), [0, 1]))
+    n = 5003
+    cases.append(("star", n, np.zeros(n - 1, np.int64), np.arange(1, n), [0, 17]))
+    cases.append(("selfloop_source", 130, np.array([5, 5, 6, 7]), np.array([5, 6, 7, 8]), [5]))
+    # root -> 3 hubs -> 1500 leaves each, plus a chain hanging off one leaf
+    hubs = np.array([1, 2, 3])
+    leaves = np.arange(4, 4 + 4500)
+    src = np.concatenate([np.zeros(3, np.int64), np.repeat(hubs, 1500), np.arange(4504, 4520)])
+    dst = np.concatenate([hubs, leaves, np.arange(4505, 4521)])
+    src = np.concatenate([src, np.array([leaves[-1]])]); dst = np.concatenate([dst, np.array([4504])])
+    cases.append(("hub_tree", 4521, src, dst, [0, 4520, 2]))
+    for name, n, a, b, sources in cases:
+        for sym, keep_loops in ((True, False), (False, False)):
+            gr = finalize_edges(np.asarray(a, np.int64), np.asarray(b, np.int64), n, symmetrize=sym)
+            ptr, ind = gr["csr"]
+            if gr["nnz"] == 0:
+                A = g.Matrix(n, n)
+                assert A.build_csr(ptr, ind, np.zeros(0, dtype=F)) == 0
+            else:
+                A = build(hb, gr)
+            for s in sources:
+                want = sr.bfs(ptr, ind, s)[0]
+                for mode in (0, 1, 2):
+                    for es in (0.0, 0.08):
+                        d = hb.descriptor(mxvmode=mode, struconly=1, opreuse=1, edgeswitch=es)
+                        v = g.Vector(n)
+                        info, res = g.bfs(v, A, s, d, fused=True)
+                        assert info == 0, (name, s, mode)
+                        got = hb.dense_values(v)
+                        assert np.array_equal(got, want), (name, sym, s, mode, es)
+                        assert res["reached"] == int(np.count_nonzero(want))
+
+
 def test_bfs_max_niter_cap(hb, graphs):
     """A frontier discovered by the last allowed iteration is never labelled (bfs.hpp:48-66)."""
     g = hb.g
