@@ -68,8 +68,10 @@ grb_info grb_sssp(grb_vector v, grb_matrix A, grb_index source, grb_descriptor d
 
 // PageRank power iteration, algorithm/pr.hpp:60-82: vxm(PlusMultiplies) + eWiseAdd scalar +
 // eWiseMult(PlusMinus) + eWiseAdd(MultipliesMultiplies) + reduce(Plus); error = sqrt(sum).
-grb_info grb_pr(grb_vector p, grb_matrix A, float alpha, float eps, grb_descriptor desc, grb_algo_result* result) {
-  if (!p || !A || !desc) return GRB_UNINITIALIZED_OBJECT;
+// Op by op, exactly the reference's call sequence (kept for GrB_PUSHONLY, whose behaviour in
+// the reference is whatever its sparse paths do, and as the fused loop's cross-check).
+static grb_info pr_op_by_op(grb_vector p, grb_matrix A, float alpha, float eps, grb_descriptor desc,
+                            grb_algo_result* result) {
   const Index n = A->nrows;
   GRB_TRY(grb_vector_clear(p));
   GRB_TRY(grb_vector_fill(p, (double)(1.f / n)));
@@ -95,6 +97,98 @@ grb_info grb_pr(grb_vector p, grb_matrix A, float alpha, float eps, grb_descript
     GRB_TRY(grb_reduce_vector(&sum, GRB_ACCUM_NULL, GRB_PLUS_MONOID, r_temp, desc));
     error = sqrtf((float)sum);
   }
+  GRB_TRY(grb_timer_stop(&ms));
+  if (result) { result->iterations = iter - 1; result->tight_ms = ms; result->last_value = error; }
+  return GRB_SUCCESS;
+}
+
+// The same iteration with the five element-wise calls and the reduction folded into one pass:
+//   p_swap = p (x) A            the SpMV kernel (pull; p is dense and strictly positive)
+//   p_new  = p_swap + (1-alpha)/n ;  r = p_new - p ;  sum += r*r ;  p = p_new     one kernel
+// The squared residual comes back through the pinned mailbox (no stream synchronise, no
+// separate reduce launches, no p_prev copy).  Per element the arithmetic is the reference's.
+namespace grb {
+__global__ __launch_bounds__(kBlock) void pr_update_kernel(const float* __restrict__ swp, float* __restrict__ p, float c,
+                                                           Index n, float* partial, unsigned int* ticket,
+                                                           unsigned long long* mail, int seq) {
+  __shared__ float s_sum[kWavesPerBlock];
+  __shared__ int s_last;
+  float acc = 0.f;
+  for (Index i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const float pn = swp[i] + c;
+    const float r = pn - p[i];
+    p[i] = pn;
+    acc += r * r;
+  }
+  acc = wave_reduce(acc, [](float a, float b) { return a + b; });
+  if (lane_id() == 0) s_sum[wave_id()] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int w = 0; w < kWavesPerBlock; ++w) t += s_sum[w];
+    __hip_atomic_store(&partial[blockIdx.x], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned int k = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = (k == gridDim.x - 1) ? 1 : 0;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  float t = 0.f;
+  for (int j = threadIdx.x; j < (int)gridDim.x; j += kBlock)
+    t += __hip_atomic_load(&partial[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  t = wave_reduce(t, [](float a, float b) { return a + b; });
+  __syncthreads();
+  if (lane_id() == 0) s_sum[wave_id()] = t;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float tot = 0.f;
+    for (int w = 0; w < kWavesPerBlock; ++w) tot += s_sum[w];
+    __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&mail[0], ((unsigned long long)(unsigned int)seq << 32) | __float_as_uint(tot),
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+}  // namespace grb
+
+grb_info grb_pr(grb_vector p, grb_matrix A, float alpha, float eps, grb_descriptor desc, grb_algo_result* result) {
+  if (!p || !A || !desc) return GRB_UNINITIALIZED_OBJECT;
+  if (!A->built) return GRB_UNINITIALIZED_OBJECT;
+  const Index n = A->nrows;
+  static const bool fused_ok = [] { const char* e = getenv("GRB_PR_FUSED"); return !e || atoi(e) != 0; }();
+  if (!fused_ok || desc->desc[GRB_MXVMODE] == GRB_PUSHONLY || !(alpha < 1.f) || p->dtype != GRB_F32 ||
+      A->dtype != GRB_F32 || A->nrows != A->ncols || p->nsize != n || !A->csc.ptr)
+    return pr_op_by_op(p, A, alpha, eps, desc, result);
+  Context& c = ctx();
+  GRB_TRY(grb_vector_clear(p));
+  GRB_TRY(grb_vector_fill(p, (double)(1.f / n)));
+  VecGuard g;
+  grb_vector p_swap;
+  GRB_TRY(g.make(&p_swap, GRB_F32, n));
+  GRB_TRY(grb_vector_set_storage(p_swap, GRB_DENSE));
+  const int grid = stream_grid(n, kBlock);
+  void* p_part;
+  GRB_TRY(scratch(4, sizeof(float) * (size_t)grid + 16, &p_part));
+  unsigned int* d_ticket = reinterpret_cast<unsigned int*>((float*)p_part + grid);
+  GRB_HIP_TRY(hipMemsetAsync(d_ticket, 0, 4, c.stream));
+  const float cst = (1.f - alpha) / n;
+  int iter = 1;
+  float error = 1.f;
+  float ms = 0.f;
+  GRB_TRY(grb_timer_start());
+  for (; error > eps && iter <= desc->max_niter; ++iter) {
+    // vxm treats A as transposed: the pull product walks the CSC orientation (operations.hpp:80-209)
+    GRB_TRY(k_spmv(GRB_PLUS_MULTIPLIES, GRB_F32, A->csc, A->plan_csc, p->d_val, nullptr, 0, 0, 0, p_swap->d_val));
+    const int seq = ++c.mail_seq;
+    hipLaunchKernelGGL(pr_update_kernel, dim3(grid), dim3(kBlock), 0, c.stream, (const float*)p_swap->d_val,
+                       (float*)p->d_val, cst, n, (float*)p_part, d_ticket, c.d_hgran, seq);
+    GRB_HIP_TRY(hipGetLastError());
+    unsigned int bits = 0;
+    GRB_TRY(wait_granules(seq, 1, &bits));
+    float sum;
+    memcpy(&sum, &bits, 4);
+    error = sqrtf(sum);
+  }
+  desc->lastmxv = GRB_PULLONLY;
   GRB_TRY(grb_timer_stop(&ms));
   if (result) { result->iterations = iter - 1; result->tight_ms = ms; result->last_value = error; }
   return GRB_SUCCESS;
