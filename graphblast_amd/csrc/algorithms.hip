@@ -20,6 +20,9 @@ struct VecGuard {               // frees temporaries on every exit path
 };
 }  // namespace
 
+grb_info sssp_persistent_run(grb_vector v, grb_matrix A, grb_index source, grb_descriptor desc, int* iterations,
+                             double* succ, float* tight_ms);
+
 extern "C" {
 
 // Bellman-Ford with frontier filtering; MinimumPlus vxm + CustomLessPlus / MinimumPlus
@@ -28,6 +31,21 @@ grb_info grb_sssp(grb_vector v, grb_matrix A, grb_index source, grb_descriptor d
   if (!v || !A || !desc) return GRB_UNINITIALIZED_OBJECT;
   if (source < 0 || source >= A->nrows) return GRB_INVALID_INDEX;
   const Index n = A->nrows;
+  static const bool fused_ok = [] { const char* e = getenv("GRB_SSSP_FUSED"); return !e || atoi(e) != 0; }();
+  if (fused_ok && A->built && v->nsize == n) {
+    // the same synchronous rounds in one launch (sssp_persist.hip); not eligible -> op by op
+    GRB_TRY(grb_vector_set_storage(v, GRB_DENSE));
+    int it = 0;
+    double sc = 0;
+    float tms = 0.f;
+    const grb_info fi = sssp_persistent_run(v, A, source, desc, &it, &sc, &tms);
+    if (fi == GRB_SUCCESS) {
+      desc->lastmxv = GRB_PUSHONLY;
+      if (result) { result->iterations = it; result->tight_ms = tms; result->last_value = sc; }
+      return GRB_SUCCESS;
+    }
+    if (fi != GRB_NOT_IMPLEMENTED) return fi;
+  }
   const double fmax = (double)FLT_MAX;
   GRB_TRY(grb_vector_fill(v, fmax));
   GRB_TRY(grb_vector_set_element(v, 0.0, source));

@@ -22,27 +22,22 @@
 //   totals         every workgroup writes {discovered, their out-degree sum, inspected, big}
 //                  into its slot; after the barrier every workgroup sums all slots
 #include "bfs_kernels.hpp"
+#include "persist_common.hpp"
 
 namespace grb {
 
 #ifndef GRB_PULL_BLOCK
 #define GRB_PULL_BLOCK 8
 #endif
-constexpr int kPThreads = 1024;
-constexpr int kPWaves = kPThreads / kWave;
 constexpr int kSmallDeg = 16;     // below: expanded inline by the discovering lane
 constexpr int kBigDeg = 512;      // from here: split into kBigChunk-edge entries for workgroups
 constexpr int kBigChunk = 1024;
 constexpr int kPullBlock = GRB_PULL_BLOCK;    // chunks (of 64 vertices) one wave carries through the pull stages together
 constexpr int kPullGroup = 16;    // lanes finishing one undecided row in the pull phase
 constexpr int kMedCap = 4096;     // LDS list of medium vertices per workgroup pass
-constexpr unsigned kSpinLimit = 1u << 22;
 
 struct PersistState {               // zeroed by the host before every launch
-  unsigned xcd_count[8][32];        // one 128 B line per counter
-  unsigned top_count[32];
-  unsigned gen[32];
-  unsigned abort_flag[32];
+  GridBarrier bar;
   unsigned big_count[2][32];
   unsigned long long acc[3][8][16]; // level totals, one line per (set, XCD group): found, deg, inspected, big
 };
@@ -72,52 +67,6 @@ struct PersistArgs {
   float ticks_to_ms;
   unsigned long long* trace;        // optional (GRB_BFS_TRACE): wall-clock stamps of workgroup 0
 };
-
-// Everything one workgroup writes for another to read goes out as an agent-scope
-// write-through store (or an atomic): the data is in memory when the store has completed,
-// which __syncthreads() waits for, so the barrier needs no L2 write-back on the way in --
-// only the L1/L2 invalidate on the way out (CDNA guide G16, recipe R1).  Labels are read by
-// nobody but the host and stay ordinary stores.
-template <typename V>
-__device__ inline void publish(V* p, V v) {
-  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// ---- grid barrier ---------------------------------------------------------------------
-// Monotonic counters: generation g of a group of m arrivers completes when its counter
-// reaches m * g.  Returns false when the barrier was abandoned (spin bound hit somewhere).
-__device__ inline bool grid_sync(PersistState* st, unsigned& gen) {
-  __shared__ int s_ok;
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's write-through stores have landed
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const unsigned g = gen + 1;
-    const unsigned G = gridDim.x;
-    const unsigned x = blockIdx.x & 7u;
-    const unsigned groups = G < 8u ? G : 8u;
-    const unsigned members = (G - x + 7u) / 8u;
-    const unsigned a = __hip_atomic_fetch_add(&st->xcd_count[x][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (a + 1u == members * g) {
-      (void)__hip_atomic_fetch_add(&st->top_count[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    unsigned spins = 0;
-    int ok = 1;
-    while (__hip_atomic_load(&st->top_count[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < groups * g) {
-      __builtin_amdgcn_s_sleep(1);
-      if (++spins > kSpinLimit ||
-          __hip_atomic_load(&st->abort_flag[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-        __hip_atomic_store(&st->abort_flag[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        ok = 0;
-        break;
-      }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    s_ok = ok;
-  }
-  __syncthreads();
-  ++gen;
-  return s_ok != 0;
-}
 
 struct __attribute__((packed, aligned(4))) Quad { Index x, y, z, w; };   // four consecutive column ids
 
@@ -171,7 +120,7 @@ __global__ __launch_bounds__(kPThreads) void bfs_persistent_kernel(PersistArgs a
     atomicOr(&a.V[0][a.source >> 5], 1u << (a.source & 31));
     a.label[a.source] = 1.f;
   }
-  if (a.mode == GRB_PULLONLY && !grid_sync(st, gen)) return;
+  if (a.mode == GRB_PULLONLY && !grid_sync(&st->bar, gen)) return;
 
   // ---- level loop (all scalars below are identical in every workgroup)
   Index nf = 1;
@@ -255,7 +204,7 @@ __global__ __launch_bounds__(kPThreads) void bfs_persistent_kernel(PersistArgs a
             }
           }
           stamp();
-          if (!grid_sync(st, gen)) return;
+          if (!grid_sync(&st->bar, gen)) return;
           stamp();
           int nent = (int)__hip_atomic_load(bcount, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           if (nent > a.big_cap) nent = a.big_cap;
@@ -499,7 +448,7 @@ __global__ __launch_bounds__(kPThreads) void bfs_persistent_kernel(PersistArgs a
       for (int w = 0; w < kPWaves; ++w) t += s_red[w][tid];
       if (t) __hip_atomic_fetch_add(&acc[(blockIdx.x & 7) * 16 + tid], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (!grid_sync(st, gen)) return;
+    if (!grid_sync(&st->bar, gen)) return;
     stamp();
     if (wave == 0) {
       unsigned long long q = 0;

@@ -380,6 +380,7 @@ struct grb_matrix_s {
   grb::SpmvPlan plan_csr, plan_csc;
   unsigned int* d_no_in_edges = nullptr;         // bitmap: CSC column empty (built lazily by bfs_fused)
   unsigned int* d_empty_csr_rows = nullptr;      // bitmap: CSR row empty (built lazily by bfs_part)
+  int nonneg_values = -1;                        // -1 unknown, else whether every stored value is >= 0 (sssp_persist)
   grb::Index* d_pull_hint = nullptr;                  // per vertex: its in-neighbour of largest out-degree (bfs_fused)
 };
 

@@ -637,6 +637,7 @@ static void matrix_release_device(grb_matrix A) {
   if (A->d_no_in_edges) { (void)hipFree(A->d_no_in_edges); A->d_no_in_edges = nullptr; }
   if (A->d_empty_csr_rows) { (void)hipFree(A->d_empty_csr_rows); A->d_empty_csr_rows = nullptr; }
   if (A->d_pull_hint) { (void)hipFree(A->d_pull_hint); A->d_pull_hint = nullptr; }
+  A->nonneg_values = -1;
   free_spmv_plan(&A->plan_csr);
   free_spmv_plan(&A->plan_csc);
   A->built = false;
@@ -818,6 +819,7 @@ grb_info grb_matrix_set_values(grb_matrix A, const void* csr_val) {
     GRB_HIP_TRY(hipMemcpy(A->csr.val, A->h_csr_val.data(), 4 * (size_t)A->nvals, hipMemcpyHostToDevice));
     GRB_HIP_TRY(hipMemcpy(A->csc.val, A->h_csc_val.data(), 4 * (size_t)A->nvals, hipMemcpyHostToDevice));
   }
+  A->nonneg_values = -1;
   return GRB_SUCCESS;
 }
 

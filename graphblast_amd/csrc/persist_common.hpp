@@ -1,0 +1,67 @@
+// persist_common.hpp -- what the one-launch ("persistent") algorithm kernels share: the
+// write-through publish and the XCD-hierarchical grid barrier.  A persistent launch is one
+// co-resident grid (one 1024-thread workgroup per CU); its phases are separated by
+// grid_sync(), every spin of which is bounded: a barrier that cannot complete raises the
+// abort flag, every workgroup leaves the kernel, and the host reports GrB_PANIC.
+#pragma once
+#include "common.hpp"
+
+namespace grb {
+
+constexpr int kPThreads = 1024;
+constexpr int kPWaves = kPThreads / kWave;
+constexpr unsigned kSpinLimit = 1u << 22;
+
+struct GridBarrier {                // zeroed by the host before every launch
+  unsigned xcd_count[8][32];        // one 128 B line per counter
+  unsigned top_count[32];
+  unsigned abort_flag[32];
+};
+
+// Everything one workgroup writes for another to read goes out as an agent-scope
+// write-through store (or an atomic): the data is in memory when the store has completed,
+// which __syncthreads() waits for, so the barrier needs no L2 write-back on the way in --
+// only the L1/L2 invalidate on the way out (CDNA guide G16, recipe R1).  Labels are read by
+// nobody but the host and stay ordinary stores.
+template <typename V>
+__device__ inline void publish(V* p, V v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// ---- grid barrier ---------------------------------------------------------------------
+// Monotonic counters: generation g of a group of m arrivers completes when its counter
+// reaches m * g.  Returns false when the barrier was abandoned (spin bound hit somewhere).
+__device__ inline bool grid_sync(GridBarrier* st, unsigned& gen) {
+  __shared__ int s_ok;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's write-through stores have landed
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned g = gen + 1;
+    const unsigned G = gridDim.x;
+    const unsigned x = blockIdx.x & 7u;
+    const unsigned groups = G < 8u ? G : 8u;
+    const unsigned members = (G - x + 7u) / 8u;
+    const unsigned a = __hip_atomic_fetch_add(&st->xcd_count[x][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (a + 1u == members * g) {
+      (void)__hip_atomic_fetch_add(&st->top_count[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    unsigned spins = 0;
+    int ok = 1;
+    while (__hip_atomic_load(&st->top_count[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < groups * g) {
+      __builtin_amdgcn_s_sleep(1);
+      if (++spins > kSpinLimit ||
+          __hip_atomic_load(&st->abort_flag[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+        __hip_atomic_store(&st->abort_flag[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ok = 0;
+        break;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    s_ok = ok;
+  }
+  __syncthreads();
+  ++gen;
+  return s_ok != 0;
+}
+
+}  // namespace grb
