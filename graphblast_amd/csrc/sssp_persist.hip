@@ -5,20 +5,19 @@
 // and stops when no distance improved.  Rounds are synchronous: round r relaxes the edges
 // of the vertices improved in round r-1 with the distances they had at the END of round r-1.
 // This kernel keeps exactly those rounds (same iteration count, same distances after every
-// round, hence the same result under a max_niter cap) on three arrays:
+// round, hence the same result under a max_niter cap) with ONE grid barrier per round:
 //
-//   D[n]  best distance at the start of the round (the reference's v)
-//   C[n]  candidates of the round being relaxed, FLT_MAX elsewhere (the reference's f2)
-//   F     bitmap of the vertices improved by the last round (the reference's f1 pattern),
-//         three buffers in rotation as in bfs_persist.hip
+//   D_r    distances at the start of round r, in three rotating buffers.  Round r only reads
+//          D_r and only writes D_(r+1) -- with atomicMin on the float's bit pattern
+//          (distances are non-negative, so unsigned order is float order).
+//   F_r    bitmap of the vertices improved by round r-1 (the reference's f1 pattern), four
+//          rotating buffers (F_(r-1), F_r read; F_(r+1) written; one being cleared).
 //
-//   phase A  every frontier word has one owner: D[v] = C[v], C[v] = FLT_MAX for its vertices;
-//            vertices of degree >= 512 are cut into 1024-edge entries of a global list
-//   barrier
-//   phase B  relax: nd = D[u] + w(u,v); if nd < D[v]: old = atomicMin(C[v], nd) on the float's
-//            bit pattern (distances are non-negative, so unsigned order is float order); the
-//            first improver of v (old == FLT_MAX) sets v's bit in the next frontier and counts it
-//   barrier  + totals (number improved = the reference's succ)
+// The buffer that becomes D_(r+1) last held D_(r-2); the two differ from D_r exactly on
+// F_(r-1) and F_r, so round r first lowers those entries to D_r -- also with atomicMin, which
+// makes the order against concurrent relaxations of the same entry irrelevant.  A relaxation
+// counts as an improvement iff nd < D_r[v] (stable data: exact), and the first one to set v's
+// bit in F_(r+1) (atomicOr return value) counts v.
 //
 // The fused loop is used for non-negative weights only (checked once per matrix); anything
 // else runs the op-by-op driver in algorithms.hip.
@@ -30,12 +29,11 @@ constexpr int kSsspSmall = 16;
 constexpr int kSsspBig = 512;
 constexpr int kSsspChunk = 1024;
 constexpr int kSsspMedCap = 4096;
-constexpr unsigned int kInfBits = 0x7f7fffffu;    // FLT_MAX
 
 struct SsspState {                  // zeroed by the host before every launch
   GridBarrier bar;
   unsigned big_count[2][32];
-  unsigned long long acc[3][8][16]; // per (set, XCD group): improved
+  unsigned long long acc[3][8][16]; // per (set, XCD group): improved, improved with degree >= kSsspBig
 };
 
 struct SsspArgs {
@@ -44,9 +42,8 @@ struct SsspArgs {
   Index n;
   Index source;
   int max_niter;
-  float* D;                         // the result vector, FLT_MAX-filled by the host
-  float* C;                         // FLT_MAX-filled by the host, C[source] = 0
-  unsigned int* F[3];               // F[0] has the source bit, F[1], F[2] are zero (host)
+  float* D[3];                      // D[0] is the result vector; all FLT_MAX, D[1][source] = 0 (host)
+  unsigned int* F[4];               // F[1] has the source bit, the rest is zero (host)
   int2* big_list;
   int big_cap;
   SsspState* st;
@@ -55,20 +52,76 @@ struct SsspArgs {
   float ticks_to_ms;
 };
 
-__device__ inline void relax(const SsspArgs& a, unsigned int* Fn, float du, Index p, unsigned long long& improved) {
+struct RoundCounters {
+  unsigned long long improved = 0, big = 0;
+};
+
+__device__ inline void relax(const SsspArgs& a, const float* Dc, float* Dn, unsigned int* Fn, float du, Index p,
+                             RoundCounters& c) {
   const Index v = a.oind[p];
   const float nd = du + a.oval[p];
-  if (!(nd < a.D[v])) return;
-  const unsigned int old = atomicMin(reinterpret_cast<unsigned int*>(&a.C[v]), __float_as_uint(nd));
-  if (old == kInfBits) {
-    atomicOr(&Fn[v >> 5], 1u << (v & 31));
-    ++improved;
+  if (!(nd < Dc[v])) return;
+  atomicMin(reinterpret_cast<unsigned int*>(&Dn[v]), __float_as_uint(nd));
+  const unsigned int bit = 1u << (v & 31);
+  if (Fn[v >> 5] & bit) return;                     // may be stale: the atomic decides
+  const unsigned int old = atomicOr(&Fn[v >> 5], bit);
+  if (old & bit) return;
+  ++c.improved;
+  if (a.optr[v + 1] - a.optr[v] >= kSsspBig) ++c.big;
+}
+
+// Up to N edges of one vertex with their dependent steps issued stage by stage (loads, then
+// distance reads, then atomics ...): a short adjacency list costs one chain of memory
+// latencies instead of one per edge.  This is what bounds rounds with tiny frontiers.
+template <int N>
+__device__ inline void relax_batch(const SsspArgs& a, const float* Dc, float* Dn, unsigned int* Fn, float du, Index p0,
+                                   Index e, RoundCounters& c) {
+  Index v[N];
+  float nd[N], dv[N];
+  bool ok[N];
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    ok[j] = p0 + j < e;
+    const Index p = ok[j] ? p0 + j : p0;
+    v[j] = a.oind[p];
+    nd[j] = du + a.oval[p];
   }
+#pragma unroll
+  for (int j = 0; j < N; ++j) dv[j] = Dc[v[j]];
+  unsigned int fw[N];
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    ok[j] = ok[j] && nd[j] < dv[j];
+    if (ok[j]) atomicMin(reinterpret_cast<unsigned int*>(&Dn[v[j]]), __float_as_uint(nd[j]));
+    fw[j] = ok[j] ? Fn[v[j] >> 5] : 0xffffffffu;
+  }
+  unsigned int old[N];
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    const unsigned int bit = 1u << (v[j] & 31);
+    old[j] = 0xffffffffu;
+    if (!(fw[j] & bit)) old[j] = atomicOr(&Fn[v[j] >> 5], bit);
+  }
+  Index d0[N], d1[N];
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    const unsigned int bit = 1u << (v[j] & 31);
+    const bool won = !(old[j] & bit);
+    d0[j] = a.optr[won ? v[j] : 0];
+    d1[j] = a.optr[won ? v[j] + 1 : 0];
+    if (!won) d1[j] = d0[j] - 1;          // marks "not an improvement" (degree -1)
+  }
+#pragma unroll
+  for (int j = 0; j < N; ++j)
+    if (d1[j] - d0[j] >= 0) {
+      ++c.improved;
+      if (d1[j] - d0[j] >= kSsspBig) ++c.big;
+    }
 }
 
 __global__ __launch_bounds__(kPThreads) void sssp_persistent_kernel(SsspArgs a) {
-  __shared__ unsigned long long s_red[kPWaves];
-  __shared__ unsigned long long s_tot;
+  __shared__ unsigned long long s_red[kPWaves][2];
+  __shared__ unsigned long long s_tot[2];
   __shared__ Index s_med[kSsspMedCap];
   __shared__ int s_nmed;
   const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
@@ -80,64 +133,72 @@ __global__ __launch_bounds__(kPThreads) void sssp_persistent_kernel(SsspArgs a) 
   unsigned gen = 0;
   const unsigned long long t_start = wall_clock64();
 
-  int fcur = 0, iter = 1;
-  unsigned long long succ = 1;
+  int iter = 1;
+  unsigned long long succ = 1, nbig = (a.optr[a.source + 1] - a.optr[a.source] >= kSsspBig) ? 1 : 0;
+  int last_round = 0;
   for (; iter <= a.max_niter; ++iter) {
-    const int fnext = (fcur + 1) % 3, fzero = (fcur + 2) % 3;
-    const unsigned int* Fc = a.F[fcur];
-    unsigned int* Fn = a.F[fnext];
+    const float* Dc = a.D[iter % 3];
+    float* Dn = a.D[(iter + 1) % 3];
+    const unsigned int* Fp = a.F[(iter + 3) % 4];
+    const unsigned int* Fc = a.F[iter % 4];
+    unsigned int* Fn = a.F[(iter + 1) % 4];
     unsigned* bcount = &st->big_count[iter & 1][0];
-    for (long long i = gtid; i < nwords; i += gthreads) publish(&a.F[fzero][i], 0u);
+    for (long long i = gtid; i < nwords; i += gthreads) publish(&a.F[(iter + 2) % 4][i], 0u);
     if (gtid == 0) publish(&st->big_count[(iter + 1) & 1][0], 0u);
-    if (blockIdx.x == 0 && tid < 8) publish(&st->acc[(iter + 1) % 3][tid][0], 0ull);
+    if (blockIdx.x == 0 && tid < 16) publish(&st->acc[(iter + 1) % 3][tid >> 1][tid & 1], 0ull);
 
-    // ---- phase A: commit the last round's improvements, list the big frontier vertices
+    // ---- bring the write buffer up to D_r where it is behind (F_(r-1) and F_r), and list
+    // the big frontier vertices as 1024-edge entries when the totals announced any
     for (long long base = 0; base < nwords; base += gthreads) {
       const long long i = base + gtid;
-      const unsigned int w = (i < nwords) ? Fc[i] : 0u;
-      int mine = 0;
-      for (unsigned int t = w; t; t &= t - 1) {
+      const unsigned int wc = (i < nwords) ? Fc[i] : 0u;
+      const unsigned int wp = (i < nwords) ? Fp[i] : 0u;
+      for (unsigned int t = wc | wp; t; t &= t - 1) {
         const Index v = (Index)i * 32 + (__ffs((int)t) - 1);
-        publish(&a.D[v], a.C[v]);
-        publish(&a.C[v], __uint_as_float(kInfBits));
-        const Index d = a.optr[v + 1] - a.optr[v];
-        if (d >= kSsspBig) mine += (d + kSsspChunk - 1) / kSsspChunk;
+        atomicMin(reinterpret_cast<unsigned int*>(&Dn[v]), __float_as_uint(Dc[v]));
       }
-      int incl = mine;
-#pragma unroll
-      for (int o = 1; o < kWave; o <<= 1) {
-        const int y = __shfl_up(incl, o, kWave);
-        if (lane >= o) incl += y;
-      }
-      const int total = __shfl(incl, kWave - 1, kWave);
-      if (total > 0) {
-        unsigned b0 = 0;
-        if (lane == 0) b0 = atomicAdd(bcount, (unsigned)total);
-        b0 = __shfl(b0, 0, kWave);
-        int at = (int)b0 + incl - mine;
-        for (unsigned int t = w; t; t &= t - 1) {
+      if (nbig > 0) {
+        int mine = 0;
+        for (unsigned int t = wc; t; t &= t - 1) {
           const Index v = (Index)i * 32 + (__ffs((int)t) - 1);
           const Index d = a.optr[v + 1] - a.optr[v];
-          if (d >= kSsspBig)
-            for (int k = 0; k < (d + kSsspChunk - 1) / kSsspChunk; ++k, ++at)
-              if (at < a.big_cap) publish(reinterpret_cast<unsigned long long*>(&a.big_list[at]),
-                                          ((unsigned long long)(unsigned)k << 32) | (unsigned)v);
+          if (d >= kSsspBig) mine += (d + kSsspChunk - 1) / kSsspChunk;
+        }
+        int incl = mine;
+#pragma unroll
+        for (int o = 1; o < kWave; o <<= 1) {
+          const int y = __shfl_up(incl, o, kWave);
+          if (lane >= o) incl += y;
+        }
+        const int total = __shfl(incl, kWave - 1, kWave);
+        if (total > 0) {
+          unsigned b0 = 0;
+          if (lane == 0) b0 = atomicAdd(bcount, (unsigned)total);
+          b0 = __shfl(b0, 0, kWave);
+          int at = (int)b0 + incl - mine;
+          for (unsigned int t = wc; t; t &= t - 1) {
+            const Index v = (Index)i * 32 + (__ffs((int)t) - 1);
+            const Index d = a.optr[v + 1] - a.optr[v];
+            if (d >= kSsspBig)
+              for (int k = 0; k < (d + kSsspChunk - 1) / kSsspChunk; ++k, ++at)
+                if (at < a.big_cap) publish(reinterpret_cast<unsigned long long*>(&a.big_list[at]),
+                                            ((unsigned long long)(unsigned)k << 32) | (unsigned)v);
+          }
         }
       }
     }
-    if (!grid_sync(&st->bar, gen)) return;
-
-    // ---- phase B: relax the frontier's edges
-    unsigned long long improved = 0;
-    {
+    RoundCounters c;
+    if (nbig > 0) {
+      if (!grid_sync(&st->bar, gen)) return;
       int nent = (int)__hip_atomic_load(bcount, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (nent > a.big_cap) nent = a.big_cap;
       for (int e = blockIdx.x; e < nent; e += G) {
         const int2 ent = a.big_list[e];
         const Index p = a.optr[ent.x] + ent.y * kSsspChunk + tid;
-        if (p < a.optr[ent.x + 1]) relax(a, Fn, a.D[ent.x], p, improved);
+        if (p < a.optr[ent.x + 1]) relax(a, Dc, Dn, Fn, Dc[ent.x], p, c);
       }
     }
+    // ---- relax the rest of the frontier: words interleaved over the workgroups
     if (tid == 0) s_nmed = 0;
     __syncthreads();
     for (long long base = 0; base < nwords; base += gthreads) {
@@ -152,16 +213,16 @@ __global__ __launch_bounds__(kPThreads) void sssp_persistent_kernel(SsspArgs a) 
           const int slot = atomicAdd(&s_nmed, 1);
           if (slot < kSsspMedCap) { s_med[slot] = v; continue; }
         }
-        const float du = a.D[v];
-        for (Index p = s; p < e; ++p) relax(a, Fn, du, p, improved);
+        const float du = Dc[v];
+        for (Index p = s; p < e; p += 4) relax_batch<4>(a, Dc, Dn, Fn, du, p, e, c);
       }
       __syncthreads();
       const int nm = s_nmed < kSsspMedCap ? s_nmed : kSsspMedCap;
       for (int k = wave; k < nm; k += kPWaves) {
         const Index v = s_med[k];
         const Index e = a.optr[v + 1];
-        const float du = a.D[v];
-        for (Index p = a.optr[v] + lane; p < e; p += kWave) relax(a, Fn, du, p, improved);
+        const float du = Dc[v];
+        for (Index p = a.optr[v] + lane; p < e; p += kWave) relax(a, Dc, Dn, Fn, du, p, c);
       }
       __syncthreads();
       if (tid == 0) s_nmed = 0;
@@ -169,40 +230,40 @@ __global__ __launch_bounds__(kPThreads) void sssp_persistent_kernel(SsspArgs a) 
     }
 
     // ---- totals
-    improved = wave_reduce(improved, [](unsigned long long x, unsigned long long y) { return x + y; });
-    if (lane == 0) s_red[wave] = improved;
+    auto add = [](unsigned long long x, unsigned long long y) { return x + y; };
+    const unsigned long long r0 = wave_reduce(c.improved, add), r1 = wave_reduce(c.big, add);
+    if (lane == 0) { s_red[wave][0] = r0; s_red[wave][1] = r1; }
     __syncthreads();
     unsigned long long* acc = &st->acc[iter % 3][0][0];
-    if (tid == 0) {
+    if (tid < 2) {
       unsigned long long t = 0;
-      for (int w = 0; w < kPWaves; ++w) t += s_red[w];
-      if (t) __hip_atomic_fetch_add(&acc[(blockIdx.x & 7) * 16], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int w = 0; w < kPWaves; ++w) t += s_red[w][tid];
+      if (t) __hip_atomic_fetch_add(&acc[(blockIdx.x & 7) * 16 + tid], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (!grid_sync(&st->bar, gen)) return;
     if (wave == 0) {
       unsigned long long q = 0;
-      if (lane < 8) q = __hip_atomic_load(&acc[lane * 16], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      q += __shfl_xor(q, 1, kWave);
+      if (lane < 16) q = __hip_atomic_load(&acc[(lane >> 1) * 16 + (lane & 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       q += __shfl_xor(q, 2, kWave);
       q += __shfl_xor(q, 4, kWave);
-      if (lane == 0) s_tot = q;
+      q += __shfl_xor(q, 8, kWave);
+      if (lane < 2) s_tot[lane] = q;
     }
     __syncthreads();
-    succ = s_tot;
+    succ = s_tot[0];
+    nbig = s_tot[1];
     __syncthreads();
-    fcur = fnext;
+    last_round = iter;
     if (succ == 0) break;           // f1.nvals == 0 / reduce(m) == 0, sssp.hpp:88-90
   }
 
-  // the last round's improvements are part of v (v = min(v, f2) happens inside the round);
-  // only pending when the iteration cap ended the loop
-  if (succ != 0) {
-    const unsigned int* Fc = a.F[fcur];
-    for (long long i = gtid; i < nwords; i += gthreads)
-      for (unsigned int w = Fc[i]; w; w &= w - 1) {
-        const Index v = (Index)i * 32 + (__ffs((int)w) - 1);
-        a.D[v] = a.C[v];
-      }
+  // the distances after the last round live in D_(last+1); the result vector is buffer 0
+  {
+    const int res = (last_round + 1) % 3;
+    if (res != 0) {
+      const float* Dr = a.D[res];
+      for (long long i = gtid; i < a.n; i += gthreads) a.D[0][i] = Dr[i];
+    }
   }
   if (gtid == 0) {
     const unsigned long long tag = (unsigned long long)(unsigned int)a.seq << 32;
@@ -215,10 +276,10 @@ __global__ __launch_bounds__(kPThreads) void sssp_persistent_kernel(SsspArgs a) 
   }
 }
 
-__global__ void sssp_seed_kernel(float* C, unsigned int* F0, Index source) {
+__global__ void sssp_seed_kernel(float* D1, unsigned int* F1, Index source) {
   if (blockIdx.x == 0 && threadIdx.x == 0) {
-    C[source] = 0.f;
-    F0[source >> 5] = 1u << (source & 31);
+    D1[source] = 0.f;
+    F1[source >> 5] = 1u << (source & 31);
   }
 }
 
@@ -251,10 +312,10 @@ grb_info sssp_persistent_run(grb_vector v, grb_matrix A, grb_index source, grb_d
   const int G = c.num_cu;
   const int big_cap = (int)(A->nvals / kSsspBig) + 2;
   const size_t st_bytes = (sizeof(SsspState) + 255) & ~(size_t)255;
-  const size_t zero_bytes = st_bytes + 12 * (size_t)nwords;
+  const size_t zero_bytes = st_bytes + 16 * (size_t)nwords;
   void *p_zero, *p_c, *p_big;
   GRB_TRY(scratch(7, zero_bytes, &p_zero));
-  GRB_TRY(scratch(8, 4 * (size_t)n + 4, &p_c));
+  GRB_TRY(scratch(8, 8 * (size_t)n + 8, &p_c));
   GRB_TRY(scratch(2, sizeof(int2) * (size_t)big_cap, &p_big));
   static float ticks_to_ms = 0.f;
   if (ticks_to_ms == 0.f) {
@@ -268,9 +329,11 @@ grb_info sssp_persistent_run(grb_vector v, grb_matrix A, grb_index source, grb_d
   a.n = n;
   a.source = source;
   a.max_niter = desc->max_niter;
-  a.D = (float*)v->d_val;
-  a.C = (float*)p_c;
-  a.F[0] = (unsigned int*)((char*)p_zero + st_bytes); a.F[1] = a.F[0] + nwords; a.F[2] = a.F[1] + nwords;
+  a.D[0] = (float*)v->d_val;
+  a.D[1] = (float*)p_c;
+  a.D[2] = a.D[1] + n;
+  a.F[0] = (unsigned int*)((char*)p_zero + st_bytes);
+  for (int k = 1; k < 4; ++k) a.F[k] = a.F[k - 1] + nwords;
   a.big_list = (int2*)p_big;
   a.big_cap = big_cap;
   a.st = (SsspState*)p_zero;
@@ -279,9 +342,10 @@ grb_info sssp_persistent_run(grb_vector v, grb_matrix A, grb_index source, grb_d
   a.ticks_to_ms = ticks_to_ms;
 
   GRB_HIP_TRY(hipMemsetAsync(p_zero, 0, zero_bytes, s));
-  GRB_TRY(k_fill(GRB_F32, a.D, (double)FLT_MAX, n));
-  GRB_TRY(k_fill(GRB_F32, a.C, (double)FLT_MAX, n));
-  hipLaunchKernelGGL(sssp_seed_kernel, dim3(1), dim3(64), 0, s, a.C, a.F[0], source);
+  GRB_TRY(k_fill(GRB_F32, a.D[0], (double)FLT_MAX, n));
+  GRB_TRY(k_fill(GRB_F32, a.D[1], (double)FLT_MAX, 2 * (size_t)n <= 0x7fffffffull ? 2 * n : n));
+  if (2 * (size_t)n > 0x7fffffffull) GRB_TRY(k_fill(GRB_F32, a.D[2], (double)FLT_MAX, n));
+  hipLaunchKernelGGL(sssp_seed_kernel, dim3(1), dim3(64), 0, s, a.D[1], a.F[1], source);
   GRB_HIP_TRY(hipGetLastError());
   hipLaunchKernelGGL(sssp_persistent_kernel, dim3(G), dim3(kPThreads), 0, s, a);
   GRB_HIP_TRY(hipGetLastError());

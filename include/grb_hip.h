@@ -261,10 +261,15 @@ grb_info grb_bfs_part_tally(grb_matrix A_out, const float* d_label_local, int64_
 typedef struct {
   int    iterations;          /* loop iterations executed                              */
   float  tight_ms;            /* HIP-event time of the loop                            */
-  double last_value;          /* sssp: last reduce(succ); pr: last residual `error`    */
+  double last_value;          /* sssp: distances improved by the last round (the part of the
+                               * reference's `succ` that decides termination; the op-by-op
+                               * driver reports the reference's reduce(m) itself);
+                               * pr: last residual `error`                              */
 } grb_algo_result;
 
-/* algorithm::sssp (algorithm/sssp.hpp:15-103): v = distances, FLT_MAX when unreachable. */
+/* algorithm::sssp (algorithm/sssp.hpp:15-103): v = distances, FLT_MAX when unreachable.
+ * Non-negative f32 weights run the same synchronous rounds in one launch (sssp_persist.hip);
+ * anything else, or GRB_SSSP_FUSED=0, runs the reference's call sequence op by op. */
 grb_info grb_sssp(grb_vector v, grb_matrix A, grb_index source, grb_descriptor desc,
                   grb_algo_result* result);
 /* algorithm::pr (algorithm/pr.hpp:15-94): A must already be the scaled column-stochastic

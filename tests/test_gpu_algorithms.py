@@ -217,6 +217,37 @@ def test_sssp(hb, graphs):
             assert np.array_equal(got == FLT_MAX, want == FLT_MAX)
 
 
+def test_sssp_rounds_are_the_references(hb, graphs):
+    """The one-launch SSSP keeps the reference's synchronous rounds: under every max_niter cap the
+    distances, the iteration count and the size of the last round's improved set (the next
+    frontier, f1.nvals) equal the op-level oracle driver's (algorithm/sssp.hpp restated call
+    for call in oracle/algorithms.py)."""
+    from backends import OracleBackend
+    from oracle import algorithms as oalg
+    ob = OracleBackend()
+    g = hb.g
+    for name, gr in (graphs[0], graphs[1], graphs[-1]):
+        ptr, ind = gr["csr"]
+        n = gr["n"]
+        rng = np.random.default_rng(5)
+        w = rng.integers(1, 9, ind.size).astype(F)
+        A = hb.matrix_from_csr(n, ptr, ind, w)
+        Ao = ob.matrix_from_csr(n, ptr, ind, w)
+        s = first_source(gr)
+        for cap in (1, 2, 3, 7, 10000):
+            do = ob.descriptor(mxvmode=1, max_niter=cap)
+            want, trace = oalg.sssp(Ao, s, do)
+            d = hb.descriptor(mxvmode=0, max_niter=cap)
+            v = g.Vector(n)
+            info, res = g.sssp(v, A, s, d)
+            assert info == 0
+            got = hb.dense_values(v)
+            assert np.array_equal(got, np.asarray(want, dtype=F)), (name, cap)
+            stopped = trace[-1][1] == 0 or trace[-1][2] == 0
+            assert res["iterations"] == (len(trace) if stopped else cap + 1), (name, cap, res, len(trace))
+            assert res["succ"] == trace[-1][1], (name, cap)
+
+
 def test_pagerank(hb, graphs):
     """algorithm::pr at fixed max_niter vs SimpleReferencePr, <= 1e-5 relative."""
     from oracle import simple_reference as sr
