@@ -6,10 +6,11 @@
 //                  "columns of B" are B's CSR rows, so C[i,j] = (+)_k A[i,k] (x) B[j,k] -- for
 //                  B = A = L this is |N(i) n N(j)| on every edge of L, whose sum is the triangle
 //                  count.  The reference gives a 32-lane warp to every row and binary-searches
-//                  every A entry in the B column; here one 64-lane wave owns a mask row and each
-//                  LANE owns a mask entry: it walks the shorter of (row i of A, column j of B)
-//                  and binary-searches the longer, so work per dot product is
-//                  min(d_i, d_j) * log max(d_i, d_j).  A's own row pointers are used (the
+//                  every A entry in the B column; here the mask entries are one flat range, a
+//                  64-lane wave takes 64 consecutive entries, short dot products are done by
+//                  a lane each and long ones by the whole wave (walk the shorter list, binary
+//                  search the longer: min(d_i, d_j) * log max(d_i, d_j) per dot product).
+//                  A's own row pointers are used (the
 //                  reference walks A with the MASK's row pointers, kernels/spgemm.hpp:35-36,51-56,
 //                  which is only meaningful when the two share structure -- as they do in tc()).
 //   grb_matrix_tril  lower triangle on the host, as the reference (tri.hpp:21-48, sequential only)
@@ -18,48 +19,99 @@
 
 namespace grb {
 
+constexpr int kLaneDotMax = 16;     // dot products whose shorter list is longer go to the whole wave
+
+// row of every mask entry (the entries are processed as one flat, evenly split range)
+__global__ void entry_rows_kernel(const Index* __restrict__ ptr, Index nrows, Index nvals, Index* __restrict__ row_of) {
+  const Index stride = (Index)gridDim.x * blockDim.x;
+  for (Index e = (Index)blockIdx.x * blockDim.x + threadIdx.x; e < nvals; e += stride) {
+    Index lo = 0, hi = nrows;               // largest r with ptr[r] <= e
+    while (hi - lo > 1) {
+      const Index mid = lo + ((hi - lo) >> 1);
+      if (ptr[mid] <= e) lo = mid; else hi = mid;
+    }
+    row_of[e] = lo;
+  }
+}
+
+__device__ inline Index lower_bound_dev(const Index* __restrict__ a, Index lo, Index hi, Index key) {
+  while (lo < hi) {
+    const Index mid = lo + ((hi - lo) >> 1);
+    if (a[mid] < key) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
+// One 64-lane wave takes 64 consecutive mask entries.  A lane computes its own dot product
+// when the shorter of the two lists has at most kLaneDotMax entries (walk it, binary-search
+// the longer one, searches only move right); the others are done one after the other by the
+// whole wave: the shorter list spread over the lanes, each lane binary-searching the longer,
+// partial sums folded with the semiring's add.  Work per dot product is
+// min(d_i, d_j) * log max(d_i, d_j) either way, but no lane of a wave is left walking a hub
+// row alone (RMAT-19 triangle count: 1074 ms with a lane per entry -> see DESIGN.md).
 template <int SR, typename T>
 __global__ __launch_bounds__(kBlock) void spgemm_masked_kernel(
-    T* __restrict__ c_val, const Index* __restrict__ m_ptr, const Index* __restrict__ m_ind,
+    T* __restrict__ c_val, const Index* __restrict__ m_row, const Index* __restrict__ m_ind,
     const void* __restrict__ m_val, int mask_f32, const Index* __restrict__ a_ptr, const Index* __restrict__ a_ind,
     const T* __restrict__ a_val, const Index* __restrict__ b_ptr, const Index* __restrict__ b_ind,
-    const T* __restrict__ b_val, Index nrows) {
+    const T* __restrict__ b_val, Index nvals) {
   typedef Semiring<SR, T> S;
   const int lane = lane_id();
   const Index wave_global = (Index)blockIdx.x * kWavesPerBlock + wave_id();
   const Index nwaves = (Index)gridDim.x * kWavesPerBlock;
-  for (Index row = wave_global; row < nrows; row += nwaves) {
-    const Index ms = m_ptr[row], me = m_ptr[row + 1];
-    const Index as = a_ptr[row], ae = a_ptr[row + 1];
-    for (Index e = ms + lane; e < me; e += kWave) {
-      T acc = S::identity();
-      if (mask_nonzero(m_val, mask_f32, e)) {
-        const Index col = m_ind[e];
-        const Index bs = b_ptr[col], be = b_ptr[col + 1];
-        const bool a_short = (ae - as) <= (be - bs);
-        const Index* s_ind = a_short ? a_ind : b_ind;   // list walked
-        const Index* l_ind = a_short ? b_ind : a_ind;   // list searched
-        const Index ss = a_short ? as : bs, se = a_short ? ae : be;
-        const Index ls = a_short ? bs : as, le = a_short ? be : ae;
-        Index lo_hint = ls;                              // both lists are sorted: searches only move right
-        for (Index p = ss; p < se; ++p) {
-          const Index key = s_ind[p];
-          Index lo = lo_hint, hi = le;
-          while (lo < hi) {
-            const Index mid = lo + ((hi - lo) >> 1);
-            if (l_ind[mid] < key) lo = mid + 1; else hi = mid;
-          }
-          lo_hint = lo;
-          if (lo < le && l_ind[lo] == key) {
-            const T av = a_short ? a_val[p] : a_val[lo];
-            const T bv = a_short ? b_val[lo] : b_val[p];
-            acc = S::add(S::mul(av, bv), acc);
-          }
-          if (lo >= le) break;
+  for (Index base = wave_global * kWave; base < nvals; base += nwaves * kWave) {
+    const Index e = base + lane;
+    const bool valid = e < nvals && mask_nonzero(m_val, mask_f32, e);
+    Index ss = 0, se = 0, ls = 0, le = 0;
+    bool a_short = true;
+    if (valid) {
+      const Index row = m_row[e], col = m_ind[e];
+      const Index as = a_ptr[row], ae = a_ptr[row + 1];
+      const Index bs = b_ptr[col], be = b_ptr[col + 1];
+      a_short = (ae - as) <= (be - bs);
+      ss = a_short ? as : bs; se = a_short ? ae : be;
+      ls = a_short ? bs : as; le = a_short ? be : ae;
+    }
+    T acc = S::identity();
+    const bool heavy = valid && (se - ss) > kLaneDotMax;
+    if (valid && !heavy) {
+      const Index* s_ind = a_short ? a_ind : b_ind;
+      const Index* l_ind = a_short ? b_ind : a_ind;
+      Index hint = ls;
+      for (Index p = ss; p < se && hint < le; ++p) {
+        const Index key = s_ind[p];
+        const Index lo = lower_bound_dev(l_ind, hint, le, key);
+        hint = lo;
+        if (lo < le && l_ind[lo] == key) {
+          const T av = a_short ? a_val[p] : a_val[lo];
+          const T bv = a_short ? b_val[lo] : b_val[p];
+          acc = S::add(S::mul(av, bv), acc);
         }
       }
-      c_val[e] = acc;
     }
+    unsigned long long todo = __ballot(heavy);
+    while (todo) {
+      const int src = __ffsll((long long)todo) - 1;
+      todo &= todo - 1;
+      const Index css = __shfl(ss, src, kWave), cse = __shfl(se, src, kWave);
+      const Index cls = __shfl(ls, src, kWave), cle = __shfl(le, src, kWave);
+      const bool c_a_short = __shfl((int)a_short, src, kWave) != 0;
+      const Index* s_ind = c_a_short ? a_ind : b_ind;
+      const Index* l_ind = c_a_short ? b_ind : a_ind;
+      T part = S::identity();
+      for (Index p = css + lane; p < cse; p += kWave) {
+        const Index key = s_ind[p];
+        const Index lo = lower_bound_dev(l_ind, cls, cle, key);
+        if (lo < cle && l_ind[lo] == key) {
+          const T av = c_a_short ? a_val[p] : a_val[lo];
+          const T bv = c_a_short ? b_val[lo] : b_val[p];
+          part = S::add(S::mul(av, bv), part);
+        }
+      }
+      part = wave_reduce(part, [](T x, T y) { return S::add(x, y); });
+      if (lane == src) acc = part;
+    }
+    if (e < nvals) c_val[e] = acc;
   }
 }
 
@@ -112,13 +164,18 @@ grb_info grb_mxm(grb_matrix C, grb_matrix mask, grb_accum accum, grb_semiring op
   C->h_csc_ptr.clear(); C->h_csc_ind.clear(); C->h_csc_val.clear();
   C->built = true;
   if (mask->nvals == 0) return GRB_SUCCESS;
-  const int grid = stream_grid((long long)mask->nrows * kWave, kBlock);
+  void* p_rows;
+  GRB_TRY(scratch(5, 4 * (size_t)mask->nvals, &p_rows));
+  hipLaunchKernelGGL(entry_rows_kernel, dim3(stream_grid(mask->nvals, kBlock)), dim3(kBlock), 0, s, mask->csr.ptr,
+                     mask->nrows, mask->nvals, (Index*)p_rows);
+  GRB_HIP_TRY(hipGetLastError());
+  const int grid = stream_grid(mask->nvals, kBlock);
   return dispatch_semiring(op, A->dtype, [&](auto tag, auto t) -> grb_info {
     using T = decltype(t);
     constexpr int SR = decltype(tag)::value;
-    hipLaunchKernelGGL((spgemm_masked_kernel<SR, T>), dim3(grid), dim3(kBlock), 0, s, (T*)C->csr.val, mask->csr.ptr,
-                       mask->csr.ind, mask->csr.val, mask->dtype == GRB_F32, Aa.ptr, Aa.ind, (const T*)Aa.val, Bb.ptr,
-                       Bb.ind, (const T*)Bb.val, mask->nrows);
+    hipLaunchKernelGGL((spgemm_masked_kernel<SR, T>), dim3(grid), dim3(kBlock), 0, s, (T*)C->csr.val,
+                       (const Index*)p_rows, mask->csr.ind, mask->csr.val, mask->dtype == GRB_F32, Aa.ptr, Aa.ind,
+                       (const T*)Aa.val, Bb.ptr, Bb.ind, (const T*)Bb.val, mask->nvals);
     GRB_HIP_TRY(hipGetLastError());
     return GRB_SUCCESS;
   });
