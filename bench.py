@@ -19,6 +19,8 @@ Rank 0 prints ONE JSON line.  Extra objects on it:
   bfs_total     the kernel's own wall-clock time per traversal and the per-level table of one
   spmv          the generic SpMV kernel (PlusMultiplies, f32) on the same graph: algorithmic
                 8*nnz + 12*n + 4 bytes per launch / HIP-event mean launch time
+  primitives    eWiseAdd / eWiseMult / reduce / assign on 64 Mi-element f32 vectors: GB/s and
+                fraction of the 8 TB/s HBM peak
   cpu_baseline  the oracle's SimpleReferenceBfs restatement (one host core) on a bounded
                 sample of the same workload (rank 0, N = 1 only)
 """
@@ -190,6 +192,31 @@ def main():
                          "achieved": round(sb / (ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(sb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                          "traffic": pmc_traffic("spmv_hub_kernel"), "gflops": round(2 * nnz / (ms * 1e-3) / 1e9, 1)}
+
+        # ---- the streaming primitives of the path (eWiseAdd / eWiseMult / reduce / assign) on
+        #      64 Mi-element f32 vectors: algorithmic bytes per element / HIP-event time
+        pn = 1 << 26
+        pu, pv, pw = g.Vector(pn), g.Vector(pn), g.Vector(pn)
+        pu.fill(1.5); pv.fill(2.5); pw.fill(0.0)
+        pd = g.Descriptor(); pd.loadArgs()
+
+        def prim(fn, bytes_per_elt, reps=10):
+            fn()
+            g.timer_start()
+            for _ in range(reps):
+                fn()
+            pms = g.timer_stop() / reps
+            gbs = bytes_per_elt * pn / (pms * 1e-3) / 1e9
+            return {"ms": round(pms, 4), "GBps": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 3)}
+
+        extra["primitives"] = {
+            "n": pn, "dtype": "f32",
+            "eWiseAdd": prim(lambda: g.eWiseAdd(pw, None, None, "PlusMultiplies", pu, pv, pd), 12),
+            "eWiseMult": prim(lambda: g.eWiseMult(pw, None, None, "PlusMultiplies", pu, pv, pd), 12),
+            "reduce": prim(lambda: g.reduce(None, "PlusMonoid", pu, pd), 4),
+            "assign": prim(lambda: g.assign(pw, pu, None, 3.0, None, pn, pd), 8),
+        }
+        del pu, pv, pw
 
         # ---- CPU baseline: the oracle's sequential BFS on a bounded sample (checker code,
         #      timed beside the GPU run; never part of the product path)
