@@ -86,7 +86,7 @@ __device__ inline void discovered(const PersistArgs& a, Index v, float new_label
 __device__ inline void push_visit(const PersistArgs& a, unsigned int* V, unsigned int* Fn, Index dst,
                                   float new_label, LevelCounters& c) {
   const unsigned int bit = 1u << (dst & 31);
-  if (V[dst >> 5] & bit) return;                    // may be stale: the atomic decides
+  if (fresh(&V[dst >> 5]) & bit) return;
   const unsigned int old = atomicOr(&V[dst >> 5], bit);
   if (old & bit) return;
   atomicOr(&Fn[dst >> 5], bit);
@@ -120,7 +120,7 @@ __global__ __launch_bounds__(kPThreads) void bfs_persistent_kernel(PersistArgs a
     atomicOr(&a.V[0][a.source >> 5], 1u << (a.source & 31));
     a.label[a.source] = 1.f;
   }
-  if (a.mode == GRB_PULLONLY && !grid_sync(&st->bar, gen)) return;
+  if (a.mode == GRB_PULLONLY && !grid_sync(&st->bar, gen, false)) return;
 
   // ---- level loop (all scalars below are identical in every workgroup)
   Index nf = 1;
@@ -174,7 +174,7 @@ __global__ __launch_bounds__(kPThreads) void bfs_persistent_kernel(PersistArgs a
           // list the >= kBigDeg frontier vertices as 1024-edge entries (wave-aggregated append)
           for (long long base = 0; base < nwords; base += gthreads) {
             const long long i = base + gtid;
-            const unsigned int w = (i < nwords) ? Fc[i] : 0u;
+            const unsigned int w = (i < nwords) ? fresh(&Fc[i]) : 0u;
             int mine = 0;
             for (unsigned int t = w; t; t &= t - 1) {
               const Index v = (Index)i * 32 + (__ffs((int)t) - 1);
@@ -204,12 +204,13 @@ __global__ __launch_bounds__(kPThreads) void bfs_persistent_kernel(PersistArgs a
             }
           }
           stamp();
-          if (!grid_sync(&st->bar, gen)) return;
+          if (!grid_sync(&st->bar, gen, false)) return;
           stamp();
           int nent = (int)__hip_atomic_load(bcount, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           if (nent > a.big_cap) nent = a.big_cap;
           for (int e = blockIdx.x; e < nent; e += G) {
-            const int2 ent = a.big_list[e];
+            const unsigned long long eb = fresh(reinterpret_cast<const unsigned long long*>(&a.big_list[e]));
+            const int2 ent = make_int2((int)(eb & 0xffffffffull), (int)(eb >> 32));
             const Index p = a.optr[ent.x] + ent.y * kBigChunk + tid;
             if (p < a.optr[ent.x + 1]) push_visit(a, V, Fn, a.oind[p], new_label, c);
           }
@@ -220,7 +221,7 @@ __global__ __launch_bounds__(kPThreads) void bfs_persistent_kernel(PersistArgs a
         __syncthreads();
         for (long long base = 0; base < nwords; base += gthreads) {
           const long long i = (base / G + tid) * G + blockIdx.x;      // word index, stride G inside the WG
-          unsigned int w = (i < nwords) ? Fc[i] : 0u;
+          unsigned int w = (i < nwords) ? fresh(&Fc[i]) : 0u;
           for (; w; w &= w - 1) {
             const Index v = (Index)i * 32 + (__ffs((int)w) - 1);
             const Index s = a.optr[v], e = a.optr[v + 1];
@@ -247,6 +248,11 @@ __global__ __launch_bounds__(kPThreads) void bfs_persistent_kernel(PersistArgs a
       last_dir = 0;
     } else {
       // ================= pull =================
+      // The barriers of this kernel do not invalidate; push levels read other workgroups' words
+      // with fresh().  A pull level probes the visited bitmap millions of times, which is
+      // faster through L1 with ordinary loads, so it pays the invalidate itself, once.
+      if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      __syncthreads();
       // One wave owns a block of 16 chunks = 1024 vertices = 32 bitmap words and runs every
       // stage for all 16 chunks at once, so a stage costs one memory latency per block instead
       // of one per chunk:  words -> hint probe -> four serial probes -> leftovers -> outputs.
@@ -448,7 +454,7 @@ __global__ __launch_bounds__(kPThreads) void bfs_persistent_kernel(PersistArgs a
       for (int w = 0; w < kPWaves; ++w) t += s_red[w][tid];
       if (t) __hip_atomic_fetch_add(&acc[(blockIdx.x & 7) * 16 + tid], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (!grid_sync(&st->bar, gen)) return;
+    if (!grid_sync(&st->bar, gen, false)) return;
     stamp();
     if (wave == 0) {
       unsigned long long q = 0;
@@ -485,7 +491,7 @@ __global__ __launch_bounds__(kPThreads) void bfs_persistent_kernel(PersistArgs a
   {
     const unsigned int* Vf = a.V[cur];
     for (long long i = gtid; i < n; i += gthreads)
-      if (!((Vf[i >> 5] >> (i & 31)) & 1u)) a.label[i] = 0.f;
+      if (!((fresh(&Vf[i >> 5]) >> (i & 31)) & 1u)) a.label[i] = 0.f;
   }
   stamp();
   if (a.trace && gtid == 0) a.trace[0] = (unsigned long long)ntrace;

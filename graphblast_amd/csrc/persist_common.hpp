@@ -28,10 +28,18 @@ __device__ inline void publish(V* p, V v) {
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// The reading side of the same recipe: data another workgroup published during this launch
+// is read with an agent-scope load (served coherently, not from this CU's L1), so that a
+// barrier whose readers all use fresh() can skip the L1/L2 invalidate on the way out.
+template <typename V>
+__device__ inline V fresh(const V* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // ---- grid barrier ---------------------------------------------------------------------
 // Monotonic counters: generation g of a group of m arrivers completes when its counter
 // reaches m * g.  Returns false when the barrier was abandoned (spin bound hit somewhere).
-__device__ inline bool grid_sync(GridBarrier* st, unsigned& gen) {
+__device__ inline bool grid_sync(GridBarrier* st, unsigned& gen, bool invalidate = true) {
   __shared__ int s_ok;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's write-through stores have landed
   __syncthreads();
@@ -56,7 +64,7 @@ __device__ inline bool grid_sync(GridBarrier* st, unsigned& gen) {
         break;
       }
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    if (invalidate) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     s_ok = ok;
   }
   __syncthreads();
