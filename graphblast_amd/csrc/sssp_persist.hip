@@ -60,10 +60,10 @@ __device__ inline void relax(const SsspArgs& a, const float* Dc, float* Dn, unsi
                              RoundCounters& c) {
   const Index v = a.oind[p];
   const float nd = du + a.oval[p];
-  if (!(nd < Dc[v])) return;
+  if (!(nd < fresh(&Dc[v]))) return;
   atomicMin(reinterpret_cast<unsigned int*>(&Dn[v]), __float_as_uint(nd));
   const unsigned int bit = 1u << (v & 31);
-  if (Fn[v >> 5] & bit) return;                     // may be stale: the atomic decides
+  if (fresh(&Fn[v >> 5]) & bit) return;
   const unsigned int old = atomicOr(&Fn[v >> 5], bit);
   if (old & bit) return;
   ++c.improved;
@@ -87,13 +87,13 @@ __device__ inline void relax_batch(const SsspArgs& a, const float* Dc, float* Dn
     nd[j] = du + a.oval[p];
   }
 #pragma unroll
-  for (int j = 0; j < N; ++j) dv[j] = Dc[v[j]];
+  for (int j = 0; j < N; ++j) dv[j] = fresh(&Dc[v[j]]);
   unsigned int fw[N];
 #pragma unroll
   for (int j = 0; j < N; ++j) {
     ok[j] = ok[j] && nd[j] < dv[j];
     if (ok[j]) atomicMin(reinterpret_cast<unsigned int*>(&Dn[v[j]]), __float_as_uint(nd[j]));
-    fw[j] = ok[j] ? Fn[v[j] >> 5] : 0xffffffffu;
+    fw[j] = ok[j] ? fresh(&Fn[v[j] >> 5]) : 0xffffffffu;
   }
   unsigned int old[N];
 #pragma unroll
@@ -151,11 +151,11 @@ __global__ __launch_bounds__(kPThreads) void sssp_persistent_kernel(SsspArgs a) 
     // the big frontier vertices as 1024-edge entries when the totals announced any
     for (long long base = 0; base < nwords; base += gthreads) {
       const long long i = base + gtid;
-      const unsigned int wc = (i < nwords) ? Fc[i] : 0u;
-      const unsigned int wp = (i < nwords) ? Fp[i] : 0u;
+      const unsigned int wc = (i < nwords) ? fresh(&Fc[i]) : 0u;
+      const unsigned int wp = (i < nwords) ? fresh(&Fp[i]) : 0u;
       for (unsigned int t = wc | wp; t; t &= t - 1) {
         const Index v = (Index)i * 32 + (__ffs((int)t) - 1);
-        atomicMin(reinterpret_cast<unsigned int*>(&Dn[v]), __float_as_uint(Dc[v]));
+        atomicMin(reinterpret_cast<unsigned int*>(&Dn[v]), __float_as_uint(fresh(&Dc[v])));
       }
       if (nbig > 0) {
         int mine = 0;
@@ -189,13 +189,14 @@ __global__ __launch_bounds__(kPThreads) void sssp_persistent_kernel(SsspArgs a) 
     }
     RoundCounters c;
     if (nbig > 0) {
-      if (!grid_sync(&st->bar, gen)) return;
+      if (!grid_sync(&st->bar, gen, false)) return;
       int nent = (int)__hip_atomic_load(bcount, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (nent > a.big_cap) nent = a.big_cap;
       for (int e = blockIdx.x; e < nent; e += G) {
-        const int2 ent = a.big_list[e];
+        const unsigned long long eb = fresh(reinterpret_cast<const unsigned long long*>(&a.big_list[e]));
+        const int2 ent = make_int2((int)(eb & 0xffffffffull), (int)(eb >> 32));
         const Index p = a.optr[ent.x] + ent.y * kSsspChunk + tid;
-        if (p < a.optr[ent.x + 1]) relax(a, Dc, Dn, Fn, Dc[ent.x], p, c);
+        if (p < a.optr[ent.x + 1]) relax(a, Dc, Dn, Fn, fresh(&Dc[ent.x]), p, c);
       }
     }
     // ---- relax the rest of the frontier: words interleaved over the workgroups
@@ -203,7 +204,7 @@ __global__ __launch_bounds__(kPThreads) void sssp_persistent_kernel(SsspArgs a) 
     __syncthreads();
     for (long long base = 0; base < nwords; base += gthreads) {
       const long long i = (base / G + tid) * G + blockIdx.x;
-      unsigned int w = (i < nwords) ? Fc[i] : 0u;
+      unsigned int w = (i < nwords) ? fresh(&Fc[i]) : 0u;
       for (; w; w &= w - 1) {
         const Index v = (Index)i * 32 + (__ffs((int)w) - 1);
         const Index s = a.optr[v], e = a.optr[v + 1];
@@ -213,7 +214,7 @@ __global__ __launch_bounds__(kPThreads) void sssp_persistent_kernel(SsspArgs a) 
           const int slot = atomicAdd(&s_nmed, 1);
           if (slot < kSsspMedCap) { s_med[slot] = v; continue; }
         }
-        const float du = Dc[v];
+        const float du = fresh(&Dc[v]);
         for (Index p = s; p < e; p += 4) relax_batch<4>(a, Dc, Dn, Fn, du, p, e, c);
       }
       __syncthreads();
@@ -221,7 +222,7 @@ __global__ __launch_bounds__(kPThreads) void sssp_persistent_kernel(SsspArgs a) 
       for (int k = wave; k < nm; k += kPWaves) {
         const Index v = s_med[k];
         const Index e = a.optr[v + 1];
-        const float du = Dc[v];
+        const float du = fresh(&Dc[v]);
         for (Index p = a.optr[v] + lane; p < e; p += kWave) relax(a, Dc, Dn, Fn, du, p, c);
       }
       __syncthreads();
@@ -240,7 +241,7 @@ __global__ __launch_bounds__(kPThreads) void sssp_persistent_kernel(SsspArgs a) 
       for (int w = 0; w < kPWaves; ++w) t += s_red[w][tid];
       if (t) __hip_atomic_fetch_add(&acc[(blockIdx.x & 7) * 16 + tid], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (!grid_sync(&st->bar, gen)) return;
+    if (!grid_sync(&st->bar, gen, false)) return;
     if (wave == 0) {
       unsigned long long q = 0;
       if (lane < 16) q = __hip_atomic_load(&acc[(lane >> 1) * 16 + (lane & 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -262,7 +263,7 @@ __global__ __launch_bounds__(kPThreads) void sssp_persistent_kernel(SsspArgs a) 
     const int res = (last_round + 1) % 3;
     if (res != 0) {
       const float* Dr = a.D[res];
-      for (long long i = gtid; i < a.n; i += gthreads) a.D[0][i] = Dr[i];
+      for (long long i = gtid; i < a.n; i += gthreads) a.D[0][i] = fresh(&Dr[i]);
     }
   }
   if (gtid == 0) {
