@@ -82,6 +82,7 @@ _SIGS = {
     "grb_matrix_build": [_vp, _vp, _vp, _vp, _i],
     "grb_matrix_build_csr": [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp],
     "grb_matrix_adopt_device_csr": [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp],
+    "grb_matrix_ingest_device": [_vp, _vp, _vp, _vp, _i, _i],
     "grb_matrix_nrows": [_vp, _ip],
     "grb_matrix_ncols": [_vp, _ip],
     "grb_matrix_nvals": [_vp, _ip],

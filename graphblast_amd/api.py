@@ -277,6 +277,15 @@ class Matrix:
         return _lib.load().grb_matrix_adopt_device_csr(self._h, d_ptr, d_ind, d_val, int(nvals), d_cptr, d_cind,
                                                        d_cval)
 
+    def ingest_device(self, d_rows, d_cols, d_vals, nvals, symmetrize=False, drop_selfloops=True,
+                      drop_duplicates=True, keep=()):
+        """readMtx's loader semantics + build on a DEVICE coordinate list (graphblas/util.hpp:197-329,
+        363-430): optionally add the reverse of every off-diagonal entry, drop self loops, drop
+        duplicates (first wins); d_vals None = pattern."""
+        self._keep = list(keep)
+        flags = (1 if symmetrize else 0) | (2 if drop_selfloops else 0) | (4 if drop_duplicates else 0)
+        return _lib.load().grb_matrix_ingest_device(self._h, d_rows, d_cols, d_vals, int(nvals), flags)
+
     def nrows(self):
         return self._nrows
 

@@ -189,6 +189,9 @@ static inline double load_scalar(int dtype, const void* src) {
 
 using namespace grb;
 
+grb_info device_build_from_coo(grb_matrix A, const Index* d_rows, const Index* d_cols, const void* d_vals,
+                               long long nvals_in, int flags);
+
 extern "C" {
 
 // =============================================================================== library
@@ -666,27 +669,6 @@ static grb_info upload(CsrArrays* d, Index n, Index nvals, const std::vector<Ind
   return GRB_SUCCESS;
 }
 
-// Sorted (major, minor) compressed build; ties keep input order (util.hpp:501-559).
-static void coo_to_compressed(const grb_index* major, const grb_index* minor, const uint32_t* vals, Index nvals,
-                              Index nmajor, std::vector<Index>* ptr, std::vector<Index>* ind,
-                              std::vector<uint32_t>* val) {
-  std::vector<Index> order((size_t)nvals);
-  std::iota(order.begin(), order.end(), 0);
-  std::stable_sort(order.begin(), order.end(), [&](Index a, Index b) {
-    if (major[a] != major[b]) return major[a] < major[b];
-    return minor[a] < minor[b];
-  });
-  ptr->assign((size_t)nmajor + 1, 0);
-  ind->resize((size_t)nvals);
-  val->resize((size_t)nvals);
-  for (Index i = 0; i < nvals; ++i) (*ptr)[(size_t)major[i] + 1]++;
-  for (Index r = 0; r < nmajor; ++r) (*ptr)[(size_t)r + 1] += (*ptr)[r];
-  for (Index i = 0; i < nvals; ++i) {
-    (*ind)[i] = minor[order[i]];
-    (*val)[i] = vals[order[i]];
-  }
-}
-
 // CSR -> CSC by counting sort (keeps row order inside every column).
 static void transpose_compressed(Index nmajor, Index nminor, const std::vector<Index>& ptr,
                                  const std::vector<Index>& ind, const std::vector<uint32_t>& val,
@@ -716,18 +698,53 @@ static grb_info matrix_finish_build(grb_matrix A) {
   return GRB_SUCCESS;
 }
 
+static grb_info finish_device_build(grb_matrix A) {
+  GRB_TRY(build_spmv_plan(A->h_csr_ptr, A->nrows, A->ncols, &A->plan_csr));
+  GRB_TRY(build_spmv_plan(A->h_csc_ptr, A->ncols, A->nrows, &A->plan_csc));
+  A->built = true;
+  return GRB_SUCCESS;
+}
+
+// build(): the coordinate list is uploaded and sorted / compressed on the device (build.hip);
+// ties keep input order, duplicates are kept (util.hpp:501-559).
 grb_info grb_matrix_build(grb_matrix A, const grb_index* rows, const grb_index* cols, const void* values,
                           grb_index nvals) {
   if (!A) return GRB_UNINITIALIZED_OBJECT;
   if (nvals < 0) return GRB_INVALID_VALUE;
   for (Index i = 0; i < nvals; ++i)
     if (rows[i] < 0 || rows[i] >= A->nrows || cols[i] < 0 || cols[i] >= A->ncols) return GRB_INDEX_OUT_OF_BOUNDS;
+  GRB_TRY(ctx_init());
   matrix_release_device(A);
-  A->nvals = nvals;
-  const uint32_t* v = (const uint32_t*)values;
-  coo_to_compressed(rows, cols, v, nvals, A->nrows, &A->h_csr_ptr, &A->h_csr_ind, &A->h_csr_val);
-  coo_to_compressed(cols, rows, v, nvals, A->ncols, &A->h_csc_ptr, &A->h_csc_ind, &A->h_csc_val);
-  return matrix_finish_build(A);
+  Index *d_r = nullptr, *d_c = nullptr;
+  void* d_v = nullptr;
+  const size_t cap = nvals > 0 ? (size_t)nvals : 1;
+  GRB_HIP_TRY(hipMalloc((void**)&d_r, 4 * cap));
+  GRB_HIP_TRY(hipMalloc((void**)&d_c, 4 * cap));
+  GRB_HIP_TRY(hipMalloc(&d_v, 4 * cap));
+  grb_info info = GRB_SUCCESS;
+  if (nvals > 0) {
+    if (hipMemcpy(d_r, rows, 4 * cap, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(d_c, cols, 4 * cap, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(d_v, values, 4 * cap, hipMemcpyHostToDevice) != hipSuccess)
+      info = GRB_PANIC;
+  }
+  if (info == GRB_SUCCESS) info = device_build_from_coo(A, d_r, d_c, d_v, nvals, 0);
+  (void)hipFree(d_r); (void)hipFree(d_c); (void)hipFree(d_v);
+  GRB_TRY(info);
+  return finish_device_build(A);
+}
+
+// The loader's semantics (util.hpp:197-329) on a DEVICE coordinate list: flags bit 0 add the
+// reverse of every off-diagonal entry, bit 1 drop self loops, bit 2 drop duplicates (first
+// occurrence wins); d_values may be NULL (pattern: every value 1).
+grb_info grb_matrix_ingest_device(grb_matrix A, const grb_index* d_rows, const grb_index* d_cols, const void* d_values,
+                                  grb_index nvals, int flags) {
+  if (!A) return GRB_UNINITIALIZED_OBJECT;
+  if (nvals < 0 || (nvals > 0 && (!d_rows || !d_cols))) return GRB_INVALID_VALUE;
+  GRB_TRY(ctx_init());
+  matrix_release_device(A);
+  GRB_TRY(device_build_from_coo(A, d_rows, d_cols, d_values, nvals, flags));
+  return finish_device_build(A);
 }
 
 grb_info grb_matrix_build_csr(grb_matrix A, const grb_index* csr_ptr, const grb_index* csr_ind, const void* csr_val,

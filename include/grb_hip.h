@@ -148,6 +148,12 @@ grb_info grb_matrix_free(grb_matrix A);
  * (coo2csr + coo2csc, backend/cuda/sparse_matrix.hpp:289-351). */
 grb_info grb_matrix_build(grb_matrix A, const grb_index* row_indices, const grb_index* col_indices,
                           const void* values, grb_index nvals);
+/* Ingest on the device: the loader's semantics of readMtx (util.hpp:197-329,
+ * 363-430) applied to a DEVICE coordinate list, then the same sort + compress as build().
+ * flags: 1 add the reverse of every off-diagonal entry (symmetric / --directed 2), 2 drop self
+ * loops, 4 drop duplicates (first occurrence wins).  d_values NULL = pattern (every value 1). */
+grb_info grb_matrix_ingest_device(grb_matrix A, const grb_index* d_rows, const grb_index* d_cols,
+                                  const void* d_values, grb_index nvals, int flags);
 /* Host CSR in, CSC derived (csr2csc); `csc_*` may be given to skip the transpose. */
 grb_info grb_matrix_build_csr(grb_matrix A, const grb_index* csr_row_ptr, const grb_index* csr_col_ind,
                               const void* csr_val, grb_index nvals, const grb_index* csc_col_ptr,

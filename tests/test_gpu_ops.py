@@ -395,3 +395,46 @@ def test_matrix_build_matches_oracle_loader(hb, ob):
             same(x, y, what=name)
         for x, y in zip(A_h.host_csc(), (A_o.cscColPtr, A_o.cscRowInd, A_o.cscVal)):
             same(x, y, what=name)
+
+
+@pytest.mark.gpu
+def test_device_build_and_ingest():
+    """build() sorts and compresses on the device: CSR and CSC equal a stable host sort of the
+    same coordinate list (duplicates kept, ties in input order).  ingest_device applies the
+    loader's options (reverse edges, self loops, duplicates) and must equal the oracle loader's
+    result on the same list."""
+    import torch
+    import graphblast_amd as g
+    rng = np.random.default_rng(11)
+    for nr, nc, m in ((1, 1, 0), (5, 7, 3), (300, 300, 5000), (70000, 65000, 400000), (1 << 20, 1 << 20, 3000000)):
+        r = rng.integers(0, nr, m).astype(np.int32)
+        c = rng.integers(0, nc, m).astype(np.int32)
+        v = rng.integers(1, 1000, m).astype(np.float32)
+        A = g.Matrix(nr, nc)
+        assert A.build(r, c, v, m, None) == 0
+        order = np.lexsort((c, r))                       # stable: ties keep input order
+        ptr = np.zeros(nr + 1, np.int64); np.add.at(ptr, r + 1, 1); ptr = np.cumsum(ptr)
+        hp, hi, hv = A.host_csr()
+        assert np.array_equal(hp, ptr) and np.array_equal(hi, c[order]) and np.array_equal(hv, v[order])
+        order2 = np.lexsort((r, c))
+        cp = np.zeros(nc + 1, np.int64); np.add.at(cp, c + 1, 1); cp = np.cumsum(cp)
+        tp, ti, tv = A.host_csc()
+        assert np.array_equal(tp, cp) and np.array_equal(ti, r[order2])
+        # equal (col, row) pairs keep CSR order, which is input order
+        assert np.array_equal(tv, v[order2])
+    # loader semantics on the device
+    dev = torch.device("cuda", 0)
+    for n, m, sym in ((50, 400, True), (50, 400, False), (100000, 1500000, True)):
+        r = rng.integers(0, n, m).astype(np.int32)
+        c = rng.integers(0, n, m).astype(np.int32)
+        tr, tc = torch.as_tensor(r).to(dev), torch.as_tensor(c).to(dev)
+        A = g.Matrix(n, n)
+        assert A.ingest_device(tr.data_ptr(), tc.data_ptr(), None, m, symmetrize=sym, keep=(tr, tc)) == 0
+        rr, cc = (np.concatenate([r, c]), np.concatenate([c, r])) if sym else (r, c)
+        keep = rr != cc
+        key = np.unique(rr[keep].astype(np.int64) * n + cc[keep])
+        wr, wc = key // n, key % n
+        ptr = np.zeros(n + 1, np.int64); np.add.at(ptr, wr + 1, 1); ptr = np.cumsum(ptr)
+        hp, hi, hv = A.host_csr()
+        assert np.array_equal(hp, ptr) and np.array_equal(hi, wc) and np.all(hv == 1.0)
+        assert A.nvals() == key.size
