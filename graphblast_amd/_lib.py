@@ -83,6 +83,8 @@ _SIGS = {
     "grb_matrix_build_csr": [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp],
     "grb_matrix_adopt_device_csr": [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp],
     "grb_matrix_ingest_device": [_vp, _vp, _vp, _vp, _i, _i],
+    "grb_matrix_eWiseMult_scalar": [_vp, _i, _vp, C.c_double],
+    "grb_matrix_eWiseMult_vector": [_vp, _i, _vp, _vp, _vp],
     "grb_matrix_nrows": [_vp, _ip],
     "grb_matrix_ncols": [_vp, _ip],
     "grb_matrix_nvals": [_vp, _ip],

@@ -115,9 +115,60 @@ __global__ __launch_bounds__(kBlock) void spgemm_masked_kernel(
   }
 }
 
+// Stored values (x) a scalar, or (x) a vector entry picked by the row (by_major) or by the stored
+// index (kernels/ewisemult.hpp:160-237: eWiseMultKernel scalar overload, eWiseMultCSRKernel,
+// eWiseMultCSCKernel -- 32-lane warp per row there, a 64-lane wave per row here).
+template <int SR, typename T>
+__global__ __launch_bounds__(kBlock) void matrix_scale_kernel(const Index* __restrict__ ptr, const Index* __restrict__ ind,
+                                                              T* __restrict__ val, Index nmajor, const T* __restrict__ vec,
+                                                              T scalar, int mode /*0 scalar, 1 by major, 2 by minor*/) {
+  typedef Semiring<SR, T> S;
+  const int lane = lane_id();
+  const Index nwaves = (Index)gridDim.x * kWavesPerBlock;
+  for (Index r = (Index)blockIdx.x * kWavesPerBlock + wave_id(); r < nmajor; r += nwaves) {
+    const Index e = ptr[r + 1];
+    const T bm = mode == 1 ? vec[r] : scalar;
+    for (Index p = ptr[r] + lane; p < e; p += kWave) {
+      const T b = mode == 2 ? vec[ind[p]] : bm;
+      val[p] = S::mul(val[p], b);
+    }
+  }
+}
+
 }  // namespace grb
 
 using namespace grb;
+
+static grb_info matrix_scale(grb_matrix A, int op, grb_vector B, double scalar, bool by_row) {
+  if (!A->built) return GRB_UNINITIALIZED_OBJECT;
+  if (!A->owned) return GRB_INVALID_OBJECT;             // adopted storage belongs to the caller
+  hipStream_t s = ctx().stream;
+  const void* vec = nullptr;
+  if (B) {
+    if (B->dtype != A->dtype) return GRB_DOMAIN_MISMATCH;
+    if (B->nsize != (by_row ? A->nrows : A->ncols)) return GRB_DIMENSION_MISMATCH;
+    if (B->vec_type != GRB_DENSE) return GRB_NOT_IMPLEMENTED;   // callers densify (extractTuples semantics)
+    vec = B->d_val;
+  }
+  grb_info info = dispatch_semiring(op, A->dtype, [&](auto tag, auto t) -> grb_info {
+    using T = decltype(t);
+    constexpr int SR = decltype(tag)::value;
+    for (int o = 0; o < 2; ++o) {
+      const CsrArrays& M = o == 0 ? A->csr : A->csc;
+      if (!M.ptr || M.nvals == 0) continue;
+      // CSR rows are matrix rows, CSC "rows" are matrix columns
+      const int mode = !B ? 0 : ((o == 0) == by_row ? 1 : 2);
+      hipLaunchKernelGGL((matrix_scale_kernel<SR, T>), dim3(stream_grid((long long)M.n * kWave, kBlock)), dim3(kBlock), 0,
+                         s, M.ptr, M.ind, (T*)M.val, M.n, (const T*)vec, (T)scalar, mode);
+      GRB_HIP_TRY(hipGetLastError());
+    }
+    return GRB_SUCCESS;
+  });
+  A->h_csr_val.clear(); A->h_csr_ind.clear();           // host mirrors are re-read on demand
+  A->h_csc_val.clear(); A->h_csc_ind.clear();
+  A->nonneg_values = -1;
+  return info;
+}
 
 extern "C" {
 
@@ -179,6 +230,22 @@ grb_info grb_mxm(grb_matrix C, grb_matrix mask, grb_accum accum, grb_semiring op
     GRB_HIP_TRY(hipGetLastError());
     return GRB_SUCCESS;
   });
+}
+
+// eWiseMult, matrix (x) broadcast scalar (operations.hpp:206-228), in place (C == A)
+grb_info grb_matrix_eWiseMult_scalar(grb_matrix C, grb_semiring op, grb_matrix A, double val) {
+  if (!C || !A) return GRB_UNINITIALIZED_OBJECT;
+  if (C != A) return GRB_NOT_IMPLEMENTED;
+  return matrix_scale(A, op, nullptr, val, true);
+}
+
+// eWiseMult, matrix (x) broadcast vector (operations.hpp:240-267): C(i,j) = A(i,j) (x) B(i), or
+// B(j) with GrB_INP1 = GrB_TRAN; in place (C == A)
+grb_info grb_matrix_eWiseMult_vector(grb_matrix C, grb_semiring op, grb_matrix A, grb_vector B, grb_descriptor desc) {
+  if (!C || !A || !B || !desc) return GRB_UNINITIALIZED_OBJECT;
+  if (C != A) return GRB_NOT_IMPLEMENTED;
+  if (desc->desc[GRB_INP0] != GRB_DEFAULT) return GRB_INVALID_VALUE;
+  return matrix_scale(A, op, B, 0.0, desc->desc[GRB_INP1] != GRB_TRAN);
 }
 
 grb_info grb_reduce_matrix_scalar(double* val, grb_accum accum, grb_monoid op, grb_matrix A, grb_descriptor desc) {

@@ -717,7 +717,11 @@ Info eWiseMult(Matrix<c>* C, const Matrix<m>* mask, BinaryOpT accum, SemiringT o
                Descriptor* desc) {
   if (C == NULL || A == NULL || desc == NULL) return GrB_UNINITIALIZED_OBJECT;
   if (mask != NULL || static_cast<const void*>(C) != static_cast<const void*>(A)) return GrB_NOT_IMPLEMENTED;
-  return C->transform_values([&](Index, Index, c v) { return op.mul_op(v, static_cast<c>(val)); });
+  (void)accum;
+  const Info i = to_info(grb_matrix_eWiseMult_scalar(C->handle(), (grb_semiring)SemiringT::grb_id, C->handle(),
+                                                     static_cast<double>(val)));
+  if (i != GrB_SUCCESS) return i;
+  return C->refresh_all();
 }
 
 // eWiseMult, matrix x broadcast column vector: C(i,j) = A(i,j) (x) B(i); with GrB_INP1 =
@@ -732,6 +736,13 @@ Info eWiseMult(Matrix<c>* C, const Matrix<m>* mask, BinaryOpT accum, SemiringT o
   desc->get(GrB_INP0, &inp0);
   desc->get(GrB_INP1, &inp1);
   if (inp0 != GrB_DEFAULT) return GrB_INVALID_VALUE;
+  (void)accum;
+  {                                  // device path: dense B (the case of example/gpr.cu); else host below
+    const grb_info di = grb_matrix_eWiseMult_vector(C->handle(), (grb_semiring)SemiringT::grb_id, C->handle(),
+                                                    const_cast<Vector<b>*>(B)->handle(), desc->handle());
+    if (di == GRB_SUCCESS) return C->refresh_all();
+    if (di != GRB_NOT_IMPLEMENTED && di != GRB_INVALID_OBJECT) return to_info(di);
+  }
   Index n = 0;
   B->size(&n);
   std::vector<b> bv;

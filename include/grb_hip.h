@@ -211,6 +211,12 @@ grb_info grb_extractGather(grb_vector w, grb_vector mask, grb_accum accum, grb_v
 /* mxm, masked SpGEMM only   operations.hpp:22-48 -> backend :18-78 (spgemm.hpp:22-110) */
 grb_info grb_mxm(grb_matrix C, grb_matrix mask, grb_accum accum, grb_semiring op, grb_matrix A, grb_matrix B,
                  grb_descriptor desc);
+/* eWiseMult, matrix (x) broadcast scalar / vector, in place (C == A)   operations.hpp:206-267 ->
+ * backend ewisemult.hpp:275-341,470-622 + kernels/ewisemult.hpp:160-237.  Vector form:
+ * C(i,j) = A(i,j) (x) B(i), or B(j) with GrB_INP1 = GrB_TRAN; B must be dense. */
+grb_info grb_matrix_eWiseMult_scalar(grb_matrix C, grb_semiring op, grb_matrix A, double val);
+grb_info grb_matrix_eWiseMult_vector(grb_matrix C, grb_semiring op, grb_matrix A, grb_vector B,
+                                     grb_descriptor desc);
 /* reduce (matrix -> scalar)   operations.hpp:662-680 -> backend :1032-1059 (reduce.hpp:81-91) */
 grb_info grb_reduce_matrix_scalar(double* val, grb_accum accum, grb_monoid op, grb_matrix A, grb_descriptor desc);
 /* tril   operations.hpp:872-886 -> tri.hpp:10-53 (host side, as in the reference) */
