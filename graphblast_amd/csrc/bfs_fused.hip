@@ -133,6 +133,7 @@ extern "C" grb_info grb_bfs_fused(grb_vector v, grb_matrix A, grb_index source, 
 
   void *p_va, *p_vb, *p_q, *p_scan, *p_rs, *p_tiles, *p_bt;
   GRB_TRY(scratch(7, 4 * (size_t)nwords, &p_va));
+  ctx().bfs_prezero_ptr = nullptr;          // this slot is about to be overwritten
   GRB_TRY(scratch(8, 4 * (size_t)nwords, &p_vb));
   GRB_TRY(scratch(9, 4 * (size_t)n + 4, &p_q));
   GRB_TRY(scratch(2, 4 * (size_t)n + 4, &p_scan));

@@ -584,11 +584,18 @@ grb_info bfs_persistent_run(grb_vector v, grb_matrix A, grb_index source, grb_de
     a.trace = (unsigned long long*)p_tr;
   }
 
-  GRB_HIP_TRY(hipMemsetAsync(p_zero, 0, zero_bytes, s));
+  // the block is normally already clear: the previous traversal queued the memset behind its own
+  // kernel, off the critical path of this call
+  if (c.bfs_prezero_ptr != p_zero || c.bfs_prezero_bytes != zero_bytes)
+    GRB_HIP_TRY(hipMemsetAsync(p_zero, 0, zero_bytes, s));
+  c.bfs_prezero_ptr = nullptr;
   if (profile & 1) GRB_HIP_TRY(hipEventRecord(c.ev0, s));
   hipLaunchKernelGGL(bfs_persistent_kernel, dim3(G), dim3(kPThreads), 0, s, a);
   GRB_HIP_TRY(hipGetLastError());
   if (profile & 1) GRB_HIP_TRY(hipEventRecord(c.ev1, s));
+  GRB_HIP_TRY(hipMemsetAsync(p_zero, 0, zero_bytes, s));     // for the next traversal
+  c.bfs_prezero_ptr = p_zero;
+  c.bfs_prezero_bytes = zero_bytes;
   unsigned int gv[8];
   GRB_TRY(wait_granules(a.seq, 8, gv));
   *levels = (int)gv[0];

@@ -278,6 +278,9 @@ struct Context {
   int* h_mail = nullptr;            // pinned, host-coherent, 64 ints; [63] = published sequence number
   int* d_hmail = nullptr;           // device-side address of h_mail
   int mail_seq = 0;
+  // the zeroed state block of the next persistent BFS launch, cleared right behind the previous one
+  void* bfs_prezero_ptr = nullptr;
+  size_t bfs_prezero_bytes = 0;
   unsigned long long* h_gran = nullptr;   // pinned, host-coherent: 8 x {value, seq} granules
   unsigned long long* d_hgran = nullptr;  // device-side address of h_gran
   int* d_mail = nullptr;            // device, 64 ints

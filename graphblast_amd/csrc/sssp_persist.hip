@@ -316,6 +316,7 @@ grb_info sssp_persistent_run(grb_vector v, grb_matrix A, grb_index source, grb_d
   const size_t zero_bytes = st_bytes + 16 * (size_t)nwords;
   void *p_zero, *p_c, *p_big;
   GRB_TRY(scratch(7, zero_bytes, &p_zero));
+  ctx().bfs_prezero_ptr = nullptr;          // this slot is about to be overwritten
   GRB_TRY(scratch(8, 8 * (size_t)n + 8, &p_c));
   GRB_TRY(scratch(2, sizeof(int2) * (size_t)big_cap, &p_big));
   static float ticks_to_ms = 0.f;
