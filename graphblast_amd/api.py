@@ -388,13 +388,17 @@ def bfs(v, A, s, desc, fused=False, profile=False, max_levels=4096):
     if not fused:
         info = _lib.load().grb_bfs(_h(v), _h(A), int(s), _h(desc), C.byref(res))
         return info, dict(levels=res.levels, tight_ms=res.tight_ms)
-    lv = (BfsLevel * max_levels)()
-    info = _lib.load().grb_bfs_fused(_h(v), _h(A), int(s), _h(desc), C.byref(res), lv, max_levels,
-                                     int(profile))
-    n = min(res.levels, max_levels)
-    levels = [dict(direction="pull" if lv[i].direction else "push", frontier=lv[i].frontier,
-                   frontier_edges=lv[i].frontier_edges, discovered=lv[i].discovered, ms=lv[i].ms)
-              for i in range(n)]
+    if not profile:                     # no per-level table wanted: nothing to allocate or copy back
+        info = _lib.load().grb_bfs_fused(_h(v), _h(A), int(s), _h(desc), C.byref(res), None, 0, 0)
+        levels = []
+    else:
+        lv = (BfsLevel * max_levels)()
+        info = _lib.load().grb_bfs_fused(_h(v), _h(A), int(s), _h(desc), C.byref(res), lv, max_levels,
+                                         int(profile))
+        n = min(res.levels, max_levels)
+        levels = [dict(direction="pull" if lv[i].direction else "push", frontier=lv[i].frontier,
+                       frontier_edges=lv[i].frontier_edges, discovered=lv[i].discovered, ms=lv[i].ms)
+                  for i in range(n)]
     return info, dict(levels=res.levels, tight_ms=res.tight_ms, edges_traversed=res.edges_traversed,
                       reached=res.reached, per_level=levels)
 

@@ -23,6 +23,7 @@
 //                  into its slot; after the barrier every workgroup sums all slots
 #include "bfs_kernels.hpp"
 #include "persist_common.hpp"
+#include <chrono>
 
 namespace grb {
 
@@ -584,6 +585,9 @@ grb_info bfs_persistent_run(grb_vector v, grb_matrix A, grb_index source, grb_de
     a.trace = (unsigned long long*)p_tr;
   }
 
+  static const bool host_timing = getenv("GRB_BFS_HOSTTIME") != nullptr;
+  static double acc_pre = 0, acc_launch = 0, acc_wait = 0; static int acc_n = 0;
+  const auto th0 = std::chrono::steady_clock::now();
   // the block is normally already clear: the previous traversal queued the memset behind its own
   // kernel, off the critical path of this call
   if (c.bfs_prezero_ptr != p_zero || c.bfs_prezero_bytes != zero_bytes)
@@ -596,8 +600,16 @@ grb_info bfs_persistent_run(grb_vector v, grb_matrix A, grb_index source, grb_de
   GRB_HIP_TRY(hipMemsetAsync(p_zero, 0, zero_bytes, s));     // for the next traversal
   c.bfs_prezero_ptr = p_zero;
   c.bfs_prezero_bytes = zero_bytes;
+  const auto th1 = std::chrono::steady_clock::now();
   unsigned int gv[8];
   GRB_TRY(wait_granules(a.seq, 8, gv));
+  if (host_timing) {
+    const auto th2 = std::chrono::steady_clock::now();
+    acc_launch += std::chrono::duration<double, std::micro>(th1 - th0).count();
+    acc_wait += std::chrono::duration<double, std::micro>(th2 - th1).count();
+    if (++acc_n % 32 == 0) { fprintf(stderr, "bfs host: enqueue %.1f us, wait %.1f us (mean of 32)\n", acc_launch / 32, acc_wait / 32); acc_launch = acc_wait = 0; }
+    (void)acc_pre;
+  }
   *levels = (int)gv[0];
   *last_dir = (int)gv[1];
   *reached = (long long)gv[2];
