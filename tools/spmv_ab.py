@@ -1,5 +1,5 @@
-"""SpMV A/B: time grb_k_spmv on RMAT-22 and check it against a float64 torch matvec.
-Run once per kernel choice (GRB_SPMV_ROWBLOCK=1 selects the row-block kernel)."""
+"""SpMV timing: grb_k_spmv on RMAT-<scale>, checked against a float64 torch matvec.  Point
+GRB_HIP_LIB at a variant built by tools/build_spmv_variants.sh to A/B kernel parameters."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -23,5 +23,5 @@ g.timer_start()
 for _ in range(20): g.k_spmv(A, 0, "PlusMultiplies", x.data_ptr(), None, 0, 0, y.data_ptr())
 ms = g.timer_stop() / 20
 print("%s scale %d: %.4f ms -> %.0f GB/s algorithmic, max rel err %.2e" % (
-    "rowblock" if os.environ.get("GRB_SPMV_ROWBLOCK") == "1" else "hubpacked", scale, ms,
+    os.path.basename(os.environ.get("GRB_HIP_LIB", "libgrb_hip.so")), scale, ms,
     g.k_spmv_bytes(A, 0) / ms / 1e6, err))
