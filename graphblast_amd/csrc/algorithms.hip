@@ -146,8 +146,7 @@ __global__ __launch_bounds__(kBlock) void pr_update_kernel(const float* __restri
     for (int w = 0; w < kWavesPerBlock; ++w) t += s_sum[w];
     __hip_atomic_store(&partial[blockIdx.x], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const unsigned int k = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    s_last = (k == gridDim.x - 1) ? 1 : 0;
+    s_last = last_workgroup_arrives(ticket) ? 1 : 0;
   }
   __syncthreads();
   if (!s_last) return;
@@ -161,7 +160,6 @@ __global__ __launch_bounds__(kBlock) void pr_update_kernel(const float* __restri
   if (threadIdx.x == 0) {
     float tot = 0.f;
     for (int w = 0; w < kWavesPerBlock; ++w) tot += s_sum[w];
-    __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(&mail[0], ((unsigned long long)(unsigned int)seq << 32) | __float_as_uint(tot),
                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
@@ -186,8 +184,7 @@ grb_info grb_pr(grb_vector p, grb_matrix A, float alpha, float eps, grb_descript
   const int grid = stream_grid(n, kBlock);
   void* p_part;
   GRB_TRY(scratch(4, sizeof(float) * (size_t)grid + 16, &p_part));
-  unsigned int* d_ticket = reinterpret_cast<unsigned int*>((float*)p_part + grid);
-  GRB_HIP_TRY(hipMemsetAsync(d_ticket, 0, 4, c.stream));
+  unsigned int* d_ticket = c.d_tickets;
   const float cst = (1.f - alpha) / n;
   int iter = 1;
   float error = 1.f;

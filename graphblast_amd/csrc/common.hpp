@@ -225,6 +225,25 @@ __device__ inline T group_reduce(T v, int L, F f) {
   return v;
 }
 
+// "Am I the last workgroup of this launch to get here?"  A single arrival counter costs
+// ~12 ns per arriver because same-address atomics serialise (2048 workgroups: 25 us), so the
+// arrivals go to eight counters first and only the last arriver of each goes on to the ninth.
+// tickets: 9 x 32 unsigned ints (one 128 B line each), zero before the launch; the overall last
+// arriver resets them.  Call from ONE thread per workgroup after its partials are stored
+// write-through and drained (s_waitcnt vmcnt(0)).
+__device__ inline bool last_workgroup_arrives(unsigned int* tickets) {
+  const unsigned int G = gridDim.x;
+  const unsigned int x = blockIdx.x & 7u;
+  const unsigned int groups = G < 8u ? G : 8u;
+  const unsigned int members = (G - x + 7u) / 8u;
+  const unsigned int a = __hip_atomic_fetch_add(&tickets[x * 32], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (a + 1u != members) return false;
+  const unsigned int b = __hip_atomic_fetch_add(&tickets[8 * 32], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (b + 1u != groups) return false;
+  for (unsigned int k = 0; k < 9u; ++k) __hip_atomic_store(&tickets[k * 32], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return true;
+}
+
 // Exclusive prefix sum of one int per thread over a 256-thread workgroup.
 // smem: at least kWavesPerBlock ints. Ends with a barrier, so smem may be reused.
 __device__ inline int block_exclusive_scan(int v, int* smem, int& total) {
@@ -284,6 +303,7 @@ struct Context {
   unsigned long long* h_gran = nullptr;   // pinned, host-coherent: 8 x {value, seq} granules
   unsigned long long* d_hgran = nullptr;  // device-side address of h_gran
   int* d_mail = nullptr;            // device, 64 ints
+  unsigned int* d_tickets = nullptr;  // device, 9 x 32 arrival counters (last_workgroup_arrives)
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool inited = false;
   int num_cu = 256;
@@ -391,6 +411,7 @@ namespace grb {
 
 // ---- kernel launchers (implemented in the *.hip files) -----------------------
 // elementwise.hip
+grb_info k_copy(void* dst, const void* src, size_t bytes);
 grb_info k_fill(int dtype, void* d, double val, Index n);
 grb_info k_fill_ascending(int dtype, void* d, Index n);
 grb_info k_scatter_const(int dtype, void* d_dense, const Index* ind, double val, Index n);

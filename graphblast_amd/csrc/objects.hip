@@ -41,6 +41,8 @@ grb_info ctx_init() {
   GRB_HIP_TRY(hipHostGetDevicePointer((void**)&c.d_hgran, c.h_gran, 0));
   GRB_HIP_TRY(hipMalloc((void**)&c.d_mail, 64 * sizeof(int)));
   GRB_HIP_TRY(hipMemset(c.d_mail, 0, 64 * sizeof(int)));
+  GRB_HIP_TRY(hipMalloc((void**)&c.d_tickets, 9 * 32 * sizeof(unsigned int)));
+  GRB_HIP_TRY(hipMemset(c.d_tickets, 0, 9 * 32 * sizeof(unsigned int)));
   GRB_HIP_TRY(hipEventCreate(&c.ev0));
   GRB_HIP_TRY(hipEventCreate(&c.ev1));
   int dev = 0;
@@ -367,14 +369,13 @@ grb_info grb_vector_get_storage(grb_vector v, int* storage) {
 grb_info grb_vector_dup(grb_vector dst, grb_vector src) {
   if (!dst || !src) return GRB_UNINITIALIZED_OBJECT;
   if (dst->nsize != src->nsize || dst->dtype != src->dtype) return GRB_DIMENSION_MISMATCH;
-  hipStream_t s = ctx().stream;
   dst->vec_type = src->vec_type;
   if (src->vec_type == GRB_SPARSE) {
     GRB_TRY(vec_alloc_sparse(dst));
     // the reference copies nsize elements (sparse_vector.hpp:110-113); nvals suffice
     if (src->s_nvals > 0) {
-      GRB_HIP_TRY(hipMemcpyAsync(dst->s_ind, src->s_ind, 4 * (size_t)src->s_nvals, hipMemcpyDeviceToDevice, s));
-      GRB_HIP_TRY(hipMemcpyAsync(dst->s_val, src->s_val, 4 * (size_t)src->s_nvals, hipMemcpyDeviceToDevice, s));
+      GRB_TRY(k_copy(dst->s_ind, src->s_ind, 4 * (size_t)src->s_nvals));
+      GRB_TRY(k_copy(dst->s_val, src->s_val, 4 * (size_t)src->s_nvals));
     }
     dst->s_nvals = src->s_nvals;
     return GRB_SUCCESS;
@@ -382,7 +383,7 @@ grb_info grb_vector_dup(grb_vector dst, grb_vector src) {
   if (src->vec_type == GRB_DENSE) {
     GRB_TRY(vec_alloc_dense(dst));
     if (src->nsize > 0)
-      GRB_HIP_TRY(hipMemcpyAsync(dst->d_val, src->d_val, 4 * (size_t)src->nsize, hipMemcpyDeviceToDevice, s));
+      GRB_TRY(k_copy(dst->d_val, src->d_val, 4 * (size_t)src->nsize));
     dst->d_nnz = src->d_nnz;
     return GRB_SUCCESS;
   }

@@ -189,7 +189,7 @@ grb_info grb_eWiseAdd(grb_vector w, grb_vector mask, grb_accum accum, grb_semiri
   else return GRB_INVALID_OBJECT;
   // ewiseadd.hpp:93-156: w = dup(dense); w = op(w, identity) everywhere; overwrite at sparse indices
   if (de != w && de->d_val != w->d_val)
-    GRB_HIP_TRY(hipMemcpyAsync(w->d_val, de->d_val, 4 * (size_t)w->nsize, hipMemcpyDeviceToDevice, ctx().stream));
+    GRB_TRY(k_copy(w->d_val, de->d_val, 4 * (size_t)w->nsize));
   GRB_TRY(k_ewise_add_const(op, dt, w->d_val, identity, reverse, w->nsize));
   return k_ewise_add_sparse_dense(op, dt, w->d_val, sp->s_ind, sp->s_val, de->d_val, sp->s_nvals);
 }
@@ -205,7 +205,7 @@ grb_info grb_eWiseAdd_scalar(grb_vector w, grb_vector mask, grb_accum accum, grb
   if (u->vec_type == GRB_DENSE) {
     GRB_TRY(grb_vector_set_storage(w, GRB_DENSE));
     if (u != w)
-      GRB_HIP_TRY(hipMemcpyAsync(w->d_val, u->d_val, 4 * (size_t)w->nsize, hipMemcpyDeviceToDevice, ctx().stream));
+      GRB_TRY(k_copy(w->d_val, u->d_val, 4 * (size_t)w->nsize));
     return k_ewise_scalar(op, dt, 1, w->d_val, val, w->nsize);
   }
   if (u->vec_type == GRB_SPARSE) {
