@@ -16,6 +16,7 @@
 #include <cstring>
 #include <string>
 #include <type_traits>
+#include <unordered_map>
 #include <vector>
 
 #include "grb_hip.h"
@@ -304,6 +305,10 @@ struct Context {
   unsigned long long* d_hgran = nullptr;  // device-side address of h_gran
   int* d_mail = nullptr;            // device, 64 ints
   unsigned int* d_tickets = nullptr;  // device, 9 x 32 arrival counters (last_workgroup_arrives)
+  // freed vector storage, reused by the next vector of the same size: the algorithm drivers
+  // create and destroy their temporaries on every call, and hipMalloc / hipFree cost ~0.1 ms each
+  std::unordered_map<size_t, std::vector<void*>> vec_pool;
+  size_t vec_pool_bytes = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool inited = false;
   int num_cu = 256;
@@ -385,6 +390,7 @@ struct grb_vector_s {
   void* s_val = nullptr;          // [nsize + 1]
   grb::Index s_nvals = 0;
   bool s_owned = true;
+  grb::Index s_alloc_n = 0, d_alloc_n = 0;   // sizes the owned blocks were allocated for (pool keys)
   // DenseVector
   void* d_val = nullptr;          // [nsize]
   grb::Index d_nnz = 0;

@@ -313,18 +313,61 @@ grb_info grb_descriptor_lastmxv(grb_descriptor d, int* value) {
 }
 
 // =============================================================================== Vector
+constexpr size_t kVecPoolCap = 4ull << 30;    // bytes of freed vector storage kept for reuse
+
+static grb_info pool_get(void** out, size_t bytes) {
+  Context& c = ctx();
+  auto it = c.vec_pool.find(bytes);
+  if (it != c.vec_pool.end() && !it->second.empty()) {
+    *out = it->second.back();
+    it->second.pop_back();
+    c.vec_pool_bytes -= bytes;
+    return GRB_SUCCESS;
+  }
+  GRB_HIP_TRY(hipMalloc(out, bytes));
+  return GRB_SUCCESS;
+}
+
+// Work queued on the library's stream may still use the block: a block taken from the pool is
+// only touched by later work on the same stream, so no synchronisation is needed to recycle it.
+static void pool_put(void* p, size_t bytes) {
+  if (!p) return;
+  Context& c = ctx();
+  if (c.vec_pool_bytes + bytes <= kVecPoolCap) {
+    c.vec_pool[bytes].push_back(p);
+    c.vec_pool_bytes += bytes;
+    return;
+  }
+  (void)hipStreamSynchronize(c.stream);
+  (void)hipFree(p);
+}
+
+static void vec_release_sparse(grb_vector v) {
+  if (v->s_owned) {
+    pool_put(v->s_ind, sizeof(Index) * (size_t)v->s_alloc_n);
+    pool_put(v->s_val, 4 * ((size_t)v->s_alloc_n + 1));
+  }
+  v->s_ind = nullptr; v->s_val = nullptr; v->s_owned = false;
+}
+static void vec_release_dense(grb_vector v) {
+  if (v->d_owned) pool_put(v->d_val, 4 * (size_t)v->d_alloc_n);
+  v->d_val = nullptr; v->d_owned = false;
+}
+
 static grb_info vec_alloc_sparse(grb_vector v) {
   if (v->nsize > 0 && !v->s_ind) {
-    GRB_HIP_TRY(hipMalloc((void**)&v->s_ind, sizeof(Index) * (size_t)v->nsize));
-    GRB_HIP_TRY(hipMalloc(&v->s_val, 4 * ((size_t)v->nsize + 1)));
+    GRB_TRY(pool_get((void**)&v->s_ind, sizeof(Index) * (size_t)v->nsize));
+    GRB_TRY(pool_get(&v->s_val, 4 * ((size_t)v->nsize + 1)));
     v->s_owned = true;
+    v->s_alloc_n = v->nsize;
   }
   return GRB_SUCCESS;
 }
 static grb_info vec_alloc_dense(grb_vector v) {
   if (v->nsize > 0 && !v->d_val) {
-    GRB_HIP_TRY(hipMalloc(&v->d_val, 4 * (size_t)v->nsize));
+    GRB_TRY(pool_get(&v->d_val, 4 * (size_t)v->nsize));
     v->d_owned = true;
+    v->d_alloc_n = v->nsize;
   }
   return GRB_SUCCESS;
 }
@@ -346,9 +389,8 @@ grb_info grb_vector_new(grb_vector* out, grb_dtype dtype, grb_index nsize) {
 
 grb_info grb_vector_free(grb_vector v) {
   if (!v) return GRB_SUCCESS;
-  (void)hipStreamSynchronize(ctx().stream);
-  if (v->s_owned) { if (v->s_ind) (void)hipFree(v->s_ind); if (v->s_val) (void)hipFree(v->s_val); }
-  if (v->d_owned && v->d_val) (void)hipFree(v->d_val);
+  vec_release_sparse(v);
+  vec_release_dense(v);
   delete v;
   return GRB_SUCCESS;
 }
@@ -442,8 +484,7 @@ grb_info grb_vector_build_dense(grb_vector v, const void* values, grb_index nval
 
 grb_info grb_vector_adopt_dense(grb_vector v, void* d_values, grb_index nvals) {
   if (!v) return GRB_UNINITIALIZED_OBJECT;
-  (void)hipStreamSynchronize(ctx().stream);
-  if (v->d_owned && v->d_val) (void)hipFree(v->d_val);
+  vec_release_dense(v);
   v->d_val = d_values;
   v->d_owned = false;
   v->nsize = nvals;
@@ -452,8 +493,7 @@ grb_info grb_vector_adopt_dense(grb_vector v, void* d_values, grb_index nvals) {
 }
 grb_info grb_vector_adopt_sparse(grb_vector v, grb_index* d_indices, void* d_values, grb_index nvals) {
   if (!v) return GRB_UNINITIALIZED_OBJECT;
-  (void)hipStreamSynchronize(ctx().stream);
-  if (v->s_owned) { if (v->s_ind) (void)hipFree(v->s_ind); if (v->s_val) (void)hipFree(v->s_val); }
+  vec_release_sparse(v);
   v->s_ind = d_indices;
   v->s_val = d_values;
   v->s_owned = false;
