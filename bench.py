@@ -41,7 +41,8 @@ HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8 TB/s spec
 
 def pmc_traffic(kernel_key):
     """HBM bytes per launch from the committed PMC passes (profiles/*/pmc_traffic.json: separate
-    `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this same command), or None."""
+    `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this same command, FETCH_SIZE doubled as
+    calibrated there on kernels of known byte count), or None."""
     best = None
     pdir = os.path.join(ROOT, "profiles")
     for d in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
@@ -49,7 +50,7 @@ def pmc_traffic(kernel_key):
         if os.path.exists(f):
             for name, rec in json.load(open(f)).get("kernels", {}).items():
                 if kernel_key in name:
-                    best = rec.get("hbm_bytes_per_launch_raw")
+                    best = rec.get("hbm_bytes_per_launch", rec.get("hbm_bytes_per_launch_raw"))
     return best
 
 
