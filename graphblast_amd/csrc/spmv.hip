@@ -119,7 +119,7 @@ void free_spmv_plan(SpmvPlan* plan) {
 // Power-law graphs send most gathers to a small set of columns (RMAT-22: the 32 Ki most
 // referenced columns take 52 % of the nonzeros, the top 1 Mi take 97 %), but their entries of
 // u are scattered over the whole vector, so every hot value drags a mostly-cold 128 B line
-// through L2 and the gather stream runs at the fabric rate (measured: 4.7 GB fetched per
+// through L2 and the gather stream runs at the fabric rate (measured: 9.3 GB of HBM traffic per
 // launch against 1.08 GB algorithmic).  The first SpMV of an orientation therefore ranks the
 // columns by reference count and keeps a private copy of the column ids renamed by rank.
 // Each launch packs u by that order (one 4 B gather per column), which puts the hot values
