@@ -176,6 +176,22 @@ def main():
                                for L, b in zip(one, ob)],
         }
 
+        # ---- the same steps with the reference's direction rule alone (vertex-count switch,
+        #      descriptor arg edgeswitch = 0), for comparison with the reported configuration
+        desc0 = g.Descriptor()
+        assert desc0.loadArgs(mxvmode=0, struconly=1, opreuse=1, earlyexit=1, edgeswitch=0.0) == 0
+        for i in range(min(args.warmup, 2)):
+            g.bfs(v, A, sources[i % len(sources)], desc0, fused=True)
+        barrier()
+        t0 = time.perf_counter()
+        e0 = 0
+        for i in range(args.steps):
+            e0 += g.bfs(v, A, sources[i % len(sources)], desc0, fused=True)[1]["edges_traversed"]
+        barrier()
+        el0 = time.perf_counter() - t0
+        extra["bfs_total"]["reference_direction_rule_only"] = {"value": e0 / el0, "unit": "TEPS",
+                                                               "ms_per_step": el0 / args.steps * 1e3}
+
         # ---- generic SpMV kernel on the same graph (the metric's second half)
         x = torch.rand(n, dtype=torch.float32, device=dev)
         y = torch.empty(n, dtype=torch.float32, device=dev)
