@@ -438,3 +438,43 @@ def test_device_build_and_ingest():
         hp, hi, hv = A.host_csr()
         assert np.array_equal(hp, ptr) and np.array_equal(hi, wc) and np.all(hv == 1.0)
         assert A.nvals() == key.size
+
+
+@pytest.mark.gpu
+def test_matrix_ewisemult_scalar_and_vector():
+    """Matrix (x) scalar and matrix (x) broadcast vector (operations.hpp:206-267) update both
+    orientations in place: C(i,j) = A(i,j) (x) s, A(i,j) (x) B(i), and A(i,j) (x) B(j) with
+    GrB_INP1 = GrB_TRAN."""
+    import graphblast_amd as g
+    from graphblast_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(4)
+    nr, nc, m = 300, 200, 4000
+    r = rng.integers(0, nr, m).astype(np.int32); c = rng.integers(0, nc, m).astype(np.int32)
+    key = np.unique(r.astype(np.int64) * nc + c)
+    r, c = (key // nc).astype(np.int32), (key % nc).astype(np.int32)
+    v = rng.integers(1, 50, r.size).astype(np.float32)
+    A = g.Matrix(nr, nc)
+    assert A.build(r, c, v, r.size, None) == 0
+    d = g.Descriptor(); d.loadArgs()
+    from graphblast_amd.api import _semiring_id
+    assert lib.grb_matrix_eWiseMult_scalar(A._h, _semiring_id("PlusMultiplies"), A._h, 0.5) == 0
+    want = v * np.float32(0.5)
+    hp, hi, hv = A.host_csr()
+    assert np.array_equal(hv, want)
+    tp, ti, tv = A.host_csc()
+    order = np.lexsort((r, c))
+    assert np.array_equal(tv, want[order])
+    # by row
+    b = rng.integers(1, 9, nr).astype(np.float32)
+    B = g.Vector(nr); assert B.build(b, nr) == 0
+    assert lib.grb_matrix_eWiseMult_vector(A._h, _semiring_id("PlusMultiplies"), A._h, B._h, d._h) == 0
+    want = want * b[r]
+    assert np.array_equal(A.host_csr()[2], want) and np.array_equal(A.host_csc()[2], want[order])
+    # by column (GrB_INP1 = GrB_TRAN), division through the semiring's multiply
+    bc = rng.integers(1, 9, nc).astype(np.float32)
+    Bc = g.Vector(nc); assert Bc.build(bc, nc) == 0
+    d.toggle(g.GrB_INP1)
+    assert lib.grb_matrix_eWiseMult_vector(A._h, _semiring_id("PlusDivides"), A._h, Bc._h, d._h) == 0
+    want = want / bc[c]
+    assert np.array_equal(A.host_csr()[2], want) and np.array_equal(A.host_csc()[2], want[order])
