@@ -586,7 +586,8 @@ grb_info bfs_persistent_run(grb_vector v, grb_matrix A, grb_index source, grb_de
   }
 
   static const bool host_timing = getenv("GRB_BFS_HOSTTIME") != nullptr;
-  static double acc_pre = 0, acc_launch = 0, acc_wait = 0; static int acc_n = 0;
+  static double acc_launch = 0, acc_wait = 0;
+  static int acc_n = 0;
   const auto th0 = std::chrono::steady_clock::now();
   // the block is normally already clear: the previous traversal queued the memset behind its own
   // kernel, off the critical path of this call
@@ -608,7 +609,6 @@ grb_info bfs_persistent_run(grb_vector v, grb_matrix A, grb_index source, grb_de
     acc_launch += std::chrono::duration<double, std::micro>(th1 - th0).count();
     acc_wait += std::chrono::duration<double, std::micro>(th2 - th1).count();
     if (++acc_n % 32 == 0) { fprintf(stderr, "bfs host: enqueue %.1f us, wait %.1f us (mean of 32)\n", acc_launch / 32, acc_wait / 32); acc_launch = acc_wait = 0; }
-    (void)acc_pre;
   }
   *levels = (int)gv[0];
   *last_dir = (int)gv[1];
