@@ -81,6 +81,8 @@ def main():
     ap.add_argument("--edgeswitch", type=float, default=0.08,
                     help="graphblast_amd extension: also leave push when frontier out-edges > edgeswitch*nnz "
                          "(0 = the reference's vertex-count rule only)")
+    ap.add_argument("--reference-rule", action="store_true",
+                    help="also time the same steps with edgeswitch = 0 (the reference's vertex-count rule alone)")
     ap.add_argument("--partitioned", action="store_true",
                     help="use the 1-D partitioned level loop even at N = 1 (debugging the N > 1 path)")
     args = ap.parse_args()
@@ -178,19 +180,21 @@ def main():
 
         # ---- the same steps with the reference's direction rule alone (vertex-count switch,
         #      descriptor arg edgeswitch = 0), for comparison with the reported configuration
-        desc0 = g.Descriptor()
-        assert desc0.loadArgs(mxvmode=0, struconly=1, opreuse=1, earlyexit=1, edgeswitch=0.0) == 0
-        for i in range(min(args.warmup, 2)):
-            g.bfs(v, A, sources[i % len(sources)], desc0, fused=True)
-        barrier()
-        t0 = time.perf_counter()
-        e0 = 0
-        for i in range(args.steps):
-            e0 += g.bfs(v, A, sources[i % len(sources)], desc0, fused=True)[1]["edges_traversed"]
-        barrier()
-        el0 = time.perf_counter() - t0
-        extra["bfs_total"]["reference_direction_rule_only"] = {"value": e0 / el0, "unit": "TEPS",
-                                                               "ms_per_step": el0 / args.steps * 1e3}
+        #      (opt-in: it launches the same kernel and would mix into a rocprof average of this command)
+        if args.reference_rule:
+            desc0 = g.Descriptor()
+            assert desc0.loadArgs(mxvmode=0, struconly=1, opreuse=1, earlyexit=1, edgeswitch=0.0) == 0
+            for i in range(min(args.warmup, 2)):
+                g.bfs(v, A, sources[i % len(sources)], desc0, fused=True)
+            barrier()
+            t0 = time.perf_counter()
+            e0 = 0
+            for i in range(args.steps):
+                e0 += g.bfs(v, A, sources[i % len(sources)], desc0, fused=True)[1]["edges_traversed"]
+            barrier()
+            el0 = time.perf_counter() - t0
+            extra["bfs_total"]["reference_direction_rule_only"] = {"value": e0 / el0, "unit": "TEPS",
+                                                                   "ms_per_step": el0 / args.steps * 1e3}
 
         # ---- generic SpMV kernel on the same graph (the metric's second half)
         x = torch.rand(n, dtype=torch.float32, device=dev)
