@@ -21,7 +21,7 @@ struct VecGuard {               // frees temporaries on every exit path
 }  // namespace
 
 grb_info sssp_persistent_run(grb_vector v, grb_matrix A, grb_index source, grb_descriptor desc, int* iterations,
-                             double* succ, float* tight_ms);
+                             double* succ, float* tight_ms, grb_vector f1_dense, bool* handed_over);
 
 extern "C" {
 
@@ -32,36 +32,43 @@ grb_info grb_sssp(grb_vector v, grb_matrix A, grb_index source, grb_descriptor d
   if (source < 0 || source >= A->nrows) return GRB_INVALID_INDEX;
   const Index n = A->nrows;
   static const bool fused_ok = [] { const char* e = getenv("GRB_SSSP_FUSED"); return !e || atoi(e) != 0; }();
-  if (fused_ok && A->built && v->nsize == n) {
-    // the same synchronous rounds in one launch (sssp_persist.hip); not eligible -> op by op
-    GRB_TRY(grb_vector_set_storage(v, GRB_DENSE));
-    int it = 0;
-    double sc = 0;
-    float tms = 0.f;
-    const grb_info fi = sssp_persistent_run(v, A, source, desc, &it, &sc, &tms);
-    if (fi == GRB_SUCCESS) {
-      desc->lastmxv = GRB_PUSHONLY;
-      if (result) { result->iterations = it; result->tight_ms = tms; result->last_value = sc; }
-      return GRB_SUCCESS;
-    }
-    if (fi != GRB_NOT_IMPLEMENTED) return fi;
-  }
   const double fmax = (double)FLT_MAX;
-  GRB_TRY(grb_vector_fill(v, fmax));
-  GRB_TRY(grb_vector_set_element(v, 0.0, source));
   VecGuard g;
   grb_vector f1, f2, m;
   GRB_TRY(g.make(&f1, GRB_F32, n));
+  int first_iter = 1;
+  float fused_ms = 0.f;
+  bool continued = false;
+  if (fused_ok && A->built && v->nsize == n) {
+    // the same synchronous rounds in one launch (sssp_persist.hip); not eligible -> op by op.  A
+    // dense frontier is handed back: from there the pull product of the op-by-op rounds is faster.
+    GRB_TRY(grb_vector_set_storage(v, GRB_DENSE));
+    GRB_TRY(grb_vector_set_storage(f1, GRB_DENSE));
+    int it = 0;
+    double sc = 0;
+    const grb_info fi = sssp_persistent_run(v, A, source, desc, &it, &sc, &fused_ms, f1, &continued);
+    if (fi == GRB_SUCCESS && !continued) {
+      desc->lastmxv = GRB_PUSHONLY;
+      if (result) { result->iterations = it; result->tight_ms = fused_ms; result->last_value = sc; }
+      return GRB_SUCCESS;
+    }
+    if (fi != GRB_SUCCESS && fi != GRB_NOT_IMPLEMENTED) return fi;
+    if (continued) first_iter = it + 1;
+  }
   GRB_TRY(g.make(&f2, GRB_F32, n));
   GRB_TRY(g.make(&m, GRB_F32, n));
-  if (desc->desc[GRB_MXVMODE] == GRB_PULLONLY) {
-    GRB_TRY(grb_vector_fill(f1, fmax));
-    GRB_TRY(grb_vector_set_element(f1, 0.0, source));
-  } else {
-    float zero = 0.f;
-    GRB_TRY(grb_vector_build_sparse(f1, &source, &zero, 1));
+  if (!continued) {
+    GRB_TRY(grb_vector_fill(v, fmax));
+    GRB_TRY(grb_vector_set_element(v, 0.0, source));
+    if (desc->desc[GRB_MXVMODE] == GRB_PULLONLY) {
+      GRB_TRY(grb_vector_fill(f1, fmax));
+      GRB_TRY(grb_vector_set_element(f1, 0.0, source));
+    } else {
+      float zero = 0.f;
+      GRB_TRY(grb_vector_build_sparse(f1, &source, &zero, 1));
+    }
   }
-  int iter = 1;
+  int iter = first_iter;
   grb_index f1_nvals = 1;
   double succ = 1;
   float ms = 0.f;
@@ -80,7 +87,10 @@ grb_info grb_sssp(grb_vector v, grb_matrix A, grb_index source, grb_descriptor d
     if (f1_nvals == 0 || succ == 0) break;
   }
   GRB_TRY(grb_timer_stop(&ms));
-  if (result) { result->iterations = iter; result->tight_ms = ms; result->last_value = succ; }
+  // a run that started in the fused loop keeps its meaning of last_value, the number of vertices the
+  // last round improved (f1.nvals of a sparse f1, reduce(m) of a dense one); a pure op-by-op run
+  // reports the reference's reduce(m) whatever the storage
+  if (result) { result->iterations = iter; result->tight_ms = ms + fused_ms; result->last_value = (continued && f1->vec_type == GRB_SPARSE) ? (double)f1_nvals : succ; }
   return GRB_SUCCESS;
 }
 

@@ -42,6 +42,7 @@ struct SsspArgs {
   Index n;
   Index source;
   int max_niter;
+  unsigned long long bail_found;    // leave the loop when a round improves more vertices than this
   float* D[3];                      // D[0] is the result vector; all FLT_MAX, D[1][source] = 0 (host)
   unsigned int* F[4];               // F[1] has the source bit, the rest is zero (host)
   int2* big_list;
@@ -135,7 +136,7 @@ __global__ __launch_bounds__(kPThreads) void sssp_persistent_kernel(SsspArgs a) 
 
   int iter = 1;
   unsigned long long succ = 1, nbig = (a.optr[a.source + 1] - a.optr[a.source] >= kSsspBig) ? 1 : 0;
-  int last_round = 0;
+  int last_round = 0, bailed = 0;
   for (; iter <= a.max_niter; ++iter) {
     const float* Dc = a.D[iter % 3];
     float* Dn = a.D[(iter + 1) % 3];
@@ -256,6 +257,7 @@ __global__ __launch_bounds__(kPThreads) void sssp_persistent_kernel(SsspArgs a) 
     __syncthreads();
     last_round = iter;
     if (succ == 0) break;           // f1.nvals == 0 / reduce(m) == 0, sssp.hpp:88-90
+    if (succ > a.bail_found && iter < a.max_niter) { bailed = 1; break; }   // dense frontier: hand over
   }
 
   // the distances after the last round live in D_(last+1); the result vector is buffer 0
@@ -270,11 +272,18 @@ __global__ __launch_bounds__(kPThreads) void sssp_persistent_kernel(SsspArgs a) 
     const unsigned long long tag = (unsigned long long)(unsigned int)a.seq << 32;
     const float ms = (float)(wall_clock64() - t_start) * a.ticks_to_ms;
     const unsigned int vals[4] = {(unsigned int)(iter > a.max_niter ? a.max_niter + 1 : iter), (unsigned int)succ,
-                                  __float_as_uint(ms), 0u};
+                                  __float_as_uint(ms), (unsigned int)bailed};
 #pragma unroll
     for (int k = 0; k < 4; ++k)
       __hip_atomic_store(&a.mail[k], tag | vals[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
+}
+
+// hand-over to the op-by-op rounds: the frontier as the dense vector f1 of sssp.hpp
+__global__ void sssp_handover_kernel(const unsigned int* __restrict__ F, const float* __restrict__ D, Index n,
+                                     float* __restrict__ f1) {
+  const Index i = (Index)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) f1[i] = ((F[i >> 5] >> (i & 31)) & 1u) ? D[i] : FLT_MAX;
 }
 
 __global__ void sssp_seed_kernel(float* D1, unsigned int* F1, Index source) {
@@ -289,9 +298,13 @@ __global__ void sssp_seed_kernel(float* D1, unsigned int* F1, Index source) {
 using namespace grb;
 
 // Runs the fused loop; `v` must be a dense f32 vector of size n.  Returns GRB_NOT_IMPLEMENTED
-// when the matrix is not eligible (the caller then runs the op-by-op driver).
+// when the matrix is not eligible (the caller then runs the op-by-op driver).  The loop relaxes
+// with atomics (push); once a round improves more than switchpoint * n vertices the frontier is
+// dense enough for the pull product (SpMV) of the op-by-op rounds to be faster, so the kernel
+// stops there and, if f1_dense is given, leaves the frontier in it: *handed_over = true and
+// *iterations = rounds done.  GrB_PUSHONLY never hands over.
 grb_info sssp_persistent_run(grb_vector v, grb_matrix A, grb_index source, grb_descriptor desc, int* iterations,
-                             double* succ, float* tight_ms) {
+                             double* succ, float* tight_ms, grb_vector f1_dense, bool* handed_over) {
   Context& c = ctx();
   hipStream_t s = c.stream;
   const Index n = A->nrows;
@@ -331,6 +344,9 @@ grb_info sssp_persistent_run(grb_vector v, grb_matrix A, grb_index source, grb_d
   a.n = n;
   a.source = source;
   a.max_niter = desc->max_niter;
+  a.bail_found = (f1_dense && desc->desc[GRB_MXVMODE] != GRB_PUSHONLY)
+                     ? (unsigned long long)((double)desc->switchpoint * (double)n)
+                     : ~0ull;
   a.D[0] = (float*)v->d_val;
   a.D[1] = (float*)p_c;
   a.D[2] = a.D[1] + n;
@@ -358,5 +374,12 @@ grb_info sssp_persistent_run(grb_vector v, grb_matrix A, grb_index source, grb_d
   float ms;
   memcpy(&ms, &gv[2], 4);
   *tight_ms = ms;
+  *handed_over = gv[3] != 0;
+  if (*handed_over) {
+    const unsigned int* Fn = a.F[(*iterations + 1) % 4];       // improved by the last round done
+    hipLaunchKernelGGL(sssp_handover_kernel, dim3(ceil_div(n, kBlock)), dim3(kBlock), 0, s, Fn, (const float*)a.D[0], n,
+                       (float*)f1_dense->d_val);
+    GRB_HIP_TRY(hipGetLastError());
+  }
   return GRB_SUCCESS;
 }
