@@ -415,3 +415,57 @@ def test_full_size_rmat22_bfs_and_spmv(hb):
     want = np.add.reduceat(x[ind].astype(np.float64), ptr[:-1][deg > 0])
     got = w1.cpu().numpy()
     assert np.array_equal(got[deg > 0], want.astype(F)) and np.all(got[deg == 0] == 0)
+
+
+def test_full_size_rmat22_sssp_cc_properties(hb):
+    """BASELINE.json's size again, the other drivers, checked through properties that do not need
+    a CPU run of that size: SSSP distances satisfy the Bellman optimality conditions on every
+    edge (no edge can still be relaxed, every finite distance is attained through some in-edge);
+    CC labels are constant across every edge, name a vertex of their own component (its smallest
+    id), and the SSSP tree lies inside one component."""
+    import torch
+    from graphblast_amd.graphgen import rmat_edges, finalize_edges
+    g = hb.g
+    dev = torch.device("cuda", 0)
+    s_, d_, n = rmat_edges(22, 16, seed=1, device=dev)
+    gr = finalize_edges(s_, d_, n, symmetrize=True)
+    del s_, d_
+    tptr, tind = gr["csr"]
+    nnz = gr["nnz"]
+    rows = torch.repeat_interleave(torch.arange(n, device=dev, dtype=torch.int64), (tptr[1:] - tptr[:-1]).long())
+    cols = tind.long()
+    # symmetric integer weights from the endpoint ids: sums are exact in f32
+    w = ((((rows ^ cols) * 2654435761) >> 7) % 64 + 1).to(torch.float32)
+    A = g.Matrix(n, n)
+    assert A.build_device_csr(tptr.data_ptr(), tind.data_ptr(), w.data_ptr(), nnz, tptr.data_ptr(), tind.data_ptr(),
+                              w.data_ptr(), keep=(tptr, tind, w)) == 0
+    src = int(torch.argmax(tptr[1:] - tptr[:-1]))
+    for mode in (0, 1):
+        v = g.Vector(n)
+        info, res = g.sssp(v, A, src, hb.descriptor(mxvmode=mode))
+        assert info == 0
+        dist = torch.from_numpy(hb.dense_values(v)).to(dev)
+        assert dist[src] == 0
+        fin = dist < FLT_MAX
+        du, dv = dist[rows], dist[cols]
+        ok = fin[rows]
+        assert not torch.any(du[ok] + w[ok] < dv[ok])                  # no edge can be relaxed further
+        assert torch.all(fin[cols][ok])                                # reachability is closed under edges
+        best = torch.full((n,), float("inf"), device=dev)
+        best.scatter_reduce_(0, cols[ok], du[ok] + w[ok], reduce="amin")
+        chk = fin.clone(); chk[src] = False
+        assert torch.equal(best[chk], dist[chk])                       # every distance is attained
+    # connected components (int matrix, pattern values)
+    ones = torch.ones(nnz, dtype=torch.int32, device=dev)
+    Ai = g.Matrix(n, n, np.int32)
+    assert Ai.build_device_csr(tptr.data_ptr(), tind.data_ptr(), ones.data_ptr(), nnz, tptr.data_ptr(), tind.data_ptr(),
+                               ones.data_ptr(), keep=(tptr, tind, ones)) == 0
+    vc = g.Vector(n, np.int32)
+    info, res = g.cc(vc, Ai, 0, hb.descriptor(mxvmode=0))
+    assert info == 0
+    lab = torch.from_numpy(hb.dense_values(vc)).to(dev).long()
+    assert torch.equal(lab[rows], lab[cols])                           # constant on every edge
+    assert torch.equal(lab[lab], lab)                                  # a label names a vertex with that label
+    assert torch.all(lab <= torch.arange(n, device=dev))               # FastSV: the smallest id of the component
+    reached = torch.from_numpy(hb.dense_values(v)).to(dev) < FLT_MAX
+    assert torch.all(lab[reached] == lab[src])                         # the SSSP tree lies in one component
