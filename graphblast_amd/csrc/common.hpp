@@ -467,7 +467,7 @@ grb_info k_spmv(int sr, int dtype, const CsrArrays& M, SpmvPlan& plan, const voi
                 const void* mask, int mask_f32, int scmp, int accum, void* w);
 grb_info k_spmv_masked_or(int dtype, const CsrArrays& M, const void* u, double identity,
                           const void* mask, int mask_f32, int scmp, int earlyexit, int opreuse,
-                          void* w);
+                          const Index* hint /* per-row best neighbour, may be null */, void* w);
 
 // spmspv.hip
 grb_info k_spmspv(int sr, int dtype, const CsrArrays& M, Index out_size, int struconly,

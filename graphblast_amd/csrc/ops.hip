@@ -24,8 +24,11 @@ static grb_info spmv_dispatch(grb_vector w, grb_vector mask, grb_accum accum, in
   const int functor = (int)semiring_add(op, w->dtype, 3, 5);
   if (use_mask && desc->fusedmask && functor == 1) {
     if (mask->vec_type == GRB_DENSE) {
+      // the per-vertex hint of the one-launch traversal is reused when that path has built it
+      // (it describes the CSC orientation; building it here would cost more than a few pulls save)
+      const Index* hint = use_tran ? A->d_pull_hint : nullptr;
       return k_spmv_masked_or(w->dtype, M, u->d_val, semiring_identity(op, w->dtype), mask->d_val,
-                              mask_is_f32(mask), use_scmp, desc->earlyexit, desc->opreuse, w->d_val);
+                              mask_is_f32(mask), use_scmp, desc->earlyexit, desc->opreuse, hint, w->d_val);
     }
     if (mask->vec_type == GRB_SPARSE) return GRB_SUCCESS;   // "not implemented": prints, no-op
     return GRB_UNINITIALIZED_OBJECT;

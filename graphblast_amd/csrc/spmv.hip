@@ -425,7 +425,8 @@ __device__ inline bool pull_hit(const void* mask, int mask_f32, const T* u, T id
 template <typename T, bool kEarlyExit, bool kOpReuse>
 __global__ __launch_bounds__(kBlock) void spmv_masked_or_kernel(
     const Index* __restrict__ ptr, const Index* __restrict__ ind, Index nrows, const T* __restrict__ u,
-    T identity, const void* __restrict__ mask, int mask_f32, int scmp, T* __restrict__ w) {
+    T identity, const void* __restrict__ mask, int mask_f32, int scmp, const Index* __restrict__ hint,
+    T* __restrict__ w) {
   const int lane = lane_id();
   const Index wave_global = (Index)blockIdx.x * kWavesPerBlock + wave_id();
   const Index nwaves = (Index)gridDim.x * kWavesPerBlock;
@@ -438,9 +439,16 @@ __global__ __launch_bounds__(kBlock) void spmv_masked_or_kernel(
       // equivalently: skip when scmp XOR (mask == 0)
       if (active) { s = ptr[row]; e = ptr[row + 1]; }
     }
-    // phase 1: each lane probes up to kSerialProbe of its own neighbours
+    // phase 0: the row's most promising neighbour from a dense side array (one coalesced 4-byte
+    // read instead of an adjacency-list cache line); a hit settles the row whatever EarlyExit says,
+    // because the only output is the flag
     Index p = s;
-    if (active) {
+    if (active && hint) {
+      const Index h = hint[row];
+      if (h >= 0 && pull_hit<T, kOpReuse>(mask, mask_f32, u, identity, h)) { found = true; p = e; }
+    }
+    // phase 1: each lane probes up to kSerialProbe of its own neighbours
+    if (active && !found) {
       Index stop = (e - s > kSerialProbe) ? s + kSerialProbe : e;
       for (; p < stop; ++p) {
         if (pull_hit<T, kOpReuse>(mask, mask_f32, u, identity, ind[p])) {
@@ -469,14 +477,14 @@ __global__ __launch_bounds__(kBlock) void spmv_masked_or_kernel(
 }
 
 grb_info k_spmv_masked_or(int dtype, const CsrArrays& M, const void* u, double identity, const void* mask,
-                          int mask_f32, int scmp, int earlyexit, int opreuse, void* w) {
+                          int mask_f32, int scmp, int earlyexit, int opreuse, const Index* hint, void* w) {
   if (M.n <= 0) return GRB_SUCCESS;
   const int grid = stream_grid(M.n, kBlock);
   auto launch = [&](auto t) -> grb_info {
     using T = decltype(t);
 #define GRB_PULL(EE, OR)                                                                          \
   hipLaunchKernelGGL((spmv_masked_or_kernel<T, EE, OR>), dim3(grid), dim3(kBlock), 0, ctx().stream, \
-                     M.ptr, M.ind, M.n, (const T*)u, (T)identity, mask, mask_f32, scmp, (T*)w)
+                     M.ptr, M.ind, M.n, (const T*)u, (T)identity, mask, mask_f32, scmp, hint, (T*)w)
     if (earlyexit && opreuse) GRB_PULL(true, true);
     else if (earlyexit) GRB_PULL(true, false);
     else if (opreuse) GRB_PULL(false, true);
