@@ -19,6 +19,7 @@ Rank 0 prints ONE JSON line.  Extra objects on it:
   bfs_total     the kernel's own wall-clock time per traversal and the per-level table of one
   spmv          the generic SpMV kernel (PlusMultiplies, f32) on the same graph: algorithmic
                 8*nnz + 12*n + 4 bytes per launch / HIP-event mean launch time
+  spmv_grid4096 the same SpMV kernel on a road-like 4096^2 grid (local gathers)
   primitives    eWiseAdd / eWiseMult / reduce / assign on 64 Mi-element f32 vectors: GB/s and
                 fraction of the 8 TB/s HBM peak
   cpu_baseline  the oracle's SimpleReferenceBfs restatement (one host core) on a bounded
@@ -213,6 +214,29 @@ def main():
                          "achieved": round(sb / (ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(sb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                          "traffic": pmc_traffic("spmv_hub_kernel"), "gflops": round(2 * nnz / (ms * 1e-3) / 1e9, 1)}
+
+        # ---- the same SpMV kernel where the gathers are local (a road-like 4096^2 grid in natural
+        #      order): what it does when the L2 request rate of scattered gathers is not the wall
+        from graphblast_amd.graphgen import grid_edges
+        ge = grid_edges(4096, keep=0.9)
+        gg = finalize_edges(torch.as_tensor(ge[0]).to(dev), torch.as_tensor(ge[1]).to(dev), ge[2], symmetrize=True)
+        gptr, gind = gg["csr"]
+        gval = torch.rand(gg["nnz"], dtype=torch.float32, device=dev)
+        gx = torch.rand(gg["n"], dtype=torch.float32, device=dev)
+        gy = torch.empty(gg["n"], dtype=torch.float32, device=dev)
+        G = g.Matrix(gg["n"], gg["n"])
+        assert G.build_device_csr(gptr.data_ptr(), gind.data_ptr(), gval.data_ptr(), gg["nnz"], keep=(gptr, gind, gval)) == 0
+        for _ in range(3):
+            assert g.k_spmv(G, 0, "PlusMultiplies", gx.data_ptr(), None, 0, 0, gy.data_ptr()) == 0
+        g.timer_start()
+        for _ in range(reps):
+            g.k_spmv(G, 0, "PlusMultiplies", gx.data_ptr(), None, 0, 0, gy.data_ptr())
+        gms = g.timer_stop() / reps
+        gb = g.k_spmv_bytes(G, 0)
+        extra["spmv_grid4096"] = {"n": gg["n"], "nnz": gg["nnz"], "algorithmic_bytes_per_launch": gb,
+                                  "avg_launch_ms": round(gms, 5), "achieved": round(gb / (gms * 1e-3) / 1e9, 2),
+                                  "unit": "GB/s", "frac": round(gb / (gms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+        del G, gptr, gind, gval, gx, gy
 
         # ---- the streaming primitives of the path (eWiseAdd / eWiseMult / reduce / assign) on
         #      64 Mi-element f32 vectors: algorithmic bytes per element / HIP-event time
