@@ -82,8 +82,10 @@ def main():
     ap.add_argument("--edgeswitch", type=float, default=0.08,
                     help="graphblast_amd extension: also leave push when frontier out-edges > edgeswitch*nnz "
                          "(0 = the reference's vertex-count rule only)")
-    ap.add_argument("--reference-rule", action="store_true",
-                    help="also time the same steps with edgeswitch = 0 (the reference's vertex-count rule alone)")
+    ap.add_argument("--extras", action="store_true",
+                    help="also time (a) the same steps with edgeswitch = 0, the reference's vertex-count rule alone, "
+                         "and (b) the SpMV kernel on a road-like grid; off by default because both launch the "
+                         "kernels of the main measurement again and would mix into a rocprof average of this command")
     ap.add_argument("--partitioned", action="store_true",
                     help="use the 1-D partitioned level loop even at N = 1 (debugging the N > 1 path)")
     args = ap.parse_args()
@@ -182,7 +184,7 @@ def main():
         # ---- the same steps with the reference's direction rule alone (vertex-count switch,
         #      descriptor arg edgeswitch = 0), for comparison with the reported configuration
         #      (opt-in: it launches the same kernel and would mix into a rocprof average of this command)
-        if args.reference_rule:
+        if args.extras:
             desc0 = g.Descriptor()
             assert desc0.loadArgs(mxvmode=0, struconly=1, opreuse=1, earlyexit=1, edgeswitch=0.0) == 0
             for i in range(min(args.warmup, 2)):
@@ -217,26 +219,27 @@ def main():
 
         # ---- the same SpMV kernel where the gathers are local (a road-like 4096^2 grid in natural
         #      order): what it does when the L2 request rate of scattered gathers is not the wall
-        from graphblast_amd.graphgen import grid_edges
-        ge = grid_edges(4096, keep=0.9)
-        gg = finalize_edges(torch.as_tensor(ge[0]).to(dev), torch.as_tensor(ge[1]).to(dev), ge[2], symmetrize=True)
-        gptr, gind = gg["csr"]
-        gval = torch.rand(gg["nnz"], dtype=torch.float32, device=dev)
-        gx = torch.rand(gg["n"], dtype=torch.float32, device=dev)
-        gy = torch.empty(gg["n"], dtype=torch.float32, device=dev)
-        G = g.Matrix(gg["n"], gg["n"])
-        assert G.build_device_csr(gptr.data_ptr(), gind.data_ptr(), gval.data_ptr(), gg["nnz"], keep=(gptr, gind, gval)) == 0
-        for _ in range(3):
-            assert g.k_spmv(G, 0, "PlusMultiplies", gx.data_ptr(), None, 0, 0, gy.data_ptr()) == 0
-        g.timer_start()
-        for _ in range(reps):
-            g.k_spmv(G, 0, "PlusMultiplies", gx.data_ptr(), None, 0, 0, gy.data_ptr())
-        gms = g.timer_stop() / reps
-        gb = g.k_spmv_bytes(G, 0)
-        extra["spmv_grid4096"] = {"n": gg["n"], "nnz": gg["nnz"], "algorithmic_bytes_per_launch": gb,
-                                  "avg_launch_ms": round(gms, 5), "achieved": round(gb / (gms * 1e-3) / 1e9, 2),
-                                  "unit": "GB/s", "frac": round(gb / (gms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
-        del G, gptr, gind, gval, gx, gy
+        if args.extras:
+          from graphblast_amd.graphgen import grid_edges
+          ge = grid_edges(4096, keep=0.9)
+          gg = finalize_edges(torch.as_tensor(ge[0]).to(dev), torch.as_tensor(ge[1]).to(dev), ge[2], symmetrize=True)
+          gptr, gind = gg["csr"]
+          gval = torch.rand(gg["nnz"], dtype=torch.float32, device=dev)
+          gx = torch.rand(gg["n"], dtype=torch.float32, device=dev)
+          gy = torch.empty(gg["n"], dtype=torch.float32, device=dev)
+          G = g.Matrix(gg["n"], gg["n"])
+          assert G.build_device_csr(gptr.data_ptr(), gind.data_ptr(), gval.data_ptr(), gg["nnz"], keep=(gptr, gind, gval)) == 0
+          for _ in range(3):
+              assert g.k_spmv(G, 0, "PlusMultiplies", gx.data_ptr(), None, 0, 0, gy.data_ptr()) == 0
+          g.timer_start()
+          for _ in range(reps):
+              g.k_spmv(G, 0, "PlusMultiplies", gx.data_ptr(), None, 0, 0, gy.data_ptr())
+          gms = g.timer_stop() / reps
+          gb = g.k_spmv_bytes(G, 0)
+          extra["spmv_grid4096"] = {"n": gg["n"], "nnz": gg["nnz"], "algorithmic_bytes_per_launch": gb,
+                                    "avg_launch_ms": round(gms, 5), "achieved": round(gb / (gms * 1e-3) / 1e9, 2),
+                                    "unit": "GB/s", "frac": round(gb / (gms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+          del G, gptr, gind, gval, gx, gy
 
         # ---- the streaming primitives of the path (eWiseAdd / eWiseMult / reduce / assign) on
         #      64 Mi-element f32 vectors: algorithmic bytes per element / HIP-event time
