@@ -220,26 +220,26 @@ def main():
         # ---- the same SpMV kernel where the gathers are local (a road-like 4096^2 grid in natural
         #      order): what it does when the L2 request rate of scattered gathers is not the wall
         if args.extras:
-          from graphblast_amd.graphgen import grid_edges
-          ge = grid_edges(4096, keep=0.9)
-          gg = finalize_edges(torch.as_tensor(ge[0]).to(dev), torch.as_tensor(ge[1]).to(dev), ge[2], symmetrize=True)
-          gptr, gind = gg["csr"]
-          gval = torch.rand(gg["nnz"], dtype=torch.float32, device=dev)
-          gx = torch.rand(gg["n"], dtype=torch.float32, device=dev)
-          gy = torch.empty(gg["n"], dtype=torch.float32, device=dev)
-          G = g.Matrix(gg["n"], gg["n"])
-          assert G.build_device_csr(gptr.data_ptr(), gind.data_ptr(), gval.data_ptr(), gg["nnz"], keep=(gptr, gind, gval)) == 0
-          for _ in range(3):
-              assert g.k_spmv(G, 0, "PlusMultiplies", gx.data_ptr(), None, 0, 0, gy.data_ptr()) == 0
-          g.timer_start()
-          for _ in range(reps):
-              g.k_spmv(G, 0, "PlusMultiplies", gx.data_ptr(), None, 0, 0, gy.data_ptr())
-          gms = g.timer_stop() / reps
-          gb = g.k_spmv_bytes(G, 0)
-          extra["spmv_grid4096"] = {"n": gg["n"], "nnz": gg["nnz"], "algorithmic_bytes_per_launch": gb,
-                                    "avg_launch_ms": round(gms, 5), "achieved": round(gb / (gms * 1e-3) / 1e9, 2),
-                                    "unit": "GB/s", "frac": round(gb / (gms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
-          del G, gptr, gind, gval, gx, gy
+            from graphblast_amd.graphgen import grid_edges
+            ge = grid_edges(4096, keep=0.9)
+            gg = finalize_edges(torch.as_tensor(ge[0]).to(dev), torch.as_tensor(ge[1]).to(dev), ge[2], symmetrize=True)
+            gptr, gind = gg["csr"]
+            gval = torch.rand(gg["nnz"], dtype=torch.float32, device=dev)
+            gx = torch.rand(gg["n"], dtype=torch.float32, device=dev)
+            gy = torch.empty(gg["n"], dtype=torch.float32, device=dev)
+            G = g.Matrix(gg["n"], gg["n"])
+            assert G.build_device_csr(gptr.data_ptr(), gind.data_ptr(), gval.data_ptr(), gg["nnz"], keep=(gptr, gind, gval)) == 0
+            for _ in range(3):
+                assert g.k_spmv(G, 0, "PlusMultiplies", gx.data_ptr(), None, 0, 0, gy.data_ptr()) == 0
+            g.timer_start()
+            for _ in range(reps):
+                g.k_spmv(G, 0, "PlusMultiplies", gx.data_ptr(), None, 0, 0, gy.data_ptr())
+            gms = g.timer_stop() / reps
+            gb = g.k_spmv_bytes(G, 0)
+            extra["spmv_grid4096"] = {"n": gg["n"], "nnz": gg["nnz"], "algorithmic_bytes_per_launch": gb,
+                                      "avg_launch_ms": round(gms, 5), "achieved": round(gb / (gms * 1e-3) / 1e9, 2),
+                                      "unit": "GB/s", "frac": round(gb / (gms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+            del G, gptr, gind, gval, gx, gy
 
         # ---- the streaming primitives of the path (eWiseAdd / eWiseMult / reduce / assign) on
         #      64 Mi-element f32 vectors: algorithmic bytes per element / HIP-event time
