@@ -115,6 +115,12 @@ _SIGS = {
     "grb_sssp": [_vp, _vp, _i, _vp, C.POINTER(AlgoResult)],
     "grb_pr": [_vp, _vp, _f, _f, _vp, C.POINTER(AlgoResult)],
     "grb_k_spmv": [_vp, _i, _i, _vp, _vp, _i, _i, _vp],
+    "grb_scatter": [_vp, _vp, _vp, _d, _vp],
+    "grb_graph_color": [_vp, _vp, _vp, C.POINTER(_i)],
+    "grb_mis": [_vp, _vp, _i, _vp, _vp, C.POINTER(AlgoResult)],
+    "grb_gc": [_vp, _vp, _i, _vp, _i, _i, _vp, C.POINTER(AlgoResult)],
+    "grb_lgc": [_vp, _vp, _i, _d, _d, _vp, C.POINTER(AlgoResult)],
+    "grb_diameter": [_vp, _vp, _i, _i, _vp, C.POINTER(_i), C.POINTER(_i)],
 }
 
 _lib = None

@@ -428,6 +428,43 @@ def tc(A, B, desc):
     return info, n.value, dict(tight_ms=res.tight_ms)
 
 
+def scatter(w, mask, u, val, desc):
+    return _lib.load().grb_scatter(_h(w), _h(mask), _h(u), float(val), _h(desc))
+
+
+def graph_color(w, A, desc):
+    n = C.c_int(0)
+    info = _lib.load().grb_graph_color(_h(w), _h(A), _h(desc), C.byref(n))
+    return info, n.value
+
+
+def mis(v, A, seed, desc, weights=None):
+    """algorithm::mis; `weights` (an int Vector) replaces the host-drawn srand(seed)/rand() vector."""
+    res = AlgoResult()
+    info = _lib.load().grb_mis(_h(v), _h(A), int(seed), _h(weights), _h(desc), C.byref(res))
+    return info, dict(iterations=res.iterations, tight_ms=res.tight_ms)
+
+
+def gc(v, A, seed, max_colors, algo, desc, weights=None):
+    """algorithm::gcJP (algo 0) / gcMIS (1) / gcIS (2)."""
+    res = AlgoResult()
+    info = _lib.load().grb_gc(_h(v), _h(A), int(seed), _h(weights), int(max_colors), int(algo), _h(desc),
+                              C.byref(res))
+    return info, dict(iterations=res.iterations, tight_ms=res.tight_ms, succ=res.last_value)
+
+
+def lgc(p, A, s, alpha, eps, desc):
+    res = AlgoResult()
+    info = _lib.load().grb_lgc(_h(p), _h(A), int(s), float(alpha), float(eps), _h(desc), C.byref(res))
+    return info, dict(iterations=res.iterations, tight_ms=res.tight_ms, succ=res.last_value)
+
+
+def diameter(v, A, s_start, s_end, desc):
+    dmax, dind = C.c_int(0), C.c_int(-1)
+    info = _lib.load().grb_diameter(_h(v), _h(A), int(s_start), int(s_end), _h(desc), C.byref(dmax), C.byref(dind))
+    return info, dmax.value, dind.value
+
+
 # ---- raw kernels / timing -----------------------------------------------------------
 def k_spmv(A, tran, op, d_u, d_mask, scmp, accum, d_w):
     return _lib.load().grb_k_spmv(_h(A), int(tran), _semiring_id(op), d_u, d_mask, int(scmp), int(accum), d_w)

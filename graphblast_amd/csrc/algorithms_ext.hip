@@ -1,0 +1,377 @@
+// algorithms_ext.hip -- the remaining drivers of graphblas/algorithm/ (SURVEY.md 8(f)4):
+// maximal independent set, graph colouring (IS / MIS / Jones-Plassmann), local graph
+// clustering and BFS eccentricity ("diameter"), plus the two extension operations only they
+// use: scatter (operations.hpp:748-761) and graphColor (operations.hpp:816-826).
+//
+// mis / gc / lgc: the reference's loops give a result that is a function of the graph and the
+// weight vector only when every vector stays dense (its --mxvmode 2).  In its push and
+// push-pull modes the weight vector -- which is mask and input of the same vxm -- is
+// converted to sparse storage in place and the loop then runs through "not implemented"
+// branches (sparse mask, sparse-sparse eWiseAdd) that leave the frontier stale: restated op
+// by op (oracle/algorithms.py) it does not terminate.  The drivers here therefore pin
+// GrB_MXVMODE to GrB_PULLONLY for the duration of the call and restore it; applications
+// that compile the reference's own algorithm/mis.hpp against the C++ frontend get the
+// reference's behaviour for whatever mode they select.
+#include <climits>
+#include <cmath>
+#include <vector>
+
+#include "common.hpp"
+
+using namespace grb;
+
+namespace {
+struct VecGuard {               // frees temporaries on every exit path
+  std::vector<grb_vector> v;
+  ~VecGuard() { for (grb_vector x : v) grb_vector_free(x); }
+  grb_info make(grb_vector* out, grb_dtype dt, Index n) {
+    grb_info i = grb_vector_new(out, dt, n);
+    if (i == GRB_SUCCESS) v.push_back(*out);
+    return i;
+  }
+};
+struct ModeGuard {              // GrB_MXVMODE pinned for a scope
+  grb_descriptor d;
+  int saved = GRB_PUSHPULL;
+  explicit ModeGuard(grb_descriptor desc, int mode) : d(desc) {
+    grb_descriptor_get(d, GRB_MXVMODE, &saved);
+    grb_descriptor_set(d, GRB_MXVMODE, mode);
+  }
+  ~ModeGuard() { grb_descriptor_set(d, GRB_MXVMODE, saved); }
+};
+
+// w[(Index)u[k]] = val for 0 < u[k] < bound   (scatterKernel, kernels/scatter.hpp:7-21)
+template <typename T, typename U>
+__global__ void scatter_const_kernel(T* __restrict__ w, Index bound, const U* __restrict__ u, Index n, T val) {
+  for (Index k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
+    const Index i = static_cast<Index>(u[k]);
+    if (i > 0 && i < bound) w[i] = val;
+  }
+}
+
+__device__ __forceinline__ unsigned mix32(unsigned x) {
+  x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+  return x;
+}
+// One Jones-Plassmann round on (cur -> next), colours from 0, -1 = uncoloured.  A vertex
+// whose (hash, id) beats every uncoloured neighbour takes the smallest colour none of its
+// coloured neighbours holds; two adjacent vertices are never coloured in the same round, so
+// reading `cur` only is race-free.  A wave per 64 rows would balance hubs better; colouring is
+// a set-up step here, not the measured path.
+__global__ void jp_round_kernel(const Index* __restrict__ ptr, const Index* __restrict__ ind, Index n,
+                                const int* __restrict__ cur, int* __restrict__ next, int* __restrict__ left) {
+  int mine = 0;
+  for (Index v = blockIdx.x * blockDim.x + threadIdx.x; v < n; v += gridDim.x * blockDim.x) {
+    const int c = cur[v];
+    if (c >= 0) { next[v] = c; continue; }
+    const unsigned hv = mix32((unsigned)v);
+    const Index b = ptr[v], e = ptr[v + 1];
+    bool top = true;
+    for (Index k = b; k < e && top; ++k) {
+      const Index u = ind[k];
+      if (u == v || cur[u] >= 0) continue;
+      const unsigned hu = mix32((unsigned)u);
+      if (hu > hv || (hu == hv && u > v)) top = false;
+    }
+    if (!top) { next[v] = -1; ++mine; continue; }
+    int pick = -1;
+    for (int base = 0; pick < 0; base += 64) {
+      unsigned long long used = 0;
+      for (Index k = b; k < e; ++k) {
+        const int cu = cur[ind[k]];
+        if (cu >= base && cu < base + 64) used |= 1ull << (cu - base);
+      }
+      if (~used) pick = base + __ffsll((long long)~used) - 1;
+    }
+    next[v] = pick;
+  }
+  if (mine) atomicAdd(left, mine);
+}
+}  // namespace
+
+extern "C" {
+
+// scatter (extension; operations.hpp:748-761 -> backend/cuda/operations.hpp:1110-1142 + scatter.hpp:10-82).
+// The dense variant of the reference passes u's length as the bound of w (scatter.hpp:38); a target
+// past w's own end would be an out-of-bounds store there, so w's size bounds it here as well.
+grb_info grb_scatter(grb_vector w, grb_vector mask, grb_vector u, double val, grb_descriptor desc) {
+  if (!w || !u) return GRB_UNINITIALIZED_OBJECT;
+  (void)desc;
+  const int ut = u->vec_type;
+  GRB_TRY(grb_vector_set_storage(w, GRB_DENSE));
+  if (ut != GRB_SPARSE && ut != GRB_DENSE) return GRB_UNINITIALIZED_OBJECT;
+  if (mask) return GRB_SUCCESS;                            // "Masked variant scatter not implemented yet"
+  const void* src = ut == GRB_DENSE ? u->d_val : u->s_val;
+  const Index n = ut == GRB_DENSE ? u->nsize : u->s_nvals;
+  const Index bound = ut == GRB_DENSE ? (u->nsize < w->nsize ? u->nsize : w->nsize) : w->nsize;
+  if (n <= 0) return GRB_SUCCESS;
+  Context& c = ctx();
+  const dim3 grid(stream_grid(n)), block(kBlock);
+  if (w->dtype == GRB_F32 && u->dtype == GRB_F32)
+    hipLaunchKernelGGL((scatter_const_kernel<float, float>), grid, block, 0, c.stream, (float*)w->d_val, bound,
+                       (const float*)src, n, (float)val);
+  else if (w->dtype == GRB_F32)
+    hipLaunchKernelGGL((scatter_const_kernel<float, int>), grid, block, 0, c.stream, (float*)w->d_val, bound,
+                       (const int*)src, n, (float)val);
+  else if (u->dtype == GRB_F32)
+    hipLaunchKernelGGL((scatter_const_kernel<int, float>), grid, block, 0, c.stream, (int*)w->d_val, bound,
+                       (const float*)src, n, (int)val);
+  else
+    hipLaunchKernelGGL((scatter_const_kernel<int, int>), grid, block, 0, c.stream, (int*)w->d_val, bound,
+                       (const int*)src, n, (int)val);
+  GRB_HIP_TRY(hipGetLastError());
+  return GRB_SUCCESS;
+}
+
+// graphColor (operations.hpp:816-826 -> backend/cuda/color.hpp:18-88).  The reference hands the CSR
+// to cuSPARSE csrcolor (closed source, not in the tree); what its callers rely on
+// (example/ggc_cusparse.cu:94-99) is a proper colouring with colours counted from 0.  This is
+// Jones-Plassmann with a hashed priority.  w: int or float vector of length nrows.
+grb_info grb_graph_color(grb_vector w, grb_matrix A, grb_descriptor desc, int* ncolors) {
+  if (!w || !A || !desc) return GRB_UNINITIALIZED_OBJECT;
+  const Index n = A->nrows;
+  if (A->ncols != w->nsize) return GRB_DIMENSION_MISMATCH;
+  if (!A->csr.ptr) return GRB_INVALID_OBJECT;
+  Context& c = ctx();
+  VecGuard g;
+  grb_vector a, b, cnt;
+  GRB_TRY(g.make(&a, GRB_I32, n));
+  GRB_TRY(g.make(&b, GRB_I32, n));
+  GRB_TRY(g.make(&cnt, GRB_I32, 64));
+  GRB_TRY(grb_vector_fill(a, -1.0));
+  GRB_TRY(grb_vector_fill(b, -1.0));
+  int* cur = (int*)a->d_val;
+  int* nxt = (int*)b->d_val;
+  for (int round = 0; round <= n; ++round) {
+    GRB_TRY(grb_vector_fill(cnt, 0.0));
+    hipLaunchKernelGGL(jp_round_kernel, dim3(stream_grid(n)), dim3(kBlock), 0, c.stream, A->csr.ptr, A->csr.ind, n,
+                       (const int*)cur, nxt, (int*)cnt->d_val);
+    GRB_HIP_TRY(hipGetLastError());
+    int left = 0;
+    GRB_TRY(fetch_ints((const int*)cnt->d_val, 1, &left));
+    std::swap(cur, nxt);
+    if (left == 0) break;
+  }
+  grb_vector colours = cur == (int*)a->d_val ? a : b;
+  double mx = 0;
+  GRB_TRY(grb_reduce_vector(&mx, GRB_ACCUM_NULL, GRB_MAXIMUM_MONOID, colours, desc));
+  if (ncolors) *ncolors = n > 0 ? (int)mx + 1 : 0;
+  if (w->dtype == GRB_I32) return grb_vector_dup(w, colours);
+  // float output (example/ggc_cusparse.cu colours a Vector<int>; kept for completeness)
+  std::vector<int> h(n > 0 ? n : 1);
+  grb_index nn = n;
+  GRB_TRY(grb_vector_extract_tuples_dense(colours, h.data(), &nn));
+  std::vector<float> f(h.begin(), h.end());
+  return grb_vector_build_dense(w, f.data(), n);
+}
+
+// ---- maximal independent set -------------------------------------------------------------
+// misInner (algorithm/mis.hpp:22-111): v = 1 on the members; w (candidate weights), f, m clobbered.
+static grb_info mis_inner(grb_vector v, grb_vector w, grb_vector f, grb_vector m, grb_matrix A, grb_descriptor desc,
+                          int* rounds_out) {
+  GRB_TRY(grb_vector_fill(v, 0.0));
+  double succ = 0;
+  int rounds = 0;
+  const Index n = A->nrows;
+  do {
+    ++rounds;
+    // a failing vxm is not fatal in the reference either (no CHECK, mis.hpp:62-63, :86-87)
+    grb_vxm(m, w, GRB_ACCUM_NULL, GRB_MAXIMUM_MULTIPLIES, w, A, desc);
+    GRB_TRY(grb_eWiseAdd(f, nullptr, GRB_ACCUM_NULL, GRB_GREATER_PLUS, w, m, desc));
+    GRB_TRY(grb_assign(v, f, GRB_ACCUM_NULL, 1.0, desc));
+    GRB_TRY(grb_assign(w, f, GRB_ACCUM_NULL, 0.0, desc));
+    GRB_TRY(grb_reduce_vector(&succ, GRB_ACCUM_NULL, GRB_PLUS_MONOID, f, desc));
+    if (succ == 0) break;
+    grb_vxm(m, w, GRB_ACCUM_NULL, GRB_LOGICAL_OR_AND, f, A, desc);
+    GRB_TRY(grb_assign(w, m, GRB_ACCUM_NULL, 0.0, desc));
+    if (rounds > n + 1) return GRB_PANIC;                  // cannot happen with dense vectors
+  } while (succ > 0);
+  if (rounds_out) *rounds_out = rounds;
+  return GRB_SUCCESS;
+}
+
+// The weight vector of mis / gc*: the caller's, or -- as the reference draws it on the host,
+// apply(set_random<int>) under GrB_SEQUENTIAL (algorithm/common.hpp:8-20, mis.hpp:128-133) --
+// srand(seed) then rand() per vertex in index order.
+static grb_info load_weights(grb_vector w, grb_vector weights, int seed, Index n) {
+  if (weights) {
+    if (weights->dtype != GRB_I32 || weights->nsize != n) return GRB_DIMENSION_MISMATCH;
+    GRB_TRY(grb_vector_dup(w, weights));
+    return grb_vector_set_storage(w, GRB_DENSE);
+  }
+  std::vector<int> h(n > 0 ? n : 1);
+  srand((unsigned)seed);
+  for (Index i = 0; i < n; ++i) h[i] = rand();
+  return grb_vector_build_dense(w, h.data(), n);
+}
+
+grb_info grb_mis(grb_vector v, grb_matrix A, int seed, grb_vector weights, grb_descriptor desc,
+                 grb_algo_result* result) {
+  if (!v || !A || !desc) return GRB_UNINITIALIZED_OBJECT;
+  if (v->dtype != GRB_I32 || A->dtype != GRB_I32) return GRB_DOMAIN_MISMATCH;
+  const Index n = A->nrows;
+  VecGuard g;
+  grb_vector w, f, m;
+  for (grb_vector* p : {&w, &f, &m}) GRB_TRY(g.make(p, GRB_I32, n));
+  GRB_TRY(load_weights(w, weights, seed, n));
+  ModeGuard pin(desc, GRB_PULLONLY);
+  int rounds = 0;
+  float ms = 0.f;
+  GRB_TRY(grb_timer_start());
+  GRB_TRY(mis_inner(v, w, f, m, A, desc, &rounds));
+  GRB_TRY(grb_timer_stop(&ms));
+  if (result) { result->iterations = rounds; result->tight_ms = ms; result->last_value = 0; }
+  return GRB_SUCCESS;
+}
+
+// algorithm::gcJP / gcMIS / gcIS (algorithm/gc.hpp:258-421, :152-255, :43-149); algo as --gcalgo:
+// 0 Jones-Plassmann, 1 maximal-independent-set per colour, 2 independent-set per colour.
+// v = colours from 1 (0 = left uncoloured when max_niter rounds ran out); iterations = `iter`.
+grb_info grb_gc(grb_vector v, grb_matrix A, int seed, grb_vector weights, int max_colors, int algo,
+                grb_descriptor desc, grb_algo_result* result) {
+  if (!v || !A || !desc) return GRB_UNINITIALIZED_OBJECT;
+  if (v->dtype != GRB_I32 || A->dtype != GRB_I32) return GRB_DOMAIN_MISMATCH;
+  if (algo < 0 || algo > 2 || max_colors < 2) return GRB_INVALID_VALUE;
+  const Index n = A->nrows;
+  VecGuard g;
+  grb_vector f, w, m, nn, temp_w, d = nullptr, ascending = nullptr, min_array = nullptr;
+  for (grb_vector* p : {&f, &w, &m, &nn, &temp_w}) GRB_TRY(g.make(p, GRB_I32, n));
+  if (algo == 0) {
+    for (grb_vector* p : {&d, &ascending, &min_array}) GRB_TRY(g.make(p, GRB_I32, max_colors));
+    GRB_TRY(grb_vector_fill_ascending(ascending, max_colors));
+  }
+  GRB_TRY(grb_vector_fill(v, 0.0));
+  GRB_TRY(load_weights(w, weights, seed, n));
+  ModeGuard pin(desc, GRB_PULLONLY);
+  int iter = 1;
+  double succ = 0;
+  float ms = 0.f;
+  GRB_TRY(grb_timer_start());
+  do {
+    double colour = iter;
+    if (algo == 1) {
+      GRB_TRY(grb_vector_dup(temp_w, w));
+      GRB_TRY(mis_inner(f, temp_w, nn, m, A, desc, nullptr));
+    } else {
+      // JP masks the product by the candidates themselves, IS does not (gc.hpp:339-340, :106-107)
+      grb_vxm(m, algo == 0 ? w : nullptr, GRB_ACCUM_NULL, GRB_MAXIMUM_MULTIPLIES, w, A, desc);
+      GRB_TRY(grb_eWiseAdd(f, nullptr, GRB_ACCUM_NULL, GRB_GREATER_PLUS, w, m, desc));
+    }
+    GRB_TRY(grb_reduce_vector(&succ, GRB_ACCUM_NULL, GRB_PLUS_MONOID, f, desc));
+    if (succ == 0) break;
+    if (algo == 0) {
+      // smallest colour unused around the whole frontier (gc.hpp:356-385)
+      grb_vxm(m, v, GRB_ACCUM_NULL, GRB_LOGICAL_OR_AND, f, A, desc);
+      GRB_TRY(grb_eWiseMult(nn, nullptr, GRB_ACCUM_NULL, GRB_PLUS_MULTIPLIES, m, v, desc));
+      GRB_TRY(grb_vector_fill(d, 0.0));
+      GRB_TRY(grb_scatter(d, nullptr, nn, (double)max_colors, desc));
+      GRB_TRY(grb_eWiseMult(min_array, nullptr, GRB_ACCUM_NULL, GRB_MINIMUM_PLUS, d, ascending, desc));
+      GRB_TRY(grb_vector_set_element(min_array, (double)max_colors, 0));
+      GRB_TRY(grb_reduce_vector(&colour, GRB_ACCUM_NULL, GRB_MINIMUM_MONOID, min_array, desc));
+    }
+    GRB_TRY(grb_assign(v, f, GRB_ACCUM_NULL, colour, desc));
+    GRB_TRY(grb_assign(w, f, GRB_ACCUM_NULL, 0.0, desc));
+    ++iter;
+    if (iter > desc->max_niter) break;
+  } while (succ > 0);
+  GRB_TRY(grb_timer_stop(&ms));
+  if (result) { result->iterations = iter; result->tight_ms = ms; result->last_value = succ; }
+  return GRB_SUCCESS;
+}
+
+// algorithm::lgc (algorithm/lgc.hpp:14-176): approximate personalised PageRank from s by
+// residual pushes; p and A are float.  iterations = loop passes, last_value = last frontier size.
+grb_info grb_lgc(grb_vector p, grb_matrix A, grb_index s, double alpha, double eps, grb_descriptor desc,
+                 grb_algo_result* result) {
+  if (!p || !A || !desc) return GRB_UNINITIALIZED_OBJECT;
+  if (p->dtype != GRB_F32 || A->dtype != GRB_F32) return GRB_DOMAIN_MISMATCH;
+  const Index n = A->nrows;
+  if (s < 0 || s >= n) return GRB_INVALID_INDEX;
+  VecGuard g;
+  grb_vector degrees, r, r2, eps_vector, degrees_eps, f, alpha_vector, alpha_vector2;
+  for (grb_vector* q : {&degrees, &r, &r2, &eps_vector, &degrees_eps, &f, &alpha_vector, &alpha_vector2})
+    GRB_TRY(g.make(q, GRB_F32, n));
+  // pinned to the dense mode, as mis / gc above: the reference's push path has no accum
+  // (spmspv.hpp:28-33), so r = r + A r2 loses r there, and its sparse masked eWiseMult with w == u
+  // (lgc.hpp:116-117) rewrites the index array other threads are still searching
+  ModeGuard pin(desc, GRB_PULLONLY);
+  GRB_TRY(grb_reduce_matrix_rows(degrees, nullptr, GRB_ACCUM_NULL, GRB_PLUS_MONOID, A, desc));
+  GRB_TRY(grb_vector_fill(p, 0.0));
+  GRB_TRY(grb_vector_fill(r2, 0.0));
+  const grb_index idx[1] = {s};
+  const float one[1] = {1.f};
+  if (desc->desc[GRB_MXVMODE] == GRB_PULLONLY) {
+    GRB_TRY(grb_vector_fill(r, 0.0));
+    GRB_TRY(grb_vector_set_element(r, 1.0, s));
+  } else {
+    GRB_TRY(grb_vector_build_sparse(r, idx, one, 1));
+  }
+  GRB_TRY(grb_vector_fill(eps_vector, (double)(float)eps));
+  GRB_TRY(grb_eWiseMult(degrees_eps, nullptr, GRB_ACCUM_NULL, GRB_PLUS_MULTIPLIES, degrees, eps_vector, desc));
+  GRB_TRY(grb_vector_build_sparse(f, idx, one, 1));
+  GRB_TRY(grb_vector_fill(alpha_vector, (double)(float)alpha));
+  GRB_TRY(grb_vector_fill(alpha_vector2, (double)(float)((1. - alpha) / 2.)));
+  int iter = 1;
+  double succ = 0;
+  float ms = 0.f;
+  GRB_TRY(grb_timer_start());
+  do {
+    // none of these is CHECKed in the reference (lgc.hpp:108-135): an op that reports an error
+    // leaves its output as it was and the loop goes on
+    grb_descriptor_toggle(desc, GRB_MASK);
+    grb_eWiseMult(r2, f, GRB_ACCUM_NULL, GRB_PLUS_MULTIPLIES, r, alpha_vector, desc);
+    grb_descriptor_toggle(desc, GRB_MASK);
+    grb_eWiseAdd(p, nullptr, GRB_ACCUM_NULL, GRB_PLUS_MULTIPLIES, p, r2, desc);
+    grb_eWiseMult(r, f, GRB_ACCUM_NULL, GRB_PLUS_MULTIPLIES, r, alpha_vector2, desc);
+    grb_descriptor_toggle(desc, GRB_MASK);
+    grb_eWiseMult(r2, f, GRB_ACCUM_NULL, GRB_PLUS_DIVIDES, r, degrees, desc);
+    grb_descriptor_toggle(desc, GRB_MASK);
+    grb_mxv(r, nullptr, GRB_ACCUM_PRESENT, GRB_PLUS_MULTIPLIES, A, r2, desc);
+    grb_eWiseMult(f, nullptr, GRB_ACCUM_NULL, GRB_PLUS_GREATER, r, degrees_eps, desc);
+    GRB_TRY(grb_reduce_vector(&succ, GRB_ACCUM_NULL, GRB_PLUS_MONOID, f, desc));
+    ++iter;
+    if (iter > desc->max_niter) break;
+  } while (succ > 0);
+  GRB_TRY(grb_timer_stop(&ms));
+  if (result) { result->iterations = iter - 1; result->tight_ms = ms; result->last_value = succ; }
+  return GRB_SUCCESS;
+}
+
+// algorithm::diameter (algorithm/diameter.hpp:14-59): BFS eccentricity of each source in
+// [s_start, s_end); *diameter_max = the largest, *diameter_ind = the last source attaining it.
+grb_info grb_diameter(grb_vector v, grb_matrix A, grb_index s_start, grb_index s_end, grb_descriptor desc,
+                      int* diameter_max, int* diameter_ind) {
+  if (!v || !A || !desc) return GRB_UNINITIALIZED_OBJECT;
+  if (v->dtype != GRB_F32 || A->dtype != GRB_F32) return GRB_DOMAIN_MISMATCH;
+  const Index n = A->nrows;
+  VecGuard g;
+  grb_vector q1, q2;
+  GRB_TRY(g.make(&q1, GRB_F32, n));
+  GRB_TRY(g.make(&q2, GRB_F32, n));
+  int dmax = 0, dind = -1;
+  for (grb_index s = s_start; s < s_end; ++s) {
+    GRB_TRY(grb_vector_fill(v, 0.0));
+    const grb_index idx[1] = {s};
+    const float one[1] = {1.f};
+    grb_vector_build_sparse(q1, idx, one, 1);              // unchecked there too (diameter.hpp:36)
+    int iter = 1;
+    double succ = 0;
+    do {
+      grb_assign(v, q1, GRB_ACCUM_NULL, (double)iter, desc);
+      grb_descriptor_toggle(desc, GRB_MASK);
+      grb_vxm(q2, v, GRB_ACCUM_NULL, GRB_LOGICAL_OR_AND, q1, A, desc);
+      grb_descriptor_toggle(desc, GRB_MASK);
+      grb_vector_swap(q2, q1);
+      GRB_TRY(grb_reduce_vector(&succ, GRB_ACCUM_NULL, GRB_PLUS_MONOID, q1, desc));
+      ++iter;
+      if (iter > n + 2) return GRB_PANIC;
+    } while (succ > 0);
+    if (iter - 2 > dmax) dmax = iter - 2;
+    if (iter - 2 == dmax) dind = (int)s;
+  }
+  if (diameter_max) *diameter_max = dmax;
+  if (diameter_ind) *diameter_ind = dind;
+  return GRB_SUCCESS;
+}
+
+}  // extern "C"

@@ -457,10 +457,10 @@ grb_info grb_vector_nvals(grb_vector v, grb_index* nvals) {
 
 grb_info grb_vector_build_sparse(grb_vector v, const grb_index* indices, const void* values, grb_index nvals) {
   if (!v) return GRB_UNINITIALIZED_OBJECT;
+  v->vec_type = GRB_SPARSE;                                // vector.hpp:154: set before sparse_.build can fail
+  GRB_TRY(vec_alloc_sparse(v));
   if (nvals > v->nsize) return GRB_PANIC;                  // sparse_vector.hpp:138-142
   if (v->s_nvals > 0) return GRB_OUTPUT_NOT_EMPTY;
-  v->vec_type = GRB_SPARSE;
-  GRB_TRY(vec_alloc_sparse(v));
   if (nvals > 0) {
     GRB_HIP_TRY(hipMemcpyAsync(v->s_ind, indices, 4 * (size_t)nvals, hipMemcpyHostToDevice, ctx().stream));
     GRB_HIP_TRY(hipMemcpyAsync(v->s_val, values, 4 * (size_t)nvals, hipMemcpyHostToDevice, ctx().stream));

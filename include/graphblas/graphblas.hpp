@@ -672,6 +672,66 @@ Info extractGather(Vector<W>* w, const Vector<M>* mask, BinaryOpT accum, const V
                                    desc->handle()));
 }
 
+// scatter (extension, operations.hpp:748-761): w[(Index)indices[k]] = val
+template <typename W, typename M, typename I, typename X>
+Info scatter(Vector<W>* w, const Vector<M>* mask, const Vector<I>* indices, X val, Descriptor* desc) {
+  if (indices == NULL || w == NULL) return GrB_UNINITIALIZED_OBJECT;
+  return to_info(grb_scatter(GRB_H(w), GRB_H(mask), GRB_H(indices), static_cast<double>(val),
+                             desc ? desc->handle() : static_cast<grb_descriptor>(NULL)));
+}
+
+// graphColor (operations.hpp:816-826; cuSPARSE csrcolor in the reference): colours from 0
+template <typename W, typename a>
+Info graphColor(Vector<W>* w, const Matrix<a>* A, Descriptor* desc) {
+  if (A == NULL || w == NULL || desc == NULL) return GrB_UNINITIALIZED_OBJECT;
+  return to_info(grb_graph_color(GRB_H(w), A->handle(), desc->handle(), NULL));
+}
+
+// apply on a vector (operations.hpp:559-579 -> backend :878-910, apply.hpp:10-62): implemented in the
+// reference only for a dense u, no mask, under GrB_BACKEND = GrB_SEQUENTIAL -- a host loop in
+// index order between a device->host and a host->device copy (so a stateful functor such as
+// set_random, algorithm/common.hpp:8-20, sees the elements in order).  Every other case prints
+// its "not implemented" line there and changes nothing but w's storage flag.
+template <typename W, typename M, typename U, typename BinaryOpT, typename UnaryOpT>
+Info apply(Vector<W>* w, const Vector<M>* mask, BinaryOpT accum, UnaryOpT op, const Vector<U>* u, Descriptor* desc) {
+  (void)accum;
+  if (w == NULL || u == NULL) return GrB_UNINITIALIZED_OBJECT;
+  if (desc == NULL) return GrB_UNINITIALIZED_OBJECT;
+  Index un = 0, wn = 0, mn = 0;
+  u->size(&un);
+  w->size(&wn);
+  if (un != wn) return GrB_DIMENSION_MISMATCH;
+  if (mask != NULL) {
+    mask->size(&mn);
+    if (mn != wn) return GrB_DIMENSION_MISMATCH;
+  }
+  Storage s;
+  u->getStorage(&s);
+  if (s == GrB_SPARSE) {
+    w->setStorage(GrB_SPARSE);
+    std::cout << "SpVec Apply\nError: Feature not implemented yet!\n";
+    return GrB_SUCCESS;
+  }
+  if (s != GrB_DENSE) return GrB_UNINITIALIZED_OBJECT;
+  w->setStorage(GrB_DENSE);
+  Desc_value backend;
+  desc->get(GrB_BACKEND, &backend);
+  if (backend != GrB_SEQUENTIAL) {
+    std::cout << "DeVec apply GPU\nError: Feature not implemented yet!\n";
+    return GrB_SUCCESS;
+  }
+  if (mask != NULL) {
+    std::cout << "Error: DeVec apply masked not implemented yet!\n";
+    return GrB_SUCCESS;
+  }
+  std::vector<U> uv;
+  Info i = const_cast<Vector<U>*>(u)->extractTuples(&uv, &un);
+  if (i != GrB_SUCCESS) return i;
+  std::vector<W> wv(un);
+  for (Index k = 0; k < un; ++k) wv[k] = op(uv[k]);
+  return w->build(&wv, un);
+}
+
 // mxm: masked SpGEMM only (operations.hpp:22-48; unmasked is a cuSPARSE call in the reference)
 template <typename c, typename m, typename a, typename b, typename BinaryOpT, typename SemiringT>
 Info mxm(Matrix<c>* C, const Matrix<m>* mask, BinaryOpT accum, SemiringT op, const Matrix<a>* A, const Matrix<b>* B,

@@ -295,6 +295,31 @@ grb_info grb_cc(grb_vector v, grb_matrix A, int seed, grb_descriptor desc, grb_a
 /* algorithm::tc (algorithm/tc.hpp:15-54): A = lower triangle (int), B = buffer matrix. */
 grb_info grb_tc(int64_t* ntris, grb_matrix A, grb_matrix B, grb_descriptor desc, grb_algo_result* result);
 
+/* ---- The remaining drivers of graphblas/algorithm/  and the two extension
+ * operations only they use. */
+/* scatter   operations.hpp:748-761 -> backend :1110-1142 (scatter.hpp:10-82): w[(Index)u[k]] = val
+ * for every stored u[k] with 0 < u[k] < size(w); masked variants are no-ops as in the reference. */
+grb_info grb_scatter(grb_vector w, grb_vector mask, grb_vector u, double val, grb_descriptor desc);
+/* graphColor   operations.hpp:816-826 -> backend/cuda/color.hpp:18-88 (cuSPARSE csrcolor there):
+ * w = a proper colouring of A's graph, colours from 0; *ncolors (nullable) = colours used. */
+grb_info grb_graph_color(grb_vector w, grb_matrix A, grb_descriptor desc, int* ncolors);
+/* algorithm::mis (algorithm/mis.hpp:22-141): v = 1 on a maximal independent set chosen by Luby
+ * rounds over the int weight vector `weights` (NULL: srand(seed) + rand() per vertex on the host,
+ * as apply(set_random) does there, algorithm/common.hpp:8-20).  v, A, weights are int. */
+grb_info grb_mis(grb_vector v, grb_matrix A, int seed, grb_vector weights, grb_descriptor desc,
+                 grb_algo_result* result);
+/* algorithm::gcJP / gcMIS / gcIS (algorithm/gc.hpp:258-421, :152-255, :43-149); algo = --gcalgo
+ * (0 JP, 1 MIS, 2 IS).  v = colours from 1. */
+grb_info grb_gc(grb_vector v, grb_matrix A, int seed, grb_vector weights, int max_colors, int algo,
+                grb_descriptor desc, grb_algo_result* result);
+/* algorithm::lgc (algorithm/lgc.hpp:14-176): p = approximate personalised PageRank from s. */
+grb_info grb_lgc(grb_vector p, grb_matrix A, grb_index s, double alpha, double eps, grb_descriptor desc,
+                 grb_algo_result* result);
+/* algorithm::diameter (algorithm/diameter.hpp:14-59): largest BFS eccentricity over the sources
+ * s_start..s_end-1 and the last source attaining it; v = the last traversal's depth labels. */
+grb_info grb_diameter(grb_vector v, grb_matrix A, grb_index s_start, grb_index s_end, grb_descriptor desc,
+                      int* diameter_max, int* diameter_ind);
+
 /* ---- Raw kernels on plain device pointers (micro-benchmarks / multi-GPU shards) --- */
 /* Generic semiring SpMV  w[i] = (+)_j A[i,j] (x) u[j] on this matrix's CSR (tran=0) or
  * CSC (tran=1) arrays: the kernel behind the pull branch (backend/cuda/spmv.hpp:178-220).

@@ -115,11 +115,11 @@ class Vector:
     # --- container API -----------------------------------------------------
     def build_sparse(self, indices, values):
         n = len(indices)
+        self.vec_type_ = GrB_SPARSE          # vector.hpp:154, before sparse_.build can fail
         if n > self.nsize_:
             return GrB_PANIC
         if self.s_nvals > 0:
             return GrB_OUTPUT_NOT_EMPTY
-        self.vec_type_ = GrB_SPARSE
         self.s_ind[:n] = np.asarray(indices, dtype=np.int32)
         self.s_val[:n] = np.asarray(values, dtype=self.dtype)
         self.s_nvals = n
@@ -702,6 +702,29 @@ def assignScatter(w, mask, accum, u, indices, desc):
 
 def extractGather(w, mask, accum, u, indices, desc):
     return _scatter_gather(w, mask, u, indices, True)
+
+
+def scatter(w, mask, u, val, desc):
+    """Extension op `scatter` (operations.hpp:748-761 -> backend/cuda/operations.hpp:1110-1142,
+    scatter.hpp:10-82, kernels/scatter.hpp:7-21): w[(Index)u[k]] = val for every stored u[k]
+    with 0 < u[k] < bound (index 0 is skipped by the kernel's `ind > 0`).  bound: the dense
+    variant passes u's length where w's belongs (scatter.hpp:38) -- writes past w's end would
+    be out of bounds there, so the restatement also bounds by w's size; the sparse variant
+    passes w's length.  Masked variants print "not implemented" and do nothing."""
+    ut = u.getStorage()
+    w.setStorage(GrB_DENSE)
+    if ut not in (GrB_SPARSE, GrB_DENSE):
+        return GrB_UNINITIALIZED_OBJECT
+    if mask is not None:
+        return GrB_SUCCESS
+    if ut == GrB_DENSE:
+        src, bound = u.d_val, min(u.nsize_, w.nsize_)
+    else:
+        src, bound = u.s_val[:u.s_nvals], w.nsize_
+    idx = src.astype(np.int64)
+    ok = (idx > 0) & (idx < bound)
+    w.d_val[idx[ok]] = w.dtype(val)
+    return GrB_SUCCESS
 
 
 # ---------------------------------------------------------------------------

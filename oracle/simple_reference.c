@@ -10,6 +10,9 @@
  *   oracle_cc    <- graphblas/algorithm/test_cc.hpp:14-56    (SimpleReferenceCc)
  *   oracle_cc_verify <- test_cc.hpp:58-95                    (SimpleVerifyCc)
  *   oracle_tc    <- graphblas/algorithm/test_tc.hpp:14-84    (SimpleReferenceTc)
+ *   oracle_mis / oracle_mis_verify <- graphblas/algorithm/test_mis.hpp:12-56 / :65-115
+ *   oracle_gc  / oracle_gc_verify  <- graphblas/algorithm/test_gc.hpp:13-57 / :59-98
+ *   oracle_lgc   <- graphblas/algorithm/test_lgc.hpp:13-88   (SimpleReferenceLgc)
  *   oracle_bfs_do_stats : instrumented BFS that follows the direction decisions of
  *       backend/cuda/vector.hpp:291-323 (convert) + algorithm/bfs.hpp:48-82 and
  *       counts the per-level quantities SURVEY.md 8(d) needs (nf, mf, nu, mi).
@@ -243,6 +246,131 @@ double oracle_tc(Index nrows, const Index* row_ptr, const Index* col_ind,
   }
   double t1 = now_ms();
   if (ntris_out) *ntris_out = ntris;
+  return t1 - t0;
+}
+
+/* ---- MIS: greedy over a vertex order (test_mis.hpp:35-52).  The reference draws the order
+ * with std::shuffle(std::mt19937(seed)) -- a libstdc++-specific stream -- so the order is an
+ * argument here; its own check of a result is the property test below, not this sequence. ---- */
+double oracle_mis(Index nrows, const Index* row_ptr, const Index* col_ind, const Index* order, int32_t* mis) {
+  unsigned char* candidate = (unsigned char*)malloc((size_t)nrows + 1);
+  memset(candidate, 1, (size_t)nrows + 1);
+  for (Index i = 0; i < nrows; ++i) mis[i] = 0;
+  double t0 = now_ms();
+  for (Index i = 0; i < nrows; ++i) {
+    Index row = order[i];
+    if (!candidate[row]) continue;
+    mis[row] = 1;
+    candidate[row] = 0;
+    for (Index e = row_ptr[row]; e < row_ptr[row + 1]; ++e) candidate[col_ind[e]] = 0;
+  }
+  double t1 = now_ms();
+  free(candidate);
+  return t1 - t0;
+}
+
+/* SimpleVerifyMis (test_mis.hpp:65-115): errors = adjacent pairs both in the set (counted per
+ * stored edge) + vertices neither in the set nor adjacent to it.  0 <=> "CORRECT". */
+int oracle_mis_verify(Index nrows, const Index* row_ptr, const Index* col_ind, const int32_t* mis,
+                      int* set_size_out) {
+  int flag = 0, set_size = 0;
+  unsigned char* discovered = (unsigned char*)calloc((size_t)nrows + 1, 1);
+  for (Index row = 0; row < nrows; ++row) {
+    if (mis[row] != 1) continue;
+    ++set_size;
+    discovered[row] = 1;
+    for (Index e = row_ptr[row]; e < row_ptr[row + 1]; ++e) {
+      Index col = col_ind[e];
+      if (mis[col] == 1) ++flag;
+      discovered[col] = 1;
+    }
+  }
+  for (Index row = 0; row < nrows; ++row)
+    if (!discovered[row]) ++flag;
+  free(discovered);
+  if (set_size_out) *set_size_out = set_size;
+  return flag;
+}
+
+/* ---- GC: greedy first-fit over a vertex order, colours from 1 (test_gc.hpp:33-51). ---- */
+double oracle_gc(Index nrows, const Index* row_ptr, const Index* col_ind, const Index* order, int max_colors,
+                 int32_t* color) {
+  unsigned char* used = (unsigned char*)malloc((size_t)max_colors + 1);
+  for (Index i = 0; i < nrows; ++i) color[i] = 0;
+  double t0 = now_ms();
+  for (Index i = 0; i < nrows; ++i) {
+    Index row = order[i];
+    memset(used, 0, (size_t)max_colors + 1);
+    for (Index e = row_ptr[row]; e < row_ptr[row + 1]; ++e) used[color[col_ind[e]]] = 1;
+    for (int c = 1; c < max_colors; ++c)
+      if (!used[c]) { color[row] = c; break; }
+  }
+  double t1 = now_ms();
+  free(used);
+  return t1 - t0;
+}
+
+/* SimpleVerifyGc (test_gc.hpp:59-98): errors = stored edges whose endpoints share a colour
+ * (uncoloured vertices, colour 0, are reported but -- as there -- not counted unless two of
+ * them are adjacent); *uncolored_out counts them so callers can require 0. */
+int oracle_gc_verify(Index nrows, const Index* row_ptr, const Index* col_ind, const int32_t* color,
+                     int* max_color_out, int* uncolored_out) {
+  int num_error = 0, max_color = 0, uncolored = 0;
+  for (Index row = 0; row < nrows; ++row) {
+    int rc = color[row];
+    if (rc > max_color) max_color = rc;
+    if (rc == 0) ++uncolored;
+    for (Index e = row_ptr[row]; e < row_ptr[row + 1]; ++e)
+      if (color[col_ind[e]] == rc) ++num_error;
+  }
+  if (max_color_out) *max_color_out = max_color;
+  if (uncolored_out) *uncolored_out = uncolored;
+  return num_error;
+}
+
+/* ---- LGC: approximate personalised PageRank by queue pushes (test_lgc.hpp:13-88), T = float,
+ * alpha / eps double: every mixed expression is evaluated in double and rounded on the store,
+ * as the C++ there does. ---- */
+double oracle_lgc(Index nrows, const Index* row_ptr, const Index* col_ind, float* pagerank, Index src,
+                  double alpha, double eps, int max_niter) {
+  float* residual = (float*)calloc((size_t)nrows + 1, sizeof(float));
+  float* residual2 = (float*)calloc((size_t)nrows + 1, sizeof(float));
+  float* degrees = (float*)calloc((size_t)nrows + 1, sizeof(float));
+  /* the frontier deque: each iteration appends at most nrows vertices after draining */
+  Index* frontier = (Index*)malloc(sizeof(Index) * ((size_t)nrows + 1));
+  Index* next = (Index*)malloc(sizeof(Index) * ((size_t)nrows + 1));
+  Index nf = 0;
+  for (Index i = 0; i < nrows; ++i) {
+    pagerank[i] = 0.f;
+    degrees[i] = (float)(row_ptr[i + 1] - row_ptr[i]);
+  }
+  residual[src] = 1.f;
+  residual2[src] = 1.f;
+  frontier[nf++] = src;
+  double t0 = now_ms();
+  for (int it = 0; it < max_niter; ++it) {
+    for (Index k = 0; k < nf; ++k) {
+      Index v = frontier[k];
+      pagerank[v] = (float)(pagerank[v] + alpha * residual[v]);
+      residual2[v] = (float)((1 - alpha) * residual[v] / 2);
+    }
+    for (Index k = 0; k < nf; ++k) {
+      Index v = frontier[k];
+      residual[v] = (float)((1 - alpha) * residual[v] / 2);
+      for (Index e = row_ptr[v]; e < row_ptr[v + 1]; ++e) {
+        Index w = col_ind[e];
+        residual2[w] += residual[v] / degrees[v];
+      }
+    }
+    memcpy(residual, residual2, sizeof(float) * (size_t)nrows);
+    Index nn = 0;
+    for (Index v = 0; v < nrows; ++v)
+      if (residual[v] >= degrees[v] * eps) next[nn++] = v;
+    memcpy(frontier, next, sizeof(Index) * (size_t)nn);
+    nf = nn;
+  }
+  double t1 = now_ms();
+  free(residual); free(residual2); free(degrees); free(frontier); free(next);
   return t1 - t0;
 }
 

@@ -22,9 +22,12 @@ def lib():
     global _LIB
     if _LIB is None:
         _LIB = ctypes.CDLL(build())
-        for name in ("oracle_bfs", "oracle_sssp", "oracle_pr", "oracle_cc", "oracle_tc"):
+        for name in ("oracle_bfs", "oracle_sssp", "oracle_pr", "oracle_cc", "oracle_tc", "oracle_mis", "oracle_gc",
+                     "oracle_lgc"):
             getattr(_LIB, name).restype = ctypes.c_double
         _LIB.oracle_cc_verify.restype = ctypes.c_int
+        _LIB.oracle_mis_verify.restype = ctypes.c_int
+        _LIB.oracle_gc_verify.restype = ctypes.c_int
         _LIB.oracle_bfs_do_stats.restype = ctypes.c_int
     return _LIB
 
@@ -106,6 +109,49 @@ def tc(row_ptr, col_ind):
     nt = ctypes.c_longlong(0)
     ms = lib().oracle_tc(rp.size - 1, _p(rp, ctypes.c_int), _p(ci, ctypes.c_int), ctypes.byref(nt))
     return nt.value, ms
+
+
+def mis(row_ptr, col_ind, order):
+    """SimpleReferenceMis over the given vertex order (the reference shuffles with mt19937)."""
+    rp, ci, od = _i32(row_ptr), _i32(col_ind), _i32(order)
+    out = np.zeros(rp.size - 1, dtype=np.int32)
+    ms = lib().oracle_mis(rp.size - 1, _p(rp, ctypes.c_int), _p(ci, ctypes.c_int), _p(od, ctypes.c_int),
+                          _p(out, ctypes.c_int))
+    return out, ms
+
+
+def mis_verify(row_ptr, col_ind, mis_vec):
+    """SimpleVerifyMis: (number of errors, set size); 0 errors is the reference's CORRECT."""
+    rp, ci, mv = _i32(row_ptr), _i32(col_ind), _i32(mis_vec)
+    size = ctypes.c_int(0)
+    err = lib().oracle_mis_verify(rp.size - 1, _p(rp, ctypes.c_int), _p(ci, ctypes.c_int), _p(mv, ctypes.c_int),
+                                  ctypes.byref(size))
+    return err, size.value
+
+
+def gc(row_ptr, col_ind, order, max_colors=10000):
+    rp, ci, od = _i32(row_ptr), _i32(col_ind), _i32(order)
+    out = np.zeros(rp.size - 1, dtype=np.int32)
+    ms = lib().oracle_gc(rp.size - 1, _p(rp, ctypes.c_int), _p(ci, ctypes.c_int), _p(od, ctypes.c_int),
+                         int(max_colors), _p(out, ctypes.c_int))
+    return out, ms
+
+
+def gc_verify(row_ptr, col_ind, color):
+    """SimpleVerifyGc: (conflicting stored edges, colours used, uncoloured vertices)."""
+    rp, ci, cv = _i32(row_ptr), _i32(col_ind), _i32(color)
+    mx, un = ctypes.c_int(0), ctypes.c_int(0)
+    err = lib().oracle_gc_verify(rp.size - 1, _p(rp, ctypes.c_int), _p(ci, ctypes.c_int), _p(cv, ctypes.c_int),
+                                 ctypes.byref(mx), ctypes.byref(un))
+    return err, mx.value, un.value
+
+
+def lgc(row_ptr, col_ind, src, alpha, eps, max_niter):
+    rp, ci = _i32(row_ptr), _i32(col_ind)
+    out = np.zeros(rp.size - 1, dtype=np.float32)
+    ms = lib().oracle_lgc(rp.size - 1, _p(rp, ctypes.c_int), _p(ci, ctypes.c_int), _p(out, ctypes.c_float),
+                          int(src), ctypes.c_double(alpha), ctypes.c_double(eps), int(max_niter))
+    return out, ms
 
 
 def bfs_do_stats(csr_ptr, csr_ind, csc_ptr, csc_ind, src, mxvmode=10, switchpoint=0.01,

@@ -469,3 +469,134 @@ def test_full_size_rmat22_sssp_cc_properties(hb):
     assert torch.all(lab <= torch.arange(n, device=dev))               # FastSV: the smallest id of the component
     reached = torch.from_numpy(hb.dense_values(v)).to(dev) < FLT_MAX
     assert torch.all(lab[reached] == lab[src])                         # the SSSP tree lies in one component
+
+
+# ---- MIS / graph colouring / LGC / diameter --------------------------------
+def _oracle_matrix(ptr, ind, n, dtype):
+    from oracle import ops
+    A = ops.Matrix(n, n, dtype)
+    A.build_csr(ptr, ind, np.ones(ind.size, dtype=dtype))
+    return A
+
+
+def _oracle_desc(**kw):
+    from oracle import ops
+    d = ops.Descriptor()
+    d.loadArgs(**kw)
+    return d
+
+
+def test_mis_and_graph_colouring(hb, graphs):
+    """grb_mis / grb_gc (JP, MIS, IS) == the reference's loops restated over the oracle ops
+    (bit-exact, same weight vector), and pass SimpleVerifyMis / SimpleVerifyGc; the mode the
+    caller sets does not change the result; grb_graph_color gives a proper 0-based colouring."""
+    from oracle import algorithms as alg, simple_reference as sr
+    g = hb.g
+    for name, gr in graphs:
+        if gr["csr"] is not gr["csc"] or gr["n"] > 6000:
+            continue                                   # undirected graphs; oracle loops are numpy-slow
+        ptr, ind = gr["csr"]
+        n = gr["n"]
+        A = g.Matrix(n, n, np.int32)
+        assert A.build_csr(ptr, ind, np.ones(ind.size, dtype=np.int32)) == 0
+        OA = _oracle_matrix(ptr, ind, n, np.int32)
+        w = (np.random.RandomState(7).permutation(n) + 1).astype(np.int32)
+        wv = g.Vector(n, np.int32)
+        assert wv.build(w, n) == 0
+        want, rounds = alg.mis(OA, w, _oracle_desc(mxvmode=2))
+        for mode in (0, 1, 2):
+            d = hb.descriptor(mxvmode=mode)
+            v = g.Vector(n, np.int32)
+            info, res = g.mis(v, A, 0, d, weights=wv)
+            assert info == 0
+            got = v.extractTuples()[1]
+            assert np.array_equal(got, want), (name, mode)
+            assert res["iterations"] == rounds
+            assert sr.mis_verify(ptr, ind, got)[0] == 0
+            assert d.get(g.GrB_MXVMODE) == (10, 11, 12)[mode]             # restored
+        for algo, fn in ((2, alg.gc_is), (1, alg.gc_mis), (0, None)):
+            d = hb.descriptor(mxvmode=0)
+            v = g.Vector(n, np.int32)
+            info, res = g.gc(v, A, 0, 256, algo, d, weights=wv)
+            assert info == 0
+            got = v.extractTuples()[1]
+            if fn is not None:
+                c, it = fn(OA, w, _oracle_desc(mxvmode=2))
+            else:
+                c, it = alg.gc_jp(OA, w, 256, _oracle_desc(mxvmode=2))
+            assert np.array_equal(got, c), (name, algo)
+            assert res["iterations"] == it
+            assert sr.gc_verify(ptr, ind, got)[::2] == (0, 0)
+        # seed path: weights drawn on the host as the reference does; property check only
+        v = g.Vector(n, np.int32)
+        assert g.mis(v, A, 5, hb.descriptor(mxvmode=0))[0] == 0
+        assert sr.mis_verify(ptr, ind, v.extractTuples()[1])[0] == 0
+        info, ncol = g.graph_color(v, A, hb.descriptor())
+        assert info == 0
+        col = v.extractTuples()[1]
+        assert col.min() == 0 and col.max() == ncol - 1
+        assert sr.gc_verify(ptr, ind, col + 1)[::2] == (0, 0)
+
+
+def test_scatter_op(hb):
+    """scatter (extension): w[u[k]] = val for 0 < u[k] < size(w); dense and sparse u; masked = no-op."""
+    from oracle import ops
+    g = hb.g
+    for wdt, udt in ((np.int32, np.int32), (np.float32, np.int32), (np.int32, np.float32)):
+        u_host = np.array([0, 3, 3, 9, 1, 0, 7, 12, -2, 5], dtype=udt)
+        for sparse in (False, True):
+            w, u = g.Vector(10, wdt), g.Vector(10, udt)
+            ow, ou = ops.Vector(10, wdt), ops.Vector(10, udt)
+            w.fill(0)
+            ow.fill(0)
+            if sparse:
+                idx = np.array([1, 4, 6], dtype=np.int32)
+                assert u.build(idx, u_host[:3], 3, None) == 0
+                ou.build_sparse(idx, u_host[:3])
+            else:
+                assert u.build(u_host, 10) == 0
+                ou.build_dense(u_host)
+            d = hb.descriptor()
+            assert g.scatter(w, None, u, 42, d) == 0
+            ops.scatter(ow, None, ou, 42, None)
+            assert np.array_equal(w.extractTuples()[1], ow.extractTuples_dense()), (wdt, udt, sparse)
+            assert g.scatter(w, u, u, 7, d) == 0                       # masked: nothing happens
+            assert np.array_equal(w.extractTuples()[1], ow.extractTuples_dense())
+
+
+def test_lgc_and_diameter(hb, graphs):
+    """grb_lgc == SimpleReferenceLgc (the check of example/glgc.cu) and == the reference's loop
+    over the oracle ops in its dense mode, whatever mode the caller sets (rtol: float sums in
+    another order); grb_diameter == SimpleReferenceBfs's depth."""
+    import math
+    from oracle import algorithms as alg, simple_reference as sr
+    g = hb.g
+    for name, gr in graphs:
+        if gr["csr"] is not gr["csc"] or gr["n"] > 6000:
+            continue
+        ptr, ind = gr["csr"]
+        n = gr["n"]
+        A = build(hb, gr)
+        OA = _oracle_matrix(ptr, ind, n, F)
+        src = first_source(gr)
+        alpha = float(F(0.25 / (225.0 * math.log(100.0 * math.sqrt(ind.size)))))
+        eps = float(F(1e-7))
+        for max_niter in (5, 25):
+            want, trace = alg.lgc(OA, src, alpha, eps, _oracle_desc(mxvmode=2, max_niter=max_niter))
+            ref, _ = sr.lgc(ptr, ind, src, alpha, eps, max_niter)
+            for mode in (0, 1, 2):
+                d = hb.descriptor(mxvmode=mode, max_niter=max_niter)
+                p = g.Vector(n)
+                info, res = g.lgc(p, A, src, alpha, eps, d)
+                assert info == 0
+                got = p.extractTuples()[1]
+                np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-10, err_msg="%s mode %d" % (name, mode))
+                np.testing.assert_allclose(got, ref, rtol=2e-5, atol=1e-9)
+                assert res["iterations"] == len(trace) and res["succ"] == trace[-1]
+                assert d.get(g.GrB_MXVMODE) == (10, 11, 12)[mode]
+        depth, _, _ = sr.bfs(ptr, ind, src)
+        for mode in (0, 2):
+            v = g.Vector(n)
+            info, dmax, dind = g.diameter(v, A, src, src + 1, hb.descriptor(mxvmode=mode))
+            assert (info, dmax, dind) == (0, int(depth.max()) - 1, src), (name, mode)
+            assert np.array_equal(v.extractTuples()[1], depth)

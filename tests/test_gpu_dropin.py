@@ -62,3 +62,55 @@ def test_reference_gtc_main(graph):
     assert "CORRECT" in out, out[-1500:]
     if graph == "chesapeake.mtx":
         assert "194" in out
+
+
+# ---- the other five mains of example/ (SURVEY.md 8(f)4).  --mxvmode 2: the mode in which the
+# reference's mis / gc loops terminate (tests/test_oracle.py records why the others do not).
+SYM = ["chesapeake.mtx", "test_mesh.mtx", "small.mtx", "test_bc.mtx", "test_mis.mtx"]
+
+
+@pytest.mark.parametrize("graph", SYM)
+def test_reference_gmis_main(graph):
+    out = _run("gmis_ref", "--mxvmode", "2", "--niter", "1", "--timing", "0", "--directed", "2", "--source", "3",
+               os.path.join(DATA, graph))
+    assert "INCORRECT" not in out and "errors occurred" not in out, out[-1500:]
+    assert out.count("CORRECT") >= 3, out[-1500:]              # CPU result, warm-up result, timed result
+
+
+@pytest.mark.parametrize("graph", SYM)
+@pytest.mark.parametrize("algo", ["0", "1", "2"])
+def test_reference_ggc_main(graph, algo):
+    out = _run("ggc_ref", "--mxvmode", "2", "--niter", "1", "--timing", "0", "--directed", "2", "--gcalgo", algo,
+               "--maxcolors", "128", "--seed", "1", os.path.join(DATA, graph))
+    assert "INCORRECT" not in out and "errors occurred" not in out, out[-1500:]
+    assert out.count("CORRECT") >= 3, out[-1500:]
+
+
+@pytest.mark.parametrize("graph", SYM)
+def test_reference_ggc_cusparse_main(graph):
+    out = _run("ggc_cusparse_ref", "--niter", "1", "--timing", "0", "--directed", "2", os.path.join(DATA, graph))
+    assert "INCORRECT" not in out and "errors occurred" not in out, out[-1500:]
+    assert out.count("CORRECT") >= 3, out[-1500:]
+
+
+@pytest.mark.parametrize("graph", ["chesapeake.mtx", "test_mesh.mtx", "small.mtx"])
+@pytest.mark.parametrize("max_niter", ["5", "30"])
+def test_reference_glgc_main(graph, max_niter):
+    """VERIFY_LIST_FLOAT against the reference's own SimpleReferenceLgc (example/glgc.cu:98-101)."""
+    out = _run("glgc_ref", "--mxvmode", "2", "--niter", "1", "--max_niter", max_niter, "--timing", "0",
+               "--directed", "2", os.path.join(DATA, graph))
+    assert "INCORRECT" not in out, out[-1500:]
+    assert out.count("CORRECT") >= 2, out[-1500:]
+
+
+@pytest.mark.parametrize("graph,want", [("chesapeake.mtx", None), ("test_mesh.mtx", None)])
+@pytest.mark.parametrize("mode", ["0", "2"])
+def test_reference_gdiameter_main(graph, want, mode):
+    import numpy as np
+    from oracle import loader, simple_reference as sr
+    r, c, v, nr, nc, nv = loader.read_mtx(os.path.join(DATA, graph), 2, np.float32)
+    ptr, ind, _ = loader.coo2csr(r, c, v, nr, nc)
+    out = _run("gdiameter_ref", "--mxvmode", mode, "--directed", "2", "--source_start", "0", "--source_end", "1",
+               os.path.join(DATA, graph))
+    depth, _, _ = sr.bfs(ptr, ind, 0)
+    assert "diameter 0:1: %d from 0" % (int(depth.max()) - 1) in out, out[-800:]

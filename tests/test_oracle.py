@@ -234,3 +234,134 @@ def test_tc_driver_on_oracle():
     L = ops.tril(A)
     d = ops.Descriptor(); d.loadArgs()
     assert algorithms.tc(L, d) == sr.tc(L.csrRowPtr, L.csrColInd)[0]
+
+
+# ---- MIS / graph colouring / LGC / diameter on the oracle -----------------
+def _sym_graph(be, name, dtype):
+    A = be.matrix_from_mtx(name, directed=2, dtype=dtype)      # --directed 2: symmetrise (run.sh:7-9)
+    A.csrVal[:] = 1
+    A.cscVal[:] = 1
+    return A
+
+
+def test_simple_reference_mis_gc_known_answers():
+    """SimpleReferenceMis / SimpleReferenceGc and their verifiers on hand-checkable inputs."""
+    from oracle import simple_reference as sr
+    # path 0-1-2-3-4
+    ptr = np.array([0, 1, 3, 5, 7, 8])
+    ind = np.array([1, 0, 2, 1, 3, 2, 4, 3])
+    m, _ = sr.mis(ptr, ind, [0, 1, 2, 3, 4])
+    assert m.tolist() == [1, 0, 1, 0, 1] and sr.mis_verify(ptr, ind, m) == (0, 3)
+    m, _ = sr.mis(ptr, ind, [1, 3, 0, 2, 4])
+    assert m.tolist() == [0, 1, 0, 1, 0] and sr.mis_verify(ptr, ind, m) == (0, 2)
+    assert sr.mis_verify(ptr, ind, [1, 1, 0, 0, 1])[0] == 2          # edge 0-1 is stored (and counted) twice
+    assert sr.mis_verify(ptr, ind, [1, 0, 0, 0, 1])[0] == 1          # vertex 2 uncovered
+    c, _ = sr.gc(ptr, ind, [0, 1, 2, 3, 4], 10)
+    assert c.tolist() == [1, 2, 1, 2, 1] and sr.gc_verify(ptr, ind, c) == (0, 2, 0)
+    assert sr.gc_verify(ptr, ind, [1, 1, 2, 1, 2])[0] == 2           # edge 0-1 stored twice
+    assert sr.gc_verify(ptr, ind, [1, 2, 0, 2, 1]) == (0, 2, 1)      # an uncoloured vertex is reported separately
+    # triangle + pendant: 3 colours needed
+    ptr = np.array([0, 2, 4, 7, 8])
+    ind = np.array([1, 2, 0, 2, 0, 1, 3, 2])
+    c, _ = sr.gc(ptr, ind, [0, 1, 2, 3], 10)
+    assert c.tolist() == [1, 2, 3, 1] and sr.gc_verify(ptr, ind, c) == (0, 3, 0)
+
+
+@pytest.mark.parametrize("graph", ["chesapeake.mtx", "test_mesh.mtx", "small.mtx", "test_bc.mtx", "test_mis.mtx"])
+def test_mis_and_gc_drivers_on_oracle(be, graph):
+    """algorithm::mis / gcIS / gcMIS / gcJP restated over the oracle ops, in the mode where the
+    reference's loop is well defined (mxvmode 2, every vector dense): the result passes the
+    reference's own SimpleVerifyMis / SimpleVerifyGc and equals the direct definition of the
+    algorithm (Luby rounds / one colour per round) computed without GraphBLAS."""
+    from oracle import algorithms as alg, simple_reference as sr
+    A = _sym_graph(be, graph, np.int32)
+    n = A.nrows_
+    ptr, ind, _ = be.host_csr(A)
+    rows = np.repeat(np.arange(n), np.diff(ptr))
+    for seed in (0, 1, 2):
+        w = np.random.RandomState(seed).permutation(n).astype(np.int32) + 1        # distinct weights
+        v, rounds = alg.mis(A, w, be.descriptor(mxvmode=2))
+        assert sr.mis_verify(ptr, ind, v)[0] == 0
+        # Luby by definition: repeatedly take local maxima among candidates, drop their neighbours
+        cand, want = w.copy(), np.zeros(n, dtype=np.int32)
+        while True:
+            nbmax = np.zeros(n, dtype=np.int64)
+            np.maximum.at(nbmax, rows, cand[ind])
+            f = (cand > nbmax) & (cand != 0)
+            if not f.any():
+                break
+            want[f] = 1
+            cand[f] = 0
+            hit = np.zeros(n, dtype=bool)
+            np.logical_or.at(hit, rows, f[ind])
+            cand[hit] = 0
+        assert np.array_equal(v, want)
+        for fn in (alg.gc_is, alg.gc_mis):
+            c, it = fn(A, w, be.descriptor(mxvmode=2))
+            err, ncol, unc = sr.gc_verify(ptr, ind, c)
+            assert (err, unc) == (0, 0) and ncol == it - 1
+        c, it = alg.gc_jp(A, w, 64, be.descriptor(mxvmode=2))
+        assert sr.gc_verify(ptr, ind, c)[::2] == (0, 0)
+
+
+def test_mis_push_pull_mode_does_not_terminate_as_written(be):
+    """Recorded behaviour, not a wish: with --mxvmode 0 the weight vector (mask AND input of the
+    same vxm) is converted to sparse storage once no candidate is left, the product and the
+    eWiseAdd that follow are "not implemented" no-ops, the frontier stays stale and the loop of
+    algorithm/mis.hpp:47-96 never sees succ == 0.  The restatement raises instead of spinning."""
+    from oracle import algorithms as alg
+    A = _sym_graph(be, "test_bc.mtx", np.int32)
+    w = np.arange(1, A.nrows_ + 1, dtype=np.int32)
+    with pytest.raises(RuntimeError):
+        alg.mis(A, w, be.descriptor(mxvmode=0))
+
+
+@pytest.mark.parametrize("graph", ["chesapeake.mtx", "test_mesh.mtx", "small.mtx"])
+@pytest.mark.parametrize("mode", [0, 2])
+def test_lgc_driver_on_oracle(be, graph, mode):
+    """algorithm::lgc over the oracle ops == SimpleReferenceLgc (the comparison example/glgc.cu
+    makes with VERIFY_LIST_FLOAT), alpha / eps / max_niter as there and in run.sh:5."""
+    import math
+    from oracle import algorithms as alg, simple_reference as sr
+    A = _sym_graph(be, graph, np.float32)
+    if mode == 0 and A.nrows_ > 100:
+        # 1/n <= switchpoint: the one-element frontier goes sparse, mxv takes the push path, and the
+        # push path has no accum (spmspv.hpp:28-33 "TODO add accum"): r = A r2 instead of r + A r2.
+        # The restated driver then differs from SimpleReferenceLgc by design of the reference.
+        pytest.skip("push path drops accum; covered by test_lgc_push_path_drops_accum")
+    ptr, ind, _ = be.host_csr(A)
+    alpha = float(np.float32(0.25 / (225.0 * math.log(100.0 * math.sqrt(A.nvals_)))))
+    eps = float(np.float32(1e-7))
+    for src in (0, 3):
+        for max_niter in (5, 40):
+            want, _ = sr.lgc(ptr, ind, src, alpha, eps, max_niter)
+            got, trace = alg.lgc(A, src, alpha, eps, be.descriptor(mxvmode=mode, max_niter=max_niter))
+            assert len(trace) == max_niter
+            np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-9)
+
+
+def test_lgc_push_path_drops_accum(be):
+    """Recorded behaviour: on a graph large enough for the frontier to turn sparse, the reference's
+    lgc in --mxvmode 0/1 loses the kept half of the residual (no accum in SpMSpV), so its result
+    is below SimpleReferenceLgc's at the source."""
+    import math
+    from oracle import algorithms as alg, simple_reference as sr
+    A = _sym_graph(be, "small.mtx", np.float32)
+    ptr, ind, _ = be.host_csr(A)
+    alpha = float(np.float32(0.25 / (225.0 * math.log(100.0 * math.sqrt(A.nvals_)))))
+    want, _ = sr.lgc(ptr, ind, 0, alpha, 1e-7, 5)
+    got, _ = alg.lgc(A, 0, alpha, 1e-7, be.descriptor(mxvmode=0, max_niter=5))
+    assert got[0] < 0.75 * want[0]
+
+
+def test_diameter_driver_on_oracle(be):
+    """algorithm::diameter: eccentricity of a source == SimpleReferenceBfs's search depth."""
+    from oracle import algorithms as alg, simple_reference as sr
+    for graph in ("chesapeake.mtx", "test_mesh.mtx"):
+        A = _sym_graph(be, graph, np.float32)
+        ptr, ind, _ = be.host_csr(A)
+        for src in (0, 5):
+            depth, sd, _ = sr.bfs(ptr, ind, src)
+            for mode in (0, 1, 2):
+                dmax, dind = alg.diameter(A, src, src + 1, be.descriptor(mxvmode=mode))
+                assert (dmax, dind) == (int(depth.max()) - 1, src), (graph, src, mode)
