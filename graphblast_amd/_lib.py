@@ -116,6 +116,8 @@ _SIGS = {
     "grb_pr": [_vp, _vp, _f, _f, _vp, C.POINTER(AlgoResult)],
     "grb_k_spmv": [_vp, _i, _i, _vp, _vp, _i, _i, _vp],
     "grb_scatter": [_vp, _vp, _vp, _d, _vp],
+    "grb_vector_resize": [_vp, _i],
+    "grb_trace_mxm_transpose": [C.POINTER(_d), _i, _vp, _vp, _vp],
     "grb_graph_color": [_vp, _vp, _vp, C.POINTER(_i)],
     "grb_mis": [_vp, _vp, _i, _vp, _vp, C.POINTER(AlgoResult)],
     "grb_gc": [_vp, _vp, _i, _vp, _i, _i, _vp, C.POINTER(AlgoResult)],

@@ -173,6 +173,9 @@ class Vector:
             return lib.grb_vector_adopt_dense(self._h, d_values_ptr, int(nvals))
         return lib.grb_vector_adopt_sparse(self._h, d_indices_ptr, d_values_ptr, int(nvals))
 
+    def resize(self, nsize):
+        return _lib.load().grb_vector_resize(self._h, int(nsize))
+
     def setElement(self, val, index):
         return _lib.load().grb_vector_set_element(self._h, float(val), int(index))
 
@@ -426,6 +429,12 @@ def tc(A, B, desc):
     n = C.c_int64(0)
     info = _lib.load().grb_tc(C.byref(n), _h(A), _h(B), _h(desc), C.byref(res))
     return info, n.value, dict(tight_ms=res.tight_ms)
+
+
+def traceMxmTranspose(op, A, B, desc):
+    out = C.c_double(0)
+    info = _lib.load().grb_trace_mxm_transpose(C.byref(out), _semiring_id(op), _h(A), _h(B), _h(desc))
+    return info, out.value
 
 
 def scatter(w, mask, u, val, desc):

@@ -135,6 +135,36 @@ __global__ __launch_bounds__(kBlock) void matrix_scale_kernel(const Index* __res
   }
 }
 
+// trace(A (+).(x) B^T) = sum over rows i of (+)_k A(i,k) (x) B(i,k)   (traceKernel, kernels/trace.hpp:7-67).
+// One wave per row: lanes stride over A's row and binary-search B's; as there, a missing B entry
+// contributes mul(a, identity), B's value passes through an Index-typed temporary (truncated towards
+// zero, trace.hpp:44-46), rows are folded with the semiring's add and the row sums are then ADDED
+// (atomicAdd whatever the semiring, trace.hpp:60-61).
+template <int SR, typename T>
+__global__ __launch_bounds__(kBlock) void trace_kernel(T* __restrict__ out, Index nrows, const Index* __restrict__ a_ptr,
+                                                       const Index* __restrict__ a_ind, const T* __restrict__ a_val,
+                                                       const Index* __restrict__ b_ptr, const Index* __restrict__ b_ind,
+                                                       const T* __restrict__ b_val) {
+  using S = Semiring<SR, T>;
+  const int lane = threadIdx.x & (kWave - 1);
+  const Index wave = (Index)((blockIdx.x * (unsigned)blockDim.x + threadIdx.x) / kWave);
+  const Index nwaves = (Index)((gridDim.x * (unsigned)blockDim.x) / kWave);
+  T total = 0;
+  for (Index row = wave; row < nrows; row += nwaves) {
+    const Index ab = a_ptr[row], ae = a_ptr[row + 1], bb = b_ptr[row], be = b_ptr[row + 1];
+    T sum = S::identity();
+    for (Index p = ab + lane; p < ae; p += kWave) {
+      const Index lo = lower_bound_dev(b_ind, bb, be, a_ind[p]);
+      Index bv = (Index)S::identity();
+      if (lo < be && b_ind[lo] == a_ind[p]) bv = (Index)b_val[lo];
+      sum = S::add(sum, S::mul(a_val[p], (T)bv));
+    }
+    sum = wave_reduce(sum, [](T x, T y) { return S::add(x, y); });
+    total += sum;
+  }
+  if (lane == 0 && total != 0) atomicAdd(out, total);
+}
+
 }  // namespace grb
 
 using namespace grb;
@@ -275,6 +305,36 @@ grb_info grb_matrix_tril(grb_matrix C, grb_matrix A, grb_descriptor desc) {
   static const uint32_t kZeroV = 0;
   return grb_matrix_build_csr(C, nptr.data(), nind.empty() ? &kZero : nind.data(), nval.empty() ? &kZeroV : nval.data(),
                               (Index)nind.size(), nullptr, nullptr, nullptr);
+}
+
+// traceMxmTranspose (extension, operations.hpp:698-711 -> backend :1076-1108, trace.hpp:10-52)
+grb_info grb_trace_mxm_transpose(double* val, grb_semiring op, grb_matrix A, grb_matrix B, grb_descriptor desc) {
+  if (!val || !A || !B) return GRB_UNINITIALIZED_OBJECT;
+  (void)desc;
+  if (!A->built || !B->built) return GRB_UNINITIALIZED_OBJECT;
+  if (A->dtype != B->dtype) return GRB_DOMAIN_MISMATCH;
+  if (A->nrows != B->nrows) return GRB_DIMENSION_MISMATCH;
+  Context& c = ctx();
+  void* d_out;
+  GRB_TRY(scratch(4, 256, &d_out));
+  GRB_HIP_TRY(hipMemsetAsync(d_out, 0, 8, c.stream));
+  const Index n = A->nrows;
+  if (n > 0) {
+    const int grid = stream_grid((long long)n * kWave, kBlock);
+    GRB_TRY(dispatch_semiring(op, A->dtype, [&](auto tag, auto t) -> grb_info {
+      using T = decltype(t);
+      constexpr int SR = decltype(tag)::value;
+      hipLaunchKernelGGL((trace_kernel<SR, T>), dim3(grid), dim3(kBlock), 0, c.stream, (T*)d_out, n, A->csr.ptr,
+                         A->csr.ind, (const T*)A->csr.val, B->csr.ptr, B->csr.ind, (const T*)B->csr.val);
+      GRB_HIP_TRY(hipGetLastError());
+      return GRB_SUCCESS;
+    }));
+  }
+  int bits = 0;
+  GRB_TRY(fetch_ints((const int*)d_out, 1, &bits));
+  if (A->dtype == GRB_F32) { float f; memcpy(&f, &bits, 4); *val = (double)f; }
+  else *val = (double)bits;
+  return GRB_SUCCESS;
 }
 
 // algorithm::tc (algorithm/tc.hpp:15-54): B = (A x A^T) .* A on the lower triangle, ntris = sum(B)

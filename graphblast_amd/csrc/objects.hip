@@ -387,6 +387,43 @@ grb_info grb_vector_new(grb_vector* out, grb_dtype dtype, grb_index nsize) {
   return GRB_SUCCESS;
 }
 
+// Vector::resize (vector.hpp:230-237 -> dense_vector.hpp:286-309 / sparse_vector.hpp:242-277): the
+// active representation is reallocated for `nsize` elements keeping its first min(nsize, nvals)
+// entries (new dense elements are zero here; the reference leaves them uninitialised).  Both
+// representations follow the new size.
+grb_info grb_vector_resize(grb_vector v, grb_index nsize) {
+  if (!v) return GRB_UNINITIALIZED_OBJECT;
+  if (nsize < 0) return GRB_INVALID_VALUE;
+  if (v->vec_type != GRB_SPARSE && v->vec_type != GRB_DENSE) return GRB_UNINITIALIZED_OBJECT;
+  Context& c = ctx();
+  const Index old = v->nsize;
+  if (nsize == old) return GRB_SUCCESS;
+  grb_vector_s t;                                     // new storage, built on a scratch descriptor
+  t.dtype = v->dtype;
+  t.nsize = nsize;
+  GRB_TRY(vec_alloc_sparse(&t));
+  GRB_TRY(vec_alloc_dense(&t));
+  if (nsize > 0) GRB_HIP_TRY(hipMemsetAsync(t.d_val, 0, 4 * (size_t)nsize, c.stream));
+  if (v->vec_type == GRB_DENSE) {
+    const Index keep = nsize < old ? nsize : old;
+    if (keep > 0 && v->d_val) GRB_TRY(k_copy(t.d_val, v->d_val, 4 * (size_t)keep));
+  } else {
+    const Index keep = nsize < v->s_nvals ? nsize : v->s_nvals;
+    if (keep > 0) {
+      GRB_TRY(k_copy(t.s_ind, v->s_ind, sizeof(Index) * (size_t)keep));
+      GRB_TRY(k_copy(t.s_val, v->s_val, 4 * (size_t)keep));
+    }
+    v->s_nvals = keep;
+  }
+  GRB_HIP_TRY(hipStreamSynchronize(c.stream));        // the old blocks go back to the pool
+  vec_release_sparse(v);
+  vec_release_dense(v);
+  v->s_ind = t.s_ind; v->s_val = t.s_val; v->s_owned = t.s_owned; v->s_alloc_n = t.s_alloc_n;
+  v->d_val = t.d_val; v->d_owned = t.d_owned; v->d_alloc_n = t.d_alloc_n;
+  v->nsize = nsize;
+  return GRB_SUCCESS;
+}
+
 grb_info grb_vector_free(grb_vector v) {
   if (!v) return GRB_SUCCESS;
   vec_release_sparse(v);

@@ -108,6 +108,8 @@ grb_info grb_vector_free(grb_vector v);
 grb_info grb_vector_dup(grb_vector dst, grb_vector src);                     /* dup / operator=    */
 grb_info grb_vector_clear(grb_vector v);
 grb_info grb_vector_size(grb_vector v, grb_index* nsize);
+/* Vector::resize (vector.hpp:230-237): keeps the first min(nsize, nvals) stored entries. */
+grb_info grb_vector_resize(grb_vector v, grb_index nsize);
 grb_info grb_vector_nvals(grb_vector v, grb_index* nvals);
 /* build(indices, values, nvals, dup) -> sparse; host arrays; values are dtype-typed. */
 grb_info grb_vector_build_sparse(grb_vector v, const grb_index* indices, const void* values,
@@ -219,6 +221,9 @@ grb_info grb_matrix_eWiseMult_vector(grb_matrix C, grb_semiring op, grb_matrix A
                                      grb_descriptor desc);
 /* reduce (matrix -> scalar)   operations.hpp:662-680 -> backend :1032-1059 (reduce.hpp:81-91) */
 grb_info grb_reduce_matrix_scalar(double* val, grb_accum accum, grb_monoid op, grb_matrix A, grb_descriptor desc);
+/* traceMxmTranspose (extension)   operations.hpp:698-711 -> backend :1076-1108 (trace.hpp:10-52):
+ * *val = sum_i (+)_k A(i,k) (x) B(i,k), the trace of A (+).(x) B^T; A and B of one element type. */
+grb_info grb_trace_mxm_transpose(double* val, grb_semiring op, grb_matrix A, grb_matrix B, grb_descriptor desc);
 /* tril   operations.hpp:872-886 -> tri.hpp:10-53 (host side, as in the reference) */
 grb_info grb_matrix_tril(grb_matrix C, grb_matrix A, grb_descriptor desc);
 
