@@ -770,3 +770,24 @@ def reduce_matrix(monoid, A_vals, nvals, desc):
     if nvals == 0:
         return monoid.identity()
     return monoid.reduce(A_vals)
+
+
+def trace_mxm_transpose(sr, A, B):
+    """traceMxmTranspose (operations.hpp:698-711 -> backend/cuda/trace.hpp:10-52,
+    kernels/trace.hpp:7-67): sum over rows i of (+)_k mul(A(i,k), B(i,k)); an A entry without a
+    partner in B contributes mul(a, identity); B's value goes through an Index-typed temporary
+    (truncation towards zero, kernels/trace.hpp:44-46); rows are folded with the semiring's add and
+    the row results are then summed with + whatever the semiring (atomicAdd, :60-61)."""
+    total = sr.dtype(0)
+    ident = sr.identity()
+    for i in range(A.nrows_):
+        a0, a1 = A.csrRowPtr[i], A.csrRowPtr[i + 1]
+        b0, b1 = B.csrRowPtr[i], B.csrRowPtr[i + 1]
+        bcols = B.csrColInd[b0:b1]
+        acc = ident
+        for p in range(a0, a1):
+            k = _binsearch(bcols, b1 - b0, A.csrColInd[p])
+            bv = np.int32(ident) if k == -1 else np.int32(B.csrVal[b0 + k])
+            acc = sr.add_op(acc, sr.mul_op(A.csrVal[p], sr.dtype(bv)))[()]
+        total = sr.dtype(total + acc)
+    return total

@@ -478,3 +478,59 @@ def test_matrix_ewisemult_scalar_and_vector():
     assert lib.grb_matrix_eWiseMult_vector(A._h, _semiring_id("PlusDivides"), A._h, Bc._h, d._h) == 0
     want = want / bc[c]
     assert np.array_equal(A.host_csr()[2], want) and np.array_equal(A.host_csc()[2], want[order])
+
+
+def test_vector_resize(hb):
+    """Vector::resize (vector.hpp:230-237): the active representation keeps its first
+    min(nsize, nvals) entries, size() follows (test/gdensevector.cu:168-186, gsparsevector.cu:188-210)."""
+    g = hb.g
+    for new in (15, 6, 10):
+        v = g.Vector(10, np.int32)
+        vals = np.arange(1, 11, dtype=np.int32)
+        assert v.build(vals, 10) == 0
+        assert v.resize(new) == 0
+        assert v.size() == new and v.nvals() == new
+        got = v.extractTuples()[1]
+        k = min(new, 10)
+        assert np.array_equal(got[:k], vals[:k]) and not got[k:].any()
+        s = g.Vector(12, np.int32)
+        idx = np.array([1, 2, 3, 4, 5, 6, 7, 8, 0, 2], dtype=np.int32)
+        assert s.build(idx, idx, 10, None) == 0
+        assert s.resize(new) == 0
+        assert s.size() == new and s.nvals() == min(new, 10)
+        info, gi, gv = s.extractTuples(sparse=True)
+        assert info == 0 and np.array_equal(gi, idx[:min(new, 10)]) and np.array_equal(gv, idx[:min(new, 10)])
+    u = g.Vector(4)
+    assert u.resize(8) == 1                                   # GrB_UNINITIALIZED_OBJECT: no storage yet
+
+
+def test_trace_mxm_transpose(hb):
+    """traceMxmTranspose against the restated kernel (oracle/ops.py), including the Index-typed
+    temporary B's value passes through; test/gtrace.cu's two literal cases (trace 91)."""
+    from oracle import ops
+    from oracle.semiring import Semiring
+    g = hb.g
+    d = hb.descriptor()
+    for rows, cols in (([0, 1, 2, 3, 4, 5, 6, 7], [0, 1, 2, 3, 4, 5, 6, 6]),
+                       ([0, 0, 2, 3, 4, 5, 6, 7], [0, 6, 2, 3, 4, 5, 6, 6])):
+        A = g.Matrix(8, 8)
+        assert A.build(rows, cols, np.array([0, 1, 2, 3, 4, 5, 6, 0], dtype=np.float32), 8, None) == 0
+        assert g.traceMxmTranspose("PlusMultiplies", A, A, d) == (0, 91.0)
+    rng = np.random.default_rng(5)
+    n = 300
+    for dt in (np.float32, np.int32):
+        mats = []
+        for _ in range(2):
+            r, c = rng.integers(0, n, 4000), rng.integers(0, n, 4000)
+            key = np.unique(r * n + c)
+            r, c = (key // n).astype(np.int32), (key % n).astype(np.int32)
+            v = (rng.integers(-6, 7, r.size) * (0.5 if dt == np.float32 else 1)).astype(dt)
+            A = g.Matrix(n, n, dt)
+            assert A.build(r, c, v, r.size, None) == 0
+            OA = ops.Matrix(n, n, dt)
+            OA.build(r, c, v)
+            mats.append((A, OA))
+        for srn in ("PlusMultiplies", "MaximumMultiplies", "PlusMinus"):        # identities an Index can hold
+            info, got = g.traceMxmTranspose(srn, mats[0][0], mats[1][0], d)
+            want = ops.trace_mxm_transpose(Semiring(srn, dt), mats[0][1], mats[1][1])
+            assert info == 0 and got == float(want), (dt, srn, got, want)
