@@ -33,7 +33,9 @@ static grb_info spmv_dispatch(grb_vector w, grb_vector mask, grb_accum accum, in
     if (mask->vec_type == GRB_SPARSE) return GRB_SUCCESS;   // "not implemented": prints, no-op
     return GRB_UNINITIALIZED_OBJECT;
   }
-  if (use_mask && mask->vec_type != GRB_DENSE) return GRB_INVALID_OBJECT;
+  // the generic branch reads mask->dense_.d_val_ without looking at the mask's storage
+  // (spmv.hpp:203-212): a sparse or cleared mask acts through whatever its dense buffer last held
+  if (use_mask && !mask->d_val) return GRB_INVALID_OBJECT;
   w->d_nnz = u->d_nnz;
   return k_spmv(op, w->dtype, M, plan, u->d_val, use_mask ? mask->d_val : nullptr, mask_is_f32(mask), use_scmp,
                 use_accum, w->d_val);
@@ -49,14 +51,19 @@ static grb_info spmspv_dispatch(grb_vector w, grb_vector mask, grb_accum accum, 
   // default is CSC here: the transposed product walks CSR rows (spmspv.hpp:52-55)
   const CsrArrays& M = use_tran ? A->csr : A->csc;
   if (!M.ptr) return GRB_INVALID_OBJECT;
-  if (use_mask && mask->vec_type != GRB_DENSE) {
-    if (mask->vec_type == GRB_SPARSE) return GRB_NOT_IMPLEMENTED;
-    return GRB_UNINITIALIZED_OBJECT;
+  // mask storage (spmspv.hpp:147-164, :199-216): dense -> applied; sparse -> "not implemented" is
+  // printed and the product goes on UNMASKED, still through the masked epilogue (key-value mode
+  // prunes reduced values == 0); anything else -> GrB_UNINITIALIZED_OBJECT
+  int mask_mode = 0;
+  if (use_mask) {
+    if (mask->vec_type == GRB_DENSE) mask_mode = 1;
+    else if (mask->vec_type == GRB_SPARSE) mask_mode = 2;
+    else return GRB_UNINITIALIZED_OBJECT;
   }
   const Index out_size = use_tran ? A->ncols : A->nrows;
   Index nv = 0;
   GRB_TRY(k_spmspv(op, w->dtype, M, out_size, desc->struconly, u->s_ind, u->s_val, u->s_nvals,
-                   use_mask ? mask->d_val : nullptr, mask_is_f32(mask), use_mask ? 1 : 0, desc_scmp ? 1 : 0,
+                   mask_mode == 1 ? mask->d_val : nullptr, mask_is_f32(mask), mask_mode, desc_scmp ? 1 : 0,
                    w->s_ind, w->s_val, &nv));
   w->s_nvals = nv;
   return GRB_SUCCESS;

@@ -108,6 +108,8 @@ __global__ void bitmap_write_kernel(unsigned int* __restrict__ words, int nwords
   }
 }
 
+// use_mask: 0 none, 1 dense mask applied, 2 masked epilogue only (the reference's sparse-mask case:
+// nothing is filtered, key-value mode still prunes zeros)
 grb_info k_spmspv(int sr, int dtype, const CsrArrays& M, Index out_size, int struconly, const Index* u_ind,
                   const void* u_val, Index nf, const void* mask, int mask_f32, int use_mask,
                   int keep_when_mask_zero, Index* w_ind, void* w_val, Index* w_nvals) {
@@ -157,12 +159,12 @@ grb_info k_spmspv(int sr, int dtype, const CsrArrays& M, Index out_size, int str
       }
     }
     if (struconly) {
-      SpmspvVisitor<SR, T, true> vis{(const T*)M.val, (const T*)u_val, mask, mask_f32, use_mask,
+      SpmspvVisitor<SR, T, true> vis{(const T*)M.val, (const T*)u_val, mask, mask_f32, use_mask == 1 ? 1 : 0,
                                      keep_when_mask_zero, (unsigned int*)p_bitmap, acc};
       GRB_TRY(launch_lb_expand(s, M, u_ind, nf, max_edges, local_scan, row_start, tile_sums, tile_off, chunk_owner,
                                d_mail, vis));
     } else {
-      SpmspvVisitor<SR, T, false> vis{(const T*)M.val, (const T*)u_val, mask, mask_f32, use_mask,
+      SpmspvVisitor<SR, T, false> vis{(const T*)M.val, (const T*)u_val, mask, mask_f32, use_mask == 1 ? 1 : 0,
                                       keep_when_mask_zero, (unsigned int*)p_bitmap, acc};
       GRB_TRY(launch_lb_expand(s, M, u_ind, nf, max_edges, local_scan, row_start, tile_sums, tile_off, chunk_owner,
                                d_mail, vis));

@@ -111,6 +111,7 @@ class Vector:
         self.s_nvals = 0
         self.d_val = np.zeros(nsize, dtype=self.dtype)
         self.d_nnz = 0
+        self.nvals_ = 0
 
     # --- container API -----------------------------------------------------
     def build_sparse(self, indices, values):
@@ -155,11 +156,13 @@ class Vector:
         return GrB_SUCCESS
 
     def nvals(self):
+        """Vector::nvals (vector.hpp:133-146): the active representation's count, cached in nvals_;
+        with no storage type the cached value of the last call is returned (0 after clear())."""
         if self.vec_type_ == GrB_SPARSE:
-            return self.s_nvals
-        if self.vec_type_ == GrB_DENSE:
-            return self.nsize_          # DenseVector::nvals == size (dense_vector.hpp:122)
-        return 0
+            self.nvals_ = self.s_nvals
+        elif self.vec_type_ == GrB_DENSE:
+            self.nvals_ = self.nsize_   # DenseVector::nvals == size (dense_vector.hpp:122)
+        return self.nvals_
 
     def size(self):
         return self.nsize_
@@ -184,6 +187,7 @@ class Vector:
 
     def clear(self):
         self.vec_type_ = GrB_UNKNOWN
+        self.nvals_ = 0
         self.s_nvals = 0
         self.d_val[:] = 0
         return GrB_SUCCESS
@@ -307,7 +311,7 @@ def _fold_rows(sr, ptr, prod):
     starts = ptr[:-1][nz]
     if prod.size and name in ("minimum", "maximum", "logical_or", "plus", "multiplies") \
             and not (name in ("plus", "multiplies") and np.issubdtype(sr.dtype, np.floating)):
-        uf = {"minimum": np.minimum, "maximum": np.maximum, "plus": np.add,
+        uf = {"minimum": np.fmin, "maximum": np.fmax, "plus": np.add,      # fminf / fmaxf: NaN operands ignored
               "multiplies": np.multiply}.get(name)
         if name == "logical_or":
             red = np.add.reduceat((prod != 0).astype(np.int64), starts) > 0
@@ -384,9 +388,17 @@ def _spmspv_merge(w, mask, accum, sr, A, u, desc):
     off = np.arange(total) - np.repeat(np.cumsum(lens) - lens, lens)
     epos = starts[owner] + off
     dest = ind[epos]
+    # mask storage (spmspv.hpp:147-164, :199-216): dense -> applied; sparse -> "not implemented" is
+    # printed, nothing is filtered, the masked epilogue still runs; else GrB_UNINITIALIZED_OBJECT
+    apply_mask = False
+    if mask is not None:
+        if mask.getStorage() == GrB_DENSE:
+            apply_mask = True
+        elif mask.getStorage() != GrB_SPARSE:
+            return GrB_UNINITIALIZED_OBJECT
     if desc.struconly():
         keys = np.unique(dest).astype(np.int32)
-        if mask is not None:
+        if apply_mask:
             keep = _mask_pass(mask.d_val[keys], scmp_desc)
             keys = keys[keep]
         w.s_ind[:keys.size] = keys
@@ -407,9 +419,10 @@ def _spmspv_merge(w, mask, accum, sr, A, u, desc):
     keys = keys.astype(np.int32)
     if mask is not None:
         # spmspv.hpp:201-243: failing entries are set to 0, then every 0 is pruned
-        fail = ~_mask_pass(mask.d_val[keys], scmp_desc)
         vals = vals.copy()
-        vals[fail] = 0
+        if apply_mask:
+            fail = ~_mask_pass(mask.d_val[keys], scmp_desc)
+            vals[fail] = 0
         keep = vals != 0
         keys, vals = keys[keep], vals[keep]
     w.s_ind[:keys.size] = keys
@@ -611,7 +624,7 @@ def eWiseMult(w, mask, accum, sr, u, v, desc):
     ident = sr.identity()
     if ut == GrB_SPARSE and vt == GrB_SPARSE:
         v.setStorage(GrB_DENSE)                     # operations.hpp:361-367 (storage flag only)
-        vt = GrB_DENSE
+        ut, vt = u.getStorage(), v.getStorage()     # both re-read (:369-370): u IS v when aliased
     if ut == GrB_DENSE and vt == GrB_DENSE:
         a, b = u.d_val, v.d_val
         if mask is not None and mask.getStorage() == GrB_SPARSE:
