@@ -53,39 +53,212 @@ __device__ __forceinline__ unsigned mix32(unsigned x) {
   x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
   return x;
 }
-// One Jones-Plassmann round on (cur -> next), colours from 0, -1 = uncoloured.  A vertex
-// whose (hash, id) beats every uncoloured neighbour takes the smallest colour none of its
-// coloured neighbours holds; two adjacent vertices are never coloured in the same round, so
-// reading `cur` only is race-free.  A wave per 64 rows would balance hubs better; colouring is
-// a set-up step here, not the measured path.
-__global__ void jp_round_kernel(const Index* __restrict__ ptr, const Index* __restrict__ ind, Index n,
-                                const int* __restrict__ cur, int* __restrict__ next, int* __restrict__ left) {
-  int mine = 0;
-  for (Index v = blockIdx.x * blockDim.x + threadIdx.x; v < n; v += gridDim.x * blockDim.x) {
-    const int c = cur[v];
-    if (c >= 0) { next[v] = c; continue; }
-    const unsigned hv = mix32((unsigned)v);
+// ---- colouring by rounds of local maxima, as a dataflow over the priority DAG ----
+// v is chosen in the round after its last BLOCKER was: a blocker of v is a neighbour u != v that is
+// a candidate and has priority(u) >= priority(v) (the reference's test is w[v] > max w[u], so an
+// equal neighbour blocks as well -- for ever).  blockers[v] counts them; a round colours its
+// frontier (the vertices whose count reached 0 in the round before) and releases the neighbours
+// they block, appending those that reach 0 to the next frontier.  Every edge is looked at twice in
+// total (count, release) instead of once per round, and a round costs what its frontier costs.
+//   kFirstFit = false: colour = the round number          (algorithm::gcIS, gc.hpp:43-149)
+//   kFirstFit = true : colour = the smallest colour no neighbour holds (Jones-Plassmann; graphColor)
+// Frontier vertices of one round are never adjacent (one would block the other), so first-fit reads
+// settled colours only.  Frontier sizes live on the device in three rotating counters (read / appended
+// to / being zeroed): the host queues a batch of rounds and looks at the sizes once per batch.
+constexpr int kColourWindow = 2048;                       // colours examined per first-fit pass
+constexpr int kColourBatch = 16;                          // rounds queued between two host looks
+constexpr int kNbrUnroll = 4;                             // neighbour loads in flight per lane
+
+// priority of u against v: does u block v?  weights: the reference's strict test; hash: total order
+__device__ __forceinline__ bool blocks(unsigned pu, Index u, unsigned pv, Index v, bool by_weight) {
+  if (by_weight) return pu != 0u && pu >= pv;             // weight 0 = not a candidate (gc.hpp:66-70)
+  return pu > pv || (pu == pv && u > v);
+}
+__device__ __forceinline__ unsigned priority(const int* weights, Index v) {
+  return weights ? (unsigned)weights[v] : mix32((unsigned)v);
+}
+
+// blockers[v] for every vertex; the vertices with none (and a non-zero weight) form round 1's frontier
+__global__ __launch_bounds__(kBlock) void colour_init_kernel(const Index* __restrict__ ptr, const Index* __restrict__ ind,
+                                                             Index n, const int* __restrict__ weights,
+                                                             int* __restrict__ blockers, Index* __restrict__ first,
+                                                             int* __restrict__ first_count) {
+  __shared__ Index requeue[kWavesPerBlock][kWave];
+  int nrequeue = 0;
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wib = threadIdx.x / kWave;
+  const Index wave = (Index)((blockIdx.x * (unsigned)blockDim.x + threadIdx.x) / kWave);
+  const Index nwaves = (Index)((gridDim.x * (unsigned)blockDim.x) / kWave);
+  for (Index v = wave; v < n; v += nwaves) {
+    const unsigned pv = priority(weights, v);
     const Index b = ptr[v], e = ptr[v + 1];
-    bool top = true;
-    for (Index k = b; k < e && top; ++k) {
-      const Index u = ind[k];
-      if (u == v || cur[u] >= 0) continue;
-      const unsigned hu = mix32((unsigned)u);
-      if (hu > hv || (hu == hv && u > v)) top = false;
+    int cnt = 0;
+    for (Index p = b + lane; p < e; p += kWave * kNbrUnroll) {
+      Index u[kNbrUnroll];
+      unsigned pu[kNbrUnroll];
+#pragma unroll
+      for (int k = 0; k < kNbrUnroll; ++k) u[k] = p + k * kWave < e ? ind[p + k * kWave] : v;
+#pragma unroll
+      for (int k = 0; k < kNbrUnroll; ++k) pu[k] = priority(weights, u[k]);
+#pragma unroll
+      for (int k = 0; k < kNbrUnroll; ++k) cnt += (u[k] != v && blocks(pu[k], u[k], pv, v, weights != nullptr)) ? 1 : 0;
     }
-    if (!top) { next[v] = -1; ++mine; continue; }
-    int pick = -1;
-    for (int base = 0; pick < 0; base += 64) {
-      unsigned long long used = 0;
-      for (Index k = b; k < e; ++k) {
-        const int cu = cur[ind[k]];
-        if (cu >= base && cu < base + 64) used |= 1ull << (cu - base);
+    cnt = wave_reduce(cnt, [](int a, int c) { return a + c; });
+    cnt = __shfl(cnt, 0, kWave);
+    const bool never = weights && pv == 0u;
+    if (lane == 0) blockers[v] = never ? INT_MAX : cnt;
+    if (cnt == 0 && !never) {
+      if (lane == 0) requeue[wib][nrequeue] = v;
+      if (++nrequeue == kWave) {
+        int pos = 0;
+        if (lane == 0) pos = atomicAdd(first_count, kWave);
+        pos = __shfl(pos, 0, kWave);
+        __builtin_amdgcn_wave_barrier();
+        first[pos + lane] = requeue[wib][lane];
+        __builtin_amdgcn_wave_barrier();
+        nrequeue = 0;
       }
-      if (~used) pick = base + __ffsll((long long)~used) - 1;
     }
-    next[v] = pick;
   }
-  if (mine) atomicAdd(left, mine);
+  if (nrequeue) {
+    int pos = 0;
+    if (lane == 0) pos = atomicAdd(first_count, nrequeue);
+    pos = __shfl(pos, 0, kWave);
+    __builtin_amdgcn_wave_barrier();
+    if (lane < nrequeue) first[pos + lane] = requeue[wib][lane];
+  }
+}
+
+template <bool kFirstFit>
+__global__ __launch_bounds__(kBlock) void colour_round_kernel(
+    const Index* __restrict__ ptr, const Index* __restrict__ ind, const int* __restrict__ weights,
+    int* __restrict__ colour, int* __restrict__ blockers, const Index* __restrict__ cur, Index* __restrict__ next,
+    int* __restrict__ list_count /* [3] rotating */, int* __restrict__ frontier_size /* per round of the batch */,
+    int round, int slot) {
+  __shared__ unsigned int forb[kWavesPerBlock][kColourWindow / 32];
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wib = threadIdx.x / kWave;
+  const int wave = (int)((blockIdx.x * (unsigned)blockDim.x + threadIdx.x) / kWave);
+  const int nwaves = (int)((gridDim.x * (unsigned)blockDim.x) / kWave);
+  const int ncur = list_count[round % 3];
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    list_count[(round + 2) % 3] = 0;                      // the round after next appends there
+    frontier_size[slot] = ncur;
+  }
+  int* next_count = &list_count[(round + 1) % 3];
+  for (int i = wave; i < ncur; i += nwaves) {
+    const Index v = cur[i];
+    const unsigned pv = priority(weights, v);
+    const Index b = ptr[v], e = ptr[v + 1];
+    int mine = round;
+    if constexpr (kFirstFit) {
+      mine = 0;
+      for (int base = 1; mine == 0; base += kColourWindow) {
+        for (int k = lane; k < kColourWindow / 32; k += kWave) forb[wib][k] = 0u;
+        __builtin_amdgcn_wave_barrier();
+        for (Index p = b + lane; p < e; p += kWave * kNbrUnroll) {
+          int cu[kNbrUnroll];
+#pragma unroll
+          for (int k = 0; k < kNbrUnroll; ++k) cu[k] = p + k * kWave < e ? colour[ind[p + k * kWave]] : 0;
+#pragma unroll
+          for (int k = 0; k < kNbrUnroll; ++k)
+            if (cu[k] >= base && cu[k] < base + kColourWindow)
+              atomicOr(&forb[wib][(cu[k] - base) >> 5], 1u << ((cu[k] - base) & 31));
+        }
+        __builtin_amdgcn_wave_barrier();
+        const unsigned freebits = ~forb[wib][lane];        // kColourWindow / 32 == kWave words
+        const unsigned long long any = __ballot(freebits != 0u);
+        if (any) {
+          const int wl = __ffsll((long long)any) - 1;
+          const unsigned fb = __shfl(freebits, wl, kWave);
+          mine = base + wl * 32 + (__ffs((int)fb) - 1);
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+    if (lane == 0) colour[v] = mine;
+    // release the neighbours v was blocking
+    for (Index p = b + lane; p < e; p += kWave * kNbrUnroll) {
+      Index u[kNbrUnroll];
+      unsigned pu[kNbrUnroll];
+#pragma unroll
+      for (int k = 0; k < kNbrUnroll; ++k) u[k] = p + k * kWave < e ? ind[p + k * kWave] : v;
+#pragma unroll
+      for (int k = 0; k < kNbrUnroll; ++k) pu[k] = priority(weights, u[k]);
+#pragma unroll
+      for (int k = 0; k < kNbrUnroll; ++k) {
+        // v blocks u  <=>  blocks(pv, v, pu[k], u[k]); a weight-0 u holds INT_MAX and never reaches 0
+        const bool freed = u[k] != v && blocks(pv, v, pu[k], u[k], weights != nullptr) &&
+                           atomicSub(&blockers[u[k]], 1) == 1;
+        const unsigned long long m = __ballot(freed);      // one append per wave, not per vertex
+        if (m) {
+          int pos = 0;
+          if (lane == __ffsll((long long)m) - 1) pos = atomicAdd(next_count, __popcll(m));
+          pos = __shfl(pos, __ffsll((long long)m) - 1, kWave);
+          if (freed) next[pos + __popcll(m & ((1ull << lane) - 1ull))] = u[k];
+        }
+      }
+    }
+  }
+}
+
+__global__ void colour_extract_kernel(const int* __restrict__ colour, int* __restrict__ out, Index n, int minus) {
+  for (Index v = blockIdx.x * blockDim.x + threadIdx.x; v < n; v += gridDim.x * blockDim.x) out[v] = colour[v] - minus;
+}
+
+// Runs rounds until a frontier is empty (or max_rounds is reached).  colours_out: int vector, colours
+// from 1 (0 = never coloured) minus `minus`.  rounds_out = the reference's `iter` (1 + rounds that
+// coloured something).
+template <bool kFirstFit>
+grb_info colour_by_rounds(grb_matrix A, const int* d_weights, int max_rounds, grb_vector colours_out, int minus,
+                          int* rounds_out) {
+  static_assert(kColourWindow / 32 == kWave, "one forbidden-set word per lane");
+  const Index n = A->nrows;
+  Context& c = ctx();
+  VecGuard g;
+  grb_vector col, blk, la, lb, cnt;
+  GRB_TRY(g.make(&col, GRB_I32, n));
+  GRB_TRY(g.make(&blk, GRB_I32, n));
+  GRB_TRY(g.make(&la, GRB_I32, n));
+  GRB_TRY(g.make(&lb, GRB_I32, n));
+  GRB_TRY(g.make(&cnt, GRB_I32, 64));
+  GRB_TRY(grb_vector_fill(col, 0.0));
+  GRB_TRY(grb_vector_fill(cnt, 0.0));
+  int* counters = (int*)cnt->d_val;                        // [0..2] frontier sizes, [8..8+batch) per round
+  int round = 1, iter = 1;
+  bool done = n == 0;
+  if (!done) {
+    // round 1 reads list la through counter 1 % 3
+    hipLaunchKernelGGL(colour_init_kernel, dim3(stream_grid((long long)n * kWave, kBlock)), dim3(kBlock), 0, c.stream,
+                       A->csr.ptr, A->csr.ind, n, d_weights, (int*)blk->d_val, (Index*)la->d_val, counters + 1);
+    GRB_HIP_TRY(hipGetLastError());
+  }
+  long long remaining = n;
+  while (!done && round <= max_rounds) {
+    GRB_HIP_TRY(hipMemsetAsync(counters + 8, 0, sizeof(int) * kColourBatch, c.stream));
+    const int first = round;
+    // a frontier can hold every remaining vertex at most; later batches shrink with it
+    const int grid = stream_grid((remaining > 0 ? remaining : 1) * kWave, kBlock);
+    for (int k = 0; k < kColourBatch && round <= max_rounds; ++k, ++round) {
+      const Index* cur = (const Index*)((round & 1) ? la->d_val : lb->d_val);
+      Index* nxt = (Index*)((round & 1) ? lb->d_val : la->d_val);
+      hipLaunchKernelGGL((colour_round_kernel<kFirstFit>), dim3(grid), dim3(kBlock), 0, c.stream, A->csr.ptr, A->csr.ind,
+                         d_weights, (int*)col->d_val, (int*)blk->d_val, cur, nxt, counters, counters + 8, round, k);
+      GRB_HIP_TRY(hipGetLastError());
+    }
+    int h[kColourBatch];
+    GRB_TRY(fetch_ints(counters + 8, kColourBatch, h));
+    for (int k = 0; k < round - first; ++k) {
+      if (h[k] == 0) { done = true; break; }               // succ == 0: the loop of gc.hpp:117-120 breaks
+      ++iter;
+      remaining -= h[k];
+    }
+  }
+  hipLaunchKernelGGL(colour_extract_kernel, dim3(stream_grid(n)), dim3(kBlock), 0, c.stream, (const int*)col->d_val,
+                     (int*)colours_out->d_val, n, minus);
+  GRB_HIP_TRY(hipGetLastError());
+  if (rounds_out) *rounds_out = iter;
+  return GRB_SUCCESS;
 }
 }  // namespace
 
@@ -126,33 +299,17 @@ grb_info grb_scatter(grb_vector w, grb_vector mask, grb_vector u, double val, gr
 // graphColor (operations.hpp:816-826 -> backend/cuda/color.hpp:18-88).  The reference hands the CSR
 // to cuSPARSE csrcolor (closed source, not in the tree); what its callers rely on
 // (example/ggc_cusparse.cu:94-99) is a proper colouring with colours counted from 0.  This is
-// Jones-Plassmann with a hashed priority.  w: int or float vector of length nrows.
+// Jones-Plassmann with a hashed priority and first-fit colours (colour_by_rounds above).  w: int or float vector of length nrows.
 grb_info grb_graph_color(grb_vector w, grb_matrix A, grb_descriptor desc, int* ncolors) {
   if (!w || !A || !desc) return GRB_UNINITIALIZED_OBJECT;
   const Index n = A->nrows;
   if (A->ncols != w->nsize) return GRB_DIMENSION_MISMATCH;
   if (!A->csr.ptr) return GRB_INVALID_OBJECT;
-  Context& c = ctx();
   VecGuard g;
-  grb_vector a, b, cnt;
-  GRB_TRY(g.make(&a, GRB_I32, n));
-  GRB_TRY(g.make(&b, GRB_I32, n));
-  GRB_TRY(g.make(&cnt, GRB_I32, 64));
-  GRB_TRY(grb_vector_fill(a, -1.0));
-  GRB_TRY(grb_vector_fill(b, -1.0));
-  int* cur = (int*)a->d_val;
-  int* nxt = (int*)b->d_val;
-  for (int round = 0; round <= n; ++round) {
-    GRB_TRY(grb_vector_fill(cnt, 0.0));
-    hipLaunchKernelGGL(jp_round_kernel, dim3(stream_grid(n)), dim3(kBlock), 0, c.stream, A->csr.ptr, A->csr.ind, n,
-                       (const int*)cur, nxt, (int*)cnt->d_val);
-    GRB_HIP_TRY(hipGetLastError());
-    int left = 0;
-    GRB_TRY(fetch_ints((const int*)cnt->d_val, 1, &left));
-    std::swap(cur, nxt);
-    if (left == 0) break;
-  }
-  grb_vector colours = cur == (int*)a->d_val ? a : b;
+  grb_vector colours;
+  GRB_TRY(g.make(&colours, GRB_I32, n));
+  GRB_TRY(grb_vector_set_storage(colours, GRB_DENSE));
+  GRB_TRY(colour_by_rounds<true>(A, nullptr, 65534, colours, 1, nullptr));
   double mx = 0;
   GRB_TRY(grb_reduce_vector(&mx, GRB_ACCUM_NULL, GRB_MAXIMUM_MONOID, colours, desc));
   if (ncolors) *ncolors = n > 0 ? (int)mx + 1 : 0;
@@ -246,6 +403,18 @@ grb_info grb_gc(grb_vector v, grb_matrix A, int seed, grb_vector weights, int ma
   int iter = 1;
   double succ = 0;
   float ms = 0.f;
+  static const bool fused_ok = [] { const char* e = getenv("GRB_GC_FUSED"); return !e || atoi(e) != 0; }();
+  if (algo == 2 && fused_ok) {
+    // gcIS as rounds of one kernel each (colour_by_rounds): the same vertices take the same colour
+    // in the same round as with the op sequence below -- v wins round r iff w[v] > 0 and w[v]
+    // exceeds the weight of every neighbour uncoloured when r began.  The reference runs at most
+    // max_niter rounds that colour something (gc.hpp:139-142).
+    GRB_TRY(grb_timer_start());
+    GRB_TRY(colour_by_rounds<false>(A, (const int*)w->d_val, desc->max_niter, v, 0, &iter));   // <= 65534 rounds
+    GRB_TRY(grb_timer_stop(&ms));
+    if (result) { result->iterations = iter; result->tight_ms = ms; result->last_value = 0; }
+    return GRB_SUCCESS;
+  }
   GRB_TRY(grb_timer_start());
   do {
     double colour = iter;
