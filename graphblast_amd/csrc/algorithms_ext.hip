@@ -68,6 +68,7 @@ __device__ __forceinline__ unsigned mix32(unsigned x) {
 constexpr int kColourWindow = 2048;                       // colours examined per first-fit pass
 constexpr int kColourBatch = 16;                          // rounds queued between two host looks
 constexpr int kNbrUnroll = 4;                             // neighbour loads in flight per lane
+constexpr int kSplitItems = 2048;                         // frontier positions with a shared forbidden set
 
 // priority of u against v: does u block v?  weights: the reference's strict test; hash: total order
 __device__ __forceinline__ bool blocks(unsigned pu, Index u, unsigned pv, Index v, bool by_weight) {
@@ -134,7 +135,8 @@ __global__ __launch_bounds__(kBlock) void colour_round_kernel(
     const Index* __restrict__ ptr, const Index* __restrict__ ind, const int* __restrict__ weights,
     int* __restrict__ colour, int* __restrict__ blockers, const Index* __restrict__ cur, Index* __restrict__ next,
     int* __restrict__ list_count /* [3] rotating */, int* __restrict__ frontier_size /* per round of the batch */,
-    int round, int slot) {
+    unsigned int* __restrict__ shared_forb /* [kSplitItems][64], zero between rounds */,
+    int* __restrict__ arrive /* [kSplitItems], zero between rounds */, int round, int slot) {
   __shared__ unsigned int forb[kWavesPerBlock][kColourWindow / 32];
   const int lane = threadIdx.x & (kWave - 1);
   const int wib = threadIdx.x / kWave;
@@ -146,14 +148,69 @@ __global__ __launch_bounds__(kBlock) void colour_round_kernel(
     frontier_size[slot] = ncur;
   }
   int* next_count = &list_count[(round + 1) % 3];
-  for (int i = wave; i < ncur; i += nwaves) {
-    const Index v = cur[i];
+  // a small frontier leaves most of the launch idle while one wave walks a hub's list, so the list
+  // is cut into `split` interleaved slices, one wave each.  Releasing neighbours needs nothing from
+  // the other slices; first-fit does: the slices OR the colours they see into a forbidden set in
+  // global memory and the last one to arrive (a ticket per frontier position) picks the colour.
+  int split = 1;
+  while (split < 32 && (long long)ncur * split * 2 <= nwaves && (!kFirstFit || ncur <= kSplitItems)) split *= 2;
+  const long long nitems = (long long)ncur * split;
+  for (long long item = wave; item < nitems; item += nwaves) {
+    const Index v = cur[item / split];
+    const int slice = (int)(item % split);
     const unsigned pv = priority(weights, v);
     const Index b = ptr[v], e = ptr[v + 1];
+    // only lists long enough to be worth it are cut (a slice = at least one full pass of the wave)
+    const int vsplit = min(split, max(1, (int)((e - b + kWave * kNbrUnroll - 1) / (kWave * kNbrUnroll))));
+    if (slice >= vsplit) continue;
     int mine = round;
+    int first_base = 1;
+    bool choose = slice == 0;                              // this wave writes colour[v]
     if constexpr (kFirstFit) {
-      mine = 0;
-      for (int base = 1; mine == 0; base += kColourWindow) {
+      if (vsplit > 1) {
+        const int fi = (int)(item / split);
+        unsigned int* fb = shared_forb + (size_t)fi * (kColourWindow / 32);
+        // collected in LDS first: the colours of a hub's neighbours fall into a handful of words, and
+        // same-address global atomics serialise
+        forb[wib][lane] = 0u;
+        __builtin_amdgcn_wave_barrier();
+        for (Index p = b + (Index)slice * kWave * kNbrUnroll + lane; p < e; p += (Index)vsplit * kWave * kNbrUnroll) {
+          int cu[kNbrUnroll];
+#pragma unroll
+          for (int k = 0; k < kNbrUnroll; ++k) cu[k] = p + k * kWave < e ? colour[ind[p + k * kWave]] : 0;
+#pragma unroll
+          for (int k = 0; k < kNbrUnroll; ++k)
+            if (cu[k] >= 1 && cu[k] <= kColourWindow) atomicOr(&forb[wib][(cu[k] - 1) >> 5], 1u << ((cu[k] - 1) & 31));
+        }
+        __builtin_amdgcn_wave_barrier();
+        const unsigned seen = forb[wib][lane];
+        if (seen) atomicOr(&fb[lane], seen);
+        __builtin_amdgcn_wave_barrier();
+        __threadfence();
+        int ticket = 0;
+        if (lane == 0) ticket = atomicAdd(&arrive[fi], 1);
+        ticket = __shfl(ticket, 0, kWave);
+        choose = ticket == vsplit - 1;
+        if (choose) {
+          __threadfence();
+          const unsigned freebits = ~__hip_atomic_load(&fb[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          fb[lane] = 0u;                                   // left clean for the next round
+          if (lane == 0) arrive[fi] = 0;
+          const unsigned long long any = __ballot(freebits != 0u);
+          if (any) {
+            const int wl = __ffsll((long long)any) - 1;
+            const unsigned fbw = __shfl(freebits, wl, kWave);
+            mine = wl * 32 + __ffs((int)fbw);              // colours from 1
+            first_base = 0;                                // settled: skip the windowed search below
+          } else {
+            first_base = 1 + kColourWindow;                // every colour of the first window is taken
+          }
+        } else {
+          first_base = 0;
+        }
+      }
+      if (first_base > 0) mine = 0;
+      for (int base = first_base; first_base > 0 && mine == 0; base += kColourWindow) {
         for (int k = lane; k < kColourWindow / 32; k += kWave) forb[wib][k] = 0u;
         __builtin_amdgcn_wave_barrier();
         for (Index p = b + lane; p < e; p += kWave * kNbrUnroll) {
@@ -176,9 +233,9 @@ __global__ __launch_bounds__(kBlock) void colour_round_kernel(
         __builtin_amdgcn_wave_barrier();
       }
     }
-    if (lane == 0) colour[v] = mine;
+    if (lane == 0 && choose) colour[v] = mine;
     // release the neighbours v was blocking
-    for (Index p = b + lane; p < e; p += kWave * kNbrUnroll) {
+    for (Index p = b + (Index)slice * kWave * kNbrUnroll + lane; p < e; p += (Index)vsplit * kWave * kNbrUnroll) {
       Index u[kNbrUnroll];
       unsigned pu[kNbrUnroll];
 #pragma unroll
@@ -224,6 +281,13 @@ grb_info colour_by_rounds(grb_matrix A, const int* d_weights, int max_rounds, gr
   GRB_TRY(g.make(&cnt, GRB_I32, 64));
   GRB_TRY(grb_vector_fill(col, 0.0));
   GRB_TRY(grb_vector_fill(cnt, 0.0));
+  grb_vector sf = nullptr, arr = nullptr;
+  if (kFirstFit) {
+    GRB_TRY(g.make(&sf, GRB_I32, kSplitItems * (kColourWindow / 32)));
+    GRB_TRY(g.make(&arr, GRB_I32, kSplitItems));
+    GRB_TRY(grb_vector_fill(sf, 0.0));
+    GRB_TRY(grb_vector_fill(arr, 0.0));
+  }
   int* counters = (int*)cnt->d_val;                        // [0..2] frontier sizes, [8..8+batch) per round
   int round = 1, iter = 1;
   bool done = n == 0;
@@ -238,12 +302,14 @@ grb_info colour_by_rounds(grb_matrix A, const int* d_weights, int max_rounds, gr
     GRB_HIP_TRY(hipMemsetAsync(counters + 8, 0, sizeof(int) * kColourBatch, c.stream));
     const int first = round;
     // a frontier can hold every remaining vertex at most; later batches shrink with it
-    const int grid = stream_grid((remaining > 0 ? remaining : 1) * kWave, kBlock);
+    int grid = stream_grid((remaining > 0 ? remaining : 1) * kWave, kBlock);
+    if (grid < c.num_cu) grid = c.num_cu;                  // idle waves are what long lists get split over
     for (int k = 0; k < kColourBatch && round <= max_rounds; ++k, ++round) {
       const Index* cur = (const Index*)((round & 1) ? la->d_val : lb->d_val);
       Index* nxt = (Index*)((round & 1) ? lb->d_val : la->d_val);
       hipLaunchKernelGGL((colour_round_kernel<kFirstFit>), dim3(grid), dim3(kBlock), 0, c.stream, A->csr.ptr, A->csr.ind,
-                         d_weights, (int*)col->d_val, (int*)blk->d_val, cur, nxt, counters, counters + 8, round, k);
+                         d_weights, (int*)col->d_val, (int*)blk->d_val, cur, nxt, counters, counters + 8,
+                         sf ? (unsigned int*)sf->d_val : nullptr, arr ? (int*)arr->d_val : nullptr, round, k);
       GRB_HIP_TRY(hipGetLastError());
     }
     int h[kColourBatch];
