@@ -284,7 +284,7 @@ def main():
         parallelism = "single"
     else:
         from graphblast_amd import dist as gdist
-        part = gdist.Partition1D(n, tptr, tind, rank, world, dev)
+        part = gdist.Partition1D(n, tptr, tind, rank, world, dev, edgeswitch=args.edgeswitch)
         for i in range(args.warmup):
             part.bfs(sources[i % len(sources)])
         barrier()

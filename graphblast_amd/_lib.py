@@ -115,6 +115,11 @@ _SIGS = {
     "grb_sssp": [_vp, _vp, _i, _vp, C.POINTER(AlgoResult)],
     "grb_pr": [_vp, _vp, _f, _f, _vp, C.POINTER(AlgoResult)],
     "grb_k_spmv": [_vp, _i, _i, _vp, _vp, _i, _i, _vp],
+    "grb_bfs_part_apply2": [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _f, C.POINTER(C.c_int32), C.POINTER(C.c_int64),
+                            C.POINTER(C.c_int64)],
+    "grb_bfs_part_push_small": [_vp, _i, _i, _vp, _vp, _vp],
+    "grb_bfs_part_seed": [_vp, _vp, _vp, _i, _i, _i, _i],
+    "grb_bitmap_or_parts": [_vp, _i, _i, _vp],
     "grb_scatter": [_vp, _vp, _vp, _d, _vp],
     "grb_vector_resize": [_vp, _i],
     "grb_trace_mxm_transpose": [C.POINTER(_d), _i, _vp, _vp, _vp],

@@ -64,6 +64,126 @@ __global__ void sum_partials_kernel(const int* __restrict__ partial, int n, int*
   if (threadIdx.x == 0) *out = c;
 }
 
+// ---- leaner level steps for the host-driven partitioned loop (one launch and one host wake-up each)
+// apply in one launch: vis |= fresh, owned labels, and two totals through the granule mailbox --
+// |fresh| (identical on every rank) and the out-degree sum of the OWNED fresh vertices (this rank's
+// share of the next push, which decides locally which push kernel to use).
+__global__ __launch_bounds__(kBlock) void bfs_part_apply2_kernel(
+    const unsigned int* __restrict__ fresh, unsigned int* __restrict__ vis, int nwords, int lo_word, int local_words,
+    Index n_local, float* __restrict__ label, float new_label, const Index* __restrict__ out_ptr,
+    const int* __restrict__ deg_full /* nullable: out-degree of every vertex */,
+    unsigned int* __restrict__ partial /* 3 per workgroup */, unsigned int* __restrict__ ticket,
+    unsigned long long* __restrict__ mail, int seq) {
+  __shared__ unsigned int smem[3][kWavesPerBlock];
+  __shared__ int s_last;
+  unsigned int cnt = 0, edges = 0, all_edges = 0;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nwords; i += gridDim.x * blockDim.x) {
+    unsigned int f = fresh[i] & ~vis[i];
+    if (!f) continue;
+    vis[i] |= f;
+    cnt += __popc(f);
+    const bool owned = i >= lo_word && i < lo_word + local_words;
+    if (!owned && !deg_full) continue;
+    while (f) {
+      const int b = __ffs((int)f) - 1;
+      f &= f - 1;
+      if (deg_full) all_edges += (unsigned int)deg_full[(Index)i * 32 + b];
+      if (owned) {
+        const Index v = (Index)(i - lo_word) * 32 + b;
+        if (v < n_local) {
+          label[v] = new_label;
+          if (out_ptr) edges += (unsigned int)(out_ptr[v + 1] - out_ptr[v]);
+        }
+      }
+    }
+  }
+  unsigned int mine[3] = {cnt, edges, all_edges};
+#pragma unroll
+  for (int k = 0; k < 3; ++k) mine[k] = wave_reduce(mine[k], [](unsigned int a, unsigned int b) { return a + b; });
+  if (lane_id() == 0)
+    for (int k = 0; k < 3; ++k) smem[k][wave_id()] = mine[k];
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int k = 0; k < 3; ++k) {
+      unsigned int t = 0;
+      for (int w = 0; w < kWavesPerBlock; ++w) t += smem[k][w];
+      __hip_atomic_store(&partial[3 * blockIdx.x + k], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    s_last = last_workgroup_arrives(ticket) ? 1 : 0;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  unsigned int f[3] = {0, 0, 0};
+  for (int j = threadIdx.x; j < (int)gridDim.x; j += kBlock)
+    for (int k = 0; k < 3; ++k) f[k] += __hip_atomic_load(&partial[3 * j + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) f[k] = wave_reduce(f[k], [](unsigned int a, unsigned int b) { return a + b; });
+  __syncthreads();
+  if (lane_id() == 0)
+    for (int k = 0; k < 3; ++k) smem[k][wave_id()] = f[k];
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int k = 0; k < 3; ++k) {
+      unsigned int t = 0;
+      for (int w = 0; w < kWavesPerBlock; ++w) t += smem[k][w];
+      __hip_atomic_store(&mail[k], ((unsigned long long)(unsigned int)seq << 32) | t, __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
+
+// push for a frontier with few out-edges on this rank: a wave per 32 owned frontier slots, lanes over
+// the edge list of each set bit, unvisited targets OR-ed into the (pre-zeroed) new-bits bitmap.  One
+// launch, nothing read back; the edge-balanced path above is for frontiers with many edges.
+__global__ __launch_bounds__(kBlock) void bfs_part_push_small_kernel(
+    const Index* __restrict__ ptr, const Index* __restrict__ ind, Index n_local, const unsigned int* __restrict__ f_local,
+    int local_words, const unsigned int* __restrict__ vis, unsigned int* __restrict__ fresh) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = (int)((blockIdx.x * (unsigned)blockDim.x + threadIdx.x) / kWave);
+  const int nwaves = (int)((gridDim.x * (unsigned)blockDim.x) / kWave);
+  for (int i = wave; i < local_words; i += nwaves) {
+    unsigned int word = f_local[i];
+    while (word) {
+      const int b = __ffs((int)word) - 1;
+      word &= word - 1;
+      const Index v = (Index)i * 32 + b;
+      if (v >= n_local) break;
+      const Index pb = ptr[v], pe = ptr[v + 1];
+      for (Index p = pb + lane; p < pe; p += kWave * 4) {
+        Index u[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) u[k] = p + k * kWave < pe ? ind[p + k * kWave] : -1;
+        unsigned int vw[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) vw[k] = u[k] >= 0 ? vis[u[k] >> 5] : 0xffffffffu;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (u[k] >= 0 && !((vw[k] >> (u[k] & 31)) & 1u)) atomicOr(&fresh[u[k] >> 5], 1u << (u[k] & 31));
+      }
+    }
+  }
+}
+
+__global__ void bfs_part_seed_kernel(unsigned int* vis, unsigned int* fresh, float* label, Index lo, Index n_local,
+                                     Index source) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const unsigned int bit = 1u << (source & 31);
+  vis[source >> 5] = bit;
+  fresh[source >> 5] = bit;
+  if (source >= lo && source < lo + n_local) label[source - lo] = 1.f;
+}
+
+// out = parts[0] | parts[1] | ... (the all-gathered new-bits bitmaps of every rank)
+__global__ void bitmap_or_parts_kernel(const unsigned int* __restrict__ parts, int world, int nwords,
+                                       unsigned int* __restrict__ out) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nwords; i += gridDim.x * blockDim.x) {
+    unsigned int x = 0;
+    for (int r = 0; r < world; ++r) x |= parts[(size_t)r * nwords + i];
+    out[i] = x;
+  }
+}
+
 }  // namespace grb
 
 using namespace grb;
@@ -76,6 +196,7 @@ grb_info grb_bfs_part_pull(grb_matrix A_in, grb_index lo, grb_index n_global, co
   if (lo % 64 != 0 || A_in->ncols != n_global) return GRB_INVALID_VALUE;
   hipStream_t s = ctx().stream;
   const Index n_local = A_in->nrows;
+  GRB_HIP_TRY(hipMemsetAsync(d_new, 0, 4 * (size_t)(2 * ceil_div(n_global, 64)), s));   // only the owned words get bits
   if (n_local == 0) return GRB_SUCCESS;
   GRB_TRY(ensure_empty_rows(&A_in->d_empty_csr_rows, A_in->csr, s));
   const int grid = stream_grid((long long)ceil_div(n_local, kWave) * kWave, kBlock);
@@ -161,6 +282,75 @@ grb_info grb_bfs_part_apply(const uint32_t* d_new_global, uint32_t* d_vis, grb_i
   int h = 0;
   GRB_TRY(fetch_ints(c.d_mail + 26, 1, &h));
   *discovered_out = h;
+  return GRB_SUCCESS;
+}
+
+grb_info grb_bfs_part_apply2(const uint32_t* d_new_global, uint32_t* d_vis, grb_index lo, grb_index n_local,
+                             grb_index n_global, grb_matrix A_out, const int32_t* d_deg_full, float* d_label_local,
+                             float new_label, int32_t* discovered_out, int64_t* local_frontier_edges_out,
+                             int64_t* frontier_edges_out) {
+  if (!d_new_global || !d_vis || !discovered_out) return GRB_UNINITIALIZED_OBJECT;
+  if (lo % 64 != 0) return GRB_INVALID_VALUE;
+  Context& c = ctx();
+  hipStream_t s = c.stream;
+  const int nwords = 2 * ceil_div(n_global, 64);
+  const int local_words = 2 * ceil_div(n_local, 64);
+  const int grid = stream_grid(nwords, kBlock);
+  void* p;
+  GRB_TRY(scratch(0, 12 * (size_t)grid + 16, &p));
+  const int seq = ++c.mail_seq;
+  hipLaunchKernelGGL(bfs_part_apply2_kernel, dim3(grid), dim3(kBlock), 0, s, d_new_global, d_vis, nwords, (int)(lo / 32),
+                     local_words, n_local, d_label_local, new_label,
+                     (A_out && A_out->built) ? (const Index*)A_out->csr.ptr : (const Index*)nullptr, (const int*)d_deg_full,
+                     (unsigned int*)p, c.d_tickets, c.d_hgran, seq);
+  GRB_HIP_TRY(hipGetLastError());
+  unsigned int out[3] = {0, 0, 0};
+  GRB_TRY(wait_granules(seq, 3, out));
+  *discovered_out = (int32_t)out[0];
+  if (local_frontier_edges_out) *local_frontier_edges_out = (int64_t)out[1];
+  if (frontier_edges_out) *frontier_edges_out = d_deg_full ? (int64_t)out[2] : -1;
+  return GRB_SUCCESS;
+}
+
+grb_info grb_bfs_part_push_small(grb_matrix A_out, grb_index lo, grb_index n_global, const uint32_t* d_frontier,
+                                 const uint32_t* d_vis, uint32_t* d_new) {
+  if (!A_out || !A_out->built || !A_out->csr.ptr || !d_frontier || !d_vis || !d_new) return GRB_UNINITIALIZED_OBJECT;
+  if (lo % 64 != 0 || A_out->ncols != n_global) return GRB_INVALID_VALUE;
+  hipStream_t s = ctx().stream;
+  const Index n_local = A_out->nrows;
+  const int nwords = 2 * ceil_div(n_global, 64);
+  const int local_words = 2 * ceil_div(n_local, 64);
+  GRB_HIP_TRY(hipMemsetAsync(d_new, 0, 4 * (size_t)nwords, s));
+  if (n_local == 0) return GRB_SUCCESS;
+  const int grid = stream_grid((long long)local_words * kWave, kBlock);
+  hipLaunchKernelGGL(bfs_part_push_small_kernel, dim3(grid), dim3(kBlock), 0, s, A_out->csr.ptr, A_out->csr.ind, n_local,
+                     d_frontier + lo / 32, local_words, d_vis, d_new);
+  GRB_HIP_TRY(hipGetLastError());
+  return GRB_SUCCESS;
+}
+
+grb_info grb_bfs_part_seed(uint32_t* d_vis, uint32_t* d_new_global, float* d_label_local, grb_index lo,
+                           grb_index n_local, grb_index n_global, grb_index source) {
+  if (!d_vis || !d_new_global || !d_label_local) return GRB_UNINITIALIZED_OBJECT;
+  if (source < 0 || source >= n_global) return GRB_INVALID_INDEX;
+  hipStream_t s = ctx().stream;
+  GRB_TRY(ctx_init());
+  const int nwords = 2 * ceil_div(n_global, 64);
+  GRB_HIP_TRY(hipMemsetAsync(d_vis, 0, 4 * (size_t)nwords, s));
+  GRB_HIP_TRY(hipMemsetAsync(d_new_global, 0, 4 * (size_t)nwords, s));
+  if (n_local > 0) GRB_HIP_TRY(hipMemsetAsync(d_label_local, 0, 4 * (size_t)n_local, s));
+  hipLaunchKernelGGL(bfs_part_seed_kernel, dim3(1), dim3(kWave), 0, s, d_vis, d_new_global, d_label_local, lo, n_local,
+                     source);
+  GRB_HIP_TRY(hipGetLastError());
+  return GRB_SUCCESS;
+}
+
+grb_info grb_bitmap_or_parts(const uint32_t* d_parts, int world, grb_index nwords, uint32_t* d_out) {
+  if (!d_parts || !d_out || world < 1) return GRB_UNINITIALIZED_OBJECT;
+  GRB_TRY(ctx_init());
+  hipLaunchKernelGGL(bitmap_or_parts_kernel, dim3(stream_grid(nwords)), dim3(kBlock), 0, ctx().stream, d_parts, world,
+                     (int)nwords, d_out);
+  GRB_HIP_TRY(hipGetLastError());
   return GRB_SUCCESS;
 }
 

@@ -77,6 +77,35 @@ class HipEngine:
         assert info == 0, info
         return out.value
 
+    # ---- leaner steps (one launch and one host wake-up each); Partition1D uses them when present
+    pull_zeroes = True                       # grb_bfs_part_pull clears the new-bits bitmap itself
+    small_push_edges = 1 << 15               # below this many local frontier out-edges: the one-launch push
+
+    def seed(self, vis, new_global, label_local, source):
+        info = self._lib.grb_bfs_part_seed(vis.data_ptr(), new_global.data_ptr(), label_local.data_ptr(), self.lo,
+                                           self.n_local, self.n, int(source))
+        assert info == 0, info
+
+    def apply2(self, new_global, vis, label_local, new_label, deg_full=None):
+        """-> (vertices discovered by this level, out-degree sum of the OWNED ones among them, out-degree
+        sum of all of them or -1 without `deg_full`, an int32 device tensor of every vertex's out-degree)"""
+        out, edges, all_edges = C.c_int32(0), C.c_int64(0), C.c_int64(-1)
+        info = self._lib.grb_bfs_part_apply2(new_global.data_ptr(), vis.data_ptr(), self.lo, self.n_local, self.n,
+                                             self.A._h, None if deg_full is None else deg_full.data_ptr(),
+                                             label_local.data_ptr(), float(new_label), C.byref(out), C.byref(edges),
+                                             C.byref(all_edges))
+        assert info == 0, info
+        return out.value, edges.value, all_edges.value
+
+    def push_small(self, frontier, vis, new_local):
+        info = self._lib.grb_bfs_part_push_small(self.A._h, self.lo, self.n, frontier.data_ptr(), vis.data_ptr(),
+                                                 new_local.data_ptr())
+        assert info == 0, info
+
+    def or_parts(self, gathered, world, nwords, out):
+        info = self._lib.grb_bitmap_or_parts(gathered.data_ptr(), int(world), int(nwords), out.data_ptr())
+        assert info == 0, info
+
     def tally(self, label_local):
         e, r = C.c_int64(0), C.c_int32(0)
         info = self._lib.grb_bfs_part_tally(self.A._h, label_local.data_ptr(), C.byref(e), C.byref(r))
@@ -133,12 +162,16 @@ class TorchComm:
         self.world, self.nwords = world, nwords
         self.gathered = torch.zeros(world * nwords, dtype=torch.int32, device=dev) if world > 1 else None
 
-    def or_combine(self, new_local, new_global):
-        """OR of every rank's new-bits bitmap: one all-gather + local OR."""
+    def or_combine(self, new_local, new_global, engine=None):
+        """OR of every rank's new-bits bitmap: one all-gather + local OR (one kernel when the engine
+        has it, world - 1 tensor ops otherwise)."""
         if self.world == 1:
             new_global.copy_(new_local)
             return
         dist.all_gather_into_tensor(self.gathered, new_local)
+        if engine is not None and hasattr(engine, "or_parts") and new_global.is_cuda:
+            engine.or_parts(self.gathered, self.world, self.nwords, new_global)
+            return
         g = self.gathered.view(self.world, self.nwords)
         new_global.copy_(g[0])
         for r in range(1, self.world):
@@ -157,7 +190,7 @@ class TorchComm:
 
 class Partition1D:
     def __init__(self, n, tptr, tind, rank, world, dev, engine_cls=HipEngine, mxvmode=GRB_PUSHPULL,
-                 switchpoint=0.01, max_niter=10000, symmetric=True, comm=None):
+                 switchpoint=0.01, max_niter=10000, symmetric=True, comm=None, edgeswitch=0.0):
         if not symmetric:
             raise NotImplementedError("directed graphs need a separate in-edge shard; pass the CSC as (tptr, tind)")
         self.n, self.rank, self.world, self.dev = n, rank, world, dev
@@ -177,22 +210,44 @@ class Partition1D:
         self.vis, self.new_local, self.new_global = z(), z(), z()
         self.comm = comm if comm is not None else TorchComm(world, self.nwords, dev)
         self.label = torch.zeros(max(self.n_local, 1), dtype=torch.float32, device=dev)
+        self.deg_host = np.diff(ptr_host[self.lo:self.hi + 1])
+        # graphblast_amd's edge-aware extension (0 = the reference's vertex-count rule only): a sparse frontier
+        # whose out-edges exceed edgeswitch * nnz is pulled.  Needs the frontier's out-degree sum, which apply2
+        # computes on every rank from the replicated new-bits bitmap (no collective).
+        self.edgeswitch = float(edgeswitch)
+        self.nnz = int(ptr_host[-1])
+        self.deg_full = None
+        if self.edgeswitch > 0 and hasattr(self.engine, "apply2"):
+            self.deg_full = (tptr[1:] - tptr[:-1]).to(torch.int32).contiguous()
+        self.deg_source = lambda s: int(ptr_host[s + 1] - ptr_host[s])
+        import inspect
+        self._combine_takes_engine = "engine" in inspect.signature(self.comm.or_combine).parameters
         self.mxvmode, self.switchpoint, self.max_niter = mxvmode, float(np.float32(switchpoint)), max_niter
 
     def _combine(self):
-        self.comm.or_combine(self.new_local, self.new_global)
+        if self._combine_takes_engine:
+            self.comm.or_combine(self.new_local, self.new_global, self.engine)
+        else:                                              # communicators with the two-argument form
+            self.comm.or_combine(self.new_local, self.new_global)
 
     def bfs(self, source):
         n = self.n
-        self.vis.zero_()
-        self.label.zero_()
-        self.new_global.zero_()
-        word, bit = source >> 5, source & 31
-        seed = (1 << bit) if bit < 31 else -(1 << 31)
-        self.new_global[word] = seed
-        self.vis[word] = seed
-        if self.lo <= source < self.hi:
-            self.label[source - self.lo] = 1.0
+        eng = self.engine
+        if hasattr(eng, "seed"):
+            eng.seed(self.vis, self.new_global, self.label, source)
+        else:
+            self.vis.zero_()
+            self.label.zero_()
+            self.new_global.zero_()
+            word, bit = source >> 5, source & 31
+            seed = (1 << bit) if bit < 31 else -(1 << 31)
+            self.new_global[word] = seed
+            self.vis[word] = seed
+            if self.lo <= source < self.hi:
+                self.label[source - self.lo] = 1.0
+        # out-edges of this rank's share of the frontier (decides locally which push kernel runs)
+        local_edges = int(self.deg_host[source - self.lo]) if self.lo <= source < self.hi else 0
+        all_edges = self.deg_source(source)
         f1_dense = self.mxvmode == GRB_PULLONLY
         ratio_f1 = ratio_f2 = np.float32(0)
         nf, levels, trace = 1, 0, []
@@ -212,13 +267,22 @@ class Partition1D:
                         ratio_f1 = ratio
             else:
                 f1_dense = self.mxvmode == GRB_PULLONLY
+            if (not f1_dense and self.mxvmode == GRB_PUSHPULL and self.deg_full is not None and nf >= 32
+                    and all_edges > self.edgeswitch * self.nnz):
+                f1_dense = True                                    # the same rule as bfs_persist.hip:145-147
             if f1_dense:
-                self.new_local.zero_()
-                self.engine.pull(self.vis, self.new_local, self.label, it + 1)
+                if not getattr(eng, "pull_zeroes", False):
+                    self.new_local.zero_()
+                eng.pull(self.vis, self.new_local, self.label, it + 1)
+            elif hasattr(eng, "push_small") and local_edges <= eng.small_push_edges:
+                eng.push_small(self.new_global, self.vis, self.new_local)
             else:
-                self.engine.push(self.new_global, self.vis, self.new_local)
+                eng.push(self.new_global, self.vis, self.new_local)
             self._combine()
-            found = self.engine.apply(self.new_global, self.vis, self.label, it + 1)
+            if hasattr(eng, "apply2"):
+                found, local_edges, all_edges = eng.apply2(self.new_global, self.vis, self.label, it + 1, self.deg_full)
+            else:
+                found = eng.apply(self.new_global, self.vis, self.label, it + 1)
             trace.append(("pull" if f1_dense else "push", nf, found))
             levels += 1
             ratio_f1, ratio_f2 = ratio_f2, ratio_f1

@@ -264,7 +264,7 @@ grb_info grb_bfs_fused(grb_vector v, grb_matrix A, grb_index source, grb_descrip
  * are 2*ceil(n_global/64) 32-bit words on the device.  The "new bits" bitmaps of all ranks
  * are OR-combined by the caller (RCCL) between push/pull and apply. */
 grb_info grb_bfs_part_pull(grb_matrix A_in, grb_index lo, grb_index n_global, const uint32_t* d_vis,
-                           uint32_t* d_new /* caller-zeroed; owned word range written */,
+                           uint32_t* d_new /* fully written: zeroed, then the owned word range */,
                            float* d_label_local, float new_label);
 grb_info grb_bfs_part_push(grb_matrix A_out, grb_index lo, grb_index n_global, const uint32_t* d_frontier,
                            const uint32_t* d_vis, uint32_t* d_work /* scratch bitmap */,
@@ -274,6 +274,20 @@ grb_info grb_bfs_part_apply(const uint32_t* d_new_global, uint32_t* d_vis, grb_i
                             int32_t* discovered_out);
 grb_info grb_bfs_part_tally(grb_matrix A_out, const float* d_label_local, int64_t* edges_out,
                             int32_t* reached_out);
+/* Leaner variants for the host-driven level loop (one launch and one host wake-up each):
+ * apply2 = apply + the out-degree sum of the OWNED newly discovered vertices (A_out nullable) and, given the
+ * out-degree of every vertex, of ALL of them (the same number on every rank: edge-aware direction switch);
+ * push_small = push for a frontier with few out-edges on this rank (d_new fully written);
+ * seed = zero vis / new / labels and plant the source; or_parts = OR of `world` all-gathered bitmaps. */
+grb_info grb_bfs_part_apply2(const uint32_t* d_new_global, uint32_t* d_vis, grb_index lo, grb_index n_local,
+                             grb_index n_global, grb_matrix A_out, const int32_t* d_deg_full /* nullable */,
+                             float* d_label_local, float new_label, int32_t* discovered_out,
+                             int64_t* local_frontier_edges_out, int64_t* frontier_edges_out /* -1 without d_deg_full */);
+grb_info grb_bfs_part_push_small(grb_matrix A_out, grb_index lo, grb_index n_global, const uint32_t* d_frontier,
+                                 const uint32_t* d_vis, uint32_t* d_new);
+grb_info grb_bfs_part_seed(uint32_t* d_vis, uint32_t* d_new_global, float* d_label_local, grb_index lo,
+                           grb_index n_local, grb_index n_global, grb_index source);
+grb_info grb_bitmap_or_parts(const uint32_t* d_parts, int world, grb_index nwords, uint32_t* d_out);
 
 typedef struct {
   int    iterations;          /* loop iterations executed                              */

@@ -106,8 +106,9 @@ def test_partition_bounds():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("edgeswitch", [0.0, 0.02])
 @pytest.mark.parametrize("world", [1, 2, 4])
-def test_partitioned_bfs_hip_engine_simulated_ranks(world):
+def test_partitioned_bfs_hip_engine_simulated_ranks(world, edgeswitch):
     """The real HIP level steps (grb_bfs_part_*) under `world` simulated ranks sharing one
     GPU: labels bit-exact vs the oracle, direction trace == single-GPU fused loop."""
     import threading
@@ -124,7 +125,7 @@ def test_partitioned_bfs_hip_engine_simulated_ranks(world):
     Eng = locked_engine(HipEngine, shared.lock)
     with shared.lock:
         parts = [Partition1D(n, tptr, tind, r, world, dev, engine_cls=Eng, comm=ThreadComm(shared, r),
-                             switchpoint=0.02) for r in range(world)]
+                             switchpoint=0.02, edgeswitch=edgeswitch) for r in range(world)]
     for src in (int(np.argmax(np.diff(ptr))), 11, 4097):
         results, labels = [None] * world, [None] * world
         def run(r):
@@ -138,6 +139,11 @@ def test_partitioned_bfs_hip_engine_simulated_ranks(world):
             assert results[r] is not None, "rank %d did not finish" % r
             assert np.array_equal(labels[r], want), (src, r)
             assert results[r]["edges_traversed"] == int(np.diff(ptr)[want != 0].sum())
+            assert results[r]["trace"] == results[0]["trace"]                  # every rank took the same decisions
+        if edgeswitch > 0 and src == int(np.argmax(np.diff(ptr))):
+            # the hub's level-2 frontier is a few thousand vertices carrying most of the edges: the
+            # vertex-count rule pushes it, the edge-aware rule pulls it
+            assert [t[0] for t in results[0]["trace"]][1] == "pull"
         _, stats = sr.bfs_do_stats(ptr, ind, ptr, ind, src, mxvmode=10, switchpoint=0.02)
         assert [t[0] for t in results[0]["trace"]] == ["pull" if s[0] else "push" for s in stats]
     # PageRank over the same simulated ranks (local SpMV shard + all-gather of the slices)
