@@ -60,14 +60,19 @@ __device__ __forceinline__ unsigned mix32(unsigned x) {
 // frontier (the vertices whose count reached 0 in the round before) and releases the neighbours
 // they block, appending those that reach 0 to the next frontier.  Every edge is looked at twice in
 // total (count, release) instead of once per round, and a round costs what its frontier costs.
-//   kFirstFit = false: colour = the round number          (algorithm::gcIS, gc.hpp:43-149)
-//   kFirstFit = true : colour = the smallest colour no neighbour holds (Jones-Plassmann; graphColor)
+//   kMode 0: colour = the round number                                  (algorithm::gcIS, gc.hpp:43-149)
+//   kMode 1: colour = the smallest colour no neighbour holds            (Jones-Plassmann; graphColor)
+//   kMode 2: ONE colour per round, the smallest held by no coloured neighbour of ANY frontier vertex
+//            (algorithm::gcJP, gc.hpp:258-421).  A vertex stores its round; the round's colour is
+//            settled by the last workgroup to finish the round (a bitmap of the colours seen, OR-ed by
+//            everybody) and read through round_colour[] from then on.
 // Frontier vertices of one round are never adjacent (one would block the other), so first-fit reads
 // settled colours only.  Frontier sizes live on the device in three rotating counters (read / appended
 // to / being zeroed): the host queues a batch of rounds and looks at the sizes once per batch.
 constexpr int kColourWindow = 2048;                       // colours examined per first-fit pass
 constexpr int kColourBatch = 16;                          // rounds queued between two host looks
 constexpr int kNbrUnroll = 4;                             // neighbour loads in flight per lane
+constexpr int kLdsSeenColours = 65536;                    // gcJP: colours a wave can collect in LDS (8 KiB)
 constexpr int kSplitItems = 2048;                         // frontier positions with a shared forbidden set
 
 // priority of u against v: does u block v?  weights: the reference's strict test; hash: total order
@@ -130,13 +135,25 @@ __global__ __launch_bounds__(kBlock) void colour_init_kernel(const Index* __rest
   }
 }
 
-template <bool kFirstFit>
+template <int kMode>
 __global__ __launch_bounds__(kBlock) void colour_round_kernel(
     const Index* __restrict__ ptr, const Index* __restrict__ ind, const int* __restrict__ weights,
     int* __restrict__ colour, int* __restrict__ blockers, const Index* __restrict__ cur, Index* __restrict__ next,
     int* __restrict__ list_count /* [3] rotating */, int* __restrict__ frontier_size /* per round of the batch */,
     unsigned int* __restrict__ shared_forb /* [kSplitItems][64], zero between rounds */,
-    int* __restrict__ arrive /* [kSplitItems], zero between rounds */, int round, int slot) {
+    int* __restrict__ arrive /* [kSplitItems], zero between rounds */,
+    unsigned int* __restrict__ seen /* kMode 2: max_colors bits, zero between rounds */,
+    int* __restrict__ round_colour /* kMode 2 */, int max_colors, unsigned int* __restrict__ tickets, int round,
+    int slot) {
+  constexpr bool kFirstFit = kMode == 1;
+  constexpr int kLdsSeenWords = kMode == 2 ? kLdsSeenColours / 32 : 1;
+  __shared__ unsigned int lds_seen[kWavesPerBlock][kLdsSeenWords];
+  const bool use_lds_seen = kMode == 2 && max_colors <= kLdsSeenColours;
+  bool touched_seen = false;
+  if (use_lds_seen) {
+    for (int k = threadIdx.x & (kWave - 1); k < (max_colors + 31) / 32; k += kWave) lds_seen[threadIdx.x / kWave][k] = 0u;
+    __builtin_amdgcn_wave_barrier();
+  }
   __shared__ unsigned int forb[kWavesPerBlock][kColourWindow / 32];
   const int lane = threadIdx.x & (kWave - 1);
   const int wib = threadIdx.x / kWave;
@@ -242,6 +259,28 @@ __global__ __launch_bounds__(kBlock) void colour_round_kernel(
       for (int k = 0; k < kNbrUnroll; ++k) u[k] = p + k * kWave < e ? ind[p + k * kWave] : v;
 #pragma unroll
       for (int k = 0; k < kNbrUnroll; ++k) pu[k] = priority(weights, u[k]);
+      if constexpr (kMode == 2) {
+        // colours around the frontier: neighbours coloured in an earlier round (gc.hpp:356-364; only
+        // colours in (0, max_colors) reach the dense array there).  Collected per wave in LDS (bits only
+        // ever get set, so a set bit is not set again) and flushed once at the end of the kernel.
+        int ru[kNbrUnroll];
+#pragma unroll
+        for (int k = 0; k < kNbrUnroll; ++k) ru[k] = u[k] != v ? colour[u[k]] : 0;
+#pragma unroll
+        for (int k = 0; k < kNbrUnroll; ++k) {
+          if (ru[k] > 0 && ru[k] < round) {
+            const int cu = round_colour[ru[k]];
+            if (cu > 0 && cu < max_colors) {
+              if (use_lds_seen) {
+                if (!((lds_seen[wib][cu >> 5] >> (cu & 31)) & 1u)) atomicOr(&lds_seen[wib][cu >> 5], 1u << (cu & 31));
+              } else if (!((seen[cu >> 5] >> (cu & 31)) & 1u)) {
+                atomicOr(&seen[cu >> 5], 1u << (cu & 31));
+              }
+            }
+          }
+        }
+        touched_seen = true;
+      }
 #pragma unroll
       for (int k = 0; k < kNbrUnroll; ++k) {
         // v blocks u  <=>  blocks(pv, v, pu[k], u[k]); a weight-0 u holds INT_MAX and never reaches 0
@@ -257,18 +296,61 @@ __global__ __launch_bounds__(kBlock) void colour_round_kernel(
       }
     }
   }
+  if constexpr (kMode == 2) {
+    if (use_lds_seen && __any(touched_seen)) {               // wave-uniform: every lane owns words to flush
+      __builtin_amdgcn_wave_barrier();
+      for (int k = lane; k < (max_colors + 31) / 32; k += kWave) {
+        const unsigned int bits = lds_seen[wib][k];
+        if (bits) atomicOr(&seen[k], bits);
+      }
+    }
+    // the last workgroup to get here settles this round's colour: the smallest index in [1, max_colors)
+    // nobody saw, max_colors if there is none (min_array[0] = max_colors, gc.hpp:380-385)
+    __shared__ int s_last, s_best[kWavesPerBlock];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      __threadfence();
+      s_last = last_workgroup_arrives(tickets) ? 1 : 0;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    const int nw = (max_colors + 31) / 32;
+    int best = max_colors;
+    for (int w = threadIdx.x; w < nw; w += kBlock) {
+      unsigned int bits = __hip_atomic_load(&seen[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      seen[w] = 0u;                                        // clean for the next round
+      if (w == 0) bits |= 1u;                              // colour 0 is "uncoloured"
+      if (~bits) {
+        const int c = w * 32 + (__ffs((int)~bits) - 1);
+        if (c < best) best = c;
+      }
+    }
+    best = wave_reduce(best, [](int a, int b) { return a < b ? a : b; });
+    if (lane_id() == 0) s_best[wave_id()] = best;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      for (int w = 1; w < kWavesPerBlock; ++w) best = s_best[w] < best ? s_best[w] : best;
+      round_colour[round] = best < max_colors ? best : max_colors;
+    }
+  }
 }
 
-__global__ void colour_extract_kernel(const int* __restrict__ colour, int* __restrict__ out, Index n, int minus) {
-  for (Index v = blockIdx.x * blockDim.x + threadIdx.x; v < n; v += gridDim.x * blockDim.x) out[v] = colour[v] - minus;
+__global__ void colour_extract_kernel(const int* __restrict__ colour, const int* __restrict__ round_colour,
+                                      int* __restrict__ out, Index n, int minus) {
+  for (Index v = blockIdx.x * blockDim.x + threadIdx.x; v < n; v += gridDim.x * blockDim.x) {
+    const int c = colour[v];
+    out[v] = (round_colour && c > 0 ? round_colour[c] : c) - minus;
+  }
 }
 
 // Runs rounds until a frontier is empty (or max_rounds is reached).  colours_out: int vector, colours
 // from 1 (0 = never coloured) minus `minus`.  rounds_out = the reference's `iter` (1 + rounds that
 // coloured something).
-template <bool kFirstFit>
+template <int kMode>
 grb_info colour_by_rounds(grb_matrix A, const int* d_weights, int max_rounds, grb_vector colours_out, int minus,
-                          int* rounds_out) {
+                          int* rounds_out, int max_colors = 0) {
+  constexpr bool kFirstFit = kMode == 1;
   static_assert(kColourWindow / 32 == kWave, "one forbidden-set word per lane");
   const Index n = A->nrows;
   Context& c = ctx();
@@ -287,6 +369,13 @@ grb_info colour_by_rounds(grb_matrix A, const int* d_weights, int max_rounds, gr
     GRB_TRY(g.make(&arr, GRB_I32, kSplitItems));
     GRB_TRY(grb_vector_fill(sf, 0.0));
     GRB_TRY(grb_vector_fill(arr, 0.0));
+  }
+  grb_vector seen = nullptr, rcol = nullptr;
+  if (kMode == 2) {
+    GRB_TRY(g.make(&seen, GRB_I32, (max_colors + 31) / 32 + 1));
+    GRB_TRY(g.make(&rcol, GRB_I32, 65536));
+    GRB_TRY(grb_vector_fill(seen, 0.0));
+    GRB_TRY(grb_vector_fill(rcol, 0.0));
   }
   int* counters = (int*)cnt->d_val;                        // [0..2] frontier sizes, [8..8+batch) per round
   int round = 1, iter = 1;
@@ -307,9 +396,11 @@ grb_info colour_by_rounds(grb_matrix A, const int* d_weights, int max_rounds, gr
     for (int k = 0; k < kColourBatch && round <= max_rounds; ++k, ++round) {
       const Index* cur = (const Index*)((round & 1) ? la->d_val : lb->d_val);
       Index* nxt = (Index*)((round & 1) ? lb->d_val : la->d_val);
-      hipLaunchKernelGGL((colour_round_kernel<kFirstFit>), dim3(grid), dim3(kBlock), 0, c.stream, A->csr.ptr, A->csr.ind,
+      hipLaunchKernelGGL((colour_round_kernel<kMode>), dim3(grid), dim3(kBlock), 0, c.stream, A->csr.ptr, A->csr.ind,
                          d_weights, (int*)col->d_val, (int*)blk->d_val, cur, nxt, counters, counters + 8,
-                         sf ? (unsigned int*)sf->d_val : nullptr, arr ? (int*)arr->d_val : nullptr, round, k);
+                         sf ? (unsigned int*)sf->d_val : nullptr, arr ? (int*)arr->d_val : nullptr,
+                         seen ? (unsigned int*)seen->d_val : nullptr, rcol ? (int*)rcol->d_val : nullptr, max_colors,
+                         c.d_tickets, round, k);
       GRB_HIP_TRY(hipGetLastError());
     }
     int h[kColourBatch];
@@ -321,7 +412,7 @@ grb_info colour_by_rounds(grb_matrix A, const int* d_weights, int max_rounds, gr
     }
   }
   hipLaunchKernelGGL(colour_extract_kernel, dim3(stream_grid(n)), dim3(kBlock), 0, c.stream, (const int*)col->d_val,
-                     (int*)colours_out->d_val, n, minus);
+                     rcol ? (const int*)rcol->d_val : (const int*)nullptr, (int*)colours_out->d_val, n, minus);
   GRB_HIP_TRY(hipGetLastError());
   if (rounds_out) *rounds_out = iter;
   return GRB_SUCCESS;
@@ -375,7 +466,7 @@ grb_info grb_graph_color(grb_vector w, grb_matrix A, grb_descriptor desc, int* n
   grb_vector colours;
   GRB_TRY(g.make(&colours, GRB_I32, n));
   GRB_TRY(grb_vector_set_storage(colours, GRB_DENSE));
-  GRB_TRY(colour_by_rounds<true>(A, nullptr, 65534, colours, 1, nullptr));
+  GRB_TRY(colour_by_rounds<1>(A, nullptr, 65534, colours, 1, nullptr));
   double mx = 0;
   GRB_TRY(grb_reduce_vector(&mx, GRB_ACCUM_NULL, GRB_MAXIMUM_MONOID, colours, desc));
   if (ncolors) *ncolors = n > 0 ? (int)mx + 1 : 0;
@@ -470,13 +561,21 @@ grb_info grb_gc(grb_vector v, grb_matrix A, int seed, grb_vector weights, int ma
   double succ = 0;
   float ms = 0.f;
   static const bool fused_ok = [] { const char* e = getenv("GRB_GC_FUSED"); return !e || atoi(e) != 0; }();
+  if (algo == 0 && fused_ok) {
+    // gcJP: the rounds (and their frontiers) are gcIS's; what differs is the colour a round hands out
+    GRB_TRY(grb_timer_start());
+    GRB_TRY(colour_by_rounds<2>(A, (const int*)w->d_val, desc->max_niter, v, 0, &iter, max_colors));
+    GRB_TRY(grb_timer_stop(&ms));
+    if (result) { result->iterations = iter; result->tight_ms = ms; result->last_value = 0; }
+    return GRB_SUCCESS;
+  }
   if (algo == 2 && fused_ok) {
     // gcIS as rounds of one kernel each (colour_by_rounds): the same vertices take the same colour
     // in the same round as with the op sequence below -- v wins round r iff w[v] > 0 and w[v]
     // exceeds the weight of every neighbour uncoloured when r began.  The reference runs at most
     // max_niter rounds that colour something (gc.hpp:139-142).
     GRB_TRY(grb_timer_start());
-    GRB_TRY(colour_by_rounds<false>(A, (const int*)w->d_val, desc->max_niter, v, 0, &iter));   // <= 65534 rounds
+    GRB_TRY(colour_by_rounds<0>(A, (const int*)w->d_val, desc->max_niter, v, 0, &iter));   // <= 65534 rounds
     GRB_TRY(grb_timer_stop(&ms));
     if (result) { result->iterations = iter; result->tight_ms = ms; result->last_value = 0; }
     return GRB_SUCCESS;
