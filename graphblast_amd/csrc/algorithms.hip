@@ -193,7 +193,7 @@ grb_info grb_pr(grb_vector p, grb_matrix A, float alpha, float eps, grb_descript
   GRB_TRY(grb_vector_set_storage(p_swap, GRB_DENSE));
   const int grid = stream_grid(n, kBlock);
   void* p_part;
-  GRB_TRY(scratch(4, sizeof(float) * (size_t)grid + 16, &p_part));
+  GRB_TRY(scratch(1, sizeof(float) * (size_t)grid + 16, &p_part));   // not 4 / 5: those hold the push path's state
   unsigned int* d_ticket = c.d_tickets;
   const float cst = (1.f - alpha) / n;
   int iter = 1;

@@ -319,7 +319,9 @@ struct Context {
 };
 Context& ctx();
 grb_info ctx_init();
-// Device scratch of at least `bytes` in slot `i` (contents not preserved on growth).
+// Device scratch of at least `bytes` in slot `i` (contents not preserved on growth).  Slots 4 and 5 are
+// NOT scratch for anyone but k_spmspv: they hold its touched-bitmap and accumulator, which it leaves all-zero /
+// all-identity between calls instead of clearing n words per call.
 grb_info scratch(int i, size_t bytes, void** out);
 // Copy `count` ints from device to host through the pinned mailbox; synchronises.
 grb_info fetch_ints(const int* d_src, int count, int* h_dst);

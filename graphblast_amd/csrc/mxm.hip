@@ -246,7 +246,7 @@ grb_info grb_mxm(grb_matrix C, grb_matrix mask, grb_accum accum, grb_semiring op
   C->built = true;
   if (mask->nvals == 0) return GRB_SUCCESS;
   void* p_rows;
-  GRB_TRY(scratch(5, 4 * (size_t)mask->nvals, &p_rows));
+  GRB_TRY(scratch(9, 4 * (size_t)mask->nvals, &p_rows));            // not 4 / 5: those hold the push path's state
   hipLaunchKernelGGL(entry_rows_kernel, dim3(stream_grid(mask->nvals, kBlock)), dim3(kBlock), 0, s, mask->csr.ptr,
                      mask->nrows, mask->nvals, (Index*)p_rows);
   GRB_HIP_TRY(hipGetLastError());
@@ -316,7 +316,7 @@ grb_info grb_trace_mxm_transpose(double* val, grb_semiring op, grb_matrix A, grb
   if (A->nrows != B->nrows) return GRB_DIMENSION_MISMATCH;
   Context& c = ctx();
   void* d_out;
-  GRB_TRY(scratch(4, 256, &d_out));
+  GRB_TRY(scratch(10, 256, &d_out));
   GRB_HIP_TRY(hipMemsetAsync(d_out, 0, 8, c.stream));
   const Index n = A->nrows;
   if (n > 0) {

@@ -534,3 +534,49 @@ def test_trace_mxm_transpose(hb):
             info, got = g.traceMxmTranspose(srn, mats[0][0], mats[1][0], d)
             want = ops.trace_mxm_transpose(Semiring(srn, dt), mats[0][1], mats[1][1])
             assert info == 0 and got == float(want), (dt, srn, got, want)
+
+
+def test_push_state_survives_other_operations(hb, ob):
+    """The push path keeps an n-bit bitmap and an n-entry accumulator clean BETWEEN calls instead of
+    clearing them per call; nothing else may write there.  (PageRank's partial sums, the masked SpGEMM's
+    row table and the trace result once used the same scratch slots: the first push after any of them
+    returned stray vertices.)  Each of them is followed by a key-value and a structure-only push."""
+    g = hb.g
+    n, ptr, ind, val = rand_graph(3000, 20000, 77)
+    A_h, A_o = both(hb, ob, n, ptr, ind, val)
+    rng = np.random.default_rng(3)
+    fidx = np.sort(rng.choice(n, 40, replace=False)).astype(np.int32)
+    fval = rng.integers(1, 4, fidx.size).astype(F)
+
+    def check_push(tag):
+        for struc in (0, 1):
+            outs = []
+            for be, A in ((hb, A_h), (ob, A_o)):
+                d = be.descriptor(mxvmode=1, struconly=struc)
+                u = be.vector(n); be.build_sparse(u, fidx, fval)
+                w = be.vector(n)
+                assert be.vxm(w, None, None, "PlusMultiplies", u, A, d) == 0
+                i, v = be.sparse_tuples(w)
+                outs.append((i, v))
+            same(outs[0][0], outs[1][0], what=(tag, struc))
+            if not struc:
+                same(outs[0][1], outs[1][1], what=(tag, struc))
+
+    check_push("fresh")
+    deg = np.maximum(np.diff(ptr), 1).astype(F)
+    P = hb.matrix_from_csr(n, ptr, ind, (F(0.85) / deg[np.repeat(np.arange(n), np.diff(ptr))]).astype(F))
+    p = g.Vector(n)
+    assert g.pr(p, P, 0.85, 0.0, hb.descriptor(mxvmode=2, max_niter=5))[0] == 0
+    check_push("after pr")
+    sym = rand_graph(3000, 20000, 78)
+    from graphblast_amd.graphgen import finalize_edges
+    gs = finalize_edges(rng.integers(0, n, 20000), rng.integers(0, n, 20000), n, symmetrize=True)
+    Ai = g.Matrix(n, n, np.int32)
+    assert Ai.build_csr(gs["csr"][0], gs["csr"][1], np.ones(gs["csr"][1].size, dtype=np.int32)) == 0
+    L, B = g.Matrix(n, n, np.int32), g.Matrix(n, n, np.int32)
+    d = hb.descriptor()
+    assert g.tril(L, Ai, d) == 0
+    assert g.tc(L, B, d)[0] == 0
+    check_push("after tc")
+    assert g.traceMxmTranspose("PlusMultiplies", A_h, A_h, d)[0] == 0
+    check_push("after trace")
