@@ -107,8 +107,14 @@ def gen_call(rng, n):
     if BFS_MIX[0]:
         return gen_bfs_call(rng, n)
     kind = rng.choice(["vxm", "mxv", "eWiseAdd", "eWiseMult", "assign", "reduce", "fill", "build_sparse",
-                       "build_dense", "dup", "swap", "toggle_mask", "mxvmode", "clear"],
-                      p=[0.16, 0.12, 0.12, 0.12, 0.12, 0.06, 0.05, 0.07, 0.05, 0.04, 0.03, 0.03, 0.02, 0.01])
+                       "build_dense", "dup", "swap", "toggle_mask", "mxvmode", "clear", "interfere"],
+                      p=[0.15, 0.11, 0.11, 0.11, 0.11, 0.06, 0.05, 0.07, 0.05, 0.04, 0.03, 0.03, 0.02, 0.01, 0.05])
+    if kind == "interfere":
+        # a whole algorithm driver / matrix operation of the library on ITS OWN vectors, between the
+        # compared calls: whatever state it keeps (scratch slots, pooled storage, plans, tickets,
+        # mailboxes) must not leak into what follows.  The oracle side does nothing.
+        return (kind, str(rng.choice(["bfs", "bfs_opbyop", "sssp", "pr", "cc", "tc", "trace", "mis", "gc", "lgc",
+                                       "reduce_rows"])), int(rng.integers(0, n)))
     v = lambda: int(rng.integers(0, NVEC))
     if kind in ("vxm", "mxv"):
         mask = v() if rng.random() < 0.5 else None
@@ -177,7 +183,49 @@ def run_call(be, call, vecs, A, desc):
         return be.set(desc, 8, call[1])
     if k == "clear":
         return vecs[call[1]].clear()
+    if k == "interfere":
+        if hasattr(be, "g"):
+            interfere(be, call[1], call[2], A)
+        return 0
     raise ValueError(k)
+
+
+_INT_TWIN = {}
+
+
+def interfere(hb, which, arg, A):
+    g = hb.g
+    n = A.nrows()
+    d = hb.descriptor(mxvmode=0)
+    twin = _INT_TWIN.get((id(A), n))
+    if twin is None:                                   # int copy of the pattern for the int drivers
+        ptr, ind, _ = A.host_csr()
+        twin = g.Matrix(n, n, np.int32)
+        assert twin.build_csr(ptr, ind, np.ones(ind.size, dtype=np.int32)) == 0
+        _INT_TWIN.clear()
+        _INT_TWIN[(id(A), n)] = twin
+    if which in ("bfs", "bfs_opbyop"):
+        g.bfs(g.Vector(n), A, arg, d, fused=(which == "bfs"))
+    elif which == "sssp":
+        g.sssp(g.Vector(n), A, arg, d)
+    elif which == "pr":
+        g.pr(g.Vector(n), A, 0.85, 0.0, hb.descriptor(mxvmode=2, max_niter=3))
+    elif which == "cc":
+        g.cc(g.Vector(n, np.int32), twin, 0, d)
+    elif which == "tc":
+        L, B = g.Matrix(n, n, np.int32), g.Matrix(n, n, np.int32)
+        if g.tril(L, twin, d) == 0:
+            g.tc(L, B, d)
+    elif which == "trace":
+        g.traceMxmTranspose("PlusMultiplies", A, A, d)
+    elif which == "mis":
+        g.mis(g.Vector(n, np.int32), twin, arg, d)
+    elif which == "gc":
+        g.gc(g.Vector(n, np.int32), twin, arg, 4096, arg % 3, d)
+    elif which == "lgc":
+        g.lgc(g.Vector(n), A, arg, 0.1, 1e-6, hb.descriptor(mxvmode=0, max_niter=4))
+    elif which == "reduce_rows":
+        g.reduce(None, "Plus", A, d, w=g.Vector(n))
 
 
 def short(call):
