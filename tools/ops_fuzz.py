@@ -193,6 +193,12 @@ def run_call(be, call, vecs, A, desc):
 _INT_TWIN = {}
 
 
+def _is_symmetric(ptr, ind, n):
+    import scipy.sparse as sp
+    M = sp.csr_matrix((np.ones(ind.size, dtype=np.int8), ind, ptr), shape=(n, n))
+    return (M != M.T).nnz == 0
+
+
 def interfere(hb, which, arg, A):
     g = hb.g
     n = A.nrows()
@@ -204,14 +210,30 @@ def interfere(hb, which, arg, A):
         assert twin.build_csr(ptr, ind, np.ones(ind.size, dtype=np.int32)) == 0
         _INT_TWIN.clear()
         _INT_TWIN[(id(A), n)] = twin
-    if which in ("bfs", "bfs_opbyop"):
-        g.bfs(g.Vector(n), A, arg, d, fused=(which == "bfs"))
-    elif which == "sssp":
-        g.sssp(g.Vector(n), A, arg, d)
+    from oracle import simple_reference as sr
+    ptr, ind, val = A.host_csr()
+    if which in ("bfs", "bfs_opbyop") and A.np_dtype == np.float32:
+        v = g.Vector(n)
+        info, _ = g.bfs(v, A, arg, d, fused=(which == "bfs"))
+        want = sr.bfs(ptr, ind, arg)[0]
+        if info != 0 or not np.array_equal(v.extractTuples()[1], want):
+            raise AssertionError("interfering %s from %d: labels differ from SimpleReferenceBfs (info %d)" % (which, arg, info))
+    elif which == "sssp" and A.np_dtype == np.float32:
+        v = g.Vector(n)
+        info, _ = g.sssp(v, A, arg, d)
+        want = sr.sssp(ptr, ind, val, arg)[0]
+        if info != 0 or not np.array_equal(v.extractTuples()[1], want):
+            raise AssertionError("interfering sssp from %d: distances differ from SimpleReferenceSssp (info %d)" % (arg, info))
     elif which == "pr":
         g.pr(g.Vector(n), A, 0.85, 0.0, hb.descriptor(mxvmode=2, max_niter=3))
     elif which == "cc":
-        g.cc(g.Vector(n, np.int32), twin, 0, d)
+        v = g.Vector(n, np.int32)
+        info, _ = g.cc(v, twin, 0, d)
+        # FastSV labels are only defined for symmetric patterns; check those
+        if info == 0 and _is_symmetric(ptr, ind, n):
+            want, k, _ = sr.cc(ptr, ind)
+            if not np.array_equal(v.extractTuples()[1], sr.cc_canonical(want)):
+                raise AssertionError("interfering cc: labels differ from SimpleReferenceCc")
     elif which == "tc":
         L, B = g.Matrix(n, n, np.int32), g.Matrix(n, n, np.int32)
         if g.tril(L, twin, d) == 0:
