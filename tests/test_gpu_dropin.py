@@ -114,3 +114,44 @@ def test_reference_gdiameter_main(graph, want, mode):
                os.path.join(DATA, graph))
     depth, _, _ = sr.bfs(ptr, ind, 0)
     assert "diameter 0:1: %d from 0" % (int(depth.max()) - 1) in out, out[-800:]
+
+
+# ---- the same mains on a graph large enough for the direction heuristic to matter: RMAT-15, written
+# out as a MatrixMarket file (the reference's data/small graphs never leave the dense representation)
+@pytest.fixture(scope="module")
+def rmat_mtx(tmp_path_factory):
+    import numpy as np
+    from graphblast_amd.graphgen import rmat_edges
+    s, d, n = rmat_edges(15, 12, seed=5)
+    keep = s != d
+    lo, hi = np.minimum(s[keep], d[keep]), np.maximum(s[keep], d[keep])
+    key = np.unique(hi.astype(np.int64) * n + lo)
+    path = tmp_path_factory.mktemp("rmat") / "rmat15.mtx"
+    with open(path, "w") as f:
+        f.write("%%MatrixMarket matrix coordinate pattern symmetric\n")
+        f.write("%d %d %d\n" % (n, n, key.size))
+        np.savetxt(f, np.stack([key // n + 1, key % n + 1], 1), fmt="%d")
+    return str(path)
+
+
+@pytest.mark.parametrize("exe,args,min_correct", [
+    ("gbfs_ref", ["--mxvmode", "0", "--struconly", "1", "--opreuse", "1", "--source", "3"], 2),
+    ("gbfs_ref", ["--mxvmode", "0", "--source", "17"], 2),
+    ("gbfs_ref", ["--mxvmode", "1", "--source", "3"], 2),
+    ("gbfs_ref", ["--mxvmode", "2", "--source", "3"], 2),
+    ("gsssp_ref", ["--mxvmode", "0", "--source", "3"], 2),
+    ("gsssp_ref", ["--mxvmode", "1", "--source", "3"], 2),
+    ("gpr_ref", ["--mxvmode", "2", "--max_niter", "10"], 0),
+    ("gcc_ref", ["--mxvmode", "0"], 1),
+    ("gcc_ref", ["--mxvmode", "2"], 1),
+    ("gtc_ref", [], 1),
+    ("gmis_ref", ["--mxvmode", "2", "--source", "2"], 3),
+    ("ggc_ref", ["--mxvmode", "2", "--gcalgo", "0", "--maxcolors", "4096", "--seed", "1"], 3),
+    ("ggc_ref", ["--mxvmode", "2", "--gcalgo", "2", "--maxcolors", "4096", "--seed", "1"], 3),
+    ("ggc_cusparse_ref", [], 3),
+    ("glgc_ref", ["--mxvmode", "2", "--max_niter", "5"], 2),
+])
+def test_reference_mains_on_rmat15(rmat_mtx, exe, args, min_correct):
+    out = _run(exe, *args, "--niter", "1", "--timing", "0", rmat_mtx)
+    assert "INCORRECT" not in out and "errors occurred" not in out, out[-1500:]
+    assert out.count("CORRECT") >= min_correct, out[-1500:]
