@@ -160,3 +160,63 @@ def test_partitioned_bfs_hip_engine_simulated_ranks(world, edgeswitch):
         got = pr_out[r][0].cpu().numpy()
         rel = np.abs(got - want_pr) / np.maximum(np.abs(want_pr), 1e-30)
         assert rel.max() <= 1e-5 and pr_out[r][1]["iterations"] == 10, (r, rel.max())
+
+
+@pytest.mark.gpu
+def test_part_level_step_kernels_direct():
+    """The one-launch level steps of the partitioned loop against numpy: seed, push_small, OR of
+    gathered bitmaps (the N > 1 combine, which no single-GPU run reaches otherwise) and apply2's three
+    totals; two owner ranges of one graph play the ranks."""
+    from graphblast_amd.dist import HipEngine, partition_bounds, bitmap_words
+    from dist_helpers import NumpyEngine
+    gr = _graph(seed=5, scale=13)
+    ptr, ind = gr["csr"]
+    n = gr["n"]
+    dev = torch.device("cuda", 0)
+    tptr = torch.from_numpy(ptr.astype(np.int64)).to(dev)
+    tind = torch.from_numpy(ind.astype(np.int64)).to(dev)
+    bounds = partition_bounds(ptr, 2)
+    nw = bitmap_words(n)
+    deg_full = torch.from_numpy(np.diff(ptr).astype(np.int32)).to(dev)
+    src = int(np.argmax(np.diff(ptr)))
+    engines, states = [], []
+    for r in range(2):
+        lo, hi = bounds[r], bounds[r + 1]
+        e0, e1 = int(ptr[lo]), int(ptr[hi])
+        lptr = (tptr[lo:hi + 1] - e0).to(torch.int32).contiguous()
+        lind = tind[e0:e1].to(torch.int32).contiguous()
+        eng = HipEngine(n, lo, lptr, lind, dev)
+        ref = NumpyEngine(n, lo, lptr.cpu(), lind.cpu(), torch.device("cpu"))
+        z = lambda: torch.zeros(nw, dtype=torch.int32, device=dev)
+        st = dict(vis=z(), new_local=z(), new_global=z(), label=torch.zeros(max(hi - lo, 1), dtype=torch.float32, device=dev))
+        eng.seed(st["vis"], st["new_global"], st["label"], src)
+        engines.append((eng, ref, lo, hi))
+        states.append(st)
+    # reference state on the host
+    hv = np.zeros(nw, dtype=np.uint32)
+    hv[src >> 5] = np.uint32(1) << np.uint32(src & 31)
+    hfront = hv.copy()
+    for level in (2, 3):
+        parts = []
+        for (eng, ref, lo, hi), st in zip(engines, states):
+            assert np.array_equal(st["vis"].cpu().numpy().view(np.uint32), hv)
+            eng.push_small(st["new_global"], st["vis"], st["new_local"])
+            want = torch.zeros(nw, dtype=torch.int32)
+            ref.push(torch.from_numpy(hfront.view(np.int32).copy()), torch.from_numpy(hv.view(np.int32).copy()), want)
+            assert np.array_equal(st["new_local"].cpu().numpy(), want.numpy()), (level, lo)
+            parts.append(st["new_local"])
+        gathered = torch.cat(parts).contiguous()
+        fresh = (parts[0].cpu().numpy().view(np.uint32) | parts[1].cpu().numpy().view(np.uint32)) & ~hv
+        for (eng, ref, lo, hi), st in zip(engines, states):
+            eng.or_parts(gathered, 2, nw, st["new_global"])
+            assert np.array_equal(st["new_global"].cpu().numpy().view(np.uint32) & ~hv, fresh)
+            found, local_edges, all_edges = eng.apply2(st["new_global"], st["vis"], st["label"], level, deg_full)
+            idx = np.nonzero(np.unpackbits(fresh.view(np.uint8), bitorder="little")[:n])[0]
+            assert found == idx.size
+            assert all_edges == int(np.diff(ptr)[idx].sum())
+            own = idx[(idx >= lo) & (idx < hi)]
+            assert local_edges == int(np.diff(ptr)[own].sum())
+            lab = st["label"].cpu().numpy()
+            assert np.all(lab[own - lo] == level)
+        hv |= fresh
+        hfront = fresh.copy()
