@@ -203,13 +203,12 @@ __global__ __launch_bounds__(kBlock) void colour_round_kernel(
         const unsigned seen = forb[wib][lane];
         if (seen) atomicOr(&fb[lane], seen);
         __builtin_amdgcn_wave_barrier();
-        __threadfence();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the ORs above are L2 atomics: drained = visible
         int ticket = 0;
         if (lane == 0) ticket = atomicAdd(&arrive[fi], 1);
         ticket = __shfl(ticket, 0, kWave);
         choose = ticket == vsplit - 1;
         if (choose) {
-          __threadfence();
           const unsigned freebits = ~__hip_atomic_load(&fb[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           fb[lane] = 0u;                                   // left clean for the next round
           if (lane == 0) arrive[fi] = 0;
@@ -307,14 +306,14 @@ __global__ __launch_bounds__(kBlock) void colour_round_kernel(
     // the last workgroup to get here settles this round's colour: the smallest index in [1, max_colors)
     // nobody saw, max_colors if there is none (min_array[0] = max_colors, gc.hpp:380-385)
     __shared__ int s_last, s_best[kWavesPerBlock];
+    // everything the settle step reads was written by device-scope atomics (they execute at L2), so
+    // draining this wave's outstanding operations is all the ordering the ticket needs -- a
+    // __threadfence() here is an L2 write-back per workgroup per round
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (threadIdx.x == 0) {
-      __threadfence();
-      s_last = last_workgroup_arrives(tickets) ? 1 : 0;
-    }
+    if (threadIdx.x == 0) s_last = last_workgroup_arrives(tickets) ? 1 : 0;
     __syncthreads();
     if (!s_last) return;
-    __threadfence();
     const int nw = (max_colors + 31) / 32;
     int best = max_colors;
     for (int w = threadIdx.x; w < nw; w += kBlock) {
