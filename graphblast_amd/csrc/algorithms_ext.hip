@@ -335,6 +335,11 @@ __global__ __launch_bounds__(kBlock) void colour_round_kernel(
   }
 }
 
+__global__ void clip_colours_kernel(int* __restrict__ colour, Index n, int max_colour) {
+  for (Index v = blockIdx.x * blockDim.x + threadIdx.x; v < n; v += gridDim.x * blockDim.x)
+    if (colour[v] > max_colour) colour[v] = 0;
+}
+
 __global__ void colour_extract_kernel(const int* __restrict__ colour, const int* __restrict__ round_colour,
                                       int* __restrict__ out, Index n, int minus) {
   for (Index v = blockIdx.x * blockDim.x + threadIdx.x; v < n; v += gridDim.x * blockDim.x) {
@@ -566,6 +571,29 @@ grb_info grb_gc(grb_vector v, grb_matrix A, int seed, grb_vector weights, int ma
     GRB_TRY(colour_by_rounds<2>(A, (const int*)w->d_val, desc->max_niter, v, 0, &iter, max_colors));
     GRB_TRY(grb_timer_stop(&ms));
     if (result) { result->iterations = iter; result->tight_ms = ms; result->last_value = 0; }
+    return GRB_SUCCESS;
+  }
+  if (algo == 1 && fused_ok) {
+    // gcMIS: colour c is the maximal independent set Luby's rounds find among the vertices left after
+    // colours < c, and with fixed weights that set is the greedy one in decreasing weight order -- so the
+    // whole algorithm is first-fit colouring in that order: v takes the smallest colour none of its
+    // heavier neighbours holds, and can do so as soon as they all have one (the same dataflow, colours
+    // chosen as in graphColor).  Equal adjacent weights block each other for ever in both formulations.
+    // The reference hands out at most max_niter colours (gc.hpp:244-247).
+    GRB_TRY(grb_timer_start());
+    GRB_TRY(colour_by_rounds<1>(A, (const int*)w->d_val, 65534, v, 0, nullptr));
+    GRB_TRY(grb_vector_set_storage(v, GRB_DENSE));
+    double mx = 0;
+    GRB_TRY(grb_reduce_vector(&mx, GRB_ACCUM_NULL, GRB_MAXIMUM_MONOID, v, desc));
+    int ncol = (int)mx;
+    if (ncol > desc->max_niter) {
+      hipLaunchKernelGGL(clip_colours_kernel, dim3(stream_grid(n)), dim3(kBlock), 0, ctx().stream, (int*)v->d_val, n,
+                         desc->max_niter);
+      GRB_HIP_TRY(hipGetLastError());
+      ncol = desc->max_niter;
+    }
+    GRB_TRY(grb_timer_stop(&ms));
+    if (result) { result->iterations = ncol + 1; result->tight_ms = ms; result->last_value = 0; }
     return GRB_SUCCESS;
   }
   if (algo == 2 && fused_ok) {
