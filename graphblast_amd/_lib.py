@@ -120,6 +120,7 @@ _SIGS = {
     "grb_bfs_part_push_small": [_vp, _i, _i, _vp, _vp, _vp],
     "grb_bfs_part_seed": [_vp, _vp, _vp, _i, _i, _i, _i],
     "grb_bitmap_or_parts": [_vp, _i, _i, _vp],
+    "grb_matrix_load_mtx": [_vp, C.c_char_p, _i, _i, _vp],
     "grb_scatter": [_vp, _vp, _vp, _d, _vp],
     "grb_vector_resize": [_vp, _i],
     "grb_trace_mxm_transpose": [C.POINTER(_d), _i, _vp, _vp, _vp],

@@ -253,6 +253,23 @@ class Matrix:
         except Exception:
             pass
 
+    @classmethod
+    def from_mtx(cls, path, dtype=np.float32, directed=0):
+        """readMtx + build with the MatrixMarket text parsed on the device (grb_matrix_load_mtx);
+        `directed` as readMtx: 0 = symmetric iff the banner says so, 1 = directed, 2 = undirected."""
+        self = cls.__new__(cls)
+        self.dtype_code = _dtype_code(dtype)
+        self.np_dtype = _NP[self.dtype_code]
+        self._h = C.c_void_p()
+        self._keep = []
+        dims = (C.c_int * 3)()
+        info = _lib.load().grb_matrix_load_mtx(C.byref(self._h), str(path).encode(), self.dtype_code, int(directed), dims)
+        if info != 0:
+            self._h = None
+            raise RuntimeError("grb_matrix_load_mtx(%s): Info %d" % (path, info))
+        self._nrows, self._ncols = int(dims[0]), int(dims[1])
+        return self
+
     def build(self, row_indices, col_indices, values, nvals=None, dup=None):
         r = np.ascontiguousarray(row_indices, dtype=np.int32)
         c = np.ascontiguousarray(col_indices, dtype=np.int32)

@@ -224,6 +224,12 @@ grb_info grb_reduce_matrix_scalar(double* val, grb_accum accum, grb_monoid op, g
 /* traceMxmTranspose (extension)   operations.hpp:698-711 -> backend :1076-1108 (trace.hpp:10-52):
  * *val = sum_i (+)_k A(i,k) (x) B(i,k), the trace of A (+).(x) B^T; A and B of one element type. */
 grb_info grb_trace_mxm_transpose(double* val, grb_semiring op, grb_matrix A, grb_matrix B, grb_descriptor desc);
+/* Extension: readMtx (graphblas/util.hpp:363-430) + Matrix::build in one call with the MatrixMarket text
+ * parsed on the device (coordinate pattern / integer / real, general / symmetric).  *A is created here;
+ * directed as readMtx (0 banner decides, 1 directed, 2 undirected); dims_out (nullable) = {nrows, ncols,
+ * nvals after the loader}.  Where the loader drops entries of a valued file each survivor keeps its own
+ * value (the reference leaves the values array unshifted there, util.hpp:311-323). */
+grb_info grb_matrix_load_mtx(grb_matrix* A, const char* path, grb_dtype dtype, int directed, grb_index* dims_out);
 /* tril   operations.hpp:872-886 -> tri.hpp:10-53 (host side, as in the reference) */
 grb_info grb_matrix_tril(grb_matrix C, grb_matrix A, grb_descriptor desc);
 
