@@ -89,3 +89,15 @@ def test_no_cpu_fallback_in_product():
         if f.endswith(".py"):
             src = open(os.path.join(ROOT, "graphblast_amd", f)).read()
             assert "import oracle" not in src and "from oracle" not in src, f
+
+
+def test_header_is_plain_c_and_the_example_links(tmp_path):
+    """include/grb_hip.h is the boundary other hosts bind (cgo / JNI / ctypes): it must be valid C99,
+    and examples/bfs_c_abi.c must compile against it and link to libgrb_hip.so with gcc alone."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path / "bfs_c_abi")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I" + os.path.join(root, "include"),
+                           os.path.join(root, "examples", "bfs_c_abi.c"), "-L" + os.path.join(root, "graphblast_amd"),
+                           "-lgrb_hip", "-Wl,-rpath," + os.path.join(root, "graphblast_amd"), "-o", out])
+    assert os.path.exists(out)

@@ -155,3 +155,15 @@ def test_reference_mains_on_rmat15(rmat_mtx, exe, args, min_correct):
     out = _run(exe, *args, "--niter", "1", "--timing", "0", rmat_mtx)
     assert "INCORRECT" not in out and "errors occurred" not in out, out[-1500:]
     assert out.count("CORRECT") >= min_correct, out[-1500:]
+
+
+def test_c_abi_example_runs(tmp_path):
+    """examples/bfs_c_abi.c (plain C99 against include/grb_hip.h) on the GPU: both BFS entry points,
+    labels checked by the program itself."""
+    out = str(tmp_path / "bfs_c_abi")
+    subprocess.check_call(["gcc", "-std=c99", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "bfs_c_abi.c"),
+                           "-L" + os.path.join(ROOT, "graphblast_amd"), "-lgrb_hip",
+                           "-Wl,-rpath," + os.path.join(ROOT, "graphblast_amd"), "-o", out])
+    res = subprocess.run([out], capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0 and "CORRECT" in res.stdout, res.stdout + res.stderr
+    assert "gfx950" in res.stdout
