@@ -185,6 +185,32 @@ class Vector:
             return GrB_UNINITIALIZED_OBJECT
         return GrB_SUCCESS
 
+    def resize(self, nsize):
+        """Vector::resize (vector.hpp:230-237 -> dense_vector.hpp:286-309 / sparse_vector.hpp:242-277): the
+        ACTIVE representation is reallocated for nsize elements keeping its first min(nsize, nvals)
+        entries (new dense elements are uninitialised there; zero here)."""
+        nsize = int(nsize)
+        if self.vec_type_ == GrB_DENSE:
+            keep = min(nsize, self.nsize_)
+            d = np.zeros(nsize, dtype=self.dtype)
+            d[:keep] = self.d_val[:keep]
+            self.d_val = d
+            self.s_ind = np.zeros(nsize, dtype=np.int32)
+            self.s_val = np.zeros(nsize + 1, dtype=self.dtype)
+            self.s_nvals = 0
+        elif self.vec_type_ == GrB_SPARSE:
+            keep = min(nsize, self.s_nvals)
+            si = np.zeros(nsize, dtype=np.int32)
+            sv = np.zeros(nsize + 1, dtype=self.dtype)
+            si[:keep] = self.s_ind[:keep]
+            sv[:keep] = self.s_val[:keep]
+            self.s_ind, self.s_val, self.s_nvals = si, sv, keep
+            self.d_val = np.zeros(nsize, dtype=self.dtype)
+        else:
+            return GrB_UNINITIALIZED_OBJECT
+        self.nsize_ = nsize
+        return GrB_SUCCESS
+
     def clear(self):
         self.vec_type_ = GrB_UNKNOWN
         self.nvals_ = 0

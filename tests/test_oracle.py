@@ -365,3 +365,72 @@ def test_diameter_driver_on_oracle(be):
             for mode in (0, 1, 2):
                 dmax, dind = alg.diameter(A, src, src + 1, be.descriptor(mxvmode=mode))
                 assert (dmax, dind) == (int(depth.max()) - 1, src), (graph, src, mode)
+
+
+# ---- the reference's container tests restated (test/gdensevector.cu, gsparsevector.cu, gdescriptor.cu):
+# the same programs, compiled unchanged, run against the HIP path in tests/test_gpu_reftests.py
+def test_reference_container_cases_on_oracle():
+    from oracle import ops
+    I = np.int32
+    # gdensevector.cu vec1: build / extract / dup / clear / size / nvals / setElement / fill / fillAscending
+    vals = np.arange(1, 11, dtype=I)
+    v = ops.Vector(10, I)
+    assert v.build_dense(vals) == 0 and np.array_equal(v.extractTuples_dense(), vals)
+    w = ops.Vector(10, I)
+    assert w.dup(v) == 0 and np.array_equal(w.extractTuples_dense(), vals)
+    assert v.size() == 10 and v.nvals() == 10
+    assert v.setElement(4, 5) == 0
+    want = vals.copy(); want[5] = 4
+    assert np.array_equal(v.extractTuples_dense(), want)
+    assert v.clear() == 0 and v.size() == 10 and v.nvals() == 0 and v.getStorage() == ops.GrB_UNKNOWN
+    f = ops.Vector(20, I)
+    assert f.fill(5) == 0 and np.array_equal(f.extractTuples_dense(), np.full(20, 5, dtype=I))
+    assert f.fillAscending() == 0 and np.array_equal(f.extractTuples_dense(), np.arange(20, dtype=I))
+    # vec2: resize keeps the first values, size and nvals follow
+    r = ops.Vector(10, I)
+    rv = np.array([1, 2, 3, 4, 5, 6, 7, 8, 0, 2], dtype=I)
+    r.build_dense(rv)
+    assert r.resize(15) == 0 and np.array_equal(r.extractTuples_dense()[:10], rv) and r.size() == 15 and r.nvals() == 15
+    # vec3: swap of two dense vectors (the reference's case uses different sizes; the contents move)
+    a, b = ops.Vector(10, I), ops.Vector(10, I)
+    a.build_dense(vals); b.build_dense(rv)
+    assert a.swap(b) == 0 and np.array_equal(a.extractTuples_dense(), rv) and np.array_equal(b.extractTuples_dense(), vals)
+    # gsparsevector.cu vec1: indices 1..10 in a vector of size 12
+    idx = np.arange(1, 11, dtype=I)
+    s = ops.Vector(12, I)
+    assert s.build_sparse(idx, idx) == 0
+    gi, gv = s.extractTuples_sparse()
+    assert np.array_equal(gi, idx) and np.array_equal(gv, idx) and s.size() == 12 and s.nvals() == 10
+    t = ops.Vector(12, I)
+    assert t.dup(s) == 0 and np.array_equal(t.extractTuples_sparse()[0], idx)
+    assert s.clear() == 0 and s.nvals() == 0 and s.getStorage() == ops.GrB_UNKNOWN
+    # vec2: sparse resize 12 -> 15 keeps the tuples (unsorted, with a repeated index, as in the test)
+    ind = np.array([1, 2, 3, 4, 5, 6, 7, 8, 0, 2], dtype=I)
+    s2 = ops.Vector(12, I)
+    s2.build_sparse(ind, ind)
+    assert s2.resize(15) == 0 and s2.size() == 15
+    gi, gv = s2.extractTuples_sparse()
+    assert np.array_equal(gi, ind) and np.array_equal(gv, ind)
+    # vec3: swap of two sparse vectors
+    ind2 = np.array([1, 2, 10, 4, 5, 6, 7, 8], dtype=I)
+    x, y = ops.Vector(12, I), ops.Vector(12, I)
+    x.build_sparse(ind, ind); y.build_sparse(ind2, ind2)
+    assert x.swap(y) == 0
+    assert np.array_equal(x.extractTuples_sparse()[0], ind2) and np.array_equal(y.extractTuples_sparse()[0], ind)
+    # a dense and a sparse vector do not swap (vector.hpp:430-434)
+    assert a.swap(x) == ops.GrB_INVALID_OBJECT
+    # gdescriptor.cu desc1 / desc2
+    fields = [ops.GrB_MASK, ops.GrB_OUTP, ops.GrB_INP0, ops.GrB_INP1, ops.GrB_MODE, ops.GrB_TA, ops.GrB_TB,
+              ops.GrB_NT, ops.GrB_MXVMODE, ops.GrB_TOL]
+    values = [ops.GrB_SCMP, ops.GrB_REPLACE, ops.GrB_TRAN, ops.GrB_TRAN, ops.GrB_FIXEDROW, 8, 8, 32, ops.GrB_PUSHONLY, 16]
+    d = ops.Descriptor()
+    for fld, val in zip(fields, values):
+        assert d.set(fld, val) == 0
+    assert [d.get(fld) for fld in fields] == values
+    d = ops.Descriptor()
+    for fld in fields:
+        d.toggle(fld)
+    for fld, val in list(zip(fields, values))[:4]:
+        assert d.get(fld) == val
+        d.toggle(fld)
+        assert d.get(fld) == ops.GrB_DEFAULT
