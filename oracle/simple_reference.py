@@ -154,6 +154,30 @@ def lgc(row_ptr, col_ind, src, alpha, eps, max_niter):
     return out, ms
 
 
+_LIB_OMP = None
+
+
+def bfs_all_cores(row_ptr, col_ind, src, nthreads=0):
+    """NOT the reference (its oracles are sequential): the same labels on all host cores, for bench.py's
+    context line.  Symmetric graphs only (the bottom-up step reads out-neighbours as in-neighbours).
+    -> (depth, ms, threads used)"""
+    global _LIB_OMP
+    if _LIB_OMP is None:
+        so = os.path.join(_HERE, "liboracle_omp.so")
+        src_c = os.path.join(_HERE, "simple_reference_omp.c")
+        if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src_c):
+            subprocess.check_call(["gcc", "-O3", "-march=native", "-fopenmp", "-shared", "-fPIC", "-o", so, src_c])
+        _LIB_OMP = ctypes.CDLL(so)
+        _LIB_OMP.oracle_bfs_all_cores.restype = ctypes.c_double
+    rp, ci = _i32(row_ptr), _i32(col_ind)
+    n = rp.size - 1
+    depth = np.zeros(n, dtype=np.float32)
+    used = ctypes.c_int(0)
+    ms = _LIB_OMP.oracle_bfs_all_cores(n, _p(rp, ctypes.c_int), _p(ci, ctypes.c_int), _p(depth, ctypes.c_float),
+                                       int(src), int(nthreads), ctypes.byref(used))
+    return depth, ms, used.value
+
+
 def bfs_do_stats(csr_ptr, csr_ind, csc_ptr, csc_ind, src, mxvmode=10, switchpoint=0.01,
                  max_niter=10000, max_levels=100000, edgeswitch=0.0):
     a, b, c, d = _i32(csr_ptr), _i32(csr_ind), _i32(csc_ptr), _i32(csc_ind)

@@ -434,3 +434,18 @@ def test_reference_container_cases_on_oracle():
         assert d.get(fld) == val
         d.toggle(fld)
         assert d.get(fld) == ops.GrB_DEFAULT
+
+
+def test_all_cores_bfs_labels_equal_the_sequential_oracle():
+    """oracle/simple_reference_omp.c (bench.py's "all host cores" context line, not the reference) gives
+    SimpleReferenceBfs's labels on symmetric graphs, in both of its directions."""
+    from oracle import simple_reference as sr
+    from graphblast_amd.graphgen import rmat_edges, finalize_edges, grid_edges
+    for gr in (finalize_edges(*rmat_edges(14, 16, seed=2), symmetrize=True),
+               finalize_edges(*grid_edges(90, keep=0.7), symmetrize=True)):
+        ptr, ind = gr["csr"]
+        for src in (int(np.argmax(np.diff(ptr))), int(np.nonzero(np.diff(ptr))[0][5])):
+            want = sr.bfs(ptr, ind, src)[0]
+            for threads in (1, 4):
+                got, ms, used = sr.bfs_all_cores(ptr, ind, src, threads)
+                assert np.array_equal(got, want) and used >= 1
