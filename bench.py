@@ -346,6 +346,22 @@ def main():
             if world > 1:
                 dist.all_reduce(tm, op=dist.ReduceOp.MAX)
                 dist.all_reduce(te, op=dist.ReduceOp.SUM)
+            if rank == 0:
+                # roofline of the kernel that does the traversing on every rank -- the one-launch BFS, measured on
+                # rank 0 exactly as in the N = 1 run (HIP events, algorithmic bytes of an accounting pass).  The
+                # partitioned loop reported as `value` is a sequence of short launches around a collective per
+                # level; its time is launch / collective latency, not a kernel's.
+                timed = [g.bfs(v, A, s_, desc, fused=True, profile=1)[1] for s_ in mine]
+                event_ms = sum(r["tight_ms"] for r in timed)
+                account = {s_: g.bfs(v, A, s_, desc, fused=True, profile=3)[1]["per_level"] for s_ in sorted(set(mine))}
+                total_bytes = sum(sum(level_bytes(account[s_], n)) for s_ in mine)
+                ach = total_bytes / (event_ms * 1e-3) / 1e9
+                roofline = {"bound": "hbm", "kernel": "bfs_persistent_kernel", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS,
+                            "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                            "traffic": pmc_traffic("bfs_persistent_kernel"), "launches": len(mine),
+                            "avg_launch_ms": round(event_ms / len(mine), 5),
+                            "algorithmic_bytes_per_launch": int(total_bytes / len(mine)),
+                            "note": "per-GPU kernel of the source_sharded_replicas leg, rank 0"}
             extra["source_sharded_replicas"] = {
                 "value": float(te.item()) / float(tm.item()), "unit": "TEPS", "scaling": "weak",
                 "steps_per_gpu": args.steps, "ms_per_step_per_gpu": float(tm.item()) / args.steps * 1e3,
