@@ -1,4 +1,4 @@
-"""GPU suite: differential fuzzing of op SEQUENCES (tools/ops_fuzz.py) -- random vxm / mxv / eWiseAdd /
+"""GPU suite: differential fuzzing of op SEQUENCES (tests/tools/ops_fuzz.py) -- random vxm / mxv / eWiseAdd /
 eWiseMult / assign / reduce / build / dup / swap / clear calls on a shared pool of vectors, in lock-step
 through the C ABI and through the oracle, every Info code and the whole observable state compared
 after every call.  Three campaigns: float vectors with all 17 semirings, int32 vectors, and the
@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.mark.parametrize("flags,seed", [((), 11), (("--int",), 12), (("--struconly",), 13)])
 def test_op_sequences_match_the_oracle(flags, seed):
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "ops_fuzz.py"), "--seqs", "250", "--len", "40",
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "tools", "ops_fuzz.py"), "--seqs", "250", "--len", "40",
                           "--seed", str(seed)] + list(flags), capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-1000:]
     assert "diverging sequences: 0" in out.stdout

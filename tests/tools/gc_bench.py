@@ -1,4 +1,4 @@
-"""MIS / graph colouring timings (GPU box): python tools/gc_bench.py [scale ...]
+"""MIS / graph colouring timings (GPU box): python tests/tools/gc_bench.py [scale ...]
 Op-by-op drivers (grb_mis, grb_gc algo 0/1/2) and grb_graph_color on symmetrised RMAT graphs;
 every result is checked with the restated SimpleVerifyMis / SimpleVerifyGc."""
 import sys

@@ -1,5 +1,5 @@
 """MatrixMarket ingest: text parsed on the device (grb_matrix_load_mtx) against the host paths.  GPU box.
-python tools/mtx_bench.py [scale]"""
+python tests/tools/mtx_bench.py [scale]"""
 import os, sys, time, tempfile
 import numpy as np
 sys.path.insert(0, ".")

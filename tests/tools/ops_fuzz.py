@@ -5,7 +5,7 @@ contents, the descriptor's lastmxv -- compared after each call.  Sequences matte
 containers keep both representations and convert in place, so what an op does depends on what the
 previous ones left behind.
 
-usage (GPU box): python tools/ops_fuzz.py [--seqs 200] [--len 30] [--seed 0] [--n 70]
+usage (GPU box): python tests/tools/ops_fuzz.py [--seqs 200] [--len 30] [--seed 0] [--n 70]
 Prints the first divergence of every failing sequence with the calls that led to it; exit code 1 if
 any.  Test infrastructure: imports oracle/ as the checker.
 """
@@ -15,7 +15,7 @@ import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
