@@ -89,6 +89,12 @@ def test_no_cpu_fallback_in_product():
         if f.endswith(".py"):
             src = open(os.path.join(ROOT, "graphblast_amd", f)).read()
             assert "import oracle" not in src and "from oracle" not in src, f
+    # the oracle is reachable from tests/ (incl. tests/tools/), smoke() and bench.py's CPU-baseline leg only
+    for d in ("tools", "examples", os.path.join("graphblast_amd", "csrc")):
+        for f in os.listdir(os.path.join(ROOT, d)):
+            if f.endswith((".py", ".sh", ".hip", ".hpp", ".c")):
+                src = open(os.path.join(ROOT, d, f)).read()
+                assert "import oracle" not in src and "from oracle" not in src and "liboracle" not in src, (d, f)
 
 
 def test_header_is_plain_c_and_the_example_links(tmp_path):
