@@ -12,6 +12,7 @@ on the GPU box.
                                  formulas
   tests/golden/semiring_ref.json identity/add/mul tables printed by oracle/_ref/semiring_ref,
                                  i.e. by the reference's own graphblas/stddef.hpp
+  tests/golden/types_ref.json    the enumerations of the reference's own graphblas/types.hpp (oracle/_ref/types_ref)
   tests/golden/mmio_ref.json     banner + size of every data file as parsed by the
                                  reference's own graphblas/mmio.hpp (oracle/_ref/libmmio_ref.so)
   tests/golden/known_answers.json  outputs of the reference CPU oracles recorded in
@@ -65,6 +66,9 @@ def main():
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "ref"])
     out = subprocess.check_output([os.path.join(ROOT, "oracle/_ref/semiring_ref")])
     json.dump(json.loads(out), open(os.path.join(HERE, "semiring_ref.json"), "w"), indent=1, sort_keys=True)
+
+    out = subprocess.check_output([os.path.join(ROOT, "oracle/_ref/types_ref")])
+    json.dump(json.loads(out), open(os.path.join(HERE, "types_ref.json"), "w"), indent=1, sort_keys=True)
 
     lib = ctypes.CDLL(os.path.join(ROOT, "oracle/_ref/libmmio_ref.so"))
     libc = ctypes.CDLL(None)

@@ -107,3 +107,55 @@ def test_header_is_plain_c_and_the_example_links(tmp_path):
                            os.path.join(root, "examples", "bfs_c_abi.c"), "-L" + os.path.join(root, "graphblast_amd"),
                            "-lgrb_hip", "-Wl,-rpath," + os.path.join(root, "graphblast_amd"), "-o", out])
     assert os.path.exists(out)
+
+
+def test_enumerations_equal_the_references_types_hpp(tmp_path):
+    """Info / Storage / Desc_field / Desc_value numbering in all four places it is written down -- the C ABI
+    header, the C++ frontend header, the Python mirror, the oracle -- against the values printed by the
+    reference's own graphblas/types.hpp (oracle/_ref/types_ref -> tests/golden/types_ref.json)."""
+    import json
+    import subprocess
+    ref = json.load(open(os.path.join(ROOT, "tests", "golden", "types_ref.json")))
+    assert ref["sizeof_Index"] == 4 and ref["sizeof_T"] == 4
+    names = [k for k in ref if k.startswith("GrB_")]
+    # Python mirror and oracle
+    import graphblast_amd as g
+    from oracle import ops
+    for k in names:
+        if hasattr(g, k):
+            assert getattr(g, k) == ref[k], ("api.py", k)
+        if hasattr(ops, k):
+            assert getattr(ops, k) == ref[k], ("oracle/ops.py", k)
+    assert all(hasattr(g, k) for k in ("GrB_SUCCESS", "GrB_PANIC", "GrB_MASK", "GrB_MXVMODE", "GrB_SCMP", "GrB_PULLONLY"))
+    # C ABI header: GRB_X <-> GrB_X (GRB_HIP takes the slot of GrB_CUDA)
+    src = tmp_path / "enums.c"
+    lines = ['#include <stdio.h>', '#include "grb_hip.h"', 'int main(void) {']
+    cnames = {k: "GRB_" + k[4:] for k in names}
+    cnames["GrB_CUDA"] = "GRB_HIP"
+    hdr = open(os.path.join(ROOT, "include", "grb_hip.h")).read()
+    checked = 0
+    for k, c in cnames.items():
+        if re.search(r"\b%s\b" % c, hdr):
+            lines.append('  printf("%s %%d\\n", (int)%s);' % (k, c))
+            checked += 1
+    lines += ["  return 0;", "}"]
+    src.write_text("\n".join(lines))
+    exe = str(tmp_path / "enums")
+    subprocess.check_call(["gcc", "-std=c99", "-I" + os.path.join(ROOT, "include"), str(src), "-o", exe])
+    for ln in subprocess.check_output([exe], text=True).split("\n"):
+        if ln:
+            k, v = ln.split()
+            assert int(v) == ref[k], ("grb_hip.h", k)
+    assert checked >= 35
+    # C++ frontend header
+    cpp = tmp_path / "enums.cpp"
+    body = "\n".join('  std::printf("%s %%d\\n", static_cast<int>(graphblas::%s));' % (k, k) for k in names)
+    cpp.write_text('#include <cstdio>\n#include "graphblas/graphblas.hpp"\nint main() {\n%s\n  return 0;\n}\n' % body)
+    exe2 = str(tmp_path / "enums_cpp")
+    subprocess.check_call(["g++", "-std=c++11", "-w", "-fpermissive", "-I" + os.path.join(ROOT, "include"), str(cpp),
+                           "-L" + os.path.join(ROOT, "graphblast_amd"), "-lgrb_hip",
+                           "-Wl,-rpath," + os.path.join(ROOT, "graphblast_amd"), "-o", exe2])
+    for ln in subprocess.check_output([exe2], text=True).split("\n"):
+        if ln:
+            k, v = ln.split()
+            assert int(v) == ref[k], ("graphblas.hpp", k)
