@@ -1,8 +1,8 @@
 """Differential stress of the one-launch BFS against the oracle's sequential BFS: many sources,
 symmetric and directed RMAT, all three mxvmodes, with and without the edge-aware switch.
-usage: tools/bfs_stress.py [scale] [sources]"""
+usage: python tests/tools/bfs_stress.py [scale] [sources]"""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import graphblast_amd as g
 from graphblast_amd.graphgen import rmat_edges, finalize_edges, random_sources

@@ -1,7 +1,7 @@
 """Differential stress of the one-launch SSSP against the oracle's Dijkstra (integer weights, so
 float sums are exact): many sources, symmetric and directed RMAT plus a grid."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import graphblast_amd as g
 from graphblast_amd.graphgen import rmat_edges, grid_edges, finalize_edges, random_sources

@@ -1,7 +1,7 @@
 """Triangle counting (masked SpGEMM L x L^T .* L + reduce) on RMAT-<scale>: GPU time vs the
-oracle's SimpleReferenceTc on one host core.  usage: tools/tc_bench.py [scale]"""
+oracle's SimpleReferenceTc on one host core.  usage: python tests/tools/tc_bench.py [scale]"""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import graphblast_amd as g
 from graphblast_amd.graphgen import rmat_edges, finalize_edges
