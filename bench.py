@@ -177,6 +177,8 @@ def main():
         ob = level_bytes(one, n)
         extra["bfs_total"] = {
             "tight_ms_mean": round(tight_ms / args.steps, 4),
+            "tight_ms_median": round(float(np.median([r["tight_ms"] for r in results])), 4),
+            "tight_ms_min": round(float(min(r["tight_ms"] for r in results)), 4),
             "graph500_teps": edges / 2 / elapsed,
             "levels_source0": [dict(dir=L["direction"], nf=L["frontier"], edges=L["frontier_edges"],
                                     found=L["discovered"], ms=round(L["ms"], 4), bytes=int(b))
