@@ -449,3 +449,82 @@ def test_all_cores_bfs_labels_equal_the_sequential_oracle():
             for threads in (1, 4):
                 got, ms, used = sr.bfs_all_cores(ptr, ind, src, threads)
                 assert np.array_equal(got, want) and used >= 1
+
+
+def test_oracle_products_against_dense_definitions(be):
+    """The oracle's pull (generic SpMV) and push (SpMSpV) paths against the textbook dense definition of the
+    semiring product on random small inputs: w = u (+).(x) A for vxm, A (+).(x) u for mxv; a failing mask
+    entry yields the identity in pull mode and is dropped in push mode; accum combines with the semiring's
+    add.  (The reference's unit tests pin literal cases; this pins the restatement between them.)"""
+    from oracle import ops
+    from oracle.semiring import Semiring
+    rng = np.random.default_rng(12)
+    defs = {
+        "PlusMultiplies": (lambda a, b: a * b, np.add, 0.0),
+        "MinimumPlus": (lambda a, b: a + b, np.minimum, np.finfo(np.float32).max),
+        "MaximumMultiplies": (lambda a, b: a * b, np.maximum, 0.0),
+        "LogicalOrAnd": (lambda a, b: ((a != 0) & (b != 0)).astype(np.float32), np.logical_or, 0.0),
+    }
+    for trial in range(6):
+        n = int(rng.integers(5, 40))
+        dense = (rng.random((n, n)) < 0.2) * rng.integers(1, 4, (n, n))
+        r, c = np.nonzero(dense)
+        A = ops.Matrix(n, n, np.float32)
+        A.build(r.astype(np.int32), c.astype(np.int32), dense[r, c].astype(np.float32))
+        uvals = (rng.integers(1, 4, n) * (rng.random(n) < 0.6)).astype(np.float32)
+        maskv = (rng.random(n) < 0.5).astype(np.float32)
+        wprev = rng.integers(0, 3, n).astype(np.float32)
+        for name, (mul, add, ident) in defs.items():
+            sr = Semiring(name, np.float32)
+            for is_vxm in (True, False):
+                M = dense.T if is_vxm else dense                      # out[i] = (+)_j M[i, j] (x) u[j]
+                want = np.full(n, ident, dtype=np.float64)
+                for i in range(n):
+                    js = np.nonzero(M[i])[0]
+                    acc = ident
+                    for j in js:
+                        acc = add(acc, mul(np.float32(M[i, j]), uvals[j]))
+                    want[i] = acc
+                want = want.astype(np.float32)
+                for use_mask, scmp, accum in ((0, 0, 0), (1, 0, 0), (1, 1, 0), (0, 0, 1)):
+                    # pull: dense u, mode 2
+                    d = be.descriptor(mxvmode=2, fusedmask=0)
+                    if scmp:
+                        d.set(ops.GrB_MASK, ops.GrB_SCMP)
+                    u = ops.Vector(n); u.build_dense(uvals)
+                    w = ops.Vector(n); w.build_dense(wprev)
+                    mk = None
+                    if use_mask:
+                        mk = ops.Vector(n); mk.build_dense(maskv)
+                    info = (ops.vxm(w, mk, accum or None, sr, u, A, d) if is_vxm else ops.mxv(w, mk, accum or None, sr, A, u, d))
+                    assert info == 0
+                    exp = want.copy()
+                    if use_mask:
+                        passes = (maskv == 0) if scmp else (maskv != 0)
+                        exp[~passes] = ident
+                    if accum:
+                        exp = np.array([add(a, b) for a, b in zip(wprev, exp)], dtype=np.float32)
+                    got = w.extractTuples_dense()
+                    if name == "LogicalOrAnd" and not accum:
+                        got, exp = (got != 0), (exp != 0)
+                    assert np.array_equal(got, exp), (trial, name, is_vxm, use_mask, scmp, accum)
+                # push: sparse u (stored entries = nonzeros), mode 1, key-value; unmasked
+                if name == "LogicalOrAnd":
+                    continue
+                idx = np.nonzero(uvals)[0].astype(np.int32)
+                if idx.size == 0:
+                    continue
+                d = be.descriptor(mxvmode=1)
+                u = ops.Vector(n); u.build_sparse(idx, uvals[idx])
+                w = ops.Vector(n)
+                info = ops.vxm(w, None, None, sr, u, A, d) if is_vxm else ops.mxv(w, None, None, sr, A, u, d)
+                assert info == 0 and w.getStorage() == ops.GrB_SPARSE
+                gi, gv = w.extractTuples_sparse()
+                # reached outputs = rows with at least one stored partner in the sparse input
+                reach = np.array([np.any((M[i] != 0) & (uvals != 0)) for i in range(n)])
+                assert np.array_equal(gi, np.nonzero(reach)[0]), (trial, name, is_vxm)
+                want_push = np.array([
+                    (lambda js: (lambda acc: acc)(
+                        __import__("functools").reduce(lambda a, j: add(a, mul(np.float32(M[i, j]), uvals[j])), js, ident)))(
+                        [j for j in np.nonzero(M[i])[0] if uvals[j] != 0]) for i in np.nonzero(reach)[0]], dtype=np.float32)
+                assert np.array_equal(gv, want_push), (trial, name, is_vxm)
