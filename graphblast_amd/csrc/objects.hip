@@ -796,11 +796,11 @@ grb_info grb_matrix_build(grb_matrix A, const grb_index* rows, const grb_index* 
   Index *d_r = nullptr, *d_c = nullptr;
   void* d_v = nullptr;
   const size_t cap = nvals > 0 ? (size_t)nvals : 1;
-  GRB_HIP_TRY(hipMalloc((void**)&d_r, 4 * cap));
-  GRB_HIP_TRY(hipMalloc((void**)&d_c, 4 * cap));
-  GRB_HIP_TRY(hipMalloc(&d_v, 4 * cap));
   grb_info info = GRB_SUCCESS;
-  if (nvals > 0) {
+  if (hipMalloc((void**)&d_r, 4 * cap) != hipSuccess || hipMalloc((void**)&d_c, 4 * cap) != hipSuccess ||
+      hipMalloc(&d_v, 4 * cap) != hipSuccess)
+    info = GRB_OUT_OF_MEMORY;                              // whatever was allocated is released below
+  if (info == GRB_SUCCESS && nvals > 0) {
     if (hipMemcpy(d_r, rows, 4 * cap, hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(d_c, cols, 4 * cap, hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(d_v, values, 4 * cap, hipMemcpyHostToDevice) != hipSuccess)
