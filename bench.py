@@ -24,8 +24,11 @@ Rank 0 prints ONE JSON line.  Extra objects on it:
                 fraction of the 8 TB/s HBM peak
   cpu_all_cores context only (not the reference, whose CPU path is sequential): the same labels from an
                 OpenMP BFS on every host core
-  cpu_baseline  the oracle's SimpleReferenceBfs restatement (one host core) on a bounded
+  cpu_baseline  the reference's own SimpleReferenceBfs (oracle/_ref/libsimple_ref.so; the restatement in
+                oracle/simple_reference.c when that library is absent), one host core, on a bounded
                 sample of the same workload (rank 0, N = 1 only)
+  parity        the labels of every source of that sample from the HIP path compared bit-exactly with
+                the CPU's, and the reached / edge counts of the timed steps; a mismatch fails the run
 """
 import argparse
 import json
@@ -43,10 +46,12 @@ HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8 TB/s spec
 
 
 def pmc_traffic(kernel_key):
-    """HBM bytes per launch from the committed PMC passes (profiles/*/pmc_traffic.json: separate
+    """(HBM bytes per launch, where it came from).  PMC counters cannot be read from inside this process; the
+    number is the one recorded by the latest committed PMC passes (profiles/rNN/pmc_traffic.json: separate
     `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this same command, FETCH_SIZE doubled as
-    calibrated there on kernels of known byte count), or None."""
-    best = None
+    calibrated there on kernels of known byte count) -- the source is named on the line so a stale value
+    cannot pass for a live one; (None, None) when no pass has been committed."""
+    best, where = None, None
     pdir = os.path.join(ROOT, "profiles")
     for d in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
         f = os.path.join(pdir, d, "pmc_traffic.json")
@@ -54,7 +59,8 @@ def pmc_traffic(kernel_key):
             for name, rec in json.load(open(f)).get("kernels", {}).items():
                 if kernel_key in name:
                     best = rec.get("hbm_bytes_per_launch", rec.get("hbm_bytes_per_launch_raw"))
-    return best
+                    where = "profiles/%s/pmc_traffic.json (separate rocprofv3 --pmc passes, not this run)" % d
+    return best, where
 
 
 def level_bytes(levels, n):
@@ -84,10 +90,12 @@ def main():
     ap.add_argument("--edgeswitch", type=float, default=0.08,
                     help="graphblast_amd extension: also leave push when frontier out-edges > edgeswitch*nnz "
                          "(0 = the reference's vertex-count rule only)")
+    ap.add_argument("--no-refrule", action="store_true",
+                    help="skip the second timing of the same steps with edgeswitch = 0 (the reference's vertex-count "
+                         "direction rule alone), reported as bfs_total.reference_direction_rule_only")
     ap.add_argument("--extras", action="store_true",
-                    help="also time (a) the same steps with edgeswitch = 0, the reference's vertex-count rule alone, "
-                         "and (b) the SpMV kernel on a road-like grid; off by default because both launch the "
-                         "kernels of the main measurement again and would mix into a rocprof average of this command")
+                    help="also time the SpMV kernel on a road-like grid (launches the SpMV kernels of the main "
+                         "measurement again: would mix into a rocprof average of this command)")
     ap.add_argument("--partitioned", action="store_true",
                     help="use the 1-D partitioned level loop even at N = 1 (debugging the N > 1 path)")
     args = ap.parse_args()
@@ -96,10 +104,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: become the launcher (one rank per GPU over RCCL, rendezvous on 127.0.0.1)
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        os.execv(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+                                  "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+                                  "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:])
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..."
-                             % (args.gpus, args.gpus))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
@@ -169,7 +184,8 @@ def main():
         ach = total_bytes / (event_ms * 1e-3) / 1e9
         roofline = {"bound": "hbm", "kernel": "bfs_persistent_kernel", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-                    "traffic": pmc_traffic("bfs_persistent_kernel"), "launches": args.steps,
+                    "traffic": pmc_traffic("bfs_persistent_kernel")[0],
+                    "traffic_source": pmc_traffic("bfs_persistent_kernel")[1], "launches": args.steps,
                     "avg_launch_ms": round(event_ms / args.steps, 5),
                     "algorithmic_bytes_per_launch": int(total_bytes / args.steps)}
         tight_ms = sum(r["tight_ms"] for r in results)
@@ -187,8 +203,9 @@ def main():
 
         # ---- the same steps with the reference's direction rule alone (vertex-count switch,
         #      descriptor arg edgeswitch = 0), for comparison with the reported configuration
-        #      (opt-in: it launches the same kernel and would mix into a rocprof average of this command)
-        if args.extras:
+        #      (it launches the same kernel again, after every launch of the main measurement:
+        #      tools/summarize_profiles.py splits a kernel trace of this command by launch order)
+        if not args.no_refrule:
             desc0 = g.Descriptor()
             assert desc0.loadArgs(mxvmode=0, struconly=1, opreuse=1, earlyexit=1, edgeswitch=0.0) == 0
             for i in range(min(args.warmup, 2)):
@@ -219,7 +236,8 @@ def main():
                          "algorithmic_bytes_per_launch": sb, "avg_launch_ms": round(ms, 5),
                          "achieved": round(sb / (ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(sb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                         "traffic": pmc_traffic("spmv_hub_kernel"), "gflops": round(2 * nnz / (ms * 1e-3) / 1e9, 1)}
+                         "traffic": pmc_traffic("spmv_hub_kernel")[0],
+                         "traffic_source": pmc_traffic("spmv_hub_kernel")[1], "gflops": round(2 * nnz / (ms * 1e-3) / 1e9, 1)}
 
         # ---- the same SpMV kernel where the gathers are local (a road-like 4096^2 grid in natural
         #      order): what it does when the L2 request rate of scattered gathers is not the wall
@@ -274,16 +292,51 @@ def main():
         #      timed beside the GPU run; never part of the product path)
         if not args.no_cpu_baseline:
             from oracle import simple_reference as sr
+            from oracle import ref_simple
             ind_host = tind.cpu().numpy()
             nsamp = min(24, len(sources))          # ~0.45 s each: about 10 s of single-core work
+            use_ref = ref_simple.available()       # the reference's own test_bfs.hpp, compiled into oracle/_ref
             cpu_edges, cpu_ms = 0, 0.0
+            step_of = {}
+            for i in range(args.steps):
+                step_of.setdefault(sources[i % len(sources)], []).append(i)
+            mismatches = []
             for s in sources[:nsamp]:
-                depth, _, ms_ = sr.bfs(ptr_host, ind_host, s)
+                if use_ref:
+                    t0c = time.perf_counter()
+                    depth = ref_simple.bfs(ptr_host, ind_host, s)[0]
+                    ms_ = (time.perf_counter() - t0c) * 1e3   # around the call: n-sized init + the traversal loop
+                else:
+                    depth, _, ms_ = sr.bfs(ptr_host, ind_host, s)
                 cpu_edges += int(deg[depth != 0].sum())
                 cpu_ms += ms_
-            extra["cpu_baseline"] = {"value": cpu_edges / (cpu_ms * 1e-3), "unit": "TEPS", "cores": 1, "kind": "port",
-                                     "sample": "SimpleReferenceBfs restatement (oracle/simple_reference.c), %d of the "
-                                               "timed sources on the same RMAT-%d graph, traversal loop only" % (nsamp, args.scale),
+                # ---- parity: the labels of this source from the HIP path, bit-exact against the CPU's, and the
+                #      (reached, edges) of every TIMED step from this source against what the CPU labels imply
+                info, _ = g.bfs(v, A, s, desc, fused=True)
+                assert info == 0, info
+                got = v.extractTuples()[1]
+                if not np.array_equal(got, depth):
+                    mismatches.append(("labels", s))
+                want_reached, want_edges = int(np.count_nonzero(depth)), int(deg[depth != 0].sum())
+                for i in step_of.get(s, []):
+                    if (results[i]["reached"], results[i]["edges_traversed"]) != (want_reached, want_edges):
+                        mismatches.append(("timed step %d" % i, s))
+            extra["parity_checked_sources"] = nsamp
+            extra["parity"] = {"checked_sources": nsamp, "mismatches": len(mismatches),
+                               "checker": "oracle/_ref/libsimple_ref.so (the reference's SimpleReferenceBfs)" if use_ref
+                               else "oracle/simple_reference.c (restatement)",
+                               "what": "depth labels bit-exact per source; reached / edges of every timed step from "
+                                       "those sources"}
+            if mismatches:
+                print(json.dumps({"error": "parity", "mismatches": mismatches[:10]}))
+                raise SystemExit(3)
+            extra["cpu_baseline"] = {"value": cpu_edges / (cpu_ms * 1e-3), "unit": "TEPS", "cores": 1,
+                                     "kind": "reference" if use_ref else "port",
+                                     "sample": ("%s, %d of the timed sources on the same RMAT-%d graph"
+                                                % ("the reference's own SimpleReferenceBfs (test_bfs.hpp compiled into "
+                                                   "oracle/_ref/libsimple_ref.so), whole call" if use_ref else
+                                                   "SimpleReferenceBfs restatement (oracle/simple_reference.c), "
+                                                   "traversal loop only", nsamp, args.scale)),
                                      "ms_per_bfs": round(cpu_ms / nsamp, 2)}
             # context only, NOT the reference (whose CPU path is sequential): the same labels with a
             # direction-switching level-synchronous BFS on every host core (oracle/simple_reference_omp.c)
@@ -360,7 +413,8 @@ def main():
                 ach = total_bytes / (event_ms * 1e-3) / 1e9
                 roofline = {"bound": "hbm", "kernel": "bfs_persistent_kernel", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS,
                             "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-                            "traffic": pmc_traffic("bfs_persistent_kernel"), "launches": len(mine),
+                            "traffic": pmc_traffic("bfs_persistent_kernel")[0],
+                            "traffic_source": pmc_traffic("bfs_persistent_kernel")[1], "launches": len(mine),
                             "avg_launch_ms": round(event_ms / len(mine), 5),
                             "algorithmic_bytes_per_launch": int(total_bytes / len(mine)),
                             "note": "per-GPU kernel of the source_sharded_replicas leg, rank 0"}
