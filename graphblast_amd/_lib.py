@@ -91,6 +91,9 @@ _SIGS = {
     "grb_matrix_host_csr": [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp)],
     "grb_matrix_host_csc": [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp)],
     "grb_matrix_set_values": [_vp, _vp],
+    "grb_cache_name": [C.c_char_p, _i, C.c_char_p, C.c_size_t],
+    "grb_matrix_write_cache": [_vp, C.c_char_p],
+    "grb_matrix_build_cache": [_vp, C.c_char_p],
     "grb_vxm": [_vp, _vp, _i, _i, _vp, _vp, _vp],
     "grb_mxv": [_vp, _vp, _i, _i, _vp, _vp, _vp],
     "grb_eWiseMult": [_vp, _vp, _i, _i, _vp, _vp, _vp],

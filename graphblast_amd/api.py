@@ -8,6 +8,7 @@ not raise) exactly like the reference's functions; container constructors raise 
 allocation failure.  All compute happens in libgrb_hip.so -- this file moves pointers.
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -336,9 +337,29 @@ class Matrix:
     def host_csc(self):
         return self._host("grb_matrix_host_csc")
 
+    def write_cache(self, path):
+        """The reference's binary CSR cache (sparse_matrix.hpp:328-348): int32 nrows, nvals, rowptr, colind."""
+        return _lib.load().grb_matrix_write_cache(self._h, os.fsencode(str(path)))
+
+    def build_cache(self, path):
+        """Matrix::build(dat_name) (sparse_matrix.hpp:355-407): values = 1, CSC made on the device."""
+        info = _lib.load().grb_matrix_build_cache(self._h, os.fsencode(str(path)))
+        if info == 0:
+            n = C.c_int(0)
+            _lib.call("grb_matrix_nrows", self._h, C.byref(n))
+            self._nrows = self._ncols = n.value
+        return info
+
     def set_values(self, csr_values):
         v = np.ascontiguousarray(csr_values, dtype=self.np_dtype)
         return _lib.load().grb_matrix_set_values(self._h, v.ctypes.data)
+
+
+def cache_name(mtx_path, is_undirected):
+    """util.hpp:340-357 (convert): `<dir>/.<file>.<ud|d>.<nosl|sl>.bin`."""
+    buf = C.create_string_buffer(1024)
+    _lib.call("grb_cache_name", os.fsencode(str(mtx_path)), int(bool(is_undirected)), buf, 1024)
+    return buf.value.decode()
 
 
 # ---- graphblas/operations.hpp ------------------------------------------------------

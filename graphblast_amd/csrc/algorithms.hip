@@ -39,7 +39,7 @@ grb_info grb_sssp(grb_vector v, grb_matrix A, grb_index source, grb_descriptor d
   int first_iter = 1;
   float fused_ms = 0.f;
   bool continued = false;
-  if (fused_ok && A->built && v->nsize == n) {
+  if (fused_ok && A->built && A->format == 0 && v->nsize == n) {   // CSR-only format: the op-by-op rounds (forced push)
     // the same synchronous rounds in one launch (sssp_persist.hip); not eligible -> op by op.  A
     // dense frontier is handed back: from there the pull product of the op-by-op rounds is faster.
     GRB_TRY(grb_vector_set_storage(v, GRB_DENSE));
@@ -181,7 +181,7 @@ grb_info grb_pr(grb_vector p, grb_matrix A, float alpha, float eps, grb_descript
   if (!A->built) return GRB_UNINITIALIZED_OBJECT;
   const Index n = A->nrows;
   static const bool fused_ok = [] { const char* e = getenv("GRB_PR_FUSED"); return !e || atoi(e) != 0; }();
-  if (!fused_ok || desc->desc[GRB_MXVMODE] == GRB_PUSHONLY || !(alpha < 1.f) || p->dtype != GRB_F32 ||
+  if (!fused_ok || A->format != 0 || desc->desc[GRB_MXVMODE] == GRB_PUSHONLY || !(alpha < 1.f) || p->dtype != GRB_F32 ||
       A->dtype != GRB_F32 || A->nrows != A->ncols || p->nsize != n || !A->csc.ptr)
     return pr_op_by_op(p, A, alpha, eps, desc, result);
   Context& c = ctx();

@@ -87,6 +87,14 @@ extern "C" grb_info grb_bfs_fused(grb_vector v, grb_matrix A, grb_index source, 
   if (v->dtype != GRB_F32) return GRB_DOMAIN_MISMATCH;
   if (A->nrows != A->ncols || v->nsize != A->nrows) return GRB_DIMENSION_MISMATCH;
   if (source < 0 || source >= A->nrows) return GRB_INVALID_INDEX;
+  if (A->format != 0) {
+    // GRB_SPARSE_MATRIX_FORMAT = 1: no CSC, vxm pushes whatever the mxvmode says (operations.hpp:131-133);
+    // the call sequence of algorithm/bfs.hpp over the ops reproduces exactly that
+    grb_info i = grb_bfs(v, A, source, desc, result);
+    if (i == GRB_SUCCESS && result) GRB_TRY(bfs_tally_labels((const float*)v->d_val, A->csr.ptr, A->nrows,
+                                                              &result->edges_traversed, &result->reached));
+    return i;
+  }
   GRB_TRY(ctx_init());
   Context& c = ctx();
   hipStream_t s = c.stream;

@@ -185,12 +185,16 @@ static int bits_for(Index dim) {
 }
 
 // ---- coordinate list -> keys, loader options
+// A coordinate outside [0, nrows) x [0, ncols) raises *bad (the host then returns
+// GrB_INDEX_OUT_OF_BOUNDS before anything is compressed: such a key would index past ptr[]).
 __global__ void make_keys_kernel(const Index* __restrict__ major, const Index* __restrict__ minor,
                                  const unsigned int* __restrict__ vals, unsigned int one, long long n, int symmetrize,
-                                 unsigned long long* __restrict__ keys, unsigned int* __restrict__ pay) {
+                                 Index nrows, Index ncols, unsigned long long* __restrict__ keys,
+                                 unsigned int* __restrict__ pay, unsigned int* __restrict__ bad) {
   const long long stride = (long long)gridDim.x * blockDim.x;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     const unsigned long long r = (unsigned int)major[i], c = (unsigned int)minor[i];
+    if (r >= (unsigned long long)(unsigned int)nrows || c >= (unsigned long long)(unsigned int)ncols) *bad = 1u;
     const unsigned int v = vals ? vals[i] : one;
     keys[i] = (r << 32) | c;
     pay[i] = v;
@@ -233,8 +237,10 @@ __global__ void split_sorted_kernel(const unsigned long long* __restrict__ keys,
                                     unsigned int* __restrict__ val) {
   const long long stride = (long long)gridDim.x * blockDim.x;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i <= n; i += stride) {
-    const long long cur = i < n ? (long long)(keys[i] >> 32) : (long long)nmajor;
-    const long long prev = i > 0 ? (long long)(keys[i - 1] >> 32) : -1;
+    long long cur = i < n ? (long long)(keys[i] >> 32) : (long long)nmajor;
+    long long prev = i > 0 ? (long long)(keys[i - 1] >> 32) : -1;
+    if (cur > nmajor) cur = nmajor;                       // defence in depth: inputs are range-checked upstream
+    if (prev > nmajor) prev = nmajor;
     for (long long r = prev + 1; r <= cur; ++r) ptr[r] = (Index)i;
     if (i < n) { ind[i] = (Index)(unsigned int)keys[i]; val[i] = pay[i]; }
   }
@@ -259,6 +265,7 @@ grb_info device_build_from_coo(grb_matrix A, const Index* d_rows, const Index* d
   Context& c = ctx();
   hipStream_t s = c.stream;
   const bool symmetrize = (flags & 1) != 0;
+  if (symmetrize && A->nrows != A->ncols) return GRB_DIMENSION_MISMATCH;   // the reverse of (r, c) must be a valid entry
   const long long n0 = symmetrize ? 2 * nvals_in : nvals_in;
   if (n0 > 0x7fffffffll) return GRB_OUT_OF_MEMORY;      // 32-bit indices throughout, like the reference
   const int nblocks = (int)((n0 + kSortTile - 1) / kSortTile) + 1;
@@ -266,7 +273,7 @@ grb_info device_build_from_coo(grb_matrix A, const Index* d_rows, const Index* d
   void* raw = nullptr;
   const size_t cap = (size_t)(n0 > 0 ? n0 : 1);
   const size_t cnt_elems = 256 * (size_t)nblocks > cap + 1 ? 256 * (size_t)nblocks : cap + 1;
-  const size_t bytes = 2 * 8 * cap + 2 * 4 * cap + 4 * cnt_elems + 4 * (cnt_elems / kScanTile + 2);
+  const size_t bytes = 2 * 8 * cap + 2 * 4 * cap + 4 * cnt_elems + 4 * (cnt_elems / kScanTile + 2) + 8;
   GRB_HIP_TRY(hipMalloc(&raw, bytes));
   struct Free { void* p; ~Free() { (void)hipFree(p); } } guard{raw};
   char* q = (char*)raw;
@@ -275,15 +282,22 @@ grb_info device_build_from_coo(grb_matrix A, const Index* d_rows, const Index* d
   b.pay[0] = (unsigned int*)q; q += 4 * cap;
   b.pay[1] = (unsigned int*)q; q += 4 * cap;
   b.cnt = (unsigned int*)q; q += 4 * cnt_elems;
-  b.totals = (unsigned int*)q;
+  b.totals = (unsigned int*)q; q += 4 * (cnt_elems / kScanTile + 2);
+  unsigned int* d_bad = (unsigned int*)q;
 
   long long n = n0;
   int cur = 0;
   const unsigned int one = A->dtype == GRB_F32 ? 0x3f800000u : 1u;
   if (nvals_in > 0) {
+    GRB_HIP_TRY(hipMemsetAsync(d_bad, 0, 4, s));
     hipLaunchKernelGGL(make_keys_kernel, dim3(stream_grid(nvals_in, kBlock)), dim3(kBlock), 0, s, d_rows, d_cols,
-                       (const unsigned int*)d_vals, one, nvals_in, symmetrize ? 1 : 0, b.keys[0], b.pay[0]);
+                       (const unsigned int*)d_vals, one, nvals_in, symmetrize ? 1 : 0, A->nrows, A->ncols, b.keys[0],
+                       b.pay[0], d_bad);
     GRB_HIP_TRY(hipGetLastError());
+    unsigned int bad = 0;
+    GRB_HIP_TRY(hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, s));
+    GRB_HIP_TRY(hipStreamSynchronize(s));
+    if (bad) return GRB_INDEX_OUT_OF_BOUNDS;
   }
   const int rbits = bits_for(A->nrows), cbits = bits_for(A->ncols);
   GRB_TRY(radix_sort_pairs(b, &cur, n, cbits, rbits, s));

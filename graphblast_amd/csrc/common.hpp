@@ -404,6 +404,11 @@ struct grb_matrix_s {
   grb::Index nrows = 0, ncols = 0, nvals = 0;
   bool built = false;
   bool owned = true;
+  // backend::SparseMatrixFormat read from GRB_SPARSE_MATRIX_FORMAT when the matrix is created
+  // (sparse_matrix.hpp:34,45): 0 CSR + CSC, 1 CSR only -- then the "CSC" arrays ARE the CSR arrays
+  // (sparse_matrix.hpp:311-319) and vxm / mxv ignore the mxvmode (operations.hpp:131-133, 258-260)
+  int format = 0;
+  bool csc_alias = false;
   // host mirrors (sparse_matrix.hpp:120-132)
   std::vector<grb::Index> h_csr_ptr, h_csr_ind, h_csc_ptr, h_csc_ind;
   std::vector<uint32_t> h_csr_val, h_csc_val;   // raw 4-byte values of dtype
@@ -416,6 +421,10 @@ struct grb_matrix_s {
 };
 
 namespace grb {
+
+// objects.hip: frees everything a matrix holds on the device (arrays it owns, plans, cached
+// per-graph side arrays: skip bitmaps, pull hint, SpMV hub packing) and marks it unbuilt
+void matrix_release_device(grb_matrix A);
 
 // ---- kernel launchers (implemented in the *.hip files) -----------------------
 // elementwise.hip

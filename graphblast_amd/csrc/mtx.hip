@@ -68,6 +68,12 @@ __device__ inline long long parse_int(const unsigned char* __restrict__ t, long 
 __device__ inline double parse_real(const unsigned char* __restrict__ t, long long i, long long n) {
   bool neg = false;
   if (i < n && (t[i] == '-' || t[i] == '+')) { neg = t[i] == '-'; ++i; }
+  // "%f" accepts inf / infinity / nan in any case (C11 7.22.1.3): parse them as such, not as 0
+  if (i + 2 < n) {
+    const unsigned char a = t[i] | 0x20, b = t[i + 1] | 0x20, c = t[i + 2] | 0x20;
+    if (a == 'i' && b == 'n' && c == 'f') return neg ? -__builtin_huge_val() : __builtin_huge_val();
+    if (a == 'n' && b == 'a' && c == 'n') return __builtin_nan("");
+  }
   unsigned long long mant = 0;
   int digits = 0, exp10 = 0;
   bool seen_point = false;
@@ -209,6 +215,8 @@ grb_info grb_matrix_load_mtx(grb_matrix* A, const char* path, grb_dtype dtype, i
     nentries = ntok / k;
     if (nentries > h.nvals) nentries = h.nvals;                     // fscanf stops after nvals tuples
     if (nentries < h.nvals) fprintf(stdout, "Error: Not enough rows in mtx file!\n");   // util.hpp:217-219
+    // 32-bit Index like the reference: the count (doubled when reverse entries are added) must fit
+    if (nentries > 0x7fffffffll || (undirected && 2 * nentries > 0x7fffffffll)) { cleanup(); return GRB_OUT_OF_MEMORY; }
     if (nentries > 0) {
       MTX_HIP(hipMemcpyAsync(d_block_off, off.data(), sizeof(long long) * (size_t)nblocks, hipMemcpyHostToDevice, s));
       MTX_HIP(hipMalloc((void**)&d_tok, sizeof(long long) * (size_t)(ntok > 0 ? ntok : 1)));

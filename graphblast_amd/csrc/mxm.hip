@@ -219,16 +219,9 @@ grb_info grb_mxm(grb_matrix C, grb_matrix mask, grb_accum accum, grb_semiring op
   if (Aa.n != mask->nrows || C->nrows != mask->nrows || C->ncols != mask->ncols) return GRB_DIMENSION_MISMATCH;
   hipStream_t s = ctx().stream;
   // C takes the mask's structure (C->dup(&mask->sparse_), spgemm.hpp:78-79)
-  GRB_HIP_TRY(hipStreamSynchronize(s));
-  if (C->owned) {
-    for (CsrArrays* m : {&C->csr, &C->csc}) {
-      if (m->ptr) (void)hipFree(m->ptr);
-      if (m->ind) (void)hipFree(m->ind);
-      if (m->val) (void)hipFree(m->val);
-    }
-  }
-  C->csr = CsrArrays(); C->csc = CsrArrays();
-  free_spmv_plan(&C->plan_csr); free_spmv_plan(&C->plan_csc);
+  // whatever C held before goes, with the per-graph side arrays that described it (skip bitmaps,
+  // pull hint, plans): a later traversal of C must not see hints of another graph
+  matrix_release_device(C);
   C->owned = true;
   C->nvals = mask->nvals;
   const size_t cap = mask->nvals > 0 ? (size_t)mask->nvals : 1;
@@ -243,8 +236,9 @@ grb_info grb_mxm(grb_matrix C, grb_matrix mask, grb_accum accum, grb_semiring op
   C->h_csr_ptr = mask->h_csr_ptr;
   C->h_csr_ind.clear(); C->h_csr_val.clear();
   C->h_csc_ptr.clear(); C->h_csc_ind.clear(); C->h_csc_val.clear();
-  C->built = true;
-  if (mask->nvals == 0) return GRB_SUCCESS;
+  GRB_TRY(build_spmv_plan(C->h_csr_ptr, C->nrows, C->ncols, &C->plan_csr));   // mxv on the result works;
+  C->built = true;                               // no CSC is made (as little as the reference's C->dup has one):
+  if (mask->nvals == 0) return GRB_SUCCESS;      // products on the transpose return GrB_INVALID_OBJECT
   void* p_rows;
   GRB_TRY(scratch(9, 4 * (size_t)mask->nvals, &p_rows));            // not 4 / 5: those hold the push path's state
   hipLaunchKernelGGL(entry_rows_kernel, dim3(stream_grid(mask->nvals, kBlock)), dim3(kBlock), 0, s, mask->csr.ptr,

@@ -618,10 +618,12 @@ grb_info grb_vector_swap(grb_vector a, grb_vector b) {
     std::swap(a->s_val, b->s_val);
     std::swap(a->s_nvals, b->s_nvals);
     std::swap(a->s_owned, b->s_owned);
+    std::swap(a->s_alloc_n, b->s_alloc_n);      // the pool files a freed block under this size
   } else {
     std::swap(a->d_val, b->d_val);
     std::swap(a->d_nnz, b->d_nnz);
     std::swap(a->d_owned, b->d_owned);
+    std::swap(a->d_alloc_n, b->d_alloc_n);
   }
   std::swap(a->nsize, b->nsize);
   std::swap(a->nvals, b->nvals);
@@ -700,14 +702,18 @@ grb_info grb_matrix_new(grb_matrix* out, grb_dtype dtype, grb_index nrows, grb_i
   A->dtype = dtype;
   A->nrows = nrows;
   A->ncols = ncols;
+  const char* fmt = getenv("GRB_SPARSE_MATRIX_FORMAT");        // sparse_matrix.hpp:34,45
+  A->format = fmt ? atoi(fmt) : 0;
   *out = A;
   return GRB_SUCCESS;
 }
 
-static void matrix_release_device(grb_matrix A) {
+extern "C++" {
+void grb::matrix_release_device(grb_matrix A) {
   (void)hipStreamSynchronize(ctx().stream);
   if (A->owned) {
     for (CsrArrays* m : {&A->csr, &A->csc}) {
+      if (m == &A->csc && A->csc_alias) continue;              // CSR-only format: the same arrays
       if (m->ptr) (void)hipFree(m->ptr);
       if (m->ind) (void)hipFree(m->ind);
       if (m->val) (void)hipFree(m->val);
@@ -715,6 +721,7 @@ static void matrix_release_device(grb_matrix A) {
   }
   A->csr = CsrArrays();
   A->csc = CsrArrays();
+  A->csc_alias = false;
   if (A->d_no_in_edges) { (void)hipFree(A->d_no_in_edges); A->d_no_in_edges = nullptr; }
   if (A->d_empty_csr_rows) { (void)hipFree(A->d_empty_csr_rows); A->d_empty_csr_rows = nullptr; }
   if (A->d_pull_hint) { (void)hipFree(A->d_pull_hint); A->d_pull_hint = nullptr; }
@@ -723,6 +730,7 @@ static void matrix_release_device(grb_matrix A) {
   free_spmv_plan(&A->plan_csc);
   A->built = false;
 }
+}  // extern "C++"
 
 grb_info grb_matrix_free(grb_matrix A) {
   if (!A) return GRB_SUCCESS;
@@ -766,6 +774,25 @@ static void transpose_compressed(Index nmajor, Index nminor, const std::vector<I
     }
 }
 
+// GRB_SPARSE_MATRIX_FORMAT = 1 (CSR only): h_csc* / d_csc* alias the CSR arrays
+// (sparse_matrix.hpp:311-319, 384-391); whatever CSC a build produced is dropped.
+static grb_info apply_format(grb_matrix A) {
+  if (A->format != 1 || A->csc_alias || !A->csr.ptr) return GRB_SUCCESS;
+  GRB_HIP_TRY(hipStreamSynchronize(ctx().stream));
+  if (A->owned && A->csc.ptr != A->csr.ptr) {
+    if (A->csc.ptr) (void)hipFree(A->csc.ptr);
+    if (A->csc.ind) (void)hipFree(A->csc.ind);
+    if (A->csc.val) (void)hipFree(A->csc.val);
+  }
+  A->csc = A->csr;
+  A->csc_alias = true;
+  A->h_csc_ptr = A->h_csr_ptr;
+  A->h_csc_ind = A->h_csr_ind;
+  A->h_csc_val = A->h_csr_val;
+  free_spmv_plan(&A->plan_csc);
+  return build_spmv_plan(A->h_csr_ptr, A->nrows, A->ncols, &A->plan_csc);
+}
+
 static grb_info matrix_finish_build(grb_matrix A) {
   A->owned = true;
   GRB_TRY(upload(&A->csr, A->nrows, A->nvals, A->h_csr_ptr, A->h_csr_ind, A->h_csr_val));
@@ -773,14 +800,14 @@ static grb_info matrix_finish_build(grb_matrix A) {
   GRB_TRY(build_spmv_plan(A->h_csr_ptr, A->nrows, A->ncols, &A->plan_csr));
   GRB_TRY(build_spmv_plan(A->h_csc_ptr, A->ncols, A->nrows, &A->plan_csc));
   A->built = true;
-  return GRB_SUCCESS;
+  return apply_format(A);
 }
 
 static grb_info finish_device_build(grb_matrix A) {
   GRB_TRY(build_spmv_plan(A->h_csr_ptr, A->nrows, A->ncols, &A->plan_csr));
   GRB_TRY(build_spmv_plan(A->h_csc_ptr, A->ncols, A->nrows, &A->plan_csc));
   A->built = true;
-  return GRB_SUCCESS;
+  return apply_format(A);
 }
 
 // build(): the coordinate list is uploaded and sorted / compressed on the device (build.hip);
@@ -863,7 +890,7 @@ grb_info grb_matrix_adopt_device_csr(grb_matrix A, grb_index* d_csr_ptr, grb_ind
   }
   A->h_csr_ind.clear(); A->h_csr_val.clear(); A->h_csc_ind.clear(); A->h_csc_val.clear();
   A->built = true;
-  return GRB_SUCCESS;
+  return apply_format(A);
 }
 
 grb_info grb_matrix_nrows(grb_matrix A, grb_index* n) { if (!A) return GRB_UNINITIALIZED_OBJECT; *n = A->nrows; return GRB_SUCCESS; }
@@ -910,12 +937,83 @@ grb_info grb_matrix_set_values(grb_matrix A, const void* csr_val) {
   std::vector<Index> tptr, tind;
   transpose_compressed(A->nrows, A->ncols, A->h_csr_ptr, A->h_csr_ind, A->h_csr_val, &tptr, &tind, &A->h_csc_val);
   GRB_HIP_TRY(hipStreamSynchronize(ctx().stream));
+  if (A->csc_alias) A->h_csc_val = A->h_csr_val;
   if (A->nvals > 0) {
     GRB_HIP_TRY(hipMemcpy(A->csr.val, A->h_csr_val.data(), 4 * (size_t)A->nvals, hipMemcpyHostToDevice));
-    GRB_HIP_TRY(hipMemcpy(A->csc.val, A->h_csc_val.data(), 4 * (size_t)A->nvals, hipMemcpyHostToDevice));
+    if (!A->csc_alias)
+      GRB_HIP_TRY(hipMemcpy(A->csc.val, A->h_csc_val.data(), 4 * (size_t)A->nvals, hipMemcpyHostToDevice));
   }
   A->nonneg_values = -1;
   return GRB_SUCCESS;
+}
+
+// ---- binary cache (sparse_matrix.hpp:328-348 write, :355-407 read; name rule util.hpp:340-357)
+// file = int32 nrows, int32 nvals, int32 rowptr[nrows + 1], int32 colind[nvals]; values implied 1
+grb_info grb_cache_name(const char* mtx_path, int is_undirected, char* out, size_t cap) {
+  if (!mtx_path || !out || cap == 0) return GRB_NULL_POINTER;
+  std::string path(mtx_path);
+  // dirname / basename (libgen semantics for the cases readMtx meets: a path to a regular file)
+  size_t slash = path.find_last_of('/');
+  std::string dir = slash == std::string::npos ? "." : (slash == 0 ? "/" : path.substr(0, slash));
+  std::string base = slash == std::string::npos ? path : path.substr(slash + 1);
+  const char* env = getenv("GRB_UTIL_REMOVE_SELFLOOP");
+  const bool remove_self_loops = !env || atoi(env) != 0;
+  int k = snprintf(out, cap, "%s/.%s.%s.%s.%sbin", dir.c_str(), base.c_str(), is_undirected ? "ud" : "d",
+                   remove_self_loops ? "nosl" : "sl", "");
+  return (k < 0 || (size_t)k >= cap) ? GRB_INSUFFICIENT_SPACE : GRB_SUCCESS;
+}
+
+grb_info grb_matrix_write_cache(grb_matrix A, const char* path) {
+  if (!A || !A->built) return GRB_UNINITIALIZED_OBJECT;
+  if (!path) return GRB_NULL_POINTER;
+  GRB_TRY(ensure_host_mirror(A, false));
+  FILE* f = fopen(path, "wb");
+  if (!f) return GRB_INVALID_VALUE;                      // "Error: Unable to open file for writing!"
+  bool ok = fwrite(&A->nrows, 4, 1, f) == 1 && fwrite(&A->nvals, 4, 1, f) == 1 &&
+            fwrite(A->h_csr_ptr.data(), 4, (size_t)A->nrows + 1, f) == (size_t)A->nrows + 1 &&
+            (A->nvals == 0 || fwrite(A->h_csr_ind.data(), 4, (size_t)A->nvals, f) == (size_t)A->nvals);
+  ok = (fclose(f) == 0) && ok;
+  return ok ? GRB_SUCCESS : GRB_PANIC;
+}
+
+// Matrix::build(dat_name): the file's two arrays go to the device as they are (no text, no sort
+// of the CSR side); the CSC side is made there by the stable column sort of build.hip.
+grb_info grb_matrix_build_cache(grb_matrix A, const char* path) {
+  if (!A) return GRB_UNINITIALIZED_OBJECT;
+  if (!path) return GRB_NULL_POINTER;
+  FILE* f = fopen(path, "rb");
+  if (!f) return GRB_NO_VALUE;                           // "Error: Unable to read file!"
+  Index hdr[2] = {0, 0};
+  if (fread(hdr, 4, 2, f) != 2 || hdr[0] < 0 || hdr[1] < 0) { fclose(f); return GRB_INVALID_VALUE; }
+  const Index nrows = hdr[0], nvals = hdr[1];
+  std::vector<Index> ptr((size_t)nrows + 1), ind((size_t)nvals);
+  const bool ok = fread(ptr.data(), 4, ptr.size(), f) == ptr.size() &&
+                  (nvals == 0 || fread(ind.data(), 4, ind.size(), f) == ind.size());
+  fclose(f);
+  if (!ok || ptr[0] != 0 || ptr[(size_t)nrows] != nvals) return GRB_INVALID_VALUE;
+  GRB_TRY(ctx_init());
+  matrix_release_device(A);
+  A->nrows = nrows;                                      // the file decides (ncols is assumed equal, :372-373)
+  A->ncols = nrows;
+  // rows of the entries from the pointer array, on the host (one pass), then the device build
+  std::vector<Index> rows((size_t)nvals);
+  for (Index r = 0; r < nrows; ++r) {
+    if (ptr[(size_t)r + 1] < ptr[r] || ptr[(size_t)r + 1] > nvals) return GRB_INVALID_VALUE;
+    for (Index p = ptr[r]; p < ptr[(size_t)r + 1]; ++p) rows[(size_t)p] = r;
+  }
+  Index *d_r = nullptr, *d_c = nullptr;
+  const size_t cap = nvals > 0 ? (size_t)nvals : 1;
+  grb_info info = GRB_SUCCESS;
+  if (hipMalloc((void**)&d_r, 4 * cap) != hipSuccess || hipMalloc((void**)&d_c, 4 * cap) != hipSuccess)
+    info = GRB_OUT_OF_MEMORY;
+  if (info == GRB_SUCCESS && nvals > 0 &&
+      (hipMemcpy(d_r, rows.data(), 4 * cap, hipMemcpyHostToDevice) != hipSuccess ||
+       hipMemcpy(d_c, ind.data(), 4 * cap, hipMemcpyHostToDevice) != hipSuccess))
+    info = GRB_PANIC;
+  if (info == GRB_SUCCESS) info = device_build_from_coo(A, d_r, d_c, nullptr, nvals, 0);   // values = 1 (:378-379)
+  (void)hipFree(d_r); (void)hipFree(d_c);
+  GRB_TRY(info);
+  return finish_device_build(A);
 }
 
 }  // extern "C"

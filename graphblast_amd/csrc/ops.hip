@@ -80,14 +80,37 @@ static grb_info mxv_common(grb_vector w, grb_vector mask, grb_accum accum, int o
   }
   const double identity = semiring_identity(op, u->dtype);
   const int mode = desc->desc[GRB_MXVMODE];
+  // GRB_LOAD_BALANCE_MODE is read on every call (operations.hpp:110, :242): 2 = merge (default) is the only
+  // implemented sparse-input path; 0 prints and returns GrB_NOT_IMPLEMENTED *without undoing the INP1 toggle*
+  // (:161-163), 1 prints, leaves w an empty sparse vector and reports success (:167-177)
+  const char* lb_env = getenv("GRB_LOAD_BALANCE_MODE");
+  const int lb_mode = lb_env ? atoi(lb_env) : 2;
   grb_info info = GRB_SUCCESS;
+  // no CSC storage (GRB_SPARSE_MATRIX_FORMAT = 1; getSymmetry() reports false for every matrix,
+  // sparse_matrix.hpp:577-582): the direction is forced whatever the mxvmode says (:131-133, :258-260)
+  if (A->format == 1) {
+    if (is_vxm && u->vec_type == GRB_DENSE) info = grb_vector_dense2sparse(u, identity, desc);
+    else if (!is_vxm && u->vec_type == GRB_SPARSE) info = grb_vector_sparse2dense(u, identity, desc);
+  } else
   if (mode == GRB_PUSHPULL) info = grb_vector_convert(u, identity, desc->switchpoint, desc);
   else if (mode == GRB_PUSHONLY && u->vec_type == GRB_DENSE) info = grb_vector_dense2sparse(u, identity, desc);
   else if (mode == GRB_PULLONLY && u->vec_type == GRB_SPARSE) info = grb_vector_sparse2dense(u, identity, desc);
   if (info == GRB_SUCCESS) {
-    if (u->vec_type == GRB_SPARSE) {
-      info = grb_vector_set_storage(w, GRB_SPARSE);
-      if (info == GRB_SUCCESS) info = spmspv_dispatch(w, mask, accum, op, A, u, desc);
+    if (u->vec_type == GRB_SPARSE && lb_mode == 0) {
+      (void)grb_vector_set_storage(w, GRB_DENSE);
+      fprintf(stdout, "Simple SPMSPV not implemented yet!\n");
+      return GRB_NOT_IMPLEMENTED;                          // INP1 stays toggled, as in the reference
+    } else if (u->vec_type == GRB_SPARSE && lb_mode == 1) {
+      fprintf(stdout, "Error: B40C load-balance algorithm not implemented yet!\n");
+      info = grb_vector_set_storage(w, GRB_DENSE);
+      if (info == GRB_SUCCESS) info = grb_vector_dense2sparse(w, identity, desc);
+      desc->lastmxv = GRB_PUSHONLY;
+    } else if (u->vec_type == GRB_SPARSE) {
+      if (lb_mode != 2) fprintf(stdout, "Error: Invalid load-balance algorithm!\n");
+      else {
+        info = grb_vector_set_storage(w, GRB_SPARSE);
+        if (info == GRB_SUCCESS) info = spmspv_dispatch(w, mask, accum, op, A, u, desc);
+      }
       desc->lastmxv = GRB_PUSHONLY;
     } else {
       if (is_vxm) info = grb_vector_set_storage(w, GRB_DENSE);

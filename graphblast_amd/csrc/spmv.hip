@@ -373,7 +373,8 @@ __global__ __launch_bounds__(kHubThreads) void spmv_hub_kernel(
 
 grb_info k_spmv(int sr, int dtype, const CsrArrays& M, SpmvPlan& plan, const void* u, const void* mask,
                 int mask_f32, int scmp, int accum, void* w) {
-  if (plan.ntiles == 0) return GRB_SUCCESS;
+  if (plan.ntiles == 0 && M.nvals > 0) return GRB_INVALID_OBJECT;   // nonzeros but no plan: never a silent no-op
+  if (plan.ntiles == 0 && plan.nrows == 0) return GRB_SUCCESS;       // nothing to write
   if (M.nvals > 0 && !plan.hub_ready) GRB_TRY(prepare_hub_packing(M, plan));
   return dispatch_semiring(sr, dtype, [&](auto tag, auto t) -> grb_info {
     using T = decltype(t);

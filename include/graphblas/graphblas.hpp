@@ -243,9 +243,16 @@ inline void parseArgs(int argc, char** argv, po::variables_map* vm) {
   }
 }
 
-// MatrixMarket coordinate reader with the reference loader's semantics: 1-based ->
-// 0-based, pattern -> 1, symmetric (or directed == 2) adds the reverse of every
-// off-diagonal entry, sorted by (row, col), self loops and duplicates dropped.
+// MatrixMarket coordinate reader with the reference loader's semantics (util.hpp:197-329, 363-430):
+// 1-based -> 0-based, pattern -> 1, symmetric (or directed == 2) adds the reverse of every
+// off-diagonal entry, sorted by (row, col), self loops and duplicates dropped -- and, as there,
+// the compaction after a removal moves the INDICES only: the value array stays in sorted order
+// of all entries and is cut to the new length (util.hpp:311-323; invisible on pattern graphs).
+// dat_name (when asked for) is the binary cache's path (util.hpp:340-357); when that file exists
+// the lists come back empty and Matrix::build(..., dat_name) reads the cache (util.hpp:398-409).
+#ifndef GRB_MAXLEN
+#define GRB_MAXLEN 256
+#endif
 template <typename X>
 inline int readMtx(const char* fname, std::vector<graphblas::Index>* row_indices,
                    std::vector<graphblas::Index>* col_indices, std::vector<X>* values, graphblas::Index* nrows,
@@ -270,38 +277,57 @@ inline int readMtx(const char* fname, std::vector<graphblas::Index>* row_indices
   } while (line[0] == '%');
   int nr, nc, nz;
   if (sscanf(line, "%d %d %d", &nr, &nc, &nz) != 3) exit(1);
-  *nrows = nr; *ncols = nc;
+  *nrows = nr; *ncols = nc; *nvals = nz;
   const bool pattern = strcmp(dtype, "pattern") == 0;
+  const bool integer = strcmp(dtype, "integer") == 0;
   const bool symmetric = strcmp(sym, "symmetric") == 0;
   bool undirected = (symmetric || directed == 2) && directed != 1;
-  if (dat_name) *dat_name = NULL;
+  row_indices->clear(); col_indices->clear(); values->clear();
+  if (dat_name) {
+    *dat_name = reinterpret_cast<char*>(malloc(GRB_MAXLEN));            // freed by Matrix::build, as in the reference
+    if (grb_cache_name(fname, undirected, *dat_name, GRB_MAXLEN) != 0) (*dat_name)[0] = 0;
+    FILE* c = (*dat_name)[0] ? fopen(*dat_name, "rb") : NULL;
+    if (c) {                                   // empty lists tell Matrix::build that the cache exists
+      fclose(c);
+      fclose(f);
+      return 0;
+    }
+  }
   struct Entry { graphblas::Index r, c; X v; };
   std::vector<Entry> e;
   e.reserve(static_cast<size_t>(nz) * (undirected ? 2 : 1));
   for (int i = 0; i < nz; ++i) {
     int r, c;
-    double v = 1.0;
-    if (fscanf(f, "%d %d", &r, &c) != 2) break;
-    if (!pattern && fscanf(f, "%lf", &v) != 1) break;
-    Entry x = {r - 1, c - 1, static_cast<X>(v)};
+    if (fscanf(f, "%d", &r) == EOF) { std::cout << "Error: Not enough rows in mtx file!\n"; break; }
+    if (fscanf(f, "%d", &c) != 1) c = 0;
+    X v = static_cast<X>(1);
+    if (integer) { int raw = 0; if (fscanf(f, "%d", &raw) != 1) raw = 0; v = static_cast<X>(raw); }
+    else if (!pattern) { float raw = 0.f; if (fscanf(f, "%f", &raw) != 1) raw = 0.f; v = static_cast<X>(raw); }
+    Entry x = {r - 1, c - 1, v};
     e.push_back(x);
-    if (undirected && r != c) { Entry y = {c - 1, r - 1, static_cast<X>(v)}; e.push_back(y); }
   }
   fclose(f);
+  if (undirected) {                            // reverse entries are appended after the originals (util.hpp:271-279)
+    const size_t m = e.size();
+    for (size_t i = 0; i < m; ++i)
+      if (e[i].r != e[i].c) { Entry y = {e[i].c, e[i].r, e[i].v}; e.push_back(y); }
+  }
+  // customSort is std::sort on (row, col): the order of equal coordinates with different values is
+  // libstdc++'s; stable order is used here (identical whenever duplicates carry equal values)
   std::stable_sort(e.begin(), e.end(), [](const Entry& a, const Entry& b) {
     return a.r != b.r ? a.r < b.r : a.c < b.c;
   });
   const char* keep_sl = getenv("GRB_UTIL_REMOVE_SELFLOOP");
   const bool remove_self_loops = !(keep_sl && atoi(keep_sl) == 0);
-  row_indices->clear(); col_indices->clear(); values->clear();
   for (size_t i = 0; i < e.size(); ++i) {
     if (remove_self_loops && e[i].r == e[i].c) continue;
-    if (!row_indices->empty() && row_indices->back() == e[i].r && col_indices->back() == e[i].c) continue;
+    if (i > 0 && e[i - 1].r == e[i].r && e[i - 1].c == e[i].c) continue;
     row_indices->push_back(e[i].r);
     col_indices->push_back(e[i].c);
-    values->push_back(e[i].v);
   }
   *nvals = static_cast<graphblas::Index>(row_indices->size());
+  values->resize(row_indices->size());
+  for (size_t i = 0; i < values->size(); ++i) (*values)[i] = e[i].v;   // values are NOT compacted (util.hpp:311-326)
   if (mtxinfo) printf("%s: %d x %d, %d stored entries (undirected: %d)\n", fname, nr, nc, *nvals, undirected);
   return 0;
 }
@@ -534,17 +560,42 @@ class Matrix {
   Info nrows(Index* n) const { *n = matrix_.nrows_; return GrB_SUCCESS; }
   Info ncols(Index* n) const { *n = matrix_.ncols_; return GrB_SUCCESS; }
   Info nvals(Index* n) const { return to_info(grb_matrix_nvals(matrix_.h_, n)); }
-  // build(row_indices, col_indices, values, nvals, dup, dat_name): COO on the host; the
-  // binary cache named by dat_name is not used (the build is not in any timed region)
+  // build(row_indices, col_indices, values, nvals, dup, dat_name) (graphblas/matrix.hpp:125-144):
+  // empty lists + dat_name = read the binary cache (sparse_matrix.hpp:355-407); lists + dat_name =
+  // build, then write the cache if the file does not exist yet (sparse_matrix.hpp:328-348)
   template <typename V, typename BinaryOpT>
   Info build(const std::vector<Index>* rows, const std::vector<Index>* cols, const std::vector<V>* values,
              Index nvals, BinaryOpT, char* dat_name = NULL) {
-    (void)dat_name;
     if (!rows || !cols || !values) return GrB_NULL_POINTER;
-    std::vector<S> tmp(values->begin(), values->end());
-    Info i = to_info(grb_matrix_build(matrix_.h_, rows->data(), cols->data(), tmp.data(), nvals));
+    if (rows->empty() && cols->empty() && values->empty() && dat_name == NULL) return GrB_NO_VALUE;
+    Info i;
+    if (dat_name == NULL || !rows->empty()) {
+      std::vector<S> tmp(values->begin(), values->end());
+      i = to_info(grb_matrix_build(matrix_.h_, rows->data(), cols->data(), tmp.data(), nvals));
+      if (i == GrB_SUCCESS && dat_name != NULL && dat_name[0]) {
+        FILE* c = fopen(dat_name, "rb");
+        if (c) {
+          fclose(c);
+        } else {
+          printf("Writing %s\n", dat_name);
+          if (grb_matrix_write_cache(matrix_.h_, dat_name) != 0)
+            std::cout << "Error: Unable to open file for writing!\n";
+        }
+      }
+    } else {
+      printf("Reading %s\n", dat_name);
+      i = to_info(grb_matrix_build_cache(matrix_.h_, dat_name));
+      if (i == GrB_NO_VALUE) {                               // sparse_matrix.hpp:403-406: prints, reports success
+        std::cout << "Error: Unable to read file!\n";
+        i = GrB_SUCCESS;
+      } else if (i == GrB_SUCCESS) {
+        grb_matrix_nrows(matrix_.h_, &matrix_.nrows_);
+        grb_matrix_ncols(matrix_.h_, &matrix_.ncols_);
+      }
+    }
+    if (dat_name) free(dat_name);
     if (i != GrB_SUCCESS) return i;
-    matrix_.nvals_ = nvals;
+    grb_matrix_nvals(matrix_.h_, &matrix_.nvals_);
     return matrix_.refresh_host();
   }
   Info print(bool force_update = false) {

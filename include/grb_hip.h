@@ -178,6 +178,17 @@ grb_info grb_matrix_host_csc(grb_matrix A, const grb_index** col_ptr, const grb_
  * through apply() + syncCpu, and gpr.cu:82-90 through the matrix eWiseMult variants. */
 grb_info grb_matrix_set_values(grb_matrix A, const void* csr_val);
 
+/* Binary CSR cache, the reference's interchange format (Appendix B of SURVEY.md):
+ * `<dir>/.<file>.<ud|d>.<nosl|sl>.bin` = int32 nrows, int32 nvals, int32 rowptr[nrows+1],
+ * int32 colind[nvals]; square matrices, values implied 1.
+ *   grb_cache_name          util.hpp:340-357 (convert): the cache path for a .mtx path
+ *   grb_matrix_write_cache  backend/cuda/sparse_matrix.hpp:328-348 (end of build(..., dat_name))
+ *   grb_matrix_build_cache  backend/cuda/sparse_matrix.hpp:355-407 (build(char* dat_name)):
+ *                           GrB_NO_VALUE when the file cannot be opened */
+grb_info grb_cache_name(const char* mtx_path, int is_undirected, char* out, size_t cap);
+grb_info grb_matrix_write_cache(grb_matrix A, const char* path);
+grb_info grb_matrix_build_cache(grb_matrix A, const char* path);
+
 /* ---- Operations (graphblas/operations.hpp) ----------------------------------- */
 /* vxm  operations.hpp:59-87   -> backend/cuda/operations.hpp:80-209  */
 grb_info grb_vxm(grb_vector w, grb_vector mask, grb_accum accum, grb_semiring op, grb_vector u,

@@ -195,3 +195,125 @@ def test_reference_library_at_full_size_if_present(hb):
         v = g.Vector(n)
         assert g.bfs(v, A, src, desc, fused=True)[0] == 0
         assert np.array_equal(hb.dense_values(v), rs.bfs(ptr, ind, src)[0]), src
+
+
+def test_binary_cache_round_trip(hb, fx, tmp_path):
+    """The reference's .bin interchange format (sparse_matrix.hpp:328-407): what grb_matrix_write_cache writes is
+    byte-identical to the restated writer's file (oracle/loader.py, same layout as the reference's ofs.write
+    sequence), and grb_matrix_build_cache gives back the same CSR / CSC with every value 1."""
+    from oracle import loader
+    g = hb.g
+    for case in ("chesapeake.d0", "rmat10.d1", "rmat12.d2", "grid48.d0", "test_cc.d1"):
+        A, n = matrix(hb, fx, case)
+        path = str(tmp_path / (case + ".bin"))
+        assert A.write_cache(path) == 0
+        ref_path = str(tmp_path / (case + ".ref.bin"))
+        loader.write_cache(ref_path, fx[case + "/csr_ptr"], fx[case + "/csr_ind"])
+        assert open(path, "rb").read() == open(ref_path, "rb").read(), case
+        B = g.Matrix(n, n)
+        assert B.build_cache(path) == 0
+        assert (B.nrows(), B.nvals()) == (n, int(fx[case + "/nvals"]))
+        ptr, ind, val = B.host_csr()
+        assert np.array_equal(ptr, fx[case + "/csr_ptr"]) and np.array_equal(ind, fx[case + "/csr_ind"]), case
+        assert np.all(val == 1)
+        cp, ci, cv = B.host_csc()
+        assert np.array_equal(cp, fx[case + "/csc_ptr"]) and np.array_equal(ci, fx[case + "/csc_ind"]), case
+        d = hb.descriptor(mxvmode=0, struconly=1, opreuse=1)
+        v = g.Vector(n)
+        assert g.bfs(v, B, int(fx[case + "/sources"][1]), d, fused=True)[0] == 0
+        assert np.array_equal(hb.dense_values(v), fx[case + "/bfs_1"]), case
+    C2 = g.Matrix(4, 4)
+    assert C2.build_cache(str(tmp_path / "absent.bin")) == g.GrB_NO_VALUE
+
+
+def test_sparse_matrix_format_csr_only(hb, fx, monkeypatch):
+    """GRB_SPARSE_MATRIX_FORMAT=1 (backend::GrB_SPARSE_MATRIX_CSRONLY, read when the matrix is created,
+    sparse_matrix.hpp:34): the CSC arrays alias the CSR arrays and -- getSymmetry() being always false (quirk 5)
+    -- vxm converts a dense input to sparse (push) and mxv a sparse one to dense (pull) whatever the mxvmode says
+    (operations.hpp:131-133, 258-260).  Results equal the default format's; lastmxv shows the forced direction."""
+    g = hb.g
+    case = "rmat10.d1"                                   # directed: a pull over the aliased arrays would be wrong
+    ptr, ind = fx[case + "/csr_ptr"], fx[case + "/csr_ind"]
+    n = ptr.size - 1
+    A0, _ = matrix(hb, fx, case)
+    monkeypatch.setenv("GRB_SPARSE_MATRIX_FORMAT", "1")
+    A1, _ = matrix(hb, fx, case)
+    monkeypatch.delenv("GRB_SPARSE_MATRIX_FORMAT")
+    p1, i1, _ = A1.host_csc()
+    assert np.array_equal(p1, ptr) and np.array_equal(i1, ind)          # h_csc* == h_csr*
+    rng = np.random.default_rng(4)
+    x = (rng.random(n) < 0.3).astype(F) * rng.integers(1, 5, n).astype(F)
+    for mode in (0, 1, 2):
+        outs = []
+        for A in (A0, A1):
+            d = hb.descriptor(mxvmode=mode)
+            u, w = g.Vector(n), g.Vector(n)
+            assert u.build(x, n) == 0
+            assert g.vxm(w, None, None, "PlusMultiplies", u, A, d) == 0
+            wd = g.Vector(n)
+            wd.dup(w)
+            wd.sparse2dense(0.0, d)
+            outs.append((hb.dense_values(wd), d.lastmxv_))
+            u2, w2 = g.Vector(n), g.Vector(n)
+            idx = np.nonzero(x)[0].astype(np.int32)
+            assert u2.build(idx, x[idx], idx.size, None) == 0
+            assert g.mxv(w2, None, None, "PlusMultiplies", A, u2, d) == 0
+            w2.sparse2dense(0.0, d)
+            outs.append((hb.dense_values(w2), d.lastmxv_))
+        assert np.allclose(outs[0][0], outs[2][0], rtol=1e-6) and np.allclose(outs[1][0], outs[3][0], rtol=1e-6), mode
+        assert outs[2][1] == g.GrB_PUSHONLY and outs[3][1] == g.GrB_PULLONLY, (mode, outs[2][1], outs[3][1])
+    # whole drivers on the CSR-only matrix: same labels / distances as the reference's
+    w = fx[case + "/weights"]
+    monkeypatch.setenv("GRB_SPARSE_MATRIX_FORMAT", "1")
+    Aw, _ = matrix(hb, fx, case, vals=w)
+    monkeypatch.delenv("GRB_SPARSE_MATRIX_FORMAT")
+    for k, src in enumerate(fx[case + "/sources"]):
+        for mode in (0, 1, 2):
+            d = hb.descriptor(mxvmode=mode, struconly=1, opreuse=1)
+            v = g.Vector(n)
+            info, res = g.bfs(v, A1, int(src), d, fused=True)
+            assert info == 0 and np.array_equal(hb.dense_values(v), fx["%s/bfs_%d" % (case, k)]), (k, mode)
+            assert res["reached"] == int(np.count_nonzero(fx["%s/bfs_%d" % (case, k)]))
+            d2 = hb.descriptor(mxvmode=mode)
+            v2 = g.Vector(n)
+            assert g.sssp(v2, Aw, int(src), d2)[0] == 0
+            assert np.array_equal(hb.dense_values(v2), fx["%s/sssp_%d" % (case, k)]), (k, mode)
+
+
+def test_load_balance_mode_switch(hb, fx, monkeypatch):
+    """GRB_LOAD_BALANCE_MODE is read on every vxm / mxv (operations.hpp:110, 242): 2 (merge) is the implemented
+    push path; 0 returns GrB_NOT_IMPLEMENTED and leaves the descriptor's INP1 toggled (vxm, :161-163); 1 prints
+    and reports success without computing (:167-177).  A dense input (pull) is not affected."""
+    g = hb.g
+    A, n = matrix(hb, fx, "chesapeake.d0")
+    idx = np.array([0, 5], np.int32)
+    val = np.ones(2, F)
+
+    def sparse_u():
+        u = g.Vector(n)
+        assert u.build(idx, val, 2, None) == 0
+        return u
+    d = hb.descriptor(mxvmode=1)
+    w = g.Vector(n)
+    assert g.vxm(w, None, None, "LogicalOrAnd", sparse_u(), A, d) == 0
+    want = hb.sparse_tuples(w)[0]
+    monkeypatch.setenv("GRB_LOAD_BALANCE_MODE", "0")
+    d0 = hb.descriptor(mxvmode=1)
+    assert g.vxm(g.Vector(n), None, None, "LogicalOrAnd", sparse_u(), A, d0) == g.GrB_NOT_IMPLEMENTED
+    assert d0.get(g.GrB_INP1) == g.GrB_TRAN
+    monkeypatch.setenv("GRB_LOAD_BALANCE_MODE", "1")
+    d1 = hb.descriptor(mxvmode=1)
+    w1 = g.Vector(n)
+    w1.fill(0.0)
+    assert g.vxm(w1, None, None, "LogicalOrAnd", sparse_u(), A, d1) == 0
+    assert w1.getStorage() == g.GrB_SPARSE and w1.nvals() == 0 and d1.lastmxv_ == g.GrB_PUSHONLY
+    dd = hb.descriptor(mxvmode=2)
+    ud, wd = g.Vector(n), g.Vector(n)
+    x = np.zeros(n, F); x[idx] = 1
+    assert ud.build(x, n) == 0
+    assert g.vxm(wd, None, None, "LogicalOrAnd", ud, A, dd) == 0
+    assert np.array_equal(np.nonzero(hb.dense_values(wd))[0], np.sort(want))
+    monkeypatch.setenv("GRB_LOAD_BALANCE_MODE", "2")
+    w2 = g.Vector(n)
+    assert g.vxm(w2, None, None, "LogicalOrAnd", sparse_u(), A, hb.descriptor(mxvmode=1)) == 0
+    assert np.array_equal(hb.sparse_tuples(w2)[0], want)
