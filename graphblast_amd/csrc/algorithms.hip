@@ -5,6 +5,7 @@
 #include <cmath>
 
 #include "common.hpp"
+#include <chrono>
 
 using namespace grb;
 
@@ -19,6 +20,10 @@ struct VecGuard {               // frees temporaries on every exit path
   }
 };
 }  // namespace
+
+static inline double host_ms() {
+  return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
 
 grb_info sssp_persistent_run(grb_vector v, grb_matrix A, grb_index source, grb_descriptor desc, int* iterations,
                              double* succ, float* tight_ms, grb_vector f1_dense, bool* handed_over);
@@ -72,6 +77,8 @@ grb_info grb_sssp(grb_vector v, grb_matrix A, grb_index source, grb_descriptor d
   grb_index f1_nvals = 1;
   double succ = 1;
   float ms = 0.f;
+  const bool log = desc->timing != 0;
+  if (!continued) desc->iter_log.clear();
   GRB_TRY(grb_timer_start());
   for (; iter <= desc->max_niter; ++iter) {
     GRB_TRY(grb_vxm(f2, nullptr, GRB_ACCUM_NULL, GRB_MINIMUM_PLUS, f1, A, desc));
@@ -84,9 +91,16 @@ grb_info grb_sssp(grb_vector v, grb_matrix A, grb_index source, grb_descriptor d
     GRB_TRY(grb_vector_swap(f2, f1));
     GRB_TRY(grb_vector_nvals(f1, &f1_nvals));
     GRB_TRY(grb_reduce_vector(&succ, GRB_ACCUM_NULL, GRB_PLUS_MONOID, m, desc));
+    if (log) {                      // the reference stops and restarts its GpuTimer every iteration too (sssp.hpp:55-64)
+      float it_ms = 0.f;
+      GRB_TRY(grb_timer_stop(&it_ms));
+      ms += it_ms;
+      desc->iter_log.push_back(grb_algo_iter{iter, desc->lastmxv, (double)f1_nvals, it_ms, 0});
+      GRB_TRY(grb_timer_start());
+    }
     if (f1_nvals == 0 || succ == 0) break;
   }
-  GRB_TRY(grb_timer_stop(&ms));
+  { float last_ms = 0.f; GRB_TRY(grb_timer_stop(&last_ms)); ms += last_ms; }
   // a run that started in the fused loop keeps its meaning of last_value, the number of vertices the
   // last round improved (f1.nvals of a sparse f1, reduce(m) of a dense one); a pure op-by-op run
   // reports the reference's reduce(m) whatever the storage
@@ -113,7 +127,9 @@ static grb_info pr_op_by_op(grb_vector p, grb_matrix A, float alpha, float eps, 
   int iter = 1;
   float error = 1.f;
   float ms = 0.f;
+  desc->iter_log.clear();
   GRB_TRY(grb_timer_start());
+  double t_iter = host_ms();
   for (; error > eps && iter <= desc->max_niter; ++iter) {
     GRB_TRY(grb_vector_dup(p_prev, p));
     GRB_TRY(grb_vxm(p_swap, nullptr, GRB_ACCUM_NULL, GRB_PLUS_MULTIPLIES, p_prev, A, desc));
@@ -124,6 +140,11 @@ static grb_info pr_op_by_op(grb_vector p, grb_matrix A, float alpha, float eps, 
     double sum = 0;
     GRB_TRY(grb_reduce_vector(&sum, GRB_ACCUM_NULL, GRB_PLUS_MONOID, r_temp, desc));
     error = sqrtf((float)sum);
+    if (desc->timing != 0) {
+      const double now = host_ms();
+      desc->iter_log.push_back(grb_algo_iter{iter, desc->lastmxv, (double)error, (float)(now - t_iter), 0});
+      t_iter = now;
+    }
   }
   GRB_TRY(grb_timer_stop(&ms));
   if (result) { result->iterations = iter - 1; result->tight_ms = ms; result->last_value = error; }
@@ -199,7 +220,9 @@ grb_info grb_pr(grb_vector p, grb_matrix A, float alpha, float eps, grb_descript
   int iter = 1;
   float error = 1.f;
   float ms = 0.f;
+  desc->iter_log.clear();
   GRB_TRY(grb_timer_start());
+  double t_iter = host_ms();
   for (; error > eps && iter <= desc->max_niter; ++iter) {
     // vxm treats A as transposed: the pull product walks the CSC orientation (operations.hpp:80-209)
     GRB_TRY(k_spmv(GRB_PLUS_MULTIPLIES, GRB_F32, A->csc, A->plan_csc, p->d_val, nullptr, 0, 0, 0, p_swap->d_val));
@@ -212,6 +235,11 @@ grb_info grb_pr(grb_vector p, grb_matrix A, float alpha, float eps, grb_descript
     float sum;
     memcpy(&sum, &bits, 4);
     error = sqrtf(sum);
+    if (desc->timing != 0) {        // the host has just seen this iteration's residual: its wall-clock share
+      const double now = host_ms();
+      desc->iter_log.push_back(grb_algo_iter{iter, GRB_PULLONLY, (double)error, (float)(now - t_iter), 0});
+      t_iter = now;
+    }
   }
   desc->lastmxv = GRB_PULLONLY;
   GRB_TRY(grb_timer_stop(&ms));
@@ -238,7 +266,9 @@ grb_info grb_cc(grb_vector v, grb_matrix A, int seed, grb_descriptor desc, grb_a
   int iter = 1;
   double succ = 0;
   float ms = 0.f;
+  desc->iter_log.clear();
   GRB_TRY(grb_timer_start());
+  double t_iter = host_ms();
   for (; iter <= desc->max_niter; ++iter) {
     GRB_TRY(grb_vector_dup(parent_temp, parent));
     GRB_TRY(grb_mxv(mnp_temp, nullptr, GRB_ACCUM_NULL, GRB_MINIMUM_SELECT_SECOND, A, grandparent, desc));
@@ -249,6 +279,11 @@ grb_info grb_cc(grb_vector v, grb_matrix A, int seed, grb_descriptor desc, grb_a
     GRB_TRY(grb_extractGather(grandparent, nullptr, GRB_ACCUM_NULL, parent, parent, desc));
     GRB_TRY(grb_eWiseMult(diff, nullptr, GRB_ACCUM_NULL, GRB_MINIMUM_NOT_EQUAL_TO, grandparent_temp, grandparent, desc));
     GRB_TRY(grb_reduce_vector(&succ, GRB_ACCUM_NULL, GRB_PLUS_MONOID, diff, desc));
+    if (desc->timing != 0) {
+      const double now = host_ms();
+      desc->iter_log.push_back(grb_algo_iter{iter, desc->lastmxv, succ, (float)(now - t_iter), 0});
+      t_iter = now;
+    }
     if (succ == 0) break;
     GRB_TRY(grb_vector_dup(grandparent_temp, grandparent));
     grb_descriptor_toggle(desc, GRB_MASK);

@@ -531,7 +531,7 @@ grb_info bfs_persistent_run(grb_vector v, grb_matrix A, grb_index source, grb_de
   }
   if (wgs_per_cu > max_per_cu) wgs_per_cu = max_per_cu;
   const int G = c.num_cu * wgs_per_cu;
-  const int rec_cap = 1024;
+  const int rec_cap = 1 << 15;
   const int big_cap = (int)(A->nvals / kBigDeg) + 2;
 
   // one allocation, one memset: [state | V0 | F0 | F1 | F2]

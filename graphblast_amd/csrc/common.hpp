@@ -379,6 +379,7 @@ struct grb_descriptor_s {
   // frontier's out-edges exceed edgeswitch * nnz
   float edgeswitch = 0.f;
   int lastmxv = GRB_PUSHONLY;
+  std::vector<grb_algo_iter> iter_log;   // grb_descriptor_iter_log: per-iteration records of the last driver call
 };
 
 struct grb_vector_s {

@@ -306,6 +306,13 @@ grb_info grb_descriptor_get_arg(grb_descriptor d, const char* name, double* valu
 #undef X
   return GRB_INVALID_VALUE;
 }
+grb_info grb_descriptor_iter_log(grb_descriptor d, grb_algo_iter* out, int cap, int* count) {
+  if (!d) return GRB_UNINITIALIZED_OBJECT;
+  const int k = (int)d->iter_log.size();
+  if (count) *count = k;
+  if (out && cap > 0 && k > 0) memcpy(out, d->iter_log.data(), sizeof(grb_algo_iter) * (size_t)(k < cap ? k : cap));
+  return GRB_SUCCESS;
+}
 grb_info grb_descriptor_lastmxv(grb_descriptor d, int* value) {
   if (!d) return GRB_UNINITIALIZED_OBJECT;
   *value = d->lastmxv;

@@ -51,6 +51,8 @@ struct SsspArgs {
   unsigned long long* mail;
   int seq;
   float ticks_to_ms;
+  grb_algo_iter* rec;               // per-round records (nullable): what sssp.hpp prints under --timing 1
+  int rec_cap;
 };
 
 struct RoundCounters {
@@ -138,6 +140,7 @@ __global__ __launch_bounds__(kPThreads) void sssp_persistent_kernel(SsspArgs a) 
   unsigned long long succ = 1, nbig = (a.optr[a.source + 1] - a.optr[a.source] >= kSsspBig) ? 1 : 0;
   int last_round = 0, bailed = 0;
   for (; iter <= a.max_niter; ++iter) {
+    const unsigned long long t_round = wall_clock64();
     const float* Dc = a.D[iter % 3];
     float* Dn = a.D[(iter + 1) % 3];
     const unsigned int* Fp = a.F[(iter + 3) % 4];
@@ -256,6 +259,14 @@ __global__ __launch_bounds__(kPThreads) void sssp_persistent_kernel(SsspArgs a) 
     nbig = s_tot[1];
     __syncthreads();
     last_round = iter;
+    if (a.rec && gtid == 0 && iter <= a.rec_cap) {
+      grb_algo_iter& R = a.rec[iter - 1];
+      R.iteration = iter;
+      R.direction = GRB_PUSHONLY;
+      R.value = (double)succ;
+      R.ms = (float)(wall_clock64() - t_round) * a.ticks_to_ms;
+      R.reserved = 0;
+    }
     if (succ == 0) break;           // f1.nvals == 0 / reduce(m) == 0, sssp.hpp:88-90
     if (succ > a.bail_found && iter < a.max_niter) { bailed = 1; break; }   // dense frontier: hand over
   }
@@ -358,6 +369,16 @@ grb_info sssp_persistent_run(grb_vector v, grb_matrix A, grb_index source, grb_d
   a.mail = c.d_hgran;
   a.seq = ++c.mail_seq;
   a.ticks_to_ms = ticks_to_ms;
+  const int rec_cap = 1 << 16;
+  a.rec = nullptr;
+  a.rec_cap = 0;
+  desc->iter_log.clear();
+  if (desc->timing != 0) {
+    void* p_rec;
+    GRB_TRY(scratch(11, sizeof(grb_algo_iter) * (size_t)rec_cap, &p_rec));
+    a.rec = (grb_algo_iter*)p_rec;
+    a.rec_cap = rec_cap;
+  }
 
   GRB_HIP_TRY(hipMemsetAsync(p_zero, 0, zero_bytes, s));
   GRB_TRY(k_fill(GRB_F32, a.D[0], (double)FLT_MAX, n));
@@ -375,6 +396,16 @@ grb_info sssp_persistent_run(grb_vector v, grb_matrix A, grb_index source, grb_d
   memcpy(&ms, &gv[2], 4);
   *tight_ms = ms;
   *handed_over = gv[3] != 0;
+  if (a.rec) {
+    int rounds = *iterations > desc->max_niter ? desc->max_niter : *iterations;
+    if (rounds > rec_cap) rounds = rec_cap;
+    if (rounds > 0) {
+      desc->iter_log.resize((size_t)rounds);
+      GRB_HIP_TRY(hipMemcpyAsync(desc->iter_log.data(), a.rec, sizeof(grb_algo_iter) * (size_t)rounds,
+                                 hipMemcpyDeviceToHost, s));
+      GRB_HIP_TRY(hipStreamSynchronize(s));
+    }
+  }
   if (*handed_over) {
     const unsigned int* Fn = a.F[(*iterations + 1) % 4];       // improved by the last round done
     hipLaunchKernelGGL(sssp_handover_kernel, dim3(ceil_div(n, kBlock)), dim3(kBlock), 0, s, Fn, (const float*)a.D[0], n,

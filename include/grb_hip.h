@@ -315,6 +315,19 @@ typedef struct {
                                * pr: last residual `error`                              */
 } grb_algo_result;
 
+/* One record per iteration of the last grb_sssp / grb_pr / grb_cc call on a descriptor: what the
+ * reference's drivers print per iteration under --timing 1 (sssp.hpp:55-62, pr.hpp:53-62) or 2
+ * (cc.hpp:61-71).  Kept when the descriptor's `timing` argument is non-zero. */
+typedef struct {
+  int32_t iteration;          /* 1-based                                                        */
+  int32_t direction;          /* desc lastmxv_ after the iteration: GRB_PUSHONLY / GRB_PULLONLY */
+  double  value;              /* sssp: f1.nvals (vertices improved); pr: error; cc: succ        */
+  float   ms;                 /* time of the iteration ("gpu_tight")                            */
+  int32_t reserved;
+} grb_algo_iter;
+/* Copies up to `cap` records into out (nullable); *count = records held (may exceed cap). */
+grb_info grb_descriptor_iter_log(grb_descriptor desc, grb_algo_iter* out, int cap, int* count);
+
 /* algorithm::sssp (algorithm/sssp.hpp:15-103): v = distances, FLT_MAX when unreachable.
  * Non-negative f32 weights run the same synchronous rounds in one launch (sssp_persist.hip);
  * anything else, or GRB_SSSP_FUSED=0, runs the reference's call sequence op by op. */

@@ -167,3 +167,84 @@ def test_c_abi_example_runs(tmp_path):
     res = subprocess.run([out], capture_output=True, text=True, timeout=120)
     assert res.returncode == 0 and "CORRECT" in res.stdout, res.stdout + res.stderr
     assert "gfx950" in res.stdout
+
+
+# ---- the drop-in path is the fast path.  The mains above include
+# "graphblas/algorithm/{bfs,sssp,pr}.hpp", which resolve to the shadows in include/graphblas/algorithm/:
+# the library's one-launch drivers by default, the reference's own text with GRB_FRONTEND_FUSED=0.
+def _run_env(exe, env, *args):
+    path = os.path.join(BIN, exe)
+    if not os.path.exists(path):
+        pytest.skip("build/refcheck/%s not built" % exe)
+    e = dict(os.environ)
+    e.update(env)
+    out = subprocess.run([path] + list(args), capture_output=True, text=True, timeout=600, cwd=ROOT, env=e)
+    assert out.returncode == 0, out.stderr[-2000:]
+    return out.stdout
+
+
+@pytest.mark.parametrize("exe,args,min_correct", [
+    ("gbfs_ref", ["--mxvmode", "0", "--struconly", "1", "--opreuse", "1", "--source", "3"], 2),
+    ("gbfs_ref", ["--mxvmode", "1", "--source", "17"], 2),
+    ("gsssp_ref", ["--mxvmode", "0", "--source", "3"], 2),
+    ("gpr_ref", ["--mxvmode", "2", "--max_niter", "10"], 0),
+])
+def test_reference_mains_both_driver_paths_and_timing_lines(rmat_mtx, exe, args, min_correct):
+    """Same verdicts through the fused drivers and through the reference's own loop text, and under the
+    reference's default --timing 1 the fused path prints the same per-iteration lines (same iteration numbers,
+    frontier sizes / residuals and directions; the millisecond column differs, of course)."""
+    import re
+    outs = {}
+    for fused in ("1", "0"):
+        out = _run_env(exe, {"GRB_FRONTEND_FUSED": fused}, *args, "--niter", "1", "--timing", "1", rmat_mtx)
+        assert "INCORRECT" not in out, out[-1500:]
+        assert out.count("CORRECT") >= min_correct, out[-1500:]
+        rows = []
+        for line in out.splitlines():
+            m = re.match(r"^(\d+), ([-+0-9.e]+)/(\d+), (?:(\d+), )?(push|pull), [-+0-9.e]+$", line.strip())
+            if m:
+                rows.append((int(m.group(1)), float(m.group(2)), m.group(4), m.group(5)))
+        outs[fused] = rows
+    assert len(outs["1"]) >= 3 and len(outs["1"]) == len(outs["0"]), (outs["1"][:12], outs["0"][:12])
+    for a, b in zip(outs["1"], outs["0"]):
+        assert a[0] == b[0] and a[2] == b[2], (a, b)
+        assert abs(a[1] - b[1]) <= 1e-4 * max(1.0, abs(b[1])), (a, b)
+        if exe != "gpr_ref":
+            assert a[3] == b[3], (a, b)           # pr: the fused loop always pulls; the printed mode is lastmxv_
+
+
+def test_reference_gbfs_main_at_scale_is_the_fast_path(tmp_path):
+    """example/gbfs.cu, unchanged, on RMAT-20 (n = 1 Mi, ~31 M edges) handed over through the reference's own
+    binary cache (a .mtx stub with banner + size line next to `.stub.mtx.ud.nosl.bin`, which readMtx finds
+    and Matrix::build reads, util.hpp:398-409): prints CORRECT twice (against the reference's CPU BFS) and its
+    `tight` time per traversal is within 1.3x of the C-ABI driver's on the same graph and source."""
+    import re
+    import numpy as np
+    import graphblast_amd as g
+    from graphblast_amd.graphgen import rmat_edges, finalize_edges
+    from oracle import loader
+    s, d, n = rmat_edges(20, 16, seed=1)
+    gr = finalize_edges(s, d, n, symmetrize=True)
+    ptr, ind = gr["csr"]
+    src = int(np.argmax(np.diff(ptr)))
+    stub = tmp_path / "stub.mtx"
+    stub.write_text("%%MatrixMarket matrix coordinate pattern symmetric\n%d %d %d\n" % (n, n, ind.size // 2))
+    loader.write_cache(str(tmp_path / ".stub.mtx.ud.nosl.bin"), ptr, ind)
+    out = _run_env("gbfs_ref", {}, "--mxvmode", "0", "--struconly", "1", "--opreuse", "1", "--earlyexit", "1",
+                   "--source", str(src), "--niter", "20", "--timing", "0", str(stub))
+    assert "Reading" in out and "INCORRECT" not in out and out.count("CORRECT") >= 2, out[-1500:]
+    tight = float(re.search(r"^tight, ([0-9.e+-]+)", out, re.M).group(1))
+    A = g.Matrix(n, n)
+    assert A.build_csr(ptr, ind, np.ones(ind.size, np.float32)) == 0
+    desc = g.Descriptor()
+    assert desc.loadArgs(mxvmode=0, struconly=1, opreuse=1, earlyexit=1) == 0
+    v = g.Vector(n)
+    for _ in range(3):
+        g.bfs(v, A, src, desc, fused=True)
+    mine = np.mean([g.bfs(v, A, src, desc, fused=True)[1]["tight_ms"] for _ in range(20)])
+    assert tight <= 1.3 * mine + 0.01, (tight, mine)
+    slow = _run_env("gbfs_ref", {"GRB_FRONTEND_FUSED": "0"}, "--mxvmode", "0", "--struconly", "1", "--opreuse", "1",
+                    "--source", str(src), "--niter", "5", "--timing", "0", str(stub))
+    assert "INCORRECT" not in slow
+    t_slow = float(re.search(r"^tight, ([0-9.e+-]+)", slow, re.M).group(1))
+    print("gbfs.cu tight per traversal: fused %.3f ms, call sequence %.3f ms, C ABI %.3f ms" % (tight, t_slow, mine))
