@@ -205,7 +205,7 @@ def test_reference_mains_both_driver_paths_and_timing_lines(rmat_mtx, exe, args,
             if m:
                 rows.append((int(m.group(1)), float(m.group(2)), m.group(4), m.group(5)))
         outs[fused] = rows
-    assert len(outs["1"]) >= 3 and len(outs["1"]) == len(outs["0"]), (outs["1"][:12], outs["0"][:12])
+    assert len(outs["1"]) >= 2 and len(outs["1"]) == len(outs["0"]), (outs["1"][:12], outs["0"][:12])
     for a, b in zip(outs["1"], outs["0"]):
         assert a[0] == b[0] and a[2] == b[2], (a, b)
         assert abs(a[1] - b[1]) <= 1e-4 * max(1.0, abs(b[1])), (a, b)
