@@ -91,6 +91,7 @@ _SIGS = {
     "grb_matrix_host_csr": [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp)],
     "grb_matrix_host_csc": [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp)],
     "grb_matrix_set_values": [_vp, _vp],
+    "grb_bfs_batch": [_vp, _i, _vp, _vp, _vp, _vp],
     "grb_descriptor_iter_log": [_vp, _vp, _i, C.POINTER(_i)],
     "grb_cache_name": [C.c_char_p, _i, C.c_char_p, C.c_size_t],
     "grb_matrix_write_cache": [_vp, C.c_char_p],

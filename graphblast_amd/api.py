@@ -444,6 +444,18 @@ def bfs(v, A, s, desc, fused=False, profile=False, max_levels=4096):
                       reached=res.reached, per_level=levels)
 
 
+def bfs_batch(vs, A, sources, desc):
+    """Up to 64 traversals at once (grb_bfs_batch): vs[i] receives the depth labels of sources[i]."""
+    k = len(vs)
+    assert k == len(sources)
+    handles = (C.c_void_p * k)(*[_h(v) for v in vs])
+    src = np.ascontiguousarray(sources, dtype=np.int32)
+    res = BfsResult()
+    info = _lib.load().grb_bfs_batch(handles, k, _h(A), src.ctypes.data, _h(desc), C.byref(res))
+    return info, dict(levels=res.levels, tight_ms=res.tight_ms, edges_traversed=res.edges_traversed,
+                      reached=res.reached)
+
+
 def sssp(v, A, s, desc):
     res = AlgoResult()
     info = _lib.load().grb_sssp(_h(v), _h(A), int(s), _h(desc), C.byref(res))

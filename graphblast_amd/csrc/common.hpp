@@ -400,6 +400,17 @@ struct grb_vector_s {
   bool d_owned = true;
 };
 
+namespace grb {
+// rows of >= 4096 entries cut into 4096-entry slices for the batched traversal (bfs_batch.hip)
+struct BatchSlices {
+  bool ready = false;
+  int4* d_slices = nullptr;      // {vertex, first entry, end entry, big index}
+  Index* d_rows = nullptr;       // the big rows' vertex ids
+  unsigned long long* d_acc = nullptr;   // one word per big row, zero between levels
+  int nslices = 0, nbig = 0;
+};
+}  // namespace grb
+
 struct grb_matrix_s {
   int dtype = GRB_F32;
   grb::Index nrows = 0, ncols = 0, nvals = 0;
@@ -419,6 +430,7 @@ struct grb_matrix_s {
   unsigned int* d_empty_csr_rows = nullptr;      // bitmap: CSR row empty (built lazily by bfs_part)
   int nonneg_values = -1;                        // -1 unknown, else whether every stored value is >= 0 (sssp_persist)
   grb::Index* d_pull_hint = nullptr;                  // per vertex: its in-neighbour of largest out-degree (bfs_fused)
+  grb::BatchSlices batch_in, batch_out;          // bfs_batch.hip, built lazily
 };
 
 namespace grb {

@@ -732,6 +732,12 @@ void grb::matrix_release_device(grb_matrix A) {
   if (A->d_no_in_edges) { (void)hipFree(A->d_no_in_edges); A->d_no_in_edges = nullptr; }
   if (A->d_empty_csr_rows) { (void)hipFree(A->d_empty_csr_rows); A->d_empty_csr_rows = nullptr; }
   if (A->d_pull_hint) { (void)hipFree(A->d_pull_hint); A->d_pull_hint = nullptr; }
+  for (BatchSlices* b : {&A->batch_in, &A->batch_out}) {
+    if (b->d_slices) (void)hipFree(b->d_slices);
+    if (b->d_rows) (void)hipFree(b->d_rows);
+    if (b->d_acc) (void)hipFree(b->d_acc);
+    *b = BatchSlices();
+  }
   A->nonneg_values = -1;
   free_spmv_plan(&A->plan_csr);
   free_spmv_plan(&A->plan_csc);

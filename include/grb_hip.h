@@ -315,6 +315,15 @@ typedef struct {
                                * pr: last residual `error`                              */
 } grb_algo_result;
 
+/* Batched traversals = the multi-frontier product (extension; the reference leaves sparse x dense
+ * mxm a stub, backend/cuda/operations.hpp:52-70, spmm.hpp:15-27): 1 <= k <= 64 sources traversed at
+ * once, one 64-bit word per vertex (bit s = source s), levels as word-wide OR.  v[s] (k dense f32
+ * vectors of size nrows) receive exactly the labels grb_bfs / grb_bfs_fused give for sources[s]
+ * under the same descriptor (mxvmode forces a direction; max_niter caps the levels).
+ * result->edges_traversed / reached are summed over the k traversals. */
+grb_info grb_bfs_batch(grb_vector* v, int k, grb_matrix A, const grb_index* sources, grb_descriptor desc,
+                       grb_bfs_result* result);
+
 /* One record per iteration of the last grb_sssp / grb_pr / grb_cc call on a descriptor: what the
  * reference's drivers print per iteration under --timing 1 (sssp.hpp:55-62, pr.hpp:53-62) or 2
  * (cc.hpp:61-71).  Kept when the descriptor's `timing` argument is non-zero. */
