@@ -8,25 +8,36 @@
 // No tile of A is dense enough for a matrix core to beat that (multi-frontier): the
 // MFMA path of this library is the dense-core SpMM in spmm.hip.
 //
-//   seen[v], F[v]   one 64-bit word per vertex; two F buffers (read / written)
-//   pull level      a lane per vertex: need = ~seen & active; the hinted in-neighbour first, four
-//                   serial probes, then the wave finishes the row together (256 entries per step,
-//                   OR-reduced across the wave), stopping as soon as every needed bit is found.
-//                   Rows of >= 4096 entries are cut into 4096-entry slices taken by separate waves
-//                   (a hub row that finds nothing must not be one wave's 2 MB)
-//   push level      frontier words != 0 expand along out-edges with atomicOr into a zeroed F';
-//                   an apply pass turns F' into new bits, labels and totals
-//   labels          label[s][v] = level of discovery (source = 1, unreached = 0): the k depth
-//                   vectors k calls of algorithm::bfs would return -- bit-identical, because BFS
-//                   depth is unique
+//   seen[v], W_L[v]  one 64-bit word per vertex; W_L = the bits discovered by level L, kept for
+//                    the first kStore levels (the frontier of level L + 1 IS W_L)
+//   direction        chosen PER SOURCE every level from that source's frontier size and out-degree
+//                    sum: bits of small frontiers are pushed, bits of large ones pulled, in the same
+//                    level.  (A union rule makes every vertex scan its whole list for the 63 sources
+//                    that are still near their start while one hub source already floods the graph.)
+//   pull (bits Q)    a lane per vertex: need = ~seen & Q; the hinted in-neighbour first, four serial
+//                    probes, then the wave finishes the row together (256 entries per step, OR-reduced
+//                    across the wave), stopping as soon as every needed bit is found.  Rows of >= 4096
+//                    entries are cut into 4096-entry slices taken by separate waves
+//   push (bits P)    frontier words with P bits expand along out-edges: atomicOr into W_L (the pull
+//                    pass has just written every word of it; zeroed when nothing is pulled), the
+//                    bits that were new go into seen with a second atomicOr
+//   labels           not written while traversing: one final pass turns the stored level words into
+//                    the k depth vectors (label[s][v] = level of discovery, source = 1, unreached =
+//                    0) with full-width coalesced stores -- no memset, no scattered 4-byte stores.
+//                    Levels beyond kStore (long-diameter graphs, tiny frontiers) label directly.
+//                    The vectors are what k calls of algorithm::bfs return: BFS depth is unique.
 #include "bfs_kernels.hpp"
+#include <chrono>
 
 namespace grb {
 
 constexpr int kBatchBig = 4096;       // row length from which a row is cut into slices
 constexpr int kBatchSlice = 4096;
+constexpr int kBatchPushSlice = 1024; // push: out-edge slices (every edge is a chain of dependent memory steps)
 constexpr int kBatchSerial = 4;       // serial probes per lane before the wave takes over
-constexpr int kBatchSlots = 64;       // counter slots (spreads same-address atomics)
+constexpr int kBatchSlots = 16;       // counter slots (spreads same-address atomics)
+constexpr int kBatchStoreMax = 16;    // level words kept for the final label pass
+constexpr int kBatchCounters = 2 + 128;   // per slot: vertices, out-degree sum, then {nf_s, mf_s} per source
 
 typedef unsigned long long u64;
 
@@ -34,16 +45,27 @@ struct BatchArgs {
   const Index *optr, *oind, *iptr, *iind;
   const Index* hint;
   Index n;
-  u64 amask;
-  u64 *seen, *fcur, *fnext;
+  u64 qmask, pmask;                   // bits pulled / pushed this level
+  u64* seen;
+  const u64* fcur;
+  u64* fnext;
   u64* bigacc;                        // one word per big row (pull slices OR into it)
   const int4* slices;                 // {vertex, first entry, end entry, big index}
   int nslices;
   const Index* bigrows;               // the big rows' vertex ids
   int nbig;
-  u64* counters;                      // [kBatchSlots][4]: vertices, their out-degree sum, pairs, pair edges
+  u64* counters;                      // [kBatchSlots][kBatchCounters]
   float new_label;
+  int direct_labels;                  // levels beyond the stored ones write labels as they discover
   int k;
+  float* label[64];
+};
+
+struct LabelArgs {
+  Index n;
+  int k, nstored, max_label;
+  const u64* seen;
+  const u64* W[kBatchStoreMax + 1];
   float* label[64];
 };
 
@@ -53,33 +75,46 @@ __device__ inline u64 wave_or(u64 x) {
   return x;
 }
 
-// labels + accounting of a lane's new bits; every lane of the wave must call it
-__device__ inline void batch_commit(const BatchArgs& a, Index v, u64 newb, u64 (&tot)[4]) {
+struct BatchTotals {                  // per workgroup, in LDS
+  u64 v[kBatchCounters];
+};
+
+// accounting (and, beyond the stored levels, labels) of a lane's new bits; wave-collective
+__device__ inline void batch_commit(const BatchArgs& a, BatchTotals* lds, Index v, u64 newb) {
   const u64 any = wave_or(newb);
+  if (!any) return;
+  const int lane = lane_id();
+  unsigned int deg = 0;
+  if (newb) deg = (unsigned int)(a.optr[v + 1] - a.optr[v]);
   for (u64 t = any; t; t &= t - 1) {
     const int s = __builtin_amdgcn_readfirstlane(__ffsll((long long)t) - 1);   // wave-uniform: a scalar index
-    if ((newb >> s) & 1ull) a.label[s][v] = a.new_label;
+    const bool bit = (newb >> s) & 1ull;
+    const unsigned long long m = __ballot(bit);
+    unsigned int dsum = bit ? deg : 0u;                   // 64 lanes x degree < 2^31
+#pragma unroll
+    for (int o = kWave / 2; o > 0; o >>= 1) dsum += __shfl_xor(dsum, o, kWave);
+    if (lane == 0) {
+      atomicAdd(&lds->v[2 + 2 * s], (u64)__popcll(m));
+      atomicAdd(&lds->v[3 + 2 * s], (u64)dsum);
+    }
+    if (a.direct_labels && bit) a.label[s][v] = a.new_label;
   }
-  if (newb) {
-    const u64 d = (u64)(a.optr[v + 1] - a.optr[v]);
-    const u64 pc = (u64)__popcll(newb);
-    tot[0] += 1; tot[1] += d; tot[2] += pc; tot[3] += pc * d;
-  }
+  const unsigned long long mv = __ballot(newb != 0);
+  unsigned int du = deg;
+#pragma unroll
+  for (int o = kWave / 2; o > 0; o >>= 1) du += __shfl_xor(du, o, kWave);
+  if (lane == 0) { atomicAdd(&lds->v[0], (u64)__popcll(mv)); atomicAdd(&lds->v[1], (u64)du); }
 }
 
-__device__ inline void batch_flush(const BatchArgs& a, u64 (&tot)[4]) {
-  __shared__ u64 s_tot[4];
-  if (threadIdx.x < 4) s_tot[threadIdx.x] = 0;
+__device__ inline void totals_init(BatchTotals* lds) {
+  for (int i = threadIdx.x; i < kBatchCounters; i += blockDim.x) lds->v[i] = 0;
   __syncthreads();
-  auto add = [](u64 x, u64 y) { return x + y; };
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const u64 r = wave_reduce(tot[j], add);
-    if (lane_id() == 0 && r) atomicAdd(&s_tot[j], r);
-  }
+}
+__device__ inline void totals_flush(const BatchArgs& a, BatchTotals* lds) {
   __syncthreads();
-  if (threadIdx.x < 4 && s_tot[threadIdx.x])
-    atomicAdd(&a.counters[(blockIdx.x & (kBatchSlots - 1)) * 4 + threadIdx.x], s_tot[threadIdx.x]);
+  u64* dst = a.counters + (size_t)(blockIdx.x & (kBatchSlots - 1)) * kBatchCounters;
+  for (int i = threadIdx.x; i < kBatchCounters; i += blockDim.x)
+    if (lds->v[i]) atomicAdd(&dst[i], lds->v[i]);
 }
 
 // the wave scans entries [rs, re) of `ind`, ORs word[ind[q]] and stops once `nd` is covered
@@ -102,26 +137,26 @@ __device__ inline u64 wave_scan_or(const Index* __restrict__ ind, const u64* __r
   return got;
 }
 
-__global__ __launch_bounds__(kBlock) void batch_seed_kernel(BatchArgs a, const Index* __restrict__ sources) {
+__global__ __launch_bounds__(kBlock) void batch_seed_kernel(u64* seen, u64* w0, const Index* __restrict__ sources, int k) {
   const int s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s < a.k) {
+  if (s < k) {
     const Index v = sources[s];
-    atomicOr(&a.seen[v], 1ull << s);
-    atomicOr(&a.fcur[v], 1ull << s);
-    a.label[s][v] = 1.f;
+    atomicOr(&seen[v], 1ull << s);
+    atomicOr(&w0[v], 1ull << s);
   }
 }
 
 __global__ __launch_bounds__(kBlock) void batch_pull_kernel(BatchArgs a) {
+  __shared__ BatchTotals lds;
+  totals_init(&lds);
   const int lane = lane_id();
   const Index nchunks = (a.n + kWave - 1) / kWave;
   const Index nwaves = (Index)gridDim.x * kWavesPerBlock;
-  u64 tot[4] = {0, 0, 0, 0};
   for (Index chunk = (Index)blockIdx.x * kWavesPerBlock + wave_id(); chunk < nchunks; chunk += nwaves) {
     const Index v = chunk * kWave + lane;
     const bool valid = v < a.n;
     const u64 seen = valid ? a.seen[v] : ~0ull;
-    u64 need = ~seen & a.amask;
+    u64 need = ~seen & a.qmask;
     Index p = 0, e = 0;
     if (need) { p = a.iptr[v]; e = a.iptr[v + 1]; }
     const bool big = e - p >= kBatchBig;                   // the slice kernels own this row
@@ -153,9 +188,9 @@ __global__ __launch_bounds__(kBlock) void batch_pull_kernel(BatchArgs a) {
       a.fnext[v] = newb;
       if (newb) a.seen[v] = seen | newb;
     }
-    batch_commit(a, valid ? v : 0, newb, tot);
+    batch_commit(a, &lds, valid ? v : 0, newb);
   }
-  batch_flush(a, tot);
+  totals_flush(a, &lds);
 }
 
 // pull, big rows: a wave per 4096-entry slice
@@ -164,7 +199,7 @@ __global__ __launch_bounds__(kBlock) void batch_pull_slices_kernel(BatchArgs a) 
   const int nwaves = gridDim.x * kWavesPerBlock;
   for (int sl = blockIdx.x * kWavesPerBlock + wave_id(); sl < a.nslices; sl += nwaves) {
     const int4 S = a.slices[sl];
-    const u64 need = ~a.seen[S.x] & a.amask;
+    const u64 need = ~a.seen[S.x] & a.qmask;
     if (!need) continue;
     const u64 got = wave_scan_or(a.iind, a.fcur, S.y, S.z, need, lane) & need;
     if (lane == 0 && got) atomicOr(&a.bigacc[S.w], got);
@@ -172,7 +207,8 @@ __global__ __launch_bounds__(kBlock) void batch_pull_slices_kernel(BatchArgs a) 
 }
 
 __global__ __launch_bounds__(kBlock) void batch_big_apply_kernel(BatchArgs a) {
-  u64 tot[4] = {0, 0, 0, 0};
+  __shared__ BatchTotals lds;
+  totals_init(&lds);
   const int nthreads = gridDim.x * blockDim.x;
   for (int base = 0; base < a.nbig; base += nthreads) {
     const int b = base + blockIdx.x * blockDim.x + threadIdx.x;
@@ -181,34 +217,64 @@ __global__ __launch_bounds__(kBlock) void batch_big_apply_kernel(BatchArgs a) {
     u64 newb = 0;
     if (valid) {
       const u64 seen = a.seen[v];
-      newb = a.bigacc[b] & ~seen & a.amask;
+      newb = a.bigacc[b] & ~seen & a.qmask;
       a.bigacc[b] = 0ull;
       a.fnext[v] = newb;
       if (newb) a.seen[v] = seen | newb;
     }
-    batch_commit(a, v, newb, tot);
+    batch_commit(a, &lds, v, newb);
   }
-  batch_flush(a, tot);
+  totals_flush(a, &lds);
 }
 
-__device__ inline void batch_push_edge(const BatchArgs& a, Index dst, u64 fw) {
-  const u64 bits = fw & ~a.seen[dst];
-  if (bits && (bits & ~a.fnext[dst])) atomicOr(&a.fnext[dst], bits);
+// N out-edges of a frontier vertex carrying the pushed bits fw, their dependent steps issued stage by
+// stage (targets, seen words, claims, seen updates, degrees): one chain of memory latencies per N edges
+template <int N>
+__device__ inline void batch_push_edges(const BatchArgs& a, BatchTotals* lds, const Index* __restrict__ ind, Index q0,
+                                        Index stride, Index end, u64 fw) {
+  Index dst[N];
+  u64 bits[N];
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    const Index q = q0 + j * stride;
+    dst[j] = q < end ? ind[q] : -1;
+  }
+#pragma unroll
+  for (int j = 0; j < N; ++j) bits[j] = dst[j] >= 0 ? (fw & ~a.seen[dst[j]]) : 0ull;
+#pragma unroll
+  for (int j = 0; j < N; ++j)
+    if (bits[j]) bits[j] &= ~atomicOr(&a.fnext[dst[j]], bits[j]);
+#pragma unroll
+  for (int j = 0; j < N; ++j)
+    if (bits[j]) bits[j] &= ~atomicOr(&a.seen[dst[j]], bits[j]);
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    if (!bits[j]) continue;
+    const u64 deg = (u64)(a.optr[dst[j] + 1] - a.optr[dst[j]]);
+    for (u64 t = bits[j]; t; t &= t - 1) {
+      const int s = __ffsll((long long)t) - 1;
+      atomicAdd(&lds->v[2 + 2 * s], 1ull);
+      atomicAdd(&lds->v[3 + 2 * s], deg);
+      if (a.direct_labels) a.label[s][dst[j]] = a.new_label;
+    }
+  }
 }
 
 __global__ __launch_bounds__(kBlock) void batch_push_kernel(BatchArgs a) {
+  __shared__ BatchTotals lds;
+  totals_init(&lds);
   const int lane = lane_id();
   const Index nchunks = (a.n + kWave - 1) / kWave;
   const Index nwaves = (Index)gridDim.x * kWavesPerBlock;
   for (Index chunk = (Index)blockIdx.x * kWavesPerBlock + wave_id(); chunk < nchunks; chunk += nwaves) {
     const Index u = chunk * kWave + lane;
-    const u64 fw = u < a.n ? a.fcur[u] : 0ull;
+    const u64 fw = u < a.n ? (a.fcur[u] & a.pmask) : 0ull;
     if (__ballot(fw != 0) == 0ull) continue;
     Index p = 0, e = 0;
     if (fw) { p = a.optr[u]; e = a.optr[u + 1]; }
     if (e - p >= kBatchBig) p = e;                         // the slice kernel expands it
     if (e - p <= 8) {
-      for (; p < e; ++p) batch_push_edge(a, a.oind[p], fw);
+      for (; p < e; p += 4) batch_push_edges<4>(a, &lds, a.oind, p, 1, e, fw);
     }
     u64 todo = __ballot(p < e);
     while (todo) {
@@ -216,43 +282,52 @@ __global__ __launch_bounds__(kBlock) void batch_push_kernel(BatchArgs a) {
       todo &= todo - 1;
       const Index rs = __shfl(p, src, kWave), re = __shfl(e, src, kWave);
       const u64 w = __shfl(fw, src, kWave);
-      for (Index q = rs + lane; q < re; q += kWave) batch_push_edge(a, a.oind[q], w);
+      for (Index q = rs + lane; q < re; q += 4 * kWave) batch_push_edges<4>(a, &lds, a.oind, q, kWave, re, w);
     }
   }
+  totals_flush(a, &lds);
 }
 
 __global__ __launch_bounds__(kBlock) void batch_push_slices_kernel(BatchArgs a) {
+  __shared__ BatchTotals lds;
+  totals_init(&lds);
   const int lane = lane_id();
   const int nwaves = gridDim.x * kWavesPerBlock;
   for (int sl = blockIdx.x * kWavesPerBlock + wave_id(); sl < a.nslices; sl += nwaves) {
     const int4 S = a.slices[sl];
-    const u64 fw = a.fcur[S.x];
+    const u64 fw = a.fcur[S.x] & a.pmask;
     if (!fw) continue;
-    for (Index q = S.y + lane; q < S.z; q += kWave) batch_push_edge(a, a.oind[q], fw);
+    for (Index q = S.y + lane; q < S.z; q += 4 * kWave) batch_push_edges<4>(a, &lds, a.oind, q, kWave, S.z, fw);
   }
+  totals_flush(a, &lds);
 }
 
-// after a push level: F' holds ORed candidate bits; make them the new frontier
-__global__ __launch_bounds__(kBlock) void batch_apply_kernel(BatchArgs a) {
+// the depth vectors from the stored level words: full 256-byte stores, every element written once
+__global__ __launch_bounds__(kBlock) void batch_labels_kernel(LabelArgs a) {
   const int lane = lane_id();
   const Index nchunks = (a.n + kWave - 1) / kWave;
   const Index nwaves = (Index)gridDim.x * kWavesPerBlock;
-  u64 tot[4] = {0, 0, 0, 0};
   for (Index chunk = (Index)blockIdx.x * kWavesPerBlock + wave_id(); chunk < nchunks; chunk += nwaves) {
     const Index v = chunk * kWave + lane;
     const bool valid = v < a.n;
-    const u64 raw = valid ? a.fnext[v] : 0ull;
-    if (__ballot(raw != 0) == 0ull) continue;
-    u64 newb = 0;
-    if (raw) {
-      const u64 seen = a.seen[v];
-      newb = raw & ~seen & a.amask;
-      if (newb != raw) a.fnext[v] = newb;
-      if (newb) a.seen[v] = seen | newb;
+    // level numbers (<= kBatchStoreMax + 1 < 32) as five bit planes: plane b holds, per source, bit b of
+    // the level that discovered this vertex (the level words are disjoint, so OR composes them); `hit` = found
+    u64 plane[5] = {0, 0, 0, 0, 0}, hit = 0;
+    for (int L = 0; L < a.nstored; ++L) {
+      const u64 w = valid ? a.W[L][v] : 0ull;
+      const int lab = L + 1 > a.max_label ? 0 : L + 1;     // discovered by the last allowed iteration: never assigned
+      hit |= w;
+#pragma unroll
+      for (int b = 0; b < 5; ++b) plane[b] |= ((lab >> b) & 1) ? w : 0ull;
     }
-    batch_commit(a, valid ? v : 0, newb, tot);
+    const u64 later = valid ? (a.seen[v] & ~hit) : ~0ull;  // seen, but by a level beyond the stored ones: labelled there
+    for (int s = 0; s < a.k; ++s) {
+      int lab = 0;
+#pragma unroll
+      for (int b = 0; b < 5; ++b) lab |= (int)((plane[b] >> s) & 1ull) << b;
+      if (!((later >> s) & 1ull)) a.label[s][v] = (float)lab;
+    }
   }
-  batch_flush(a, tot);
 }
 
 __global__ void batch_unlabel_kernel(BatchArgs a, float bad) {
@@ -277,8 +352,9 @@ static grb_info ensure_slices(grb_matrix A, bool in_edges) {
   for (Index v = 0; v < n; ++v) {
     const Index d = ptr[(size_t)v + 1] - ptr[v];
     if (d < kBatchBig) continue;
-    for (Index s = ptr[v]; s < ptr[(size_t)v + 1]; s += kBatchSlice)
-      sl.push_back(make_int4(v, s, std::min<Index>(s + kBatchSlice, ptr[(size_t)v + 1]), (int)rows.size()));
+    const Index step = in_edges ? kBatchSlice : kBatchPushSlice;
+    for (Index s = ptr[v]; s < ptr[(size_t)v + 1]; s += step)
+      sl.push_back(make_int4(v, s, std::min<Index>(s + step, ptr[(size_t)v + 1]), (int)rows.size()));
     rows.push_back(v);
   }
   B.nslices = (int)sl.size();
@@ -315,60 +391,88 @@ extern "C" grb_info grb_bfs_batch(grb_vector* v, int k, grb_matrix A, const grb_
   GRB_TRY(ensure_slices(A, true));
   GRB_TRY(ensure_slices(A, false));
 
+  // stored level words: as many as fit 1 GiB, at most kBatchStoreMax (+ the seed words) + two rotating buffers
+  int nstore = (int)((1ull << 30) / (sizeof(u64) * (size_t)(n > 0 ? n : 1)));
+  if (nstore > kBatchStoreMax) nstore = kBatchStoreMax;
+  if (nstore < 1) nstore = 1;
+  const int nbuf = nstore + 1 + 2 + 1;                     // W[0..nstore], X0, X1, seen
   void *p_words, *p_cnt, *p_src;
-  GRB_TRY(scratch(7, 3 * sizeof(u64) * (size_t)n + 256, &p_words));
+  GRB_TRY(scratch(7, (size_t)nbuf * sizeof(u64) * (size_t)n + 256, &p_words));
   c.bfs_prezero_ptr = nullptr;                              // slot 7 is the one-launch traversal's pre-zeroed block
-  GRB_TRY(scratch(10, sizeof(u64) * kBatchSlots * 4, &p_cnt));
+  GRB_TRY(scratch(10, sizeof(u64) * kBatchSlots * kBatchCounters, &p_cnt));
   GRB_TRY(scratch(9, sizeof(Index) * 64, &p_src));
+  u64* seen = (u64*)p_words;
+  auto W = [&](int i) -> u64* {                             // words written by level i (0 = the seeds)
+    const int b = i <= nstore ? i : nstore + 1 + ((i - nstore - 1) & 1);
+    return seen + (size_t)(1 + b) * (size_t)n;
+  };
   BatchArgs a;
   a.optr = A->csr.ptr; a.oind = A->csr.ind; a.iptr = A->csc.ptr; a.iind = A->csc.ind;
   a.hint = A->d_pull_hint;
   a.n = n;
-  a.amask = k == 64 ? ~0ull : ((1ull << k) - 1ull);
-  a.seen = (u64*)p_words;
-  a.fcur = a.seen + n;
-  a.fnext = a.fcur + n;
+  a.seen = seen;
   a.counters = (u64*)p_cnt;
   a.k = k;
   for (int s = 0; s < 64; ++s) a.label[s] = nullptr;
   for (int s = 0; s < k; ++s) {
     GRB_TRY(grb_vector_set_storage(v[s], GRB_DENSE));
     a.label[s] = (float*)v[s]->d_val;
-    GRB_HIP_TRY(hipMemsetAsync(a.label[s], 0, sizeof(float) * (size_t)n, st));
   }
-  GRB_HIP_TRY(hipMemsetAsync(a.seen, 0, 2 * sizeof(u64) * (size_t)n, st));
+  GRB_HIP_TRY(hipMemsetAsync(seen, 0, 2 * sizeof(u64) * (size_t)n, st));       // seen and W[0]
   GRB_HIP_TRY(hipMemcpyAsync(p_src, sources, sizeof(Index) * (size_t)k, hipMemcpyHostToDevice, st));
-  a.new_label = 1.f;
-  a.bigacc = nullptr; a.slices = nullptr; a.nslices = 0; a.bigrows = nullptr; a.nbig = 0;
-  hipLaunchKernelGGL(batch_seed_kernel, dim3(1), dim3(kBlock), 0, st, a, (const Index*)p_src);
+  hipLaunchKernelGGL(batch_seed_kernel, dim3(1), dim3(kBlock), 0, st, seen, W(0), (const Index*)p_src, k);
   GRB_HIP_TRY(hipGetLastError());
 
-  // frontier totals of the seed level on the host (k <= 64 sources)
-  long long nf = 0, mf = 0;
-  unsigned long long edges = 0, reached = 0;
-  {
-    std::vector<Index> uniq(sources, sources + k);
-    std::sort(uniq.begin(), uniq.end());
-    uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
-    nf = (long long)uniq.size();
-    for (Index u : uniq) mf += A->h_csr_ptr[(size_t)u + 1] - A->h_csr_ptr[u];
-    for (int s = 0; s < k; ++s) edges += (unsigned long long)(A->h_csr_ptr[(size_t)sources[s] + 1] - A->h_csr_ptr[sources[s]]);
-    reached = (unsigned long long)k;
+  // per-source frontier totals of the seed level
+  unsigned long long nf_s[64], mf_s[64];
+  unsigned long long edges = 0, reached = (unsigned long long)k;
+  for (int s = 0; s < k; ++s) {
+    nf_s[s] = 1;
+    mf_s[s] = (unsigned long long)(A->h_csr_ptr[(size_t)sources[s] + 1] - A->h_csr_ptr[sources[s]]);
+    edges += mf_s[s];
   }
   const int mode = desc->desc[GRB_MXVMODE];
   const int grid = stream_grid((long long)ceil_div(n, kWave) * kWave, kBlock);
   int iter = 1, levels = 0, last_dir = 0;
-  bool hit_cap = false;
+  bool any_left = true;
   float ms = 0.f;
+  static const bool trace = getenv("GRB_BATCH_TRACE") != nullptr;
+  auto now_us = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   GRB_TRY(grb_timer_start());
   for (; iter <= desc->max_niter; ++iter) {
-    // direction: the reference's vertex-count rule on the union frontier, plus the edge-aware switch
-    bool pull = mode == GRB_PULLONLY;
-    if (mode == GRB_PUSHPULL)
-      pull = (double)nf > (double)desc->switchpoint * (double)n || (double)mf > 0.02 * (double)A->nvals;
+    const double t_lvl = trace ? now_us() : 0.0;
+    // ---- direction per source: the reference's vertex-count rule (switchpoint) on that source's own
+    // frontier, and a budget on the edges pushed in one level
+    u64 P = 0, Q = 0;
+    {
+      int order[64];
+      int m = 0;
+      for (int s = 0; s < k; ++s) if (nf_s[s] > 0) order[m++] = s;
+      if (mode == GRB_PULLONLY) { for (int i = 0; i < m; ++i) Q |= 1ull << order[i]; }
+      else if (mode == GRB_PUSHONLY) { for (int i = 0; i < m; ++i) P |= 1ull << order[i]; }
+      else {
+        // pull the sources whose own frontier passed the reference's switch point (their bits are found within
+        // a few probes, so the early exit works); push the others -- unless their out-edges together exceed a
+        // quarter of the matrix, then the heaviest of them are pulled as well
+        std::sort(order, order + m, [&](int x, int y) { return mf_s[x] > mf_s[y]; });
+        double pushed = 0;
+        for (int i = 0; i < m; ++i)
+          if ((double)nf_s[order[i]] <= (double)desc->switchpoint * (double)n) pushed += (double)mf_s[order[i]];
+        for (int i = 0; i < m; ++i) {
+          const int s = order[i];
+          bool pull = (double)nf_s[s] > (double)desc->switchpoint * (double)n;
+          if (!pull && pushed > 0.25 * (double)A->nvals) { pull = true; pushed -= (double)mf_s[s]; }
+          if (pull) Q |= 1ull << s; else P |= 1ull << s;
+        }
+      }
+    }
+    a.qmask = Q; a.pmask = P;
+    a.fcur = W(iter - 1);
+    a.fnext = W(iter);
     a.new_label = (float)(iter + 1);
-    GRB_HIP_TRY(hipMemsetAsync(a.counters, 0, sizeof(u64) * kBatchSlots * 4, st));
-    if (pull) {
+    a.direct_labels = iter > nstore ? 1 : 0;
+    GRB_HIP_TRY(hipMemsetAsync(a.counters, 0, sizeof(u64) * kBatchSlots * kBatchCounters, st));
+    if (Q) {
       const BatchSlices& B = A->batch_in;
       a.slices = B.d_slices; a.nslices = B.nslices; a.bigrows = B.d_rows; a.nbig = B.nbig; a.bigacc = B.d_acc;
       hipLaunchKernelGGL(batch_pull_kernel, dim3(grid), dim3(kBlock), 0, st, a);
@@ -381,9 +485,11 @@ extern "C" grb_info grb_bfs_batch(grb_vector* v, int k, grb_matrix A, const grb_
         GRB_HIP_TRY(hipGetLastError());
       }
     } else {
+      GRB_HIP_TRY(hipMemsetAsync(a.fnext, 0, sizeof(u64) * (size_t)n, st));
+    }
+    if (P) {
       const BatchSlices& B = A->batch_out;
       a.slices = B.d_slices; a.nslices = B.nslices; a.bigrows = B.d_rows; a.nbig = B.nbig; a.bigacc = B.d_acc;
-      GRB_HIP_TRY(hipMemsetAsync(a.fnext, 0, sizeof(u64) * (size_t)n, st));
       hipLaunchKernelGGL(batch_push_kernel, dim3(grid), dim3(kBlock), 0, st, a);
       GRB_HIP_TRY(hipGetLastError());
       if (B.nslices > 0) {
@@ -391,27 +497,46 @@ extern "C" grb_info grb_bfs_batch(grb_vector* v, int k, grb_matrix A, const grb_
                            0, st, a);
         GRB_HIP_TRY(hipGetLastError());
       }
-      hipLaunchKernelGGL(batch_apply_kernel, dim3(grid), dim3(kBlock), 0, st, a);
-      GRB_HIP_TRY(hipGetLastError());
     }
-    u64 h[kBatchSlots * 4];
+    static u64 h[kBatchSlots * kBatchCounters];
     GRB_HIP_TRY(hipMemcpyAsync(h, a.counters, sizeof(h), hipMemcpyDeviceToHost, st));
     GRB_HIP_TRY(hipStreamSynchronize(st));
-    u64 t[4] = {0, 0, 0, 0};
+    u64 t[kBatchCounters];
+    for (int j = 0; j < kBatchCounters; ++j) t[j] = 0;
     for (int i = 0; i < kBatchSlots; ++i)
-      for (int j = 0; j < 4; ++j) t[j] += h[i * 4 + j];
+      for (int j = 0; j < kBatchCounters; ++j) t[j] += h[i * kBatchCounters + j];
     ++levels;
-    last_dir = pull ? 1 : 0;
-    nf = (long long)t[0];
-    mf = (long long)t[1];
-    reached += t[2];
-    edges += t[3];
-    std::swap(a.fcur, a.fnext);
-    if (nf == 0) break;
+    last_dir = Q ? 1 : 0;
+    any_left = false;
+    u64 pairs = 0;
+    for (int s = 0; s < k; ++s) {
+      nf_s[s] = t[2 + 2 * s];
+      mf_s[s] = t[3 + 2 * s];
+      pairs += nf_s[s];
+      reached += nf_s[s];
+      edges += mf_s[s];
+      if (nf_s[s]) any_left = true;
+    }
+    if (trace)
+      fprintf(stderr, "batch level %d: pull %d sources, push %d -> vertices %llu pairs %llu  %.1f us\n", iter,
+              __builtin_popcountll(Q), __builtin_popcountll(P), t[0], pairs, now_us() - t_lvl);
+    if (!any_left) break;
   }
-  if (iter > desc->max_niter && nf > 0) {
+  const bool hit_cap = iter > desc->max_niter && any_left;
+  // ---- the depth vectors
+  {
+    LabelArgs L;
+    L.n = n; L.k = k;
+    L.nstored = 1 + (levels < nstore ? levels : nstore);
+    L.max_label = desc->max_niter;
+    L.seen = seen;
+    for (int i = 0; i <= kBatchStoreMax; ++i) L.W[i] = i < L.nstored ? W(i) : nullptr;
+    for (int s = 0; s < 64; ++s) L.label[s] = a.label[s];
+    hipLaunchKernelGGL(batch_labels_kernel, dim3(grid), dim3(kBlock), 0, st, L);
+    GRB_HIP_TRY(hipGetLastError());
+  }
+  if (hit_cap && levels > nstore) {
     // vertices discovered by the last allowed iteration are never assigned by the reference loop (bfs.hpp:48-66)
-    hit_cap = true;
     hipLaunchKernelGGL(batch_unlabel_kernel, dim3(stream_grid(n, kBlock)), dim3(kBlock), 0, st, a,
                        (float)(desc->max_niter + 1));
     GRB_HIP_TRY(hipGetLastError());
