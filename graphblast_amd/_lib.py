@@ -91,6 +91,8 @@ _SIGS = {
     "grb_matrix_host_csr": [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp)],
     "grb_matrix_host_csc": [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp)],
     "grb_matrix_set_values": [_vp, _vp],
+    "grb_spmm": [_i, _vp, _i, _vp, _vp, _i, _vp],
+    "grb_spmm_core_info": [_vp, _i, C.POINTER(_i), C.POINTER(C.c_int64)],
     "grb_bfs_batch": [_vp, _i, _vp, _vp, _vp, _vp],
     "grb_descriptor_iter_log": [_vp, _vp, _i, C.POINTER(_i)],
     "grb_cache_name": [C.c_char_p, _i, C.c_char_p, C.c_size_t],

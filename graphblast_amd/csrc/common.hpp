@@ -409,6 +409,21 @@ struct BatchSlices {
   unsigned long long* d_acc = nullptr;   // one word per big row, zero between levels
   int nslices = 0, nbig = 0;
 };
+// dense-core split of one orientation for the MFMA SpMM path (spmm.hip)
+struct SpmmCore {
+  bool built = false;
+  int H = 0;                      // rows / columns considered
+  int ntiles = 0, ntrows = 0;     // stored 16 x 16 tiles, tile rows
+  long long nnz_core = 0;         // entries moved into tiles
+  int* d_trow_ptr = nullptr;      // [ntrows + 1]
+  int* d_tcol = nullptr;          // [ntiles] tile column
+  float* d_tvals = nullptr;       // [ntiles][16][16], transposed ([kk][i])
+  Index* d_rows = nullptr;        // [ntrows * 16] core row -> matrix row (-1 padding)
+  Index* d_cols = nullptr;        // [ntcols * 16] core column -> matrix column (-1 padding)
+  CsrArrays rest;                 // the matrix without the entries of stored tiles
+  SpmvPlan rest_plan;
+};
+void free_spmm_core(SpmmCore* core);
 }  // namespace grb
 
 struct grb_matrix_s {
@@ -431,6 +446,7 @@ struct grb_matrix_s {
   int nonneg_values = -1;                        // -1 unknown, else whether every stored value is >= 0 (sssp_persist)
   grb::Index* d_pull_hint = nullptr;                  // per vertex: its in-neighbour of largest out-degree (bfs_fused)
   grb::BatchSlices batch_in, batch_out;          // bfs_batch.hip, built lazily
+  grb::SpmmCore spmm_core_csr, spmm_core_csc;    // spmm.hip, built lazily when GRB_SPMM_CORE is set
 };
 
 namespace grb {

@@ -739,6 +739,8 @@ void grb::matrix_release_device(grb_matrix A) {
     *b = BatchSlices();
   }
   A->nonneg_values = -1;
+  free_spmm_core(&A->spmm_core_csr);
+  free_spmm_core(&A->spmm_core_csc);
   free_spmv_plan(&A->plan_csr);
   free_spmv_plan(&A->plan_csc);
   A->built = false;

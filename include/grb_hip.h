@@ -315,6 +315,18 @@ typedef struct {
                                * pr: last residual `error`                              */
 } grb_algo_result;
 
+/* mxm with a dense right-hand side (declared and left a stub by the reference:
+ * backend/cuda/operations.hpp:52-70 "SpMM and GEMM not implemented yet", spmm.hpp:15-27):
+ *   C = A (+).(x) B   (tran = 0)      C = A^T (+).(x) B   (tran = 1)
+ * B [ncols(A or A^T) x k] and C [nrows x k] dense row-major DEVICE arrays of A's element type, any of
+ * the 17 semirings; no mask / accum (NULL in the reference's signature).  With GRB_SPMM_CORE=<H> in
+ * the environment and PlusMultiplies f32, the dense 16 x 16 tiles among the top-H rows x top-H
+ * columns are multiplied on the matrix cores (v_mfma_f32_16x16x4_f32); grb_spmm_core_info reports
+ * how many tiles / entries that split holds. */
+grb_info grb_spmm(grb_semiring op, grb_matrix A, int tran, const void* d_B, void* d_C, grb_index k,
+                  grb_descriptor desc);
+grb_info grb_spmm_core_info(grb_matrix A, int tran, int* ntiles, int64_t* nnz_in_tiles);
+
 /* Batched traversals = the multi-frontier product (extension; the reference leaves sparse x dense
  * mxm a stub, backend/cuda/operations.hpp:52-70, spmm.hpp:15-27): 1 <= k <= 64 sources traversed at
  * once, one 64-bit word per vertex (bit s = source s), levels as word-wide OR.  v[s] (k dense f32
