@@ -33,70 +33,71 @@ constexpr int kCoreMinNnz = 24;       // a 16 x 16 tile is stored densely from t
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-template <int SR, typename T>
+// KG = output columns one lane group owns (16, 32 or 64); the 64 / KG groups of a wave take different
+// ROWS of the tile at the same time, so a narrow right-hand side still fills the wave and every row
+// keeps its CSR summation order.
+template <int SR, typename T, int KG>
 __global__ __launch_bounds__(kBlock) void spmm_tile_kernel(const SpmvBlock* __restrict__ tiles, int ntiles,
                                                            const Index* __restrict__ ptr, const Index* __restrict__ ind,
                                                            const T* __restrict__ val, const T* __restrict__ B,
                                                            T* __restrict__ C, T* __restrict__ partials, Index k,
                                                            Index col0) {
   typedef Semiring<SR, T> S;
+  constexpr int G = kWave / KG;
+  __shared__ Index s_ci[kWavesPerBlock][kSpmmTile];
+  __shared__ T s_cv[kWavesPerBlock][kSpmmTile];
   const int lane = lane_id();
-  const Index c = col0 + lane;
+  const int grp = lane / KG;
+  const Index c = col0 + (lane % KG);
   const bool on = c < k;
   const Index cc = on ? c : 0;
   const int nwaves = gridDim.x * kWavesPerBlock;
   for (int t = blockIdx.x * kWavesPerBlock + wave_id(); t < ntiles; t += nwaves) {
     const SpmvBlock blk = tiles[t];
     const int cnt = blk.nnz_end - blk.nnz_start;
-    // the tile's entries, 8 per lane, coalesced
-    Index ci[kSpmmTile / kWave];
-    T cv[kSpmmTile / kWave];
+    // the tile's entries, 8 per lane, coalesced, parked in this wave's LDS region: every lane group then
+    // reads the entries of ITS row from there
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int j = 0; j < kSpmmTile / kWave; ++j) {
       const int at = j * kWave + lane;
       const int q = blk.nnz_start + (at < cnt ? at : 0);
-      ci[j] = ind[q];
-      cv[j] = val[q];
+      s_ci[wave_id()][at] = ind[q];
+      s_cv[wave_id()][at] = val[q];
     }
-    int done = 0;                                          // entries of the tile consumed so far
-    for (int r = blk.row_start; r < blk.row_end; ++r) {
-      const int len = blk.slot >= 0 ? cnt : (int)(ptr[r + 1] - ptr[r]);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    auto entry = [&](int at, Index* col, T* v) {
+      *col = s_ci[wave_id()][at & (kSpmmTile - 1)];
+      *v = s_cv[wave_id()][at & (kSpmmTile - 1)];
+    };
+    const bool slice = blk.slot >= 0;
+    for (int r0 = blk.row_start; r0 < blk.row_end; r0 += G) {
+      const int r = r0 + grp;
+      const bool mine = slice ? grp == 0 : r < blk.row_end;
+      int at0 = 0, len = 0;
+      if (mine) {
+        at0 = slice ? 0 : (int)(ptr[r] - blk.nnz_start);
+        len = slice ? cnt : (int)(ptr[r + 1] - ptr[r]);
+      }
       T acc = S::identity();
-      int e = 0;
-      // entries done .. done + len of the tile, in order; four rows of B in flight
-      for (; e + 4 <= len; e += 4) {
+      for (int e = 0; __any(e < len); e += 4) {            // four rows of B in flight per lane
         Index jj[4];
         T aa[4], bb[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-          const int at = done + e + u;
-          Index x = ci[0];
-          T y = cv[0];
-#pragma unroll
-          for (int j = 1; j < kSpmmTile / kWave; ++j)
-            if ((at >> 6) == j) { x = ci[j]; y = cv[j]; }
-          jj[u] = __shfl(x, at & (kWave - 1), kWave);
-          aa[u] = __shfl(y, at & (kWave - 1), kWave);
+          const int ee = e + u < len ? e + u : (len > 0 ? len - 1 : 0);
+          entry(at0 + ee, &jj[u], &aa[u]);
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) bb[u] = B[(size_t)jj[u] * k + cc];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) acc = S::add(acc, S::mul(aa[u], bb[u]));
+        for (int u = 0; u < 4; ++u)
+          if (e + u < len) acc = S::add(acc, S::mul(aa[u], bb[u]));
       }
-      for (; e < len; ++e) {
-        const int at = done + e;
-        Index x = ci[0];
-        T y = cv[0];
-#pragma unroll
-        for (int j = 1; j < kSpmmTile / kWave; ++j)
-          if ((at >> 6) == j) { x = ci[j]; y = cv[j]; }
-        const Index jx = __shfl(x, at & (kWave - 1), kWave);
-        const T ax = __shfl(y, at & (kWave - 1), kWave);
-        acc = S::add(acc, S::mul(ax, B[(size_t)jx * k + cc]));
-      }
-      done += len;
-      if (on) {
-        if (blk.slot >= 0) partials[(size_t)blk.slot * k + c] = acc;
+      if (mine && on) {
+        if (slice) partials[(size_t)blk.slot * k + c] = acc;
         else C[(size_t)r * k + c] = acc;
       }
     }
@@ -310,11 +311,19 @@ grb_info run_tiles(const CsrArrays& M, const SpmvPlan& plan, const T* B, T* C, I
   void* p_part = nullptr;
   if (plan.nslots > 0) GRB_TRY(scratch(6, sizeof(T) * (size_t)plan.nslots * (size_t)k, &p_part));
   const int grid = stream_grid((long long)plan.ntiles * kWave, kBlock);
-  for (Index col0 = 0; col0 < k; col0 += kWave) {
-    hipLaunchKernelGGL((spmm_tile_kernel<SR, T>), dim3(grid), dim3(kBlock), 0, s, plan.d_tiles, plan.ntiles, M.ptr, M.ind,
-                       (const T*)M.val, B, C, (T*)p_part, k, col0);
-    GRB_HIP_TRY(hipGetLastError());
-  }
+#define GRB_SPMM_LAUNCH(KG, COL0)                                                                                     \
+  hipLaunchKernelGGL((spmm_tile_kernel<SR, T, KG>), dim3(grid), dim3(kBlock), 0, s, plan.d_tiles, plan.ntiles, M.ptr, \
+                     M.ind, (const T*)M.val, B, C, (T*)p_part, k, COL0)
+  if (k <= 16) GRB_SPMM_LAUNCH(16, 0);
+  else if (k <= 32) GRB_SPMM_LAUNCH(32, 0);
+  else
+    for (Index col0 = 0; col0 < k; col0 += kWave) {
+      if (k - col0 <= 16) GRB_SPMM_LAUNCH(16, col0);
+      else if (k - col0 <= 32) GRB_SPMM_LAUNCH(32, col0);
+      else GRB_SPMM_LAUNCH(64, col0);
+    }
+#undef GRB_SPMM_LAUNCH
+  GRB_HIP_TRY(hipGetLastError());
   if (plan.nlong > 0) {
     hipLaunchKernelGGL((spmm_finalize_kernel<SR, T>), dim3(stream_grid((long long)plan.nlong * k, kBlock)), dim3(kBlock), 0,
                        s, plan.d_long_row, plan.d_long_slot_ptr, plan.nlong, (const T*)p_part, C, k);
