@@ -355,7 +355,16 @@ def main():
         parallelism = "single"
     else:
         from graphblast_amd import dist as gdist
-        part = gdist.Partition1D(n, tptr, tind, rank, world, dev, edgeswitch=args.edgeswitch)
+        # collectives through the library's own RCCL communicator (csrc/comm.hip: second HIP stream, event
+        # fences) unless GRB_DIST_COMM=torch asks for torch.distributed; falls back to it when RCCL cannot be bound
+        comm, comm_kind = None, "torch.distributed (%s)" % ("nccl = RCCL" if world > 1 else "no collective at N = 1")
+        if os.environ.get("GRB_DIST_COMM", "rccl") != "torch":
+            try:
+                comm = gdist.RcclComm(rank, world, gdist.bitmap_words(n), dev)
+                comm_kind = "library RCCL communicator (csrc/comm.hip), collectives on a second HIP stream"
+            except Exception as exc:                                  # noqa: BLE001 -- reported on the line
+                comm_kind += "; library communicator unavailable: %s" % str(exc)[:120]
+        part = gdist.Partition1D(n, tptr, tind, rank, world, dev, edgeswitch=args.edgeswitch, comm=comm)
         for i in range(args.warmup):
             part.bfs(sources[i % len(sources)])
         barrier()
@@ -371,6 +380,38 @@ def main():
             elapsed = float(t.item())
         roofline = None
         parallelism = "1d_vertex_partition_x%d" % world
+        extra["collectives"] = {"through": comm_kind}
+        if comm is not None:
+            # a second, short pass with per-collective HIP-event timing (it adds a host wait per collective,
+            # so it is kept out of the timed region): what share of a traversal is communication
+            comm.timing(True)
+            comm.stats(reset=True)
+            nprobe = min(8, args.steps)
+            barrier()
+            t0p = time.perf_counter()
+            lv = 0
+            for i in range(nprobe):
+                lv += part.bfs(sources[i % len(sources)])["levels"]
+            barrier()
+            probe_ms = (time.perf_counter() - t0p) * 1e3 / nprobe
+            us, calls = comm.stats(reset=True)
+            comm.timing(False)
+            extra["collectives"].update({"collective_us_per_traversal": round(us / nprobe, 1),
+                                         "collectives_per_traversal": round(calls / nprobe, 2),
+                                         "levels_per_traversal": round(lv / nprobe, 2),
+                                         "ms_per_traversal_with_timing_on": round(probe_ms, 4)})
+            # config 4 of BASELINE.json: PageRank on the same 1-D partition, the slices of the next vector
+            # all-gathered chunk by chunk on the communication stream while the next chunk is multiplied
+            degf = (tptr[1:] - tptr[:-1]).to(torch.float32).clamp_(min=1.0)
+            part.pagerank(degf, alpha=0.85, eps=0.0, max_niter=2)               # set-up + warm-up
+            barrier()
+            t0p = time.perf_counter()
+            pvec, pinfo = part.pagerank(degf, alpha=0.85, eps=0.0, max_niter=10)
+            barrier()
+            pr_ms = (time.perf_counter() - t0p) * 1e3
+            extra["pagerank_partitioned"] = {"iterations": pinfo["iterations"], "ms_total_incl_setup": round(pr_ms, 3),
+                                             "overlapped_chunks": pinfo.get("overlapped_chunks"),
+                                             "checksum": float(pvec.sum().item())}
 
         # ---- for comparison, NOT the reported value: RMAT-22 fits one GPU 100 times over, so a
         #      batch of traversals can also be sharded by SOURCE over replicas of the graph (no

@@ -91,6 +91,17 @@ _SIGS = {
     "grb_matrix_host_csr": [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp)],
     "grb_matrix_host_csc": [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp)],
     "grb_matrix_set_values": [_vp, _vp],
+    "grb_comm_unique_id": [_vp],
+    "grb_comm_init": [_vp, _i, _i],
+    "grb_comm_destroy": [],
+    "grb_comm_info": [C.POINTER(_i), C.POINTER(_i)],
+    "grb_comm_wait": [],
+    "grb_comm_allgather": [_vp, _vp, C.c_size_t],
+    "grb_comm_allgatherv_inplace": [_vp, _vp, _vp],
+    "grb_comm_allreduce_sum_f64": [_vp, C.c_size_t],
+    "grb_comm_timing": [_i],
+    "grb_comm_stats": [C.POINTER(C.c_double), C.POINTER(C.c_longlong), _i],
+    "grb_pr_part_update": [_vp, _vp, _f, _vp, _i, _vp],
     "grb_spmm": [_i, _vp, _i, _vp, _vp, _i, _vp],
     "grb_spmm_core_info": [_vp, _i, C.POINTER(_i), C.POINTER(C.c_int64)],
     "grb_bfs_batch": [_vp, _i, _vp, _vp, _vp, _vp],

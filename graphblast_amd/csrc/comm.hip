@@ -1,0 +1,271 @@
+// comm.hip -- the library's own RCCL communicator: one process per GPU, the
+// collectives of the 1-D partitioned drivers enqueued from C++ on a SECOND HIP stream and fenced
+// against the compute stream with events, so a collective runs while the next local kernel does:
+//
+//   compute stream   kernel(chunk 0) -- ev --> kernel(chunk 1) ------- wait(done) --> next step
+//   comm stream              wait(ev) --> all-gather(chunk 0) ... all-gather(chunk 1) -- done
+//
+// No host synchronisation inside a step.  The reference has nothing to mirror here (its --ndevice
+// flag is unused, backend/cuda/descriptor.hpp:242,283-284); this is the contract of SURVEY.md 8(e).
+//
+// RCCL is bound at run time (dlopen: the copy already in the process -- PyTorch ships one -- else
+// ROCm's), so libgrb_hip.so has no link-time dependency on it and loads on a box without RCCL.
+#include "common.hpp"
+
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+namespace {
+
+struct Rccl {
+  void* so = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+
+struct Comm {
+  Rccl api;
+  ncclComm_t comm = nullptr;
+  int rank = 0, world = 1;
+  hipStream_t stream = nullptr;       // the communication stream
+  hipEvent_t ev_ready = nullptr;      // compute -> comm: the data to send is complete
+  hipEvent_t ev_done = nullptr;       // comm -> compute: the collective has completed
+  hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;   // timing of the last collective
+  bool timed = false;
+  double total_us = 0;                // sum over the collectives since the last reset
+  long long calls = 0;
+  bool pending = false;               // the last collective's time has not been added yet
+};
+
+Comm g_comm;
+
+bool load_rccl(Rccl* r) {
+  if (r->so) return true;
+  const char* names[] = {"librccl.so", "librccl.so.1"};
+  for (const char* n : names)
+    if (!r->so) r->so = dlopen(n, RTLD_NOW | RTLD_NOLOAD);          // the copy the process already holds
+  const char* paths[] = {"/opt/rocm/lib/librccl.so.1", "librccl.so.1", "librccl.so"};
+  for (const char* p : paths)
+    if (!r->so) r->so = dlopen(p, RTLD_NOW | RTLD_LOCAL);
+  if (!r->so) return false;
+#define GRB_SYM(field, name)                                      \
+  r->field = reinterpret_cast<decltype(r->field)>(dlsym(r->so, name)); \
+  if (!r->field) return false;
+  GRB_SYM(GetUniqueId, "ncclGetUniqueId")
+  GRB_SYM(CommInitRank, "ncclCommInitRank")
+  GRB_SYM(CommDestroy, "ncclCommDestroy")
+  GRB_SYM(AllGather, "ncclAllGather")
+  GRB_SYM(Broadcast, "ncclBroadcast")
+  GRB_SYM(AllReduce, "ncclAllReduce")
+  GRB_SYM(GroupStart, "ncclGroupStart")
+  GRB_SYM(GroupEnd, "ncclGroupEnd")
+  GRB_SYM(GetErrorString, "ncclGetErrorString")
+#undef GRB_SYM
+  return true;
+}
+
+#define GRB_NCCL_TRY(call)                                                                             \
+  do {                                                                                                 \
+    ncclResult_t r_ = (call);                                                                          \
+    if (r_ != ncclSuccess) {                                                                           \
+      fprintf(stderr, "RCCL error: %s at %s:%d\n", g_comm.api.GetErrorString(r_), __FILE__, __LINE__); \
+      return GRB_PANIC;                                                                                \
+    }                                                                                                  \
+  } while (0)
+
+// the collective may start once everything enqueued on the compute stream so far has finished
+grb_info fence_in() {
+  Comm& c = g_comm;
+  GRB_HIP_TRY(hipEventRecord(c.ev_ready, grb::ctx().stream));
+  GRB_HIP_TRY(hipStreamWaitEvent(c.stream, c.ev_ready, 0));
+  if (c.timed) GRB_HIP_TRY(hipEventRecord(c.ev_t0, c.stream));
+  return GRB_SUCCESS;
+}
+grb_info fence_out() {
+  Comm& c = g_comm;
+  if (c.timed) GRB_HIP_TRY(hipEventRecord(c.ev_t1, c.stream));
+  GRB_HIP_TRY(hipEventRecord(c.ev_done, c.stream));
+  ++c.calls;
+  c.pending = true;
+  return GRB_SUCCESS;
+}
+
+}  // namespace
+
+using namespace grb;
+
+namespace grb {
+// PageRank on a row shard: the element-wise tail of an iteration for one chunk of owned rows
+//   p_next = y + c ;  r = p_next - p_old ;  *acc += sum r^2        (algorithm/pr.hpp:70-80 per element)
+__global__ __launch_bounds__(kBlock) void pr_part_update_kernel(const float* __restrict__ y, const float* __restrict__ p_old,
+                                                                float c, float* __restrict__ p_next, Index n,
+                                                                double* __restrict__ acc) {
+  __shared__ double s_sum[kWavesPerBlock];
+  double a = 0.0;
+  for (Index i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const float pn = y[i] + c;
+    const float r = pn - p_old[i];
+    p_next[i] = pn;
+    a += (double)(r * r);
+  }
+  a = wave_reduce(a, [](double x, double z) { return x + z; });
+  if (lane_id() == 0) s_sum[wave_id()] = a;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int w = 0; w < kWavesPerBlock; ++w) t += s_sum[w];
+    if (t != 0.0) atomicAdd(acc, t);
+  }
+}
+}  // namespace grb
+
+extern "C" {
+
+grb_info grb_pr_part_update(const void* d_y, const void* d_p_old, float c, void* d_p_next, grb_index n, void* d_acc) {
+  if (!d_acc) return GRB_NULL_POINTER;
+  if (n <= 0) return GRB_SUCCESS;
+  if (!d_y || !d_p_old || !d_p_next) return GRB_NULL_POINTER;
+  GRB_TRY(ctx_init());
+  int grid = stream_grid(n, kBlock * 4);
+  if (grid > 256) grid = 256;
+  hipLaunchKernelGGL(pr_part_update_kernel, dim3(grid), dim3(kBlock), 0, ctx().stream, (const float*)d_y,
+                     (const float*)d_p_old, c, (float*)d_p_next, n, (double*)d_acc);
+  GRB_HIP_TRY(hipGetLastError());
+  return GRB_SUCCESS;
+}
+
+grb_info grb_comm_unique_id(void* out128) {
+  if (!out128) return GRB_NULL_POINTER;
+  if (!load_rccl(&g_comm.api)) return GRB_NOT_IMPLEMENTED;          // no RCCL on this box
+  ncclUniqueId id;
+  GRB_NCCL_TRY(g_comm.api.GetUniqueId(&id));
+  static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+  memcpy(out128, &id, sizeof(id));
+  return GRB_SUCCESS;
+}
+
+grb_info grb_comm_init(const void* id128, int rank, int world) {
+  if (!id128 || world < 1 || rank < 0 || rank >= world) return GRB_INVALID_VALUE;
+  Comm& c = g_comm;
+  if (c.comm) return GRB_OUTPUT_NOT_EMPTY;
+  if (!load_rccl(&c.api)) return GRB_NOT_IMPLEMENTED;
+  GRB_TRY(ctx_init());
+  ncclUniqueId id;
+  memcpy(&id, id128, sizeof(id));
+  GRB_NCCL_TRY(c.api.CommInitRank(&c.comm, world, id, rank));
+  c.rank = rank;
+  c.world = world;
+  GRB_HIP_TRY(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+  GRB_HIP_TRY(hipEventCreateWithFlags(&c.ev_ready, hipEventDisableTiming));
+  GRB_HIP_TRY(hipEventCreateWithFlags(&c.ev_done, hipEventDisableTiming));
+  GRB_HIP_TRY(hipEventCreate(&c.ev_t0));
+  GRB_HIP_TRY(hipEventCreate(&c.ev_t1));
+  c.total_us = 0;
+  c.calls = 0;
+  return GRB_SUCCESS;
+}
+
+grb_info grb_comm_destroy(void) {
+  Comm& c = g_comm;
+  if (!c.comm) return GRB_SUCCESS;
+  (void)hipStreamSynchronize(c.stream);
+  (void)c.api.CommDestroy(c.comm);
+  (void)hipStreamDestroy(c.stream);
+  for (hipEvent_t e : {c.ev_ready, c.ev_done, c.ev_t0, c.ev_t1})
+    if (e) (void)hipEventDestroy(e);
+  Rccl api = c.api;
+  c = Comm();
+  c.api = api;
+  return GRB_SUCCESS;
+}
+
+grb_info grb_comm_info(int* rank, int* world) {
+  if (rank) *rank = g_comm.rank;
+  if (world) *world = g_comm.comm ? g_comm.world : 0;
+  return GRB_SUCCESS;
+}
+
+// Per-collective timing (HIP events on the communication stream) on / off; grb_comm_stats reads and resets.
+grb_info grb_comm_timing(int on) {
+  g_comm.timed = on != 0;
+  return GRB_SUCCESS;
+}
+
+// Waits (host) for the last collective, then adds its duration to the running total when timing is on.
+static grb_info account_last() {
+  Comm& c = g_comm;
+  if (!c.timed || !c.pending) return GRB_SUCCESS;
+  c.pending = false;
+  GRB_HIP_TRY(hipEventSynchronize(c.ev_t1));
+  float ms = 0.f;
+  GRB_HIP_TRY(hipEventElapsedTime(&ms, c.ev_t0, c.ev_t1));
+  c.total_us += (double)ms * 1e3;
+  return GRB_SUCCESS;
+}
+
+grb_info grb_comm_stats(double* total_us, long long* calls, int reset) {
+  Comm& c = g_comm;
+  if (total_us) *total_us = c.total_us;
+  if (calls) *calls = c.calls;
+  if (reset) { c.total_us = 0; c.calls = 0; }
+  return GRB_SUCCESS;
+}
+
+// The compute stream waits (on the device) for the last collective; no host synchronisation.
+grb_info grb_comm_wait(void) {
+  Comm& c = g_comm;
+  if (!c.comm) return GRB_UNINITIALIZED_OBJECT;
+  GRB_TRY(account_last());
+  GRB_HIP_TRY(hipStreamWaitEvent(ctx().stream, c.ev_done, 0));
+  return GRB_SUCCESS;
+}
+
+// Equal-sized all-gather: every rank sends `bytes` from d_send, d_recv holds world * bytes.
+grb_info grb_comm_allgather(const void* d_send, void* d_recv, size_t bytes) {
+  Comm& c = g_comm;
+  if (!c.comm) return GRB_UNINITIALIZED_OBJECT;
+  GRB_TRY(account_last());
+  GRB_TRY(fence_in());
+  GRB_NCCL_TRY(c.api.AllGather(d_send, d_recv, bytes, ncclUint8, c.comm, c.stream));
+  return fence_out();
+}
+
+// In-place all-gather of unequal slices: rank r's slice is d_buf[offsets[r] .. offsets[r] + counts[r]) bytes,
+// already in place on rank r; afterwards every rank holds every slice.  One broadcast per rank inside a group:
+// on point-to-point xGMI every peer link carries its slice concurrently.
+grb_info grb_comm_allgatherv_inplace(void* d_buf, const long long* offsets, const long long* counts) {
+  Comm& c = g_comm;
+  if (!c.comm) return GRB_UNINITIALIZED_OBJECT;
+  if (!offsets || !counts) return GRB_NULL_POINTER;
+  GRB_TRY(account_last());
+  GRB_TRY(fence_in());
+  if (c.world > 1) {
+    GRB_NCCL_TRY(c.api.GroupStart());
+    for (int r = 0; r < c.world; ++r) {
+      if (counts[r] <= 0) continue;
+      char* p = (char*)d_buf + offsets[r];
+      GRB_NCCL_TRY(c.api.Broadcast(p, p, (size_t)counts[r], ncclUint8, r, c.comm, c.stream));
+    }
+    GRB_NCCL_TRY(c.api.GroupEnd());
+  }
+  return fence_out();
+}
+
+// In-place sum all-reduce of `count` doubles (convergence scalars, totals).
+grb_info grb_comm_allreduce_sum_f64(void* d_buf, size_t count) {
+  Comm& c = g_comm;
+  if (!c.comm) return GRB_UNINITIALIZED_OBJECT;
+  GRB_TRY(account_last());
+  GRB_TRY(fence_in());
+  GRB_NCCL_TRY(c.api.AllReduce(d_buf, d_buf, count, ncclFloat64, ncclSum, c.comm, c.stream));
+  return fence_out();
+}
+
+}  // extern "C"

@@ -48,7 +48,10 @@ def bitmap_words(n):
 class HipEngine:
     """Level steps through the C ABI on device tensors."""
 
-    def __init__(self, n, lo, lptr, lind, dev):
+    def __init__(self, n, lo, lptr, lind, dev, in_lptr=None, in_lind=None):
+        """lptr / lind: the OUT-edges of the owned vertices (rows lo.. of the CSR; walked by push, counted
+        for TEPS); in_lptr / in_lind: their IN-edges (rows lo.. of the CSC; walked by pull and by the PageRank
+        shard).  A symmetric graph passes one pair for both."""
         import graphblast_amd as g
         from . import _lib
         self._lib = _lib.load()
@@ -58,10 +61,19 @@ class HipEngine:
         info = self.A.build_device_csr(lptr.data_ptr(), lind.data_ptr(), None, int(lind.numel()), keep=self.keep)
         if info != 0:
             raise RuntimeError("grb_matrix_adopt_device_csr failed: %d" % info)
+        if in_lptr is None:
+            self.A_in, self.keep_in = self.A, self.keep
+        else:
+            self.keep_in = (in_lptr, in_lind)
+            self.A_in = g.Matrix(self.n_local, n)
+            info = self.A_in.build_device_csr(in_lptr.data_ptr(), in_lind.data_ptr(), None, int(in_lind.numel()),
+                                              keep=self.keep_in)
+            if info != 0:
+                raise RuntimeError("grb_matrix_adopt_device_csr (in-edges) failed: %d" % info)
         self.work = torch.zeros(bitmap_words(n), dtype=torch.int32, device=dev)
 
     def pull(self, vis, new_local, label_local, new_label):
-        info = self._lib.grb_bfs_part_pull(self.A._h, self.lo, self.n, vis.data_ptr(), new_local.data_ptr(),
+        info = self._lib.grb_bfs_part_pull(self.A_in._h, self.lo, self.n, vis.data_ptr(), new_local.data_ptr(),
                                            label_local.data_ptr(), float(new_label))
         assert info == 0, info
 
@@ -115,7 +127,7 @@ class HipEngine:
     # ---- PageRank shard: rows = in-edges of the owned vertices, values alpha / outdeg(source)
     def pr_setup(self, vals, dev):
         import graphblast_amd as g
-        lptr, lind = self.keep
+        lptr, lind = self.keep_in
         self.pr_vals = vals
         self.Apr = g.Matrix(self.n_local, self.n)
         info = self.Apr.build_device_csr(lptr.data_ptr(), lind.data_ptr(), vals.data_ptr(), int(vals.numel()),
@@ -127,6 +139,33 @@ class HipEngine:
         n1 = max(self.n_local, 1)
         self._buf = {k: torch.zeros(n1, dtype=torch.float32, device=dev) for k in ("r", "r2")}
         self._vec = {}
+
+    def pr_setup_chunks(self, vals, dev, nchunks=2):
+        """The in-edge shard cut into `nchunks` row chunks (nnz-balanced, boundaries anywhere): chunk c's slice
+        of the new vector is all-gathered on the communication stream while chunk c + 1 is multiplied."""
+        import graphblast_amd as g
+        lptr, lind = self.keep_in
+        hp = lptr.cpu().numpy().astype(np.int64)
+        nnz = int(hp[-1])
+        cuts = [0]
+        for c in range(1, nchunks):
+            cuts.append(int(min(self.n_local, max(cuts[-1], np.searchsorted(hp, nnz * c // nchunks)))))
+        cuts.append(self.n_local)
+        self.pr_chunks = []
+        for c in range(nchunks):
+            a, b = cuts[c], cuts[c + 1]
+            e0, e1 = int(hp[a]), int(hp[b])
+            cptr = (lptr[a:b + 1] - e0).to(torch.int32).contiguous()
+            cind = lind[e0:e1].contiguous() if e1 > e0 else torch.zeros(1, dtype=torch.int32, device=dev)
+            cval = vals[e0:e1].contiguous() if e1 > e0 else torch.zeros(1, dtype=torch.float32, device=dev)
+            M = g.Matrix(max(b - a, 0), self.n)
+            if b > a:
+                info = M.build_device_csr(cptr.data_ptr(), cind.data_ptr(), cval.data_ptr(), e1 - e0,
+                                          keep=(cptr, cind, cval))
+                assert info == 0, info
+            self.pr_chunks.append((a, b, M))
+        self.g = g
+        return cuts
 
     def _adopt(self, key, tensor):
         v = self._vec.get(key)
@@ -188,22 +227,121 @@ class TorchComm:
         return out.view(self.world, pad.numel())
 
 
+class RcclComm:
+    """The same collectives through the LIBRARY's communicator (csrc/comm.hip): RCCL calls enqueued from C++
+    on a second HIP stream, fenced with events against the compute stream -- no torch.distributed in the data
+    path, no host synchronisation per collective.  torch.distributed is only used once, to hand rank 0's
+    ncclUniqueId to the other ranks."""
+
+    def __init__(self, rank, world, nwords, dev):
+        from . import _lib
+        self._lib = _lib.load()
+        self.rank, self.world, self.nwords, self.dev = rank, world, nwords, dev
+        have_r, have_w = C.c_int(0), C.c_int(0)
+        self._lib.grb_comm_info(C.byref(have_r), C.byref(have_w))
+        if have_w.value == 0:
+            ident = torch.zeros(128, dtype=torch.uint8)
+            if rank == 0:
+                buf = (C.c_ubyte * 128)()
+                info = self._lib.grb_comm_unique_id(buf)
+                if info != 0:
+                    raise RuntimeError("grb_comm_unique_id: Info %d (no RCCL?)" % info)
+                ident = torch.tensor(list(buf), dtype=torch.uint8)
+            if world > 1:
+                t = ident.to(dev) if dist.get_backend() == "nccl" else ident
+                dist.broadcast(t, 0)
+                ident = t.cpu()
+            raw = (C.c_ubyte * 128)(*ident.tolist())
+            info = self._lib.grb_comm_init(raw, rank, world)
+            if info != 0:
+                raise RuntimeError("grb_comm_init: Info %d" % info)
+        elif (have_r.value, have_w.value) != (rank, world):
+            raise RuntimeError("the library communicator is rank %d of %d" % (have_r.value, have_w.value))
+        self.gathered = torch.zeros(world * nwords, dtype=torch.int32, device=dev) if world > 1 else None
+        self._acc = torch.zeros(2, dtype=torch.float64, device=dev)
+
+    def or_combine(self, new_local, new_global, engine=None):
+        if self.world == 1:
+            new_global.copy_(new_local)
+            return
+        assert self._lib.grb_comm_allgather(new_local.data_ptr(), self.gathered.data_ptr(), 4 * self.nwords) == 0
+        assert self._lib.grb_comm_wait() == 0                      # the compute stream waits, not the host
+        engine.or_parts(self.gathered, self.world, self.nwords, new_global)
+
+    def gather_word_slices(self, bitmap, word_bounds):
+        """In-place all-gather of every rank's own word range of a replicated bitmap (pull levels: a rank only
+        discovers vertices it owns, so the slices are disjoint -- no OR pass, 1/P of the bytes per rank)."""
+        if self.world == 1:
+            return
+        off = (C.c_longlong * self.world)(*[4 * word_bounds[r] for r in range(self.world)])
+        cnt = (C.c_longlong * self.world)(*[4 * (word_bounds[r + 1] - word_bounds[r]) for r in range(self.world)])
+        assert self._lib.grb_comm_allgatherv_inplace(bitmap.data_ptr(), off, cnt) == 0
+        assert self._lib.grb_comm_wait() == 0
+
+    def gather_slices_async(self, buf, offsets_bytes, counts_bytes):
+        """Enqueue an in-place all-gather of unequal slices; returns at once (grb_comm_wait fences it later)."""
+        off = (C.c_longlong * self.world)(*offsets_bytes)
+        cnt = (C.c_longlong * self.world)(*counts_bytes)
+        assert self._lib.grb_comm_allgatherv_inplace(buf.data_ptr(), off, cnt) == 0
+
+    def wait(self):
+        assert self._lib.grb_comm_wait() == 0
+
+    def sum_(self, t):
+        if self.world > 1:
+            acc = t.to(torch.float64).contiguous()
+            assert self._lib.grb_comm_allreduce_sum_f64(acc.data_ptr(), acc.numel()) == 0
+            assert self._lib.grb_comm_wait() == 0
+            t.copy_(acc.to(t.dtype))
+        return t
+
+    def all_gather_padded(self, pad):
+        out = torch.zeros(self.world * pad.numel(), dtype=pad.dtype, device=pad.device)
+        if self.world == 1:
+            out.copy_(pad)
+        else:
+            assert self._lib.grb_comm_allgather(pad.data_ptr(), out.data_ptr(), pad.numel() * pad.element_size()) == 0
+            assert self._lib.grb_comm_wait() == 0
+        return out.view(self.world, pad.numel())
+
+    def timing(self, on):
+        self._lib.grb_comm_timing(1 if on else 0)
+
+    def stats(self, reset=True):
+        us, calls = C.c_double(0), C.c_longlong(0)
+        self._lib.grb_comm_stats(C.byref(us), C.byref(calls), 1 if reset else 0)
+        return us.value, calls.value
+
+
 class Partition1D:
     def __init__(self, n, tptr, tind, rank, world, dev, engine_cls=HipEngine, mxvmode=GRB_PUSHPULL,
-                 switchpoint=0.01, max_niter=10000, symmetric=True, comm=None, edgeswitch=0.0):
-        if not symmetric:
-            raise NotImplementedError("directed graphs need a separate in-edge shard; pass the CSC as (tptr, tind)")
+                 switchpoint=0.01, max_niter=10000, symmetric=True, comm=None, edgeswitch=0.0, in_edges=None):
+        """tptr / tind: the whole graph's CSR (out-edges).  A directed graph also passes in_edges = (cptr, cind),
+        its CSC: every rank then holds the out-edge rows (push) AND the in-edge rows (pull, PageRank) of the
+        vertices it owns.  A symmetric graph needs one shard for both."""
+        if not symmetric and in_edges is None:
+            raise NotImplementedError("a directed graph needs its in-edges too: pass in_edges=(csc_ptr, csc_ind)")
         self.n, self.rank, self.world, self.dev = n, rank, world, dev
         ptr_host = tptr.cpu().numpy()
         self.bounds = partition_bounds(ptr_host, world)
         self.lo, self.hi = self.bounds[rank], self.bounds[rank + 1]
-        e0, e1 = int(ptr_host[self.lo]), int(ptr_host[self.hi])
-        lptr = (tptr[self.lo:self.hi + 1] - e0).to(torch.int32).contiguous()
-        lind = tind[e0:e1].to(torch.int32).contiguous()
-        if lind.numel() == 0:
-            lind = torch.zeros(1, dtype=torch.int32, device=dev)
+
+        def shard(p, i):
+            ph = p.cpu().numpy()
+            e0, e1 = int(ph[self.lo]), int(ph[self.hi])
+            lp = (p[self.lo:self.hi + 1] - e0).to(torch.int32).contiguous()
+            li = i[e0:e1].to(torch.int32).contiguous()
+            if li.numel() == 0:
+                li = torch.zeros(1, dtype=torch.int32, device=dev)
+            return lp, li
+        lptr, lind = shard(tptr, tind)
         self.lptr, self.lind = lptr, lind
-        self.engine = engine_cls(n, self.lo, lptr, lind, dev)
+        if in_edges is None:
+            self.in_lptr, self.in_lind = lptr, lind
+            self.engine = engine_cls(n, self.lo, lptr, lind, dev)
+        else:
+            self.in_lptr, self.in_lind = shard(in_edges[0], in_edges[1])
+            self.engine = engine_cls(n, self.lo, lptr, lind, dev, self.in_lptr, self.in_lind)
         self.n_local = self.hi - self.lo
         self.nwords = bitmap_words(n)
         z = lambda: torch.zeros(self.nwords, dtype=torch.int32, device=dev)
@@ -270,15 +408,21 @@ class Partition1D:
             if (not f1_dense and self.mxvmode == GRB_PUSHPULL and self.deg_full is not None and nf >= 32
                     and all_edges > self.edgeswitch * self.nnz):
                 f1_dense = True                                    # the same rule as bfs_persist.hip:145-147
-            if f1_dense:
-                if not getattr(eng, "pull_zeroes", False):
-                    self.new_local.zero_()
-                eng.pull(self.vis, self.new_local, self.label, it + 1)
-            elif hasattr(eng, "push_small") and local_edges <= eng.small_push_edges:
-                eng.push_small(self.new_global, self.vis, self.new_local)
+            if f1_dense and hasattr(self.comm, "gather_word_slices") and getattr(eng, "pull_zeroes", False):
+                # pull discovers owned vertices only: written straight into the replicated bitmap, then ONE
+                # in-place all-gather of the ranks' own word ranges (no OR pass, 1/P of the bytes)
+                eng.pull(self.vis, self.new_global, self.label, it + 1)
+                self.comm.gather_word_slices(self.new_global, [b // 32 for b in self.bounds[:-1]] + [self.nwords])
             else:
-                eng.push(self.new_global, self.vis, self.new_local)
-            self._combine()
+                if f1_dense:
+                    if not getattr(eng, "pull_zeroes", False):
+                        self.new_local.zero_()
+                    eng.pull(self.vis, self.new_local, self.label, it + 1)
+                elif hasattr(eng, "push_small") and local_edges <= eng.small_push_edges:
+                    eng.push_small(self.new_global, self.vis, self.new_local)
+                else:
+                    eng.push(self.new_global, self.vis, self.new_local)
+                self._combine()
             if hasattr(eng, "apply2"):
                 found, local_edges, all_edges = eng.apply2(self.new_global, self.vis, self.label, it + 1, self.deg_full)
             else:
@@ -305,7 +449,9 @@ class Partition1D:
         of length n on this rank's device)."""
         n, dev = self.n, self.dev
         eng = self.engine
-        lptr, lind = self.lptr, self.lind
+        lptr, lind = self.in_lptr, self.in_lind
+        if isinstance(self.comm, RcclComm) and hasattr(eng, "pr_setup_chunks"):
+            return self._pagerank_overlapped(deg_full, alpha, eps, max_niter)
         vals = (alpha / deg_full.to(torch.float32)[lind[:int(lptr[-1].item())].long()]).to(torch.float32).contiguous()
         if vals.numel() == 0:
             vals = torch.zeros(1, dtype=torch.float32, device=dev)
@@ -334,6 +480,48 @@ class Partition1D:
                     p[self.bounds[r]:self.bounds[r + 1]] = out[r, :sizes[r]]
             it += 1
         return p, dict(iterations=it, errors=errs)
+
+    def _pagerank_overlapped(self, deg_full, alpha, eps, max_niter, nchunks=2):
+        """The same iteration with the library's communicator: the owned rows are cut into row chunks; chunk
+        c's slice of the next vector is all-gathered on the communication stream while chunk c + 1 is being
+        multiplied on the compute stream (events, no host synchronisation); the squared residual is
+        all-reduced behind the last gather and read once per iteration."""
+        n, dev, eng, comm = self.n, self.dev, self.engine, self.comm
+        lptr, lind = self.in_lptr, self.in_lind
+        nnz_l = int(lptr[-1].item())
+        vals = (alpha / deg_full.to(torch.float32)[lind[:nnz_l].long()]).to(torch.float32).contiguous()
+        if vals.numel() == 0:
+            vals = torch.zeros(1, dtype=torch.float32, device=dev)
+        cuts = eng.pr_setup_chunks(vals, dev, nchunks)
+        # every rank's chunk boundaries (vertex ids), identical on all ranks: one small all-gather at set-up
+        mine = torch.tensor([self.lo + c for c in cuts], dtype=torch.float64, device=dev)
+        allc = comm.all_gather_padded(mine).cpu().numpy().astype(np.int64)           # [world, nchunks + 1]
+        g = eng.g
+        lib = eng._lib
+        p_cur = torch.full((n,), 1.0 / n, dtype=torch.float32, device=dev)
+        p_next = torch.empty_like(p_cur)
+        y = torch.zeros(max(self.n_local, 1), dtype=torch.float32, device=dev)
+        acc = torch.zeros(1, dtype=torch.float64, device=dev)
+        const = float(np.float32((np.float32(1.0) - np.float32(alpha)) / np.float32(n)))
+        error, it, errs = 1.0, 0, []
+        torch.cuda.synchronize()
+        while error > eps and it < max_niter:
+            acc.zero_()
+            for c, (a, b, M) in enumerate(eng.pr_chunks):
+                if b > a:
+                    assert g.k_spmv(M, 0, "PlusMultiplies", p_cur.data_ptr(), None, 0, 0, y[a:].data_ptr()) == 0
+                    assert lib.grb_pr_part_update(y[a:].data_ptr(), p_cur[self.lo + a:].data_ptr(), const,
+                                                  p_next[self.lo + a:].data_ptr(), b - a, acc.data_ptr()) == 0
+                comm.gather_slices_async(p_next, [4 * int(allc[r, c]) for r in range(self.world)],
+                                         [4 * int(allc[r, c + 1] - allc[r, c]) for r in range(self.world)])
+            if self.world > 1:
+                assert lib.grb_comm_allreduce_sum_f64(acc.data_ptr(), 1) == 0
+            comm.wait()
+            error = float(np.sqrt(np.float32(acc.item())))
+            errs.append(error)
+            p_cur, p_next = p_next, p_cur
+            it += 1
+        return p_cur, dict(iterations=it, errors=errs, overlapped_chunks=nchunks)
 
     def gather_labels(self):
         """Full label vector on every rank (tests / verification only)."""

@@ -390,6 +390,27 @@ grb_info grb_lgc(grb_vector p, grb_matrix A, grb_index s, double alpha, double e
 grb_info grb_diameter(grb_vector v, grb_matrix A, grb_index s_start, grb_index s_end, grb_descriptor desc,
                       int* diameter_max, int* diameter_ind);
 
+/* ---- The library's RCCL communicator (the reference has no multi-GPU path:
+ * backend/cuda/descriptor.hpp:242,283-284 leave --ndevice unused).  One process per GPU; collectives
+ * are enqueued from C++ on a second HIP stream, fenced with events against the stream of
+ * grb_set_stream: a collective starts when the work enqueued before it has finished, and the
+ * compute stream continues until grb_comm_wait() makes it wait (on the device) for the last one.
+ * RCCL is bound with dlopen; GrB_NOT_IMPLEMENTED when it is absent. */
+grb_info grb_comm_unique_id(void* out128);                  /* ncclGetUniqueId: rank 0 calls it, every rank gets the bytes */
+grb_info grb_comm_init(const void* id128, int rank, int world);
+grb_info grb_comm_destroy(void);
+grb_info grb_comm_info(int* rank, int* world);               /* world = 0: not initialised */
+grb_info grb_comm_wait(void);
+grb_info grb_comm_allgather(const void* d_send, void* d_recv, size_t bytes_per_rank);
+/* rank r's slice = d_buf[offsets[r] .. +counts[r]) bytes, in place; afterwards every rank holds all slices */
+grb_info grb_comm_allgatherv_inplace(void* d_buf, const long long* offsets, const long long* counts);
+grb_info grb_comm_allreduce_sum_f64(void* d_buf, size_t count);
+grb_info grb_comm_timing(int on);                            /* HIP-event time of every collective (adds a host wait) */
+grb_info grb_comm_stats(double* total_us, long long* calls, int reset);
+/* element-wise tail of a PageRank iteration on a chunk of owned rows (algorithm/pr.hpp:70-80):
+ * p_next = y + c, *d_acc (double) += sum (p_next - p_old)^2 */
+grb_info grb_pr_part_update(const void* d_y, const void* d_p_old, float c, void* d_p_next, grb_index n, void* d_acc);
+
 /* ---- Raw kernels on plain device pointers (micro-benchmarks / multi-GPU shards) --- */
 /* Generic semiring SpMV  w[i] = (+)_j A[i,j] (x) u[j] on this matrix's CSR (tran=0) or
  * CSC (tran=1) arrays: the kernel behind the pull branch (backend/cuda/spmv.hpp:178-220).

@@ -12,12 +12,16 @@ def _bits(t):
 
 
 class NumpyEngine:
-    def __init__(self, n, lo, lptr, lind, dev):
+    def __init__(self, n, lo, lptr, lind, dev, in_lptr=None, in_lind=None):
         self.n, self.lo = n, lo
         self.ptr = lptr.cpu().numpy().astype(np.int64)
         self.ind = lind.cpu().numpy().astype(np.int64)
         self.n_local = self.ptr.size - 1
         self.rows = np.repeat(np.arange(self.n_local), np.diff(self.ptr))
+        # in-edges of the owned vertices (pull, PageRank); a symmetric graph has one shard for both
+        self.iptr = self.ptr if in_lptr is None else in_lptr.cpu().numpy().astype(np.int64)
+        self.iind = self.ind if in_lind is None else in_lind.cpu().numpy().astype(np.int64)
+        self.irows = np.repeat(np.arange(self.n_local), np.diff(self.iptr))
 
     @staticmethod
     def _test(bm, idx):
@@ -31,9 +35,9 @@ class NumpyEngine:
         v, nl = _bits(vis), _bits(new_local)
         own = np.arange(self.n_local) + self.lo
         unvisited = ~self._test(v, own)
-        hit_edge = self._test(v, self.ind[:self.ptr[-1]])
+        hit_edge = self._test(v, self.iind[:self.iptr[-1]])
         any_hit = np.zeros(self.n_local, dtype=bool)
-        np.logical_or.at(any_hit, self.rows, hit_edge)
+        np.logical_or.at(any_hit, self.irows, hit_edge)
         found = np.nonzero(unvisited & any_hit)[0]
         self._set(nl, found + self.lo)
         label_local.numpy()[found] = new_label
@@ -64,9 +68,9 @@ class NumpyEngine:
 
     def pr_step(self, p_full, y_local, p_old_local, const):
         p = p_full.numpy()
-        prod = self.pr_vals[:self.ptr[-1]] * p[self.ind[:self.ptr[-1]]]
+        prod = self.pr_vals[:self.iptr[-1]] * p[self.iind[:self.iptr[-1]]]
         y = np.zeros(self.n_local, dtype=np.float32)
-        np.add.at(y, self.rows, prod)
+        np.add.at(y, self.irows, prod)
         y = (y + np.float32(const)).astype(np.float32)
         y_local.numpy()[:self.n_local] = y
         po = p_old_local.numpy()[:self.n_local]

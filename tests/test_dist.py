@@ -220,3 +220,140 @@ def test_part_level_step_kernels_direct():
             assert np.all(lab[own - lo] == level)
         hv |= fresh
         hfront = fresh.copy()
+
+
+def _worker_directed(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import sys
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        from dist_helpers import NumpyEngine
+        from graphblast_amd.dist import Partition1D
+        gr = _graph(seed=7, scale=11, sym=False)
+        ptr, ind = gr["csr"]
+        cptr, cind = gr["csc"]
+        t = lambda a: torch.from_numpy(a.astype(np.int64))
+        out = []
+        for mode in (10, 11, 12):
+            part = Partition1D(gr["n"], t(ptr), t(ind), rank, world, torch.device("cpu"), engine_cls=NumpyEngine,
+                               mxvmode=mode, switchpoint=0.05, symmetric=False, in_edges=(t(cptr), t(cind)))
+            for src in (int(np.argmax(np.diff(ptr))), 9):
+                res = part.bfs(src)
+                out.append((mode, src, res["edges_traversed"], res["reached"], part.gather_labels().numpy().copy()))
+        part = Partition1D(gr["n"], t(ptr), t(ind), rank, world, torch.device("cpu"), engine_cls=NumpyEngine,
+                           symmetric=False, in_edges=(t(cptr), t(cind)))
+        deg = torch.from_numpy(np.maximum(np.diff(ptr), 1).astype(np.float32))
+        pvec, info = part.pagerank(deg, alpha=0.85, eps=0.0, max_niter=8)
+        if rank == 0:
+            q.put((out, pvec.numpy().copy(), info["iterations"]))
+    except Exception:
+        import traceback
+        q.put(("error", "rank %d: %s" % (rank, traceback.format_exc()), 0))
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+def test_partitioned_directed_graph_gloo():
+    """A DIRECTED graph on two ranks: every rank holds the out-edge rows (push) and the in-edge rows (pull,
+    PageRank) of its vertices.  BFS labels bit-exact against the oracle on the CSR (out-edges); PageRank
+    against the oracle's push formulation on the same CSR."""
+    from oracle import simple_reference as sr
+    gr = _graph(seed=7, scale=11, sym=False)
+    ptr, ind = gr["csr"]
+    assert not np.array_equal(gr["csr"][1], gr["csc"][1])
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_directed, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out, pr_vec, pr_iters = q.get(timeout=180)
+    assert not (isinstance(out, str) and out == "error"), pr_vec
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    deg = np.diff(ptr)
+    for mode, src, edges, reached, labels in out:
+        want = sr.bfs(ptr, ind, src)[0]
+        assert np.array_equal(labels, want), (mode, src)
+        assert edges == int(deg[want != 0].sum()) and reached == int(np.count_nonzero(want))
+    # SimpleReferencePr divides by the out-degree; sinks only ever divide their own (unused) contribution
+    n = gr["n"]
+    p = np.full(n, np.float32(1.0 / n), np.float32)
+    rows = np.repeat(np.arange(n), deg)
+    for _ in range(8):
+        contrib = (np.float32(0.85) * p / np.maximum(deg, 1).astype(np.float32)).astype(np.float32)
+        nxt = np.full(n, np.float32((1 - 0.85) / n), np.float64)
+        np.add.at(nxt, ind, contrib[rows].astype(np.float64))
+        p = nxt.astype(np.float32)
+    assert pr_iters == 8
+    rel = np.abs(pr_vec - p) / np.maximum(np.abs(p), 1e-30)
+    assert rel.max() <= 1e-4, rel.max()
+
+
+@pytest.mark.gpu
+def test_library_communicator_on_one_gpu():
+    """csrc/comm.hip with a world of one rank on the GPU box: RCCL bound with dlopen, communicator created from
+    a unique id, all-gather / in-place all-gather-v / all-reduce enqueued on the communication stream and fenced
+    against the compute stream; then the partitioned BFS and the chunk-overlapped PageRank through RcclComm, and
+    a DIRECTED graph through the HIP engine's two shards."""
+    import ctypes as C
+    from graphblast_amd import _lib
+    from graphblast_amd.dist import Partition1D, RcclComm, bitmap_words
+    from oracle import simple_reference as sr
+    lib = _lib.load()
+    dev = torch.device("cuda", 0)
+    gr = _graph(seed=3, scale=14)
+    ptr, ind = gr["csr"]
+    n = gr["n"]
+    comm = RcclComm(0, 1, bitmap_words(n), dev)
+    r, w = C.c_int(-1), C.c_int(-1)
+    lib.grb_comm_info(C.byref(r), C.byref(w))
+    assert (r.value, w.value) == (0, 1)
+    comm.timing(True)
+    a = torch.arange(1000, dtype=torch.float32, device=dev)
+    b = torch.zeros(1000, dtype=torch.float32, device=dev)
+    assert lib.grb_comm_allgather(a.data_ptr(), b.data_ptr(), 4000) == 0
+    assert lib.grb_comm_wait() == 0
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)
+    acc = torch.tensor([2.5, 4.0], dtype=torch.float64, device=dev)
+    assert lib.grb_comm_allreduce_sum_f64(acc.data_ptr(), 2) == 0
+    assert lib.grb_comm_wait() == 0
+    torch.cuda.synchronize()
+    assert acc.tolist() == [2.5, 4.0]
+    off, cnt = (C.c_longlong * 1)(0), (C.c_longlong * 1)(4000)
+    assert lib.grb_comm_allgatherv_inplace(a.data_ptr(), off, cnt) == 0
+    assert lib.grb_comm_wait() == 0
+    us, calls = comm.stats()
+    assert calls == 3 and us > 0
+    comm.timing(False)
+    tptr, tind = torch.from_numpy(ptr.astype(np.int64)).to(dev), torch.from_numpy(ind.astype(np.int64)).to(dev)
+    part = Partition1D(n, tptr, tind, 0, 1, dev, comm=comm, switchpoint=0.02)
+    for src in (int(np.argmax(np.diff(ptr))), 5):
+        res = part.bfs(src)
+        want = sr.bfs(ptr, ind, src)[0]
+        assert np.array_equal(part.gather_labels().cpu().numpy(), want)
+        assert res["edges_traversed"] == int(np.diff(ptr)[want != 0].sum())
+    deg = torch.from_numpy(np.diff(ptr).astype(np.float32)).to(dev)
+    pvec, info = part.pagerank(deg, alpha=0.85, eps=0.0, max_niter=10)
+    assert info["iterations"] == 10 and info["overlapped_chunks"] == 2
+    want_pr = sr.pr(ptr, ind, 0.85, 0.0, 10)[0]
+    rel = np.abs(pvec.cpu().numpy() - want_pr) / np.maximum(np.abs(want_pr), 1e-30)
+    assert rel.max() <= 1e-5, rel.max()
+    # directed graph: out-edge and in-edge shards
+    gd = _graph(seed=9, scale=13, sym=False)
+    dp, di = gd["csr"]
+    cp, ci = gd["csc"]
+    t = lambda x: torch.from_numpy(x.astype(np.int64)).to(dev)
+    pd = Partition1D(gd["n"], t(dp), t(di), 0, 1, dev, comm=RcclComm(0, 1, bitmap_words(gd["n"]), dev),
+                     symmetric=False, in_edges=(t(cp), t(ci)), switchpoint=0.02)
+    for mode_src in (int(np.argmax(np.diff(dp))), 3):
+        pd.bfs(mode_src)
+        assert np.array_equal(pd.gather_labels().cpu().numpy(), sr.bfs(dp, di, mode_src)[0])
+    lib.grb_comm_destroy()
