@@ -36,6 +36,7 @@ constexpr int kBigChunk = 1024;
 constexpr int kPullBlock = GRB_PULL_BLOCK;    // chunks (of 64 vertices) one wave carries through the pull stages together
 constexpr int kPullGroup = 16;    // lanes finishing one undecided row in the pull phase
 constexpr int kMedCap = 4096;     // LDS list of medium vertices per workgroup pass
+constexpr int kKeep = 32;         // levels whose discovered-bitmaps are kept for the final label pass
 
 struct PersistState {               // zeroed by the host before every launch
   GridBarrier bar;
@@ -56,8 +57,13 @@ struct PersistArgs {
   int max_niter;
   int count_inspected;
   float* label;
-  unsigned int* V[2];               // V[0] and F[0..2] are zeroed by the host with the state
-  unsigned int* F[3];
+  unsigned int* V[2];               // V[0] and every F are zeroed by the host with the state
+  // F[L] = bitmap of the vertices discovered by level L (F[0] = the source), kept for L < kKeep: labels are
+  // NOT written while traversing -- one coalesced pass at the end turns the kept bitmaps into the depth vector
+  // (a scattered 4-byte label store costs a 32-byte memory write: 131 MB per traversal of RMAT-22 against
+  // 17 MB of labels).  Levels >= kKeep (long-diameter graphs, tiny frontiers) rotate through three more
+  // buffers and label directly.
+  unsigned int* F[kKeep + 3];
   int2* big_list;
   int big_cap;
   PersistState* st;
@@ -75,9 +81,11 @@ struct LevelCounters {
   unsigned long long found = 0, deg = 0, inspected = 0, big = 0;
 };
 
-// a vertex was discovered: label it, account for it
+__device__ inline int fbuf(int level) { return level < kKeep ? level : kKeep + (level - kKeep) % 3; }
+
+// a vertex was discovered: account for it (and label it at once beyond the kept levels: new_label > 0)
 __device__ inline void discovered(const PersistArgs& a, Index v, float new_label, LevelCounters& c) {
-  a.label[v] = new_label;
+  if (new_label > 0.f) a.label[v] = new_label;
   const Index d = a.optr[v + 1] - a.optr[v];
   ++c.found;
   c.deg += (unsigned long long)d;
@@ -119,7 +127,7 @@ __global__ __launch_bounds__(kPThreads) void bfs_persistent_kernel(PersistArgs a
   const Index src_deg = a.optr[a.source + 1] - a.optr[a.source];
   if (gtid == 0) {
     atomicOr(&a.V[0][a.source >> 5], 1u << (a.source & 31));
-    a.label[a.source] = 1.f;
+    atomicOr(&a.F[0][a.source >> 5], 1u << (a.source & 31));
   }
   if (a.mode == GRB_PULLONLY && !grid_sync(&st->bar, gen, false)) return;
 
@@ -131,7 +139,7 @@ __global__ __launch_bounds__(kPThreads) void bfs_persistent_kernel(PersistArgs a
   unsigned long long edges_cum = mf;
   bool f1_dense = (a.mode == GRB_PULLONLY);
   float ratio_f1 = 0.f, ratio_f2 = 0.f;
-  int cur = 0, fcur = 0, levels = 0, last_dir = 0;
+  int cur = 0, levels = 0, last_dir = 0;
   int iter = 1;
   for (; iter <= a.max_niter; ++iter) {
     const unsigned long long t_level = wall_clock64();
@@ -148,14 +156,15 @@ __global__ __launch_bounds__(kPThreads) void bfs_persistent_kernel(PersistArgs a
     } else {
       f1_dense = (a.mode == GRB_PULLONLY);
     }
-    const int fnext = (fcur + 1) % 3, fzero = (fcur + 2) % 3;
-    const unsigned int* Fc = a.F[fcur];
-    unsigned int* Fn = a.F[fnext];
-    const float new_label = (float)(iter + 1);
+    const unsigned int* Fc = a.F[fbuf(iter - 1)];
+    unsigned int* Fn = a.F[fbuf(iter)];
+    const bool direct = iter >= kKeep;                    // this level's bitmap will be recycled: label now
+    const float new_label = direct ? (float)(iter + 1) : 0.f;
     LevelCounters c;
     // recycle: the frontier buffer of two levels ahead, the entry counter and the totals of
     // the next level (nobody touches them during this one)
-    for (long long i = gtid; i < nwords; i += gthreads) publish(&a.F[fzero][i], 0u);
+    if (iter + 1 >= kKeep + 3)                            // a rotating buffer about to be reused
+      for (long long i = gtid; i < nwords; i += gthreads) publish(&a.F[fbuf(iter + 1)][i], 0u);
     if (gtid == 0) publish(&st->big_count[(iter + 1) & 1][0], 0u);
     if (blockIdx.x == 0 && tid < 32) publish(&st->acc[(iter + 1) % 3][tid >> 2][tid & 3], 0ull);
 
@@ -427,7 +436,7 @@ __global__ __launch_bounds__(kPThreads) void bfs_persistent_kernel(PersistArgs a
             const Index vj = f ? vbase + kWave * j : 0;
             d0[j] = a.optr[vj];
             d1[j] = a.optr[vj + 1];
-            if (f) a.label[vj] = new_label;
+            if (f && direct) a.label[vj] = new_label;
           }
 #pragma unroll
           for (int j = 0; j < kPullBlock; ++j)
@@ -480,7 +489,6 @@ __global__ __launch_bounds__(kPThreads) void bfs_persistent_kernel(PersistArgs a
     reached += (long long)tot_found;
     edges_cum += tot_deg;
     if (f1_dense) cur ^= 1;
-    fcur = fnext;
     const float tmp = ratio_f1; ratio_f1 = ratio_f2; ratio_f2 = tmp;
     nf = (Index)tot_found;
     mf = tot_deg;
@@ -488,11 +496,41 @@ __global__ __launch_bounds__(kPThreads) void bfs_persistent_kernel(PersistArgs a
     if (nf == 0) break;
   }
 
-  // ---- labels of everything never reached (V[cur] is final and visible after the last barrier)
+  // ---- the depth vector, written once and coalesced: level L + 1 for the vertices of F[L] (the kept bitmaps
+  // are disjoint), 0 for everything never reached; a vertex that is visited but in none of the kept bitmaps was
+  // discovered by a level >= kKeep and labelled there.  (V[cur] and every F are final after the last barrier.)
   {
-    const unsigned int* Vf = a.V[cur];
-    for (long long i = gtid; i < n; i += gthreads)
-      if (!((fresh(&Vf[i >> 5]) >> (i & 31)) & 1u)) a.label[i] = 0.f;
+    // nothing is written any more: read the bitmaps through L1 (one invalidate), eight 64-vertex chunks per
+    // wave step so that a step costs one memory latency, not one per level
+    if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    __syncthreads();
+    const unsigned int* __restrict__ Vf = a.V[cur];
+    const int kept = levels + 1 < kKeep ? levels + 1 : kKeep;      // F[0 .. kept)
+    constexpr int kLB = 8;
+    const Index nchunks = (n + kWave - 1) / kWave;
+    const Index nblk = (nchunks + kLB - 1) / kLB;
+    const int sh = lane & 31;
+    for (Index blk = (Index)blockIdx.x * kPWaves + wave; blk < nblk; blk += (Index)G * kPWaves) {
+      int wi[kLB];
+      unsigned int vis[kLB], lab[kLB];
+#pragma unroll
+      for (int j = 0; j < kLB; ++j) {
+        const long long w = ((long long)blk * kLB + j) * 2 + (lane >> 5);
+        wi[j] = w < nwords ? (int)w : 0;
+        vis[j] = Vf[wi[j]];
+        lab[j] = 0u;
+      }
+      for (int L = 0; L < kept; ++L) {
+        const unsigned int* __restrict__ FL = a.F[L];
+#pragma unroll
+        for (int j = 0; j < kLB; ++j) lab[j] += ((FL[wi[j]] >> sh) & 1u) * (unsigned int)(L + 1);
+      }
+#pragma unroll
+      for (int j = 0; j < kLB; ++j) {
+        const long long v = ((long long)blk * kLB + j) * kWave + lane;
+        if (v < n && (lab[j] != 0u || !((vis[j] >> sh) & 1u))) a.label[v] = (float)lab[j];
+      }
+    }
   }
   stamp();
   if (a.trace && gtid == 0) a.trace[0] = (unsigned long long)ntrace;
@@ -534,9 +572,9 @@ grb_info bfs_persistent_run(grb_vector v, grb_matrix A, grb_index source, grb_de
   const int rec_cap = 1 << 15;
   const int big_cap = (int)(A->nvals / kBigDeg) + 2;
 
-  // one allocation, one memset: [state | V0 | F0 | F1 | F2]
+  // one allocation, one memset: [state | V0 | F0 .. F(kKeep + 2)]
   const size_t st_bytes = (sizeof(PersistState) + 255) & ~(size_t)255;
-  const size_t zero_bytes = st_bytes + 16 * (size_t)nwords;
+  const size_t zero_bytes = st_bytes + 4 * (size_t)(1 + kKeep + 3) * (size_t)nwords;
   void *p_zero, *p_v1, *p_big, *p_rec;
   GRB_TRY(scratch(7, zero_bytes, &p_zero));
   GRB_TRY(scratch(8, 4 * (size_t)nwords, &p_v1));
@@ -568,7 +606,7 @@ grb_info bfs_persistent_run(grb_vector v, grb_matrix A, grb_index source, grb_de
   a.count_inspected = (profile & 2) ? 1 : 0;
   a.label = (float*)v->d_val;
   a.V[0] = p_v0; a.V[1] = (unsigned int*)p_v1;
-  a.F[0] = p_v0 + nwords; a.F[1] = a.F[0] + nwords; a.F[2] = a.F[1] + nwords;
+  for (int L = 0; L < kKeep + 3; ++L) a.F[L] = p_v0 + (size_t)(1 + L) * (size_t)nwords;
   a.big_list = (int2*)p_big;
   a.big_cap = big_cap;
   a.st = (PersistState*)p_st;
@@ -598,12 +636,17 @@ grb_info bfs_persistent_run(grb_vector v, grb_matrix A, grb_index source, grb_de
   hipLaunchKernelGGL(bfs_persistent_kernel, dim3(G), dim3(kPThreads), 0, s, a);
   GRB_HIP_TRY(hipGetLastError());
   if (profile & 1) GRB_HIP_TRY(hipEventRecord(c.ev1, s));
-  GRB_HIP_TRY(hipMemsetAsync(p_zero, 0, zero_bytes, s));     // for the next traversal
-  c.bfs_prezero_ptr = p_zero;
-  c.bfs_prezero_bytes = zero_bytes;
   const auto th1 = std::chrono::steady_clock::now();
   unsigned int gv[8];
   GRB_TRY(wait_granules(a.seq, 8, gv));
+  {
+    // for the next traversal: clear what this one dirtied -- the state, V0 and the level bitmaps it wrote
+    // (every buffer when it went past the kept levels), queued now, off the critical path of this call
+    const int used = (int)gv[0] + 2 >= kKeep ? kKeep + 3 : (int)gv[0] + 2;
+    GRB_HIP_TRY(hipMemsetAsync(p_zero, 0, st_bytes + 4 * (size_t)(1 + used) * (size_t)nwords, s));
+    c.bfs_prezero_ptr = p_zero;
+    c.bfs_prezero_bytes = zero_bytes;
+  }
   if (host_timing) {
     const auto th2 = std::chrono::steady_clock::now();
     acc_launch += std::chrono::duration<double, std::micro>(th1 - th0).count();
