@@ -20,6 +20,8 @@ Rank 0 prints ONE JSON line.  Extra objects on it:
   spmv          the generic SpMV kernel (PlusMultiplies, f32) on the same graph: algorithmic
                 8*nnz + 12*n + 4 bytes per launch / HIP-event mean launch time
   spmv_grid4096 the same SpMV kernel on a road-like 4096^2 grid (local gathers)
+  bfs_batch64   all 64 sources in one bit-parallel sweep (grb_bfs_batch), labels spot-checked against the
+                single traversal; spmm_k64: sparse x dense mxm with 64 right-hand sides (grb_spmm)
   primitives    eWiseAdd / eWiseMult / reduce / assign on 64 Mi-element f32 vectors: GB/s and
                 fraction of the 8 TB/s HBM peak
   cpu_all_cores context only (not the reference, whose CPU path is sequential): the same labels from an
@@ -96,6 +98,8 @@ def main():
     ap.add_argument("--extras", action="store_true",
                     help="also time the SpMV kernel on a road-like grid (launches the SpMV kernels of the main "
                          "measurement again: would mix into a rocprof average of this command)")
+    ap.add_argument("--no-batch", action="store_true",
+                    help="skip the multi-frontier measurements (64-source sweep, sparse x dense mxm)")
     ap.add_argument("--partitioned", action="store_true",
                     help="use the 1-D partitioned level loop even at N = 1 (debugging the N > 1 path)")
     args = ap.parse_args()
@@ -238,6 +242,61 @@ def main():
                          "frac": round(sb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                          "traffic": pmc_traffic("spmv_hub_kernel")[0],
                          "traffic_source": pmc_traffic("spmv_hub_kernel")[1], "gflops": round(2 * nnz / (ms * 1e-3) / 1e9, 1)}
+
+        # ---- the multi-frontier forms, reported NEXT TO the per-traversal number above, not
+        #      instead of it: (a) all 64 sources in one bit-parallel sweep (grb_bfs_batch: one 64-bit word per
+        #      vertex, direction chosen per source, labels identical per source -- checked below); its algorithmic
+        #      bytes are the 64 single traversals' (BASELINE.md 3 summed over sources and levels): the sweep
+        #      shares edge reads between sources, so this fraction can exceed what one traversal could reach;
+        #      (b) sparse x dense mxm with 64 right-hand sides (grb_spmm), the product the reference leaves a stub
+        if not args.no_batch:
+            bvs = [g.Vector(n) for _ in sources]
+            bdesc = g.Descriptor()
+            assert bdesc.loadArgs(mxvmode=0, struconly=1, opreuse=1, earlyexit=1) == 0
+            info, bres = g.bfs_batch(bvs, A, sources, bdesc)
+            assert info == 0, info
+            breps = 5
+            barrier()
+            t0b = time.perf_counter()
+            for _ in range(breps):
+                info, bres = g.bfs_batch(bvs, A, sources, bdesc)
+            barrier()
+            b_ms = (time.perf_counter() - t0b) * 1e3 / breps
+            for i in (0, 1, len(sources) // 2, len(sources) - 1):       # spot check against the single traversal
+                assert g.bfs(v, A, sources[i], desc, fused=True)[0] == 0
+                assert np.array_equal(v.extractTuples()[1], bvs[i].extractTuples()[1]), "batch labels differ"
+            acc_all = {s: (account[s] if s in account else g.bfs(v, A, s, desc, fused=True, profile=3)[1]["per_level"])
+                       for s in sorted(set(sources))}
+            batch_bytes = float(sum(sum(level_bytes(acc_all[s], n)) for s in sources))
+            extra["bfs_batch64"] = {
+                "kernel": "grb_bfs_batch (batch_pull_kernel / batch_push_kernel / batch_labels_kernel)",
+                "sources_per_sweep": len(sources), "ms_per_sweep": round(b_ms, 4),
+                "us_per_traversal": round(b_ms * 1e3 / len(sources), 2), "levels": bres["levels"],
+                "value": bres["edges_traversed"] / (b_ms * 1e-3), "unit": "TEPS",
+                "algorithmic_bytes_per_sweep": int(batch_bytes),
+                "achieved": round(batch_bytes / (b_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit_bw": "GB/s",
+                "frac": round(batch_bytes / (b_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "note": "algorithmic bytes = the 64 single traversals' (shared edge reads are what the batch saves)"}
+            del bvs
+            kk = 64
+            tB = torch.rand((n, kk), dtype=torch.float32, device=dev)
+            tC = torch.empty((n, kk), dtype=torch.float32, device=dev)
+            torch.cuda.synchronize()
+            for _ in range(2):
+                assert g.spmm("PlusMultiplies", A, tB.data_ptr(), tC.data_ptr(), kk) == 0
+            g.timer_start()
+            for _ in range(3):
+                g.spmm("PlusMultiplies", A, tB.data_ptr(), tC.data_ptr(), kk)
+            sp_ms = g.timer_stop() / 3
+            sp_bytes = 8.0 * nnz + 4.0 * (n + 1) + 2 * 4.0 * n * kk
+            extra["spmm_k64"] = {"kernel": "spmm_tile_kernel<PlusMultiplies,f32,64>", "k": kk, "avg_launch_ms": round(sp_ms, 4),
+                                 "gflops": round(2.0 * nnz * kk / (sp_ms * 1e-3) / 1e9, 1),
+                                 "algorithmic_bytes_per_launch": int(sp_bytes),
+                                 "achieved": round(sp_bytes / (sp_ms * 1e-3) / 1e9, 1), "unit": "GB/s",
+                                 "frac": round(sp_bytes / (sp_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                 "gathered_B_rows_GBps": round(4.0 * kk * nnz / (sp_ms * 1e-3) / 1e9, 1),
+                                 "vs_64_spmv_launches": round(64 * ms / sp_ms, 2)}
+            del tB, tC
 
         # ---- the same SpMV kernel where the gathers are local (a road-like 4096^2 grid in natural
         #      order): what it does when the L2 request rate of scattered gathers is not the wall

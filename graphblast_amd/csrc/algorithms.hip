@@ -225,7 +225,8 @@ grb_info grb_pr(grb_vector p, grb_matrix A, float alpha, float eps, grb_descript
   double t_iter = host_ms();
   for (; error > eps && iter <= desc->max_niter; ++iter) {
     // vxm treats A as transposed: the pull product walks the CSC orientation (operations.hpp:80-209)
-    GRB_TRY(k_spmv(GRB_PLUS_MULTIPLIES, GRB_F32, A->csc, A->plan_csc, p->d_val, nullptr, 0, 0, 0, p_swap->d_val));
+    GRB_TRY(k_spmv(GRB_PLUS_MULTIPLIES, GRB_F32, A->csc, A->plan_csc, p->d_val, nullptr, 0, 0, 0, p_swap->d_val,
+                   A->csc_alias ? nullptr : A->csr.ptr));
     const int seq = ++c.mail_seq;
     hipLaunchKernelGGL(pr_update_kernel, dim3(grid), dim3(kBlock), 0, c.stream, (const float*)p_swap->d_val,
                        (float*)p->d_val, cst, n, (float*)p_part, d_ticket, c.d_hgran, seq);

@@ -254,9 +254,95 @@ __global__ void swap_halves_kernel(unsigned long long* __restrict__ keys, long l
   }
 }
 
+// ---- column ranking for the SpMV hub packing (spmv.hip): counts, stable sort by descending count
+__global__ void rank_counts_from_ptr_kernel(const Index* __restrict__ ptr, Index m, unsigned int* __restrict__ cnt) {
+  const Index stride = (Index)gridDim.x * blockDim.x;
+  for (Index c = (Index)blockIdx.x * blockDim.x + threadIdx.x; c < m; c += stride) cnt[c] = (unsigned int)(ptr[c + 1] - ptr[c]);
+}
+// no transposed pointer array at hand (a row shard): a plain histogram.  The hub columns' increments are
+// same-address atomics; this is the one-off preparation of a shard, not a path any iteration takes
+__global__ void rank_counts_hist_kernel(const Index* __restrict__ ind, Index nvals, unsigned int* __restrict__ cnt) {
+  const Index stride = (Index)gridDim.x * blockDim.x;
+  for (Index p = (Index)blockIdx.x * blockDim.x + threadIdx.x; p < nvals; p += stride) atomicAdd(&cnt[ind[p]], 1u);
+}
+__global__ void rank_keys_kernel(const unsigned int* __restrict__ cnt, Index m, unsigned long long* __restrict__ keys,
+                                 unsigned int* __restrict__ pay) {
+  const Index stride = (Index)gridDim.x * blockDim.x;
+  for (Index c = (Index)blockIdx.x * blockDim.x + threadIdx.x; c < m; c += stride) {
+    keys[c] = ((unsigned long long)(0xffffffffu - cnt[c]) << 32) | (unsigned int)c;   // descending count, ties by column
+    pay[c] = cnt[c];
+  }
+}
+__global__ void rank_scatter_kernel(const unsigned long long* __restrict__ keys, const unsigned int* __restrict__ pay, Index m,
+                                    Index hot, Index* __restrict__ order, Index* __restrict__ rank,
+                                    unsigned long long* __restrict__ out /* [0] hot refs, [1] referenced columns */) {
+  const Index stride = (Index)gridDim.x * blockDim.x;
+  unsigned long long refs = 0, used = 0;
+  for (Index r = (Index)blockIdx.x * blockDim.x + threadIdx.x; r < m; r += stride) {
+    const Index c = (Index)(unsigned int)keys[r];
+    order[r] = c;
+    rank[c] = r;
+    if (r < hot) refs += pay[r];
+    if (pay[r]) ++used;
+  }
+  auto add = [](unsigned long long x, unsigned long long y) { return x + y; };
+  refs = wave_reduce(refs, add);
+  used = wave_reduce(used, add);
+  if (lane_id() == 0) {
+    if (refs) atomicAdd(&out[0], refs);
+    if (used) atomicAdd(&out[1], used);
+  }
+}
+
 }  // namespace grb
 
 using namespace grb;
+
+// Columns ranked by reference count, entirely on the device: counts from the transposed orientation's pointer
+// array when there is one (no histogram at all), stable LSD radix sort of (0xffffffff - count, column).
+grb_info grb::device_rank_columns(const Index* d_ind, Index nvals, const Index* d_other_ptr, Index m, Index hot,
+                                  Index* d_order, Index* d_rank, long long* hot_refs, Index* nreferenced) {
+  hipStream_t s = ctx().stream;
+  const size_t cap = (size_t)(m > 0 ? m : 1);
+  const int nblocks = (int)((m + kSortTile - 1) / kSortTile) + 1;
+  const size_t cnt_elems = 256 * (size_t)nblocks > cap + 1 ? 256 * (size_t)nblocks : cap + 1;
+  void* raw = nullptr;
+  GRB_HIP_TRY(hipMalloc(&raw, 2 * 8 * cap + 2 * 4 * cap + 4 * cap + 4 * cnt_elems + 4 * (cnt_elems / kScanTile + 2) + 16));
+  struct Free { void* p; ~Free() { (void)hipFree(p); } } guard{raw};
+  SortBuffers b;
+  char* q = (char*)raw;
+  b.keys[0] = (unsigned long long*)q; q += 8 * cap;
+  b.keys[1] = (unsigned long long*)q; q += 8 * cap;
+  b.pay[0] = (unsigned int*)q; q += 4 * cap;
+  b.pay[1] = (unsigned int*)q; q += 4 * cap;
+  unsigned int* d_cnt = (unsigned int*)q; q += 4 * cap;
+  b.cnt = (unsigned int*)q; q += 4 * cnt_elems;
+  b.totals = (unsigned int*)q; q += 4 * (cnt_elems / kScanTile + 2);
+  q = (char*)(((uintptr_t)q + 7) & ~(uintptr_t)7);
+  unsigned long long* d_out = (unsigned long long*)q;
+  if (d_other_ptr) {
+    hipLaunchKernelGGL(rank_counts_from_ptr_kernel, dim3(stream_grid(m, kBlock)), dim3(kBlock), 0, s, d_other_ptr, m, d_cnt);
+  } else {
+    GRB_HIP_TRY(hipMemsetAsync(d_cnt, 0, 4 * cap, s));
+    hipLaunchKernelGGL(rank_counts_hist_kernel, dim3(stream_grid(nvals, kBlock)), dim3(kBlock), 0, s, d_ind, nvals, d_cnt);
+  }
+  GRB_HIP_TRY(hipGetLastError());
+  hipLaunchKernelGGL(rank_keys_kernel, dim3(stream_grid(m, kBlock)), dim3(kBlock), 0, s, (const unsigned int*)d_cnt, m,
+                     b.keys[0], b.pay[0]);
+  GRB_HIP_TRY(hipGetLastError());
+  int cur = 0;
+  GRB_TRY(radix_sort_pairs(b, &cur, m, 0, 32, s));          // the count digits only: stable, so ties stay in column order
+  GRB_HIP_TRY(hipMemsetAsync(d_out, 0, 16, s));
+  hipLaunchKernelGGL(rank_scatter_kernel, dim3(stream_grid(m, kBlock)), dim3(kBlock), 0, s,
+                     (const unsigned long long*)b.keys[cur], (const unsigned int*)b.pay[cur], m, hot, d_order, d_rank, d_out);
+  GRB_HIP_TRY(hipGetLastError());
+  unsigned long long out[2] = {0, 0};
+  GRB_HIP_TRY(hipMemcpyAsync(out, d_out, 16, hipMemcpyDeviceToHost, s));
+  GRB_HIP_TRY(hipStreamSynchronize(s));
+  *hot_refs = (long long)out[0];
+  *nreferenced = (Index)out[1];
+  return GRB_SUCCESS;
+}
 
 // Device coordinate list -> the matrix's device CSR + CSC (owned), host row/column pointers.
 // flags: bit 0 add reverse entries, bit 1 drop self loops, bit 2 drop duplicates.

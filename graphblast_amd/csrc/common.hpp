@@ -503,8 +503,14 @@ grb_info k_gather_indexed(int dtype, void* w, Index w_n, const int* idx, Index n
 // spmv.hip
 grb_info build_spmv_plan(const std::vector<Index>& ptr, Index n, Index nminor, SpmvPlan* plan);
 void free_spmv_plan(SpmvPlan* plan);
+// build.hip: columns ranked by descending reference count on the device (d_other_ptr: the transposed
+// orientation's pointer array, whose differences ARE the counts; nullptr: histogram of d_ind)
+grb_info device_rank_columns(const Index* d_ind, Index nvals, const Index* d_other_ptr, Index m, Index hot,
+                             Index* d_order, Index* d_rank, long long* hot_refs, Index* nreferenced);
+// other_ptr: pointer array of the transposed orientation (length nminor + 1) or nullptr; only read by the
+// one-off hub-packing preparation
 grb_info k_spmv(int sr, int dtype, const CsrArrays& M, SpmvPlan& plan, const void* u,
-                const void* mask, int mask_f32, int scmp, int accum, void* w);
+                const void* mask, int mask_f32, int scmp, int accum, void* w, const Index* other_ptr = nullptr);
 grb_info k_spmv_masked_or(int dtype, const CsrArrays& M, const void* u, double identity,
                           const void* mask, int mask_f32, int scmp, int earlyexit, int opreuse,
                           const Index* hint /* per-row best neighbour, may be null */, void* w);

@@ -37,8 +37,9 @@ static grb_info spmv_dispatch(grb_vector w, grb_vector mask, grb_accum accum, in
   // (spmv.hpp:203-212): a sparse or cleared mask acts through whatever its dense buffer last held
   if (use_mask && !mask->d_val) return GRB_INVALID_OBJECT;
   w->d_nnz = u->d_nnz;
+  const CsrArrays& other = use_tran ? A->csr : A->csc;
   return k_spmv(op, w->dtype, M, plan, u->d_val, use_mask ? mask->d_val : nullptr, mask_is_f32(mask), use_scmp,
-                use_accum, w->d_val);
+                use_accum, w->d_val, (other.ptr && other.n == plan.nminor && !A->csc_alias) ? other.ptr : nullptr);
 }
 
 // push: backend/cuda/spmspv.hpp:15-257
@@ -396,7 +397,9 @@ grb_info grb_k_spmv(grb_matrix A, int tran, grb_semiring op, const void* d_u, co
   const CsrArrays& M = tran ? A->csc : A->csr;
   SpmvPlan& plan = tran ? A->plan_csc : A->plan_csr;
   if (!M.ptr) return GRB_INVALID_OBJECT;
-  return k_spmv(op, A->dtype, M, plan, d_u, d_mask, A->dtype == GRB_F32, scmp, accum, d_w);
+  const CsrArrays& other = tran ? A->csr : A->csc;
+  return k_spmv(op, A->dtype, M, plan, d_u, d_mask, A->dtype == GRB_F32, scmp, accum, d_w,
+                (other.ptr && other.n == plan.nminor && !A->csc_alias) ? other.ptr : nullptr);
 }
 
 int64_t grb_k_spmv_bytes(grb_matrix A, int tran) {

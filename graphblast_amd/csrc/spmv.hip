@@ -126,12 +126,6 @@ void free_spmv_plan(SpmvPlan* plan) {
 // in a dense prefix: the first kHot of them are staged in LDS by every workgroup and the next
 // few hundred thousand stay L2-resident.  The row sums are formed in the same order as
 // before, so results are bit-identical to the unpacked kernel.
-__global__ void column_count_kernel(const Index* __restrict__ ind, Index nvals, int* __restrict__ cnt) {
-  const Index stride = (Index)gridDim.x * blockDim.x;
-  for (Index p = (Index)blockIdx.x * blockDim.x + threadIdx.x; p < nvals; p += stride)
-    atomicAdd(&cnt[ind[p]], 1);
-}
-
 __global__ void rename_columns_kernel(const Index* __restrict__ ind, Index nvals, const Index* __restrict__ rank,
                                       Index* __restrict__ ind2) {
   const Index stride = (Index)gridDim.x * blockDim.x;
@@ -145,46 +139,29 @@ __global__ void pack_vector_kernel(const T* __restrict__ u, const Index* __restr
   if (i < n) u2[i] = u[order[i]];
 }
 
-static grb_info prepare_hub_packing(const CsrArrays& M, SpmvPlan& plan) {
+static grb_info prepare_hub_packing(const CsrArrays& M, SpmvPlan& plan, const Index* other_ptr) {
   plan.hub_ready = true;
   const Index m = plan.nminor;
   plan.nhot = m < kHot ? m : kHot;      // a short vector fits LDS whole: no renaming needed
   if (m <= kHot || M.nvals == 0) return GRB_SUCCESS;
-  int* d_cnt = nullptr;
-  GRB_HIP_TRY(hipMalloc(&d_cnt, 4 * (size_t)m));
-  GRB_HIP_TRY(hipMemsetAsync(d_cnt, 0, 4 * (size_t)m, ctx().stream));
-  hipLaunchKernelGGL(column_count_kernel, dim3(stream_grid(M.nvals, kBlock)), dim3(kBlock), 0, ctx().stream,
-                     M.ind, M.nvals, d_cnt);
-  std::vector<int> cnt((size_t)m);
-  GRB_HIP_TRY(hipMemcpyAsync(cnt.data(), d_cnt, 4 * (size_t)m, hipMemcpyDeviceToHost, ctx().stream));
-  GRB_HIP_TRY(hipStreamSynchronize(ctx().stream));
-  (void)hipFree(d_cnt);
-  // counting sort by descending count, ties in column order
-  int maxc = 0;
-  for (int c : cnt) maxc = c > maxc ? c : maxc;
-  std::vector<Index> bucket((size_t)maxc + 2, 0);
-  for (int c : cnt) bucket[(size_t)(maxc - c) + 1]++;
-  for (size_t b = 1; b < bucket.size(); ++b) bucket[b] += bucket[b - 1];
-  std::vector<Index> order((size_t)m), rank((size_t)m);
-  for (Index c = 0; c < m; ++c) {
-    Index r = bucket[(size_t)(maxc - cnt[c])]++;
-    order[r] = c;
-    rank[c] = r;
-  }
-  // worth it only when the LDS prefix takes a real share of the gathers
+  // columns ranked by reference count on the device (build.hip): counts = row lengths of the transposed
+  // orientation when the matrix has one, radix sort by descending count, ties in column order
+  Index* d_rank = nullptr;
+  GRB_HIP_TRY(hipMalloc(&d_rank, 4 * (size_t)m));
+  GRB_HIP_TRY(hipMalloc(&plan.d_order, 4 * (size_t)m));
   long long hot_refs = 0;
-  for (Index r = 0; r < kHot; ++r) hot_refs += cnt[order[r]];
-  if (hot_refs * 8 < (long long)M.nvals) {   // < 12.5 %: keep the natural column order
+  Index nref = 0;
+  grb_info ri = device_rank_columns(M.ind, M.nvals, other_ptr, m, kHot, plan.d_order, d_rank, &hot_refs, &nref);
+  // worth it only when the LDS prefix takes a real share of the gathers
+  if (ri != GRB_SUCCESS || hot_refs * 8 < (long long)M.nvals) {   // < 12.5 %: keep the natural column order
+    (void)hipFree(d_rank);
+    (void)hipFree(plan.d_order);
+    plan.d_order = nullptr;
     plan.nhot = 0;
-    return GRB_SUCCESS;
+    return ri;
   }
   // columns nobody references sort last and are never gathered: they need no packing
-  Index nref = m;
-  while (nref > 0 && cnt[order[nref - 1]] == 0) --nref;
   plan.npacked = nref;
-  Index* d_rank = nullptr;
-  GRB_TRY(to_device(rank, &d_rank));
-  GRB_TRY(to_device(order, &plan.d_order));
   GRB_HIP_TRY(hipMalloc(&plan.d_ind2, 4 * (size_t)M.nvals));
   GRB_HIP_TRY(hipMalloc(&plan.d_u2, 4 * (size_t)m));
   hipLaunchKernelGGL(rename_columns_kernel, dim3(stream_grid(M.nvals, kBlock)), dim3(kBlock), 0, ctx().stream,
@@ -372,10 +349,10 @@ __global__ __launch_bounds__(kHubThreads) void spmv_hub_kernel(
 }
 
 grb_info k_spmv(int sr, int dtype, const CsrArrays& M, SpmvPlan& plan, const void* u, const void* mask,
-                int mask_f32, int scmp, int accum, void* w) {
+                int mask_f32, int scmp, int accum, void* w, const Index* other_ptr) {
   if (plan.ntiles == 0 && M.nvals > 0) return GRB_INVALID_OBJECT;   // nonzeros but no plan: never a silent no-op
   if (plan.ntiles == 0 && plan.nrows == 0) return GRB_SUCCESS;       // nothing to write
-  if (M.nvals > 0 && !plan.hub_ready) GRB_TRY(prepare_hub_packing(M, plan));
+  if (M.nvals > 0 && !plan.hub_ready) GRB_TRY(prepare_hub_packing(M, plan, other_ptr));
   return dispatch_semiring(sr, dtype, [&](auto tag, auto t) -> grb_info {
     using T = decltype(t);
     constexpr int SR = decltype(tag)::value;
