@@ -307,7 +307,7 @@ grb_info grb::device_rank_columns(const Index* d_ind, Index nvals, const Index* 
   const int nblocks = (int)((m + kSortTile - 1) / kSortTile) + 1;
   const size_t cnt_elems = 256 * (size_t)nblocks > cap + 1 ? 256 * (size_t)nblocks : cap + 1;
   void* raw = nullptr;
-  GRB_HIP_TRY(hipMalloc(&raw, 2 * 8 * cap + 2 * 4 * cap + 4 * cap + 4 * cnt_elems + 4 * (cnt_elems / kScanTile + 2) + 16));
+  GRB_HIP_TRY(hipMalloc(&raw, 2 * 8 * cap + 2 * 4 * cap + 4 * cap + 4 * cnt_elems + 4 * (cnt_elems / kScanTile + 2) + 64));
   struct Free { void* p; ~Free() { (void)hipFree(p); } } guard{raw};
   SortBuffers b;
   char* q = (char*)raw;

@@ -228,7 +228,7 @@ def test_reference_gbfs_main_at_scale_is_the_fast_path(tmp_path):
     ptr, ind = gr["csr"]
     src = int(np.argmax(np.diff(ptr)))
     stub = tmp_path / "stub.mtx"
-    stub.write_text("%%MatrixMarket matrix coordinate pattern symmetric\n%d %d %d\n" % (n, n, ind.size // 2))
+    stub.write_text("%%MatrixMarket matrix coordinate pattern symmetric\n" + "%d %d %d\n" % (n, n, ind.size // 2))
     loader.write_cache(str(tmp_path / ".stub.mtx.ud.nosl.bin"), ptr, ind)
     out = _run_env("gbfs_ref", {}, "--mxvmode", "0", "--struconly", "1", "--opreuse", "1", "--earlyexit", "1",
                    "--source", str(src), "--niter", "20", "--timing", "0", str(stub))
