@@ -1,5 +1,5 @@
-"""gpurun_out/<dir> (rocprofv3 --kernel-trace --stats run + two --pmc passes of bench.py) -> profiles/<round>/.
-usage: tools/summarize_profiles.py gpurun_out/prof_r1e profiles/r01"""
+"""gpurun_out/<dir> (tools/profile_round.sh: rocprofv3 --kernel-trace --stats run + two --pmc passes of bench.py)
+-> profiles/<round>/.      usage: tools/summarize_profiles.py gpurun_out/prof_r2 profiles/r02"""
 import csv, collections, json, shutil, os, sys
 src, dst = sys.argv[1], sys.argv[2]
 os.makedirs(dst, exist_ok=True)
@@ -14,6 +14,32 @@ with open(dst + '/bench_kernel_stats_grb.csv', 'w', newline='') as f:
             w.writerow(r)
 shutil.copy(src + '/bench_stdout.log', dst + '/bench_stdout_under_rocprof.log')
 shutil.copy(src + '/bench_plain.log', dst + '/bench_stdout.log')
+# ---- bfs_persistent_kernel by phase of the default command.  Launch order in bench.py: W warm-up, K timed, K with HIP
+# events (the roofline pass), then accounting / reference-rule / spot-check launches.  The whole-run mean in the stats
+# file mixes them (the reference-rule launches run 2x longer by design); the timed region is launches [W, W + K).
+trace = src + '/bench_kernel_trace_grb.csv'
+if os.path.exists(trace):
+    shutil.copy(trace, dst + '/bench_kernel_trace_grb.csv')
+    line = json.loads(open(src + '/bench_stdout.log').read().strip().splitlines()[-1])
+    W, K = line["warmup"], line["steps"]
+    tr = [r for r in csv.DictReader(open(trace))]
+    bfs = [int(r["duration_ns"]) for r in tr if r["kernel"].startswith("grb::bfs_persistent_kernel")]
+    spmv = {}
+    for r in tr:
+        for key in ("spmv_hub_kernel", "pack_vector_kernel", "spmv_long_finalize_kernel"):
+            if key in r["kernel"]:
+                spmv.setdefault(key, []).append(int(r["duration_ns"]))
+    ph = {"source": "rocprofv3 --kernel-trace of the default `python bench.py` (same run as bench_kernel_stats_*.csv)",
+          "warmup": W, "steps": K, "bfs_persistent_kernel_launches": len(bfs),
+          "bfs_persistent_kernel_mean_us": {
+              "timed_region_launches_W_to_W+K": round(sum(bfs[W:W + K]) / K / 1e3, 2),
+              "hip_event_pass_launches_W+K_to_W+2K": round(sum(bfs[W + K:W + 2 * K]) / K / 1e3, 2),
+              "all_launches_of_the_run": round(sum(bfs) / len(bfs) / 1e3, 2)},
+          "hip_event_mean_us_reported_by_bench": round(line["roofline"]["avg_launch_ms"] * 1e3, 2),
+          "spmv_kernels_mean_us": {k: round(sum(v) / len(v) / 1e3, 2) for k, v in spmv.items()},
+          "spmv_hip_event_mean_us_reported_by_bench": round(line["spmv"]["avg_launch_ms"] * 1e3, 2)}
+    json.dump(ph, open(dst + '/bench_kernel_phases.json', 'w'), indent=1)
+    print(json.dumps(ph["bfs_persistent_kernel_mean_us"]), ph["hip_event_mean_us_reported_by_bench"], ph["spmv_kernels_mean_us"])
 out = {}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     rr = list(csv.DictReader(open(src + '/pmc_%s/p_counter_collection.csv' % c)))
@@ -35,7 +61,7 @@ for k, v in out.items():
     v["hbm_bytes_per_launch"] = int((2 * f_ + w_) * 1024)
 cal = {k: out[k] for k in out if k.startswith("grb::reduce_kernel") or "ewise_add_dd" in k or "assign_dense_mask_dense" in k or "fill_kernel" in k}
 doc = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, each with --kernel-trace only) over "
-                 "`python bench.py --steps 8 --warmup 2 --no-cpu-baseline` on MI355X",
+                 "`python bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-refrule --no-batch` on MI355X",
        "note": "hbm_bytes_per_launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 B.  The factor 2 on reads is MI355X_MICROARCH.md's gfx950 "
                "correction (128-B requests tallied at 64 B), calibrated in this same run on this library's own 4 B/lane kernels of "
                "known byte count (`calibration`: the 64 Mi-float reduce reads 262144 KB, eWiseAdd 524288 KB, assign 262144 KB; each is "
