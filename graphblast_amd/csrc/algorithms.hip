@@ -57,7 +57,16 @@ grb_info grb_sssp(grb_vector v, grb_matrix A, grb_index source, grb_descriptor d
       if (result) { result->iterations = it; result->tight_ms = fused_ms; result->last_value = sc; }
       return GRB_SUCCESS;
     }
-    if (fi != GRB_SUCCESS && fi != GRB_NOT_IMPLEMENTED) return fi;
+    if (fi == GRB_PANIC) {            // the persistent launch gave up (grid not co-resident): the call sequence instead
+      static bool told = false;
+      if (!told) fprintf(stderr, "libgrb_hip: one-launch SSSP unavailable, using the op-by-op rounds\n");
+      told = true;
+      GRB_HIP_TRY(hipStreamSynchronize(ctx().stream));
+      continued = false;
+      fused_ms = 0.f;
+    } else if (fi != GRB_SUCCESS && fi != GRB_NOT_IMPLEMENTED) {
+      return fi;
+    }
     if (continued) first_iter = it + 1;
   }
   GRB_TRY(g.make(&f2, GRB_F32, n));

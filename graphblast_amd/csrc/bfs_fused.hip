@@ -118,8 +118,20 @@ extern "C" grb_info grb_bfs_fused(grb_vector v, grb_matrix A, grb_index source, 
     Index p_nf = 0;
     bool p_cap = false;
     float p_ms = 0.f;
-    GRB_TRY(bfs_persistent_run(v, A, source, desc, profile, levels_out, max_levels, &p_levels, &p_dir, &p_reached,
-                               &p_edges, &p_nf, &p_cap, &p_ms));
+    const grb_info pi = bfs_persistent_run(v, A, source, desc, profile, levels_out, max_levels, &p_levels, &p_dir,
+                                           &p_reached, &p_edges, &p_nf, &p_cap, &p_ms);
+    if (pi == GRB_PANIC || pi == GRB_NOT_IMPLEMENTED) {
+      // the one-launch traversal could not run to its end here (launch refused, or its grid barrier gave up
+      // because the grid was not co-resident -- other work on the device): same traversal, level loop driven
+      // from the host (below), instead of an error
+      static bool told = false;
+      if (!told) fprintf(stderr, "libgrb_hip: one-launch BFS unavailable (Info %d), using the host-driven level loop\n", pi);
+      told = true;
+      GRB_HIP_TRY(hipStreamSynchronize(s));
+      c.bfs_prezero_ptr = nullptr;
+      goto host_loop;
+    }
+    GRB_TRY(pi);
     desc->lastmxv = p_dir ? GRB_PULLONLY : GRB_PUSHONLY;
     if (p_cap && p_nf > 0) {
       hipLaunchKernelGGL(bfs_unlabel_kernel, dim3(stream_grid(n)), dim3(kBlock), 0, s, (float*)v->d_val, n,
@@ -139,6 +151,7 @@ extern "C" grb_info grb_bfs_fused(grb_vector v, grb_matrix A, grb_index source, 
     return GRB_SUCCESS;
   }
 
+host_loop:
   void *p_va, *p_vb, *p_q, *p_scan, *p_rs, *p_tiles, *p_bt;
   GRB_TRY(scratch(7, 4 * (size_t)nwords, &p_va));
   ctx().bfs_prezero_ptr = nullptr;          // this slot is about to be overwritten

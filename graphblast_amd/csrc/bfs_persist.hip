@@ -633,8 +633,24 @@ grb_info bfs_persistent_run(grb_vector v, grb_matrix A, grb_index source, grb_de
     GRB_HIP_TRY(hipMemsetAsync(p_zero, 0, zero_bytes, s));
   c.bfs_prezero_ptr = nullptr;
   if (profile & 1) GRB_HIP_TRY(hipEventRecord(c.ev0, s));
-  hipLaunchKernelGGL(bfs_persistent_kernel, dim3(G), dim3(kPThreads), 0, s, a);
-  GRB_HIP_TRY(hipGetLastError());
+  // The grid barrier needs every workgroup resident at once.  GRB_BFS_COOPERATIVE=1 asks the runtime to
+  // guarantee that (hipLaunchCooperativeKernel fails fast when it cannot); the default launch relies on the
+  // occupancy query above and on the bounded spins of the barrier.  Either way a traversal that cannot run
+  // here is reported as GRB_NOT_IMPLEMENTED / GRB_PANIC and grb_bfs_fused re-runs it with the host-driven loop.
+  static const bool cooperative = [] { const char* e = getenv("GRB_BFS_COOPERATIVE"); return e && atoi(e) != 0; }();
+  static const bool force_fallback = [] { const char* e = getenv("GRB_BFS_FORCE_FALLBACK"); return e && atoi(e) != 0; }();
+  if (force_fallback) return GRB_NOT_IMPLEMENTED;            // test hook: behave as if the launch had been refused
+  if (cooperative) {
+    void* kargs[] = {&a};
+    if (hipLaunchCooperativeKernel(reinterpret_cast<void*>(bfs_persistent_kernel), dim3(G), dim3(kPThreads), kargs, 0, s) !=
+        hipSuccess) {
+      (void)hipGetLastError();
+      return GRB_NOT_IMPLEMENTED;
+    }
+  } else {
+    hipLaunchKernelGGL(bfs_persistent_kernel, dim3(G), dim3(kPThreads), 0, s, a);
+    GRB_HIP_TRY(hipGetLastError());
+  }
   if (profile & 1) GRB_HIP_TRY(hipEventRecord(c.ev1, s));
   const auto th1 = std::chrono::steady_clock::now();
   unsigned int gv[8];

@@ -386,6 +386,8 @@ grb_info sssp_persistent_run(grb_vector v, grb_matrix A, grb_index source, grb_d
   if (2 * (size_t)n > 0x7fffffffull) GRB_TRY(k_fill(GRB_F32, a.D[2], (double)FLT_MAX, n));
   hipLaunchKernelGGL(sssp_seed_kernel, dim3(1), dim3(64), 0, s, a.D[1], a.F[1], source);
   GRB_HIP_TRY(hipGetLastError());
+  static const bool force_fallback = [] { const char* e = getenv("GRB_SSSP_FORCE_FALLBACK"); return e && atoi(e) != 0; }();
+  if (force_fallback) return GRB_PANIC;                        // test hook: as if the grid barrier had given up
   hipLaunchKernelGGL(sssp_persistent_kernel, dim3(G), dim3(kPThreads), 0, s, a);
   GRB_HIP_TRY(hipGetLastError());
   unsigned int gv[4];

@@ -317,3 +317,45 @@ def test_load_balance_mode_switch(hb, fx, monkeypatch):
     w2 = g.Vector(n)
     assert g.vxm(w2, None, None, "LogicalOrAnd", sparse_u(), A, hb.descriptor(mxvmode=1)) == 0
     assert np.array_equal(hb.sparse_tuples(w2)[0], want)
+
+
+def test_persistent_launch_falls_back_instead_of_panicking(fx):
+    """A one-launch traversal that cannot run (launch refused / grid barrier gave up) is re-run through the
+    host-driven level loop (BFS) or the op-by-op rounds (SSSP): same labels / distances and a one-line note on
+    stderr, not GrB_PANIC.  Forced here with the test hooks GRB_BFS_FORCE_FALLBACK / GRB_SSSP_FORCE_FALLBACK in a
+    fresh process (they are read once); GRB_BFS_COOPERATIVE=1 (hipLaunchCooperativeKernel) is exercised too."""
+    import subprocess
+    import sys
+    code = r'''
+import os, sys, numpy as np
+sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
+import graphblast_amd as g
+fx = np.load("tests/golden/algo_ref.npz")
+for case in ("rmat14.d2", "rmat14.d0", "grid48.d0"):
+    ptr, ind = fx[case + "/csr_ptr"], fx[case + "/csr_ind"]
+    n = ptr.size - 1
+    A = g.Matrix(n, n); assert A.build_csr(ptr, ind, np.ones(ind.size, np.float32)) == 0
+    W = g.Matrix(n, n); assert W.build_csr(ptr, ind, fx[case + "/weights"]) == 0
+    for k, src in enumerate(fx[case + "/sources"]):
+        d = g.Descriptor(); assert d.loadArgs(mxvmode=0, struconly=1, opreuse=1) == 0
+        v = g.Vector(n)
+        info, res = g.bfs(v, A, int(src), d, fused=True)
+        assert info == 0, info
+        assert np.array_equal(v.extractTuples()[1], fx["%s/bfs_%d" % (case, k)]), (case, k)
+        d2 = g.Descriptor(); assert d2.loadArgs(mxvmode=0) == 0
+        v2 = g.Vector(n)
+        assert g.sssp(v2, W, int(src), d2)[0] == 0
+        assert np.array_equal(v2.extractTuples()[1], fx["%s/sssp_%d" % (case, k)]), (case, k)
+print("OK")
+'''
+    for env, note in (({"GRB_BFS_FORCE_FALLBACK": "1", "GRB_SSSP_FORCE_FALLBACK": "1"}, True),
+                      ({"GRB_BFS_COOPERATIVE": "1"}, False)):
+        e = dict(os.environ)
+        e.update(env)
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd=root, env=e)
+        assert out.returncode == 0 and "OK" in out.stdout, out.stderr[-1500:]
+        if note:
+            assert "one-launch BFS unavailable" in out.stderr and "one-launch SSSP unavailable" in out.stderr
+        else:
+            assert "unavailable" not in out.stderr, out.stderr[-800:]
