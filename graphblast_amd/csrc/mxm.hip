@@ -34,6 +34,15 @@ __global__ void entry_rows_kernel(const Index* __restrict__ ptr, Index nrows, In
   }
 }
 
+// sum of int32 entries in 64 bits (the triangle count of a com-Orkut-sized graph does not fit an int)
+__global__ __launch_bounds__(kBlock) void sum_i32_wide_kernel(const int* __restrict__ d, Index n, long long* __restrict__ out) {
+  long long acc = 0;
+  const Index stride = (Index)gridDim.x * blockDim.x;
+  for (Index i = (Index)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) acc += d[i];
+  acc = wave_reduce(acc, [](long long x, long long y) { return x + y; });
+  if (lane_id() == 0 && acc) atomicAdd(reinterpret_cast<unsigned long long*>(out), (unsigned long long)acc);
+}
+
 __device__ inline Index lower_bound_dev(const Index* __restrict__ a, Index lo, Index hi, Index key) {
   while (lo < hi) {
     const Index mid = lo + ((hi - lo) >> 1);
@@ -339,10 +348,29 @@ grb_info grb_tc(int64_t* ntris, grb_matrix A, grb_matrix B, grb_descriptor desc,
   grb_info info = grb_timer_start();
   if (info == GRB_SUCCESS) info = grb_mxm(B, A, GRB_ACCUM_NULL, GRB_PLUS_MULTIPLIES, A, A, desc);
   double sum = 0;
-  if (info == GRB_SUCCESS) info = grb_reduce_matrix_scalar(&sum, GRB_ACCUM_NULL, GRB_PLUS_MONOID, B, desc);
+  long long wide = 0;
+  if (info == GRB_SUCCESS && B->dtype == GRB_I32 && !desc->struconly) {
+    // reduce<int, int>(ntris, ...) in the reference (tc.hpp:41-42) wraps beyond 2^31 triangles; this entry
+    // point returns the count in 64 bits (the frontend's int* overload keeps the reference's int)
+    void* p_sum;
+    info = scratch(10, 8, &p_sum);
+    if (info == GRB_SUCCESS && hipMemsetAsync(p_sum, 0, 8, ctx().stream) != hipSuccess) info = GRB_PANIC;
+    if (info == GRB_SUCCESS && B->nvals > 0) {
+      hipLaunchKernelGGL(sum_i32_wide_kernel, dim3(stream_grid(B->nvals, kBlock * 8)), dim3(kBlock), 0, ctx().stream,
+                         (const int*)B->csr.val, B->nvals, (long long*)p_sum);
+      if (hipGetLastError() != hipSuccess) info = GRB_PANIC;
+    }
+    if (info == GRB_SUCCESS && (hipMemcpyAsync(&wide, p_sum, 8, hipMemcpyDeviceToHost, ctx().stream) != hipSuccess ||
+                                hipStreamSynchronize(ctx().stream) != hipSuccess))
+      info = GRB_PANIC;
+    sum = (double)wide;
+  } else if (info == GRB_SUCCESS) {
+    info = grb_reduce_matrix_scalar(&sum, GRB_ACCUM_NULL, GRB_PLUS_MONOID, B, desc);
+    wide = (long long)sum;
+  }
   if (info == GRB_SUCCESS) info = grb_timer_stop(&ms);
   // (the reference leaves GrB_INP1 toggled: tc.hpp:23 has no matching toggle back)
-  *ntris = (int64_t)sum;
+  *ntris = (int64_t)wide;
   if (result) { result->iterations = 1; result->tight_ms = ms; result->last_value = sum; }
   return info;
 }
