@@ -37,11 +37,14 @@ constexpr int kPullBlock = GRB_PULL_BLOCK;    // chunks (of 64 vertices) one wav
 constexpr int kPullGroup = 16;    // lanes finishing one undecided row in the pull phase
 constexpr int kMedCap = 4096;     // LDS list of medium vertices per workgroup pass
 constexpr int kKeep = 32;         // levels whose discovered-bitmaps are kept for the final label pass
+constexpr int kOcWords = 8192;    // owner-computes push: visited words a workgroup owns at most (32 KiB of LDS)
+constexpr int kOcMaxBuckets = 512;
 
 struct PersistState {               // zeroed by the host before every launch
   GridBarrier bar;
   unsigned big_count[2][32];
   unsigned long long acc[3][8][16]; // level totals, one line per (set, XCD group): found, deg, inspected, big
+  unsigned oc_cursor[2][kOcMaxBuckets];   // owner-computes push: entries appended to each destination bucket
 };
 
 struct PersistArgs {
@@ -66,6 +69,12 @@ struct PersistArgs {
   unsigned int* F[kKeep + 3];
   int2* big_list;
   int big_cap;
+  // owner-computes push for heavy sparse frontiers (nullptr: off).  The vertices are cut into oc_nb ranges of
+  // 2^oc_shift; range b's edges are appended to oc_arena[iptr[b << oc_shift] ...) -- it cannot overflow: a range
+  // receives at most its in-degree sum -- and settled by workgroup b against its slice of the visited bitmap in LDS.
+  Index* oc_arena;
+  int oc_shift, oc_nb;
+  unsigned long long oc_min_edges;
   PersistState* st;
   grb_bfs_level* rec;
   int rec_cap;
@@ -110,6 +119,8 @@ __global__ __launch_bounds__(kPThreads) void bfs_persistent_kernel(PersistArgs a
   __shared__ int2 s_left[kPWaves][kPullBlock * kWave / 2];        // pull leftovers per wave: {next, end}
   __shared__ unsigned short s_leftid[kPWaves][kPullBlock * kWave / 2];
   __shared__ unsigned int s_leftfound[kPWaves][2 * kPullBlock];
+  __shared__ unsigned int s_ocw[kOcWords];
+  __shared__ int s_occnt[kOcMaxBuckets], s_ocbase[kOcMaxBuckets], s_ocreg[kOcMaxBuckets];
   const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
   const int G = gridDim.x;
   const long long gtid = (long long)blockIdx.x * kPThreads + tid;
@@ -167,6 +178,11 @@ __global__ __launch_bounds__(kPThreads) void bfs_persistent_kernel(PersistArgs a
       for (long long i = gtid; i < nwords; i += gthreads) publish(&a.F[fbuf(iter + 1)][i], 0u);
     if (gtid == 0) publish(&st->big_count[(iter + 1) & 1][0], 0u);
     if (blockIdx.x == 0 && tid < 32) publish(&st->acc[(iter + 1) % 3][tid >> 2][tid & 3], 0ull);
+    if (blockIdx.x == 0 && tid < kOcMaxBuckets) publish(&st->oc_cursor[(iter + 1) & 1][tid], 0u);
+    // A push level whose frontier carries many edges through few vertices runs at the rate of racing global
+    // atomics (two per discovery, most attempts losers).  Such a level buckets its big vertices' edges by
+    // destination range instead and lets the range's owner settle them in LDS: no global atomics at all.
+    const bool heavy = !f1_dense && iter > 1 && a.oc_arena != nullptr && nbig > 0 && mf >= a.oc_min_edges;
 
     if (!f1_dense) {
       // ================= push =================
@@ -218,11 +234,54 @@ __global__ __launch_bounds__(kPThreads) void bfs_persistent_kernel(PersistArgs a
           stamp();
           int nent = (int)__hip_atomic_load(bcount, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           if (nent > a.big_cap) nent = a.big_cap;
-          for (int e = blockIdx.x; e < nent; e += G) {
-            const unsigned long long eb = fresh(reinterpret_cast<const unsigned long long*>(&a.big_list[e]));
-            const int2 ent = make_int2((int)(eb & 0xffffffffull), (int)(eb >> 32));
-            const Index p = a.optr[ent.x] + ent.y * kBigChunk + tid;
-            if (p < a.optr[ent.x + 1]) push_visit(a, V, Fn, a.oind[p], new_label, c);
+          if (!heavy) {
+            for (int e = blockIdx.x; e < nent; e += G) {
+              const unsigned long long eb = fresh(reinterpret_cast<const unsigned long long*>(&a.big_list[e]));
+              const int2 ent = make_int2((int)(eb & 0xffffffffull), (int)(eb >> 32));
+              const Index p = a.optr[ent.x] + ent.y * kBigChunk + tid;
+              if (p < a.optr[ent.x + 1]) push_visit(a, V, Fn, a.oind[p], new_label, c);
+            }
+          } else {
+            // ---- owner-computes, pass 1: the entries' destinations go to their range's bucket.  Four entries
+            // (4096 edges) per step: ranks from LDS counters, ONE global atomic per non-empty bucket and step
+            // to reserve the space, write-through stores into the arena.
+            for (int b = tid; b < a.oc_nb; b += kPThreads) {
+              const long long v0 = (long long)b << a.oc_shift;
+              s_ocreg[b] = a.iptr[v0 < (long long)n ? v0 : (long long)n];
+              s_occnt[b] = 0;
+            }
+            __syncthreads();
+            unsigned* cursor = &st->oc_cursor[iter & 1][0];
+            for (int e0 = blockIdx.x * 4; e0 < nent; e0 += G * 4) {
+              Index dst[4];
+              int rank[4];
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                const int e = e0 + j;
+                dst[j] = -1;
+                if (e < nent) {
+                  const unsigned long long eb = fresh(reinterpret_cast<const unsigned long long*>(&a.big_list[e]));
+                  const Index u = (Index)(eb & 0xffffffffull);
+                  const Index p = a.optr[u] + (Index)(eb >> 32) * kBigChunk + tid;
+                  if (p < a.optr[u + 1]) dst[j] = a.oind[p];
+                }
+              }
+#pragma unroll
+              for (int j = 0; j < 4; ++j) rank[j] = dst[j] >= 0 ? atomicAdd(&s_occnt[dst[j] >> a.oc_shift], 1) : 0;
+              __syncthreads();
+              for (int b = tid; b < a.oc_nb; b += kPThreads) {
+                const int cnt = s_occnt[b];
+                s_ocbase[b] = cnt ? (int)atomicAdd(&cursor[b], (unsigned)cnt) : 0;
+                s_occnt[b] = 0;
+              }
+              __syncthreads();
+#pragma unroll
+              for (int j = 0; j < 4; ++j)
+                if (dst[j] >= 0) {
+                  const int b = dst[j] >> a.oc_shift;
+                  publish(&a.oc_arena[(size_t)s_ocreg[b] + (size_t)(s_ocbase[b] + rank[j])], dst[j]);
+                }
+            }
           }
         }
         stamp();
@@ -253,6 +312,46 @@ __global__ __launch_bounds__(kPThreads) void bfs_persistent_kernel(PersistArgs a
           __syncthreads();
           if (tid == 0) s_nmed = 0;
           __syncthreads();
+        }
+        if (heavy) {
+          // ---- owner-computes, pass 2 (every atomic of this level has landed after the barrier): workgroup b
+          // settles bucket b against its slice of the visited bitmap in LDS, writes the slice and the level's
+          // new-bits back with plain (write-through) stores and accounts for what it discovered
+          if (!grid_sync(&st->bar, gen, false)) return;
+          const int b = blockIdx.x;
+          if (b < a.oc_nb) {
+            const long long v0 = (long long)b << a.oc_shift;
+            const long long w0 = v0 >> 5;
+            long long nw = (1ll << a.oc_shift) >> 5;
+            if (w0 + nw > nwords) nw = nwords - w0;
+            for (int i = tid; i < nw; i += kPThreads) s_ocw[i] = fresh(&V[w0 + i]);
+            __syncthreads();
+            const unsigned cnt = fresh(&st->oc_cursor[iter & 1][b]);
+            const Index* reg = a.oc_arena + a.iptr[v0 < (long long)n ? v0 : (long long)n];
+            for (unsigned i0 = 0; i0 < cnt; i0 += 4 * kPThreads) {
+              Index d[4];
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                const unsigned i = i0 + j * kPThreads + tid;
+                d[j] = i < cnt ? fresh(&reg[i]) : -1;
+              }
+#pragma unroll
+              for (int j = 0; j < 4; ++j)
+                if (d[j] >= 0) atomicOr(&s_ocw[(d[j] - (Index)v0) >> 5], 1u << (d[j] & 31));
+            }
+            __syncthreads();
+            for (int i = tid; i < nw; i += kPThreads) {
+              const unsigned int old = fresh(&V[w0 + i]);
+              const unsigned int now = s_ocw[i];
+              unsigned int newb = now & ~old;
+              if (newb) {
+                publish(&V[w0 + i], now);
+                publish(&Fn[w0 + i], fresh(&Fn[w0 + i]) | newb);
+                for (; newb; newb &= newb - 1)
+                  discovered(a, (Index)((w0 + i) * 32) + (__ffs((int)newb) - 1), new_label, c);
+              }
+            }
+          }
         }
       }
       last_dir = 0;
@@ -609,6 +708,23 @@ grb_info bfs_persistent_run(grb_vector v, grb_matrix A, grb_index source, grb_de
   for (int L = 0; L < kKeep + 3; ++L) a.F[L] = p_v0 + (size_t)(1 + L) * (size_t)nwords;
   a.big_list = (int2*)p_big;
   a.big_cap = big_cap;
+  // owner-computes push: ranges of 2^shift vertices, one per workgroup (at most kOcWords visited words each);
+  // the arena is nnz entries: range b appends into the slots of its own in-edges
+  a.oc_arena = nullptr; a.oc_shift = 0; a.oc_nb = 0; a.oc_min_edges = ~0ull;
+  {
+    const char* e = getenv("GRB_BFS_OC_MIN");              // frontier out-edges from which a push level uses it; 0 = off
+    const long long oc_min = e ? atoll(e) : 262144;
+    int shift = 5;
+    while (((long long)1 << shift) * G < (long long)n) ++shift;
+    const int nb = (int)(((long long)n + ((long long)1 << shift) - 1) >> shift);
+    if (oc_min > 0 && (1 << shift) <= kOcWords * 32 && nb <= kOcMaxBuckets && nb <= G && A->nvals > 0) {
+      if (!A->d_oc_arena) GRB_HIP_TRY(hipMalloc((void**)&A->d_oc_arena, sizeof(Index) * (size_t)A->nvals));
+      a.oc_arena = A->d_oc_arena;
+      a.oc_shift = shift;
+      a.oc_nb = nb;
+      a.oc_min_edges = (unsigned long long)oc_min;
+    }
+  }
   a.st = (PersistState*)p_st;
   a.rec = (grb_bfs_level*)p_rec;
   a.rec_cap = rec_cap;

@@ -445,6 +445,7 @@ struct grb_matrix_s {
   unsigned int* d_empty_csr_rows = nullptr;      // bitmap: CSR row empty (built lazily by bfs_part)
   int nonneg_values = -1;                        // -1 unknown, else whether every stored value is >= 0 (sssp_persist)
   grb::Index* d_pull_hint = nullptr;                  // per vertex: its in-neighbour of largest out-degree (bfs_fused)
+  grb::Index* d_oc_arena = nullptr;              // bfs_persist.hip: destination buckets of the owner-computes push (nnz entries)
   grb::BatchSlices batch_in, batch_out;          // bfs_batch.hip, built lazily
   grb::SpmmCore spmm_core_csr, spmm_core_csc;    // spmm.hip, built lazily when GRB_SPMM_CORE is set
 };
