@@ -54,6 +54,19 @@ def _semiring_id(op):
     return SEMIRINGS.index(name)
 
 
+BINARY_OPS = ["logical_or", "logical_and", "logical_xor", "equal", "not_equal_to", "greater", "less", "greater_equal",
+              "less_equal", "first", "second", "minimum", "maximum", "plus", "minus", "multiplies", "divides"]
+
+
+def register_semiring(add_op, add_identity, mul_op):
+    """REGISTER_SEMIRING over REGISTER_MONOID (graphblas/stddef.hpp:140-191): a monoid (binary operator by name +
+    identity) with any binary operator as the multiply.  Returns an id usable wherever a semiring name is."""
+    out = C.c_int(0)
+    _lib.call("grb_semiring_register", BINARY_OPS.index(add_op), float(add_identity), BINARY_OPS.index(mul_op),
+              C.byref(out))
+    return out.value
+
+
 def _h(obj):
     return None if obj is None else obj._h
 

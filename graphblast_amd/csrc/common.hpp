@@ -164,11 +164,95 @@ struct Semiring {
   __host__ __device__ static T mul(T a, T b) { return binop<mulop, T>(a, b); }
 };
 
+// ---- semirings registered at run time (REGISTER_SEMIRING / REGISTER_MONOID of graphblas/stddef.hpp:140-191:
+// any monoid = (binary operator, identity) with any binary operator as the multiply).  The 17 the reference
+// itself registers are compiled as above; every other composition runs through ONE more instantiation of
+// each kernel whose operators are selected by wave-uniform switches on a descriptor in constant memory
+// (these kernels are bound by memory requests, not by a branch per element).
+constexpr int GRB_RUNTIME_SR = 17;               // internal: never an id of the C ABI
+constexpr int GRB_USER_SEMIRING_BASE = 64;       // ids grb_semiring_register hands out
+struct RtSemiring {
+  int add_op, mul_op;                            // BinOp codes
+  float ident_f;
+  int ident_i;
+};
+namespace {                                      // one copy per translation unit (no relocatable device code);
+__device__ __constant__ RtSemiring d_rt_semiring;   // dispatch_semiring binds the copy of the unit it is
+RtSemiring h_rt_semiring = {OP_PLUS, OP_TIMES, 0.f, 0};   // instantiated in, just before the kernels launch
+}
+
+template <typename T>
+__host__ __device__ inline T binop_rt(int op, T a, T b) {
+  switch (op) {
+    case OP_LOR: return binop<OP_LOR, T>(a, b);
+    case OP_LAND: return binop<OP_LAND, T>(a, b);
+    case OP_LXOR: return binop<OP_LXOR, T>(a, b);
+    case OP_EQ: return binop<OP_EQ, T>(a, b);
+    case OP_NE: return binop<OP_NE, T>(a, b);
+    case OP_GT: return binop<OP_GT, T>(a, b);
+    case OP_LT: return binop<OP_LT, T>(a, b);
+    case OP_GE: return binop<OP_GE, T>(a, b);
+    case OP_LE: return binop<OP_LE, T>(a, b);
+    case OP_FIRST: return a;
+    case OP_SECOND: return b;
+    case OP_MIN: return binop<OP_MIN, T>(a, b);
+    case OP_MAX: return binop<OP_MAX, T>(a, b);
+    case OP_PLUS: return binop<OP_PLUS, T>(a, b);
+    case OP_MINUS: return binop<OP_MINUS, T>(a, b);
+    case OP_TIMES: return binop<OP_TIMES, T>(a, b);
+    default: return binop<OP_DIV, T>(a, b);
+  }
+}
+
+__host__ __device__ inline const RtSemiring& rt_semiring() {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return d_rt_semiring;
+#else
+  return h_rt_semiring;
+#endif
+}
+
+template <typename T>
+struct Semiring<GRB_RUNTIME_SR, T> {
+  static constexpr int monoid = -1;              // no compile-time monoid: atomic_combine takes its CAS loop
+  static constexpr int mulop = -1;
+  __host__ __device__ static T identity() {
+    if constexpr (std::is_same<T, float>::value) return rt_semiring().ident_f;
+    else return (T)rt_semiring().ident_i;
+  }
+  __host__ __device__ static T add(T a, T b) { return binop_rt<T>(rt_semiring().add_op, a, b); }
+  __host__ __device__ static T mul(T a, T b) { return binop_rt<T>(rt_semiring().mul_op, a, b); }
+};
+
+// objects.hip: the registry behind grb_semiring_register.  `builtin` >= 0 when the composition is one of the 17.
+struct UserSemiring {
+  int add_op, mul_op;
+  double identity;
+  int builtin;
+};
+bool user_semiring_lookup(int id, UserSemiring* out);
+hipStream_t current_stream();                    // objects.hip: the library's stream (grb_set_stream)
+
 template <int N> struct IntTag { static constexpr int value = N; };
 
 // Runtime (semiring, dtype) -> compile-time dispatch: f(IntTag<SR>{}, T{}).
 template <typename F>
 inline grb_info dispatch_semiring(int sr, int dtype, F&& f) {
+  if (sr >= GRB_USER_SEMIRING_BASE) {
+    UserSemiring u;
+    if (!user_semiring_lookup(sr, &u)) return GRB_INVALID_VALUE;
+    if (u.builtin >= 0) return dispatch_semiring(u.builtin, dtype, f);      // the compiled kernels
+    RtSemiring r;
+    r.add_op = u.add_op;
+    r.mul_op = u.mul_op;
+    r.ident_f = (float)u.identity;
+    r.ident_i = u.identity >= 2147483647.0 ? INT_MAX : (u.identity <= -2147483648.0 ? INT_MIN : (int)u.identity);
+    h_rt_semiring = r;
+    // constant memory is read by kernels still in flight on the stream: order the update behind them
+    GRB_HIP_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(d_rt_semiring), &r, sizeof(r), 0, hipMemcpyHostToDevice, current_stream()));
+    if (dtype == GRB_F32) return f(IntTag<GRB_RUNTIME_SR>{}, float{});
+    return f(IntTag<GRB_RUNTIME_SR>{}, int{});
+  }
 #define GRB_CASE(SR)                                                         \
   case SR:                                                                   \
     if (dtype == GRB_F32) return f(IntTag<SR>{}, float{});                   \

@@ -172,10 +172,32 @@ double monoid_identity(int m, int dtype) {
 int semiring_monoid(int sr) {
   int out = -1;
   dispatch_semiring(sr, GRB_F32, [&](auto tag, auto t) -> grb_info {
-    out = SemiringTraits<decltype(tag)::value>::monoid;
+    constexpr int SR = decltype(tag)::value;
+    if constexpr (SR != GRB_RUNTIME_SR) out = SemiringTraits<SR>::monoid;
     return GRB_SUCCESS;
   });
   return out;
+}
+
+// ---- semirings registered at run time --------------------------------------------------
+static std::vector<UserSemiring>& user_semirings() {
+  static std::vector<UserSemiring> v;
+  return v;
+}
+bool user_semiring_lookup(int id, UserSemiring* out) {
+  const int k = id - GRB_USER_SEMIRING_BASE;
+  if (k < 0 || k >= (int)user_semirings().size()) return false;
+  *out = user_semirings()[(size_t)k];
+  return true;
+}
+hipStream_t current_stream() { return ctx().stream; }
+
+template <int SR>
+static void match_builtin(int add_op, double identity, int mul_op, int* out) {
+  typedef SemiringTraits<SR> Tr;
+  if (MonoidTraits<Tr::monoid>::op == add_op && Tr::mul == mul_op &&
+      ((double)Monoid<Tr::monoid, float>::identity() == identity || (double)Monoid<Tr::monoid, int>::identity() == identity))
+    *out = SR;
 }
 
 static inline void store_scalar(int dtype, void* dst, double v) {
@@ -306,6 +328,30 @@ grb_info grb_descriptor_get_arg(grb_descriptor d, const char* name, double* valu
 #undef X
   return GRB_INVALID_VALUE;
 }
+// REGISTER_SEMIRING(SR, ADD_MONOID, MULT_BINARYOP) / REGISTER_MONOID(M, BINARYOP, IDENTITY) at run time
+// (graphblas/stddef.hpp:140-191).  Operators are numbered as the functor templates of stddef.hpp:14-138 appear there
+// (grb_binary_op); the same composition registered twice gets the same id.
+grb_info grb_semiring_register(int add_op, double add_identity, int mul_op, int* id) {
+  if (!id) return GRB_NULL_POINTER;
+  if (add_op < 0 || add_op > OP_DIV || mul_op < 0 || mul_op > OP_DIV) return GRB_INVALID_VALUE;
+  std::vector<UserSemiring>& reg = user_semirings();
+  for (size_t k = 0; k < reg.size(); ++k)
+    if (reg[k].add_op == add_op && reg[k].mul_op == mul_op && reg[k].identity == add_identity) {
+      *id = GRB_USER_SEMIRING_BASE + (int)k;
+      return GRB_SUCCESS;
+    }
+  UserSemiring u = {add_op, mul_op, add_identity, -1};
+#define GRB_M(SR) match_builtin<SR>(add_op, add_identity, mul_op, &u.builtin);
+  GRB_M(GRB_LOGICAL_OR_AND) GRB_M(GRB_PLUS_MULTIPLIES) GRB_M(GRB_MINIMUM_PLUS) GRB_M(GRB_MAXIMUM_MULTIPLIES)
+  GRB_M(GRB_PLUS_DIVIDES) GRB_M(GRB_PLUS_GREATER) GRB_M(GRB_GREATER_PLUS) GRB_M(GRB_PLUS_MINUS) GRB_M(GRB_PLUS_LESS)
+  GRB_M(GRB_CUSTOM_LESS_PLUS) GRB_M(GRB_MINIMUM_MULTIPLIES) GRB_M(GRB_MULTIPLIES_MULTIPLIES) GRB_M(GRB_NOT_EQUAL_TO_PLUS)
+  GRB_M(GRB_MINIMUM_SELECT_SECOND) GRB_M(GRB_PLUS_NOT_EQUAL_TO) GRB_M(GRB_CUSTOM_LESS_LESS) GRB_M(GRB_MINIMUM_NOT_EQUAL_TO)
+#undef GRB_M
+  reg.push_back(u);
+  *id = GRB_USER_SEMIRING_BASE + (int)reg.size() - 1;
+  return GRB_SUCCESS;
+}
+
 grb_info grb_descriptor_iter_log(grb_descriptor d, grb_algo_iter* out, int cap, int* count) {
   if (!d) return GRB_UNINITIALIZED_OBJECT;
   const int k = (int)d->iter_log.size();

@@ -30,6 +30,20 @@ namespace grb {
 // Monoid-specific atomic combine into the accumulator.
 template <int M, typename T>
 __device__ inline void atomic_combine(T* addr, T v) {
+  if constexpr (M < 0) {             // a semiring registered at run time: CAS loop with its add
+    unsigned int* a = reinterpret_cast<unsigned int*>(addr);
+    unsigned int old = *a, assumed;
+    do {
+      assumed = old;
+      T cur;
+      memcpy(&cur, &assumed, 4);
+      T nv = Semiring<GRB_RUNTIME_SR, T>::add(cur, v);
+      unsigned int nb;
+      memcpy(&nb, &nv, 4);
+      old = atomicCAS(a, assumed, nb);
+    } while (old != assumed);
+    return;
+  } else {
   constexpr int op = MonoidTraits<M>::op;
   if constexpr (op == OP_PLUS) {
     atomicAdd(addr, v);
@@ -52,6 +66,7 @@ __device__ inline void atomic_combine(T* addr, T v) {
       memcpy(&nb, &nv, 4);
       old = atomicCAS(a, assumed, nb);
     } while (old != assumed);
+  }
   }
 }
 

@@ -118,6 +118,22 @@ inline X apply_op(X a, X b) {
     default: return a / b;
   }
 }
+// detail::k* -> grb_binary_op (include/grb_hip.h), for semirings composed with REGISTER_SEMIRING
+template <int OP> struct op_code;
+template <> struct op_code<kLor> { static const int value = GRB_OP_LOGICAL_OR; };
+template <> struct op_code<kLand> { static const int value = GRB_OP_LOGICAL_AND; };
+template <> struct op_code<kEq> { static const int value = GRB_OP_EQUAL; };
+template <> struct op_code<kNe> { static const int value = GRB_OP_NOT_EQUAL_TO; };
+template <> struct op_code<kGt> { static const int value = GRB_OP_GREATER; };
+template <> struct op_code<kLt> { static const int value = GRB_OP_LESS; };
+template <> struct op_code<kFirst> { static const int value = GRB_OP_FIRST; };
+template <> struct op_code<kSecond> { static const int value = GRB_OP_SECOND; };
+template <> struct op_code<kMin> { static const int value = GRB_OP_MINIMUM; };
+template <> struct op_code<kMax> { static const int value = GRB_OP_MAXIMUM; };
+template <> struct op_code<kPlus> { static const int value = GRB_OP_PLUS; };
+template <> struct op_code<kMinus> { static const int value = GRB_OP_MINUS; };
+template <> struct op_code<kTimes> { static const int value = GRB_OP_MULTIPLIES; };
+template <> struct op_code<kDiv> { static const int value = GRB_OP_DIVIDES; };
 template <typename X> inline X ident_zero() { return static_cast<X>(0); }
 template <typename X> inline X ident_one() { return static_cast<X>(1); }
 template <typename X> inline X ident_max() { return std::numeric_limits<X>::max(); }
@@ -139,6 +155,7 @@ template <typename A> inline grb_accum accum_of(const A&) {
   template <typename T_out>                                                                        \
   struct NAME {                                                                                    \
     static const int grb_id = ID;                                                                  \
+    static const int grb_op = detail::op_code<detail::OP>::value;                                  \
     inline T_out identity() const { return detail::IDENT<T_out>(); }                               \
     inline T_out operator()(T_out lhs, T_out rhs) const { return detail::apply_op<detail::OP, T_out>(lhs, rhs); } \
   };
@@ -159,6 +176,7 @@ GRB_MONOID(NotEqualToMonoid, GRB_NOT_EQUAL_TO_MONOID, kNe, ident_max)
     typedef T_out result_type;                                                                     \
     typedef T_out T_out_type;                                                                      \
     static const int grb_id = ID;                                                                  \
+    static int grb_registered_id() { return ID; }                                                  \
     inline T_out identity() const { return MONOID<T_out>().identity(); }                           \
     inline T_out add_op(T_out lhs, T_out rhs) const { return MONOID<T_out>()(lhs, rhs); }          \
     inline T_out mul_op(T_in1 lhs, T_in2 rhs) const {                                              \
@@ -183,7 +201,76 @@ GRB_SEMIRING(PlusNotEqualToSemiring, GRB_PLUS_NOT_EQUAL_TO, PlusMonoid, kNe)
 GRB_SEMIRING(CustomLessLessSemiring, GRB_CUSTOM_LESS_LESS, CustomLessMonoid, kLt)
 GRB_SEMIRING(MinimumNotEqualToSemiring, GRB_MINIMUM_NOT_EQUAL_TO, MinimumMonoid, kNe)
 #undef GRB_SEMIRING
+
+// The binary-operator functor templates of graphblas/stddef.hpp:14-138, each carrying its grb_binary_op code,
+// and the two generator macros applications use to make their own monoids and semirings (:140-191).
+#define GRB_BINARYOP(NAME, CODE, DEF1, DEF2, DEFO, EXPR)                                           \
+  template <typename T_in1 DEF1, typename T_in2 DEF2, typename T_out DEFO>                         \
+  struct NAME {                                                                                    \
+    static const int grb_op = CODE;                                                                \
+    inline T_out operator()(T_in1 lhs, T_in2 rhs) const { return static_cast<T_out>(EXPR); }       \
+  };
+#define GRB_C ,
+GRB_BINARYOP(logical_or, GRB_OP_LOGICAL_OR, = bool, = bool, = bool, lhs || rhs)
+GRB_BINARYOP(logical_and, GRB_OP_LOGICAL_AND, = bool, = bool, = bool, lhs && rhs)
+GRB_BINARYOP(logical_xor, GRB_OP_LOGICAL_XOR, = bool, = bool, = bool, (lhs && !rhs) || (!lhs && rhs))
+GRB_BINARYOP(equal, GRB_OP_EQUAL, , = T_in1, = T_in1, lhs == rhs)
+GRB_BINARYOP(not_equal_to, GRB_OP_NOT_EQUAL_TO, , = T_in1, = T_in1, lhs != rhs)
+GRB_BINARYOP(greater, GRB_OP_GREATER, , = T_in1, = bool, lhs > rhs)
+GRB_BINARYOP(less, GRB_OP_LESS, , = T_in1, = bool, lhs < rhs)
+GRB_BINARYOP(greater_equal, GRB_OP_GREATER_EQUAL, , = T_in1, = bool, lhs >= rhs)
+GRB_BINARYOP(less_equal, GRB_OP_LESS_EQUAL, , = T_in1, = bool, lhs <= rhs)
+GRB_BINARYOP(first, GRB_OP_FIRST, , = T_in1, = T_in1, lhs)
+GRB_BINARYOP(second, GRB_OP_SECOND, , = T_in1, = T_in1, rhs)
+GRB_BINARYOP(minimum, GRB_OP_MINIMUM, , = T_in1, = T_in1, lhs < rhs ? lhs : rhs)
+GRB_BINARYOP(maximum, GRB_OP_MAXIMUM, , = T_in1, = T_in1, lhs < rhs ? rhs : lhs)
+GRB_BINARYOP(plus, GRB_OP_PLUS, , = T_in1, = T_in1, lhs + rhs)
+GRB_BINARYOP(minus, GRB_OP_MINUS, , = T_in1, = T_in1, lhs - rhs)
+GRB_BINARYOP(multiplies, GRB_OP_MULTIPLIES, , = T_in1, = T_in1, lhs * rhs)
+GRB_BINARYOP(divides, GRB_OP_DIVIDES, , = T_in1, = T_in1, lhs / rhs)
+GRB_BINARYOP(select_second, GRB_OP_SECOND, , = T_in1, = T_in1, rhs)
+#undef GRB_C
+#undef GRB_BINARYOP
+
+namespace detail {
+// the C-ABI id of a semiring functor type: the enum for the 17 of stddef.hpp, a registered id for the rest
+template <typename SemiringT>
+inline grb_semiring sr_id() {
+  return static_cast<grb_semiring>(SemiringT::grb_id >= 0 ? SemiringT::grb_id : SemiringT::grb_registered_id());
+}
+}  // namespace detail
 }  // namespace graphblas
+
+// REGISTER_MONOID / REGISTER_SEMIRING (graphblas/stddef.hpp:140-191), same argument meaning: the binary operator
+// and multiply are functor templates from the list above, the identity any expression in T_out.  The composition is
+// registered with the library on first use (grb_semiring_register); it then works in vxm / mxv / eWiseAdd / eWiseMult
+// / mxm like the built-in ones.  (`reduce` takes the nine monoids of stddef.hpp only.)
+#define REGISTER_MONOID(M_NAME, BINARYOP, IDENTITY)                                                \
+  template <typename T_out>                                                                        \
+  struct M_NAME {                                                                                  \
+    static const int grb_id = -1;                                                                  \
+    static const int grb_op = BINARYOP<T_out>::grb_op;                                             \
+    inline T_out identity() const { return static_cast<T_out>(IDENTITY); }                         \
+    inline T_out operator()(T_out lhs, T_out rhs) const { return BINARYOP<T_out>()(lhs, rhs); }    \
+  };
+
+#define REGISTER_SEMIRING(SR_NAME, ADD_MONOID, MULT_BINARYOP)                                      \
+  template <typename T_in1, typename T_in2 = T_in1, typename T_out = T_in1>                        \
+  struct SR_NAME {                                                                                 \
+    typedef T_out result_type;                                                                     \
+    typedef T_out T_out_type;                                                                      \
+    static const int grb_id = -1;                                                                  \
+    static int grb_registered_id() {                                                               \
+      static int id = -1;                                                                          \
+      if (id < 0)                                                                                  \
+        grb_semiring_register(ADD_MONOID<T_out>::grb_op, static_cast<double>(ADD_MONOID<T_out>().identity()), \
+                              MULT_BINARYOP<T_in1, T_in2, T_out>::grb_op, &id);                    \
+      return id;                                                                                   \
+    }                                                                                              \
+    inline T_out identity() const { return ADD_MONOID<T_out>().identity(); }                       \
+    inline T_out add_op(T_out lhs, T_out rhs) const { return ADD_MONOID<T_out>()(lhs, rhs); }      \
+    inline T_out mul_op(T_in1 lhs, T_in2 rhs) const { return MULT_BINARYOP<T_in1, T_in2, T_out>()(lhs, rhs); } \
+  };
 
 // ------------------------------------------------------------------------------------
 // Host utilities the applications use (graphblas/util.hpp of the reference)
@@ -647,7 +734,7 @@ Info vxm(Vector<W>* w, const Vector<M>* mask, BinaryOpT accum, SemiringT op, con
          Descriptor* desc) {
   if (w == NULL || u == NULL || A == NULL || desc == NULL) return GrB_UNINITIALIZED_OBJECT;
   Descriptor* d = desc;
-  Info i = to_info(grb_vxm(GRB_H(w), GRB_H(mask), detail::accum_of(accum), static_cast<grb_semiring>(SemiringT::grb_id),
+  Info i = to_info(grb_vxm(GRB_H(w), GRB_H(mask), detail::accum_of(accum), detail::sr_id<SemiringT>(),
                            GRB_H(u), A->handle(), d->handle()));
   d->sync();
   return i;
@@ -658,7 +745,7 @@ Info mxv(Vector<W>* w, const Vector<M>* mask, BinaryOpT accum, SemiringT op, con
          Descriptor* desc) {
   if (w == NULL || u == NULL || A == NULL || desc == NULL) return GrB_UNINITIALIZED_OBJECT;
   Descriptor* d = desc;
-  Info i = to_info(grb_mxv(GRB_H(w), GRB_H(mask), detail::accum_of(accum), static_cast<grb_semiring>(SemiringT::grb_id),
+  Info i = to_info(grb_mxv(GRB_H(w), GRB_H(mask), detail::accum_of(accum), detail::sr_id<SemiringT>(),
                            A->handle(), GRB_H(u), d->handle()));
   d->sync();
   return i;
@@ -669,7 +756,7 @@ Info eWiseMult(Vector<W>* w, const Vector<M>* mask, BinaryOpT accum, SemiringT o
                const Vector<V>* v, Descriptor* desc) {
   if (w == NULL || u == NULL || v == NULL || desc == NULL) return GrB_UNINITIALIZED_OBJECT;
   return to_info(grb_eWiseMult(GRB_H(w), GRB_H(mask), detail::accum_of(accum),
-                               static_cast<grb_semiring>(SemiringT::grb_id), GRB_H(u), GRB_H(v),
+                               detail::sr_id<SemiringT>(), GRB_H(u), GRB_H(v),
                                desc->handle()));
 }
 
@@ -678,7 +765,7 @@ Info eWiseAdd(Vector<W>* w, const Vector<M>* mask, BinaryOpT accum, SemiringT op
               const Vector<V>* v, Descriptor* desc) {
   if (w == NULL || u == NULL || v == NULL || desc == NULL) return GrB_UNINITIALIZED_OBJECT;
   return to_info(grb_eWiseAdd(GRB_H(w), GRB_H(mask), detail::accum_of(accum),
-                              static_cast<grb_semiring>(SemiringT::grb_id), GRB_H(u), GRB_H(v),
+                              detail::sr_id<SemiringT>(), GRB_H(u), GRB_H(v),
                               desc->handle()));
 }
 
@@ -687,7 +774,7 @@ Info eWiseAdd(Vector<W>* w, const Vector<M>* mask, BinaryOpT accum, SemiringT op
               Descriptor* desc) {
   if (w == NULL || u == NULL || desc == NULL) return GrB_UNINITIALIZED_OBJECT;
   return to_info(grb_eWiseAdd_scalar(GRB_H(w), GRB_H(mask), detail::accum_of(accum),
-                                     static_cast<grb_semiring>(SemiringT::grb_id), GRB_H(u),
+                                     detail::sr_id<SemiringT>(), GRB_H(u),
                                      static_cast<double>(val), desc->handle()));
 }
 
@@ -802,7 +889,7 @@ Info mxm(Matrix<c>* C, const Matrix<m>* mask, BinaryOpT accum, SemiringT op, con
          Descriptor* desc) {
   if (C == NULL || A == NULL || B == NULL || desc == NULL) return GrB_UNINITIALIZED_OBJECT;
   Info i = to_info(grb_mxm(C->handle(), mask ? mask->handle() : static_cast<grb_matrix>(NULL), detail::accum_of(accum),
-                           static_cast<grb_semiring>(SemiringT::grb_id), A->handle(), B->handle(), desc->handle()));
+                           detail::sr_id<SemiringT>(), A->handle(), B->handle(), desc->handle()));
   if (i == GrB_SUCCESS) C->refresh_csr_only();
   return i;
 }
@@ -823,7 +910,7 @@ Info traceMxmTranspose(X* val, SemiringT op, const Matrix<a>* A, const Matrix<b>
   (void)op;
   if (val == NULL || A == NULL || B == NULL) return GrB_UNINITIALIZED_OBJECT;
   double d = 0;
-  Info i = to_info(grb_trace_mxm_transpose(&d, static_cast<grb_semiring>(SemiringT::grb_id), A->handle(), B->handle(),
+  Info i = to_info(grb_trace_mxm_transpose(&d, detail::sr_id<SemiringT>(), A->handle(), B->handle(),
                                            desc ? desc->handle() : static_cast<grb_descriptor>(NULL)));
   *val = static_cast<X>(d);
   return i;
@@ -854,7 +941,7 @@ Info eWiseMult(Matrix<c>* C, const Matrix<m>* mask, BinaryOpT accum, SemiringT o
   if (C == NULL || A == NULL || desc == NULL) return GrB_UNINITIALIZED_OBJECT;
   if (mask != NULL || static_cast<const void*>(C) != static_cast<const void*>(A)) return GrB_NOT_IMPLEMENTED;
   (void)accum;
-  const Info i = to_info(grb_matrix_eWiseMult_scalar(C->handle(), (grb_semiring)SemiringT::grb_id, C->handle(),
+  const Info i = to_info(grb_matrix_eWiseMult_scalar(C->handle(), detail::sr_id<SemiringT>(), C->handle(),
                                                      static_cast<double>(val)));
   if (i != GrB_SUCCESS) return i;
   return C->refresh_all();
@@ -874,7 +961,7 @@ Info eWiseMult(Matrix<c>* C, const Matrix<m>* mask, BinaryOpT accum, SemiringT o
   if (inp0 != GrB_DEFAULT) return GrB_INVALID_VALUE;
   (void)accum;
   {                                  // device path: dense B (the case of example/gpr.cu); else host below
-    const grb_info di = grb_matrix_eWiseMult_vector(C->handle(), (grb_semiring)SemiringT::grb_id, C->handle(),
+    const grb_info di = grb_matrix_eWiseMult_vector(C->handle(), detail::sr_id<SemiringT>(), C->handle(),
                                                     const_cast<Vector<b>*>(B)->handle(), desc->handle());
     if (di == GRB_SUCCESS) return C->refresh_all();
     if (di != GRB_NOT_IMPLEMENTED && di != GRB_INVALID_OBJECT) return to_info(di);

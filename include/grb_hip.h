@@ -68,9 +68,24 @@ typedef enum {
   GRB_CUSTOM_LESS_LESS, GRB_MINIMUM_NOT_EQUAL_TO, GRB_N_SEMIRINGS
 } grb_semiring;
 
+/* Binary operators, in the order graphblas/stddef.hpp:14-138 defines its functor templates
+ * (logical_or ... divides; select_second == second). */
+typedef enum {
+  GRB_OP_LOGICAL_OR = 0, GRB_OP_LOGICAL_AND, GRB_OP_LOGICAL_XOR, GRB_OP_EQUAL, GRB_OP_NOT_EQUAL_TO,
+  GRB_OP_GREATER, GRB_OP_LESS, GRB_OP_GREATER_EQUAL, GRB_OP_LESS_EQUAL, GRB_OP_FIRST, GRB_OP_SECOND,
+  GRB_OP_MINIMUM, GRB_OP_MAXIMUM, GRB_OP_PLUS, GRB_OP_MINUS, GRB_OP_MULTIPLIES, GRB_OP_DIVIDES, GRB_N_BINARY_OPS
+} grb_binary_op;
+
 /* `accum` argument: the reference only tests its presence
  * (typeid(accum).name().size() > 1, backend/cuda/spmv.hpp:34-40). */
 typedef enum { GRB_ACCUM_NULL = 0, GRB_ACCUM_PRESENT = 1 } grb_accum;
+
+/* Semirings an application registers itself -- REGISTER_SEMIRING(SR, ADD_MONOID, MULT_BINARYOP) over
+ * REGISTER_MONOID(M, BINARYOP, IDENTITY), graphblas/stddef.hpp:140-191: *id (>= 64) is accepted wherever a
+ * grb_semiring is.  A composition that is one of the 17 above runs their compiled kernels; any other runs the
+ * same kernels with the operators selected at run time. */
+grb_info grb_semiring_register(int add_op /* grb_binary_op */, double add_identity, int mul_op /* grb_binary_op */,
+                               int* id);
 
 typedef struct grb_vector_s*     grb_vector;      /* graphblas::Vector<T>   vector.hpp:12-66 */
 typedef struct grb_matrix_s*     grb_matrix;      /* graphblas::Matrix<T>   matrix.hpp:13-84 */

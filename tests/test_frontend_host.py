@@ -78,3 +78,19 @@ def test_cache_name_rule(dump_exe, tmp_path):
     (tmp_path / ".t.mtx.ud.nosl.bin").write_bytes(b"\0" * 8)
     head, name, r, c, v = run_dump(dump_exe, str(p), 0, name=True)
     assert head[3] == 0 and r.size == 0
+
+
+def test_register_semiring_macros(tmp_path):
+    """REGISTER_MONOID / REGISTER_SEMIRING of stddef.hpp:140-191 work against the drop-in header: the functors
+    evaluate on the host like the reference's, and each composition resolves to a C-ABI id >= 64 (the same id on
+    every use)."""
+    out = str(tmp_path / "user_semiring")
+    subprocess.check_call(["g++", "-std=c++11", "-O1", "-w", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "tools", "user_semiring.cpp"),
+                           "-L" + os.path.join(ROOT, "graphblast_amd"), "-lgrb_hip",
+                           "-Wl,-rpath," + os.path.join(ROOT, "graphblast_amd"), "-o", out])
+    lines = subprocess.check_output([out]).decode().split("\n")
+    ids = [int(x) for x in lines[0].split()]
+    assert ids[0] == 1 and ids[1] >= 64 and ids[2] >= 64 and ids[3] >= 64 and len(set(ids[1:])) == 3
+    assert [float(x) for x in lines[1].split()] == [0.0, 5.0, 7.0, -1000.0, 12.0]
+    assert int(lines[2]) == ids[1]
