@@ -11,7 +11,16 @@ import pytest
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BIN = os.path.join(ROOT, "build", "refcheck")
-DATA = os.path.join(ROOT, "tests", "golden", "data")
+import shutil
+import tempfile
+
+# the mains write the reference's binary cache next to the graph they load (`.<file>.<ud|d>.<nosl|sl>.bin`,
+# sparse_matrix.hpp:328-348): give them a scratch copy of the data files, not the fixtures themselves
+_SRC = os.path.join(ROOT, "tests", "golden", "data")
+DATA = tempfile.mkdtemp(prefix="grb_dropin_data_")
+for _f in os.listdir(_SRC):
+    if _f.endswith(".mtx") and not _f.startswith("."):
+        shutil.copy(os.path.join(_SRC, _f), os.path.join(DATA, _f))
 
 
 def _run(exe, *args):

@@ -617,7 +617,7 @@ def test_load_mtx_on_device(hb, tmp_path):
             assert np.array_equal(hv, val) and np.array_equal(tv, cv), path
 
     data = os.path.join(GOLDEN, "data")
-    for f in sorted(os.listdir(data)):
+    for f in sorted(x for x in os.listdir(data) if x.endswith(".mtx") and not x.startswith(".")):
         for directed in (0, 1, 2):
             check(os.path.join(data, f), np.float32, directed)
     check(os.path.join(data, "chesapeake.mtx"), np.int32, 0)
