@@ -340,6 +340,32 @@ inline void parseArgs(int argc, char** argv, po::variables_map* vm) {
 #ifndef GRB_MAXLEN
 #define GRB_MAXLEN 256
 #endif
+namespace graphblas {
+namespace detail {
+// Cache names handed out by readMtx / convert.  Matrix::build only acts on (and frees) a dat_name it finds here:
+// the reference's own test/gtrace.cu:32-36 passes an UNINITIALISED char* to build(), which the reference
+// dereferences (it works there when the stack word happens to be zero).
+inline std::vector<char*>& issued_cache_names() {
+  static std::vector<char*> v;
+  return v;
+}
+inline bool take_cache_name(char* p) {
+  std::vector<char*>& v = issued_cache_names();
+  for (size_t i = 0; i < v.size(); ++i)
+    if (v[i] == p) { v.erase(v.begin() + i); return true; }
+  return false;
+}
+}  // namespace detail
+}  // namespace graphblas
+
+// util.hpp:340-357: the binary cache's path for a .mtx path (malloc'ed, freed by Matrix::build)
+inline char* convert(const char* fname, bool is_undirected = true) {
+  char* dat_name = reinterpret_cast<char*>(malloc(GRB_MAXLEN));
+  if (grb_cache_name(fname, is_undirected, dat_name, GRB_MAXLEN) != 0) dat_name[0] = 0;
+  graphblas::detail::issued_cache_names().push_back(dat_name);
+  return dat_name;
+}
+
 template <typename X>
 inline int readMtx(const char* fname, std::vector<graphblas::Index>* row_indices,
                    std::vector<graphblas::Index>* col_indices, std::vector<X>* values, graphblas::Index* nrows,
@@ -371,8 +397,7 @@ inline int readMtx(const char* fname, std::vector<graphblas::Index>* row_indices
   bool undirected = (symmetric || directed == 2) && directed != 1;
   row_indices->clear(); col_indices->clear(); values->clear();
   if (dat_name) {
-    *dat_name = reinterpret_cast<char*>(malloc(GRB_MAXLEN));            // freed by Matrix::build, as in the reference
-    if (grb_cache_name(fname, undirected, *dat_name, GRB_MAXLEN) != 0) (*dat_name)[0] = 0;
+    *dat_name = convert(fname, undirected);                              // freed by Matrix::build, as in the reference
     FILE* c = (*dat_name)[0] ? fopen(*dat_name, "rb") : NULL;
     if (c) {                                   // empty lists tell Matrix::build that the cache exists
       fclose(c);
@@ -654,6 +679,7 @@ class Matrix {
   Info build(const std::vector<Index>* rows, const std::vector<Index>* cols, const std::vector<V>* values,
              Index nvals, BinaryOpT, char* dat_name = NULL) {
     if (!rows || !cols || !values) return GrB_NULL_POINTER;
+    if (dat_name != NULL && !detail::take_cache_name(dat_name)) dat_name = NULL;   // not a name readMtx / convert issued
     if (rows->empty() && cols->empty() && values->empty() && dat_name == NULL) return GrB_NO_VALUE;
     Info i;
     if (dat_name == NULL || !rows->empty()) {
