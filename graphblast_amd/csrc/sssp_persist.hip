@@ -43,6 +43,7 @@ struct SsspArgs {
   Index source;
   int max_niter;
   unsigned long long bail_found;    // leave the loop when a round improves more vertices than this
+  unsigned long long bail_edges;    // ... and only when they also carry more out-edges than this (a share of nnz)
   float* D[3];                      // D[0] is the result vector; all FLT_MAX, D[1][source] = 0 (host)
   unsigned int* F[4];               // F[1] has the source bit, the rest is zero (host)
   int2* big_list;
@@ -56,7 +57,7 @@ struct SsspArgs {
 };
 
 struct RoundCounters {
-  unsigned long long improved = 0, big = 0;
+  unsigned long long improved = 0, big = 0, deg = 0;   // deg: out-degree sum of the improved vertices
 };
 
 __device__ inline void relax(const SsspArgs& a, const float* Dc, float* Dn, unsigned int* Fn, float du, Index p,
@@ -70,7 +71,9 @@ __device__ inline void relax(const SsspArgs& a, const float* Dc, float* Dn, unsi
   const unsigned int old = atomicOr(&Fn[v >> 5], bit);
   if (old & bit) return;
   ++c.improved;
-  if (a.optr[v + 1] - a.optr[v] >= kSsspBig) ++c.big;
+  const Index dv = a.optr[v + 1] - a.optr[v];
+  c.deg += (unsigned long long)dv;
+  if (dv >= kSsspBig) ++c.big;
 }
 
 // Up to N edges of one vertex with their dependent steps issued stage by stage (loads, then
@@ -118,13 +121,14 @@ __device__ inline void relax_batch(const SsspArgs& a, const float* Dc, float* Dn
   for (int j = 0; j < N; ++j)
     if (d1[j] - d0[j] >= 0) {
       ++c.improved;
+      c.deg += (unsigned long long)(d1[j] - d0[j]);
       if (d1[j] - d0[j] >= kSsspBig) ++c.big;
     }
 }
 
 __global__ __launch_bounds__(kPThreads) void sssp_persistent_kernel(SsspArgs a) {
-  __shared__ unsigned long long s_red[kPWaves][2];
-  __shared__ unsigned long long s_tot[2];
+  __shared__ unsigned long long s_red[kPWaves][4];
+  __shared__ unsigned long long s_tot[4];
   __shared__ Index s_med[kSsspMedCap];
   __shared__ int s_nmed;
   const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
@@ -149,7 +153,7 @@ __global__ __launch_bounds__(kPThreads) void sssp_persistent_kernel(SsspArgs a) 
     unsigned* bcount = &st->big_count[iter & 1][0];
     for (long long i = gtid; i < nwords; i += gthreads) publish(&a.F[(iter + 2) % 4][i], 0u);
     if (gtid == 0) publish(&st->big_count[(iter + 1) & 1][0], 0u);
-    if (blockIdx.x == 0 && tid < 16) publish(&st->acc[(iter + 1) % 3][tid >> 1][tid & 1], 0ull);
+    if (blockIdx.x == 0 && tid < 32) publish(&st->acc[(iter + 1) % 3][tid >> 2][tid & 3], 0ull);
 
     // ---- bring the write buffer up to D_r where it is behind (F_(r-1) and F_r), and list
     // the big frontier vertices as 1024-edge entries when the totals announced any
@@ -237,10 +241,11 @@ __global__ __launch_bounds__(kPThreads) void sssp_persistent_kernel(SsspArgs a) 
     // ---- totals
     auto add = [](unsigned long long x, unsigned long long y) { return x + y; };
     const unsigned long long r0 = wave_reduce(c.improved, add), r1 = wave_reduce(c.big, add);
-    if (lane == 0) { s_red[wave][0] = r0; s_red[wave][1] = r1; }
+    const unsigned long long r2 = wave_reduce(c.deg, add);
+    if (lane == 0) { s_red[wave][0] = r0; s_red[wave][1] = r1; s_red[wave][2] = r2; }
     __syncthreads();
     unsigned long long* acc = &st->acc[iter % 3][0][0];
-    if (tid < 2) {
+    if (tid < 3) {
       unsigned long long t = 0;
       for (int w = 0; w < kPWaves; ++w) t += s_red[w][tid];
       if (t) __hip_atomic_fetch_add(&acc[(blockIdx.x & 7) * 16 + tid], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -248,15 +253,16 @@ __global__ __launch_bounds__(kPThreads) void sssp_persistent_kernel(SsspArgs a) 
     if (!grid_sync(&st->bar, gen, false)) return;
     if (wave == 0) {
       unsigned long long q = 0;
-      if (lane < 16) q = __hip_atomic_load(&acc[(lane >> 1) * 16 + (lane & 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      q += __shfl_xor(q, 2, kWave);
+      if (lane < 32) q = __hip_atomic_load(&acc[(lane >> 2) * 16 + (lane & 3)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       q += __shfl_xor(q, 4, kWave);
       q += __shfl_xor(q, 8, kWave);
-      if (lane < 2) s_tot[lane] = q;
+      q += __shfl_xor(q, 16, kWave);
+      if (lane < 4) s_tot[lane] = q;
     }
     __syncthreads();
     succ = s_tot[0];
     nbig = s_tot[1];
+    const unsigned long long next_edges = s_tot[2];
     __syncthreads();
     last_round = iter;
     if (a.rec && gtid == 0 && iter <= a.rec_cap) {
@@ -268,7 +274,10 @@ __global__ __launch_bounds__(kPThreads) void sssp_persistent_kernel(SsspArgs a) 
       R.reserved = 0;
     }
     if (succ == 0) break;           // f1.nvals == 0 / reduce(m) == 0, sssp.hpp:88-90
-    if (succ > a.bail_found && iter < a.max_niter) { bailed = 1; break; }   // dense frontier: hand over
+    // hand over to the op-by-op rounds (whose dense product costs about nnz) only when the next frontier is
+    // dense in EDGES: a road network's wave front can pass switchpoint * n vertices and still carry a sliver
+    // of the graph's edges -- relaxing it here costs microseconds, a pull over the whole matrix does not
+    if (succ > a.bail_found && next_edges > a.bail_edges && iter < a.max_niter) { bailed = 1; break; }
   }
 
   // the distances after the last round live in D_(last+1); the result vector is buffer 0
@@ -358,6 +367,7 @@ grb_info sssp_persistent_run(grb_vector v, grb_matrix A, grb_index source, grb_d
   a.bail_found = (f1_dense && desc->desc[GRB_MXVMODE] != GRB_PUSHONLY)
                      ? (unsigned long long)((double)desc->switchpoint * (double)n)
                      : ~0ull;
+  a.bail_edges = (unsigned long long)(A->nvals / 8);
   a.D[0] = (float*)v->d_val;
   a.D[1] = (float*)p_c;
   a.D[2] = a.D[1] + n;
