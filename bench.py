@@ -81,8 +81,182 @@ def level_bytes(levels, n):
     return out
 
 
+def other_workload(args):
+    """BASELINE.json's other configurations at their own size, one JSON line each (N = 1):
+      lj_bfs     config 2: direction-optimised BFS on soc-LiveJournal1 ($GRB_DATA) or RMAT-22 ef 16 DIRECTED
+      road_sssp  config 3: MinimumPlus SSSP on road_usa ($GRB_DATA) or a 4896^2 grid with 40 % of the edges removed
+      orkut_tc   config 5: triangle count (masked L * L^T) on com-Orkut ($GRB_DATA) or RMAT-22 ef 28 symmetrised"""
+    import torch
+    import graphblast_amd as g
+    from graphblast_amd.graphgen import rmat_edges, grid_edges, finalize_edges, random_sources
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    data = os.environ.get("GRB_DATA")
+
+    def have(name):
+        p = os.path.join(data, name + ".mtx") if data else None
+        return p if p and os.path.exists(p) else None
+    line = {"n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "data": "synthetic", "cpu_baseline": None}
+    if args.workload == "lj_bfs":
+        path = have("soc-LiveJournal1")
+        if path:
+            A = g.Matrix.from_mtx(path, directed=0)
+            n = A.nrows()
+            ptr = A.host_csr()[0]
+            nnz = int(ptr[-1])
+            line["data"] = "soc-LiveJournal1.mtx"
+        else:
+            s, d, n = rmat_edges(22, 16, seed=1, device=dev)
+            gr = finalize_edges(s, d, n, symmetrize=False)
+            tptr, tind = gr["csr"]
+            cptr, cind = gr["csc"]
+            nnz = gr["nnz"]
+            ones = torch.ones(nnz, dtype=torch.float32, device=dev)
+            A = g.Matrix(n, n)
+            assert A.build_device_csr(tptr.data_ptr(), tind.data_ptr(), ones.data_ptr(), nnz, cptr.data_ptr(),
+                                      cind.data_ptr(), ones.data_ptr(), keep=(tptr, tind, cptr, cind, ones)) == 0
+            ptr = tptr.cpu().numpy()
+        sources = [int(np.argmax(np.diff(ptr)))] + random_sources(ptr, 63, seed=0)
+        desc = g.Descriptor()
+        assert desc.loadArgs(mxvmode=0, struconly=1, opreuse=1, earlyexit=1, edgeswitch=args.edgeswitch) == 0
+        v = g.Vector(n)
+        for i in range(args.warmup):
+            g.bfs(v, A, sources[i % 64], desc, fused=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        res = [g.bfs(v, A, sources[i % 64], desc, fused=True)[1] for i in range(args.steps)]
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        ev = sum(g.bfs(v, A, sources[i % 64], desc, fused=True, profile=1)[1]["tight_ms"] for i in range(args.steps))
+        acct = {s_: g.bfs(v, A, s_, desc, fused=True, profile=3)[1]["per_level"] for s_ in set(sources[i % 64] for i in range(args.steps))}
+        tb = float(sum(sum(level_bytes(acct[sources[i % 64]], n)) for i in range(args.steps)))
+        line.update({"metric": "BFS TEPS (edges/sec), direction-optimised, directed graph of soc-LiveJournal1's size",
+                     "value": sum(r["edges_traversed"] for r in res) / el, "unit": "TEPS", "ms_per_step": el / args.steps * 1e3,
+                     "dtype": "f32", "config": {"workload": "lj_bfs" if path else "rmat22_ef16_directed_do_bfs (stand-in)",
+                                               "n": n, "nnz": nnz},
+                     "roofline": {"bound": "hbm", "kernel": "bfs_persistent_kernel", "achieved": round(tb / (ev * 1e-3) / 1e9, 2),
+                                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(tb / (ev * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                  "traffic": None, "avg_launch_ms": round(ev / args.steps, 5),
+                                  "algorithmic_bytes_per_launch": int(tb / args.steps)}})
+    elif args.workload == "road_sssp":
+        path = have("road_usa")
+        if path:
+            A0 = g.Matrix.from_mtx(path, directed=0)
+            n = A0.nrows()
+            hp, hi, _ = A0.host_csr()
+            gptr, gind = torch.as_tensor(hp).to(dev), torch.as_tensor(hi).to(dev)
+            nnz = int(hi.size)
+            del A0
+            line["data"] = "road_usa.mtx, integer weights 1..64"
+        else:
+            es, ed, n = grid_edges(4896, keep=0.6, seed=3)
+            gg = finalize_edges(torch.as_tensor(es).to(dev), torch.as_tensor(ed).to(dev), n, symmetrize=True)
+            gptr, gind = gg["csr"]
+            nnz = gg["nnz"]
+        grow = torch.repeat_interleave(torch.arange(n, device=dev, dtype=torch.int64), (gptr[1:] - gptr[:-1]).long())
+        lo, hi_ = torch.minimum(grow, gind.long()), torch.maximum(grow, gind.long())
+        gw = ((((lo * 1000003) ^ hi_) * 2654435761 >> 7) % 64 + 1).to(torch.float32)
+        del grow, lo, hi_
+        G = g.Matrix(n, n)
+        assert G.build_device_csr(gptr.data_ptr(), gind.data_ptr(), gw.data_ptr(), nnz, gptr.data_ptr(), gind.data_ptr(),
+                                  gw.data_ptr(), keep=(gptr, gind, gw)) == 0
+        hp = gptr.cpu().numpy()
+        src = int(np.nonzero(np.diff(hp))[0][len(hp) // 3])
+        desc = g.Descriptor()
+        assert desc.loadArgs(mxvmode=0, timing=0) == 0
+        v = g.Vector(n)
+        steps = max(1, min(args.steps, 3))
+        g.sssp(v, G, src, desc)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            info, res = g.sssp(v, G, src, desc)
+        torch.cuda.synchronize()
+        el = (time.perf_counter() - t0) / steps
+        d2 = g.Descriptor()
+        assert d2.loadArgs(mxvmode=0, timing=1) == 0
+        g.sssp(v, G, src, d2)
+        # per-round frontier sizes (improved vertices) of the run: algorithmic bytes per round = the push formula
+        # of BASELINE.md 3 with a weight per edge: 12 nf + 12 mf + 8 nf' (mf taken as nf x average degree)
+        from graphblast_amd import _lib as _l
+        import ctypes as _C
+
+        class It(_C.Structure):
+            _fields_ = [("iteration", _C.c_int32), ("direction", _C.c_int32), ("value", _C.c_double), ("ms", _C.c_float),
+                        ("reserved", _C.c_int32)]
+        k = _C.c_int(0)
+        _l.load().grb_descriptor_iter_log(d2._h, None, 0, _C.byref(k))
+        buf = (It * max(k.value, 1))()
+        _l.load().grb_descriptor_iter_log(d2._h, buf, k.value, _C.byref(k))
+        nfs = np.array([buf[i].value for i in range(k.value)], dtype=np.float64)
+        avgdeg = nnz / float(n)
+        alg = float(np.sum(12 * np.r_[1.0, nfs[:-1]] + 12 * avgdeg * np.r_[1.0, nfs[:-1]] + 8 * nfs))
+        line.update({"metric": "SSSP (MinimumPlus vxm) time on a road network of road_usa's size", "value": el * 1e3,
+                     "unit": "ms", "higher_is_better": False, "ms_per_step": el * 1e3, "dtype": "f32", "steps": steps,
+                     "config": {"workload": "road_sssp" if path else "grid4896_thinned_sssp (stand-in)", "n": n, "nnz": nnz,
+                                "rounds": res["iterations"], "us_per_round": round(el * 1e6 / max(res["iterations"], 1), 2)},
+                     "roofline": {"bound": "hbm", "kernel": "sssp_persistent_kernel", "achieved": round(alg / el / 1e9, 2),
+                                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg / el / 1e9 / HBM_PEAK_GBS, 5),
+                                  "traffic": None, "algorithmic_bytes_per_launch": int(alg),
+                                  "note": "per-round bytes from the recorded frontier sizes (mf = nf x average degree); the "
+                                          "launch is bound by one grid barrier + ~13 dependent memory steps per round"}})
+    else:
+        path = have("com-Orkut")
+        if path:
+            A0 = g.Matrix.from_mtx(path, dtype=np.int32, directed=0)
+            n = A0.nrows()
+            ptr, ind, _ = A0.host_csr()
+            del A0
+            line["data"] = "com-Orkut.mtx"
+        else:
+            s, d, n = rmat_edges(22, 28, seed=6, device=dev)
+            gr = finalize_edges(s, d, n, symmetrize=True)
+            ptr, ind = gr["csr"][0].cpu().numpy(), gr["csr"][1].cpu().numpy()
+            del gr, s, d
+        rows = np.repeat(np.arange(n, dtype=np.int32), np.diff(ptr))
+        keep = ind <= rows
+        lp = np.zeros(n + 1, dtype=np.int32)
+        np.cumsum(np.bincount(rows[keep], minlength=n), out=lp[1:])
+        li = ind[keep]
+        del rows, keep
+        L = g.Matrix(n, n, np.int32)
+        assert L.build_csr(lp, li, np.ones(li.size, dtype=np.int32)) == 0
+        B = g.Matrix(n, n, np.int32)
+        steps = max(1, min(args.steps, 3))
+        desc = g.Descriptor()
+        desc.loadArgs()
+        g.tc(L, B, desc)
+        ms = []
+        for _ in range(steps):
+            dd = g.Descriptor()
+            dd.loadArgs()
+            info, ntri, res = g.tc(L, B, dd)
+            assert info == 0
+            ms.append(res["tight_ms"])
+        dl = np.diff(lp).astype(np.float64)
+        erow = np.repeat(np.arange(n, dtype=np.int64), np.diff(lp))
+        # every mask entry (i, j) intersects rows i and j of L: the algorithmic bytes are both lists + the entry
+        alg = float(4.0 * (np.sum(dl * dl) + np.sum(dl[li])) + 12.0 * li.size)
+        del erow
+        t = float(np.mean(ms)) * 1e-3
+        line.update({"metric": "triangle count (masked SpGEMM L*L^T .* L) time on a graph of com-Orkut's size",
+                     "value": t * 1e3, "unit": "ms", "higher_is_better": False, "ms_per_step": t * 1e3, "dtype": "i32",
+                     "steps": steps, "config": {"workload": "orkut_tc" if path else "rmat22_ef28_sym_tc (stand-in)", "n": n,
+                                                "nnz_L": int(li.size), "triangles": int(ntri)},
+                     "roofline": {"bound": "hbm", "kernel": "spgemm_masked_kernel", "achieved": round(alg / t / 1e9, 2),
+                                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg / t / 1e9 / HBM_PEAK_GBS, 4),
+                                  "traffic": None, "algorithmic_bytes_per_launch": int(alg),
+                                  "note": "bytes = both adjacency lists of every mask entry (most are served by L2: the "
+                                          "hub lists are re-read by every neighbour)"}})
+    print(json.dumps(line))
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", default="rmat22_bfs", choices=["rmat22_bfs", "lj_bfs", "road_sssp", "orkut_tc"],
+                    help="rmat22_bfs = BASELINE.json's headline (default); the others are its configs 2, 3, 5 at their own "
+                         "size (files under $GRB_DATA when present, SURVEY 8(d) stand-ins otherwise), N = 1")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=32)
     ap.add_argument("--warmup", type=int, default=4)
@@ -103,6 +277,8 @@ def main():
     ap.add_argument("--partitioned", action="store_true",
                     help="use the 1-D partitioned level loop even at N = 1 (debugging the N > 1 path)")
     args = ap.parse_args()
+    if args.workload != "rmat22_bfs":
+        return other_workload(args)
 
     import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
