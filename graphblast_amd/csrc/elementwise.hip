@@ -254,7 +254,32 @@ __global__ __launch_bounds__(kBlock) void reduce_kernel(const T* __restrict__ d,
   auto from = [](unsigned int u) { T x; memcpy(&x, &u, 4); return x; };
   T acc = kCountNeq ? (T)0 : Mo::identity();
   int cnt = 0;
-  for (Index i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+  // 16-byte loads, two in flight per lane, where the fold may be re-associated (counting, and the monoids that
+  // are associative and commutative: plus, multiplies, minimum, maximum, logical or / and); the order-sensitive
+  // "monoids" of stddef.hpp (greater, less, not_equal_to) keep the element-per-lane stride
+  constexpr bool kWide = kCountNeq || M <= GRB_LOGICAL_AND_MONOID;
+  Index done = 0;
+  if constexpr (kWide) {
+    if ((reinterpret_cast<uintptr_t>(d) & 15u) == 0) {
+      struct alignas(16) Vec4 { T x, y, z, w; };
+      const Vec4* __restrict__ d4 = reinterpret_cast<const Vec4*>(d);
+      const Index n4 = n / 4;
+      const Index stride = (Index)gridDim.x * blockDim.x;
+      Index i = blockIdx.x * blockDim.x + threadIdx.x;
+      auto fold = [&](const Vec4& q) {
+        if constexpr (kCountNeq) cnt += (q.x != cmp) + (q.y != cmp) + (q.z != cmp) + (q.w != cmp);
+        else acc = Mo::add(Mo::add(acc, Mo::add(q.x, q.y)), Mo::add(q.z, q.w));
+      };
+      for (; i + stride < n4; i += 2 * stride) {
+        const Vec4 a = d4[i], b = d4[i + stride];
+        fold(a);
+        fold(b);
+      }
+      if (i < n4) fold(d4[i]);
+      done = n4 * 4;
+    }
+  }
+  for (Index i = done + blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const T x = d[i];
     if constexpr (kCountNeq) cnt += (x != cmp) ? 1 : 0;
     else acc = Mo::add(acc, x);
@@ -388,7 +413,33 @@ grb_info k_reduce_rows(int monoid, int dtype, const Index* ptr, const void* val,
 template <typename T>
 __global__ void assign_dense_mask_dense_kernel(T* __restrict__ w, Index n, const void* __restrict__ mask,
                                                int mask_f32, int scmp, T val) {
-  for (Index i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+  // four elements per lane with 16-byte accesses where w and the mask are aligned: one wide store when all four
+  // pass (the usual case in the drivers: masks are frontiers or their complements), single stores otherwise
+  Index done = 0;
+  if (((reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(mask)) & 15u) == 0) {
+    struct alignas(16) Vec4 { T x, y, z, w; };
+    struct alignas(16) Raw4 { unsigned int x, y, z, w; };
+    const Raw4* __restrict__ m4 = reinterpret_cast<const Raw4*>(mask);
+    Vec4* __restrict__ w4 = reinterpret_cast<Vec4*>(w);
+    const Index n4 = n / 4;
+    const bool want = scmp == 0;
+    for (Index i = blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += gridDim.x * blockDim.x) {
+      const Raw4 m = m4[i];
+      // "castable to true": value != 0; for floats -0.0f (0x80000000) is zero too
+      auto nz = [&](unsigned int u) { return mask_f32 ? ((u << 1) != 0u) : (u != 0u); };
+      const bool p0 = nz(m.x) == want, p1 = nz(m.y) == want, p2 = nz(m.z) == want, p3 = nz(m.w) == want;
+      if (p0 && p1 && p2 && p3) {
+        w4[i] = Vec4{val, val, val, val};
+      } else {
+        if (p0) w[4 * i] = val;
+        if (p1) w[4 * i + 1] = val;
+        if (p2) w[4 * i + 2] = val;
+        if (p3) w[4 * i + 3] = val;
+      }
+    }
+    done = n4 * 4;
+  }
+  for (Index i = done + blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
     if (mask_pass(mask, mask_f32, scmp, i)) w[i] = val;
 }
 template <typename T>
