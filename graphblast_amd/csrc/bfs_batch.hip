@@ -18,9 +18,10 @@
 //                    probes, then the wave finishes the row together (256 entries per step, OR-reduced
 //                    across the wave), stopping as soon as every needed bit is found.  Rows of >= 4096
 //                    entries are cut into 4096-entry slices taken by separate waves
-//   push (bits P)    frontier words with P bits expand along out-edges: atomicOr into W_L (the pull
-//                    pass has just written every word of it; zeroed when nothing is pulled), the
-//                    bits that were new go into seen with a second atomicOr
+//   push (bits P)    frontier words with P bits expand along out-edges, the edges of a wave's 64 vertices dealt
+//                    evenly to its lanes: an atomicOr into seen claims the unseen bits, a second into W_L
+//                    records them (the pull pass has just written every word of W_L; zeroed when nothing is
+//                    pulled); a streaming pass then counts the pushed bits of W_L per source
 //   labels           not written while traversing: one final pass turns the stored level words into
 //                    the k depth vectors (label[s][v] = level of discovery, source = 1, unreached =
 //                    0) with full-width coalesced stores -- no memset, no scattered 4-byte stores.
@@ -79,38 +80,51 @@ struct BatchTotals {                  // per workgroup, in LDS
   u64 v[kBatchCounters];
 };
 
-// accounting (and, beyond the stored levels, labels) of a lane's new bits; wave-collective
-__device__ inline void batch_commit(const BatchArgs& a, BatchTotals* lds, Index v, u64 newb) {
-  const u64 any = wave_or(newb);
-  if (!any) return;
+// A wave's running totals, source s in lane s: nf = (vertex, source) pairs discovered, mf = their out-degrees
+struct WaveTotals {
+  u64 nf = 0, mf = 0;
+  unsigned int verts = 0;             // wave-uniform: vertices with any new bit
+};
+
+// accounting (and, beyond the stored levels, labels) of a lane's new bits; wave-collective.  The 64 x 64 bit
+// matrix (lane = vertex, bit = source) is transposed with one ballot per live source, so lane s holds the
+// mask m of vertices new to source s: nf_s += popcount(m), and the degree sum comes from the degrees' bit
+// planes, mf_s += sum_b 2^b popcount(m & plane_b) -- all 64 sources in parallel, no per-source reduction.
+__device__ inline void batch_commit(const BatchArgs& a, WaveTotals& acc, Index v, u64 newb) {
+  const unsigned long long mv = __ballot(newb != 0);
+  if (!mv) return;
   const int lane = lane_id();
+  acc.verts += (unsigned int)__popcll(mv);
   unsigned int deg = 0;
   if (newb) deg = (unsigned int)(a.optr[v + 1] - a.optr[v]);
-  for (u64 t = any; t; t &= t - 1) {
+  u64 m = 0;
+  for (u64 t = wave_or(newb); t; t &= t - 1) {
     const int s = __builtin_amdgcn_readfirstlane(__ffsll((long long)t) - 1);   // wave-uniform: a scalar index
-    const bool bit = (newb >> s) & 1ull;
-    const unsigned long long m = __ballot(bit);
-    unsigned int dsum = bit ? deg : 0u;                   // 64 lanes x degree < 2^31
-#pragma unroll
-    for (int o = kWave / 2; o > 0; o >>= 1) dsum += __shfl_xor(dsum, o, kWave);
-    if (lane == 0) {
-      atomicAdd(&lds->v[2 + 2 * s], (u64)__popcll(m));
-      atomicAdd(&lds->v[3 + 2 * s], (u64)dsum);
-    }
-    if (a.direct_labels && bit) a.label[s][v] = a.new_label;
+    const unsigned long long col = __ballot((newb >> s) & 1ull);
+    if (lane == s) m = col;
   }
-  const unsigned long long mv = __ballot(newb != 0);
-  unsigned int du = deg;
+  acc.nf += (u64)__popcll(m);
+  unsigned int dor = deg;
 #pragma unroll
-  for (int o = kWave / 2; o > 0; o >>= 1) du += __shfl_xor(du, o, kWave);
-  if (lane == 0) { atomicAdd(&lds->v[0], (u64)__popcll(mv)); atomicAdd(&lds->v[1], (u64)du); }
+  for (int o = kWave / 2; o > 0; o >>= 1) dor |= __shfl_xor(dor, o, kWave);
+  for (unsigned int t = dor; t; t &= t - 1) {
+    const int b = __builtin_amdgcn_readfirstlane(__ffs((int)t) - 1);
+    const unsigned long long plane = __ballot((deg >> b) & 1u);
+    acc.mf += (u64)__popcll(m & plane) << b;
+  }
+  if (a.direct_labels)
+    for (u64 t = newb; t; t &= t - 1) a.label[__ffsll((long long)t) - 1][v] = a.new_label;
 }
 
 __device__ inline void totals_init(BatchTotals* lds) {
   for (int i = threadIdx.x; i < kBatchCounters; i += blockDim.x) lds->v[i] = 0;
   __syncthreads();
 }
-__device__ inline void totals_flush(const BatchArgs& a, BatchTotals* lds) {
+__device__ inline void totals_flush(const BatchArgs& a, BatchTotals* lds, const WaveTotals& acc) {
+  const int lane = lane_id();
+  if (acc.nf) atomicAdd(&lds->v[2 + 2 * lane], acc.nf);
+  if (acc.mf) atomicAdd(&lds->v[3 + 2 * lane], acc.mf);
+  if (lane == 0 && acc.verts) atomicAdd(&lds->v[0], (u64)acc.verts);
   __syncthreads();
   u64* dst = a.counters + (size_t)(blockIdx.x & (kBatchSlots - 1)) * kBatchCounters;
   for (int i = threadIdx.x; i < kBatchCounters; i += blockDim.x)
@@ -149,6 +163,7 @@ __global__ __launch_bounds__(kBlock) void batch_seed_kernel(u64* seen, u64* w0, 
 __global__ __launch_bounds__(kBlock) void batch_pull_kernel(BatchArgs a) {
   __shared__ BatchTotals lds;
   totals_init(&lds);
+  WaveTotals tot;
   const int lane = lane_id();
   const Index nchunks = (a.n + kWave - 1) / kWave;
   const Index nwaves = (Index)gridDim.x * kWavesPerBlock;
@@ -188,9 +203,9 @@ __global__ __launch_bounds__(kBlock) void batch_pull_kernel(BatchArgs a) {
       a.fnext[v] = newb;
       if (newb) a.seen[v] = seen | newb;
     }
-    batch_commit(a, &lds, valid ? v : 0, newb);
+    batch_commit(a, tot, valid ? v : 0, newb);
   }
-  totals_flush(a, &lds);
+  totals_flush(a, &lds, tot);
 }
 
 // pull, big rows: a wave per 4096-entry slice
@@ -209,6 +224,7 @@ __global__ __launch_bounds__(kBlock) void batch_pull_slices_kernel(BatchArgs a) 
 __global__ __launch_bounds__(kBlock) void batch_big_apply_kernel(BatchArgs a) {
   __shared__ BatchTotals lds;
   totals_init(&lds);
+  WaveTotals tot;
   const int nthreads = gridDim.x * blockDim.x;
   for (int base = 0; base < a.nbig; base += nthreads) {
     const int b = base + blockIdx.x * blockDim.x + threadIdx.x;
@@ -222,84 +238,120 @@ __global__ __launch_bounds__(kBlock) void batch_big_apply_kernel(BatchArgs a) {
       a.fnext[v] = newb;
       if (newb) a.seen[v] = seen | newb;
     }
-    batch_commit(a, &lds, v, newb);
+    batch_commit(a, tot, v, newb);
   }
-  totals_flush(a, &lds);
+  totals_flush(a, &lds, tot);
 }
 
-// N out-edges of a frontier vertex carrying the pushed bits fw, their dependent steps issued stage by
-// stage (targets, seen words, claims, seen updates, degrees): one chain of memory latencies per N edges
+// N out-edge slots of frontier vertices (entry q[j] < 0 = empty) carrying the pushed bits fw[j]: the dependent
+// steps are issued stage by stage (targets, seen words, the claim in seen, a fire-and-forget OR of the claimed
+// bits into fnext) -- one chain of memory latencies per N edges.  The claimed pairs are counted (and, beyond
+// the stored levels, labelled) by batch_push_commit_kernel, which reads them back from fnext in one streaming
+// pass instead of two random row-pointer reads and LDS atomics per pair here.
 template <int N>
-__device__ inline void batch_push_edges(const BatchArgs& a, BatchTotals* lds, const Index* __restrict__ ind, Index q0,
-                                        Index stride, Index end, u64 fw) {
+__device__ inline void batch_push_slots(const BatchArgs& a, const Index* __restrict__ ind, const Index (&q)[N],
+                                        const u64 (&fw)[N]) {
   Index dst[N];
   u64 bits[N];
 #pragma unroll
-  for (int j = 0; j < N; ++j) {
-    const Index q = q0 + j * stride;
-    dst[j] = q < end ? ind[q] : -1;
-  }
+  for (int j = 0; j < N; ++j) dst[j] = q[j] >= 0 ? ind[q[j]] : -1;
 #pragma unroll
-  for (int j = 0; j < N; ++j) bits[j] = dst[j] >= 0 ? (fw & ~a.seen[dst[j]]) : 0ull;
-#pragma unroll
-  for (int j = 0; j < N; ++j)
-    if (bits[j]) bits[j] &= ~atomicOr(&a.fnext[dst[j]], bits[j]);
+  for (int j = 0; j < N; ++j) bits[j] = dst[j] >= 0 ? (fw[j] & ~a.seen[dst[j]]) : 0ull;
 #pragma unroll
   for (int j = 0; j < N; ++j)
     if (bits[j]) bits[j] &= ~atomicOr(&a.seen[dst[j]], bits[j]);
 #pragma unroll
-  for (int j = 0; j < N; ++j) {
-    if (!bits[j]) continue;
-    const u64 deg = (u64)(a.optr[dst[j] + 1] - a.optr[dst[j]]);
-    for (u64 t = bits[j]; t; t &= t - 1) {
-      const int s = __ffsll((long long)t) - 1;
-      atomicAdd(&lds->v[2 + 2 * s], 1ull);
-      atomicAdd(&lds->v[3 + 2 * s], deg);
-      if (a.direct_labels) a.label[s][dst[j]] = a.new_label;
-    }
-  }
+  for (int j = 0; j < N; ++j)
+    if (bits[j]) atomicOr(&a.fnext[dst[j]], bits[j]);
 }
 
+// push, rows below kBatchBig: the out-edges of a wave's 64 vertices are laid end to end (prefix sum of the
+// degrees in LDS) and dealt to the lanes 256 at a time, so a wave pays one chain of memory latencies per 256
+// edges whatever the row lengths are
 __global__ __launch_bounds__(kBlock) void batch_push_kernel(BatchArgs a) {
-  __shared__ BatchTotals lds;
-  totals_init(&lds);
-  const int lane = lane_id();
+  __shared__ Index s_pre[kWavesPerBlock][kWave];
+  __shared__ Index s_p[kWavesPerBlock][kWave];
+  __shared__ u64 s_fw[kWavesPerBlock][kWave];
+  const int lane = lane_id(), w = wave_id();
   const Index nchunks = (a.n + kWave - 1) / kWave;
   const Index nwaves = (Index)gridDim.x * kWavesPerBlock;
-  for (Index chunk = (Index)blockIdx.x * kWavesPerBlock + wave_id(); chunk < nchunks; chunk += nwaves) {
+  for (Index chunk = (Index)blockIdx.x * kWavesPerBlock + w; chunk < nchunks; chunk += nwaves) {
     const Index u = chunk * kWave + lane;
     const u64 fw = u < a.n ? (a.fcur[u] & a.pmask) : 0ull;
     if (__ballot(fw != 0) == 0ull) continue;
     Index p = 0, e = 0;
     if (fw) { p = a.optr[u]; e = a.optr[u + 1]; }
     if (e - p >= kBatchBig) p = e;                         // the slice kernel expands it
-    if (e - p <= 8) {
-      for (; p < e; p += 4) batch_push_edges<4>(a, &lds, a.oind, p, 1, e, fw);
+    const Index d = e - p;
+    Index inc = d;
+#pragma unroll
+    for (int o = 1; o < kWave; o <<= 1) {
+      const Index t = __shfl_up(inc, o, kWave);
+      if (lane >= o) inc += t;
     }
-    u64 todo = __ballot(p < e);
-    while (todo) {
-      const int src = __ffsll((long long)todo) - 1;
-      todo &= todo - 1;
-      const Index rs = __shfl(p, src, kWave), re = __shfl(e, src, kWave);
-      const u64 w = __shfl(fw, src, kWave);
-      for (Index q = rs + lane; q < re; q += 4 * kWave) batch_push_edges<4>(a, &lds, a.oind, q, kWave, re, w);
+    const Index total = __shfl(inc, kWave - 1, kWave);
+    __builtin_amdgcn_wave_barrier();
+    s_pre[w][lane] = inc - d;
+    s_p[w][lane] = p;
+    s_fw[w][lane] = fw;
+    __builtin_amdgcn_wave_barrier();
+    for (Index base = 0; base < total; base += 4 * kWave) {
+      Index q[4];
+      u64 f[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const Index at = base + j * kWave + lane;
+        q[j] = -1; f[j] = 0ull;
+        if (at < total) {
+          int r = 0;                                       // the last row whose first edge is <= at
+#pragma unroll
+          for (int step = kWave / 2; step > 0; step >>= 1)
+            if (s_pre[w][r + step] <= at) r += step;
+          q[j] = s_p[w][r] + (at - s_pre[w][r]);
+          f[j] = s_fw[w][r];
+        }
+      }
+      batch_push_slots<4>(a, a.oind, q, f);
     }
   }
-  totals_flush(a, &lds);
 }
 
 __global__ __launch_bounds__(kBlock) void batch_push_slices_kernel(BatchArgs a) {
-  __shared__ BatchTotals lds;
-  totals_init(&lds);
   const int lane = lane_id();
   const int nwaves = gridDim.x * kWavesPerBlock;
   for (int sl = blockIdx.x * kWavesPerBlock + wave_id(); sl < a.nslices; sl += nwaves) {
     const int4 S = a.slices[sl];
     const u64 fw = a.fcur[S.x] & a.pmask;
     if (!fw) continue;
-    for (Index q = S.y + lane; q < S.z; q += 4 * kWave) batch_push_edges<4>(a, &lds, a.oind, q, kWave, S.z, fw);
+    for (Index base = S.y + lane; base < S.z; base += 4 * kWave) {
+      Index q[4];
+      u64 f[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const Index at = base + j * kWave;
+        q[j] = at < S.z ? at : -1;
+        f[j] = fw;
+      }
+      batch_push_slots<4>(a, a.oind, q, f);
+    }
   }
-  totals_flush(a, &lds);
+}
+
+// after the push kernels of a level: the pushed bits that arrived in fnext are this level's discoveries
+__global__ __launch_bounds__(kBlock) void batch_push_commit_kernel(BatchArgs a) {
+  __shared__ BatchTotals lds;
+  totals_init(&lds);
+  WaveTotals tot;
+  const int lane = lane_id();
+  const Index nchunks = (a.n + kWave - 1) / kWave;
+  const Index nwaves = (Index)gridDim.x * kWavesPerBlock;
+  for (Index chunk = (Index)blockIdx.x * kWavesPerBlock + wave_id(); chunk < nchunks; chunk += nwaves) {
+    const Index v = chunk * kWave + lane;
+    const u64 pb = v < a.n ? (a.fnext[v] & a.pmask) : 0ull;
+    if (__ballot(pb != 0) == 0ull) continue;
+    batch_commit(a, tot, pb ? v : 0, pb);
+  }
+  totals_flush(a, &lds, tot);
 }
 
 // the depth vectors from the stored level words: full 256-byte stores, every element written once
@@ -497,9 +549,12 @@ extern "C" grb_info grb_bfs_batch(grb_vector* v, int k, grb_matrix A, const grb_
                            0, st, a);
         GRB_HIP_TRY(hipGetLastError());
       }
+      hipLaunchKernelGGL(batch_push_commit_kernel, dim3(grid), dim3(kBlock), 0, st, a);
+      GRB_HIP_TRY(hipGetLastError());
     }
-    static u64 h[kBatchSlots * kBatchCounters];
-    GRB_HIP_TRY(hipMemcpyAsync(h, a.counters, sizeof(h), hipMemcpyDeviceToHost, st));
+    static u64* h = nullptr;                                 // pinned: the copy lands without a staging hop
+    if (!h) GRB_HIP_TRY(hipHostMalloc((void**)&h, sizeof(u64) * kBatchSlots * kBatchCounters, hipHostMallocDefault));
+    GRB_HIP_TRY(hipMemcpyAsync(h, a.counters, sizeof(u64) * kBatchSlots * kBatchCounters, hipMemcpyDeviceToHost, st));
     GRB_HIP_TRY(hipStreamSynchronize(st));
     u64 t[kBatchCounters];
     for (int j = 0; j < kBatchCounters; ++j) t[j] = 0;
