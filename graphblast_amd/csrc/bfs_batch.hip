@@ -15,9 +15,10 @@
 //                    level.  (A union rule makes every vertex scan its whole list for the 63 sources
 //                    that are still near their start while one hub source already floods the graph.)
 //   pull (bits Q)    a lane per vertex: need = ~seen & Q; the hinted in-neighbour first, four serial
-//                    probes, then the wave finishes the row together (256 entries per step, OR-reduced
-//                    across the wave), stopping as soon as every needed bit is found.  Rows of >= 4096
-//                    entries are cut into 4096-entry slices taken by separate waves
+//                    probes, then the wave finishes its open rows together in rounds (each row's next 32,
+//                    128, 512 ... entries laid end to end and dealt evenly to the lanes, ORed per row in
+//                    LDS), a row stopping once every needed bit is found.  Rows of >= 4096 entries are
+//                    cut into 4096-entry slices taken by separate waves
 //   push (bits P)    frontier words with P bits expand along out-edges, the edges of a wave's 64 vertices dealt
 //                    evenly to its lanes: an atomicOr into seen claims the unseen bits, a second into W_L
 //                    records them (the pull pass has just written every word of W_L; zeroed when nothing is
@@ -32,8 +33,8 @@
 
 namespace grb {
 
-constexpr int kBatchBig = 4096;       // row length from which a row is cut into slices
-constexpr int kBatchSlice = 4096;
+constexpr int kBatchBig = 4096;       // row length from which a row is cut into slices (GRB_BATCH_BIG_IN / _OUT)
+constexpr int kBatchSlice = 4096;     // pull: entries per slice, at most
 constexpr int kBatchPushSlice = 1024; // push: out-edge slices (every edge is a chain of dependent memory steps)
 constexpr int kBatchSerial = 4;       // serial probes per lane before the wave takes over
 constexpr int kBatchSlots = 16;       // counter slots (spreads same-address atomics)
@@ -50,7 +51,8 @@ struct BatchArgs {
   u64* seen;
   const u64* fcur;
   u64* fnext;
-  u64* bigacc;                        // one word per big row (pull slices OR into it)
+  int big;                            // rows of this many entries or more belong to the slice kernels
+  const u64* prev;                    // heavy push levels: seen as it stood before the push kernels (else null)
   const int4* slices;                 // {vertex, first entry, end entry, big index}
   int nslices;
   const Index* bigrows;               // the big rows' vertex ids
@@ -162,9 +164,12 @@ __global__ __launch_bounds__(kBlock) void batch_seed_kernel(u64* seen, u64* w0, 
 
 __global__ __launch_bounds__(kBlock) void batch_pull_kernel(BatchArgs a) {
   __shared__ BatchTotals lds;
+  __shared__ Index s_pre[kWavesPerBlock][kWave];
+  __shared__ Index s_p[kWavesPerBlock][kWave];
+  __shared__ u64 s_acc[kWavesPerBlock][kWave];
   totals_init(&lds);
   WaveTotals tot;
-  const int lane = lane_id();
+  const int lane = lane_id(), w = wave_id();
   const Index nchunks = (a.n + kWave - 1) / kWave;
   const Index nwaves = (Index)gridDim.x * kWavesPerBlock;
   for (Index chunk = (Index)blockIdx.x * kWavesPerBlock + wave_id(); chunk < nchunks; chunk += nwaves) {
@@ -174,10 +179,10 @@ __global__ __launch_bounds__(kBlock) void batch_pull_kernel(BatchArgs a) {
     u64 need = ~seen & a.qmask;
     Index p = 0, e = 0;
     if (need) { p = a.iptr[v]; e = a.iptr[v + 1]; }
-    const bool big = e - p >= kBatchBig;                   // the slice kernels own this row
-    if (big || p == e) need = 0;
+    const bool big = e - p >= a.big;                       // probed here, finished by the slice kernels
+    if (p == e) need = 0;
     if (__ballot(need != 0) == 0ull) {
-      if (valid && !big) a.fnext[v] = 0ull;
+      if (valid) a.fnext[v] = 0ull;
       continue;
     }
     u64 acc = 0;
@@ -189,21 +194,60 @@ __global__ __launch_bounds__(kBlock) void batch_pull_kernel(BatchArgs a) {
       const u64 w = a.fcur[go ? c : 0];
       if (go) { acc |= w; ++p; }
     }
-    u64 todo = __ballot(need && (acc & need) != need && p < e);
-    while (todo) {
-      const int src = __ffsll((long long)todo) - 1;
-      todo &= todo - 1;
-      const Index rs = __shfl(p, src, kWave), re = __shfl(e, src, kWave);
-      const u64 nd = __shfl(need & ~acc, src, kWave);
-      const u64 got = wave_scan_or(a.iind, a.fcur, rs, re, nd, lane);
-      if (lane == src) acc |= got;
+    // the rows still open finish together: round by round each takes its next `quota` entries (32, 128, 512, ...),
+    // the entries of all of them are laid end to end and dealt to the lanes 256 at a time, the gathered
+    // words are ORed per row in LDS -- full lanes whatever the row lengths, an exit test per row per round
+    Index quota = 32;
+    for (;;) {
+      const bool open = !big && need && (acc & need) != need && p < e;
+      if (__ballot(open) == 0ull) break;
+      const Index cnt = open ? (e - p < quota ? e - p : quota) : 0;
+      Index inc = cnt;
+#pragma unroll
+      for (int o = 1; o < kWave; o <<= 1) {
+        const Index t = __shfl_up(inc, o, kWave);
+        if (lane >= o) inc += t;
+      }
+      const Index total = __shfl(inc, kWave - 1, kWave);
+      __builtin_amdgcn_wave_barrier();
+      s_pre[w][lane] = inc - cnt;
+      s_p[w][lane] = p;
+      s_acc[w][lane] = 0ull;
+      __builtin_amdgcn_wave_barrier();
+      for (Index base = 0; base < total; base += 4 * kWave) {
+        Index c[4];
+        int row[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const Index at = base + j * kWave + lane;
+          c[j] = -1; row[j] = 0;
+          if (at < total) {
+            int r = 0;                                     // the last row whose first entry is <= at
+#pragma unroll
+            for (int step = kWave / 2; step > 0; step >>= 1)
+              if (s_pre[w][r + step] <= at) r += step;
+            row[j] = r;
+            c[j] = a.iind[s_p[w][r] + (at - s_pre[w][r])];
+          }
+        }
+        u64 wv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wv[j] = c[j] >= 0 ? a.fcur[c[j]] : 0ull;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (wv[j]) atomicOr(&s_acc[w][row[j]], wv[j]);
+      }
+      __builtin_amdgcn_wave_barrier();
+      acc |= s_acc[w][lane];
+      p += cnt;
+      if (quota < (1 << 20)) quota *= 4;
     }
     const u64 newb = acc & need;
-    if (valid && !big) {
-      a.fnext[v] = newb;
-      if (newb) a.seen[v] = seen | newb;
+    if (valid) {
+      a.fnext[v] = newb;                                   // a big row's probe result: the slices add to it,
+      if (newb && !big) a.seen[v] = seen | newb;           // batch_big_apply_kernel claims and counts it
     }
-    batch_commit(a, tot, valid ? v : 0, newb);
+    batch_commit(a, tot, valid ? v : 0, big ? 0ull : newb);
   }
   totals_flush(a, &lds, tot);
 }
@@ -214,10 +258,10 @@ __global__ __launch_bounds__(kBlock) void batch_pull_slices_kernel(BatchArgs a) 
   const int nwaves = gridDim.x * kWavesPerBlock;
   for (int sl = blockIdx.x * kWavesPerBlock + wave_id(); sl < a.nslices; sl += nwaves) {
     const int4 S = a.slices[sl];
-    const u64 need = ~a.seen[S.x] & a.qmask;
+    const u64 need = ~a.seen[S.x] & a.qmask & ~a.fnext[S.x];   // what the probes (and other slices) left open
     if (!need) continue;
     const u64 got = wave_scan_or(a.iind, a.fcur, S.y, S.z, need, lane) & need;
-    if (lane == 0 && got) atomicOr(&a.bigacc[S.w], got);
+    if (lane == 0 && got) atomicOr(&a.fnext[S.x], got);
   }
 }
 
@@ -233,9 +277,7 @@ __global__ __launch_bounds__(kBlock) void batch_big_apply_kernel(BatchArgs a) {
     u64 newb = 0;
     if (valid) {
       const u64 seen = a.seen[v];
-      newb = a.bigacc[b] & ~seen & a.qmask;
-      a.bigacc[b] = 0ull;
-      a.fnext[v] = newb;
+      newb = a.fnext[v] & ~seen & a.qmask;
       if (newb) a.seen[v] = seen | newb;
     }
     batch_commit(a, tot, v, newb);
@@ -257,6 +299,14 @@ __device__ inline void batch_push_slots(const BatchArgs& a, const Index* __restr
   for (int j = 0; j < N; ++j) dst[j] = q[j] >= 0 ? ind[q[j]] : -1;
 #pragma unroll
   for (int j = 0; j < N; ++j) bits[j] = dst[j] >= 0 ? (fw[j] & ~a.seen[dst[j]]) : 0ull;
+  if (a.prev) {
+    // heavy level: the claim alone, fire and forget -- one random line per edge; the commit pass finds the
+    // claimed bits as seen & ~prev
+#pragma unroll
+    for (int j = 0; j < N; ++j)
+      if (bits[j]) atomicOr(&a.seen[dst[j]], bits[j]);
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < N; ++j)
     if (bits[j]) bits[j] &= ~atomicOr(&a.seen[dst[j]], bits[j]);
@@ -281,7 +331,7 @@ __global__ __launch_bounds__(kBlock) void batch_push_kernel(BatchArgs a) {
     if (__ballot(fw != 0) == 0ull) continue;
     Index p = 0, e = 0;
     if (fw) { p = a.optr[u]; e = a.optr[u + 1]; }
-    if (e - p >= kBatchBig) p = e;                         // the slice kernel expands it
+    if (e - p >= a.big) p = e;                             // the slice kernel expands it
     const Index d = e - p;
     Index inc = d;
 #pragma unroll
@@ -347,7 +397,15 @@ __global__ __launch_bounds__(kBlock) void batch_push_commit_kernel(BatchArgs a) 
   const Index nwaves = (Index)gridDim.x * kWavesPerBlock;
   for (Index chunk = (Index)blockIdx.x * kWavesPerBlock + wave_id(); chunk < nchunks; chunk += nwaves) {
     const Index v = chunk * kWave + lane;
-    const u64 pb = v < a.n ? (a.fnext[v] & a.pmask) : 0ull;
+    u64 pb = 0;
+    if (v < a.n) {
+      if (a.prev) {
+        pb = a.seen[v] & ~a.prev[v];
+        if (pb) a.fnext[v] |= pb;
+      } else {
+        pb = a.fnext[v] & a.pmask;
+      }
+    }
     if (__ballot(pb != 0) == 0ull) continue;
     batch_commit(a, tot, pb ? v : 0, pb);
   }
@@ -393,6 +451,13 @@ __global__ void batch_unlabel_kernel(BatchArgs a, float bad) {
 using namespace grb;
 
 // rows of >= kBatchBig entries cut into slices; cached per matrix and orientation
+static int batch_big(bool in_edges) {
+  static const int big_in = getenv("GRB_BATCH_BIG_IN") ? atoi(getenv("GRB_BATCH_BIG_IN")) : kBatchBig;
+  static const int big_out = getenv("GRB_BATCH_BIG_OUT") ? atoi(getenv("GRB_BATCH_BIG_OUT")) : kBatchBig;
+  const int b = in_edges ? big_in : big_out;
+  return b < 64 ? 64 : b;
+}
+
 static grb_info ensure_slices(grb_matrix A, bool in_edges) {
   BatchSlices& B = in_edges ? A->batch_in : A->batch_out;
   if (B.ready) return GRB_SUCCESS;
@@ -403,8 +468,8 @@ static grb_info ensure_slices(grb_matrix A, bool in_edges) {
   std::vector<Index> rows;
   for (Index v = 0; v < n; ++v) {
     const Index d = ptr[(size_t)v + 1] - ptr[v];
-    if (d < kBatchBig) continue;
-    const Index step = in_edges ? kBatchSlice : kBatchPushSlice;
+    if (d < batch_big(in_edges)) continue;
+    const Index step = std::min<Index>(batch_big(in_edges), in_edges ? kBatchSlice : kBatchPushSlice);
     for (Index s = ptr[v]; s < ptr[(size_t)v + 1]; s += step)
       sl.push_back(make_int4(v, s, std::min<Index>(s + step, ptr[(size_t)v + 1]), (int)rows.size()));
     rows.push_back(v);
@@ -414,10 +479,8 @@ static grb_info ensure_slices(grb_matrix A, bool in_edges) {
   if (B.nslices > 0) {
     GRB_HIP_TRY(hipMalloc((void**)&B.d_slices, sizeof(int4) * sl.size()));
     GRB_HIP_TRY(hipMalloc((void**)&B.d_rows, sizeof(Index) * rows.size()));
-    GRB_HIP_TRY(hipMalloc((void**)&B.d_acc, sizeof(u64) * rows.size()));
     GRB_HIP_TRY(hipMemcpy(B.d_slices, sl.data(), sizeof(int4) * sl.size(), hipMemcpyHostToDevice));
     GRB_HIP_TRY(hipMemcpy(B.d_rows, rows.data(), sizeof(Index) * rows.size(), hipMemcpyHostToDevice));
-    GRB_HIP_TRY(hipMemset(B.d_acc, 0, sizeof(u64) * rows.size()));
   }
   B.ready = true;
   return GRB_SUCCESS;
@@ -447,13 +510,14 @@ extern "C" grb_info grb_bfs_batch(grb_vector* v, int k, grb_matrix A, const grb_
   int nstore = (int)((1ull << 30) / (sizeof(u64) * (size_t)(n > 0 ? n : 1)));
   if (nstore > kBatchStoreMax) nstore = kBatchStoreMax;
   if (nstore < 1) nstore = 1;
-  const int nbuf = nstore + 1 + 2 + 1;                     // W[0..nstore], X0, X1, seen
+  const int nbuf = nstore + 1 + 2 + 1 + 1;                 // W[0..nstore], X0, X1, seen, prev
   void *p_words, *p_cnt, *p_src;
   GRB_TRY(scratch(7, (size_t)nbuf * sizeof(u64) * (size_t)n + 256, &p_words));
   c.bfs_prezero_ptr = nullptr;                              // slot 7 is the one-launch traversal's pre-zeroed block
   GRB_TRY(scratch(10, sizeof(u64) * kBatchSlots * kBatchCounters, &p_cnt));
   GRB_TRY(scratch(9, sizeof(Index) * 64, &p_src));
   u64* seen = (u64*)p_words;
+  u64* prev = seen + (size_t)(nbuf - 1) * (size_t)n;
   auto W = [&](int i) -> u64* {                             // words written by level i (0 = the seeds)
     const int b = i <= nstore ? i : nstore + 1 + ((i - nstore - 1) & 1);
     return seen + (size_t)(1 + b) * (size_t)n;
@@ -489,6 +553,7 @@ extern "C" grb_info grb_bfs_batch(grb_vector* v, int k, grb_matrix A, const grb_
   bool any_left = true;
   float ms = 0.f;
   static const bool trace = getenv("GRB_BATCH_TRACE") != nullptr;
+  static const double budget = getenv("GRB_BATCH_BUDGET") ? atof(getenv("GRB_BATCH_BUDGET")) : 0.25;
   auto now_us = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   GRB_TRY(grb_timer_start());
   for (; iter <= desc->max_niter; ++iter) {
@@ -496,6 +561,7 @@ extern "C" grb_info grb_bfs_batch(grb_vector* v, int k, grb_matrix A, const grb_
     // ---- direction per source: the reference's vertex-count rule (switchpoint) on that source's own
     // frontier, and a budget on the edges pushed in one level
     u64 P = 0, Q = 0;
+    double pushed_edges = 0;
     {
       int order[64];
       int m = 0;
@@ -513,12 +579,14 @@ extern "C" grb_info grb_bfs_batch(grb_vector* v, int k, grb_matrix A, const grb_
         for (int i = 0; i < m; ++i) {
           const int s = order[i];
           bool pull = (double)nf_s[s] > (double)desc->switchpoint * (double)n;
-          if (!pull && pushed > 0.25 * (double)A->nvals) { pull = true; pushed -= (double)mf_s[s]; }
+          if (!pull && pushed > budget * (double)A->nvals) { pull = true; pushed -= (double)mf_s[s]; }
           if (pull) Q |= 1ull << s; else P |= 1ull << s;
         }
       }
     }
+    for (int s = 0; s < k; ++s) if ((P >> s) & 1ull) pushed_edges += (double)mf_s[s];
     a.qmask = Q; a.pmask = P;
+    a.prev = nullptr;
     a.fcur = W(iter - 1);
     a.fnext = W(iter);
     a.new_label = (float)(iter + 1);
@@ -526,7 +594,8 @@ extern "C" grb_info grb_bfs_batch(grb_vector* v, int k, grb_matrix A, const grb_
     GRB_HIP_TRY(hipMemsetAsync(a.counters, 0, sizeof(u64) * kBatchSlots * kBatchCounters, st));
     if (Q) {
       const BatchSlices& B = A->batch_in;
-      a.slices = B.d_slices; a.nslices = B.nslices; a.bigrows = B.d_rows; a.nbig = B.nbig; a.bigacc = B.d_acc;
+      a.big = batch_big(true);
+      a.slices = B.d_slices; a.nslices = B.nslices; a.bigrows = B.d_rows; a.nbig = B.nbig;
       hipLaunchKernelGGL(batch_pull_kernel, dim3(grid), dim3(kBlock), 0, st, a);
       GRB_HIP_TRY(hipGetLastError());
       if (B.nslices > 0) {
@@ -541,7 +610,12 @@ extern "C" grb_info grb_bfs_batch(grb_vector* v, int k, grb_matrix A, const grb_
     }
     if (P) {
       const BatchSlices& B = A->batch_out;
-      a.slices = B.d_slices; a.nslices = B.nslices; a.bigrows = B.d_rows; a.nbig = B.nbig; a.bigacc = B.d_acc;
+      a.big = batch_big(false);
+      if (pushed_edges > 0.5 * (double)n) {                 // heavy: claims only, the new bits read back against a copy
+        GRB_HIP_TRY(hipMemcpyAsync(prev, seen, sizeof(u64) * (size_t)n, hipMemcpyDeviceToDevice, st));
+        a.prev = prev;
+      }
+      a.slices = B.d_slices; a.nslices = B.nslices; a.bigrows = B.d_rows; a.nbig = B.nbig;
       hipLaunchKernelGGL(batch_push_kernel, dim3(grid), dim3(kBlock), 0, st, a);
       GRB_HIP_TRY(hipGetLastError());
       if (B.nslices > 0) {

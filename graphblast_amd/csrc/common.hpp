@@ -490,7 +490,6 @@ struct BatchSlices {
   bool ready = false;
   int4* d_slices = nullptr;      // {vertex, first entry, end entry, big index}
   Index* d_rows = nullptr;       // the big rows' vertex ids
-  unsigned long long* d_acc = nullptr;   // one word per big row, zero between levels
   int nslices = 0, nbig = 0;
 };
 // dense-core split of one orientation for the MFMA SpMM path (spmm.hip)

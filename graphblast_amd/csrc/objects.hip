@@ -782,7 +782,6 @@ void grb::matrix_release_device(grb_matrix A) {
   for (BatchSlices* b : {&A->batch_in, &A->batch_out}) {
     if (b->d_slices) (void)hipFree(b->d_slices);
     if (b->d_rows) (void)hipFree(b->d_rows);
-    if (b->d_acc) (void)hipFree(b->d_acc);
     *b = BatchSlices();
   }
   A->nonneg_values = -1;
