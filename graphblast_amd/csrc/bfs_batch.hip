@@ -34,6 +34,7 @@
 namespace grb {
 
 constexpr int kBatchBig = 4096;       // row length from which a row is cut into slices (GRB_BATCH_BIG_IN / _OUT)
+constexpr int kBatchBigPush = 512;    // the same for out-edge rows: a pushed edge costs more than a pulled one
 constexpr int kBatchSlice = 4096;     // pull: entries per slice, at most
 constexpr int kBatchPushSlice = 1024; // push: out-edge slices (every edge is a chain of dependent memory steps)
 constexpr int kBatchSerial = 4;       // serial probes per lane before the wave takes over
@@ -440,6 +441,23 @@ __global__ __launch_bounds__(kBlock) void batch_labels_kernel(LabelArgs a) {
   }
 }
 
+// the level's totals summed over the counter slots (left zero for the next level) and published to the host:
+// box[0 .. kBatchCounters) the totals, box[kBatchCounters] the level's sequence number, written last
+__global__ __launch_bounds__(kBlock) void batch_totals_kernel(u64* counters, u64* box, u64 seq) {
+  const int i = threadIdx.x;
+  if (i < kBatchCounters) {
+    u64 t = 0;
+    for (int slot = 0; slot < kBatchSlots; ++slot) {
+      t += counters[slot * kBatchCounters + i];
+      counters[slot * kBatchCounters + i] = 0ull;
+    }
+    __hip_atomic_store(&box[i], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  __threadfence_system();
+  __syncthreads();
+  if (i == 0) __hip_atomic_store(&box[kBatchCounters], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 __global__ void batch_unlabel_kernel(BatchArgs a, float bad) {
   for (int s = 0; s < a.k; ++s)
     for (Index i = blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += gridDim.x * blockDim.x)
@@ -453,7 +471,7 @@ using namespace grb;
 // rows of >= kBatchBig entries cut into slices; cached per matrix and orientation
 static int batch_big(bool in_edges) {
   static const int big_in = getenv("GRB_BATCH_BIG_IN") ? atoi(getenv("GRB_BATCH_BIG_IN")) : kBatchBig;
-  static const int big_out = getenv("GRB_BATCH_BIG_OUT") ? atoi(getenv("GRB_BATCH_BIG_OUT")) : kBatchBig;
+  static const int big_out = getenv("GRB_BATCH_BIG_OUT") ? atoi(getenv("GRB_BATCH_BIG_OUT")) : kBatchBigPush;
   const int b = in_edges ? big_in : big_out;
   return b < 64 ? 64 : b;
 }
@@ -534,6 +552,14 @@ extern "C" grb_info grb_bfs_batch(grb_vector* v, int k, grb_matrix A, const grb_
     GRB_TRY(grb_vector_set_storage(v[s], GRB_DENSE));
     a.label[s] = (float*)v[s]->d_val;
   }
+  static u64 *h_box = nullptr, *d_box = nullptr;            // {totals, sequence number}: pinned, host-coherent
+  static u64 box_seq = 0;
+  if (!h_box) {
+    GRB_HIP_TRY(hipHostMalloc((void**)&h_box, sizeof(u64) * (kBatchCounters + 1), hipHostMallocMapped | hipHostMallocCoherent));
+    memset(h_box, 0, sizeof(u64) * (kBatchCounters + 1));
+    GRB_HIP_TRY(hipHostGetDevicePointer((void**)&d_box, h_box, 0));
+  }
+  GRB_HIP_TRY(hipMemsetAsync(a.counters, 0, sizeof(u64) * kBatchSlots * kBatchCounters, st));
   GRB_HIP_TRY(hipMemsetAsync(seen, 0, 2 * sizeof(u64) * (size_t)n, st));       // seen and W[0]
   GRB_HIP_TRY(hipMemcpyAsync(p_src, sources, sizeof(Index) * (size_t)k, hipMemcpyHostToDevice, st));
   hipLaunchKernelGGL(batch_seed_kernel, dim3(1), dim3(kBlock), 0, st, seen, W(0), (const Index*)p_src, k);
@@ -553,7 +579,7 @@ extern "C" grb_info grb_bfs_batch(grb_vector* v, int k, grb_matrix A, const grb_
   bool any_left = true;
   float ms = 0.f;
   static const bool trace = getenv("GRB_BATCH_TRACE") != nullptr;
-  static const double budget = getenv("GRB_BATCH_BUDGET") ? atof(getenv("GRB_BATCH_BUDGET")) : 0.25;
+  static const double budget = getenv("GRB_BATCH_BUDGET") ? atof(getenv("GRB_BATCH_BUDGET")) : 0.15;
   auto now_us = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   GRB_TRY(grb_timer_start());
   for (; iter <= desc->max_niter; ++iter) {
@@ -570,8 +596,9 @@ extern "C" grb_info grb_bfs_batch(grb_vector* v, int k, grb_matrix A, const grb_
       else if (mode == GRB_PUSHONLY) { for (int i = 0; i < m; ++i) P |= 1ull << order[i]; }
       else {
         // pull the sources whose own frontier passed the reference's switch point (their bits are found within
-        // a few probes, so the early exit works); push the others -- unless their out-edges together exceed a
-        // quarter of the matrix, then the heaviest of them are pulled as well
+        // a few probes, so the early exit works); push the others -- unless their out-edges together exceed 0.15
+        // of the matrix (GRB_BATCH_BUDGET: a pushed edge is a random line of seen plus an atomic on it, about
+        // 50 G edges/s on RMAT-22 against 85 G/s for a pulled entry), then the heaviest of them are pulled as well
         std::sort(order, order + m, [&](int x, int y) { return mf_s[x] > mf_s[y]; });
         double pushed = 0;
         for (int i = 0; i < m; ++i)
@@ -591,7 +618,6 @@ extern "C" grb_info grb_bfs_batch(grb_vector* v, int k, grb_matrix A, const grb_
     a.fnext = W(iter);
     a.new_label = (float)(iter + 1);
     a.direct_labels = iter > nstore ? 1 : 0;
-    GRB_HIP_TRY(hipMemsetAsync(a.counters, 0, sizeof(u64) * kBatchSlots * kBatchCounters, st));
     if (Q) {
       const BatchSlices& B = A->batch_in;
       a.big = batch_big(true);
@@ -626,14 +652,21 @@ extern "C" grb_info grb_bfs_batch(grb_vector* v, int k, grb_matrix A, const grb_
       hipLaunchKernelGGL(batch_push_commit_kernel, dim3(grid), dim3(kBlock), 0, st, a);
       GRB_HIP_TRY(hipGetLastError());
     }
-    static u64* h = nullptr;                                 // pinned: the copy lands without a staging hop
-    if (!h) GRB_HIP_TRY(hipHostMalloc((void**)&h, sizeof(u64) * kBatchSlots * kBatchCounters, hipHostMallocDefault));
-    GRB_HIP_TRY(hipMemcpyAsync(h, a.counters, sizeof(u64) * kBatchSlots * kBatchCounters, hipMemcpyDeviceToHost, st));
-    GRB_HIP_TRY(hipStreamSynchronize(st));
+    // the totals come back through a pinned, host-coherent box the host polls: no copy, no stream wait
+    hipLaunchKernelGGL(batch_totals_kernel, dim3(1), dim3(kBlock), 0, st, a.counters, d_box, ++box_seq);
+    GRB_HIP_TRY(hipGetLastError());
+    {
+      const auto t0 = std::chrono::steady_clock::now();
+      unsigned spins = 0;
+      while (__atomic_load_n(&h_box[kBatchCounters], __ATOMIC_ACQUIRE) != box_seq) {
+        if ((++spins & 1023u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(5)) {
+          GRB_HIP_TRY(hipStreamSynchronize(st));               // a long level, or a fault this wait reports
+          if (__atomic_load_n(&h_box[kBatchCounters], __ATOMIC_ACQUIRE) != box_seq) return GRB_PANIC;
+        }
+      }
+    }
     u64 t[kBatchCounters];
-    for (int j = 0; j < kBatchCounters; ++j) t[j] = 0;
-    for (int i = 0; i < kBatchSlots; ++i)
-      for (int j = 0; j < kBatchCounters; ++j) t[j] += h[i * kBatchCounters + j];
+    for (int j = 0; j < kBatchCounters; ++j) t[j] = __atomic_load_n(&h_box[j], __ATOMIC_RELAXED);
     ++levels;
     last_dir = Q ? 1 : 0;
     any_left = false;
@@ -647,8 +680,9 @@ extern "C" grb_info grb_bfs_batch(grb_vector* v, int k, grb_matrix A, const grb_
       if (nf_s[s]) any_left = true;
     }
     if (trace)
-      fprintf(stderr, "batch level %d: pull %d sources, push %d -> vertices %llu pairs %llu  %.1f us\n", iter,
-              __builtin_popcountll(Q), __builtin_popcountll(P), t[0], pairs, now_us() - t_lvl);
+      fprintf(stderr, "batch level %d: pull %d sources, push %d (%.0f edges, %s) -> vertices %llu pairs %llu  %.1f us\n",
+              iter, __builtin_popcountll(Q), __builtin_popcountll(P), pushed_edges, a.prev ? "claims" : "direct", t[0],
+              pairs, now_us() - t_lvl);
     if (!any_left) break;
   }
   const bool hit_cap = iter > desc->max_niter && any_left;
