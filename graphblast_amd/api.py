@@ -553,6 +553,15 @@ def k_spmv(A, tran, op, d_u, d_mask, scmp, accum, d_w):
     return _lib.load().grb_k_spmv(_h(A), int(tran), _semiring_id(op), d_u, d_mask, int(scmp), int(accum), d_w)
 
 
+def spmv_plan_info(A, tran=0, warm=False):
+    """{"bands", "band_nnz", "pieces", "nhot"} of the SpMV plan of this orientation (grb_spmv_plan_info)."""
+    bands, nhot = C.c_int(0), C.c_int(0)
+    bn, pc = C.c_int64(0), C.c_int64(0)
+    _lib.call("grb_spmv_plan_info", _h(A), int(bool(tran)), int(bool(warm)), C.byref(bands), C.byref(bn), C.byref(pc),
+              C.byref(nhot))
+    return {"bands": bands.value, "band_nnz": bn.value, "pieces": pc.value, "nhot": nhot.value}
+
+
 def k_spmv_bytes(A, tran):
     return int(_lib.load().grb_k_spmv_bytes(_h(A), int(tran)))
 

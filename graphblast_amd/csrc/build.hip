@@ -298,6 +298,19 @@ __global__ void rank_scatter_kernel(const unsigned long long* __restrict__ keys,
 
 using namespace grb;
 
+// In-place exclusive scan of n unsigned ints on the context stream (scratch for the tile totals allocated here).
+grb_info grb::device_exclusive_scan_u32(unsigned int* d, long long n) {
+  if (n <= 0) return GRB_SUCCESS;
+  unsigned int* totals = nullptr;
+  GRB_HIP_TRY(hipMalloc((void**)&totals, 4 * (size_t)(n / kScanTile + 2)));
+  const grb_info info = exclusive_scan_u32(d, n, totals, ctx().stream);
+  const hipError_t e = hipStreamSynchronize(ctx().stream);
+  (void)hipFree(totals);
+  if (info != GRB_SUCCESS) return info;
+  GRB_HIP_TRY(e);
+  return GRB_SUCCESS;
+}
+
 // Columns ranked by reference count, entirely on the device: counts from the transposed orientation's pointer
 // array when there is one (no histogram at all), stable LSD radix sort of (0xffffffff - count, column).
 grb_info grb::device_rank_columns(const Index* d_ind, Index nvals, const Index* d_other_ptr, Index m, Index hot,

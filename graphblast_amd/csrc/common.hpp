@@ -439,6 +439,7 @@ struct SpmvPlan {         // built once per matrix orientation at build()
   Index* d_ind2 = nullptr;   // column ids renamed by descending reference count (nullptr: not renamed)
   Index* d_order = nullptr;  // [nminor] packed position -> original column
   void* d_u2 = nullptr;      // [nminor] packed copy of the input vector
+  struct SpmvBands* bands = nullptr;   // column bands with an LDS prefix each (spmv_bands.hpp); null: one prefix
 };
 
 struct CsrArrays {
@@ -589,12 +590,15 @@ grb_info build_spmv_plan(const std::vector<Index>& ptr, Index n, Index nminor, S
 void free_spmv_plan(SpmvPlan* plan);
 // build.hip: columns ranked by descending reference count on the device (d_other_ptr: the transposed
 // orientation's pointer array, whose differences ARE the counts; nullptr: histogram of d_ind)
+grb_info device_exclusive_scan_u32(unsigned int* d, long long n);   // build.hip
 grb_info device_rank_columns(const Index* d_ind, Index nvals, const Index* d_other_ptr, Index m, Index hot,
                              Index* d_order, Index* d_rank, long long* hot_refs, Index* nreferenced);
 // other_ptr: pointer array of the transposed orientation (length nminor + 1) or nullptr; only read by the
 // one-off hub-packing preparation
 grb_info k_spmv(int sr, int dtype, const CsrArrays& M, SpmvPlan& plan, const void* u,
                 const void* mask, int mask_f32, int scmp, int accum, void* w, const Index* other_ptr = nullptr);
+grb_info k_spmv_plan_info(const CsrArrays& M, SpmvPlan& plan, const Index* other_ptr, int warm, int* bands,
+                          long long* band_nnz, long long* pieces, int* nhot);
 grb_info k_spmv_masked_or(int dtype, const CsrArrays& M, const void* u, double identity,
                           const void* mask, int mask_f32, int scmp, int earlyexit, int opreuse,
                           const Index* hint /* per-row best neighbour, may be null */, void* w);

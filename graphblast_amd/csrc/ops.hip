@@ -402,6 +402,22 @@ grb_info grb_k_spmv(grb_matrix A, int tran, grb_semiring op, const void* d_u, co
                 (other.ptr && other.n == plan.nminor && !A->csc_alias) ? other.ptr : nullptr);
 }
 
+grb_info grb_spmv_plan_info(grb_matrix A, int tran, int warm, int* bands, int64_t* band_nnz, int64_t* pieces,
+                            int* nhot) {
+  if (!A || !A->built) return GRB_UNINITIALIZED_OBJECT;
+  if (!bands || !band_nnz || !pieces || !nhot) return GRB_NULL_POINTER;
+  const CsrArrays& M = tran ? A->csc : A->csr;
+  SpmvPlan& plan = tran ? A->plan_csc : A->plan_csr;
+  if (!M.ptr) return GRB_INVALID_OBJECT;
+  const CsrArrays& other = tran ? A->csr : A->csc;
+  long long bn = 0, pc = 0;
+  GRB_TRY(k_spmv_plan_info(M, plan, (other.ptr && other.n == plan.nminor && !A->csc_alias) ? other.ptr : nullptr, warm,
+                           bands, &bn, &pc, nhot));
+  *band_nnz = bn;
+  *pieces = pc;
+  return GRB_SUCCESS;
+}
+
 int64_t grb_k_spmv_bytes(grb_matrix A, int tran) {
   if (!A) return 0;
   const int64_t n = tran ? A->ncols : A->nrows;

@@ -55,6 +55,13 @@ __device__ inline V stream_load(const V* p) {
 #endif
 }
 
+template <int SR, typename T>
+__device__ inline void spmv_store(T* w, Index row, T value, const void* mask, int mask_f32, int scmp, int accum);
+
+}  // namespace grb
+#include "spmv_bands.hpp"
+namespace grb {
+
 // ---- plan ---------------------------------------------------------------------------
 template <typename V>
 static grb_info to_device(const std::vector<V>& h, V** d) {
@@ -112,6 +119,7 @@ void free_spmv_plan(SpmvPlan* plan) {
                   plan->d_ind2, plan->d_order, plan->d_u2};
   for (void* q : ptrs)
     if (q) (void)hipFree(q);
+  free_spmv_bands(plan->bands);
   *plan = SpmvPlan();
 }
 
@@ -137,6 +145,210 @@ __global__ void pack_vector_kernel(const T* __restrict__ u, const Index* __restr
                                    T* __restrict__ u2) {
   const Index i = (Index)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) u2[i] = u[order[i]];
+}
+
+// Splits the matrix by column rank into `k` bands (spmv_bands.hpp) and builds the tiles of every phase.
+// Heavy per-entry work on the device; the tile lists from the piece pointers on the host, like build_spmv_plan.
+static int spmv_band_count(Index npacked) {
+  static const int want = getenv("GRB_SPMV_BANDS") ? atoi(getenv("GRB_SPMV_BANDS")) : kMaxBands;
+  int k = (int)((npacked + kHot - 1) / kHot);
+  if (k > want) k = want;
+  if (k > kMaxBands) k = kMaxBands;
+  return k;
+}
+
+static grb_info prepare_bands(const CsrArrays& M, SpmvPlan& plan, const Index* d_rank) {
+  const Index n = plan.nrows;
+  const int k = spmv_band_count(plan.npacked);
+  const int G = ctx().num_cu * kHubPerCu;
+  if (k < 2 || n < 2 * G || (long long)M.nvals < 64ll * kWaveTile * G) return GRB_SUCCESS;   // too small to cut per workgroup
+  hipStream_t st = ctx().stream;
+  SpmvBands* B = new SpmvBands();
+  struct Guard { SpmvBands* b; ~Guard() { free_spmv_bands(b); } } guard{B};
+  std::vector<void*> temp;
+  struct TempGuard { std::vector<void*>& v; ~TempGuard() { for (void* p : v) if (p) (void)hipFree(p); } } tguard{temp};
+  auto dalloc = [&](size_t bytes, bool keep) -> void* {
+    void* p = nullptr;
+    if (hipMalloc(&p, bytes ? bytes : 4) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    (keep ? B->owned : temp).push_back(p);
+    return p;
+  };
+  const size_t nb = (size_t)(k - 1) * (size_t)n;             // (band, row) cells of the bands >= 1
+  unsigned int* cnt0 = (unsigned int*)dalloc(4 * ((size_t)n + 1), true);     // becomes the main part's row pointers
+  unsigned int* cntb = (unsigned int*)dalloc(4 * (nb + 1), false);          // becomes the band stream offsets
+  unsigned int* pid = (unsigned int*)dalloc(4 * (nb + 1), false);
+  unsigned int* flag = (unsigned int*)dalloc(4 * (nb + 1), false);
+  if (!cnt0 || !cntb || !pid || !flag) return GRB_OUT_OF_MEMORY;
+  GRB_HIP_TRY(hipMemsetAsync(cnt0 + n, 0, 4, st));
+  GRB_HIP_TRY(hipMemsetAsync(cntb + nb, 0, 4, st));
+  const int rgrid = stream_grid((long long)n * kWave, kBlock);
+  hipLaunchKernelGGL(band_count_kernel, dim3(rgrid), dim3(kBlock), 0, st, M.ptr, M.ind, d_rank, n, k, cnt0, cntb);
+  GRB_HIP_TRY(hipGetLastError());
+  hipLaunchKernelGGL(band_flags_kernel, dim3(stream_grid((long long)nb + 1, kBlock)), dim3(kBlock), 0, st,
+                     (const unsigned int*)cntb, (long long)nb + 1, flag);
+  GRB_HIP_TRY(hipMemcpyAsync(pid, flag, 4 * (nb + 1), hipMemcpyDeviceToDevice, st));
+  GRB_TRY(device_exclusive_scan_u32(cnt0, (long long)n + 1));
+  GRB_TRY(device_exclusive_scan_u32(cntb, (long long)nb + 1));
+  GRB_TRY(device_exclusive_scan_u32(pid, (long long)nb + 1));
+  unsigned int nnz0 = 0, nnzb = 0, npieces = 0;
+  GRB_HIP_TRY(hipMemcpy(&nnz0, cnt0 + n, 4, hipMemcpyDeviceToHost));
+  GRB_HIP_TRY(hipMemcpy(&nnzb, cntb + nb, 4, hipMemcpyDeviceToHost));
+  GRB_HIP_TRY(hipMemcpy(&npieces, pid + nb, 4, hipMemcpyDeviceToHost));
+  if ((long long)nnz0 + nnzb != (long long)M.nvals) return GRB_PANIC;
+  if ((long long)nnzb * 16 < (long long)M.nvals) return GRB_SUCCESS;         // the later prefixes carry < 6 %: not worth a copy
+  Index* m0_ind = (Index*)dalloc(4 * (size_t)nnz0, true);
+  unsigned int* m0_val = (unsigned int*)dalloc(4 * (size_t)nnz0, true);
+  Index* bs_ind = (Index*)dalloc(4 * (size_t)nnzb, true);
+  unsigned int* bs_val = (unsigned int*)dalloc(4 * (size_t)nnzb, true);
+  Index* piece_ptr = (Index*)dalloc(4 * ((size_t)npieces + 1), true);
+  Index* piece_row = (Index*)dalloc(4 * ((size_t)npieces + 1), true);
+  if (!m0_ind || !m0_val || !bs_ind || !bs_val || !piece_ptr || !piece_row) return GRB_OUT_OF_MEMORY;
+  hipLaunchKernelGGL(band_scatter_kernel, dim3(rgrid), dim3(kBlock), 0, st, M.ptr, M.ind, (const unsigned int*)M.val, d_rank,
+                     n, k, (const unsigned int*)cnt0, (const unsigned int*)cntb, (const unsigned int*)pid,
+                     (const unsigned int*)flag, m0_ind, m0_val, bs_ind, bs_val, piece_ptr, piece_row);
+  GRB_HIP_TRY(hipGetLastError());
+  const Index sentinel = (Index)nnzb;
+  GRB_HIP_TRY(hipMemcpyAsync(piece_ptr + npieces, &sentinel, 4, hipMemcpyHostToDevice, st));
+  GRB_HIP_TRY(hipStreamSynchronize(st));
+
+  // ---- host: the tile lists
+  std::vector<Index> ptr((size_t)n + 1), m0((size_t)n + 1), pptr((size_t)npieces + 1), prow((size_t)npieces + 1);
+  std::vector<unsigned int> band_first((size_t)k);           // first piece of band b (b >= 1), [k-1] = npieces
+  GRB_HIP_TRY(hipMemcpy(ptr.data(), M.ptr, 4 * ((size_t)n + 1), hipMemcpyDeviceToHost));
+  GRB_HIP_TRY(hipMemcpy(m0.data(), cnt0, 4 * ((size_t)n + 1), hipMemcpyDeviceToHost));
+  GRB_HIP_TRY(hipMemcpy(pptr.data(), piece_ptr, 4 * ((size_t)npieces + 1), hipMemcpyDeviceToHost));
+  if (npieces) GRB_HIP_TRY(hipMemcpy(prow.data(), piece_row, 4 * (size_t)npieces, hipMemcpyDeviceToHost));
+  for (int b = 1; b < k; ++b)
+    GRB_HIP_TRY(hipMemcpy(&band_first[b - 1], pid + (size_t)(b - 1) * n, 4, hipMemcpyDeviceToHost));
+  band_first[k - 1] = npieces;
+
+  // rows of more than a tile are sliced in every phase; the others are cut into one range per workgroup,
+  // balanced by their nonzeros
+  auto is_long = [&](Index r) { return ptr[(size_t)r + 1] - ptr[r] > kWaveTile; };
+  long long short_nnz = 0;
+  for (Index r = 0; r < n; ++r) if (!is_long(r)) short_nnz += ptr[(size_t)r + 1] - ptr[r];
+  std::vector<Index> cut((size_t)G + 1, n);
+  {
+    long long acc = 0;
+    int g = 0;
+    cut[0] = 0;
+    for (Index r = 0; r < n && g + 1 < G; ++r) {
+      if (!is_long(r)) acc += ptr[(size_t)r + 1] - ptr[r];
+      while (g + 1 < G && acc * G >= short_nnz * (long long)(g + 1)) cut[++g] = r + 1;
+    }
+  }
+  // slots of the long rows: main slices first, then band 1, ...
+  std::vector<int> long_id((size_t)n, -1), long_row, slices_of;
+  for (Index r = 0; r < n; ++r)
+    if (is_long(r)) { long_id[r] = (int)long_row.size(); long_row.push_back(r); slices_of.push_back(0); }
+  auto nslices = [](Index len) { return (int)((len + kWaveTile - 1) / kWaveTile); };
+  for (size_t i = 0; i < long_row.size(); ++i) slices_of[i] = nslices(m0[(size_t)long_row[i] + 1] - m0[long_row[i]]);
+  for (unsigned int p = 0; p < npieces; ++p)
+    if (long_id[prow[p]] >= 0) slices_of[long_id[prow[p]]] += nslices(pptr[(size_t)p + 1] - pptr[p]);
+  std::vector<int> slot_ptr(long_row.size() + 1, 0), next_slot(long_row.size());
+  for (size_t i = 0; i < long_row.size(); ++i) slot_ptr[i + 1] = slot_ptr[i] + slices_of[i];
+  for (size_t i = 0; i < long_row.size(); ++i) next_slot[i] = slot_ptr[i];
+
+  std::vector<SpmvBlock> short_t[kMaxBands], long_t[kMaxBands];
+  std::vector<int> short_lo[kMaxBands];
+  // main part: every row appears (an empty main part still has to emit t[row])
+  {
+    short_lo[0].assign((size_t)G + 1, 0);
+    for (int g = 0; g < G; ++g) {
+      short_lo[0][g] = (int)short_t[0].size();
+      Index r = cut[g];
+      while (r < cut[g + 1]) {
+        if (is_long(r)) {
+          const int li = long_id[r];
+          const Index e = m0[(size_t)r + 1];
+          for (Index s0 = m0[r]; s0 < e; s0 += kWaveTile)
+            long_t[0].push_back(SpmvBlock{r, r + 1, s0, s0 + kWaveTile < e ? s0 + kWaveTile : e, next_slot[li]++});
+          ++r;
+          continue;
+        }
+        const Index start = r;
+        Index nnz = 0;
+        while (r < cut[g + 1] && r - start < kWaveRows && !is_long(r)) {
+          const Index l = m0[(size_t)r + 1] - m0[r];
+          if (nnz + l > kWaveTile) break;
+          nnz += l;
+          ++r;
+        }
+        short_t[0].push_back(SpmvBlock{start, r, m0[start], m0[r], -1});
+      }
+    }
+    short_lo[0][G] = (int)short_t[0].size();
+  }
+  for (int b = 1; b < k; ++b) {
+    short_lo[b].assign((size_t)G + 1, 0);
+    unsigned int p = band_first[b - 1];
+    const unsigned int pe = band_first[b];
+    for (int g = 0; g < G; ++g) {
+      short_lo[b][g] = (int)short_t[b].size();
+      while (p < pe && prow[p] < cut[g + 1]) {
+        if (long_id[prow[p]] >= 0) {
+          const int li = long_id[prow[p]];
+          const Index e = pptr[(size_t)p + 1];
+          for (Index s0 = pptr[p]; s0 < e; s0 += kWaveTile)
+            long_t[b].push_back(SpmvBlock{(int)p, (int)p + 1, s0, s0 + kWaveTile < e ? s0 + kWaveTile : e, next_slot[li]++});
+          ++p;
+          continue;
+        }
+        const unsigned int start = p;
+        Index nnz = 0;
+        while (p < pe && prow[p] < cut[g + 1] && p - start < (unsigned int)kWaveRows && long_id[prow[p]] < 0) {
+          const Index l = pptr[(size_t)p + 1] - pptr[p];
+          if (nnz + l > kWaveTile) break;
+          nnz += l;
+          ++p;
+        }
+        short_t[b].push_back(SpmvBlock{(int)start, (int)p, pptr[start], pptr[p], -1});
+      }
+    }
+    short_lo[b][G] = (int)short_t[b].size();
+    if (p != pe) return GRB_PANIC;
+  }
+
+  // ---- upload
+  auto upload = [&](const void* h, size_t bytes) -> void* {
+    void* d = dalloc(bytes, true);
+    if (d && bytes && hipMemcpy(d, h, bytes, hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+    return d;
+  };
+  BandArgs& A = B->args;
+  A.k = k;
+  A.grid = G;
+  A.row_cut = (const Index*)upload(cut.data(), 4 * cut.size());
+  if (!A.row_cut) return GRB_OUT_OF_MEMORY;
+  for (int b = 0; b < k; ++b) {
+    BandPhase& P = A.ph[b];
+    P.short_tiles = (const SpmvBlock*)upload(short_t[b].data(), sizeof(SpmvBlock) * short_t[b].size());
+    P.short_lo = (const int*)upload(short_lo[b].data(), 4 * short_lo[b].size());
+    P.long_tiles = (const SpmvBlock*)upload(long_t[b].data(), sizeof(SpmvBlock) * long_t[b].size());
+    P.nlong_tiles = (int)long_t[b].size();
+    if (!P.short_tiles || !P.short_lo || !P.long_tiles) return GRB_OUT_OF_MEMORY;
+    P.ptr = b == 0 ? (const Index*)cnt0 : piece_ptr;
+    P.rowmap = b == 0 ? nullptr : piece_row;
+    P.ind = b == 0 ? m0_ind : bs_ind;
+    P.val = b == 0 ? (const void*)m0_val : (const void*)bs_val;
+    P.hot_base = (Index)b * kHot;
+    const Index left = plan.npacked - P.hot_base;
+    P.nhot = (int)(left < kHot ? (left > 0 ? left : 0) : kHot);
+  }
+  B->nlong = (int)long_row.size();
+  if (B->nlong) {
+    B->d_long_row = (int*)upload(long_row.data(), 4 * long_row.size());
+    B->d_long_slot_ptr = (int*)upload(slot_ptr.data(), 4 * slot_ptr.size());
+    B->d_partials = dalloc(4 * (size_t)slot_ptr.back(), true);
+    if (!B->d_long_row || !B->d_long_slot_ptr || !B->d_partials) return GRB_OUT_OF_MEMORY;
+  }
+  B->d_t = dalloc(4 * (size_t)n, true);
+  if (!B->d_t) return GRB_OUT_OF_MEMORY;
+  B->band_nnz = nnzb;
+  B->pieces = npieces;
+  plan.bands = B;
+  guard.b = nullptr;
+  return GRB_SUCCESS;
 }
 
 static grb_info prepare_hub_packing(const CsrArrays& M, SpmvPlan& plan, const Index* other_ptr) {
@@ -167,8 +379,14 @@ static grb_info prepare_hub_packing(const CsrArrays& M, SpmvPlan& plan, const In
   hipLaunchKernelGGL(rename_columns_kernel, dim3(stream_grid(M.nvals, kBlock)), dim3(kBlock), 0, ctx().stream,
                      M.ind, M.nvals, d_rank, plan.d_ind2);
   GRB_HIP_TRY(hipStreamSynchronize(ctx().stream));
+  // column bands: more LDS prefixes when the columns after the first still carry weight
+  const grb_info bi = prepare_bands(M, plan, d_rank);
   (void)hipFree(d_rank);
-  return GRB_SUCCESS;
+  if (bi == GRB_SUCCESS && plan.bands) {                    // the banded copy replaces the renamed column ids
+    (void)hipFree(plan.d_ind2);
+    plan.d_ind2 = nullptr;
+  }
+  return bi == GRB_OUT_OF_MEMORY ? GRB_SUCCESS : bi;        // no room for the second copy: one prefix it is
 }
 
 // Epilogue shared by the SpMV kernels: mask -> identity where the mask FAILS
@@ -364,11 +582,24 @@ grb_info k_spmv(int sr, int dtype, const CsrArrays& M, SpmvPlan& plan, const voi
     }
     const Index* ind = M.ind;
     const T* uu = (const T*)u;
-    if (plan.d_ind2) {
+    if (plan.d_ind2 || plan.bands) {
       hipLaunchKernelGGL((pack_vector_kernel<T>), dim3(ceil_div(plan.npacked, kBlock)), dim3(kBlock), 0,
                          ctx().stream, (const T*)u, plan.d_order, plan.npacked, (T*)plan.d_u2);
       ind = plan.d_ind2;
       uu = (const T*)plan.d_u2;
+    }
+    if (plan.bands) {
+      SpmvBands& B = *plan.bands;
+      hipLaunchKernelGGL((spmv_band_kernel<SR, T>), dim3(B.args.grid), dim3(kHubThreads), 0, ctx().stream, B.args, uu, mask,
+                         mask_f32, scmp, accum, (T*)w, (T*)B.d_partials, (T*)B.d_t);
+      GRB_HIP_TRY(hipGetLastError());
+      if (B.nlong) {
+        hipLaunchKernelGGL((spmv_long_finalize_kernel<SR, T>), dim3(ceil_div(B.nlong * kFinalLanes, kBlock)), dim3(kBlock),
+                           0, ctx().stream, B.d_long_row, B.d_long_slot_ptr, B.nlong, (const T*)B.d_partials, mask,
+                           mask_f32, scmp, accum, (T*)w);
+        GRB_HIP_TRY(hipGetLastError());
+      }
+      return GRB_SUCCESS;
     }
     int grid = ceil_div(plan.ntiles, kHubWaves);
     if (grid > ctx().num_cu * kHubPerCu) grid = ctx().num_cu * kHubPerCu;
@@ -384,6 +615,16 @@ grb_info k_spmv(int sr, int dtype, const CsrArrays& M, SpmvPlan& plan, const voi
     }
     return GRB_SUCCESS;
   });
+}
+
+grb_info k_spmv_plan_info(const CsrArrays& M, SpmvPlan& plan, const Index* other_ptr, int warm, int* bands,
+                          long long* band_nnz, long long* pieces, int* nhot) {
+  if (warm && M.nvals > 0 && !plan.hub_ready) GRB_TRY(prepare_hub_packing(M, plan, other_ptr));
+  *bands = plan.bands ? plan.bands->args.k : (plan.hub_ready && plan.nhot > 0 ? 1 : 0);
+  *band_nnz = plan.bands ? plan.bands->band_nnz : 0;
+  *pieces = plan.bands ? plan.bands->pieces : 0;
+  *nhot = plan.nhot;
+  return GRB_SUCCESS;
 }
 
 // ------------------------------------------------------------------------------------

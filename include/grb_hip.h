@@ -342,6 +342,13 @@ grb_info grb_spmm(grb_semiring op, grb_matrix A, int tran, const void* d_B, void
                   grb_descriptor desc);
 grb_info grb_spmm_core_info(grb_matrix A, int tran, int* ntiles, int64_t* nnz_in_tiles);
 
+/* How the generic SpMV (grb_k_spmv, the pull half of mxv / vxm) reads the input vector for this orientation:
+ * `nhot` leading values of the rank-packed vector are staged in LDS; with `bands` > 1 the matrix is also split
+ * by column rank into that many bands with an LDS prefix each (`band_nnz` entries in `pieces` (row, band) runs
+ * live outside the first prefix's part).  warm != 0 prepares the plan first (otherwise the first product
+ * does).  No reference counterpart: mgpu::SpmvCsrBinary (backend/cuda/spmv.hpp:188-190) has no plan. */
+grb_info grb_spmv_plan_info(grb_matrix A, int tran, int warm, int* bands, int64_t* band_nnz, int64_t* pieces, int* nhot);
+
 /* Batched traversals = the multi-frontier product (extension; the reference leaves sparse x dense
  * mxm a stub, backend/cuda/operations.hpp:52-70, spmm.hpp:15-27): 1 <= k <= 64 sources traversed at
  * once, one 64-bit word per vertex (bit s = source s), levels as word-wide OR.  v[s] (k dense f32
