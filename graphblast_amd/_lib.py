@@ -105,6 +105,7 @@ _SIGS = {
     "grb_semiring_register": [_i, _d, _i, C.POINTER(_i)],
     "grb_spmm": [_i, _vp, _i, _vp, _vp, _i, _vp],
     "grb_spmm_core_info": [_vp, _i, C.POINTER(_i), C.POINTER(C.c_int64)],
+    "grb_spmv_set_bands": [_i],
     "grb_spmv_plan_info": [_vp, _i, _i, C.POINTER(_i), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(_i)],
     "grb_bfs_batch": [_vp, _i, _vp, _vp, _vp, _vp],
     "grb_descriptor_iter_log": [_vp, _vp, _i, C.POINTER(_i)],

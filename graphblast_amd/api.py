@@ -553,6 +553,11 @@ def k_spmv(A, tran, op, d_u, d_mask, scmp, accum, d_w):
     return _lib.load().grb_k_spmv(_h(A), int(tran), _semiring_id(op), d_u, d_mask, int(scmp), int(accum), d_w)
 
 
+def spmv_set_bands(k=0):
+    """LDS prefixes SpMV plans prepared from now on may use (grb_spmv_set_bands); 0 only queries."""
+    return int(_lib.load().grb_spmv_set_bands(int(k)))
+
+
 def spmv_plan_info(A, tran=0, warm=False):
     """{"bands", "band_nnz", "pieces", "nhot"} of the SpMV plan of this orientation (grb_spmv_plan_info)."""
     bands, nhot = C.c_int(0), C.c_int(0)

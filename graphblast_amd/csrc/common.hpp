@@ -597,6 +597,7 @@ grb_info device_rank_columns(const Index* d_ind, Index nvals, const Index* d_oth
 // one-off hub-packing preparation
 grb_info k_spmv(int sr, int dtype, const CsrArrays& M, SpmvPlan& plan, const void* u,
                 const void* mask, int mask_f32, int scmp, int accum, void* w, const Index* other_ptr = nullptr);
+int spmv_bands_setting(int set);   // spmv.hip: 0 = query
 grb_info k_spmv_plan_info(const CsrArrays& M, SpmvPlan& plan, const Index* other_ptr, int warm, int* bands,
                           long long* band_nnz, long long* pieces, int* nhot);
 grb_info k_spmv_masked_or(int dtype, const CsrArrays& M, const void* u, double identity,

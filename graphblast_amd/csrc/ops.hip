@@ -402,6 +402,8 @@ grb_info grb_k_spmv(grb_matrix A, int tran, grb_semiring op, const void* d_u, co
                 (other.ptr && other.n == plan.nminor && !A->csc_alias) ? other.ptr : nullptr);
 }
 
+int grb_spmv_set_bands(int k) { return spmv_bands_setting(k); }
+
 grb_info grb_spmv_plan_info(grb_matrix A, int tran, int warm, int* bands, int64_t* band_nnz, int64_t* pieces,
                             int* nhot) {
   if (!A || !A->built) return GRB_UNINITIALIZED_OBJECT;

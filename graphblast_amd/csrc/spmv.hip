@@ -149,8 +149,18 @@ __global__ void pack_vector_kernel(const T* __restrict__ u, const Index* __restr
 
 // Splits the matrix by column rank into `k` bands (spmv_bands.hpp) and builds the tiles of every phase.
 // Heavy per-entry work on the device; the tile lists from the piece pointers on the host, like build_spmv_plan.
+// LDS prefixes a plan prepared from now on may use: 1 (default) = the one-prefix kernel; GRB_SPMV_BANDS or
+// grb_spmv_set_bands raise it.  Off by default: measured -7 % on RMAT-22 at 4 bands against a second copy of the
+// matrix, ~0.1 s of preparation and a different (fixed) summation order.
+static int g_spmv_bands = -1;
+int spmv_bands_setting(int set) {
+  if (g_spmv_bands < 0) g_spmv_bands = getenv("GRB_SPMV_BANDS") ? atoi(getenv("GRB_SPMV_BANDS")) : 1;
+  if (set > 0) g_spmv_bands = set > kMaxBands ? kMaxBands : set;
+  return g_spmv_bands;
+}
+
 static int spmv_band_count(Index npacked) {
-  static const int want = getenv("GRB_SPMV_BANDS") ? atoi(getenv("GRB_SPMV_BANDS")) : kMaxBands;
+  const int want = spmv_bands_setting(0);
   int k = (int)((npacked + kHot - 1) / kHot);
   if (k > want) k = want;
   if (k > kMaxBands) k = kMaxBands;

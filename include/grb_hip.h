@@ -348,6 +348,10 @@ grb_info grb_spmm_core_info(grb_matrix A, int tran, int* ntiles, int64_t* nnz_in
  * live outside the first prefix's part).  warm != 0 prepares the plan first (otherwise the first product
  * does).  No reference counterpart: mgpu::SpmvCsrBinary (backend/cuda/spmv.hpp:188-190) has no plan. */
 grb_info grb_spmv_plan_info(grb_matrix A, int tran, int warm, int* bands, int64_t* band_nnz, int64_t* pieces, int* nhot);
+/* How many LDS prefixes (column bands) SpMV plans prepared from now on may use: 1..8, 1 = the one-prefix kernel
+ * (the default; the environment variable GRB_SPMV_BANDS sets the initial value).  k <= 0 only queries.  Returns
+ * the value in force.  Plans already prepared keep their layout. */
+int grb_spmv_set_bands(int k);
 
 /* Batched traversals = the multi-frontier product (extension; the reference leaves sparse x dense
  * mxm a stub, backend/cuda/operations.hpp:52-70, spmm.hpp:15-27): 1 <= k <= 64 sources traversed at

@@ -14,6 +14,8 @@ def banded():
     import graphblast_amd as g
     from graphblast_amd.graphgen import rmat_edges, finalize_edges
     dev = torch.device("cuda", 0)
+    before = g.spmv_set_bands(0)
+    g.spmv_set_bands(8)                                    # off by default: on for this module's plans
     src, dst, n = rmat_edges(19, 16, seed=5, device=dev)
     gr = finalize_edges(src, dst, n, symmetrize=True)
     ptr, ind = gr["csr"]
@@ -26,8 +28,10 @@ def banded():
         tv = torch.from_numpy(vals).to(dev)
         A = g.Matrix(n, n)
         assert A.build_device_csr(ptr.data_ptr(), ind.data_ptr(), tv.data_ptr(), nnz, keep=(ptr, ind, tv)) == 0
+        assert g.spmv_plan_info(A, 0, warm=True)["bands"] >= 2     # the plan is prepared while the setting holds
         out["A_" + name] = A
         out["v_" + name] = vals
+    g.spmv_set_bands(before)
     return out
 
 

@@ -43,10 +43,12 @@ def run(tag, tind):
     for _ in range(20):
         g.k_spmv(A, 0, "PlusMultiplies", x.data_ptr(), None, 0, 0, y.data_ptr())
     ms = g.timer_stop() / 20
-    print("%-44s %.4f ms  %.0f GB/s algorithmic" % (tag, ms, g.k_spmv_bytes(A, 0) / ms / 1e6))
+    print("%-44s %.4f ms  %.0f GB/s algorithmic  plan %s" % (tag, ms, g.k_spmv_bytes(A, 0) / ms / 1e6, g.spmv_plan_info(A, 0)))
 
 
-run("as is (one LDS prefix)", ind)
+run("as is (GRB_SPMV_BANDS prefixes)", ind)
+if len(sys.argv) > 2 and sys.argv[2] == "first":
+    sys.exit(0)
 for k in (2, 4, 8, 16):
     fold = (rk >= H) & (rk < k * H)
     tind = torch.where(fold, order[rk % H], ind.long()).to(torch.int32).contiguous()
