@@ -72,4 +72,51 @@ __device__ inline bool grid_sync(GridBarrier* st, unsigned& gen, bool invalidate
   return s_ok != 0;
 }
 
+// The set bits of a wave's 64 bitmap words, one per lane per step.  A thread that walks its own word bit by bit
+// is fine while the frontier is a few scattered vertices; a road network's wave front fills whole words, and
+// then a handful of lanes each run 32 vertices' dependent memory chains one after the other while the rest of
+// the machine idles (measured on the 4896^2 grid: 240 us per round for 0.4 M frontier vertices).  Here the
+// wave's bits are numbered by a prefix sum over the lanes' popcounts and lane j of step t takes bit 64 t + j:
+// its word by a 6-step search of the prefix (LDS), its position in the word by 5 popcount halvings.
+// f(word_lane, bit) is called with word_lane < 0 for a lane without a bit in the last step.
+struct WaveBits {
+  int pre[kWave];
+  unsigned int word[kWave];
+};
+template <typename F>
+__device__ inline void wave_for_each_bit(WaveBits* sb, unsigned int w, int lane, F f) {
+  const int cnt = __popc(w);
+  int incl = cnt;
+#pragma unroll
+  for (int o = 1; o < kWave; o <<= 1) {
+    const int y = __shfl_up(incl, o, kWave);
+    if (lane >= o) incl += y;
+  }
+  const int total = __shfl(incl, kWave - 1, kWave);
+  if (total == 0) return;
+  __builtin_amdgcn_wave_barrier();
+  sb->pre[lane] = incl - cnt;
+  sb->word[lane] = w;
+  __builtin_amdgcn_wave_barrier();
+  for (int j0 = 0; j0 < total; j0 += kWave) {
+    const int j = j0 + lane;
+    int L = -1, bit = 0;
+    if (j < total) {
+      L = 0;
+#pragma unroll
+      for (int step = kWave / 2; step > 0; step >>= 1)
+        if (sb->pre[L + step] <= j) L += step;
+      unsigned int x = sb->word[L];
+      int k = j - sb->pre[L];                               // the k-th set bit of x (k < popc(x))
+#pragma unroll
+      for (int h = 16; h > 0; h >>= 1) {
+        const int c = __popc(x & ((1u << h) - 1u));
+        if (k >= c) { k -= c; bit += h; x >>= h; }
+      }
+    }
+    f(L, bit);
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+
 }  // namespace grb
