@@ -119,4 +119,57 @@ __device__ inline void wave_for_each_bit(WaveBits* sb, unsigned int w, int lane,
   __builtin_amdgcn_wave_barrier();
 }
 
+
+// The same over four words per lane (entry 4 L + k = word k of lane L): a pass of the kernel covers four times the
+// words, so a sparse bitmap costs a quarter of the workgroup barriers and the slowest wave of a pass matters less.
+constexpr int kBitsWords = 4;
+struct WaveBits4 {
+  int pre[kWave * kBitsWords];
+  unsigned int word[kWave * kBitsWords];
+};
+template <typename F>
+__device__ inline void wave_for_each_bit4(WaveBits4* sb, const unsigned int (&w)[kBitsWords], int lane, F f) {
+  int cnt = 0;
+#pragma unroll
+  for (int k = 0; k < kBitsWords; ++k) cnt += __popc(w[k]);
+  int incl = cnt;
+#pragma unroll
+  for (int o = 1; o < kWave; o <<= 1) {
+    const int y = __shfl_up(incl, o, kWave);
+    if (lane >= o) incl += y;
+  }
+  const int total = __shfl(incl, kWave - 1, kWave);
+  if (total == 0) return;
+  __builtin_amdgcn_wave_barrier();
+  {
+    int run = incl - cnt;
+#pragma unroll
+    for (int k = 0; k < kBitsWords; ++k) {
+      sb->pre[lane * kBitsWords + k] = run;
+      sb->word[lane * kBitsWords + k] = w[k];
+      run += __popc(w[k]);
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  for (int j0 = 0; j0 < total; j0 += kWave) {
+    const int j = j0 + lane;
+    int E = -1, bit = 0;
+    if (j < total) {
+      E = 0;
+#pragma unroll
+      for (int step = kWave * kBitsWords / 2; step > 0; step >>= 1)
+        if (sb->pre[E + step] <= j) E += step;
+      unsigned int x = sb->word[E];
+      int k = j - sb->pre[E];
+#pragma unroll
+      for (int h = 16; h > 0; h >>= 1) {
+        const int c = __popc(x & ((1u << h) - 1u));
+        if (k >= c) { k -= c; bit += h; x >>= h; }
+      }
+    }
+    f(E < 0 ? -1 : E / kBitsWords, E < 0 ? 0 : E % kBitsWords, bit);   // (lane, word of that lane, bit)
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+
 }  // namespace grb

@@ -128,6 +128,7 @@ __device__ inline void relax_batch(const SsspArgs& a, const float* Dc, float* Dn
 
 __global__ __launch_bounds__(kPThreads) void sssp_persistent_kernel(SsspArgs a) {
   __shared__ WaveBits s_bits[kPWaves];
+  __shared__ WaveBits4 s_bits4[kPWaves];
   __shared__ unsigned long long s_red[kPWaves][4];
   __shared__ unsigned long long s_tot[4];
   __shared__ Index s_med[kSsspMedCap];
@@ -197,6 +198,7 @@ __global__ __launch_bounds__(kPThreads) void sssp_persistent_kernel(SsspArgs a) 
         }
       }
     }
+    const unsigned long long t_copy = wall_clock64();
     RoundCounters c;
     if (nbig > 0) {
       if (!grid_sync(&st->bar, gen, false)) return;
@@ -212,14 +214,20 @@ __global__ __launch_bounds__(kPThreads) void sssp_persistent_kernel(SsspArgs a) 
     // ---- relax the rest of the frontier: words interleaved over the workgroups
     if (tid == 0) s_nmed = 0;
     __syncthreads();
-    for (long long base = 0; base < nwords; base += gthreads) {
-      const long long i = (base / G + tid) * G + blockIdx.x;
-      const unsigned int w = (i < nwords) ? fresh(&Fc[i]) : 0u;
-      wave_for_each_bit(&s_bits[wave], w, lane, [&](int L, int bit) {
+    for (long long base = 0; base < nwords; base += kBitsWords * gthreads) {
+      // workgroup b owns the words = b (mod G); thread tid takes four of them per pass, kPThreads apart
+      const long long q0 = base / G + tid;
+      unsigned int w[kBitsWords];
+#pragma unroll
+      for (int k = 0; k < kBitsWords; ++k) {
+        const long long i = (q0 + (long long)k * kPThreads) * G + blockIdx.x;
+        w[k] = (i < nwords) ? fresh(&Fc[i]) : 0u;
+      }
+      wave_for_each_bit4(&s_bits4[wave], w, lane, [&](int L, int k, int bit) {
         // every lane walks relax_batch together (a lane without a vertex with an empty range)
         Index v = 0, s = 0, e = 0;
         if (L >= 0) {
-          v = (Index)(i + (long long)(L - lane) * G) * 32 + bit;   // the words of a wave are G apart
+          v = (Index)((q0 + (L - lane) + (long long)k * kPThreads) * G + blockIdx.x) * 32 + bit;
           s = a.optr[v];
           e = a.optr[v + 1];
           const Index d = e - s;
@@ -246,6 +254,7 @@ __global__ __launch_bounds__(kPThreads) void sssp_persistent_kernel(SsspArgs a) 
     }
 
     // ---- totals
+    const unsigned long long t_relax = wall_clock64();
     auto add = [](unsigned long long x, unsigned long long y) { return x + y; };
     const unsigned long long r0 = wave_reduce(c.improved, add), r1 = wave_reduce(c.big, add);
     const unsigned long long r2 = wave_reduce(c.deg, add);
@@ -278,7 +287,11 @@ __global__ __launch_bounds__(kPThreads) void sssp_persistent_kernel(SsspArgs a) 
       R.direction = GRB_PUSHONLY;
       R.value = (double)succ;
       R.ms = (float)(wall_clock64() - t_round) * a.ticks_to_ms;
-      R.reserved = 0;
+      // diagnostic (workgroup 0's clock): tenths of a microsecond spent copying forward / relaxing, packed 16 : 16
+      const float to_tenth_us = a.ticks_to_ms * 1e4f;
+      const unsigned int t_a = (unsigned int)((float)(t_copy - t_round) * to_tenth_us);
+      const unsigned int t_b = (unsigned int)((float)(t_relax - t_copy) * to_tenth_us);
+      R.reserved = (int)(((t_a > 0xffffu ? 0xffffu : t_a) << 16) | (t_b > 0xffffu ? 0xffffu : t_b));
     }
     if (succ == 0) break;           // f1.nvals == 0 / reduce(m) == 0, sssp.hpp:88-90
     // hand over to the op-by-op rounds (whose dense product costs about nnz) only when the next frontier is

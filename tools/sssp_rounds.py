@@ -47,9 +47,13 @@ _lib.call("grb_descriptor_iter_log", desc._h if hasattr(desc, "_h") else desc.ha
 k = min(cnt.value, cap)
 ms = np.array([buf[i].ms for i in range(k)])
 fr = np.array([buf[i].value for i in range(k)])
+rs = np.array([buf[i].reserved for i in range(k)], dtype=np.int64) & 0xffffffff
+t_copy, t_relax = (rs >> 16) * 0.1, (rs & 0xffff) * 0.1       # us, workgroup 0's clock
 print("logged rounds %d: total %.1f ms; per round us: median %.1f mean %.1f p90 %.1f max %.1f" % (k, ms.sum(), np.median(ms) * 1e3, ms.mean() * 1e3, np.percentile(ms, 90) * 1e3, ms.max() * 1e3))
 print("improved per round: median %.0f mean %.0f max %.0f" % (np.median(fr), fr.mean(), fr.max()))
 for lo_, hi2 in ((0, 100), (100, 1000), (1000, 10000), (10000, 100000), (100000, 10**9)):
     m = (fr >= lo_) & (fr < hi2)
     if m.any():
-        print("  improved in [%d, %d): %5d rounds, mean %.1f us, share of time %.2f" % (lo_, hi2, m.sum(), ms[m].mean() * 1e3, ms[m].sum() / ms.sum()))
+        print("  improved in [%d, %d): %5d rounds, mean %.1f us (copy forward %.1f, relax %.1f, barrier + totals %.1f), share of time %.2f"
+              % (lo_, hi2, m.sum(), ms[m].mean() * 1e3, t_copy[m].mean(), t_relax[m].mean(),
+                 ms[m].mean() * 1e3 - t_copy[m].mean() - t_relax[m].mean(), ms[m].sum() / ms.sum()))
