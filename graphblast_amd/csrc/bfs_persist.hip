@@ -116,7 +116,6 @@ __global__ __launch_bounds__(kPThreads) void bfs_persistent_kernel(PersistArgs a
   __shared__ unsigned long long s_tot[4];
   __shared__ Index s_med[kMedCap];
   __shared__ int s_nmed;
-  __shared__ WaveBits s_bits[kPWaves];
   __shared__ int2 s_left[kPWaves][kPullBlock * kWave / 2];        // pull leftovers per wave: {next, end}
   __shared__ unsigned short s_leftid[kPWaves][kPullBlock * kWave / 2];
   __shared__ unsigned int s_leftfound[kPWaves][2 * kPullBlock];
@@ -291,21 +290,18 @@ __global__ __launch_bounds__(kPThreads) void bfs_persistent_kernel(PersistArgs a
         __syncthreads();
         for (long long base = 0; base < nwords; base += gthreads) {
           const long long i = (base / G + tid) * G + blockIdx.x;      // word index, stride G inside the WG
-          const unsigned int w = (i < nwords) ? fresh(&Fc[i]) : 0u;
-          // one frontier vertex per lane per step (persist_common.hpp): a wave front that fills whole words must
-          // not leave 32 vertices' chains to one lane
-          wave_for_each_bit(&s_bits[wave], w, lane, [&](int L, int bit) {
-            if (L < 0) return;
-            const Index v = (Index)(i + (long long)(L - lane) * G) * 32 + bit;   // the words of a wave are G apart
+          unsigned int w = (i < nwords) ? fresh(&Fc[i]) : 0u;
+          for (; w; w &= w - 1) {
+            const Index v = (Index)i * 32 + (__ffs((int)w) - 1);
             const Index s = a.optr[v], e = a.optr[v + 1];
             const Index d = e - s;
-            if (d >= kBigDeg) return;
+            if (d >= kBigDeg) continue;
             if (d >= kSmallDeg) {
               const int slot = atomicAdd(&s_nmed, 1);
-              if (slot < kMedCap) { s_med[slot] = v; return; }
+              if (slot < kMedCap) { s_med[slot] = v; continue; }
             }
             for (Index p = s; p < e; ++p) push_visit(a, V, Fn, a.oind[p], new_label, c);
-          });
+          }
           __syncthreads();
           const int nm = s_nmed < kMedCap ? s_nmed : kMedCap;
           for (int k = wave; k < nm; k += kPWaves) {
