@@ -553,6 +553,16 @@ def k_spmv(A, tran, op, d_u, d_mask, scmp, accum, d_w):
     return _lib.load().grb_k_spmv(_h(A), int(tran), _semiring_id(op), d_u, d_mask, int(scmp), int(accum), d_w)
 
 
+def sssp_set_nearfar(mode=-2):
+    """-1 auto (default), 0 synchronous rounds only, 1 near / far whenever eligible; -2 queries (grb_sssp_set_nearfar)."""
+    return int(_lib.load().grb_sssp_set_nearfar(int(mode)))
+
+
+def sssp_last_order():
+    """0: the last sssp() ran the reference's synchronous rounds; else the passes of the near / far order."""
+    return int(_lib.load().grb_sssp_last_order())
+
+
 def spmv_set_bands(k=0):
     """LDS prefixes SpMV plans prepared from now on may use (grb_spmv_set_bands); 0 only queries."""
     return int(_lib.load().grb_spmv_set_bands(int(k)))

@@ -528,6 +528,8 @@ struct grb_matrix_s {
   unsigned int* d_no_in_edges = nullptr;         // bitmap: CSC column empty (built lazily by bfs_fused)
   unsigned int* d_empty_csr_rows = nullptr;      // bitmap: CSR row empty (built lazily by bfs_part)
   int nonneg_values = -1;                        // -1 unknown, else whether every stored value is >= 0 (sssp_persist)
+  double mean_value = -1.0;                      // < 0 unknown (sssp_nearfar: the bucket width)
+  int small_int_values = -1;                     // -1 unknown, else whether every stored value is an integer in [0, 2^20]
   grb::Index* d_pull_hint = nullptr;                  // per vertex: its in-neighbour of largest out-degree (bfs_fused)
   grb::Index* d_oc_arena = nullptr;              // bfs_persist.hip: destination buckets of the owner-computes push (nnz entries)
   grb::BatchSlices batch_in, batch_out;          // bfs_batch.hip, built lazily
@@ -600,6 +602,10 @@ grb_info k_spmv(int sr, int dtype, const CsrArrays& M, SpmvPlan& plan, const voi
 int spmv_bands_setting(int set);   // spmv.hip: 0 = query
 grb_info k_spmv_plan_info(const CsrArrays& M, SpmvPlan& plan, const Index* other_ptr, int warm, int* bands,
                           long long* band_nnz, long long* pieces, int* nhot);
+int sssp_nearfar_setting(int set, bool apply);   // sssp_nearfar.hip
+int sssp_last_order(int set);                    // set < 0 queries
+grb_info sssp_nearfar_run(grb_vector v, grb_matrix A, grb_index source, grb_descriptor desc, int* iterations,
+                          double* succ, float* tight_ms, int* passes);   // sssp_nearfar.hip
 grb_info k_spmv_masked_or(int dtype, const CsrArrays& M, const void* u, double identity,
                           const void* mask, int mask_f32, int scmp, int earlyexit, int opreuse,
                           const Index* hint /* per-row best neighbour, may be null */, void* w);

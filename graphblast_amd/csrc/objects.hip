@@ -784,7 +784,7 @@ void grb::matrix_release_device(grb_matrix A) {
     if (b->d_rows) (void)hipFree(b->d_rows);
     *b = BatchSlices();
   }
-  A->nonneg_values = -1;
+  A->nonneg_values = -1; A->mean_value = -1.0; A->small_int_values = -1;
   free_spmm_core(&A->spmm_core_csr);
   free_spmm_core(&A->spmm_core_csc);
   free_spmv_plan(&A->plan_csr);
@@ -1004,7 +1004,7 @@ grb_info grb_matrix_set_values(grb_matrix A, const void* csr_val) {
     if (!A->csc_alias)
       GRB_HIP_TRY(hipMemcpy(A->csc.val, A->h_csc_val.data(), 4 * (size_t)A->nvals, hipMemcpyHostToDevice));
   }
-  A->nonneg_values = -1;
+  A->nonneg_values = -1; A->mean_value = -1.0; A->small_int_values = -1;
   return GRB_SUCCESS;
 }
 

@@ -403,6 +403,8 @@ grb_info grb_k_spmv(grb_matrix A, int tran, grb_semiring op, const void* d_u, co
 }
 
 int grb_spmv_set_bands(int k) { return spmv_bands_setting(k); }
+int grb_sssp_set_nearfar(int mode) { return sssp_nearfar_setting(mode, mode >= -1); }
+int grb_sssp_last_order(void) { return sssp_last_order(-1); }
 
 grb_info grb_spmv_plan_info(grb_matrix A, int tran, int warm, int* bands, int64_t* band_nnz, int64_t* pieces,
                             int* nhot) {

@@ -357,6 +357,14 @@ grb_info sssp_persistent_run(grb_vector v, grb_matrix A, grb_index source, grb_d
   }
   if (!A->nonneg_values) return GRB_NOT_IMPLEMENTED;
 
+  // road-like graphs: the work-efficient order first (sssp_nearfar.hip) -- same distances, same round count, or it
+  // declines and the rounds below run
+  {
+    const grb_info nf = sssp_nearfar_run(v, A, source, desc, iterations, succ, tight_ms, nullptr);
+    if (nf == GRB_SUCCESS) { *handed_over = false; return GRB_SUCCESS; }
+    if (nf != GRB_NOT_IMPLEMENTED) return nf;
+  }
+
   const int nwords = 2 * ceil_div(n, 64);
   static int max_per_cu = 0;
   if (!max_per_cu) {

@@ -353,6 +353,22 @@ grb_info grb_spmv_plan_info(grb_matrix A, int tran, int warm, int* bands, int64_
  * the value in force.  Plans already prepared keep their layout. */
 int grb_spmv_set_bands(int k);
 
+/* Which order grb_sssp (and algorithm::sssp through the shadow header) relaxes in on eligible matrices:
+ *   -1 (default)  the work-efficient near / far order (csrc/sssp_nearfar.hip) for graphs with fewer than 8 stored
+ *                 entries per row whose weights are small non-negative integers -- distances AND the reported round
+ *                 count are the reference's (graphblas/algorithm/sssp.hpp:53-90); everything else runs the
+ *                 reference's synchronous rounds (csrc/sssp_persist.hip);
+ *    0            always the synchronous rounds;
+ *    1            near / far whenever the matrix is f32 with non-negative weights (distances identical; with
+ *                 non-integer weights the reported round count may differ from the reference's).
+ * A run whose round count would exceed the descriptor's max_niter, or that asks for per-round records
+ * (--timing), always takes the synchronous rounds.  mode < -1 only queries.  Returns the mode in force;
+ * the environment variable GRB_SSSP_NEARFAR sets the initial value. */
+int grb_sssp_set_nearfar(int mode);
+/* 0 if the last grb_sssp of this process produced its result with the synchronous rounds, else the number of
+ * passes the near / far order took. */
+int grb_sssp_last_order(void);
+
 /* Batched traversals = the multi-frontier product (extension; the reference leaves sparse x dense
  * mxm a stub, backend/cuda/operations.hpp:52-70, spmm.hpp:15-27): 1 <= k <= 64 sources traversed at
  * once, one 64-bit word per vertex (bit s = source s), levels as word-wide OR.  v[s] (k dense f32

@@ -1,0 +1,109 @@
+"""The work-efficient order of grb_sssp (csrc/sssp_nearfar.hip) against the reference's synchronous rounds
+(csrc/sssp_persist.hip, itself pinned to the oracle in test_gpu_algorithms.py / test_gpu_golden.py): the same floats
+and the same round count, and the rounds themselves whenever the caller could tell the difference."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+FMAX = np.finfo(np.float32).max
+
+
+def _grid(side, keep, seed, weights):
+    import torch
+    import graphblast_amd as g
+    from graphblast_amd.graphgen import grid_edges, finalize_edges
+    dev = torch.device("cuda", 0)
+    es, ed, n = grid_edges(side, keep=keep, seed=seed)
+    gg = finalize_edges(torch.as_tensor(es).to(dev), torch.as_tensor(ed).to(dev), n, symmetrize=True)
+    ptr, ind = gg["csr"]
+    nnz = gg["nnz"]
+    row = torch.repeat_interleave(torch.arange(n, device=dev, dtype=torch.int64), (ptr[1:] - ptr[:-1]).long())
+    lo, hi = torch.minimum(row, ind.long()), torch.maximum(row, ind.long())
+    h = (((lo * 1000003) ^ hi) * 2654435761 >> 7) % 64 + 1                     # symmetric: a function of the edge
+    w = h.to(torch.float32) if weights == "int" else (h.to(torch.float32) * 0.37 + 0.11)
+    A = g.Matrix(n, n)
+    assert A.build_device_csr(ptr.data_ptr(), ind.data_ptr(), w.data_ptr(), nnz, ptr.data_ptr(), ind.data_ptr(),
+                              w.data_ptr(), keep=(ptr, ind, w)) == 0
+    deg = (ptr[1:] - ptr[:-1]).cpu().numpy()
+    return g, A, n, deg
+
+
+def _run(g, A, n, src, mode, max_niter=None, timing=0):
+    before = g.sssp_set_nearfar(-2)
+    g.sssp_set_nearfar(mode)
+    try:
+        d = g.Descriptor()
+        kw = dict(mxvmode=0, timing=timing)
+        if max_niter is not None:
+            kw["max_niter"] = max_niter
+        assert d.loadArgs(**kw) == 0
+        v = g.Vector(n)
+        info, res = g.sssp(v, A, src, d)
+        assert info == 0
+        return v.extractTuples()[1].copy(), res["iterations"], g.sssp_last_order()
+    finally:
+        g.sssp_set_nearfar(before)
+
+
+@pytest.mark.parametrize("side,keep,seed", [(64, 0.6, 1), (300, 0.6, 2), (700, 0.8, 3)])
+def test_integer_weights_same_distances_and_round_count(side, keep, seed):
+    g, A, n, deg = _grid(side, keep, seed, "int")
+    for src in (int(np.nonzero(deg)[0][0]), int(np.nonzero(deg)[0][len(np.nonzero(deg)[0]) // 2])):
+        d_rounds, it_rounds, o0 = _run(g, A, n, src, 0)
+        d_nf, it_nf, o1 = _run(g, A, n, src, -1)
+        assert o0 == 0 and o1 >= 1                      # the default really picked the near / far order here
+        assert np.array_equal(d_rounds, d_nf)
+        assert it_rounds == it_nf
+        assert (d_nf == FMAX).sum() > 0 or keep > 0.7   # thinned grids leave unreachable vertices: FLT_MAX, as the reference
+
+
+def test_float_weights_same_distances_when_forced():
+    """the fixed point of d[v] = min fl(d[u] + w) does not depend on the order of the relaxations"""
+    g, A, n, deg = _grid(300, 0.7, 5, "float")
+    src = int(np.nonzero(deg)[0][7])
+    d_rounds, it_rounds, o0 = _run(g, A, n, src, 0)
+    d_auto, it_auto, oa = _run(g, A, n, src, -1)
+    assert oa == 0 and np.array_equal(d_rounds, d_auto) and it_auto == it_rounds      # not small integers: the rounds run
+    d_nf, it_nf, o1 = _run(g, A, n, src, 1)
+    assert o1 >= 1
+    assert np.array_equal(d_rounds, d_nf)
+
+
+def test_a_cap_or_a_round_log_takes_the_rounds():
+    g, A, n, deg = _grid(200, 0.7, 7, "int")
+    src = int(np.nonzero(deg)[0][0])
+    d_full, it_full, _ = _run(g, A, n, src, 0)
+    cap = it_full // 2
+    d_cap_rounds, it_cap_rounds, _ = _run(g, A, n, src, 0, max_niter=cap)
+    d_cap_auto, it_cap_auto, o = _run(g, A, n, src, -1, max_niter=cap)
+    assert o == 0                                        # the fixed point said "cut off": the rounds produced the answer
+    assert np.array_equal(d_cap_rounds, d_cap_auto) and it_cap_rounds == it_cap_auto
+    assert not np.array_equal(d_cap_rounds, d_full)
+    # exactly enough rounds: still the near / far order
+    d_eq, it_eq, o = _run(g, A, n, src, -1, max_niter=it_full)
+    assert o >= 1 and it_eq == it_full and np.array_equal(d_eq, d_full)
+    # per-round records requested: the rounds
+    _, _, o = _run(g, A, n, src, -1, timing=1)
+    assert o == 0
+
+
+def test_dense_graphs_keep_the_rounds_by_default_and_agree_when_forced():
+    import torch
+    import graphblast_amd as g
+    from graphblast_amd.graphgen import rmat_edges, finalize_edges
+    dev = torch.device("cuda", 0)
+    s, d, n = rmat_edges(14, 16, seed=3, device=dev)
+    gr = finalize_edges(s, d, n, symmetrize=True)
+    ptr, ind = gr["csr"]
+    nnz = gr["nnz"]
+    row = torch.repeat_interleave(torch.arange(n, device=dev, dtype=torch.int64), (ptr[1:] - ptr[:-1]).long())
+    lo, hi = torch.minimum(row, ind.long()), torch.maximum(row, ind.long())
+    w = ((((lo * 1000003) ^ hi) * 2654435761 >> 7) % 16 + 1).to(torch.float32)
+    A = g.Matrix(n, n)
+    assert A.build_device_csr(ptr.data_ptr(), ind.data_ptr(), w.data_ptr(), nnz, ptr.data_ptr(), ind.data_ptr(), w.data_ptr(),
+                              keep=(ptr, ind, w)) == 0
+    src = int(torch.argmax(ptr[1:] - ptr[:-1]))          # a hub: the whole-wave expansion of wide vertices
+    d0, it0, o0 = _run(g, A, n, src, -1)
+    assert o0 == 0                                       # 30 entries per row: not road-like
+    d1, it1, o1 = _run(g, A, n, src, 1)
+    assert o1 >= 1 and np.array_equal(d0, d1) and it0 == it1
