@@ -204,7 +204,12 @@ __global__ __launch_bounds__(kPThreads) void sssp_nearfar_kernel(NfArgs a) {
     __syncthreads();
     // vertices made dirty in this pass may be near or far: only "nothing expanded, nothing dirty" is the end
     if (t_expanded == 0 && t_far == 0 && t_made == 0) { converged = 1; break; }
-    if (t_expanded == 0 && t_made == 0 && t_minfar != 0xffffffffu) T = __uint_as_float(t_minfar) + a.delta;
+    if (t_expanded == 0 && t_made == 0 && t_minfar != 0xffffffffu) {
+      // at least the next float above the smallest dirty distance: delta can vanish in the sum at large distances
+      const float up = __uint_as_float(t_minfar + 1u);
+      T = __uint_as_float(t_minfar) + a.delta;
+      T = T > up ? T : up;
+    }
   }
 
   // ---- distances out, and the largest hop count of a reached vertex (the reference's round count - 1)

@@ -194,6 +194,30 @@ class HipEngine:
         return float(val)
 
 
+    # ---- SSSP shard: rows = in-edges of the owned vertices with their weights
+    def sssp_setup(self, vals, dev):
+        import graphblast_amd as g
+        lptr, lind = self.keep_in
+        self.Asssp = g.Matrix(self.n_local, self.n)
+        info = self.Asssp.build_device_csr(lptr.data_ptr(), lind.data_ptr(), vals.data_ptr(), int(vals.numel()),
+                                           keep=(lptr, lind, vals))
+        assert info == 0, info
+        self.g = g
+        self._sssp_y = torch.empty(max(self.n_local, 1), dtype=torch.float32, device=dev)
+
+    def sssp_step(self, d_full, d_local):
+        """d_local = min(d_local, A_in min.+ d_full) over the owned rows; -> how many of them improved"""
+        if self.n_local == 0:
+            return 0
+        y = self._sssp_y
+        assert self.g.k_spmv(self.Asssp, 0, "MinimumPlus", d_full.data_ptr(), None, 0, 0, y.data_ptr()) == 0
+        better = y[:self.n_local] < d_local[:self.n_local]
+        changed = int(better.sum().item())
+        if changed:
+            torch.minimum(d_local[:self.n_local], y[:self.n_local], out=d_local[:self.n_local])
+        return changed
+
+
 class TorchComm:
     """The collectives of the partitioned BFS over torch.distributed (RCCL / gloo)."""
 
@@ -333,14 +357,14 @@ class Partition1D:
             li = i[e0:e1].to(torch.int32).contiguous()
             if li.numel() == 0:
                 li = torch.zeros(1, dtype=torch.int32, device=dev)
-            return lp, li
-        lptr, lind = shard(tptr, tind)
+            return lp, li, (e0, e1)
+        lptr, lind, out_range = shard(tptr, tind)
         self.lptr, self.lind = lptr, lind
         if in_edges is None:
-            self.in_lptr, self.in_lind = lptr, lind
+            self.in_lptr, self.in_lind, self.in_range = lptr, lind, out_range
             self.engine = engine_cls(n, self.lo, lptr, lind, dev)
         else:
-            self.in_lptr, self.in_lind = shard(in_edges[0], in_edges[1])
+            self.in_lptr, self.in_lind, self.in_range = shard(in_edges[0], in_edges[1])
             self.engine = engine_cls(n, self.lo, lptr, lind, dev, self.in_lptr, self.in_lind)
         self.n_local = self.hi - self.lo
         self.nwords = bitmap_words(n)
@@ -522,6 +546,49 @@ class Partition1D:
             p_cur, p_next = p_next, p_cur
             it += 1
         return p_cur, dict(iterations=it, errors=errs, overlapped_chunks=nchunks)
+
+    def sssp(self, in_weights, source, max_niter=None):
+        """algorithm::sssp (graphblas/algorithm/sssp.hpp:53-90) on the 1-D partition, as synchronous rounds:
+        every rank relaxes the IN-edges of the vertices it owns against the replicated distance vector
+        (MinimumPlus product over its in-edge shard -- round r+1 reads only round r's distances, so the distances
+        after every round, and the number of rounds, are the reference's), keeps the minimum with its own slice,
+        the slices are all-gathered into the next vector and the number of improved vertices is all-reduced;
+        the loop ends with the first round that improves nothing.
+        in_weights: the weight of every stored in-edge of the WHOLE graph, in the order of the in-edge arrays
+        this partition was built from (the CSC's; for a symmetric graph the CSR's).  Non-negative f32.
+        -> (distances of all vertices on every rank, FLT_MAX = unreached; {"iterations": rounds done})"""
+        n, dev, eng = self.n, self.dev, self.engine
+        fmax = float(np.finfo(np.float32).max)
+        max_niter = self.max_niter if max_niter is None else max_niter
+        e0, e1 = self.in_range
+        w = in_weights[e0:e1].to(torch.float32).contiguous()
+        if w.numel() == 0:
+            w = torch.zeros(1, dtype=torch.float32, device=dev)
+        eng.sssp_setup(w, dev)
+        d = torch.full((n,), fmax, dtype=torch.float32, device=dev)
+        d[source] = 0.0
+        n1 = max(self.n_local, 1)
+        d_local = torch.full((n1,), fmax, dtype=torch.float32, device=dev)
+        d_local[:self.n_local] = d[self.lo:self.hi]
+        sizes = [self.bounds[r + 1] - self.bounds[r] for r in range(self.world)]
+        pad = torch.zeros(max(max(sizes), 1), dtype=torch.float32, device=dev)
+        it, improved = 0, []
+        for it in range(1, max_niter + 1):
+            changed = eng.sssp_step(d, d_local)                      # d_local = min(d_local, A_in min.+ d)
+            total = int(self.comm.sum_(torch.tensor([float(changed)], dtype=torch.float64, device=dev))[0].item())
+            improved.append(total)
+            if total == 0:
+                break
+            if self.world == 1:
+                d[self.lo:self.hi] = d_local[:self.n_local]
+            else:
+                pad[:self.n_local] = d_local[:self.n_local]
+                out = self.comm.all_gather_padded(pad)
+                for r in range(self.world):
+                    d[self.bounds[r]:self.bounds[r + 1]] = out[r, :sizes[r]]
+        else:
+            it = max_niter + 1                                       # the reference's loop counter after a cut-off
+        return d, dict(iterations=it, improved=improved)
 
     def gather_labels(self):
         """Full label vector on every rank (tests / verification only)."""

@@ -77,6 +77,20 @@ class NumpyEngine:
         r = np.where((y == 0) | (po == 0), np.float32(0), y - po)      # eWiseMult identity short-circuit
         return float(np.sum((r * r).astype(np.float32), dtype=np.float32))
 
+    def sssp_setup(self, vals, dev):
+        self.sssp_vals = vals.cpu().numpy().astype(np.float32)
+
+    def sssp_step(self, d_full, d_local):
+        d = d_full.numpy()
+        m = int(self.iptr[-1])
+        cand = (d[self.iind[:m]] + self.sssp_vals[:m]).astype(np.float32)     # one rounding, like the kernel
+        y = np.full(self.n_local, np.finfo(np.float32).max, dtype=np.float32)
+        np.minimum.at(y, self.irows, cand)
+        dl = d_local.numpy()[:self.n_local]
+        better = y < dl
+        dl[better] = y[better]
+        return int(better.sum())
+
     def tally(self, label_local):
         lab = label_local.numpy()[:self.n_local]
         deg = np.diff(self.ptr)
@@ -141,6 +155,14 @@ def locked_engine(engine_cls, lock):
         def pr_setup(self, *a):
             with lock:
                 super().pr_setup(*a); torch.cuda.synchronize()
+        def sssp_setup(self, *a):
+            with lock:
+                super().sssp_setup(*a); torch.cuda.synchronize()
+        def sssp_step(self, *a):
+            with lock:
+                r = super().sssp_step(*a); torch.cuda.synchronize()
+                return r
+
         def pr_step(self, *a):
             with lock:
                 r = super().pr_step(*a); torch.cuda.synchronize()

@@ -16,6 +16,39 @@ def _graph(seed=1, scale=11, sym=True):
     return finalize_edges(s, d, n, symmetrize=sym)
 
 
+def _weights(ptr, ind):
+    """a weight per stored edge that is a function of the (unordered) endpoints: symmetric graphs stay symmetric"""
+    rows = np.repeat(np.arange(ptr.size - 1, dtype=np.int64), np.diff(ptr))
+    lo, hi = np.minimum(rows, ind.astype(np.int64)), np.maximum(rows, ind.astype(np.int64))
+    return ((((lo * 1000003) ^ hi) * 2654435761 >> 7) % 16 + 1).astype(np.float32)
+
+
+def _directed_weights(major_ptr, minor_ind, major_is_source):
+    """a weight per stored entry that depends on the ORDERED pair (source, target): the same edge gets the same
+    weight whether it is listed in the CSR (major = source) or in the CSC (major = target)"""
+    major = np.repeat(np.arange(major_ptr.size - 1, dtype=np.int64), np.diff(major_ptr))
+    minor = minor_ind.astype(np.int64)
+    s_, t_ = (major, minor) if major_is_source else (minor, major)
+    return ((((s_ * 1000003) ^ (t_ * 7919)) * 2654435761 >> 7) % 16 + 1).astype(np.float32)
+
+
+def _sssp_rounds(ptr, ind, w, src, max_niter=10000):
+    """the synchronous rounds of algorithm/sssp.hpp on the host: distances and the loop counter at exit"""
+    n = ptr.size - 1
+    fmax = np.finfo(np.float32).max
+    d = np.full(n, fmax, dtype=np.float32)
+    d[src] = 0
+    rows = np.repeat(np.arange(n), np.diff(ptr))
+    for it in range(1, max_niter + 1):
+        cand = (d[rows] + w).astype(np.float32)                 # relax every stored edge (row -> column)
+        y = d.copy()
+        np.minimum.at(y, ind, cand)
+        if not (y < d).any():
+            return d, it
+        d = y
+    return d, max_niter + 1
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -49,12 +82,18 @@ def _worker(rank, world, port, q):
         part = Partition1D(gr["n"], tptr, tind, rank, world, torch.device("cpu"), engine_cls=NumpyEngine)
         deg = torch.from_numpy(np.diff(ptr).astype(np.float32))
         pvec, info = part.pagerank(deg, alpha=0.85, eps=0.0, max_niter=10)
+        # SSSP on the partition (MinimumPlus product over the in-edge shard + all-gather of the slices)
+        w = torch.from_numpy(_weights(ptr, ind))
+        src_s = int(np.argmax(np.diff(ptr)))
+        dvec, sinfo = part.sssp(w, src_s)
+        dcap, cinfo = part.sssp(w, src_s, max_niter=2)
         if rank == 0:
-            q.put((out, pvec.numpy().copy(), info["iterations"]))
+            q.put((out, pvec.numpy().copy(), info["iterations"],
+                   (src_s, dvec.numpy().copy(), sinfo["iterations"], dcap.numpy().copy(), cinfo["iterations"])))
         ok = True
     except Exception as exc:                       # fail fast instead of letting the parent time out
         import traceback
-        q.put(("error", "rank %d: %s" % (rank, traceback.format_exc()), 0))
+        q.put(("error", "rank %d: %s" % (rank, traceback.format_exc()), 0, None))
         raise
     finally:
         dist.destroy_process_group()
@@ -71,12 +110,21 @@ def test_partitioned_bfs_gloo(world):
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    out, pr_vec, pr_iters = q.get(timeout=180)
+    out, pr_vec, pr_iters, sssp_out = q.get(timeout=180)
     assert not (isinstance(out, str) and out == "error"), pr_vec
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
     deg = np.diff(ptr)
+    # partitioned SSSP: the reference's distances (its own CPU Dijkstra-style oracle) and the rounds' counter,
+    # also under a max_niter that cuts the loop short
+    src_s, dvec, s_iters, dcap, c_iters = sssp_out
+    w = _weights(ptr, ind)
+    assert np.array_equal(dvec, sr.sssp(ptr, ind, w, src_s)[0])
+    want_d, want_it = _sssp_rounds(ptr, ind, w, src_s)
+    assert np.array_equal(dvec, want_d) and s_iters == want_it
+    want_c, want_cit = _sssp_rounds(ptr, ind, w, src_s, max_niter=2)
+    assert np.array_equal(dcap, want_c) and c_iters == want_cit == 3
     for mode, src, levels, edges, reached, dirs, labels in out:
         want = sr.bfs(ptr, ind, src)[0]
         assert np.array_equal(labels, want), (mode, src)
@@ -160,6 +208,21 @@ def test_partitioned_bfs_hip_engine_simulated_ranks(world, edgeswitch):
         got = pr_out[r][0].cpu().numpy()
         rel = np.abs(got - want_pr) / np.maximum(np.abs(want_pr), 1e-30)
         assert rel.max() <= 1e-5 and pr_out[r][1]["iterations"] == 10, (r, rel.max())
+    # SSSP over the same simulated ranks: the HIP MinimumPlus product on every in-edge shard
+    wh = _weights(ptr, ind)
+    w = torch.from_numpy(wh).to(dev)
+    src_s = int(np.argmax(np.diff(ptr)))
+    ss_out = [None] * world
+    def run_sssp(r):
+        ss_out[r] = parts[r].sssp(w, src_s)
+    ts = [threading.Thread(target=run_sssp, args=(r,)) for r in range(world)]
+    [t.start() for t in ts]
+    [t.join(timeout=300) for t in ts]
+    want_d, want_it = _sssp_rounds(ptr, ind, wh, src_s)
+    assert np.array_equal(want_d, sr.sssp(ptr, ind, wh, src_s)[0])
+    for r in range(world):
+        assert ss_out[r] is not None
+        assert np.array_equal(ss_out[r][0].cpu().numpy(), want_d) and ss_out[r][1]["iterations"] == want_it, r
 
 
 @pytest.mark.gpu
@@ -247,11 +310,15 @@ def _worker_directed(rank, world, port, q):
                            symmetric=False, in_edges=(t(cptr), t(cind)))
         deg = torch.from_numpy(np.maximum(np.diff(ptr), 1).astype(np.float32))
         pvec, info = part.pagerank(deg, alpha=0.85, eps=0.0, max_niter=8)
+        # SSSP along the edge directions: the in-edge shard carries the weights in CSC order
+        w_in = torch.from_numpy(_directed_weights(cptr, cind, major_is_source=False))
+        src_s = int(np.argmax(np.diff(ptr)))
+        dvec, sinfo = part.sssp(w_in, src_s)
         if rank == 0:
-            q.put((out, pvec.numpy().copy(), info["iterations"]))
+            q.put((out, pvec.numpy().copy(), info["iterations"], (src_s, dvec.numpy().copy(), sinfo["iterations"])))
     except Exception:
         import traceback
-        q.put(("error", "rank %d: %s" % (rank, traceback.format_exc()), 0))
+        q.put(("error", "rank %d: %s" % (rank, traceback.format_exc()), 0, None))
         raise
     finally:
         dist.destroy_process_group()
@@ -272,12 +339,17 @@ def test_partitioned_directed_graph_gloo():
     procs = [ctx.Process(target=_worker_directed, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    out, pr_vec, pr_iters = q.get(timeout=180)
+    out, pr_vec, pr_iters, sssp_out = q.get(timeout=180)
     assert not (isinstance(out, str) and out == "error"), pr_vec
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
     deg = np.diff(ptr)
+    src_s, dvec, s_iters = sssp_out
+    w_out = _directed_weights(ptr, ind, major_is_source=True)
+    want_d, want_it = _sssp_rounds(ptr, ind, w_out, src_s)
+    assert np.array_equal(dvec, want_d) and s_iters == want_it
+    assert np.array_equal(dvec, sr.sssp(ptr, ind, w_out, src_s)[0])
     for mode, src, edges, reached, labels in out:
         want = sr.bfs(ptr, ind, src)[0]
         assert np.array_equal(labels, want), (mode, src)
