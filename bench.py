@@ -672,15 +672,41 @@ def main():
         # ---- for comparison, NOT the reported value: RMAT-22 fits one GPU 100 times over, so a
         #      batch of traversals can also be sharded by SOURCE over replicas of the graph (no
         #      collective at all; every rank runs the single-GPU kernel on its own K sources).
-        if world > 1 or os.environ.get("GRB_BENCH_TEST_REPLICAS"):
-            tval = torch.ones(nnz, dtype=torch.float32, device=dev)
-            A = g.Matrix(n, n)
-            info = A.build_device_csr(tptr.data_ptr(), tind.data_ptr(), tval.data_ptr(), nnz, tptr.data_ptr(),
-                                      tind.data_ptr(), tval.data_ptr(), keep=(tptr, tind, tval))
+        # ---- parity of the partitioned traversal: the labels gathered from all ranks against the one-launch
+        #      traversal of this rank's own replica of the graph (itself asserted against the reference's CPU BFS
+        #      in the N = 1 run), a few sources, every rank checks, any mismatch fails the run
+        tval = torch.ones(nnz, dtype=torch.float32, device=dev)
+        A = g.Matrix(n, n)
+        info = A.build_device_csr(tptr.data_ptr(), tind.data_ptr(), tval.data_ptr(), nnz, tptr.data_ptr(),
+                                  tind.data_ptr(), tval.data_ptr(), keep=(tptr, tind, tval))
+        assert info == 0, info
+        desc = g.Descriptor()
+        assert desc.loadArgs(mxvmode=0, struconly=1, opreuse=1, earlyexit=1, edgeswitch=args.edgeswitch) == 0
+        v = g.Vector(n)
+        bad = 0
+        check = sources[:4]
+        for s_ in check:
+            res_p = part.bfs(s_)
+            lab_p = part.gather_labels()
+            info, res_1 = g.bfs(v, A, s_, desc, fused=True)
             assert info == 0, info
-            desc = g.Descriptor()
-            assert desc.loadArgs(mxvmode=0, struconly=1, opreuse=1, earlyexit=1, edgeswitch=args.edgeswitch) == 0
-            v = g.Vector(n)
+            lab_1 = torch.from_numpy(v.extractTuples()[1]).to(lab_p.device)
+            if not torch.equal(lab_p, lab_1) or res_p["edges_traversed"] != res_1["edges_traversed"]:
+                bad += 1
+        tb = torch.tensor([float(bad)], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(tb, op=dist.ReduceOp.SUM)
+        extra["parity"] = {"checked_sources": len(check), "mismatches": int(tb.item()),
+                           "checker": "bfs_persistent_kernel on every rank's replica of the graph",
+                           "what": "depth labels gathered from all ranks, bit-exact; edges traversed"}
+        if tb.item() > 0:
+            if rank == 0:
+                print(json.dumps({"error": "parity (partitioned traversal)", "mismatching_rank_source_pairs": int(tb.item())}))
+            if world > 1:
+                dist.destroy_process_group()
+            sys.exit(3)
+
+        if world > 1 or os.environ.get("GRB_BENCH_TEST_REPLICAS"):
             mine = [sources[(rank * args.steps + i) % len(sources)] for i in range(args.steps)]
             for s_ in mine[:args.warmup]:
                 g.bfs(v, A, s_, desc, fused=True)
