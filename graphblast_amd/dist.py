@@ -264,18 +264,20 @@ class RcclComm:
         have_r, have_w = C.c_int(0), C.c_int(0)
         self._lib.grb_comm_info(C.byref(have_r), C.byref(have_w))
         if have_w.value == 0:
-            ident = torch.zeros(128, dtype=torch.uint8)
+            # byte 128 says whether rank 0 got an id: a failure there must reach every rank (they would otherwise
+            # wait in the broadcast for a rank that has already fallen back to torch.distributed)
+            ident = torch.zeros(129, dtype=torch.uint8)
             if rank == 0:
                 buf = (C.c_ubyte * 128)()
-                info = self._lib.grb_comm_unique_id(buf)
-                if info != 0:
-                    raise RuntimeError("grb_comm_unique_id: Info %d (no RCCL?)" % info)
-                ident = torch.tensor(list(buf), dtype=torch.uint8)
+                if self._lib.grb_comm_unique_id(buf) == 0:
+                    ident = torch.tensor(list(buf) + [1], dtype=torch.uint8)
             if world > 1:
                 t = ident.to(dev) if dist.get_backend() == "nccl" else ident
                 dist.broadcast(t, 0)
                 ident = t.cpu()
-            raw = (C.c_ubyte * 128)(*ident.tolist())
+            if int(ident[128]) != 1:
+                raise RuntimeError("grb_comm_unique_id failed on rank 0 (no RCCL?)")
+            raw = (C.c_ubyte * 128)(*ident[:128].tolist())
             info = self._lib.grb_comm_init(raw, rank, world)
             if info != 0:
                 raise RuntimeError("grb_comm_init: Info %d" % info)
@@ -283,6 +285,35 @@ class RcclComm:
             raise RuntimeError("the library communicator is rank %d of %d" % (have_r.value, have_w.value))
         self.gathered = torch.zeros(world * nwords, dtype=torch.int32, device=dev) if world > 1 else None
         self._acc = torch.zeros(2, dtype=torch.float64, device=dev)
+        if world > 1:
+            self._self_test()
+
+    def _self_test(self):
+        """Every collective of this class once on known data; the ranks agree on the verdict through
+        torch.distributed, so either all of them keep this communicator or all of them raise (and the caller
+        falls back to TorchComm everywhere)."""
+        rank, world, dev = self.rank, self.world, self.dev
+        ok = True
+        try:
+            got = self.all_gather_padded(torch.full((16,), float(rank + 1), dtype=torch.float32, device=dev))
+            want = torch.arange(1, world + 1, dtype=torch.float32, device=dev)[:, None].expand(world, 16)
+            ok = ok and bool(torch.equal(got, want))
+            # unequal slices in place: rank r owns r + 1 words
+            offs = [r * (r + 1) // 2 for r in range(world + 1)]
+            buf = torch.zeros(offs[world], dtype=torch.int32, device=dev)
+            buf[offs[rank]:offs[rank + 1]] = rank + 1
+            self.gather_slices_async(buf, [4 * offs[r] for r in range(world)], [4 * (r + 1) for r in range(world)])
+            self.wait()
+            want = torch.cat([torch.full((r + 1,), r + 1, dtype=torch.int32, device=dev) for r in range(world)])
+            ok = ok and bool(torch.equal(buf, want))
+            t = self.sum_(torch.tensor([float(rank + 1)], dtype=torch.float64, device=dev))
+            ok = ok and float(t.item()) == world * (world + 1) / 2
+        except Exception:                                             # noqa: BLE001 -- reported through the verdict
+            ok = False
+        verdict = torch.tensor([1.0 if ok else 0.0], dtype=torch.float32, device=dev if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(verdict, op=dist.ReduceOp.MIN)
+        if float(verdict.item()) != 1.0:
+            raise RuntimeError("the library communicator failed its self-test on some rank")
 
     def or_combine(self, new_local, new_global, engine=None):
         if self.world == 1:
