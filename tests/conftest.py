@@ -15,6 +15,17 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """A ceiling per test when pytest-timeout is installed (it is in this image): the whole GPU suite takes two
+    minutes, so a test that is still running after ten is stuck in something outside Python's reach (a collective's
+    rendezvous, a driver call) and the run should fail there instead of sitting until the caller's limit."""
+    if not config.pluginmanager.hasplugin("timeout"):
+        return
+    for item in items:
+        if item.get_closest_marker("timeout") is None:
+            item.add_marker(pytest.mark.timeout(600))
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
