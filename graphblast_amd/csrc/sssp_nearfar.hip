@@ -74,7 +74,7 @@ __device__ inline void nf_relax(const NfArgs& a, float du, unsigned int hu, Inde
 template <int N>
 __device__ inline void nf_relax_batch(const NfArgs& a, float du, unsigned int hu, Index p0, Index e, unsigned int& made) {
   Index v[N];
-  u64 nk[N], cur[N];
+  u64 nk[N];
   bool ok[N];
 #pragma unroll
   for (int j = 0; j < N; ++j) {
@@ -83,13 +83,11 @@ __device__ inline void nf_relax_batch(const NfArgs& a, float du, unsigned int hu
     v[j] = a.oind[p];
     nk[j] = nf_key(du + a.oval[p], hu + 1u);
   }
+  // no peek at the target's key first: a pass of this kernel is a chain of dependent memory steps, not a
+  // throughput problem (a few thousand vertices per pass), and the atomicMin answers the question itself
 #pragma unroll
-  for (int j = 0; j < N; ++j) cur[j] = fresh(&a.K[v[j]]);
-#pragma unroll
-  for (int j = 0; j < N; ++j) {
-    ok[j] = ok[j] && nk[j] < cur[j];
+  for (int j = 0; j < N; ++j)
     if (ok[j]) ok[j] = nk[j] < atomicMin(&a.K[v[j]], nk[j]);
-  }
   unsigned int fw[N];
 #pragma unroll
   for (int j = 0; j < N; ++j) fw[j] = ok[j] ? fresh(&a.dirty[v[j] >> 5]) : 0xffffffffu;
