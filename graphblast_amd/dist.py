@@ -492,9 +492,11 @@ class Partition1D:
         if it > self.max_niter and nf > 0:                          # bfs.hpp:48-66: never assigned
             self.label[self.label == float(self.max_niter + 1)] = 0.0
         e, r = self.engine.tally(self.label)
-        t = torch.tensor([e, r], dtype=torch.int64, device=self.dev)
-        self.comm.sum_(t)
-        return dict(levels=levels, edges_traversed=int(t[0].item()), reached=int(t[1].item()), trace=trace)
+        if self.world > 1:                                           # one collective, one read-back
+            t = torch.tensor([e, r], dtype=torch.int64, device=self.dev)
+            self.comm.sum_(t)
+            e, r = (int(x) for x in t.tolist())
+        return dict(levels=levels, edges_traversed=int(e), reached=int(r), trace=trace)
 
     def pagerank(self, deg_full, alpha=0.85, eps=1e-8, max_niter=10):
         """algorithm::pr (graphblas/algorithm/pr.hpp:15-94) on the 1-D partition: every rank
