@@ -352,7 +352,10 @@ grb_info grb::sssp_nearfar_run(grb_vector v, grb_matrix A, grb_index source, grb
   a.mail = c.d_hgran;
   a.seq = ++c.mail_seq;
   a.ticks_to_ms = ticks_to_ms;
-  a.max_passes = 0x7fffff00;
+  // a pass either expands a vertex or raises the threshold past one: far fewer than n of each are ever needed;
+  // the cap only turns a logic error into "not converged" (the rounds then run) instead of an endless launch
+  const long long pass_cap = 8ll * (long long)n + 1024;
+  a.max_passes = pass_cap > 0x7fffff00ll ? 0x7fffff00 : (int)pass_cap;
   static const int inner = getenv("GRB_SSSP_INNER") ? atoi(getenv("GRB_SSSP_INNER")) : 2;
   a.inner = inner < 1 ? 1 : inner;
   GRB_HIP_TRY(hipMemsetAsync(p_zero, 0, zero_bytes, s));
