@@ -51,7 +51,11 @@ grb_info grb_sssp(grb_vector v, grb_matrix A, grb_index source, grb_descriptor d
     GRB_TRY(grb_vector_set_storage(f1, GRB_DENSE));
     int it = 0;
     double sc = 0;
-    const grb_info fi = sssp_persistent_run(v, A, source, desc, &it, &sc, &fused_ms, f1, &continued);
+    static int persistent_failures = 0;       // as in grb_bfs_fused: three give-ups in a row end the attempts
+    const grb_info fi = persistent_failures < 3
+                            ? sssp_persistent_run(v, A, source, desc, &it, &sc, &fused_ms, f1, &continued)
+                            : GRB_NOT_IMPLEMENTED;
+    if (fi == GRB_PANIC) ++persistent_failures; else if (fi == GRB_SUCCESS) persistent_failures = 0;
     if (fi == GRB_SUCCESS && !continued) {
       desc->lastmxv = GRB_PUSHONLY;
       if (result) { result->iterations = it; result->tight_ms = fused_ms; result->last_value = sc; }

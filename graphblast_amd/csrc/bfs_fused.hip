@@ -110,7 +110,10 @@ extern "C" grb_info grb_bfs_fused(grb_vector v, grb_matrix A, grb_index source, 
   GRB_TRY(ensure_pull_hint(&A->d_pull_hint, A->csc, A->csr.ptr, s));
 
   static const bool use_persistent = [] { const char* e = getenv("GRB_BFS_PERSISTENT"); return !e || atoi(e) != 0; }();
-  if (use_persistent) {
+  // three barrier give-ups in a row (each costs seconds of bounded spinning): the device is evidently shared;
+  // stop trying for the rest of the process
+  static int persistent_failures = 0;
+  if (use_persistent && persistent_failures < 3) {
     GRB_TRY(grb_vector_set_storage(v, GRB_DENSE));
     int p_levels = 0, p_dir = 0;
     long long p_reached = 0;
@@ -120,6 +123,7 @@ extern "C" grb_info grb_bfs_fused(grb_vector v, grb_matrix A, grb_index source, 
     float p_ms = 0.f;
     const grb_info pi = bfs_persistent_run(v, A, source, desc, profile, levels_out, max_levels, &p_levels, &p_dir,
                                            &p_reached, &p_edges, &p_nf, &p_cap, &p_ms);
+    if (pi == GRB_PANIC) ++persistent_failures; else persistent_failures = 0;
     if (pi == GRB_PANIC || pi == GRB_NOT_IMPLEMENTED) {
       // the one-launch traversal could not run to its end here (launch refused, or its grid barrier gave up
       // because the grid was not co-resident -- other work on the device): same traversal, level loop driven

@@ -276,6 +276,7 @@ int grb::sssp_nearfar_setting(int set, bool apply) {
   return g_nearfar_mode;
 }
 static int nearfar_env() { return sssp_nearfar_setting(0, false); }
+static int g_barrier_failures = 0;   // consecutive launches whose grid barrier gave up
 static int g_last_order = 0;         // what the last grb_sssp of this process ran: 0 synchronous rounds, else near / far (its passes)
 int grb::sssp_last_order(int set) {
   if (set >= 0) g_last_order = set;
@@ -309,6 +310,7 @@ grb_info grb::sssp_nearfar_run(grb_vector v, grb_matrix A, grb_index source, grb
                                double* succ, float* tight_ms, int* passes) {
   bool wanted = false;
   g_last_order = 0;
+  if (g_barrier_failures >= 3) return GRB_NOT_IMPLEMENTED;   // the device is evidently shared: stop paying for the attempts
   GRB_TRY(nearfar_wanted(A, desc, &wanted));
   if (!wanted) return GRB_NOT_IMPLEMENTED;
   Context& c = ctx();
@@ -365,7 +367,11 @@ grb_info grb::sssp_nearfar_run(grb_vector v, grb_matrix A, grb_index source, grb
   hipLaunchKernelGGL(sssp_nearfar_kernel, dim3(c.num_cu), dim3(kPThreads), 0, s, a);
   GRB_HIP_TRY(hipGetLastError());
   unsigned int gv[5];
-  if (wait_granules(a.seq, 5, gv) != GRB_SUCCESS) return GRB_NOT_IMPLEMENTED;   // the barrier gave up: round-exact path
+  if (wait_granules(a.seq, 5, gv) != GRB_SUCCESS) {       // the barrier gave up: round-exact path
+    ++g_barrier_failures;
+    return GRB_NOT_IMPLEMENTED;
+  }
+  g_barrier_failures = 0;
   if (!gv[3]) return GRB_NOT_IMPLEMENTED;
   float maxdist;
   memcpy(&maxdist, &gv[4], 4);
