@@ -297,6 +297,11 @@ def main():
                     help="skip the multi-frontier measurements (64-source sweep, sparse x dense mxm)")
     ap.add_argument("--partitioned", action="store_true",
                     help="use the 1-D partitioned level loop even at N = 1 (debugging the N > 1 path)")
+    ap.add_argument("--levels-per-launch", type=int, default=1,
+                    help="partitioned traversal, N = 1 only: levels one launch may run (1 = a launch per level, as "
+                         "every N > 1 run does; a large number = the whole traversal in one launch)")
+    ap.add_argument("--host-loop", action="store_true",
+                    help="partitioned traversal through the host-driven level loop of round 2 (for comparison)")
     args = ap.parse_args()
     if args.workload != "rmat22_bfs":
         return other_workload(args)
@@ -620,14 +625,18 @@ def main():
                 comm_kind = "library RCCL communicator (csrc/comm.hip), collectives on a second HIP stream"
             except Exception as exc:                                  # noqa: BLE001 -- reported on the line
                 comm_kind += "; library communicator unavailable: %s" % str(exc)[:120]
-        part = gdist.Partition1D(n, tptr, tind, rank, world, dev, edgeswitch=args.edgeswitch, comm=comm)
+        part = gdist.Partition1D(n, tptr, tind, rank, world, dev, edgeswitch=args.edgeswitch, comm=comm,
+                                 device_loop=not args.host_loop, levels_per_launch=args.levels_per_launch)
         for i in range(args.warmup):
-            part.bfs(sources[i % len(sources)])
+            part.bfs(sources[i % len(sources)], want_trace=False)
         barrier()
         t0 = time.perf_counter()
-        edges = 0
+        edges, launches, dev_ms = 0, 0, 0.0
         for i in range(args.steps):
-            edges += part.bfs(sources[i % len(sources)])["edges_traversed"]
+            r_ = part.bfs(sources[i % len(sources)], want_trace=False)
+            edges += r_["edges_traversed"]
+            launches += r_.get("launches", 0)
+            dev_ms += r_.get("device_ms", 0.0)
         barrier()
         elapsed = time.perf_counter() - t0
         if world > 1:
@@ -637,6 +646,12 @@ def main():
         roofline = None
         parallelism = "1d_vertex_partition_x%d" % world
         extra["collectives"] = {"through": comm_kind}
+        extra["level_loop"] = ({"where": "device (csrc/bfs_part_run.hip): one co-resident launch per level + one all-gather, "
+                                         "nothing read back until the traversal ends",
+                                "levels_per_launch": args.levels_per_launch,
+                                "launches_per_traversal": round(launches / max(args.steps, 1), 2),
+                                "device_ms_per_traversal": round(dev_ms / max(args.steps, 1), 4)}
+                               if part.device_loop else {"where": "host (graphblast_amd/dist.py, round 2)"})
         if comm is not None:
             # a second, short pass with per-collective HIP-event timing (it adds a host wait per collective,
             # so it is kept out of the timed region): what share of a traversal is communication

@@ -124,6 +124,46 @@ class HipEngine:
         assert info == 0, info
         return e.value, r.value
 
+    # ---- the whole traversal with the level loop on the device (csrc/bfs_part_run.hip)
+    def part_context(self, rank, world, deg_full, nnz):
+        """the rank context of grb_bfs_part_run: shards + replicated out-degrees (int32 device tensor, kept alive)"""
+        if getattr(self, "_part", None) is None:
+            h = C.c_void_p()
+            a_in = None if self.A_in is self.A else self.A_in._h
+            info = self._lib.grb_part_new(C.byref(h), int(rank), int(world), self.n, self.lo, self.A._h, a_in,
+                                          deg_full.data_ptr(), int(nnz))
+            if info != 0:
+                raise RuntimeError("grb_part_new: Info %d" % info)
+            self._part, self._part_keep = h, deg_full
+        return self._part
+
+    def run_bfs(self, part, source, mxvmode, switchpoint, edgeswitch, max_niter, label_local, levels_per_launch=1,
+                want_trace=True):
+        """-> (PartBfsResult, [(direction, frontier, discovered)] per level); nothing is read back per level"""
+        from ._lib import PartBfsResult, BfsLevel
+        if getattr(self, "_lv", None) is None:
+            self._lv_cap = 4096
+            self._lv = (BfsLevel * self._lv_cap)()
+            self._res = PartBfsResult()
+        res, lv = self._res, self._lv
+        info = self._lib.grb_bfs_part_run(part, int(source), int(mxvmode), float(switchpoint), float(edgeswitch),
+                                          int(max_niter), int(levels_per_launch), label_local.data_ptr(), C.byref(res),
+                                          lv, self._lv_cap if want_trace else 0)
+        if info != 0:
+            raise RuntimeError("grb_bfs_part_run: Info %d" % info)
+        trace = [("pull" if lv[i].direction else "push", int(lv[i].frontier), int(lv[i].discovered))
+                 for i in range(min(res.levels, self._lv_cap))] if want_trace else None
+        return res, trace
+
+    def __del__(self):
+        part = getattr(self, "_part", None)
+        if part is not None:
+            try:
+                self._lib.grb_part_free(part)
+            except Exception:                                         # noqa: BLE001 -- interpreter shutdown
+                pass
+            self._part = None
+
     # ---- PageRank shard: rows = in-edges of the owned vertices, values alpha / outdeg(source)
     def pr_setup(self, vals, dev):
         import graphblast_amd as g
@@ -368,9 +408,68 @@ class RcclComm:
         return us.value, calls.value
 
 
+class LoopbackGroup:
+    """Every rank of a world of `world` on ONE device, driven in lock-step by grb_bfs_part_run_group with device copies
+    as the all-gather: what a multi-GPU run executes per rank (the same launches, the same apply over `world`
+    gathered bitmaps) minus RCCL.  Used by the tests (N > 1 logic on a one-GPU box) and by tools/part_scaling.py
+    (per-rank compute time as a function of the world size)."""
+
+    def __init__(self, n, tptr, tind, world, dev, in_edges=None):
+        from . import _lib
+        self._lib = _lib.load()
+        self.n, self.world, self.dev = n, world, dev
+        ptr_host = tptr.cpu().numpy()
+        self.bounds = partition_bounds(ptr_host, world)
+        self.nnz = int(ptr_host[-1])
+        self.deg_full = (tptr[1:] - tptr[:-1]).to(torch.int32).contiguous()
+        self.engines, self.labels, handles = [], [], []
+        for r in range(world):
+            lo, hi = self.bounds[r], self.bounds[r + 1]
+
+            def shard(p, i):
+                ph = p.cpu().numpy()
+                e0, e1 = int(ph[lo]), int(ph[hi])
+                lp = (p[lo:hi + 1] - e0).to(torch.int32).contiguous()
+                li = i[e0:e1].to(torch.int32).contiguous()
+                if li.numel() == 0:
+                    li = torch.zeros(1, dtype=torch.int32, device=dev)
+                return lp, li
+            lptr, lind = shard(tptr, tind)
+            if in_edges is None:
+                eng = HipEngine(n, lo, lptr, lind, dev)
+            else:
+                ip, ii = shard(in_edges[0], in_edges[1])
+                eng = HipEngine(n, lo, lptr, lind, dev, ip, ii)
+            handles.append(eng.part_context(r, world, self.deg_full, self.nnz))
+            self.engines.append(eng)
+            self.labels.append(torch.zeros(max(hi - lo, 1), dtype=torch.float32, device=dev))
+        self._handles = (C.c_void_p * world)(*[h.value for h in handles])
+        self._label_ptrs = (C.c_void_p * world)(*[t.data_ptr() for t in self.labels])
+
+    def bfs(self, source, mxvmode=GRB_PUSHPULL, switchpoint=0.01, edgeswitch=0.0, max_niter=10000):
+        """-> (labels of the whole graph [n] as numpy, per-rank result dicts, trace of rank 0)"""
+        from ._lib import PartBfsResult, BfsLevel
+        res = (PartBfsResult * self.world)()
+        cap = 1 << 15
+        lv = (BfsLevel * cap)()
+        info = self._lib.grb_bfs_part_run_group(self._handles, self.world, int(source), int(mxvmode),
+                                                float(np.float32(switchpoint)), float(edgeswitch), int(max_niter),
+                                                self._label_ptrs, res, lv, cap)
+        if info != 0:
+            raise RuntimeError("grb_bfs_part_run_group: Info %d" % info)
+        labels = np.concatenate([self.labels[r][:self.bounds[r + 1] - self.bounds[r]].cpu().numpy()
+                                 for r in range(self.world)])
+        out = [dict(levels=int(x.levels), launches=int(x.launches), hit_cap=int(x.hit_cap),
+                    edges_traversed=int(x.edges_traversed), reached=int(x.reached), device_ms=float(x.ms)) for x in res]
+        trace = [("pull" if lv[i].direction else "push", int(lv[i].frontier), int(lv[i].discovered))
+                 for i in range(min(out[0]["levels"], cap))]
+        return labels, out, trace
+
+
 class Partition1D:
     def __init__(self, n, tptr, tind, rank, world, dev, engine_cls=HipEngine, mxvmode=GRB_PUSHPULL,
-                 switchpoint=0.01, max_niter=10000, symmetric=True, comm=None, edgeswitch=0.0, in_edges=None):
+                 switchpoint=0.01, max_niter=10000, symmetric=True, comm=None, edgeswitch=0.0, in_edges=None,
+                 device_loop=True, levels_per_launch=1):
         """tptr / tind: the whole graph's CSR (out-edges).  A directed graph also passes in_edges = (cptr, cind),
         its CSC: every rank then holds the out-edge rows (push) AND the in-edge rows (pull, PageRank) of the
         vertices it owns.  A symmetric graph needs one shard for both."""
@@ -413,6 +512,14 @@ class Partition1D:
         if self.edgeswitch > 0 and hasattr(self.engine, "apply2"):
             self.deg_full = (tptr[1:] - tptr[:-1]).to(torch.int32).contiguous()
         self.deg_source = lambda s: int(ptr_host[s + 1] - ptr_host[s])
+        # the engine's own level loop (HipEngine: one launch + one all-gather per level, nothing read back until
+        # the end, csrc/bfs_part_run.hip).  It needs every vertex's out-degree on the device, and a communicator
+        # the library can drive itself: its own RCCL one, or none at all for a world of one rank.
+        self.device_loop = (hasattr(self.engine, "run_bfs") and device_loop
+                            and (world == 1 or isinstance(self.comm, RcclComm)))
+        self.levels_per_launch = int(levels_per_launch)
+        if self.device_loop and self.deg_full is None:
+            self.deg_full = (tptr[1:] - tptr[:-1]).to(torch.int32).contiguous()
         import inspect
         self._combine_takes_engine = "engine" in inspect.signature(self.comm.or_combine).parameters
         self.mxvmode, self.switchpoint, self.max_niter = mxvmode, float(np.float32(switchpoint)), max_niter
@@ -423,9 +530,15 @@ class Partition1D:
         else:                                              # communicators with the two-argument form
             self.comm.or_combine(self.new_local, self.new_global)
 
-    def bfs(self, source):
+    def bfs(self, source, want_trace=True):
         n = self.n
         eng = self.engine
+        if self.device_loop:
+            part = eng.part_context(self.rank, self.world, self.deg_full, self.nnz)
+            res, trace = eng.run_bfs(part, source, self.mxvmode, self.switchpoint, self.edgeswitch, self.max_niter,
+                                     self.label, self.levels_per_launch, want_trace)
+            return dict(levels=int(res.levels), edges_traversed=int(res.edges_traversed), reached=int(res.reached),
+                        trace=trace, launches=int(res.launches), device_ms=float(res.ms))
         if hasattr(eng, "seed"):
             eng.seed(self.vis, self.new_global, self.label, source)
         else:
@@ -460,13 +573,16 @@ class Partition1D:
                         ratio_f1 = ratio
             else:
                 f1_dense = self.mxvmode == GRB_PULLONLY
-            if (not f1_dense and self.mxvmode == GRB_PUSHPULL and self.deg_full is not None and nf >= 32
+            if (not f1_dense and self.mxvmode == GRB_PUSHPULL and self.deg_full is not None and self.edgeswitch > 0 and nf >= 32
                     and all_edges > self.edgeswitch * self.nnz):
                 f1_dense = True                                    # the same rule as bfs_persist.hip:145-147
-            if f1_dense and hasattr(self.comm, "gather_word_slices") and getattr(eng, "pull_zeroes", False):
+            if (f1_dense and hasattr(self.comm, "gather_word_slices") and getattr(eng, "pull_zeroes", False)
+                    and all(b % 32 == 0 for b in self.bounds[1:-1])):
                 # pull discovers owned vertices only: written straight into the replicated bitmap, then ONE
                 # in-place all-gather of the ranks' own word ranges (no OR pass, 1/P of the bytes)
                 eng.pull(self.vis, self.new_global, self.label, it + 1)
+                # (partition_bounds clamps an interior bound to n: with n % 64 >= 32 and a heavy tail vertex a
+                # bound can fall inside a word -- then the word has two owners and the OR path below is taken)
                 self.comm.gather_word_slices(self.new_global, [b // 32 for b in self.bounds[:-1]] + [self.nwords])
             else:
                 if f1_dense:

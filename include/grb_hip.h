@@ -321,6 +321,38 @@ grb_info grb_bfs_part_seed(uint32_t* d_vis, uint32_t* d_new_global, float* d_lab
                            grb_index n_local, grb_index n_global, grb_index source);
 grb_info grb_bitmap_or_parts(const uint32_t* d_parts, int world, grb_index nwords, uint32_t* d_out);
 
+/* ---- The same traversal with the level loop on the DEVICE (csrc/bfs_part_run.hip).  A rank context holds the
+ * shards (A_out / A_in: the owned vertices' out- / in-neighbour lists, nrows x n_global, global column ids;
+ * A_in NULL = the graph is symmetric and one shard serves both), the replicated n-bit visited bitmap, the
+ * frontier bitmaps of its owned vertices and the scalars of the level loop.  d_deg_full: out-degree of every
+ * vertex (device, int32, replicated; must outlive the context).  grb_bfs_part_run enqueues ONE co-resident
+ * launch per level (apply the gathered new bits -> grid barrier -> decide -> expand) followed by ONE all-gather
+ * of the n/8-byte new-bits bitmaps on the library communicator (grb_comm_*; skipped when world == 1) and reads
+ * nothing back until the traversal has ended: launch k + 1 is enqueued when launch k - 1 has reported through
+ * one pinned word -- a rule that uses only values identical on every rank, so all ranks issue the same number
+ * of collectives.  levels_per_launch > 1 (world == 1 only) runs that many levels inside one launch.
+ * grb_bfs_part_run_group drives `nranks` contexts of a world of `nranks` in lock-step on ONE device with device
+ * copies as the all-gather: the test stand-in for a multi-GPU run.  Labels are those of algorithm::bfs
+ * (algorithm/bfs.hpp:14-89); the reference has no multi-GPU code (backend/cuda/descriptor.hpp:242). */
+typedef struct grb_part_s* grb_part;
+typedef struct {
+  int32_t levels;             /* levels expanded                                        */
+  int32_t launches;           /* level launches enqueued (levels + 2 when one level per launch) */
+  int32_t hit_cap;            /* max_niter ended the loop with a non-empty frontier     */
+  int64_t edges_traversed;    /* sum of out-degree over reached vertices, whole graph   */
+  int64_t reached;            /* vertices with a nonzero label, whole graph             */
+  float   ms;                 /* HIP-event time: first launch .. label pass             */
+} grb_part_bfs_result;
+grb_info grb_part_new(grb_part* part, int rank, int world, grb_index n_global, grb_index lo, grb_matrix A_out,
+                      grb_matrix A_in /* nullable */, const int32_t* d_deg_full, int64_t nnz_global);
+grb_info grb_part_free(grb_part part);
+grb_info grb_bfs_part_run(grb_part part, grb_index source, int mxvmode, float switchpoint, float edgeswitch,
+                          int max_niter, int levels_per_launch, float* d_label_local, grb_part_bfs_result* result,
+                          grb_bfs_level* levels_out /* nullable */, int max_levels);
+grb_info grb_bfs_part_run_group(grb_part* parts, int nranks, grb_index source, int mxvmode, float switchpoint,
+                                float edgeswitch, int max_niter, float* const* d_labels,
+                                grb_part_bfs_result* results /* nranks */, grb_bfs_level* levels_out, int max_levels);
+
 typedef struct {
   int    iterations;          /* loop iterations executed                              */
   float  tight_ms;            /* HIP-event time of the loop                            */

@@ -1,0 +1,138 @@
+"""The 1-D partitioned BFS with its level loop on the device (csrc/bfs_part_run.hip): one co-resident launch per
+level, the all-gather of the new-bits bitmaps, nothing read back until the end.  On the one-GPU box every rank of a
+world of 1 .. 8 lives on the same device (grb_bfs_part_run_group: device copies stand in for RCCL); labels bit-exact
+against the oracle's SimpleReferenceBfs restatement, direction trace against the oracle's accounting run."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _graph(seed=3, scale=15, sym=True, ef=8):
+    from graphblast_amd.graphgen import rmat_edges, finalize_edges
+    s, d, n = rmat_edges(scale, ef, seed=seed)
+    return finalize_edges(s, d, n, symmetrize=sym)
+
+
+def _t(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a).astype(np.int64)).to(dev)
+
+
+def _check(labels, res, trace, ptr, ind, src, mode, switchpoint, csc=None, check_trace=True):
+    from oracle import simple_reference as sr
+    want = sr.bfs(ptr, ind, src)[0]
+    assert np.array_equal(labels, want), (src, mode)
+    deg = np.diff(ptr)
+    for r in res:
+        assert r["edges_traversed"] == int(deg[want != 0].sum()) and r["reached"] == int(np.count_nonzero(want))
+        assert r["levels"] == res[0]["levels"] and r["launches"] == res[0]["launches"]
+    if check_trace:
+        cp, ci = csc if csc is not None else (ptr, ind)
+        _, stats = sr.bfs_do_stats(ptr, ind, cp, ci, src, mxvmode=mode, switchpoint=switchpoint)
+        assert [t[0] for t in trace] == ["pull" if s[0] else "push" for s in stats], (src, mode)
+        assert res[0]["levels"] == len(stats)
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 4, 8])
+def test_device_loop_simulated_ranks(world):
+    from graphblast_amd.dist import LoopbackGroup
+    gr = _graph()
+    ptr, ind = gr["csr"]
+    dev = torch.device("cuda", 0)
+    grp = LoopbackGroup(gr["n"], _t(ptr, dev), _t(ind, dev), world, dev)
+    hub = int(np.argmax(np.diff(ptr)))
+    for mode in (10, 11, 12):
+        for src in (hub, 11, 4097):
+            labels, res, trace = grp.bfs(src, mxvmode=mode, switchpoint=0.02)
+            _check(labels, res, trace, ptr, ind, src, mode, 0.02)
+            assert res[0]["launches"] == res[0]["levels"] + 2        # one launch per level, one to see the end, one spare
+    # the edge-aware extension: the hub's second frontier is few vertices carrying most of the edges
+    labels, res, trace = grp.bfs(hub, switchpoint=0.02, edgeswitch=0.02)
+    _check(labels, res, trace, ptr, ind, hub, 10, 0.02, check_trace=False)
+    assert trace[1][0] == "pull"
+
+
+def test_device_loop_directed_graph():
+    from graphblast_amd.dist import LoopbackGroup
+    gd = _graph(seed=9, scale=13, sym=False)
+    ptr, ind = gd["csr"]
+    cp, ci = gd["csc"]
+    dev = torch.device("cuda", 0)
+    for world in (1, 3):
+        grp = LoopbackGroup(gd["n"], _t(ptr, dev), _t(ind, dev), world, dev, in_edges=(_t(cp, dev), _t(ci, dev)))
+        for mode in (10, 11, 12):
+            for src in (int(np.argmax(np.diff(ptr))), 3):
+                labels, res, trace = grp.bfs(src, mxvmode=mode, switchpoint=0.02)
+                _check(labels, res, trace, ptr, ind, src, mode, 0.02, csc=(cp, ci))
+
+
+def test_device_loop_long_diameter_and_cap():
+    """more levels than kept level bitmaps (32): later levels label at once; and a max_niter that cuts the loop"""
+    from graphblast_amd.dist import LoopbackGroup
+    from oracle import simple_reference as sr
+    side = 48
+    idx = np.arange(side * side).reshape(side, side)
+    e = np.concatenate([np.stack([idx[:, :-1].ravel(), idx[:, 1:].ravel()]),
+                        np.stack([idx[:-1, :].ravel(), idx[1:, :].ravel()])], axis=1)
+    from graphblast_amd.graphgen import finalize_edges
+    gr = finalize_edges(e[0].astype(np.int64), e[1].astype(np.int64), side * side, symmetrize=True)
+    ptr, ind = gr["csr"]
+    dev = torch.device("cuda", 0)
+    for world in (1, 2, 5):
+        grp = LoopbackGroup(gr["n"], _t(ptr, dev), _t(ind, dev), world, dev)
+        for mode in (10, 11, 12):
+            labels, res, trace = grp.bfs(0, mxvmode=mode, switchpoint=0.01)
+            _check(labels, res, trace, ptr, ind, 0, mode, 0.01)
+            assert res[0]["levels"] > 64
+        want = sr.bfs(ptr, ind, 5)[0]
+        for cap in (1, 2, 7, 40):
+            labels, res, trace = grp.bfs(5, max_niter=cap)
+            assert np.array_equal(labels, np.where(want <= cap, want, 0)), (world, cap)
+            assert res[0]["levels"] == cap and res[0]["hit_cap"] == 1
+            assert res[0]["reached"] == int(np.count_nonzero(np.where(want <= cap, want, 0)))
+
+
+def test_device_loop_ragged_sizes_and_empty_ranks():
+    """n not a multiple of 64, a heavy tail vertex (the advisor's n = 190 case: an interior bound inside a word),
+    and more ranks than the graph can feed (empty ranks)"""
+    from graphblast_amd.dist import LoopbackGroup, partition_bounds
+    from graphblast_amd.graphgen import finalize_edges
+    rng = np.random.default_rng(4)
+    n = 190
+    s = rng.integers(0, n, 600)
+    d = rng.integers(0, n, 600)
+    s = np.concatenate([s, np.full(150, n - 1)])                   # vertex n - 1 is a hub
+    d = np.concatenate([d, rng.integers(0, n - 1, 150)])
+    gr = finalize_edges(s.astype(np.int64), d.astype(np.int64), n, symmetrize=True)
+    ptr, ind = gr["csr"]
+    dev = torch.device("cuda", 0)
+    for world in (2, 4, 8):
+        b = partition_bounds(ptr, world)
+        grp = LoopbackGroup(n, _t(ptr, dev), _t(ind, dev), world, dev)
+        for mode in (10, 11, 12):
+            for src in (0, n - 1, 97):
+                labels, res, trace = grp.bfs(src, mxvmode=mode, switchpoint=0.05)
+                _check(labels, res, trace, ptr, ind, src, mode, 0.05)
+        assert world < 8 or any(b[i] == b[i + 1] for i in range(world))
+
+
+def test_device_loop_one_rank_levels_per_launch():
+    """a world of one rank: one level per launch (what N > 1 runs, minus the collective) and every level in ONE
+    launch give the same labels and trace; Partition1D takes the device loop by itself"""
+    from graphblast_amd.dist import Partition1D
+    gr = _graph(seed=5, scale=16)
+    ptr, ind = gr["csr"]
+    dev = torch.device("cuda", 0)
+    hub = int(np.argmax(np.diff(ptr)))
+    for lpl in (1, 2, 1 << 20):
+        part = Partition1D(gr["n"], _t(ptr, dev), _t(ind, dev), 0, 1, dev, switchpoint=0.02, levels_per_launch=lpl)
+        assert part.device_loop
+        for src in (hub, 123):
+            res = part.bfs(src)
+            labels = part.gather_labels().cpu().numpy()
+            _check(labels, [res], res["trace"], ptr, ind, src, 10, 0.02)
+            if lpl == 1:
+                assert res["launches"] == res["levels"] + 2
+            if lpl == 1 << 20:
+                assert res["launches"] == 1
