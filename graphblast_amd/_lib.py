@@ -111,6 +111,9 @@ _SIGS = {
     "grb_spmm": [_i, _vp, _i, _vp, _vp, _i, _vp],
     "grb_spmm_core_info": [_vp, _i, C.POINTER(_i), C.POINTER(C.c_int64)],
     "grb_spmv_set_bands": [_i],
+    "grb_spmv_set_format": [_i],
+    "grb_spmv_format_info": [_vp, _i, C.POINTER(_i), C.POINTER(C.c_int64), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i),
+                             C.POINTER(_i), C.POINTER(C.c_int64)],
     "grb_sssp_set_nearfar": [_i],
     "grb_sssp_last_order": [],
     "grb_spmv_plan_info": [_vp, _i, _i, C.POINTER(_i), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(_i)],

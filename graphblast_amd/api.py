@@ -577,6 +577,22 @@ def spmv_plan_info(A, tran=0, warm=False):
     return {"bands": bands.value, "band_nnz": bn.value, "pieces": pc.value, "nhot": nhot.value}
 
 
+def spmv_set_format(fmt=-1):
+    """matrix format of the generic SpMV (grb_spmv_set_format): 0 CSR only, 1 auto, 2 column-sorted bands wherever
+    the monoid allows; < 0 only queries"""
+    return int(_lib.load().grb_spmv_set_format(int(fmt)))
+
+
+def spmv_format_info(A, tran=0):
+    """the column-sorted copy of this orientation, if prepared (grb_spmv_format_info)"""
+    used, bands, items, hub, iso = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0)
+    groups, nbytes = C.c_int64(0), C.c_int64(0)
+    _lib.call("grb_spmv_format_info", _h(A), int(bool(tran)), C.byref(used), C.byref(groups), C.byref(bands),
+              C.byref(items), C.byref(hub), C.byref(iso), C.byref(nbytes))
+    return {"in_use": used.value, "groups": groups.value, "bands": bands.value, "items": items.value,
+            "hub_rows": hub.value, "iso": iso.value, "bytes_per_launch": nbytes.value}
+
+
 def k_spmv_bytes(A, tran):
     return int(_lib.load().grb_k_spmv_bytes(_h(A), int(tran)))
 

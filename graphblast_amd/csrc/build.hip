@@ -311,6 +311,34 @@ grb_info grb::device_exclusive_scan_u32(unsigned int* d, long long n) {
   return GRB_SUCCESS;
 }
 
+// Stable sort of n (64-bit key, 32-bit payload) pairs on the context stream, in place: digit positions [0, lo_bits)
+// of the low word and [32, 32 + hi_bits) of the high word (spmv_cband.hpp: entries by (band, column rank)).
+grb_info grb::device_sort_pairs(unsigned long long* d_keys, unsigned int* d_pay, long long n, int lo_bits, int hi_bits) {
+  if (n <= 1) return GRB_SUCCESS;
+  hipStream_t s = ctx().stream;
+  const int nblocks = (int)((n + kSortTile - 1) / kSortTile) + 1;
+  const size_t cnt_elems = 256 * (size_t)nblocks;
+  void* raw = nullptr;
+  GRB_HIP_TRY(hipMalloc(&raw, 12 * (size_t)n + 4 * cnt_elems + 4 * (cnt_elems / kScanTile + 2) + 64));
+  struct Free { void* p; ~Free() { (void)hipFree(p); } } guard{raw};
+  SortBuffers b;
+  char* q = (char*)raw;
+  b.keys[0] = d_keys;
+  b.keys[1] = (unsigned long long*)q; q += 8 * (size_t)n;
+  b.pay[0] = d_pay;
+  b.pay[1] = (unsigned int*)q; q += 4 * (size_t)n;
+  b.cnt = (unsigned int*)q; q += 4 * cnt_elems;
+  b.totals = (unsigned int*)q;
+  int cur = 0;
+  GRB_TRY(radix_sort_pairs(b, &cur, n, lo_bits, hi_bits, s));
+  if (cur != 0) {
+    GRB_HIP_TRY(hipMemcpyAsync(d_keys, b.keys[1], 8 * (size_t)n, hipMemcpyDeviceToDevice, s));
+    GRB_HIP_TRY(hipMemcpyAsync(d_pay, b.pay[1], 4 * (size_t)n, hipMemcpyDeviceToDevice, s));
+  }
+  GRB_HIP_TRY(hipStreamSynchronize(s));
+  return GRB_SUCCESS;
+}
+
 // Columns ranked by reference count, entirely on the device: counts from the transposed orientation's pointer
 // array when there is one (no histogram at all), stable LSD radix sort of (0xffffffff - count, column).
 grb_info grb::device_rank_columns(const Index* d_ind, Index nvals, const Index* d_other_ptr, Index m, Index hot,

@@ -440,6 +440,8 @@ struct SpmvPlan {         // built once per matrix orientation at build()
   Index* d_order = nullptr;  // [nminor] packed position -> original column
   void* d_u2 = nullptr;      // [nminor] packed copy of the input vector
   struct SpmvBands* bands = nullptr;   // column bands with an LDS prefix each (spmv_bands.hpp); null: one prefix
+  struct SpmvCBand* cband = nullptr;   // row bands, entries sorted by column rank, 16-bit coded (spmv_cband.hpp)
+  bool cband_tried = false;
 };
 
 struct CsrArrays {
@@ -593,6 +595,7 @@ void free_spmv_plan(SpmvPlan* plan);
 // build.hip: columns ranked by descending reference count on the device (d_other_ptr: the transposed
 // orientation's pointer array, whose differences ARE the counts; nullptr: histogram of d_ind)
 grb_info device_exclusive_scan_u32(unsigned int* d, long long n);   // build.hip
+grb_info device_sort_pairs(unsigned long long* d_keys, unsigned int* d_pay, long long n, int lo_bits, int hi_bits);   // build.hip
 grb_info device_rank_columns(const Index* d_ind, Index nvals, const Index* d_other_ptr, Index m, Index hot,
                              Index* d_order, Index* d_rank, long long* hot_refs, Index* nreferenced);
 // other_ptr: pointer array of the transposed orientation (length nminor + 1) or nullptr; only read by the
@@ -600,6 +603,9 @@ grb_info device_rank_columns(const Index* d_ind, Index nvals, const Index* d_oth
 grb_info k_spmv(int sr, int dtype, const CsrArrays& M, SpmvPlan& plan, const void* u,
                 const void* mask, int mask_f32, int scmp, int accum, void* w, const Index* other_ptr = nullptr);
 int spmv_bands_setting(int set);   // spmv.hip: 0 = query
+int k_spmv_cband_info(const SpmvPlan& plan, long long* groups, int* bands, int* items, int* hub_rows, int* iso,
+                      long long* bytes_per_launch);   // spmv.hip: 0 when the column-sorted format is not prepared
+int spmv_format_setting(int set);  // spmv.hip: < 0 = query; 0 CSR kernel, 1 auto, 2 column-sorted bands wherever allowed
 grb_info k_spmv_plan_info(const CsrArrays& M, SpmvPlan& plan, const Index* other_ptr, int warm, int* bands,
                           long long* band_nnz, long long* pieces, int* nhot);
 int sssp_nearfar_setting(int set, bool apply);   // sssp_nearfar.hip

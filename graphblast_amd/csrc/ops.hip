@@ -403,6 +403,24 @@ grb_info grb_k_spmv(grb_matrix A, int tran, grb_semiring op, const void* d_u, co
 }
 
 int grb_spmv_set_bands(int k) { return spmv_bands_setting(k); }
+int grb_spmv_set_format(int fmt) { return spmv_format_setting(fmt); }
+
+grb_info grb_spmv_format_info(grb_matrix A, int tran, int* in_use, int64_t* groups, int* bands, int* items, int* hub_rows,
+                              int* iso, int64_t* bytes_per_launch) {
+  if (!A || !A->built) return GRB_UNINITIALIZED_OBJECT;
+  SpmvPlan& plan = tran ? A->plan_csc : A->plan_csr;
+  long long g = 0, by = 0;
+  int b = 0, it = 0, h = 0, is = 0;
+  const int used = k_spmv_cband_info(plan, &g, &b, &it, &h, &is, &by);
+  if (in_use) *in_use = used;
+  if (groups) *groups = g;
+  if (bands) *bands = b;
+  if (items) *items = it;
+  if (hub_rows) *hub_rows = h;
+  if (iso) *iso = is;
+  if (bytes_per_launch) *bytes_per_launch = by;
+  return GRB_SUCCESS;
+}
 int grb_sssp_set_nearfar(int mode) { return sssp_nearfar_setting(mode, mode >= -1); }
 int grb_sssp_last_order(void) { return sssp_last_order(-1); }
 

@@ -60,6 +60,8 @@ __device__ inline void spmv_store(T* w, Index row, T value, const void* mask, in
 
 }  // namespace grb
 #include "spmv_bands.hpp"
+#include "spmv_cband.hpp"
+#include <algorithm>
 namespace grb {
 
 // ---- plan ---------------------------------------------------------------------------
@@ -120,6 +122,7 @@ void free_spmv_plan(SpmvPlan* plan) {
   for (void* q : ptrs)
     if (q) (void)hipFree(q);
   free_spmv_bands(plan->bands);
+  free_spmv_cband(plan->cband);
   *plan = SpmvPlan();
 }
 
@@ -384,8 +387,29 @@ static grb_info prepare_hub_packing(const CsrArrays& M, SpmvPlan& plan, const In
   }
   // columns nobody references sort last and are never gathered: they need no packing
   plan.npacked = nref;
-  GRB_HIP_TRY(hipMalloc(&plan.d_ind2, 4 * (size_t)M.nvals));
   GRB_HIP_TRY(hipMalloc(&plan.d_u2, 4 * (size_t)m));
+  (void)hipFree(d_rank);
+  return GRB_SUCCESS;
+}
+
+// rank[order[i]] = i on the device (columns nobody references keep rank 0: they are never looked up)
+static grb_info column_ranks(const SpmvPlan& plan, Index** d_rank) {
+  const Index m = plan.nminor;
+  GRB_HIP_TRY(hipMalloc(d_rank, 4 * (size_t)m));
+  GRB_HIP_TRY(hipMemsetAsync(*d_rank, 0, 4 * (size_t)m, ctx().stream));
+  hipLaunchKernelGGL(cband_invert_kernel, dim3(ceil_div(plan.npacked, kBlock)), dim3(kBlock), 0, ctx().stream,
+                     (const Index*)plan.d_order, plan.npacked, *d_rank);
+  GRB_HIP_TRY(hipGetLastError());
+  return GRB_SUCCESS;
+}
+
+// The CSR kernel's private copy of the column ids renamed by rank (and the optional column bands), made when that
+// kernel first runs on a hub-packed orientation -- the column-sorted format below has its own coded copy.
+static grb_info ensure_renamed_columns(const CsrArrays& M, SpmvPlan& plan) {
+  if (!plan.d_order || plan.d_ind2 || plan.bands) return GRB_SUCCESS;
+  Index* d_rank = nullptr;
+  GRB_TRY(column_ranks(plan, &d_rank));
+  GRB_HIP_TRY(hipMalloc(&plan.d_ind2, 4 * (size_t)M.nvals));
   hipLaunchKernelGGL(rename_columns_kernel, dim3(stream_grid(M.nvals, kBlock)), dim3(kBlock), 0, ctx().stream,
                      M.ind, M.nvals, d_rank, plan.d_ind2);
   GRB_HIP_TRY(hipStreamSynchronize(ctx().stream));
@@ -397,6 +421,271 @@ static grb_info prepare_hub_packing(const CsrArrays& M, SpmvPlan& plan, const In
     plan.d_ind2 = nullptr;
   }
   return bi == GRB_OUT_OF_MEMORY ? GRB_SUCCESS : bi;        // no room for the second copy: one prefix it is
+}
+
+// ---- column-sorted row bands (spmv_cband.hpp): preparation -----------------------------------------------------
+// 0 = CSR kernel only, 1 = auto (the column-sorted format on hub-packed orientations, commutative monoids),
+// 2 = the column-sorted format wherever the monoid allows it (tests).  GRB_SPMV_FORMAT=csr|auto|cband.
+static int g_spmv_format = -1;
+int spmv_format_setting(int set) {
+  if (g_spmv_format < 0) {
+    const char* e = getenv("GRB_SPMV_FORMAT");
+    g_spmv_format = !e ? 1 : (!strcmp(e, "csr") ? 0 : (!strcmp(e, "cband") ? 2 : 1));
+  }
+  if (set >= 0) g_spmv_format = set > 2 ? 2 : set;
+  return g_spmv_format;
+}
+
+static int cband_bits_for(long long dim) {
+  int b = 1;
+  while (b < 32 && (1ll << b) < dim) ++b;
+  return b;
+}
+
+static grb_info prepare_cband(const CsrArrays& M, SpmvPlan& plan) {
+  plan.cband_tried = true;
+  const Index n = plan.nrows;
+  const long long nnz = M.nvals;
+  if (n <= 0 || nnz <= 0) return GRB_SUCCESS;
+  hipStream_t st = ctx().stream;
+  const int G = ctx().num_cu;
+  SpmvCBand* C = new SpmvCBand();
+  struct Guard { SpmvCBand* c; ~Guard() { free_spmv_cband(c); } } guard{C};
+  std::vector<void*> temp;
+  struct TempGuard { std::vector<void*>& v; ~TempGuard() { for (void* p : v) if (p) (void)hipFree(p); } } tguard{temp};
+  bool oom = false;
+  auto dalloc = [&](size_t bytes, bool keep) -> void* {
+    void* p = nullptr;
+    if (hipMalloc(&p, bytes ? bytes : 4) != hipSuccess) { (void)hipGetLastError(); oom = true; return nullptr; }
+    (keep ? C->owned : temp).push_back(p);
+    return p;
+  };
+  auto upload = [&](const void* h, size_t bytes, bool keep) -> void* {
+    void* d = dalloc(bytes, keep);
+    if (d && bytes && hipMemcpy(d, h, bytes, hipMemcpyHostToDevice) != hipSuccess) { oom = true; return nullptr; }
+    return d;
+  };
+
+  // ---- host: hubs, bands
+  std::vector<Index> ptr((size_t)n + 1);
+  GRB_HIP_TRY(hipMemcpy(ptr.data(), M.ptr, 4 * ((size_t)n + 1), hipMemcpyDeviceToHost));
+  Index hub_above = 0x7fffffff;                          // rows with more entries than this are hubs
+  if (n > kCbRows) {
+    std::vector<Index> deg((size_t)n);
+    for (Index r = 0; r < n; ++r) deg[r] = ptr[(size_t)r + 1] - ptr[r];
+    std::nth_element(deg.begin(), deg.begin() + kCbRows, deg.end(), [](Index x, Index y) { return x > y; });
+    hub_above = deg[kCbRows] > 64 ? deg[kCbRows] : 64;   // at most kCbRows rows are strictly above the (kCbRows+1)-th largest
+  }
+  std::vector<unsigned int> row_band((size_t)n);
+  std::vector<unsigned short> row_loc((size_t)n);
+  std::vector<Index> hub_rows;
+  std::vector<unsigned int> hub_bits(((size_t)n + 31) / 32, 0u);
+  long long hub_entries = 0;
+  for (Index r = 0; r < n; ++r)
+    if (ptr[(size_t)r + 1] - ptr[r] > hub_above) {
+      hub_bits[r >> 5] |= 1u << (r & 31);
+      hub_rows.push_back(r);
+      hub_entries += ptr[(size_t)r + 1] - ptr[r];
+    }
+  const int nhub = (int)hub_rows.size();
+  std::vector<CbBand> bands;
+  std::vector<long long> band_start;                     // sorted position of every band's first entry
+  if (nhub > 0) {
+    bands.push_back(CbBand{0, nhub, 1});
+    band_start.push_back(0);
+  }
+  {
+    long long at = hub_entries, in_band = 0;
+    Index r0 = 0;
+    for (Index r = 0; r < n; ++r) {
+      const bool hub = (hub_bits[r >> 5] >> (r & 31)) & 1u;
+      const Index d = hub ? 0 : ptr[(size_t)r + 1] - ptr[r];
+      if (r > r0 && (r - r0 == kCbRows || in_band + d > (long long)kCbLightGroups * kWave)) {
+        bands.push_back(CbBand{r0, r - r0, 0});
+        band_start.push_back(at);
+        at += in_band;
+        in_band = 0;
+        r0 = r;
+      }
+      in_band += d;
+    }
+    bands.push_back(CbBand{r0, n - r0, 0});
+    band_start.push_back(at);
+    at += in_band;
+    band_start.push_back(at);
+    if (at != nnz) return GRB_PANIC;
+  }
+  const int nbands = (int)bands.size();
+  {
+    int hub_i = 0;
+    for (int b = 0; b < nbands; ++b) {
+      if (bands[b].hub) continue;
+      for (Index r = bands[b].row0; r < bands[b].row0 + bands[b].nrows; ++r) {
+        const bool hub = (hub_bits[r >> 5] >> (r & 31)) & 1u;
+        row_band[r] = hub ? 0u : (unsigned int)b;
+        row_loc[r] = (unsigned short)(hub ? hub_i++ : r - bands[b].row0);
+      }
+    }
+  }
+
+  // ---- device: keys, sort, segments
+  const long long ncols = plan.d_order ? (long long)plan.npacked : (long long)plan.nminor;
+  Index* d_rank = nullptr;
+  if (plan.d_order) {
+    GRB_TRY(column_ranks(plan, &d_rank));
+    temp.push_back(d_rank);
+  }
+  unsigned int* d_row_band = (unsigned int*)upload(row_band.data(), 4 * (size_t)n, false);
+  unsigned short* d_row_loc = (unsigned short*)upload(row_loc.data(), 2 * (size_t)n, false);
+  unsigned long long* d_keys = (unsigned long long*)dalloc(8 * (size_t)nnz, false);
+  unsigned int* d_pay = (unsigned int*)dalloc(4 * (size_t)nnz, false);
+  unsigned short* d_eloc = (unsigned short*)dalloc(2 * (size_t)nnz, false);
+  if (oom) return GRB_OUT_OF_MEMORY;
+  hipLaunchKernelGGL(cband_keys_kernel, dim3(stream_grid((long long)n * kWave, kBlock)), dim3(kBlock), 0, st, M.ptr, M.ind, n,
+                     (const unsigned int*)d_row_band, (const unsigned short*)d_row_loc, (const Index*)d_rank, d_keys, d_pay,
+                     d_eloc);
+  GRB_HIP_TRY(hipGetLastError());
+  {
+    const grb_info si = device_sort_pairs(d_keys, d_pay, nnz, cband_bits_for(ncols), cband_bits_for(nbands));
+    if (si != GRB_SUCCESS) return si == GRB_PANIC ? GRB_OUT_OF_MEMORY : si;     // the sort's scratch did not fit
+  }
+  const int ncb = (int)((ncols + 65535) / 65536);
+  long long* d_band_start = (long long*)upload(band_start.data(), 8 * band_start.size(), false);
+  long long* d_seg = (long long*)dalloc(8 * (size_t)nbands * (size_t)(ncb + 1), false);
+  if (oom) return GRB_OUT_OF_MEMORY;
+  hipLaunchKernelGGL(cband_segments_kernel, dim3(ceil_div((long long)nbands * (ncb + 1), kBlock)), dim3(kBlock), 0, st,
+                     (const unsigned long long*)d_keys, (const long long*)d_band_start, nbands, ncb, d_seg);
+  GRB_HIP_TRY(hipGetLastError());
+  std::vector<long long> seg((size_t)nbands * (size_t)(ncb + 1));
+  GRB_HIP_TRY(hipMemcpy(seg.data(), d_seg, 8 * seg.size(), hipMemcpyDeviceToHost));
+
+  // ---- host: non-empty segments -> groups; the bands' group ranges
+  std::vector<long long> seg_entry, seg_group;
+  std::vector<unsigned int> seg_base;
+  std::vector<long long> band_g((size_t)nbands + 1, 0);
+  long long ngroups = 0;
+  for (int b = 0; b < nbands; ++b) {
+    band_g[b] = ngroups;
+    for (int cb = 0; cb < ncb; ++cb) {
+      const long long e0 = seg[(size_t)b * (ncb + 1) + cb], e1 = seg[(size_t)b * (ncb + 1) + cb + 1];
+      if (e1 <= e0) continue;
+      seg_entry.push_back(e0);
+      seg_group.push_back(ngroups);
+      seg_base.push_back((unsigned int)cb << 16);
+      ngroups += (e1 - e0 + kWave - 1) / kWave;
+    }
+  }
+  band_g[nbands] = ngroups;
+  const int nseg = (int)seg_entry.size();
+  if (nseg == 0 || ngroups <= 0 || ngroups >= (1ll << 31)) return GRB_SUCCESS;
+  seg_entry.push_back(nnz);                               // closes the last segment (segments tile [0, nnz))
+  seg_group.push_back(ngroups);
+  // a segment ends where the next begins, except across bands with empty tails: make the ends explicit
+  std::vector<long long> seg_end_fix = seg_entry;
+  {
+    int si = 0;
+    for (int b = 0; b < nbands; ++b)
+      for (int cb = 0; cb < ncb; ++cb) {
+        const long long e0 = seg[(size_t)b * (ncb + 1) + cb], e1 = seg[(size_t)b * (ncb + 1) + cb + 1];
+        if (e1 <= e0) continue;
+        if (seg_end_fix[(size_t)si + 1] != e1) return GRB_PANIC;   // sorted keys tile the range: cannot happen
+        ++si;
+      }
+  }
+
+  // ---- iso?
+  unsigned int iso_out[2] = {0xffffffffu, 0u};
+  if (M.val) {
+    unsigned int* d_iso = (unsigned int*)upload(iso_out, 8, false);
+    if (oom) return GRB_OUT_OF_MEMORY;
+    hipLaunchKernelGGL(cband_iso_kernel, dim3(stream_grid(nnz, kBlock * 8)), dim3(kBlock), 0, st, (const unsigned int*)M.val, nnz,
+                       d_iso);
+    GRB_HIP_TRY(hipGetLastError());
+    GRB_HIP_TRY(hipMemcpy(iso_out, d_iso, 8, hipMemcpyDeviceToHost));
+  } else {
+    return GRB_SUCCESS;                                   // a matrix without a value array never reaches the generic SpMV
+  }
+  C->iso = iso_out[0] == iso_out[1];
+
+  // ---- device: the coded entries
+  long long* d_seg_entry = (long long*)upload(seg_entry.data(), 8 * seg_entry.size(), false);
+  long long* d_seg_group = (long long*)upload(seg_group.data(), 8 * seg_group.size(), false);
+  unsigned int* d_seg_base = (unsigned int*)upload(seg_base.data(), 4 * seg_base.size(), false);
+  unsigned int* d_pack = (unsigned int*)dalloc(4 * (size_t)ngroups * kWave, true);
+  unsigned int* d_val2 = C->iso ? nullptr : (unsigned int*)dalloc(4 * (size_t)ngroups * kWave, true);
+  unsigned int* d_gbase = (unsigned int*)dalloc(4 * (size_t)ngroups, true);
+  if (oom) return GRB_OUT_OF_MEMORY;
+  hipLaunchKernelGGL(cband_emit_kernel, dim3(stream_grid(ngroups * kWave, kBlock)), dim3(kBlock), 0, st,
+                     (const unsigned long long*)d_keys, (const unsigned int*)d_pay, (const unsigned short*)d_eloc,
+                     (const unsigned int*)M.val, (const long long*)d_seg_entry, (const long long*)d_seg_group,
+                     (const unsigned int*)d_seg_base, nseg, ngroups, d_pack, d_val2, d_gbase);
+  GRB_HIP_TRY(hipGetLastError());
+
+  // ---- items, dealt to the workgroups largest first (LPT)
+  std::vector<CbItem> items;
+  for (int b = 0; b < nbands; ++b) {
+    if (band_g[b + 1] == band_g[b] && bands[b].hub) continue;
+    if (bands[b].hub) {
+      for (long long g = band_g[b]; g < band_g[b + 1]; g += kCbItemGroups)
+        items.push_back(CbItem{b, (int)g, (int)(g + kCbItemGroups < band_g[b + 1] ? g + kCbItemGroups : band_g[b + 1])});
+    } else {
+      items.push_back(CbItem{b, (int)band_g[b], (int)band_g[b + 1]});    // an empty light band still writes its rows
+    }
+  }
+  std::vector<int> order(items.size());
+  for (size_t i = 0; i < items.size(); ++i) order[i] = (int)i;
+  std::stable_sort(order.begin(), order.end(), [&](int x, int y) {
+    return items[x].g1 - items[x].g0 > items[y].g1 - items[y].g0;
+  });
+  std::vector<long long> load((size_t)G, 0);
+  std::vector<std::vector<int>> mine((size_t)G);
+  for (int id : order) {
+    int best = 0;
+    for (int g = 1; g < G; ++g)
+      if (load[g] < load[best]) best = g;
+    // every item also costs the clearing and writing of its band's slice
+    load[best] += (long long)(items[id].g1 - items[id].g0) + bands[items[id].band].nrows / kWave / 4 + 1;
+    mine[best].push_back(id);
+  }
+  std::vector<CbItem> dealt;
+  std::vector<int> wg_ptr((size_t)G + 1, 0), wg_slot((size_t)G, -1);
+  int nslots = 0;
+  for (int g = 0; g < G; ++g) {
+    wg_ptr[g] = (int)dealt.size();
+    std::stable_sort(mine[g].begin(), mine[g].end(), [&](int x, int y) {
+      const int hx = bands[items[x].band].hub, hy = bands[items[y].band].hub;
+      if (hx != hy) return hx > hy;                       // the hub items first, consecutive: one slice, one flush
+      return items[x].g0 < items[y].g0;
+    });
+    for (int id : mine[g]) dealt.push_back(items[id]);
+    if (!mine[g].empty() && bands[items[mine[g][0]].band].hub) wg_slot[g] = nslots++;
+  }
+  wg_ptr[G] = (int)dealt.size();
+
+  CbArgs& A = C->args;
+  A.bands = (const CbBand*)upload(bands.data(), sizeof(CbBand) * bands.size(), true);
+  A.items = (const CbItem*)upload(dealt.data(), sizeof(CbItem) * dealt.size(), true);
+  A.wg_ptr = (const int*)upload(wg_ptr.data(), 4 * wg_ptr.size(), true);
+  A.wg_slot = (const int*)upload(wg_slot.data(), 4 * wg_slot.size(), true);
+  A.pack = d_pack;
+  A.val = d_val2;
+  A.gbase = d_gbase;
+  A.hub_rows = (const Index*)upload(hub_rows.data(), 4 * hub_rows.size(), true);
+  A.hub_bits = (const unsigned int*)upload(hub_bits.data(), 4 * hub_bits.size(), true);
+  A.iso_bits = iso_out[0];
+  A.nhub = nhub;
+  if (nslots > 0) C->d_partials = dalloc(8 * (size_t)nslots * (size_t)nhub, true);   // accumulators of <= 8 bytes
+  if (oom) return GRB_OUT_OF_MEMORY;
+  GRB_HIP_TRY(hipStreamSynchronize(st));
+  C->grid = G;
+  C->nbands = nbands;
+  C->nitems = (int)dealt.size();
+  C->nslots = nslots;
+  C->ngroups = ngroups;
+  C->entries = nnz;
+  plan.cband = C;
+  guard.c = nullptr;
+  return GRB_SUCCESS;
 }
 
 // Epilogue shared by the SpMV kernels: mask -> identity where the mask FAILS
@@ -576,6 +865,16 @@ __global__ __launch_bounds__(kHubThreads) void spmv_hub_kernel(
 #undef GRB_HUB_LDS_INDEX
 }
 
+// true commutative monoids only: the column-sorted format sums a row in column-rank order, by atomics
+template <int SR>
+constexpr bool cband_monoid_ok() {
+  if constexpr (SR == GRB_RUNTIME_SR) return false;
+  else {
+    constexpr int op = MonoidTraits<SemiringTraits<SR>::monoid>::op;
+    return op == OP_PLUS || op == OP_TIMES || op == OP_MIN || op == OP_MAX || op == OP_LOR || op == OP_LAND;
+  }
+}
+
 grb_info k_spmv(int sr, int dtype, const CsrArrays& M, SpmvPlan& plan, const void* u, const void* mask,
                 int mask_f32, int scmp, int accum, void* w, const Index* other_ptr) {
   if (plan.ntiles == 0 && M.nvals > 0) return GRB_INVALID_OBJECT;   // nonzeros but no plan: never a silent no-op
@@ -590,6 +889,39 @@ grb_info k_spmv(int sr, int dtype, const CsrArrays& M, SpmvPlan& plan, const voi
       GRB_HIP_TRY(hipGetLastError());
       return GRB_SUCCESS;
     }
+    const int fmt = spmv_format_setting(-1);
+    if constexpr (cband_monoid_ok<SR>()) {
+      if (fmt == 2 || (fmt == 1 && plan.d_order)) {
+        if (!plan.cband && !plan.cband_tried) {
+          const grb_info pi = prepare_cband(M, plan);
+          if (pi != GRB_SUCCESS && pi != GRB_OUT_OF_MEMORY) return pi;     // no room for the second copy: CSR it is
+        }
+        if (plan.cband) {
+          SpmvCBand& C = *plan.cband;
+          const T* uu = (const T*)u;
+          if (plan.d_order) {
+            hipLaunchKernelGGL((pack_vector_kernel<T>), dim3(ceil_div(plan.npacked, kBlock)), dim3(kBlock), 0,
+                               ctx().stream, (const T*)u, plan.d_order, plan.npacked, (T*)plan.d_u2);
+            uu = (const T*)plan.d_u2;
+          }
+          if (C.iso)
+            hipLaunchKernelGGL((spmv_cband_kernel<SR, T, true>), dim3(C.grid), dim3(kCbThreads), 0, ctx().stream, C.args, uu,
+                               mask, mask_f32, scmp, accum, (T*)w, C.d_partials);
+          else
+            hipLaunchKernelGGL((spmv_cband_kernel<SR, T, false>), dim3(C.grid), dim3(kCbThreads), 0, ctx().stream, C.args, uu,
+                               mask, mask_f32, scmp, accum, (T*)w, C.d_partials);
+          GRB_HIP_TRY(hipGetLastError());
+          if (C.args.nhub > 0) {
+            hipLaunchKernelGGL((spmv_cband_hub_kernel<SR, T>), dim3(ceil_div(C.args.nhub, kBlock)), dim3(kBlock), 0,
+                               ctx().stream, (const void*)C.d_partials, C.nslots, C.args.nhub, C.args.hub_rows, mask, mask_f32,
+                               scmp, accum, (T*)w);
+            GRB_HIP_TRY(hipGetLastError());
+          }
+          return GRB_SUCCESS;
+        }
+      }
+    }
+    GRB_TRY(ensure_renamed_columns(M, plan));
     const Index* ind = M.ind;
     const T* uu = (const T*)u;
     if (plan.d_ind2 || plan.bands) {
@@ -627,9 +959,27 @@ grb_info k_spmv(int sr, int dtype, const CsrArrays& M, SpmvPlan& plan, const voi
   });
 }
 
+// the column-sorted format of this orientation, if it has been prepared: what one launch streams (coded entries,
+// values unless iso, group bases; the packed vector written and read; the result; the hub band's partial slices)
+int k_spmv_cband_info(const SpmvPlan& plan, long long* groups, int* bands, int* items, int* hub_rows, int* iso,
+                      long long* bytes_per_launch) {
+  if (!plan.cband) return 0;
+  const SpmvCBand& C = *plan.cband;
+  *groups = C.ngroups;
+  *bands = C.nbands;
+  *items = C.nitems;
+  *hub_rows = C.args.nhub;
+  *iso = C.iso ? 1 : 0;
+  const long long per_group = (C.iso ? 256 : 512) + 4;
+  *bytes_per_launch = C.ngroups * per_group + 4ll * plan.nrows + (plan.d_order ? 12ll * plan.npacked : 4ll * plan.nminor) +
+                      8ll * C.nslots * C.args.nhub;
+  return 1;
+}
+
 grb_info k_spmv_plan_info(const CsrArrays& M, SpmvPlan& plan, const Index* other_ptr, int warm, int* bands,
                           long long* band_nnz, long long* pieces, int* nhot) {
   if (warm && M.nvals > 0 && !plan.hub_ready) GRB_TRY(prepare_hub_packing(M, plan, other_ptr));
+  if (warm && M.nvals > 0 && spmv_format_setting(-1) == 0) GRB_TRY(ensure_renamed_columns(M, plan));
   *bands = plan.bands ? plan.bands->args.k : (plan.hub_ready && plan.nhot > 0 ? 1 : 0);
   *band_nnz = plan.bands ? plan.bands->band_nnz : 0;
   *pieces = plan.bands ? plan.bands->pieces : 0;

@@ -384,6 +384,19 @@ grb_info grb_spmv_plan_info(grb_matrix A, int tran, int warm, int* bands, int64_
  * (the default; the environment variable GRB_SPMV_BANDS sets the initial value).  k <= 0 only queries.  Returns
  * the value in force.  Plans already prepared keep their layout. */
 int grb_spmv_set_bands(int k);
+/* Which matrix format the generic SpMV multiplies from (csrc/spmv_cband.hpp; GRB_SPMV_FORMAT=csr|auto|cband sets the
+ * initial value): 0 the CSR arrays only; 1 (default) a second, column-sorted copy -- row bands of <= 32 Ki rows
+ * whose entries are sorted by column rank and coded in 16 + 16 bits, values dropped when all equal -- on
+ * orientations whose columns are skewed enough for the hub packing, for the commutative monoids (plus, times,
+ * min, max, or, and); 2 that format wherever the monoid allows it.  fmt < 0 only queries.  Returns the value in
+ * force.  grb_spmv_format_info reports the prepared copy of an orientation: groups of 64 coded entries (padding
+ * included), bands, work items, rows in the hub band, whether the values are stored (iso = 0) and the bytes one
+ * launch moves by design.  Results: identical for integer data and the idempotent monoids; float sums are formed
+ * in column-rank order by atomics (within rounding of the CSR kernel's, not bit-reproducible run to run).
+ * Replaces mgpu::SpmvCsrBinary (backend/cuda/spmv.hpp:178-220) as the CSR kernel does. */
+int grb_spmv_set_format(int fmt);
+grb_info grb_spmv_format_info(grb_matrix A, int tran, int* in_use, int64_t* groups, int* bands, int* items,
+                              int* hub_rows, int* iso, int64_t* bytes_per_launch);
 
 /* Which order grb_sssp (and algorithm::sssp through the shadow header) relaxes in on eligible matrices:
  *   -1 (default)  the work-efficient near / far order (csrc/sssp_nearfar.hip) for graphs with fewer than 8 stored

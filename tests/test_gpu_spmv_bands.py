@@ -15,6 +15,8 @@ def banded():
     from graphblast_amd.graphgen import rmat_edges, finalize_edges
     dev = torch.device("cuda", 0)
     before = g.spmv_set_bands(0)
+    fmt_before = g.spmv_set_format(-1)
+    g.spmv_set_format(0)                                   # the CSR kernel (the column-sorted format would take these products)
     g.spmv_set_bands(8)                                    # off by default: on for this module's plans
     src, dst, n = rmat_edges(19, 16, seed=5, device=dev)
     gr = finalize_edges(src, dst, n, symmetrize=True)
@@ -32,7 +34,8 @@ def banded():
         out["A_" + name] = A
         out["v_" + name] = vals
     g.spmv_set_bands(before)
-    return out
+    yield out
+    g.spmv_set_format(fmt_before)
 
 
 def _rows(b):

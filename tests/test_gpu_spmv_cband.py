@@ -1,0 +1,216 @@
+"""The SpMV's column-sorted band format (csrc/spmv_cband.hpp) against the textbook definition on the host: exactly
+for integer-valued data and the idempotent monoids, within north_star's 1e-5 for float sums (a row is summed in
+column-rank order by atomics).  Power-law matrices take the format by themselves; small, rectangular and
+road-like ones are forced into it (grb_spmv_set_format(2)) so that one band / many column blocks / no hub band /
+natural column order are all walked."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+FMAX = np.finfo(np.float32).max
+
+
+@pytest.fixture(scope="module")
+def forced():
+    import graphblast_amd as g
+    before = g.spmv_set_format(-1)
+    g.spmv_set_format(2)
+    yield g
+    g.spmv_set_format(before)
+
+
+def _matrix(g, torch, dev, nrows, ncols, ptr, ind, vals):
+    tp = torch.from_numpy(np.ascontiguousarray(ptr, dtype=np.int32)).to(dev)
+    ti = torch.from_numpy(np.ascontiguousarray(ind, dtype=np.int32)).to(dev)
+    tv = torch.from_numpy(np.ascontiguousarray(vals)).to(dev)
+    A = g.Matrix(nrows, ncols, dtype=vals.dtype.type)
+    assert A.build_device_csr(tp.data_ptr(), ti.data_ptr(), tv.data_ptr(), int(ind.size), keep=(tp, ti, tv)) == 0
+    return A
+
+
+def _run(g, torch, dev, A, nrows, op, u, mask=None, scmp=0, accum=0, w0=None):
+    tu = torch.from_numpy(u).to(dev)
+    tw = torch.from_numpy(w0.copy()).to(dev) if w0 is not None else torch.full((nrows,), -7, dtype=tu.dtype, device=dev)
+    tm = torch.from_numpy(mask).to(dev) if mask is not None else None
+    assert g.k_spmv(A, 0, op, tu.data_ptr(), tm.data_ptr() if tm is not None else None, scmp, accum, tw.data_ptr()) == 0
+    torch.cuda.synchronize()
+    return tw.cpu().numpy()
+
+
+def _reference(ptr, ind, vals, u, op, nrows):
+    rows = np.repeat(np.arange(nrows), np.diff(ptr))
+    a, x = vals, u[ind]
+    nonempty = np.diff(ptr) > 0
+    starts = ptr[:-1][nonempty]
+    if op == "PlusMultiplies":
+        return np.bincount(rows, weights=a.astype(np.float64) * x.astype(np.float64), minlength=nrows)
+    if op == "MinimumPlus":
+        prod, red, ident = a + x, np.minimum, FMAX if vals.dtype != np.int32 else np.iinfo(np.int32).max
+    elif op == "MaximumMultiplies":
+        prod, red, ident = a * x, np.maximum, 0
+    elif op == "LogicalOrAnd":
+        prod, red, ident = ((a != 0) & (x != 0)).astype(vals.dtype), np.maximum, 0
+    elif op == "MinimumSelectSecond":
+        prod, red, ident = x.copy(), np.minimum, FMAX if vals.dtype != np.int32 else np.iinfo(np.int32).max
+    else:
+        raise AssertionError(op)
+    want = np.full(nrows, ident, dtype=vals.dtype)
+    want[nonempty] = red.reduceat(prod.astype(vals.dtype), starts)
+    return want
+
+
+@pytest.fixture(scope="module")
+def powerlaw():
+    import torch
+    import graphblast_amd as g
+    from graphblast_amd.graphgen import rmat_edges, finalize_edges
+    dev = torch.device("cuda", 0)
+    assert g.spmv_set_format(-1) == 1                      # the default: auto
+    src, dst, n = rmat_edges(19, 16, seed=5, device=dev)
+    gr = finalize_edges(src, dst, n, symmetrize=True)
+    ptr, ind = gr["csr"][0].cpu().numpy(), gr["csr"][1].cpu().numpy()
+    rng = np.random.default_rng(11)
+    out = {"g": g, "torch": torch, "dev": dev, "n": n, "ptr": ptr, "ind": ind}
+    for name, vals in (("int", rng.integers(1, 4, ind.size).astype(np.float32)),
+                       ("f", rng.random(ind.size, dtype=np.float32) + 0.25),
+                       ("iso", np.ones(ind.size, dtype=np.float32)),
+                       ("i32", rng.integers(1, 9, ind.size).astype(np.int32))):
+        out["A_" + name] = _matrix(g, torch, dev, n, n, ptr, ind, vals)
+        out["v_" + name] = vals
+    return out
+
+
+def test_power_law_matrix_takes_the_format_by_itself(powerlaw):
+    b = powerlaw
+    g = b["g"]
+    u = np.random.default_rng(1).integers(0, 3, b["n"]).astype(np.float32)
+    got = _run(g, b["torch"], b["dev"], b["A_int"], b["n"], "PlusMultiplies", u)
+    assert np.array_equal(got, _reference(b["ptr"], b["ind"], b["v_int"], u, "PlusMultiplies", b["n"]).astype(np.float32))
+    info = g.spmv_format_info(b["A_int"], 0)
+    assert info["in_use"] == 1 and info["hub_rows"] > 0 and info["bands"] >= 2 and info["iso"] == 0, info
+    assert info["groups"] * 64 >= b["ind"].size and info["groups"] * 64 < 1.05 * b["ind"].size     # padding stays small
+    # all values equal: the value array is not stored at all
+    got = _run(g, b["torch"], b["dev"], b["A_iso"], b["n"], "PlusMultiplies", u)
+    assert np.array_equal(got, _reference(b["ptr"], b["ind"], b["v_iso"], u, "PlusMultiplies", b["n"]).astype(np.float32))
+    iso = g.spmv_format_info(b["A_iso"], 0)
+    assert iso["iso"] == 1 and iso["bytes_per_launch"] < 0.62 * info["bytes_per_launch"], (iso, info)
+
+
+def test_float_sums_within_tolerance(powerlaw):
+    b = powerlaw
+    u = np.random.default_rng(2).random(b["n"], dtype=np.float32)
+    got = _run(b["g"], b["torch"], b["dev"], b["A_f"], b["n"], "PlusMultiplies", u)
+    want = _reference(b["ptr"], b["ind"], b["v_f"], u, "PlusMultiplies", b["n"])
+    assert np.allclose(got, want, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("op", ["MinimumPlus", "MaximumMultiplies", "LogicalOrAnd", "MinimumSelectSecond"])
+def test_idempotent_monoids_exact(powerlaw, op):
+    b = powerlaw
+    rng = np.random.default_rng(3)
+    u = (rng.random(b["n"], dtype=np.float32) * 8).astype(np.float32)
+    u[rng.random(b["n"]) < 0.3] = 0.0
+    got = _run(b["g"], b["torch"], b["dev"], b["A_f"], b["n"], op, u)
+    assert np.array_equal(got, _reference(b["ptr"], b["ind"], b["v_f"], u, op, b["n"]))
+
+
+@pytest.mark.parametrize("op", ["PlusMultiplies", "MinimumPlus", "MinimumSelectSecond"])
+def test_int32_exact(powerlaw, op):
+    b = powerlaw
+    u = np.random.default_rng(4).integers(0, 50, b["n"]).astype(np.int32)
+    got = _run(b["g"], b["torch"], b["dev"], b["A_i32"], b["n"], op, u)
+    want = _reference(b["ptr"], b["ind"], b["v_i32"], u, op, b["n"])
+    assert np.array_equal(got, want.astype(np.int32))
+
+
+@pytest.mark.parametrize("scmp,accum", [(0, 0), (1, 0), (0, 1), (1, 1)])
+def test_mask_and_accumulate(powerlaw, scmp, accum):
+    b = powerlaw
+    rng = np.random.default_rng(5)
+    u = rng.integers(0, 3, b["n"]).astype(np.float32)
+    mask = (rng.random(b["n"]) < 0.5).astype(np.float32)
+    w0 = rng.integers(0, 5, b["n"]).astype(np.float32)
+    got = _run(b["g"], b["torch"], b["dev"], b["A_int"], b["n"], "PlusMultiplies", u, mask=mask, scmp=scmp, accum=accum, w0=w0)
+    full = _reference(b["ptr"], b["ind"], b["v_int"], u, "PlusMultiplies", b["n"]).astype(np.float32)
+    want = np.where((mask != 0) != bool(scmp), full, np.float32(0))
+    if accum:
+        want = w0 + want
+    assert np.array_equal(got, want)
+
+
+def test_comparison_monoids_keep_the_csr_kernel(powerlaw):
+    """the comparison "monoids" of stddef.hpp depend on the order of a row's products: they stay on the CSR kernel,
+    whose results the 17-semiring test of test_gpu_ops.py pins; here: same answer with the format on and off"""
+    b = powerlaw
+    g = b["g"]
+    u = np.random.default_rng(6).integers(0, 4, b["n"]).astype(np.float32)
+    on = _run(g, b["torch"], b["dev"], b["A_int"], b["n"], "GreaterPlus", u)
+    before = g.spmv_set_format(-1)
+    g.spmv_set_format(0)
+    try:
+        off = _run(g, b["torch"], b["dev"], b["A_int"], b["n"], "GreaterPlus", u)
+        plus_off = _run(g, b["torch"], b["dev"], b["A_int"], b["n"], "PlusMultiplies", u)
+    finally:
+        g.spmv_set_format(before)
+    assert np.array_equal(on, off)
+    assert np.array_equal(plus_off, _reference(b["ptr"], b["ind"], b["v_int"], u, "PlusMultiplies", b["n"]).astype(np.float32))
+
+
+def _random_csr(rng, nrows, ncols, avg, empty_frac=0.2, heavy=()):
+    deg = rng.poisson(avg, nrows)
+    deg[rng.random(nrows) < empty_frac] = 0
+    for r, d in heavy:
+        deg[r] = d
+    deg = np.minimum(deg, ncols)
+    ptr = np.zeros(nrows + 1, dtype=np.int64)
+    ptr[1:] = np.cumsum(deg)
+    ind = np.concatenate([np.sort(rng.choice(ncols, d, replace=False)) for d in deg]) if ptr[-1] else np.zeros(0, np.int64)
+    return ptr.astype(np.int32), ind.astype(np.int32)
+
+
+@pytest.mark.parametrize("shape", [(1, 1), (37, 5), (300, 70001), (5000, 140000), (40000, 3000), (70000, 70000)])
+def test_forced_format_on_small_and_rectangular_matrices(forced, shape):
+    """one band / several bands without hubs / a hub band by row count alone / more than one 65536-column block /
+    empty rows at both ends / a row holding every column"""
+    import torch
+    g = forced
+    dev = torch.device("cuda", 0)
+    nrows, ncols = shape
+    rng = np.random.default_rng(nrows * 7 + ncols)
+    heavy = [(nrows // 2, ncols)] if nrows > 30 else []
+    if nrows > 35000:
+        heavy += [(int(r), 200) for r in rng.choice(nrows, 50, replace=False) if r != nrows // 2]
+    ptr, ind = _random_csr(rng, nrows, ncols, 6, heavy=heavy)
+    if ind.size == 0:
+        ptr, ind = np.array([0] + [1] * nrows, dtype=np.int32), np.zeros(1, dtype=np.int32)
+    vals = rng.integers(1, 5, ind.size).astype(np.float32)
+    A = _matrix(g, torch, dev, nrows, ncols, ptr, ind, vals)
+    u = rng.integers(0, 4, ncols).astype(np.float32)
+    for op in ("PlusMultiplies", "MinimumPlus", "LogicalOrAnd"):
+        got = _run(g, torch, dev, A, nrows, op, u)
+        assert np.array_equal(got, _reference(ptr, ind, vals, u, op, nrows).astype(np.float32)), (shape, op)
+    info = g.spmv_format_info(A, 0)
+    assert info["in_use"] == 1, info
+    if nrows > 35000:
+        assert info["hub_rows"] >= 1
+
+
+def test_forced_format_on_a_road_like_grid(forced):
+    import torch
+    g = forced
+    dev = torch.device("cuda", 0)
+    side = 300
+    idx = np.arange(side * side).reshape(side, side)
+    e = np.concatenate([np.stack([idx[:, :-1].ravel(), idx[:, 1:].ravel()]),
+                        np.stack([idx[:-1, :].ravel(), idx[1:, :].ravel()])], axis=1)
+    from graphblast_amd.graphgen import finalize_edges
+    gr = finalize_edges(e[0].astype(np.int64), e[1].astype(np.int64), side * side, symmetrize=True)
+    ptr, ind = gr["csr"]
+    n = side * side
+    rng = np.random.default_rng(9)
+    vals = (rng.integers(1, 65, ind.size)).astype(np.float32)
+    A = _matrix(g, torch, dev, n, n, ptr, ind, vals)
+    u = rng.integers(0, 100, n).astype(np.float32)
+    for op in ("PlusMultiplies", "MinimumPlus"):
+        assert np.array_equal(_run(g, torch, dev, A, n, op, u), _reference(ptr, ind, vals, u, op, n).astype(np.float32))
+    assert g.spmv_format_info(A, 0)["hub_rows"] == 0
