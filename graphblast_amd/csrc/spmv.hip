@@ -494,13 +494,31 @@ static grb_info prepare_cband(const CsrArrays& M, SpmvPlan& plan) {
     bands.push_back(CbBand{0, nhub, 1});
     band_start.push_back(0);
   }
+  // Light bands are sized so that a whole number of them is one workgroup's share: the hub band gets the
+  // workgroups its cost asks for (a light entry costs more than a hub entry, see the dealing below), the light
+  // rows' entries are split evenly over the rest, and a share that does not fit kCbRows rows is cut into k equal
+  // bands -- then the equal-cost cuts of the dealing fall on band boundaries and few bands need partial slices.
+  static const int light_weight = getenv("GRB_CB_LIGHT_WEIGHT") ? atoi(getenv("GRB_CB_LIGHT_WEIGHT")) : 17;   // hub = 10
+  long long band_entries_max = (long long)kCbLightGroups * kWave;
+  {
+    const long long light_entries = nnz - hub_entries;
+    const double hub_cost = 10.0 * (double)hub_entries, light_cost = (double)light_weight * (double)light_entries;
+    int wg_hub = nhub > 0 ? (int)(G * hub_cost / (hub_cost + light_cost) + 0.5) : 0;
+    if (nhub > 0 && wg_hub < 1) wg_hub = 1;
+    if (wg_hub > G - 1) wg_hub = G - 1;
+    const long long share = light_entries / (G - wg_hub) + 1;                 // entries per light workgroup
+    const double rows_per_share = (double)share * (double)(n - nhub) / (double)(light_entries > 0 ? light_entries : 1);
+    const int k = (int)(rows_per_share / (0.97 * kCbRows)) + 1;
+    if (share / k + 1 < band_entries_max) band_entries_max = share / k + 1;
+    if (band_entries_max < 64 * kWave) band_entries_max = 64 * kWave;
+  }
   {
     long long at = hub_entries, in_band = 0;
     Index r0 = 0;
     for (Index r = 0; r < n; ++r) {
       const bool hub = (hub_bits[r >> 5] >> (r & 31)) & 1u;
       const Index d = hub ? 0 : ptr[(size_t)r + 1] - ptr[r];
-      if (r > r0 && (r - r0 == kCbRows || in_band + d > (long long)kCbLightGroups * kWave)) {
+      if (r > r0 && (r - r0 == kCbRows || in_band + d > band_entries_max)) {
         bands.push_back(CbBand{r0, r - r0, 0});
         band_start.push_back(at);
         at += in_band;
@@ -529,12 +547,20 @@ static grb_info prepare_cband(const CsrArrays& M, SpmvPlan& plan) {
   }
 
   // ---- device: keys, sort, segments
-  const long long ncols = plan.d_order ? (long long)plan.npacked : (long long)plan.nminor;
+  // column codes: the hot prefix of the rank order (<= 512 Ki columns, packed per launch: 6 MB instead of the whole
+  // vector's 50), then every column under its own id -- past the prefix a band's list is as sparse in rank order
+  // as in natural order, so packing the tail buys no locality
+  unsigned int nhot = 0;
   Index* d_rank = nullptr;
   if (plan.d_order) {
     GRB_TRY(column_ranks(plan, &d_rank));
     temp.push_back(d_rank);
+    const unsigned int want = ((unsigned int)plan.npacked + 65535u) & ~65535u;
+    nhot = want < 8u * 65536u ? want : 8u * 65536u;
+    hipLaunchKernelGGL(cband_codes_kernel, dim3(ceil_div(plan.nminor, kBlock)), dim3(kBlock), 0, st, d_rank, plan.nminor, nhot);
+    GRB_HIP_TRY(hipGetLastError());
   }
+  const long long ncols = (long long)nhot + (long long)plan.nminor;
   unsigned int* d_row_band = (unsigned int*)upload(row_band.data(), 4 * (size_t)n, false);
   unsigned short* d_row_loc = (unsigned short*)upload(row_loc.data(), 2 * (size_t)n, false);
   unsigned long long* d_keys = (unsigned long long*)dalloc(8 * (size_t)nnz, false);
@@ -560,7 +586,7 @@ static grb_info prepare_cband(const CsrArrays& M, SpmvPlan& plan) {
   GRB_HIP_TRY(hipMemcpy(seg.data(), d_seg, 8 * seg.size(), hipMemcpyDeviceToHost));
 
   // ---- host: non-empty segments -> groups; the bands' group ranges
-  std::vector<long long> seg_entry, seg_group;
+  std::vector<long long> seg_entry, seg_group, seg_band_g0;
   std::vector<unsigned int> seg_base;
   std::vector<long long> band_g((size_t)nbands + 1, 0);
   long long ngroups = 0;
@@ -572,8 +598,10 @@ static grb_info prepare_cband(const CsrArrays& M, SpmvPlan& plan) {
       seg_entry.push_back(e0);
       seg_group.push_back(ngroups);
       seg_base.push_back((unsigned int)cb << 16);
+      seg_band_g0.push_back(band_g[b]);
       ngroups += (e1 - e0 + kWave - 1) / kWave;
     }
+    ngroups = band_g[b] + (ngroups - band_g[b] + kCbChunk - 1) / kCbChunk * kCbChunk;   // whole chunks: the tail is padding
   }
   band_g[nbands] = ngroups;
   const int nseg = (int)seg_entry.size();
@@ -610,63 +638,120 @@ static grb_info prepare_cband(const CsrArrays& M, SpmvPlan& plan) {
   // ---- device: the coded entries
   long long* d_seg_entry = (long long*)upload(seg_entry.data(), 8 * seg_entry.size(), false);
   long long* d_seg_group = (long long*)upload(seg_group.data(), 8 * seg_group.size(), false);
+  long long* d_seg_band_g0 = (long long*)upload(seg_band_g0.data(), 8 * seg_band_g0.size(), false);
   unsigned int* d_seg_base = (unsigned int*)upload(seg_base.data(), 4 * seg_base.size(), false);
-  unsigned int* d_pack = (unsigned int*)dalloc(4 * (size_t)ngroups * kWave, true);
-  unsigned int* d_val2 = C->iso ? nullptr : (unsigned int*)dalloc(4 * (size_t)ngroups * kWave, true);
+  // (a wave step reads whole 4-group chunks: room for the last chunk to run past the last group)
+  unsigned int* d_pack = (unsigned int*)dalloc(4 * (size_t)(ngroups + kCbChunk) * kWave, true);
+  unsigned int* d_val2 = C->iso ? nullptr : (unsigned int*)dalloc(4 * (size_t)(ngroups + kCbChunk) * kWave, true);
   unsigned int* d_gbase = (unsigned int*)dalloc(4 * (size_t)ngroups, true);
   if (oom) return GRB_OUT_OF_MEMORY;
   hipLaunchKernelGGL(cband_emit_kernel, dim3(stream_grid(ngroups * kWave, kBlock)), dim3(kBlock), 0, st,
                      (const unsigned long long*)d_keys, (const unsigned int*)d_pay, (const unsigned short*)d_eloc,
                      (const unsigned int*)M.val, (const long long*)d_seg_entry, (const long long*)d_seg_group,
-                     (const unsigned int*)d_seg_base, nseg, ngroups, d_pack, d_val2, d_gbase);
+                     (const unsigned int*)d_seg_base, (const long long*)d_seg_band_g0, nseg, ngroups, d_pack, d_val2, d_gbase);
   GRB_HIP_TRY(hipGetLastError());
 
-  // ---- items, dealt to the workgroups largest first (LPT)
-  std::vector<CbItem> items;
-  for (int b = 0; b < nbands; ++b) {
-    if (band_g[b + 1] == band_g[b] && bands[b].hub) continue;
-    if (bands[b].hub) {
-      for (long long g = band_g[b]; g < band_g[b + 1]; g += kCbItemGroups)
-        items.push_back(CbItem{b, (int)g, (int)(g + kCbItemGroups < band_g[b + 1] ? g + kCbItemGroups : band_g[b + 1])});
-    } else {
-      items.push_back(CbItem{b, (int)band_g[b], (int)band_g[b + 1]});    // an empty light band still writes its rows
-    }
-  }
-  std::vector<int> order(items.size());
-  for (size_t i = 0; i < items.size(); ++i) order[i] = (int)i;
-  std::stable_sort(order.begin(), order.end(), [&](int x, int y) {
-    return items[x].g1 - items[x].g0 > items[y].g1 - items[y].g0;
-  });
-  std::vector<long long> load((size_t)G, 0);
-  std::vector<std::vector<int>> mine((size_t)G);
-  for (int id : order) {
-    int best = 0;
-    for (int g = 1; g < G; ++g)
-      if (load[g] < load[best]) best = g;
-    // every item also costs the clearing and writing of its band's slice
-    load[best] += (long long)(items[id].g1 - items[id].g0) + bands[items[id].band].nrows / kWave / 4 + 1;
-    mine[best].push_back(id);
-  }
+  // ---- items: the bands' groups form one sequence (hub band first); it is cut into one piece of equal COST per
+  // workgroup -- a light band's group costs more than the hub band's: its column-sorted list is sparser, so its
+  // gathers touch more lines (GRB_SPMV_TRACE, ticks per group per workgroup: 3.3 against 2.0) -- so every
+  // workgroup walks consecutive groups (consecutive columns) and at most its first and last band are shared with
+  // a neighbour.  A band that several workgroups share is accumulated in partial slices, folded by the second kernel.
+  auto weight = [&](int b) { return (long long)(bands[b].hub ? 10 : light_weight); };
+  auto fixed = [&](int b) { return (long long)bands[b].nrows / 4 + 40; };        // clearing and writing the slice
+  long long total_cost = 0;
+  for (int b = 0; b < nbands; ++b) total_cost += (band_g[b + 1] - band_g[b]) * weight(b) + fixed(b);
   std::vector<CbItem> dealt;
-  std::vector<int> wg_ptr((size_t)G + 1, 0), wg_slot((size_t)G, -1);
-  int nslots = 0;
-  for (int g = 0; g < G; ++g) {
-    wg_ptr[g] = (int)dealt.size();
-    std::stable_sort(mine[g].begin(), mine[g].end(), [&](int x, int y) {
-      const int hx = bands[items[x].band].hub, hy = bands[items[y].band].hub;
-      if (hx != hy) return hx > hy;                       // the hub items first, consecutive: one slice, one flush
-      return items[x].g0 < items[y].g0;
-    });
-    for (int id : mine[g]) dealt.push_back(items[id]);
-    if (!mine[g].empty() && bands[items[mine[g][0]].band].hub) wg_slot[g] = nslots++;
+  std::vector<int> item_wg;
+  std::vector<int> wg_ptr((size_t)G + 1, 0);
+  // one pass of the cutting for a given share; returns the largest load any workgroup ends up with
+  auto deal = [&](long long target) -> long long {
+    dealt.clear();
+    item_wg.clear();
+    int wg = 0;
+    long long acc = 0, worst = 0;
+    for (int b = 0; b < nbands; ++b) {
+      long long g = band_g[b];
+      const long long band_cost = (band_g[b + 1] - g) * weight(b) + fixed(b);
+      if (g == band_g[b + 1]) {                            // no entries: a light band still writes its rows
+        if (!bands[b].hub) { dealt.push_back(CbItem{b, (int)g, (int)g, -1}); item_wg.push_back(wg); acc += fixed(b); }
+        continue;
+      }
+      // a band that nearly fits is not started here, one that nearly ends is finished here: whole bands where possible
+      const long long slack = (band_cost < target ? band_cost : target) / 6;
+      if (wg < G - 1 && acc > 0 && target - acc < band_cost && target - acc < slack) { worst = acc > worst ? acc : worst; ++wg; acc = 0; }
+      while (g < band_g[b + 1]) {
+        long long take = band_g[b + 1] - g;
+        if (wg < G - 1) {
+          long long room = (target - acc - fixed(b)) / weight(b);
+          room = room / kCbChunk * kCbChunk;
+          if (room < kCbChunk) room = kCbChunk;
+          if (room < take && (take - room) * weight(b) > slack) take = room;
+        }
+        dealt.push_back(CbItem{b, (int)g, (int)(g + take), -1});
+        item_wg.push_back(wg);
+        acc += take * weight(b) + fixed(b);
+        g += take;
+        if (acc >= target && wg < G - 1) { worst = acc > worst ? acc : worst; ++wg; acc = 0; }
+      }
+    }
+    return acc > worst ? acc : worst;
+  };
+  // the per-item fixed costs and the snapping are not in total_cost / G: try shares up to 1.6 x that, keep the best
+  {
+    const long long base = total_cost / G + 1;
+    long long best_target = base, best = -1;
+    for (int k = 0; k <= 60; ++k) {
+      const long long t = base + base * k / 100;
+      const long long worst = deal(t);
+      if (best < 0 || worst < best) { best = worst; best_target = t; }
+    }
+    (void)deal(best_target);
   }
-  wg_ptr[G] = (int)dealt.size();
+  {
+    size_t i = 0;
+    C->wg_groups.clear(); C->wg_hub_groups.clear(); C->wg_items.clear();
+    for (int g = 0; g < G; ++g) {
+      wg_ptr[g] = (int)i;
+      int gr = 0, hg = 0, ni = 0;
+      while (i < dealt.size() && item_wg[i] == g) {
+        gr += dealt[i].g1 - dealt[i].g0;
+        if (bands[dealt[i].band].hub) hg += dealt[i].g1 - dealt[i].g0;
+        ++ni; ++i;
+      }
+      C->wg_groups.push_back(gr); C->wg_hub_groups.push_back(hg); C->wg_items.push_back(ni);
+    }
+    wg_ptr[G] = (int)dealt.size();
+  }
+  // partial slices for the bands more than one workgroup works on
+  std::vector<int> fin_band, fin_ptr(1, 0), fin_off;
+  long long partial_elems = 0;
+  int max_fin_rows = 0;
+  for (size_t i = 0; i < dealt.size();) {
+    size_t j = i;
+    while (j < dealt.size() && dealt[j].band == dealt[i].band) ++j;
+    if (j - i > 1) {
+      const int b = dealt[i].band;
+      fin_band.push_back(b);
+      for (size_t k = i; k < j; ++k) {
+        dealt[k].slot_off = (int)partial_elems;
+        fin_off.push_back((int)partial_elems);
+        partial_elems += bands[b].nrows;
+      }
+      fin_ptr.push_back((int)fin_off.size());
+      if (bands[b].nrows > max_fin_rows) max_fin_rows = bands[b].nrows;
+    }
+    i = j;
+  }
+  if (partial_elems >= (1ll << 31)) return GRB_SUCCESS;
+  const int nslots = (int)fin_off.size();
 
   CbArgs& A = C->args;
   A.bands = (const CbBand*)upload(bands.data(), sizeof(CbBand) * bands.size(), true);
   A.items = (const CbItem*)upload(dealt.data(), sizeof(CbItem) * dealt.size(), true);
   A.wg_ptr = (const int*)upload(wg_ptr.data(), 4 * wg_ptr.size(), true);
-  A.wg_slot = (const int*)upload(wg_slot.data(), 4 * wg_slot.size(), true);
+  A.fin_band = (const int*)upload(fin_band.data(), 4 * fin_band.size(), true);
+  A.fin_ptr = (const int*)upload(fin_ptr.data(), 4 * fin_ptr.size(), true);
+  A.fin_off = (const int*)upload(fin_off.data(), 4 * fin_off.size(), true);
   A.pack = d_pack;
   A.val = d_val2;
   A.gbase = d_gbase;
@@ -674,10 +759,14 @@ static grb_info prepare_cband(const CsrArrays& M, SpmvPlan& plan) {
   A.hub_bits = (const unsigned int*)upload(hub_bits.data(), 4 * hub_bits.size(), true);
   A.iso_bits = iso_out[0];
   A.nhub = nhub;
-  if (nslots > 0) C->d_partials = dalloc(8 * (size_t)nslots * (size_t)nhub, true);   // accumulators of <= 8 bytes
+  if (partial_elems > 0) C->d_partials = dalloc(8 * (size_t)partial_elems, true);   // accumulators of <= 8 bytes
+  C->nfin = (int)fin_band.size();
+  C->max_fin_rows = max_fin_rows;
+  C->partial_elems = partial_elems;
   if (oom) return GRB_OUT_OF_MEMORY;
   GRB_HIP_TRY(hipStreamSynchronize(st));
   C->grid = G;
+  C->nhot = nhot;
   C->nbands = nbands;
   C->nitems = (int)dealt.size();
   C->nslots = nslots;
@@ -898,24 +987,48 @@ grb_info k_spmv(int sr, int dtype, const CsrArrays& M, SpmvPlan& plan, const voi
         }
         if (plan.cband) {
           SpmvCBand& C = *plan.cband;
-          const T* uu = (const T*)u;
-          if (plan.d_order) {
-            hipLaunchKernelGGL((pack_vector_kernel<T>), dim3(ceil_div(plan.npacked, kBlock)), dim3(kBlock), 0,
-                               ctx().stream, (const T*)u, plan.d_order, plan.npacked, (T*)plan.d_u2);
-            uu = (const T*)plan.d_u2;
+          if (C.nhot > 0) {
+            const Index np = plan.npacked < (Index)C.nhot ? plan.npacked : (Index)C.nhot;
+            hipLaunchKernelGGL((cband_pack_kernel<T>), dim3(ceil_div(np, kBlock)), dim3(kBlock), 0, ctx().stream, (const T*)u,
+                               (const Index*)plan.d_order, np, (T*)plan.d_u2);
+          }
+          static const bool want_trace = getenv("GRB_SPMV_TRACE") != nullptr;
+          unsigned long long* d_trace = nullptr;
+          if (want_trace) {
+            void* p_tr;
+            GRB_TRY(scratch(10, 16 * (size_t)C.grid, &p_tr));
+            d_trace = (unsigned long long*)p_tr;
           }
           if (C.iso)
-            hipLaunchKernelGGL((spmv_cband_kernel<SR, T, true>), dim3(C.grid), dim3(kCbThreads), 0, ctx().stream, C.args, uu,
-                               mask, mask_f32, scmp, accum, (T*)w, C.d_partials);
+            hipLaunchKernelGGL((spmv_cband_kernel<SR, T, true>), dim3(C.grid), dim3(kCbThreads), 0, ctx().stream, C.args,
+                               (const T*)plan.d_u2, (const T*)u, C.nhot, mask, mask_f32, scmp, accum, (T*)w, C.d_partials, d_trace);
           else
-            hipLaunchKernelGGL((spmv_cband_kernel<SR, T, false>), dim3(C.grid), dim3(kCbThreads), 0, ctx().stream, C.args, uu,
-                               mask, mask_f32, scmp, accum, (T*)w, C.d_partials);
+            hipLaunchKernelGGL((spmv_cband_kernel<SR, T, false>), dim3(C.grid), dim3(kCbThreads), 0, ctx().stream, C.args,
+                               (const T*)plan.d_u2, (const T*)u, C.nhot, mask, mask_f32, scmp, accum, (T*)w, C.d_partials, d_trace);
           GRB_HIP_TRY(hipGetLastError());
-          if (C.args.nhub > 0) {
-            hipLaunchKernelGGL((spmv_cband_hub_kernel<SR, T>), dim3(ceil_div(C.args.nhub, kBlock)), dim3(kBlock), 0,
-                               ctx().stream, (const void*)C.d_partials, C.nslots, C.args.nhub, C.args.hub_rows, mask, mask_f32,
-                               scmp, accum, (T*)w);
+          if (C.nfin > 0) {
+            hipLaunchKernelGGL((spmv_cband_fold_kernel<SR, T>), dim3(ceil_div(C.max_fin_rows, kWave), C.nfin), dim3(kBlock), 0,
+                               ctx().stream, C.args, (const void*)C.d_partials, mask, mask_f32, scmp, accum, (T*)w);
             GRB_HIP_TRY(hipGetLastError());
+          }
+          if (want_trace) {                                  // per-workgroup wall clock of the main kernel
+            std::vector<unsigned long long> h(2 * (size_t)C.grid);
+            GRB_HIP_TRY(hipMemcpy(h.data(), d_trace, 16 * (size_t)C.grid, hipMemcpyDeviceToHost));
+            unsigned long long t0 = ~0ull, t1 = 0;
+            double sum = 0, mx = 0, mn = 1e30;
+            for (int g = 0; g < C.grid; ++g) {
+              t0 = h[2 * g] < t0 ? h[2 * g] : t0;
+              t1 = h[2 * g + 1] > t1 ? h[2 * g + 1] : t1;
+              const double d = (double)(h[2 * g + 1] - h[2 * g]);
+              sum += d; mx = d > mx ? d : mx; mn = d < mn ? d : mn;
+            }
+            fprintf(stderr, "spmv_cband_kernel workgroups (wall-clock ticks, 100 MHz): span %llu, busy min %.0f mean %.0f max %.0f\n",
+                    t1 - t0, mn, sum / C.grid, mx);
+            static int dumped = 0;
+            if (atoi(getenv("GRB_SPMV_TRACE")) >= 2 && dumped++ == 2)
+              for (int g = 0; g < C.grid; ++g)
+                fprintf(stderr, "  wg %3d items %d groups %6d of which hub %6d: start %6llu ticks %6llu\n", g, C.wg_items[g],
+                        C.wg_groups[g], C.wg_hub_groups[g], h[2 * g] - t0, h[2 * g + 1] - h[2 * g]);
           }
           return GRB_SUCCESS;
         }
@@ -971,8 +1084,10 @@ int k_spmv_cband_info(const SpmvPlan& plan, long long* groups, int* bands, int* 
   *hub_rows = C.args.nhub;
   *iso = C.iso ? 1 : 0;
   const long long per_group = (C.iso ? 256 : 512) + 4;
-  *bytes_per_launch = C.ngroups * per_group + 4ll * plan.nrows + (plan.d_order ? 12ll * plan.npacked : 4ll * plan.nminor) +
-                      8ll * C.nslots * C.args.nhub;
+  // coded entries (+ values) + bases; the result; the input vector once + the hot prefix's pack (order, gather,
+  // store); the hub band's partial slices written and read
+  *bytes_per_launch = C.ngroups * per_group + 4ll * plan.nrows + 4ll * plan.nminor + 12ll * C.nhot +
+                      16ll * C.partial_elems;
   return 1;
 }
 

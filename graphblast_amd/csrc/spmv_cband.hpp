@@ -39,10 +39,16 @@ namespace grb {
 constexpr int kCbThreads = 1024;
 constexpr int kCbWaves = kCbThreads / kWave;
 constexpr int kCbRows = 16384;            // rows per band: 16 Ki accumulators of <= 8 bytes = 128 KiB of LDS
-constexpr int kCbItemGroups = 4096;       // groups per work item of the hub band
+#ifndef GRB_CB_ITEM_GROUPS
+#define GRB_CB_ITEM_GROUPS 4096
+#endif
+constexpr int kCbItemGroups = GRB_CB_ITEM_GROUPS;   // groups per work item of the hub band
 constexpr int kCbLightGroups = 16384;     // a light band is cut when it reaches this many groups
 constexpr unsigned int kCbPad = 0x8000u;
-constexpr int kCbUnroll = 8;              // groups a wave has in flight
+#ifndef GRB_CB_UNROLL
+#define GRB_CB_UNROLL 8
+#endif
+constexpr int kCbUnroll = GRB_CB_UNROLL;  // groups of one pipeline stage of a wave
 
 struct CbBand {
   int row0, nrows;                        // light: rows [row0, row0 + nrows); hub: the hub list [0, nrows)
@@ -51,13 +57,16 @@ struct CbBand {
 struct CbItem {
   int band;
   int g0, g1;                             // groups
-};
+  int slot_off;                           // -1: the band is this workgroup's alone (rows written directly); else
+};                                        // the element offset of its partial slice
 
 struct CbArgs {
   const CbBand* bands;
   const CbItem* items;                    // grouped by workgroup; a workgroup's hub items are consecutive
   const int* wg_ptr;                      // [grid + 1]
-  const int* wg_slot;                     // [grid] partial slot of the workgroup's hub items, -1: none
+  const int* fin_band;                    // bands several workgroups share ...
+  const int* fin_ptr;                     // ... their partial slices [fin_ptr[f], fin_ptr[f + 1]) ...
+  const int* fin_off;                     // ... as element offsets
   const unsigned int* pack;               // [ngroups * 64]
   const void* val;                        // [ngroups * 64], null for an iso matrix
   const unsigned int* gbase;              // [ngroups]
@@ -67,12 +76,16 @@ struct CbArgs {
   int nhub;
 };
 
+
 struct SpmvCBand {
   CbArgs args;
-  int grid = 0, nbands = 0, nitems = 0, nslots = 0;
+  unsigned int nhot = 0;                  // column codes below this index the packed hot prefix (plan.d_u2)
+  int grid = 0, nbands = 0, nitems = 0, nslots = 0, nfin = 0, max_fin_rows = 0;
+  long long partial_elems = 0;
   long long ngroups = 0, entries = 0;
   bool iso = false;
   void* d_partials = nullptr;             // [nslots][nhub]
+  std::vector<int> wg_groups, wg_hub_groups, wg_items;   // per workgroup, for GRB_SPMV_TRACE
   std::vector<void*> owned;
 };
 
@@ -121,15 +134,19 @@ __global__ void cband_segments_kernel(const unsigned long long* __restrict__ key
   out[t] = lo;
 }
 
-// one wave per group: the coded entries, their values, the group's base
+// one wave per group: the coded entries, their values, the group's base.  Inside a chunk of four groups (chunks are
+// aligned to the band's first group; bands hold whole chunks) the entries are stored TRANSPOSED: lane L's 16-byte
+// word holds entry L of each of the four groups, so a lane streams 16 bytes while gather instruction k of a wave
+// still covers the 64 consecutive entries of group k (few lines) and the group's base is wave-uniform.
 __global__ __launch_bounds__(kBlock) void cband_emit_kernel(const unsigned long long* __restrict__ keys,
                                                             const unsigned int* __restrict__ pay,
                                                             const unsigned short* __restrict__ eloc,
                                                             const unsigned int* __restrict__ val /* nullable */,
                                                             const long long* __restrict__ seg_entry /* [nseg + 1] */,
                                                             const long long* __restrict__ seg_group /* [nseg + 1] */,
-                                                            const unsigned int* __restrict__ seg_base, int nseg,
-                                                            long long ngroups, unsigned int* __restrict__ pack,
+                                                            const unsigned int* __restrict__ seg_base,
+                                                            const long long* __restrict__ seg_band_g0 /* first group of the segment's band */,
+                                                            int nseg, long long ngroups, unsigned int* __restrict__ pack,
                                                             unsigned int* __restrict__ val2, unsigned int* __restrict__ gbase) {
   const int lane = lane_id();
   const long long nwaves = (long long)gridDim.x * kWavesPerBlock;
@@ -139,16 +156,20 @@ __global__ __launch_bounds__(kBlock) void cband_emit_kernel(const unsigned long 
       const int mid = (lo + hi + 1) >> 1;
       if (seg_group[mid] <= g) lo = mid; else hi = mid - 1;
     }
+    // groups past the segment's last one are the band's padding up to a whole chunk
     const long long q = seg_entry[lo] + (g - seg_group[lo]) * kWave + lane;
-    const bool valid = q < seg_entry[lo + 1];
+    const long long seg_groups = (seg_entry[lo + 1] - seg_entry[lo] + kWave - 1) / kWave;
+    const bool valid = g - seg_group[lo] < seg_groups && q < seg_entry[lo + 1];
     unsigned int pk = kCbPad, v = 0;
     if (valid) {
       const unsigned int p = pay[q];
       pk = (((unsigned int)(keys[q] & 0xffffffffull) - seg_base[lo]) << 16) | (unsigned int)eloc[p];
       if (val) v = val[p];
     }
-    pack[g * kWave + lane] = pk;
-    if (val2) val2[g * kWave + lane] = v;
+    const long long rel = g - seg_band_g0[lo];
+    const long long at = (seg_band_g0[lo] + (rel & ~3ll)) * kWave + (long long)lane * 4 + (rel & 3ll);
+    pack[at] = pk;
+    if (val2) val2[at] = v;
     if (lane == 0) gbase[g] = seg_base[lo];
   }
 }
@@ -185,9 +206,25 @@ __device__ inline void cband_combine(A* addr, T v) {
   if constexpr (op == OP_PLUS) {
     atomicAdd(addr, (A)v);                             // ds_add_f64 / ds_add_u32
   } else if constexpr (op == OP_MIN) {
-    if (v < *addr) atomicMin(addr, v);
+    // floats through the integer unit (ds_min_i32 / ds_max_u32: IEEE order is integer order for v >= 0 and the
+    // reverse unsigned order below); a NaN product fails the test and is dropped, as fminf drops it
+    if (v < *addr) {
+      if constexpr (std::is_same<T, float>::value) {
+        if (v >= 0.f) atomicMin(reinterpret_cast<int*>(addr), __float_as_int(v));
+        else atomicMax(reinterpret_cast<unsigned int*>(addr), __float_as_uint(v));
+      } else {
+        atomicMin(addr, v);
+      }
+    }
   } else if constexpr (op == OP_MAX) {
-    if (v > *addr) atomicMax(addr, v);
+    if (v > *addr) {
+      if constexpr (std::is_same<T, float>::value) {
+        if (v >= 0.f) atomicMax(reinterpret_cast<int*>(addr), __float_as_int(v));
+        else atomicMin(reinterpret_cast<unsigned int*>(addr), __float_as_uint(v));
+      } else {
+        atomicMax(addr, v);
+      }
+    }
   } else if constexpr (op == OP_LOR) {
     if (v != (T)0) *addr = (T)1;                       // idempotent store: benign race
   } else if constexpr (op == OP_LAND) {
@@ -207,10 +244,20 @@ __device__ inline void cband_combine(A* addr, T v) {
   }
 }
 
+// One lane takes one entry of each of FOUR groups (one 16-byte load of the coded words, one of the values; the
+// chunk is stored transposed, see cband_emit_kernel): 4-byte loads reach 4.4 TB/s on this stream, and the guide
+// prices 8-byte accesses at 0.54-0.70 of the 16-byte rate.
+constexpr int kCbChunk = 4;               // groups per chunk
+constexpr int kCbStage = 2;               // chunks per pipeline stage of a wave
+
+typedef unsigned int CbWord4 __attribute__((ext_vector_type(4)));
+
 template <int SR, typename T, bool kIso>
-__global__ __launch_bounds__(kCbThreads) void spmv_cband_kernel(CbArgs a, const T* __restrict__ u,
+__global__ __launch_bounds__(kCbThreads) void spmv_cband_kernel(CbArgs a, const T* __restrict__ u_hot,
+                                                                const T* __restrict__ u_nat, unsigned int nhot,
                                                                 const void* __restrict__ mask, int mask_f32, int scmp,
-                                                                int accum, T* w, void* __restrict__ partials_raw) {
+                                                                int accum, T* w, void* __restrict__ partials_raw,
+                                                                unsigned long long* __restrict__ trace) {
   typedef Semiring<SR, T> S;
   typedef typename CbAcc<S::monoid, T>::type Acc;
   __shared__ unsigned long long ys_raw[kCbRows];
@@ -219,73 +266,166 @@ __global__ __launch_bounds__(kCbThreads) void spmv_cband_kernel(CbArgs a, const 
   const int tid = threadIdx.x, lane = tid & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int i0 = a.wg_ptr[blockIdx.x], i1 = a.wg_ptr[blockIdx.x + 1];
-  const T* __restrict__ val = reinterpret_cast<const T*>(a.val);
+  const CbWord4* __restrict__ pack4 = reinterpret_cast<const CbWord4*>(a.pack);
+  const CbWord4* __restrict__ val4 = reinterpret_cast<const CbWord4*>(a.val);
+  const CbWord4* __restrict__ gbase4 = reinterpret_cast<const CbWord4*>(a.gbase);
+  if (trace && tid == 0) trace[2 * blockIdx.x] = wall_clock64();
   T iso;
   memcpy(&iso, &a.iso_bits, 4);
-  int cur = -1;
   CbBand B = {0, 0, 0};
-  auto flush = [&]() {
+  auto flush = [&](int slot_off) {
     __syncthreads();
-    if (B.hub) {
-      Acc* out = partials + (size_t)a.wg_slot[blockIdx.x] * (size_t)a.nhub;
+    if (slot_off >= 0) {
+      Acc* out = partials + slot_off;
       for (int i = tid; i < B.nrows; i += kCbThreads) out[i] = ys[i];
     } else {
       for (int i = tid; i < B.nrows; i += kCbThreads) {
-        const Index row = B.row0 + i;
-        if (!((a.hub_bits[row >> 5] >> (row & 31)) & 1u)) spmv_store<SR, T>(w, row, (T)ys[i], mask, mask_f32, scmp, accum);
+        const Index row = B.hub ? a.hub_rows[i] : B.row0 + i;
+        if (B.hub || !((a.hub_bits[row >> 5] >> (row & 31)) & 1u)) spmv_store<SR, T>(w, row, (T)ys[i], mask, mask_f32, scmp, accum);
       }
     }
     __syncthreads();
   };
+  // a column code below nhot is a position in the packed hot prefix; above, nhot + the column itself
+  auto gather = [&](unsigned int code) -> T {
+#if defined(GRB_CB_EXP_NOGATHER)   // isolating experiment (tools/spmv_cband_variants.sh): every gather hits one hot KiB
+    return u_hot[code & 255u];
+#else
+    const T* p = code < nhot ? u_hot + code : u_nat + (code - nhot);
+    return *p;
+#endif
+  };
   for (int it = i0; it < i1; ++it) {
-    const CbItem I = a.items[it];
-    if (I.band != cur) {
-      if (cur >= 0) flush();
-      B = a.bands[I.band];
-      cur = I.band;
-      for (int i = tid; i < B.nrows; i += kCbThreads) ys[i] = (Acc)S::identity();
-      __syncthreads();
-    }
-    for (int g = I.g0 + wave; g < I.g1; g += kCbWaves * kCbUnroll) {
-      unsigned int pk[kCbUnroll], base[kCbUnroll];
-      T av[kCbUnroll], x[kCbUnroll];
-#pragma unroll
-      for (int k = 0; k < kCbUnroll; ++k) {
-        const int gg = g + k * kCbWaves;
-        const int gc = gg < I.g1 ? gg : I.g1 - 1;
-        pk[k] = stream_load(&a.pack[(size_t)gc * kWave + lane]);
-        if (!kIso) av[k] = stream_load(&val[(size_t)gc * kWave + lane]);
-        base[k] = a.gbase[gc];
-        if (gg >= I.g1) pk[k] = kCbPad;
-      }
-#pragma unroll
-      for (int k = 0; k < kCbUnroll; ++k) x[k] = u[base[k] + (pk[k] >> 16)];
-#pragma unroll
-      for (int k = 0; k < kCbUnroll; ++k)
-        if (!(pk[k] & kCbPad)) cband_combine<S::monoid, T, Acc>(&ys[pk[k] & 0x7fffu], S::mul(kIso ? iso : av[k], x[k]));
-    }
+    const CbItem I = a.items[it];                        // one run of one band: clear, accumulate, write
+    B = a.bands[I.band];
+    for (int i = tid; i < B.nrows; i += kCbThreads) ys[i] = (Acc)S::identity();
+    __syncthreads();
+    // Three stages in flight per wave, two chunks each: the coded entries (and values) of step i + 2 are streaming
+    // in while the gathers of step i + 1 are outstanding and step i is accumulated -- the only waits on memory are
+    // for loads issued two steps earlier.
+    const int nch = (I.g1 - I.g0 + kCbChunk - 1) / kCbChunk;
+    constexpr int kStep = kCbWaves * kCbStage;
+    CbWord4 pk0[kCbStage], pk1[kCbStage], av0[kCbStage], av1[kCbStage];
+    CbWord4 base0[kCbStage], base1[kCbStage];       // the four groups' bases: wave-uniform
+    T x0[kCbStage][4];
+#define GRB_CB_STREAM(C, PK, AV, BASE)                                                          \
+  _Pragma("unroll") for (int k = 0; k < kCbStage; ++k) {                                         \
+    const int cc = (C) + k * kCbWaves;                                                           \
+    const int cl = cc < nch ? cc : nch - 1;                                                      \
+    const size_t at = ((size_t)(I.g0 + kCbChunk * cl) * kWave) / 4 + lane;                       \
+    (PK)[k] = __builtin_nontemporal_load(&pack4[at]);                                            \
+    if (!kIso) (AV)[k] = __builtin_nontemporal_load(&val4[at]);                                  \
+    (BASE)[k] = gbase4[(I.g0 + kCbChunk * cl) / 4];                                              \
+    if (cc >= nch) (PK)[k] = CbWord4{kCbPad, kCbPad, kCbPad, kCbPad};                            \
   }
-  if (cur >= 0) flush();
+#define GRB_CB_GATHER(PK, BASE, X)                                   \
+  _Pragma("unroll") for (int k = 0; k < kCbStage; ++k) {              \
+    (X)[k][0] = gather((BASE)[k].x + ((PK)[k].x >> 16));             \
+    (X)[k][1] = gather((BASE)[k].y + ((PK)[k].y >> 16));             \
+    (X)[k][2] = gather((BASE)[k].z + ((PK)[k].z >> 16));             \
+    (X)[k][3] = gather((BASE)[k].w + ((PK)[k].w >> 16));             \
+  }
+    auto accumulate = [&](unsigned int pk, unsigned int vbits, T x) {
+      if (pk & kCbPad) return;
+      T av;
+      memcpy(&av, &vbits, 4);
+      const T prod = S::mul(kIso ? iso : av, x);
+#if defined(GRB_CB_EXP_NOATOMIC)   // isolating experiment: the products are consumed without touching the LDS slice
+      if (prod == (T)12345) ys[pk & 0x7fffu] = (Acc)1;
+#else
+      cband_combine<S::monoid, T, Acc>(&ys[pk & 0x7fffu], prod);
+#endif
+    };
+    int c = wave;
+    if (c < nch) {
+      GRB_CB_STREAM(c, pk0, av0, base0)
+      asm volatile("" ::: "memory");
+      GRB_CB_STREAM(c + kStep, pk1, av1, base1)
+      asm volatile("" ::: "memory");
+      GRB_CB_GATHER(pk0, base0, x0)
+      for (; c < nch; c += kStep) {
+        CbWord4 pk2[kCbStage], av2[kCbStage], base2[kCbStage];
+        T x1[kCbStage][4];
+        asm volatile("" ::: "memory");
+        GRB_CB_STREAM(c + 2 * kStep, pk2, av2, base2)
+        asm volatile("" ::: "memory");
+        GRB_CB_GATHER(pk1, base1, x1)
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int k = 0; k < kCbStage; ++k) {
+          accumulate(pk0[k].x, av0[k].x, x0[k][0]);
+          accumulate(pk0[k].y, av0[k].y, x0[k][1]);
+          accumulate(pk0[k].z, av0[k].z, x0[k][2]);
+          accumulate(pk0[k].w, av0[k].w, x0[k][3]);
+        }
+#pragma unroll
+        for (int k = 0; k < kCbStage; ++k) {
+          pk0[k] = pk1[k]; base0[k] = base1[k];
+          pk1[k] = pk2[k]; base1[k] = base2[k];
+          if (!kIso) { av0[k] = av1[k]; av1[k] = av2[k]; }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) x0[k][j] = x1[k][j];
+        }
+      }
+    }
+#undef GRB_CB_STREAM
+#undef GRB_CB_GATHER
+    flush(I.slot_off);
+  }
+  if (trace && tid == 0) trace[2 * blockIdx.x + 1] = wall_clock64();
 }
 
-// the hub band's rows: partial slices folded in slot order, then the epilogue
+// the rows of the bands several workgroups worked on: partial slices folded in slot order by four lanes per row,
+// then the epilogue.  blockIdx.y = shared band, blockIdx.x = 64 of its rows.
 template <int SR, typename T>
-__global__ __launch_bounds__(kBlock) void spmv_cband_hub_kernel(const void* __restrict__ partials_raw, int nslots, int nhub,
-                                                                const Index* __restrict__ hub_rows,
-                                                                const void* __restrict__ mask, int mask_f32, int scmp,
-                                                                int accum, T* w) {
+__global__ __launch_bounds__(kBlock) void spmv_cband_fold_kernel(CbArgs a, const void* __restrict__ partials_raw,
+                                                                 const void* __restrict__ mask, int mask_f32, int scmp,
+                                                                 int accum, T* w) {
   typedef Semiring<SR, T> S;
   typedef typename CbAcc<S::monoid, T>::type Acc;
   const Acc* __restrict__ partials = reinterpret_cast<const Acc*>(partials_raw);
-  const int i = blockIdx.x * kBlock + threadIdx.x;
-  if (i >= nhub) return;
+  const int f = blockIdx.y;
+  const CbBand B = a.bands[a.fin_band[f]];
+  if ((int)blockIdx.x * kWave >= B.nrows) return;
+  const int s0 = a.fin_ptr[f], s1 = a.fin_ptr[f + 1];
+  const int l = threadIdx.x & (kWave - 1), q = threadIdx.x >> 6;     // wave q takes slots s0 + q, s0 + q + 4, ...
+  const int i = blockIdx.x * kWave + l;
+  __shared__ unsigned long long s_part[kWavesPerBlock][kWave];
   Acc acc = (Acc)S::identity();
-  for (int s = 0; s < nslots; ++s) {
-    const Acc p = partials[(size_t)s * nhub + i];
-    if constexpr (std::is_same<Acc, T>::value) acc = S::add(acc, p);
-    else acc += p;
+  if (i < B.nrows)
+    for (int s = s0 + q; s < s1; s += kWavesPerBlock) {
+      const Acc p = partials[(size_t)a.fin_off[s] + i];
+      if constexpr (std::is_same<Acc, T>::value) acc = S::add(acc, p);
+      else acc += p;
+    }
+  *reinterpret_cast<Acc*>(&s_part[q][l]) = acc;
+  __syncthreads();
+  if (q == 0 && i < B.nrows) {
+    Acc tot = acc;
+    for (int k = 1; k < kWavesPerBlock; ++k) {
+      const Acc p = *reinterpret_cast<Acc*>(&s_part[k][l]);
+      if constexpr (std::is_same<Acc, T>::value) tot = S::add(tot, p);
+      else tot += p;
+    }
+    const Index row = B.hub ? a.hub_rows[i] : B.row0 + i;
+    if (B.hub || !((a.hub_bits[row >> 5] >> (row & 31)) & 1u)) spmv_store<SR, T>(w, row, (T)tot, mask, mask_f32, scmp, accum);
   }
-  spmv_store<SR, T>(w, hub_rows[i], (T)acc, mask, mask_f32, scmp, accum);
+}
+
+// the hot prefix of the packed vector: u_hot[i] = u[order[i]] for the nhot most referenced columns
+template <typename T>
+__global__ void cband_pack_kernel(const T* __restrict__ u, const Index* __restrict__ order, Index nhot, T* __restrict__ u_hot) {
+  const Index i = (Index)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < nhot) u_hot[i] = u[order[i]];
+}
+
+// column -> code: its rank when that is below nhot, else nhot + the column itself
+__global__ void cband_codes_kernel(Index* __restrict__ rank_to_code, Index m, unsigned int nhot) {
+  const Index c = (Index)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < m) {
+    const unsigned int r = (unsigned int)rank_to_code[c];
+    rank_to_code[c] = (Index)(r < nhot ? r : nhot + (unsigned int)c);
+  }
 }
 
 }  // namespace grb

@@ -93,7 +93,7 @@ def test_power_law_matrix_takes_the_format_by_itself(powerlaw):
     got = _run(g, b["torch"], b["dev"], b["A_iso"], b["n"], "PlusMultiplies", u)
     assert np.array_equal(got, _reference(b["ptr"], b["ind"], b["v_iso"], u, "PlusMultiplies", b["n"]).astype(np.float32))
     iso = g.spmv_format_info(b["A_iso"], 0)
-    assert iso["iso"] == 1 and iso["bytes_per_launch"] < 0.62 * info["bytes_per_launch"], (iso, info)
+    assert iso["iso"] == 1 and iso["bytes_per_launch"] < 0.8 * info["bytes_per_launch"], (iso, info)
 
 
 def test_float_sums_within_tolerance(powerlaw):
