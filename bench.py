@@ -426,24 +426,55 @@ def main():
             extra["bfs_total"]["reference_direction_rule_only"] = {"value": e0 / el0, "unit": "TEPS",
                                                                    "ms_per_step": el0 / args.steps * 1e3}
 
-        # ---- generic SpMV kernel on the same graph (the metric's second half)
+        # ---- generic SpMV kernel on the same graph (the metric's second half).  The traversal's matrix is a
+        #      pattern (every stored value 1, as the reference's readMtx leaves a pattern file): the column-sorted
+        #      format (csrc/spmv_cband.hpp) then stores no values at all ("iso"); the same product with random
+        #      values is timed next to it, and the CSR kernel of rounds 1-2 (grb_spmv_set_format(0)) as the yardstick.
+        #      `frac` is always quoted on the REFERENCE's bytes (CSR: 8 nnz + 12 n + 4); the format's own bytes per
+        #      launch and the fraction on those stand beside it.
         x = torch.rand(n, dtype=torch.float32, device=dev)
         y = torch.empty(n, dtype=torch.float32, device=dev)
         torch.cuda.synchronize()
-        for _ in range(3):
-            assert g.k_spmv(A, 0, "PlusMultiplies", x.data_ptr(), None, 0, 0, y.data_ptr()) == 0
-        reps = 20
-        g.timer_start()
-        for _ in range(reps):
-            g.k_spmv(A, 0, "PlusMultiplies", x.data_ptr(), None, 0, 0, y.data_ptr())
-        ms = g.timer_stop() / reps
-        sb = g.k_spmv_bytes(A, 0)
-        extra["spmv"] = {"kernel": "spmv_hub_kernel<PlusMultiplies,f32>", "bound": "hbm",
-                         "algorithmic_bytes_per_launch": sb, "avg_launch_ms": round(ms, 5),
-                         "achieved": round(sb / (ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(sb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                         "traffic": pmc_traffic("spmv_hub_kernel")[0],
-                         "traffic_source": pmc_traffic("spmv_hub_kernel")[1], "gflops": round(2 * nnz / (ms * 1e-3) / 1e9, 1)}
+
+        def time_spmv(M, reps=20):
+            for _ in range(3):
+                assert g.k_spmv(M, 0, "PlusMultiplies", x.data_ptr(), None, 0, 0, y.data_ptr()) == 0
+            g.timer_start()
+            for _ in range(reps):
+                g.k_spmv(M, 0, "PlusMultiplies", x.data_ptr(), None, 0, 0, y.data_ptr())
+            return g.timer_stop() / reps
+
+        def spmv_record(M, ms_, note):
+            sb_ = g.k_spmv_bytes(M, 0)
+            info = g.spmv_format_info(M, 0)
+            kern = "spmv_cband_kernel" if info["in_use"] else "spmv_hub_kernel"
+            rec = {"kernel": "%s<PlusMultiplies,f32>" % kern, "bound": "hbm", "matrix_values": note,
+                   "algorithmic_bytes_per_launch": sb_, "avg_launch_ms": round(ms_, 5),
+                   "achieved": round(sb_ / (ms_ * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                   "frac": round(sb_ / (ms_ * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                   "traffic": pmc_traffic(kern)[0], "traffic_source": pmc_traffic(kern)[1],
+                   "gflops": round(2 * nnz / (ms_ * 1e-3) / 1e9, 1)}
+            if info["in_use"]:
+                rec["format"] = {"groups_of_64": info["groups"], "row_bands": info["bands"], "hub_rows": info["hub_rows"],
+                                 "values_stored": not info["iso"], "own_bytes_per_launch": info["bytes_per_launch"],
+                                 "achieved_on_own_bytes": round(info["bytes_per_launch"] / (ms_ * 1e-3) / 1e9, 2),
+                                 "frac_on_own_bytes": round(info["bytes_per_launch"] / (ms_ * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+            return rec
+
+        ms = time_spmv(A)
+        extra["spmv"] = spmv_record(A, ms, "pattern (all ones): the traversal's matrix")
+        tval_r = torch.rand(nnz, dtype=torch.float32, device=dev) + 0.25
+        Ar = g.Matrix(n, n)
+        assert Ar.build_device_csr(tptr.data_ptr(), tind.data_ptr(), tval_r.data_ptr(), nnz, keep=(tptr, tind, tval_r)) == 0
+        extra["spmv_valued"] = spmv_record(Ar, time_spmv(Ar), "uniform random in [0.25, 1.25)")
+        del Ar
+        fmt_before = g.spmv_set_format(-1)
+        g.spmv_set_format(0)
+        Ac = g.Matrix(n, n)
+        assert Ac.build_device_csr(tptr.data_ptr(), tind.data_ptr(), tval_r.data_ptr(), nnz, keep=(tptr, tind, tval_r)) == 0
+        extra["spmv_csr_kernel"] = spmv_record(Ac, time_spmv(Ac), "uniform random in [0.25, 1.25); CSR kernel of rounds 1-2")
+        g.spmv_set_format(fmt_before)
+        del Ac, tval_r
 
         # ---- the multi-frontier forms, reported NEXT TO the per-traversal number above, not
         #      instead of it: (a) all 64 sources in one bit-parallel sweep (grb_bfs_batch: one 64-bit word per

@@ -577,6 +577,11 @@ def spmv_plan_info(A, tran=0, warm=False):
     return {"bands": bands.value, "band_nnz": bn.value, "pieces": pc.value, "nhot": nhot.value}
 
 
+def cc_set_fused(on=-1):
+    """1: FastSV's element-wise tail in one launch (default); 0: the reference's call sequence; < 0 queries"""
+    return int(_lib.load().grb_cc_set_fused(int(on)))
+
+
 def spmv_set_format(fmt=-1):
     """matrix format of the generic SpMV (grb_spmv_set_format): 0 CSR only, 1 auto, 2 column-sorted bands wherever
     the monoid allows; < 0 only queries"""

@@ -4,7 +4,7 @@
 // (bfs lives in ops.hip / bfs_fused.hip.)
 #include <cmath>
 
-#include "common.hpp"
+#include "persist_common.hpp"
 #include <chrono>
 
 using namespace grb;
@@ -261,6 +261,117 @@ grb_info grb_pr(grb_vector p, grb_matrix A, float alpha, float eps, grb_descript
   return GRB_SUCCESS;
 }
 
+// ---- FastSV's element-wise tail in ONE launch ----------------------------------------------------------------
+// After the MinimumSelectSecond product an iteration of algorithm::cc is eight more calls (cc.hpp:83-112: three
+// eWiseAdd, assignScatter, extractGather, eWiseMult, reduce, masked assign, plus two dup): nine launches and
+// 4 n x 13 bytes of traffic.  One co-resident launch does them in two passes around a grid barrier:
+//
+//   pass A (per u)   m = min(mnp[u], mnp_temp[u]);  mnp[u] = m                    eWiseAdd (:83-85)
+//                    atomicMin(parent[parent_temp[u]], m)                         assignScatter (:87-88)
+//                    atomicMin(parent[u], m)                                      eWiseAdd (:92-93); the third one,
+//                                                                                 min with parent_temp (:97-98), is
+//                                                                                 implied: parent starts as parent_temp
+//   -- grid barrier --
+//   pass B (per u)   gf = parent[parent[u]]                                       extractGather (:102-103)
+//                    d = grandparent_temp[u] != gf;  succ += d                     eWiseMult + reduce (:106-109)
+//                    grandparent_temp[u] = gf;  grandparent[u] = d ? gf : INT_MAX  dup + masked assign (:113-119)
+//                    parent_temp[u] = parent[u]                                    the next iteration's dup (:77)
+//
+// The reference's scatter lets racing writers of one parent[i] overwrite each other (kernels/scatter.hpp:24-39: any
+// candidate may win); atomicMin picks the smallest candidate -- one of the outcomes the reference admits, and since
+// the two eWiseAdds that follow only take minima with values that are all in the atomicMin already, parent after
+// pass A is exactly what the call sequence yields for that winner.  Converged labels do not depend on the winner.
+namespace grb {
+__global__ __launch_bounds__(kPThreads) void cc_tail_kernel(int* __restrict__ mnp, const int* __restrict__ mnp_temp,
+                                                            int* parent, int* __restrict__ parent_temp,
+                                                            int* __restrict__ grandparent, int* __restrict__ grandparent_temp,
+                                                            Index n, GridBarrier* bar, unsigned gen0,
+                                                            unsigned int* partial, unsigned int* ticket,
+                                                            unsigned long long* mail, int seq) {
+  __shared__ unsigned int s_cnt[kPWaves];
+  __shared__ int s_last;
+  const long long gtid = (long long)blockIdx.x * kPThreads + threadIdx.x;
+  const long long gthreads = (long long)gridDim.x * kPThreads;
+  for (long long u = gtid; u < n; u += gthreads) {
+    const int a = mnp[u], b = mnp_temp[u];
+    const int m = a < b ? a : b;
+    mnp[u] = m;
+    // parent only ever decreases during this pass, so a value read now bounds it from above: an atomic that
+    // could not lower it is skipped (most vertices of a large component point at one root -- millions of
+    // atomics on one address serialise at ~12 ns each)
+    const int pt = parent_temp[u];
+    if (pt >= 0 && pt < n && m < __hip_atomic_load(&parent[pt], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&parent[pt], m);
+    if (m < pt) atomicMin(&parent[u], m);
+  }
+  unsigned gen = gen0;
+  if (!grid_sync(bar, gen, true)) {
+    if (gtid == 0)
+      __hip_atomic_store(&mail[0], ((unsigned long long)(unsigned int)seq << 32) | 0xffffffffull, __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_SYSTEM);
+    return;
+  }
+  unsigned int cnt = 0;
+  for (long long u = gtid; u < n; u += gthreads) {
+    const int f = parent[u];
+    const int gf = (f >= 0 && f < n) ? parent[f] : 0;
+    const int gt = grandparent_temp[u];
+    const bool d = gt != gf;
+    cnt += d ? 1u : 0u;
+    grandparent_temp[u] = gf;
+    grandparent[u] = d ? gf : INT_MAX;
+    parent_temp[u] = f;
+  }
+  cnt = wave_reduce(cnt, [](unsigned int x, unsigned int y) { return x + y; });
+  if ((threadIdx.x & (kWave - 1)) == 0) s_cnt[threadIdx.x >> 6] = cnt;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned int t = 0;
+    for (int w = 0; w < kPWaves; ++w) t += s_cnt[w];
+    __hip_atomic_store(&partial[blockIdx.x], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    s_last = last_workgroup_arrives(ticket) ? 1 : 0;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  unsigned int t = 0;
+  for (int j = threadIdx.x; j < (int)gridDim.x; j += kPThreads)
+    t += __hip_atomic_load(&partial[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  t = wave_reduce(t, [](unsigned int x, unsigned int y) { return x + y; });
+  __syncthreads();
+  if ((threadIdx.x & (kWave - 1)) == 0) s_cnt[threadIdx.x >> 6] = t;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned int tot = 0;
+    for (int w = 0; w < kPWaves; ++w) tot += s_cnt[w];
+    if (tot == 0xffffffffu) tot = 0xfffffffeu;            // 0xffffffff is the barrier's distress value
+    __hip_atomic_store(&mail[0], ((unsigned long long)(unsigned int)seq << 32) | tot, __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+}  // namespace grb
+
+// the call sequence of algorithm/cc.hpp:77-119 for one iteration, op by op (fallback and yardstick: GRB_CC_FUSED=0)
+static grb_info cc_tail_op_by_op(grb_vector diff, grb_vector parent, grb_vector parent_temp, grb_vector grandparent,
+                                 grb_vector grandparent_temp, grb_vector mnp, grb_vector mnp_temp, grb_descriptor desc,
+                                 double* succ) {
+  GRB_TRY(grb_eWiseAdd(mnp, nullptr, GRB_ACCUM_NULL, GRB_MINIMUM_SELECT_SECOND, mnp, mnp_temp, desc));
+  GRB_TRY(grb_assignScatter(parent, nullptr, GRB_ACCUM_NULL, mnp, parent_temp, desc));
+  GRB_TRY(grb_eWiseAdd(parent, nullptr, GRB_ACCUM_NULL, GRB_MINIMUM_PLUS, parent, mnp, desc));
+  GRB_TRY(grb_eWiseAdd(parent, nullptr, GRB_ACCUM_NULL, GRB_MINIMUM_PLUS, parent, parent_temp, desc));
+  GRB_TRY(grb_extractGather(grandparent, nullptr, GRB_ACCUM_NULL, parent, parent, desc));
+  GRB_TRY(grb_eWiseMult(diff, nullptr, GRB_ACCUM_NULL, GRB_MINIMUM_NOT_EQUAL_TO, grandparent_temp, grandparent, desc));
+  GRB_TRY(grb_reduce_vector(succ, GRB_ACCUM_NULL, GRB_PLUS_MONOID, diff, desc));
+  return GRB_SUCCESS;
+}
+
+// 1 (default; GRB_CC_FUSED=0 in the environment starts with 0): the element-wise tail of an iteration in one
+// launch; 0: the reference's call sequence op by op.  on < 0 only queries.  Returns the value in force.
+int grb_cc_set_fused(int on) {
+  static int v = [] { const char* e = getenv("GRB_CC_FUSED"); return (!e || atoi(e) != 0) ? 1 : 0; }();
+  if (on >= 0) v = on ? 1 : 0;
+  return v;
+}
+
 // FastSV connected components, algorithm/cc.hpp:17-136: v = parent vector (component label =
 // smallest vertex id of the component once converged). A is an int matrix (pattern values).
 grb_info grb_cc(grb_vector v, grb_matrix A, int seed, grb_descriptor desc, grb_algo_result* result) {
@@ -277,6 +388,22 @@ grb_info grb_cc(grb_vector v, grb_matrix A, int seed, grb_descriptor desc, grb_a
   GRB_TRY(grb_vector_dup(mnp_temp, parent));
   GRB_TRY(grb_vector_dup(grandparent, parent));
   GRB_TRY(grb_vector_dup(grandparent_temp, parent));
+  bool fused = grb_cc_set_fused(-1) != 0 && n > 0 && A->nrows == A->ncols;
+  Context& c = ctx();
+  GridBarrier* d_bar = nullptr;
+  unsigned int* d_partial = nullptr;
+  int launches = 0;
+  if (fused) {
+    // the barrier's counters live across the launches of this call and the products in between use the scratch
+    // slots: a small block of its own, allocated once per process
+    static void* p_bar = nullptr;
+    if (!p_bar) GRB_HIP_TRY(hipMalloc(&p_bar, sizeof(GridBarrier) + 4 * 1024 + 64));
+    if (c.num_cu > 1024) return GRB_PANIC;
+    GRB_HIP_TRY(hipMemsetAsync(p_bar, 0, sizeof(GridBarrier) + 4 * 1024 + 64, c.stream));
+    d_bar = (GridBarrier*)p_bar;
+    d_partial = (unsigned int*)((char*)p_bar + sizeof(GridBarrier));
+    GRB_TRY(grb_vector_dup(parent_temp, parent));          // kept equal to parent by the fused tail from here on
+  }
   int iter = 1;
   double succ = 0;
   float ms = 0.f;
@@ -284,21 +411,33 @@ grb_info grb_cc(grb_vector v, grb_matrix A, int seed, grb_descriptor desc, grb_a
   GRB_TRY(grb_timer_start());
   double t_iter = host_ms();
   for (; iter <= desc->max_niter; ++iter) {
-    GRB_TRY(grb_vector_dup(parent_temp, parent));
+    if (!fused) GRB_TRY(grb_vector_dup(parent_temp, parent));
     GRB_TRY(grb_mxv(mnp_temp, nullptr, GRB_ACCUM_NULL, GRB_MINIMUM_SELECT_SECOND, A, grandparent, desc));
-    GRB_TRY(grb_eWiseAdd(mnp, nullptr, GRB_ACCUM_NULL, GRB_MINIMUM_SELECT_SECOND, mnp, mnp_temp, desc));
-    GRB_TRY(grb_assignScatter(parent, nullptr, GRB_ACCUM_NULL, mnp, parent_temp, desc));
-    GRB_TRY(grb_eWiseAdd(parent, nullptr, GRB_ACCUM_NULL, GRB_MINIMUM_PLUS, parent, mnp, desc));
-    GRB_TRY(grb_eWiseAdd(parent, nullptr, GRB_ACCUM_NULL, GRB_MINIMUM_PLUS, parent, parent_temp, desc));
-    GRB_TRY(grb_extractGather(grandparent, nullptr, GRB_ACCUM_NULL, parent, parent, desc));
-    GRB_TRY(grb_eWiseMult(diff, nullptr, GRB_ACCUM_NULL, GRB_MINIMUM_NOT_EQUAL_TO, grandparent_temp, grandparent, desc));
-    GRB_TRY(grb_reduce_vector(&succ, GRB_ACCUM_NULL, GRB_PLUS_MONOID, diff, desc));
+    if (fused) {
+      // the product may have left its result sparse (push): the tail reads it dense; entries it does not hold
+      // are the monoid's identity, under which min() changes nothing
+      if (mnp_temp->vec_type == GRB_SPARSE) GRB_TRY(grb_vector_sparse2dense(mnp_temp, (double)INT_MAX, desc));
+      const int seq = ++c.mail_seq;
+      hipLaunchKernelGGL(cc_tail_kernel, dim3(c.num_cu), dim3(kPThreads), 0, c.stream, (int*)mnp->d_val,
+                         (const int*)mnp_temp->d_val, (int*)parent->d_val, (int*)parent_temp->d_val, (int*)grandparent->d_val,
+                         (int*)grandparent_temp->d_val, n, d_bar, (unsigned)launches, d_partial, c.d_tickets, c.d_hgran, seq);
+      GRB_HIP_TRY(hipGetLastError());
+      ++launches;
+      unsigned int bits = 0;
+      GRB_TRY(wait_granules(seq, 1, &bits));
+      if (bits == 0xffffffffu) return GRB_PANIC;           // the grid barrier gave up
+      succ = (double)bits;
+      for (grb_vector x : {mnp, parent, parent_temp, grandparent, grandparent_temp}) GRB_TRY(grb_vector_set_storage(x, GRB_DENSE));
+    } else {
+      GRB_TRY(cc_tail_op_by_op(diff, parent, parent_temp, grandparent, grandparent_temp, mnp, mnp_temp, desc, &succ));
+    }
     if (desc->timing != 0) {
       const double now = host_ms();
       desc->iter_log.push_back(grb_algo_iter{iter, desc->lastmxv, succ, (float)(now - t_iter), 0});
       t_iter = now;
     }
     if (succ == 0) break;
+    if (fused) continue;                                   // the dup and the masked assign happened in the tail
     GRB_TRY(grb_vector_dup(grandparent_temp, grandparent));
     grb_descriptor_toggle(desc, GRB_MASK);
     grb_info ai = grb_assign(grandparent, diff, GRB_ACCUM_NULL, (double)INT_MAX, desc);

@@ -498,7 +498,7 @@ static grb_info prepare_cband(const CsrArrays& M, SpmvPlan& plan) {
   // workgroups its cost asks for (a light entry costs more than a hub entry, see the dealing below), the light
   // rows' entries are split evenly over the rest, and a share that does not fit kCbRows rows is cut into k equal
   // bands -- then the equal-cost cuts of the dealing fall on band boundaries and few bands need partial slices.
-  static const int light_weight = getenv("GRB_CB_LIGHT_WEIGHT") ? atoi(getenv("GRB_CB_LIGHT_WEIGHT")) : 17;   // hub = 10
+  static const int light_weight = getenv("GRB_CB_LIGHT_WEIGHT") ? atoi(getenv("GRB_CB_LIGHT_WEIGHT")) : 14;   // hub = 10
   long long band_entries_max = (long long)kCbLightGroups * kWave;
   {
     const long long light_entries = nnz - hub_entries;

@@ -248,7 +248,10 @@ __device__ inline void cband_combine(A* addr, T v) {
 // chunk is stored transposed, see cband_emit_kernel): 4-byte loads reach 4.4 TB/s on this stream, and the guide
 // prices 8-byte accesses at 0.54-0.70 of the 16-byte rate.
 constexpr int kCbChunk = 4;               // groups per chunk
-constexpr int kCbStage = 2;               // chunks per pipeline stage of a wave
+#ifndef GRB_CB_STAGE
+#define GRB_CB_STAGE 2
+#endif
+constexpr int kCbStage = GRB_CB_STAGE;    // chunks per pipeline stage of a wave
 
 typedef unsigned int CbWord4 __attribute__((ext_vector_type(4)));
 
@@ -392,12 +395,21 @@ __global__ __launch_bounds__(kBlock) void spmv_cband_fold_kernel(CbArgs a, const
   const int i = blockIdx.x * kWave + l;
   __shared__ unsigned long long s_part[kWavesPerBlock][kWave];
   Acc acc = (Acc)S::identity();
-  if (i < B.nrows)
-    for (int s = s0 + q; s < s1; s += kWavesPerBlock) {
-      const Acc p = partials[(size_t)a.fin_off[s] + i];
+  if (i < B.nrows) {
+    auto fold = [&](Acc p) {
       if constexpr (std::is_same<Acc, T>::value) acc = S::add(acc, p);
       else acc += p;
+    };
+    int s = s0 + q;
+    for (; s + 3 * kWavesPerBlock < s1; s += 4 * kWavesPerBlock) {       // four slices in flight
+      const Acc p0 = partials[(size_t)a.fin_off[s] + i];
+      const Acc p1 = partials[(size_t)a.fin_off[s + kWavesPerBlock] + i];
+      const Acc p2 = partials[(size_t)a.fin_off[s + 2 * kWavesPerBlock] + i];
+      const Acc p3 = partials[(size_t)a.fin_off[s + 3 * kWavesPerBlock] + i];
+      fold(p0); fold(p1); fold(p2); fold(p3);
     }
+    for (; s < s1; s += kWavesPerBlock) fold(partials[(size_t)a.fin_off[s] + i]);
+  }
   *reinterpret_cast<Acc*>(&s_part[q][l]) = acc;
   __syncthreads();
   if (q == 0 && i < B.nrows) {

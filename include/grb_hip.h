@@ -446,8 +446,12 @@ grb_info grb_sssp(grb_vector v, grb_matrix A, grb_index source, grb_descriptor d
 grb_info grb_pr(grb_vector p, grb_matrix A, float alpha, float eps, grb_descriptor desc,
                 grb_algo_result* result);
 
-/* algorithm::cc (algorithm/cc.hpp:17-136): FastSV; v and A are int; v = parent labels. */
+/* algorithm::cc (algorithm/cc.hpp:17-136): FastSV; v and A are int; v = parent labels.  Per iteration the
+ * MinimumSelectSecond product and ONE launch for the element-wise tail (cc.hpp:77-119: three eWiseAdd,
+ * assignScatter, extractGather, eWiseMult, reduce, masked assign, two dup); grb_cc_set_fused(0) (or GRB_CC_FUSED=0
+ * in the environment) runs the tail as the reference's call sequence instead; on < 0 only queries. */
 grb_info grb_cc(grb_vector v, grb_matrix A, int seed, grb_descriptor desc, grb_algo_result* result);
+int grb_cc_set_fused(int on);
 
 /* algorithm::tc (algorithm/tc.hpp:15-54): A = lower triangle (int), B = buffer matrix. */
 grb_info grb_tc(int64_t* ntris, grb_matrix A, grb_matrix B, grb_descriptor desc, grb_algo_result* result);

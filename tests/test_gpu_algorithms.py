@@ -295,6 +295,26 @@ def test_connected_components(hb, graphs):
             got = v.extractTuples()[1]
             assert np.array_equal(got, sr.cc_canonical(want)), (name, mode)
             assert sr.cc_verify(ptr, ind, got) == (0, k)
+            # the element-wise tail of an iteration as ONE launch (the default, above) and as the reference's
+            # call sequence: the same converged parent vector; under a max_niter that cuts the loop short both
+            # are valid FastSV states -- every label is a member of the vertex's own component and no larger
+            # than the vertex itself
+            assert g.cc_set_fused(-1) == 1
+            g.cc_set_fused(0)
+            try:
+                v2 = g.Vector(n, np.int32)
+                info2, res2 = g.cc(v2, A, 0, d)
+            finally:
+                g.cc_set_fused(1)
+            assert info2 == 0 and np.array_equal(v2.extractTuples()[1], got), (name, mode)
+            assert res2["succ"] == res["succ"] == 0
+        for cap in (1, 2):
+            d = hb.descriptor(mxvmode=0, max_niter=cap)
+            v = g.Vector(n, np.int32)
+            assert g.cc(v, A, 0, d)[0] == 0
+            lab = v.extractTuples()[1]
+            canon = sr.cc_canonical(want)
+            assert np.all(lab <= np.arange(n)) and np.array_equal(canon[lab], canon), (name, cap)
 
 
 def test_triangle_count(hb, graphs):

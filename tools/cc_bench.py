@@ -14,8 +14,13 @@ A = g.Matrix(n, n, np.int32)
 assert A.build_device_csr(ptr.data_ptr(), ind.data_ptr(), val.data_ptr(), nnz, ptr.data_ptr(), ind.data_ptr(), val.data_ptr(), keep=(ptr, ind, val)) == 0
 d_ = g.Descriptor(); d_.loadArgs(mxvmode=int(os.environ.get("MXVMODE", "1")))
 v = g.Vector(n, np.int32)
-g.cc(v, A, 0, d_)
-torch.cuda.synchronize(); t0 = time.perf_counter()
-info, r = g.cc(v, A, 0, d_)
-torch.cuda.synchronize()
-print("rmat%d cc: %d iterations, tight %.3f ms, wall %.3f ms" % (scale, r["iterations"], r["tight_ms"], (time.perf_counter() - t0) * 1e3))
+for fused in (1, 0):
+    g.cc_set_fused(fused)
+    g.cc(v, A, 0, d_)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    info, r = g.cc(v, A, 0, d_)
+    torch.cuda.synchronize()
+    print("rmat%d cc (%s): %d iterations, tight %.3f ms, wall %.3f ms" % (
+        scale, "element-wise tail in one launch" if fused else "the reference's call sequence", r["iterations"], r["tight_ms"],
+        (time.perf_counter() - t0) * 1e3))
+g.cc_set_fused(1)
