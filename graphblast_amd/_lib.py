@@ -38,6 +38,11 @@ class BfsLevel(C.Structure):
                 ("discovered", C.c_int32), ("ms", C.c_float)]
 
 
+class PartSsspResult(C.Structure):
+    _fields_ = [("iterations", C.c_int32), ("rounds", C.c_int32), ("launches", C.c_int32), ("hit_cap", C.c_int32),
+                ("ms", C.c_float)]
+
+
 class PartBfsResult(C.Structure):
     _fields_ = [("levels", C.c_int32), ("launches", C.c_int32), ("hit_cap", C.c_int32),
                 ("edges_traversed", C.c_int64), ("reached", C.c_int64), ("ms", C.c_float)]
@@ -152,8 +157,13 @@ _SIGS = {
     "grb_bfs_part_push_small": [_vp, _i, _i, _vp, _vp, _vp],
     "grb_bfs_part_seed": [_vp, _vp, _vp, _i, _i, _i, _i],
     "grb_bitmap_or_parts": [_vp, _i, _i, _vp],
+    "grb_bfs_part_unlabel": [_vp, _i, _f],
     "grb_part_new": [C.POINTER(_vp), _i, _i, _i, _i, _vp, _vp, _vp, C.c_int64],
     "grb_part_free": [_vp],
+    "grb_part_sssp_new": [C.POINTER(_vp), _i, _i, _i, _i, _vp, _i],
+    "grb_part_sssp_free": [_vp],
+    "grb_sssp_part_run": [_vp, _i, _i, _i, _vp, C.POINTER(PartSsspResult)],
+    "grb_sssp_part_run_group": [C.POINTER(_vp), _i, _i, _i, C.POINTER(_vp), C.POINTER(PartSsspResult)],
     "grb_bfs_part_run": [_vp, _i, _i, _f, _f, _i, _i, _vp, C.POINTER(PartBfsResult), C.POINTER(BfsLevel), _i],
     "grb_bfs_part_run_group": [C.POINTER(_vp), _i, _i, _i, _f, _f, _i, C.POINTER(_vp), C.POINTER(PartBfsResult),
                                C.POINTER(BfsLevel), _i],

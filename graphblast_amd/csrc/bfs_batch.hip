@@ -573,7 +573,10 @@ extern "C" grb_info grb_bfs_batch(grb_vector* v, int k, grb_matrix A, const grb_
     mf_s[s] = (unsigned long long)(A->h_csr_ptr[(size_t)sources[s] + 1] - A->h_csr_ptr[sources[s]]);
     edges += mf_s[s];
   }
-  const int mode = desc->desc[GRB_MXVMODE];
+  // GRB_SPARSE_MATRIX_FORMAT = 1: no CSC storage -- the "CSC" arrays ARE the CSR arrays, and the reference's vxm
+  // is forced to push whatever the mxvmode says (operations.hpp:131-133).  A pull over them would walk out-edges
+  // as if they were in-edges: every source is pushed.
+  const int mode = (A->format != 0 || A->csc_alias) ? GRB_PUSHONLY : desc->desc[GRB_MXVMODE];
   const int grid = stream_grid((long long)ceil_div(n, kWave) * kWave, kBlock);
   int iter = 1, levels = 0, last_dir = 0;
   bool any_left = true;

@@ -174,6 +174,12 @@ __global__ void bfs_part_seed_kernel(unsigned int* vis, unsigned int* fresh, flo
   if (source >= lo && source < lo + n_local) label[source - lo] = 1.f;
 }
 
+// label == value -> 0: the vertices the level that ended a cut-off loop discovered are never assigned (bfs.hpp:48-66)
+__global__ void bfs_part_unlabel_kernel(float* __restrict__ label, Index n, float value) {
+  for (Index i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+    if (label[i] == value) label[i] = 0.f;
+}
+
 // out = parts[0] | parts[1] | ... (the all-gathered new-bits bitmaps of every rank)
 __global__ void bitmap_or_parts_kernel(const unsigned int* __restrict__ parts, int world, int nwords,
                                        unsigned int* __restrict__ out) {
@@ -341,6 +347,16 @@ grb_info grb_bfs_part_seed(uint32_t* d_vis, uint32_t* d_new_global, float* d_lab
   if (n_local > 0) GRB_HIP_TRY(hipMemsetAsync(d_label_local, 0, 4 * (size_t)n_local, s));
   hipLaunchKernelGGL(bfs_part_seed_kernel, dim3(1), dim3(kWave), 0, s, d_vis, d_new_global, d_label_local, lo, n_local,
                      source);
+  GRB_HIP_TRY(hipGetLastError());
+  return GRB_SUCCESS;
+}
+
+grb_info grb_bfs_part_unlabel(float* d_label_local, grb_index n_local, float value) {
+  if (n_local <= 0) return GRB_SUCCESS;
+  if (!d_label_local) return GRB_NULL_POINTER;
+  GRB_TRY(ctx_init());
+  hipLaunchKernelGGL(bfs_part_unlabel_kernel, dim3(stream_grid(n_local)), dim3(kBlock), 0, ctx().stream, d_label_local,
+                     (Index)n_local, value);
   GRB_HIP_TRY(hipGetLastError());
   return GRB_SUCCESS;
 }

@@ -248,8 +248,13 @@ inline grb_info dispatch_semiring(int sr, int dtype, F&& f) {
     r.ident_f = (float)u.identity;
     r.ident_i = u.identity >= 2147483647.0 ? INT_MAX : (u.identity <= -2147483648.0 ? INT_MIN : (int)u.identity);
     h_rt_semiring = r;
-    // constant memory is read by kernels still in flight on the stream: order the update behind them
-    GRB_HIP_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(d_rt_semiring), &r, sizeof(r), 0, hipMemcpyHostToDevice, current_stream()));
+    // constant memory is read by kernels still in flight on the stream: order the update behind them.  The copy's
+    // source must outlive this call if the runtime does not stage it at once: a ring of static slots, not the stack
+    static RtSemiring ring[32];
+    static unsigned ring_at = 0;
+    RtSemiring* src = &ring[ring_at++ & 31u];
+    *src = r;
+    GRB_HIP_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(d_rt_semiring), src, sizeof(r), 0, hipMemcpyHostToDevice, current_stream()));
     if (dtype == GRB_F32) return f(IntTag<GRB_RUNTIME_SR>{}, float{});
     return f(IntTag<GRB_RUNTIME_SR>{}, int{});
   }

@@ -489,13 +489,29 @@ __global__ void ewise_add_dd_kernel(T* w, const T* u, const T* v, Index n) {
     auto* w4 = reinterpret_cast<Vec4<T>*>(w);
     auto* u4 = reinterpret_cast<const Vec4<T>*>(u);
     auto* v4 = reinterpret_cast<const Vec4<T>*>(v);
-    for (Index i = blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += gridDim.x * blockDim.x) {
+    // w may BE u or v (the reference's in-place calls), never overlap them otherwise: element i of the output
+    // depends on element i of the inputs only, so the loads of four strides are issued before the first store
+    // (without this the compiler keeps every load behind the previous iteration's store: 5.2 against 5.9 TB/s)
+    const Index stride = gridDim.x * blockDim.x;
+    Index i = blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + 3 * stride < n4; i += 4 * stride) {
+      Vec4<T> a[4], b[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { a[k] = u4[i + k * stride]; b[k] = v4[i + k * stride]; }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        Vec4<T> r;
+        r.x = S::add(a[k].x, b[k].x); r.y = S::add(a[k].y, b[k].y); r.z = S::add(a[k].z, b[k].z); r.w = S::add(a[k].w, b[k].w);
+        w4[i + k * stride] = r;
+      }
+    }
+    for (; i < n4; i += stride) {
       Vec4<T> a = u4[i], b = v4[i], r;
       r.x = S::add(a.x, b.x); r.y = S::add(a.y, b.y); r.z = S::add(a.z, b.z); r.w = S::add(a.w, b.w);
       w4[i] = r;
     }
-    for (Index i = (n4 << 2) + blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
-      w[i] = S::add(u[i], v[i]);
+    for (Index j = (n4 << 2) + blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x)
+      w[j] = S::add(u[j], v[j]);
   } else {
     for (Index i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
       w[i] = S::add(u[i], v[i]);

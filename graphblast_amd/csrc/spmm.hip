@@ -62,9 +62,10 @@ __global__ __launch_bounds__(kBlock) void spmm_tile_kernel(const SpmvBlock* __re
 #pragma unroll
     for (int j = 0; j < kSpmmTile / kWave; ++j) {
       const int at = j * kWave + lane;
-      const int q = blk.nnz_start + (at < cnt ? at : 0);
-      s_ci[wave_id()][at] = ind[q];
-      s_cv[wave_id()][at] = val[q];
+      // an all-empty tile (trailing empty rows) starts AT the end of the arrays: nothing of it may be read
+      const int q = cnt > 0 ? blk.nnz_start + (at < cnt ? at : 0) : 0;
+      s_ci[wave_id()][at] = cnt > 0 ? ind[q] : 0;
+      s_cv[wave_id()][at] = cnt > 0 ? val[q] : (T)0;
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();

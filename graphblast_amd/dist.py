@@ -118,6 +118,9 @@ class HipEngine:
         info = self._lib.grb_bitmap_or_parts(gathered.data_ptr(), int(world), int(nwords), out.data_ptr())
         assert info == 0, info
 
+    def unlabel(self, label_local, value):
+        assert self._lib.grb_bfs_part_unlabel(label_local.data_ptr(), self.n_local, float(value)) == 0
+
     def tally(self, label_local):
         e, r = C.c_int64(0), C.c_int32(0)
         info = self._lib.grb_bfs_part_tally(self.A._h, label_local.data_ptr(), C.byref(e), C.byref(r))
@@ -155,7 +158,46 @@ class HipEngine:
                  for i in range(min(res.levels, self._lv_cap))] if want_trace else None
         return res, trace
 
+    # ---- algorithm::sssp in frontier form, round loop on the device (csrc/sssp_part_run.hip)
+    def sssp_context(self, rank, world, out_weights_local, outbox_pairs=65536):
+        """out_weights_local: the weights of the OWNED vertices' out-edges, in the order of this shard's arrays"""
+        import graphblast_amd as g
+        lptr, lind = self.keep
+        w = out_weights_local.to(torch.float32).contiguous()
+        if w.numel() == 0:
+            w = torch.zeros(1, dtype=torch.float32, device=lind.device)
+        old = getattr(self, "_sssp_part", None)
+        if old is not None:
+            self._lib.grb_part_sssp_free(old)
+            self._sssp_part = None
+        self.A_w = g.Matrix(self.n_local, self.n)
+        info = self.A_w.build_device_csr(lptr.data_ptr(), lind.data_ptr(), w.data_ptr(), int(self.A.nvals()), keep=(lptr, lind, w))
+        if info != 0:
+            raise RuntimeError("grb_matrix_adopt_device_csr (weights) failed: %d" % info)
+        h = C.c_void_p()
+        info = self._lib.grb_part_sssp_new(C.byref(h), int(rank), int(world), self.n, self.lo, self.A_w._h, int(outbox_pairs))
+        if info != 0:
+            raise RuntimeError("grb_part_sssp_new: Info %d" % info)
+        self._sssp_part = h
+        return h
+
+    def run_sssp(self, part, source, max_niter, dist_local, rounds_per_launch=1):
+        from ._lib import PartSsspResult
+        res = PartSsspResult()
+        info = self._lib.grb_sssp_part_run(part, int(source), int(max_niter), int(rounds_per_launch), dist_local.data_ptr(),
+                                           C.byref(res))
+        if info != 0:
+            raise RuntimeError("grb_sssp_part_run: Info %d" % info)
+        return res
+
     def __del__(self):
+        sp = getattr(self, "_sssp_part", None)
+        if sp is not None:
+            try:
+                self._lib.grb_part_sssp_free(sp)
+            except Exception:                                         # noqa: BLE001 -- interpreter shutdown
+                pass
+            self._sssp_part = None
         part = getattr(self, "_part", None)
         if part is not None:
             try:
@@ -246,16 +288,30 @@ class HipEngine:
         self._sssp_y = torch.empty(max(self.n_local, 1), dtype=torch.float32, device=dev)
 
     def sssp_step(self, d_full, d_local):
-        """d_local = min(d_local, A_in min.+ d_full) over the owned rows; -> how many of them improved"""
+        """d_local = min(d_local, A_in min.+ d_full) over the owned rows; -> how many of them improved.
+        The dense (pull) form of a round as library calls -- the product, then the reference's own three
+        element-wise steps (sssp.hpp:70-75, :83): m = y < d, d = min(d, y), succ = sum(m).  The HIP engine's
+        own drivers use the frontier form (run_sssp); this is what the host-driven loop falls back to."""
         if self.n_local == 0:
             return 0
+        g = self.g
         y = self._sssp_y
-        assert self.g.k_spmv(self.Asssp, 0, "MinimumPlus", d_full.data_ptr(), None, 0, 0, y.data_ptr()) == 0
-        better = y[:self.n_local] < d_local[:self.n_local]
-        changed = int(better.sum().item())
-        if changed:
-            torch.minimum(d_local[:self.n_local], y[:self.n_local], out=d_local[:self.n_local])
-        return changed
+        assert g.k_spmv(self.Asssp, 0, "MinimumPlus", d_full.data_ptr(), None, 0, 0, y.data_ptr()) == 0
+        if getattr(self, "_sssp_vec", None) is None:
+            self._sssp_vec = {k: g.Vector(max(self.n_local, 1)) for k in ("y", "d", "m")}
+            self._sssp_m = torch.empty(max(self.n_local, 1), dtype=torch.float32, device=y.device)
+            self._sssp_desc = g.Descriptor()
+            assert self._sssp_desc.loadArgs(mxvmode=2) == 0
+        vy, vd, vm = self._sssp_vec["y"], self._sssp_vec["d"], self._sssp_vec["m"]
+        n1 = max(self.n_local, 1)
+        assert vy.build_device(y.data_ptr(), n1) == 0
+        assert vd.build_device(d_local.data_ptr(), n1) == 0
+        assert vm.build_device(self._sssp_m.data_ptr(), n1) == 0
+        assert g.eWiseAdd(vm, None, None, "CustomLessPlus", vy, vd, self._sssp_desc) == 0
+        assert g.eWiseAdd(vd, None, None, "MinimumPlus", vd, vy, self._sssp_desc) == 0
+        info, val = g.reduce(None, "Plus", vm, self._sssp_desc)
+        assert info == 0
+        return int(round(float(val)))
 
 
 class TorchComm:
@@ -419,6 +475,7 @@ class LoopbackGroup:
         self._lib = _lib.load()
         self.n, self.world, self.dev = n, world, dev
         ptr_host = tptr.cpu().numpy()
+        self._ptr_host = ptr_host
         self.bounds = partition_bounds(ptr_host, world)
         self.nnz = int(ptr_host[-1])
         self.deg_full = (tptr[1:] - tptr[:-1]).to(torch.int32).contiguous()
@@ -466,6 +523,31 @@ class LoopbackGroup:
         return labels, out, trace
 
 
+    def sssp(self, weights, source, max_niter=10000, outbox_pairs=65536):
+        """weights: of every stored out-edge, CSR order.  -> (distances [n] numpy, per-rank result dicts)"""
+        from ._lib import PartSsspResult
+        key = (weights.data_ptr(), int(outbox_pairs))
+        if getattr(self, "_sssp_key", None) != key:
+            ptr_host = self._ptr_host
+            hs = []
+            for r, eng in enumerate(self.engines):
+                e0, e1 = int(ptr_host[self.bounds[r]]), int(ptr_host[self.bounds[r + 1]])
+                hs.append(eng.sssp_context(r, self.world, weights[e0:e1], outbox_pairs))
+            self._sssp_handles = (C.c_void_p * self.world)(*[h.value for h in hs])
+            self._sssp_key = key
+            self._dist = [torch.empty(max(self.bounds[r + 1] - self.bounds[r], 1), dtype=torch.float32, device=self.dev)
+                          for r in range(self.world)]
+            self._dist_ptrs = (C.c_void_p * self.world)(*[t.data_ptr() for t in self._dist])
+        res = (PartSsspResult * self.world)()
+        info = self._lib.grb_sssp_part_run_group(self._sssp_handles, self.world, int(source), int(max_niter),
+                                                 self._dist_ptrs, res)
+        if info != 0:
+            raise RuntimeError("grb_sssp_part_run_group: Info %d" % info)
+        d = np.concatenate([self._dist[r][:self.bounds[r + 1] - self.bounds[r]].cpu().numpy() for r in range(self.world)])
+        return d, [dict(iterations=int(x.iterations), rounds=int(x.rounds), launches=int(x.launches), hit_cap=int(x.hit_cap),
+                        device_ms=float(x.ms)) for x in res]
+
+
 class Partition1D:
     def __init__(self, n, tptr, tind, rank, world, dev, engine_cls=HipEngine, mxvmode=GRB_PUSHPULL,
                  switchpoint=0.01, max_niter=10000, symmetric=True, comm=None, edgeswitch=0.0, in_edges=None,
@@ -489,7 +571,7 @@ class Partition1D:
                 li = torch.zeros(1, dtype=torch.int32, device=dev)
             return lp, li, (e0, e1)
         lptr, lind, out_range = shard(tptr, tind)
-        self.lptr, self.lind = lptr, lind
+        self.lptr, self.lind, self.out_range = lptr, lind, out_range
         if in_edges is None:
             self.in_lptr, self.in_lind, self.in_range = lptr, lind, out_range
             self.engine = engine_cls(n, self.lo, lptr, lind, dev)
@@ -606,7 +688,10 @@ class Partition1D:
                 break
             it += 1
         if it > self.max_niter and nf > 0:                          # bfs.hpp:48-66: never assigned
-            self.label[self.label == float(self.max_niter + 1)] = 0.0
+            if hasattr(eng, "unlabel"):
+                eng.unlabel(self.label, float(self.max_niter + 1))
+            else:
+                self.label[self.label == float(self.max_niter + 1)] = 0.0
         e, r = self.engine.tally(self.label)
         if self.world > 1:                                           # one collective, one read-back
             t = torch.tensor([e, r], dtype=torch.int64, device=self.dev)
@@ -696,7 +781,7 @@ class Partition1D:
             it += 1
         return p_cur, dict(iterations=it, errors=errs, overlapped_chunks=nchunks)
 
-    def sssp(self, in_weights, source, max_niter=None):
+    def sssp(self, in_weights, source, max_niter=None, out_weights=None, outbox_pairs=65536, rounds_per_launch=1):
         """algorithm::sssp (graphblas/algorithm/sssp.hpp:53-90) on the 1-D partition, as synchronous rounds:
         every rank relaxes the IN-edges of the vertices it owns against the replicated distance vector
         (MinimumPlus product over its in-edge shard -- round r+1 reads only round r's distances, so the distances
@@ -709,6 +794,28 @@ class Partition1D:
         n, dev, eng = self.n, self.dev, self.engine
         fmax = float(np.finfo(np.float32).max)
         max_niter = self.max_niter if max_niter is None else max_niter
+        if out_weights is None and self.in_lptr is self.lptr:
+            out_weights = in_weights                                  # a symmetric graph: one shard, one weight array
+        if self.device_loop and hasattr(eng, "run_sssp") and out_weights is not None:
+            # the frontier form with the round loop on the device (csrc/sssp_part_run.hip): per round the
+            # improved vertices' out-edges, an all-gather of (vertex, candidate) pairs, nothing read back
+            o0, o1 = self.out_range
+            key = (out_weights.data_ptr(), int(outbox_pairs))
+            if getattr(self, "_sssp_key", None) != key:
+                self._sssp_ctx = eng.sssp_context(self.rank, self.world, out_weights[o0:o1], outbox_pairs)
+                self._sssp_key = key
+            d_local = torch.empty(max(self.n_local, 1), dtype=torch.float32, device=dev)
+            res = eng.run_sssp(self._sssp_ctx, source, max_niter, d_local, rounds_per_launch)
+            if self.world == 1:
+                d = d_local[:self.n_local].clone()
+            else:
+                sizes = [self.bounds[r + 1] - self.bounds[r] for r in range(self.world)]
+                pad = torch.zeros(max(max(sizes), 1), dtype=torch.float32, device=dev)
+                pad[:self.n_local] = d_local[:self.n_local]
+                out = self.comm.all_gather_padded(pad)
+                d = torch.cat([out[r, :sizes[r]] for r in range(self.world)])
+            return d, dict(iterations=int(res.iterations), rounds=int(res.rounds), launches=int(res.launches),
+                           device_ms=float(res.ms), form="frontier, round loop on the device")
         e0, e1 = self.in_range
         w = in_weights[e0:e1].to(torch.float32).contiguous()
         if w.numel() == 0:

@@ -320,6 +320,8 @@ grb_info grb_bfs_part_push_small(grb_matrix A_out, grb_index lo, grb_index n_glo
 grb_info grb_bfs_part_seed(uint32_t* d_vis, uint32_t* d_new_global, float* d_label_local, grb_index lo,
                            grb_index n_local, grb_index n_global, grb_index source);
 grb_info grb_bitmap_or_parts(const uint32_t* d_parts, int world, grb_index nwords, uint32_t* d_out);
+/* label == value -> 0 on the owned labels (the host-driven loop after a max_niter cut-off, bfs.hpp:48-66) */
+grb_info grb_bfs_part_unlabel(float* d_label_local, grb_index n_local, float value);
 
 /* ---- The same traversal with the level loop on the DEVICE (csrc/bfs_part_run.hip).  A rank context holds the
  * shards (A_out / A_in: the owned vertices' out- / in-neighbour lists, nrows x n_global, global column ids;
@@ -353,6 +355,31 @@ grb_info grb_bfs_part_run_group(grb_part* parts, int nranks, grb_index source, i
                                 float edgeswitch, int max_niter, float* const* d_labels,
                                 grb_part_bfs_result* results /* nranks */, grb_bfs_level* levels_out, int max_levels);
 
+/* ---- algorithm::sssp (algorithm/sssp.hpp:15-103) on the same 1-D partition, in its frontier form with the round
+ * loop on the device (csrc/sssp_part_run.hip).  A_out: the owned vertices' out-edges (nrows x n_global, global
+ * column ids, f32 weights >= 0).  Per launch: the (vertex, candidate) pairs the ranks exchanged are applied, a
+ * round that every rank has finished expanding is closed (synchronous rounds: the distances after every round and
+ * the loop counter are the reference's), the next queue is expanded -- owned targets at once, the others into an
+ * outbox of `outbox_pairs` pairs; one all-gather of the outboxes follows every launch (grb_comm_*).  A full outbox
+ * only postpones the rest of the round to the next launch.  Nothing is read back until the loop has ended (launch
+ * rule as grb_bfs_part_run).  d_dist_local receives the owned distances (FLT_MAX = unreached).
+ * grb_sssp_part_run_group: every rank of a world of `nranks` on one device (tests). */
+typedef struct grb_part_sssp_s* grb_part_sssp;
+typedef struct {
+  int32_t iterations;         /* the reference's loop counter at exit (max_niter + 1 when the cap ended it) */
+  int32_t rounds;             /* rounds closed                                          */
+  int32_t launches;
+  int32_t hit_cap;
+  float   ms;                 /* HIP-event time, first launch .. distances copied       */
+} grb_part_sssp_result;
+grb_info grb_part_sssp_new(grb_part_sssp* part, int rank, int world, grb_index n_global, grb_index lo, grb_matrix A_out,
+                           int outbox_pairs);
+grb_info grb_part_sssp_free(grb_part_sssp part);
+grb_info grb_sssp_part_run(grb_part_sssp part, grb_index source, int max_niter, int rounds_per_launch,
+                           float* d_dist_local, grb_part_sssp_result* result);
+grb_info grb_sssp_part_run_group(grb_part_sssp* parts, int nranks, grb_index source, int max_niter,
+                                 float* const* d_dist_local, grb_part_sssp_result* results /* nranks */);
+
 typedef struct {
   int    iterations;          /* loop iterations executed                              */
   float  tight_ms;            /* HIP-event time of the loop                            */
@@ -369,7 +396,9 @@ typedef struct {
  * the 17 semirings; no mask / accum (NULL in the reference's signature).  With GRB_SPMM_CORE=<H> in
  * the environment and PlusMultiplies f32, the dense 16 x 16 tiles among the top-H rows x top-H
  * columns are multiplied on the matrix cores (v_mfma_f32_16x16x4_f32); grb_spmm_core_info reports
- * how many tiles / entries that split holds. */
+ * how many tiles / entries that split holds.  That path multiplies the explicit zeros of a stored tile with
+ * rows of B and sums duplicate entries into one cell: it is for FINITE B (0 x Inf = NaN would reach rows
+ * that hold no entry in that column) and off unless the variable is set. */
 grb_info grb_spmm(grb_semiring op, grb_matrix A, int tran, const void* d_B, void* d_C, grb_index k,
                   grb_descriptor desc);
 grb_info grb_spmm_core_info(grb_matrix A, int tran, int* ntiles, int64_t* nnz_in_tiles);

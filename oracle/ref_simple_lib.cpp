@@ -24,7 +24,7 @@
 #include <unistd.h>
 #include <fcntl.h>
 
-namespace graphblas { typedef int Index; }
+#include "graphblas/types.hpp"         // the reference's own Index (types.hpp:18); -D__GRB_BACKEND_ROOT=cuda names its backend
 #include "graphblas/mmio.hpp"
 #include "util_noargs.hpp"
 

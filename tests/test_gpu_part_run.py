@@ -136,3 +136,90 @@ def test_device_loop_one_rank_levels_per_launch():
                 assert res["launches"] == res["levels"] + 2
             if lpl == 1 << 20:
                 assert res["launches"] == 1
+
+
+def _sssp_rounds(ptr, ind, w, src, max_niter=10000):
+    """the synchronous rounds of algorithm/sssp.hpp on the host: distances and the loop counter at exit"""
+    n = ptr.size - 1
+    fmax = np.finfo(np.float32).max
+    d = np.full(n, fmax, dtype=np.float32)
+    d[src] = 0
+    rows = np.repeat(np.arange(n), np.diff(ptr))
+    for it in range(1, max_niter + 1):
+        live = d[rows] < fmax
+        cand = (d[rows][live] + w[live]).astype(np.float32)
+        y = d.copy()
+        np.minimum.at(y, ind[live], cand)
+        if not (y < d).any():
+            return d, it
+        d = y
+    return d, max_niter + 1
+
+
+def _edge_weights(ptr, ind, sym=True, seed=0):
+    rows = np.repeat(np.arange(ptr.size - 1, dtype=np.int64), np.diff(ptr))
+    a, b = (np.minimum(rows, ind.astype(np.int64)), np.maximum(rows, ind.astype(np.int64))) if sym else (rows, ind.astype(np.int64))
+    return ((((a * 1000003) ^ (b * 7919 + seed)) * 2654435761 >> 7) % 16 + 1).astype(np.float32)
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 8])
+def test_device_loop_sssp_simulated_ranks(world):
+    """algorithm::sssp in frontier form on the partition: distances bit-exact (integer weights) and the reference's
+    loop counter, for an outbox that holds every round's pairs and for one so small that most rounds need several
+    launches (the round then continues from the recorded resume points); also under a max_niter that ends the loop"""
+    from graphblast_amd.dist import LoopbackGroup
+    from oracle import simple_reference as sr
+    gr = _graph(seed=3, scale=13)
+    ptr, ind = gr["csr"]
+    dev = torch.device("cuda", 0)
+    wh = _edge_weights(ptr, ind)
+    w = torch.from_numpy(wh).to(dev)
+    grp = LoopbackGroup(gr["n"], _t(ptr, dev), _t(ind, dev), world, dev)
+    hub = int(np.argmax(np.diff(ptr)))
+    for src in (hub, 17):
+        want_d, want_it = _sssp_rounds(ptr, ind, wh, src)
+        assert np.array_equal(want_d, sr.sssp(ptr, ind, wh, src)[0])
+        for cap in (65536, 64):
+            d, res = grp.sssp(w, src, outbox_pairs=cap)
+            assert np.array_equal(d, want_d), (world, src, cap)
+            assert all(r["iterations"] == want_it and r["hit_cap"] == 0 for r in res), (res, want_it)
+            if cap == 64 and world > 1:
+                assert res[0]["launches"] > res[0]["rounds"] + 2          # rounds that took more than one launch
+        for mx in (1, 2, 3):
+            want_c, want_cit = _sssp_rounds(ptr, ind, wh, src, max_niter=mx)
+            d, res = grp.sssp(w, src, max_niter=mx, outbox_pairs=256)
+            assert np.array_equal(d, want_c) and res[0]["iterations"] == want_cit, (world, src, mx, res)
+
+
+def test_device_loop_sssp_directed_and_road_like():
+    from graphblast_amd.dist import LoopbackGroup, Partition1D
+    from graphblast_amd.graphgen import finalize_edges
+    dev = torch.device("cuda", 0)
+    gd = _graph(seed=9, scale=12, sym=False)
+    ptr, ind = gd["csr"]
+    wh = _edge_weights(ptr, ind, sym=False, seed=5)
+    src = int(np.argmax(np.diff(ptr)))
+    want_d, want_it = _sssp_rounds(ptr, ind, wh, src)
+    for world in (2, 5):
+        grp = LoopbackGroup(gd["n"], _t(ptr, dev), _t(ind, dev), world, dev, in_edges=(_t(gd["csc"][0], dev), _t(gd["csc"][1], dev)))
+        d, res = grp.sssp(torch.from_numpy(wh).to(dev), src, outbox_pairs=512)
+        assert np.array_equal(d, want_d) and res[0]["iterations"] == want_it
+    # a grid: hundreds of rounds with small frontiers; one rank, one round per launch and many per launch
+    side = 40
+    idx = np.arange(side * side).reshape(side, side)
+    e = np.concatenate([np.stack([idx[:, :-1].ravel(), idx[:, 1:].ravel()]),
+                        np.stack([idx[:-1, :].ravel(), idx[1:, :].ravel()])], axis=1)
+    gr = finalize_edges(e[0].astype(np.int64), e[1].astype(np.int64), side * side, symmetrize=True)
+    ptr, ind = gr["csr"]
+    wh = _edge_weights(ptr, ind)
+    want_d, want_it = _sssp_rounds(ptr, ind, wh, 0)
+    w = torch.from_numpy(wh).to(dev)
+    for rpl in (1, 64):
+        part = Partition1D(gr["n"], _t(ptr, dev), _t(ind, dev), 0, 1, dev)
+        d, info = part.sssp(w, 0, rounds_per_launch=rpl)
+        assert np.array_equal(d.cpu().numpy(), want_d) and info["iterations"] == want_it, (rpl, info, want_it)
+        assert info["form"].startswith("frontier")
+    for world in (3,):
+        grp = LoopbackGroup(gr["n"], _t(ptr, dev), _t(ind, dev), world, dev)
+        d, res = grp.sssp(w, 0, outbox_pairs=64)
+        assert np.array_equal(d, want_d) and res[0]["iterations"] == want_it
