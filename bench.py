@@ -47,18 +47,21 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8 TB/s spec
 
 
-def pmc_traffic(kernel_key):
+def pmc_traffic(kernel_key, workload="rmat22_bfs"):
     """(HBM bytes per launch, where it came from).  PMC counters cannot be read from inside this process; the
     number is the one recorded by the latest committed PMC passes (profiles/rNN/pmc_traffic.json: separate
     `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this same command, FETCH_SIZE doubled as
     calibrated there on kernels of known byte count) -- the source is named on the line so a stale value
-    cannot pass for a live one; (None, None) when no pass has been committed."""
+    cannot pass for a live one; (None, None) when no pass has been committed.  The passes of the other
+    workloads are kept under "workloads": {name: {"kernels": ...}} in the same file."""
     best, where = None, None
     pdir = os.path.join(ROOT, "profiles")
     for d in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
         f = os.path.join(pdir, d, "pmc_traffic.json")
         if os.path.exists(f):
-            for name, rec in json.load(open(f)).get("kernels", {}).items():
+            doc = json.load(open(f))
+            kernels = doc.get("kernels", {}) if workload == "rmat22_bfs" else doc.get("workloads", {}).get(workload, {}).get("kernels", {})
+            for name, rec in kernels.items():
                 if kernel_key in name:
                     best = rec.get("hbm_bytes_per_launch", rec.get("hbm_bytes_per_launch_raw"))
                     where = "profiles/%s/pmc_traffic.json (separate rocprofv3 --pmc passes, not this run)" % d
@@ -131,14 +134,44 @@ def other_workload(args):
         ev = sum(g.bfs(v, A, sources[i % 64], desc, fused=True, profile=1)[1]["tight_ms"] for i in range(args.steps))
         acct = {s_: g.bfs(v, A, s_, desc, fused=True, profile=3)[1]["per_level"] for s_ in set(sources[i % 64] for i in range(args.steps))}
         tb = float(sum(sum(level_bytes(acct[sources[i % 64]], n)) for i in range(args.steps)))
+        kern = "bfs_persistent_kernel"
         line.update({"metric": "BFS TEPS (edges/sec), direction-optimised, directed graph of soc-LiveJournal1's size",
                      "value": sum(r["edges_traversed"] for r in res) / el, "unit": "TEPS", "ms_per_step": el / args.steps * 1e3,
                      "dtype": "f32", "config": {"workload": "lj_bfs" if path else "rmat22_ef16_directed_do_bfs (stand-in)",
                                                "n": n, "nnz": nnz},
-                     "roofline": {"bound": "hbm", "kernel": "bfs_persistent_kernel", "achieved": round(tb / (ev * 1e-3) / 1e9, 2),
+                     "roofline": {"bound": "hbm", "kernel": kern, "achieved": round(tb / (ev * 1e-3) / 1e9, 2),
                                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(tb / (ev * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                  "traffic": None, "avg_launch_ms": round(ev / args.steps, 5),
+                                  "traffic": pmc_traffic(kern, "lj_bfs")[0], "traffic_source": pmc_traffic(kern, "lj_bfs")[1],
+                                  "avg_launch_ms": round(ev / args.steps, 5),
                                   "algorithmic_bytes_per_launch": int(tb / args.steps)}})
+        if not args.no_cpu_baseline:
+            # the reference's own SimpleReferenceBfs (oracle/_ref) on a bounded sample of the timed sources, one
+            # core; the HIP labels of the same sources must equal its labels bit for bit
+            from oracle import ref_simple, simple_reference as sr
+            use_ref = ref_simple.available()
+            if "tptr" in dir():
+                ind_host = tind.cpu().numpy()
+            else:
+                ind_host = A.host_csr()[1]
+            nsamp = min(16, len(sources))
+            cpu_ms, cpu_edges, bad = 0.0, 0, 0
+            deg = np.diff(ptr)
+            for s_ in sources[:nsamp]:
+                t0c = time.perf_counter()
+                depth = (ref_simple.bfs(ptr, ind_host, s_)[0] if use_ref else sr.bfs(ptr, ind_host, s_)[0])
+                cpu_ms += (time.perf_counter() - t0c) * 1e3
+                cpu_edges += int(deg[depth != 0].sum())
+                assert g.bfs(v, A, s_, desc, fused=True)[0] == 0
+                if not np.array_equal(v.extractTuples()[1], depth):
+                    bad += 1
+            line["cpu_baseline"] = {"value": cpu_edges / (cpu_ms * 1e-3), "unit": "TEPS", "cores": 1,
+                                    "kind": "reference" if use_ref else "port",
+                                    "sample": "SimpleReferenceBfs, %d of the timed sources on the same graph" % nsamp,
+                                    "ms_per_bfs": round(cpu_ms / nsamp, 2)}
+            line["parity"] = {"checked_sources": nsamp, "mismatches": bad, "what": "depth labels bit-exact against the CPU reference"}
+            if bad:
+                print(json.dumps({"error": "parity", "workload": args.workload, "mismatching_sources": bad}))
+                sys.exit(3)
     elif args.workload == "road_sssp":
         path = have("road_usa")
         if path:
@@ -209,19 +242,49 @@ def other_workload(args):
         nfs = np.array([buf[i].value for i in range(k.value)], dtype=np.float64)
         avgdeg = nnz / float(n)
         alg = float(np.sum(12 * np.r_[1.0, nfs[:-1]] + 12 * avgdeg * np.r_[1.0, nfs[:-1]] + 8 * nfs))
+        # the default path's own work, summed over its passes by the kernel itself (grb_sssp_last_work): vertices
+        # expanded, their out-edges, vertices newly marked -- priced with the push formula of BASELINE.md 3 carrying a
+        # weight per edge (12 nf + 12 mf + 8 nf')
+        g.sssp(v, G, src, desc)
+        nf_work = g.sssp_last_work() if passes else (0, 0, 0)
+        alg_nf = float(12 * nf_work[0] + 12 * nf_work[1] + 8 * nf_work[2])
+        kern = "sssp_nearfar_kernel" if passes else "sssp_persistent_kernel"
+        roof = ({"bound": "hbm", "kernel": kern, "achieved": round(alg_nf / el / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                 "frac": round(alg_nf / el / 1e9 / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(kern, "road_sssp")[0],
+                 "traffic_source": pmc_traffic(kern, "road_sssp")[1], "algorithmic_bytes_per_launch": int(alg_nf),
+                 "work": {"passes": passes, "vertices_expanded": nf_work[0], "edges_relaxed": nf_work[1], "vertices_marked": nf_work[2]},
+                 "note": "one launch per SSSP; %d passes of ~%d expanded vertices each: the launch is bound by its "
+                         "grid barrier and dependent memory steps per pass, not by bytes" % (passes, nf_work[0] // max(passes, 1))}
+                if passes else
+                {"bound": "hbm", "kernel": kern, "achieved": round(alg / el_rounds / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                 "frac": round(alg / el_rounds / 1e9 / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(kern, "road_sssp")[0],
+                 "traffic_source": pmc_traffic(kern, "road_sssp")[1], "algorithmic_bytes_per_launch": int(alg)})
         line.update({"metric": "SSSP (MinimumPlus vxm) time on a road network of road_usa's size", "value": el * 1e3,
                      "unit": "ms", "higher_is_better": False, "ms_per_step": el * 1e3, "dtype": "f32", "steps": steps,
                      "config": {"workload": "road_sssp" if path else "grid4896_thinned_sssp (stand-in)", "n": n, "nnz": nnz,
                                 "rounds": res["iterations"], "us_per_round": round(el * 1e6 / max(res["iterations"], 1), 2)},
                      "order": ("near / far, %d passes (sssp_nearfar_kernel)" % passes) if passes else "synchronous rounds",
                      "synchronous_rounds": {"ms": round(el_rounds * 1e3, 2), "us_per_round": round(el_rounds * 1e6 / max(res0["iterations"], 1), 2),
-                                            "distances_and_round_count_identical": same},
-                     "roofline": {"bound": "hbm", "kernel": "sssp_persistent_kernel", "achieved": round(alg / el_rounds / 1e9, 2),
-                                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg / el_rounds / 1e9 / HBM_PEAK_GBS, 5),
-                                  "traffic": None, "algorithmic_bytes_per_launch": int(alg),
-                                  "note": "the reference's rounds (synchronous_rounds.ms): per-round bytes from the recorded "
-                                          "frontier sizes (mf = nf x average degree); that launch is bound by the atomic rate "
-                                          "of its wide rounds.  `value` is the default path, which does not do that work"}})
+                                            "distances_and_round_count_identical": same,
+                                            "algorithmic_bytes": int(alg), "achieved_GBps": round(alg / el_rounds / 1e9, 2)},
+                     "roofline": roof})
+        if not args.no_cpu_baseline:
+            # the reference's own SimpleReferenceSssp (a binary-heap Dijkstra, test_sssp.hpp:15-79), one core, the same
+            # source: its distances must equal the HIP path's exactly (integer weights)
+            from oracle import ref_simple, simple_reference as sr
+            use_ref = ref_simple.available()
+            hi_host, w_host = gind.cpu().numpy(), gw.cpu().numpy()
+            t0c = time.perf_counter()
+            want = (ref_simple.sssp(hp, hi_host, w_host, src)[0] if use_ref else sr.sssp(hp, hi_host, w_host, src)[0])
+            cpu_ms = (time.perf_counter() - t0c) * 1e3
+            ok = bool(np.array_equal(want, dist_default))
+            line["cpu_baseline"] = {"value": cpu_ms, "unit": "ms", "cores": 1, "kind": "reference" if use_ref else "port",
+                                    "sample": "SimpleReferenceSssp, the timed source, whole graph"}
+            line["parity"] = {"checked_sources": 1, "mismatches": 0 if ok else 1,
+                              "what": "distances bit-exact against the CPU reference (integer weights); near / far == rounds"}
+            if not ok:
+                print(json.dumps({"error": "parity", "workload": args.workload}))
+                sys.exit(3)
     else:
         path = have("com-Orkut")
         if path:
@@ -261,15 +324,45 @@ def other_workload(args):
         alg = float(4.0 * (np.sum(dl * dl) + np.sum(dl[li])) + 12.0 * li.size)
         del erow
         t = float(np.mean(ms)) * 1e-3
+        kern = "spgemm_masked_kernel"
+        # compulsory HBM bytes: L's structure read (as the left operand, the right operand and the mask: one copy in
+        # memory), the result's values written, its structure copied; the intersections themselves re-read adjacency
+        # lists that the L2 serves (alg: both lists of every mask entry)
+        compulsory = float(4.0 * (n + 1) + 4.0 * li.size + 4.0 * li.size + 4.0 * (n + 1) + 4.0 * li.size)
         line.update({"metric": "triangle count (masked SpGEMM L*L^T .* L) time on a graph of com-Orkut's size",
                      "value": t * 1e3, "unit": "ms", "higher_is_better": False, "ms_per_step": t * 1e3, "dtype": "i32",
                      "steps": steps, "config": {"workload": "orkut_tc" if path else "rmat22_ef28_sym_tc (stand-in)", "n": n,
                                                 "nnz_L": int(li.size), "triangles": int(ntri)},
-                     "roofline": {"bound": "hbm", "kernel": "spgemm_masked_kernel", "achieved": round(alg / t / 1e9, 2),
-                                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg / t / 1e9 / HBM_PEAK_GBS, 4),
-                                  "traffic": None, "algorithmic_bytes_per_launch": int(alg),
-                                  "note": "bytes = both adjacency lists of every mask entry (most are served by L2: the "
-                                          "hub lists are re-read by every neighbour)"}})
+                     "roofline": {"bound": "hbm", "kernel": kern, "achieved": round(compulsory / t / 1e9, 2),
+                                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(compulsory / t / 1e9 / HBM_PEAK_GBS, 5),
+                                  "traffic": pmc_traffic(kern, "orkut_tc")[0], "traffic_source": pmc_traffic(kern, "orkut_tc")[1],
+                                  "algorithmic_bytes_per_launch": int(compulsory),
+                                  "list_bytes_served_on_chip": int(alg), "list_GBps": round(alg / t / 1e9, 1),
+                                  "note": "bytes = compulsory HBM traffic (operands once, result once); the kernel is bound "
+                                          "by the on-chip rate of its list intersections (list_GBps), not by HBM"}})
+        if not args.no_cpu_baseline:
+            # the reference's own SimpleReferenceTc (test_tc.hpp:41-87) on the first k rows of L -- one core, k chosen
+            # for about 15 s of work (the whole graph would take minutes); the HIP result's per-entry counts over the
+            # same rows must add up to the same number
+            from oracle import ref_simple, simple_reference as sr
+            use_ref = ref_simple.available()
+            work = np.cumsum(dl * dl + np.bincount(np.repeat(np.arange(n), np.diff(lp)), weights=dl[li], minlength=n))
+            k_rows = int(np.searchsorted(work, 2e10)) + 1
+            k_rows = max(1, min(k_rows, n))
+            t0c = time.perf_counter()
+            want = ref_simple.tc(lp, li, nrows=k_rows) if use_ref else sr.tc(lp, li, nrows=k_rows)[0]
+            cpu_ms = (time.perf_counter() - t0c) * 1e3
+            bvals = B.host_csr()[2]
+            got = int(np.asarray(bvals[:int(lp[k_rows])], dtype=np.int64).sum())
+            line["cpu_baseline"] = {"value": cpu_ms, "unit": "ms", "cores": 1, "kind": "reference" if use_ref else "port",
+                                    "sample": "SimpleReferenceTc on the first %d rows of L (%d of %d mask entries, %.1f %% of the "
+                                              "intersection work)" % (k_rows, int(lp[k_rows]), int(li.size), 100.0 * work[k_rows - 1] / work[-1]),
+                                    "triangles_in_sample": int(want)}
+            line["parity"] = {"checked_rows": k_rows, "mismatches": 0 if got == int(want) else 1,
+                              "what": "per-entry counts of the HIP result summed over the sampled rows == the CPU reference's count"}
+            if got != int(want):
+                print(json.dumps({"error": "parity", "workload": args.workload, "got": got, "want": int(want)}))
+                sys.exit(3)
     print(json.dumps(line))
 
 

@@ -122,6 +122,7 @@ _SIGS = {
                              C.POINTER(_i), C.POINTER(C.c_int64)],
     "grb_sssp_set_nearfar": [_i],
     "grb_sssp_last_order": [],
+    "grb_sssp_last_work": [_vp],
     "grb_spmv_plan_info": [_vp, _i, _i, C.POINTER(_i), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(_i)],
     "grb_bfs_batch": [_vp, _i, _vp, _vp, _vp, _vp],
     "grb_descriptor_iter_log": [_vp, _vp, _i, C.POINTER(_i)],

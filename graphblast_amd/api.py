@@ -558,6 +558,13 @@ def sssp_set_nearfar(mode=-2):
     return int(_lib.load().grb_sssp_set_nearfar(int(mode)))
 
 
+def sssp_last_work():
+    """(vertices expanded, out-edges relaxed, vertices marked) over all passes of the last near / far sssp()"""
+    out = (C.c_int64 * 3)()
+    _lib.load().grb_sssp_last_work(out)
+    return tuple(int(x) for x in out)
+
+
 def sssp_last_order():
     """0: the last sssp() ran the reference's synchronous rounds; else the passes of the near / far order."""
     return int(_lib.load().grb_sssp_last_order())

@@ -615,6 +615,7 @@ grb_info k_spmv_plan_info(const CsrArrays& M, SpmvPlan& plan, const Index* other
                           long long* band_nnz, long long* pieces, int* nhot);
 int sssp_nearfar_setting(int set, bool apply);   // sssp_nearfar.hip
 int sssp_last_order(int set);                    // set < 0 queries
+void sssp_last_work(long long* out3);            // near / far: vertices expanded, out-edges relaxed, vertices marked, all passes
 grb_info sssp_nearfar_run(grb_vector v, grb_matrix A, grb_index source, grb_descriptor desc, int* iterations,
                           double* succ, float* tight_ms, int* passes);   // sssp_nearfar.hip
 grb_info k_spmv_masked_or(int dtype, const CsrArrays& M, const void* u, double identity,

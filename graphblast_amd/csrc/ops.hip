@@ -423,6 +423,7 @@ grb_info grb_spmv_format_info(grb_matrix A, int tran, int* in_use, int64_t* grou
 }
 int grb_sssp_set_nearfar(int mode) { return sssp_nearfar_setting(mode, mode >= -1); }
 int grb_sssp_last_order(void) { return sssp_last_order(-1); }
+void grb_sssp_last_work(int64_t* out3) { long long w[3]; sssp_last_work(w); if (out3) for (int i = 0; i < 3; ++i) out3[i] = w[i]; }
 
 grb_info grb_spmv_plan_info(grb_matrix A, int tran, int warm, int* bands, int64_t* band_nnz, int64_t* pieces,
                             int* nhot) {

@@ -31,7 +31,7 @@ typedef unsigned long long u64;
 
 struct NfState {                    // zeroed by the host before every launch
   GridBarrier bar;
-  u64 acc[3][8][16];                // per (set, XCD group): expanded, left far, made dirty
+  u64 acc[3][8][16];                // per (set, XCD group): expanded, left far, made dirty, out-edges of the expanded
   unsigned int minfar[3][32];       // smallest distance (float bits) among the dirty vertices left far; host sets all ones
   unsigned int maxhops[32];
   unsigned int maxdist[32];         // float bits of the largest finite distance
@@ -100,9 +100,9 @@ __device__ inline void nf_relax_batch(const NfArgs& a, float du, unsigned int hu
 
 __global__ __launch_bounds__(kPThreads) void sssp_nearfar_kernel(NfArgs a) {
   __shared__ WaveBits4 s_bits4[kPWaves];
-  __shared__ u64 s_red[kPWaves][3];
+  __shared__ u64 s_red[kPWaves][4];
   __shared__ unsigned int s_min[kPWaves];
-  __shared__ u64 s_tot[3];
+  __shared__ u64 s_tot[4];
   __shared__ unsigned int s_minfar;
   const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
   const int G = gridDim.x;
@@ -115,11 +115,13 @@ __global__ __launch_bounds__(kPThreads) void sssp_nearfar_kernel(NfArgs a) {
   float T = a.delta;                // the source (distance 0) is near
   int pass = 1;
   int converged = 0;
+  u64 cum_expanded = 0, cum_made = 0, cum_relaxed = 0;   // over all passes: what the kernel's algorithmic bytes are priced on
   for (; pass <= a.max_passes; ++pass) {
     // the next pass's totals (nobody touches them during this one)
-    if (blockIdx.x == 0 && tid < 24) publish(&st->acc[(pass + 1) % 3][tid / 3][tid % 3], 0ull);
-    if (blockIdx.x == 0 && tid == 24) publish(&st->minfar[(pass + 1) % 3][0], 0xffffffffu);
+    if (blockIdx.x == 0 && tid < 32) publish(&st->acc[(pass + 1) % 3][tid / 4][tid % 4], 0ull);
+    if (blockIdx.x == 0 && tid == 32) publish(&st->minfar[(pass + 1) % 3][0], 0xffffffffu);
     unsigned int expanded = 0, far = 0, made = 0, mymin = 0xffffffffu;
+    u64 relaxed = 0;                  // out-edges of the vertices expanded (accounting only)
     // A wave walks its words up to `inner` (2) times per pass, as long as the last walk expanded something: what
     // it (or anybody) made dirty and near in its own words meanwhile moves on without waiting for the barrier.
     for (int walk = 0; walk < a.inner; ++walk) {
@@ -150,6 +152,7 @@ __global__ __launch_bounds__(kPThreads) void sssp_nearfar_kernel(NfArgs a) {
             s = a.optr[v];
             e = a.optr[v + 1];
             ++expanded;
+            relaxed += (u64)(e - s);
           } else {
             ++far;
             mymin = dbits < mymin ? dbits : mymin;
@@ -172,16 +175,17 @@ __global__ __launch_bounds__(kPThreads) void sssp_nearfar_kernel(NfArgs a) {
     // ---- totals
     auto add = [](u64 x, u64 y) { return x + y; };
     const u64 r0 = wave_reduce((u64)expanded, add), r1 = wave_reduce((u64)far, add), r2 = wave_reduce((u64)made, add);
+    const u64 r3 = wave_reduce(relaxed, add);
     const unsigned int rm = wave_reduce(mymin, [](unsigned int x, unsigned int y) { return x < y ? x : y; });
-    if (lane == 0) { s_red[wave][0] = r0; s_red[wave][1] = r1; s_red[wave][2] = r2; s_min[wave] = rm; }
+    if (lane == 0) { s_red[wave][0] = r0; s_red[wave][1] = r1; s_red[wave][2] = r2; s_red[wave][3] = r3; s_min[wave] = rm; }
     __syncthreads();
     u64* acc = &st->acc[pass % 3][0][0];
-    if (tid < 3) {
+    if (tid < 4) {
       u64 t = 0;
       for (int w2 = 0; w2 < kPWaves; ++w2) t += s_red[w2][tid];
       if (t) __hip_atomic_fetch_add(&acc[(blockIdx.x & 7) * 16 + tid], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (tid == 3) {
+    if (tid == 4) {
       unsigned int m = 0xffffffffu;
       for (int w2 = 0; w2 < kPWaves; ++w2) m = s_min[w2] < m ? s_min[w2] : m;
       if (m != 0xffffffffu) atomicMin(&st->minfar[pass % 3][0], m);
@@ -193,11 +197,12 @@ __global__ __launch_bounds__(kPThreads) void sssp_nearfar_kernel(NfArgs a) {
       q += __shfl_xor(q, 4, kWave);
       q += __shfl_xor(q, 8, kWave);
       q += __shfl_xor(q, 16, kWave);
-      if (lane < 3) s_tot[lane] = q;
+      if (lane < 4) s_tot[lane] = q;
       if (lane == 0) s_minfar = fresh(&st->minfar[pass % 3][0]);
     }
     __syncthreads();
     const u64 t_expanded = s_tot[0], t_far = s_tot[1], t_made = s_tot[2];
+    cum_expanded += t_expanded; cum_made += t_made; cum_relaxed += s_tot[3];
     const unsigned int t_minfar = s_minfar;
     __syncthreads();
     // vertices made dirty in this pass may be near or far: only "nothing expanded, nothing dirty" is the end
@@ -230,10 +235,12 @@ __global__ __launch_bounds__(kPThreads) void sssp_nearfar_kernel(NfArgs a) {
   if (gtid == 0) {
     const u64 tag = (u64)(unsigned int)a.seq << 32;
     const float ms = (float)(wall_clock64() - t_start) * a.ticks_to_ms;
-    const unsigned int vals[5] = {fresh(&st->maxhops[0]), (unsigned int)pass, __float_as_uint(ms), (unsigned int)converged,
-                                  fresh(&st->maxdist[0])};
+    const unsigned int vals[8] = {fresh(&st->maxhops[0]), (unsigned int)pass, __float_as_uint(ms), (unsigned int)converged,
+                                  fresh(&st->maxdist[0]), (unsigned int)(cum_expanded > 0xffffffffull ? 0xffffffffull : cum_expanded),
+                                  (unsigned int)(cum_relaxed >> 4 > 0xffffffffull ? 0xffffffffull : cum_relaxed >> 4),
+                                  (unsigned int)(cum_made > 0xffffffffull ? 0xffffffffull : cum_made)};
 #pragma unroll
-    for (int k = 0; k < 5; ++k)
+    for (int k = 0; k < 8; ++k)
       __hip_atomic_store(&a.mail[k], tag | vals[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
@@ -277,7 +284,9 @@ int grb::sssp_nearfar_setting(int set, bool apply) {
 }
 static int nearfar_env() { return sssp_nearfar_setting(0, false); }
 static int g_barrier_failures = 0;   // consecutive launches whose grid barrier gave up
+static long long g_last_work[3] = {0, 0, 0};
 static int g_last_order = 0;         // what the last grb_sssp of this process ran: 0 synchronous rounds, else near / far (its passes)
+void grb::sssp_last_work(long long* out3) { for (int i = 0; i < 3; ++i) out3[i] = g_last_work[i]; }
 int grb::sssp_last_order(int set) {
   if (set >= 0) g_last_order = set;
   return g_last_order;
@@ -366,8 +375,8 @@ grb_info grb::sssp_nearfar_run(grb_vector v, grb_matrix A, grb_index source, grb
   GRB_HIP_TRY(hipGetLastError());
   hipLaunchKernelGGL(sssp_nearfar_kernel, dim3(c.num_cu), dim3(kPThreads), 0, s, a);
   GRB_HIP_TRY(hipGetLastError());
-  unsigned int gv[5];
-  if (wait_granules(a.seq, 5, gv) != GRB_SUCCESS) {       // the barrier gave up: round-exact path
+  unsigned int gv[8];
+  if (wait_granules(a.seq, 8, gv) != GRB_SUCCESS) {       // the barrier gave up: round-exact path
     ++g_barrier_failures;
     return GRB_NOT_IMPLEMENTED;
   }
@@ -384,5 +393,8 @@ grb_info grb::sssp_nearfar_run(grb_vector v, grb_matrix A, grb_index source, grb
   if (passes) *passes = (int)gv[1];
   desc->iter_log.clear();
   g_last_order = (int)gv[1] > 0 ? (int)gv[1] : 1;       // the passes it took
+  g_last_work[0] = (long long)gv[5];                    // vertices expanded, out-edges relaxed, vertices made dirty: all passes
+  g_last_work[1] = (long long)gv[6] << 4;
+  g_last_work[2] = (long long)gv[7];
   return GRB_SUCCESS;
 }

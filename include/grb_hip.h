@@ -442,6 +442,9 @@ int grb_sssp_set_nearfar(int mode);
 /* 0 if the last grb_sssp of this process produced its result with the synchronous rounds, else the number of
  * passes the near / far order took. */
 int grb_sssp_last_order(void);
+/* After a grb_sssp that ran the near / far order: {vertices expanded, out-edges relaxed, vertices marked dirty} summed
+ * over its passes -- what that kernel's algorithmic bytes are priced on (bench.py, config 3). */
+void grb_sssp_last_work(int64_t* out3);
 
 /* Batched traversals = the multi-frontier product (extension; the reference leaves sparse x dense
  * mxm a stub, backend/cuda/operations.hpp:52-70, spmm.hpp:15-27): 1 <= k <= 64 sources traversed at

@@ -90,10 +90,10 @@ def pr(row_ptr, col_ind, alpha=0.85, eps=1e-8, max_niter=10):
     return rank, it
 
 
-def tc(row_ptr, col_ind):
-    """SimpleReferenceTc<int> (test_tc.hpp:41-87)."""
+def tc(row_ptr, col_ind, nrows=None):
+    """SimpleReferenceTc<int> (test_tc.hpp:41-87).  nrows: only the first rows' wedges (its loop bound)."""
     rp, ci = _i(row_ptr), _i(col_ind)
-    return _libs()[0].ref_tc(rp.size - 1, _pi(rp), _pi(ci))
+    return _libs()[0].ref_tc(rp.size - 1 if nrows is None else int(nrows), _pi(rp), _pi(ci))
 
 
 def lgc(row_ptr, col_ind, val, src, alpha, eps, max_niter, dense=False):

@@ -104,10 +104,10 @@ def cc_canonical(label):
     return out
 
 
-def tc(row_ptr, col_ind):
+def tc(row_ptr, col_ind, nrows=None):
     rp, ci = _i32(row_ptr), _i32(col_ind)
     nt = ctypes.c_longlong(0)
-    ms = lib().oracle_tc(rp.size - 1, _p(rp, ctypes.c_int), _p(ci, ctypes.c_int), ctypes.byref(nt))
+    ms = lib().oracle_tc(rp.size - 1 if nrows is None else int(nrows), _p(rp, ctypes.c_int), _p(ci, ctypes.c_int), ctypes.byref(nt))
     return nt.value, ms
 
 
