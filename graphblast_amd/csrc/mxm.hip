@@ -17,6 +17,8 @@
 //   grb_reduce_matrix_scalar  reduce.hpp:81-91
 #include "common.hpp"
 
+#include <algorithm>
+
 namespace grb {
 
 constexpr int kLaneDotMax = 16;     // dot products whose shorter list is longer go to the whole wave
@@ -63,14 +65,20 @@ __global__ __launch_bounds__(kBlock) void spgemm_masked_kernel(
     T* __restrict__ c_val, const Index* __restrict__ m_row, const Index* __restrict__ m_ind,
     const void* __restrict__ m_val, int mask_f32, const Index* __restrict__ a_ptr, const Index* __restrict__ a_ind,
     const T* __restrict__ a_val, const Index* __restrict__ b_ptr, const Index* __restrict__ b_ind,
-    const T* __restrict__ b_val, Index nvals) {
+    const T* __restrict__ b_val, Index nvals, int only_b_longer /* 1: only the entries whose row of B is longer than
+                                                                   their row of A (the others were done elsewhere) */) {
   typedef Semiring<SR, T> S;
   const int lane = lane_id();
   const Index wave_global = (Index)blockIdx.x * kWavesPerBlock + wave_id();
   const Index nwaves = (Index)gridDim.x * kWavesPerBlock;
   for (Index base = wave_global * kWave; base < nvals; base += nwaves * kWave) {
     const Index e = base + lane;
-    const bool valid = e < nvals && mask_nonzero(m_val, mask_f32, e);
+    bool mine = e < nvals;
+    if (mine && only_b_longer) {
+      const Index row = m_row[e], col = m_ind[e];
+      mine = b_ptr[col + 1] - b_ptr[col] > a_ptr[row + 1] - a_ptr[row];
+    }
+    const bool valid = mine && mask_nonzero(m_val, mask_f32, e);
     Index ss = 0, se = 0, ls = 0, le = 0;
     bool a_short = true;
     if (valid) {
@@ -120,8 +128,428 @@ __global__ __launch_bounds__(kBlock) void spgemm_masked_kernel(
       part = wave_reduce(part, [](T x, T y) { return S::add(x, y); });
       if (lane == src) acc = part;
     }
-    if (e < nvals) c_val[e] = acc;
+    if (mine) c_val[e] = acc;
   }
+}
+
+// ---- the pivot-driven form ("wavefront per row, the row of L cached in LDS") ---------------------
+// The entry-driven kernel above walks the shorter list of a mask entry and binary-searches the longer one in global
+// memory, every lane on its own chain of dependent loads.  Here the LONGER list of an entry is a pivot that goes into
+// an LDS hash table (column -> value) once, and the shorter lists of all the entries that share the pivot are
+// streamed past it: coalesced reads, one LDS probe per element, no searching.
+//   pass 1, pivot = row i of A      the entries (i, j) of the mask's row i whose row j of B is not longer than row i
+//   pass 2, pivot = row j of B      the entries (i, j) of the mask's COLUMN j (its CSC) whose row i of A is shorter
+// so every entry is done exactly once, at min(d_i, d_j) probes.  Inside a pivot the elements of all its partner lists
+// form ONE index space dealt to the lanes (prefix sums of the partner lengths in LDS): a lane's work does not depend
+// on how long "its" list is, consecutive lanes read consecutive elements, and the per-entry sums are accumulated in
+// LDS with the monoid's atomic.  Pivots of up to kWaveCap entries are a wave's (64 partners per tile); longer ones
+// take a 1024-thread workgroup (1024 partners per tile) whose table is 64 KiB of LDS (two workgroups per CU): 4096
+// (key, value) slots -- or 8192 keys when the pivot side holds one value throughout, as a pattern matrix does -- and
+// a global arena for pivots beyond that.  Without a CSC of the mask pass 2 falls back to the entry-driven kernel for its entries.
+constexpr int kWaveCap = 512;              // pivot entries a wave's table holds (1024 slots x 8 B = 8 KiB per wave)
+constexpr int kWaveSlots = 2 * kWaveCap;
+constexpr unsigned int kEmptyKey = 0xffffffffu;
+
+struct HashSlot { unsigned int key; unsigned int val; };
+struct KeySlot { unsigned int key; };                      // the pivot side's values are all equal: nothing to store
+
+__device__ inline unsigned int tc_hash(unsigned int c) { return c * 2654435761u; }
+
+// Tables are probed sixteen bytes at a time (four keys, or two (key, value) pairs): a probe is one LDS round trip and
+// almost always the only one -- slot by slot, the lanes of a wave wait for the longest chain among them, and that
+// chain of dependent LDS reads, not any memory traffic, was what bounded the kernel.  Insertion fills the first free
+// slot of the key's group, then of the following groups; a lookup stops at the first group with a free slot.
+// Slots are read and written with workgroup-scope atomics: the table may live in global memory (the arena of the
+// longest rows), where one wave's plain store need not be what another wave of the workgroup loads.
+typedef unsigned int TcWord4 __attribute__((ext_vector_type(4)));
+
+__device__ inline void tc_insert(HashSlot* tab, unsigned int mask, unsigned int col, unsigned int vbits) {
+  unsigned int s = (tc_hash(col) >> 7) & mask & ~1u;
+  for (;;) {
+    for (int j = 0; j < 2; ++j) {
+      const unsigned int old = atomicCAS(&tab[s + j].key, kEmptyKey, col);
+      if (old == kEmptyKey || old == col) {
+        __hip_atomic_store(&tab[s + j].val, vbits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        return;
+      }
+    }
+    s = (s + 2) & mask;
+  }
+}
+__device__ inline void tc_insert(KeySlot* tab, unsigned int mask, unsigned int col, unsigned int) {
+  unsigned int s = (tc_hash(col) >> 7) & mask & ~3u;
+  for (;;) {
+    for (int j = 0; j < 4; ++j) {
+      const unsigned int old = atomicCAS(&tab[s + j].key, kEmptyKey, col);
+      if (old == kEmptyKey || old == col) return;
+    }
+    s = (s + 4) & mask;
+  }
+}
+__device__ inline TcWord4 tc_group(const void* tab, unsigned int slot_bytes_index) {
+  return *reinterpret_cast<const TcWord4*>(reinterpret_cast<const char*>(tab) + slot_bytes_index);
+}
+__device__ inline bool tc_find(const KeySlot* tab, unsigned int mask, unsigned int col, unsigned int*) {
+  unsigned int s = (tc_hash(col) >> 7) & mask & ~3u;
+  for (;;) {
+    const TcWord4 g = tc_group(tab, s * 4u);
+    if (g.x == col || g.y == col || g.z == col || g.w == col) return true;
+    if (g.x == kEmptyKey || g.y == kEmptyKey || g.z == kEmptyKey || g.w == kEmptyKey) return false;
+    s = (s + 4) & mask;
+  }
+}
+__device__ inline bool tc_find(const HashSlot* tab, unsigned int mask, unsigned int col, unsigned int* vbits) {
+  unsigned int s = (tc_hash(col) >> 7) & mask & ~1u;
+  for (;;) {
+    const TcWord4 g = tc_group(tab, s * 8u);
+    if (g.x == col) { *vbits = g.y; return true; }
+    if (g.z == col) { *vbits = g.w; return true; }
+    if (g.x == kEmptyKey || g.z == kEmptyKey) return false;
+    s = (s + 2) & mask;
+  }
+}
+
+// first group of a key, and the verdict of one group: 1 found (value in *vbits), 0 absent, -1 look at the next group
+__device__ inline unsigned int tc_home(const KeySlot*, unsigned int mask, unsigned int col) { return (tc_hash(col) >> 7) & mask & ~3u; }
+__device__ inline unsigned int tc_home(const HashSlot*, unsigned int mask, unsigned int col) { return (tc_hash(col) >> 7) & mask & ~1u; }
+__device__ inline TcWord4 tc_load(const KeySlot* tab, unsigned int s) { return tc_group(tab, s * 4u); }
+__device__ inline TcWord4 tc_load(const HashSlot* tab, unsigned int s) { return tc_group(tab, s * 8u); }
+__device__ inline int tc_verdict(const KeySlot*, TcWord4 g, unsigned int col, unsigned int*) {
+  if (g.x == col || g.y == col || g.z == col || g.w == col) return 1;
+  if (g.x == kEmptyKey || g.y == kEmptyKey || g.z == kEmptyKey || g.w == kEmptyKey) return 0;
+  return -1;
+}
+__device__ inline int tc_verdict(const HashSlot*, TcWord4 g, unsigned int col, unsigned int* vbits) {
+  if (g.x == col) { *vbits = g.y; return 1; }
+  if (g.z == col) { *vbits = g.w; return 1; }
+  if (g.x == kEmptyKey || g.z == kEmptyKey) return 0;
+  return -1;
+}
+__device__ inline unsigned int tc_step(const KeySlot*) { return 4u; }
+__device__ inline unsigned int tc_step(const HashSlot*) { return 2u; }
+
+// monoid-specific atomic combine of a per-entry sum in LDS
+template <int SR, typename T>
+__device__ inline void tc_accumulate(T* addr, T v) {
+  typedef Semiring<SR, T> S;
+  constexpr bool int_sum = [] {
+    if constexpr (SR == GRB_RUNTIME_SR) return false;
+    else return MonoidTraits<SemiringTraits<SR>::monoid>::op == OP_PLUS && std::is_same<T, int>::value;
+  }();
+  if constexpr (int_sum) {
+    atomicAdd(addr, v);
+  } else {
+    unsigned int* a = reinterpret_cast<unsigned int*>(addr);
+    unsigned int old = *a, assumed;
+    do {
+      assumed = old;
+      T cur;
+      memcpy(&cur, &assumed, 4);
+      const T nv = S::add(v, cur);
+      unsigned int nb;
+      memcpy(&nb, &nv, 4);
+      old = atomicCAS(a, assumed, nb);
+    } while (old != assumed);
+  }
+}
+
+// The lanes of a wave hold products for partners `key` (non-decreasing across the lanes: they read consecutive
+// elements): a segmented scan folds each partner's run inside the wave, and only the last lane of a run touches the
+// partner's sum in LDS.  (One atomic per lane instead: most lanes of a wave hit the SAME word, and the LDS serialises
+// same-address atomics -- 65 cycles per wave instruction, tools/probes/lds_atomic_probe.hip.)
+template <int SR, typename T>
+__device__ inline void tc_commit_runs(T* acc, int key, T c, bool active, int lane) {
+  typedef Semiring<SR, T> S;
+  if (!active) key = -1 - lane;                            // a run of its own, never committed
+#pragma unroll
+  for (int o = 1; o < kWave; o <<= 1) {
+    const T y = __shfl_up(c, o, kWave);
+    const int ky = __shfl_up(key, o, kWave);
+    if (lane >= o && ky == key) c = S::add(y, c);
+  }
+  const int knext = __shfl_down(key, 1, kWave);
+  if (active && (lane == kWave - 1 || knext != key)) tc_accumulate<SR, T>(&acc[key], c);
+}
+
+// What the two passes differ in.  `major` arrays: the pivot's side (pass 1: A, pass 2: B); `minor`: the partners'.
+struct PivotView {
+  const Index *piv_ptr, *piv_ind;   const void* piv_val;     // pivot lists
+  const Index *par_ptr, *par_ind;   const void* par_val;     // partner lists
+  const Index *ent_ptr, *ent_ind;                            // the pivot's entries: mask CSR (pass 1) / CSC (pass 2)
+  const Index *m_ptr, *m_ind;       const void* m_val;       // the mask's CSR (output positions, mask values)
+  int mask_f32;
+  int cols;                                                  // 0: pass 1, 1: pass 2
+  unsigned int iso_bits;                                     // the pivot side's one value (key-only tables)
+  int par_iso;                                               // the partner side holds one value throughout ...
+  unsigned int par_iso_bits;                                 // ... this one: its value array is not read
+};
+
+// entry t of pivot r: is it this pass's, its partner list, its position in C
+__device__ inline bool tc_entry_of(const PivotView& v, Index r, Index t, Index dpiv, Index* ps, Index* pe, Index* out) {
+  const Index other = v.ent_ind[t];
+  const Index s = v.par_ptr[other], e = v.par_ptr[other + 1];
+  Index pos = t;
+  if (v.cols) {                                            // (i = other, j = r): where is j in the mask's row i
+    if (!(e - s < dpiv)) return false;                     // pass 1 has it
+    pos = lower_bound_dev(v.m_ind, v.m_ptr[other], v.m_ptr[other + 1], r);
+  } else if (!(e - s <= dpiv)) {
+    return false;
+  }
+  if (!mask_nonzero(v.m_val, v.mask_f32, pos)) return false;
+  *ps = s; *pe = e; *out = pos;
+  return true;
+}
+
+// c = C's values; entries this pass does not own are left alone (the other pass, or the initialisation, has them)
+template <int SR, typename T>
+__global__ __launch_bounds__(kBlock) void spgemm_pivot_wave_kernel(T* __restrict__ c_val, PivotView v, Index npivots) {
+  typedef Semiring<SR, T> S;
+  __shared__ HashSlot s_tab[kWavesPerBlock][kWaveSlots];
+  __shared__ Index s_off[kWavesPerBlock][kWave + 1];
+  __shared__ Index s_start[kWavesPerBlock][kWave];
+  __shared__ T s_acc[kWavesPerBlock][kWave];
+  const int lane = lane_id(), wave = wave_id();
+  HashSlot* tab = s_tab[wave];
+  Index* off = s_off[wave];
+  const T* __restrict__ par_val = reinterpret_cast<const T*>(v.par_val);
+  const T* __restrict__ piv_val = reinterpret_cast<const T*>(v.piv_val);
+  T par_one;
+  memcpy(&par_one, &v.par_iso_bits, 4);
+  const Index nwaves = (Index)gridDim.x * kWavesPerBlock;
+  for (Index r = (Index)blockIdx.x * kWavesPerBlock + wave; r < npivots; r += nwaves) {
+    const Index es = v.ent_ptr[r], ee = v.ent_ptr[r + 1];
+    if (ee == es) continue;
+    const Index as = v.piv_ptr[r], ae = v.piv_ptr[r + 1];
+    const Index da = ae - as;
+    if (da > kWaveCap || da == 0) continue;               // the workgroup kernel's / nothing to intersect with
+    bool built = false;
+    unsigned int tmask = 0;
+    for (Index t0 = es; t0 < ee; t0 += kWave) {
+      // ---- this tile's partners: one per lane
+      const Index t = t0 + lane;
+      Index ps = 0, pe = 0, out = 0;
+      const bool mine = t < ee && tc_entry_of(v, r, t, da, &ps, &pe, &out);
+      const Index len = mine ? pe - ps : 0;
+      Index incl = len;
+#pragma unroll
+      for (int o = 1; o < kWave; o <<= 1) {
+        const Index y = __shfl_up(incl, o, kWave);
+        if (lane >= o) incl += y;
+      }
+      const Index total = __shfl(incl, kWave - 1, kWave);
+      if (__ballot(mine) == 0ull) continue;
+      if (!built) {                                        // the pivot's table, once, and only if somebody needs it
+        unsigned int slots = 64;
+        while ((Index)slots < 2 * da) slots <<= 1;
+        tmask = slots - 1;
+        for (unsigned int i = lane; i < slots; i += kWave) tab[i].key = kEmptyKey;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (Index p = as + lane; p < ae; p += kWave) {
+          unsigned int vb;
+          const T av = piv_val[p];
+          memcpy(&vb, &av, 4);
+          tc_insert(tab, tmask, (unsigned int)v.piv_ind[p], vb);
+        }
+        built = true;
+      }
+      off[lane] = incl - len;
+      if (lane == kWave - 1) off[kWave] = total;
+      s_start[wave][lane] = ps;
+      s_acc[wave][lane] = S::identity();
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      // ---- the partners' elements as one index space
+      for (Index x0 = 0; x0 < total; x0 += kWave) {
+        const Index x = x0 + lane;
+        const bool live = x < total;
+        int lo = 0;                                        // last partner whose offset is <= x
+        T prod = S::identity();
+        if (live) {
+#pragma unroll
+          for (int step = kWave / 2; step > 0; step >>= 1)
+            if (off[lo + step] <= x) lo += step;
+          const Index q = s_start[wave][lo] + (x - off[lo]);
+          unsigned int vb;
+          if (tc_find(tab, tmask, (unsigned int)v.par_ind[q], &vb)) {
+            T pv;
+            memcpy(&pv, &vb, 4);
+            const T bv = v.par_iso ? par_one : par_val[q];
+            prod = v.cols ? S::mul(bv, pv) : S::mul(pv, bv);
+          }
+        }
+        tc_commit_runs<SR, T>(s_acc[wave], lo, prod, live, lane);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      if (mine) c_val[out] = s_acc[wave][lane];
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+}
+
+// pivots longer than kWaveCap: a 1024-thread workgroup per run of entries (listed in big), table in LDS or -- beyond
+// kCap entries -- in this workgroup's slice of a global arena (arena_slots per workgroup, a power of two)
+struct PivotItem { Index pivot, e0, e1; };                // a run of a long pivot's entries (whole tiles of 1024)
+
+template <int SR, typename T, bool kArena, typename Slot, int kTableBytes>
+__global__ __launch_bounds__(1024) void spgemm_pivot_block_kernel(T* __restrict__ c_val, PivotView v,
+                                                                  const PivotItem* __restrict__ big, int nbig,
+                                                                  Slot* __restrict__ arena, unsigned int arena_slots,
+                                                                  Index min_len, unsigned long long* __restrict__ trace) {
+  typedef Semiring<SR, T> S;
+  // kTableBytes of LDS table at half load: 64 KiB = two workgroups per CU; the 128 KiB instantiation takes the
+  // pivots too long for that one; the arena instantiation those too long for any LDS table
+  constexpr int kCap = kTableBytes / (int)sizeof(Slot) / 2;
+  const unsigned long long t_begin = wall_clock64();
+  unsigned long long t_items = 0;
+  int n_items = 0;
+  __shared__ Slot s_tab[kArena ? 1 : 2 * kCap];
+  const int tid = threadIdx.x, lane = tid & (kWave - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const T* __restrict__ par_val = reinterpret_cast<const T*>(v.par_val);
+  const T* __restrict__ piv_val = reinterpret_cast<const T*>(v.piv_val);
+  T par_one;
+  memcpy(&par_one, &v.par_iso_bits, 4);
+  for (int bi = blockIdx.x; bi < nbig; bi += gridDim.x) {
+    const Index r = big[bi].pivot;
+    const Index es = big[bi].e0, ee = big[bi].e1;
+    const Index as = v.piv_ptr[r], ae = v.piv_ptr[r + 1];
+    const Index da = ae - as;
+    if (kArena ? da <= min_len : (da > kCap || da <= min_len)) continue;   // another instantiation's
+    const unsigned long long t_item = wall_clock64();
+    ++n_items;
+    Slot* tab = kArena ? arena + (size_t)blockIdx.x * arena_slots : s_tab;
+    unsigned int slots = 1024;
+    while ((Index)slots < 2 * da) slots <<= 1;
+    const unsigned int tmask = slots - 1;
+    __syncthreads();
+    for (unsigned int i = tid; i < slots; i += 1024) __hip_atomic_store(&tab[i].key, kEmptyKey, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __threadfence_block();
+    __syncthreads();
+    for (Index p = as + tid; p < ae; p += 1024) {
+      unsigned int vb;
+      const T av = piv_val[p];
+      memcpy(&vb, &av, 4);
+      tc_insert(tab, tmask, (unsigned int)v.piv_ind[p], vb);
+    }
+    __threadfence_block();
+    __syncthreads();
+    if (kArena) {                                          // the probes are plain loads: drop what this CU's L1 still
+      if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // holds of the slice's previous table
+      __syncthreads();
+    }
+    // A wave per partner: the pivots here are long, and so are their partners on average (RMAT-22 ef 28: 450
+    // entries) -- the lanes stride one list, count in registers, fold once.  No LDS bookkeeping, no atomics: the
+    // flat-index form this replaces issued ~400 instructions per 64 elements and was bound by that.  The partners'
+    // descriptors (list bounds, output position: three to twenty dependent loads each) are fetched 64 at a time,
+    // one per lane, and handed round with shuffles -- fetched by the wave as scalars they cost a latency chain each.
+    for (Index t0 = es + wave * kWave; t0 < ee; t0 += 1024) {
+      const Index t = t0 + lane;
+      Index ps = 0, pe = 0, out = 0;
+      const bool mine = t < ee && tc_entry_of(v, r, t, da, &ps, &pe, &out);
+      T result = S::identity();
+      // The partners' lists as one sequence of 256-element chunks, software-pipelined: the keys of the next chunk
+      // (the same partner's, or the next partner's first) are in flight while the current chunk is probed -- a
+      // partner is a couple of dependent memory steps otherwise, and a wave does hundreds of them one after the other.
+      unsigned long long todo = __ballot(mine);
+      int src_n = todo ? __ffsll((long long)todo) - 1 : -1;   // partner the next chunk belongs to
+      Index cs_n = 0, ce_n = 0;
+      if (src_n >= 0) { cs_n = __shfl(ps, src_n, kWave); ce_n = __shfl(pe, src_n, kWave); todo &= todo - 1; }
+      unsigned int kn[4] = {kEmptyKey, kEmptyKey, kEmptyKey, kEmptyKey};
+      Index q_n = cs_n;
+      auto fetch = [&]() {
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+          const Index q = q_n + h * kWave + lane;
+          kn[h] = (src_n >= 0 && q < ce_n) ? (unsigned int)v.par_ind[q] : kEmptyKey;   // the empty key is in no table
+        }
+      };
+      fetch();
+      T acc = S::identity();
+      while (src_n >= 0) {
+        // the chunk just fetched becomes the current one
+        unsigned int kc[4];
+#pragma unroll
+        for (int h = 0; h < 4; ++h) kc[h] = kn[h];
+        const int src_c = src_n;
+        const Index q_c = q_n;
+        const bool last_of_partner = q_n + 4 * kWave >= ce_n;
+        // ... and the next one is requested before this one is looked at
+        if (!last_of_partner) {
+          q_n += 4 * kWave;
+        } else if (todo) {
+          src_n = __ffsll((long long)todo) - 1;
+          todo &= todo - 1;
+          cs_n = __shfl(ps, src_n, kWave);
+          ce_n = __shfl(pe, src_n, kWave);
+          q_n = cs_n;
+        } else {
+          src_n = -1;
+        }
+        fetch();
+        // the four keys' home groups are read together (one LDS round trip); a key whose group is full and does
+        // not hold it -- rare at half load -- walks on alone
+        TcWord4 gr[4];
+        unsigned int home[4];
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+          home[h] = tc_home(tab, tmask, kc[h] != kEmptyKey ? kc[h] : 0u);
+          gr[h] = tc_load(tab, home[h]);
+        }
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+          if (kc[h] == kEmptyKey) continue;
+          unsigned int vb = v.iso_bits;
+          int verdict = tc_verdict(tab, gr[h], kc[h], &vb);
+          for (unsigned int sl = home[h]; verdict < 0;) {
+            sl = (sl + tc_step(tab)) & tmask;
+            verdict = tc_verdict(tab, tc_load(tab, sl), kc[h], &vb);
+          }
+          if (verdict > 0) {
+            T pv;
+            memcpy(&pv, &vb, 4);
+            const T bv = v.par_iso ? par_one : par_val[q_c + h * kWave + lane];
+            acc = S::add(v.cols ? S::mul(bv, pv) : S::mul(pv, bv), acc);
+          }
+        }
+        if (last_of_partner) {
+          acc = wave_reduce(acc, [](T x, T y) { return S::add(x, y); });
+          if (lane == src_c) result = acc;
+          acc = S::identity();
+        }
+      }
+      if (mine) c_val[out] = result;
+    }
+    const unsigned long long dt = wall_clock64() - t_item;
+    t_items = dt > t_items ? dt : t_items;
+  }
+  if (trace && threadIdx.x == 0) {
+    trace[3 * blockIdx.x] = wall_clock64() - t_begin;
+    trace[3 * blockIdx.x + 1] = t_items;
+    trace[3 * blockIdx.x + 2] = (unsigned long long)n_items;
+  }
+}
+
+// min and max of the raw 4-byte values (out preset to {~0, 0}): equal = one value throughout
+__global__ __launch_bounds__(kBlock) void value_range_kernel(const unsigned int* __restrict__ val, Index n, unsigned int* __restrict__ out) {
+  unsigned int lo = 0xffffffffu, hi = 0u;
+  const Index stride = (Index)gridDim.x * blockDim.x;
+  for (Index i = (Index)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const unsigned int x = val[i];
+    lo = x < lo ? x : lo;
+    hi = x > hi ? x : hi;
+  }
+  lo = wave_reduce(lo, [](unsigned int a, unsigned int b) { return a < b ? a : b; });
+  hi = wave_reduce(hi, [](unsigned int a, unsigned int b) { return a > b ? a : b; });
+  if (lane_id() == 0) { atomicMin(&out[0], lo); atomicMax(&out[1], hi); }
+}
+
+// C's values start as the semiring's identity (an entry neither pass owns -- a zero in the mask -- keeps it)
+template <typename T>
+__global__ void fill_value_kernel(T* __restrict__ d, Index n, T v) {
+  const Index stride = (Index)gridDim.x * blockDim.x;
+  for (Index i = (Index)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) d[i] = v;
 }
 
 // Stored values (x) a scalar, or (x) a vector entry picked by the row (by_major) or by the stored
@@ -248,20 +676,160 @@ grb_info grb_mxm(grb_matrix C, grb_matrix mask, grb_accum accum, grb_semiring op
   GRB_TRY(build_spmv_plan(C->h_csr_ptr, C->nrows, C->ncols, &C->plan_csr));   // mxv on the result works;
   C->built = true;                               // no CSC is made (as little as the reference's C->dup has one):
   if (mask->nvals == 0) return GRB_SUCCESS;      // products on the transpose return GrB_INVALID_OBJECT
-  void* p_rows;
-  GRB_TRY(scratch(9, 4 * (size_t)mask->nvals, &p_rows));            // not 4 / 5: those hold the push path's state
-  hipLaunchKernelGGL(entry_rows_kernel, dim3(stream_grid(mask->nvals, kBlock)), dim3(kBlock), 0, s, mask->csr.ptr,
-                     mask->nrows, mask->nvals, (Index*)p_rows);
-  GRB_HIP_TRY(hipGetLastError());
+  // ---- pivot-driven passes when the host mirrors of the row pointers are there (they list the long pivots);
+  // GRB_MXM_PIVOT=0 keeps the entry-driven kernel alone
+  static const bool pivot_ok = [] { const char* e = getenv("GRB_MXM_PIVOT"); return !e || atoi(e) != 0; }();
+  const std::vector<Index>& hpa = tran_a ? A->h_csc_ptr : A->h_csr_ptr;
+  const std::vector<Index>& hpb = tran_b ? B->h_csr_ptr : B->h_csc_ptr;
+  const bool use_pivot = pivot_ok && (Index)hpa.size() == Aa.n + 1 && (Index)hpb.size() == Bb.n + 1 &&
+                         (Index)mask->h_csr_ptr.size() == mask->nrows + 1 && Bb.n == mask->ncols;
+  const bool have_csc = use_pivot && mask->csc.ptr && !mask->csc_alias && (Index)mask->h_csc_ptr.size() == mask->ncols + 1;
   const int grid = stream_grid(mask->nvals, kBlock);
+  void* p_rows = nullptr;
+  if (!use_pivot || !have_csc) {
+    GRB_TRY(scratch(9, 4 * (size_t)mask->nvals, &p_rows));            // not 4 / 5: those hold the push path's state
+    hipLaunchKernelGGL(entry_rows_kernel, dim3(stream_grid(mask->nvals, kBlock)), dim3(kBlock), 0, s, mask->csr.ptr,
+                       mask->nrows, mask->nvals, (Index*)p_rows);
+    GRB_HIP_TRY(hipGetLastError());
+  }
   return dispatch_semiring(op, A->dtype, [&](auto tag, auto t) -> grb_info {
     using T = decltype(t);
     constexpr int SR = decltype(tag)::value;
-    hipLaunchKernelGGL((spgemm_masked_kernel<SR, T>), dim3(grid), dim3(kBlock), 0, s, (T*)C->csr.val,
-                       (const Index*)p_rows, mask->csr.ind, mask->csr.val, mask->dtype == GRB_F32, Aa.ptr, Aa.ind,
-                       (const T*)Aa.val, Bb.ptr, Bb.ind, (const T*)Bb.val, mask->nvals);
+    auto entry_driven = [&](int only_b_longer) -> grb_info {
+      hipLaunchKernelGGL((spgemm_masked_kernel<SR, T>), dim3(grid), dim3(kBlock), 0, s, (T*)C->csr.val,
+                         (const Index*)p_rows, mask->csr.ind, mask->csr.val, mask->dtype == GRB_F32, Aa.ptr, Aa.ind,
+                         (const T*)Aa.val, Bb.ptr, Bb.ind, (const T*)Bb.val, mask->nvals, only_b_longer);
+      GRB_HIP_TRY(hipGetLastError());
+      return GRB_SUCCESS;
+    };
+    if (!use_pivot) return entry_driven(0);
+    hipLaunchKernelGGL((fill_value_kernel<T>), dim3(stream_grid(mask->nvals, kBlock)), dim3(kBlock), 0, s, (T*)C->csr.val,
+                       mask->nvals, Semiring<SR, T>::identity());
     GRB_HIP_TRY(hipGetLastError());
-    return GRB_SUCCESS;
+    std::vector<PivotItem> big;
+    auto run_pass = [&](const PivotView& v, Index npiv, bool piv_iso, const std::vector<Index>& hp_piv,
+                        const std::vector<Index>& hp_ent, int scratch_list, int scratch_arena) -> grb_info {
+      // the long pivots' entries in runs of <= 4 tiles, heaviest first (a run costs about entries x pivot length:
+      // its partners are no longer than the pivot), dealt round-robin: the few giant rows do not become the tail
+      big.clear();
+      Index longest = 0;
+      for (Index r = 0; r < npiv; ++r) {
+        const Index d = hp_piv[(size_t)r + 1] - hp_piv[r];
+        if (d <= kWaveCap || hp_ent[(size_t)r + 1] <= hp_ent[r]) continue;
+        longest = d > longest ? d : longest;
+        for (Index e0 = hp_ent[r]; e0 < hp_ent[(size_t)r + 1]; e0 += 4 * 1024) {
+          const Index e1 = e0 + 4 * 1024 < hp_ent[(size_t)r + 1] ? e0 + 4 * 1024 : hp_ent[(size_t)r + 1];
+          big.push_back(PivotItem{r, e0, e1});
+        }
+      }
+      std::stable_sort(big.begin(), big.end(), [&](const PivotItem& x, const PivotItem& y) {
+        const double cx = (double)(x.e1 - x.e0) * (double)(hp_piv[(size_t)x.pivot + 1] - hp_piv[x.pivot]);
+        const double cy = (double)(y.e1 - y.e0) * (double)(hp_piv[(size_t)y.pivot + 1] - hp_piv[y.pivot]);
+        return cx > cy;
+      });
+      hipLaunchKernelGGL((spgemm_pivot_wave_kernel<SR, T>), dim3(stream_grid((long long)npiv * kWave, kBlock)), dim3(kBlock), 0, s,
+                         (T*)C->csr.val, v, npiv);
+      GRB_HIP_TRY(hipGetLastError());
+      if (big.empty()) return GRB_SUCCESS;
+      // two workgroups per CU (64 KiB tables); is the pivot side one value throughout?  then the tables hold keys only
+      const int bgrid = (int)big.size() < 2 * ctx().num_cu ? (int)big.size() : 2 * ctx().num_cu;
+      void *p_big, *p_arena = nullptr;
+      GRB_TRY(scratch(scratch_list, sizeof(PivotItem) * big.size() + 64, &p_big));
+      GRB_HIP_TRY(hipMemcpyAsync(p_big, big.data(), sizeof(PivotItem) * big.size(), hipMemcpyHostToDevice, s));
+      const bool iso = piv_iso;
+      const PivotView& vv = v;
+      auto launch = [&](auto slot_tag) -> grb_info {
+        using Slot = decltype(slot_tag);
+        const Index cap = 131072 / (Index)sizeof(Slot) / 2;
+        unsigned int arena_slots = 0;
+        if (longest > cap) {
+          arena_slots = 1024;
+          while ((Index)arena_slots < 2 * longest) arena_slots <<= 1;
+          GRB_TRY(scratch(scratch_arena, sizeof(Slot) * (size_t)arena_slots * (size_t)bgrid, &p_arena));
+        }
+        static const bool want_trace = getenv("GRB_MXM_TRACE") != nullptr;
+        unsigned long long* d_trace = nullptr;
+        if (want_trace) {
+          void* p_tr;
+          GRB_TRY(scratch(2, 24 * (size_t)bgrid, &p_tr));
+          d_trace = (unsigned long long*)p_tr;
+        }
+        auto dump = [&](const char* what) -> grb_info {
+          if (!want_trace) return GRB_SUCCESS;
+          std::vector<unsigned long long> h(3 * (size_t)bgrid);
+          GRB_HIP_TRY(hipMemcpy(h.data(), d_trace, 24 * (size_t)bgrid, hipMemcpyDeviceToHost));
+          double sum = 0, mx = 0, mxi = 0, items = 0;
+          for (int g = 0; g < bgrid; ++g) {
+            sum += (double)h[3 * g]; mx = (double)h[3 * g] > mx ? (double)h[3 * g] : mx;
+            mxi = (double)h[3 * g + 1] > mxi ? (double)h[3 * g + 1] : mxi; items += (double)h[3 * g + 2];
+          }
+          fprintf(stderr, "mxm pivot block kernel (%s, pass %d): %d workgroups, %.0f items; busy ticks (100 MHz) mean %.0f max %.0f; "
+                  "longest item %.0f\n", what, vv.cols + 1, bgrid, items, sum / bgrid, mx, mxi);
+          return GRB_SUCCESS;
+        };
+        const Index cap64 = 65536 / (Index)sizeof(Slot) / 2, cap128 = 131072 / (Index)sizeof(Slot) / 2;
+        if (want_trace) GRB_HIP_TRY(hipMemsetAsync(d_trace, 0, 24 * (size_t)bgrid, s));
+        hipLaunchKernelGGL((spgemm_pivot_block_kernel<SR, T, false, Slot, 65536>), dim3(bgrid), dim3(1024), 0, s, (T*)C->csr.val, vv,
+                           (const PivotItem*)p_big, (int)big.size(), (Slot*)nullptr, 0u, (Index)0, d_trace);
+        GRB_HIP_TRY(hipGetLastError());
+        GRB_TRY(dump("64 KiB LDS tables"));
+        if (longest > cap64) {
+          if (want_trace) GRB_HIP_TRY(hipMemsetAsync(d_trace, 0, 24 * (size_t)bgrid, s));
+          hipLaunchKernelGGL((spgemm_pivot_block_kernel<SR, T, false, Slot, 131072>), dim3(bgrid), dim3(1024), 0, s, (T*)C->csr.val, vv,
+                             (const PivotItem*)p_big, (int)big.size(), (Slot*)nullptr, 0u, cap64, d_trace);
+          GRB_HIP_TRY(hipGetLastError());
+          GRB_TRY(dump("128 KiB LDS tables"));
+        }
+        if (longest > cap128) {
+          if (want_trace) GRB_HIP_TRY(hipMemsetAsync(d_trace, 0, 24 * (size_t)bgrid, s));
+          hipLaunchKernelGGL((spgemm_pivot_block_kernel<SR, T, true, Slot, 65536>), dim3(bgrid), dim3(1024), 0, s, (T*)C->csr.val, vv,
+                             (const PivotItem*)p_big, (int)big.size(), (Slot*)p_arena, arena_slots, cap128, d_trace);
+          GRB_HIP_TRY(hipGetLastError());
+          GRB_TRY(dump("arena tables"));
+        }
+        return GRB_SUCCESS;
+      };
+      if (iso) GRB_TRY(launch(KeySlot{}));
+      else GRB_TRY(launch(HashSlot{}));
+      GRB_HIP_TRY(hipStreamSynchronize(s));               // `big` is a host vector the copy above reads
+      return GRB_SUCCESS;
+    };
+    PivotView v1;
+    v1.piv_ptr = Aa.ptr; v1.piv_ind = Aa.ind; v1.piv_val = Aa.val;
+    v1.par_ptr = Bb.ptr; v1.par_ind = Bb.ind; v1.par_val = Bb.val;
+    v1.ent_ptr = mask->csr.ptr; v1.ent_ind = mask->csr.ind;
+    v1.m_ptr = mask->csr.ptr; v1.m_ind = mask->csr.ind; v1.m_val = mask->csr.val;
+    v1.mask_f32 = mask->dtype == GRB_F32;
+    v1.cols = 0;
+    // is a side one value throughout (a pattern matrix)?  then its tables hold keys only and its value array is not read
+    unsigned int rng[4] = {0xffffffffu, 0u, 0xffffffffu, 0u};
+    {
+      void* p_rng;
+      GRB_TRY(scratch(3, 64, &p_rng));
+      GRB_HIP_TRY(hipMemcpyAsync(p_rng, rng, 16, hipMemcpyHostToDevice, s));
+      hipLaunchKernelGGL(value_range_kernel, dim3(stream_grid(Aa.nvals, kBlock * 8)), dim3(kBlock), 0, s,
+                         (const unsigned int*)Aa.val, Aa.nvals, (unsigned int*)p_rng);
+      hipLaunchKernelGGL(value_range_kernel, dim3(stream_grid(Bb.nvals, kBlock * 8)), dim3(kBlock), 0, s,
+                         (const unsigned int*)Bb.val, Bb.nvals, (unsigned int*)p_rng + 2);
+      GRB_HIP_TRY(hipGetLastError());
+      GRB_HIP_TRY(hipMemcpyAsync(rng, p_rng, 16, hipMemcpyDeviceToHost, s));
+      GRB_HIP_TRY(hipStreamSynchronize(s));
+    }
+    const bool iso_a = rng[0] == rng[1] && Aa.nvals > 0, iso_b = rng[2] == rng[3] && Bb.nvals > 0;
+    v1.iso_bits = rng[0];
+    v1.par_iso = iso_b ? 1 : 0;
+    v1.par_iso_bits = rng[2];
+    GRB_TRY(run_pass(v1, Aa.n, iso_a, hpa, mask->h_csr_ptr, 6, 10));
+    if (!have_csc) return entry_driven(1);                // the entries whose row of B is the longer list
+    PivotView v2 = v1;
+    v2.piv_ptr = Bb.ptr; v2.piv_ind = Bb.ind; v2.piv_val = Bb.val;
+    v2.par_ptr = Aa.ptr; v2.par_ind = Aa.ind; v2.par_val = Aa.val;
+    v2.ent_ptr = mask->csc.ptr; v2.ent_ind = mask->csc.ind;
+    v2.cols = 1;
+    v2.iso_bits = rng[2];
+    v2.par_iso = iso_a ? 1 : 0;
+    v2.par_iso_bits = rng[0];
+    return run_pass(v2, Bb.n, iso_b, hpb, mask->h_csc_ptr, 6, 10);
   });
 }
 
