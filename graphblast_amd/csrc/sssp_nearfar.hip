@@ -245,6 +245,348 @@ __global__ __launch_bounds__(kPThreads) void sssp_nearfar_kernel(NfArgs a) {
   }
 }
 
+// ---- the same order from queues ------------------------------------------------------------------------------------
+// A pass of the kernel above is a chain of dependent memory steps, not a throughput problem: a road network's near
+// set is a few thousand vertices, and finding them costs a walk over the whole dirty bitmap (3 MB for 24 M vertices)
+// before the first key is read -- 30 us per pass, 6 947 passes.  Here the near set IS a list, and every step that
+// list would add to the chain is designed away:
+//   * an entry is (distance bits, vertex), written once per successful atomicMin.  No "queued" bit per vertex and
+//     no clearing of it: a vertex lowered twice has two entries, and the one whose distance is no longer the key's
+//     is dropped when it is taken out (one compare against the key that is read anyway);
+//   * an entry at or above the threshold goes to the far pile instead; when a pass leaves the next queue empty the
+//     threshold moves to the smallest far distance + delta and one pass deals the pile out again (live near ones to
+//     the queue, live far ones to the other pile);
+//   * joiners are staged in LDS and each workgroup asks for its slots in the next queue ONCE per pass -- one
+//     global atomic per workgroup instead of one per wave step on the same word (those serialise: measured 10.3 us
+//     per pass with them, whatever the number of workgroups);
+//   * the count of the next queue is the low half of the very word the barrier's last arrivals add to: the poll
+//     that sees everybody arrive has read it.
+// A wave takes 16 queue entries per step and gives each of them 4 lanes, one per out-edge (a road network's rows
+// hold 2-4 entries): every stage -- entry, key + row bounds, edges, atomicMin -- is one wave instruction for all
+// the edges of 16 vertices.  Chain per pass: entry, key / bounds, edges, atomicMin, [LDS], slots, stores, arrive, poll.
+constexpr int kNfqStageNear = 2048; // entries a workgroup stages per pass before it appends one by one
+constexpr int kNfqStageFar = 1024;
+
+// (vertex, float bits of the distance it was given, its row's bounds): everything the pass that takes the entry
+// out needs to issue the edge loads at once -- the key is read beside them, only to see whether the entry is
+// still the vertex's latest and for the hop count
+struct NfqEntry {
+  u64 vd;                           // distance bits << 32 | vertex
+  u64 se;                           // row end << 32 | row start
+};
+
+struct NfqState {                   // zeroed by the host before every launch
+  unsigned int xcd_count[3][8][32]; // barrier b uses set b % 3 (one 128 B line per counter)
+  u64 top[3][16];                   // high half: arrivals; low half: entries of the queue the pass filled
+  unsigned int fcount[2][32];       // entries of the far piles
+  unsigned int minfar[2][32];       // smallest distance (float bits) that went to the pile; host sets all ones
+  unsigned int stop[32];            // 1: a barrier gave up; 2: a list is full (the caller takes the bitmap form)
+  unsigned int maxhops[32];
+  unsigned int maxdist[32];
+  u64 work[4][16];                  // all passes: entries expanded, out-edges relaxed, entries written
+};
+
+struct NfqArgs {
+  const Index *optr, *oind;
+  const float* oval;
+  Index n;
+  float delta;
+  u64* K;
+  NfqEntry* qn[2];                  // near queues, near_cap entries each
+  NfqEntry* qf[2];                  // far piles, far_cap entries each
+  unsigned int near_cap, far_cap;
+  float* D;
+  NfqState* st;
+  u64* mail;
+  int seq;
+  float ticks_to_ms;
+  int max_passes;
+};
+
+constexpr int kNfqSlots = 16;       // queue entries a wave takes per step
+constexpr int kNfqLanes = kWave / kNfqSlots;
+
+__device__ inline void nfq_put(NfqEntry* p, const NfqEntry& x) { publish(&p->vd, x.vd); publish(&p->se, x.se); }
+__device__ inline NfqEntry nfq_get(const NfqEntry* p) { NfqEntry x; x.vd = fresh(&p->vd); x.se = fresh(&p->se); return x; }
+
+// Barrier number b of the launch; returns false when it was abandoned.  *lo = the low half of its word.
+// (One flat counter for all 256 workgroups would be one step less for the last arrivals, and measured 15 % slower
+// per pass: 256 pollers and the arrivals share the one word.  Letting the idle workgroups poll 16x less often
+// changed neither form.)
+__device__ inline bool nfq_sync(NfqState* st, unsigned int b, unsigned int* lo) {
+  __shared__ u64 s_word;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned int G = gridDim.x, x = blockIdx.x & 7u;
+    const unsigned int groups = G < 8u ? G : 8u, members = (G - x + 7u) / 8u;
+    const unsigned int set = b % 3u, next = (b + 1u) % 3u;
+    if (blockIdx.x == 0) {
+      // the set after this one was last used two barriers ago: everybody has left it
+      for (int i = 0; i < 8; ++i) publish(&st->xcd_count[next][i][0], 0u);
+      publish(&st->top[next][0], 0ull);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    const unsigned int a = __hip_atomic_fetch_add(&st->xcd_count[set][x][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (a + 1u == members) (void)__hip_atomic_fetch_add(&st->top[set][0], 1ull << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned int want = groups;
+    unsigned int spins = 0;
+    u64 w;
+    while ((unsigned int)((w = __hip_atomic_load(&st->top[set][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) < want) {
+      __builtin_amdgcn_s_sleep(1);
+      if (++spins > kSpinLimit || fresh(&st->stop[0]) == 1u) {
+        publish(&st->stop[0], 1u);
+        w = ~0ull;
+        break;
+      }
+    }
+    s_word = w;
+  }
+  __syncthreads();
+  const u64 w = s_word;
+  *lo = (unsigned int)w;
+  return w != ~0ull;
+}
+
+__global__ __launch_bounds__(kPThreads) void sssp_nfq_kernel(NfqArgs a) {
+  __shared__ NfqEntry s_near[kNfqStageNear];
+  __shared__ NfqEntry s_far[kNfqStageFar];
+  __shared__ unsigned int s_cnt[4];                       // staged near, staged far, smallest far distance
+  __shared__ unsigned int s_base[2];
+  const int tid = threadIdx.x, lane = tid & (kWave - 1);
+  const int sub = lane & (kNfqLanes - 1), slot = lane / kNfqLanes;
+  const int G = gridDim.x;
+  const long long gtid = (long long)blockIdx.x * kPThreads + tid;
+  const long long gthreads = (long long)G * kPThreads;
+  const long long gwave = gtid >> 6, nwaves = gthreads >> 6;
+  NfqState* st = a.st;
+  const u64 t_start = wall_clock64();
+  float T = a.delta;
+  int pass = 1, converged = 0, fsel = 0;
+  int ftarget = 0;                                        // the pile this pass adds to
+  unsigned int bidx = 1;                                  // the barrier that ends this pass; the queue it fills is counted in that barrier's word
+  unsigned int ncur = 1;                                  // the host queued the source
+  u64 my_expanded = 0, my_relaxed = 0, my_queued = 0;
+  if (tid == 0) { s_cnt[0] = 0u; s_cnt[1] = 0u; s_cnt[2] = 0xffffffffu; }
+  __syncthreads();
+
+  // the joiners of one wave step, staged; what does not fit goes to the list itself, a wave at a time
+  auto stage = [&](bool joins, const NfqEntry& entry, NfqEntry* staged, unsigned int* staged_n, unsigned int room, NfqEntry* list,
+                   bool near_list) {
+    const u64 m = __ballot(joins);
+    if (m == 0ull) return;
+    unsigned int base = 0;
+    if (lane == 0) base = atomicAdd(staged_n, (unsigned int)__popcll(m));
+    base = __shfl(base, 0, kWave);
+    const unsigned int pos = base + (unsigned int)__popcll(m & ((1ull << lane) - 1ull));
+    const bool over = joins && pos >= room;
+    if (joins && !over) staged[pos] = entry;
+    if (joins) ++my_queued;
+    const u64 mo = __ballot(over);
+    if (mo == 0ull) return;
+    const unsigned int cnt = (unsigned int)__popcll(mo);
+    unsigned int gb = 0;
+    if (lane == 0)
+      gb = near_list ? (unsigned int)__hip_atomic_fetch_add(&st->top[bidx % 3u][0], (u64)cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                     : atomicAdd(&st->fcount[ftarget][0], cnt);
+    gb = __shfl(gb, 0, kWave);
+    const unsigned int cap = near_list ? a.near_cap : a.far_cap;
+    if (gb + cnt > cap) { if (lane == 0) publish(&st->stop[0], 2u); return; }
+    if (over) nfq_put(&list[gb + (unsigned int)__popcll(mo & ((1ull << lane) - 1ull))], entry);
+  };
+  // what the workgroup staged, into the lists: one request for slots per list
+  auto flush = [&](NfqEntry* near_list) {
+    NfqEntry* far_list = a.qf[ftarget];
+    const int far_sel = ftarget;
+    __syncthreads();
+    const unsigned int sn = s_cnt[0], sf = s_cnt[1], mn = s_cnt[2];
+    if (sn == 0u && sf == 0u && mn == 0xffffffffu) return;     // (the same for the whole workgroup)
+    const unsigned int nn = sn < (unsigned int)kNfqStageNear ? sn : (unsigned int)kNfqStageNear;
+    const unsigned int nf = sf < (unsigned int)kNfqStageFar ? sf : (unsigned int)kNfqStageFar;
+    if (tid == 0 && nn)
+      s_base[0] = (unsigned int)__hip_atomic_fetch_add(&st->top[bidx % 3u][0], (u64)nn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == kWave && nf) s_base[1] = atomicAdd(&st->fcount[far_sel][0], nf);
+    if (tid == 2 * kWave && mn != 0xffffffffu) atomicMin(&st->minfar[far_sel][0], mn);
+    __syncthreads();
+    if (nn) {
+      const unsigned int b0 = s_base[0];
+      if (b0 + nn > a.near_cap) { if (tid == 0) publish(&st->stop[0], 2u); }
+      else for (unsigned int i = tid; i < nn; i += kPThreads) nfq_put(&near_list[b0 + i], s_near[i]);
+    }
+    if (nf) {
+      const unsigned int b1 = s_base[1];
+      if (b1 + nf > a.far_cap) { if (tid == 0) publish(&st->stop[0], 2u); }
+      else for (unsigned int i = tid; i < nf; i += kPThreads) nfq_put(&far_list[b1 + i], s_far[i]);
+    }
+    __syncthreads();
+    if (tid == 0) { s_cnt[0] = 0u; s_cnt[1] = 0u; s_cnt[2] = 0xffffffffu; }
+  };
+  auto stage_far = [&](bool jf, const NfqEntry& entry) {
+    if (__ballot(jf) == 0ull) return;
+    const unsigned int db = jf ? (unsigned int)(entry.vd >> 32) : 0xffffffffu;
+    const unsigned int rm = wave_reduce(db, [](unsigned int x, unsigned int y) { return x < y ? x : y; });
+    if (lane == 0) atomicMin(&s_cnt[2], rm);
+    stage(jf, entry, s_far, &s_cnt[1], kNfqStageFar, a.qf[ftarget], false);
+  };
+  // one out-edge per active lane
+  auto relax = [&](bool act, float du, unsigned int hu, Index p, NfqEntry* qnext) {
+    bool jn = false, jf = false;
+    NfqEntry entry = {0ull, 0ull};
+    if (act) {
+      const Index t = a.oind[p];
+      const float dn = du + a.oval[p];
+      const u64 nk = nf_key(dn, hu + 1u);
+      // the target's row bounds travel with its entry: asked for beside the atomic, not after it
+      const Index ts = a.optr[t], te = a.optr[t + 1];
+      if (nk < atomicMin(&a.K[t], nk)) {
+        entry.vd = ((u64)__float_as_uint(dn) << 32) | (u64)(unsigned int)t;
+        entry.se = ((u64)(unsigned int)te << 32) | (u64)(unsigned int)ts;
+        jn = dn < T;
+        jf = !jn;
+      }
+    }
+    stage(jn, entry, s_near, &s_cnt[0], kNfqStageNear, qnext, true);
+    stage_far(jf, entry);
+  };
+
+  for (; pass <= a.max_passes; ++pass) {
+    NfqEntry* qnext = a.qn[(pass + 1) & 1];
+    if (ncur == 0u) {
+      // ---- nothing near: the threshold moves, the pile is dealt out
+      const unsigned int nfar = fresh(&st->fcount[fsel][0]);
+      if (nfar == 0u) { converged = 1; break; }
+      const unsigned int mf = fresh(&st->minfar[fsel][0]);
+      if (mf != 0xffffffffu) {
+        // at least the next float above the smallest far distance: delta can vanish in the sum at large distances
+        const float up = __uint_as_float(mf + 1u);
+        T = __uint_as_float(mf) + a.delta;
+        T = T > up ? T : up;
+      } else {
+        T = FLT_MAX;
+      }
+      const NfqEntry* pile = a.qf[fsel];
+      ftarget = fsel ^ 1;
+      for (long long b = gwave * kWave; b < (long long)nfar; b += nwaves * kWave) {
+        const long long i = b + lane;
+        bool jn = false, jf = false;
+        NfqEntry entry = {0ull, 0ull};
+        if (i < (long long)nfar) {
+          entry = nfq_get(&pile[i]);
+          const unsigned int db = (unsigned int)(entry.vd >> 32);
+          const bool live = (unsigned int)(fresh(&a.K[(unsigned int)entry.vd]) >> 32) == db;
+          jn = live && __uint_as_float(db) < T;
+          jf = live && !jn;
+        }
+        stage(jn, entry, s_near, &s_cnt[0], kNfqStageNear, qnext, true);
+        stage_far(jf, entry);
+      }
+      flush(qnext);
+      if (!nfq_sync(st, bidx++, &ncur)) return;
+      if (fresh(&st->stop[0]) != 0u) break;
+      fsel ^= 1;
+      if (gtid == 0) { publish(&st->fcount[fsel ^ 1][0], 0u); publish(&st->minfar[fsel ^ 1][0], 0xffffffffu); }
+      continue;
+    }
+    // ---- a pass over the near queue
+    const NfqEntry* qcur = a.qn[pass & 1];
+    ftarget = fsel;
+    for (long long b = gwave * kNfqSlots; b < (long long)ncur; b += nwaves * kNfqSlots) {
+      const long long i = b + slot;
+      NfqEntry entry = {0ull, 0ull};
+      if (i < (long long)ncur) entry = nfq_get(&qcur[i]);            // (the 4 lanes of a slot read the same 16 bytes)
+      const Index s = (Index)(unsigned int)entry.se, e = (Index)(unsigned int)(entry.se >> 32);
+      const u64 key = fresh(&a.K[(unsigned int)entry.vd]);           // in flight with the edges below
+      const bool wide = e - s >= kNfWide;
+      const float du = __uint_as_float((unsigned int)(entry.vd >> 32));
+      // narrow rows: the first edge of every lane is loaded before the key is looked at
+      Index t0 = 0;
+      float w0 = 0.f;
+      const bool first = !wide && s + sub < e;
+      if (first) { t0 = a.oind[s + sub]; w0 = a.oval[s + sub]; }
+      const bool live = e > s && (unsigned int)(key >> 32) == (unsigned int)(entry.vd >> 32);   // else: lowered since, and queued again then
+      const unsigned int hu = (unsigned int)key;
+      if (live && sub == 0) { ++my_expanded; my_relaxed += (u64)(e - s); }
+      {
+        bool jn = false, jf = false;
+        NfqEntry out = {0ull, 0ull};
+        if (first && live) {
+          const float dn = du + w0;
+          const u64 nk = nf_key(dn, hu + 1u);
+          const Index ts = a.optr[t0], te = a.optr[t0 + 1];
+          if (nk < atomicMin(&a.K[t0], nk)) {
+            out.vd = ((u64)__float_as_uint(dn) << 32) | (u64)(unsigned int)t0;
+            out.se = ((u64)(unsigned int)te << 32) | (u64)(unsigned int)ts;
+            jn = dn < T;
+            jf = !jn;
+          }
+        }
+        stage(jn, out, s_near, &s_cnt[0], kNfqStageNear, qnext, true);
+        stage_far(jf, out);
+      }
+      for (Index off = sub + kNfqLanes; __ballot(live && !wide && s + off < e) != 0ull; off += kNfqLanes)
+        relax(live && !wide && s + off < e, du, hu, s + off, qnext);
+      for (u64 todo = __ballot(live && wide && sub == 0); todo; todo &= todo - 1) {       // a hub: the whole wave takes its edges
+        const int src = __ffsll((long long)todo) - 1;
+        const Index s2 = __shfl(s, src, kWave), e2 = __shfl(e, src, kWave);
+        const float d2 = __shfl(du, src, kWave);
+        const unsigned int h2 = __shfl(hu, src, kWave);
+        for (Index p0 = s2; p0 < e2; p0 += kWave) relax(p0 + lane < e2, d2, h2, p0 + lane, qnext);
+      }
+    }
+    flush(qnext);
+    if (!nfq_sync(st, bidx++, &ncur)) return;
+    if (fresh(&st->stop[0]) != 0u) break;
+  }
+
+  // ---- distances out, and the largest hop count of a reached vertex (the reference's round count - 1)
+  unsigned int mh = 0, md = 0;
+  if (converged)
+    for (long long i = gtid; i < a.n; i += gthreads) {
+      const u64 key = fresh(&a.K[i]);
+      a.D[i] = __uint_as_float((unsigned int)(key >> 32));
+      const unsigned int h = (unsigned int)key;
+      if (h != 0xffffffffu) {
+        mh = h > mh ? h : mh;
+        md = (unsigned int)(key >> 32) > md ? (unsigned int)(key >> 32) : md;
+      }
+    }
+  auto umax = [](unsigned int x, unsigned int y) { return x > y ? x : y; };
+  auto add = [](u64 x, u64 y) { return x + y; };
+  mh = wave_reduce(mh, umax);
+  md = wave_reduce(md, umax);
+  const u64 w0 = wave_reduce(my_expanded, add), w1 = wave_reduce(my_relaxed, add), w2 = wave_reduce(my_queued, add);
+  if (lane == 0) {
+    if (mh) atomicMax(&st->maxhops[0], mh);
+    if (md) atomicMax(&st->maxdist[0], md);
+    if (w0) __hip_atomic_fetch_add(&st->work[0][0], w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (w1) __hip_atomic_fetch_add(&st->work[1][0], w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (w2) __hip_atomic_fetch_add(&st->work[2][0], w2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  unsigned int unused;
+  if (!nfq_sync(st, bidx++, &unused)) return;
+  if (gtid == 0) {
+    const u64 tag = (u64)(unsigned int)a.seq << 32;
+    const float ms = (float)(wall_clock64() - t_start) * a.ticks_to_ms;
+    const u64 c0 = fresh(&st->work[0][0]), c1 = fresh(&st->work[1][0]), c2 = fresh(&st->work[2][0]);
+    const unsigned int how = converged ? 1u : fresh(&st->stop[0]) == 2u ? 2u : 0u;     // 2: a list was full
+    const unsigned int vals[8] = {fresh(&st->maxhops[0]), (unsigned int)pass, __float_as_uint(ms), how,
+                                  fresh(&st->maxdist[0]), (unsigned int)(c0 > 0xffffffffull ? 0xffffffffull : c0),
+                                  (unsigned int)(c1 >> 4 > 0xffffffffull ? 0xffffffffull : c1 >> 4),
+                                  (unsigned int)(c2 > 0xffffffffull ? 0xffffffffull : c2)};
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      __hip_atomic_store(&a.mail[k], tag | vals[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
+__global__ void nfq_seed_kernel(NfqEntry* q1, NfqState* st, Index source, const Index* optr) {
+  if (threadIdx.x == 0) {                                        // distance 0
+    q1[0].vd = (u64)(unsigned int)source;
+    q1[0].se = ((u64)(unsigned int)optr[source + 1] << 32) | (u64)(unsigned int)optr[source];
+  }
+  if (threadIdx.x < 2) st->minfar[threadIdx.x][0] = 0xffffffffu;
+}
+
 // stored values that are not integers in [0, 2^20]: with none, every path sum below 2^24 is exact
 __global__ void nf_count_inexact_kernel(const float* __restrict__ val, Index nvals, unsigned int* __restrict__ out) {
   const Index stride = (Index)gridDim.x * blockDim.x;
@@ -333,15 +675,12 @@ grb_info grb::sssp_nearfar_run(grb_vector v, grb_matrix A, grb_index source, grb
   const int nwords = 2 * ceil_div(n, 64);
   static int max_per_cu = 0;
   if (!max_per_cu) {
+    int m2 = 0;
     GRB_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&max_per_cu, sssp_nearfar_kernel, kPThreads, 0));
+    GRB_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&m2, sssp_nfq_kernel, kPThreads, 0));
+    if (m2 < max_per_cu) max_per_cu = m2;
     if (max_per_cu < 1) return GRB_NOT_IMPLEMENTED;
   }
-  const size_t st_bytes = (sizeof(NfState) + 255) & ~(size_t)255;
-  const size_t zero_bytes = st_bytes + 4 * (size_t)nwords;
-  void *p_zero, *p_k;
-  GRB_TRY(scratch(7, zero_bytes, &p_zero));
-  c.bfs_prezero_ptr = nullptr;              // this slot is about to be overwritten
-  GRB_TRY(scratch(8, 8 * (size_t)n + 8, &p_k));
   static float ticks_to_ms = 0.f;
   if (ticks_to_ms == 0.f) {
     int khz = 0, dev = 0;
@@ -349,39 +688,93 @@ grb_info grb::sssp_nearfar_run(grb_vector v, grb_matrix A, grb_index source, grb
     GRB_HIP_TRY(hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev));
     ticks_to_ms = khz > 0 ? 1.0f / (float)khz : 1e-5f;
   }
-  NfArgs a;
-  a.optr = A->csr.ptr; a.oind = A->csr.ind; a.oval = (const float*)A->csr.val;
-  a.n = n;
-  a.source = source;
-  static const double delta_factor = getenv("GRB_SSSP_DELTA") ? atof(getenv("GRB_SSSP_DELTA")) : 32.0;
-  a.delta = (float)(delta_factor * A->mean_value);
-  if (!(a.delta > 0.f)) a.delta = 1.f;       // all-zero weights: any positive width
-  a.K = (u64*)p_k;
-  a.st = (NfState*)p_zero;
-  a.dirty = (unsigned int*)((char*)p_zero + st_bytes);
-  a.D = (float*)v->d_val;
-  a.mail = c.d_hgran;
-  a.seq = ++c.mail_seq;
-  a.ticks_to_ms = ticks_to_ms;
+  // the band: GRB_SSSP_DELTA x the mean edge weight.  Measured flat from 32 to 128 for the queue form (85-88 ms on
+  // the road-like stand-in: fewer passes, each a little longer) and from 16 to 64 for the bitmap form
+  static const double delta_env = getenv("GRB_SSSP_DELTA") ? atof(getenv("GRB_SSSP_DELTA")) : 0.0;
   // a pass either expands a vertex or raises the threshold past one: far fewer than n of each are ever needed;
   // the cap only turns a logic error into "not converged" (the rounds then run) instead of an endless launch
   const long long pass_cap = 8ll * (long long)n + 1024;
-  a.max_passes = pass_cap > 0x7fffff00ll ? 0x7fffff00 : (int)pass_cap;
-  static const int inner = getenv("GRB_SSSP_INNER") ? atoi(getenv("GRB_SSSP_INNER")) : 2;
-  a.inner = inner < 1 ? 1 : inner;
-  GRB_HIP_TRY(hipMemsetAsync(p_zero, 0, zero_bytes, s));
-  hipLaunchKernelGGL(nf_init_kernel, dim3(stream_grid(n, kBlock)), dim3(kBlock), 0, s, a.K, n, (Index)source);
-  hipLaunchKernelGGL(nf_seed_kernel, dim3(1), dim3(64), 0, s, a.dirty, &a.st->minfar[0][0], (Index)source);
-  GRB_HIP_TRY(hipGetLastError());
-  hipLaunchKernelGGL(sssp_nearfar_kernel, dim3(c.num_cu), dim3(kPThreads), 0, s, a);
-  GRB_HIP_TRY(hipGetLastError());
+  const int max_passes = pass_cap > 0x7fffff00ll ? 0x7fffff00 : (int)pass_cap;
+  // GRB_SSSP_QUEUE=0: the near set found by walking the dirty bitmap (the first form of this kernel) instead of kept in queues
+  static const int use_queue = getenv("GRB_SSSP_QUEUE") ? atoi(getenv("GRB_SSSP_QUEUE")) : 1;
+  void *p_zero, *p_k;
+  c.bfs_prezero_ptr = nullptr;              // slot 7 is about to be overwritten
+  GRB_TRY(scratch(8, 8 * (size_t)n + 8, &p_k));
+  int seq = 0;
   unsigned int gv[8];
-  if (wait_granules(a.seq, 8, gv) != GRB_SUCCESS) {       // the barrier gave up: round-exact path
+  for (int attempt = 0; attempt < 2; ++attempt) {
+  const bool queue_form = use_queue != 0 && attempt == 0;
+  float delta = (float)((delta_env > 0.0 ? delta_env : queue_form ? 64.0 : 32.0) * A->mean_value);
+  if (!(delta > 0.f)) delta = 1.f;           // all-zero weights: any positive width
+  if (queue_form) {
+    const size_t st_bytes = (sizeof(NfqState) + 255) & ~(size_t)255;
+    // one entry (16 bytes) per successful atomicMin: a pass writes a few thousand on a road network, and cannot
+    // write more than it relaxes edges; the far pile keeps entries that have gone stale until it is dealt out.
+    // Neither list is sized for the worst case -- when one fills up the kernel says so and the bitmap form runs
+    size_t near_cap = (size_t)n + (size_t)A->nvals / 4 + 64, far_cap = 2 * (size_t)n + (size_t)A->nvals / 4 + 64;
+    static const long long cap_env = getenv("GRB_SSSP_QUEUE_CAP") ? atoll(getenv("GRB_SSSP_QUEUE_CAP")) : 0;   // (tests: make the lists overflow)
+    if (cap_env > 0) { near_cap = (size_t)cap_env; far_cap = (size_t)cap_env; }
+    if (far_cap > 0xfffffff0ull) continue;
+    void* p_q;
+    GRB_TRY(scratch(7, st_bytes, &p_zero));
+    GRB_TRY(scratch(11, sizeof(NfqEntry) * (2 * near_cap + 2 * far_cap), &p_q));
+    NfqArgs a;
+    a.optr = A->csr.ptr; a.oind = A->csr.ind; a.oval = (const float*)A->csr.val;
+    a.n = n;
+    a.delta = delta;
+    a.K = (u64*)p_k;
+    a.st = (NfqState*)p_zero;
+    a.qn[0] = (NfqEntry*)p_q; a.qn[1] = a.qn[0] + near_cap;
+    a.qf[0] = a.qn[1] + near_cap; a.qf[1] = a.qf[0] + far_cap;
+    a.near_cap = (unsigned int)near_cap; a.far_cap = (unsigned int)far_cap;
+    a.D = (float*)v->d_val;
+    a.mail = c.d_hgran;
+    a.seq = seq = ++c.mail_seq;
+    a.ticks_to_ms = ticks_to_ms;
+    a.max_passes = max_passes;
+    GRB_HIP_TRY(hipMemsetAsync(p_zero, 0, st_bytes, s));
+    hipLaunchKernelGGL(nf_init_kernel, dim3(stream_grid(n, kBlock)), dim3(kBlock), 0, s, a.K, n, (Index)source);
+    hipLaunchKernelGGL(nfq_seed_kernel, dim3(1), dim3(64), 0, s, a.qn[1], a.st, (Index)source, a.optr);
+    GRB_HIP_TRY(hipGetLastError());
+    // (every CU takes part: the passes of a road network would be as fast with 32 workgroups -- their cost is the
+    // chain of dependent steps, measured equal from 32 to 256 -- but a wide frontier wants the whole machine)
+    hipLaunchKernelGGL(sssp_nfq_kernel, dim3(c.num_cu), dim3(kPThreads), 0, s, a);
+    GRB_HIP_TRY(hipGetLastError());
+  } else {
+    const size_t st_bytes = (sizeof(NfState) + 255) & ~(size_t)255;
+    const size_t zero_bytes = st_bytes + 4 * (size_t)nwords;
+    GRB_TRY(scratch(7, zero_bytes, &p_zero));
+    NfArgs a;
+    a.optr = A->csr.ptr; a.oind = A->csr.ind; a.oval = (const float*)A->csr.val;
+    a.n = n;
+    a.source = source;
+    a.delta = delta;
+    a.K = (u64*)p_k;
+    a.st = (NfState*)p_zero;
+    a.dirty = (unsigned int*)((char*)p_zero + st_bytes);
+    a.D = (float*)v->d_val;
+    a.mail = c.d_hgran;
+    a.seq = seq = ++c.mail_seq;
+    a.ticks_to_ms = ticks_to_ms;
+    a.max_passes = max_passes;
+    static const int inner = getenv("GRB_SSSP_INNER") ? atoi(getenv("GRB_SSSP_INNER")) : 2;
+    a.inner = inner < 1 ? 1 : inner;
+    GRB_HIP_TRY(hipMemsetAsync(p_zero, 0, zero_bytes, s));
+    hipLaunchKernelGGL(nf_init_kernel, dim3(stream_grid(n, kBlock)), dim3(kBlock), 0, s, a.K, n, (Index)source);
+    hipLaunchKernelGGL(nf_seed_kernel, dim3(1), dim3(64), 0, s, a.dirty, &a.st->minfar[0][0], (Index)source);
+    GRB_HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(sssp_nearfar_kernel, dim3(c.num_cu), dim3(kPThreads), 0, s, a);
+    GRB_HIP_TRY(hipGetLastError());
+  }
+  if (wait_granules(seq, 8, gv) != GRB_SUCCESS) {       // the barrier gave up: round-exact path
     ++g_barrier_failures;
     return GRB_NOT_IMPLEMENTED;
   }
   g_barrier_failures = 0;
-  if (!gv[3]) return GRB_NOT_IMPLEMENTED;
+  if (queue_form && gv[3] == 2u) continue;              // a list was full: the bitmap form needs none
+  break;
+  }
+  if (gv[3] != 1u) return GRB_NOT_IMPLEMENTED;
   float maxdist;
   memcpy(&maxdist, &gv[4], 4);
   if (nearfar_env() <= 0 && !(maxdist < 16777216.f)) return GRB_NOT_IMPLEMENTED;   // sums no longer exact: rounds could differ

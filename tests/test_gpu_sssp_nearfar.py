@@ -107,3 +107,37 @@ def test_dense_graphs_keep_the_rounds_by_default_and_agree_when_forced():
     assert o0 == 0                                       # 30 entries per row: not road-like
     d1, it1, o1 = _run(g, A, n, src, 1)
     assert o1 >= 1 and np.array_equal(d0, d1) and it0 == it1
+
+
+_FORMS = r"""
+import json, sys
+import numpy as np
+sys.path.insert(0, %r)
+from test_gpu_sssp_nearfar import _grid, _run
+g, A, n, deg = _grid(300, 0.6, 2, "int")
+src = int(np.nonzero(deg)[0][len(np.nonzero(deg)[0]) // 2])
+d0, it0, o0 = _run(g, A, n, src, 0)
+d1, it1, o1 = _run(g, A, n, src, -1)
+print(json.dumps({"same": bool(np.array_equal(d0, d1)), "it": [it0, it1], "order": [o0, o1], "work": list(g.sssp_last_work())}))
+"""
+
+
+@pytest.mark.parametrize("env", [{"GRB_SSSP_QUEUE": "0"}, {"GRB_SSSP_QUEUE_CAP": "40"}, {}])
+def test_bitmap_form_and_the_fallback_when_a_list_is_full(env):
+    """the near set as a bitmap walk (the first form), the queues (default), and the queues with lists far too short
+    for this graph: the launch reports `full` and the bitmap form produces the answer -- each in its own process (the
+    settings are read once)"""
+    import json
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    e = dict(os.environ)
+    e.update(env)
+    e["PYTHONPATH"] = os.path.dirname(here) + os.pathsep + e.get("PYTHONPATH", "")
+    out = subprocess.run([sys.executable, "-c", _FORMS % here], env=e, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    r = json.loads(out.stdout.strip().splitlines()[-1])
+    assert r["same"] and r["it"][0] == r["it"][1]
+    assert r["order"][0] == 0 and r["order"][1] >= 1     # near / far in every case: the fallback is its bitmap form, not the rounds
+    assert r["work"][0] > 0
