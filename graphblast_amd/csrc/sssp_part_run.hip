@@ -79,15 +79,8 @@ struct SsspArgs {
   int launch, nsteps;
 };
 
-// wave-aggregated append of the lanes with `want` to a list: one atomic per wave
-__device__ inline int wave_append(unsigned* counter, bool want, int lane) {
-  const unsigned long long m = __ballot(want);
-  if (m == 0ull) return -1;
-  unsigned base = 0;
-  if (lane == (__ffsll((long long)m) - 1)) base = atomicAdd(counter, (unsigned)__popcll(m));
-  base = __shfl(base, __ffsll((long long)m) - 1, kWave);
-  return want ? (int)(base + (unsigned)__popcll(m & ((1ull << lane) - 1ull))) : -1;
-}
+constexpr int kStageQ = 8192;           // queue joiners a workgroup stages per phase
+
 
 __global__ __launch_bounds__(kPThreads) void sssp_part_kernel(SsspArgs a) {
   const int tid = threadIdx.x, lane = tid & (kWave - 1);
@@ -122,6 +115,38 @@ __global__ __launch_bounds__(kPThreads) void sssp_part_kernel(SsspArgs a) {
   }
   auto give_up = [&]() { if (tid == 0) publish(&st->panic[0], 1u); };
   const int stride = kSsspHdr + 2 * a.cap;
+  // joiners of the next queue are staged per workgroup and get their slots with ONE atomic per phase: a wave step's
+  // own atomicAdd on the queue's counter serialises with everybody else's (0.4-1 M vertices per round on a road
+  // network: 60 K same-address atomics, ~0.75 ms of a round)
+  __shared__ Index s_q[kStageQ];
+  __shared__ unsigned s_qn, s_qbase;
+  if (tid == 0) s_qn = 0u;
+  __syncthreads();
+  auto stage_q = [&](bool joins, Index val, unsigned* qcnt, Index* qnext) {
+    const unsigned long long m = __ballot(joins);
+    if (m == 0ull) return;
+    unsigned base = 0;
+    if (lane == 0) base = atomicAdd(&s_qn, (unsigned)__popcll(m));
+    base = __shfl(base, 0, kWave);
+    if (!joins) return;
+    const unsigned pos = base + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+    if (pos < (unsigned)kStageQ) s_q[pos] = val;
+    else publish(&qnext[atomicAdd(qcnt, 1u)], val);
+  };
+  auto flush_q = [&](unsigned* qcnt, Index* qnext) {
+    __syncthreads();
+    const unsigned staged = s_qn < (unsigned)kStageQ ? s_qn : (unsigned)kStageQ;
+    if (staged != 0u) {                                  // (the same for the whole workgroup)
+      if (tid == 0) s_qbase = atomicAdd(qcnt, staged);
+      __syncthreads();
+      const unsigned b0 = s_qbase;
+      for (unsigned i = tid; i < staged; i += kPThreads) publish(&qnext[b0 + i], s_q[i]);
+      __syncthreads();
+      if (tid == 0) s_qn = 0u;
+    }
+  };
+  constexpr int kSlots = 16, kSubLanes = kWave / kSlots;   // queue vertices per wave step; lanes per vertex
+  const int sub = lane & (kSubLanes - 1), slot = lane / kSubLanes;
 
   for (int step = 0; step < a.nsteps; ++step) {
     const bool first = (k == 0 && step == 0);            // the host seeded round 0's result: nothing to apply
@@ -157,10 +182,10 @@ __global__ __launch_bounds__(kPThreads) void sssp_part_kernel(SsspArgs a) {
               }
             }
           }
-          const int at = wave_append(&st->qcount[cy.qsel ^ 1][0], joins, lane);
-          if (at >= 0) publish(&a.Q[cy.qsel ^ 1][at], lv);
+          stage_q(joins, lv, &st->qcount[cy.qsel ^ 1][0], a.Q[cy.qsel ^ 1]);
         }
       }
+      flush_q(&st->qcount[cy.qsel ^ 1][0], a.Q[cy.qsel ^ 1]);
       if (!grid_sync(bar, gen, false)) { give_up(); return; }
     }
     // ---- the loop's exit tests (sssp.hpp:53, :86-88), one exchange after the round they are about: the headers read
@@ -213,8 +238,7 @@ __global__ __launch_bounds__(kPThreads) void sssp_part_kernel(SsspArgs a) {
           const unsigned old = atomicMin(&a.D[v], c);
           joins = c < old && old == fresh(&a.dcur[v - lo]);
         }
-        const int at = wave_append(qcnt, joins, lane);
-        if (at >= 0) publish(&a.Q[cy.qsel ^ 1][at], v - lo);
+        stage_q(joins, v - lo, qcnt, a.Q[cy.qsel ^ 1]);
         if (a.world > 1) {
           const bool emit = valid && !owned && c < fresh(&a.D[v]);
           const unsigned long long m = __ballot(emit);
@@ -249,12 +273,75 @@ __global__ __launch_bounds__(kPThreads) void sssp_part_kernel(SsspArgs a) {
         const unsigned long long e = fresh(reinterpret_cast<const unsigned long long*>(&cin[i]));
         relax((Index)(e & 0xffffffffull), (Index)(e >> 32));
       }
-      for (long long i = (long long)cy.pos + gwave; i < (long long)cy.qn; i += nwaves) {
-        const Index u = fresh(&a.Q[cy.qsel][i]);
-        relax(u, a.optr[u]);
+      // the queue: 16 vertices per wave step, 4 lanes each (a road network's rows hold 2-4 entries: a wave per
+      // vertex left 60 lanes idle and took 3.7 ms per round on the 4896^2 grid); rows of 64 and more entries
+      // get the whole wave, one after the other
+      for (long long b = (long long)cy.pos + gwave * kSlots; b < (long long)cy.qn; b += nwaves * kSlots) {
+        const long long i = b + slot;
+        const bool have = i < (long long)cy.qn;
+        const Index u = have ? fresh(&a.Q[cy.qsel][i]) : 0;
+        const Index s = have ? a.optr[u] : 0, e = have ? a.optr[u + 1] : 0;
+        const bool wide = e - s >= kWave;
+        const float duf = __uint_as_float(have ? fresh(&a.dcur[u]) : 0u);
+        bool stopped = false;
+        for (Index off = 0; !stopped && __ballot(!wide && s + off + sub < e) != 0ull; off += kSubLanes) {
+          if (a.world > 1 && fresh(&st->full[0]) != 0u) {
+            // no room in the outbox: what is left of every row of this step waits for the next launch
+            if (sub == 0 && !wide && s + off < e) {
+              const unsigned at = atomicAdd(ccnt, 1u);
+              if ((int)at < a.ccap) publish(reinterpret_cast<unsigned long long*>(&cout[at]), ((unsigned long long)(unsigned)(s + off) << 32) | (unsigned)u);
+            }
+            stopped = true;
+            break;
+          }
+          const Index p = s + off + sub;
+          const bool valid = !wide && p < e;
+          const Index v = valid ? a.oind[p] : 0;
+          const unsigned c = valid ? __float_as_uint(duf + a.oval[p]) : 0u;
+          const bool owned = valid && v >= lo && v < hi;
+          bool joins = false;
+          if (owned && c < fresh(&a.D[v])) {
+            const unsigned old = atomicMin(&a.D[v], c);
+            joins = c < old && old == fresh(&a.dcur[v - lo]);
+          }
+          stage_q(joins, v - lo, qcnt, a.Q[cy.qsel ^ 1]);
+          if (a.world > 1) {
+            const bool emit = valid && !owned && c < fresh(&a.D[v]);
+            const unsigned long long m = __ballot(emit);
+            if (m != 0ull) {
+              const int cnt = __popcll(m);
+              unsigned base = 0;
+              if (lane == 0) base = atomicAdd(&st->cursor[0], (unsigned)cnt);
+              base = __shfl(base, 0, kWave);
+              if (base + (unsigned)cnt > (unsigned)a.cap) {
+                if (lane == 0) publish(&st->full[0], 1u);
+                if (sub == 0 && !wide && s + off < e) {
+                  const unsigned atc = atomicAdd(ccnt, 1u);
+                  if ((int)atc < a.ccap) publish(reinterpret_cast<unsigned long long*>(&cout[atc]), ((unsigned long long)(unsigned)(s + off) << 32) | (unsigned)u);
+                }
+                for (unsigned q = base + lane; q < (unsigned)a.cap && q < base + (unsigned)cnt; q += kWave)
+                  publish(&a.outbox[kSsspHdr + 2 * q], kSsspNone);
+                stopped = true;
+                break;
+              }
+              if (emit) {
+                const unsigned q = base + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+                publish(&a.outbox[kSsspHdr + 2 * q], (unsigned)v);
+                publish(&a.outbox[kSsspHdr + 2 * q + 1], c);
+                atomicMin(&a.D[v], c);
+              }
+            }
+          }
+        }
+        for (unsigned long long todo = __ballot(wide && sub == 0); todo; todo &= todo - 1) {
+          const int src = __ffsll((long long)todo) - 1;
+          const Index u2 = __shfl(u, src, kWave), s2 = __shfl(s, src, kWave);
+          relax(u2, s2);
+        }
       }
     }
     // ---- what this launch leaves behind
+    flush_q(qcnt, a.Q[cy.qsel ^ 1]);
     if (!grid_sync(bar, gen, false)) { give_up(); return; }
     const unsigned left = fresh(&st->ccount[cy.csel ^ 1][0]);
     unsigned sent = fresh(&st->cursor[0]);
