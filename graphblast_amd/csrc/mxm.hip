@@ -60,6 +60,18 @@ __device__ inline Index lower_bound_dev(const Index* __restrict__ a, Index lo, I
 // partial sums folded with the semiring's add.  Work per dot product is
 // min(d_i, d_j) * log max(d_i, d_j) either way, but no lane of a wave is left walking a hub
 // row alone (RMAT-19 triangle count: 1074 ms with a lane per entry -> see DESIGN.md).
+// Whether the products of one entry may be folded in any order: true commutative, associative monoids.  The
+// comparison "monoids" of stddef.hpp (and whatever an application registers) are folded exactly as spgemmMasked's
+// loop does -- add(mul(a, b), acc) over the common columns in ascending order -- by one lane per entry.
+template <int SR>
+constexpr bool mxm_order_free() {
+  if constexpr (SR == GRB_RUNTIME_SR) return false;
+  else {
+    constexpr int op = MonoidTraits<SemiringTraits<SR>::monoid>::op;
+    return op == OP_PLUS || op == OP_TIMES || op == OP_MIN || op == OP_MAX || op == OP_LOR || op == OP_LAND;
+  }
+}
+
 template <int SR, typename T>
 __global__ __launch_bounds__(kBlock) void spgemm_masked_kernel(
     T* __restrict__ c_val, const Index* __restrict__ m_row, const Index* __restrict__ m_ind,
@@ -90,7 +102,7 @@ __global__ __launch_bounds__(kBlock) void spgemm_masked_kernel(
       ls = a_short ? bs : as; le = a_short ? be : ae;
     }
     T acc = S::identity();
-    const bool heavy = valid && (se - ss) > kLaneDotMax;
+    const bool heavy = mxm_order_free<SR>() && valid && (se - ss) > kLaneDotMax;
     if (valid && !heavy) {
       const Index* s_ind = a_short ? a_ind : b_ind;
       const Index* l_ind = a_short ? b_ind : a_ind;
@@ -686,12 +698,15 @@ grb_info grb_mxm(grb_matrix C, grb_matrix mask, grb_accum accum, grb_semiring op
   const bool have_csc = use_pivot && mask->csc.ptr && !mask->csc_alias && (Index)mask->h_csc_ptr.size() == mask->ncols + 1;
   const int grid = stream_grid(mask->nvals, kBlock);
   void* p_rows = nullptr;
-  if (!use_pivot || !have_csc) {
+  auto ensure_rows = [&]() -> grb_info {
+    if (p_rows) return GRB_SUCCESS;
     GRB_TRY(scratch(9, 4 * (size_t)mask->nvals, &p_rows));            // not 4 / 5: those hold the push path's state
     hipLaunchKernelGGL(entry_rows_kernel, dim3(stream_grid(mask->nvals, kBlock)), dim3(kBlock), 0, s, mask->csr.ptr,
                        mask->nrows, mask->nvals, (Index*)p_rows);
     GRB_HIP_TRY(hipGetLastError());
-  }
+    return GRB_SUCCESS;
+  };
+  if (!use_pivot || !have_csc) GRB_TRY(ensure_rows());
   return dispatch_semiring(op, A->dtype, [&](auto tag, auto t) -> grb_info {
     using T = decltype(t);
     constexpr int SR = decltype(tag)::value;
@@ -703,6 +718,10 @@ grb_info grb_mxm(grb_matrix C, grb_matrix mask, grb_accum accum, grb_semiring op
       return GRB_SUCCESS;
     };
     if (!use_pivot) return entry_driven(0);
+    if constexpr (!mxm_order_free<SR>()) {                // the fold's order is part of the answer: a lane per entry
+      GRB_TRY(ensure_rows());
+      return entry_driven(0);
+    }
     hipLaunchKernelGGL((fill_value_kernel<T>), dim3(stream_grid(mask->nvals, kBlock)), dim3(kBlock), 0, s, (T*)C->csr.val,
                        mask->nvals, Semiring<SR, T>::identity());
     GRB_HIP_TRY(hipGetLastError());

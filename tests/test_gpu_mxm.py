@@ -1,0 +1,109 @@
+"""Masked SpGEMM (csrc/mxm.hip: the pivot-driven kernels and the entry-driven one) against the oracle's restatement of
+spgemmMasked (oracle/ops.py: mxm_masked, spgemm.hpp:22-110): every semiring, stored values, zero mask values, A != B,
+and the long-pivot / arena paths on hub-rich RMAT graphs (sampled mask entries, the reference loop per entry)."""
+import numpy as np
+import pytest
+
+from backends import HipBackend
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hb():
+    return HipBackend()
+
+
+def _rand_csr(rng, n, m):
+    from graphblast_amd.graphgen import finalize_edges
+    gr = finalize_edges(rng.integers(0, n, m), rng.integers(0, n, m), n, symmetrize=False)
+    return gr["csr"]
+
+
+def _entry(sr, arow, aval, bcol, bval):
+    """one mask entry as mxm_masked forms it: add(mul(a, b), acc) over the common columns in ascending order"""
+    common, ia, ib = np.intersect1d(arow, bcol, return_indices=True)
+    acc = sr.identity()
+    for x, y in zip(aval[ia], bval[ib]):
+        acc = sr.add_op(sr.mul_op(x, y), acc)[()]
+    return acc
+
+
+@pytest.mark.parametrize("dt", [np.int32, np.float32])
+def test_every_semiring_with_values_and_zero_mask_entries(hb, dt):
+    from oracle import ops as oops
+    from oracle.semiring import Semiring, SEMIRINGS
+    g = hb.g
+    rng = np.random.default_rng(5)
+    n = 300
+    (ap, ai), (bp, bi), (mp, mi) = _rand_csr(rng, n, 6000), _rand_csr(rng, n, 6000), _rand_csr(rng, n, 4000)
+    av = rng.integers(1, 5, ai.size).astype(dt)
+    bv = rng.integers(1, 5, bi.size).astype(dt)
+    mv = (rng.random(mi.size) < 0.8).astype(dt)               # a fifth of the mask's stored values are 0: skipped
+    A, B, M = g.Matrix(n, n, dt), g.Matrix(n, n, dt), g.Matrix(n, n, dt)
+    assert A.build_csr(ap, ai, av) == 0 and B.build_csr(bp, bi, bv) == 0 and M.build_csr(mp, mi, mv) == 0
+    Ao, Bo, Mo = oops.Matrix(n, n, dt), oops.Matrix(n, n, dt), oops.Matrix(n, n, dt)
+    Ao.build_csr(ap, ai, av); Bo.build_csr(bp, bi, bv); Mo.build_csr(mp, mi, mv)
+    for tran_b in (True, False):
+        d = hb.descriptor()
+        do = oops.Descriptor(); do.loadArgs()
+        if tran_b:
+            assert d.toggle(g.GrB_INP1) == 0
+            do.toggle(oops.GrB_INP1)
+        for name in SEMIRINGS:
+            Cm = g.Matrix(n, n, dt)
+            assert g.mxm(Cm, M, None, name, A, B, d) == 0, name
+            cp, ci, cv = Cm.host_csr()
+            want = oops.mxm_masked(Mo, Semiring(name, dt), Ao, Bo, do)
+            assert np.array_equal(cp, mp) and np.array_equal(ci, mi)
+            if dt == np.float32 and name == "PlusDivides":
+                # quotients are not integers: a float sum folded in another order than the reference's loop differs
+                # in the last bit (the pivot kernels fold a row's products as a tree); everything else here is exact
+                assert np.allclose(cv, want, rtol=4e-7, atol=0), (name, tran_b)
+            else:
+                assert np.array_equal(cv, want), (name, tran_b, int((cv != want).sum()))
+
+
+@pytest.mark.parametrize("scale,values", [(15, "ones"), (15, "int"), (18, "ones"), (18, "int")])
+def test_long_pivots_on_rmat_sampled_entries(hb, scale, values):
+    """hub rows of thousands (scale 15: the workgroup kernel's LDS tables) and tens of thousands of entries (scale 18:
+    the 128 KiB tables and the global-memory arena); stored values take the key + value slots, ones the key-only ones"""
+    import torch
+    from oracle.semiring import Semiring
+    from graphblast_amd.graphgen import rmat_edges, finalize_edges
+    g = hb.g
+    s, d_, n = rmat_edges(scale, 16, seed=2, device=torch.device("cuda", 0))
+    gr = finalize_edges(s, d_, n, symmetrize=True)
+    ptr, ind = (x.cpu().numpy() for x in gr["csr"])
+    rng = np.random.default_rng(scale)
+    dt = np.int32
+    vals = np.ones(ind.size, dtype=dt) if values == "ones" else rng.integers(1, 4, ind.size).astype(dt)
+    A = g.Matrix(n, n, dt)
+    assert A.build_csr(ptr, ind, vals) == 0
+    d = hb.descriptor()
+    L, Cm = g.Matrix(n, n, dt), g.Matrix(n, n, dt)
+    assert g.tril(L, A, d) == 0
+    lp, li, lv = L.host_csr()
+    assert d.toggle(g.GrB_INP1) == 0                          # C<L> = L x L^T, as tc.hpp calls it
+    deg = np.diff(lp)
+    hub = int(np.argmax(deg))
+    assert deg[hub] > (2000 if scale == 15 else 16384)       # beyond the 128 KiB key-only table: the arena
+    for name in ("PlusMultiplies", "MinimumPlus"):
+        assert g.mxm(Cm, L, None, name, L, L, d) == 0
+        cp, ci, cv = Cm.host_csr()
+        assert np.array_equal(cp, lp) and np.array_equal(ci, li)
+        sr = Semiring(name, dt)
+        rows = np.repeat(np.arange(n), deg)
+        # entries of the hub row and of rows that meet the hub's column (its partners in both passes), plus a random sample
+        pick = np.concatenate([np.arange(lp[hub], lp[hub + 1])[:: max(1, deg[hub] // 300)],
+                               np.nonzero(li == hub)[0][:300], rng.integers(0, li.size, 1500)])
+        for e in pick:
+            i, j = rows[e], li[e]
+            want = _entry(sr, li[lp[i]:lp[i + 1]], lv[lp[i]:lp[i + 1]], li[lp[j]:lp[j + 1]], lv[lp[j]:lp[j + 1]])
+            assert cv[e] == want, (name, int(e), int(i), int(j), int(cv[e]), int(want))
+    if values == "ones":                                       # the triangle count is the sum of the PlusMultiplies product
+        assert g.mxm(Cm, L, None, "PlusMultiplies", L, L, d) == 0
+        total = int(Cm.host_csr()[2].astype(np.int64).sum())
+        T = g.Matrix(n, n, dt)
+        info, ntris, _ = g.tc(L, T, hb.descriptor())
+        assert info == 0 and ntris == total
