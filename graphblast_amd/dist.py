@@ -41,6 +41,14 @@ def partition_bounds(ptr, world):
     return bounds
 
 
+def word_slices_usable(bounds):
+    """Whether the ranks' vertex ranges are also disjoint ranges of 32-bit bitmap words -- the condition for the
+    pull levels' in-place all-gather of word ranges.  partition_bounds clamps an interior bound to n: with
+    n % 64 >= 32 and a heavy tail vertex a bound falls inside a word (n = 190, world 2: [0, 190, 190]); that word
+    would then be broadcast by the empty rank from its stale copy and the owner's discoveries lost."""
+    return all(b % 32 == 0 for b in bounds[1:-1])
+
+
 def bitmap_words(n):
     return 2 * ((n + 63) // 64)
 
@@ -659,7 +667,7 @@ class Partition1D:
                     and all_edges > self.edgeswitch * self.nnz):
                 f1_dense = True                                    # the same rule as bfs_persist.hip:145-147
             if (f1_dense and hasattr(self.comm, "gather_word_slices") and getattr(eng, "pull_zeroes", False)
-                    and all(b % 32 == 0 for b in self.bounds[1:-1])):
+                    and word_slices_usable(self.bounds)):
                 # pull discovers owned vertices only: written straight into the replicated bitmap, then ONE
                 # in-place all-gather of the ranks' own word ranges (no OR pass, 1/P of the bytes)
                 eng.pull(self.vis, self.new_global, self.label, it + 1)

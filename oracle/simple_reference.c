@@ -17,9 +17,10 @@
  *       backend/cuda/vector.hpp:291-323 (convert) + algorithm/bfs.hpp:48-82 and
  *       counts the per-level quantities SURVEY.md 8(d) needs (nf, mf, nu, mi).
  *
- * Parity status: the reference's own headers cannot be compiled in this image
- * (graphblas/util.hpp needs Boost.ProgramOptions for CpuTimer/printArray), so these
- * functions are pinned against known answers only (tests/golden).
+ * Parity status: PINNED.  The reference's own SimpleReference* / SimpleVerify* compile from
+ * their sources (oracle/Makefile, target `ref` -> oracle/_ref/libsimple_ref*.so; util.hpp
+ * without its one Boost user, parseArgs) and generated tests/golden/algo_ref.npz;
+ * tests/test_oracle_pinned.py holds these restatements to it bit for bit.
  *
  * Index = int32, values = float32, exactly as graphblas/types.hpp:18-19.
  * Each timed function returns the elapsed milliseconds of the same region the

@@ -153,6 +153,21 @@ def test_partition_bounds():
             assert share.max() <= 1.5 * gr["nnz"] / world + 64 * np.diff(ptr).max()
 
 
+def test_word_range_gather_only_when_the_bounds_are_word_bounds():
+    """round-2 review: n = 190 with a heavy last vertex gives bounds [0, 190, 190]; word 5 (vertices 160..189) belongs
+    to rank 0 but sits in the empty rank 1's word range -- the in-place gather of word ranges must not be taken"""
+    from graphblast_amd.dist import partition_bounds, word_slices_usable
+    n = 190
+    deg = np.ones(n, dtype=np.int64)
+    deg[-1] = 5000                                          # the nnz split lands in the last vertex
+    ptr = np.concatenate([[0], np.cumsum(deg)])
+    b = partition_bounds(ptr, 2)
+    assert b == [0, 190, 190]
+    assert not word_slices_usable(b)
+    assert word_slices_usable([0, 128, 190]) and word_slices_usable([0, 64, 128, 190]) and word_slices_usable([0, 190])
+    assert not word_slices_usable([0, 64, 190, 190])
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("edgeswitch", [0.0, 0.02])
 @pytest.mark.parametrize("world", [1, 2, 4])
