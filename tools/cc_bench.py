@@ -12,7 +12,7 @@ ptr, ind = gr["csr"]; nnz = gr["nnz"]
 val = torch.ones(nnz, dtype=torch.int32, device=dev)
 A = g.Matrix(n, n, np.int32)
 assert A.build_device_csr(ptr.data_ptr(), ind.data_ptr(), val.data_ptr(), nnz, ptr.data_ptr(), ind.data_ptr(), val.data_ptr(), keep=(ptr, ind, val)) == 0
-d_ = g.Descriptor(); d_.loadArgs(mxvmode=int(os.environ.get("MXVMODE", "1")))
+d_ = g.Descriptor(); d_.loadArgs(mxvmode=int(os.environ.get("MXVMODE", "0")))
 v = g.Vector(n, np.int32)
 for fused in (1, 0):
     g.cc_set_fused(fused)
