@@ -262,7 +262,8 @@ def other_workload(args):
         g.sssp(v, G, src, desc)
         nf_work = g.sssp_last_work() if passes else (0, 0, 0)
         alg_nf = float(12 * nf_work[0] + 12 * nf_work[1] + 8 * nf_work[2])
-        kern = "sssp_nearfar_kernel" if passes else "sssp_persistent_kernel"
+        kern = (("sssp_nfq_kernel" if os.environ.get("GRB_SSSP_QUEUE", "1") != "0" else "sssp_nearfar_kernel") if passes
+                else "sssp_persistent_kernel")
         roof = ({"bound": "hbm", "kernel": kern, "achieved": round(alg_nf / el / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                  "frac": round(alg_nf / el / 1e9 / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(kern, "road_sssp")[0],
                  "traffic_source": pmc_traffic(kern, "road_sssp")[1], "algorithmic_bytes_per_launch": int(alg_nf),
@@ -277,7 +278,7 @@ def other_workload(args):
                      "unit": "ms", "higher_is_better": False, "ms_per_step": el * 1e3, "dtype": "f32", "steps": steps,
                      "config": {"workload": "road_sssp" if path else "grid4896_thinned_sssp (stand-in)", "n": n, "nnz": nnz,
                                 "rounds": res["iterations"], "us_per_round": round(el * 1e6 / max(res["iterations"], 1), 2)},
-                     "order": ("near / far, %d passes (sssp_nearfar_kernel)" % passes) if passes else "synchronous rounds",
+                     "order": ("near / far, %d passes (%s)" % (passes, kern)) if passes else "synchronous rounds",
                      "synchronous_rounds": {"ms": round(el_rounds * 1e3, 2), "us_per_round": round(el_rounds * 1e6 / max(res0["iterations"], 1), 2),
                                             "distances_and_round_count_identical": same,
                                             "algorithmic_bytes": int(alg), "achieved_GBps": round(alg / el_rounds / 1e9, 2)},

@@ -26,7 +26,8 @@ if os.path.exists(trace):
     bfs = [int(r["duration_ns"]) for r in tr if r["kernel"].startswith("grb::bfs_persistent_kernel")]
     spmv = {}
     for r in tr:
-        for key in ("spmv_hub_kernel", "pack_vector_kernel", "spmv_long_finalize_kernel"):
+        for key in ("spmv_cband_kernel", "cband_pack_kernel", "spmv_cband_fold_kernel", "spmv_hub_kernel", "pack_vector_kernel",
+                    "spmv_long_finalize_kernel"):
             if key in r["kernel"]:
                 spmv.setdefault(key, []).append(int(r["duration_ns"]))
     ph = {"source": "rocprofv3 --kernel-trace of the default `python bench.py` (same run as bench_kernel_stats_*.csv)",
@@ -40,36 +41,82 @@ if os.path.exists(trace):
           "spmv_hip_event_mean_us_reported_by_bench": round(line["spmv"]["avg_launch_ms"] * 1e3, 2)}
     json.dump(ph, open(dst + '/bench_kernel_phases.json', 'w'), indent=1)
     print(json.dumps(ph["bfs_persistent_kernel_mean_us"]), ph["hip_event_mean_us_reported_by_bench"], ph["spmv_kernels_mean_us"])
-out = {}
-for c in ("FETCH_SIZE", "WRITE_SIZE"):
-    rr = list(csv.DictReader(open(src + '/pmc_%s/p_counter_collection.csv' % c)))
-    acc = collections.defaultdict(list)
-    for r in rr:
-        if r['Counter_Name'] != c or 'grb::' not in r['Kernel_Name']:
+def pmc_tables(prefix, csv_prefix):
+    """per-kernel means of the two passes under src/<prefix>FETCH_SIZE, src/<prefix>WRITE_SIZE"""
+    out = {}
+    for c in ("FETCH_SIZE", "WRITE_SIZE"):
+        f = src + '/%s%s/p_counter_collection.csv' % (prefix, c)
+        if not os.path.exists(f):
             continue
-        acc[r['Kernel_Name'].split('(')[0].replace('void ', '')].append(float(r['Counter_Value']))
-    for k, v in acc.items():
-        out.setdefault(k, {})[c + "_KB_mean"] = sum(v) / len(v)
-        out[k]["launches_" + c] = len(v)
-    with open(dst + '/pmc_%s_per_kernel.csv' % c, 'w', newline='') as f:
-        w = csv.writer(f); w.writerow(["kernel", "launches", "mean_KB", "min_KB", "max_KB"])
-        for k, v in sorted(acc.items()):
-            w.writerow([k, len(v), round(sum(v) / len(v), 1), min(v), max(v)])
-for k, v in out.items():
-    f_, w_ = v.get("FETCH_SIZE_KB_mean", 0), v.get("WRITE_SIZE_KB_mean", 0)
-    v["hbm_bytes_per_launch_raw"] = int((f_ + w_) * 1024)
-    v["hbm_bytes_per_launch"] = int((2 * f_ + w_) * 1024)
+        rr = list(csv.DictReader(open(f)))
+        acc = collections.defaultdict(list)
+        for r in rr:
+            if r['Counter_Name'] != c or 'grb::' not in r['Kernel_Name']:
+                continue
+            acc[r['Kernel_Name'].split('(')[0].replace('void ', '')].append(float(r['Counter_Value']))
+        for k, v in acc.items():
+            out.setdefault(k, {})[c + "_KB_mean"] = sum(v) / len(v)
+            out[k]["launches_" + c] = len(v)
+        with open(dst + '/%s%s_per_kernel.csv' % (csv_prefix, c), 'w', newline='') as fo:
+            w = csv.writer(fo); w.writerow(["kernel", "launches", "mean_KB", "min_KB", "max_KB"])
+            for k, v in sorted(acc.items()):
+                w.writerow([k, len(v), round(sum(v) / len(v), 1), min(v), max(v)])
+    for k, v in out.items():
+        f_, w_ = v.get("FETCH_SIZE_KB_mean", 0), v.get("WRITE_SIZE_KB_mean", 0)
+        v["hbm_bytes_per_launch_raw"] = int((f_ + w_) * 1024)
+        v["hbm_bytes_per_launch"] = int((2 * f_ + w_) * 1024)
+    return out
+
+
+out = pmc_tables("pmc_", "pmc_")
 cal = {k: out[k] for k in out if k.startswith("grb::reduce_kernel") or "ewise_add_dd" in k or "assign_dense_mask_dense" in k or "fill_kernel" in k}
+# a unit made of several kernels: the 64-source sweep = every batch_* launch between two batch_seed_kernel launches
+groups = {}
+seeds = [v for k, v in out.items() if "batch_seed_kernel" in k]
+if seeds:
+    sweeps = min(seeds[0].get("launches_FETCH_SIZE", 0), seeds[0].get("launches_WRITE_SIZE", 0))
+    if sweeps > 0:
+        tot = 0.0
+        for k, v in out.items():
+            if "grb::batch_" in k:
+                tot += 1024.0 * (2 * v.get("FETCH_SIZE_KB_mean", 0) * v.get("launches_FETCH_SIZE", 0)
+                                 + v.get("WRITE_SIZE_KB_mean", 0) * v.get("launches_WRITE_SIZE", 0))
+        groups["bfs_batch_sweep"] = {"hbm_bytes_per_unit": int(tot / sweeps), "units": sweeps,
+                                     "what": "sum over every batch_* kernel of (2 x FETCH_SIZE + WRITE_SIZE) x launches, per batch_seed_kernel launch"}
+workloads = {}
+lines = []
+for W in ("lj_bfs", "road_sssp", "orkut_tc"):
+    if os.path.exists(src + '/%s.log' % W):
+        txt = open(src + '/%s.log' % W).read().strip().splitlines()
+        if txt:
+            lines.append(txt[-1])
+    if os.path.exists(src + '/%s_kernel_stats.csv' % W):
+        rr = list(csv.reader(open(src + '/%s_kernel_stats.csv' % W)))
+        with open(dst + '/%s_kernel_stats_grb.csv' % W, 'w', newline='') as fo:
+            w = csv.writer(fo); w.writerow(rr[0])
+            for r in rr[1:]:
+                if 'grb::' in r[0]:
+                    w.writerow(r)
+    ow = pmc_tables("pmc_%s_" % W, "pmc_%s_" % W)
+    if ow:
+        workloads[W] = {"command": "python bench.py --workload %s --no-cpu-baseline" % W, "kernels": ow}
+if lines:
+    open(dst + '/other_workloads.jsonl', 'w').write("\n".join(lines) + "\n")
 doc = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, each with --kernel-trace only) over "
-                 "`python bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-refrule --no-batch` on MI355X",
+                 "`python bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-refrule` on MI355X",
        "note": "hbm_bytes_per_launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 B.  The factor 2 on reads is MI355X_MICROARCH.md's gfx950 "
                "correction (128-B requests tallied at 64 B), calibrated in this same run on this library's own 4 B/lane kernels of "
                "known byte count (`calibration`: the 64 Mi-float reduce reads 262144 KB, eWiseAdd 524288 KB, assign 262144 KB; each is "
                "reported at exactly 1/2; WRITE_SIZE matches the written 262144 KB).  hbm_bytes_per_launch_raw is the uncorrected sum.",
-       "calibration": cal, "kernels": out}
+       "calibration": cal, "kernels": out, "groups": groups, "workloads": workloads}
 json.dump(doc, open(dst + '/pmc_traffic.json', 'w'), indent=1, sort_keys=True)
-for k in ("grb::bfs_persistent_kernel", "grb::spmv_hub_kernel<1, float>", "grb::pack_vector_kernel<float>"):
+for k in ("grb::bfs_persistent_kernel", "grb::spmv_cband_kernel<1, float, false>", "grb::spmv_cband_kernel<1, float, true>", "grb::cband_pack_kernel<float>"):
     print(k, out.get(k, {}).get("hbm_bytes_per_launch"))
+print("groups", groups)
+for W, d in workloads.items():
+    for k, v in d["kernels"].items():
+        if v["hbm_bytes_per_launch"] > (1 << 26):
+            print(W, k[:80], v["hbm_bytes_per_launch"])
 for k, v in cal.items():
     print("calibration", k, v.get("FETCH_SIZE_KB_mean"), v.get("WRITE_SIZE_KB_mean"))
 for r in rows[1:]:
