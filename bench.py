@@ -68,14 +68,15 @@ def pmc_traffic(kernel_key, workload="rmat22_bfs"):
     return best, where
 
 
-def pmc_group(name):
+def pmc_group(name, workload=None):
     """(HBM bytes per unit of a group of kernels -- e.g. all batch_* launches of one 64-source sweep -- , source)"""
     best, where = None, None
     pdir = os.path.join(ROOT, "profiles")
     for d in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
         f = os.path.join(pdir, d, "pmc_traffic.json")
         if os.path.exists(f):
-            rec = json.load(open(f)).get("groups", {}).get(name)
+            doc = json.load(open(f))
+            rec = (doc if workload is None else doc.get("workloads", {}).get(workload, {})).get("groups", {}).get(name)
             if rec:
                 best = rec.get("hbm_bytes_per_unit")
                 where = "profiles/%s/pmc_traffic.json (separate rocprofv3 --pmc passes, not this run)" % d
@@ -339,7 +340,7 @@ def other_workload(args):
         alg = float(4.0 * (np.sum(dl * dl) + np.sum(dl[li])) + 12.0 * li.size)
         del erow
         t = float(np.mean(ms)) * 1e-3
-        kern = "spgemm_masked_kernel"
+        kern = "spgemm_pivot_block_kernel / spgemm_pivot_wave_kernel"
         # compulsory HBM bytes: L's structure read (as the left operand, the right operand and the mask: one copy in
         # memory), the result's values written, its structure copied; the intersections themselves re-read adjacency
         # lists that the L2 serves (alg: both lists of every mask entry)
@@ -350,7 +351,7 @@ def other_workload(args):
                                                 "nnz_L": int(li.size), "triangles": int(ntri)},
                      "roofline": {"bound": "hbm", "kernel": kern, "achieved": round(compulsory / t / 1e9, 2),
                                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(compulsory / t / 1e9 / HBM_PEAK_GBS, 5),
-                                  "traffic": pmc_traffic(kern, "orkut_tc")[0], "traffic_source": pmc_traffic(kern, "orkut_tc")[1],
+                                  "traffic": pmc_group("masked_spgemm_call", "orkut_tc")[0], "traffic_source": pmc_group("masked_spgemm_call", "orkut_tc")[1],
                                   "algorithmic_bytes_per_launch": int(compulsory),
                                   "list_bytes_served_on_chip": int(alg), "list_GBps": round(alg / t / 1e9, 1),
                                   "note": "bytes = compulsory HBM traffic (operands once, result once); the kernel is bound "
@@ -556,11 +557,12 @@ def main():
             sb_ = g.k_spmv_bytes(M, 0)
             info = g.spmv_format_info(M, 0)
             kern = "spmv_cband_kernel" if info["in_use"] else "spmv_hub_kernel"
+            pkey = ("spmv_cband_kernel<1, float, %s>" % ("true" if info["iso"] else "false")) if info["in_use"] else kern
             rec = {"kernel": "%s<PlusMultiplies,f32>" % kern, "bound": "hbm", "matrix_values": note,
                    "algorithmic_bytes_per_launch": sb_, "avg_launch_ms": round(ms_, 5),
                    "achieved": round(sb_ / (ms_ * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                    "frac": round(sb_ / (ms_ * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                   "traffic": pmc_traffic(kern)[0], "traffic_source": pmc_traffic(kern)[1],
+                   "traffic": pmc_traffic(pkey)[0], "traffic_source": pmc_traffic(pkey)[1],
                    "gflops": round(2 * nnz / (ms_ * 1e-3) / 1e9, 1)}
             if info["in_use"]:
                 rec["format"] = {"groups_of_64": info["groups"], "row_bands": info["bands"], "hub_rows": info["hub_rows"],

@@ -100,6 +100,16 @@ for W in ("lj_bfs", "road_sssp", "orkut_tc"):
     ow = pmc_tables("pmc_%s_" % W, "pmc_%s_" % W)
     if ow:
         workloads[W] = {"command": "python bench.py --workload %s --no-cpu-baseline" % W, "kernels": ow}
+        if W == "orkut_tc":
+            # one masked SpGEMM = one fill_value_kernel launch + the pivot kernels of both passes
+            calls = [v for k, v in ow.items() if "fill_value_kernel" in k]
+            ncall = min(calls[0].get("launches_FETCH_SIZE", 0), calls[0].get("launches_WRITE_SIZE", 0)) if calls else 0
+            if ncall > 0:
+                tot = sum(1024.0 * (2 * v.get("FETCH_SIZE_KB_mean", 0) * v.get("launches_FETCH_SIZE", 0)
+                                    + v.get("WRITE_SIZE_KB_mean", 0) * v.get("launches_WRITE_SIZE", 0))
+                          for k, v in ow.items() if "spgemm_" in k or "fill_value_kernel" in k)
+                workloads[W]["groups"] = {"masked_spgemm_call": {"hbm_bytes_per_unit": int(tot / ncall), "units": ncall,
+                                                                 "what": "every spgemm_* kernel + fill_value_kernel, per mxm call"}}
 if lines:
     open(dst + '/other_workloads.jsonl', 'w').write("\n".join(lines) + "\n")
 doc = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, each with --kernel-trace only) over "
