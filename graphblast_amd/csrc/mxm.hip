@@ -157,7 +157,8 @@ __global__ __launch_bounds__(kBlock) void spgemm_masked_kernel(
 // LDS with the monoid's atomic.  Pivots of up to kWaveCap entries are a wave's (64 partners per tile); longer ones
 // take a 1024-thread workgroup (1024 partners per tile) whose table is 64 KiB of LDS (two workgroups per CU): 4096
 // (key, value) slots -- or 8192 keys when the pivot side holds one value throughout, as a pattern matrix does -- and
-// a global arena for pivots beyond that.  Without a CSC of the mask pass 2 falls back to the entry-driven kernel for its entries.
+// pivots beyond 128 KiB of table are taken in column-range segments.  Without a CSC of the mask pass 2 falls back to the
+// entry-driven kernel for its entries.
 constexpr int kWaveCap = 512;              // pivot entries a wave's table holds (1024 slots x 8 B = 8 KiB per wave)
 constexpr int kWaveSlots = 2 * kWaveCap;
 constexpr unsigned int kEmptyKey = 0xffffffffu;
@@ -171,8 +172,6 @@ __device__ inline unsigned int tc_hash(unsigned int c) { return c * 2654435761u;
 // almost always the only one -- slot by slot, the lanes of a wave wait for the longest chain among them, and that
 // chain of dependent LDS reads, not any memory traffic, was what bounded the kernel.  Insertion fills the first free
 // slot of the key's group, then of the following groups; a lookup stops at the first group with a free slot.
-// Slots are read and written with workgroup-scope atomics: the table may live in global memory (the arena of the
-// longest rows), where one wave's plain store need not be what another wave of the workgroup loads.
 typedef unsigned int TcWord4 __attribute__((ext_vector_type(4)));
 
 __device__ inline void tc_insert(HashSlot* tab, unsigned int mask, unsigned int col, unsigned int vbits) {
@@ -400,23 +399,22 @@ __global__ __launch_bounds__(kBlock) void spgemm_pivot_wave_kernel(T* __restrict
   }
 }
 
-// pivots longer than kWaveCap: a 1024-thread workgroup per run of entries (listed in big), table in LDS or -- beyond
-// kCap entries -- in this workgroup's slice of a global arena (arena_slots per workgroup, a power of two)
+// pivots longer than kWaveCap: a 1024-thread workgroup per run of entries (listed in big), table in LDS; a pivot of
+// more than kCap entries is taken kCap entries at a time (kSegments)
 struct PivotItem { Index pivot, e0, e1; };                // a run of a long pivot's entries (whole tiles of 1024)
 
-template <int SR, typename T, bool kArena, typename Slot, int kTableBytes>
+template <int SR, typename T, bool kSegments, typename Slot, int kTableBytes>
 __global__ __launch_bounds__(1024) void spgemm_pivot_block_kernel(T* __restrict__ c_val, PivotView v,
                                                                   const PivotItem* __restrict__ big, int nbig,
-                                                                  Slot* __restrict__ arena, unsigned int arena_slots,
                                                                   Index min_len, unsigned long long* __restrict__ trace) {
   typedef Semiring<SR, T> S;
   // kTableBytes of LDS table at half load: 64 KiB = two workgroups per CU; the 128 KiB instantiation takes the
-  // pivots too long for that one; the arena instantiation those too long for any LDS table
+  // pivots too long for that one, and with kSegments those too long for any LDS table
   constexpr int kCap = kTableBytes / (int)sizeof(Slot) / 2;
   const unsigned long long t_begin = wall_clock64();
   unsigned long long t_items = 0;
   int n_items = 0;
-  __shared__ Slot s_tab[kArena ? 1 : 2 * kCap];
+  __shared__ Slot s_tab[2 * kCap];
   const int tid = threadIdx.x, lane = tid & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const T* __restrict__ par_val = reinterpret_cast<const T*>(v.par_val);
@@ -428,29 +426,33 @@ __global__ __launch_bounds__(1024) void spgemm_pivot_block_kernel(T* __restrict_
     const Index es = big[bi].e0, ee = big[bi].e1;
     const Index as = v.piv_ptr[r], ae = v.piv_ptr[r + 1];
     const Index da = ae - as;
-    if (kArena ? da <= min_len : (da > kCap || da <= min_len)) continue;   // another instantiation's
+    if (kSegments ? da <= min_len : (da > kCap || da <= min_len)) continue;   // another instantiation's
     const unsigned long long t_item = wall_clock64();
     ++n_items;
-    Slot* tab = kArena ? arena + (size_t)blockIdx.x * arena_slots : s_tab;
+    Slot* tab = s_tab;
+    // A pivot too long for the table is taken in SEGMENTS of kCap consecutive entries (= a column range, the lists
+    // are sorted): the table holds one segment, every partner is restricted to that column range by two binary
+    // searches, and an entry's result is folded over the segments.  (The first form of this probed a table in
+    // global memory instead: 251 GB of HBM traffic per launch on RMAT-22 ef 28 -- it ran at the HBM rate on hash
+    // probes, 97 ms for a few hundred rows; in segments 45 ms.)
+    const Index nseg = kSegments ? (da + kCap - 1) / kCap : 1;
+    for (Index seg = 0; seg < nseg; ++seg) {
+    const Index seg_s = as + seg * (Index)kCap;
+    const Index seg_e = (kSegments && seg_s + kCap < ae) ? seg_s + (Index)kCap : ae;
+    const Index c_lo = kSegments ? v.piv_ind[seg_s] : 0, c_hi = kSegments ? v.piv_ind[seg_e - 1] : 0;
     unsigned int slots = 1024;
-    while ((Index)slots < 2 * da) slots <<= 1;
+    while ((Index)slots < 2 * (seg_e - seg_s)) slots <<= 1;
     const unsigned int tmask = slots - 1;
     __syncthreads();
-    for (unsigned int i = tid; i < slots; i += 1024) __hip_atomic_store(&tab[i].key, kEmptyKey, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    __threadfence_block();
+    for (unsigned int i = tid; i < slots; i += 1024) tab[i].key = kEmptyKey;
     __syncthreads();
-    for (Index p = as + tid; p < ae; p += 1024) {
+    for (Index p = seg_s + tid; p < seg_e; p += 1024) {
       unsigned int vb;
       const T av = piv_val[p];
       memcpy(&vb, &av, 4);
       tc_insert(tab, tmask, (unsigned int)v.piv_ind[p], vb);
     }
-    __threadfence_block();
     __syncthreads();
-    if (kArena) {                                          // the probes are plain loads: drop what this CU's L1 still
-      if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // holds of the slice's previous table
-      __syncthreads();
-    }
     // A wave per partner: the pivots here are long, and so are their partners on average (RMAT-22 ef 28: 450
     // entries) -- the lanes stride one list, count in registers, fold once.  No LDS bookkeeping, no atomics: the
     // flat-index form this replaces issued ~400 instructions per 64 elements and was bound by that.  The partners'
@@ -460,11 +462,15 @@ __global__ __launch_bounds__(1024) void spgemm_pivot_block_kernel(T* __restrict_
       const Index t = t0 + lane;
       Index ps = 0, pe = 0, out = 0;
       const bool mine = t < ee && tc_entry_of(v, r, t, da, &ps, &pe, &out);
+      if (kSegments && mine) {                               // the part of the partner inside this segment's columns
+        ps = lower_bound_dev(v.par_ind, ps, pe, c_lo);
+        pe = lower_bound_dev(v.par_ind, ps, pe, c_hi + 1);
+      }
       T result = S::identity();
       // The partners' lists as one sequence of 256-element chunks, software-pipelined: the keys of the next chunk
       // (the same partner's, or the next partner's first) are in flight while the current chunk is probed -- a
       // partner is a couple of dependent memory steps otherwise, and a wave does hundreds of them one after the other.
-      unsigned long long todo = __ballot(mine);
+      unsigned long long todo = __ballot(mine && pe > ps);
       int src_n = todo ? __ffsll((long long)todo) - 1 : -1;   // partner the next chunk belongs to
       Index cs_n = 0, ce_n = 0;
       if (src_n >= 0) { cs_n = __shfl(ps, src_n, kWave); ce_n = __shfl(pe, src_n, kWave); todo &= todo - 1; }
@@ -531,7 +537,8 @@ __global__ __launch_bounds__(1024) void spgemm_pivot_block_kernel(T* __restrict_
           acc = S::identity();
         }
       }
-      if (mine) c_val[out] = result;
+      if (mine) c_val[out] = (kSegments && seg > 0) ? S::add(result, c_val[out]) : result;
+    }
     }
     const unsigned long long dt = wall_clock64() - t_item;
     t_items = dt > t_items ? dt : t_items;
@@ -727,7 +734,7 @@ grb_info grb_mxm(grb_matrix C, grb_matrix mask, grb_accum accum, grb_semiring op
     GRB_HIP_TRY(hipGetLastError());
     std::vector<PivotItem> big;
     auto run_pass = [&](const PivotView& v, Index npiv, bool piv_iso, const std::vector<Index>& hp_piv,
-                        const std::vector<Index>& hp_ent, int scratch_list, int scratch_arena) -> grb_info {
+                        const std::vector<Index>& hp_ent, int scratch_list) -> grb_info {
       // the long pivots' entries in runs of <= 4 tiles, heaviest first (a run costs about entries x pivot length:
       // its partners are no longer than the pivot), dealt round-robin: the few giant rows do not become the tail
       big.clear();
@@ -752,20 +759,13 @@ grb_info grb_mxm(grb_matrix C, grb_matrix mask, grb_accum accum, grb_semiring op
       if (big.empty()) return GRB_SUCCESS;
       // two workgroups per CU (64 KiB tables); is the pivot side one value throughout?  then the tables hold keys only
       const int bgrid = (int)big.size() < 2 * ctx().num_cu ? (int)big.size() : 2 * ctx().num_cu;
-      void *p_big, *p_arena = nullptr;
+      void* p_big;
       GRB_TRY(scratch(scratch_list, sizeof(PivotItem) * big.size() + 64, &p_big));
       GRB_HIP_TRY(hipMemcpyAsync(p_big, big.data(), sizeof(PivotItem) * big.size(), hipMemcpyHostToDevice, s));
       const bool iso = piv_iso;
       const PivotView& vv = v;
       auto launch = [&](auto slot_tag) -> grb_info {
         using Slot = decltype(slot_tag);
-        const Index cap = 131072 / (Index)sizeof(Slot) / 2;
-        unsigned int arena_slots = 0;
-        if (longest > cap) {
-          arena_slots = 1024;
-          while ((Index)arena_slots < 2 * longest) arena_slots <<= 1;
-          GRB_TRY(scratch(scratch_arena, sizeof(Slot) * (size_t)arena_slots * (size_t)bgrid, &p_arena));
-        }
         static const bool want_trace = getenv("GRB_MXM_TRACE") != nullptr;
         unsigned long long* d_trace = nullptr;
         if (want_trace) {
@@ -789,22 +789,22 @@ grb_info grb_mxm(grb_matrix C, grb_matrix mask, grb_accum accum, grb_semiring op
         const Index cap64 = 65536 / (Index)sizeof(Slot) / 2, cap128 = 131072 / (Index)sizeof(Slot) / 2;
         if (want_trace) GRB_HIP_TRY(hipMemsetAsync(d_trace, 0, 24 * (size_t)bgrid, s));
         hipLaunchKernelGGL((spgemm_pivot_block_kernel<SR, T, false, Slot, 65536>), dim3(bgrid), dim3(1024), 0, s, (T*)C->csr.val, vv,
-                           (const PivotItem*)p_big, (int)big.size(), (Slot*)nullptr, 0u, (Index)0, d_trace);
+                           (const PivotItem*)p_big, (int)big.size(), (Index)0, d_trace);
         GRB_HIP_TRY(hipGetLastError());
         GRB_TRY(dump("64 KiB LDS tables"));
         if (longest > cap64) {
           if (want_trace) GRB_HIP_TRY(hipMemsetAsync(d_trace, 0, 24 * (size_t)bgrid, s));
           hipLaunchKernelGGL((spgemm_pivot_block_kernel<SR, T, false, Slot, 131072>), dim3(bgrid), dim3(1024), 0, s, (T*)C->csr.val, vv,
-                             (const PivotItem*)p_big, (int)big.size(), (Slot*)nullptr, 0u, cap64, d_trace);
+                             (const PivotItem*)p_big, (int)big.size(), cap64, d_trace);
           GRB_HIP_TRY(hipGetLastError());
           GRB_TRY(dump("128 KiB LDS tables"));
         }
         if (longest > cap128) {
           if (want_trace) GRB_HIP_TRY(hipMemsetAsync(d_trace, 0, 24 * (size_t)bgrid, s));
-          hipLaunchKernelGGL((spgemm_pivot_block_kernel<SR, T, true, Slot, 65536>), dim3(bgrid), dim3(1024), 0, s, (T*)C->csr.val, vv,
-                             (const PivotItem*)p_big, (int)big.size(), (Slot*)p_arena, arena_slots, cap128, d_trace);
+          hipLaunchKernelGGL((spgemm_pivot_block_kernel<SR, T, true, Slot, 131072>), dim3(bgrid), dim3(1024), 0, s, (T*)C->csr.val, vv,
+                             (const PivotItem*)p_big, (int)big.size(), cap128, d_trace);
           GRB_HIP_TRY(hipGetLastError());
-          GRB_TRY(dump("arena tables"));
+          GRB_TRY(dump("128 KiB LDS tables, pivot in segments"));
         }
         return GRB_SUCCESS;
       };
@@ -838,7 +838,7 @@ grb_info grb_mxm(grb_matrix C, grb_matrix mask, grb_accum accum, grb_semiring op
     v1.iso_bits = rng[0];
     v1.par_iso = iso_b ? 1 : 0;
     v1.par_iso_bits = rng[2];
-    GRB_TRY(run_pass(v1, Aa.n, iso_a, hpa, mask->h_csr_ptr, 6, 10));
+    GRB_TRY(run_pass(v1, Aa.n, iso_a, hpa, mask->h_csr_ptr, 6));
     if (!have_csc) return entry_driven(1);                // the entries whose row of B is the longer list
     PivotView v2 = v1;
     v2.piv_ptr = Bb.ptr; v2.piv_ind = Bb.ind; v2.piv_val = Bb.val;
@@ -848,7 +848,7 @@ grb_info grb_mxm(grb_matrix C, grb_matrix mask, grb_accum accum, grb_semiring op
     v2.iso_bits = rng[2];
     v2.par_iso = iso_a ? 1 : 0;
     v2.par_iso_bits = rng[0];
-    return run_pass(v2, Bb.n, iso_b, hpb, mask->h_csc_ptr, 6, 10);
+    return run_pass(v2, Bb.n, iso_b, hpb, mask->h_csc_ptr, 6);
   });
 }
 
