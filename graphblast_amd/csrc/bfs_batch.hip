@@ -388,6 +388,137 @@ __global__ __launch_bounds__(kBlock) void batch_push_slices_kernel(BatchArgs a) 
   }
 }
 
+// ---- heavy push levels, the big rows by destination range ----------------------------------------------------------
+// A heavy level pushes tens of millions of edges, nearly all of them out of a few thousand hub rows, and every edge
+// was one atomicOr on a random 8-byte word of the 33 MB `seen` array: ~45 G edges/s, 290 us for the 15 M edges of
+// RMAT-22's second level.  The rows are sorted, so a row's entries that fall into one range of destinations are one
+// contiguous piece: a workgroup OWNS a range, keeps its words in LDS (at most 8 Ki of them, 64 KiB), ORs into them
+// the pieces of every big frontier row (offsets per (row, range) precomputed once per matrix), and writes the range
+// back with plain coalesced stores.  No global atomics, every edge read once: 293 -> 105 us for that level's big rows.
+constexpr int kOwnRows = 8192;         // 64 KiB of LDS: two workgroups of 1024 per CU
+constexpr int kOwnSmallRows = 2048;
+
+__global__ void batch_range_off_kernel(const Index* __restrict__ optr, const Index* __restrict__ oind,
+                                       const Index* __restrict__ bigrows, int nbig, int R, const Index* __restrict__ bounds,
+                                       Index* __restrict__ off) {
+  const long long total = (long long)nbig * (R + 1);
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int bi = (int)(i / (R + 1)), b = (int)(i % (R + 1));
+    const Index u = bigrows[bi];
+    Index lo = optr[u], hi = optr[u + 1];
+    const long long key = (long long)bounds[b];            // first entry with a destination >= key
+    while (lo < hi) {
+      const Index mid = lo + (hi - lo) / 2;
+      if ((long long)oind[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    off[(size_t)b * nbig + bi] = lo;                       // range-major: a range's owner reads neighbouring rows' offsets from one line
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void batch_big_list_kernel(BatchArgs a, int* __restrict__ list, u64* __restrict__ list_fw,
+                                                                unsigned int* __restrict__ count) {
+  const int lane = lane_id();
+  for (int base = (blockIdx.x * kWavesPerBlock + wave_id()) * kWave; base < a.nbig; base += gridDim.x * kBlock) {
+    const int bi = base + lane;
+    const u64 fw = bi < a.nbig ? (a.fcur[a.bigrows[bi]] & a.pmask) : 0ull;
+    const unsigned long long m = __ballot(fw != 0ull);
+    if (!m) continue;
+    unsigned int b0 = 0;
+    if (lane == 0) b0 = atomicAdd(count, (unsigned int)__popcll(m));
+    b0 = __shfl(b0, 0, kWave);
+    if (fw) {
+      const unsigned int at = b0 + (unsigned int)__popcll(m & ((1ull << lane) - 1ull));
+      list[at] = bi;
+      list_fw[at] = fw;                                    // the owners read (row, bits) in one step, not three
+    }
+  }
+}
+
+// A power-law graph sends a fifth of all edges to its first 16 Ki vertices: the ranges are cut at equal in-degree
+// mass (at most 8 Ki rows each), so the hub region is many narrow ranges.  (Equal-width ranges with the heavy ones
+// shared between several workgroups -- each with its own LDS copy, written back with atomicOr -- were measured
+// first: 115-130 us.)  A lane takes a list entry: the piece of one big row inside the range; the pieces of a wave's
+// entries are laid end to end and dealt to the lanes.  Two instantiations: the narrow ranges of the hub region
+// (<= 2 Ki rows, 16 KiB of LDS, 512 threads: four workgroups per CU -- a workgroup's work is a short chain of
+// dependent steps, and with one per CU the chip mostly waits) and the wide ones (two per CU): 27 + 77 us.
+template <int kRows, int kThreads>
+__global__ __launch_bounds__(kThreads) void batch_push_owner_kernel(BatchArgs a, const Index* __restrict__ range_off, int R,
+                                                                    const int* __restrict__ list, const u64* __restrict__ list_fw,
+                                                                    const unsigned int* __restrict__ count, const Index* __restrict__ bounds,
+                                                                    const int* __restrict__ ids) {
+  __shared__ u64 acc[kRows];
+  __shared__ Index s_pre[kThreads / kWave][kWave];
+  __shared__ Index s_p[kThreads / kWave][kWave];
+  __shared__ u64 s_fw[kThreads / kWave][kWave];
+  const int tid = threadIdx.x, lane = tid & (kWave - 1);
+  const int b = ids[blockIdx.x];
+  const Index base = bounds[b];
+  const int rows = (int)(bounds[b + 1] - base);
+  for (int i = tid; i < rows; i += kThreads) acc[i] = 0ull;
+  __syncthreads();
+  const long long nlist = (long long)*count;
+  for (long long k0 = 0; k0 < nlist; k0 += kThreads) {
+    const long long i = k0 + tid;
+    Index o0 = 0, o1 = 0;
+    u64 fw = 0ull;
+    if (i < nlist) {
+      const int bi = list[i];
+      fw = list_fw[i];
+      o0 = range_off[(size_t)b * a.nbig + bi];
+      o1 = range_off[(size_t)(b + 1) * a.nbig + bi];
+    }
+    // the pieces of a wave's 64 entries laid end to end and dealt to the lanes 256 edges at a time (as batch_push_kernel
+    // does with rows): a wave pays one chain of memory latencies per 256 edges whatever the piece lengths are
+    const Index len = o1 - o0;
+    Index inc = len;
+#pragma unroll
+    for (int o = 1; o < kWave; o <<= 1) {
+      const Index t = __shfl_up(inc, o, kWave);
+      if (lane >= o) inc += t;
+    }
+    const Index total = __shfl(inc, kWave - 1, kWave);
+    if (total == 0) continue;
+    const int w = tid >> 6;
+    __builtin_amdgcn_wave_barrier();
+    s_pre[w][lane] = inc - len;
+    s_p[w][lane] = o0;
+    s_fw[w][lane] = fw;
+    __builtin_amdgcn_wave_barrier();
+    constexpr int kPer = 8;                                // edges per lane and step: that many loads in flight
+    for (Index at0 = 0; at0 < total; at0 += kPer * kWave) {
+      Index q[kPer], d[kPer];
+      u64 f[kPer];
+#pragma unroll
+      for (int j = 0; j < kPer; ++j) {
+        const Index at = at0 + j * kWave + lane;
+        q[j] = -1; f[j] = 0ull;
+        if (at < total) {
+          int r = 0;                                       // the last entry whose first edge is <= at
+#pragma unroll
+          for (int step = kWave / 2; step > 0; step >>= 1)
+            if (s_pre[w][r + step] <= at) r += step;
+          q[j] = s_p[w][r] + (at - s_pre[w][r]);
+          f[j] = s_fw[w][r];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < kPer; ++j) d[j] = q[j] >= 0 ? a.oind[q[j]] - base : -1;
+#pragma unroll
+      for (int j = 0; j < kPer; ++j)
+        if (d[j] >= 0) atomicOr(&acc[d[j]], f[j]);
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < rows; i += kThreads) {
+    const Index v = base + i;
+    const u64 x = acc[i];
+    if (x != 0ull) {
+      const u64 sv = a.seen[v];
+      if (x & ~sv) a.seen[v] = sv | x;                     // the claim; the commit pass finds it as seen & ~prev
+    }
+  }
+}
+
 // after the push kernels of a level: the pushed bits that arrived in fnext are this level's discoveries
 __global__ __launch_bounds__(kBlock) void batch_push_commit_kernel(BatchArgs a) {
   __shared__ BatchTotals lds;
@@ -499,6 +630,45 @@ static grb_info ensure_slices(grb_matrix A, bool in_edges) {
     GRB_HIP_TRY(hipMalloc((void**)&B.d_rows, sizeof(Index) * rows.size()));
     GRB_HIP_TRY(hipMemcpy(B.d_slices, sl.data(), sizeof(int4) * sl.size(), hipMemcpyHostToDevice));
     GRB_HIP_TRY(hipMemcpy(B.d_rows, rows.data(), sizeof(Index) * rows.size(), hipMemcpyHostToDevice));
+    // out-edges: where each big row enters each destination range (the owner-computes push of heavy levels); ranges of
+    // equal in-degree mass, about four per CU-sized share, at most kOwnRows rows
+    if (!in_edges && n >= 2 * kOwnRows) {
+      const std::vector<Index>& iptr = (Index)A->h_csc_ptr.size() == n + 1 ? A->h_csc_ptr : A->h_csr_ptr;
+      const long long total = (long long)iptr[(size_t)n];
+      const long long target = std::max<long long>(1, total / (3 * 256));
+      std::vector<Index> bounds(1, 0);
+      while (bounds.back() < n) {
+        const Index s0 = bounds.back();
+        Index e = (Index)std::min<long long>((long long)n, (long long)s0 + kOwnRows);
+        // the last row whose prefix stays within the target, at least one row
+        const Index* lo = iptr.data() + s0 + 1;
+        const Index* hi = iptr.data() + e + 1;
+        const Index* cut = std::upper_bound(lo, hi, (Index)std::min<long long>((long long)iptr[s0] + target, 0x7fffffffll));
+        Index e2 = (Index)(cut - iptr.data()) - 1;
+        if (e2 <= s0) e2 = s0 + 1;
+        if (e2 < e) e = e2;
+        bounds.push_back(e);
+      }
+      const long long R = (long long)bounds.size() - 1;
+      if (R >= 2 && (long long)rows.size() * (R + 1) <= (128ll << 20)) {
+        GRB_HIP_TRY(hipMalloc((void**)&B.d_range_bounds, sizeof(Index) * bounds.size()));
+        GRB_HIP_TRY(hipMemcpy(B.d_range_bounds, bounds.data(), sizeof(Index) * bounds.size(), hipMemcpyHostToDevice));
+        GRB_HIP_TRY(hipMalloc((void**)&B.d_range_off, sizeof(Index) * rows.size() * (size_t)(R + 1)));
+        hipLaunchKernelGGL(batch_range_off_kernel, dim3(stream_grid((long long)rows.size() * (R + 1), kBlock)), dim3(kBlock), 0,
+                           ctx().stream, A->csr.ptr, A->csr.ind, B.d_rows, (int)rows.size(), (int)R, (const Index*)B.d_range_bounds,
+                           B.d_range_off);
+        GRB_HIP_TRY(hipGetLastError());
+        B.nranges = (int)R;
+        std::vector<int> ids;
+        for (int pass = 0; pass < 2; ++pass) {
+          for (long long b = 0; b < R; ++b)
+            if ((bounds[(size_t)b + 1] - bounds[(size_t)b] <= kOwnSmallRows) == (pass == 0)) ids.push_back((int)b);
+          if (pass == 0) B.nsmall = (int)ids.size();
+        }
+        GRB_HIP_TRY(hipMalloc((void**)&B.d_range_ids, sizeof(int) * ids.size()));
+        GRB_HIP_TRY(hipMemcpy(B.d_range_ids, ids.data(), sizeof(int) * ids.size(), hipMemcpyHostToDevice));
+      }
+    }
   }
   B.ready = true;
   return GRB_SUCCESS;
@@ -647,7 +817,33 @@ extern "C" grb_info grb_bfs_batch(grb_vector* v, int k, grb_matrix A, const grb_
       a.slices = B.d_slices; a.nslices = B.nslices; a.bigrows = B.d_rows; a.nbig = B.nbig;
       hipLaunchKernelGGL(batch_push_kernel, dim3(grid), dim3(kBlock), 0, st, a);
       GRB_HIP_TRY(hipGetLastError());
-      if (B.nslices > 0) {
+      static const bool owner_ok = [] { const char* e = getenv("GRB_BATCH_OWNER"); return !e || atoi(e) != 0; }();
+      if (B.nslices > 0 && a.prev && owner_ok && B.d_range_off) {
+        // heavy level: the big rows' edges are settled by the owners of their destination ranges, in LDS
+        void* p_list;
+        const size_t list_bytes = (sizeof(int) * (size_t)B.nbig + 255) & ~(size_t)255;
+        GRB_TRY(scratch(11, 256 + list_bytes + sizeof(u64) * (size_t)B.nbig, &p_list));
+        unsigned int* d_count = (unsigned int*)p_list;
+        int* d_list = (int*)((char*)p_list + 256);
+        u64* d_list_fw = (u64*)((char*)p_list + 256 + list_bytes);
+        GRB_HIP_TRY(hipMemsetAsync(d_count, 0, 4, st));
+        hipLaunchKernelGGL(batch_big_list_kernel, dim3(stream_grid(B.nbig, kBlock)), dim3(kBlock), 0, st, a, d_list, d_list_fw, d_count);
+        GRB_HIP_TRY(hipGetLastError());
+        if (B.nsmall > 0)
+          hipLaunchKernelGGL((batch_push_owner_kernel<kOwnSmallRows, 512>), dim3(B.nsmall), dim3(512), 0, st, a, (const Index*)B.d_range_off,
+                             B.nranges, (const int*)d_list, (const u64*)d_list_fw, (const unsigned int*)d_count,
+                             (const Index*)B.d_range_bounds, (const int*)B.d_range_ids);
+        if (B.nranges > B.nsmall)
+          hipLaunchKernelGGL((batch_push_owner_kernel<kOwnRows, 1024>), dim3(B.nranges - B.nsmall), dim3(1024), 0, st, a,
+                             (const Index*)B.d_range_off, B.nranges, (const int*)d_list, (const u64*)d_list_fw, (const unsigned int*)d_count,
+                             (const Index*)B.d_range_bounds, (const int*)B.d_range_ids + B.nsmall);
+        GRB_HIP_TRY(hipGetLastError());
+        if (trace) {
+          unsigned int hc = 0;
+          GRB_HIP_TRY(hipMemcpy(&hc, d_count, 4, hipMemcpyDeviceToHost));
+          fprintf(stderr, "batch level %d: owner-computes push, %u of %d big rows in the frontier, %d ranges\n", iter, hc, B.nbig, B.nranges);
+        }
+      } else if (B.nslices > 0) {
         hipLaunchKernelGGL(batch_push_slices_kernel, dim3(stream_grid((long long)B.nslices * kWave, kBlock)), dim3(kBlock),
                            0, st, a);
         GRB_HIP_TRY(hipGetLastError());

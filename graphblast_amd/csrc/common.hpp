@@ -499,6 +499,11 @@ struct BatchSlices {
   int4* d_slices = nullptr;      // {vertex, first entry, end entry, big index}
   Index* d_rows = nullptr;       // the big rows' vertex ids
   int nslices = 0, nbig = 0;
+  Index* d_range_off = nullptr;  // out-edges only: [nranges + 1][nbig] where a big row's entries enter each destination range
+  int nranges = 0;
+  Index* d_range_bounds = nullptr;   // [nranges + 1] first destination of each range: equal in-degree mass, at most 16 Ki rows
+  int* d_range_ids = nullptr;        // the ranges of at most 2 Ki rows first (nsmall of them), then the wider ones
+  int nsmall = 0;
 };
 // dense-core split of one orientation for the MFMA SpMM path (spmm.hip)
 struct SpmmCore {

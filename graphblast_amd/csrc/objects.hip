@@ -782,6 +782,9 @@ void grb::matrix_release_device(grb_matrix A) {
   for (BatchSlices* b : {&A->batch_in, &A->batch_out}) {
     if (b->d_slices) (void)hipFree(b->d_slices);
     if (b->d_rows) (void)hipFree(b->d_rows);
+    if (b->d_range_off) (void)hipFree(b->d_range_off);
+    if (b->d_range_bounds) (void)hipFree(b->d_range_bounds);
+    if (b->d_range_ids) (void)hipFree(b->d_range_ids);
     *b = BatchSlices();
   }
   A->nonneg_values = -1; A->mean_value = -1.0; A->small_int_values = -1;
