@@ -14,7 +14,7 @@ val = torch.ones(nnz, dtype=torch.float32, device=dev)
 A = g.Matrix(n, n)
 assert A.build_device_csr(ptr.data_ptr(), ind.data_ptr(), val.data_ptr(), nnz, ptr.data_ptr(), ind.data_ptr(), val.data_ptr(), keep=(ptr, ind, val)) == 0
 d = g.Descriptor(); d.loadArgs(mxvmode=0, struconly=1, opreuse=1, earlyexit=1, edgeswitch=float(os.environ.get("EDGESWITCH", "0.08")))
-srcs = random_sources(ptr.cpu().numpy(), 4, seed=0)
+srcs = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else random_sources(ptr.cpu().numpy(), 4, seed=0)
 v = g.Vector(n)
 for s in srcs + srcs:
     info, r = g.bfs(v, A, int(s), d, fused=True, profile=1)
