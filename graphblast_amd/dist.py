@@ -20,6 +20,8 @@ tests plug in a numpy engine (tests/), which is how the N > 1 path is covered wi
 """
 import ctypes as C
 
+import time
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -758,10 +760,16 @@ class Partition1D:
         vals = (alpha / deg_full.to(torch.float32)[lind[:nnz_l].long()]).to(torch.float32).contiguous()
         if vals.numel() == 0:
             vals = torch.zeros(1, dtype=torch.float32, device=dev)
-        cuts = eng.pr_setup_chunks(vals, dev, nchunks)
-        # every rank's chunk boundaries (vertex ids), identical on all ranks: one small all-gather at set-up
-        mine = torch.tensor([self.lo + c for c in cuts], dtype=torch.float64, device=dev)
-        allc = comm.all_gather_padded(mine).cpu().numpy().astype(np.int64)           # [world, nchunks + 1]
+        # the chunk matrices (and their SpMV plans: ~50 ms of preparation on RMAT-22) are kept between calls on the
+        # same degrees / alpha -- every rank takes the same branch, so the set-up all-gather stays symmetric
+        key = (deg_full.data_ptr(), float(alpha), int(nchunks), int(deg_full.numel()))
+        if getattr(self, "_pr_key", None) != key:
+            cuts = eng.pr_setup_chunks(vals, dev, nchunks)
+            # every rank's chunk boundaries (vertex ids), identical on all ranks: one small all-gather at set-up
+            mine = torch.tensor([self.lo + c for c in cuts], dtype=torch.float64, device=dev)
+            self._pr_allc = comm.all_gather_padded(mine).cpu().numpy().astype(np.int64)   # [world, nchunks + 1]
+            self._pr_key = key
+        allc = self._pr_allc
         g = eng.g
         lib = eng._lib
         p_cur = torch.full((n,), 1.0 / n, dtype=torch.float32, device=dev)
@@ -771,6 +779,7 @@ class Partition1D:
         const = float(np.float32((np.float32(1.0) - np.float32(alpha)) / np.float32(n)))
         error, it, errs = 1.0, 0, []
         torch.cuda.synchronize()
+        t_loop = time.perf_counter()
         while error > eps and it < max_niter:
             acc.zero_()
             for c, (a, b, M) in enumerate(eng.pr_chunks):
@@ -787,7 +796,9 @@ class Partition1D:
             errs.append(error)
             p_cur, p_next = p_next, p_cur
             it += 1
-        return p_cur, dict(iterations=it, errors=errs, overlapped_chunks=nchunks)
+        torch.cuda.synchronize()
+        return p_cur, dict(iterations=it, errors=errs, overlapped_chunks=nchunks,
+                           ms_iterations=(time.perf_counter() - t_loop) * 1e3)
 
     def sssp(self, in_weights, source, max_niter=None, out_weights=None, outbox_pairs=65536, rounds_per_launch=1):
         """algorithm::sssp (graphblas/algorithm/sssp.hpp:53-90) on the 1-D partition, as synchronous rounds:
