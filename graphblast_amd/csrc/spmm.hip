@@ -133,6 +133,10 @@ __global__ void spmm_empty_kernel(T* C, long long total) {
 // section 3): A lane l -> A[i = l & 15][kk = l >> 4], B lane l -> B[kk = l >> 4][j = l & 15],
 // D reg q of lane l -> D[row = 4 (l >> 4) + q][col = l & 15].  Tiles are stored transposed
 // ([kk][i]) so that the A operand of a K step is one coalesced 256-byte read.
+// Restriction (why the path is opt-in, GRB_SPMM_CORE): a stored tile is dense, so the matrix core multiplies the
+// tile's explicit zeros with rows of B -- finite B only (0 x Inf = NaN would reach core rows that have no entry in
+// that column; the CSR tile kernel never forms such products), and duplicate entries of one cell were summed when
+// the tiles were built, so the result can differ from the other path by more than rounding in those two cases.
 __global__ __launch_bounds__(kBlock) void spmm_core_kernel(const int* __restrict__ trow_ptr, const int* __restrict__ tcol,
                                                            const float* __restrict__ tvals,
                                                            const Index* __restrict__ core_rows,
