@@ -121,8 +121,13 @@ extern "C" grb_info grb_bfs_fused(grb_vector v, grb_matrix A, grb_index source, 
     Index p_nf = 0;
     bool p_cap = false;
     float p_ms = 0.f;
-    const grb_info pi = bfs_persistent_run(v, A, source, desc, profile, levels_out, max_levels, &p_levels, &p_dir,
-                                           &p_reached, &p_edges, &p_nf, &p_cap, &p_ms);
+    // a road network (few entries per row, thousands of levels): the levels from queues (sssp_nearfar.hip) -- unless
+    // per-level records were asked for, which only the bitmap kernel keeps
+    grb_info pi = GRB_NOT_IMPLEMENTED;
+    if (profile == 0 && !levels_out) pi = bfs_queue_run(v, A, source, desc, &p_levels, &p_reached, &p_edges, &p_ms);
+    if (pi != GRB_SUCCESS)
+      pi = bfs_persistent_run(v, A, source, desc, profile, levels_out, max_levels, &p_levels, &p_dir,
+                              &p_reached, &p_edges, &p_nf, &p_cap, &p_ms);
     if (pi == GRB_PANIC) ++persistent_failures; else persistent_failures = 0;
     if (pi == GRB_PANIC || pi == GRB_NOT_IMPLEMENTED) {
       // the one-launch traversal could not run to its end here (launch refused, or its grid barrier gave up

@@ -622,7 +622,9 @@ int sssp_nearfar_setting(int set, bool apply);   // sssp_nearfar.hip
 int sssp_last_order(int set);                    // set < 0 queries
 void sssp_last_work(long long* out3);            // near / far: vertices expanded, out-edges relaxed, vertices marked, all passes
 grb_info sssp_nearfar_run(grb_vector v, grb_matrix A, grb_index source, grb_descriptor desc, int* iterations,
-                          double* succ, float* tight_ms, int* passes);   // sssp_nearfar.hip
+                          double* succ, float* tight_ms, int* passes);
+grb_info bfs_queue_run(grb_vector v, grb_matrix A, grb_index source, grb_descriptor desc, int* levels,
+                       long long* reached, unsigned long long* edges, float* tight_ms);   // sssp_nearfar.hip
 grb_info k_spmv_masked_or(int dtype, const CsrArrays& M, const void* u, double identity,
                           const void* mask, int mask_f32, int scmp, int earlyexit, int opreuse,
                           const Index* hint /* per-row best neighbour, may be null */, void* w);

@@ -284,6 +284,7 @@ struct NfqState {                   // zeroed by the host before every launch
   unsigned int maxhops[32];
   unsigned int maxdist[32];
   u64 work[4][16];                  // all passes: entries expanded, out-edges relaxed, entries written
+  u64 tally[2][16];                 // as a traversal: vertices reached, their out-degrees
 };
 
 struct NfqArgs {
@@ -301,6 +302,8 @@ struct NfqArgs {
   int seq;
   float ticks_to_ms;
   int max_passes;
+  int unit;                         // every weight is 1 (the value array is not read): the passes are BFS levels
+  int as_bfs;                       // the result is algorithm::bfs's: depth labels (source 1, unreached 0), reached / edge totals
 };
 
 constexpr int kNfqSlots = 16;       // queue entries a wave takes per step
@@ -434,7 +437,7 @@ __global__ __launch_bounds__(kPThreads) void sssp_nfq_kernel(NfqArgs a) {
     NfqEntry entry = {0ull, 0ull};
     if (act) {
       const Index t = a.oind[p];
-      const float dn = du + a.oval[p];
+      const float dn = du + (a.unit ? 1.f : a.oval[p]);
       const u64 nk = nf_key(dn, hu + 1u);
       // the target's row bounds travel with its entry: asked for beside the atomic, not after it
       const Index ts = a.optr[t], te = a.optr[t + 1];
@@ -502,7 +505,7 @@ __global__ __launch_bounds__(kPThreads) void sssp_nfq_kernel(NfqArgs a) {
       Index t0 = 0;
       float w0 = 0.f;
       const bool first = !wide && s + sub < e;
-      if (first) { t0 = a.oind[s + sub]; w0 = a.oval[s + sub]; }
+      if (first) { t0 = a.oind[s + sub]; w0 = a.unit ? 1.f : a.oval[s + sub]; }
       const bool live = e > s && (unsigned int)(key >> 32) == (unsigned int)(entry.vd >> 32);   // else: lowered since, and queued again then
       const unsigned int hu = (unsigned int)key;
       if (live && sub == 0) { ++my_expanded; my_relaxed += (u64)(e - s); }
@@ -540,11 +543,18 @@ __global__ __launch_bounds__(kPThreads) void sssp_nfq_kernel(NfqArgs a) {
 
   // ---- distances out, and the largest hop count of a reached vertex (the reference's round count - 1)
   unsigned int mh = 0, md = 0;
+  u64 n_reached = 0, n_edges = 0;
   if (converged)
     for (long long i = gtid; i < a.n; i += gthreads) {
       const u64 key = fresh(&a.K[i]);
-      a.D[i] = __uint_as_float((unsigned int)(key >> 32));
       const unsigned int h = (unsigned int)key;
+      const float d = __uint_as_float((unsigned int)(key >> 32));
+      if (a.as_bfs) {
+        a.D[i] = h != 0xffffffffu ? d + 1.f : 0.f;          // depth labels: the source is 1, unreached vertices 0
+        if (h != 0xffffffffu) { ++n_reached; n_edges += (u64)(a.optr[i + 1] - a.optr[i]); }
+      } else {
+        a.D[i] = d;
+      }
       if (h != 0xffffffffu) {
         mh = h > mh ? h : mh;
         md = (unsigned int)(key >> 32) > md ? (unsigned int)(key >> 32) : md;
@@ -555,23 +565,28 @@ __global__ __launch_bounds__(kPThreads) void sssp_nfq_kernel(NfqArgs a) {
   mh = wave_reduce(mh, umax);
   md = wave_reduce(md, umax);
   const u64 w0 = wave_reduce(my_expanded, add), w1 = wave_reduce(my_relaxed, add), w2 = wave_reduce(my_queued, add);
+  const u64 r0 = a.as_bfs ? wave_reduce(n_reached, add) : 0ull, r1 = a.as_bfs ? wave_reduce(n_edges, add) : 0ull;
   if (lane == 0) {
     if (mh) atomicMax(&st->maxhops[0], mh);
     if (md) atomicMax(&st->maxdist[0], md);
     if (w0) __hip_atomic_fetch_add(&st->work[0][0], w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (w1) __hip_atomic_fetch_add(&st->work[1][0], w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (w2) __hip_atomic_fetch_add(&st->work[2][0], w2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (r0) __hip_atomic_fetch_add(&st->tally[0][0], r0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (r1) __hip_atomic_fetch_add(&st->tally[1][0], r1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   unsigned int unused;
   if (!nfq_sync(st, bidx++, &unused)) return;
   if (gtid == 0) {
     const u64 tag = (u64)(unsigned int)a.seq << 32;
     const float ms = (float)(wall_clock64() - t_start) * a.ticks_to_ms;
-    const u64 c0 = fresh(&st->work[0][0]), c1 = fresh(&st->work[1][0]), c2 = fresh(&st->work[2][0]);
+    u64 c0 = fresh(&st->work[0][0]), c1 = fresh(&st->work[1][0]) >> 4;
+    const u64 c2 = fresh(&st->work[2][0]);
+    if (a.as_bfs) { c0 = fresh(&st->tally[0][0]); c1 = fresh(&st->tally[1][0]); }     // (an edge total fits: nnz < 2^31)
     const unsigned int how = converged ? 1u : fresh(&st->stop[0]) == 2u ? 2u : 0u;     // 2: a list was full
     const unsigned int vals[8] = {fresh(&st->maxhops[0]), (unsigned int)pass, __float_as_uint(ms), how,
                                   fresh(&st->maxdist[0]), (unsigned int)(c0 > 0xffffffffull ? 0xffffffffull : c0),
-                                  (unsigned int)(c1 >> 4 > 0xffffffffull ? 0xffffffffull : c1 >> 4),
+                                  (unsigned int)(c1 > 0xffffffffull ? 0xffffffffull : c1),
                                   (unsigned int)(c2 > 0xffffffffull ? 0xffffffffull : c2)};
 #pragma unroll
     for (int k = 0; k < 8; ++k)
@@ -732,6 +747,8 @@ grb_info grb::sssp_nearfar_run(grb_vector v, grb_matrix A, grb_index source, grb
     a.seq = seq = ++c.mail_seq;
     a.ticks_to_ms = ticks_to_ms;
     a.max_passes = max_passes;
+    a.unit = 0;
+    a.as_bfs = 0;
     GRB_HIP_TRY(hipMemsetAsync(p_zero, 0, st_bytes, s));
     hipLaunchKernelGGL(nf_init_kernel, dim3(stream_grid(n, kBlock)), dim3(kBlock), 0, s, a.K, n, (Index)source);
     hipLaunchKernelGGL(nfq_seed_kernel, dim3(1), dim3(64), 0, s, a.qn[1], a.st, (Index)source, a.optr);
@@ -789,5 +806,78 @@ grb_info grb::sssp_nearfar_run(grb_vector v, grb_matrix A, grb_index source, grb
   g_last_work[0] = (long long)gv[5];                    // vertices expanded, out-edges relaxed, vertices made dirty: all passes
   g_last_work[1] = (long long)gv[6] << 4;
   g_last_work[2] = (long long)gv[7];
+  return GRB_SUCCESS;
+}
+
+// algorithm::bfs on a long-diameter, low-degree graph (a road network) through the same queues: with every weight 1
+// a pass IS a level, a vertex is queued exactly once, and a level of a few thousand vertices costs the 7.6 us of a
+// pass instead of the 26-31 us the bitmap kernel of bfs_persist.hip pays for walking and recycling 3 MB of bitmap
+// (4896^2 grid, 8 134 levels: 215 -> see DESIGN.md 5.0).  GRB_SUCCESS: v holds the depth labels (source 1, unreached
+// 0) and the totals are the one-launch traversal's; GRB_NOT_IMPLEMENTED: not this kind of graph / call, or the
+// traversal would have been cut off by max_niter -- the caller runs the bitmap kernel.
+grb_info grb::bfs_queue_run(grb_vector v, grb_matrix A, grb_index source, grb_descriptor desc, int* levels,
+                            long long* reached, unsigned long long* edges, float* tight_ms) {
+  static const int use = getenv("GRB_BFS_QUEUE") ? atoi(getenv("GRB_BFS_QUEUE")) : -1;   // -1 auto, 0 never, 1 whenever possible
+  if (use == 0 || g_barrier_failures >= 3) return GRB_NOT_IMPLEMENTED;
+  const Index n = A->nrows;
+  if (use < 0 && !(A->nvals < 8ll * (long long)n && n >= (1 << 16))) return GRB_NOT_IMPLEMENTED;
+  if (desc->desc[GRB_MXVMODE] == GRB_PULLONLY) return GRB_NOT_IMPLEMENTED;
+  Context& c = ctx();
+  hipStream_t s = c.stream;
+  static int max_per_cu = 0;
+  if (!max_per_cu) {
+    GRB_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&max_per_cu, sssp_nfq_kernel, kPThreads, 0));
+    if (max_per_cu < 1) return GRB_NOT_IMPLEMENTED;
+  }
+  static float ticks_to_ms = 0.f;
+  if (ticks_to_ms == 0.f) {
+    int khz = 0, dev = 0;
+    GRB_HIP_TRY(hipGetDevice(&dev));
+    GRB_HIP_TRY(hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev));
+    ticks_to_ms = khz > 0 ? 1.0f / (float)khz : 1e-5f;
+  }
+  const size_t st_bytes = (sizeof(NfqState) + 255) & ~(size_t)255;
+  const size_t near_cap = (size_t)n + 64, far_cap = 64;   // a vertex is queued once (its first key is its last); nothing is far
+  void *p_zero, *p_k, *p_q;
+  c.bfs_prezero_ptr = nullptr;              // slot 7 is about to be overwritten
+  GRB_TRY(scratch(7, st_bytes, &p_zero));
+  GRB_TRY(scratch(8, 8 * (size_t)n + 8, &p_k));
+  GRB_TRY(scratch(11, sizeof(NfqEntry) * (2 * near_cap + 2 * far_cap), &p_q));
+  NfqArgs a;
+  a.optr = A->csr.ptr; a.oind = A->csr.ind; a.oval = nullptr;
+  a.n = n;
+  a.delta = FLT_MAX;                        // every distance is near: no far pile, no threshold
+  a.K = (u64*)p_k;
+  a.st = (NfqState*)p_zero;
+  a.qn[0] = (NfqEntry*)p_q; a.qn[1] = a.qn[0] + near_cap;
+  a.qf[0] = a.qn[1] + near_cap; a.qf[1] = a.qf[0] + far_cap;
+  a.near_cap = (unsigned int)near_cap; a.far_cap = (unsigned int)far_cap;
+  a.D = (float*)v->d_val;
+  a.mail = c.d_hgran;
+  a.seq = ++c.mail_seq;
+  a.ticks_to_ms = ticks_to_ms;
+  const long long pass_cap = (long long)n + 1024;
+  a.max_passes = pass_cap > 0x7fffff00ll ? 0x7fffff00 : (int)pass_cap;
+  a.unit = 1;
+  a.as_bfs = 1;
+  GRB_HIP_TRY(hipMemsetAsync(p_zero, 0, st_bytes, s));
+  hipLaunchKernelGGL(nf_init_kernel, dim3(stream_grid(n, kBlock)), dim3(kBlock), 0, s, a.K, n, (Index)source);
+  hipLaunchKernelGGL(nfq_seed_kernel, dim3(1), dim3(64), 0, s, a.qn[1], a.st, (Index)source, a.optr);
+  GRB_HIP_TRY(hipGetLastError());
+  hipLaunchKernelGGL(sssp_nfq_kernel, dim3(c.num_cu), dim3(kPThreads), 0, s, a);
+  GRB_HIP_TRY(hipGetLastError());
+  unsigned int gv[8];
+  if (wait_granules(a.seq, 8, gv) != GRB_SUCCESS) {
+    ++g_barrier_failures;
+    return GRB_NOT_IMPLEMENTED;
+  }
+  g_barrier_failures = 0;
+  if (gv[3] != 1u) return GRB_NOT_IMPLEMENTED;
+  const long long lv = (long long)gv[0] + 1;            // the level that finds nothing is counted, as the loop counts it
+  if (lv > (long long)desc->max_niter) return GRB_NOT_IMPLEMENTED;   // it would have been cut off: the exact loop runs
+  *levels = (int)lv;
+  *reached = (long long)gv[5];
+  *edges = (unsigned long long)gv[6];
+  memcpy(tight_ms, &gv[2], 4);
   return GRB_SUCCESS;
 }

@@ -141,3 +141,41 @@ def test_bitmap_form_and_the_fallback_when_a_list_is_full(env):
     assert r["same"] and r["it"][0] == r["it"][1]
     assert r["order"][0] == 0 and r["order"][1] >= 1     # near / far in every case: the fallback is its bitmap form, not the rounds
     assert r["work"][0] > 0
+
+
+def test_bfs_on_a_road_like_graph_takes_the_queues_and_equals_the_bitmap_kernel():
+    """algorithm::bfs on a long-diameter, low-degree graph runs its levels from queues (bfs_queue_run); labels, levels,
+    reached and edge totals must be the one-launch bitmap kernel's (which a request for per-level records selects),
+    and a max_niter that would cut the loop short must hand the call to the exact loop"""
+    import torch
+    import graphblast_amd as g
+    from graphblast_amd.graphgen import grid_edges, finalize_edges
+    dev = torch.device("cuda", 0)
+    es, ed, n = grid_edges(400, keep=0.7, seed=11)
+    gg = finalize_edges(torch.as_tensor(es).to(dev), torch.as_tensor(ed).to(dev), n, symmetrize=True)
+    ptr, ind = gg["csr"]
+    val = torch.ones(gg["nnz"], dtype=torch.float32, device=dev)
+    A = g.Matrix(n, n)
+    assert A.build_device_csr(ptr.data_ptr(), ind.data_ptr(), val.data_ptr(), gg["nnz"], ptr.data_ptr(), ind.data_ptr(),
+                              val.data_ptr(), keep=(ptr, ind, val)) == 0
+    deg = (ptr[1:] - ptr[:-1]).cpu().numpy()
+    d = g.Descriptor()
+    assert d.loadArgs(mxvmode=0, struconly=1, opreuse=1, earlyexit=1) == 0
+    v = g.Vector(n)
+    for src in (int(np.nonzero(deg)[0][0]), int(np.nonzero(deg)[0][len(np.nonzero(deg)[0]) // 2])):
+        info, rq = g.bfs(v, A, src, d, fused=True)                    # the queues (n >= 65536, < 8 entries per row)
+        assert info == 0
+        lq = v.extractTuples()[1].copy()
+        info, rb = g.bfs(v, A, src, d, fused=True, profile=1)         # per-level records: the bitmap kernel
+        assert info == 0
+        lb = v.extractTuples()[1].copy()
+        assert np.array_equal(lq, lb)
+        assert rq["levels"] == rb["levels"] and rq["reached"] == rb["reached"] and rq["edges_traversed"] == rb["edges_traversed"]
+        assert rq["levels"] > 300 and (lq == 0).sum() > 0             # long diameter; thinned grids leave unreachable vertices
+        # cut short: labels and totals of the capped loop, from whichever kernel
+        dc = g.Descriptor()
+        assert dc.loadArgs(mxvmode=0, struconly=1, opreuse=1, earlyexit=1, max_niter=50) == 0
+        info, rc = g.bfs(v, A, src, dc, fused=True)
+        lc = v.extractTuples()[1].copy()
+        info, rc2 = g.bfs(v, A, src, dc, fused=True, profile=1)
+        assert np.array_equal(lc, v.extractTuples()[1]) and rc["levels"] == rc2["levels"] and rc["reached"] == rc2["reached"]
