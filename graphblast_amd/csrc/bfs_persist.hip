@@ -38,13 +38,11 @@ constexpr int kPullGroup = 16;    // lanes finishing one undecided row in the pu
 constexpr int kMedCap = 4096;     // LDS list of medium vertices per workgroup pass
 constexpr int kKeep = 32;         // levels whose discovered-bitmaps are kept for the final label pass
 constexpr int kOcWords = 8192;    // owner-computes push: visited words a workgroup owns at most (32 KiB of LDS)
-constexpr int kOcMaxBuckets = 512;
 
 struct PersistState {               // zeroed by the host before every launch
   GridBarrier bar;
   unsigned big_count[2][32];
   unsigned long long acc[3][8][16]; // level totals, one line per (set, XCD group): found, deg, inspected, big
-  unsigned oc_cursor[2][kOcMaxBuckets];   // owner-computes push: entries appended to each destination bucket
 };
 
 struct PersistArgs {
@@ -69,11 +67,16 @@ struct PersistArgs {
   unsigned int* F[kKeep + 3];
   int2* big_list;
   int big_cap;
-  // owner-computes push for heavy sparse frontiers (nullptr: off).  The vertices are cut into oc_nb ranges of
-  // 2^oc_shift; range b's edges are appended to oc_arena[iptr[b << oc_shift] ...) -- it cannot overflow: a range
-  // receives at most its in-degree sum -- and settled by workgroup b against its slice of the visited bitmap in LDS.
-  Index* oc_arena;
-  int oc_shift, oc_nb;
+  // owner-computes push for heavy sparse frontiers (oc_off == nullptr: off).  The vertices are cut into oc_nb ranges
+  // [oc_bounds[b], oc_bounds[b + 1]) of about equal in-edge mass (word-aligned, at most kOcWords words); a row of
+  // >= kBigDeg entries is sorted, so its entries inside a range are one piece, oc_off[b * oc_nrows + r] ..
+  // oc_off[(b + 1) * oc_nrows + r) for big row number r = oc_bigidx[v] (precomputed once per matrix).  The
+  // workgroup that owns a range ORs the pieces of all big frontier vertices into its slice of the visited bitmap
+  // in LDS: no edge is written anywhere, no global atomic per edge.
+  const Index* oc_bounds;
+  const Index* oc_off;
+  const int* oc_bigidx;
+  int oc_nb, oc_nrows;
   unsigned long long oc_min_edges;
   PersistState* st;
   grb_bfs_level* rec;
@@ -120,7 +123,6 @@ __global__ __launch_bounds__(kPThreads) void bfs_persistent_kernel(PersistArgs a
   __shared__ unsigned short s_leftid[kPWaves][kPullBlock * kWave / 2];
   __shared__ unsigned int s_leftfound[kPWaves][2 * kPullBlock];
   __shared__ unsigned int s_ocw[kOcWords];
-  __shared__ int s_occnt[kOcMaxBuckets], s_ocbase[kOcMaxBuckets], s_ocreg[kOcMaxBuckets];
   const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
   const int G = gridDim.x;
   const long long gtid = (long long)blockIdx.x * kPThreads + tid;
@@ -178,11 +180,10 @@ __global__ __launch_bounds__(kPThreads) void bfs_persistent_kernel(PersistArgs a
       for (long long i = gtid; i < nwords; i += gthreads) publish(&a.F[fbuf(iter + 1)][i], 0u);
     if (gtid == 0) publish(&st->big_count[(iter + 1) & 1][0], 0u);
     if (blockIdx.x == 0 && tid < 32) publish(&st->acc[(iter + 1) % 3][tid >> 2][tid & 3], 0ull);
-    if (blockIdx.x == 0 && tid < kOcMaxBuckets) publish(&st->oc_cursor[(iter + 1) & 1][tid], 0u);
     // A push level whose frontier carries many edges through few vertices runs at the rate of racing global
     // atomics (two per discovery, most attempts losers).  Such a level buckets its big vertices' edges by
     // destination range instead and lets the range's owner settle them in LDS: no global atomics at all.
-    const bool heavy = !f1_dense && iter > 1 && a.oc_arena != nullptr && nbig > 0 && mf >= a.oc_min_edges;
+    const bool heavy = !f1_dense && iter > 1 && a.oc_off != nullptr && nbig > 0 && mf >= a.oc_min_edges;
 
     if (!f1_dense) {
       // ================= push =================
@@ -205,7 +206,7 @@ __global__ __launch_bounds__(kPThreads) void bfs_persistent_kernel(PersistArgs a
             for (unsigned int t = w; t; t &= t - 1) {
               const Index v = (Index)i * 32 + (__ffs((int)t) - 1);
               const Index d = a.optr[v + 1] - a.optr[v];
-              if (d >= kBigDeg) mine += (d + kBigChunk - 1) / kBigChunk;
+              if (d >= kBigDeg) mine += heavy ? 1 : (d + kBigChunk - 1) / kBigChunk;
             }
             int incl = mine;
 #pragma unroll
@@ -223,7 +224,7 @@ __global__ __launch_bounds__(kPThreads) void bfs_persistent_kernel(PersistArgs a
                 const Index v = (Index)i * 32 + (__ffs((int)t) - 1);
                 const Index d = a.optr[v + 1] - a.optr[v];
                 if (d >= kBigDeg)
-                  for (int k = 0; k < (d + kBigChunk - 1) / kBigChunk; ++k, ++at)
+                  for (int k = 0; k < (heavy ? 1 : (d + kBigChunk - 1) / kBigChunk); ++k, ++at)
                     if (at < a.big_cap) publish(reinterpret_cast<unsigned long long*>(&a.big_list[at]),
                                                 ((unsigned long long)(unsigned)k << 32) | (unsigned)v);
               }
@@ -242,45 +243,76 @@ __global__ __launch_bounds__(kPThreads) void bfs_persistent_kernel(PersistArgs a
               if (p < a.optr[ent.x + 1]) push_visit(a, V, Fn, a.oind[p], new_label, c);
             }
           } else {
-            // ---- owner-computes, pass 1: the entries' destinations go to their range's bucket.  Four entries
-            // (4096 edges) per step: ranks from LDS counters, ONE global atomic per non-empty bucket and step
-            // to reserve the space, write-through stores into the arena.
-            for (int b = tid; b < a.oc_nb; b += kPThreads) {
-              const long long v0 = (long long)b << a.oc_shift;
-              s_ocreg[b] = a.iptr[v0 < (long long)n ? v0 : (long long)n];
-              s_occnt[b] = 0;
-            }
-            __syncthreads();
-            unsigned* cursor = &st->oc_cursor[iter & 1][0];
-            for (int e0 = blockIdx.x * 4; e0 < nent; e0 += G * 4) {
-              Index dst[4];
-              int rank[4];
-#pragma unroll
-              for (int j = 0; j < 4; ++j) {
-                const int e = e0 + j;
-                dst[j] = -1;
+            // ---- owner-computes: this workgroup's ranges, one after the other.  The pieces of a wave's 64 list
+            // entries are laid end to end and dealt to the lanes 256 edges at a time (prefix sums in the LDS the
+            // pull levels use for their leftovers), so a step costs one chain of memory latencies whatever the
+            // piece lengths are; the range's new bits go out with one atomicOr per changed word -- the other
+            // workgroups push the small vertices of the frontier with atomics meanwhile.
+            for (int b = blockIdx.x; b < a.oc_nb; b += G) {
+              const Index v0 = a.oc_bounds[b];
+              const int w0 = (int)(v0 >> 5);
+              int nw = (int)((a.oc_bounds[b + 1] - v0 + 31) >> 5);
+              if (w0 + nw > nwords) nw = nwords - w0;
+              __syncthreads();
+              for (int i = tid; i < nw; i += kPThreads) s_ocw[i] = 0u;
+              __syncthreads();
+              for (int e0 = 0; e0 < nent; e0 += kPThreads) {
+                const int e = e0 + tid;
+                Index o0 = 0, o1 = 0;
                 if (e < nent) {
-                  const unsigned long long eb = fresh(reinterpret_cast<const unsigned long long*>(&a.big_list[e]));
-                  const Index u = (Index)(eb & 0xffffffffull);
-                  const Index p = a.optr[u] + (Index)(eb >> 32) * kBigChunk + tid;
-                  if (p < a.optr[u + 1]) dst[j] = a.oind[p];
+                  const Index u = (Index)(fresh(reinterpret_cast<const unsigned long long*>(&a.big_list[e])) & 0xffffffffull);
+                  const int r = a.oc_bigidx[u];
+                  o0 = a.oc_off[(size_t)b * a.oc_nrows + r];
+                  o1 = a.oc_off[(size_t)(b + 1) * a.oc_nrows + r];
+                }
+                const Index len = o1 - o0;
+                Index inc = len;
+#pragma unroll
+                for (int o = 1; o < kWave; o <<= 1) {
+                  const Index y = __shfl_up(inc, o, kWave);
+                  if (lane >= o) inc += y;
+                }
+                const Index total = __shfl(inc, kWave - 1, kWave);
+                if (total == 0) continue;
+                __builtin_amdgcn_wave_barrier();
+                s_left[wave][lane] = make_int2(inc - len, o0);
+                __builtin_amdgcn_wave_barrier();
+                for (Index at0 = 0; at0 < total; at0 += 4 * kWave) {
+                  Index q[4];
+#pragma unroll
+                  for (int j = 0; j < 4; ++j) {
+                    const Index at = at0 + j * kWave + lane;
+                    q[j] = -1;
+                    if (at < total) {
+                      int r = 0;                           // the last entry whose first edge is <= at
+#pragma unroll
+                      for (int step = kWave / 2; step > 0; step >>= 1)
+                        if (s_left[wave][r + step].x <= at) r += step;
+                      q[j] = s_left[wave][r].y + (at - s_left[wave][r].x);
+                    }
+                  }
+                  Index d[4];
+#pragma unroll
+                  for (int j = 0; j < 4; ++j) d[j] = q[j] >= 0 ? a.oind[q[j]] : -1;
+#pragma unroll
+                  for (int j = 0; j < 4; ++j)
+                    if (d[j] >= 0) atomicOr(&s_ocw[(d[j] >> 5) - w0], 1u << (d[j] & 31));
+                }
+                __builtin_amdgcn_wave_barrier();
+              }
+              __syncthreads();
+              for (int i = tid; i < nw; i += kPThreads) {
+                const unsigned int acc = s_ocw[i];
+                if (!acc) continue;
+                unsigned int newb = acc & ~fresh(&V[w0 + i]);
+                if (!newb) continue;
+                newb &= ~atomicOr(&V[w0 + i], newb);
+                if (newb) {
+                  atomicOr(&Fn[w0 + i], newb);
+                  for (; newb; newb &= newb - 1)
+                    discovered(a, (Index)((w0 + i) * 32) + (__ffs((int)newb) - 1), new_label, c);
                 }
               }
-#pragma unroll
-              for (int j = 0; j < 4; ++j) rank[j] = dst[j] >= 0 ? atomicAdd(&s_occnt[dst[j] >> a.oc_shift], 1) : 0;
-              __syncthreads();
-              for (int b = tid; b < a.oc_nb; b += kPThreads) {
-                const int cnt = s_occnt[b];
-                s_ocbase[b] = cnt ? (int)atomicAdd(&cursor[b], (unsigned)cnt) : 0;
-                s_occnt[b] = 0;
-              }
-              __syncthreads();
-#pragma unroll
-              for (int j = 0; j < 4; ++j)
-                if (dst[j] >= 0) {
-                  const int b = dst[j] >> a.oc_shift;
-                  publish(&a.oc_arena[(size_t)s_ocreg[b] + (size_t)(s_ocbase[b] + rank[j])], dst[j]);
-                }
             }
           }
         }
@@ -312,46 +344,6 @@ __global__ __launch_bounds__(kPThreads) void bfs_persistent_kernel(PersistArgs a
           __syncthreads();
           if (tid == 0) s_nmed = 0;
           __syncthreads();
-        }
-        if (heavy) {
-          // ---- owner-computes, pass 2 (every atomic of this level has landed after the barrier): workgroup b
-          // settles bucket b against its slice of the visited bitmap in LDS, writes the slice and the level's
-          // new-bits back with plain (write-through) stores and accounts for what it discovered
-          if (!grid_sync(&st->bar, gen, false)) return;
-          const int b = blockIdx.x;
-          if (b < a.oc_nb) {
-            const long long v0 = (long long)b << a.oc_shift;
-            const long long w0 = v0 >> 5;
-            long long nw = (1ll << a.oc_shift) >> 5;
-            if (w0 + nw > nwords) nw = nwords - w0;
-            for (int i = tid; i < nw; i += kPThreads) s_ocw[i] = fresh(&V[w0 + i]);
-            __syncthreads();
-            const unsigned cnt = fresh(&st->oc_cursor[iter & 1][b]);
-            const Index* reg = a.oc_arena + a.iptr[v0 < (long long)n ? v0 : (long long)n];
-            for (unsigned i0 = 0; i0 < cnt; i0 += 4 * kPThreads) {
-              Index d[4];
-#pragma unroll
-              for (int j = 0; j < 4; ++j) {
-                const unsigned i = i0 + j * kPThreads + tid;
-                d[j] = i < cnt ? fresh(&reg[i]) : -1;
-              }
-#pragma unroll
-              for (int j = 0; j < 4; ++j)
-                if (d[j] >= 0) atomicOr(&s_ocw[(d[j] - (Index)v0) >> 5], 1u << (d[j] & 31));
-            }
-            __syncthreads();
-            for (int i = tid; i < nw; i += kPThreads) {
-              const unsigned int old = fresh(&V[w0 + i]);
-              const unsigned int now = s_ocw[i];
-              unsigned int newb = now & ~old;
-              if (newb) {
-                publish(&V[w0 + i], now);
-                publish(&Fn[w0 + i], fresh(&Fn[w0 + i]) | newb);
-                for (; newb; newb &= newb - 1)
-                  discovered(a, (Index)((w0 + i) * 32) + (__ffs((int)newb) - 1), new_label, c);
-              }
-            }
-          }
         }
       }
       last_dir = 0;
@@ -646,6 +638,23 @@ __global__ __launch_bounds__(kPThreads) void bfs_persistent_kernel(PersistArgs a
   }
 }
 
+// where big row rows[r] enters range b: off[b * nrows + r] = the first entry of the row with a destination >= bounds[b]
+__global__ void oc_range_off_kernel(const Index* __restrict__ optr, const Index* __restrict__ oind, const Index* __restrict__ rows,
+                                    int nrows, int R, const Index* __restrict__ bounds, Index* __restrict__ off) {
+  const long long total = (long long)nrows * (R + 1);
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int b = (int)(i / nrows), r = (int)(i % nrows);
+    const Index u = rows[r];
+    Index lo = optr[u], hi = optr[u + 1];
+    const Index key = bounds[b];
+    while (lo < hi) {
+      const Index mid = lo + (hi - lo) / 2;
+      if (oind[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    off[i] = lo;
+  }
+}
+
 }  // namespace grb
 
 using namespace grb;
@@ -708,20 +717,64 @@ grb_info bfs_persistent_run(grb_vector v, grb_matrix A, grb_index source, grb_de
   for (int L = 0; L < kKeep + 3; ++L) a.F[L] = p_v0 + (size_t)(1 + L) * (size_t)nwords;
   a.big_list = (int2*)p_big;
   a.big_cap = big_cap;
-  // owner-computes push: ranges of 2^shift vertices, one per workgroup (at most kOcWords visited words each);
-  // the arena is nnz entries: range b appends into the slots of its own in-edges
-  a.oc_arena = nullptr; a.oc_shift = 0; a.oc_nb = 0; a.oc_min_edges = ~0ull;
+  // owner-computes push: the tables are made once per matrix (ranges of equal in-edge mass, at most kOcWords words
+  // wide, about two per workgroup; the big rows; where each big row enters each range)
+  a.oc_bounds = nullptr; a.oc_off = nullptr; a.oc_bigidx = nullptr; a.oc_nb = 0; a.oc_nrows = 0; a.oc_min_edges = ~0ull;
   {
     const char* e = getenv("GRB_BFS_OC_MIN");              // frontier out-edges from which a push level uses it; 0 = off
     const long long oc_min = e ? atoll(e) : 262144;
-    int shift = 5;
-    while (((long long)1 << shift) * G < (long long)n) ++shift;
-    const int nb = (int)(((long long)n + ((long long)1 << shift) - 1) >> shift);
-    if (oc_min > 0 && (1 << shift) <= kOcWords * 32 && nb <= kOcMaxBuckets && nb <= G && A->nvals > 0) {
-      if (!A->d_oc_arena) GRB_HIP_TRY(hipMalloc((void**)&A->d_oc_arena, sizeof(Index) * (size_t)A->nvals));
-      a.oc_arena = A->d_oc_arena;
-      a.oc_shift = shift;
-      a.oc_nb = nb;
+    if (oc_min > 0 && A->oc_state == 0) {
+      A->oc_state = -1;
+      const std::vector<Index>& iptr = A->csc_alias ? A->h_csr_ptr : A->h_csc_ptr;   // (the cut only balances: any prefix works)
+      const std::vector<Index>& optr = A->h_csr_ptr;
+      if ((Index)iptr.size() == n + 1 && (Index)optr.size() == n + 1 && A->nvals > 0) {
+        std::vector<Index> rows;
+        std::vector<int> bigidx((size_t)n, -1);
+        for (Index v = 0; v < n; ++v)
+          if (optr[(size_t)v + 1] - optr[v] >= kBigDeg) { bigidx[v] = (int)rows.size(); rows.push_back(v); }
+        const long long total = (long long)iptr[(size_t)n];
+        const long long target = std::max<long long>(1, total / (1ll * G));
+        std::vector<Index> bounds(1, 0);
+        while (bounds.back() < n && bounds.size() <= 4096) {
+          const Index s0 = bounds.back();
+          Index e1 = (Index)std::min<long long>((long long)n, (long long)s0 + (long long)kOcWords * 32);
+          const Index* cut = std::upper_bound(iptr.data() + s0 + 1, iptr.data() + e1 + 1,
+                                              (Index)std::min<long long>((long long)iptr[s0] + target, 0x7fffffffll));
+          long long e2 = (long long)(cut - iptr.data()) - 1;
+          e2 = (e2 + 31) / 32 * 32;                        // word-aligned, at least one word
+          if (e2 <= s0) e2 = (long long)s0 + 32;
+          if (e2 < e1) e1 = (Index)e2;
+          if (e1 > n) e1 = n;
+          bounds.push_back(e1);
+        }
+        const long long R = (long long)bounds.size() - 1;
+        if (!rows.empty() && bounds.back() == n && R >= 2 && (long long)rows.size() * (R + 1) <= (64ll << 20)) {
+          GRB_HIP_TRY(hipMalloc((void**)&A->d_oc_bounds, sizeof(Index) * bounds.size()));
+          GRB_HIP_TRY(hipMalloc((void**)&A->d_oc_bigidx, sizeof(int) * (size_t)n));
+          GRB_HIP_TRY(hipMalloc((void**)&A->d_oc_off, sizeof(Index) * rows.size() * (size_t)(R + 1)));
+          void* p_rows = nullptr;                          // (one-off: not a scratch slot, those are in use by this call)
+          GRB_HIP_TRY(hipMalloc(&p_rows, sizeof(Index) * rows.size()));
+          GRB_HIP_TRY(hipMemcpyAsync(A->d_oc_bounds, bounds.data(), sizeof(Index) * bounds.size(), hipMemcpyHostToDevice, s));
+          GRB_HIP_TRY(hipMemcpyAsync(A->d_oc_bigidx, bigidx.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice, s));
+          GRB_HIP_TRY(hipMemcpyAsync(p_rows, rows.data(), sizeof(Index) * rows.size(), hipMemcpyHostToDevice, s));
+          hipLaunchKernelGGL(oc_range_off_kernel, dim3(stream_grid((long long)rows.size() * (R + 1), kBlock)), dim3(kBlock), 0, s,
+                             A->csr.ptr, A->csr.ind, (const Index*)p_rows, (int)rows.size(), (int)R, (const Index*)A->d_oc_bounds,
+                             A->d_oc_off);
+          GRB_HIP_TRY(hipGetLastError());
+          GRB_HIP_TRY(hipStreamSynchronize(s));            // the host vectors above go out of scope
+          (void)hipFree(p_rows);
+          A->oc_nb = (int)R;
+          A->oc_nrows = (int)rows.size();
+          A->oc_state = 1;
+        }
+      }
+    }
+    if (oc_min > 0 && A->oc_state == 1) {
+      a.oc_bounds = A->d_oc_bounds;
+      a.oc_off = A->d_oc_off;
+      a.oc_bigidx = A->d_oc_bigidx;
+      a.oc_nb = A->oc_nb;
+      a.oc_nrows = A->oc_nrows;
       a.oc_min_edges = (unsigned long long)oc_min;
     }
   }

@@ -543,7 +543,12 @@ struct grb_matrix_s {
   double mean_value = -1.0;                      // < 0 unknown (sssp_nearfar: the bucket width)
   int small_int_values = -1;                     // -1 unknown, else whether every stored value is an integer in [0, 2^20]
   grb::Index* d_pull_hint = nullptr;                  // per vertex: its in-neighbour of largest out-degree (bfs_fused)
-  grb::Index* d_oc_arena = nullptr;              // bfs_persist.hip: destination buckets of the owner-computes push (nnz entries)
+  // bfs_persist.hip, owner-computes push: destination ranges of equal in-edge mass, the big rows' numbers and where
+  // each big row enters each range ([oc_nb + 1][oc_nrows]); oc_state: 0 not tried, 1 ready, -1 not applicable
+  grb::Index* d_oc_bounds = nullptr;
+  grb::Index* d_oc_off = nullptr;
+  int* d_oc_bigidx = nullptr;
+  int oc_nb = 0, oc_nrows = 0, oc_state = 0;
   grb::BatchSlices batch_in, batch_out;          // bfs_batch.hip, built lazily
   grb::SpmmCore spmm_core_csr, spmm_core_csc;    // spmm.hip, built lazily when GRB_SPMM_CORE is set
 };

@@ -778,7 +778,10 @@ void grb::matrix_release_device(grb_matrix A) {
   if (A->d_no_in_edges) { (void)hipFree(A->d_no_in_edges); A->d_no_in_edges = nullptr; }
   if (A->d_empty_csr_rows) { (void)hipFree(A->d_empty_csr_rows); A->d_empty_csr_rows = nullptr; }
   if (A->d_pull_hint) { (void)hipFree(A->d_pull_hint); A->d_pull_hint = nullptr; }
-  if (A->d_oc_arena) { (void)hipFree(A->d_oc_arena); A->d_oc_arena = nullptr; }
+  if (A->d_oc_bounds) { (void)hipFree(A->d_oc_bounds); A->d_oc_bounds = nullptr; }
+  if (A->d_oc_off) { (void)hipFree(A->d_oc_off); A->d_oc_off = nullptr; }
+  if (A->d_oc_bigidx) { (void)hipFree(A->d_oc_bigidx); A->d_oc_bigidx = nullptr; }
+  A->oc_nb = A->oc_nrows = A->oc_state = 0;
   for (BatchSlices* b : {&A->batch_in, &A->batch_out}) {
     if (b->d_slices) (void)hipFree(b->d_slices);
     if (b->d_rows) (void)hipFree(b->d_rows);
