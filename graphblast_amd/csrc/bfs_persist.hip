@@ -37,6 +37,7 @@ constexpr int kPullBlock = GRB_PULL_BLOCK;    // chunks (of 64 vertices) one wav
 constexpr int kPullGroup = 16;    // lanes finishing one undecided row in the pull phase
 constexpr int kMedCap = 4096;     // LDS list of medium vertices per workgroup pass
 constexpr int kKeep = 32;         // levels whose discovered-bitmaps are kept for the final label pass
+constexpr int kOcBin = 256;        // owner-computes push: the ranges are cut on multiples of this many vertices
 constexpr int kOcWords = 8192;    // owner-computes push: visited words a workgroup owns at most (32 KiB of LDS)
 
 struct PersistState {               // zeroed by the host before every launch
@@ -638,6 +639,18 @@ __global__ __launch_bounds__(kPThreads) void bfs_persistent_kernel(PersistArgs a
   }
 }
 
+// destinations of the big rows' entries, counted in bins of kOcBin vertices (one wave per row)
+__global__ __launch_bounds__(kBlock) void oc_mass_kernel(const Index* __restrict__ optr, const Index* __restrict__ oind,
+                                                         const Index* __restrict__ rows, int nrows, unsigned int* __restrict__ bins) {
+  const int lane = lane_id();
+  const int nwaves = gridDim.x * kWavesPerBlock;
+  for (int r = blockIdx.x * kWavesPerBlock + wave_id(); r < nrows; r += nwaves) {
+    const Index u = rows[r];
+    const Index e = optr[u + 1];
+    for (Index p = optr[u] + lane; p < e; p += kWave) atomicAdd(&bins[oind[p] / kOcBin], 1u);
+  }
+}
+
 // where big row rows[r] enters range b: off[b * nrows + r] = the first entry of the row with a destination >= bounds[b]
 __global__ void oc_range_off_kernel(const Index* __restrict__ optr, const Index* __restrict__ oind, const Index* __restrict__ rows,
                                     int nrows, int R, const Index* __restrict__ bounds, Index* __restrict__ off) {
@@ -725,27 +738,51 @@ grb_info bfs_persistent_run(grb_vector v, grb_matrix A, grb_index source, grb_de
     const long long oc_min = e ? atoll(e) : 262144;
     if (oc_min > 0 && A->oc_state == 0) {
       A->oc_state = -1;
-      const std::vector<Index>& iptr = A->csc_alias ? A->h_csr_ptr : A->h_csc_ptr;   // (the cut only balances: any prefix works)
       const std::vector<Index>& optr = A->h_csr_ptr;
-      if ((Index)iptr.size() == n + 1 && (Index)optr.size() == n + 1 && A->nvals > 0) {
+      if ((Index)optr.size() == n + 1 && A->nvals > 0) {
         std::vector<Index> rows;
         std::vector<int> bigidx((size_t)n, -1);
         for (Index v = 0; v < n; ++v)
           if (optr[(size_t)v + 1] - optr[v] >= kBigDeg) { bigidx[v] = (int)rows.size(); rows.push_back(v); }
-        const long long total = (long long)iptr[(size_t)n];
+        // what a range will receive is edges OUT OF BIG ROWS, and those favour the hub region more than in-edges at
+        // large do (cut by in-edge mass, the hub ranges' owners finished 15 us after the others): the cut follows
+        // the big rows' own destinations, counted on the device in bins of 256 vertices
+        const int nbins = (int)(((long long)n + kOcBin - 1) / kOcBin);
+        std::vector<unsigned int> bins((size_t)nbins, 0u);
+        if (!rows.empty()) {
+          void *p_rows0 = nullptr, *p_bins = nullptr;
+          GRB_HIP_TRY(hipMalloc(&p_rows0, sizeof(Index) * rows.size()));
+          GRB_HIP_TRY(hipMalloc(&p_bins, 4 * (size_t)nbins));
+          GRB_HIP_TRY(hipMemsetAsync(p_bins, 0, 4 * (size_t)nbins, s));
+          GRB_HIP_TRY(hipMemcpyAsync(p_rows0, rows.data(), sizeof(Index) * rows.size(), hipMemcpyHostToDevice, s));
+          hipLaunchKernelGGL(oc_mass_kernel, dim3(stream_grid((long long)rows.size() * kWave, kBlock)), dim3(kBlock), 0, s, A->csr.ptr,
+                             A->csr.ind, (const Index*)p_rows0, (int)rows.size(), (unsigned int*)p_bins);
+          GRB_HIP_TRY(hipGetLastError());
+          GRB_HIP_TRY(hipMemcpyAsync(bins.data(), p_bins, 4 * (size_t)nbins, hipMemcpyDeviceToHost, s));
+          GRB_HIP_TRY(hipStreamSynchronize(s));
+          (void)hipFree(p_rows0);
+          (void)hipFree(p_bins);
+        }
+        long long total = 0;
+        for (unsigned int x : bins) total += (long long)x;
         const long long target = std::max<long long>(1, total / (1ll * G));
         std::vector<Index> bounds(1, 0);
-        while (bounds.back() < n && bounds.size() <= 4096) {
-          const Index s0 = bounds.back();
-          Index e1 = (Index)std::min<long long>((long long)n, (long long)s0 + (long long)kOcWords * 32);
-          const Index* cut = std::upper_bound(iptr.data() + s0 + 1, iptr.data() + e1 + 1,
-                                              (Index)std::min<long long>((long long)iptr[s0] + target, 0x7fffffffll));
-          long long e2 = (long long)(cut - iptr.data()) - 1;
-          e2 = (e2 + 31) / 32 * 32;                        // word-aligned, at least one word
-          if (e2 <= s0) e2 = (long long)s0 + 32;
-          if (e2 < e1) e1 = (Index)e2;
-          if (e1 > n) e1 = n;
-          bounds.push_back(e1);
+        {
+          static const int cap_env = getenv("GRB_BFS_OC_WIDTH") ? atoi(getenv("GRB_BFS_OC_WIDTH")) : 0;   // vertices per range at most
+          int max_bins = kOcWords * 32 / kOcBin;           // a range's slice of the visited bitmap fits the LDS buffer
+          if (cap_env >= kOcBin && cap_env / kOcBin < max_bins) max_bins = cap_env / kOcBin;
+          long long acc = 0;
+          int first = 0;
+          for (int b = 0; b < nbins; ++b) {
+            acc += (long long)bins[(size_t)b];
+            if (acc >= target || b + 1 - first >= max_bins || b + 1 == nbins) {
+              const long long e1 = std::min<long long>((long long)n, (long long)(b + 1) * kOcBin);
+              bounds.push_back((Index)e1);
+              first = b + 1;
+              acc = 0;
+            }
+          }
+          if (bounds.back() != n) bounds.push_back(n);
         }
         const long long R = (long long)bounds.size() - 1;
         if (!rows.empty() && bounds.back() == n && R >= 2 && (long long)rows.size() * (R + 1) <= (64ll << 20)) {
