@@ -86,6 +86,12 @@ struct PartArgs {
   float* label;                     // owned labels
   int2* big_list;
   int big_cap;
+  // owner-computes push (bfs_persist.hip: oc_tables_build) for this rank's big rows; oc_off == nullptr: the big
+  // vertices' edges go out with atomics, 1024 at a time
+  const Index* oc_bounds;
+  const Index* oc_off;
+  const int* oc_bigidx;
+  int oc_nb, oc_nrows;
   PartState* st;
   grb_bfs_level* rec;               // pinned host memory: one record per level
   int rec_cap;
@@ -115,6 +121,7 @@ __global__ __launch_bounds__(kPThreads) void bfs_part_level_kernel(PartArgs a) {
   __shared__ int2 s_left[kPWaves][kPPullBlock * kWave / 2];
   __shared__ unsigned short s_leftid[kPWaves][kPPullBlock * kWave / 2];
   __shared__ unsigned int s_leftfound[kPWaves][2 * kPPullBlock];
+  __shared__ unsigned int s_ocw[kOcWords];
   const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
   const int G = gridDim.x;
   const long long gtid = (long long)blockIdx.x * kPThreads + tid;
@@ -203,7 +210,7 @@ __global__ __launch_bounds__(kPThreads) void bfs_part_level_kernel(PartArgs a) {
           if (owned && count_only) a.label[vtx - a.lo] = 0.f;   // found by the level that ended the loop: never assigned (bfs.hpp:48-66)
           if (owned && !count_only) {
             if (direct) a.label[vtx - a.lo] = lab;
-            if (d >= kPBigDeg) { ++c_big; ent += (d + kPBigChunk - 1) / kPBigChunk; }
+            if (d >= kPBigDeg) { ++c_big; ent += a.oc_off ? 1 : (d + kPBigChunk - 1) / kPBigChunk; }
           }
         }
         if (__ballot(ent > 0)) {                          // the owned big vertices as 1024-edge entries
@@ -223,7 +230,7 @@ __global__ __launch_bounds__(kPThreads) void bfs_part_level_kernel(PartArgs a) {
               const Index vtx = (Index)i * 32 + (__ffs((int)t) - 1);
               const int d = a.deg[vtx];
               if (d >= kPBigDeg)
-                for (int kk = 0; kk < (d + kPBigChunk - 1) / kPBigChunk; ++kk, ++at)
+                for (int kk = 0; kk < (a.oc_off ? 1 : (d + kPBigChunk - 1) / kPBigChunk); ++kk, ++at)
                   if (at < a.big_cap)
                     publish(reinterpret_cast<unsigned long long*>(&a.big_list[at]),
                             ((unsigned long long)(unsigned)kk << 32) | (unsigned)(vtx - a.lo));
@@ -311,11 +318,77 @@ __global__ __launch_bounds__(kPThreads) void bfs_part_level_kernel(PartArgs a) {
         if (cy.nbig > 0) {
           int nent = (int)fresh(&st->big_count[iter & 1][0]);
           if (nent > a.big_cap) nent = a.big_cap;
-          for (int e = blockIdx.x; e < nent; e += G) {
-            const unsigned long long eb = fresh(reinterpret_cast<const unsigned long long*>(&a.big_list[e]));
-            const Index vl = (Index)(eb & 0xffffffffull);
-            const Index p = a.optr[vl] + (Index)(eb >> 32) * kPBigChunk + tid;
-            if (p < a.optr[vl + 1]) part_push_visit(a.V, a.Fn, a.oind[p]);
+          if (!a.oc_off) {
+            for (int e = blockIdx.x; e < nent; e += G) {
+              const unsigned long long eb = fresh(reinterpret_cast<const unsigned long long*>(&a.big_list[e]));
+              const Index vl = (Index)(eb & 0xffffffffull);
+              const Index p = a.optr[vl] + (Index)(eb >> 32) * kPBigChunk + tid;
+              if (p < a.optr[vl + 1]) part_push_visit(a.V, a.Fn, a.oind[p]);
+            }
+          } else {
+            // owner-computes (as bfs_persistent_kernel's heavy levels): this workgroup's destination ranges, the
+            // pieces of every listed big vertex ORed into LDS, one atomicOr per changed word of V / Fn
+            for (int b = blockIdx.x; b < a.oc_nb; b += G) {
+              const Index v0 = a.oc_bounds[b];
+              const int w0 = (int)(v0 >> 5);
+              int nw = (int)((a.oc_bounds[b + 1] - v0 + 31) >> 5);
+              if (w0 + nw > nwords) nw = nwords - w0;
+              __syncthreads();
+              for (int i = tid; i < nw; i += kPThreads) s_ocw[i] = 0u;
+              __syncthreads();
+              for (int e0 = 0; e0 < nent; e0 += kPThreads) {
+                const int e = e0 + tid;
+                Index o0 = 0, o1 = 0;
+                if (e < nent) {
+                  const Index vl = (Index)(fresh(reinterpret_cast<const unsigned long long*>(&a.big_list[e])) & 0xffffffffull);
+                  const int r = a.oc_bigidx[vl];
+                  o0 = a.oc_off[(size_t)b * a.oc_nrows + r];
+                  o1 = a.oc_off[(size_t)(b + 1) * a.oc_nrows + r];
+                }
+                const Index len = o1 - o0;
+                Index inc = len;
+#pragma unroll
+                for (int o = 1; o < kWave; o <<= 1) {
+                  const Index y = __shfl_up(inc, o, kWave);
+                  if (lane >= o) inc += y;
+                }
+                const Index total = __shfl(inc, kWave - 1, kWave);
+                if (total == 0) continue;
+                __builtin_amdgcn_wave_barrier();
+                s_left[wave][lane] = make_int2(inc - len, o0);
+                __builtin_amdgcn_wave_barrier();
+                for (Index at0 = 0; at0 < total; at0 += 4 * kWave) {
+                  Index q[4], d[4];
+#pragma unroll
+                  for (int j = 0; j < 4; ++j) {
+                    const Index at = at0 + j * kWave + lane;
+                    q[j] = -1;
+                    if (at < total) {
+                      int r = 0;                           // the last entry whose first edge is <= at
+#pragma unroll
+                      for (int step = kWave / 2; step > 0; step >>= 1)
+                        if (s_left[wave][r + step].x <= at) r += step;
+                      q[j] = s_left[wave][r].y + (at - s_left[wave][r].x);
+                    }
+                  }
+#pragma unroll
+                  for (int j = 0; j < 4; ++j) d[j] = q[j] >= 0 ? a.oind[q[j]] : -1;
+#pragma unroll
+                  for (int j = 0; j < 4; ++j)
+                    if (d[j] >= 0) atomicOr(&s_ocw[(d[j] >> 5) - w0], 1u << (d[j] & 31));
+                }
+                __builtin_amdgcn_wave_barrier();
+              }
+              __syncthreads();
+              for (int i = tid; i < nw; i += kPThreads) {
+                const unsigned int acc = s_ocw[i];
+                if (!acc) continue;
+                unsigned int newb = acc & ~fresh(&a.V[w0 + i]);
+                if (!newb) continue;
+                newb &= ~atomicOr(&a.V[w0 + i], newb);
+                if (newb) atomicOr(&a.Fn[w0 + i], newb);
+              }
+            }
           }
         }
         if (tid == 0) s_nmed = 0;
@@ -590,6 +663,10 @@ struct grb_part_s {
   unsigned int* d_gathered = nullptr;   // world > 1: the all-gather's receive buffer (world x nwords)
   int2* d_big = nullptr;
   int big_cap = 0;
+  Index* d_oc_bounds = nullptr;       // owner-computes push tables of this rank's out-edge shard (oc_tables_build)
+  Index* d_oc_off = nullptr;
+  int* d_oc_bigidx = nullptr;
+  int oc_nb = 0, oc_nrows = 0;
   grb_bfs_level* h_rec = nullptr;       // pinned; d_rec is its device-side address
   grb_bfs_level* d_rec = nullptr;
   int rec_cap = 1 << 15;
@@ -676,6 +753,8 @@ grb_info part_bfs_run(grb_part* ps, int nranks, grb_index source, int mode, floa
     a.Fn = q.Fn; a.V = q.V; a.F = q.F;
     a.label = labels[r];
     a.big_list = p->d_big; a.big_cap = p->big_cap;
+    a.oc_bounds = p->d_oc_bounds; a.oc_off = p->d_oc_off; a.oc_bigidx = p->d_oc_bigidx;
+    a.oc_nb = p->oc_nb; a.oc_nrows = p->oc_nrows;
     a.st = q.st;
     a.rec = p->d_rec; a.rec_cap = p->rec_cap;
     a.mail = p->d_mail;
@@ -794,6 +873,15 @@ grb_info grb_part_new(grb_part* out, int rank, int world, grb_index n_global, gr
   if (world > 1 && hipMalloc((void**)&p->d_gathered, 4 * (size_t)world * (size_t)p->nwords) != hipSuccess) return fail(GRB_OUT_OF_MEMORY);
   p->big_cap = (int)(A_out->nvals / kPBigDeg) + 2;
   if (hipMalloc((void**)&p->d_big, sizeof(int2) * (size_t)p->big_cap) != hipSuccess) return fail(GRB_OUT_OF_MEMORY);
+  {
+    // GRB_PART_OC=0: the big vertices' edges with atomics, as before round 3's owner-computes push
+    static const bool oc_ok = [] { const char* e = getenv("GRB_PART_OC"); return !e || atoi(e) != 0; }();
+    if (oc_ok && A_out->nvals > 0 && (Index)A_out->h_csr_ptr.size() == A_out->nrows + 1) {
+      const grb_info oi = oc_tables_build(A_out->csr.ptr, A_out->csr.ind, A_out->h_csr_ptr, A_out->nrows, (Index)n_global, c.num_cu,
+                                          &p->d_oc_bounds, &p->d_oc_off, &p->d_oc_bigidx, &p->oc_nb, &p->oc_nrows);
+      if (oi != GRB_SUCCESS) return fail(oi);
+    }
+  }
   if (hipHostMalloc((void**)&p->h_rec, sizeof(grb_bfs_level) * (size_t)p->rec_cap, hipHostMallocMapped) != hipSuccess) return fail(GRB_OUT_OF_MEMORY);
   if (hipHostGetDevicePointer((void**)&p->d_rec, p->h_rec, 0) != hipSuccess) return fail(GRB_PANIC);
   if (hipHostMalloc((void**)&p->h_mail, 256, hipHostMallocMapped) != hipSuccess) return fail(GRB_OUT_OF_MEMORY);
@@ -819,6 +907,9 @@ grb_info grb_part_free(grb_part p) {
   if (p->d_block) (void)hipFree(p->d_block);
   if (p->d_gathered) (void)hipFree(p->d_gathered);
   if (p->d_big) (void)hipFree(p->d_big);
+  if (p->d_oc_bounds) (void)hipFree(p->d_oc_bounds);
+  if (p->d_oc_off) (void)hipFree(p->d_oc_off);
+  if (p->d_oc_bigidx) (void)hipFree(p->d_oc_bigidx);
   if (p->h_rec) (void)hipHostFree(p->h_rec);
   if (p->d_hint) (void)hipFree(p->d_hint);
   if (p->h_mail) (void)hipHostFree(p->h_mail);

@@ -37,8 +37,6 @@ constexpr int kPullBlock = GRB_PULL_BLOCK;    // chunks (of 64 vertices) one wav
 constexpr int kPullGroup = 16;    // lanes finishing one undecided row in the pull phase
 constexpr int kMedCap = 4096;     // LDS list of medium vertices per workgroup pass
 constexpr int kKeep = 32;         // levels whose discovered-bitmaps are kept for the final label pass
-constexpr int kOcBin = 256;        // owner-computes push: the ranges are cut on multiples of this many vertices
-constexpr int kOcWords = 8192;    // owner-computes push: visited words a workgroup owns at most (32 KiB of LDS)
 
 struct PersistState {               // zeroed by the host before every launch
   GridBarrier bar;
@@ -672,6 +670,71 @@ __global__ void oc_range_off_kernel(const Index* __restrict__ optr, const Index*
 
 using namespace grb;
 
+// The tables of the owner-computes push for the rows [0, nrows) of a CSR whose columns are [0, ncols): the rows of
+// >= kBigDeg entries numbered (bigidx, -1 for the others), destination ranges cut at equal mass of those rows' own
+// destinations (counted on the device in bins of kOcBin vertices; at most kOcWords words wide), and where each big
+// row enters each range ([nb + 1][nbig]).  Leaves *d_off null when there is nothing to gain (no big rows, a table
+// beyond 64 M entries).  Also used by the partitioned traversal (bfs_part_run.hip) for a rank's out-edge shard.
+grb_info grb::oc_tables_build(const Index* d_ptr, const Index* d_ind, const std::vector<Index>& optr, Index nrows, Index ncols, int G,
+                              Index** d_bounds, Index** d_off, int** d_bigidx, int* nb, int* nbig) {
+  hipStream_t s = ctx().stream;
+  *d_bounds = nullptr; *d_off = nullptr; *d_bigidx = nullptr; *nb = 0; *nbig = 0;
+  const Index n = ncols;
+  std::vector<Index> rows;
+  std::vector<int> bigidx((size_t)(nrows > 0 ? nrows : 1), -1);
+  for (Index v = 0; v < nrows; ++v)
+    if (optr[(size_t)v + 1] - optr[v] >= kBigDeg) { bigidx[v] = (int)rows.size(); rows.push_back(v); }
+  if (rows.empty() || n < 2 * kOcBin) return GRB_SUCCESS;
+  const int nbins = (int)(((long long)n + kOcBin - 1) / kOcBin);
+  std::vector<unsigned int> bins((size_t)nbins, 0u);
+  void *p_rows = nullptr, *p_bins = nullptr;
+  GRB_HIP_TRY(hipMalloc(&p_rows, sizeof(Index) * rows.size()));
+  GRB_HIP_TRY(hipMalloc(&p_bins, 4 * (size_t)nbins));
+  GRB_HIP_TRY(hipMemsetAsync(p_bins, 0, 4 * (size_t)nbins, s));
+  GRB_HIP_TRY(hipMemcpyAsync(p_rows, rows.data(), sizeof(Index) * rows.size(), hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(oc_mass_kernel, dim3(stream_grid((long long)rows.size() * kWave, kBlock)), dim3(kBlock), 0, s, d_ptr, d_ind,
+                     (const Index*)p_rows, (int)rows.size(), (unsigned int*)p_bins);
+  GRB_HIP_TRY(hipGetLastError());
+  GRB_HIP_TRY(hipMemcpyAsync(bins.data(), p_bins, 4 * (size_t)nbins, hipMemcpyDeviceToHost, s));
+  GRB_HIP_TRY(hipStreamSynchronize(s));
+  (void)hipFree(p_bins);
+  long long total = 0;
+  for (unsigned int x : bins) total += (long long)x;
+  const long long target = std::max<long long>(1, total / (1ll * G));
+  std::vector<Index> bounds(1, 0);
+  {
+    static const int cap_env = getenv("GRB_BFS_OC_WIDTH") ? atoi(getenv("GRB_BFS_OC_WIDTH")) : 0;   // vertices per range at most
+    int max_bins = kOcWords * 32 / kOcBin;                 // a range's slice of the visited bitmap fits the LDS buffer
+    if (cap_env >= kOcBin && cap_env / kOcBin < max_bins) max_bins = cap_env / kOcBin;
+    long long acc = 0;
+    int first = 0;
+    for (int b = 0; b < nbins; ++b) {
+      acc += (long long)bins[(size_t)b];
+      if (acc >= target || b + 1 - first >= max_bins || b + 1 == nbins) {
+        bounds.push_back((Index)std::min<long long>((long long)n, (long long)(b + 1) * kOcBin));
+        first = b + 1;
+        acc = 0;
+      }
+    }
+    if (bounds.back() != n) bounds.push_back(n);
+  }
+  const long long R = (long long)bounds.size() - 1;
+  if (R < 2 || (long long)rows.size() * (R + 1) > (64ll << 20)) { (void)hipFree(p_rows); return GRB_SUCCESS; }
+  GRB_HIP_TRY(hipMalloc((void**)d_bounds, sizeof(Index) * bounds.size()));
+  GRB_HIP_TRY(hipMalloc((void**)d_bigidx, sizeof(int) * bigidx.size()));
+  GRB_HIP_TRY(hipMalloc((void**)d_off, sizeof(Index) * rows.size() * (size_t)(R + 1)));
+  GRB_HIP_TRY(hipMemcpyAsync(*d_bounds, bounds.data(), sizeof(Index) * bounds.size(), hipMemcpyHostToDevice, s));
+  GRB_HIP_TRY(hipMemcpyAsync(*d_bigidx, bigidx.data(), sizeof(int) * bigidx.size(), hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(oc_range_off_kernel, dim3(stream_grid((long long)rows.size() * (R + 1), kBlock)), dim3(kBlock), 0, s, d_ptr, d_ind,
+                     (const Index*)p_rows, (int)rows.size(), (int)R, (const Index*)*d_bounds, *d_off);
+  GRB_HIP_TRY(hipGetLastError());
+  GRB_HIP_TRY(hipStreamSynchronize(s));                    // the host vectors above go out of scope
+  (void)hipFree(p_rows);
+  *nb = (int)R;
+  *nbig = (int)rows.size();
+  return GRB_SUCCESS;
+}
+
 // Runs the persistent traversal.  Outputs mirror what the fused loop keeps on the host.
 grb_info bfs_persistent_run(grb_vector v, grb_matrix A, grb_index source, grb_descriptor desc, int profile,
                             grb_bfs_level* levels_out, int max_levels, int* levels, int* last_dir,
@@ -738,72 +801,10 @@ grb_info bfs_persistent_run(grb_vector v, grb_matrix A, grb_index source, grb_de
     const long long oc_min = e ? atoll(e) : 262144;
     if (oc_min > 0 && A->oc_state == 0) {
       A->oc_state = -1;
-      const std::vector<Index>& optr = A->h_csr_ptr;
-      if ((Index)optr.size() == n + 1 && A->nvals > 0) {
-        std::vector<Index> rows;
-        std::vector<int> bigidx((size_t)n, -1);
-        for (Index v = 0; v < n; ++v)
-          if (optr[(size_t)v + 1] - optr[v] >= kBigDeg) { bigidx[v] = (int)rows.size(); rows.push_back(v); }
-        // what a range will receive is edges OUT OF BIG ROWS, and those favour the hub region more than in-edges at
-        // large do (cut by in-edge mass, the hub ranges' owners finished 15 us after the others): the cut follows
-        // the big rows' own destinations, counted on the device in bins of 256 vertices
-        const int nbins = (int)(((long long)n + kOcBin - 1) / kOcBin);
-        std::vector<unsigned int> bins((size_t)nbins, 0u);
-        if (!rows.empty()) {
-          void *p_rows0 = nullptr, *p_bins = nullptr;
-          GRB_HIP_TRY(hipMalloc(&p_rows0, sizeof(Index) * rows.size()));
-          GRB_HIP_TRY(hipMalloc(&p_bins, 4 * (size_t)nbins));
-          GRB_HIP_TRY(hipMemsetAsync(p_bins, 0, 4 * (size_t)nbins, s));
-          GRB_HIP_TRY(hipMemcpyAsync(p_rows0, rows.data(), sizeof(Index) * rows.size(), hipMemcpyHostToDevice, s));
-          hipLaunchKernelGGL(oc_mass_kernel, dim3(stream_grid((long long)rows.size() * kWave, kBlock)), dim3(kBlock), 0, s, A->csr.ptr,
-                             A->csr.ind, (const Index*)p_rows0, (int)rows.size(), (unsigned int*)p_bins);
-          GRB_HIP_TRY(hipGetLastError());
-          GRB_HIP_TRY(hipMemcpyAsync(bins.data(), p_bins, 4 * (size_t)nbins, hipMemcpyDeviceToHost, s));
-          GRB_HIP_TRY(hipStreamSynchronize(s));
-          (void)hipFree(p_rows0);
-          (void)hipFree(p_bins);
-        }
-        long long total = 0;
-        for (unsigned int x : bins) total += (long long)x;
-        const long long target = std::max<long long>(1, total / (1ll * G));
-        std::vector<Index> bounds(1, 0);
-        {
-          static const int cap_env = getenv("GRB_BFS_OC_WIDTH") ? atoi(getenv("GRB_BFS_OC_WIDTH")) : 0;   // vertices per range at most
-          int max_bins = kOcWords * 32 / kOcBin;           // a range's slice of the visited bitmap fits the LDS buffer
-          if (cap_env >= kOcBin && cap_env / kOcBin < max_bins) max_bins = cap_env / kOcBin;
-          long long acc = 0;
-          int first = 0;
-          for (int b = 0; b < nbins; ++b) {
-            acc += (long long)bins[(size_t)b];
-            if (acc >= target || b + 1 - first >= max_bins || b + 1 == nbins) {
-              const long long e1 = std::min<long long>((long long)n, (long long)(b + 1) * kOcBin);
-              bounds.push_back((Index)e1);
-              first = b + 1;
-              acc = 0;
-            }
-          }
-          if (bounds.back() != n) bounds.push_back(n);
-        }
-        const long long R = (long long)bounds.size() - 1;
-        if (!rows.empty() && bounds.back() == n && R >= 2 && (long long)rows.size() * (R + 1) <= (64ll << 20)) {
-          GRB_HIP_TRY(hipMalloc((void**)&A->d_oc_bounds, sizeof(Index) * bounds.size()));
-          GRB_HIP_TRY(hipMalloc((void**)&A->d_oc_bigidx, sizeof(int) * (size_t)n));
-          GRB_HIP_TRY(hipMalloc((void**)&A->d_oc_off, sizeof(Index) * rows.size() * (size_t)(R + 1)));
-          void* p_rows = nullptr;                          // (one-off: not a scratch slot, those are in use by this call)
-          GRB_HIP_TRY(hipMalloc(&p_rows, sizeof(Index) * rows.size()));
-          GRB_HIP_TRY(hipMemcpyAsync(A->d_oc_bounds, bounds.data(), sizeof(Index) * bounds.size(), hipMemcpyHostToDevice, s));
-          GRB_HIP_TRY(hipMemcpyAsync(A->d_oc_bigidx, bigidx.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice, s));
-          GRB_HIP_TRY(hipMemcpyAsync(p_rows, rows.data(), sizeof(Index) * rows.size(), hipMemcpyHostToDevice, s));
-          hipLaunchKernelGGL(oc_range_off_kernel, dim3(stream_grid((long long)rows.size() * (R + 1), kBlock)), dim3(kBlock), 0, s,
-                             A->csr.ptr, A->csr.ind, (const Index*)p_rows, (int)rows.size(), (int)R, (const Index*)A->d_oc_bounds,
-                             A->d_oc_off);
-          GRB_HIP_TRY(hipGetLastError());
-          GRB_HIP_TRY(hipStreamSynchronize(s));            // the host vectors above go out of scope
-          (void)hipFree(p_rows);
-          A->oc_nb = (int)R;
-          A->oc_nrows = (int)rows.size();
-          A->oc_state = 1;
-        }
+      if (A->nvals > 0 && (Index)A->h_csr_ptr.size() == n + 1) {
+        GRB_TRY(oc_tables_build(A->csr.ptr, A->csr.ind, A->h_csr_ptr, n, n, G, &A->d_oc_bounds, &A->d_oc_off, &A->d_oc_bigidx,
+                                &A->oc_nb, &A->oc_nrows));
+        if (A->d_oc_off) A->oc_state = 1;
       }
     }
     if (oc_min > 0 && A->oc_state == 1) {

@@ -628,6 +628,10 @@ int sssp_last_order(int set);                    // set < 0 queries
 void sssp_last_work(long long* out3);            // near / far: vertices expanded, out-edges relaxed, vertices marked, all passes
 grb_info sssp_nearfar_run(grb_vector v, grb_matrix A, grb_index source, grb_descriptor desc, int* iterations,
                           double* succ, float* tight_ms, int* passes);
+constexpr int kOcBin = 256;        // owner-computes push (bfs_persist.hip, bfs_part_run.hip): the ranges are cut on multiples of this many vertices
+constexpr int kOcWords = 8192;     // ... and a range's slice of the visited bitmap is at most this many words (32 KiB of LDS)
+grb_info oc_tables_build(const Index* d_ptr, const Index* d_ind, const std::vector<Index>& h_ptr, Index nrows, Index ncols, int G,
+                         Index** d_bounds, Index** d_off, int** d_bigidx, int* nb, int* nbig);
 grb_info bfs_queue_run(grb_vector v, grb_matrix A, grb_index source, grb_descriptor desc, int* levels,
                        long long* reached, unsigned long long* edges, float* tight_ms);   // sssp_nearfar.hip
 grb_info k_spmv_masked_or(int dtype, const CsrArrays& M, const void* u, double identity,
