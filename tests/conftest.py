@@ -23,7 +23,13 @@ def pytest_collection_modifyitems(config, items):
         return
     for item in items:
         if item.get_closest_marker("timeout") is None:
-            item.add_marker(pytest.mark.timeout(600))
+            # GPU tests: the "thread" method -- a test stuck inside a driver call never returns to the interpreter, so
+            # the default (a signal handled between bytecodes) would never fire; the watchdog thread dumps the stacks and
+            # ends the run instead
+            if item.get_closest_marker("gpu") is not None:
+                item.add_marker(pytest.mark.timeout(600, method="thread"))
+            else:
+                item.add_marker(pytest.mark.timeout(600))
 
 
 @pytest.fixture(scope="session")
