@@ -762,7 +762,8 @@ class Partition1D:
             vals = torch.zeros(1, dtype=torch.float32, device=dev)
         # the chunk matrices (and their SpMV plans: ~50 ms of preparation on RMAT-22) are kept between calls on the
         # same degrees / alpha -- every rank takes the same branch, so the set-up all-gather stays symmetric
-        key = (deg_full.data_ptr(), float(alpha), int(nchunks), int(deg_full.numel()))
+        # (the sum guards against another tensor that happens to sit at a freed one's address)
+        key = (deg_full.data_ptr(), float(alpha), int(nchunks), int(deg_full.numel()), float(deg_full.double().sum().item()))
         if getattr(self, "_pr_key", None) != key:
             cuts = eng.pr_setup_chunks(vals, dev, nchunks)
             # every rank's chunk boundaries (vertex ids), identical on all ranks: one small all-gather at set-up
