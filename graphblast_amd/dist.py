@@ -820,7 +820,7 @@ class Partition1D:
             # the frontier form with the round loop on the device (csrc/sssp_part_run.hip): per round the
             # improved vertices' out-edges, an all-gather of (vertex, candidate) pairs, nothing read back
             o0, o1 = self.out_range
-            key = (out_weights.data_ptr(), int(outbox_pairs))
+            key = (out_weights.data_ptr(), int(outbox_pairs), int(out_weights.numel()), float(out_weights.double().sum().item()))
             if getattr(self, "_sssp_key", None) != key:
                 self._sssp_ctx = eng.sssp_context(self.rank, self.world, out_weights[o0:o1], outbox_pairs)
                 self._sssp_key = key
