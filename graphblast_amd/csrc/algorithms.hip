@@ -374,10 +374,29 @@ int grb_cc_set_fused(int on) {
 
 // FastSV connected components, algorithm/cc.hpp:17-136: v = parent vector (component label =
 // smallest vertex id of the component once converged). A is an int matrix (pattern values).
+static grb_info cc_run(grb_vector v, grb_matrix A, grb_descriptor desc, grb_algo_result* result, bool want_fused,
+                       bool* barrier_gave_up);
+
+// The fused tail's grid barrier needs its workgroups co-resident; on a shared device it can give up.  The call then
+// starts over op by op (every vector is re-initialised by cc_run), and after two such failures in a process later
+// calls do not try the fused tail again -- the same rule as the one-launch BFS / SSSP (persistent_failures).
+static int g_cc_barrier_failures = 0;
+
 grb_info grb_cc(grb_vector v, grb_matrix A, int seed, grb_descriptor desc, grb_algo_result* result) {
   (void)seed;
   if (!v || !A || !desc) return GRB_UNINITIALIZED_OBJECT;
   if (v->dtype != GRB_I32 || A->dtype != GRB_I32) return GRB_DOMAIN_MISMATCH;
+  const bool want_fused = grb_cc_set_fused(-1) != 0 && g_cc_barrier_failures < 2;
+  bool gave_up = false;
+  const grb_info info = cc_run(v, A, desc, result, want_fused, &gave_up);
+  if (!gave_up) return info;
+  ++g_cc_barrier_failures;
+  return cc_run(v, A, desc, result, false, &gave_up);
+}
+
+static grb_info cc_run(grb_vector v, grb_matrix A, grb_descriptor desc, grb_algo_result* result, bool want_fused,
+                       bool* barrier_gave_up) {
+  *barrier_gave_up = false;
   const Index n = A->nrows;
   VecGuard g;
   grb_vector diff, parent, parent_temp, grandparent, grandparent_temp, mnp, mnp_temp;
@@ -388,7 +407,7 @@ grb_info grb_cc(grb_vector v, grb_matrix A, int seed, grb_descriptor desc, grb_a
   GRB_TRY(grb_vector_dup(mnp_temp, parent));
   GRB_TRY(grb_vector_dup(grandparent, parent));
   GRB_TRY(grb_vector_dup(grandparent_temp, parent));
-  bool fused = grb_cc_set_fused(-1) != 0 && n > 0 && A->nrows == A->ncols;
+  const bool fused = want_fused && n > 0 && A->nrows == A->ncols;
   Context& c = ctx();
   GridBarrier* d_bar = nullptr;
   unsigned int* d_partial = nullptr;
@@ -425,7 +444,10 @@ grb_info grb_cc(grb_vector v, grb_matrix A, int seed, grb_descriptor desc, grb_a
       ++launches;
       unsigned int bits = 0;
       GRB_TRY(wait_granules(seq, 1, &bits));
-      if (bits == 0xffffffffu) return GRB_PANIC;           // the grid barrier gave up
+      if (bits == 0xffffffffu) {                           // the grid barrier gave up: grb_cc starts over op by op
+        *barrier_gave_up = true;
+        return GRB_PANIC;
+      }
       succ = (double)bits;
       for (grb_vector x : {mnp, parent, parent_temp, grandparent, grandparent_temp}) GRB_TRY(grb_vector_set_storage(x, GRB_DENSE));
     } else {

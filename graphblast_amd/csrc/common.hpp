@@ -520,6 +520,7 @@ struct SpmmCore {
   SpmvPlan rest_plan;
 };
 void free_spmm_core(SpmmCore* core);
+void spmv_plan_values_changed(SpmvPlan* plan);   // drops every private copy of the stored values (spmv.hip)
 }  // namespace grb
 
 struct grb_matrix_s {
@@ -552,6 +553,15 @@ struct grb_matrix_s {
   grb::BatchSlices batch_in, batch_out;          // bfs_batch.hip, built lazily
   grb::SpmmCore spmm_core_csr, spmm_core_csc;    // spmm.hip, built lazily when GRB_SPMM_CORE is set
 };
+
+// Every cache that holds a copy of the stored VALUES (not structure) is dropped: the SpMV band formats, the SpMM
+// dense-core tiles.  Called by whatever rewrites csr.val / csc.val in place.
+inline void matrix_values_changed(grb_matrix_s* A) {
+  grb::spmv_plan_values_changed(&A->plan_csr);
+  grb::spmv_plan_values_changed(&A->plan_csc);
+  grb::free_spmm_core(&A->spmm_core_csr);
+  grb::free_spmm_core(&A->spmm_core_csc);
+}
 
 namespace grb {
 

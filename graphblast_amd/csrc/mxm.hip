@@ -653,6 +653,7 @@ static grb_info matrix_scale(grb_matrix A, int op, grb_vector B, double scalar, 
   A->h_csr_val.clear(); A->h_csr_ind.clear();           // host mirrors are re-read on demand
   A->h_csc_val.clear(); A->h_csc_ind.clear();
   A->nonneg_values = -1; A->mean_value = -1.0; A->small_int_values = -1;
+  matrix_values_changed(A);
   return info;
 }
 

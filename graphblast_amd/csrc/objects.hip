@@ -1011,6 +1011,7 @@ grb_info grb_matrix_set_values(grb_matrix A, const void* csr_val) {
       GRB_HIP_TRY(hipMemcpy(A->csc.val, A->h_csc_val.data(), 4 * (size_t)A->nvals, hipMemcpyHostToDevice));
   }
   A->nonneg_values = -1; A->mean_value = -1.0; A->small_int_values = -1;
+  matrix_values_changed(A);
   return GRB_SUCCESS;
 }
 

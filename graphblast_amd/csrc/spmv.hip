@@ -126,6 +126,17 @@ void free_spmv_plan(SpmvPlan* plan) {
   *plan = SpmvPlan();
 }
 
+// The stored values were rewritten in place (grb_matrix_set_values, matrix (x) scalar / vector): the two band
+// formats keep private copies of the values (or one iso value) taken at their first product, so they go; the
+// next product prepares them again from the live arrays.  The tiles and the renamed column ids hold structure only.
+void spmv_plan_values_changed(SpmvPlan* plan) {
+  free_spmv_bands(plan->bands);
+  free_spmv_cband(plan->cband);
+  plan->bands = nullptr;
+  plan->cband = nullptr;
+  plan->cband_tried = false;
+}
+
 // ---- hub packing ----------------------------------------------------------------------
 // Power-law graphs send most gathers to a small set of columns (RMAT-22: the 32 Ki most
 // referenced columns take 52 % of the nonzeros, the top 1 Mi take 97 %), but their entries of

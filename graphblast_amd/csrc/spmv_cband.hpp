@@ -210,7 +210,7 @@ __device__ inline void cband_combine(A* addr, T v) {
     // reverse unsigned order below); a NaN product fails the test and is dropped, as fminf drops it
     if (v < *addr) {
       if constexpr (std::is_same<T, float>::value) {
-        if (v >= 0.f) atomicMin(reinterpret_cast<int*>(addr), __float_as_int(v));
+        if (__float_as_int(v) >= 0) atomicMin(reinterpret_cast<int*>(addr), __float_as_int(v));   // by sign BIT: -0.0 goes below
         else atomicMax(reinterpret_cast<unsigned int*>(addr), __float_as_uint(v));
       } else {
         atomicMin(addr, v);
@@ -219,7 +219,7 @@ __device__ inline void cband_combine(A* addr, T v) {
   } else if constexpr (op == OP_MAX) {
     if (v > *addr) {
       if constexpr (std::is_same<T, float>::value) {
-        if (v >= 0.f) atomicMax(reinterpret_cast<int*>(addr), __float_as_int(v));
+        if (__float_as_int(v) >= 0) atomicMax(reinterpret_cast<int*>(addr), __float_as_int(v));
         else atomicMin(reinterpret_cast<unsigned int*>(addr), __float_as_uint(v));
       } else {
         atomicMax(addr, v);

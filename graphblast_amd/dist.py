@@ -536,7 +536,7 @@ class LoopbackGroup:
     def sssp(self, weights, source, max_niter=10000, outbox_pairs=65536):
         """weights: of every stored out-edge, CSR order.  -> (distances [n] numpy, per-rank result dicts)"""
         from ._lib import PartSsspResult
-        key = (weights.data_ptr(), int(outbox_pairs))
+        key = (weights.data_ptr(), int(weights.numel()), float(weights.double().sum().item()), int(outbox_pairs))
         if getattr(self, "_sssp_key", None) != key:
             ptr_host = self._ptr_host
             hs = []
@@ -763,7 +763,11 @@ class Partition1D:
         # the chunk matrices (and their SpMV plans: ~50 ms of preparation on RMAT-22) are kept between calls on the
         # same degrees / alpha -- every rank takes the same branch, so the set-up all-gather stays symmetric
         # (the sum guards against another tensor that happens to sit at a freed one's address)
-        key = (deg_full.data_ptr(), float(alpha), int(nchunks), int(deg_full.numel()), float(deg_full.double().sum().item()))
+        # only values that are the same on every rank go in the key (deg_full is replicated): an address is
+        # rank-local, and one rank hitting while another misses would leave the set-up all-gather unmatched
+        dsum = deg_full.double()
+        key = (float(alpha), int(nchunks), int(deg_full.numel()), float(dsum.sum().item()),
+               float((dsum * torch.arange(1, dsum.numel() + 1, device=dsum.device, dtype=torch.float64)).sum().item()))
         if getattr(self, "_pr_key", None) != key:
             cuts = eng.pr_setup_chunks(vals, dev, nchunks)
             # every rank's chunk boundaries (vertex ids), identical on all ranks: one small all-gather at set-up

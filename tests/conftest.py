@@ -19,6 +19,11 @@ def pytest_collection_modifyitems(config, items):
     """A ceiling per test when pytest-timeout is installed (it is in this image): the whole GPU suite takes two
     minutes, so a test that is still running after ten is stuck in something outside Python's reach (a collective's
     rendezvous, a driver call) and the run should fail there instead of sitting until the caller's limit."""
+    # Collection order on the GPU box (the driver runs -x): the cheap, high-coverage parity files first, the long
+    # subprocess campaigns (fuzz, the reference's mains, full-size graphs) last, so that a failure in a campaign
+    # cannot leave the per-op / golden / kernel tests unexecuted.  Stable within a file.
+    late = {"test_gpu_reftests": 1, "test_gpu_dropin": 2, "test_gpu_fullsize": 3, "test_gpu_fuzz": 4}
+    items.sort(key=lambda it: late.get(os.path.splitext(os.path.basename(str(it.fspath)))[0], 0))
     if not config.pluginmanager.hasplugin("timeout"):
         return
     for item in items:

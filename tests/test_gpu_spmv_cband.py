@@ -214,3 +214,63 @@ def test_forced_format_on_a_road_like_grid(forced):
     for op in ("PlusMultiplies", "MinimumPlus"):
         assert np.array_equal(_run(g, torch, dev, A, n, op, u), _reference(ptr, ind, vals, u, op, n).astype(np.float32))
     assert g.spmv_format_info(A, 0)["hub_rows"] == 0
+
+
+def test_values_rewritten_in_place_are_seen_by_the_next_product():
+    """The band formats keep a private copy of the stored values (or one iso value) from their first product;
+    grb_matrix_set_values and matrix (x) scalar / vector rewrite csr.val / csc.val in place (objects.hip, mxm.hip
+    matrix_scale) and must drop those copies -- the PageRank set-up (pattern matrix, then 1 / outdegree scaling,
+    gpr.cu / pr.hpp) is exactly mxv -> scale -> mxv.  Both orientations, an iso and a valued start."""
+    import torch
+    import graphblast_amd as g
+    from graphblast_amd import _lib
+    from graphblast_amd.api import _semiring_id
+    from graphblast_amd.graphgen import rmat_edges, finalize_edges
+    dev = torch.device("cuda", 0)
+    assert g.spmv_set_format(-1) == 1
+    src, dst, n = rmat_edges(18, 16, seed=9, device=dev)
+    gr = finalize_edges(src, dst, n, symmetrize=True)
+    ptr, ind = gr["csr"][0].cpu().numpy(), gr["csr"][1].cpu().numpy()
+    rng = np.random.default_rng(21)
+    u = rng.integers(0, 3, n).astype(np.float32)
+    lib = _lib.load()
+    d = g.Descriptor()
+    d.loadArgs()
+    for start in ("iso", "valued"):
+        vals = np.ones(ind.size, dtype=np.float32) if start == "iso" else rng.integers(1, 4, ind.size).astype(np.float32)
+        A = g.Matrix(n, n)
+        assert A.build_csr(ptr, ind, vals) == 0
+        rows = np.repeat(np.arange(n), np.diff(ptr))
+
+        def transposed(v):
+            tu = torch.from_numpy(u).to(dev)
+            tw = torch.empty(n, dtype=torch.float32, device=dev)
+            assert g.k_spmv(A, 1, "PlusMultiplies", tu.data_ptr(), None, 0, 0, tw.data_ptr()) == 0
+            torch.cuda.synchronize()
+            want = np.bincount(ind, weights=v.astype(np.float64) * u[rows].astype(np.float64), minlength=n)
+            assert np.array_equal(tw.cpu().numpy(), want.astype(np.float32)), start
+
+        # first products: both orientations prepare their plans (and their copies of the values)
+        got = _run(g, torch, dev, A, n, "PlusMultiplies", u)
+        assert np.array_equal(got, _reference(ptr, ind, vals, u, "PlusMultiplies", n).astype(np.float32)), start
+        transposed(vals)
+        assert g.spmv_format_info(A, 0)["in_use"] == 1
+        # 1. new values through set_values
+        vals2 = rng.integers(1, 6, ind.size).astype(np.float32)
+        assert A.set_values(vals2) == 0
+        got = _run(g, torch, dev, A, n, "PlusMultiplies", u)
+        assert np.array_equal(got, _reference(ptr, ind, vals2, u, "PlusMultiplies", n).astype(np.float32)), start
+        # 2. scaled by a scalar in place
+        assert lib.grb_matrix_eWiseMult_scalar(A._h, _semiring_id("PlusMultiplies"), A._h, 2.0) == 0
+        got = _run(g, torch, dev, A, n, "PlusMultiplies", u)
+        assert np.array_equal(got, _reference(ptr, ind, vals2 * 2, u, "PlusMultiplies", n).astype(np.float32)), start
+        # 3. scaled row-wise by a vector in place (the PageRank set-up's shape)
+        scale = rng.integers(1, 4, n).astype(np.float32)
+        B = g.Vector(n)
+        assert B.build(scale) == 0
+        assert lib.grb_matrix_eWiseMult_vector(A._h, _semiring_id("PlusMultiplies"), A._h, B._h, d._h) == 0
+        vals3 = vals2 * 2 * scale[rows]
+        got = _run(g, torch, dev, A, n, "PlusMultiplies", u)
+        assert np.array_equal(got, _reference(ptr, ind, vals3, u, "PlusMultiplies", n).astype(np.float32)), start
+        # the transposed orientation reads csc.val, rewritten by the same calls
+        transposed(vals3)

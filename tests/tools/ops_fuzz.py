@@ -203,15 +203,17 @@ def interfere(hb, which, arg, A):
     g = hb.g
     n = A.nrows()
     d = hb.descriptor(mxvmode=0)
-    twin = _INT_TWIN.get((id(A), n))
-    if twin is None:                                   # int copy of the pattern for the int drivers
-        ptr, ind, _ = A.host_csr()
+    from oracle import simple_reference as sr
+    ptr, ind, val = A.host_csr()
+    # the int copy of the pattern for the int drivers, cached on the pattern's CONTENT: id(A) recurs once a
+    # sequence's matrix is freed, and a twin of the previous sequence's matrix would then be handed to cc / tc
+    key = (n, ptr.tobytes(), ind.tobytes())
+    twin = _INT_TWIN.get(key)
+    if twin is None:
         twin = g.Matrix(n, n, np.int32)
         assert twin.build_csr(ptr, ind, np.ones(ind.size, dtype=np.int32)) == 0
         _INT_TWIN.clear()
-        _INT_TWIN[(id(A), n)] = twin
-    from oracle import simple_reference as sr
-    ptr, ind, val = A.host_csr()
+        _INT_TWIN[key] = twin
     if which in ("bfs", "bfs_opbyop") and A.np_dtype == np.float32:
         v = g.Vector(n)
         info, _ = g.bfs(v, A, arg, d, fused=(which == "bfs"))
