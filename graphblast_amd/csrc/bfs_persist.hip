@@ -30,6 +30,25 @@ namespace grb {
 #ifndef GRB_PULL_BLOCK
 #define GRB_PULL_BLOCK 8
 #endif
+#ifndef GRB_BFS_SPARSE_PULL
+#define GRB_BFS_SPARSE_PULL 1
+#endif
+#ifndef GRB_BFS_SPARSE_DIV
+#define GRB_BFS_SPARSE_DIV 8
+#endif
+#ifndef GRB_BFS_SYM
+#define GRB_BFS_SYM 1
+#endif
+#ifndef GRB_BFS_LAB_UNROLL
+#define GRB_BFS_LAB_UNROLL 1
+#endif
+#ifndef GRB_BFS_L1_FAST
+#define GRB_BFS_L1_FAST 1
+#endif
+#ifndef GRB_BFS_RELAUNDER
+#define GRB_BFS_RELAUNDER 1
+#endif
+constexpr int kSparseWords = 32;  // bitmap words (of 32 vertices) a wave takes per step of a pull level with a sparse active set
 constexpr int kSmallDeg = 16;     // below: expanded inline by the discovering lane
 constexpr int kBigDeg = 512;      // from here: split into kBigChunk-edge entries for workgroups
 constexpr int kBigChunk = 1024;
@@ -51,6 +70,9 @@ struct PersistArgs {
   const Index* hint;                // best in-neighbour per vertex (nullptr in accounting runs)
   Index n;
   long long nnz;
+  long long n_in;                   // vertices with at least one in-edge (the only ones a pull level can discover); < 0 unknown
+  int out_is_in;                    // optr and iptr hold the same numbers (a structurally symmetric matrix): a row's
+                                    // out-degree is the difference of the in-edge pointers a pull level already holds
   Index source;
   int mode;
   float switchpoint, edgeswitch;
@@ -122,9 +144,24 @@ __global__ __launch_bounds__(kPThreads) void bfs_persistent_kernel(PersistArgs a
   __shared__ unsigned short s_leftid[kPWaves][kPullBlock * kWave / 2];
   __shared__ unsigned int s_leftfound[kPWaves][2 * kPullBlock];
   __shared__ unsigned int s_ocw[kOcWords];
-  const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
+  int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
   const int G = gridDim.x;
-  const long long gtid = (long long)blockIdx.x * kPThreads + tid;
+  long long gtid = (long long)blockIdx.x * kPThreads + tid;
+  // The phases of a level are long and disjoint; left alone, the compiler computes every lane-derived index, mask and
+  // LDS address of ALL of them once before the level loop and keeps them in registers for the whole kernel (the
+  // kernel sits at its 128-register limit, so each such value is a spill somewhere else).  Each phase therefore
+  // starts from a thread id the optimiser cannot see through: what it derives from it lives inside that phase only.
+#if GRB_BFS_RELAUNDER
+#define GRB_PHASE_START()                                         \
+  do {                                                            \
+    asm volatile("" : "+v"(tid));                                 \
+    lane = tid & (kWave - 1);                                     \
+    wave = tid >> 6;                                              \
+    gtid = (long long)blockIdx.x * kPThreads + tid;               \
+  } while (0)
+#else
+#define GRB_PHASE_START() do { } while (0)
+#endif
   const long long gthreads = (long long)G * kPThreads;
   const Index n = a.n;
   const int nwords = 2 * ((n + 63) / 64);
@@ -186,13 +223,28 @@ __global__ __launch_bounds__(kPThreads) void bfs_persistent_kernel(PersistArgs a
 
     if (!f1_dense) {
       // ================= push =================
+      GRB_PHASE_START();
       unsigned int* V = a.V[cur];
       if (iter == 1) {
         // the frontier is the source alone: its edges spread over the whole grid
         const Index e = a.optr[a.source + 1];
         for (long long p = a.optr[a.source] + gtid; p < e; p += gthreads) {
           const Index dst = a.oind[p];
-          if (dst != a.source) push_visit(a, V, Fn, dst, new_label, c);
+          if (dst == a.source) continue;
+#if GRB_BFS_L1_FAST
+          // nothing but the source is visited yet: no peek, and the winner's bookkeeping loads go out beside the
+          // atomic instead of behind it (the returning atomic still settles a repeated entry of the row)
+          const Index d0 = a.optr[dst], d1 = a.optr[dst + 1];
+          const unsigned int bit = 1u << (dst & 31);
+          if (atomicOr(&V[dst >> 5], bit) & bit) continue;
+          atomicOr(&Fn[dst >> 5], bit);
+          if (new_label > 0.f) a.label[dst] = new_label;
+          ++c.found;
+          c.deg += (unsigned long long)(d1 - d0);
+          if (d1 - d0 >= kBigDeg) ++c.big;
+#else
+          push_visit(a, V, Fn, dst, new_label, c);
+#endif
         }
       } else {
         unsigned* bcount = &st->big_count[iter & 1][0];
@@ -348,6 +400,7 @@ __global__ __launch_bounds__(kPThreads) void bfs_persistent_kernel(PersistArgs a
       last_dir = 0;
     } else {
       // ================= pull =================
+      GRB_PHASE_START();
       // The barriers of this kernel do not invalidate; push levels read other workgroups' words
       // with fresh().  A pull level probes the visited bitmap millions of times, which is
       // faster through L1 with ordinary loads, so it pays the invalidate itself, once.
@@ -363,6 +416,118 @@ __global__ __launch_bounds__(kPThreads) void bfs_persistent_kernel(PersistArgs a
       const Index nblocks = (nchunks + kPullBlock - 1) / kPullBlock;
       const Index nwaves = (Index)G * kPWaves;
       const unsigned long long lt_mask = (1ull << lane) - 1ull;
+      // Few vertices are left to discover (the levels after the big one): the dense walk below would carry 512-vertex
+      // blocks with a handful of live lanes through every stage.  Here a wave numbers the active bits of kSparseWords
+      // bitmap words (wave_for_each_bit) and takes them 64 at a time, one vertex per lane: the same stages, every lane
+      // busy, one step where the dense walk takes two passes of eight chunks.  Same discoveries, same accounting.
+      const bool sparse_act = GRB_BFS_SPARSE_PULL && a.n_in >= 0 &&
+                              (a.n_in - reached) * GRB_BFS_SPARSE_DIV < (long long)n;
+      if (sparse_act) {
+        int2* lq = s_left[wave];                                            // [0, 64): leftover rows {next, end}
+        WaveBits* sb = reinterpret_cast<WaveBits*>(s_left[wave] + kWave);    // 512 B
+        unsigned int* s_new = reinterpret_cast<unsigned int*>(s_left[wave] + 2 * kWave);   // [kSparseWords] new bits
+        unsigned int* lf = s_leftfound[wave];                               // 64 flags of the leftover rows
+        const Index ngroups = (Index)((nwords + kSparseWords - 1) / kSparseWords);
+        const int grp = lane >> 4, gl = lane & 15;
+        for (Index g = (Index)blockIdx.x * kPWaves + wave; g < ngroups; g += nwaves) {
+          const Index wi = g * kSparseWords + lane;
+          const bool has_word = lane < kSparseWords && wi < nwords;
+          unsigned int vw = 0xffffffffu, act = 0u;
+          if (has_word) { vw = vin[wi]; act = ~(vw | a.skip[wi]); }
+          if (__ballot(act != 0u) == 0ull) {
+            if (has_word) publish(&vout[wi], vw);
+            continue;
+          }
+          if (lane < kSparseWords) s_new[lane] = 0u;
+          wave_for_each_bit(sb, act, lane, [&](int L, int bit) {
+            const bool on = L >= 0;
+            const Index v = on ? (g * kSparseWords + L) * 32 + bit : 0;
+            const Index hv = hint ? hint[v] : 0;
+            const Index p = a.iptr[v], e = a.iptr[v + 1];
+            bool found = false;
+            if (hint) found = on && bit_set(vin, hv);
+            bool und = on && !found && p < e;
+            Index next = p;
+            if (__ballot(und)) {
+              if (a.nnz >= kPullProbe) {
+                Index at = und ? p : 0;
+                const Index last = (Index)a.nnz - kPullProbe;
+                const int shift = at > last ? at - last : 0;
+                at -= shift;
+                Quad cq = *reinterpret_cast<const Quad*>(a.iind + at);
+                for (int t = 0; t < shift; ++t) { cq.x = cq.y; cq.y = cq.z; cq.z = cq.w; }
+                const Index len = und ? e - p : 0;
+                const Index c4[kPullProbe] = {cq.x, cq.y, cq.z, cq.w};
+                unsigned int wq[kPullProbe];
+#pragma unroll
+                for (int k = 0; k < kPullProbe; ++k) wq[k] = vin[k < len ? (c4[k] >> 5) : 0];
+                int first = -1;
+#pragma unroll
+                for (int k = kPullProbe - 1; k >= 0; --k)
+                  if (k < len && ((wq[k] >> (c4[k] & 31)) & 1u)) first = k;
+                const int seen = first >= 0 ? first + 1 : (len < kPullProbe ? (int)len : kPullProbe);
+                c.inspected += (unsigned long long)seen;
+                if (first >= 0) { found = true; und = false; }
+                next = p + kPullProbe;
+                if (next >= e) und = false;
+              }
+              // rows with entries left: 16 lanes per row through the wave's LDS queue
+              const unsigned long long um = __ballot(und);
+              if (um) {
+                if (lane < 2) lf[lane] = 0u;
+                if (und) lq[__popcll(um & lt_mask)] = make_int2(next, e);
+                if (und) s_leftid[wave][__popcll(um & lt_mask)] = (unsigned short)lane;
+                const int qn = __popcll(um);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                for (int q0 = 0; q0 < qn; q0 += kWave / kPullGroup) {
+                  const int qi = q0 + grp;
+                  Index rs = 0, re = 0;
+                  int id = 0;
+                  if (qi < qn) { const int2 r = lq[qi]; rs = r.x; re = r.y; id = s_leftid[wave][qi]; }
+                  bool done = false;
+                  for (Index q = rs; __any(q < re && !done); q += kPullGroup) {
+                    bool h = false;
+                    const bool live = q < re && !done;
+                    if (live && q + gl < re) h = bit_set(vin, a.iind[q + gl]);
+                    const unsigned int hb = (unsigned int)(__ballot(h) >> (grp * kPullGroup)) & ((1u << kPullGroup) - 1u);
+                    if (live && gl == 0) {
+                      const Index span = (re - q < kPullGroup) ? re - q : kPullGroup;
+                      c.inspected += hb ? (unsigned long long)__ffs((int)hb) : (unsigned long long)span;
+                    }
+                    if (live && hb) {
+                      done = true;
+                      if (gl == 0) atomicOr(&lf[id >> 5], 1u << (id & 31));
+                    }
+                  }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                if (und && ((lf[lane >> 5] >> (lane & 31)) & 1u)) found = true;
+                __builtin_amdgcn_wave_barrier();
+              }
+            }
+            if (found) {
+              atomicOr(&s_new[L], 1u << bit);
+              Index d;
+              if (GRB_BFS_SYM && a.out_is_in) d = e - p;
+              else d = a.optr[v + 1] - a.optr[v];
+              ++c.found;
+              c.deg += (unsigned long long)d;
+              if (d >= kBigDeg) ++c.big;
+              if (direct) a.label[v] = new_label;
+            }
+          });
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          if (has_word) {
+            const unsigned int nb = s_new[lane];
+            publish(&vout[wi], vw | nb);
+            if (nb) publish(&Fn[wi], nb);
+          }
+          __builtin_amdgcn_wave_barrier();
+        }
+      } else
       for (Index blk = (Index)blockIdx.x * kPWaves + wave; blk < nblocks; blk += nwaves) {
         // ---- stage 0: the block's 32 words; a lane's 16 vertices are vbase + 64 j
         const Index wi = blk * (2 * kPullBlock) + lane;
@@ -519,23 +684,37 @@ __global__ __launch_bounds__(kPThreads) void bfs_persistent_kernel(PersistArgs a
           if (nb) publish(&Fn[wi], nb);
         }
         if (__ballot(fnd != 0u)) {
-          Index d0[kPullBlock], d1[kPullBlock];
+          if (GRB_BFS_SYM && a.out_is_in) {
+            // the out-degree is the in-degree: no second pair of row pointers, no dependent load at the end of the step
+            const Index adj = a.nnz >= kPullProbe ? 0 : kPullProbe;
 #pragma unroll
-          for (int j = 0; j < kPullBlock; ++j) {
-            const bool f = (fnd >> j) & 1u;
-            const Index vj = f ? vbase + kWave * j : 0;
-            d0[j] = a.optr[vj];
-            d1[j] = a.optr[vj + 1];
-            if (f && direct) a.label[vj] = new_label;
-          }
+            for (int j = 0; j < kPullBlock; ++j)
+              if ((fnd >> j) & 1u) {
+                const Index d = e[j] - p[j] - adj;
+                ++c.found;
+                c.deg += (unsigned long long)d;
+                if (d >= kBigDeg) ++c.big;
+                if (direct) a.label[vbase + kWave * j] = new_label;
+              }
+          } else {
+            Index d0[kPullBlock], d1[kPullBlock];
 #pragma unroll
-          for (int j = 0; j < kPullBlock; ++j)
-            if ((fnd >> j) & 1u) {
-              const Index d = d1[j] - d0[j];
-              ++c.found;
-              c.deg += (unsigned long long)d;
-              if (d >= kBigDeg) ++c.big;
+            for (int j = 0; j < kPullBlock; ++j) {
+              const bool f = (fnd >> j) & 1u;
+              const Index vj = f ? vbase + kWave * j : 0;
+              d0[j] = a.optr[vj];
+              d1[j] = a.optr[vj + 1];
+              if (f && direct) a.label[vj] = new_label;
             }
+#pragma unroll
+            for (int j = 0; j < kPullBlock; ++j)
+              if ((fnd >> j) & 1u) {
+                const Index d = d1[j] - d0[j];
+                ++c.found;
+                c.deg += (unsigned long long)d;
+                if (d >= kBigDeg) ++c.big;
+              }
+          }
         }
       }
       last_dir = 1;
@@ -543,6 +722,7 @@ __global__ __launch_bounds__(kPThreads) void bfs_persistent_kernel(PersistArgs a
 
     stamp();
     // ---- level totals: one atomic per value per workgroup into this XCD group's line
+    GRB_PHASE_START();
     auto add = [](unsigned long long x, unsigned long long y) { return x + y; };
     unsigned long long r0 = wave_reduce(c.found, add), r1 = wave_reduce(c.deg, add);
     unsigned long long r2 = wave_reduce(c.inspected, add), r3 = wave_reduce(c.big, add);
@@ -590,6 +770,7 @@ __global__ __launch_bounds__(kPThreads) void bfs_persistent_kernel(PersistArgs a
   // are disjoint), 0 for everything never reached; a vertex that is visited but in none of the kept bitmaps was
   // discovered by a level >= kKeep and labelled there.  (V[cur] and every F are final after the last barrier.)
   {
+    GRB_PHASE_START();
     // nothing is written any more: read the bitmaps through L1 (one invalidate), eight 64-vertex chunks per
     // wave step so that a step costs one memory latency, not one per level
     if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -610,11 +791,30 @@ __global__ __launch_bounds__(kPThreads) void bfs_persistent_kernel(PersistArgs a
         vis[j] = Vf[wi[j]];
         lab[j] = 0u;
       }
+#if GRB_BFS_LAB_UNROLL
+      // four levels' words in flight together: a step costs one L2 latency per four kept levels
+      for (int L0 = 0; L0 < kept; L0 += 4) {
+        unsigned int f[4][kLB];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const unsigned int* __restrict__ FL = a.F[L0 + u < kept ? L0 + u : L0];
+#pragma unroll
+          for (int j = 0; j < kLB; ++j) f[u][j] = FL[wi[j]];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (L0 + u < kept) {
+#pragma unroll
+            for (int j = 0; j < kLB; ++j) lab[j] += ((f[u][j] >> sh) & 1u) * (unsigned int)(L0 + u + 1);
+          }
+      }
+#else
       for (int L = 0; L < kept; ++L) {
         const unsigned int* __restrict__ FL = a.F[L];
 #pragma unroll
         for (int j = 0; j < kLB; ++j) lab[j] += ((FL[wi[j]] >> sh) & 1u) * (unsigned int)(L + 1);
       }
+#endif
 #pragma unroll
       for (int j = 0; j < kLB; ++j) {
         const long long v = ((long long)blk * kLB + j) * kWave + lane;
@@ -700,9 +900,13 @@ grb_info grb::oc_tables_build(const Index* d_ptr, const Index* d_ind, const std:
   (void)hipFree(p_bins);
   long long total = 0;
   for (unsigned int x : bins) total += (long long)x;
-  const long long target = std::max<long long>(1, total / (1ll * G));
-  std::vector<Index> bounds(1, 0);
-  {
+  long long target = std::max<long long>(1, total / (1ll * G));
+  std::vector<Index> bounds;
+  // At most one range per workgroup (GRB_BFS_OC_FIT=0: whatever the first cut gives, 5 % more than workgroups on
+  // RMAT-22): the workgroups that own two ranges are the owner phase's critical path, twice everybody else's.
+  static const bool fit = !getenv("GRB_BFS_OC_FIT") || atoi(getenv("GRB_BFS_OC_FIT")) != 0;
+  for (int attempt = 0; attempt < 64; ++attempt) {
+    bounds.assign(1, 0);
     static const int cap_env = getenv("GRB_BFS_OC_WIDTH") ? atoi(getenv("GRB_BFS_OC_WIDTH")) : 0;   // vertices per range at most
     int max_bins = kOcWords * 32 / kOcBin;                 // a range's slice of the visited bitmap fits the LDS buffer
     if (cap_env >= kOcBin && cap_env / kOcBin < max_bins) max_bins = cap_env / kOcBin;
@@ -717,6 +921,8 @@ grb_info grb::oc_tables_build(const Index* d_ptr, const Index* d_ind, const std:
       }
     }
     if (bounds.back() != n) bounds.push_back(n);
+    if (!fit || (long long)bounds.size() - 1 <= G || (nbins + max_bins - 1) / max_bins > G) break;   // fits, or never can
+    target += std::max<long long>(1, target / 32);
   }
   const long long R = (long long)bounds.size() - 1;
   if (R < 2 || (long long)rows.size() * (R + 1) > (64ll << 20)) { (void)hipFree(p_rows); return GRB_SUCCESS; }
@@ -782,6 +988,21 @@ grb_info bfs_persistent_run(grb_vector v, grb_matrix A, grb_index source, grb_de
   a.hint = A->d_pull_hint;
   a.n = n;
   a.nnz = A->nvals;
+  // once per matrix: how many vertices have in-edges at all (the complement of the skip bitmap), and whether the two
+  // pointer arrays hold the same numbers (the same array, or equal host mirrors)
+  if (A->bfs_n_in < 0) {
+    std::vector<unsigned int> h_skip((size_t)nwords);
+    GRB_HIP_TRY(hipMemcpyAsync(h_skip.data(), A->d_no_in_edges, 4 * (size_t)nwords, hipMemcpyDeviceToHost, s));
+    GRB_HIP_TRY(hipStreamSynchronize(s));
+    long long empty = 0;
+    for (unsigned int w : h_skip) empty += __builtin_popcount(w);
+    A->bfs_n_in = (long long)nwords * 32 - empty;           // the padding bits beyond n are set in the skip bitmap
+    A->bfs_out_is_in = A->csr.ptr == A->csc.ptr ||
+                       (A->h_csr_ptr.size() == (size_t)n + 1 && A->h_csc_ptr.size() == (size_t)n + 1 &&
+                        memcmp(A->h_csr_ptr.data(), A->h_csc_ptr.data(), sizeof(Index) * ((size_t)n + 1)) == 0);
+  }
+  a.n_in = A->bfs_n_in;
+  a.out_is_in = A->bfs_out_is_in ? 1 : 0;
   a.source = source;
   a.mode = desc->desc[GRB_MXVMODE];
   a.switchpoint = desc->switchpoint;

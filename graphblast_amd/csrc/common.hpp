@@ -544,6 +544,8 @@ struct grb_matrix_s {
   double mean_value = -1.0;                      // < 0 unknown (sssp_nearfar: the bucket width)
   int small_int_values = -1;                     // -1 unknown, else whether every stored value is an integer in [0, 2^20]
   grb::Index* d_pull_hint = nullptr;                  // per vertex: its in-neighbour of largest out-degree (bfs_fused)
+  long long bfs_n_in = -1;                       // vertices with in-edges (-1 unknown) and whether csr.ptr == csc.ptr in
+  bool bfs_out_is_in = false;                    // content (bfs_persist.hip: sparse pull levels, degree bookkeeping)
   // bfs_persist.hip, owner-computes push: destination ranges of equal in-edge mass, the big rows' numbers and where
   // each big row enters each range ([oc_nb + 1][oc_nrows]); oc_state: 0 not tried, 1 ready, -1 not applicable
   grb::Index* d_oc_bounds = nullptr;

@@ -778,6 +778,7 @@ void grb::matrix_release_device(grb_matrix A) {
   if (A->d_no_in_edges) { (void)hipFree(A->d_no_in_edges); A->d_no_in_edges = nullptr; }
   if (A->d_empty_csr_rows) { (void)hipFree(A->d_empty_csr_rows); A->d_empty_csr_rows = nullptr; }
   if (A->d_pull_hint) { (void)hipFree(A->d_pull_hint); A->d_pull_hint = nullptr; }
+  A->bfs_n_in = -1; A->bfs_out_is_in = false;
   if (A->d_oc_bounds) { (void)hipFree(A->d_oc_bounds); A->d_oc_bounds = nullptr; }
   if (A->d_oc_off) { (void)hipFree(A->d_oc_off); A->d_oc_off = nullptr; }
   if (A->d_oc_bigidx) { (void)hipFree(A->d_oc_bigidx); A->d_oc_bigidx = nullptr; }

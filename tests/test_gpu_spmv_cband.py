@@ -227,7 +227,15 @@ def test_values_rewritten_in_place_are_seen_by_the_next_product():
     from graphblast_amd.api import _semiring_id
     from graphblast_amd.graphgen import rmat_edges, finalize_edges
     dev = torch.device("cuda", 0)
-    assert g.spmv_set_format(-1) == 1
+    before = g.spmv_set_format(-1)                      # the module's `forced` fixture may still be in force
+    g.spmv_set_format(1)
+    try:
+        _values_rewritten(g, torch, dev, _lib, _semiring_id, rmat_edges, finalize_edges)
+    finally:
+        g.spmv_set_format(before)
+
+
+def _values_rewritten(g, torch, dev, _lib, _semiring_id, rmat_edges, finalize_edges):
     src, dst, n = rmat_edges(18, 16, seed=9, device=dev)
     gr = finalize_edges(src, dst, n, symmetrize=True)
     ptr, ind = gr["csr"][0].cpu().numpy(), gr["csr"][1].cpu().numpy()
