@@ -53,7 +53,6 @@ constexpr int kSmallDeg = 16;     // below: expanded inline by the discovering l
 constexpr int kBigDeg = 512;      // from here: split into kBigChunk-edge entries for workgroups
 constexpr int kBigChunk = 1024;
 constexpr int kPullBlock = GRB_PULL_BLOCK;    // chunks (of 64 vertices) one wave carries through the pull stages together
-constexpr int kPullGroup = 16;    // lanes finishing one undecided row in the pull phase
 constexpr int kMedCap = 4096;     // LDS list of medium vertices per workgroup pass
 constexpr int kKeep = 32;         // levels whose discovered-bitmaps are kept for the final label pass
 
@@ -135,14 +134,160 @@ __device__ inline void push_visit(const PersistArgs& a, unsigned int* V, unsigne
   discovered(a, dst, new_label, c);
 }
 
+// ---- pull levels: what a wave does with the rows its first probe (the hinted in-neighbour) did not settle --------
+// They are QUEUED in the wave's LDS ({next entry, end}, id of the vertex inside the wave's block) and then taken
+// dense: kPullR rows per lane and round for the first kPullProbe entries (one 16-byte load + four bitmap probes per
+// row, all rounds' loads in flight together), survivors written back to the front of the queue; then the survivors'
+// remaining entries are laid end to end and dealt to the lanes, 256 entries per step, whatever the rows' lengths
+// (offsets by a wave scan, a lane's row by a 6-step search) -- a step is one index load + one probe for 256 entries.
+// A row contributes at most `cap` entries per pass (64, doubling): a hub with an early hit is not read to its end.
+// The first hit of a row is the smallest offset that hits (LDS atomicMin), so the inspected-edge count stays the
+// sequential early-exit count of the oracle: entries up to and including the first hit, or all of them.
+constexpr int kPullQueue = kPullBlock * kWave;      // rows a wave can queue: every vertex of its block
+constexpr int kPullR = 4;                           // rows per lane and round of the first-entries stage
+struct PullLds {
+  int2 row[kPullQueue];                             // {next entry, end}
+  unsigned short id[kPullQueue];
+  unsigned int found[32];                           // bit id: the row had a hit
+  int off[kWave], nxt[kWave], hit[kWave];           // dealing a pass: first slot / first entry / smallest hitting offset
+  WaveBits bits;                                    // sparse active sets: the active bits numbered (wave_for_each_bit)
+  unsigned int fresh_bits[kSparseWords];            // ... and what they discovered, by word
+};
+
+// T rows are queued; afterwards found[] has the bit of every queued row with an in-neighbour in vin.
+__device__ __forceinline__ void pull_queue_run(const PersistArgs& a, const unsigned int* __restrict__ vin, PullLds& L,
+                                               int lane, int T, LevelCounters& c) {
+  const unsigned long long lt_mask = (1ull << lane) - 1ull;
+  int S = 0;                                                       // survivors, compacted to the front of the queue
+  if (a.nnz >= kPullProbe) {
+    const Index last = (Index)a.nnz - kPullProbe;
+    for (int q0 = 0; q0 < T; q0 += kWave * kPullR) {
+      int2 it[kPullR];
+      int id[kPullR];
+      Quad cq[kPullR];
+#pragma unroll
+      for (int k = 0; k < kPullR; ++k) {
+        const int qi = q0 + k * kWave + lane;
+        const bool valid = qi < T;
+        it[k] = valid ? L.row[qi] : make_int2(0, 0);
+        id[k] = valid ? (int)L.id[qi] : 0;
+      }
+#pragma unroll
+      for (int k = 0; k < kPullR; ++k) {
+        Index at = it[k].x;
+        const int shift = at > last ? at - last : 0;               // only the final entries of the array
+        at -= shift;
+        cq[k] = *reinterpret_cast<const Quad*>(a.iind + at);
+        for (int t = 0; t < shift; ++t) { cq[k].x = cq[k].y; cq[k].y = cq[k].z; cq[k].z = cq[k].w; }
+      }
+      unsigned int wq[kPullR][kPullProbe];
+#pragma unroll
+      for (int k = 0; k < kPullR; ++k) {
+        const Index len = it[k].y - it[k].x;
+        const Index c4[kPullProbe] = {cq[k].x, cq[k].y, cq[k].z, cq[k].w};
+#pragma unroll
+        for (int t = 0; t < kPullProbe; ++t) wq[k][t] = vin[t < len ? (c4[t] >> 5) : 0];
+      }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int k = 0; k < kPullR; ++k) {
+        const Index len = it[k].y - it[k].x;
+        const Index c4[kPullProbe] = {cq[k].x, cq[k].y, cq[k].z, cq[k].w};
+        int first = -1;
+#pragma unroll
+        for (int t = kPullProbe - 1; t >= 0; --t)
+          if (t < len && ((wq[k][t] >> (c4[t] & 31)) & 1u)) first = t;
+        const int seen = first >= 0 ? first + 1 : (len < kPullProbe ? (int)len : kPullProbe);
+        c.inspected += (unsigned long long)seen;
+        if (first >= 0) atomicOr(&L.found[id[k] >> 5], 1u << (id[k] & 31));
+        const bool surv = first < 0 && len > kPullProbe;
+        const unsigned long long m = __ballot(surv);
+        if (surv) {
+          const int slot = S + __popcll(m & lt_mask);
+          L.row[slot] = make_int2(it[k].x + kPullProbe, it[k].y);
+          L.id[slot] = (unsigned short)id[k];
+        }
+        S += __popcll(m);
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  } else {
+    S = T;                                                         // a matrix of fewer than four entries: all left over
+  }
+  for (int g0 = 0; g0 < S; g0 += kWave) {
+    const int gi = g0 + lane;
+    bool alive = gi < S;
+    Index nx = 0, en = 0;
+    int id = 0;
+    if (alive) { const int2 r = L.row[gi]; nx = r.x; en = r.y; id = L.id[gi]; }
+    alive = alive && nx < en;
+    Index cap = kWave;
+    while (__ballot(alive)) {
+      const Index rem = alive ? (en - nx < cap ? en - nx : cap) : 0;
+      Index incl = rem;
+#pragma unroll
+      for (int o = 1; o < kWave; o <<= 1) {
+        const Index y = __shfl_up(incl, o, kWave);
+        if (lane >= o) incl += y;
+      }
+      const Index total = __shfl(incl, kWave - 1, kWave);
+      __builtin_amdgcn_wave_barrier();
+      L.off[lane] = incl - rem;
+      L.nxt[lane] = nx;
+      L.hit[lane] = 0x7fffffff;
+      __builtin_amdgcn_wave_barrier();
+      for (Index t0 = 0; t0 < total; t0 += 4 * kWave) {
+        int r[4];
+        Index o[4], col[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const Index t = t0 + j * kWave + lane;
+          r[j] = -1;
+          o[j] = 0;
+          col[j] = 0;
+          if (t < total) {
+            int x = 0;                                             // the last row whose first slot is <= t
+#pragma unroll
+            for (int step = kWave / 2; step > 0; step >>= 1)
+              if (L.off[x + step] <= t) x += step;
+            r[j] = x;
+            o[j] = t - L.off[x];
+            col[j] = a.iind[L.nxt[x] + o[j]];
+          }
+        }
+        unsigned int w[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w[j] = vin[col[j] >> 5];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (r[j] >= 0 && ((w[j] >> (col[j] & 31)) & 1u)) atomicMin(&L.hit[r[j]], (int)o[j]);
+      }
+      __builtin_amdgcn_wave_barrier();
+      const int h = L.hit[lane];
+      if (alive) {
+        if (h != 0x7fffffff) {
+          c.inspected += (unsigned long long)(h + 1);
+          atomicOr(&L.found[id >> 5], 1u << (id & 31));
+          alive = false;
+        } else {
+          c.inspected += (unsigned long long)rem;
+          nx += rem;
+          alive = nx < en;
+        }
+      }
+      if (cap < 4096) cap <<= 1;
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+
 __global__ __launch_bounds__(kPThreads) void bfs_persistent_kernel(PersistArgs a) {
   __shared__ unsigned long long s_red[kPWaves][4];
   __shared__ unsigned long long s_tot[4];
   __shared__ Index s_med[kMedCap];
   __shared__ int s_nmed;
-  __shared__ int2 s_left[kPWaves][kPullBlock * kWave / 2];        // pull leftovers per wave: {next, end}
-  __shared__ unsigned short s_leftid[kPWaves][kPullBlock * kWave / 2];
-  __shared__ unsigned int s_leftfound[kPWaves][2 * kPullBlock];
+  __shared__ PullLds s_pull[kPWaves];                              // one per wave: the pull levels' row queue
   __shared__ unsigned int s_ocw[kOcWords];
   int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
   const int G = gridDim.x;
@@ -326,7 +471,7 @@ __global__ __launch_bounds__(kPThreads) void bfs_persistent_kernel(PersistArgs a
                 const Index total = __shfl(inc, kWave - 1, kWave);
                 if (total == 0) continue;
                 __builtin_amdgcn_wave_barrier();
-                s_left[wave][lane] = make_int2(inc - len, o0);
+                s_pull[wave].row[lane] = make_int2(inc - len, o0);
                 __builtin_amdgcn_wave_barrier();
                 for (Index at0 = 0; at0 < total; at0 += 4 * kWave) {
                   Index q[4];
@@ -338,8 +483,8 @@ __global__ __launch_bounds__(kPThreads) void bfs_persistent_kernel(PersistArgs a
                       int r = 0;                           // the last entry whose first edge is <= at
 #pragma unroll
                       for (int step = kWave / 2; step > 0; step >>= 1)
-                        if (s_left[wave][r + step].x <= at) r += step;
-                      q[j] = s_left[wave][r].y + (at - s_left[wave][r].x);
+                        if (s_pull[wave].row[r + step].x <= at) r += step;
+                      q[j] = s_pull[wave].row[r].y + (at - s_pull[wave].row[r].x);
                     }
                   }
                   Index d[4];
@@ -406,9 +551,6 @@ __global__ __launch_bounds__(kPThreads) void bfs_persistent_kernel(PersistArgs a
       // faster through L1 with ordinary loads, so it pays the invalidate itself, once.
       if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
       __syncthreads();
-      // One wave owns a block of 16 chunks = 1024 vertices = 32 bitmap words and runs every
-      // stage for all 16 chunks at once, so a stage costs one memory latency per block instead
-      // of one per chunk:  words -> hint probe -> four serial probes -> leftovers -> outputs.
       const unsigned int* vin = a.V[cur];
       unsigned int* vout = a.V[cur ^ 1];
       const Index* hint = a.count_inspected ? nullptr : a.hint;
@@ -416,19 +558,15 @@ __global__ __launch_bounds__(kPThreads) void bfs_persistent_kernel(PersistArgs a
       const Index nblocks = (nchunks + kPullBlock - 1) / kPullBlock;
       const Index nwaves = (Index)G * kPWaves;
       const unsigned long long lt_mask = (1ull << lane) - 1ull;
+      PullLds& L = s_pull[wave];
       // Few vertices are left to discover (the levels after the big one): the dense walk below would carry 512-vertex
-      // blocks with a handful of live lanes through every stage.  Here a wave numbers the active bits of kSparseWords
-      // bitmap words (wave_for_each_bit) and takes them 64 at a time, one vertex per lane: the same stages, every lane
-      // busy, one step where the dense walk takes two passes of eight chunks.  Same discoveries, same accounting.
+      // blocks with a handful of live lanes through its stages.  Here a wave numbers the active bits of kSparseWords
+      // bitmap words (wave_for_each_bit) and takes them 64 at a time, one vertex per lane.  Same discoveries, same
+      // accounting.
       const bool sparse_act = GRB_BFS_SPARSE_PULL && a.n_in >= 0 &&
                               (a.n_in - reached) * GRB_BFS_SPARSE_DIV < (long long)n;
       if (sparse_act) {
-        int2* lq = s_left[wave];                                            // [0, 64): leftover rows {next, end}
-        WaveBits* sb = reinterpret_cast<WaveBits*>(s_left[wave] + kWave);    // 512 B
-        unsigned int* s_new = reinterpret_cast<unsigned int*>(s_left[wave] + 2 * kWave);   // [kSparseWords] new bits
-        unsigned int* lf = s_leftfound[wave];                               // 64 flags of the leftover rows
         const Index ngroups = (Index)((nwords + kSparseWords - 1) / kSparseWords);
-        const int grp = lane >> 4, gl = lane & 15;
         for (Index g = (Index)blockIdx.x * kPWaves + wave; g < ngroups; g += nwaves) {
           const Index wi = g * kSparseWords + lane;
           const bool has_word = lane < kSparseWords && wi < nwords;
@@ -438,77 +576,30 @@ __global__ __launch_bounds__(kPThreads) void bfs_persistent_kernel(PersistArgs a
             if (has_word) publish(&vout[wi], vw);
             continue;
           }
-          if (lane < kSparseWords) s_new[lane] = 0u;
-          wave_for_each_bit(sb, act, lane, [&](int L, int bit) {
-            const bool on = L >= 0;
-            const Index v = on ? (g * kSparseWords + L) * 32 + bit : 0;
+          if (lane < kSparseWords) L.fresh_bits[lane] = 0u;
+          wave_for_each_bit(&L.bits, act, lane, [&](int wl, int bit) {
+            const bool on = wl >= 0;
+            const Index v = on ? (g * kSparseWords + wl) * 32 + bit : 0;
             const Index hv = hint ? hint[v] : 0;
             const Index p = a.iptr[v], e = a.iptr[v + 1];
             bool found = false;
             if (hint) found = on && bit_set(vin, hv);
-            bool und = on && !found && p < e;
-            Index next = p;
-            if (__ballot(und)) {
-              if (a.nnz >= kPullProbe) {
-                Index at = und ? p : 0;
-                const Index last = (Index)a.nnz - kPullProbe;
-                const int shift = at > last ? at - last : 0;
-                at -= shift;
-                Quad cq = *reinterpret_cast<const Quad*>(a.iind + at);
-                for (int t = 0; t < shift; ++t) { cq.x = cq.y; cq.y = cq.z; cq.z = cq.w; }
-                const Index len = und ? e - p : 0;
-                const Index c4[kPullProbe] = {cq.x, cq.y, cq.z, cq.w};
-                unsigned int wq[kPullProbe];
-#pragma unroll
-                for (int k = 0; k < kPullProbe; ++k) wq[k] = vin[k < len ? (c4[k] >> 5) : 0];
-                int first = -1;
-#pragma unroll
-                for (int k = kPullProbe - 1; k >= 0; --k)
-                  if (k < len && ((wq[k] >> (c4[k] & 31)) & 1u)) first = k;
-                const int seen = first >= 0 ? first + 1 : (len < kPullProbe ? (int)len : kPullProbe);
-                c.inspected += (unsigned long long)seen;
-                if (first >= 0) { found = true; und = false; }
-                next = p + kPullProbe;
-                if (next >= e) und = false;
+            const bool und = on && !found && p < e;
+            const unsigned long long um = __ballot(und);
+            if (um) {
+              if (lane < 2) L.found[lane] = 0u;
+              if (und) {
+                const int slot = __popcll(um & lt_mask);
+                L.row[slot] = make_int2(p, e);
+                L.id[slot] = (unsigned short)lane;
               }
-              // rows with entries left: 16 lanes per row through the wave's LDS queue
-              const unsigned long long um = __ballot(und);
-              if (um) {
-                if (lane < 2) lf[lane] = 0u;
-                if (und) lq[__popcll(um & lt_mask)] = make_int2(next, e);
-                if (und) s_leftid[wave][__popcll(um & lt_mask)] = (unsigned short)lane;
-                const int qn = __popcll(um);
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                for (int q0 = 0; q0 < qn; q0 += kWave / kPullGroup) {
-                  const int qi = q0 + grp;
-                  Index rs = 0, re = 0;
-                  int id = 0;
-                  if (qi < qn) { const int2 r = lq[qi]; rs = r.x; re = r.y; id = s_leftid[wave][qi]; }
-                  bool done = false;
-                  for (Index q = rs; __any(q < re && !done); q += kPullGroup) {
-                    bool h = false;
-                    const bool live = q < re && !done;
-                    if (live && q + gl < re) h = bit_set(vin, a.iind[q + gl]);
-                    const unsigned int hb = (unsigned int)(__ballot(h) >> (grp * kPullGroup)) & ((1u << kPullGroup) - 1u);
-                    if (live && gl == 0) {
-                      const Index span = (re - q < kPullGroup) ? re - q : kPullGroup;
-                      c.inspected += hb ? (unsigned long long)__ffs((int)hb) : (unsigned long long)span;
-                    }
-                    if (live && hb) {
-                      done = true;
-                      if (gl == 0) atomicOr(&lf[id >> 5], 1u << (id & 31));
-                    }
-                  }
-                }
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                if (und && ((lf[lane >> 5] >> (lane & 31)) & 1u)) found = true;
-                __builtin_amdgcn_wave_barrier();
-              }
+              __builtin_amdgcn_wave_barrier();
+              pull_queue_run(a, vin, L, lane, __popcll(um), c);
+              if (und && ((L.found[lane >> 5] >> (lane & 31)) & 1u)) found = true;
+              __builtin_amdgcn_wave_barrier();
             }
             if (found) {
-              atomicOr(&s_new[L], 1u << bit);
+              atomicOr(&L.fresh_bits[wl], 1u << bit);
               Index d;
               if (GRB_BFS_SYM && a.out_is_in) d = e - p;
               else d = a.optr[v + 1] - a.optr[v];
@@ -518,18 +609,20 @@ __global__ __launch_bounds__(kPThreads) void bfs_persistent_kernel(PersistArgs a
               if (direct) a.label[v] = new_label;
             }
           });
-          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
           __builtin_amdgcn_wave_barrier();
           if (has_word) {
-            const unsigned int nb = s_new[lane];
+            const unsigned int nb = L.fresh_bits[lane];
             publish(&vout[wi], vw | nb);
             if (nb) publish(&Fn[wi], nb);
           }
           __builtin_amdgcn_wave_barrier();
         }
       } else
+      // One wave owns a block of kPullBlock chunks of 64 vertices and runs every stage for all of them at once, so a
+      // stage costs one memory latency per block instead of one per chunk:  words -> hint probe (the row pointers
+      // travel with it) -> the rows it did not settle, queued and taken dense (pull_queue_run) -> outputs.
       for (Index blk = (Index)blockIdx.x * kPWaves + wave; blk < nblocks; blk += nwaves) {
-        // ---- stage 0: the block's 32 words; a lane's 16 vertices are vbase + 64 j
+        // ---- stage 0: the block's words; a lane's vertices are vbase + 64 j
         const Index wi = blk * (2 * kPullBlock) + lane;
         const bool has_word = lane < 2 * kPullBlock && wi < nwords;
         unsigned int vw = 0xffffffffu, inact = 0xffffffffu;
@@ -568,109 +661,33 @@ __global__ __launch_bounds__(kPThreads) void bfs_persistent_kernel(PersistArgs a
           }
         }
         unsigned int und = act & ~fnd;
+#pragma unroll
+        for (int j = 0; j < kPullBlock; ++j)
+          if (p[j] >= e[j]) und &= ~(1u << j);
         if (__ballot(und != 0u)) {
-          // ---- stage 2: the first kPullProbe entries of every undecided row in one 16-byte
-          // load, probed together; the accounting stays the sequential early-exit count
-          if (a.nnz >= kPullProbe) {
+          // ---- the undecided rows, queued in lane order
+          if (lane < 2 * kPullBlock) L.found[lane] = 0u;
+          const int mine = __popc(und);
+          int incl = mine;
 #pragma unroll
-            for (int half = 0; half < 2; ++half) {     // two halves: bounds the registers in flight
-              constexpr int H = kPullBlock / 2;
-              Quad cq[H];
-#pragma unroll
-              for (int jj = 0; jj < H; ++jj) {
-                const int j = half * H + jj;
-                const bool nd = ((und >> j) & 1u) && p[j] < e[j];
-                Index at = nd ? p[j] : 0;
-                const Index last = (Index)a.nnz - kPullProbe;
-                const int shift = at > last ? at - last : 0;      // only the final entries of the array
-                at -= shift;
-                cq[jj] = *reinterpret_cast<const Quad*>(a.iind + at);
-                for (int t = 0; t < shift; ++t) { cq[jj].x = cq[jj].y; cq[jj].y = cq[jj].z; cq[jj].z = cq[jj].w; }
-              }
-              unsigned int wq[H][kPullProbe];
-#pragma unroll
-              for (int jj = 0; jj < H; ++jj) {
-                const int j = half * H + jj;
-                const Index len = ((und >> j) & 1u) ? e[j] - p[j] : 0;
-                const Index c4[kPullProbe] = {cq[jj].x, cq[jj].y, cq[jj].z, cq[jj].w};
-#pragma unroll
-                for (int k = 0; k < kPullProbe; ++k) wq[jj][k] = vin[k < len ? (c4[k] >> 5) : 0];
-              }
-#pragma unroll
-              for (int jj = 0; jj < H; ++jj) {
-                const int j = half * H + jj;
-                const Index len = ((und >> j) & 1u) ? e[j] - p[j] : 0;
-                const Index c4[kPullProbe] = {cq[jj].x, cq[jj].y, cq[jj].z, cq[jj].w};
-                int first = -1;
-#pragma unroll
-                for (int k = kPullProbe - 1; k >= 0; --k)
-                  if (k < len && ((wq[jj][k] >> (c4[k] & 31)) & 1u)) first = k;
-                const int seen = first >= 0 ? first + 1 : (len < kPullProbe ? (int)len : kPullProbe);
-                c.inspected += (unsigned long long)seen;
-                if (first >= 0) { fnd |= 1u << j; und &= ~(1u << j); }
-              }
-              asm volatile("" ::: "memory");
-            }
-          } else {
-#pragma unroll
-            for (int j = 0; j < kPullBlock; ++j) p[j] -= kPullProbe;    // tiny matrix: everything is a leftover
+          for (int o = 1; o < kWave; o <<= 1) {
+            const int y = __shfl_up(incl, o, kWave);
+            if (lane >= o) incl += y;
           }
-          // rows with nothing left are decided (not discoverable this level)
+          const int T = __shfl(incl, kWave - 1, kWave);
+          int at = incl - mine;
 #pragma unroll
           for (int j = 0; j < kPullBlock; ++j)
-            if (p[j] + kPullProbe >= e[j]) und &= ~(1u << j);
-          // ---- leftovers: queue them in this wave's LDS region, then 16 lanes per row
-          if (__ballot(und != 0u)) {
-            int2* lq = s_left[wave];
-            unsigned int* lf = s_leftfound[wave];
-            if (lane < 2 * kPullBlock) lf[lane] = 0u;
-            const int grp = lane >> 4, gl = lane & 15;
-#pragma unroll
-            for (int half = 0; half < 2; ++half) {      // the queue holds half a block's rows
-              int qn = 0;
-#pragma unroll
-              for (int jj = 0; jj < kPullBlock / 2; ++jj) {
-                const int j = half * (kPullBlock / 2) + jj;
-                const unsigned long long m = __ballot((und >> j) & 1u);
-                if ((und >> j) & 1u) {
-                  const int slot = qn + __popcll(m & lt_mask);
-                  lq[slot] = make_int2(p[j] + kPullProbe, e[j]);
-                  s_leftid[wave][slot] = (unsigned short)(j * kWave + lane);
-                }
-                qn += __popcll(m);
-              }
-              __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-              __builtin_amdgcn_wave_barrier();
-              for (int q0 = 0; q0 < qn; q0 += kWave / kPullGroup) {
-                const int qi = q0 + grp;
-                Index rs = 0, re = 0;
-                int id = 0;
-                if (qi < qn) { const int2 r = lq[qi]; rs = r.x; re = r.y; id = s_leftid[wave][qi]; }
-                bool done = false;
-                for (Index q = rs; __any(q < re && !done); q += kPullGroup) {
-                  bool h = false;
-                  const bool live = q < re && !done;
-                  if (live && q + gl < re) h = bit_set(vin, a.iind[q + gl]);
-                  const unsigned int hb = (unsigned int)(__ballot(h) >> (grp * kPullGroup)) & ((1u << kPullGroup) - 1u);
-                  if (live && gl == 0) {
-                    const Index span = (re - q < kPullGroup) ? re - q : kPullGroup;
-                    c.inspected += hb ? (unsigned long long)__ffs((int)hb) : (unsigned long long)span;
-                  }
-                  if (live && hb) {
-                    done = true;
-                    if (gl == 0) atomicOr(&lf[id >> 5], 1u << (id & 31));
-                  }
-                }
-              }
-              __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-              __builtin_amdgcn_wave_barrier();
+            if ((und >> j) & 1u) {
+              L.row[at] = make_int2(p[j], e[j]);
+              L.id[at] = (unsigned short)(j * kWave + lane);
+              ++at;
             }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_wave_barrier();
+          pull_queue_run(a, vin, L, lane, T, c);
 #pragma unroll
-            for (int j = 0; j < kPullBlock; ++j) fnd |= ((lf[2 * j + (lane >> 5)] >> (lane & 31)) & 1u) << j;
-            __builtin_amdgcn_wave_barrier();
-          }
+          for (int j = 0; j < kPullBlock; ++j) fnd |= ((L.found[2 * j + (lane >> 5)] >> (lane & 31)) & 1u) << j;
+          __builtin_amdgcn_wave_barrier();
         }
         // ---- outputs: new words, labels, accounting
         unsigned int nb = 0;
@@ -686,11 +703,10 @@ __global__ __launch_bounds__(kPThreads) void bfs_persistent_kernel(PersistArgs a
         if (__ballot(fnd != 0u)) {
           if (GRB_BFS_SYM && a.out_is_in) {
             // the out-degree is the in-degree: no second pair of row pointers, no dependent load at the end of the step
-            const Index adj = a.nnz >= kPullProbe ? 0 : kPullProbe;
 #pragma unroll
             for (int j = 0; j < kPullBlock; ++j)
               if ((fnd >> j) & 1u) {
-                const Index d = e[j] - p[j] - adj;
+                const Index d = e[j] - p[j];
                 ++c.found;
                 c.deg += (unsigned long long)d;
                 if (d >= kBigDeg) ++c.big;
