@@ -48,6 +48,12 @@ namespace grb {
 #ifndef GRB_BFS_RELAUNDER
 #define GRB_BFS_RELAUNDER 1
 #endif
+#ifndef GRB_BFS_LABEL_WORDS
+#define GRB_BFS_LABEL_WORDS 1
+#endif
+#ifndef GRB_BFS_SPARSE_FRESH
+#define GRB_BFS_SPARSE_FRESH 1
+#endif
 constexpr int kSparseWords = 32;  // bitmap words (of 32 vertices) a wave takes per step of a pull level with a sparse active set
 constexpr int kSmallDeg = 16;     // below: expanded inline by the discovering lane
 constexpr int kBigDeg = 512;      // from here: split into kBigChunk-edge entries for workgroups
@@ -155,7 +161,13 @@ struct PullLds {
 };
 
 // T rows are queued; afterwards found[] has the bit of every queued row with an in-neighbour in vin.
-__device__ __forceinline__ void pull_queue_run(const PersistArgs& a, const unsigned int* __restrict__ vin, PullLds& L,
+// kFresh: the bitmap is probed with agent-scope loads (a level with few probes skips the L1 invalidate instead).
+template <bool kFresh>
+__device__ __forceinline__ unsigned int probe_word(const unsigned int* vin, Index w) {
+  return kFresh ? fresh(&vin[w]) : vin[w];
+}
+template <bool kFresh>
+__device__ __forceinline__ void pull_queue_run(const PersistArgs& a, const unsigned int* vin, PullLds& L,
                                                int lane, int T, LevelCounters& c) {
   const unsigned long long lt_mask = (1ull << lane) - 1ull;
   int S = 0;                                                       // survivors, compacted to the front of the queue
@@ -186,7 +198,7 @@ __device__ __forceinline__ void pull_queue_run(const PersistArgs& a, const unsig
         const Index len = it[k].y - it[k].x;
         const Index c4[kPullProbe] = {cq[k].x, cq[k].y, cq[k].z, cq[k].w};
 #pragma unroll
-        for (int t = 0; t < kPullProbe; ++t) wq[k][t] = vin[t < len ? (c4[t] >> 5) : 0];
+        for (int t = 0; t < kPullProbe; ++t) wq[k][t] = probe_word<kFresh>(vin, t < len ? (c4[t] >> 5) : 0);
       }
       __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -257,7 +269,7 @@ __device__ __forceinline__ void pull_queue_run(const PersistArgs& a, const unsig
         }
         unsigned int w[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) w[j] = vin[col[j] >> 5];
+        for (int j = 0; j < 4; ++j) w[j] = probe_word<kFresh>(vin, col[j] >> 5);
 #pragma unroll
         for (int j = 0; j < 4; ++j)
           if (r[j] >= 0 && ((w[j] >> (col[j] & 31)) & 1u)) atomicMin(&L.hit[r[j]], (int)o[j]);
@@ -393,17 +405,32 @@ __global__ __launch_bounds__(kPThreads) void bfs_persistent_kernel(PersistArgs a
         }
       } else {
         unsigned* bcount = &st->big_count[iter & 1][0];
-        if (nbig > 0) {
-          // list the >= kBigDeg frontier vertices as 1024-edge entries (wave-aggregated append)
-          for (long long base = 0; base < nwords; base += gthreads) {
-            const long long i = base + gtid;
-            const unsigned int w = (i < nwords) ? fresh(&Fc[i]) : 0u;
-            int mine = 0;
-            for (unsigned int t = w; t; t &= t - 1) {
-              const Index v = (Index)i * 32 + (__ffs((int)t) - 1);
-              const Index d = a.optr[v + 1] - a.optr[v];
-              if (d >= kBigDeg) mine += heavy ? 1 : (d + kBigChunk - 1) / kBigChunk;
+        // One scan of the frontier bitmap (words interleaved over the workgroups) does everything that needs a
+        // vertex's degree: rows of >= kBigDeg entries are LISTED (wave-aggregated append; they are expanded after a
+        // barrier, by whole workgroups or by the owners of destination ranges), rows of < kSmallDeg entries are
+        // expanded by the lane that found them, the ones in between by a wave each (workgroup-local LDS list).
+        // A heavy level lists first and expands its small rows after the owners' phase (their racing atomics would
+        // otherwise sit in front of the barrier every workgroup waits at); any other level does both in one scan.
+        auto scan = [&](const bool do_list, const bool do_expand) {
+        if (tid == 0) s_nmed = 0;
+        __syncthreads();
+        for (long long base = 0; base < nwords; base += gthreads) {
+          const long long i = (base / G + tid) * G + blockIdx.x;      // word index, stride G inside the WG
+          const unsigned int w = (i < nwords) ? fresh(&Fc[i]) : 0u;
+          int mine = 0;
+          for (unsigned int t = w; t; t &= t - 1) {
+            const Index v = (Index)i * 32 + (__ffs((int)t) - 1);
+            const Index s = a.optr[v], e = a.optr[v + 1];
+            const Index d = e - s;
+            if (d >= kBigDeg) { mine += heavy ? 1 : (d + kBigChunk - 1) / kBigChunk; continue; }
+            if (!do_expand) continue;
+            if (d >= kSmallDeg) {
+              const int slot = atomicAdd(&s_nmed, 1);
+              if (slot < kMedCap) { s_med[slot] = v; continue; }
             }
+            for (Index p = s; p < e; ++p) push_visit(a, V, Fn, a.oind[p], new_label, c);
+          }
+          if (do_list) {
             int incl = mine;
 #pragma unroll
             for (int o = 1; o < kWave; o <<= 1) {
@@ -426,6 +453,21 @@ __global__ __launch_bounds__(kPThreads) void bfs_persistent_kernel(PersistArgs a
               }
             }
           }
+          if (!do_expand) continue;
+          __syncthreads();
+          const int nm = s_nmed < kMedCap ? s_nmed : kMedCap;
+          for (int k = wave; k < nm; k += kPWaves) {
+            const Index v = s_med[k];
+            const Index e = a.optr[v + 1];
+            for (Index p = a.optr[v] + lane; p < e; p += kWave) push_visit(a, V, Fn, a.oind[p], new_label, c);
+          }
+          __syncthreads();
+          if (tid == 0) s_nmed = 0;
+          __syncthreads();
+        }
+        };
+        if (heavy) scan(true, false); else scan(nbig > 0, true);
+        if (nbig > 0) {
           stamp();
           if (!grid_sync(&st->bar, gen, false)) return;
           stamp();
@@ -510,36 +552,9 @@ __global__ __launch_bounds__(kPThreads) void bfs_persistent_kernel(PersistArgs a
                 }
               }
             }
+            stamp();
+            scan(false, true);                             // the small and medium rows of a heavy level
           }
-        }
-        stamp();
-        // the rest of the frontier: words interleaved over the workgroups
-        if (tid == 0) s_nmed = 0;
-        __syncthreads();
-        for (long long base = 0; base < nwords; base += gthreads) {
-          const long long i = (base / G + tid) * G + blockIdx.x;      // word index, stride G inside the WG
-          unsigned int w = (i < nwords) ? fresh(&Fc[i]) : 0u;
-          for (; w; w &= w - 1) {
-            const Index v = (Index)i * 32 + (__ffs((int)w) - 1);
-            const Index s = a.optr[v], e = a.optr[v + 1];
-            const Index d = e - s;
-            if (d >= kBigDeg) continue;
-            if (d >= kSmallDeg) {
-              const int slot = atomicAdd(&s_nmed, 1);
-              if (slot < kMedCap) { s_med[slot] = v; continue; }
-            }
-            for (Index p = s; p < e; ++p) push_visit(a, V, Fn, a.oind[p], new_label, c);
-          }
-          __syncthreads();
-          const int nm = s_nmed < kMedCap ? s_nmed : kMedCap;
-          for (int k = wave; k < nm; k += kPWaves) {
-            const Index v = s_med[k];
-            const Index e = a.optr[v + 1];
-            for (Index p = a.optr[v] + lane; p < e; p += kWave) push_visit(a, V, Fn, a.oind[p], new_label, c);
-          }
-          __syncthreads();
-          if (tid == 0) s_nmed = 0;
-          __syncthreads();
         }
       }
       last_dir = 0;
@@ -549,8 +564,6 @@ __global__ __launch_bounds__(kPThreads) void bfs_persistent_kernel(PersistArgs a
       // The barriers of this kernel do not invalidate; push levels read other workgroups' words
       // with fresh().  A pull level probes the visited bitmap millions of times, which is
       // faster through L1 with ordinary loads, so it pays the invalidate itself, once.
-      if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      __syncthreads();
       const unsigned int* vin = a.V[cur];
       unsigned int* vout = a.V[cur ^ 1];
       const Index* hint = a.count_inspected ? nullptr : a.hint;
@@ -565,13 +578,18 @@ __global__ __launch_bounds__(kPThreads) void bfs_persistent_kernel(PersistArgs a
       // accounting.
       const bool sparse_act = GRB_BFS_SPARSE_PULL && a.n_in >= 0 &&
                               (a.n_in - reached) * GRB_BFS_SPARSE_DIV < (long long)n;
+      if (!sparse_act || !GRB_BFS_SPARSE_FRESH) {
+        if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        __syncthreads();
+      }
       if (sparse_act) {
+        constexpr bool kF = GRB_BFS_SPARSE_FRESH != 0;     // few probes: agent-scope loads instead of the invalidate
         const Index ngroups = (Index)((nwords + kSparseWords - 1) / kSparseWords);
         for (Index g = (Index)blockIdx.x * kPWaves + wave; g < ngroups; g += nwaves) {
           const Index wi = g * kSparseWords + lane;
           const bool has_word = lane < kSparseWords && wi < nwords;
           unsigned int vw = 0xffffffffu, act = 0u;
-          if (has_word) { vw = vin[wi]; act = ~(vw | a.skip[wi]); }
+          if (has_word) { vw = probe_word<kF>(vin, wi); act = ~(vw | a.skip[wi]); }
           if (__ballot(act != 0u) == 0ull) {
             if (has_word) publish(&vout[wi], vw);
             continue;
@@ -583,7 +601,7 @@ __global__ __launch_bounds__(kPThreads) void bfs_persistent_kernel(PersistArgs a
             const Index hv = hint ? hint[v] : 0;
             const Index p = a.iptr[v], e = a.iptr[v + 1];
             bool found = false;
-            if (hint) found = on && bit_set(vin, hv);
+            if (hint) found = on && ((probe_word<kF>(vin, hv >> 5) >> (hv & 31)) & 1u);
             const bool und = on && !found && p < e;
             const unsigned long long um = __ballot(und);
             if (um) {
@@ -594,7 +612,7 @@ __global__ __launch_bounds__(kPThreads) void bfs_persistent_kernel(PersistArgs a
                 L.id[slot] = (unsigned short)lane;
               }
               __builtin_amdgcn_wave_barrier();
-              pull_queue_run(a, vin, L, lane, __popcll(um), c);
+              pull_queue_run<kF>(a, vin, L, lane, __popcll(um), c);
               if (und && ((L.found[lane >> 5] >> (lane & 31)) & 1u)) found = true;
               __builtin_amdgcn_wave_barrier();
             }
@@ -684,7 +702,7 @@ __global__ __launch_bounds__(kPThreads) void bfs_persistent_kernel(PersistArgs a
               ++at;
             }
           __builtin_amdgcn_wave_barrier();
-          pull_queue_run(a, vin, L, lane, T, c);
+          pull_queue_run<false>(a, vin, L, lane, T, c);
 #pragma unroll
           for (int j = 0; j < kPullBlock; ++j) fnd |= ((L.found[2 * j + (lane >> 5)] >> (lane & 31)) & 1u) << j;
           __builtin_amdgcn_wave_barrier();
@@ -787,6 +805,62 @@ __global__ __launch_bounds__(kPThreads) void bfs_persistent_kernel(PersistArgs a
   // discovered by a level >= kKeep and labelled there.  (V[cur] and every F are final after the last barrier.)
   {
     GRB_PHASE_START();
+#if GRB_BFS_LABEL_WORDS
+    // One bitmap word (32 vertices) per lane: the visited word and the word of every kept level go out together
+    // (agent-scope loads: no invalidate to wait for), so the pass is one memory latency deep; a lane then writes its
+    // 32 labels as eight 16-byte stores (a whole 128-byte line per lane).
+    const unsigned int* Vf = a.V[cur];
+    const int kept = levels + 1 < kKeep ? levels + 1 : kKeep;      // F[0 .. kept)
+    const bool label_aligned = (reinterpret_cast<unsigned long long>(a.label) & 15ull) == 0ull;
+    for (long long wi = gtid; wi < nwords; wi += gthreads) {
+      const unsigned int vis = fresh(&Vf[wi]);
+      unsigned int f[kKeep];
+#pragma unroll
+      for (int L0 = 0; L0 < kKeep; L0 += 8) {
+        if (L0 < kept) {
+#pragma unroll
+          for (int u = 0; u < 8; ++u) f[L0 + u] = L0 + u < kept ? fresh(&a.F[L0 + u][wi]) : 0u;
+        } else {
+#pragma unroll
+          for (int u = 0; u < 8; ++u) f[L0 + u] = 0u;
+        }
+      }
+      // vertical counters: bit b of plane k = bit k of the label of vertex 32 wi + b (levels < kKeep = 32: 6 planes)
+      unsigned int pl[6] = {0u, 0u, 0u, 0u, 0u, 0u};
+#pragma unroll
+      for (int L = 0; L < kKeep; ++L) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k)
+          if (((L + 1) >> k) & 1) pl[k] |= f[L];
+      }
+      const long long v0 = wi * 32;
+      // a vertex that is visited but in no kept bitmap was labelled by a level >= kKeep: its label stays
+      const unsigned int keepm = vis & ~(pl[0] | pl[1] | pl[2] | pl[3] | pl[4] | pl[5]);
+      if (v0 + 32 <= (long long)n && keepm == 0u && label_aligned) {
+        float4* out = reinterpret_cast<float4*>(a.label + v0);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          float x[4];
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const int b = q * 4 + t;
+            unsigned int lab = 0u;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) lab |= ((pl[k] >> b) & 1u) << k;
+            x[t] = (float)lab;
+          }
+          out[q] = make_float4(x[0], x[1], x[2], x[3]);
+        }
+      } else {
+        for (int b = 0; b < 32 && v0 + b < (long long)n; ++b) {
+          unsigned int lab = 0u;
+#pragma unroll
+          for (int k = 0; k < 6; ++k) lab |= ((pl[k] >> b) & 1u) << k;
+          if (!((keepm >> b) & 1u)) a.label[v0 + b] = (float)lab;
+        }
+      }
+    }
+#else
     // nothing is written any more: read the bitmaps through L1 (one invalidate), eight 64-vertex chunks per
     // wave step so that a step costs one memory latency, not one per level
     if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -837,6 +911,7 @@ __global__ __launch_bounds__(kPThreads) void bfs_persistent_kernel(PersistArgs a
         if (v < n && (lab[j] != 0u || !((vis[j] >> sh) & 1u))) a.label[v] = (float)lab[j];
       }
     }
+#endif
   }
   stamp();
   if (a.trace && gtid == 0) a.trace[0] = (unsigned long long)ntrace;
