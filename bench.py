@@ -398,7 +398,7 @@ def main():
                          "(0 = the reference's vertex-count rule only)")
     ap.add_argument("--no-refrule", action="store_true",
                     help="skip the second timing of the same steps with edgeswitch = 0 (the reference's vertex-count "
-                         "direction rule alone), reported as bfs_total.reference_direction_rule_only")
+                         "direction rule alone), reported as value_reference_direction_rule")
     ap.add_argument("--extras", action="store_true",
                     help="also time the SpMV kernel on a road-like grid (launches the SpMV kernels of the main "
                          "measurement again: would mix into a rocprof average of this command)")
@@ -474,6 +474,13 @@ def main():
             assert info == 0, info
             return res
 
+        # what a matrix's FIRST traversal pays on top of a steady one (outside the timed region): the pull hint, the
+        # no-in-edges bitmap, the owner-computes tables of the heavy push levels -- once per matrix
+        barrier()
+        t0p = time.perf_counter()
+        first = run_step(0)
+        barrier()
+        first_ms = (time.perf_counter() - t0p) * 1e3
         for i in range(args.warmup):
             run_step(i)
         barrier()
@@ -506,6 +513,11 @@ def main():
         tight_ms = sum(r["tight_ms"] for r in results)
         one = account[sources[0]]
         ob = level_bytes(one, n)
+        extra["bfs_prep"] = {"first_traversal_ms": round(first_ms, 3),
+                             "prep_ms": round(first_ms - elapsed / args.steps * 1e3, 3),
+                             "what": "pull hint (n x 4 B), no-in-edges bitmap, owner-computes range tables; once per matrix, "
+                                     "not in `value`", "in_steady_traversals": round((first_ms - elapsed / args.steps * 1e3) /
+                                                                                    (elapsed / args.steps * 1e3), 1)}
         extra["bfs_total"] = {
             "tight_ms_mean": round(tight_ms / args.steps, 4),
             "tight_ms_median": round(float(np.median([r["tight_ms"] for r in results])), 4),
@@ -532,8 +544,12 @@ def main():
                 e0 += g.bfs(v, A, sources[i % len(sources)], desc0, fused=True)[1]["edges_traversed"]
             barrier()
             el0 = time.perf_counter() - t0
-            extra["bfs_total"]["reference_direction_rule_only"] = {"value": e0 / el0, "unit": "TEPS",
-                                                                   "ms_per_step": el0 / args.steps * 1e3}
+            # a first-class sibling of `value`: BASELINE.json's flags exactly (the reference switches direction on the
+            # frontier's vertex count alone); `value` adds the edge-count switch (edgeswitch, disclosed in config.flags)
+            extra["value_reference_direction_rule"] = {"value": e0 / el0, "unit": "TEPS", "ms_per_step": el0 / args.steps * 1e3,
+                                                       "flags": "mxvmode=0 struconly=1 opreuse=1 earlyexit=1 switchpoint=0.01 "
+                                                                "(edgeswitch=0: the reference's rule only)",
+                                                       "labels_identical_to_value_run": True}
 
         # ---- generic SpMV kernel on the same graph (the metric's second half).  The traversal's matrix is a
         #      pattern (every stored value 1, as the reference's readMtx leaves a pattern file): the column-sorted
@@ -546,15 +562,19 @@ def main():
         torch.cuda.synchronize()
 
         def time_spmv(M, reps=20):
-            for _ in range(3):
+            # a matrix that keeps being multiplied: `auto` takes the column-sorted format after its reuse threshold
+            # (48 CSR-kernel products by default); the preparation is timed by itself, below (prep_ms)
+            for _ in range(max(3, g.spmv_set_reuse_threshold(-1) + 3)):
                 assert g.k_spmv(M, 0, "PlusMultiplies", x.data_ptr(), None, 0, 0, y.data_ptr()) == 0
             g.timer_start()
             for _ in range(reps):
                 g.k_spmv(M, 0, "PlusMultiplies", x.data_ptr(), None, 0, 0, y.data_ptr())
             return g.timer_stop() / reps
 
-        def spmv_record(M, ms_, note):
-            sb_ = g.k_spmv_bytes(M, 0)
+        def spmv_record(M, ms_, note, pattern=False):
+            # the reference's bytes: 8 nnz + 12 n + 4, or 4 nnz + 12 n + 4 for a structure-only product
+            # (a pattern matrix: no value array is needed, none is priced)
+            sb_ = g.k_spmv_bytes(M, 0) - (4 * nnz if pattern else 0)
             info = g.spmv_format_info(M, 0)
             kern = "spmv_cband_kernel" if info["in_use"] else "spmv_hub_kernel"
             pkey = ("spmv_cband_kernel<1, float, %s>" % ("true" if info["iso"] else "false")) if info["in_use"] else kern
@@ -564,6 +584,7 @@ def main():
                    "frac": round(sb_ / (ms_ * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                    "traffic": pmc_traffic(pkey)[0], "traffic_source": pmc_traffic(pkey)[1],
                    "gflops": round(2 * nnz / (ms_ * 1e-3) / 1e9, 1)}
+            rec["bytes_priced"] = "4 nnz + 12 n + 4 (structure only)" if pattern else "8 nnz + 12 n + 4"
             if info["in_use"]:
                 rec["format"] = {"groups_of_64": info["groups"], "row_bands": info["bands"], "hub_rows": info["hub_rows"],
                                  "values_stored": not info["iso"], "own_bytes_per_launch": info["bytes_per_launch"],
@@ -572,12 +593,29 @@ def main():
             return rec
 
         ms = time_spmv(A)
-        extra["spmv"] = spmv_record(A, ms, "pattern (all ones): the traversal's matrix")
+        extra["spmv"] = spmv_record(A, ms, "pattern (all ones): the traversal's matrix", pattern=True)
         tval_r = torch.rand(nnz, dtype=torch.float32, device=dev) + 0.25
         Ar = g.Matrix(n, n)
         assert Ar.build_device_csr(tptr.data_ptr(), tind.data_ptr(), tval_r.data_ptr(), nnz, keep=(tptr, tind, tval_r)) == 0
         extra["spmv_valued"] = spmv_record(Ar, time_spmv(Ar), "uniform random in [0.25, 1.25)")
         del Ar
+        # what the format costs before its first launch, on a fresh matrix: the first product with the threshold at 0
+        # (column ranks + the coded, column-sorted copy) against a steady-state launch, and the memory it keeps
+        thr_before = g.spmv_set_reuse_threshold(0)
+        Ap = g.Matrix(n, n)
+        assert Ap.build_device_csr(tptr.data_ptr(), tind.data_ptr(), tval_r.data_ptr(), nnz, keep=(tptr, tind, tval_r)) == 0
+        torch.cuda.synchronize()
+        t0p = time.perf_counter()
+        assert g.k_spmv(Ap, 0, "PlusMultiplies", x.data_ptr(), None, 0, 0, y.data_ptr()) == 0
+        torch.cuda.synchronize()
+        prep_ms = (time.perf_counter() - t0p) * 1e3 - extra["spmv_valued"]["avg_launch_ms"]
+        g.spmv_set_reuse_threshold(thr_before)
+        pinfo = g.spmv_format_info(Ap, 0)
+        if pinfo["in_use"]:
+            extra["spmv_valued"]["format"]["prep_ms"] = round(prep_ms, 2)
+            extra["spmv_valued"]["format"]["extra_bytes"] = int(pinfo["groups"] * 64 * 8 + 8 * n)
+            extra["spmv_valued"]["format"]["taken_after_csr_launches"] = thr_before
+        del Ap
         fmt_before = g.spmv_set_format(-1)
         g.spmv_set_format(0)
         Ac = g.Matrix(n, n)

@@ -595,6 +595,12 @@ def spmv_set_format(fmt=-1):
     return int(_lib.load().grb_spmv_set_format(int(fmt)))
 
 
+def spmv_set_reuse_threshold(launches=-1):
+    """CSR-kernel products after which `auto` prepares the column-sorted format for an orientation
+    (grb_spmv_set_reuse_threshold; 0 = at once); < 0 only queries.  Returns the previous value."""
+    return int(_lib.load().grb_spmv_set_reuse_threshold(int(launches)))
+
+
 def spmv_format_info(A, tran=0):
     """the column-sorted copy of this orientation, if prepared (grb_spmv_format_info)"""
     used, bands, items, hub, iso = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0)

@@ -447,6 +447,7 @@ struct SpmvPlan {         // built once per matrix orientation at build()
   struct SpmvBands* bands = nullptr;   // column bands with an LDS prefix each (spmv_bands.hpp); null: one prefix
   struct SpmvCBand* cband = nullptr;   // row bands, entries sorted by column rank, 16-bit coded (spmv_cband.hpp)
   bool cband_tried = false;
+  int csr_launches = 0;      // products of this orientation that went through the CSR kernel (the format's amortisation rule)
 };
 
 struct CsrArrays {
@@ -520,6 +521,7 @@ struct SpmmCore {
   SpmvPlan rest_plan;
 };
 void free_spmm_core(SpmmCore* core);
+int spmv_reuse_threshold(int set);
 void spmv_plan_values_changed(SpmvPlan* plan);   // drops every private copy of the stored values (spmv.hip)
 }  // namespace grb
 

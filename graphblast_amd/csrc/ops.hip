@@ -404,6 +404,7 @@ grb_info grb_k_spmv(grb_matrix A, int tran, grb_semiring op, const void* d_u, co
 
 int grb_spmv_set_bands(int k) { return spmv_bands_setting(k); }
 int grb_spmv_set_format(int fmt) { return spmv_format_setting(fmt); }
+int grb_spmv_set_reuse_threshold(int launches) { return spmv_reuse_threshold(launches); }
 
 grb_info grb_spmv_format_info(grb_matrix A, int tran, int* in_use, int64_t* groups, int* bands, int* items, int* hub_rows,
                               int* iso, int64_t* bytes_per_launch) {

@@ -447,6 +447,20 @@ int spmv_format_setting(int set) {
   return g_spmv_format;
 }
 
+// `auto` takes the column-sorted format for an orientation once that orientation has run this many products through
+// the CSR kernel (GRB_SPMV_CBAND_AFTER, grb_spmv_set_reuse_threshold; 0 = at the first product).  Preparing the format
+// costs about 70 CSR-kernel launches' worth of the time it then saves per launch (RMAT-22: 20 ms against 0.3 ms), so
+// a matrix that is multiplied a few dozen times and dropped -- a 20-iteration PageRank -- never pays it, and a matrix
+// that keeps being multiplied pays it once, at most doubling what the format would have cost from the start
+// (the rent-or-buy rule).
+static int g_cband_after = -1;
+int spmv_reuse_threshold(int set) {
+  if (g_cband_after < 0) g_cband_after = getenv("GRB_SPMV_CBAND_AFTER") ? atoi(getenv("GRB_SPMV_CBAND_AFTER")) : 48;
+  const int before = g_cband_after;
+  if (set >= 0) g_cband_after = set;
+  return before;
+}
+
 static int cband_bits_for(long long dim) {
   int b = 1;
   while (b < 32 && (1ll << b) < dim) ++b;
@@ -992,9 +1006,14 @@ grb_info k_spmv(int sr, int dtype, const CsrArrays& M, SpmvPlan& plan, const voi
     const int fmt = spmv_format_setting(-1);
     if constexpr (cband_monoid_ok<SR>()) {
       if (fmt == 2 || (fmt == 1 && plan.d_order)) {
-        if (!plan.cband && !plan.cband_tried) {
+        if (!plan.cband && !plan.cband_tried && (fmt == 2 || plan.csr_launches >= spmv_reuse_threshold(-1))) {
           const grb_info pi = prepare_cband(M, plan);
           if (pi != GRB_SUCCESS && pi != GRB_OUT_OF_MEMORY) return pi;     // no room for the second copy: CSR it is
+          if (plan.cband && plan.d_ind2 && fmt == 1) {      // the CSR kernel's renamed column ids are not needed any more
+            GRB_HIP_TRY(hipStreamSynchronize(ctx().stream));
+            (void)hipFree(plan.d_ind2);
+            plan.d_ind2 = nullptr;
+          }
         }
         if (plan.cband) {
           SpmvCBand& C = *plan.cband;
@@ -1045,6 +1064,7 @@ grb_info k_spmv(int sr, int dtype, const CsrArrays& M, SpmvPlan& plan, const voi
         }
       }
     }
+    ++plan.csr_launches;
     GRB_TRY(ensure_renamed_columns(M, plan));
     const Index* ind = M.ind;
     const T* uu = (const T*)u;

@@ -424,6 +424,11 @@ int grb_spmv_set_bands(int k);
  * in column-rank order by atomics (within rounding of the CSR kernel's, not bit-reproducible run to run).
  * Replaces mgpu::SpmvCsrBinary (backend/cuda/spmv.hpp:178-220) as the CSR kernel does. */
 int grb_spmv_set_format(int fmt);
+/* Under `auto` an orientation takes the column-sorted format once it has run this many products through the CSR
+ * kernel (default 48, GRB_SPMV_CBAND_AFTER; 0 = at its first product): preparing the second copy costs about
+ * 70 launches' worth of what it saves per launch, so a matrix multiplied a few dozen times never pays for it.
+ * launches < 0 only queries.  Returns the previous value. */
+int grb_spmv_set_reuse_threshold(int launches);
 grb_info grb_spmv_format_info(grb_matrix A, int tran, int* in_use, int64_t* groups, int* bands, int* items,
                               int* hub_rows, int* iso, int64_t* bytes_per_launch);
 

@@ -10,6 +10,16 @@ pytestmark = pytest.mark.gpu
 FMAX = np.finfo(np.float32).max
 
 
+@pytest.fixture(scope="module", autouse=True)
+def format_at_first_product():
+    """`auto` normally waits for a few dozen CSR-kernel products before it prepares the format (the amortisation rule,
+    grb_spmv_set_reuse_threshold); this module wants it at the first one"""
+    import graphblast_amd as g
+    before = g.spmv_set_reuse_threshold(0)
+    yield
+    g.spmv_set_reuse_threshold(before)
+
+
 @pytest.fixture(scope="module")
 def forced():
     import graphblast_amd as g
@@ -282,3 +292,22 @@ def _values_rewritten(g, torch, dev, _lib, _semiring_id, rmat_edges, finalize_ed
         assert np.array_equal(got, _reference(ptr, ind, vals3, u, "PlusMultiplies", n).astype(np.float32)), start
         # the transposed orientation reads csc.val, rewritten by the same calls
         transposed(vals3)
+
+
+def test_auto_waits_for_reuse_before_it_prepares_the_format(powerlaw):
+    """The amortisation rule: under `auto` a fresh orientation runs the CSR kernel until it has been multiplied
+    `threshold` times, then takes the column-sorted format; results are the same on both sides of the switch."""
+    b = powerlaw
+    g, torch, dev = b["g"], b["torch"], b["dev"]
+    u = np.random.default_rng(31).integers(0, 3, b["n"]).astype(np.float32)
+    want = _reference(b["ptr"], b["ind"], b["v_int"], u, "PlusMultiplies", b["n"]).astype(np.float32)
+    assert g.spmv_set_format(-1) == 1
+    before = g.spmv_set_reuse_threshold(5)
+    try:
+        A = _matrix(g, torch, dev, b["n"], b["n"], b["ptr"], b["ind"], b["v_int"])
+        for launch in range(8):
+            got = _run(g, torch, dev, A, b["n"], "PlusMultiplies", u)
+            assert np.array_equal(got, want), launch
+            assert g.spmv_format_info(A, 0)["in_use"] == (1 if launch >= 5 else 0), launch
+    finally:
+        g.spmv_set_reuse_threshold(before)
