@@ -41,7 +41,6 @@ constexpr int kPSmallDeg = 16;      // push: below, expanded by the lane that fo
 constexpr int kPBigDeg = 512;       // push: from here, cut into kPBigChunk-edge entries for whole workgroups
 constexpr int kPBigChunk = 1024;
 constexpr int kPPullBlock = 8;      // 64-vertex chunks a wave carries through the pull stages together
-constexpr int kPPullGroup = 16;     // lanes finishing one undecided row
 constexpr int kPMedCap = 4096;
 
 struct PartCarry {                  // the level loop's scalars: identical on every rank and in every workgroup
@@ -70,6 +69,7 @@ struct PartArgs {
   const Index *iptr, *iind;         // their in-edges
   long long innz;                   // stored in-edges of this shard
   const unsigned int* skip;         // local bitmap: owned vertices without in-edges (and the padding bits)
+  long long n_in_local;             // owned vertices WITH in-edges (-1 unknown)
   const Index* hint;                // local: the in-neighbour (global id) of largest out-degree; may be null
   const int* deg;                   // [n] out-degree of every vertex (replicated)
   Index n, lo, n_local;
@@ -118,13 +118,20 @@ __global__ __launch_bounds__(kPThreads) void bfs_part_level_kernel(PartArgs a) {
   __shared__ unsigned long long s_tot[3];
   __shared__ Index s_med[kPMedCap];
   __shared__ int s_nmed;
-  __shared__ int2 s_left[kPWaves][kPPullBlock * kWave / 2];
-  __shared__ unsigned short s_leftid[kPWaves][kPPullBlock * kWave / 2];
-  __shared__ unsigned int s_leftfound[kPWaves][2 * kPPullBlock];
+  __shared__ PullLds s_pull[kPWaves];                 // one per wave: the pull levels' row queue (persist_common.hpp)
   __shared__ unsigned int s_ocw[kOcWords];
-  const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
+  int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
   const int G = gridDim.x;
-  const long long gtid = (long long)blockIdx.x * kPThreads + tid;
+  long long gtid = (long long)blockIdx.x * kPThreads + tid;
+  // every phase starts from a thread id the optimiser cannot see through (bfs_persist.hip: what a phase derives from
+  // it lives in that phase only, instead of in registers across the whole kernel)
+#define GRB_PART_PHASE()                                          \
+  do {                                                            \
+    asm volatile("" : "+v"(tid));                                 \
+    lane = tid & (kWave - 1);                                     \
+    wave = tid >> 6;                                              \
+    gtid = (long long)blockIdx.x * kPThreads + tid;               \
+  } while (0)
   const long long gthreads = (long long)G * kPThreads;
   const Index n = a.n;
   const int nwords = 2 * ((n + 63) / 64);
@@ -176,6 +183,7 @@ __global__ __launch_bounds__(kPThreads) void bfs_part_level_kernel(PartArgs a) {
 
     if (iter > 1) {
       // ================= apply: what level iter - 1 discovered, on every rank =================
+      GRB_PART_PHASE();
       const bool count_only = iter > a.max_niter;        // the loop has ended: the last level is only counted
       const bool direct = (iter - 1) >= kPKeep;          // its bitmap will be recycled: label now
       const float lab = (float)iter;
@@ -305,6 +313,7 @@ __global__ __launch_bounds__(kPThreads) void bfs_part_level_kernel(PartArgs a) {
 
     if (!pull) {
       // ================= push: the owned frontier's out-edges =================
+      GRB_PART_PHASE();
       if (iter == 1) {
         if (a.source >= a.lo && a.source < a.lo + a.n_local) {
           const Index sl = a.source - a.lo;
@@ -355,7 +364,7 @@ __global__ __launch_bounds__(kPThreads) void bfs_part_level_kernel(PartArgs a) {
                 const Index total = __shfl(inc, kWave - 1, kWave);
                 if (total == 0) continue;
                 __builtin_amdgcn_wave_barrier();
-                s_left[wave][lane] = make_int2(inc - len, o0);
+                s_pull[wave].row[lane] = make_int2(inc - len, o0);
                 __builtin_amdgcn_wave_barrier();
                 for (Index at0 = 0; at0 < total; at0 += 4 * kWave) {
                   Index q[4], d[4];
@@ -367,8 +376,8 @@ __global__ __launch_bounds__(kPThreads) void bfs_part_level_kernel(PartArgs a) {
                       int r = 0;                           // the last entry whose first edge is <= at
 #pragma unroll
                       for (int step = kWave / 2; step > 0; step >>= 1)
-                        if (s_left[wave][r + step].x <= at) r += step;
-                      q[j] = s_left[wave][r].y + (at - s_left[wave][r].x);
+                        if (s_pull[wave].row[r + step].x <= at) r += step;
+                      q[j] = s_pull[wave].row[r].y + (at - s_pull[wave].row[r].x);
                     }
                   }
 #pragma unroll
@@ -421,16 +430,64 @@ __global__ __launch_bounds__(kPThreads) void bfs_part_level_kernel(PartArgs a) {
       }
     } else {
       // ================= pull: the owned unvisited vertices' in-edges =================
+      GRB_PART_PHASE();
+      const unsigned int* vin = a.V;
+      const Index* hint = a.hint;
+      const Index nwaves = (Index)G * kPWaves;
+      const unsigned long long lt_mask = (1ull << lane) - 1ull;
+      PullLds& L = s_pull[wave];
+      unsigned long long unused = 0;                       // the partitioned loop keeps no inspected-edge count
+      // Few owned vertices left to discover (this rank's share of what has been reached, taken as even): the active
+      // bits are numbered and taken 64 at a time, probed with agent-scope loads (no invalidate) -- as the one-launch
+      // kernel does.  Ranks may decide differently: both walks find the same vertices.
+      const bool sparse_act = a.n_in_local >= 0 &&
+                              (a.n_in_local - (cy.reached * (long long)a.n_local) / (long long)(n > 0 ? n : 1)) * 8 < (long long)a.n_local;
+      if (sparse_act) {
+        const Index ngroups = (Index)((local_words + kSparseWords - 1) / kSparseWords);
+        for (Index g = (Index)blockIdx.x * kPWaves + wave; g < ngroups; g += nwaves) {
+          const Index wl = g * kSparseWords + lane;
+          const bool has_word = lane < kSparseWords && wl < local_words;
+          unsigned int act = 0u;
+          if (has_word) act = ~(fresh(&vin[lo_w + wl]) | a.skip[wl]);
+          if (__ballot(act != 0u) == 0ull) continue;
+          if (lane < kSparseWords) L.fresh_bits[lane] = 0u;
+          wave_for_each_bit(&L.bits, act, lane, [&](int wlane, int bit) {
+            const bool on = wlane >= 0;
+            const Index v = on ? (g * kSparseWords + wlane) * 32 + bit : 0;     // local id
+            const Index hv = hint ? hint[v] : -1;
+            const Index p = a.iptr[v], e = a.iptr[v + 1];
+            bool found = false;
+            if (hv >= 0) found = on && ((fresh(&vin[hv >> 5]) >> (hv & 31)) & 1u);
+            const bool und = on && !found && p < e;
+            const unsigned long long um = __ballot(und);
+            if (um) {
+              if (lane < 2) L.found[lane] = 0u;
+              if (und) {
+                const int slot = __popcll(um & lt_mask);
+                L.row[slot] = make_int2(p, e);
+                L.id[slot] = (unsigned short)lane;
+              }
+              __builtin_amdgcn_wave_barrier();
+              pull_queue_run<true>(a.iind, a.innz, vin, L, lane, __popcll(um), unused);
+              if (und && ((L.found[lane >> 5] >> (lane & 31)) & 1u)) found = true;
+              __builtin_amdgcn_wave_barrier();
+            }
+            if (found) atomicOr(&L.fresh_bits[wlane], 1u << bit);
+          });
+          __builtin_amdgcn_wave_barrier();
+          if (has_word) {
+            const unsigned int nb = L.fresh_bits[lane];
+            if (nb) publish(&a.Fn[lo_w + wl], nb);
+          }
+          __builtin_amdgcn_wave_barrier();
+        }
+      } else {
       // The visited bitmap was published before the barrier; the probes below are ordinary loads through L1,
       // so this workgroup drops what its L1 may still hold (bfs_persist.hip does the same).
       if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
       __syncthreads();
-      const unsigned int* vin = a.V;
-      const Index* hint = a.hint;
       const Index nchunks = (a.n_local + kWave - 1) / kWave;
       const Index nblocks = (nchunks + kPPullBlock - 1) / kPPullBlock;
-      const Index nwaves = (Index)G * kPWaves;
-      const unsigned long long lt_mask = (1ull << lane) - 1ull;
       for (Index blk = (Index)blockIdx.x * kPWaves + wave; blk < nblocks; blk += nwaves) {
         // ---- stage 0: the block's 16 words; a lane's 8 vertices are vbase + 64 j (local ids)
         const Index wl = blk * (2 * kPPullBlock) + lane;
@@ -467,101 +524,33 @@ __global__ __launch_bounds__(kPThreads) void bfs_part_level_kernel(PartArgs a) {
           }
         }
         unsigned int und = act & ~fnd;
+#pragma unroll
+        for (int j = 0; j < kPPullBlock; ++j)
+          if (p[j] >= e[j]) und &= ~(1u << j);
         if (__ballot(und != 0u)) {
-          // ---- stage 2: the first four entries of every undecided row in one 16-byte load, probed together
-          if (a.innz >= kPullProbe) {
+          // ---- the undecided rows, queued in lane order and taken dense (persist_common.hpp: pull_queue_run)
+          if (lane < 2 * kPPullBlock) L.found[lane] = 0u;
+          const int mine = __popc(und);
+          int incl = mine;
 #pragma unroll
-            for (int half = 0; half < 2; ++half) {
-              constexpr int H = kPPullBlock / 2;
-              PQuad cq[H];
-#pragma unroll
-              for (int jj = 0; jj < H; ++jj) {
-                const int j = half * H + jj;
-                const bool nd = ((und >> j) & 1u) && p[j] < e[j];
-                Index at = nd ? p[j] : 0;
-                const Index last = (Index)a.innz - kPullProbe;
-                const int shift = at > last ? at - last : 0;      // only the final entries of the array
-                at -= shift;
-                cq[jj] = *reinterpret_cast<const PQuad*>(a.iind + at);
-                for (int t = 0; t < shift; ++t) { cq[jj].x = cq[jj].y; cq[jj].y = cq[jj].z; cq[jj].z = cq[jj].w; }
-              }
-              unsigned int wq[H][kPullProbe];
-#pragma unroll
-              for (int jj = 0; jj < H; ++jj) {
-                const int j = half * H + jj;
-                const Index len = ((und >> j) & 1u) ? e[j] - p[j] : 0;
-                const Index c4[kPullProbe] = {cq[jj].x, cq[jj].y, cq[jj].z, cq[jj].w};
-#pragma unroll
-                for (int q = 0; q < kPullProbe; ++q) wq[jj][q] = vin[q < len ? (c4[q] >> 5) : 0];
-              }
-#pragma unroll
-              for (int jj = 0; jj < H; ++jj) {
-                const int j = half * H + jj;
-                const Index len = ((und >> j) & 1u) ? e[j] - p[j] : 0;
-                const Index c4[kPullProbe] = {cq[jj].x, cq[jj].y, cq[jj].z, cq[jj].w};
-                bool hit = false;
-#pragma unroll
-                for (int q = 0; q < kPullProbe; ++q)
-                  if (q < len && ((wq[jj][q] >> (c4[q] & 31)) & 1u)) hit = true;
-                if (hit) { fnd |= 1u << j; und &= ~(1u << j); }
-              }
-              asm volatile("" ::: "memory");
-            }
-          } else {
-#pragma unroll
-            for (int j = 0; j < kPPullBlock; ++j) p[j] -= kPullProbe;    // tiny shard: everything is a leftover
+          for (int o = 1; o < kWave; o <<= 1) {
+            const int y = __shfl_up(incl, o, kWave);
+            if (lane >= o) incl += y;
           }
+          const int T = __shfl(incl, kWave - 1, kWave);
+          int at = incl - mine;
 #pragma unroll
           for (int j = 0; j < kPPullBlock; ++j)
-            if (p[j] + kPullProbe >= e[j]) und &= ~(1u << j);
-          // ---- leftovers: queued in this wave's LDS region, then 16 lanes per row
-          if (__ballot(und != 0u)) {
-            int2* lq = s_left[wave];
-            unsigned int* lf = s_leftfound[wave];
-            if (lane < 2 * kPPullBlock) lf[lane] = 0u;
-            const int grp = lane >> 4, gl = lane & 15;
-#pragma unroll
-            for (int half = 0; half < 2; ++half) {
-              int qn = 0;
-#pragma unroll
-              for (int jj = 0; jj < kPPullBlock / 2; ++jj) {
-                const int j = half * (kPPullBlock / 2) + jj;
-                const unsigned long long m = __ballot((und >> j) & 1u);
-                if ((und >> j) & 1u) {
-                  const int slot = qn + __popcll(m & lt_mask);
-                  lq[slot] = make_int2(p[j] + kPullProbe, e[j]);
-                  s_leftid[wave][slot] = (unsigned short)(j * kWave + lane);
-                }
-                qn += __popcll(m);
-              }
-              __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-              __builtin_amdgcn_wave_barrier();
-              for (int q0 = 0; q0 < qn; q0 += kWave / kPPullGroup) {
-                const int qi = q0 + grp;
-                Index rs = 0, re = 0;
-                int id = 0;
-                if (qi < qn) { const int2 r = lq[qi]; rs = r.x; re = r.y; id = s_leftid[wave][qi]; }
-                bool done = false;
-                for (Index q = rs; __any(q < re && !done); q += kPPullGroup) {
-                  bool h = false;
-                  const bool live = q < re && !done;
-                  if (live && q + gl < re) h = bit_set(vin, a.iind[q + gl]);
-                  const unsigned int hb = (unsigned int)(__ballot(h) >> (grp * kPPullGroup)) & ((1u << kPPullGroup) - 1u);
-                  if (live && hb) {
-                    done = true;
-                    if (gl == 0) atomicOr(&lf[id >> 5], 1u << (id & 31));
-                  }
-                }
-              }
-              __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-              __builtin_amdgcn_wave_barrier();
+            if ((und >> j) & 1u) {
+              L.row[at] = make_int2(p[j], e[j]);
+              L.id[at] = (unsigned short)(j * kWave + lane);
+              ++at;
             }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_wave_barrier();
+          pull_queue_run<false>(a.iind, a.innz, vin, L, lane, T, unused);
 #pragma unroll
-            for (int j = 0; j < kPPullBlock; ++j) fnd |= ((lf[2 * j + (lane >> 5)] >> (lane & 31)) & 1u) << j;
-            __builtin_amdgcn_wave_barrier();
-          }
+          for (int j = 0; j < kPPullBlock; ++j) fnd |= ((L.found[2 * j + (lane >> 5)] >> (lane & 31)) & 1u) << j;
+          __builtin_amdgcn_wave_barrier();
         }
         // ---- output: the new bits of the owned words
         unsigned int nb = 0;
@@ -571,6 +560,7 @@ __global__ __launch_bounds__(kPThreads) void bfs_part_level_kernel(PartArgs a) {
           if ((lane >> 1) == j) nb = (lane & 1) ? (unsigned int)(fb >> 32) : (unsigned int)(fb & 0xffffffffull);
         }
         if (has_word && nb) publish(&a.Fn[lo_w + wl], nb);
+      }
       }
     }
     cy.last_dir = pull ? 1 : 0;
@@ -583,20 +573,59 @@ __global__ __launch_bounds__(kPThreads) void bfs_part_level_kernel(PartArgs a) {
     // ---- the depth vector of the owned vertices, written once and coalesced from the kept level bitmaps: level
     // L + 1 for the vertices of F[L]; 0 for everything never reached; levels beyond the kept ones were labelled when
     // found.  (V and every F are final: the ending launch passed the apply barrier.)
-    if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    __syncthreads();
+    GRB_PART_PHASE();
     int kept = cy.hit_cap ? cy.levels : cy.levels + 1;      // F[levels] of a cut-off traversal was never written
     if (kept > kPKeep) kept = kPKeep;
-    const unsigned int* __restrict__ V_own = a.V + lo_w;
-    const int sh = lane & 31;
-    const Index nchunks = (a.n_local + kWave - 1) / kWave;
-    for (Index chunk = (Index)blockIdx.x * kPWaves + wave; chunk < nchunks; chunk += (Index)G * kPWaves) {
-      const int wi = 2 * chunk + (lane >> 5);
-      const unsigned int vis = V_own[wi];
-      unsigned int lab = 0;
-      for (int L = 0; L < kept; ++L) lab += ((a.F[(size_t)L * local_words + wi] >> sh) & 1u) * (unsigned int)(L + 1);
-      const Index v = chunk * kWave + lane;
-      if (v < a.n_local && (lab != 0u || !((vis >> sh) & 1u))) a.label[v] = (float)lab;
+    // one owned bitmap word (32 vertices) per lane: the visited word and the word of every kept level in flight
+    // together (agent-scope loads, no invalidate), the 32 labels as eight 16-byte stores (bfs_persist.hip)
+    const unsigned int* V_own = a.V + lo_w;
+    const bool label_aligned = (reinterpret_cast<unsigned long long>(a.label) & 15ull) == 0ull;
+    for (long long wi = gtid; wi < local_words; wi += gthreads) {
+      const unsigned int vis = fresh(&V_own[wi]);
+      unsigned int f[kPKeep];
+#pragma unroll
+      for (int L0 = 0; L0 < kPKeep; L0 += 8) {
+        if (L0 < kept) {
+#pragma unroll
+          for (int u = 0; u < 8; ++u) f[L0 + u] = L0 + u < kept ? fresh(&a.F[(size_t)(L0 + u) * local_words + wi]) : 0u;
+        } else {
+#pragma unroll
+          for (int u = 0; u < 8; ++u) f[L0 + u] = 0u;
+        }
+      }
+      unsigned int pl[6] = {0u, 0u, 0u, 0u, 0u, 0u};      // bit b of plane q = bit q of the label of vertex 32 wi + b
+#pragma unroll
+      for (int L = 0; L < kPKeep; ++L) {
+#pragma unroll
+        for (int q = 0; q < 6; ++q)
+          if (((L + 1) >> q) & 1) pl[q] |= f[L];
+      }
+      const long long v0 = wi * 32;
+      // visited but in no kept bitmap: labelled when found (a level beyond the kept ones), or never assigned
+      const unsigned int keepm = vis & ~(pl[0] | pl[1] | pl[2] | pl[3] | pl[4] | pl[5]);
+      if (v0 + 32 <= (long long)a.n_local && keepm == 0u && label_aligned) {
+        float4* out = reinterpret_cast<float4*>(a.label + v0);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          float x[4];
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const int b = q * 4 + t;
+            unsigned int lab = 0u;
+#pragma unroll
+            for (int z = 0; z < 6; ++z) lab |= ((pl[z] >> b) & 1u) << z;
+            x[t] = (float)lab;
+          }
+          out[q] = make_float4(x[0], x[1], x[2], x[3]);
+        }
+      } else {
+        for (int b = 0; b < 32 && v0 + b < (long long)a.n_local; ++b) {
+          unsigned int lab = 0u;
+#pragma unroll
+          for (int z = 0; z < 6; ++z) lab |= ((pl[z] >> b) & 1u) << z;
+          if (!((keepm >> b) & 1u)) a.label[v0 + b] = (float)lab;
+        }
+      }
     }
   }
   if (gtid == 0) {
@@ -672,6 +701,7 @@ struct grb_part_s {
   int rec_cap = 1 << 15;
   bool prezeroed = false;               // the zeroed part of d_block was cleared behind the previous traversal
   Index* d_hint = nullptr;
+  long long n_in_local = -1;            // owned vertices with in-edges
   unsigned long long* h_mail = nullptr;   // pinned
   unsigned long long* d_mail = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -739,6 +769,7 @@ grb_info part_bfs_run(grb_part* ps, int nranks, grb_index source, int mode, floa
     a.iptr = p->A_in->csr.ptr;  a.iind = p->A_in->csr.ind;
     a.innz = p->A_in->nvals;
     a.skip = p->A_in->d_empty_csr_rows;
+    a.n_in_local = p->n_in_local;
     a.hint = p->d_hint;
     a.deg = p->d_deg;
     a.n = p->n; a.lo = p->lo; a.n_local = p->n_local;
@@ -897,6 +928,15 @@ grb_info grb_part_new(grb_part* out, int rank, int world, grb_index n_global, gr
     if (hipGetLastError() != hipSuccess) return fail(GRB_PANIC);
   }
   if (hipStreamSynchronize(s) != hipSuccess) return fail(GRB_PANIC);
+  {                                     // owned vertices with in-edges: the complement of the skip bitmap (padding bits are set)
+    std::vector<unsigned int> h_skip((size_t)(p->local_words > 0 ? p->local_words : 1), 0xffffffffu);
+    if (p->local_words > 0 &&
+        hipMemcpy(h_skip.data(), A_in->d_empty_csr_rows, 4 * (size_t)p->local_words, hipMemcpyDeviceToHost) != hipSuccess)
+      return fail(GRB_PANIC);
+    long long empty = 0;
+    for (int i = 0; i < p->local_words; ++i) empty += __builtin_popcount(h_skip[(size_t)i]);
+    p->n_in_local = (long long)p->local_words * 32 - empty;
+  }
   *out = p;
   return GRB_SUCCESS;
 }

@@ -54,11 +54,11 @@ namespace grb {
 #ifndef GRB_BFS_SPARSE_FRESH
 #define GRB_BFS_SPARSE_FRESH 1
 #endif
-constexpr int kSparseWords = 32;  // bitmap words (of 32 vertices) a wave takes per step of a pull level with a sparse active set
 constexpr int kSmallDeg = 16;     // below: expanded inline by the discovering lane
 constexpr int kBigDeg = 512;      // from here: split into kBigChunk-edge entries for workgroups
 constexpr int kBigChunk = 1024;
 constexpr int kPullBlock = GRB_PULL_BLOCK;    // chunks (of 64 vertices) one wave carries through the pull stages together
+static_assert(kPullBlock * kWave <= kPullQueue, "a wave queues at most every vertex of its block");
 constexpr int kMedCap = 4096;     // LDS list of medium vertices per workgroup pass
 constexpr int kKeep = 32;         // levels whose discovered-bitmaps are kept for the final label pass
 
@@ -113,7 +113,6 @@ struct PersistArgs {
   unsigned long long* trace;        // optional (GRB_BFS_TRACE): wall-clock stamps of workgroup 0
 };
 
-struct __attribute__((packed, aligned(4))) Quad { Index x, y, z, w; };   // four consecutive column ids
 
 struct LevelCounters {
   unsigned long long found = 0, deg = 0, inspected = 0, big = 0;
@@ -138,160 +137,6 @@ __device__ inline void push_visit(const PersistArgs& a, unsigned int* V, unsigne
   if (old & bit) return;
   atomicOr(&Fn[dst >> 5], bit);
   discovered(a, dst, new_label, c);
-}
-
-// ---- pull levels: what a wave does with the rows its first probe (the hinted in-neighbour) did not settle --------
-// They are QUEUED in the wave's LDS ({next entry, end}, id of the vertex inside the wave's block) and then taken
-// dense: kPullR rows per lane and round for the first kPullProbe entries (one 16-byte load + four bitmap probes per
-// row, all rounds' loads in flight together), survivors written back to the front of the queue; then the survivors'
-// remaining entries are laid end to end and dealt to the lanes, 256 entries per step, whatever the rows' lengths
-// (offsets by a wave scan, a lane's row by a 6-step search) -- a step is one index load + one probe for 256 entries.
-// A row contributes at most `cap` entries per pass (64, doubling): a hub with an early hit is not read to its end.
-// The first hit of a row is the smallest offset that hits (LDS atomicMin), so the inspected-edge count stays the
-// sequential early-exit count of the oracle: entries up to and including the first hit, or all of them.
-constexpr int kPullQueue = kPullBlock * kWave;      // rows a wave can queue: every vertex of its block
-constexpr int kPullR = 4;                           // rows per lane and round of the first-entries stage
-struct PullLds {
-  int2 row[kPullQueue];                             // {next entry, end}
-  unsigned short id[kPullQueue];
-  unsigned int found[32];                           // bit id: the row had a hit
-  int off[kWave], nxt[kWave], hit[kWave];           // dealing a pass: first slot / first entry / smallest hitting offset
-  WaveBits bits;                                    // sparse active sets: the active bits numbered (wave_for_each_bit)
-  unsigned int fresh_bits[kSparseWords];            // ... and what they discovered, by word
-};
-
-// T rows are queued; afterwards found[] has the bit of every queued row with an in-neighbour in vin.
-// kFresh: the bitmap is probed with agent-scope loads (a level with few probes skips the L1 invalidate instead).
-template <bool kFresh>
-__device__ __forceinline__ unsigned int probe_word(const unsigned int* vin, Index w) {
-  return kFresh ? fresh(&vin[w]) : vin[w];
-}
-template <bool kFresh>
-__device__ __forceinline__ void pull_queue_run(const PersistArgs& a, const unsigned int* vin, PullLds& L,
-                                               int lane, int T, LevelCounters& c) {
-  const unsigned long long lt_mask = (1ull << lane) - 1ull;
-  int S = 0;                                                       // survivors, compacted to the front of the queue
-  if (a.nnz >= kPullProbe) {
-    const Index last = (Index)a.nnz - kPullProbe;
-    for (int q0 = 0; q0 < T; q0 += kWave * kPullR) {
-      int2 it[kPullR];
-      int id[kPullR];
-      Quad cq[kPullR];
-#pragma unroll
-      for (int k = 0; k < kPullR; ++k) {
-        const int qi = q0 + k * kWave + lane;
-        const bool valid = qi < T;
-        it[k] = valid ? L.row[qi] : make_int2(0, 0);
-        id[k] = valid ? (int)L.id[qi] : 0;
-      }
-#pragma unroll
-      for (int k = 0; k < kPullR; ++k) {
-        Index at = it[k].x;
-        const int shift = at > last ? at - last : 0;               // only the final entries of the array
-        at -= shift;
-        cq[k] = *reinterpret_cast<const Quad*>(a.iind + at);
-        for (int t = 0; t < shift; ++t) { cq[k].x = cq[k].y; cq[k].y = cq[k].z; cq[k].z = cq[k].w; }
-      }
-      unsigned int wq[kPullR][kPullProbe];
-#pragma unroll
-      for (int k = 0; k < kPullR; ++k) {
-        const Index len = it[k].y - it[k].x;
-        const Index c4[kPullProbe] = {cq[k].x, cq[k].y, cq[k].z, cq[k].w};
-#pragma unroll
-        for (int t = 0; t < kPullProbe; ++t) wq[k][t] = probe_word<kFresh>(vin, t < len ? (c4[t] >> 5) : 0);
-      }
-      __builtin_amdgcn_wave_barrier();
-#pragma unroll
-      for (int k = 0; k < kPullR; ++k) {
-        const Index len = it[k].y - it[k].x;
-        const Index c4[kPullProbe] = {cq[k].x, cq[k].y, cq[k].z, cq[k].w};
-        int first = -1;
-#pragma unroll
-        for (int t = kPullProbe - 1; t >= 0; --t)
-          if (t < len && ((wq[k][t] >> (c4[t] & 31)) & 1u)) first = t;
-        const int seen = first >= 0 ? first + 1 : (len < kPullProbe ? (int)len : kPullProbe);
-        c.inspected += (unsigned long long)seen;
-        if (first >= 0) atomicOr(&L.found[id[k] >> 5], 1u << (id[k] & 31));
-        const bool surv = first < 0 && len > kPullProbe;
-        const unsigned long long m = __ballot(surv);
-        if (surv) {
-          const int slot = S + __popcll(m & lt_mask);
-          L.row[slot] = make_int2(it[k].x + kPullProbe, it[k].y);
-          L.id[slot] = (unsigned short)id[k];
-        }
-        S += __popcll(m);
-      }
-      __builtin_amdgcn_wave_barrier();
-    }
-  } else {
-    S = T;                                                         // a matrix of fewer than four entries: all left over
-  }
-  for (int g0 = 0; g0 < S; g0 += kWave) {
-    const int gi = g0 + lane;
-    bool alive = gi < S;
-    Index nx = 0, en = 0;
-    int id = 0;
-    if (alive) { const int2 r = L.row[gi]; nx = r.x; en = r.y; id = L.id[gi]; }
-    alive = alive && nx < en;
-    Index cap = kWave;
-    while (__ballot(alive)) {
-      const Index rem = alive ? (en - nx < cap ? en - nx : cap) : 0;
-      Index incl = rem;
-#pragma unroll
-      for (int o = 1; o < kWave; o <<= 1) {
-        const Index y = __shfl_up(incl, o, kWave);
-        if (lane >= o) incl += y;
-      }
-      const Index total = __shfl(incl, kWave - 1, kWave);
-      __builtin_amdgcn_wave_barrier();
-      L.off[lane] = incl - rem;
-      L.nxt[lane] = nx;
-      L.hit[lane] = 0x7fffffff;
-      __builtin_amdgcn_wave_barrier();
-      for (Index t0 = 0; t0 < total; t0 += 4 * kWave) {
-        int r[4];
-        Index o[4], col[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const Index t = t0 + j * kWave + lane;
-          r[j] = -1;
-          o[j] = 0;
-          col[j] = 0;
-          if (t < total) {
-            int x = 0;                                             // the last row whose first slot is <= t
-#pragma unroll
-            for (int step = kWave / 2; step > 0; step >>= 1)
-              if (L.off[x + step] <= t) x += step;
-            r[j] = x;
-            o[j] = t - L.off[x];
-            col[j] = a.iind[L.nxt[x] + o[j]];
-          }
-        }
-        unsigned int w[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) w[j] = probe_word<kFresh>(vin, col[j] >> 5);
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          if (r[j] >= 0 && ((w[j] >> (col[j] & 31)) & 1u)) atomicMin(&L.hit[r[j]], (int)o[j]);
-      }
-      __builtin_amdgcn_wave_barrier();
-      const int h = L.hit[lane];
-      if (alive) {
-        if (h != 0x7fffffff) {
-          c.inspected += (unsigned long long)(h + 1);
-          atomicOr(&L.found[id >> 5], 1u << (id & 31));
-          alive = false;
-        } else {
-          c.inspected += (unsigned long long)rem;
-          nx += rem;
-          alive = nx < en;
-        }
-      }
-      if (cap < 4096) cap <<= 1;
-      __builtin_amdgcn_wave_barrier();
-    }
-  }
-  __builtin_amdgcn_wave_barrier();
 }
 
 __global__ __launch_bounds__(kPThreads) void bfs_persistent_kernel(PersistArgs a) {
@@ -612,7 +457,7 @@ __global__ __launch_bounds__(kPThreads) void bfs_persistent_kernel(PersistArgs a
                 L.id[slot] = (unsigned short)lane;
               }
               __builtin_amdgcn_wave_barrier();
-              pull_queue_run<kF>(a, vin, L, lane, __popcll(um), c);
+              pull_queue_run<kF>(a.iind, a.nnz, vin, L, lane, __popcll(um), c.inspected);
               if (und && ((L.found[lane >> 5] >> (lane & 31)) & 1u)) found = true;
               __builtin_amdgcn_wave_barrier();
             }
@@ -702,7 +547,7 @@ __global__ __launch_bounds__(kPThreads) void bfs_persistent_kernel(PersistArgs a
               ++at;
             }
           __builtin_amdgcn_wave_barrier();
-          pull_queue_run<false>(a, vin, L, lane, T, c);
+          pull_queue_run<false>(a.iind, a.nnz, vin, L, lane, T, c.inspected);
 #pragma unroll
           for (int j = 0; j < kPullBlock; ++j) fnd |= ((L.found[2 * j + (lane >> 5)] >> (lane & 31)) & 1u) << j;
           __builtin_amdgcn_wave_barrier();

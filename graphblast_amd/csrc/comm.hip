@@ -42,6 +42,12 @@ struct Comm {
   double total_us = 0;                // sum over the collectives since the last reset
   long long calls = 0;
   bool pending = false;               // the last collective's time has not been added yet
+  // host-staged transport (grb_comm_set_host_transport): the collectives as callbacks over pinned host buffers
+  grb_comm_host_fn host_fn = nullptr;
+  void* host_user = nullptr;
+  char* h_stage = nullptr;            // pinned: [send | recv]
+  size_t h_cap = 0;
+  bool up() const { return comm != nullptr || host_fn != nullptr; }
 };
 
 Comm g_comm;
@@ -172,8 +178,59 @@ grb_info grb_comm_init(const void* id128, int rank, int world) {
   return GRB_SUCCESS;
 }
 
+// ---- host-staged transport ---------------------------------------------------------------------------------------
+// The same entry points, the data moved by the caller's own collective over HOST memory: a collective waits for the
+// compute stream, copies what it sends into pinned memory, calls fn, copies what it received back.  Synchronous and
+// slow on purpose -- it exists so that the device-side level / round loops (bfs_part_run.hip, sssp_part_run.hip),
+// whose host logic only ever sees these entry points, can be driven by several PROCESSES where RCCL cannot run
+// (ranks that share one GPU in the tests; a gloo group).  fn(user, op, send, recv, bytes, offsets, counts) -> 0 on
+// success; op 0: all-gather of `bytes` per rank (send -> recv[world * bytes]); op 1: in-place all-gather of the
+// byte ranges [offsets[r], offsets[r] + counts[r]) of recv (send == recv, bytes = the buffer's extent); op 2: sum
+// all-reduce of bytes / 8 doubles in place (send == recv).
+static grb_info host_stage(size_t bytes) {
+  Comm& c = g_comm;
+  if (bytes <= c.h_cap) return GRB_SUCCESS;
+  if (c.h_stage) (void)hipHostFree(c.h_stage);
+  c.h_stage = nullptr;
+  c.h_cap = 0;
+  GRB_HIP_TRY(hipHostMalloc((void**)&c.h_stage, bytes, hipHostMallocDefault));
+  c.h_cap = bytes;
+  return GRB_SUCCESS;
+}
+
+grb_info grb_comm_set_host_transport(int rank, int world, grb_comm_host_fn fn, void* user) {
+  Comm& c = g_comm;
+  if (c.comm) return GRB_OUTPUT_NOT_EMPTY;
+  if (!fn) {                                             // off
+    c.host_fn = nullptr;
+    c.host_user = nullptr;
+    c.rank = 0;
+    c.world = 1;
+    return GRB_SUCCESS;
+  }
+  if (world < 1 || rank < 0 || rank >= world) return GRB_INVALID_VALUE;
+  GRB_TRY(ctx_init());
+  c.host_fn = fn;
+  c.host_user = user;
+  c.rank = rank;
+  c.world = world;
+  c.total_us = 0;
+  c.calls = 0;
+  return GRB_SUCCESS;
+}
+
 grb_info grb_comm_destroy(void) {
   Comm& c = g_comm;
+  if (c.host_fn) {
+    if (c.h_stage) (void)hipHostFree(c.h_stage);
+    c.h_stage = nullptr;
+    c.h_cap = 0;
+    c.host_fn = nullptr;
+    c.host_user = nullptr;
+    c.rank = 0;
+    c.world = 1;
+    return GRB_SUCCESS;
+  }
   if (!c.comm) return GRB_SUCCESS;
   (void)hipStreamSynchronize(c.stream);
   (void)c.api.CommDestroy(c.comm);
@@ -188,7 +245,7 @@ grb_info grb_comm_destroy(void) {
 
 grb_info grb_comm_info(int* rank, int* world) {
   if (rank) *rank = g_comm.rank;
-  if (world) *world = g_comm.comm ? g_comm.world : 0;
+  if (world) *world = g_comm.up() ? g_comm.world : 0;
   return GRB_SUCCESS;
 }
 
@@ -221,6 +278,7 @@ grb_info grb_comm_stats(double* total_us, long long* calls, int reset) {
 // The compute stream waits (on the device) for the last collective; no host synchronisation.
 grb_info grb_comm_wait(void) {
   Comm& c = g_comm;
+  if (c.host_fn) return GRB_SUCCESS;                      // host-staged collectives have completed when they return
   if (!c.comm) return GRB_UNINITIALIZED_OBJECT;
   GRB_TRY(account_last());
   GRB_HIP_TRY(hipStreamWaitEvent(ctx().stream, c.ev_done, 0));
@@ -230,6 +288,17 @@ grb_info grb_comm_wait(void) {
 // Equal-sized all-gather: every rank sends `bytes` from d_send, d_recv holds world * bytes.
 grb_info grb_comm_allgather(const void* d_send, void* d_recv, size_t bytes) {
   Comm& c = g_comm;
+  if (c.host_fn) {
+    hipStream_t s = grb::ctx().stream;
+    GRB_TRY(host_stage(bytes * (size_t)(c.world + 1)));
+    GRB_HIP_TRY(hipMemcpyAsync(c.h_stage, d_send, bytes, hipMemcpyDeviceToHost, s));
+    GRB_HIP_TRY(hipStreamSynchronize(s));
+    if (c.host_fn(c.host_user, 0, c.h_stage, c.h_stage + bytes, (long long)bytes, nullptr, nullptr) != 0) return GRB_PANIC;
+    GRB_HIP_TRY(hipMemcpyAsync(d_recv, c.h_stage + bytes, bytes * (size_t)c.world, hipMemcpyHostToDevice, s));
+    GRB_HIP_TRY(hipStreamSynchronize(s));
+    ++c.calls;
+    return GRB_SUCCESS;
+  }
   if (!c.comm) return GRB_UNINITIALIZED_OBJECT;
   GRB_TRY(account_last());
   GRB_TRY(fence_in());
@@ -242,6 +311,26 @@ grb_info grb_comm_allgather(const void* d_send, void* d_recv, size_t bytes) {
 // on point-to-point xGMI every peer link carries its slice concurrently.
 grb_info grb_comm_allgatherv_inplace(void* d_buf, const long long* offsets, const long long* counts) {
   Comm& c = g_comm;
+  if (c.host_fn) {
+    if (!offsets || !counts) return GRB_NULL_POINTER;
+    hipStream_t s = grb::ctx().stream;
+    long long extent = 0;
+    for (int r = 0; r < c.world; ++r)
+      if (counts[r] > 0 && offsets[r] + counts[r] > extent) extent = offsets[r] + counts[r];
+    if (extent == 0) return GRB_SUCCESS;
+    GRB_TRY(host_stage((size_t)extent));
+    if (counts[c.rank] > 0)
+      GRB_HIP_TRY(hipMemcpyAsync(c.h_stage + offsets[c.rank], (const char*)d_buf + offsets[c.rank], (size_t)counts[c.rank],
+                                 hipMemcpyDeviceToHost, s));
+    GRB_HIP_TRY(hipStreamSynchronize(s));
+    if (c.host_fn(c.host_user, 1, c.h_stage, c.h_stage, extent, offsets, counts) != 0) return GRB_PANIC;
+    for (int r = 0; r < c.world; ++r)
+      if (r != c.rank && counts[r] > 0)
+        GRB_HIP_TRY(hipMemcpyAsync((char*)d_buf + offsets[r], c.h_stage + offsets[r], (size_t)counts[r], hipMemcpyHostToDevice, s));
+    GRB_HIP_TRY(hipStreamSynchronize(s));
+    ++c.calls;
+    return GRB_SUCCESS;
+  }
   if (!c.comm) return GRB_UNINITIALIZED_OBJECT;
   if (!offsets || !counts) return GRB_NULL_POINTER;
   GRB_TRY(account_last());
@@ -261,6 +350,17 @@ grb_info grb_comm_allgatherv_inplace(void* d_buf, const long long* offsets, cons
 // In-place sum all-reduce of `count` doubles (convergence scalars, totals).
 grb_info grb_comm_allreduce_sum_f64(void* d_buf, size_t count) {
   Comm& c = g_comm;
+  if (c.host_fn) {
+    hipStream_t s = grb::ctx().stream;
+    GRB_TRY(host_stage(8 * count));
+    GRB_HIP_TRY(hipMemcpyAsync(c.h_stage, d_buf, 8 * count, hipMemcpyDeviceToHost, s));
+    GRB_HIP_TRY(hipStreamSynchronize(s));
+    if (c.host_fn(c.host_user, 2, c.h_stage, c.h_stage, (long long)(8 * count), nullptr, nullptr) != 0) return GRB_PANIC;
+    GRB_HIP_TRY(hipMemcpyAsync(d_buf, c.h_stage, 8 * count, hipMemcpyHostToDevice, s));
+    GRB_HIP_TRY(hipStreamSynchronize(s));
+    ++c.calls;
+    return GRB_SUCCESS;
+  }
   if (!c.comm) return GRB_UNINITIALIZED_OBJECT;
   GRB_TRY(account_last());
   GRB_TRY(fence_in());

@@ -50,6 +50,13 @@ grb_info ctx_init() {
   hipDeviceProp_t prop;
   GRB_HIP_TRY(hipGetDeviceProperties(&prop, dev));
   c.num_cu = prop.multiProcessorCount;
+  // GRB_NUM_CU: workgroups of the co-resident ("persistent") launches, at most the device's CUs.  Processes that share
+  // one GPU (tests/test_gpu_part_run.py: two ranks of the partitioned loops on one device) each take a part of it, so
+  // that all their grids can be resident at once -- a grid barrier needs that.
+  if (const char* e = getenv("GRB_NUM_CU")) {
+    const int want = atoi(e);
+    if (want >= 1 && want < c.num_cu) c.num_cu = want;
+  }
   c.inited = true;
   return GRB_SUCCESS;
 }

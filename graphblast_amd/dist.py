@@ -474,6 +474,56 @@ class RcclComm:
         return us.value, calls.value
 
 
+class HostStagedComm(RcclComm):
+    """The library communicator over HOST-STAGED collectives (grb_comm_set_host_transport): every grb_comm_* call of
+    the library -- the ones this class makes and the ones the device-side level / round loops make themselves --
+    becomes a torch.distributed collective on CPU tensors over pinned staging buffers.  For process groups RCCL cannot
+    serve: gloo, or several ranks on ONE GPU (tests/test_gpu_part_run.py drives grb_bfs_part_run / grb_sssp_part_run
+    from two processes this way).  Synchronous and slow on purpose."""
+
+    def __init__(self, rank, world, nwords, dev, group=None):
+        from . import _lib
+        self._lib = _lib.load()
+        self.rank, self.world, self.nwords, self.dev = rank, world, nwords, dev
+        self._group = group
+        fn_t = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_longlong,
+                           C.POINTER(C.c_longlong), C.POINTER(C.c_longlong))
+
+        def view(ptr, nbytes, dtype=np.uint8):
+            raw = (C.c_ubyte * int(nbytes)).from_address(ptr)
+            return torch.from_numpy(np.frombuffer(raw, dtype=dtype))
+
+        def transport(user, op, send, recv, nbytes, offsets, counts):
+            try:
+                if op == 0:
+                    dist.all_gather_into_tensor(view(recv, nbytes * world), view(send, nbytes), group=group)
+                elif op == 1:
+                    for r in range(world):
+                        if counts[r] > 0:
+                            dist.broadcast(view(recv + offsets[r], counts[r]), src=dist.get_global_rank(group, r)
+                                           if group is not None else r, group=group)
+                elif op == 2:
+                    dist.all_reduce(view(recv, nbytes, np.float64), op=dist.ReduceOp.SUM, group=group)
+                else:
+                    return 2
+                return 0
+            except Exception:                                            # noqa: BLE001 -- reported as GrB_PANIC
+                import traceback
+                traceback.print_exc()
+                return 1
+        self._cb = fn_t(transport)                                       # kept alive: the library holds the pointer
+        info = self._lib.grb_comm_set_host_transport(int(rank), int(world), C.cast(self._cb, C.c_void_p), None)
+        if info != 0:
+            raise RuntimeError("grb_comm_set_host_transport: Info %d" % info)
+        self.gathered = torch.zeros(world * nwords, dtype=torch.int32, device=dev) if world > 1 else None
+        self._acc = torch.zeros(2, dtype=torch.float64, device=dev)
+        if world > 1:
+            self._self_test()
+
+    def close(self):
+        self._lib.grb_comm_set_host_transport(0, 1, None, None)
+
+
 class LoopbackGroup:
     """Every rank of a world of `world` on ONE device, driven in lock-step by grb_bfs_part_run_group with device copies
     as the all-gather: what a multi-GPU run executes per rank (the same launches, the same apply over `world`

@@ -524,6 +524,15 @@ grb_info grb_diameter(grb_vector v, grb_matrix A, grb_index s_start, grb_index s
  * grb_set_stream: a collective starts when the work enqueued before it has finished, and the
  * compute stream continues until grb_comm_wait() makes it wait (on the device) for the last one.
  * RCCL is bound with dlopen; GrB_NOT_IMPLEMENTED when it is absent. */
+/* Host-staged transport instead of RCCL: the same collectives, each one a callback over pinned HOST buffers (the
+ * library waits for its compute stream, stages the data, calls fn, copies the result back).  For ranks that cannot form
+ * an RCCL communicator -- several processes on one GPU (the tests drive grb_bfs_part_run / grb_sssp_part_run from two
+ * processes this way), a gloo group.  op 0: all-gather of `bytes` per rank, send -> recv[world * bytes]; op 1: in-place
+ * all-gather of the byte ranges offsets[r] .. + counts[r] of recv (bytes = the buffer's extent); op 2: sum all-reduce
+ * of bytes / 8 doubles in place.  fn returns 0 on success.  fn == NULL switches it off. */
+typedef int (*grb_comm_host_fn)(void* user, int op, const void* send, void* recv, long long bytes,
+                                const long long* offsets, const long long* counts);
+grb_info grb_comm_set_host_transport(int rank, int world, grb_comm_host_fn fn, void* user);
 grb_info grb_comm_unique_id(void* out128);                  /* ncclGetUniqueId: rank 0 calls it, every rank gets the bytes */
 grb_info grb_comm_init(const void* id128, int rank, int world);
 grb_info grb_comm_destroy(void);

@@ -223,3 +223,91 @@ def test_device_loop_sssp_directed_and_road_like():
         grp = LoopbackGroup(gr["n"], _t(ptr, dev), _t(ind, dev), world, dev)
         d, res = grp.sssp(w, 0, outbox_pairs=64)
         assert np.array_equal(d, want_d) and res[0]["iterations"] == want_it
+
+
+# ---- two real PROCESSES drive the device-side loops (world 2 on the one GPU of the box) ---------------------------
+def _two_process_worker(rank, world, port, q):
+    import os
+    import traceback
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from graphblast_amd.dist import Partition1D, HostStagedComm, bitmap_words
+        dev = torch.device("cuda", 0)
+        torch.cuda.set_device(dev)
+        gr = _graph(seed=3, scale=14)
+        ptr, ind = gr["csr"]
+        n = gr["n"]
+        comm = HostStagedComm(rank, world, bitmap_words(n), dev)
+        hub = int(np.argmax(np.diff(ptr)))
+        out = []
+        for mode in (10, 11, 12):
+            part = Partition1D(n, _t(ptr, dev), _t(ind, dev), rank, world, dev, mxvmode=mode, switchpoint=0.02, comm=comm)
+            assert part.device_loop                                   # grb_bfs_part_run, not the Python level loop
+            for src in (hub, 11):
+                res = part.bfs(src)
+                labels = part.gather_labels().cpu().numpy()
+                out.append((mode, src, dict(levels=res["levels"], launches=res["launches"], reached=res["reached"],
+                                            edges_traversed=res["edges_traversed"]),
+                            [tuple(t) for t in res["trace"]], labels))
+        wh = _edge_weights(ptr, ind)
+        part = Partition1D(n, _t(ptr, dev), _t(ind, dev), rank, world, dev, comm=comm)
+        sssp = []
+        for cap in (65536, 64):                                      # 64: most rounds take several launches
+            d, info = part.sssp(torch.from_numpy(wh).to(dev), hub, outbox_pairs=cap)
+            sssp.append((cap, d.cpu().numpy(), info))
+        comm.close()
+        if rank == 0:
+            q.put(("ok", out, sssp))
+    except Exception:                                                 # noqa: BLE001 -- the parent must not wait for a dead rank
+        q.put(("error", "rank %d: %s" % (rank, traceback.format_exc()), None))
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+def test_device_loop_two_processes_host_staged_collectives():
+    """grb_bfs_part_run / grb_sssp_part_run with world = 2 driven by two PROCESSES: each enqueues its own launches by
+    the "launch k goes out when launch k - 2 has reported" rule and meets the other in a real collective per level /
+    round (the library's host-staged transport over a gloo group, csrc/comm.hip), instead of the loop-back group of the
+    tests above where one host thread drives every rank.  Each process takes 112 of the GPU's CUs (GRB_NUM_CU) so
+    that both co-resident grids fit at once."""
+    import os
+    import socket
+    import torch.multiprocessing as mp
+    from oracle import simple_reference as sr
+    gr = _graph(seed=3, scale=14)
+    ptr, ind = gr["csr"]
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    before = os.environ.get("GRB_NUM_CU")
+    os.environ["GRB_NUM_CU"] = "112"
+    try:
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        procs = [ctx.Process(target=_two_process_worker, args=(r, 2, port, q)) for r in range(2)]
+        for p in procs:
+            p.start()
+        status, out, sssp = q.get(timeout=300)
+        assert status == "ok", out
+        for p in procs:
+            p.join(timeout=120)
+            assert p.exitcode == 0
+    finally:
+        if before is None:
+            os.environ.pop("GRB_NUM_CU", None)
+        else:
+            os.environ["GRB_NUM_CU"] = before
+    for mode, src, res, trace, labels in out:
+        _check(labels, [res], trace, ptr, ind, src, mode, 0.02)
+        assert res["launches"] == res["levels"] + 2
+    wh = _edge_weights(ptr, ind)
+    hub = int(np.argmax(np.diff(ptr)))
+    want_d, want_it = _sssp_rounds(ptr, ind, wh, hub)
+    assert np.array_equal(want_d, sr.sssp(ptr, ind, wh, hub)[0])
+    for cap, d, info in sssp:
+        assert np.array_equal(d, want_d), cap
+        assert info["iterations"] == want_it, (cap, info)
