@@ -105,7 +105,7 @@ class ThreadComm:
             self.world = world
             self.barrier = threading.Barrier(world)
             self.slots = [None] * world
-            self.lock = threading.Lock()          # serialises calls into the C library
+            self.lock = threading.RLock()         # serialises calls into the C library (re-entrant: engine methods call each other)
 
     def __init__(self, shared, rank):
         self.s, self.rank, self.world = shared, rank, shared.world
@@ -136,35 +136,29 @@ class ThreadComm:
 
 
 def locked_engine(engine_cls, lock):
-    """Wrap an engine class so every level step holds `lock` (the C library's scratch
-    context is per process, not per thread)."""
-    class Locked(engine_cls):
-        def pull(self, *a):
-            with lock:
-                super().pull(*a); torch.cuda.synchronize()
-        def push(self, *a):
-            with lock:
-                super().push(*a); torch.cuda.synchronize()
-        def apply(self, *a):
-            with lock:
-                r = super().apply(*a); torch.cuda.synchronize()
-                return r
-        def tally(self, *a):
-            with lock:
-                return super().tally(*a)
-        def pr_setup(self, *a):
-            with lock:
-                super().pr_setup(*a); torch.cuda.synchronize()
-        def sssp_setup(self, *a):
-            with lock:
-                super().sssp_setup(*a); torch.cuda.synchronize()
-        def sssp_step(self, *a):
-            with lock:
-                r = super().sssp_step(*a); torch.cuda.synchronize()
-                return r
+    """Wrap an engine class so that EVERY library call of a simulated rank holds `lock` (the C library's context --
+    scratch slots, the mailbox and its sequence number -- is per process, not per thread: two threads inside
+    grb_bfs_part_apply2 at once take each other's sequence numbers and one of them waits for a record that was
+    overwritten).  Every public method is wrapped, not a list of names: a method added to the engine later is
+    covered too."""
+    import functools
 
-        def pr_step(self, *a):
+    class Locked(engine_cls):
+        pass
+
+    def wrap(fn):
+        @functools.wraps(fn)
+        def locked(self, *a, **k):
             with lock:
-                r = super().pr_step(*a); torch.cuda.synchronize()
+                r = fn(self, *a, **k)
+                if torch.cuda.is_available():
+                    torch.cuda.synchronize()
                 return r
+        return locked
+    for name in dir(engine_cls):
+        if name.startswith("_"):
+            continue
+        fn = getattr(engine_cls, name)
+        if callable(fn) and not isinstance(fn, (staticmethod, classmethod, type)):
+            setattr(Locked, name, wrap(fn))
     return Locked

@@ -196,7 +196,7 @@ def test_partitioned_bfs_hip_engine_simulated_ranks(world, edgeswitch):
             labels[r] = parts[r].gather_labels().cpu().numpy()
         ts = [threading.Thread(target=run, args=(r,)) for r in range(world)]
         [t.start() for t in ts]
-        [t.join(timeout=300) for t in ts]
+        [t.join(timeout=90) for t in ts]
         want = sr.bfs(ptr, ind, src)[0]
         for r in range(world):
             assert results[r] is not None, "rank %d did not finish" % r
@@ -216,7 +216,7 @@ def test_partitioned_bfs_hip_engine_simulated_ranks(world, edgeswitch):
         pr_out[r] = parts[r].pagerank(deg, alpha=0.85, eps=0.0, max_niter=10)
     ts = [threading.Thread(target=run_pr, args=(r,)) for r in range(world)]
     [t.start() for t in ts]
-    [t.join(timeout=300) for t in ts]
+    [t.join(timeout=90) for t in ts]
     want_pr = sr.pr(ptr, ind, 0.85, 0.0, 10)[0]
     for r in range(world):
         assert pr_out[r] is not None
@@ -232,7 +232,7 @@ def test_partitioned_bfs_hip_engine_simulated_ranks(world, edgeswitch):
         ss_out[r] = parts[r].sssp(w, src_s)
     ts = [threading.Thread(target=run_sssp, args=(r,)) for r in range(world)]
     [t.start() for t in ts]
-    [t.join(timeout=300) for t in ts]
+    [t.join(timeout=90) for t in ts]
     want_d, want_it = _sssp_rounds(ptr, ind, wh, src_s)
     assert np.array_equal(want_d, sr.sssp(ptr, ind, wh, src_s)[0])
     for r in range(world):

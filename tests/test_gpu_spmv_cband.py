@@ -301,7 +301,8 @@ def test_auto_waits_for_reuse_before_it_prepares_the_format(powerlaw):
     g, torch, dev = b["g"], b["torch"], b["dev"]
     u = np.random.default_rng(31).integers(0, 3, b["n"]).astype(np.float32)
     want = _reference(b["ptr"], b["ind"], b["v_int"], u, "PlusMultiplies", b["n"]).astype(np.float32)
-    assert g.spmv_set_format(-1) == 1
+    fmt_before = g.spmv_set_format(-1)                  # the module's `forced` fixture may still be in force
+    g.spmv_set_format(1)
     before = g.spmv_set_reuse_threshold(5)
     try:
         A = _matrix(g, torch, dev, b["n"], b["n"], b["ptr"], b["ind"], b["v_int"])
@@ -311,3 +312,4 @@ def test_auto_waits_for_reuse_before_it_prepares_the_format(powerlaw):
             assert g.spmv_format_info(A, 0)["in_use"] == (1 if launch >= 5 else 0), launch
     finally:
         g.spmv_set_reuse_threshold(before)
+        g.spmv_set_format(fmt_before)
