@@ -413,6 +413,20 @@ def assign(w, mask, accum, val, indices, nindices, desc):
     return _lib.load().grb_assign(_h(w), _h(mask), _accum(accum), float(val), _h(desc))
 
 
+UNARY_OPS = ["identity", "ainv", "minv", "abs", "lnot", "bind_first", "bind_second"]      # grb_unary_op
+BINARY_OPS = ["logical_or", "logical_and", "logical_xor", "equal", "not_equal_to", "greater", "less", "greater_equal",
+              "less_equal", "first", "second", "minimum", "maximum", "plus", "minus", "multiplies", "divides"]
+
+
+def apply(w, mask, accum, unary, u, desc, binop=None, scalar=0.0):
+    """apply on the device (grb_vector_apply / grb_matrix_apply): w = f(u) on every stored element.  unary: a name of
+    UNARY_OPS; the two bind kinds take binop (a name of BINARY_OPS) and scalar."""
+    k = UNARY_OPS.index(unary)
+    b = BINARY_OPS.index(binop) if binop is not None else 0
+    fn = "grb_matrix_apply" if isinstance(w, Matrix) else "grb_vector_apply"
+    return getattr(_lib.load(), fn)(_h(w), _h(mask), _accum(accum), k, b, float(scalar), _h(u), _h(desc))
+
+
 def mxm(Cm, mask, accum, op, A, B, desc):
     return _lib.load().grb_mxm(_h(Cm), _h(mask), _accum(accum), _semiring_id(op), _h(A), _h(B), _h(desc))
 

@@ -522,6 +522,7 @@ struct SpmmCore {
 };
 void free_spmm_core(SpmmCore* core);
 int spmv_reuse_threshold(int set);
+grb_info k_apply_unary(int dtype, int unary, int op, double scalar, const void* in, void* out, Index n);   // elementwise.hip
 void spmv_plan_values_changed(SpmvPlan* plan);   // drops every private copy of the stored values (spmv.hip)
 }  // namespace grb
 

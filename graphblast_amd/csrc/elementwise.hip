@@ -803,4 +803,37 @@ grb_info k_gather_indexed(int dtype, void* w, Index w_n, const int* idx, Index n
   });
 }
 
+// ---- apply: w[i] = f(u[i]) ----------------------------------------------------------------------------------------
+// The unary operators of include/grb_hip.h (grb_unary_op); the two BIND kinds go through the run-time binary operator
+// switch the registered semirings use (binop_rt: wave-uniform).  in == out is allowed.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void apply_unary_kernel(const T* in, T* out, Index n, int unary, int op, T scalar) {
+  for (Index i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const T x = in[i];
+    T y;
+    switch (unary) {
+      case GRB_UNARY_IDENTITY: y = x; break;
+      case GRB_UNARY_AINV: y = (T)0 - x; break;
+      case GRB_UNARY_MINV: y = binop<OP_DIV, T>((T)1, x); break;
+      case GRB_UNARY_ABS: y = x < (T)0 ? (T)0 - x : x; break;
+      case GRB_UNARY_LNOT: y = (T)(x == (T)0); break;
+      case GRB_UNARY_BIND_FIRST: y = binop_rt<T>(op, scalar, x); break;
+      default: y = binop_rt<T>(op, x, scalar); break;
+    }
+    out[i] = y;
+  }
+}
+grb_info k_apply_unary(int dtype, int unary, int op, double scalar, const void* in, void* out, Index n) {
+  if (n <= 0) return GRB_SUCCESS;
+  if (unary < 0 || unary >= GRB_N_UNARY_OPS) return GRB_INVALID_VALUE;
+  if ((unary == GRB_UNARY_BIND_FIRST || unary == GRB_UNARY_BIND_SECOND) && (op < 0 || op >= GRB_N_BINARY_OPS)) return GRB_INVALID_VALUE;
+  return dispatch_dtype(dtype, [&](auto t) -> grb_info {
+    using T = decltype(t);
+    hipLaunchKernelGGL(apply_unary_kernel<T>, dim3(stream_grid(n, kBlock * 4)), dim3(kBlock), 0, ctx().stream, (const T*)in,
+                       (T*)out, n, unary, op, (T)scalar);
+    GRB_LAUNCH_CHECK();
+    return GRB_SUCCESS;
+  });
+}
+
 }  // namespace grb

@@ -529,6 +529,33 @@ grb_info grb_vector_dup(grb_vector dst, grb_vector src) {
   return GRB_UNINITIALIZED_OBJECT;
 }
 
+// apply on the device (include/grb_hip.h): w = f(u) on every stored element; w takes u's storage
+grb_info grb_vector_apply(grb_vector w, grb_vector mask, grb_accum accum, int unary, int binop, double scalar, grb_vector u,
+                          grb_descriptor desc) {
+  (void)accum;
+  if (!w || !u || !desc) return GRB_UNINITIALIZED_OBJECT;
+  if (w->nsize != u->nsize) return GRB_DIMENSION_MISMATCH;
+  if (w->dtype != u->dtype) return GRB_DOMAIN_MISMATCH;
+  if (mask) return GRB_NOT_IMPLEMENTED;                  // "apply masked not implemented yet" (apply.hpp:36-37)
+  if (u->vec_type == GRB_SPARSE) {
+    if (w != u) {
+      w->vec_type = GRB_SPARSE;
+      GRB_TRY(vec_alloc_sparse(w));
+      if (u->s_nvals > 0) GRB_TRY(k_copy(w->s_ind, u->s_ind, 4 * (size_t)u->s_nvals));
+      w->s_nvals = u->s_nvals;
+    }
+    return k_apply_unary(u->dtype, unary, binop, scalar, u->s_val, w->s_val, u->s_nvals);
+  }
+  if (u->vec_type != GRB_DENSE) return GRB_UNINITIALIZED_OBJECT;
+  if (w != u) {
+    w->vec_type = GRB_DENSE;
+    GRB_TRY(vec_alloc_dense(w));
+  }
+  GRB_TRY(k_apply_unary(u->dtype, unary, binop, scalar, u->d_val, w->d_val, u->nsize));
+  w->d_nnz = u->nsize;                                   // recounted on demand (grb_vector_nvals: dense -> size)
+  return GRB_SUCCESS;
+}
+
 grb_info grb_vector_clear(grb_vector v) {
   if (!v) return GRB_UNINITIALIZED_OBJECT;
   v->vec_type = GRB_UNKNOWN;          // vector.hpp:105-112
@@ -1018,6 +1045,28 @@ grb_info grb_matrix_set_values(grb_matrix A, const void* csr_val) {
     if (!A->csc_alias)
       GRB_HIP_TRY(hipMemcpy(A->csc.val, A->h_csc_val.data(), 4 * (size_t)A->nvals, hipMemcpyHostToDevice));
   }
+  A->nonneg_values = -1; A->mean_value = -1.0; A->small_int_values = -1;
+  matrix_values_changed(A);
+  return GRB_SUCCESS;
+}
+
+// apply on the stored values of a matrix, in place, both orientations (an element-wise function of the value alone
+// commutes with the transposition); the host mirrors are re-read on demand; every private copy of the values goes
+grb_info grb_matrix_apply(grb_matrix C, grb_matrix mask, grb_accum accum, int unary, int binop, double scalar, grb_matrix A,
+                          grb_descriptor desc) {
+  (void)accum;
+  if (!C || !A || !desc) return GRB_UNINITIALIZED_OBJECT;
+  if (!A->built) return GRB_UNINITIALIZED_OBJECT;
+  if (mask) return GRB_NOT_IMPLEMENTED;                  // "SpMat apply masked not implemented yet" (apply.hpp:103-104)
+  if (C != A) return GRB_NOT_IMPLEMENTED;                // the reference's callers apply in place (gsssp.cu:83)
+  if (!A->owned) return GRB_INVALID_OBJECT;              // adopted storage belongs to the caller
+  if (A->nvals > 0) {
+    GRB_TRY(k_apply_unary(A->dtype, unary, binop, scalar, A->csr.val, A->csr.val, A->nvals));
+    if (A->csc.val && A->csc.val != A->csr.val)
+      GRB_TRY(k_apply_unary(A->dtype, unary, binop, scalar, A->csc.val, A->csc.val, A->nvals));
+  }
+  A->h_csr_val.clear(); A->h_csr_ind.clear();            // host mirrors are re-read on demand (keyed on the index array)
+  A->h_csc_val.clear(); A->h_csc_ind.clear();
   A->nonneg_values = -1; A->mean_value = -1.0; A->small_int_values = -1;
   matrix_values_changed(A);
   return GRB_SUCCESS;

@@ -864,11 +864,88 @@ Info graphColor(Vector<W>* w, const Matrix<a>* A, Descriptor* desc) {
   return to_info(grb_graph_color(GRB_H(w), A->handle(), desc->handle(), NULL));
 }
 
+// ---- unary operators the DEVICE knows (not in the reference: its stddef.hpp has none, and its only apply() callers
+// pass the stateful host generators of algorithm/common.hpp).  apply() with one of these runs on the GPU whatever
+// GrB_BACKEND says; any other functor type is a host functor and keeps the reference's host loop in index order.
+#define GRB_UNARYOP(NAME, CODE, EXPR)                                                              \
+  template <typename T_in = float, typename T_out = T_in>                                          \
+  struct NAME {                                                                                    \
+    static const int grb_unary = CODE;                                                             \
+    static const int grb_op = 0;                                                                   \
+    inline double grb_scalar() const { return 0.0; }                                               \
+    inline T_out operator()(T_in x) const { return static_cast<T_out>(EXPR); }                     \
+  };
+GRB_UNARYOP(unary_identity, GRB_UNARY_IDENTITY, x)
+GRB_UNARYOP(unary_minus, GRB_UNARY_AINV, -x)
+GRB_UNARYOP(unary_reciprocal, GRB_UNARY_MINV, static_cast<T_in>(1) / x)
+GRB_UNARYOP(unary_abs, GRB_UNARY_ABS, x < static_cast<T_in>(0) ? -x : x)
+GRB_UNARYOP(unary_logical_not, GRB_UNARY_LNOT, !x)
+#undef GRB_UNARYOP
+// x -> op(scalar, x) and x -> op(x, scalar) for any of the binary-operator functors above
+template <typename BinaryOpT, typename T = float>
+struct bind_first {
+  static const int grb_unary = GRB_UNARY_BIND_FIRST;
+  static const int grb_op = BinaryOpT::grb_op;
+  T scalar;
+  explicit bind_first(T s) : scalar(s) {}
+  inline double grb_scalar() const { return static_cast<double>(scalar); }
+  inline T operator()(T x) const { return static_cast<T>(BinaryOpT()(scalar, x)); }
+};
+template <typename BinaryOpT, typename T = float>
+struct bind_second {
+  static const int grb_unary = GRB_UNARY_BIND_SECOND;
+  static const int grb_op = BinaryOpT::grb_op;
+  T scalar;
+  explicit bind_second(T s) : scalar(s) {}
+  inline double grb_scalar() const { return static_cast<double>(scalar); }
+  inline T operator()(T x) const { return static_cast<T>(BinaryOpT()(x, scalar)); }
+};
+namespace detail {
+template <typename F> struct is_device_unary {
+  template <typename G> static char test(decltype(G::grb_unary)*);
+  template <typename G> static long test(...);
+  static const bool value = sizeof(test<F>(0)) == sizeof(char);
+};
+}  // namespace detail
+
 // apply on a vector (operations.hpp:559-579 -> backend :878-910, apply.hpp:10-62): implemented in the
 // reference only for a dense u, no mask, under GrB_BACKEND = GrB_SEQUENTIAL -- a host loop in
 // index order between a device->host and a host->device copy (so a stateful functor such as
 // set_random, algorithm/common.hpp:8-20, sees the elements in order).  Every other case prints
 // its "not implemented" line there and changes nothing but w's storage flag.
+namespace detail {
+template <typename W, typename M, typename U, typename BinaryOpT, typename UnaryOpT>
+inline typename std::enable_if<is_device_unary<UnaryOpT>::value, Info>::type
+apply_on_device(Vector<W>* w, const Vector<M>* mask, BinaryOpT accum, const UnaryOpT& op, const Vector<U>* u, Descriptor* desc) {
+  const grb_info i = grb_vector_apply(GRB_H(w), mask ? GRB_H(const_cast<Vector<M>*>(mask)) : static_cast<grb_vector>(NULL),
+                                      accum_of(accum), UnaryOpT::grb_unary, UnaryOpT::grb_op, op.grb_scalar(),
+                                      GRB_H(const_cast<Vector<U>*>(u)), desc->handle());
+  if (i == GRB_NOT_IMPLEMENTED) {
+    std::cout << "Error: DeVec apply masked not implemented yet!\n";
+    return GrB_SUCCESS;
+  }
+  return to_info(i);
+}
+template <typename W, typename M, typename U, typename BinaryOpT, typename UnaryOpT>
+inline typename std::enable_if<!is_device_unary<UnaryOpT>::value, Info>::type
+apply_on_device(Vector<W>*, const Vector<M>*, BinaryOpT, const UnaryOpT&, const Vector<U>*, Descriptor*) {
+  return GrB_NOT_IMPLEMENTED;
+}
+template <typename c, typename UnaryOpT>
+inline typename std::enable_if<is_device_unary<UnaryOpT>::value, Info>::type
+apply_matrix_on_device(Matrix<c>* C, const UnaryOpT& op, Descriptor* desc) {
+  const Info i = to_info(grb_matrix_apply(C->handle(), static_cast<grb_matrix>(NULL), GRB_ACCUM_NULL, UnaryOpT::grb_unary,
+                                          UnaryOpT::grb_op, op.grb_scalar(), C->handle(), desc->handle()));
+  if (i != GrB_SUCCESS) return i;
+  return C->refresh_all();
+}
+template <typename c, typename UnaryOpT>
+inline typename std::enable_if<!is_device_unary<UnaryOpT>::value, Info>::type
+apply_matrix_on_device(Matrix<c>*, const UnaryOpT&, Descriptor*) {
+  return GrB_NOT_IMPLEMENTED;
+}
+}  // namespace detail
+
 template <typename W, typename M, typename U, typename BinaryOpT, typename UnaryOpT>
 Info apply(Vector<W>* w, const Vector<M>* mask, BinaryOpT accum, UnaryOpT op, const Vector<U>* u, Descriptor* desc) {
   (void)accum;
@@ -882,6 +959,8 @@ Info apply(Vector<W>* w, const Vector<M>* mask, BinaryOpT accum, UnaryOpT op, co
     mask->size(&mn);
     if (mn != wn) return GrB_DIMENSION_MISMATCH;
   }
+  if (detail::is_device_unary<UnaryOpT>::value)           // a unary operator the device knows: one kernel, any backend flag
+    return detail::apply_on_device(w, mask, accum, op, u, desc);
   Storage s;
   u->getStorage(&s);
   if (s == GrB_SPARSE) {
@@ -957,6 +1036,10 @@ template <typename c, typename a, typename m, typename BinaryOpT, typename Unary
 Info apply(Matrix<c>* C, const Matrix<m>* mask, BinaryOpT accum, UnaryOpT op, const Matrix<a>* A, Descriptor* desc) {
   if (C == NULL || A == NULL || desc == NULL) return GrB_UNINITIALIZED_OBJECT;
   if (mask != NULL || static_cast<const void*>(C) != static_cast<const void*>(A)) return GrB_NOT_IMPLEMENTED;
+  if (detail::is_device_unary<UnaryOpT>::value) {       // a unary operator the device knows: in place on the device
+    const Info di = detail::apply_matrix_on_device(C, op, desc);
+    if (di != GrB_NOT_IMPLEMENTED && di != GrB_INVALID_OBJECT) return di;   // adopted storage: the host path below
+  }
   return C->transform_values([&](Index, Index, c v) { return op(v); });
 }
 

@@ -76,6 +76,15 @@ typedef enum {
   GRB_OP_MINIMUM, GRB_OP_MAXIMUM, GRB_OP_PLUS, GRB_OP_MINUS, GRB_OP_MULTIPLIES, GRB_OP_DIVIDES, GRB_N_BINARY_OPS
 } grb_binary_op;
 
+/* Unary operators of the device-side apply (the reference declares apply and implements it as a HOST loop under
+ * GrB_BACKEND = GrB_SEQUENTIAL only, backend/cuda/apply.hpp:34-42,102-111; its own callers pass stateful random
+ * functors that only a host loop in index order can serve).  BIND_FIRST / BIND_SECOND make a unary operator of any
+ * grb_binary_op and a scalar: x -> op(scalar, x) / x -> op(x, scalar). */
+typedef enum {
+  GRB_UNARY_IDENTITY = 0, GRB_UNARY_AINV /* -x */, GRB_UNARY_MINV /* 1 / x */, GRB_UNARY_ABS, GRB_UNARY_LNOT /* !x */,
+  GRB_UNARY_BIND_FIRST, GRB_UNARY_BIND_SECOND, GRB_N_UNARY_OPS
+} grb_unary_op;
+
 /* `accum` argument: the reference only tests its presence
  * (typeid(accum).name().size() > 1, backend/cuda/spmv.hpp:34-40). */
 typedef enum { GRB_ACCUM_NULL = 0, GRB_ACCUM_PRESENT = 1 } grb_accum;
@@ -235,6 +244,16 @@ grb_info grb_assignScatter(grb_vector w, grb_vector mask, grb_accum accum, grb_v
 /* extractGather  w[k] = u[indices[k]]   operations.hpp:800-815 -> backend :1212-1253 (gather.hpp:11-50) */
 grb_info grb_extractGather(grb_vector w, grb_vector mask, grb_accum accum, grb_vector u, grb_vector indices,
                            grb_descriptor desc);
+
+/* apply on the device   operations.hpp:559-579 / :581-601 -> backend :878-957 (apply.hpp: host loops there).
+ * Vector: w = f(u) on every stored element (dense: all of them; sparse: the nvals stored ones, indices copied), w takes
+ * u's storage; w == u is allowed.  A mask is GrB_NOT_IMPLEMENTED (the reference prints "apply masked not implemented").
+ * Matrix: in place on the stored values of both orientations (C == A, owned storage), as the reference's
+ * C->h_csrVal_[i] = op(A->h_csrVal_[i]) + syncCpu.  binop is a grb_binary_op for the two BIND kinds, ignored otherwise. */
+grb_info grb_vector_apply(grb_vector w, grb_vector mask, grb_accum accum, int unary, int binop, double scalar, grb_vector u,
+                          grb_descriptor desc);
+grb_info grb_matrix_apply(grb_matrix C, grb_matrix mask, grb_accum accum, int unary, int binop, double scalar, grb_matrix A,
+                          grb_descriptor desc);
 
 /* mxm, masked SpGEMM only   operations.hpp:22-48 -> backend :18-78 (spgemm.hpp:22-110) */
 grb_info grb_mxm(grb_matrix C, grb_matrix mask, grb_accum accum, grb_semiring op, grb_matrix A, grb_matrix B,

@@ -140,3 +140,105 @@ def test_registered_composition_of_a_builtin_uses_its_kernels(hb):
     want = np.zeros(n, F)
     np.maximum.at(want, rows, val + x[ind])
     assert np.allclose(outs[2], want, rtol=1e-6)
+
+
+# ---- apply on the device (grb_vector_apply / grb_matrix_apply) -----------------------------------
+def _unary_ref(name, x, binop=None, scalar=0):
+    s = np.array(scalar, dtype=x.dtype)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        if name == "identity": return x.copy()
+        if name == "ainv": return (0 - x).astype(x.dtype)
+        if name == "minv":
+            if x.dtype == np.int32:
+                return np.where(x == 0, 0, (1 / np.where(x == 0, 1, x)).astype(np.int64)).astype(np.int32)   # C: 1 / x truncated
+            return (np.float32(1) / x).astype(x.dtype)
+        if name == "abs": return np.abs(x)
+        if name == "lnot": return (x == 0).astype(x.dtype)
+        a, b = (np.broadcast_to(s, x.shape), x) if name == "bind_first" else (x, np.broadcast_to(s, x.shape))
+        if binop == "divides":
+            if x.dtype == np.int32:
+                q = np.where(b == 0, 0, (a.astype(np.int64) / np.where(b == 0, 1, b)).astype(np.int64))   # truncation, /0 -> 0
+                return q.astype(np.int32)
+            return (a / b).astype(x.dtype)
+        table = dict(OPS, equal=lambda p, q: (p == q).astype(p.dtype), greater_equal=lambda p, q: (p >= q).astype(p.dtype),
+                     less_equal=lambda p, q: (p <= q).astype(p.dtype),
+                     logical_xor=lambda p, q: ((p != 0) != (q != 0)).astype(p.dtype))
+        return np.asarray(table[binop](a.copy(), b.copy())).astype(x.dtype)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.int32])
+def test_apply_on_the_device_vectors_and_matrix_values(hb, dtype):
+    """every unary operator of the C ABI, every binary operator bound to a scalar on either side, dense and sparse
+    vectors (in place too), and the stored values of a matrix (both orientations; the next product sees them) --
+    against the reference's host loop w[i] = op(u[i]) (backend/cuda/apply.hpp:39-41, :106-108) in numpy"""
+    import graphblast_amd as g
+    from graphblast_amd.api import UNARY_OPS, BINARY_OPS
+    rng = np.random.default_rng(5)
+    n = 5000
+    x = rng.integers(-6, 7, n).astype(dtype)
+    d = g.Descriptor(); d.loadArgs()
+    cases = [(k, None, 0) for k in UNARY_OPS[:5]]
+    cases += [(k, b, s) for k in ("bind_first", "bind_second") for b in BINARY_OPS for s in (3, 0, -2)]
+    for unary, binop, scalar in cases:
+        u, w = g.Vector(n, dtype), g.Vector(n, dtype)
+        assert u.build(x) == 0
+        assert g.apply(w, None, None, unary, u, d, binop=binop, scalar=scalar) == 0
+        want = _unary_ref(unary, x, binop, scalar)
+        got = w.extractTuples()[1]
+        assert np.array_equal(got, want, equal_nan=True), (unary, binop, scalar)
+        assert np.array_equal(u.extractTuples()[1], x)                      # the input is untouched
+    # in place, and a sparse vector: only the stored values change, the indices stay
+    u = g.Vector(n, dtype)
+    assert u.build(x) == 0
+    assert g.apply(u, None, None, "bind_second", u, d, binop="multiplies", scalar=3) == 0
+    assert np.array_equal(u.extractTuples()[1], (x * 3).astype(dtype))
+    idx = np.sort(rng.choice(n, 700, replace=False)).astype(np.int32)
+    sv = rng.integers(1, 9, idx.size).astype(dtype)
+    us, ws = g.Vector(n, dtype), g.Vector(n, dtype)
+    assert us.build(idx, sv, idx.size, None) == 0
+    assert g.apply(ws, None, None, "ainv", us, d) == 0
+    info, gi, gv = ws.extractTuples(sparse=True)
+    assert info == 0 and np.array_equal(gi, idx) and np.array_equal(gv, (0 - sv).astype(dtype))
+    # a mask is not implemented, as in the reference
+    assert g.apply(ws, us, None, "ainv", us, d) == 9                        # GrB_NOT_IMPLEMENTED
+    # matrix values: both orientations, then a product
+    from graphblast_amd.graphgen import finalize_edges
+    src, dst = rng.integers(0, 300, 4000), rng.integers(0, 300, 4000)
+    gr = finalize_edges(src, dst, 300, symmetrize=False)
+    ptr, ind = gr["csr"]
+    val = rng.integers(1, 6, ind.size).astype(dtype)
+    A = g.Matrix(300, 300, dtype)
+    assert A.build_csr(ptr, ind, val) == 0
+    csc_before = A.host_csc()[2].copy()
+    assert g.apply(A, None, None, "bind_second", A, d, binop="plus", scalar=10) == 0
+    assert np.array_equal(A.host_csr()[2], (val + 10).astype(dtype))
+    assert np.array_equal(A.host_csc()[2], (csc_before + 10).astype(dtype))
+    xv = rng.integers(0, 3, 300).astype(dtype)
+    vu, vw = g.Vector(300, dtype), g.Vector(300, dtype)
+    assert vu.build(xv) == 0
+    d2 = g.Descriptor(); d2.loadArgs(mxvmode=2)
+    assert g.mxv(vw, None, None, "PlusMultiplies", A, vu, d2) == 0
+    rows = np.repeat(np.arange(300), np.diff(ptr))
+    want = np.bincount(rows, weights=(val + 10).astype(np.float64) * xv[ind], minlength=300).astype(dtype)
+    assert np.array_equal(vw.extractTuples()[1], want)
+
+
+def test_apply_through_the_cpp_frontend(tmp_path):
+    """graphblas::apply in the drop-in header: the device operators run on the GPU under any GrB_BACKEND, a stateful
+    host functor keeps the reference's host loop in index order (tests/tools/apply_device.cpp)"""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path / "apply_device")
+    subprocess.check_call(["g++", "-std=c++11", "-O1", "-w", "-I" + os.path.join(root, "include"),
+                           os.path.join(root, "tests", "tools", "apply_device.cpp"),
+                           "-L" + os.path.join(root, "graphblast_amd"), "-lgrb_hip",
+                           "-Wl,-rpath," + os.path.join(root, "graphblast_amd"), "-o", out])
+    lines = [[float(t) for t in ln.split()] for ln in subprocess.check_output([out]).decode().strip().split("\n")]
+    u = np.arange(10, dtype=np.float32) - 4
+    assert lines[0] == list(u * 2.5)
+    assert lines[1] == list(np.abs(u))
+    u2 = 10 - u
+    assert lines[2] == list(u2)
+    assert lines[3] == list(u2 + np.arange(10))                               # the k-th call adds k: index order
+    assert lines[4] == [float(i + 1 + 100) for i in range(10)]                # row i holds one entry, value i + 1 + 100
