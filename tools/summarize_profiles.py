@@ -4,7 +4,8 @@ import csv, collections, json, shutil, os, sys
 src, dst = sys.argv[1], sys.argv[2]
 os.makedirs(dst, exist_ok=True)
 for f in os.listdir(dst):
-    os.remove(os.path.join(dst, f))
+    if not f.startswith(("full_suite", "bfs_ab", "tests_")):     # logs of test / A-B runs kept beside the profiles
+        os.remove(os.path.join(dst, f))
 rows = list(csv.reader(open(src + '/bench_kernel_stats.csv')))
 shutil.copy(src + '/bench_kernel_stats.csv', dst + '/bench_kernel_stats_all.csv')
 with open(dst + '/bench_kernel_stats_grb.csv', 'w', newline='') as f:
@@ -22,6 +23,8 @@ if os.path.exists(trace):
     shutil.copy(trace, dst + '/bench_kernel_trace_grb.csv')
     line = json.loads(open(src + '/bench_stdout.log').read().strip().splitlines()[-1])
     W, K = line["warmup"], line["steps"]
+    if "bfs_prep" in line:                   # since round 4 the bench times a matrix's FIRST traversal before the warm-up
+        W += 1
     tr = [r for r in csv.DictReader(open(trace))]
     bfs = [int(r["duration_ns"]) for r in tr if r["kernel"].startswith("grb::bfs_persistent_kernel")]
     spmv = {}
