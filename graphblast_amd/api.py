@@ -609,6 +609,17 @@ def spmv_set_format(fmt=-1):
     return int(_lib.load().grb_spmv_set_format(int(fmt)))
 
 
+def set_lazy(on=-1):
+    """the queue of element-wise calls (grb_set_lazy): 1 queue and fuse (default), 0 run every call at once; < 0 queries.
+    Returns the previous setting."""
+    return int(_lib.load().grb_set_lazy(int(on)))
+
+
+def lazy_pending():
+    """element-wise calls waiting in the queue (grb_lazy_pending; does not flush)"""
+    return int(_lib.load().grb_lazy_pending())
+
+
 def spmv_set_reuse_threshold(launches=-1):
     """CSR-kernel products after which `auto` prepares the column-sorted format for an orientation
     (grb_spmv_set_reuse_threshold; 0 = at once); < 0 only queries.  Returns the previous value."""

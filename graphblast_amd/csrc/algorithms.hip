@@ -32,7 +32,7 @@ extern "C" {
 
 // Bellman-Ford with frontier filtering; MinimumPlus vxm + CustomLessPlus / MinimumPlus
 // eWiseAdd + masked assign + reduce, as algorithm/sssp.hpp:62-91.
-grb_info grb_sssp(grb_vector v, grb_matrix A, grb_index source, grb_descriptor desc, grb_algo_result* result) {
+grb_info grb_sssp(grb_vector v, grb_matrix A, grb_index source, grb_descriptor desc, grb_algo_result* result) { GRB_API_ENTER();
   if (!v || !A || !desc) return GRB_UNINITIALIZED_OBJECT;
   if (source < 0 || source >= A->nrows) return GRB_INVALID_INDEX;
   const Index n = A->nrows;
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(kBlock) void pr_update_kernel(const float* __restri
 }
 }  // namespace grb
 
-grb_info grb_pr(grb_vector p, grb_matrix A, float alpha, float eps, grb_descriptor desc, grb_algo_result* result) {
+grb_info grb_pr(grb_vector p, grb_matrix A, float alpha, float eps, grb_descriptor desc, grb_algo_result* result) { GRB_API_ENTER();
   if (!p || !A || !desc) return GRB_UNINITIALIZED_OBJECT;
   if (!A->built) return GRB_UNINITIALIZED_OBJECT;
   const Index n = A->nrows;
@@ -366,7 +366,7 @@ static grb_info cc_tail_op_by_op(grb_vector diff, grb_vector parent, grb_vector 
 
 // 1 (default; GRB_CC_FUSED=0 in the environment starts with 0): the element-wise tail of an iteration in one
 // launch; 0: the reference's call sequence op by op.  on < 0 only queries.  Returns the value in force.
-int grb_cc_set_fused(int on) {
+int grb_cc_set_fused(int on) { GRB_API_ENTER_NOINFO();
   static int v = [] { const char* e = getenv("GRB_CC_FUSED"); return (!e || atoi(e) != 0) ? 1 : 0; }();
   if (on >= 0) v = on ? 1 : 0;
   return v;
@@ -382,7 +382,7 @@ static grb_info cc_run(grb_vector v, grb_matrix A, grb_descriptor desc, grb_algo
 // calls do not try the fused tail again -- the same rule as the one-launch BFS / SSSP (persistent_failures).
 static int g_cc_barrier_failures = 0;
 
-grb_info grb_cc(grb_vector v, grb_matrix A, int seed, grb_descriptor desc, grb_algo_result* result) {
+grb_info grb_cc(grb_vector v, grb_matrix A, int seed, grb_descriptor desc, grb_algo_result* result) { GRB_API_ENTER();
   (void)seed;
   if (!v || !A || !desc) return GRB_UNINITIALIZED_OBJECT;
   if (v->dtype != GRB_I32 || A->dtype != GRB_I32) return GRB_DOMAIN_MISMATCH;

@@ -428,7 +428,7 @@ extern "C" {
 // scatter (extension; operations.hpp:748-761 -> backend/cuda/operations.hpp:1110-1142 + scatter.hpp:10-82).
 // The dense variant of the reference passes u's length as the bound of w (scatter.hpp:38); a target
 // past w's own end would be an out-of-bounds store there, so w's size bounds it here as well.
-grb_info grb_scatter(grb_vector w, grb_vector mask, grb_vector u, double val, grb_descriptor desc) {
+grb_info grb_scatter(grb_vector w, grb_vector mask, grb_vector u, double val, grb_descriptor desc) { GRB_API_ENTER();
   if (!w || !u) return GRB_UNINITIALIZED_OBJECT;
   (void)desc;
   const int ut = u->vec_type;
@@ -461,7 +461,7 @@ grb_info grb_scatter(grb_vector w, grb_vector mask, grb_vector u, double val, gr
 // to cuSPARSE csrcolor (closed source, not in the tree); what its callers rely on
 // (example/ggc_cusparse.cu:94-99) is a proper colouring with colours counted from 0.  This is
 // Jones-Plassmann with a hashed priority and first-fit colours (colour_by_rounds above).  w: int or float vector of length nrows.
-grb_info grb_graph_color(grb_vector w, grb_matrix A, grb_descriptor desc, int* ncolors) {
+grb_info grb_graph_color(grb_vector w, grb_matrix A, grb_descriptor desc, int* ncolors) { GRB_API_ENTER();
   if (!w || !A || !desc) return GRB_UNINITIALIZED_OBJECT;
   const Index n = A->nrows;
   if (A->ncols != w->nsize) return GRB_DIMENSION_MISMATCH;
@@ -524,7 +524,7 @@ static grb_info load_weights(grb_vector w, grb_vector weights, int seed, Index n
 }
 
 grb_info grb_mis(grb_vector v, grb_matrix A, int seed, grb_vector weights, grb_descriptor desc,
-                 grb_algo_result* result) {
+                 grb_algo_result* result) { GRB_API_ENTER();
   if (!v || !A || !desc) return GRB_UNINITIALIZED_OBJECT;
   if (v->dtype != GRB_I32 || A->dtype != GRB_I32) return GRB_DOMAIN_MISMATCH;
   const Index n = A->nrows;
@@ -546,7 +546,7 @@ grb_info grb_mis(grb_vector v, grb_matrix A, int seed, grb_vector weights, grb_d
 // 0 Jones-Plassmann, 1 maximal-independent-set per colour, 2 independent-set per colour.
 // v = colours from 1 (0 = left uncoloured when max_niter rounds ran out); iterations = `iter`.
 grb_info grb_gc(grb_vector v, grb_matrix A, int seed, grb_vector weights, int max_colors, int algo,
-                grb_descriptor desc, grb_algo_result* result) {
+                grb_descriptor desc, grb_algo_result* result) { GRB_API_ENTER();
   if (!v || !A || !desc) return GRB_UNINITIALIZED_OBJECT;
   if (v->dtype != GRB_I32 || A->dtype != GRB_I32) return GRB_DOMAIN_MISMATCH;
   if (algo < 0 || algo > 2 || max_colors < 2) return GRB_INVALID_VALUE;
@@ -643,7 +643,7 @@ grb_info grb_gc(grb_vector v, grb_matrix A, int seed, grb_vector weights, int ma
 // algorithm::lgc (algorithm/lgc.hpp:14-176): approximate personalised PageRank from s by
 // residual pushes; p and A are float.  iterations = loop passes, last_value = last frontier size.
 grb_info grb_lgc(grb_vector p, grb_matrix A, grb_index s, double alpha, double eps, grb_descriptor desc,
-                 grb_algo_result* result) {
+                 grb_algo_result* result) { GRB_API_ENTER();
   if (!p || !A || !desc) return GRB_UNINITIALIZED_OBJECT;
   if (p->dtype != GRB_F32 || A->dtype != GRB_F32) return GRB_DOMAIN_MISMATCH;
   const Index n = A->nrows;
@@ -701,7 +701,7 @@ grb_info grb_lgc(grb_vector p, grb_matrix A, grb_index s, double alpha, double e
 // algorithm::diameter (algorithm/diameter.hpp:14-59): BFS eccentricity of each source in
 // [s_start, s_end); *diameter_max = the largest, *diameter_ind = the last source attaining it.
 grb_info grb_diameter(grb_vector v, grb_matrix A, grb_index s_start, grb_index s_end, grb_descriptor desc,
-                      int* diameter_max, int* diameter_ind) {
+                      int* diameter_max, int* diameter_ind) { GRB_API_ENTER();
   if (!v || !A || !desc) return GRB_UNINITIALIZED_OBJECT;
   if (v->dtype != GRB_F32 || A->dtype != GRB_F32) return GRB_DOMAIN_MISMATCH;
   const Index n = A->nrows;

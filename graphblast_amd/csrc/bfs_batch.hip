@@ -675,7 +675,7 @@ static grb_info ensure_slices(grb_matrix A, bool in_edges) {
 }
 
 extern "C" grb_info grb_bfs_batch(grb_vector* v, int k, grb_matrix A, const grb_index* sources, grb_descriptor desc,
-                                  grb_bfs_result* result) {
+                                  grb_bfs_result* result) { GRB_API_ENTER();
   if (!v || !A || !desc || !sources) return GRB_UNINITIALIZED_OBJECT;
   if (k < 1 || k > 64) return GRB_INVALID_VALUE;
   if (!A->built || !A->csr.ptr || !A->csc.ptr) return GRB_UNINITIALIZED_OBJECT;

@@ -81,7 +81,7 @@ static grb_info bfs_tally_labels(const float* label, const Index* ptr, Index n, 
 }
 
 extern "C" grb_info grb_bfs_fused(grb_vector v, grb_matrix A, grb_index source, grb_descriptor desc,
-                                  grb_bfs_result* result, grb_bfs_level* levels_out, int max_levels, int profile) {
+                                  grb_bfs_result* result, grb_bfs_level* levels_out, int max_levels, int profile) { GRB_API_ENTER();
   if (!v || !A || !desc) return GRB_UNINITIALIZED_OBJECT;
   if (!A->built || !A->csr.ptr || !A->csc.ptr) return GRB_UNINITIALIZED_OBJECT;
   if (v->dtype != GRB_F32) return GRB_DOMAIN_MISMATCH;

@@ -197,7 +197,7 @@ using namespace grb;
 extern "C" {
 
 grb_info grb_bfs_part_pull(grb_matrix A_in, grb_index lo, grb_index n_global, const uint32_t* d_vis, uint32_t* d_new,
-                           float* d_label_local, float new_label) {
+                           float* d_label_local, float new_label) { GRB_API_ENTER();
   if (!A_in || !A_in->built || !A_in->csr.ptr || !d_vis || !d_new) return GRB_UNINITIALIZED_OBJECT;
   if (lo % 64 != 0 || A_in->ncols != n_global) return GRB_INVALID_VALUE;
   hipStream_t s = ctx().stream;
@@ -214,7 +214,7 @@ grb_info grb_bfs_part_pull(grb_matrix A_in, grb_index lo, grb_index n_global, co
 }
 
 grb_info grb_bfs_part_push(grb_matrix A_out, grb_index lo, grb_index n_global, const uint32_t* d_frontier,
-                           const uint32_t* d_vis, uint32_t* d_work, uint32_t* d_new, int64_t* expanded_edges_out) {
+                           const uint32_t* d_vis, uint32_t* d_work, uint32_t* d_new, int64_t* expanded_edges_out) { GRB_API_ENTER();
   if (!A_out || !A_out->built || !A_out->csr.ptr || !d_frontier || !d_vis || !d_work || !d_new)
     return GRB_UNINITIALIZED_OBJECT;
   if (lo % 64 != 0 || A_out->ncols != n_global) return GRB_INVALID_VALUE;
@@ -270,7 +270,7 @@ grb_info grb_bfs_part_push(grb_matrix A_out, grb_index lo, grb_index n_global, c
 }
 
 grb_info grb_bfs_part_apply(const uint32_t* d_new_global, uint32_t* d_vis, grb_index lo, grb_index n_local,
-                            grb_index n_global, float* d_label_local, float new_label, int32_t* discovered_out) {
+                            grb_index n_global, float* d_label_local, float new_label, int32_t* discovered_out) { GRB_API_ENTER();
   if (!d_new_global || !d_vis || !discovered_out) return GRB_UNINITIALIZED_OBJECT;
   if (lo % 64 != 0) return GRB_INVALID_VALUE;
   Context& c = ctx();
@@ -294,7 +294,7 @@ grb_info grb_bfs_part_apply(const uint32_t* d_new_global, uint32_t* d_vis, grb_i
 grb_info grb_bfs_part_apply2(const uint32_t* d_new_global, uint32_t* d_vis, grb_index lo, grb_index n_local,
                              grb_index n_global, grb_matrix A_out, const int32_t* d_deg_full, float* d_label_local,
                              float new_label, int32_t* discovered_out, int64_t* local_frontier_edges_out,
-                             int64_t* frontier_edges_out) {
+                             int64_t* frontier_edges_out) { GRB_API_ENTER();
   if (!d_new_global || !d_vis || !discovered_out) return GRB_UNINITIALIZED_OBJECT;
   if (lo % 64 != 0) return GRB_INVALID_VALUE;
   Context& c = ctx();
@@ -319,7 +319,7 @@ grb_info grb_bfs_part_apply2(const uint32_t* d_new_global, uint32_t* d_vis, grb_
 }
 
 grb_info grb_bfs_part_push_small(grb_matrix A_out, grb_index lo, grb_index n_global, const uint32_t* d_frontier,
-                                 const uint32_t* d_vis, uint32_t* d_new) {
+                                 const uint32_t* d_vis, uint32_t* d_new) { GRB_API_ENTER();
   if (!A_out || !A_out->built || !A_out->csr.ptr || !d_frontier || !d_vis || !d_new) return GRB_UNINITIALIZED_OBJECT;
   if (lo % 64 != 0 || A_out->ncols != n_global) return GRB_INVALID_VALUE;
   hipStream_t s = ctx().stream;
@@ -336,7 +336,7 @@ grb_info grb_bfs_part_push_small(grb_matrix A_out, grb_index lo, grb_index n_glo
 }
 
 grb_info grb_bfs_part_seed(uint32_t* d_vis, uint32_t* d_new_global, float* d_label_local, grb_index lo,
-                           grb_index n_local, grb_index n_global, grb_index source) {
+                           grb_index n_local, grb_index n_global, grb_index source) { GRB_API_ENTER();
   if (!d_vis || !d_new_global || !d_label_local) return GRB_UNINITIALIZED_OBJECT;
   if (source < 0 || source >= n_global) return GRB_INVALID_INDEX;
   hipStream_t s = ctx().stream;
@@ -351,7 +351,7 @@ grb_info grb_bfs_part_seed(uint32_t* d_vis, uint32_t* d_new_global, float* d_lab
   return GRB_SUCCESS;
 }
 
-grb_info grb_bfs_part_unlabel(float* d_label_local, grb_index n_local, float value) {
+grb_info grb_bfs_part_unlabel(float* d_label_local, grb_index n_local, float value) { GRB_API_ENTER();
   if (n_local <= 0) return GRB_SUCCESS;
   if (!d_label_local) return GRB_NULL_POINTER;
   GRB_TRY(ctx_init());
@@ -361,7 +361,7 @@ grb_info grb_bfs_part_unlabel(float* d_label_local, grb_index n_local, float val
   return GRB_SUCCESS;
 }
 
-grb_info grb_bitmap_or_parts(const uint32_t* d_parts, int world, grb_index nwords, uint32_t* d_out) {
+grb_info grb_bitmap_or_parts(const uint32_t* d_parts, int world, grb_index nwords, uint32_t* d_out) { GRB_API_ENTER();
   if (!d_parts || !d_out || world < 1) return GRB_UNINITIALIZED_OBJECT;
   GRB_TRY(ctx_init());
   hipLaunchKernelGGL(bitmap_or_parts_kernel, dim3(stream_grid(nwords)), dim3(kBlock), 0, ctx().stream, d_parts, world,
@@ -371,7 +371,7 @@ grb_info grb_bitmap_or_parts(const uint32_t* d_parts, int world, grb_index nword
 }
 
 // sum of out-degree over labelled owned vertices + their count (TEPS numerator, local part)
-grb_info grb_bfs_part_tally(grb_matrix A_out, const float* d_label_local, int64_t* edges_out, int32_t* reached_out) {
+grb_info grb_bfs_part_tally(grb_matrix A_out, const float* d_label_local, int64_t* edges_out, int32_t* reached_out) { GRB_API_ENTER();
   if (!A_out || !A_out->built || !d_label_local) return GRB_UNINITIALIZED_OBJECT;
   Context& c = ctx();
   hipStream_t s = c.stream;

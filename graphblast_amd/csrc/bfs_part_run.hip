@@ -876,7 +876,7 @@ grb_info part_bfs_run(grb_part* ps, int nranks, grb_index source, int mode, floa
 extern "C" {
 
 grb_info grb_part_new(grb_part* out, int rank, int world, grb_index n_global, grb_index lo, grb_matrix A_out,
-                      grb_matrix A_in, const int32_t* d_deg_full, int64_t nnz_global) {
+                      grb_matrix A_in, const int32_t* d_deg_full, int64_t nnz_global) { GRB_API_ENTER();
   if (!out) return GRB_NULL_POINTER;
   if (!A_out || !A_out->built || !d_deg_full) return GRB_UNINITIALIZED_OBJECT;
   if (!A_in) A_in = A_out;
@@ -941,7 +941,7 @@ grb_info grb_part_new(grb_part* out, int rank, int world, grb_index n_global, gr
   return GRB_SUCCESS;
 }
 
-grb_info grb_part_free(grb_part p) {
+grb_info grb_part_free(grb_part p) { GRB_API_ENTER();
   if (!p) return GRB_SUCCESS;
   (void)hipStreamSynchronize(ctx().stream);
   if (p->d_block) (void)hipFree(p->d_block);
@@ -961,7 +961,7 @@ grb_info grb_part_free(grb_part p) {
 
 grb_info grb_bfs_part_run(grb_part p, grb_index source, int mxvmode, float switchpoint, float edgeswitch, int max_niter,
                           int levels_per_launch, float* d_label_local, grb_part_bfs_result* result,
-                          grb_bfs_level* levels_out, int max_levels) {
+                          grb_bfs_level* levels_out, int max_levels) { GRB_API_ENTER();
   if (!p) return GRB_UNINITIALIZED_OBJECT;
   float* labels[1] = {d_label_local};
   return part_bfs_run(&p, 1, source, mxvmode, switchpoint, edgeswitch, max_niter, levels_per_launch, labels, result,
@@ -970,7 +970,7 @@ grb_info grb_bfs_part_run(grb_part p, grb_index source, int mxvmode, float switc
 
 grb_info grb_bfs_part_run_group(grb_part* parts, int nranks, grb_index source, int mxvmode, float switchpoint,
                                 float edgeswitch, int max_niter, float* const* d_labels, grb_part_bfs_result* results,
-                                grb_bfs_level* levels_out, int max_levels) {
+                                grb_bfs_level* levels_out, int max_levels) { GRB_API_ENTER();
   if (!parts || !d_labels || nranks < 1) return GRB_NULL_POINTER;
   for (int r = 0; r < nranks; ++r)
     if (!parts[r] || parts[r]->rank != r) return GRB_INVALID_VALUE;

@@ -134,7 +134,7 @@ __global__ __launch_bounds__(kBlock) void pr_part_update_kernel(const float* __r
 
 extern "C" {
 
-grb_info grb_pr_part_update(const void* d_y, const void* d_p_old, float c, void* d_p_next, grb_index n, void* d_acc) {
+grb_info grb_pr_part_update(const void* d_y, const void* d_p_old, float c, void* d_p_next, grb_index n, void* d_acc) { GRB_API_ENTER();
   if (!d_acc) return GRB_NULL_POINTER;
   if (n <= 0) return GRB_SUCCESS;
   if (!d_y || !d_p_old || !d_p_next) return GRB_NULL_POINTER;
@@ -147,7 +147,7 @@ grb_info grb_pr_part_update(const void* d_y, const void* d_p_old, float c, void*
   return GRB_SUCCESS;
 }
 
-grb_info grb_comm_unique_id(void* out128) {
+grb_info grb_comm_unique_id(void* out128) { GRB_API_ENTER();
   if (!out128) return GRB_NULL_POINTER;
   if (!load_rccl(&g_comm.api)) return GRB_NOT_IMPLEMENTED;          // no RCCL on this box
   ncclUniqueId id;
@@ -157,7 +157,7 @@ grb_info grb_comm_unique_id(void* out128) {
   return GRB_SUCCESS;
 }
 
-grb_info grb_comm_init(const void* id128, int rank, int world) {
+grb_info grb_comm_init(const void* id128, int rank, int world) { GRB_API_ENTER();
   if (!id128 || world < 1 || rank < 0 || rank >= world) return GRB_INVALID_VALUE;
   Comm& c = g_comm;
   if (c.comm) return GRB_OUTPUT_NOT_EMPTY;
@@ -198,7 +198,7 @@ static grb_info host_stage(size_t bytes) {
   return GRB_SUCCESS;
 }
 
-grb_info grb_comm_set_host_transport(int rank, int world, grb_comm_host_fn fn, void* user) {
+grb_info grb_comm_set_host_transport(int rank, int world, grb_comm_host_fn fn, void* user) { GRB_API_ENTER();
   Comm& c = g_comm;
   if (c.comm) return GRB_OUTPUT_NOT_EMPTY;
   if (!fn) {                                             // off
@@ -219,7 +219,7 @@ grb_info grb_comm_set_host_transport(int rank, int world, grb_comm_host_fn fn, v
   return GRB_SUCCESS;
 }
 
-grb_info grb_comm_destroy(void) {
+grb_info grb_comm_destroy(void) { GRB_API_ENTER();
   Comm& c = g_comm;
   if (c.host_fn) {
     if (c.h_stage) (void)hipHostFree(c.h_stage);
@@ -243,14 +243,14 @@ grb_info grb_comm_destroy(void) {
   return GRB_SUCCESS;
 }
 
-grb_info grb_comm_info(int* rank, int* world) {
+grb_info grb_comm_info(int* rank, int* world) { GRB_API_ENTER();
   if (rank) *rank = g_comm.rank;
   if (world) *world = g_comm.up() ? g_comm.world : 0;
   return GRB_SUCCESS;
 }
 
 // Per-collective timing (HIP events on the communication stream) on / off; grb_comm_stats reads and resets.
-grb_info grb_comm_timing(int on) {
+grb_info grb_comm_timing(int on) { GRB_API_ENTER();
   g_comm.timed = on != 0;
   return GRB_SUCCESS;
 }
@@ -267,7 +267,7 @@ static grb_info account_last() {
   return GRB_SUCCESS;
 }
 
-grb_info grb_comm_stats(double* total_us, long long* calls, int reset) {
+grb_info grb_comm_stats(double* total_us, long long* calls, int reset) { GRB_API_ENTER();
   Comm& c = g_comm;
   if (total_us) *total_us = c.total_us;
   if (calls) *calls = c.calls;
@@ -276,7 +276,7 @@ grb_info grb_comm_stats(double* total_us, long long* calls, int reset) {
 }
 
 // The compute stream waits (on the device) for the last collective; no host synchronisation.
-grb_info grb_comm_wait(void) {
+grb_info grb_comm_wait(void) { GRB_API_ENTER();
   Comm& c = g_comm;
   if (c.host_fn) return GRB_SUCCESS;                      // host-staged collectives have completed when they return
   if (!c.comm) return GRB_UNINITIALIZED_OBJECT;
@@ -286,7 +286,7 @@ grb_info grb_comm_wait(void) {
 }
 
 // Equal-sized all-gather: every rank sends `bytes` from d_send, d_recv holds world * bytes.
-grb_info grb_comm_allgather(const void* d_send, void* d_recv, size_t bytes) {
+grb_info grb_comm_allgather(const void* d_send, void* d_recv, size_t bytes) { GRB_API_ENTER();
   Comm& c = g_comm;
   if (c.host_fn) {
     hipStream_t s = grb::ctx().stream;
@@ -309,7 +309,7 @@ grb_info grb_comm_allgather(const void* d_send, void* d_recv, size_t bytes) {
 // In-place all-gather of unequal slices: rank r's slice is d_buf[offsets[r] .. offsets[r] + counts[r]) bytes,
 // already in place on rank r; afterwards every rank holds every slice.  One broadcast per rank inside a group:
 // on point-to-point xGMI every peer link carries its slice concurrently.
-grb_info grb_comm_allgatherv_inplace(void* d_buf, const long long* offsets, const long long* counts) {
+grb_info grb_comm_allgatherv_inplace(void* d_buf, const long long* offsets, const long long* counts) { GRB_API_ENTER();
   Comm& c = g_comm;
   if (c.host_fn) {
     if (!offsets || !counts) return GRB_NULL_POINTER;
@@ -348,7 +348,7 @@ grb_info grb_comm_allgatherv_inplace(void* d_buf, const long long* offsets, cons
 }
 
 // In-place sum all-reduce of `count` doubles (convergence scalars, totals).
-grb_info grb_comm_allreduce_sum_f64(void* d_buf, size_t count) {
+grb_info grb_comm_allreduce_sum_f64(void* d_buf, size_t count) { GRB_API_ENTER();
   Comm& c = g_comm;
   if (c.host_fn) {
     hipStream_t s = grb::ctx().stream;

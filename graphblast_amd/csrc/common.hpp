@@ -523,6 +523,26 @@ struct SpmmCore {
 void free_spmm_core(SpmmCore* core);
 int spmv_reuse_threshold(int set);
 grb_info k_apply_unary(int dtype, int unary, int op, double scalar, const void* in, void* out, Index n);   // elementwise.hip
+// ---- lazy.hip: the queue of element-wise calls.  EVERY entry point of the C ABI starts with one of these macros:
+// GRB_API_ENTER flushes the queue (top-level calls only: depth 0 -> 1) before the function touches anything,
+// GRB_API_ENTER_QUEUE is for the functions that may append to it.
+enum { LZ_ADD_VV = 0, LZ_MULT_VV, LZ_ADD_VS, LZ_MULT_VS, LZ_DUP };
+struct ApiScope {
+  static int depth;
+  bool entered_ = false;
+  grb_info enter(bool queue_aware);
+  ~ApiScope();
+};
+grb_info lazy_flush();
+bool lazy_try(int kind, int sr, grb_vector_s* w, grb_vector_s* u, grb_vector_s* v, double scalar, grb_info* flush_info);
+#define GRB_API_ENTER()                                                         \
+  grb::ApiScope api_scope__;                                                    \
+  do {                                                                          \
+    const grb_info api_fi__ = api_scope__.enter(false);                         \
+    if (api_fi__ != GRB_SUCCESS) return api_fi__;                               \
+  } while (0)
+#define GRB_API_ENTER_NOINFO() grb::ApiScope api_scope__; (void)api_scope__.enter(false)
+#define GRB_API_ENTER_QUEUE() grb::ApiScope api_scope__; (void)api_scope__.enter(true)
 void spmv_plan_values_changed(SpmvPlan* plan);   // drops every private copy of the stored values (spmv.hip)
 }  // namespace grb
 

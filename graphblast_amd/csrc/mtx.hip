@@ -165,7 +165,7 @@ extern "C" {
 // Extension: readMtx + Matrix::build in one call, the text parsed on the device.  directed as readMtx:
 // 0 = symmetric iff the banner says so, 1 = force directed, 2 = force undirected.  *A is created here
 // (grb_matrix_free it); dims_out (nullable) = {nrows, ncols, nvals after the loader}.
-grb_info grb_matrix_load_mtx(grb_matrix* A, const char* path, grb_dtype dtype, int directed, grb_index* dims_out) {
+grb_info grb_matrix_load_mtx(grb_matrix* A, const char* path, grb_dtype dtype, int directed, grb_index* dims_out) { GRB_API_ENTER();
   if (!A || !path) return GRB_NULL_POINTER;
   GRB_TRY(ctx_init());
   FILE* f = fopen(path, "rb");

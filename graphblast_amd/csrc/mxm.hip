@@ -660,7 +660,7 @@ static grb_info matrix_scale(grb_matrix A, int op, grb_vector B, double scalar, 
 extern "C" {
 
 grb_info grb_mxm(grb_matrix C, grb_matrix mask, grb_accum accum, grb_semiring op, grb_matrix A, grb_matrix B,
-                 grb_descriptor desc) {
+                 grb_descriptor desc) { GRB_API_ENTER();
   (void)accum;
   if (!C || !A || !B || !desc) return GRB_UNINITIALIZED_OBJECT;
   if (!A->built || !B->built) return GRB_UNINITIALIZED_OBJECT;
@@ -854,7 +854,7 @@ grb_info grb_mxm(grb_matrix C, grb_matrix mask, grb_accum accum, grb_semiring op
 }
 
 // eWiseMult, matrix (x) broadcast scalar (operations.hpp:206-228), in place (C == A)
-grb_info grb_matrix_eWiseMult_scalar(grb_matrix C, grb_semiring op, grb_matrix A, double val) {
+grb_info grb_matrix_eWiseMult_scalar(grb_matrix C, grb_semiring op, grb_matrix A, double val) { GRB_API_ENTER();
   if (!C || !A) return GRB_UNINITIALIZED_OBJECT;
   if (C != A) return GRB_NOT_IMPLEMENTED;
   return matrix_scale(A, op, nullptr, val, true);
@@ -862,14 +862,14 @@ grb_info grb_matrix_eWiseMult_scalar(grb_matrix C, grb_semiring op, grb_matrix A
 
 // eWiseMult, matrix (x) broadcast vector (operations.hpp:240-267): C(i,j) = A(i,j) (x) B(i), or
 // B(j) with GrB_INP1 = GrB_TRAN; in place (C == A)
-grb_info grb_matrix_eWiseMult_vector(grb_matrix C, grb_semiring op, grb_matrix A, grb_vector B, grb_descriptor desc) {
+grb_info grb_matrix_eWiseMult_vector(grb_matrix C, grb_semiring op, grb_matrix A, grb_vector B, grb_descriptor desc) { GRB_API_ENTER();
   if (!C || !A || !B || !desc) return GRB_UNINITIALIZED_OBJECT;
   if (C != A) return GRB_NOT_IMPLEMENTED;
   if (desc->desc[GRB_INP0] != GRB_DEFAULT) return GRB_INVALID_VALUE;
   return matrix_scale(A, op, B, 0.0, desc->desc[GRB_INP1] != GRB_TRAN);
 }
 
-grb_info grb_reduce_matrix_scalar(double* val, grb_accum accum, grb_monoid op, grb_matrix A, grb_descriptor desc) {
+grb_info grb_reduce_matrix_scalar(double* val, grb_accum accum, grb_monoid op, grb_matrix A, grb_descriptor desc) { GRB_API_ENTER();
   (void)accum;
   if (!val || !A || !desc) return GRB_UNINITIALIZED_OBJECT;
   if (!A->built) return GRB_UNINITIALIZED_OBJECT;
@@ -877,7 +877,7 @@ grb_info grb_reduce_matrix_scalar(double* val, grb_accum accum, grb_monoid op, g
   return k_reduce(op, A->dtype, A->csr.val, A->nvals, val);
 }
 
-grb_info grb_matrix_tril(grb_matrix C, grb_matrix A, grb_descriptor desc) {
+grb_info grb_matrix_tril(grb_matrix C, grb_matrix A, grb_descriptor desc) { GRB_API_ENTER();
   if (!C || !A || !desc) return GRB_UNINITIALIZED_OBJECT;
   if (!A->built) return GRB_UNINITIALIZED_OBJECT;
   if (C->nrows != A->nrows || C->ncols != A->ncols) return GRB_DIMENSION_MISMATCH;
@@ -899,7 +899,7 @@ grb_info grb_matrix_tril(grb_matrix C, grb_matrix A, grb_descriptor desc) {
 }
 
 // traceMxmTranspose (extension, operations.hpp:698-711 -> backend :1076-1108, trace.hpp:10-52)
-grb_info grb_trace_mxm_transpose(double* val, grb_semiring op, grb_matrix A, grb_matrix B, grb_descriptor desc) {
+grb_info grb_trace_mxm_transpose(double* val, grb_semiring op, grb_matrix A, grb_matrix B, grb_descriptor desc) { GRB_API_ENTER();
   if (!val || !A || !B) return GRB_UNINITIALIZED_OBJECT;
   (void)desc;
   if (!A->built || !B->built) return GRB_UNINITIALIZED_OBJECT;
@@ -929,7 +929,7 @@ grb_info grb_trace_mxm_transpose(double* val, grb_semiring op, grb_matrix A, grb
 }
 
 // algorithm::tc (algorithm/tc.hpp:15-54): B = (A x A^T) .* A on the lower triangle, ntris = sum(B)
-grb_info grb_tc(int64_t* ntris, grb_matrix A, grb_matrix B, grb_descriptor desc, grb_algo_result* result) {
+grb_info grb_tc(int64_t* ntris, grb_matrix A, grb_matrix B, grb_descriptor desc, grb_algo_result* result) { GRB_API_ENTER();
   if (!ntris || !A || !B || !desc) return GRB_UNINITIALIZED_OBJECT;
   float ms = 0.f;
   grb_descriptor_toggle(desc, GRB_INP1);

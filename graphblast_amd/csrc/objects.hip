@@ -226,13 +226,13 @@ grb_info device_build_from_coo(grb_matrix A, const Index* d_rows, const Index* d
 extern "C" {
 
 // =============================================================================== library
-grb_info grb_set_stream(void* hip_stream) {
+grb_info grb_set_stream(void* hip_stream) { GRB_API_ENTER();
   GRB_TRY(ctx_init());
   ctx().stream = (hipStream_t)hip_stream;
   return GRB_SUCCESS;
 }
 
-grb_info grb_device_info(char* buf, size_t buflen) {
+grb_info grb_device_info(char* buf, size_t buflen) { GRB_API_ENTER();
   GRB_TRY(ctx_init());
   int dev = 0;
   GRB_HIP_TRY(hipGetDevice(&dev));
@@ -242,14 +242,14 @@ grb_info grb_device_info(char* buf, size_t buflen) {
   return GRB_SUCCESS;
 }
 
-const char* grb_version(void) { return "graphblast_amd 0.1 (gfx950)"; }
+const char* grb_version(void) { GRB_API_ENTER_NOINFO(); return "graphblast_amd 0.1 (gfx950)"; }
 
-grb_info grb_timer_start(void) {
+grb_info grb_timer_start(void) { GRB_API_ENTER();
   GRB_TRY(ctx_init());
   GRB_HIP_TRY(hipEventRecord(ctx().ev0, ctx().stream));
   return GRB_SUCCESS;
 }
-grb_info grb_timer_stop(float* elapsed_ms) {
+grb_info grb_timer_stop(float* elapsed_ms) { GRB_API_ENTER();
   GRB_HIP_TRY(hipEventRecord(ctx().ev1, ctx().stream));
   GRB_HIP_TRY(hipEventSynchronize(ctx().ev1));
   GRB_HIP_TRY(hipEventElapsedTime(elapsed_ms, ctx().ev0, ctx().ev1));
@@ -257,7 +257,7 @@ grb_info grb_timer_stop(float* elapsed_ms) {
 }
 
 // =============================================================================== Descriptor
-grb_info grb_descriptor_new(grb_descriptor* desc) {
+grb_info grb_descriptor_new(grb_descriptor* desc) { GRB_API_ENTER();
   if (!desc) return GRB_NULL_POINTER;
   grb_descriptor d = new grb_descriptor_s();
   // backend/cuda/descriptor.hpp:17-18
@@ -267,22 +267,22 @@ grb_info grb_descriptor_new(grb_descriptor* desc) {
   *desc = d;
   return GRB_SUCCESS;
 }
-grb_info grb_descriptor_free(grb_descriptor desc) { delete desc; return GRB_SUCCESS; }
+grb_info grb_descriptor_free(grb_descriptor desc) { GRB_API_ENTER(); delete desc; return GRB_SUCCESS; }
 
-grb_info grb_descriptor_set(grb_descriptor desc, int field, int value) {
+grb_info grb_descriptor_set(grb_descriptor desc, int field, int value) { GRB_API_ENTER();
   if (!desc) return GRB_UNINITIALIZED_OBJECT;
   if (field < 0 || field >= GRB_NDESCFIELD) return GRB_INVALID_VALUE;
   desc->desc[field] = value;
   return GRB_SUCCESS;
 }
-grb_info grb_descriptor_get(grb_descriptor desc, int field, int* value) {
+grb_info grb_descriptor_get(grb_descriptor desc, int field, int* value) { GRB_API_ENTER();
   if (!desc) return GRB_UNINITIALIZED_OBJECT;
   if (field < 0 || field >= GRB_NDESCFIELD) return GRB_INVALID_VALUE;
   *value = desc->desc[field];
   return GRB_SUCCESS;
 }
 // backend/cuda/descriptor.hpp:141-154
-grb_info grb_descriptor_toggle(grb_descriptor desc, int field) {
+grb_info grb_descriptor_toggle(grb_descriptor desc, int field) { GRB_API_ENTER();
   if (!desc) return GRB_UNINITIALIZED_OBJECT;
   if (field >= 0 && field < 4) {
     if (desc->desc[field] != GRB_DEFAULT) desc->desc[field] = GRB_DEFAULT;
@@ -307,7 +307,7 @@ static grb_info desc_apply_modes(grb_descriptor d) {
 }
 
 // parseArgs defaults, graphblas/util.hpp:39-132
-grb_info grb_descriptor_load_defaults(grb_descriptor d) {
+grb_info grb_descriptor_load_defaults(grb_descriptor d) { GRB_API_ENTER();
   if (!d) return GRB_UNINITIALIZED_OBJECT;
   d->niter = 10; d->max_niter = 10000; d->directed = 0; d->timing = 1; d->transpose = 0;
   d->mxvmode = 1; d->switchpoint = 0.01f; d->dirinfo = 0; d->struconly = 0; d->opreuse = 0;
@@ -321,14 +321,14 @@ grb_info grb_descriptor_load_defaults(grb_descriptor d) {
   X(memusage) X(atomic) X(dirinfo) X(nthread) X(max_niter) X(niter) X(timing) X(debug) X(directed) \
   X(transpose) X(edgeswitch)
 
-grb_info grb_descriptor_set_arg(grb_descriptor d, const char* name, double value) {
+grb_info grb_descriptor_set_arg(grb_descriptor d, const char* name, double value) { GRB_API_ENTER();
   if (!d || !name) return GRB_UNINITIALIZED_OBJECT;
 #define X(f) if (strcmp(name, #f) == 0) { d->f = (decltype(d->f))value; return desc_apply_modes(d); }
   GRB_DESC_ARGS(X)
 #undef X
   return GRB_INVALID_VALUE;
 }
-grb_info grb_descriptor_get_arg(grb_descriptor d, const char* name, double* value) {
+grb_info grb_descriptor_get_arg(grb_descriptor d, const char* name, double* value) { GRB_API_ENTER();
   if (!d || !name || !value) return GRB_UNINITIALIZED_OBJECT;
 #define X(f) if (strcmp(name, #f) == 0) { *value = (double)d->f; return GRB_SUCCESS; }
   GRB_DESC_ARGS(X)
@@ -338,7 +338,7 @@ grb_info grb_descriptor_get_arg(grb_descriptor d, const char* name, double* valu
 // REGISTER_SEMIRING(SR, ADD_MONOID, MULT_BINARYOP) / REGISTER_MONOID(M, BINARYOP, IDENTITY) at run time
 // (graphblas/stddef.hpp:140-191).  Operators are numbered as the functor templates of stddef.hpp:14-138 appear there
 // (grb_binary_op); the same composition registered twice gets the same id.
-grb_info grb_semiring_register(int add_op, double add_identity, int mul_op, int* id) {
+grb_info grb_semiring_register(int add_op, double add_identity, int mul_op, int* id) { GRB_API_ENTER();
   if (!id) return GRB_NULL_POINTER;
   if (add_op < 0 || add_op > OP_DIV || mul_op < 0 || mul_op > OP_DIV) return GRB_INVALID_VALUE;
   std::vector<UserSemiring>& reg = user_semirings();
@@ -359,14 +359,14 @@ grb_info grb_semiring_register(int add_op, double add_identity, int mul_op, int*
   return GRB_SUCCESS;
 }
 
-grb_info grb_descriptor_iter_log(grb_descriptor d, grb_algo_iter* out, int cap, int* count) {
+grb_info grb_descriptor_iter_log(grb_descriptor d, grb_algo_iter* out, int cap, int* count) { GRB_API_ENTER();
   if (!d) return GRB_UNINITIALIZED_OBJECT;
   const int k = (int)d->iter_log.size();
   if (count) *count = k;
   if (out && cap > 0 && k > 0) memcpy(out, d->iter_log.data(), sizeof(grb_algo_iter) * (size_t)(k < cap ? k : cap));
   return GRB_SUCCESS;
 }
-grb_info grb_descriptor_lastmxv(grb_descriptor d, int* value) {
+grb_info grb_descriptor_lastmxv(grb_descriptor d, int* value) { GRB_API_ENTER();
   if (!d) return GRB_UNINITIALIZED_OBJECT;
   *value = d->lastmxv;
   return GRB_SUCCESS;
@@ -432,7 +432,7 @@ static grb_info vec_alloc_dense(grb_vector v) {
   return GRB_SUCCESS;
 }
 
-grb_info grb_vector_new(grb_vector* out, grb_dtype dtype, grb_index nsize) {
+grb_info grb_vector_new(grb_vector* out, grb_dtype dtype, grb_index nsize) { GRB_API_ENTER();
   if (!out) return GRB_NULL_POINTER;
   if (nsize < 0) return GRB_INVALID_VALUE;
   GRB_TRY(ctx_init());
@@ -451,7 +451,7 @@ grb_info grb_vector_new(grb_vector* out, grb_dtype dtype, grb_index nsize) {
 // active representation is reallocated for `nsize` elements keeping its first min(nsize, nvals)
 // entries (new dense elements are zero here; the reference leaves them uninitialised).  Both
 // representations follow the new size.
-grb_info grb_vector_resize(grb_vector v, grb_index nsize) {
+grb_info grb_vector_resize(grb_vector v, grb_index nsize) { GRB_API_ENTER();
   if (!v) return GRB_UNINITIALIZED_OBJECT;
   if (nsize < 0) return GRB_INVALID_VALUE;
   if (v->vec_type != GRB_SPARSE && v->vec_type != GRB_DENSE) return GRB_UNINITIALIZED_OBJECT;
@@ -484,7 +484,7 @@ grb_info grb_vector_resize(grb_vector v, grb_index nsize) {
   return GRB_SUCCESS;
 }
 
-grb_info grb_vector_free(grb_vector v) {
+grb_info grb_vector_free(grb_vector v) { GRB_API_ENTER();
   if (!v) return GRB_SUCCESS;
   vec_release_sparse(v);
   vec_release_dense(v);
@@ -492,22 +492,35 @@ grb_info grb_vector_free(grb_vector v) {
   return GRB_SUCCESS;
 }
 
-grb_info grb_vector_set_storage(grb_vector v, int storage) {
+grb_info grb_vector_set_storage(grb_vector v, int storage) { GRB_API_ENTER();
   if (!v) return GRB_UNINITIALIZED_OBJECT;
   v->vec_type = storage;
   if (storage == GRB_SPARSE) return vec_alloc_sparse(v);
   if (storage == GRB_DENSE) return vec_alloc_dense(v);
   return GRB_SUCCESS;
 }
-grb_info grb_vector_get_storage(grb_vector v, int* storage) {
+grb_info grb_vector_get_storage(grb_vector v, int* storage) { GRB_API_ENTER();
   if (!v) return GRB_UNINITIALIZED_OBJECT;
   *storage = v->vec_type;
   return GRB_SUCCESS;
 }
 
-grb_info grb_vector_dup(grb_vector dst, grb_vector src) {
-  if (!dst || !src) return GRB_UNINITIALIZED_OBJECT;
-  if (dst->nsize != src->nsize || dst->dtype != src->dtype) return GRB_DIMENSION_MISMATCH;
+grb_info grb_vector_dup(grb_vector dst, grb_vector src) { GRB_API_ENTER_QUEUE();
+  if (!dst || !src) { GRB_TRY(lazy_flush()); return GRB_UNINITIALIZED_OBJECT; }
+  if (dst->nsize != src->nsize || dst->dtype != src->dtype) { GRB_TRY(lazy_flush()); return GRB_DIMENSION_MISMATCH; }
+  {
+    // a dense copy between library-owned vectors joins the queue of element-wise calls (lazy.hip)
+    grb_info fi = GRB_SUCCESS;
+    if (src->vec_type == GRB_DENSE && dst != src && dst->d_val && dst->d_owned) {
+      const int before = dst->vec_type;
+      dst->vec_type = GRB_DENSE;
+      if (lazy_try(LZ_DUP, 0, dst, src, nullptr, 0.0, &fi)) { dst->d_nnz = src->d_nnz; return GRB_SUCCESS; }
+      dst->vec_type = before;
+    } else {
+      fi = lazy_flush();
+    }
+    GRB_TRY(fi);
+  }
   dst->vec_type = src->vec_type;
   if (src->vec_type == GRB_SPARSE) {
     GRB_TRY(vec_alloc_sparse(dst));
@@ -531,7 +544,7 @@ grb_info grb_vector_dup(grb_vector dst, grb_vector src) {
 
 // apply on the device (include/grb_hip.h): w = f(u) on every stored element; w takes u's storage
 grb_info grb_vector_apply(grb_vector w, grb_vector mask, grb_accum accum, int unary, int binop, double scalar, grb_vector u,
-                          grb_descriptor desc) {
+                          grb_descriptor desc) { GRB_API_ENTER();
   (void)accum;
   if (!w || !u || !desc) return GRB_UNINITIALIZED_OBJECT;
   if (w->nsize != u->nsize) return GRB_DIMENSION_MISMATCH;
@@ -556,7 +569,7 @@ grb_info grb_vector_apply(grb_vector w, grb_vector mask, grb_accum accum, int un
   return GRB_SUCCESS;
 }
 
-grb_info grb_vector_clear(grb_vector v) {
+grb_info grb_vector_clear(grb_vector v) { GRB_API_ENTER();
   if (!v) return GRB_UNINITIALIZED_OBJECT;
   v->vec_type = GRB_UNKNOWN;          // vector.hpp:105-112
   v->nvals = 0;
@@ -564,14 +577,14 @@ grb_info grb_vector_clear(grb_vector v) {
   return k_fill(v->dtype, v->d_val, 0.0, v->nsize);
 }
 
-grb_info grb_vector_size(grb_vector v, grb_index* nsize) {
+grb_info grb_vector_size(grb_vector v, grb_index* nsize) { GRB_API_ENTER();
   if (!v) return GRB_UNINITIALIZED_OBJECT;
   *nsize = v->nsize;
   return GRB_SUCCESS;
 }
 
 // vector.hpp:132-146: sparse -> stored count, dense -> size, unknown -> cached
-grb_info grb_vector_nvals(grb_vector v, grb_index* nvals) {
+grb_info grb_vector_nvals(grb_vector v, grb_index* nvals) { GRB_API_ENTER();
   if (!v) return GRB_UNINITIALIZED_OBJECT;
   if (v->vec_type == GRB_SPARSE) v->nvals = v->s_nvals;
   else if (v->vec_type == GRB_DENSE) v->nvals = v->nsize;
@@ -579,7 +592,7 @@ grb_info grb_vector_nvals(grb_vector v, grb_index* nvals) {
   return GRB_SUCCESS;
 }
 
-grb_info grb_vector_build_sparse(grb_vector v, const grb_index* indices, const void* values, grb_index nvals) {
+grb_info grb_vector_build_sparse(grb_vector v, const grb_index* indices, const void* values, grb_index nvals) { GRB_API_ENTER();
   if (!v) return GRB_UNINITIALIZED_OBJECT;
   v->vec_type = GRB_SPARSE;                                // vector.hpp:154: set before sparse_.build can fail
   GRB_TRY(vec_alloc_sparse(v));
@@ -594,7 +607,7 @@ grb_info grb_vector_build_sparse(grb_vector v, const grb_index* indices, const v
   return GRB_SUCCESS;
 }
 
-grb_info grb_vector_build_dense(grb_vector v, const void* values, grb_index nvals) {
+grb_info grb_vector_build_dense(grb_vector v, const void* values, grb_index nvals) { GRB_API_ENTER();
   if (!v) return GRB_UNINITIALIZED_OBJECT;
   if (nvals > v->nsize) return GRB_INDEX_OUT_OF_BOUNDS;    // dense_vector.hpp:201-202
   v->vec_type = GRB_DENSE;
@@ -606,7 +619,7 @@ grb_info grb_vector_build_dense(grb_vector v, const void* values, grb_index nval
   return GRB_SUCCESS;
 }
 
-grb_info grb_vector_adopt_dense(grb_vector v, void* d_values, grb_index nvals) {
+grb_info grb_vector_adopt_dense(grb_vector v, void* d_values, grb_index nvals) { GRB_API_ENTER();
   if (!v) return GRB_UNINITIALIZED_OBJECT;
   vec_release_dense(v);
   v->d_val = d_values;
@@ -615,7 +628,7 @@ grb_info grb_vector_adopt_dense(grb_vector v, void* d_values, grb_index nvals) {
   v->vec_type = GRB_DENSE;
   return GRB_SUCCESS;
 }
-grb_info grb_vector_adopt_sparse(grb_vector v, grb_index* d_indices, void* d_values, grb_index nvals) {
+grb_info grb_vector_adopt_sparse(grb_vector v, grb_index* d_indices, void* d_values, grb_index nvals) { GRB_API_ENTER();
   if (!v) return GRB_UNINITIALIZED_OBJECT;
   vec_release_sparse(v);
   v->s_ind = d_indices;
@@ -626,7 +639,7 @@ grb_info grb_vector_adopt_sparse(grb_vector v, grb_index* d_indices, void* d_val
   return GRB_SUCCESS;
 }
 
-grb_info grb_vector_set_element(grb_vector v, double val, grb_index index) {
+grb_info grb_vector_set_element(grb_vector v, double val, grb_index index) { GRB_API_ENTER();
   if (!v) return GRB_UNINITIALIZED_OBJECT;
   if (index < 0 || index >= v->nsize) return GRB_INDEX_OUT_OF_BOUNDS;
   uint32_t raw;
@@ -648,7 +661,7 @@ grb_info grb_vector_set_element(grb_vector v, double val, grb_index index) {
   return GRB_UNINITIALIZED_OBJECT;
 }
 
-grb_info grb_vector_extract_element(grb_vector v, double* val, grb_index index) {
+grb_info grb_vector_extract_element(grb_vector v, double* val, grb_index index) { GRB_API_ENTER();
   if (!v || !val) return GRB_UNINITIALIZED_OBJECT;
   if (index < 0 || index >= v->nsize) return GRB_INDEX_OUT_OF_BOUNDS;
   if (v->vec_type != GRB_DENSE) return GRB_NOT_IMPLEMENTED;
@@ -659,7 +672,7 @@ grb_info grb_vector_extract_element(grb_vector v, double* val, grb_index index) 
   return GRB_SUCCESS;
 }
 
-grb_info grb_vector_extract_tuples_sparse(grb_vector v, grb_index* indices, void* values, grb_index* n) {
+grb_info grb_vector_extract_tuples_sparse(grb_vector v, grb_index* indices, void* values, grb_index* n) { GRB_API_ENTER();
   if (!v || !n) return GRB_UNINITIALIZED_OBJECT;
   if (v->vec_type != GRB_SPARSE) return v->vec_type == GRB_DENSE ? GRB_NOT_IMPLEMENTED : GRB_UNINITIALIZED_OBJECT;
   if (*n > v->s_nvals) return GRB_UNINITIALIZED_OBJECT;    // sparse_vector.hpp:203-211
@@ -673,7 +686,7 @@ grb_info grb_vector_extract_tuples_sparse(grb_vector v, grb_index* indices, void
   return GRB_SUCCESS;
 }
 
-grb_info grb_vector_extract_tuples_dense(grb_vector v, void* values, grb_index* n) {
+grb_info grb_vector_extract_tuples_dense(grb_vector v, void* values, grb_index* n) { GRB_API_ENTER();
   if (!v || !n) return GRB_UNINITIALIZED_OBJECT;
   if (v->vec_type == GRB_SPARSE) GRB_TRY(grb_vector_sparse2dense(v, 0.0, nullptr));   // vector.hpp:208-217
   if (v->vec_type != GRB_DENSE) return GRB_UNINITIALIZED_OBJECT;
@@ -685,19 +698,19 @@ grb_info grb_vector_extract_tuples_dense(grb_vector v, void* values, grb_index* 
   return GRB_SUCCESS;
 }
 
-grb_info grb_vector_fill(grb_vector v, double val) {
+grb_info grb_vector_fill(grb_vector v, double val) { GRB_API_ENTER();
   if (!v) return GRB_UNINITIALIZED_OBJECT;
   if (v->vec_type != GRB_DENSE) GRB_TRY(grb_vector_set_storage(v, GRB_DENSE));
   return k_fill(v->dtype, v->d_val, val, v->nsize);
 }
-grb_info grb_vector_fill_ascending(grb_vector v, grb_index) {
+grb_info grb_vector_fill_ascending(grb_vector v, grb_index) { GRB_API_ENTER();
   if (!v) return GRB_UNINITIALIZED_OBJECT;
   if (v->vec_type != GRB_DENSE) GRB_TRY(grb_vector_set_storage(v, GRB_DENSE));
   return k_fill_ascending(v->dtype, v->d_val, v->nsize);
 }
 
 // vector.hpp:428-450: same storage required; size, nvals and ratio_ travel with the contents
-grb_info grb_vector_swap(grb_vector a, grb_vector b) {
+grb_info grb_vector_swap(grb_vector a, grb_vector b) { GRB_API_ENTER();
   if (!a || !b) return GRB_UNINITIALIZED_OBJECT;
   if (a->vec_type != b->vec_type || a->vec_type == GRB_UNKNOWN) return GRB_INVALID_OBJECT;
   if (a->vec_type == GRB_SPARSE) {
@@ -719,7 +732,7 @@ grb_info grb_vector_swap(grb_vector a, grb_vector b) {
 }
 
 // vector.hpp:325-364
-grb_info grb_vector_sparse2dense(grb_vector v, double identity, grb_descriptor desc) {
+grb_info grb_vector_sparse2dense(grb_vector v, double identity, grb_descriptor desc) { GRB_API_ENTER();
   if (!v) return GRB_UNINITIALIZED_OBJECT;
   if (v->vec_type == GRB_DENSE) return GRB_SUCCESS;
   if (v->vec_type == GRB_UNKNOWN) return grb_vector_set_storage(v, GRB_DENSE);
@@ -736,7 +749,7 @@ grb_info grb_vector_sparse2dense(grb_vector v, double identity, grb_descriptor d
 }
 
 // vector.hpp:366-425
-grb_info grb_vector_dense2sparse(grb_vector v, double identity, grb_descriptor desc) {
+grb_info grb_vector_dense2sparse(grb_vector v, double identity, grb_descriptor desc) { GRB_API_ENTER();
   if (!v || !desc) return GRB_UNINITIALIZED_OBJECT;
   if (v->vec_type == GRB_SPARSE) return GRB_INVALID_OBJECT;
   GRB_TRY(vec_alloc_sparse(v));
@@ -749,7 +762,7 @@ grb_info grb_vector_dense2sparse(grb_vector v, double identity, grb_descriptor d
 }
 
 // vector.hpp:291-323: the direction-optimisation heuristic
-grb_info grb_vector_convert(grb_vector v, double identity, float switchpoint, grb_descriptor desc) {
+grb_info grb_vector_convert(grb_vector v, double identity, float switchpoint, grb_descriptor desc) { GRB_API_ENTER();
   if (!v || !desc) return GRB_UNINITIALIZED_OBJECT;
   Index nvals_t = 0, nsize_t = v->nsize;
   if (v->vec_type == GRB_SPARSE) {
@@ -772,7 +785,7 @@ grb_info grb_vector_convert(grb_vector v, double identity, float switchpoint, gr
   return GRB_SUCCESS;
 }
 
-grb_info grb_vector_device_ptrs(grb_vector v, grb_index** d_sparse_ind, void** d_sparse_val, void** d_dense_val) {
+grb_info grb_vector_device_ptrs(grb_vector v, grb_index** d_sparse_ind, void** d_sparse_val, void** d_dense_val) { GRB_API_ENTER();
   if (!v) return GRB_UNINITIALIZED_OBJECT;
   if (d_sparse_ind) *d_sparse_ind = v->s_ind;
   if (d_sparse_val) *d_sparse_val = v->s_val;
@@ -781,7 +794,7 @@ grb_info grb_vector_device_ptrs(grb_vector v, grb_index** d_sparse_ind, void** d
 }
 
 // =============================================================================== Matrix
-grb_info grb_matrix_new(grb_matrix* out, grb_dtype dtype, grb_index nrows, grb_index ncols) {
+grb_info grb_matrix_new(grb_matrix* out, grb_dtype dtype, grb_index nrows, grb_index ncols) { GRB_API_ENTER();
   if (!out) return GRB_NULL_POINTER;
   if (nrows < 0 || ncols < 0) return GRB_INVALID_VALUE;
   GRB_TRY(ctx_init());
@@ -834,7 +847,7 @@ void grb::matrix_release_device(grb_matrix A) {
 }
 }  // extern "C++"
 
-grb_info grb_matrix_free(grb_matrix A) {
+grb_info grb_matrix_free(grb_matrix A) { GRB_API_ENTER();
   if (!A) return GRB_SUCCESS;
   matrix_release_device(A);
   delete A;
@@ -915,7 +928,7 @@ static grb_info finish_device_build(grb_matrix A) {
 // build(): the coordinate list is uploaded and sorted / compressed on the device (build.hip);
 // ties keep input order, duplicates are kept (util.hpp:501-559).
 grb_info grb_matrix_build(grb_matrix A, const grb_index* rows, const grb_index* cols, const void* values,
-                          grb_index nvals) {
+                          grb_index nvals) { GRB_API_ENTER();
   if (!A) return GRB_UNINITIALIZED_OBJECT;
   if (nvals < 0) return GRB_INVALID_VALUE;
   for (Index i = 0; i < nvals; ++i)
@@ -945,7 +958,7 @@ grb_info grb_matrix_build(grb_matrix A, const grb_index* rows, const grb_index* 
 // reverse of every off-diagonal entry, bit 1 drop self loops, bit 2 drop duplicates (first
 // occurrence wins); d_values may be NULL (pattern: every value 1).
 grb_info grb_matrix_ingest_device(grb_matrix A, const grb_index* d_rows, const grb_index* d_cols, const void* d_values,
-                                  grb_index nvals, int flags) {
+                                  grb_index nvals, int flags) { GRB_API_ENTER();
   if (!A) return GRB_UNINITIALIZED_OBJECT;
   if (nvals < 0 || (nvals > 0 && (!d_rows || !d_cols))) return GRB_INVALID_VALUE;
   GRB_TRY(ctx_init());
@@ -956,7 +969,7 @@ grb_info grb_matrix_ingest_device(grb_matrix A, const grb_index* d_rows, const g
 
 grb_info grb_matrix_build_csr(grb_matrix A, const grb_index* csr_ptr, const grb_index* csr_ind, const void* csr_val,
                               grb_index nvals, const grb_index* csc_ptr, const grb_index* csc_ind,
-                              const void* csc_val) {
+                              const void* csc_val) { GRB_API_ENTER();
   if (!A || !csr_ptr) return GRB_UNINITIALIZED_OBJECT;
   matrix_release_device(A);
   A->nvals = nvals;
@@ -975,7 +988,7 @@ grb_info grb_matrix_build_csr(grb_matrix A, const grb_index* csr_ptr, const grb_
 }
 
 grb_info grb_matrix_adopt_device_csr(grb_matrix A, grb_index* d_csr_ptr, grb_index* d_csr_ind, void* d_csr_val,
-                                     grb_index nvals, grb_index* d_csc_ptr, grb_index* d_csc_ind, void* d_csc_val) {
+                                     grb_index nvals, grb_index* d_csc_ptr, grb_index* d_csc_ind, void* d_csc_val) { GRB_API_ENTER();
   if (!A || !d_csr_ptr) return GRB_UNINITIALIZED_OBJECT;
   matrix_release_device(A);
   A->owned = false;
@@ -995,9 +1008,9 @@ grb_info grb_matrix_adopt_device_csr(grb_matrix A, grb_index* d_csr_ptr, grb_ind
   return apply_format(A);
 }
 
-grb_info grb_matrix_nrows(grb_matrix A, grb_index* n) { if (!A) return GRB_UNINITIALIZED_OBJECT; *n = A->nrows; return GRB_SUCCESS; }
-grb_info grb_matrix_ncols(grb_matrix A, grb_index* n) { if (!A) return GRB_UNINITIALIZED_OBJECT; *n = A->ncols; return GRB_SUCCESS; }
-grb_info grb_matrix_nvals(grb_matrix A, grb_index* n) { if (!A) return GRB_UNINITIALIZED_OBJECT; *n = A->nvals; return GRB_SUCCESS; }
+grb_info grb_matrix_nrows(grb_matrix A, grb_index* n) { GRB_API_ENTER(); if (!A) return GRB_UNINITIALIZED_OBJECT; *n = A->nrows; return GRB_SUCCESS; }
+grb_info grb_matrix_ncols(grb_matrix A, grb_index* n) { GRB_API_ENTER(); if (!A) return GRB_UNINITIALIZED_OBJECT; *n = A->ncols; return GRB_SUCCESS; }
+grb_info grb_matrix_nvals(grb_matrix A, grb_index* n) { GRB_API_ENTER(); if (!A) return GRB_UNINITIALIZED_OBJECT; *n = A->nvals; return GRB_SUCCESS; }
 
 static grb_info ensure_host_mirror(grb_matrix A, bool csc) {
   std::vector<Index>& ind = csc ? A->h_csc_ind : A->h_csr_ind;
@@ -1014,7 +1027,7 @@ static grb_info ensure_host_mirror(grb_matrix A, bool csc) {
   return GRB_SUCCESS;
 }
 
-grb_info grb_matrix_host_csr(grb_matrix A, const grb_index** ptr, const grb_index** ind, const void** val) {
+grb_info grb_matrix_host_csr(grb_matrix A, const grb_index** ptr, const grb_index** ind, const void** val) { GRB_API_ENTER();
   if (!A || !A->built) return GRB_UNINITIALIZED_OBJECT;
   GRB_TRY(ensure_host_mirror(A, false));
   if (ptr) *ptr = A->h_csr_ptr.data();
@@ -1022,7 +1035,7 @@ grb_info grb_matrix_host_csr(grb_matrix A, const grb_index** ptr, const grb_inde
   if (val) *val = A->h_csr_val.data();
   return GRB_SUCCESS;
 }
-grb_info grb_matrix_host_csc(grb_matrix A, const grb_index** ptr, const grb_index** ind, const void** val) {
+grb_info grb_matrix_host_csc(grb_matrix A, const grb_index** ptr, const grb_index** ind, const void** val) { GRB_API_ENTER();
   if (!A || !A->built) return GRB_UNINITIALIZED_OBJECT;
   if (!A->csc.ptr) return GRB_NO_VALUE;
   GRB_TRY(ensure_host_mirror(A, true));
@@ -1032,7 +1045,7 @@ grb_info grb_matrix_host_csc(grb_matrix A, const grb_index** ptr, const grb_inde
   return GRB_SUCCESS;
 }
 
-grb_info grb_matrix_set_values(grb_matrix A, const void* csr_val) {
+grb_info grb_matrix_set_values(grb_matrix A, const void* csr_val) { GRB_API_ENTER();
   if (!A || !A->built || !A->owned) return GRB_UNINITIALIZED_OBJECT;
   GRB_TRY(ensure_host_mirror(A, false));
   A->h_csr_val.assign((const uint32_t*)csr_val, (const uint32_t*)csr_val + A->nvals);
@@ -1053,7 +1066,7 @@ grb_info grb_matrix_set_values(grb_matrix A, const void* csr_val) {
 // apply on the stored values of a matrix, in place, both orientations (an element-wise function of the value alone
 // commutes with the transposition); the host mirrors are re-read on demand; every private copy of the values goes
 grb_info grb_matrix_apply(grb_matrix C, grb_matrix mask, grb_accum accum, int unary, int binop, double scalar, grb_matrix A,
-                          grb_descriptor desc) {
+                          grb_descriptor desc) { GRB_API_ENTER();
   (void)accum;
   if (!C || !A || !desc) return GRB_UNINITIALIZED_OBJECT;
   if (!A->built) return GRB_UNINITIALIZED_OBJECT;
@@ -1074,7 +1087,7 @@ grb_info grb_matrix_apply(grb_matrix C, grb_matrix mask, grb_accum accum, int un
 
 // ---- binary cache (sparse_matrix.hpp:328-348 write, :355-407 read; name rule util.hpp:340-357)
 // file = int32 nrows, int32 nvals, int32 rowptr[nrows + 1], int32 colind[nvals]; values implied 1
-grb_info grb_cache_name(const char* mtx_path, int is_undirected, char* out, size_t cap) {
+grb_info grb_cache_name(const char* mtx_path, int is_undirected, char* out, size_t cap) { GRB_API_ENTER();
   if (!mtx_path || !out || cap == 0) return GRB_NULL_POINTER;
   std::string path(mtx_path);
   // dirname / basename (libgen semantics for the cases readMtx meets: a path to a regular file)
@@ -1088,7 +1101,7 @@ grb_info grb_cache_name(const char* mtx_path, int is_undirected, char* out, size
   return (k < 0 || (size_t)k >= cap) ? GRB_INSUFFICIENT_SPACE : GRB_SUCCESS;
 }
 
-grb_info grb_matrix_write_cache(grb_matrix A, const char* path) {
+grb_info grb_matrix_write_cache(grb_matrix A, const char* path) { GRB_API_ENTER();
   if (!A || !A->built) return GRB_UNINITIALIZED_OBJECT;
   if (!path) return GRB_NULL_POINTER;
   GRB_TRY(ensure_host_mirror(A, false));
@@ -1103,7 +1116,7 @@ grb_info grb_matrix_write_cache(grb_matrix A, const char* path) {
 
 // Matrix::build(dat_name): the file's two arrays go to the device as they are (no text, no sort
 // of the CSR side); the CSC side is made there by the stable column sort of build.hip.
-grb_info grb_matrix_build_cache(grb_matrix A, const char* path) {
+grb_info grb_matrix_build_cache(grb_matrix A, const char* path) { GRB_API_ENTER();
   if (!A) return GRB_UNINITIALIZED_OBJECT;
   if (!path) return GRB_NULL_POINTER;
   FILE* f = fopen(path, "rb");

@@ -127,7 +127,7 @@ static grb_info mxv_common(grb_vector w, grb_vector mask, grb_accum accum, int o
 extern "C" {
 
 grb_info grb_vxm(grb_vector w, grb_vector mask, grb_accum accum, grb_semiring op, grb_vector u, grb_matrix A,
-                 grb_descriptor desc) {
+                 grb_descriptor desc) { GRB_API_ENTER();
   if (!w || !u || !A || !desc) return GRB_UNINITIALIZED_OBJECT;        // operations.hpp:66-68
   grb_index u_nvals = 0;
   GRB_TRY(grb_vector_nvals(u, &u_nvals));
@@ -140,7 +140,7 @@ grb_info grb_vxm(grb_vector w, grb_vector mask, grb_accum accum, grb_semiring op
 }
 
 grb_info grb_mxv(grb_vector w, grb_vector mask, grb_accum accum, grb_semiring op, grb_matrix A, grb_vector u,
-                 grb_descriptor desc) {
+                 grb_descriptor desc) { GRB_API_ENTER();
   if (!w || !u || !A || !desc) return GRB_UNINITIALIZED_OBJECT;        // operations.hpp:106-108
   grb_index u_nvals = 0;
   GRB_TRY(grb_vector_nvals(u, &u_nvals));
@@ -154,12 +154,28 @@ grb_info grb_mxv(grb_vector w, grb_vector mask, grb_accum accum, grb_semiring op
 
 // backend/cuda/operations.hpp:331-410 + ewisemult.hpp:32-270
 grb_info grb_eWiseMult(grb_vector w, grb_vector mask, grb_accum accum, grb_semiring op, grb_vector u, grb_vector v,
-                       grb_descriptor desc) {
+                       grb_descriptor desc) { GRB_API_ENTER_QUEUE();
   (void)accum;
-  if (!w || !u || !v || !desc) return GRB_UNINITIALIZED_OBJECT;
-  if (u->nsize != v->nsize || u->nsize != w->nsize || (mask && mask->nsize != w->nsize))
+  if (!w || !u || !v || !desc) { GRB_TRY(lazy_flush()); return GRB_UNINITIALIZED_OBJECT; }
+  if (u->nsize != v->nsize || u->nsize != w->nsize || (mask && mask->nsize != w->nsize)) {
+    GRB_TRY(lazy_flush());
     return GRB_DIMENSION_MISMATCH;
+  }
   const int dt = u->dtype;
+  {
+    // dense (x) dense, no mask: queued when every operand is library-owned (lazy.hip); anything else flushes first
+    grb_info fi = GRB_SUCCESS;
+    const bool plain = !mask && u->vec_type == GRB_DENSE && v->vec_type == GRB_DENSE && w->d_val && w->d_owned;
+    if (plain) {
+      const int before = w->vec_type;
+      w->vec_type = GRB_DENSE;                              // what grb_vector_set_storage(w, GRB_DENSE) does below
+      if (lazy_try(LZ_MULT_VV, op, w, u, v, 0.0, &fi)) return GRB_SUCCESS;
+      w->vec_type = before;
+    } else {
+      fi = lazy_flush();
+    }
+    GRB_TRY(fi);
+  }
   if (u->vec_type == GRB_SPARSE && v->vec_type == GRB_SPARSE)
     GRB_TRY(grb_vector_set_storage(v, GRB_DENSE));          // operations.hpp:361-367: flag only
   if (u->vec_type == GRB_DENSE && v->vec_type == GRB_DENSE) {
@@ -199,12 +215,27 @@ grb_info grb_eWiseMult(grb_vector w, grb_vector mask, grb_accum accum, grb_semir
 
 // backend/cuda/operations.hpp:567-627 + ewiseadd.hpp
 grb_info grb_eWiseAdd(grb_vector w, grb_vector mask, grb_accum accum, grb_semiring op, grb_vector u, grb_vector v,
-                      grb_descriptor desc) {
+                      grb_descriptor desc) { GRB_API_ENTER_QUEUE();
   (void)accum;
-  if (!w || !u || !v || !desc) return GRB_UNINITIALIZED_OBJECT;
-  if (u->nsize != v->nsize || u->nsize != w->nsize || (mask && mask->nsize != w->nsize))
+  if (!w || !u || !v || !desc) { GRB_TRY(lazy_flush()); return GRB_UNINITIALIZED_OBJECT; }
+  if (u->nsize != v->nsize || u->nsize != w->nsize || (mask && mask->nsize != w->nsize)) {
+    GRB_TRY(lazy_flush());
     return GRB_DIMENSION_MISMATCH;
+  }
   const int dt = u->dtype;
+  {
+    grb_info fi = GRB_SUCCESS;
+    const bool plain = !mask && u->vec_type == GRB_DENSE && v->vec_type == GRB_DENSE && w->d_val && w->d_owned;
+    if (plain) {
+      const int before = w->vec_type;
+      w->vec_type = GRB_DENSE;
+      if (lazy_try(LZ_ADD_VV, op, w, u, v, 0.0, &fi)) return GRB_SUCCESS;
+      w->vec_type = before;
+    } else {
+      fi = lazy_flush();
+    }
+    GRB_TRY(fi);
+  }
   const double identity = semiring_identity(op, dt);
   int ut = u->vec_type, vt = v->vec_type;
   if ((u == w && ut == GRB_SPARSE) || (v == w && vt == GRB_SPARSE)) {
@@ -230,12 +261,24 @@ grb_info grb_eWiseAdd(grb_vector w, grb_vector mask, grb_accum accum, grb_semiri
 
 // backend/cuda/operations.hpp:649-699 + ewiseadd.hpp:161-280
 grb_info grb_eWiseAdd_scalar(grb_vector w, grb_vector mask, grb_accum accum, grb_semiring op, grb_vector u,
-                             double val, grb_descriptor desc) {
+                             double val, grb_descriptor desc) { GRB_API_ENTER_QUEUE();
   (void)accum;
-  if (!w || !u || !desc) return GRB_UNINITIALIZED_OBJECT;
-  if (u->nsize != w->nsize) return GRB_DIMENSION_MISMATCH;
-  if (mask) return GRB_NOT_IMPLEMENTED;
+  if (!w || !u || !desc) { GRB_TRY(lazy_flush()); return GRB_UNINITIALIZED_OBJECT; }
+  if (u->nsize != w->nsize) { GRB_TRY(lazy_flush()); return GRB_DIMENSION_MISMATCH; }
+  if (mask) { GRB_TRY(lazy_flush()); return GRB_NOT_IMPLEMENTED; }
   const int dt = u->dtype;
+  {
+    grb_info fi = GRB_SUCCESS;
+    if (u->vec_type == GRB_DENSE && w->d_val && w->d_owned) {
+      const int before = w->vec_type;
+      w->vec_type = GRB_DENSE;
+      if (lazy_try(LZ_ADD_VS, op, w, u, nullptr, val, &fi)) return GRB_SUCCESS;
+      w->vec_type = before;
+    } else {
+      fi = lazy_flush();
+    }
+    GRB_TRY(fi);
+  }
   if (u->vec_type == GRB_DENSE) {
     GRB_TRY(grb_vector_set_storage(w, GRB_DENSE));
     if (u != w)
@@ -252,7 +295,7 @@ grb_info grb_eWiseAdd_scalar(grb_vector w, grb_vector mask, grb_accum accum, grb
 }
 
 // backend/cuda/operations.hpp:1004-1030 + reduce.hpp:13-76
-grb_info grb_reduce_vector(double* val, grb_accum accum, grb_monoid op, grb_vector u, grb_descriptor desc) {
+grb_info grb_reduce_vector(double* val, grb_accum accum, grb_monoid op, grb_vector u, grb_descriptor desc) { GRB_API_ENTER();
   (void)accum;
   if (!val || !u || !desc) return GRB_UNINITIALIZED_OBJECT;
   if (u->vec_type == GRB_SPARSE) {
@@ -265,7 +308,7 @@ grb_info grb_reduce_vector(double* val, grb_accum accum, grb_monoid op, grb_vect
 
 // backend/cuda/operations.hpp:953-986 + reduce.hpp:109-145
 grb_info grb_reduce_matrix_rows(grb_vector w, grb_vector mask, grb_accum accum, grb_monoid op, grb_matrix A,
-                                grb_descriptor desc) {
+                                grb_descriptor desc) { GRB_API_ENTER();
   (void)accum;
   if (!w || !A || !desc) return GRB_UNINITIALIZED_OBJECT;
   if (!A->built) return GRB_UNINITIALIZED_OBJECT;
@@ -279,7 +322,7 @@ grb_info grb_reduce_matrix_rows(grb_vector w, grb_vector mask, grb_accum accum, 
 }
 
 // backend/cuda/operations.hpp:822-860 + assign.hpp:14-241
-grb_info grb_assign(grb_vector w, grb_vector mask, grb_accum accum, double val, grb_descriptor desc) {
+grb_info grb_assign(grb_vector w, grb_vector mask, grb_accum accum, double val, grb_descriptor desc) { GRB_API_ENTER();
   (void)accum;
   if (!w || !desc) return GRB_UNINITIALIZED_OBJECT;
   if (mask && mask->nsize != w->nsize) return GRB_DIMENSION_MISMATCH;
@@ -333,20 +376,20 @@ static grb_info scatter_gather(grb_vector w, grb_vector mask, grb_vector u, grb_
 }
 
 grb_info grb_assignScatter(grb_vector w, grb_vector mask, grb_accum accum, grb_vector u, grb_vector indices,
-                           grb_descriptor desc) {
+                           grb_descriptor desc) { GRB_API_ENTER();
   (void)accum;
   if (!desc) return GRB_UNINITIALIZED_OBJECT;
   return scatter_gather(w, mask, u, indices, false);
 }
 grb_info grb_extractGather(grb_vector w, grb_vector mask, grb_accum accum, grb_vector u, grb_vector indices,
-                           grb_descriptor desc) {
+                           grb_descriptor desc) { GRB_API_ENTER();
   (void)accum;
   if (!desc) return GRB_UNINITIALIZED_OBJECT;
   return scatter_gather(w, mask, u, indices, true);
 }
 
 // ---- algorithm::bfs op by op (graphblas/algorithm/bfs.hpp:14-89) ------------------
-grb_info grb_bfs(grb_vector v, grb_matrix A, grb_index source, grb_descriptor desc, grb_bfs_result* result) {
+grb_info grb_bfs(grb_vector v, grb_matrix A, grb_index source, grb_descriptor desc, grb_bfs_result* result) { GRB_API_ENTER();
   if (!v || !A || !desc) return GRB_UNINITIALIZED_OBJECT;
   if (source < 0 || source >= A->nrows) return GRB_INVALID_INDEX;
   const Index n = A->nrows;
@@ -392,7 +435,7 @@ grb_info grb_bfs(grb_vector v, grb_matrix A, grb_index source, grb_descriptor de
 
 // ---- raw kernel entry points ------------------------------------------------------
 grb_info grb_k_spmv(grb_matrix A, int tran, grb_semiring op, const void* d_u, const void* d_mask, int scmp,
-                    int accum, void* d_w) {
+                    int accum, void* d_w) { GRB_API_ENTER();
   if (!A || !A->built) return GRB_UNINITIALIZED_OBJECT;
   const CsrArrays& M = tran ? A->csc : A->csr;
   SpmvPlan& plan = tran ? A->plan_csc : A->plan_csr;
@@ -402,12 +445,12 @@ grb_info grb_k_spmv(grb_matrix A, int tran, grb_semiring op, const void* d_u, co
                 (other.ptr && other.n == plan.nminor && !A->csc_alias) ? other.ptr : nullptr);
 }
 
-int grb_spmv_set_bands(int k) { return spmv_bands_setting(k); }
-int grb_spmv_set_format(int fmt) { return spmv_format_setting(fmt); }
-int grb_spmv_set_reuse_threshold(int launches) { return spmv_reuse_threshold(launches); }
+int grb_spmv_set_bands(int k) { GRB_API_ENTER_NOINFO(); return spmv_bands_setting(k); }
+int grb_spmv_set_format(int fmt) { GRB_API_ENTER_NOINFO(); return spmv_format_setting(fmt); }
+int grb_spmv_set_reuse_threshold(int launches) { GRB_API_ENTER_NOINFO(); return spmv_reuse_threshold(launches); }
 
 grb_info grb_spmv_format_info(grb_matrix A, int tran, int* in_use, int64_t* groups, int* bands, int* items, int* hub_rows,
-                              int* iso, int64_t* bytes_per_launch) {
+                              int* iso, int64_t* bytes_per_launch) { GRB_API_ENTER();
   if (!A || !A->built) return GRB_UNINITIALIZED_OBJECT;
   SpmvPlan& plan = tran ? A->plan_csc : A->plan_csr;
   long long g = 0, by = 0;
@@ -422,12 +465,12 @@ grb_info grb_spmv_format_info(grb_matrix A, int tran, int* in_use, int64_t* grou
   if (bytes_per_launch) *bytes_per_launch = by;
   return GRB_SUCCESS;
 }
-int grb_sssp_set_nearfar(int mode) { return sssp_nearfar_setting(mode, mode >= -1); }
-int grb_sssp_last_order(void) { return sssp_last_order(-1); }
-void grb_sssp_last_work(int64_t* out3) { long long w[3]; sssp_last_work(w); if (out3) for (int i = 0; i < 3; ++i) out3[i] = w[i]; }
+int grb_sssp_set_nearfar(int mode) { GRB_API_ENTER_NOINFO(); return sssp_nearfar_setting(mode, mode >= -1); }
+int grb_sssp_last_order(void) { GRB_API_ENTER_NOINFO(); return sssp_last_order(-1); }
+void grb_sssp_last_work(int64_t* out3) { GRB_API_ENTER_NOINFO(); long long w[3]; sssp_last_work(w); if (out3) for (int i = 0; i < 3; ++i) out3[i] = w[i]; }
 
 grb_info grb_spmv_plan_info(grb_matrix A, int tran, int warm, int* bands, int64_t* band_nnz, int64_t* pieces,
-                            int* nhot) {
+                            int* nhot) { GRB_API_ENTER();
   if (!A || !A->built) return GRB_UNINITIALIZED_OBJECT;
   if (!bands || !band_nnz || !pieces || !nhot) return GRB_NULL_POINTER;
   const CsrArrays& M = tran ? A->csc : A->csr;
@@ -442,7 +485,7 @@ grb_info grb_spmv_plan_info(grb_matrix A, int tran, int warm, int* bands, int64_
   return GRB_SUCCESS;
 }
 
-int64_t grb_k_spmv_bytes(grb_matrix A, int tran) {
+int64_t grb_k_spmv_bytes(grb_matrix A, int tran) { GRB_API_ENTER_NOINFO();
   if (!A) return 0;
   const int64_t n = tran ? A->ncols : A->nrows;
   return 8 * (int64_t)A->nvals + 12 * n + 4;

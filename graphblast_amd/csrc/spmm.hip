@@ -343,7 +343,7 @@ void grb::free_spmm_core(SpmmCore* core) { free_core(core); }
 
 extern "C" {
 
-grb_info grb_spmm(grb_semiring op, grb_matrix A, int tran, const void* d_B, void* d_C, grb_index k, grb_descriptor desc) {
+grb_info grb_spmm(grb_semiring op, grb_matrix A, int tran, const void* d_B, void* d_C, grb_index k, grb_descriptor desc) { GRB_API_ENTER();
   (void)desc;
   if (!A || !d_B || !d_C) return GRB_UNINITIALIZED_OBJECT;
   if (!A->built) return GRB_UNINITIALIZED_OBJECT;
@@ -386,7 +386,7 @@ grb_info grb_spmm(grb_semiring op, grb_matrix A, int tran, const void* d_B, void
 }
 
 // what the dense-core split of the last grb_spmm on this orientation looks like (0s when it is off)
-grb_info grb_spmm_core_info(grb_matrix A, int tran, int* ntiles, int64_t* nnz_in_tiles) {
+grb_info grb_spmm_core_info(grb_matrix A, int tran, int* ntiles, int64_t* nnz_in_tiles) { GRB_API_ENTER();
   if (!A) return GRB_UNINITIALIZED_OBJECT;
   const SpmmCore& core = tran ? A->spmm_core_csc : A->spmm_core_csr;
   if (ntiles) *ntiles = core.ntiles;

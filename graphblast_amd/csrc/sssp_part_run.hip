@@ -558,7 +558,7 @@ grb_info part_sssp_run(grb_part_sssp* ps, int nranks, grb_index source, int max_
 extern "C" {
 
 grb_info grb_part_sssp_new(grb_part_sssp* out, int rank, int world, grb_index n_global, grb_index lo, grb_matrix A_out,
-                           int outbox_pairs) {
+                           int outbox_pairs) { GRB_API_ENTER();
   if (!out) return GRB_NULL_POINTER;
   if (!A_out || !A_out->built) return GRB_UNINITIALIZED_OBJECT;
   if (A_out->dtype != GRB_F32 || (A_out->nvals > 0 && !A_out->csr.val)) return GRB_DOMAIN_MISMATCH;
@@ -596,7 +596,7 @@ grb_info grb_part_sssp_new(grb_part_sssp* out, int rank, int world, grb_index n_
   return GRB_SUCCESS;
 }
 
-grb_info grb_part_sssp_free(grb_part_sssp p) {
+grb_info grb_part_sssp_free(grb_part_sssp p) { GRB_API_ENTER();
   if (!p) return GRB_SUCCESS;
   (void)hipStreamSynchronize(ctx().stream);
   if (p->d_block) (void)hipFree(p->d_block);
@@ -609,14 +609,14 @@ grb_info grb_part_sssp_free(grb_part_sssp p) {
 }
 
 grb_info grb_sssp_part_run(grb_part_sssp p, grb_index source, int max_niter, int rounds_per_launch, float* d_dist_local,
-                           grb_part_sssp_result* result) {
+                           grb_part_sssp_result* result) { GRB_API_ENTER();
   if (!p) return GRB_UNINITIALIZED_OBJECT;
   float* out[1] = {d_dist_local};
   return part_sssp_run(&p, 1, source, max_niter, rounds_per_launch, out, result);
 }
 
 grb_info grb_sssp_part_run_group(grb_part_sssp* parts, int nranks, grb_index source, int max_niter,
-                                 float* const* d_dist_local, grb_part_sssp_result* results) {
+                                 float* const* d_dist_local, grb_part_sssp_result* results) { GRB_API_ENTER();
   if (!parts || !d_dist_local || nranks < 1) return GRB_NULL_POINTER;
   for (int r = 0; r < nranks; ++r)
     if (!parts[r] || parts[r]->rank != r) return GRB_INVALID_VALUE;

@@ -245,6 +245,15 @@ grb_info grb_assignScatter(grb_vector w, grb_vector mask, grb_accum accum, grb_v
 grb_info grb_extractGather(grb_vector w, grb_vector mask, grb_accum accum, grb_vector u, grb_vector indices,
                            grb_descriptor desc);
 
+/* The queue of element-wise calls (csrc/lazy.hip).  eWiseAdd / eWiseMult / dup on dense, library-owned
+ * vectors without a mask are not run when they are called: up to six of them wait and run as ONE kernel -- every vector
+ * read once, every result written once -- as soon as ANY other entry point of this header is called (each one starts by
+ * flushing), so nothing can observe the difference except the launch count.  Vectors over adopted (caller-owned)
+ * storage never take part.  grb_set_lazy(0) / GRB_LAZY=0: every call runs when it is called; on < 0 only queries;
+ * returns the previous setting.  grb_lazy_pending(): steps waiting (does not flush). */
+int grb_set_lazy(int on);
+int grb_lazy_pending(void);
+
 /* apply on the device   operations.hpp:559-579 / :581-601 -> backend :878-957 (apply.hpp: host loops there).
  * Vector: w = f(u) on every stored element (dense: all of them; sparse: the nvals stored ones, indices copied), w takes
  * u's storage; w == u is allowed.  A mask is GrB_NOT_IMPLEMENTED (the reference prints "apply masked not implemented").

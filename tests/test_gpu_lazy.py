@@ -1,0 +1,145 @@
+"""The queue of element-wise calls (csrc/lazy.hip): eWiseAdd / eWiseMult / dup on dense, library-owned
+vectors are queued and run as ONE kernel when anything else is called.  Nothing but the launch count may differ: every
+chain here runs twice, queued and call by call (grb_set_lazy(0) -- the path the per-operation tests and the fuzz
+campaigns pin against the oracle), and the two final states must be equal bit for bit: all 17 semirings, f32 and
+i32, operands that hold the semiring's identity (eWiseMult's dead-element rule), aliased operands, chains longer
+than the queue and wider than its buffer table, and the calls that must never be queued."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+SEMIRINGS = ["LogicalOrAnd", "PlusMultiplies", "MinimumPlus", "MaximumMultiplies", "PlusDivides", "PlusGreater",
+             "GreaterPlus", "PlusMinus", "PlusLess", "CustomLessPlus", "MinimumMultiplies", "MultipliesMultiplies",
+             "NotEqualToPlus", "MinimumSelectSecond", "PlusNotEqualTo", "CustomLessLess", "MinimumNotEqualTo"]
+
+
+def _values(rng, n, dtype):
+    x = rng.integers(-3, 4, n).astype(dtype)
+    special = [0, 1, np.finfo(np.float32).max if dtype == np.float32 else np.iinfo(np.int32).max,
+               np.finfo(np.float32).tiny if dtype == np.float32 else np.iinfo(np.int32).min]
+    pick = rng.random(n) < 0.3                              # the identities of the 17 semirings, often
+    x[pick] = np.array(special, dtype=dtype)[rng.integers(0, 4, int(pick.sum()))]
+    return x
+
+
+def _random_chain(rng, npool, length):
+    chain = []
+    for _ in range(length):
+        kind = rng.choice(["add", "mult", "add_scalar", "dup"], p=[0.35, 0.35, 0.15, 0.15])
+        w, u, v = (int(z) for z in rng.integers(0, npool, 3))
+        chain.append((kind, SEMIRINGS[int(rng.integers(0, len(SEMIRINGS)))], w, u, v, float(rng.integers(-2, 3))))
+    return chain
+
+
+def _run(g, chain, init, dtype, lazy, probe=None):
+    before = g.set_lazy(1 if lazy else 0)
+    try:
+        d = g.Descriptor(); d.loadArgs()
+        vecs = []
+        for x in init:
+            v = g.Vector(x.size, dtype)
+            assert v.build(x) == 0
+            vecs.append(v)
+        most = 0
+        for kind, sr, w, u, v, s in chain:
+            if kind == "add":
+                assert g.eWiseAdd(vecs[w], None, None, sr, vecs[u], vecs[v], d) == 0
+            elif kind == "mult":
+                assert g.eWiseMult(vecs[w], None, None, sr, vecs[u], vecs[v], d) == 0
+            elif kind == "add_scalar":
+                assert g.eWiseAdd(vecs[w], None, None, sr, vecs[u], s, d) == 0
+            else:
+                assert vecs[w].dup(vecs[u]) == 0
+            most = max(most, g.lazy_pending())
+        if probe is not None:
+            probe.append(most)
+        out = [v.extractTuples()[1].copy() for v in vecs]
+        assert g.lazy_pending() == 0                         # reading a vector ran everything
+        return out
+    finally:
+        g.set_lazy(before)
+
+
+def _same(a, b):
+    return all(np.array_equal(x.view(np.uint32), y.view(np.uint32)) for x, y in zip(a, b))
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.int32])
+def test_random_chains_equal_call_by_call(dtype):
+    import graphblast_amd as g
+    rng = np.random.default_rng(7 if dtype == np.float32 else 8)
+    for trial in range(60):
+        npool = int(rng.integers(2, 12))                     # up to 11 vectors: more than the queue's 8 buffers
+        n = int(rng.choice([1, 63, 64, 1000, 4097]))
+        init = [_values(rng, n, dtype) for _ in range(npool)]
+        chain = _random_chain(rng, npool, int(rng.integers(1, 15)))     # up to 14 steps: more than the queue's 6
+        depth = []
+        with np.errstate(all="ignore"):
+            got = _run(g, chain, init, dtype, True, depth)
+            want = _run(g, chain, init, dtype, False)
+        assert _same(got, want), (trial, chain)
+        if len(chain) >= 2 and dtype == np.float32:
+            assert depth[0] >= 1                             # the calls really waited
+
+
+def test_multiply_then_add_is_not_contracted():
+    """x * y + z in two calls rounds the product before the sum; a fused multiply-add would not"""
+    import graphblast_amd as g
+    rng = np.random.default_rng(3)
+    n = 100000
+    x = (rng.random(n, dtype=np.float32) + np.float32(1)).astype(np.float32)
+    y = (rng.random(n, dtype=np.float32) + np.float32(1)).astype(np.float32)
+    z = (-(x * y)).astype(np.float32) + np.float32(2 ** -20)
+    chain = [("mult", "PlusMultiplies", 3, 0, 1, 0.0), ("add", "PlusMultiplies", 3, 3, 2, 0.0)]
+    init = [x, y, z, np.zeros(n, np.float32)]
+    got = _run(g, chain, init, np.float32, True)
+    want = _run(g, chain, init, np.float32, False)
+    assert _same(got, want)
+    assert np.array_equal(got[3], ((x * y).astype(np.float32) + z).astype(np.float32))
+    assert not np.array_equal(got[3], (x.astype(np.float64) * y + z).astype(np.float32))   # the fma's answer differs
+
+
+def test_what_flushes_and_what_is_never_queued():
+    import torch
+    import graphblast_amd as g
+    before = g.set_lazy(1)
+    try:
+        dev = torch.device("cuda", 0)
+        n = 5000
+        rng = np.random.default_rng(1)
+        d = g.Descriptor(); d.loadArgs()
+        a, b, c = (g.Vector(n) for _ in range(3))
+        xa, xb = rng.integers(0, 5, n).astype(np.float32), rng.integers(0, 5, n).astype(np.float32)
+        assert a.build(xa) == 0 and b.build(xb) == 0
+        assert g.eWiseAdd(c, None, None, "PlusMultiplies", a, b, d) == 0
+        assert g.lazy_pending() == 1
+        info, val = g.reduce(None, "Plus", c, d)               # a reduction reads c: the queue runs first
+        assert info == 0 and g.lazy_pending() == 0 and val == float((xa + xb).sum())
+        # a sparse operand, a mask, adopted storage: executed at once
+        idx = np.arange(0, n, 7, dtype=np.int32)
+        s = g.Vector(n)
+        assert s.build(idx, np.ones(idx.size, np.float32), idx.size, None) == 0
+        assert g.eWiseAdd(c, None, None, "PlusMultiplies", a, s, d) == 0 and g.lazy_pending() == 0
+        assert g.eWiseMult(c, a, None, "PlusMultiplies", a, b, d) == 0 and g.lazy_pending() == 0
+        t = torch.from_numpy(xa.copy()).to(dev)
+        ad = g.Vector(n)
+        assert ad.build_device(t.data_ptr(), n) == 0           # adopted: the caller may touch t without asking
+        assert g.eWiseAdd(c, None, None, "PlusMultiplies", ad, b, d) == 0 and g.lazy_pending() == 0
+        assert g.eWiseAdd(ad, None, None, "PlusMultiplies", a, b, d) == 0 and g.lazy_pending() == 0
+        torch.cuda.synchronize()
+        assert np.array_equal(t.cpu().numpy(), xa + xb)
+        # a queued result feeds a product: the product sees it
+        assert g.eWiseAdd(c, None, None, "PlusMultiplies", a, b, d) == 0
+        assert g.eWiseAdd(c, None, None, "PlusMultiplies", c, 1.0, d) == 0
+        assert g.lazy_pending() == 2
+        A = g.Matrix(n, n)
+        rows = np.arange(n, dtype=np.int32)
+        assert A.build(rows, (rows + 1) % n, np.ones(n, np.float32), n, None) == 0
+        w = g.Vector(n)
+        dd = g.Descriptor(); dd.loadArgs(mxvmode=2)
+        assert g.mxv(w, None, None, "PlusMultiplies", A, c, dd) == 0
+        assert g.lazy_pending() == 0
+        assert np.array_equal(w.extractTuples()[1], np.roll(xa + xb + 1, -1))
+    finally:
+        g.set_lazy(before)
