@@ -526,7 +526,7 @@ grb_info k_apply_unary(int dtype, int unary, int op, double scalar, const void* 
 // ---- lazy.hip: the queue of element-wise calls.  EVERY entry point of the C ABI starts with one of these macros:
 // GRB_API_ENTER flushes the queue (top-level calls only: depth 0 -> 1) before the function touches anything,
 // GRB_API_ENTER_QUEUE is for the functions that may append to it.
-enum { LZ_ADD_VV = 0, LZ_MULT_VV, LZ_ADD_VS, LZ_MULT_VS, LZ_DUP };
+enum { LZ_ADD_VV = 0, LZ_MULT_VV, LZ_ADD_VS, LZ_MULT_VS, LZ_DUP, LZ_ASSIGN /* u = the mask, sr = scmp, scalar = the value */ };
 struct ApiScope {
   static int depth;
   bool entered_ = false;

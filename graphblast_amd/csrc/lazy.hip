@@ -10,7 +10,8 @@
 // out storage with work pending on it.  What is observable is what the calls would have left: the same functors
 // (binop<>, the dense (x) dense identity rule of kernels/ewisemult.hpp:22-25), each step's result rounded where the
 // separate kernels would have stored it (an optimisation barrier keeps a multiply and the next add from contracting
-// into an fma), the Info codes and the storage bookkeeping done at call time.
+// into an fma), the Info codes and the storage bookkeeping done at call time.  A masked constant assign (dense w, dense
+// mask of the same type) joins the queue too: sssp.hpp's and cc.hpp's tails are eWise calls around one.
 //
 // Not queued (flushed, then run as before): masks, sparse operands, adopted (caller-owned) storage -- the caller
 // may look at it, or rewrite an input, without asking the library --, registered semirings, calls made from inside a
@@ -119,6 +120,13 @@ __device__ __forceinline__ void lz_steps(const LzProg& p, LzVec<T> (*r)[kBlock])
           if (a.e[c] == ident || b.e[c] == ident) y.e[c] = ident;
         break;
       }
+      case LZ_ASSIGN: {                                              // w = value where the mask (a) passes, else w stays
+        y = r[o.w][me];
+#pragma unroll
+        for (int c = 0; c < kLzVec; ++c)
+          if ((a.e[c] != (T)0) != (o.add_op != 0)) y.e[c] = sc;       // add_op carries scmp
+        break;
+      }
       default: y = a; break;                                          // LZ_DUP
     }
 #pragma unroll
@@ -164,6 +172,8 @@ static grb_info lazy_run_step(const LazyStep& st, int dtype, Index n) {
     case LZ_MULT_VS:
       if (st.u != st.w) GRB_TRY(k_copy(st.w->d_val, st.u->d_val, 4 * (size_t)n));
       return k_ewise_scalar(st.sr, dtype, st.kind == LZ_ADD_VS ? 1 : 0, st.w->d_val, st.scalar, n);
+    case LZ_ASSIGN:
+      return k_assign_dense_mask_dense(dtype, st.w->d_val, n, st.u->d_val, dtype == GRB_F32 ? 1 : 0, st.sr, st.scalar);
     default:
       if (n > 0 && st.u != st.w) return k_copy(st.w->d_val, st.u->d_val, 4 * (size_t)n);
       return GRB_SUCCESS;
@@ -192,7 +202,8 @@ grb_info lazy_flush() {
     o.kind = (short)st.kind;
     int add_op = 0, mul_op = 0;
     unsigned int ident_bits = 0;
-    const grb_info di = dispatch_semiring(st.sr, q.dtype, [&](auto tag, auto t) -> grb_info {
+    const bool arithmetic = st.kind != LZ_DUP && st.kind != LZ_ASSIGN;
+    const grb_info di = !arithmetic ? GRB_SUCCESS : dispatch_semiring(st.sr, q.dtype, [&](auto tag, auto t) -> grb_info {
       using T = decltype(t);
       constexpr int SR = decltype(tag)::value;
       if constexpr (SR == GRB_RUNTIME_SR) return GRB_INVALID_VALUE;
@@ -205,6 +216,7 @@ grb_info lazy_flush() {
       }
     });
     if (di != GRB_SUCCESS) return di;
+    if (st.kind == LZ_ASSIGN) add_op = st.sr;                         // scmp
     o.add_op = (short)add_op;
     o.mul_op = (short)mul_op;
     o.ident_bits = ident_bits;
@@ -214,11 +226,12 @@ grb_info lazy_flush() {
     if (st.kind == LZ_ADD_VV || st.kind == LZ_MULT_VV) {
       sv = slot(st.v);
       if (!((written >> sv) & 1u)) p.load_mask |= 1u << sv;
-    } else if (st.kind == LZ_ADD_VS || st.kind == LZ_MULT_VS) {
+    } else if (st.kind == LZ_ADD_VS || st.kind == LZ_MULT_VS || st.kind == LZ_ASSIGN) {
       if (q.dtype == GRB_F32) { const float f = (float)st.scalar; memcpy(&o.scalar_bits, &f, 4); }
       else { const int iv = (int)st.scalar; memcpy(&o.scalar_bits, &iv, 4); }
     }
     const int sw = slot(st.w);
+    if (st.kind == LZ_ASSIGN && !((written >> sw) & 1u)) p.load_mask |= 1u << sw;    // w keeps its value where the mask fails
     written |= 1u << sw;
     p.store_mask |= 1u << sw;
     o.u = (signed char)su;
@@ -238,7 +251,8 @@ grb_info lazy_flush() {
 bool lazy_try(int kind, int sr, grb_vector w, grb_vector u, grb_vector v, double scalar, grb_info* flush_info) {
   *flush_info = GRB_SUCCESS;
   const bool two = kind == LZ_ADD_VV || kind == LZ_MULT_VV;
-  bool ok = lazy_enabled() && ApiScope::depth == 1 && sr >= 0 && sr < GRB_N_SEMIRINGS && w && u && (!two || v);
+  const bool arithmetic = kind != LZ_DUP && kind != LZ_ASSIGN;
+  bool ok = lazy_enabled() && ApiScope::depth == 1 && (!arithmetic || (sr >= 0 && sr < GRB_N_SEMIRINGS)) && w && u && (!two || v);
   if (ok) {
     ok = u->vec_type == GRB_DENSE && u->d_owned && u->d_val && w->d_owned && w->d_val && w->vec_type == GRB_DENSE &&
          u->dtype == w->dtype && u->nsize == w->nsize && u->nsize > 0;

@@ -322,11 +322,21 @@ grb_info grb_reduce_matrix_rows(grb_vector w, grb_vector mask, grb_accum accum, 
 }
 
 // backend/cuda/operations.hpp:822-860 + assign.hpp:14-241
-grb_info grb_assign(grb_vector w, grb_vector mask, grb_accum accum, double val, grb_descriptor desc) { GRB_API_ENTER();
+grb_info grb_assign(grb_vector w, grb_vector mask, grb_accum accum, double val, grb_descriptor desc) { GRB_API_ENTER_QUEUE();
   (void)accum;
-  if (!w || !desc) return GRB_UNINITIALIZED_OBJECT;
-  if (mask && mask->nsize != w->nsize) return GRB_DIMENSION_MISMATCH;
+  if (!w || !desc) { GRB_TRY(lazy_flush()); return GRB_UNINITIALIZED_OBJECT; }
+  if (mask && mask->nsize != w->nsize) { GRB_TRY(lazy_flush()); return GRB_DIMENSION_MISMATCH; }
   const int scmp = desc->desc[GRB_MASK] == GRB_SCMP;
+  {
+    // dense w under a dense mask of the same type: joins the queue of element-wise calls (lazy.hip)
+    grb_info fi = GRB_SUCCESS;
+    if (mask && mask != w && w->vec_type == GRB_DENSE && mask->vec_type == GRB_DENSE && mask->dtype == w->dtype) {
+      if (lazy_try(LZ_ASSIGN, scmp, w, mask, nullptr, val, &fi)) return GRB_SUCCESS;
+    } else {
+      fi = lazy_flush();
+    }
+    GRB_TRY(fi);
+  }
   if (w->vec_type == GRB_DENSE) {
     if (!mask) return GRB_SUCCESS;                          // unmasked: error print, no-op
     if (mask->vec_type == GRB_DENSE)

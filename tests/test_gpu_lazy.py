@@ -26,7 +26,7 @@ def _values(rng, n, dtype):
 def _random_chain(rng, npool, length):
     chain = []
     for _ in range(length):
-        kind = rng.choice(["add", "mult", "add_scalar", "dup"], p=[0.35, 0.35, 0.15, 0.15])
+        kind = rng.choice(["add", "mult", "add_scalar", "dup", "assign", "assign_scmp"], p=[0.3, 0.3, 0.1, 0.1, 0.1, 0.1])
         w, u, v = (int(z) for z in rng.integers(0, npool, 3))
         chain.append((kind, SEMIRINGS[int(rng.integers(0, len(SEMIRINGS)))], w, u, v, float(rng.integers(-2, 3))))
     return chain
@@ -36,6 +36,8 @@ def _run(g, chain, init, dtype, lazy, probe=None):
     before = g.set_lazy(1 if lazy else 0)
     try:
         d = g.Descriptor(); d.loadArgs()
+        ds = g.Descriptor(); ds.loadArgs()
+        assert ds.toggle(0) == 0                             # GrB_MASK -> GrB_SCMP
         vecs = []
         for x in init:
             v = g.Vector(x.size, dtype)
@@ -49,6 +51,8 @@ def _run(g, chain, init, dtype, lazy, probe=None):
                 assert g.eWiseMult(vecs[w], None, None, sr, vecs[u], vecs[v], d) == 0
             elif kind == "add_scalar":
                 assert g.eWiseAdd(vecs[w], None, None, sr, vecs[u], s, d) == 0
+            elif kind in ("assign", "assign_scmp"):          # w = s where the mask u passes (w == u: run at once)
+                assert g.assign(vecs[w], vecs[u], None, s, None, None, ds if kind == "assign_scmp" else d) == 0
             else:
                 assert vecs[w].dup(vecs[u]) == 0
             most = max(most, g.lazy_pending())
