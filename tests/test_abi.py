@@ -159,3 +159,31 @@ def test_enumerations_equal_the_references_types_hpp(tmp_path):
         if ln:
             k, v = ln.split()
             assert int(v) == ref[k], ("graphblas.hpp", k)
+
+
+def test_every_entry_point_flushes_the_lazy_queue():
+    """csrc/lazy.hip defers element-wise calls; that is only invisible if EVERY entry point of the C ABI starts by
+    flushing the queue (GRB_API_ENTER / _NOINFO) or is one of the few that may append to it (GRB_API_ENTER_QUEUE, which
+    flush themselves before they touch data).  A new entry point without the macro would read stale vectors: this test
+    is the guard.  Source-level check, no GPU."""
+    import glob
+    names = set(_declared_symbols())
+    found = {}
+    for path in glob.glob(os.path.join(ROOT, "graphblast_amd", "csrc", "*.hip")):
+        src = open(path).read()
+        for m in re.finditer(r'^(?:extern "C" )?([A-Za-z_][\w \*]*?)\s*\b(grb_[A-Za-z0-9_]+)\s*\(', src, re.M):
+            ret, name = m.group(1).strip(), m.group(2)
+            if name not in names or ret.startswith("static") or "return" in ret or "=" in ret:
+                continue
+            i, depth = m.end(), 1
+            while depth and i < len(src):
+                depth += (src[i] == "(") - (src[i] == ")")
+                i += 1
+            mm = re.match(r"\s*\{", src[i:i + 40])
+            if not mm:
+                continue                                   # a declaration or a call, not the definition
+            body = src[i + mm.end(): i + mm.end() + 400]
+            found[name] = bool(re.match(r"\s*(GRB_API_ENTER(_NOINFO|_QUEUE)?\(\)|grb::ApiScope api_scope__)", body)) \
+                or name == "grb_lazy_pending"              # reports the queue; must not flush it
+    assert set(found) == names, sorted(names - set(found))
+    assert all(found.values()), sorted(n for n, ok in found.items() if not ok)
