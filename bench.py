@@ -430,12 +430,21 @@ def main():
                                   "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:])
     if args.gpus != world:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    # GRB_BENCH_SHARED_GPU=1 (tests only): every rank on cuda:0, a gloo group, the library communicator over its
+    # host-staged transport -- the N > 1 code path of this file end to end on a one-GPU box, RCCL itself excepted
+    shared_gpu = world > 1 and os.environ.get("GRB_BENCH_SHARED_GPU") == "1"
+    if shared_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    sdev = torch.device("cpu") if shared_gpu else dev      # where the few scalars the ranks exchange through torch live
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if shared_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     import graphblast_amd as g
     from graphblast_amd.graphgen import rmat_edges, finalize_edges, random_sources
@@ -809,7 +818,10 @@ def main():
         # collectives through the library's own RCCL communicator (csrc/comm.hip: second HIP stream, event
         # fences) unless GRB_DIST_COMM=torch asks for torch.distributed; falls back to it when RCCL cannot be bound
         comm, comm_kind = None, "torch.distributed (%s)" % ("nccl = RCCL" if world > 1 else "no collective at N = 1")
-        if os.environ.get("GRB_DIST_COMM", "rccl") != "torch":
+        if shared_gpu:
+            comm = gdist.HostStagedComm(rank, world, gdist.bitmap_words(n), dev)
+            comm_kind = "library communicator over its host-staged transport (gloo; ranks share one GPU: a test configuration)"
+        elif os.environ.get("GRB_DIST_COMM", "rccl") != "torch":
             try:
                 comm = gdist.RcclComm(rank, world, gdist.bitmap_words(n), dev)
                 comm_kind = "library RCCL communicator (csrc/comm.hip), collectives on a second HIP stream"
@@ -830,7 +842,7 @@ def main():
         barrier()
         elapsed = time.perf_counter() - t0
         if world > 1:
-            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            t = torch.tensor([elapsed], dtype=torch.float64, device=sdev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
         roofline = None
@@ -900,7 +912,7 @@ def main():
             lab_1 = torch.from_numpy(v.extractTuples()[1]).to(lab_p.device)
             if not torch.equal(lab_p, lab_1) or res_p["edges_traversed"] != res_1["edges_traversed"]:
                 bad += 1
-        tb = torch.tensor([float(bad)], dtype=torch.float64, device=dev)
+        tb = torch.tensor([float(bad)], dtype=torch.float64, device=sdev)
         if world > 1:
             dist.all_reduce(tb, op=dist.ReduceOp.SUM)
         extra["parity"] = {"checked_sources": len(check), "mismatches": int(tb.item()),
@@ -926,7 +938,7 @@ def main():
                 my_edges += res["edges_traversed"]
             barrier()
             el = time.perf_counter() - t0
-            t = torch.tensor([el, float(my_edges)], dtype=torch.float64, device=dev)
+            t = torch.tensor([el, float(my_edges)], dtype=torch.float64, device=sdev)
             tm, te = t[:1].clone(), t[1:].clone()
             if world > 1:
                 dist.all_reduce(tm, op=dist.ReduceOp.MAX)

@@ -311,3 +311,37 @@ def test_device_loop_two_processes_host_staged_collectives():
     for cap, d, info in sssp:
         assert np.array_equal(d, want_d), cap
         assert info["iterations"] == want_it, (cap, info)
+
+
+def test_bench_n_greater_than_one_path_with_two_ranks_on_one_gpu():
+    """`bench.py --gpus 2` end to end on the one-GPU box: two ranks launched as the driver launches them
+    (torch.distributed.run), both on cuda:0 with 112 CUs each, a gloo group, the library communicator over its
+    host-staged transport (GRB_BENCH_SHARED_GPU=1).  Everything of the N > 1 path of bench.py runs -- the partition, the
+    device-side level loop with a real collective per level, max-over-ranks timing, the partitioned PageRank, the
+    parity check against every rank's replica, the source-sharded leg, the one JSON line from rank 0 -- except RCCL
+    itself."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, GRB_BENCH_SHARED_GPU="1", GRB_NUM_CU="112")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
+                          "--gpus", "2", "--steps", "4", "--warmup", "1", "--scale", "16", "--no-cpu-baseline"],
+                         capture_output=True, text=True, timeout=500, cwd=root, env=env)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-2500:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-1500:]                       # rank 0 prints, once
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 4 and line["value"] > 0
+    assert line["config"]["parallelism"] == "1d_vertex_partition_x2"
+    assert line["parity"]["mismatches"] == 0 and line["parity"]["checked_sources"] == 4
+    assert line["level_loop"]["where"].startswith("device") and line["level_loop"]["launches_per_traversal"] > 2
+    assert line["collectives"]["collectives_per_traversal"] >= 2
+    assert line["pagerank_partitioned"]["iterations"] == 10
+    assert line["source_sharded_replicas"]["value"] > 0
