@@ -543,6 +543,9 @@ bool lazy_try(int kind, int sr, grb_vector_s* w, grb_vector_s* u, grb_vector_s* 
   } while (0)
 #define GRB_API_ENTER_NOINFO() grb::ApiScope api_scope__; (void)api_scope__.enter(false)
 #define GRB_API_ENTER_QUEUE() grb::ApiScope api_scope__; (void)api_scope__.enter(true)
+// host-only entry points that never look at a vector or a matrix (descriptor fields): no flush, so that the toggles an
+// application puts between two element-wise calls (sssp.hpp:77-81) do not cut its chain
+#define GRB_API_ENTER_HOST() grb::ApiScope api_scope__; (void)api_scope__.enter(true)
 void spmv_plan_values_changed(SpmvPlan* plan);   // drops every private copy of the stored values (spmv.hip)
 }  // namespace grb
 

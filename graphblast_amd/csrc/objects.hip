@@ -269,20 +269,20 @@ grb_info grb_descriptor_new(grb_descriptor* desc) { GRB_API_ENTER();
 }
 grb_info grb_descriptor_free(grb_descriptor desc) { GRB_API_ENTER(); delete desc; return GRB_SUCCESS; }
 
-grb_info grb_descriptor_set(grb_descriptor desc, int field, int value) { GRB_API_ENTER();
+grb_info grb_descriptor_set(grb_descriptor desc, int field, int value) { GRB_API_ENTER_HOST();
   if (!desc) return GRB_UNINITIALIZED_OBJECT;
   if (field < 0 || field >= GRB_NDESCFIELD) return GRB_INVALID_VALUE;
   desc->desc[field] = value;
   return GRB_SUCCESS;
 }
-grb_info grb_descriptor_get(grb_descriptor desc, int field, int* value) { GRB_API_ENTER();
+grb_info grb_descriptor_get(grb_descriptor desc, int field, int* value) { GRB_API_ENTER_HOST();
   if (!desc) return GRB_UNINITIALIZED_OBJECT;
   if (field < 0 || field >= GRB_NDESCFIELD) return GRB_INVALID_VALUE;
   *value = desc->desc[field];
   return GRB_SUCCESS;
 }
 // backend/cuda/descriptor.hpp:141-154
-grb_info grb_descriptor_toggle(grb_descriptor desc, int field) { GRB_API_ENTER();
+grb_info grb_descriptor_toggle(grb_descriptor desc, int field) { GRB_API_ENTER_HOST();
   if (!desc) return GRB_UNINITIALIZED_OBJECT;
   if (field >= 0 && field < 4) {
     if (desc->desc[field] != GRB_DEFAULT) desc->desc[field] = GRB_DEFAULT;
@@ -321,14 +321,14 @@ grb_info grb_descriptor_load_defaults(grb_descriptor d) { GRB_API_ENTER();
   X(memusage) X(atomic) X(dirinfo) X(nthread) X(max_niter) X(niter) X(timing) X(debug) X(directed) \
   X(transpose) X(edgeswitch)
 
-grb_info grb_descriptor_set_arg(grb_descriptor d, const char* name, double value) { GRB_API_ENTER();
+grb_info grb_descriptor_set_arg(grb_descriptor d, const char* name, double value) { GRB_API_ENTER_HOST();
   if (!d || !name) return GRB_UNINITIALIZED_OBJECT;
 #define X(f) if (strcmp(name, #f) == 0) { d->f = (decltype(d->f))value; return desc_apply_modes(d); }
   GRB_DESC_ARGS(X)
 #undef X
   return GRB_INVALID_VALUE;
 }
-grb_info grb_descriptor_get_arg(grb_descriptor d, const char* name, double* value) { GRB_API_ENTER();
+grb_info grb_descriptor_get_arg(grb_descriptor d, const char* name, double* value) { GRB_API_ENTER_HOST();
   if (!d || !name || !value) return GRB_UNINITIALIZED_OBJECT;
 #define X(f) if (strcmp(name, #f) == 0) { *value = (double)d->f; return GRB_SUCCESS; }
   GRB_DESC_ARGS(X)
@@ -366,7 +366,7 @@ grb_info grb_descriptor_iter_log(grb_descriptor d, grb_algo_iter* out, int cap, 
   if (out && cap > 0 && k > 0) memcpy(out, d->iter_log.data(), sizeof(grb_algo_iter) * (size_t)(k < cap ? k : cap));
   return GRB_SUCCESS;
 }
-grb_info grb_descriptor_lastmxv(grb_descriptor d, int* value) { GRB_API_ENTER();
+grb_info grb_descriptor_lastmxv(grb_descriptor d, int* value) { GRB_API_ENTER_HOST();
   if (!d) return GRB_UNINITIALIZED_OBJECT;
   *value = d->lastmxv;
   return GRB_SUCCESS;

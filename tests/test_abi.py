@@ -164,7 +164,7 @@ def test_enumerations_equal_the_references_types_hpp(tmp_path):
 def test_every_entry_point_flushes_the_lazy_queue():
     """csrc/lazy.hip defers element-wise calls; that is only invisible if EVERY entry point of the C ABI starts by
     flushing the queue (GRB_API_ENTER / _NOINFO) or is one of the few that may append to it (GRB_API_ENTER_QUEUE, which
-    flush themselves before they touch data).  A new entry point without the macro would read stale vectors: this test
+    flush themselves before they touch data; GRB_API_ENTER_HOST: descriptor fields only, nothing to see).  A new entry point without the macro would read stale vectors: this test
     is the guard.  Source-level check, no GPU."""
     import glob
     names = set(_declared_symbols())
@@ -183,7 +183,7 @@ def test_every_entry_point_flushes_the_lazy_queue():
             if not mm:
                 continue                                   # a declaration or a call, not the definition
             body = src[i + mm.end(): i + mm.end() + 400]
-            found[name] = bool(re.match(r"\s*(GRB_API_ENTER(_NOINFO|_QUEUE)?\(\)|grb::ApiScope api_scope__)", body)) \
+            found[name] = bool(re.match(r"\s*(GRB_API_ENTER(_NOINFO|_QUEUE|_HOST)?\(\)|grb::ApiScope api_scope__)", body)) \
                 or name == "grb_lazy_pending"              # reports the queue; must not flush it
     assert set(found) == names, sorted(names - set(found))
     assert all(found.values()), sorted(n for n, ok in found.items() if not ok)

@@ -147,3 +147,30 @@ def test_what_flushes_and_what_is_never_queued():
         assert np.array_equal(w.extractTuples()[1], np.roll(xa + xb + 1, -1))
     finally:
         g.set_lazy(before)
+
+
+def test_descriptor_toggles_do_not_cut_a_chain():
+    """sssp.hpp:70-83: eWiseAdd, eWiseAdd, toggle(GrB_MASK), assign, toggle(GrB_MASK) -- the toggles touch no vector,
+    so the three element-wise calls stay one queue; the assign keeps the mask sense it was CALLED with"""
+    import graphblast_amd as g
+    before = g.set_lazy(1)
+    try:
+        rng = np.random.default_rng(2)
+        n = 3000
+        d = g.Descriptor(); d.loadArgs()
+        f2x, vx = rng.integers(0, 9, n).astype(np.float32), rng.integers(0, 9, n).astype(np.float32)
+        f2, v, m = g.Vector(n), g.Vector(n), g.Vector(n)
+        assert f2.build(f2x) == 0 and v.build(vx) == 0 and m.fill(0.0) == 0
+        assert g.eWiseAdd(m, None, None, "CustomLessPlus", f2, v, d) == 0        # m = f2 < v
+        assert g.eWiseAdd(v, None, None, "MinimumPlus", v, f2, d) == 0           # v = min(v, f2)
+        assert d.toggle(0) == 0
+        assert g.lazy_pending() == 2
+        assert g.assign(f2, m, None, 99.0, None, None, d) == 0                   # f2 = 99 where m is ZERO (scmp)
+        assert d.toggle(0) == 0
+        assert g.lazy_pending() == 3
+        want_m = (f2x < vx).astype(np.float32)
+        assert np.array_equal(m.extractTuples()[1], want_m) and g.lazy_pending() == 0
+        assert np.array_equal(v.extractTuples()[1], np.minimum(vx, f2x))
+        assert np.array_equal(f2.extractTuples()[1], np.where(want_m == 0, np.float32(99), f2x))
+    finally:
+        g.set_lazy(before)
