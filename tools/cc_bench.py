@@ -3,6 +3,7 @@ import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import graphblast_amd as g
+g.spmv_set_reuse_threshold(0)   # measurement scripts: the band format at the first product (the library waits for 48 by default)
 from graphblast_amd.graphgen import rmat_edges, finalize_edges
 dev = torch.device("cuda", 0)
 scale = int(sys.argv[1]) if len(sys.argv) > 1 else 20

@@ -1,6 +1,7 @@
 import sys, numpy as np, torch
 sys.path.insert(0, ".")
 import graphblast_amd as g
+g.spmv_set_reuse_threshold(0)   # measurement scripts: the band format at the first product (the library waits for 48 by default)
 from graphblast_amd.graphgen import rmat_edges, finalize_edges
 dev = torch.device("cuda", 0)
 s, d, n = rmat_edges(22, 16, seed=1, device=dev)

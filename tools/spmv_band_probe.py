@@ -10,6 +10,7 @@ import sys
 import torch
 sys.path.insert(0, ".")
 import graphblast_amd as g
+g.spmv_set_reuse_threshold(0)   # measurement scripts: the band format at the first product (the library waits for 48 by default)
 from graphblast_amd.graphgen import rmat_edges, finalize_edges
 
 dev = torch.device("cuda", 0)

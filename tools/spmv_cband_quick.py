@@ -5,6 +5,7 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch                                                    # noqa: E402
 import graphblast_amd as g                                      # noqa: E402
+g.spmv_set_reuse_threshold(0)   # measurement scripts: the band format at the first product (the library waits for 48 by default)
 from graphblast_amd.graphgen import rmat_edges, finalize_edges  # noqa: E402
 dev = torch.device("cuda", 0)
 scale = int(sys.argv[1]) if len(sys.argv) > 1 else 22
