@@ -730,6 +730,10 @@ def main():
         pu.fill(1.5); pv.fill(2.5); pw.fill(0.0)
         pd = g.Descriptor(); pd.loadArgs()
 
+        # (the queue of element-wise calls is switched off for this measurement: ten identical calls in a row would
+        # otherwise run as two fused kernels, and the number asked for here is the bandwidth of ONE call's kernel)
+        lazy_before = g.set_lazy(0)
+
         def prim(fn, bytes_per_elt, reps=10):
             fn()
             g.timer_start()
@@ -745,7 +749,9 @@ def main():
             "eWiseMult": prim(lambda: g.eWiseMult(pw, None, None, "PlusMultiplies", pu, pv, pd), 12),
             "reduce": prim(lambda: g.reduce(None, "PlusMonoid", pu, pd), 4),
             "assign": prim(lambda: g.assign(pw, pu, None, 3.0, None, pn, pd), 8),
+            "element_wise_queue": "off for this measurement (one kernel per call)",
         }
+        g.set_lazy(lazy_before)
         del pu, pv, pw
 
         # ---- CPU baseline: the oracle's sequential BFS on a bounded sample (checker code,

@@ -3,6 +3,7 @@ import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import graphblast_amd as g
+g.set_lazy(0)                     # one kernel per call: this script measures kernels
 dev = torch.device("cuda", 0)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 26
 d = g.Descriptor(); d.loadArgs()
