@@ -39,17 +39,8 @@ namespace grb {
 #ifndef GRB_BFS_SYM
 #define GRB_BFS_SYM 1
 #endif
-#ifndef GRB_BFS_LAB_UNROLL
-#define GRB_BFS_LAB_UNROLL 1
-#endif
-#ifndef GRB_BFS_L1_FAST
-#define GRB_BFS_L1_FAST 1
-#endif
 #ifndef GRB_BFS_RELAUNDER
 #define GRB_BFS_RELAUNDER 1
-#endif
-#ifndef GRB_BFS_LABEL_WORDS
-#define GRB_BFS_LABEL_WORDS 1
 #endif
 #ifndef GRB_BFS_SPARSE_FRESH
 #define GRB_BFS_SPARSE_FRESH 1
@@ -233,20 +224,7 @@ __global__ __launch_bounds__(kPThreads) void bfs_persistent_kernel(PersistArgs a
         for (long long p = a.optr[a.source] + gtid; p < e; p += gthreads) {
           const Index dst = a.oind[p];
           if (dst == a.source) continue;
-#if GRB_BFS_L1_FAST
-          // nothing but the source is visited yet: no peek, and the winner's bookkeeping loads go out beside the
-          // atomic instead of behind it (the returning atomic still settles a repeated entry of the row)
-          const Index d0 = a.optr[dst], d1 = a.optr[dst + 1];
-          const unsigned int bit = 1u << (dst & 31);
-          if (atomicOr(&V[dst >> 5], bit) & bit) continue;
-          atomicOr(&Fn[dst >> 5], bit);
-          if (new_label > 0.f) a.label[dst] = new_label;
-          ++c.found;
-          c.deg += (unsigned long long)(d1 - d0);
-          if (d1 - d0 >= kBigDeg) ++c.big;
-#else
           push_visit(a, V, Fn, dst, new_label, c);
-#endif
         }
       } else {
         unsigned* bcount = &st->big_count[iter & 1][0];
@@ -650,7 +628,6 @@ __global__ __launch_bounds__(kPThreads) void bfs_persistent_kernel(PersistArgs a
   // discovered by a level >= kKeep and labelled there.  (V[cur] and every F are final after the last barrier.)
   {
     GRB_PHASE_START();
-#if GRB_BFS_LABEL_WORDS
     // One bitmap word (32 vertices) per lane: the visited word and the word of every kept level go out together
     // (agent-scope loads: no invalidate to wait for), so the pass is one memory latency deep; a lane then writes its
     // 32 labels as eight 16-byte stores (a whole 128-byte line per lane).
@@ -705,58 +682,6 @@ __global__ __launch_bounds__(kPThreads) void bfs_persistent_kernel(PersistArgs a
         }
       }
     }
-#else
-    // nothing is written any more: read the bitmaps through L1 (one invalidate), eight 64-vertex chunks per
-    // wave step so that a step costs one memory latency, not one per level
-    if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    __syncthreads();
-    const unsigned int* __restrict__ Vf = a.V[cur];
-    const int kept = levels + 1 < kKeep ? levels + 1 : kKeep;      // F[0 .. kept)
-    constexpr int kLB = 8;
-    const Index nchunks = (n + kWave - 1) / kWave;
-    const Index nblk = (nchunks + kLB - 1) / kLB;
-    const int sh = lane & 31;
-    for (Index blk = (Index)blockIdx.x * kPWaves + wave; blk < nblk; blk += (Index)G * kPWaves) {
-      int wi[kLB];
-      unsigned int vis[kLB], lab[kLB];
-#pragma unroll
-      for (int j = 0; j < kLB; ++j) {
-        const long long w = ((long long)blk * kLB + j) * 2 + (lane >> 5);
-        wi[j] = w < nwords ? (int)w : 0;
-        vis[j] = Vf[wi[j]];
-        lab[j] = 0u;
-      }
-#if GRB_BFS_LAB_UNROLL
-      // four levels' words in flight together: a step costs one L2 latency per four kept levels
-      for (int L0 = 0; L0 < kept; L0 += 4) {
-        unsigned int f[4][kLB];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const unsigned int* __restrict__ FL = a.F[L0 + u < kept ? L0 + u : L0];
-#pragma unroll
-          for (int j = 0; j < kLB; ++j) f[u][j] = FL[wi[j]];
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-          if (L0 + u < kept) {
-#pragma unroll
-            for (int j = 0; j < kLB; ++j) lab[j] += ((f[u][j] >> sh) & 1u) * (unsigned int)(L0 + u + 1);
-          }
-      }
-#else
-      for (int L = 0; L < kept; ++L) {
-        const unsigned int* __restrict__ FL = a.F[L];
-#pragma unroll
-        for (int j = 0; j < kLB; ++j) lab[j] += ((FL[wi[j]] >> sh) & 1u) * (unsigned int)(L + 1);
-      }
-#endif
-#pragma unroll
-      for (int j = 0; j < kLB; ++j) {
-        const long long v = ((long long)blk * kLB + j) * kWave + lane;
-        if (v < n && (lab[j] != 0u || !((vis[j] >> sh) & 1u))) a.label[v] = (float)lab[j];
-      }
-    }
-#endif
   }
   stamp();
   if (a.trace && gtid == 0) a.trace[0] = (unsigned long long)ntrace;
