@@ -112,6 +112,8 @@ _SIGS = {
     "grb_comm_timing": [_i],
     "grb_comm_stats": [C.POINTER(C.c_double), C.POINTER(C.c_longlong), _i],
     "grb_pr_part_update": [_vp, _vp, _f, _vp, _i, _vp],
+    "grb_pr_part_run": [_i, _vp, _vp, _vp, _i, _f, _f, _i, _vp, _vp, _vp, _vp, C.POINTER(_i), C.POINTER(_d),
+                        C.POINTER(_i)],
     "grb_semiring_register": [_i, _d, _i, C.POINTER(_i)],
     "grb_spmm": [_i, _vp, _i, _vp, _vp, _i, _vp],
     "grb_spmm_core_info": [_vp, _i, C.POINTER(_i), C.POINTER(C.c_int64)],

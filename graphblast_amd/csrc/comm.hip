@@ -368,4 +368,63 @@ grb_info grb_comm_allreduce_sum_f64(void* d_buf, size_t count) { GRB_API_ENTER()
   return fence_out();
 }
 
+// The whole partitioned PageRank iteration loop in the library (graphblas/algorithm/pr.hpp:52-90 on a 1-D partition):
+// per iteration, for every row chunk of the in-edge shard: y = chunk . p (PlusMultiplies SpMV), p_next = y + c with
+// the squared residual accumulated, the chunk's slice of p_next all-gathered on the communication stream while the
+// next chunk is multiplied; then the residual is all-reduced and read once (the one host read of the iteration).
+//   chunks[c]      : matrix of local rows [row_cut[c], row_cut[c+1]) over all n columns (values alpha / outdeg)
+//   vertex_cut     : [world][nchunks + 1] global vertex ids of every rank's chunk boundaries (same on every rank)
+//   d_p_cur/d_p_next: n floats each; *result_in_next tells which holds the result
+grb_info grb_pr_part_run(int nchunks, const grb_matrix* chunks, const long long* row_cut, const long long* vertex_cut,
+                         grb_index lo, float c_add, float eps, int max_niter, void* d_p_cur, void* d_p_next, void* d_y,
+                         void* d_acc, int* iterations, double* errors, int* result_in_next) { GRB_API_ENTER();
+  if (!chunks || !row_cut || !vertex_cut || !d_p_cur || !d_p_next || !d_y || !d_acc || !iterations) return GRB_NULL_POINTER;
+  if (nchunks <= 0 || nchunks > 64) return GRB_INVALID_VALUE;
+  GRB_TRY(ctx_init());
+  Comm& cm = g_comm;
+  const int world = (cm.comm || cm.host_fn) ? cm.world : 1;
+  const bool have_comm = cm.comm || cm.host_fn;
+  std::vector<long long> off((size_t)world * nchunks), cnt((size_t)world * nchunks);
+  for (int c = 0; c < nchunks; ++c)
+    for (int r = 0; r < world; ++r) {
+      const long long* vc = vertex_cut + (size_t)r * (nchunks + 1);
+      off[(size_t)c * world + r] = 4 * vc[c];
+      cnt[(size_t)c * world + r] = 4 * (vc[c + 1] - vc[c]);
+    }
+  hipStream_t s = ctx().stream;
+  double h_acc = 0.0;
+  float* p_cur = (float*)d_p_cur;
+  float* p_next = (float*)d_p_next;
+  float* y = (float*)d_y;
+  int it = 0;
+  float error = 1.0f;
+  grb_info info = GRB_SUCCESS;
+  auto step = [&](grb_info r) { if (info == GRB_SUCCESS && r != GRB_SUCCESS) info = r; return info == GRB_SUCCESS; };
+  while (error > eps && it < max_niter && info == GRB_SUCCESS) {
+    if (hipMemsetAsync(d_acc, 0, 8, s) != hipSuccess) { info = GRB_PANIC; break; }
+    for (int c = 0; c < nchunks && info == GRB_SUCCESS; ++c) {
+      const long long a = row_cut[c], b = row_cut[c + 1];
+      if (b > a) {
+        if (!step(grb_k_spmv(chunks[c], 0, GRB_PLUS_MULTIPLIES, p_cur, nullptr, 0, 0, y + a))) break;
+        if (!step(grb_pr_part_update(y + a, p_cur + lo + a, c_add, p_next + lo + a, (grb_index)(b - a), d_acc))) break;
+      }
+      if (have_comm && world > 1)
+        step(grb_comm_allgatherv_inplace(p_next, off.data() + (size_t)c * world, cnt.data() + (size_t)c * world));
+    }
+    if (info != GRB_SUCCESS) break;
+    if (have_comm && world > 1) {
+      if (!step(grb_comm_allreduce_sum_f64(d_acc, 1))) break;
+      if (!step(grb_comm_wait())) break;
+    }
+    if (!step(fetch_ints((const int*)d_acc, 2, (int*)&h_acc))) break;      // pinned mailbox; the iteration's one wait
+    error = sqrtf((float)h_acc);                      // pr.hpp:84-86: the residual is reduced and rooted in float
+    if (errors) errors[it] = (double)error;
+    std::swap(p_cur, p_next);
+    ++it;
+  }
+  *iterations = it;
+  if (result_in_next) *result_in_next = (p_cur != (float*)d_p_cur) ? 1 : 0;
+  return info;
+}
+
 }  // extern "C"

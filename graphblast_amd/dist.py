@@ -832,25 +832,24 @@ class Partition1D:
         y = torch.zeros(max(self.n_local, 1), dtype=torch.float32, device=dev)
         acc = torch.zeros(1, dtype=torch.float64, device=dev)
         const = float(np.float32((np.float32(1.0) - np.float32(alpha)) / np.float32(n)))
-        error, it, errs = 1.0, 0, []
+        # the loop itself runs in the library (grb_pr_part_run): SpMV + update per chunk, the chunk's slice gathered
+        # behind it, one residual read per iteration
+        nck = len(eng.pr_chunks)
+        handles = (C.c_void_p * nck)(*[M._h.value for _, _, M in eng.pr_chunks])
+        row_cut = (C.c_longlong * (nck + 1))(*([a for a, _, _ in eng.pr_chunks] + [eng.pr_chunks[-1][1]]))
+        vcut = (C.c_longlong * (self.world * (nck + 1)))(*[int(x) for x in np.asarray(allc).reshape(-1)])
+        n_it, in_next = C.c_int(0), C.c_int(0)
+        err_buf = (C.c_double * max(int(max_niter), 1))()
         torch.cuda.synchronize()
         t_loop = time.perf_counter()
-        while error > eps and it < max_niter:
-            acc.zero_()
-            for c, (a, b, M) in enumerate(eng.pr_chunks):
-                if b > a:
-                    assert g.k_spmv(M, 0, "PlusMultiplies", p_cur.data_ptr(), None, 0, 0, y[a:].data_ptr()) == 0
-                    assert lib.grb_pr_part_update(y[a:].data_ptr(), p_cur[self.lo + a:].data_ptr(), const,
-                                                  p_next[self.lo + a:].data_ptr(), b - a, acc.data_ptr()) == 0
-                comm.gather_slices_async(p_next, [4 * int(allc[r, c]) for r in range(self.world)],
-                                         [4 * int(allc[r, c + 1] - allc[r, c]) for r in range(self.world)])
-            if self.world > 1:
-                assert lib.grb_comm_allreduce_sum_f64(acc.data_ptr(), 1) == 0
-            comm.wait()
-            error = float(np.sqrt(np.float32(acc.item())))
-            errs.append(error)
+        info = lib.grb_pr_part_run(nck, handles, row_cut, vcut, int(self.lo), const, float(eps), int(max_niter),
+                                   p_cur.data_ptr(), p_next.data_ptr(), y.data_ptr(), acc.data_ptr(),
+                                   C.byref(n_it), err_buf, C.byref(in_next))
+        assert info == 0, info
+        it = n_it.value
+        errs = [float(err_buf[i]) for i in range(it)]
+        if in_next.value:
             p_cur, p_next = p_next, p_cur
-            it += 1
         torch.cuda.synchronize()
         return p_cur, dict(iterations=it, errors=errs, overlapped_chunks=nchunks,
                            ms_iterations=(time.perf_counter() - t_loop) * 1e3)

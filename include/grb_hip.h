@@ -575,6 +575,16 @@ grb_info grb_comm_stats(double* total_us, long long* calls, int reset);
 /* element-wise tail of a PageRank iteration on a chunk of owned rows (algorithm/pr.hpp:70-80):
  * p_next = y + c, *d_acc (double) += sum (p_next - p_old)^2 */
 grb_info grb_pr_part_update(const void* d_y, const void* d_p_old, float c, void* d_p_next, grb_index n, void* d_acc);
+/* The whole iteration loop of algorithm::pr (algorithm/pr.hpp:52-90) on this rank's in-edge shard, cut into nchunks
+ * row chunks: chunk c's slice of the next vector is all-gathered (library communicator, if one is up) while chunk
+ * c + 1 is multiplied; the squared residual is all-reduced and read once per iteration -- the only host read.
+ * chunks[c]: local rows [row_cut[c], row_cut[c+1]) x n, values alpha / outdeg; vertex_cut: [world][nchunks+1] global
+ * vertex ids of every rank's chunk boundaries; lo: this rank's first vertex; c_add = (1 - alpha) / n.
+ * d_p_cur (initial vector) / d_p_next: n floats; d_y: n_local floats; d_acc: one double.
+ * errors (may be NULL): max_niter doubles; *result_in_next: 1 when the result is in d_p_next. */
+grb_info grb_pr_part_run(int nchunks, const grb_matrix* chunks, const long long* row_cut, const long long* vertex_cut,
+                         grb_index lo, float c_add, float eps, int max_niter, void* d_p_cur, void* d_p_next, void* d_y,
+                         void* d_acc, int* iterations, double* errors, int* result_in_next);
 
 /* ---- Raw kernels on plain device pointers (micro-benchmarks / multi-GPU shards) --- */
 /* Generic semiring SpMV  w[i] = (+)_j A[i,j] (x) u[j] on this matrix's CSR (tran=0) or

@@ -258,9 +258,13 @@ def _two_process_worker(rank, world, port, q):
         for cap in (65536, 64):                                      # 64: most rounds take several launches
             d, info = part.sssp(torch.from_numpy(wh).to(dev), hub, outbox_pairs=cap)
             sssp.append((cap, d.cpu().numpy(), info))
+        deg = torch.from_numpy(np.maximum(np.diff(ptr), 1).astype(np.float32)).to(dev)
+        pvec, pinfo = part.pagerank(deg, alpha=0.85, eps=0.0, max_niter=10)          # grb_pr_part_run
+        pvec2, pinfo2 = part.pagerank(deg, alpha=0.85, eps=1e-3, max_niter=50)       # stops on the residual
+        pr = (pvec.cpu().numpy(), pinfo, pvec2.cpu().numpy(), pinfo2)
         comm.close()
         if rank == 0:
-            q.put(("ok", out, sssp))
+            q.put(("ok", out, (sssp, pr)))
     except Exception:                                                 # noqa: BLE001 -- the parent must not wait for a dead rank
         q.put(("error", "rank %d: %s" % (rank, traceback.format_exc()), None))
         raise
@@ -291,8 +295,9 @@ def test_device_loop_two_processes_host_staged_collectives():
         procs = [ctx.Process(target=_two_process_worker, args=(r, 2, port, q)) for r in range(2)]
         for p in procs:
             p.start()
-        status, out, sssp = q.get(timeout=300)
+        status, out, rest = q.get(timeout=300)
         assert status == "ok", out
+        sssp, pr = rest
         for p in procs:
             p.join(timeout=120)
             assert p.exitcode == 0
@@ -311,6 +316,19 @@ def test_device_loop_two_processes_host_staged_collectives():
     for cap, d, info in sssp:
         assert np.array_equal(d, want_d), cap
         assert info["iterations"] == want_it, (cap, info)
+    # PageRank: the library's iteration loop over two chunks per rank, slices gathered between the processes
+    pvec, pinfo, pvec2, pinfo2 = pr
+    assert pinfo["iterations"] == 10 and pinfo["overlapped_chunks"] == 2 and len(pinfo["errors"]) == 10
+    want = sr.pr(ptr, ind, 0.85, 0.0, 10)[0]
+    rel = np.abs(pvec - want) / np.maximum(np.abs(want), 1e-30)
+    assert rel.max() <= 1e-5, rel.max()
+    # eps = 1e-3: the loop leaves after the first iteration whose residual (pr.hpp:84-90, rooted) is within eps
+    stop = 1 + next(i for i, e in enumerate(pinfo["errors"]) if e <= 1e-3)
+    assert pinfo2["iterations"] == stop < 10, (pinfo2["iterations"], stop)
+    assert np.allclose(pinfo2["errors"], pinfo["errors"][:stop], rtol=1e-5)      # atomic sums: order may differ
+    want2 = sr.pr(ptr, ind, 0.85, 0.0, stop)[0]
+    rel2 = np.abs(pvec2 - want2) / np.maximum(np.abs(want2), 1e-30)
+    assert rel2.max() <= 1e-5, rel2.max()
 
 
 def test_bench_n_greater_than_one_path_with_two_ranks_on_one_gpu():
