@@ -133,6 +133,7 @@ _SIGS = {
     "grb_sssp_last_work": [_vp],
     "grb_spmv_plan_info": [_vp, _i, _i, C.POINTER(_i), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(_i)],
     "grb_bfs_batch": [_vp, _i, _vp, _vp, _vp, _vp],
+    "grb_bfs_batch_set_tail": [C.c_longlong],
     "grb_descriptor_iter_log": [_vp, _vp, _i, C.POINTER(_i)],
     "grb_cache_name": [C.c_char_p, _i, C.c_char_p, C.c_size_t],
     "grb_matrix_write_cache": [_vp, C.c_char_p],
@@ -225,6 +226,7 @@ def load():
     lib.grb_version.restype = C.c_char_p
     lib.grb_version.argtypes = []
     lib.grb_k_spmv_bytes.restype = C.c_int64
+    lib.grb_bfs_batch_set_tail.restype = C.c_longlong
     lib.grb_k_spmv_bytes.argtypes = [_vp, _i]
     _lib = lib
     return lib

@@ -494,6 +494,12 @@ def bfs_batch(vs, A, sources, desc):
                       reached=res.reached)
 
 
+def bfs_batch_set_tail(edges=-1):
+    """Out-edge limit of the levels grb_bfs_batch runs inside its one light-level launch (grb_bfs_batch_set_tail):
+    0 never, < 0 only queries; returns the previous limit."""
+    return int(_lib.load().grb_bfs_batch_set_tail(int(edges)))
+
+
 def sssp(v, A, s, desc):
     res = AlgoResult()
     info = _lib.load().grb_sssp(_h(v), _h(A), int(s), _h(desc), C.byref(res))

@@ -29,6 +29,7 @@
 //                    Levels beyond kStore (long-diameter graphs, tiny frontiers) label directly.
 //                    The vectors are what k calls of algorithm::bfs return: BFS depth is unique.
 #include "bfs_kernels.hpp"
+#include "persist_common.hpp"
 #include <chrono>
 
 namespace grb {
@@ -67,9 +68,10 @@ struct BatchArgs {
 
 struct LabelArgs {
   Index n;
-  int k, nstored, max_label;
+  int k, nstored;
   const u64* seen;
-  const u64* W[kBatchStoreMax + 1];
+  const u64* W[kBatchStoreMax + 1];   // the stored levels' words ...
+  float lab[kBatchStoreMax + 1];      // ... and the depth each of them assigns (0: the level the iteration cap cuts off)
   float* label[64];
 };
 
@@ -93,7 +95,7 @@ struct WaveTotals {
 // matrix (lane = vertex, bit = source) is transposed with one ballot per live source, so lane s holds the
 // mask m of vertices new to source s: nf_s += popcount(m), and the degree sum comes from the degrees' bit
 // planes, mf_s += sum_b 2^b popcount(m & plane_b) -- all 64 sources in parallel, no per-source reduction.
-__device__ inline void batch_commit(const BatchArgs& a, WaveTotals& acc, Index v, u64 newb) {
+__device__ inline void batch_commit_l(const BatchArgs& a, WaveTotals& acc, Index v, u64 newb, bool direct, float label) {
   const unsigned long long mv = __ballot(newb != 0);
   if (!mv) return;
   const int lane = lane_id();
@@ -115,23 +117,29 @@ __device__ inline void batch_commit(const BatchArgs& a, WaveTotals& acc, Index v
     const unsigned long long plane = __ballot((deg >> b) & 1u);
     acc.mf += (u64)__popcll(m & plane) << b;
   }
-  if (a.direct_labels)
-    for (u64 t = newb; t; t &= t - 1) a.label[__ffsll((long long)t) - 1][v] = a.new_label;
+  if (direct)
+    for (u64 t = newb; t; t &= t - 1) a.label[__ffsll((long long)t) - 1][v] = label;
+}
+__device__ inline void batch_commit(const BatchArgs& a, WaveTotals& acc, Index v, u64 newb) {
+  batch_commit_l(a, acc, v, newb, a.direct_labels != 0, a.new_label);
 }
 
 __device__ inline void totals_init(BatchTotals* lds) {
   for (int i = threadIdx.x; i < kBatchCounters; i += blockDim.x) lds->v[i] = 0;
   __syncthreads();
 }
-__device__ inline void totals_flush(const BatchArgs& a, BatchTotals* lds, const WaveTotals& acc) {
+__device__ inline void totals_flush_to(u64* slots, BatchTotals* lds, const WaveTotals& acc) {
   const int lane = lane_id();
   if (acc.nf) atomicAdd(&lds->v[2 + 2 * lane], acc.nf);
   if (acc.mf) atomicAdd(&lds->v[3 + 2 * lane], acc.mf);
   if (lane == 0 && acc.verts) atomicAdd(&lds->v[0], (u64)acc.verts);
   __syncthreads();
-  u64* dst = a.counters + (size_t)(blockIdx.x & (kBatchSlots - 1)) * kBatchCounters;
+  u64* dst = slots + (size_t)(blockIdx.x & (kBatchSlots - 1)) * kBatchCounters;
   for (int i = threadIdx.x; i < kBatchCounters; i += blockDim.x)
     if (lds->v[i]) atomicAdd(&dst[i], lds->v[i]);
+}
+__device__ inline void totals_flush(const BatchArgs& a, BatchTotals* lds, const WaveTotals& acc) {
+  totals_flush_to(a.counters, lds, acc);
 }
 
 // the wave scans entries [rs, re) of `ind`, ORs word[ind[q]] and stops once `nd` is covered
@@ -546,28 +554,30 @@ __global__ __launch_bounds__(kBlock) void batch_push_commit_kernel(BatchArgs a) 
 
 // the depth vectors from the stored level words: full 256-byte stores, every element written once
 __global__ __launch_bounds__(kBlock) void batch_labels_kernel(LabelArgs a) {
+  __shared__ float s_lab[32];
+  if (threadIdx.x < 32) s_lab[threadIdx.x] = threadIdx.x >= 1 && (int)threadIdx.x <= a.nstored ? a.lab[threadIdx.x - 1] : 0.f;
+  __syncthreads();
   const int lane = lane_id();
   const Index nchunks = (a.n + kWave - 1) / kWave;
   const Index nwaves = (Index)gridDim.x * kWavesPerBlock;
   for (Index chunk = (Index)blockIdx.x * kWavesPerBlock + wave_id(); chunk < nchunks; chunk += nwaves) {
     const Index v = chunk * kWave + lane;
     const bool valid = v < a.n;
-    // level numbers (<= kBatchStoreMax + 1 < 32) as five bit planes: plane b holds, per source, bit b of
-    // the level that discovered this vertex (the level words are disjoint, so OR composes them); `hit` = found
+    // which stored level found the vertex (1-based, <= kBatchStoreMax + 1 < 32) as five bit planes: plane b holds,
+    // per source, bit b of that number (the level words are disjoint, so OR composes them); 0 = none of them
     u64 plane[5] = {0, 0, 0, 0, 0}, hit = 0;
     for (int L = 0; L < a.nstored; ++L) {
       const u64 w = valid ? a.W[L][v] : 0ull;
-      const int lab = L + 1 > a.max_label ? 0 : L + 1;     // discovered by the last allowed iteration: never assigned
       hit |= w;
 #pragma unroll
-      for (int b = 0; b < 5; ++b) plane[b] |= ((lab >> b) & 1) ? w : 0ull;
+      for (int b = 0; b < 5; ++b) plane[b] |= (((L + 1) >> b) & 1) ? w : 0ull;
     }
-    const u64 later = valid ? (a.seen[v] & ~hit) : ~0ull;  // seen, but by a level beyond the stored ones: labelled there
+    const u64 later = valid ? (a.seen[v] & ~hit) : ~0ull;  // seen, but by a level that labelled as it went
     for (int s = 0; s < a.k; ++s) {
-      int lab = 0;
+      int idx = 0;
 #pragma unroll
-      for (int b = 0; b < 5; ++b) lab |= (int)((plane[b] >> s) & 1ull) << b;
-      if (!((later >> s) & 1ull)) a.label[s][v] = (float)lab;
+      for (int b = 0; b < 5; ++b) idx |= (int)((plane[b] >> s) & 1ull) << b;
+      if (!((later >> s) & 1ull)) a.label[s][v] = s_lab[idx];
     }
   }
 }
@@ -587,6 +597,394 @@ __global__ __launch_bounds__(kBlock) void batch_totals_kernel(u64* counters, u64
   __threadfence_system();
   __syncthreads();
   if (i == 0) __hip_atomic_store(&box[kBatchCounters], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// ---- the light levels in one launch ----------------------------------------------------------------------------------
+// A level that pushes a few thousand edges costs what its launches cost: four kernels over all n words, a totals
+// kernel and a host round trip -- 45-100 us for microseconds of work, on the first level of a sweep and on every level
+// of its tail (and on EVERY level of a high-diameter graph, where 64 small frontiers never grow).  While every live
+// source is pushed and the level's out-edges stay under a limit, the levels run inside one co-resident launch
+// instead: the frontier is a QUEUE of {vertex, first edge} pieces (rows cut at kTailPiece edges, so a hub that turns
+// up is shared by many waves), a wave lays the edges of 64 pieces end to end and deals them to its lanes, a claimed
+// target gets its bits ORed into the next level's words, and whoever finds that word zero appends the target to the
+// next queue.  The words a level read are cleaned through its queue while the following level runs (three word arrays
+// in rotation: a word holds bits of several sources, and a vertex one source reached two levels ago may be claimed by
+// another right now -- the cleaner and the claimers must not share an array): no memset, no pass over n words after
+// the first.
+// Labels are written as the pairs are claimed (few of them, by definition); totals per source go through the same
+// wave transposition as everywhere else.  One grid barrier per level.
+constexpr int kTailPiece = 256;        // edges per queue entry: one step of a wave
+constexpr int kTailList = 4096;        // a workgroup's list of newly claimed vertices (beyond it a wave queues its own)
+constexpr int kTailLong = 64;          // ... of rows of more than eight pieces
+
+struct TailState {                    // zeroed by the host before every launch
+  GridBarrier bar;
+  unsigned int count[4][32];          // queue lengths (one line each; [2..3]: the out-edges queued): level j reads [j & 3], appends to [(j + 1) & 3]
+  u64 slots[3][kBatchSlots * kBatchCounters];
+  u64 ts[64];                         // GRB_BATCH_TRACE: wall-clock stamps of workgroup 0 (100 MHz)
+  u64 dec[3][8][16];                  // what the level loop decides on: {pairs, out-edges} of a level, one line per eighth of the grid
+};
+
+struct TailArgs {
+  const u64* f0;                      // frontier words of the level before (a stored level: read, never cleaned)
+  u64* X[3];                          // all-zero on entry: level j writes X[j % 3], reads X[(j - 1) % 3] and cleans X[(j - 2) % 3]
+  u64* queue[3];                      // entries (first edge << 32 | vertex), vertex complemented on all but a row's first piece
+  TailState* st;
+  u64* box;                           // host-coherent: the last level's totals, then {seq, levels, edges, pairs, status}
+  u64 seq;
+  int iter0, max_niter;
+  unsigned long long edge_limit;      // leave when the next level would push more out-edges than this
+  const Index* src;                   // the sweep's first level: the sources (nsrc > 0), else the words of f0 are scanned
+  int nsrc;
+};
+
+__global__ __launch_bounds__(kPThreads) void batch_tail_kernel(BatchArgs a, TailArgs t) {
+  __shared__ BatchTotals lds;
+  __shared__ Index s_pre[kPWaves][kWave];
+  __shared__ Index s_p[kPWaves][kWave];
+  __shared__ u64 s_fw[kPWaves][kWave];
+  __shared__ u64 s_sum[kBatchCounters];
+  __shared__ u64 s_dec[2];
+  __shared__ Index s_list[kTailList];                       // vertices this workgroup was the first to claim this level
+  __shared__ unsigned int s_nlist, s_wp[kPWaves], s_we[kPWaves], s_base, s_nlong;
+  __shared__ unsigned long long s_before;
+  __shared__ int4 s_long[kTailLong];                        // {vertex, first edge, pieces, where}: rows the whole workgroup writes
+  const int lane = lane_id(), w = threadIdx.x / kWave;
+  const unsigned int gw = blockIdx.x * kPWaves + w, nw = gridDim.x * kPWaves;
+  const unsigned int gt = blockIdx.x * kPThreads + threadIdx.x, nt = gridDim.x * kPThreads;
+  TailState* st = t.st;
+  unsigned gen = 0;
+  int nts = 0;
+  auto stamp = [&] { if (blockIdx.x == 0 && threadIdx.x == 0 && nts < 64) st->ts[nts++] = wall_clock64(); };
+  stamp();
+
+  // wave-collective: every lane brings up to N vertices (v[i] < 0: none); one counter update per call for the whole
+  // wave (a level that discovers 300 K vertices would otherwise queue behind 300 K updates of one address).  The
+  // out-edges queued so far are counted as well: once they pass the limit the launch is going to hand the next level
+  // back to the host, which reads the words, not the queue -- nothing more is written (the level that ends a sweep's
+  // first launch discovers rows with 16 M out-edges: 60 K pieces nobody would read).  Rows of more than four pieces are
+  // written by the whole wave.
+  auto enqueue = [&](u64* q, unsigned int* cnt, const Index (&v)[4], int N) {
+    Index p[4];
+    unsigned int pieces[4], mine = 0, mine_edges = 0;
+    for (int i = 0; i < N; ++i) {
+      pieces[i] = 0; p[i] = 0;
+      if (v[i] >= 0) {
+        p[i] = a.optr[v[i]];
+        const Index e = a.optr[v[i] + 1];
+        pieces[i] = e > p[i] ? (unsigned int)((e - p[i] + kTailPiece - 1) / kTailPiece) : 1u;   // an empty row is queued too: its word must be cleaned
+        mine += pieces[i];
+        mine_edges += (unsigned int)(e - p[i]);
+      }
+    }
+    if (__ballot(mine != 0u) == 0ull) return;
+    unsigned int inc = mine, ince = mine_edges;
+#pragma unroll
+    for (int o = 1; o < kWave; o <<= 1) {
+      const unsigned int tt = __shfl_up(inc, o, kWave);
+      const unsigned int te = __shfl_up(ince, o, kWave);
+      if (lane >= o) { inc += tt; ince += te; }
+    }
+    unsigned int base = 0;
+    unsigned long long before = 0;
+    if (lane == kWave - 1) {
+      base = atomicAdd(cnt, inc);
+      before = atomicAdd((unsigned long long*)(cnt + 2), (unsigned long long)ince);
+    }
+    base = __shfl(base, kWave - 1, kWave);
+    before = __shfl(before, kWave - 1, kWave);
+    if (before > t.edge_limit) return;
+    unsigned int at = base + inc - mine;
+    for (int i = 0; i < N; ++i) {
+      if (pieces[i] <= 4u)
+        for (unsigned int c = 0; c < pieces[i]; ++c)
+          publish(&q[at + c], ((u64)(unsigned int)(p[i] + (Index)c * kTailPiece) << 32) | (u64)(unsigned int)(c == 0 ? v[i] : ~v[i]));
+      for (unsigned long long mk = __ballot(pieces[i] > 4u); mk; mk &= mk - 1) {
+        const int l = __ffsll((long long)mk) - 1;
+        const Index vv = __shfl(v[i], l, kWave), pp = __shfl(p[i], l, kWave);
+        const unsigned int np = __shfl(pieces[i], l, kWave), aa = __shfl(at, l, kWave);
+        for (unsigned int c = lane; c < np; c += kWave)
+          publish(&q[aa + c], ((u64)(unsigned int)(pp + (Index)c * kTailPiece) << 32) | (u64)(unsigned int)(c == 0 ? vv : ~vv));
+      }
+      at += pieces[i];
+    }
+  };
+
+  // The queue's length is one word: a wave per piece (what keeps a level's latency short) would mean a same-address
+  // update per piece -- 5 ns each, 50 us for a level of 5 K pieces, measured.  So the waves of a workgroup collect
+  // what they claim in LDS and the workgroup takes its room in the queue with ONE update per level; only a wave that
+  // finds the LDS list full queues by itself.
+  auto collect = [&](u64* q, unsigned int* cnt, const Index (&v)[4], int N) {
+    unsigned int mine = 0;
+    for (int i = 0; i < N; ++i) mine += v[i] >= 0 ? 1u : 0u;
+    if (__ballot(mine != 0u) == 0ull) return;
+    unsigned int inc = mine;
+#pragma unroll
+    for (int o = 1; o < kWave; o <<= 1) {
+      const unsigned int tt = __shfl_up(inc, o, kWave);
+      if (lane >= o) inc += tt;
+    }
+    unsigned int base = 0;
+    if (lane == kWave - 1) base = atomicAdd(&s_nlist, inc);
+    base = __shfl(base, kWave - 1, kWave);
+    const unsigned int total = __shfl(inc, kWave - 1, kWave);
+    unsigned int at = base + inc - mine;
+    Index rest[4] = {-1, -1, -1, -1};
+    for (int i = 0; i < N; ++i)
+      if (v[i] >= 0) {
+        if (at < (unsigned int)kTailList) s_list[at] = v[i]; else rest[i] = v[i];   // the list stays dense up to its capacity
+        ++at;
+      }
+    if (base + total > (unsigned int)kTailList) enqueue(q, cnt, rest, N);
+  };
+  auto block_flush = [&](u64* q, unsigned int* cnt) {
+    __syncthreads();
+    const unsigned int nl = s_nlist < (unsigned int)kTailList ? s_nlist : (unsigned int)kTailList;
+    if (threadIdx.x == 0) s_nlong = 0;
+    Index v[4], p[4];
+    unsigned int pieces[4], mine = 0, mine_e = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const unsigned int at = threadIdx.x * 4 + i;
+      v[i] = -1; p[i] = 0; pieces[i] = 0;
+      if (at < nl) {
+        v[i] = s_list[at];
+        p[i] = a.optr[v[i]];
+        const Index e = a.optr[v[i] + 1];
+        pieces[i] = e > p[i] ? (unsigned int)((e - p[i] + kTailPiece - 1) / kTailPiece) : 1u;
+        mine += pieces[i];
+        mine_e += (unsigned int)(e - p[i]);
+      }
+    }
+    unsigned int inc = mine, ince = mine_e;
+#pragma unroll
+    for (int o = 1; o < kWave; o <<= 1) {
+      const unsigned int tt = __shfl_up(inc, o, kWave);
+      const unsigned int te = __shfl_up(ince, o, kWave);
+      if (lane >= o) { inc += tt; ince += te; }
+    }
+    if (lane == kWave - 1) { s_wp[w] = inc; s_we[w] = ince; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      unsigned int tp = 0;
+      unsigned long long te = 0;
+      for (int i = 0; i < kPWaves; ++i) { const unsigned int x = s_wp[i]; s_wp[i] = tp; tp += x; te += s_we[i]; }
+      s_base = 0; s_before = 0;
+      if (tp) {
+        s_base = atomicAdd(cnt, tp);
+        s_before = atomicAdd((unsigned long long*)(cnt + 2), te);
+      }
+      s_nlist = 0;
+    }
+    __syncthreads();
+    if (s_before <= t.edge_limit) {
+      unsigned int at = s_base + s_wp[w] + inc - mine;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (pieces[i] > 8u) {
+          const unsigned int li = atomicAdd(&s_nlong, 1u);
+          if (li < (unsigned int)kTailLong) s_long[li] = make_int4(v[i], p[i], (int)pieces[i], (int)at);
+          else
+            for (unsigned int c = 0; c < pieces[i]; ++c)
+              publish(&q[at + c], ((u64)(unsigned int)(p[i] + (Index)c * kTailPiece) << 32) | (u64)(unsigned int)(c == 0 ? v[i] : ~v[i]));
+        } else {
+          for (unsigned int c = 0; c < pieces[i]; ++c)
+            publish(&q[at + c], ((u64)(unsigned int)(p[i] + (Index)c * kTailPiece) << 32) | (u64)(unsigned int)(c == 0 ? v[i] : ~v[i]));
+        }
+        at += pieces[i];
+      }
+      __syncthreads();
+      const unsigned int nlong = s_nlong < (unsigned int)kTailLong ? s_nlong : (unsigned int)kTailLong;
+      for (unsigned int li = 0; li < nlong; ++li) {
+        const int4 L = s_long[li];
+        for (unsigned int c = threadIdx.x; c < (unsigned int)L.z; c += kPThreads)
+          publish(&q[(unsigned int)L.w + c], ((u64)(unsigned int)(L.y + (Index)c * kTailPiece) << 32) | (u64)(unsigned int)(c == 0 ? L.x : ~L.x));
+      }
+    }
+    __syncthreads();
+  };
+  if (threadIdx.x == 0) s_nlist = 0;
+  __syncthreads();
+
+  if (t.nsrc > 0) {                                         // the first queue of a sweep's first level: the sources themselves
+    if (gw == 0) {
+      const Index u = lane < t.nsrc ? t.src[lane] : -1;
+      // a vertex named twice is queued once: by the lane of its lowest source
+      bool first = u >= 0;
+      for (int o = 0; o < kWave; ++o) {
+        const Index other = __shfl(u, o, kWave);
+        if (o < lane && other == u) first = false;
+      }
+      const Index vq[4] = {first ? u : -1, -1, -1, -1};
+      collect(t.queue[0], &st->count[0][0], vq, 1);
+    }
+  } else {                                                  // otherwise one pass over the stored frontier words, four chunks in flight
+    const Index nchunks = (a.n + kWave - 1) / kWave;
+    for (Index chunk = (Index)gw * 4; chunk < nchunks; chunk += (Index)nw * 4) {
+      u64 fw[4];
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        const Index u = (chunk + r4) * kWave + lane;
+        fw[r4] = u < a.n ? (t.f0[u] & a.pmask) : 0ull;
+      }
+      Index vq[4];
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) vq[r4] = fw[r4] ? (chunk + r4) * kWave + lane : -1;
+      collect(t.queue[0], &st->count[0][0], vq, 4);
+    }
+  }
+  block_flush(t.queue[0], &st->count[0][0]);
+  stamp();
+  if (!grid_sync(&st->bar, gen)) return;
+  stamp();
+
+  int iter = t.iter0, j = 0, status = 0;
+  unsigned long long levels = 0, cum_edges = 0, cum_pairs = 0;
+  for (;;) {
+    totals_init(&lds);
+    WaveTotals tot;
+    if (blockIdx.x == 0) {
+      u64* z = st->slots[(j + 1) % 3];
+      for (int i = threadIdx.x; i < kBatchSlots * kBatchCounters; i += kPThreads) publish(&z[i], 0ull);
+      if (threadIdx.x < 4) publish(&st->count[(j + 2) & 3][threadIdx.x], 0u);   // length, and the out-edges behind it
+      if (threadIdx.x < 16) publish(&st->dec[(j + 1) % 3][threadIdx.x >> 1][threadIdx.x & 1], 0ull);
+    }
+    if (j >= 2) {                                           // the words level j - 1 read: the array level j + 1 will write
+      const unsigned int mq = fresh(&st->count[(j - 1) & 3][0]);
+      const u64* qp = t.queue[(j - 1) % 3];
+      u64* Xw = t.X[(j - 2) % 3];
+      for (unsigned int i = gt; i < mq; i += nt) {
+        const int x = (int)(unsigned int)qp[i];
+        if (x >= 0) publish(&Xw[x], 0ull);
+      }
+    }
+    const u64* F = j == 0 ? t.f0 : t.X[(j - 1) % 3];
+    u64* Xn = t.X[j % 3];
+    const u64* qc = t.queue[j % 3];
+    u64* qn = t.queue[(j + 1) % 3];
+    unsigned int* cn = &st->count[(j + 1) & 3][0];
+    const unsigned int m = fresh(&st->count[j & 3][0]);
+    const float lab = (float)(iter + 1);
+    // a short queue is spread over the waves (a step is a chain of dependent memory round trips: 64 pieces in one
+    // wave are 64 such chains one after the other, one piece in each of 64 waves is one)
+    const unsigned int per = m >= (unsigned long long)nw * kWave ? (unsigned int)kWave : (m + nw - 1) / nw > 0 ? (m + nw - 1) / nw : 1u;
+    for (unsigned int c = gw; (unsigned long long)c * per < m; c += nw) {
+      const unsigned int idx = c * per + lane;
+      const bool has = (unsigned int)lane < per && idx < m;
+      const u64 ent = has ? qc[idx] : 0ull;
+      const int x = (int)(unsigned int)ent;
+      const Index u = x >= 0 ? x : ~x;
+      Index p = (Index)(ent >> 32), e = p;
+      u64 fw = 0;
+      if (has) {
+        const Index re = a.optr[u + 1];
+        e = p + kTailPiece < re ? p + kTailPiece : re;
+        fw = F[u] & a.pmask;
+      }
+      const Index d = e - p;
+      Index inc = d;
+#pragma unroll
+      for (int o = 1; o < kWave; o <<= 1) {
+        const Index tt = __shfl_up(inc, o, kWave);
+        if (lane >= o) inc += tt;
+      }
+      const Index total = __shfl(inc, kWave - 1, kWave);
+      __builtin_amdgcn_wave_barrier();
+      s_pre[w][lane] = inc - d;
+      s_p[w][lane] = p;
+      s_fw[w][lane] = fw;
+      __builtin_amdgcn_wave_barrier();
+      for (Index base = 0; base < total; base += 4 * kWave) {
+        Index dst[4];
+        u64 bits[4];
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+          const Index at = base + r4 * kWave + lane;
+          dst[r4] = -1; bits[r4] = 0ull;
+          if (at < total) {
+            int r = 0;                                     // the last piece whose first edge is <= at
+#pragma unroll
+            for (int step = kWave / 2; step > 0; step >>= 1)
+              if (s_pre[w][r + step] <= at) r += step;
+            dst[r4] = a.oind[s_p[w][r] + (at - s_pre[w][r])];
+            bits[r4] = s_fw[w][r];
+          }
+        }
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) bits[r4] = dst[r4] >= 0 ? (bits[r4] & ~a.seen[dst[r4]]) : 0ull;
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4)
+          if (bits[r4]) bits[r4] &= ~atomicOr(&a.seen[dst[r4]], bits[r4]);
+        Index vq[4];
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) vq[r4] = bits[r4] && atomicOr(&Xn[dst[r4]], bits[r4]) == 0ull ? dst[r4] : -1;
+        collect(qn, cn, vq, 4);
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) batch_commit_l(a, tot, bits[r4] ? dst[r4] : 0, bits[r4], true, lab);
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    block_flush(qn, cn);
+    stamp();
+    totals_flush_to(st->slots[j % 3], &lds, tot);          // per source: read by workgroup 0 when the launch ends, by nobody else
+    if (threadIdx.x < kWave) {                             // what everybody needs: the level's pairs and their out-edges
+      u64 np = lds.v[2 + 2 * lane], ne = lds.v[3 + 2 * lane];
+#pragma unroll
+      for (int o = kWave / 2; o > 0; o >>= 1) { np += __shfl_xor(np, o, kWave); ne += __shfl_xor(ne, o, kWave); }
+      if (lane == 0 && np) {
+        atomicAdd(&st->dec[j % 3][blockIdx.x & 7][0], np);
+        atomicAdd(&st->dec[j % 3][blockIdx.x & 7][1], ne);
+      }
+    }
+    stamp();
+    if (!grid_sync(&st->bar, gen)) return;
+    stamp();
+    if (threadIdx.x < kWave) {
+      u64 x = lane < 16 ? fresh(&st->dec[j % 3][lane >> 1][lane & 1]) : 0ull;
+      x += __shfl_xor(x, 2, kWave); x += __shfl_xor(x, 4, kWave); x += __shfl_xor(x, 8, kWave);   // lane 0: pairs, lane 1: edges
+      if (lane < 2) s_dec[lane] = x;
+    }
+    __syncthreads();
+    const u64 pairs = s_dec[0], edges = s_dec[1];
+    ++levels;
+    cum_pairs += pairs;
+    cum_edges += edges;
+    if (pairs == 0) { status = 0; break; }
+    if (iter >= t.max_niter) { status = 1; break; }
+    if (edges > t.edge_limit) { status = 2; break; }
+    ++iter;
+    ++j;
+    __syncthreads();                                        // s_sum / s_dec are rewritten next level
+  }
+  if (j >= 1) {                                             // the words the last level read: every array but the new frontier's is left all-zero
+    const unsigned int mq = fresh(&st->count[j & 3][0]);
+    const u64* qp = t.queue[j % 3];
+    u64* Xw = t.X[(j - 1) % 3];
+    for (unsigned int i = gt; i < mq; i += nt) {
+      const int x = (int)(unsigned int)qp[i];
+      if (x >= 0) publish(&Xw[x], 0ull);
+    }
+  }
+  if (blockIdx.x == 0) {
+    for (int i = threadIdx.x; i < kBatchCounters; i += kPThreads) s_sum[i] = 0ull;
+    __syncthreads();
+    for (int i = threadIdx.x; i < kBatchSlots * kBatchCounters; i += kPThreads) {
+      const u64 x = fresh(&st->slots[j % 3][i]);
+      if (x) atomicAdd(&s_sum[i % kBatchCounters], x);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < kBatchCounters; i += kPThreads)
+      __hip_atomic_store(&t.box[i], s_sum[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (threadIdx.x == 0) {
+      __hip_atomic_store(&t.box[kBatchCounters + 1], (u64)levels, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(&t.box[kBatchCounters + 2], (u64)cum_edges, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(&t.box[kBatchCounters + 3], (u64)cum_pairs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(&t.box[kBatchCounters + 4], (u64)status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(&t.box[kBatchCounters], t.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
 }
 
 __global__ void batch_unlabel_kernel(BatchArgs a, float bad) {
@@ -674,6 +1072,23 @@ static grb_info ensure_slices(grb_matrix A, bool in_edges) {
   return GRB_SUCCESS;
 }
 
+// out-edges a level may push inside the light-level launch (0: every level through the host loop)
+static long long& batch_tail_limit() {
+  static long long limit = [] {
+    const char* on = getenv("GRB_BATCH_TAIL");
+    if (on && atoi(on) == 0) return 0ll;
+    const char* e = getenv("GRB_BATCH_TAIL_EDGES");
+    return e ? atoll(e) : 1048576ll;
+  }();
+  return limit;
+}
+
+extern "C" long long grb_bfs_batch_set_tail(long long edges) { GRB_API_ENTER_NOINFO();
+  const long long before = batch_tail_limit();
+  if (edges >= 0) batch_tail_limit() = edges;
+  return before;
+}
+
 extern "C" grb_info grb_bfs_batch(grb_vector* v, int k, grb_matrix A, const grb_index* sources, grb_descriptor desc,
                                   grb_bfs_result* result) { GRB_API_ENTER();
   if (!v || !A || !desc || !sources) return GRB_UNINITIALIZED_OBJECT;
@@ -698,18 +1113,43 @@ extern "C" grb_info grb_bfs_batch(grb_vector* v, int k, grb_matrix A, const grb_
   int nstore = (int)((1ull << 30) / (sizeof(u64) * (size_t)(n > 0 ? n : 1)));
   if (nstore > kBatchStoreMax) nstore = kBatchStoreMax;
   if (nstore < 1) nstore = 1;
-  const int nbuf = nstore + 1 + 2 + 1 + 1;                 // W[0..nstore], X0, X1, seen, prev
+  const int nbuf = 1 + (nstore + 1) + 4;                    // seen, the kept levels' words, four rotating arrays
   void *p_words, *p_cnt, *p_src;
   GRB_TRY(scratch(7, (size_t)nbuf * sizeof(u64) * (size_t)n + 256, &p_words));
   c.bfs_prezero_ptr = nullptr;                              // slot 7 is the one-launch traversal's pre-zeroed block
   GRB_TRY(scratch(10, sizeof(u64) * kBatchSlots * kBatchCounters, &p_cnt));
   GRB_TRY(scratch(9, sizeof(Index) * 64, &p_src));
   u64* seen = (u64*)p_words;
-  u64* prev = seen + (size_t)(nbuf - 1) * (size_t)n;
-  auto W = [&](int i) -> u64* {                             // words written by level i (0 = the seeds)
-    const int b = i <= nstore ? i : nstore + 1 + ((i - nstore - 1) & 1);
-    return seen + (size_t)(1 + b) * (size_t)n;
+  // level words: slot 0 .. nstore are kept for the label pass (which level each holds is recorded as it is taken);
+  // four more rotate -- a level beyond the kept ones (it labels as it discovers), the copy of `seen` a heavy push
+  // compares against, the three word arrays of the light-level launch
+  auto Slot = [&](int i) -> u64* { return seen + (size_t)(1 + i) * (size_t)n; };
+  u64* const pool[4] = {Slot(nstore + 1), Slot(nstore + 2), Slot(nstore + 3), Slot(nstore + 4)};
+  // known all-zero: the light-level launch leaves its arrays so, and the knowledge survives to the next sweep if nobody
+  // else has had the scratch slot in between
+  static struct { bool valid = false; unsigned long long epoch = 0; void* ptr = nullptr; Index n = 0; int nstore = 0; bool clean[4]; } kept_pool;
+  bool pool_clean[4] = {false, false, false, false};
+  if (kept_pool.valid && kept_pool.epoch + 1 == c.slot_epoch[7] && kept_pool.ptr == p_words && kept_pool.n == n && kept_pool.nstore == nstore)
+    for (int i = 0; i < 4; ++i) pool_clean[i] = kept_pool.clean[i];
+  kept_pool.valid = false;
+  // a rotating array other than x and y: for the light-level launch a clean one if there is one (no memset), for
+  // everybody else a dirty one (so that the clean ones stay clean)
+  auto pick = [&](const u64* x, const u64* y, const u64* z, bool want_clean) -> int {
+    int other = -1;
+    for (int i = 0; i < 4; ++i) {
+      if (pool[i] == x || pool[i] == y || pool[i] == z) continue;
+      if (pool_clean[i] == want_clean) return i;
+      if (other < 0) other = i;
+    }
+    return other;
   };
+  const u64* kept_words[kBatchStoreMax + 1];
+  int kept_level[kBatchStoreMax + 1];
+  int nkept = 1;                                            // the seeds
+  kept_words[0] = Slot(0);
+  kept_level[0] = 0;
+  bool any_direct = false;
+  const u64* fcur_words = Slot(0);
   BatchArgs a;
   a.optr = A->csr.ptr; a.oind = A->csr.ind; a.iptr = A->csc.ptr; a.iind = A->csc.ind;
   a.hint = A->d_pull_hint;
@@ -725,14 +1165,14 @@ extern "C" grb_info grb_bfs_batch(grb_vector* v, int k, grb_matrix A, const grb_
   static u64 *h_box = nullptr, *d_box = nullptr;            // {totals, sequence number}: pinned, host-coherent
   static u64 box_seq = 0;
   if (!h_box) {
-    GRB_HIP_TRY(hipHostMalloc((void**)&h_box, sizeof(u64) * (kBatchCounters + 1), hipHostMallocMapped | hipHostMallocCoherent));
-    memset(h_box, 0, sizeof(u64) * (kBatchCounters + 1));
+    GRB_HIP_TRY(hipHostMalloc((void**)&h_box, sizeof(u64) * (kBatchCounters + 8), hipHostMallocMapped | hipHostMallocCoherent));
+    memset(h_box, 0, sizeof(u64) * (kBatchCounters + 8));
     GRB_HIP_TRY(hipHostGetDevicePointer((void**)&d_box, h_box, 0));
   }
   GRB_HIP_TRY(hipMemsetAsync(a.counters, 0, sizeof(u64) * kBatchSlots * kBatchCounters, st));
-  GRB_HIP_TRY(hipMemsetAsync(seen, 0, 2 * sizeof(u64) * (size_t)n, st));       // seen and W[0]
+  GRB_HIP_TRY(hipMemsetAsync(seen, 0, 2 * sizeof(u64) * (size_t)n, st));       // seen and the seeds' words
   GRB_HIP_TRY(hipMemcpyAsync(p_src, sources, sizeof(Index) * (size_t)k, hipMemcpyHostToDevice, st));
-  hipLaunchKernelGGL(batch_seed_kernel, dim3(1), dim3(kBlock), 0, st, seen, W(0), (const Index*)p_src, k);
+  hipLaunchKernelGGL(batch_seed_kernel, dim3(1), dim3(kBlock), 0, st, seen, Slot(0), (const Index*)p_src, k);
   GRB_HIP_TRY(hipGetLastError());
 
   // per-source frontier totals of the seed level
@@ -753,7 +1193,21 @@ extern "C" grb_info grb_bfs_batch(grb_vector* v, int k, grb_matrix A, const grb_
   float ms = 0.f;
   static const bool trace = getenv("GRB_BATCH_TRACE") != nullptr;
   static const double budget = getenv("GRB_BATCH_BUDGET") ? atof(getenv("GRB_BATCH_BUDGET")) : 0.15;
+  const double tail_edges = (double)batch_tail_limit();
+  const bool tail_on = tail_edges > 0;
   auto now_us = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  // results come back through the pinned, host-coherent box the host polls: no copy, no stream wait
+  auto wait_box = [&]() -> grb_info {
+    const auto t0 = std::chrono::steady_clock::now();
+    unsigned spins = 0;
+    while (__atomic_load_n(&h_box[kBatchCounters], __ATOMIC_ACQUIRE) != box_seq) {
+      if ((++spins & 1023u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(5)) {
+        GRB_HIP_TRY(hipStreamSynchronize(st));               // a long level, or a fault this wait reports
+        if (__atomic_load_n(&h_box[kBatchCounters], __ATOMIC_ACQUIRE) != box_seq) return GRB_PANIC;
+      }
+    }
+    return GRB_SUCCESS;
+  };
   GRB_TRY(grb_timer_start());
   for (; iter <= desc->max_niter; ++iter) {
     const double t_lvl = trace ? now_us() : 0.0;
@@ -787,10 +1241,73 @@ extern "C" grb_info grb_bfs_batch(grb_vector* v, int k, grb_matrix A, const grb_
     for (int s = 0; s < k; ++s) if ((P >> s) & 1ull) pushed_edges += (double)mf_s[s];
     a.qmask = Q; a.pmask = P;
     a.prev = nullptr;
-    a.fcur = W(iter - 1);
-    a.fnext = W(iter);
+    a.fcur = fcur_words;
+    // ---- every live source pushed and few edges to push: this level and the light ones after it in one launch
+    if (tail_on && Q == 0 && P != 0 && pushed_edges <= tail_edges) {
+      int xi[3];
+      xi[0] = pick(fcur_words, nullptr, nullptr, true);
+      xi[1] = pick(fcur_words, pool[xi[0]], nullptr, true);
+      xi[2] = pick(fcur_words, pool[xi[0]], pool[xi[1]], true);
+      void* p_tail;
+      const size_t qcap = (size_t)n + (size_t)(A->nvals / kTailPiece) + 64;
+      const size_t st_bytes = (sizeof(TailState) + 255) & ~(size_t)255;
+      GRB_TRY(scratch(8, st_bytes + 3 * sizeof(u64) * qcap, &p_tail));
+      TailArgs t;
+      t.f0 = fcur_words;
+      for (int i = 0; i < 3; ++i) t.X[i] = pool[xi[i]];
+      t.st = (TailState*)p_tail;
+      for (int i = 0; i < 3; ++i) t.queue[i] = (u64*)((char*)p_tail + st_bytes) + (size_t)i * qcap;
+      t.box = d_box;
+      t.seq = ++box_seq;
+      t.iter0 = iter;
+      t.max_niter = desc->max_niter;
+      t.edge_limit = (unsigned long long)tail_edges;
+      t.src = (const Index*)p_src;
+      t.nsrc = iter == 1 ? k : 0;
+      a.direct_labels = 1;
+      GRB_HIP_TRY(hipMemsetAsync(p_tail, 0, st_bytes, st));
+      for (int i = 0; i < 3; ++i)
+        if (!pool_clean[xi[i]]) GRB_HIP_TRY(hipMemsetAsync(t.X[i], 0, sizeof(u64) * (size_t)n, st));
+      hipLaunchKernelGGL(batch_tail_kernel, dim3(c.num_cu), dim3(kPThreads), 0, st, a, t);
+      GRB_HIP_TRY(hipGetLastError());
+      GRB_TRY(wait_box());                                   // any number of levels; GRB_PANIC: a grid barrier gave up
+      const int done = (int)h_box[kBatchCounters + 1];
+      const int status = (int)h_box[kBatchCounters + 4];
+      edges += h_box[kBatchCounters + 2];
+      reached += h_box[kBatchCounters + 3];
+      any_left = false;
+      for (int s = 0; s < k; ++s) {
+        nf_s[s] = h_box[2 + 2 * s];
+        mf_s[s] = h_box[3 + 2 * s];
+        if (nf_s[s]) any_left = true;
+      }
+      levels += done;
+      last_dir = 0;
+      any_direct = true;
+      for (int i = 0; i < 3; ++i) pool_clean[xi[i]] = true;
+      fcur_words = t.X[(done - 1) % 3];                     // the last level run, j = done - 1, wrote X[j % 3]
+      if (status != 0) pool_clean[xi[(done - 1) % 3]] = false;   // the new frontier; every other array was left all-zero
+      if (trace) {
+        u64 ts[64];
+        GRB_HIP_TRY(hipMemcpy(ts, &t.st->ts[0], sizeof(ts), hipMemcpyDeviceToHost));
+        fprintf(stderr, "  launch stamps (us from start; prologue, barrier, then per level: work, flush, barrier):");
+        for (int i = 1; i < 64 && ts[i]; ++i) fprintf(stderr, " %.1f", (double)(ts[i] - ts[0]) * 0.01);
+        fprintf(stderr, "\n");
+      }
+      if (trace)
+        fprintf(stderr, "batch levels %d..%d: one launch (light levels), status %d, pairs %llu  %.1f us\n", iter, iter + done - 1,
+                status, (unsigned long long)h_box[kBatchCounters + 3], now_us() - t_lvl);
+      iter += done - 1;                                     // the level the launch ended on
+      if (status == 0) break;                               // nothing new: the traversals are over
+      continue;                                             // capped (the loop condition ends it) or grown heavy again
+    }
+    const bool keep = nkept <= nstore;                       // a slot left: the label pass reads this level's words
+    const int fi = keep ? -1 : pick(fcur_words, nullptr, nullptr, false);
+    a.fnext = keep ? Slot(nkept) : pool[fi];
+    if (fi >= 0) pool_clean[fi] = false;
     a.new_label = (float)(iter + 1);
-    a.direct_labels = iter > nstore ? 1 : 0;
+    a.direct_labels = keep ? 0 : 1;
+    if (keep) { kept_words[nkept] = a.fnext; kept_level[nkept] = iter; ++nkept; } else any_direct = true;
     if (Q) {
       const BatchSlices& B = A->batch_in;
       a.big = batch_big(true);
@@ -811,6 +1328,9 @@ extern "C" grb_info grb_bfs_batch(grb_vector* v, int k, grb_matrix A, const grb_
       const BatchSlices& B = A->batch_out;
       a.big = batch_big(false);
       if (pushed_edges > 0.5 * (double)n) {                 // heavy: claims only, the new bits read back against a copy
+        const int pi = pick(fcur_words, a.fnext, nullptr, false);
+        u64* prev = pool[pi];
+        pool_clean[pi] = false;
         GRB_HIP_TRY(hipMemcpyAsync(prev, seen, sizeof(u64) * (size_t)n, hipMemcpyDeviceToDevice, st));
         a.prev = prev;
       }
@@ -854,20 +1374,12 @@ extern "C" grb_info grb_bfs_batch(grb_vector* v, int k, grb_matrix A, const grb_
     // the totals come back through a pinned, host-coherent box the host polls: no copy, no stream wait
     hipLaunchKernelGGL(batch_totals_kernel, dim3(1), dim3(kBlock), 0, st, a.counters, d_box, ++box_seq);
     GRB_HIP_TRY(hipGetLastError());
-    {
-      const auto t0 = std::chrono::steady_clock::now();
-      unsigned spins = 0;
-      while (__atomic_load_n(&h_box[kBatchCounters], __ATOMIC_ACQUIRE) != box_seq) {
-        if ((++spins & 1023u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(5)) {
-          GRB_HIP_TRY(hipStreamSynchronize(st));               // a long level, or a fault this wait reports
-          if (__atomic_load_n(&h_box[kBatchCounters], __ATOMIC_ACQUIRE) != box_seq) return GRB_PANIC;
-        }
-      }
-    }
+    GRB_TRY(wait_box());
     u64 t[kBatchCounters];
     for (int j = 0; j < kBatchCounters; ++j) t[j] = __atomic_load_n(&h_box[j], __ATOMIC_RELAXED);
     ++levels;
     last_dir = Q ? 1 : 0;
+    fcur_words = a.fnext;
     any_left = false;
     u64 pairs = 0;
     for (int s = 0; s < k; ++s) {
@@ -889,21 +1401,30 @@ extern "C" grb_info grb_bfs_batch(grb_vector* v, int k, grb_matrix A, const grb_
   {
     LabelArgs L;
     L.n = n; L.k = k;
-    L.nstored = 1 + (levels < nstore ? levels : nstore);
-    L.max_label = desc->max_niter;
+    L.nstored = nkept;
     L.seen = seen;
-    for (int i = 0; i <= kBatchStoreMax; ++i) L.W[i] = i < L.nstored ? W(i) : nullptr;
+    for (int i = 0; i <= kBatchStoreMax; ++i) {
+      L.W[i] = i < nkept ? kept_words[i] : nullptr;
+      // discovered by the last allowed iteration: never assigned (bfs.hpp:48-66)
+      L.lab[i] = i < nkept && kept_level[i] + 1 <= desc->max_niter ? (float)(kept_level[i] + 1) : 0.f;
+    }
     for (int s = 0; s < 64; ++s) L.label[s] = a.label[s];
     hipLaunchKernelGGL(batch_labels_kernel, dim3(grid), dim3(kBlock), 0, st, L);
     GRB_HIP_TRY(hipGetLastError());
   }
-  if (hit_cap && levels > nstore) {
+  if (hit_cap && any_direct) {
     // vertices discovered by the last allowed iteration are never assigned by the reference loop (bfs.hpp:48-66)
     hipLaunchKernelGGL(batch_unlabel_kernel, dim3(stream_grid(n, kBlock)), dim3(kBlock), 0, st, a,
                        (float)(desc->max_niter + 1));
     GRB_HIP_TRY(hipGetLastError());
   }
   GRB_TRY(grb_timer_stop(&ms));
+  kept_pool.valid = true;
+  kept_pool.epoch = c.slot_epoch[7];
+  kept_pool.ptr = p_words;
+  kept_pool.n = n;
+  kept_pool.nstore = nstore;
+  for (int i = 0; i < 4; ++i) kept_pool.clean[i] = pool_clean[i];
   desc->lastmxv = last_dir ? GRB_PULLONLY : GRB_PUSHONLY;
   if (result) {
     result->levels = levels;

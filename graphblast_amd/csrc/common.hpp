@@ -384,6 +384,7 @@ struct Context {
   static constexpr int kSlots = 12;
   void* slot[kSlots] = {nullptr};
   size_t slot_cap[kSlots] = {0};
+  unsigned long long slot_epoch[kSlots] = {0};   // bumped by every scratch(i, ...): "nobody but me has had this slot since"
   int* h_mail = nullptr;            // pinned, host-coherent, 64 ints; [63] = published sequence number
   int* d_hmail = nullptr;           // device-side address of h_mail
   int mail_seq = 0;

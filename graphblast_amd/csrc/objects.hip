@@ -65,6 +65,7 @@ grb_info scratch(int i, size_t bytes, void** out) {
   Context& c = ctx();
   GRB_TRY(ctx_init());
   if (bytes < 256) bytes = 256;
+  ++c.slot_epoch[i];
   if (c.slot_cap[i] < bytes) {
     if (c.slot[i]) {
       // stream-ordered users of the old buffer must finish before it is released

@@ -487,6 +487,11 @@ void grb_sssp_last_work(int64_t* out3);
  * result->edges_traversed / reached are summed over the k traversals. */
 grb_info grb_bfs_batch(grb_vector* v, int k, grb_matrix A, const grb_index* sources, grb_descriptor desc,
                        grb_bfs_result* result);
+/* Levels in which every live source is pushed and at most `edges` out-edges leave the frontiers run inside one
+ * co-resident launch, one grid barrier per level, instead of four kernels and a host round trip each (the first level,
+ * the tail, every level of a high-diameter graph).  0: never; < 0: only query.  Returns the previous limit
+ * (default 1 Mi; GRB_BATCH_TAIL=0 / GRB_BATCH_TAIL_EDGES set it from the environment).  Same labels either way. */
+long long grb_bfs_batch_set_tail(long long edges);
 
 /* One record per iteration of the last grb_sssp / grb_pr / grb_cc call on a descriptor: what the
  * reference's drivers print per iteration under --timing 1 (sssp.hpp:55-62, pr.hpp:53-62) or 2

@@ -133,3 +133,54 @@ def test_batch_max_niter_cap_and_errors(hb, fx):
     assert g.bfs_batch([g.Vector(n)], A, [n], d)[0] == g.GrB_INVALID_INDEX
     assert g.bfs_batch([g.Vector(n + 1)], A, [0], d)[0] == g.GrB_DIMENSION_MISMATCH
     assert g.bfs_batch([g.Vector(n) for _ in range(65)], A, [0] * 65, d)[0] == g.GrB_INVALID_VALUE
+
+
+def test_light_levels_in_one_launch_equal_the_host_loop(hb):
+    """The levels grb_bfs_batch runs inside its one co-resident launch (every live source pushed, few out-edges:
+    the first level, the tail, every level of a high-diameter graph) against the same sweep with the launch
+    switched off: labels, level count and totals identical -- with the default limit (the whole grid sweep is one
+    launch), with limits so small that the launch hands levels back to the host loop and is entered again and again
+    (kept and directly-labelled levels interleave, the rotating word arrays change hands), and under iteration caps
+    that end inside the launch."""
+    from oracle import simple_reference as sr
+    from graphblast_amd.graphgen import rmat_edges, grid_edges, finalize_edges
+    g = hb.g
+    graphs = []
+    s, d, n = grid_edges(160, keep=0.62, seed=5)
+    graphs.append(("grid160", finalize_edges(s, d, n, symmetrize=True)))
+    s, d, n = rmat_edges(15, 12, seed=6)
+    graphs.append(("rmat15", finalize_edges(s, d, n, symmetrize=True)))
+    s, d, n = rmat_edges(14, 8, seed=7)
+    graphs.append(("rmat14_dir", finalize_edges(s, d, n, symmetrize=False)))
+    rng = np.random.default_rng(8)
+    before = g.bfs_batch_set_tail(-1)
+    try:
+        for name, gr in graphs:
+            ptr, ind = gr["csr"]
+            cptr, cind = gr["csc"]
+            n = gr["n"]
+            deg = np.diff(ptr)
+            A = g.Matrix(n, n)
+            assert A.build_csr(ptr, ind, np.ones(ind.size, F), csc=(cptr, cind, np.ones(cind.size, F))) == 0
+            srcs = [int(np.argmax(deg))] + [int(x) for x in rng.integers(0, n, 62)] + [int(np.argmax(deg))]
+            want = {s_: sr.bfs(ptr, ind, s_)[0] for s_ in set(srcs)}
+            depth = max(int(w.max()) for w in want.values())
+            for cap in (None, 3, max(2, depth // 2), depth - 1, depth):
+                args = dict(mxvmode=0, struconly=1, opreuse=1)
+                if cap is not None:
+                    args["max_niter"] = cap
+                g.bfs_batch_set_tail(0)
+                ref, ref_res, _ = run_batch(hb, A, n, srcs, **args)
+                if cap is None:
+                    for s_, lab in zip(srcs, ref):
+                        assert np.array_equal(lab, want[s_]), (name, s_)
+                for limit in (1 << 20, 4096, 96, 7):
+                    g.bfs_batch_set_tail(limit)
+                    for rep in range(2):                        # the second sweep starts from the arrays the first left clean
+                        got, res, _ = run_batch(hb, A, n, srcs, **args)
+                        for k, (x, y) in enumerate(zip(got, ref)):
+                            assert np.array_equal(x, y), (name, cap, limit, rep, k)
+                        assert res["levels"] == ref_res["levels"], (name, cap, limit)
+                        assert res["reached"] == ref_res["reached"] and res["edges_traversed"] == ref_res["edges_traversed"]
+    finally:
+        g.bfs_batch_set_tail(before)
