@@ -85,6 +85,11 @@ struct BatchTotals {                  // per workgroup, in LDS
   u64 v[kBatchCounters];
 };
 
+#ifndef GRB_BATCH_TRANSPOSE_FROM
+#define GRB_BATCH_TRANSPOSE_FROM 8
+#endif
+constexpr int kTransposeFrom = GRB_BATCH_TRANSPOSE_FROM;     // live sources in a wave from which the bit matrix is transposed by exchanges
+
 // A wave's running totals, source s in lane s: nf = (vertex, source) pairs discovered, mf = their out-degrees
 struct WaveTotals {
   u64 nf = 0, mf = 0;
@@ -103,10 +108,27 @@ __device__ inline void batch_commit_l(const BatchArgs& a, WaveTotals& acc, Index
   unsigned int deg = 0;
   if (newb) deg = (unsigned int)(a.optr[v + 1] - a.optr[v]);
   u64 m = 0;
-  for (u64 t = wave_or(newb); t; t &= t - 1) {
-    const int s = __builtin_amdgcn_readfirstlane(__ffsll((long long)t) - 1);   // wave-uniform: a scalar index
-    const unsigned long long col = __ballot((newb >> s) & 1ull);
-    if (lane == s) m = col;
+  const u64 live = wave_or(newb);
+  if (__popcll(live) <= kTransposeFrom) {
+    for (u64 t = live; t; t &= t - 1) {
+      const int s = __builtin_amdgcn_readfirstlane(__ffsll((long long)t) - 1);   // wave-uniform: a scalar index
+      const unsigned long long col = __ballot((newb >> s) & 1ull);
+      if (lane == s) m = col;
+    }
+  } else {
+    // many live sources: the 64 x 64 bit matrix is transposed in six exchange steps (blocks of 32, 16, ... 1 swapped
+    // with the lane `k` away) instead of one ballot per source -- ~70 instructions against ~10 per source
+    m = newb;
+    auto exchange = [&](int k, u64 keep) {
+      const u64 y = __shfl_xor(m, k, kWave);
+      m = (lane & k) ? ((m & ~keep) | ((y >> k) & keep)) : ((m & keep) | ((y << k) & ~keep));
+    };
+    exchange(32, 0x00000000ffffffffull);
+    exchange(16, 0x0000ffff0000ffffull);
+    exchange(8, 0x00ff00ff00ff00ffull);
+    exchange(4, 0x0f0f0f0f0f0f0f0full);
+    exchange(2, 0x3333333333333333ull);
+    exchange(1, 0x5555555555555555ull);
   }
   acc.nf += (u64)__popcll(m);
   unsigned int dor = deg;
