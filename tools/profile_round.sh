@@ -8,7 +8,7 @@
 #    --kernel-trace only, over `bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-refrule` (the 64-source
 #    sweep and the sparse x dense product included, so their kernels get counters too)
 # 4. BASELINE.json's other configurations: the plain JSON line, a --kernel-trace --stats run and the same two --pmc
-#    passes each (`--no-cpu-baseline`)
+#    passes each (`--no-cpu-baseline`); PROFILE_WORKLOADS="" skips them (their kernels unchanged since the last take)
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 P=gpurun_out/${1:-prof_r3}; mkdir -p $P
 grb_trace() {   # $1: a rocprofv3 kernel trace csv -> $2: this library's kernels in launch order
@@ -34,7 +34,7 @@ for C in FETCH_SIZE WRITE_SIZE; do
   timeout 500 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $P/pmc_$C -o p -- python bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-refrule > $P/pmc_$C.log 2>&1
   for f in $(find $P/pmc_$C -name "p_counter_collection.csv"); do cp $f $P/pmc_$C/p_counter_collection.csv 2>/dev/null; done
 done
-for W in lj_bfs road_sssp orkut_tc; do
+for W in ${PROFILE_WORKLOADS-lj_bfs road_sssp orkut_tc}; do
   timeout 400 python bench.py --workload $W > $P/$W.log 2> $P/$W.err
   timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $P/stats_$W -o w -- python bench.py --workload $W --no-cpu-baseline > $P/${W}_under_rocprof.log 2> $P/stats_$W.err
   for f in $(find $P/stats_$W -name "w_kernel_stats.csv"); do cp $f $P/${W}_kernel_stats.csv; done
@@ -46,4 +46,4 @@ for W in lj_bfs road_sssp orkut_tc; do
 done
 rm -rf $P/stats; find $P -name "*kernel_trace.csv" ! -name "bench_kernel_trace_grb.csv" -delete; find $P -name "*agent_info.csv" -delete
 find $P -type d -empty -delete
-du -sh $P; cut -c1-300 $P/bench_plain.log; for W in lj_bfs road_sssp orkut_tc; do cut -c1-200 $P/$W.log; done
+du -sh $P; cut -c1-300 $P/bench_plain.log; for W in ${PROFILE_WORKLOADS-lj_bfs road_sssp orkut_tc}; do cut -c1-200 $P/$W.log; done

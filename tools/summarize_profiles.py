@@ -3,8 +3,20 @@
 import csv, collections, json, shutil, os, sys
 src, dst = sys.argv[1], sys.argv[2]
 os.makedirs(dst, exist_ok=True)
+ALL_W = ("lj_bfs", "road_sssp", "orkut_tc")
+# a partial take (PROFILE_WORKLOADS="" or a subset): what belongs to a workload that was not run again stays as it is
+kept_w = [W for W in ALL_W if not os.path.exists(src + '/%s.log' % W)]
+prev_doc, prev_lines = {}, {}
+if kept_w and os.path.exists(dst + '/pmc_traffic.json'):
+    prev_doc = json.load(open(dst + '/pmc_traffic.json')).get("workloads", {})
+if kept_w and os.path.exists(dst + '/other_workloads.jsonl'):
+    for ln in open(dst + '/other_workloads.jsonl').read().strip().splitlines():
+        for W, key in (("lj_bfs", "soc-L"), ("road_sssp", "road"), ("orkut_tc", "rkut")):
+            if key in json.loads(ln).get("metric", "") + json.dumps(json.loads(ln).get("config", {})):
+                prev_lines.setdefault(W, ln)
+keep_prefixes = ("full_suite", "bfs_ab", "tests_") + tuple(kept_w) + tuple("pmc_%s_" % W for W in kept_w)
 for f in os.listdir(dst):
-    if not f.startswith(("full_suite", "bfs_ab", "tests_")):     # logs of test / A-B runs kept beside the profiles
+    if not f.startswith(keep_prefixes):     # logs of test / A-B runs kept beside the profiles
         os.remove(os.path.join(dst, f))
 rows = list(csv.reader(open(src + '/bench_kernel_stats.csv')))
 shutil.copy(src + '/bench_kernel_stats.csv', dst + '/bench_kernel_stats_all.csv')
@@ -88,7 +100,13 @@ if seeds:
                                      "what": "sum over every batch_* kernel of (2 x FETCH_SIZE + WRITE_SIZE) x launches, per batch_seed_kernel launch"}
 workloads = {}
 lines = []
-for W in ("lj_bfs", "road_sssp", "orkut_tc"):
+for W in ALL_W:
+    if W in kept_w:
+        if W in prev_lines:
+            lines.append(prev_lines[W])
+        if W in prev_doc:
+            workloads[W] = prev_doc[W]
+        continue
     if os.path.exists(src + '/%s.log' % W):
         txt = open(src + '/%s.log' % W).read().strip().splitlines()
         if txt:
