@@ -159,6 +159,18 @@ __global__ __launch_bounds__(kBlock) void spgemm_masked_kernel(
 // (key, value) slots -- or 8192 keys when the pivot side holds one value throughout, as a pattern matrix does -- and
 // pivots beyond 128 KiB of table are taken in column-range segments.  Without a CSC of the mask pass 2 falls back to the
 // entry-driven kernel for its entries.
+#ifndef GRB_TC_EXP
+#define GRB_TC_EXP 0
+#endif
+#ifndef GRB_TC_FILTER
+#define GRB_TC_FILTER 1                    // key-only tables: a 16 KiB Bloom filter in front of the table
+#endif
+#ifndef GRB_TC_LOAD_INV
+#define GRB_TC_LOAD_INV 4                  // table slots per pivot entry aimed at (2 = half load is the guaranteed minimum)
+#endif
+#ifndef GRB_TC_DEPTH
+#define GRB_TC_DEPTH 2                     // chunks of a partner stream in flight behind the one being probed
+#endif
 constexpr int kWaveCap = 512;              // pivot entries a wave's table holds (1024 slots x 8 B = 8 KiB per wave)
 constexpr int kWaveSlots = 2 * kWaveCap;
 constexpr unsigned int kEmptyKey = 0xffffffffu;
@@ -316,6 +328,9 @@ template <int SR, typename T>
 __global__ __launch_bounds__(kBlock) void spgemm_pivot_wave_kernel(T* __restrict__ c_val, PivotView v, Index npivots) {
   typedef Semiring<SR, T> S;
   __shared__ HashSlot s_tab[kWavesPerBlock][kWaveSlots];
+  constexpr bool kFilter = GRB_TC_FILTER != 0;             // a Bloom filter in front of the table, as in the block kernel
+  constexpr int kFiltWords = kFilter ? kWaveCap / 2 : 1;   // 16 bits per key at capacity
+  __shared__ unsigned int s_filt[kWavesPerBlock][kFiltWords];
   __shared__ Index s_off[kWavesPerBlock][kWave + 1];
   __shared__ Index s_start[kWavesPerBlock][kWave];
   __shared__ T s_acc[kWavesPerBlock][kWave];
@@ -334,7 +349,8 @@ __global__ __launch_bounds__(kBlock) void spgemm_pivot_wave_kernel(T* __restrict
     const Index da = ae - as;
     if (da > kWaveCap || da == 0) continue;               // the workgroup kernel's / nothing to intersect with
     bool built = false;
-    unsigned int tmask = 0;
+    unsigned int tmask = 0, fmask = 0;
+    unsigned int* filt = s_filt[wave];
     for (Index t0 = es; t0 < ee; t0 += kWave) {
       // ---- this tile's partners: one per lane
       const Index t = t0 + lane;
@@ -354,13 +370,24 @@ __global__ __launch_bounds__(kBlock) void spgemm_pivot_wave_kernel(T* __restrict
         while ((Index)slots < 2 * da) slots <<= 1;
         tmask = slots - 1;
         for (unsigned int i = lane; i < slots; i += kWave) tab[i].key = kEmptyKey;
+        if constexpr (kFilter) {
+          unsigned int fwords = 16;
+          while (2 * (Index)fwords < da && fwords < (unsigned int)kFiltWords) fwords <<= 1;
+          fmask = fwords - 1;
+          for (unsigned int i = lane; i < fwords; i += kWave) filt[i] = 0u;
+        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         for (Index p = as + lane; p < ae; p += kWave) {
           unsigned int vb;
           const T av = piv_val[p];
           memcpy(&vb, &av, 4);
-          tc_insert(tab, tmask, (unsigned int)v.piv_ind[p], vb);
+          const unsigned int col = (unsigned int)v.piv_ind[p];
+          tc_insert(tab, tmask, col, vb);
+          if constexpr (kFilter) {
+            const unsigned int hh = tc_hash(col);
+            atomicOr(&filt[(hh >> 12) & fmask], (1u << (hh & 31u)) | (1u << ((hh >> 5) & 31u)));
+          }
         }
         built = true;
       }
@@ -382,7 +409,14 @@ __global__ __launch_bounds__(kBlock) void spgemm_pivot_wave_kernel(T* __restrict
             if (off[lo + step] <= x) lo += step;
           const Index q = s_start[wave][lo] + (x - off[lo]);
           unsigned int vb;
-          if (tc_find(tab, tmask, (unsigned int)v.par_ind[q], &vb)) {
+          const unsigned int col = (unsigned int)v.par_ind[q];
+          bool maybe = true;
+          if constexpr (kFilter) {
+            const unsigned int hh = tc_hash(col);
+            const unsigned int pat = (1u << (hh & 31u)) | (1u << ((hh >> 5) & 31u));
+            maybe = (filt[(hh >> 12) & fmask] & pat) == pat;
+          }
+          if (maybe && tc_find(tab, tmask, col, &vb)) {
             T pv;
             memcpy(&pv, &vb, 4);
             const T bv = v.par_iso ? par_one : par_val[q];
@@ -415,6 +449,13 @@ __global__ __launch_bounds__(1024) void spgemm_pivot_block_kernel(T* __restrict_
   unsigned long long t_items = 0;
   int n_items = 0;
   __shared__ Slot s_tab[2 * kCap];
+  // Most probes miss (RMAT-22 ef 28: one in seven finds its key), and what this kernel waits for is the LDS executing
+  // a wave's random 16-byte reads (GRB_TC_EXP: the probes, not the stream, are its time).  A Bloom filter in front of
+  // the table settles the misses with one 4-byte read: two bits of one word per key, 16 bits per key at the
+  // capacity of the 64 KiB table (8 at the 128 KiB one's), so a few percent of the misses still look at the table.
+  constexpr bool kFilter = GRB_TC_FILTER != 0;
+  constexpr int kFiltWords = kFilter ? 4096 : 1;
+  __shared__ unsigned int s_filt[kFiltWords];
   const int tid = threadIdx.x, lane = tid & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const T* __restrict__ par_val = reinterpret_cast<const T*>(v.par_val);
@@ -440,17 +481,31 @@ __global__ __launch_bounds__(1024) void spgemm_pivot_block_kernel(T* __restrict_
     const Index seg_s = as + seg * (Index)kCap;
     const Index seg_e = (kSegments && seg_s + kCap < ae) ? seg_s + (Index)kCap : ae;
     const Index c_lo = kSegments ? v.piv_ind[seg_s] : 0, c_hi = kSegments ? v.piv_ind[seg_e - 1] : 0;
+    // the table at a QUARTER load where the pivot allows it (half load is what the capacity guarantees): with four keys
+    // per group and two expected, one group in seven is full and a probe walks on -- a dependent LDS read the whole wave
+    // waits for, for each of its four keys in turn.  The isolating runs (GRB_TC_EXP) say the probes, not the stream,
+    // are this kernel's time, and the LDS executes a wave's random 16-byte reads at ~70 cycles each.
     unsigned int slots = 1024;
+    while ((Index)slots < GRB_TC_LOAD_INV * (seg_e - seg_s) && slots < 2u * (unsigned int)kCap) slots <<= 1;
     while ((Index)slots < 2 * (seg_e - seg_s)) slots <<= 1;
     const unsigned int tmask = slots - 1;
+    unsigned int fwords = 64;
+    while (kFilter && 2 * (Index)fwords < seg_e - seg_s && fwords < (unsigned int)kFiltWords) fwords <<= 1;   // 16 bits per key
+    const unsigned int fmask = fwords - 1;
     __syncthreads();
     for (unsigned int i = tid; i < slots; i += 1024) tab[i].key = kEmptyKey;
+    if constexpr (kFilter)
+      for (unsigned int i = tid; i < fwords; i += 1024) s_filt[i] = 0u;
     __syncthreads();
     for (Index p = seg_s + tid; p < seg_e; p += 1024) {
       unsigned int vb;
       const T av = piv_val[p];
       memcpy(&vb, &av, 4);
       tc_insert(tab, tmask, (unsigned int)v.piv_ind[p], vb);
+      if constexpr (kFilter) {
+        const unsigned int hh = tc_hash((unsigned int)v.piv_ind[p]);
+        atomicOr(&s_filt[(hh >> 12) & fmask], (1u << (hh & 31u)) | (1u << ((hh >> 5) & 31u)));
+      }
     }
     __syncthreads();
     // A wave per partner: the pivots here are long, and so are their partners on average (RMAT-22 ef 28: 450
@@ -471,53 +526,102 @@ __global__ __launch_bounds__(1024) void spgemm_pivot_block_kernel(T* __restrict_
       // (the same partner's, or the next partner's first) are in flight while the current chunk is probed -- a
       // partner is a couple of dependent memory steps otherwise, and a wave does hundreds of them one after the other.
       unsigned long long todo = __ballot(mine && pe > ps);
-      int src_n = todo ? __ffsll((long long)todo) - 1 : -1;   // partner the next chunk belongs to
-      Index cs_n = 0, ce_n = 0;
-      if (src_n >= 0) { cs_n = __shfl(ps, src_n, kWave); ce_n = __shfl(pe, src_n, kWave); todo &= todo - 1; }
-      unsigned int kn[4] = {kEmptyKey, kEmptyKey, kEmptyKey, kEmptyKey};
-      Index q_n = cs_n;
-      auto fetch = [&]() {
+      // chunk descriptors: the partner (lane of the batch) a chunk belongs to (-1: none left), its first element, the
+      // partner's end.  GRB_TC_DEPTH chunks are in flight behind the one being probed: every element comes from
+      // HBM exactly once (the partners' lists are far larger than the caches), and with one chunk -- 1 KiB -- ahead
+      // per wave the stream ran at 0.8 TB/s.
+      struct Chunk { int src; Index q, ce; };
+      auto advance = [&](Chunk d) -> Chunk {
+        if (d.src < 0) return d;
+        if (d.q + 4 * kWave < d.ce) { d.q += 4 * kWave; return d; }
+        if (todo) {
+          d.src = __ffsll((long long)todo) - 1;
+          todo &= todo - 1;
+          d.q = __shfl(ps, d.src, kWave);
+          d.ce = __shfl(pe, d.src, kWave);
+        } else {
+          d.src = -1;
+        }
+        return d;
+      };
+      auto fetch = [&](const Chunk& d, unsigned int (&k)[4]) {
 #pragma unroll
         for (int h = 0; h < 4; ++h) {
-          const Index q = q_n + h * kWave + lane;
-          kn[h] = (src_n >= 0 && q < ce_n) ? (unsigned int)v.par_ind[q] : kEmptyKey;   // the empty key is in no table
+          const Index q = d.q + h * kWave + lane;
+#if GRB_TC_EXP == 2   // isolating experiment: no stream from memory, the keys are made up (results wrong)
+          k[h] = (d.src >= 0 && q < d.ce) ? (unsigned int)(q * 2654435761u) >> 12 : kEmptyKey;
+#else
+          k[h] = (d.src >= 0 && q < d.ce) ? (unsigned int)v.par_ind[q] : kEmptyKey;   // the empty key is in no table
+#endif
         }
       };
-      fetch();
+      Chunk d0 = {-1, 0, 0};
+      if (todo) {
+        d0.src = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        d0.q = __shfl(ps, d0.src, kWave);
+        d0.ce = __shfl(pe, d0.src, kWave);
+      }
+      constexpr int kDepth = GRB_TC_DEPTH;
+      Chunk dq[kDepth + 1];
+      unsigned int kq[kDepth + 1][4];
+      dq[0] = d0;
+      fetch(dq[0], kq[0]);
+#pragma unroll
+      for (int i = 1; i <= kDepth; ++i) {
+        dq[i] = advance(dq[i - 1]);
+        fetch(dq[i], kq[i]);
+      }
       T acc = S::identity();
-      while (src_n >= 0) {
-        // the chunk just fetched becomes the current one
+      while (dq[0].src >= 0) {
+        // the oldest chunk becomes the current one ...
         unsigned int kc[4];
 #pragma unroll
-        for (int h = 0; h < 4; ++h) kc[h] = kn[h];
-        const int src_c = src_n;
-        const Index q_c = q_n;
-        const bool last_of_partner = q_n + 4 * kWave >= ce_n;
-        // ... and the next one is requested before this one is looked at
-        if (!last_of_partner) {
-          q_n += 4 * kWave;
-        } else if (todo) {
-          src_n = __ffsll((long long)todo) - 1;
-          todo &= todo - 1;
-          cs_n = __shfl(ps, src_n, kWave);
-          ce_n = __shfl(pe, src_n, kWave);
-          q_n = cs_n;
-        } else {
-          src_n = -1;
+        for (int h = 0; h < 4; ++h) kc[h] = kq[0][h];
+        const int src_c = dq[0].src;
+        const Index q_c = dq[0].q;
+        const bool last_of_partner = dq[0].q + 4 * kWave >= dq[0].ce;
+        // ... and one more is requested before this one is looked at
+#pragma unroll
+        for (int i = 0; i < kDepth; ++i) {
+          dq[i] = dq[i + 1];
+#pragma unroll
+          for (int h = 0; h < 4; ++h) kq[i][h] = kq[i + 1][h];
         }
-        fetch();
+        dq[kDepth] = advance(dq[kDepth]);
+        fetch(dq[kDepth], kq[kDepth]);
         // the four keys' home groups are read together (one LDS round trip); a key whose group is full and does
         // not hold it -- rare at half load -- walks on alone
         TcWord4 gr[4];
         unsigned int home[4];
+        if constexpr (kFilter) {
+          unsigned int fw[4], pat[4];
+#pragma unroll
+          for (int h = 0; h < 4; ++h) {
+            const unsigned int hh = tc_hash(kc[h]);
+            pat[h] = (1u << (hh & 31u)) | (1u << ((hh >> 5) & 31u));
+            fw[h] = s_filt[(hh >> 12) & fmask];
+          }
+#pragma unroll
+          for (int h = 0; h < 4; ++h)
+            if ((fw[h] & pat[h]) != pat[h]) kc[h] = kEmptyKey;     // not in the table: as if the slot were empty
+        }
 #pragma unroll
         for (int h = 0; h < 4; ++h) {
           home[h] = tc_home(tab, tmask, kc[h] != kEmptyKey ? kc[h] : 0u);
-          gr[h] = tc_load(tab, home[h]);
+#if GRB_TC_EXP == 1   // isolating experiment: the stream is consumed without probing the table (results wrong)
+          gr[h] = TcWord4{kc[h], 0u, 0u, 0u};
+#else
+          if (!kFilter || kc[h] != kEmptyKey) gr[h] = tc_load(tab, home[h]);
+#endif
         }
 #pragma unroll
         for (int h = 0; h < 4; ++h) {
           if (kc[h] == kEmptyKey) continue;
+#if GRB_TC_EXP == 1
+          if ((kc[h] & 1023u) == 7u) acc = S::add(acc, (T)1);
+          continue;
+#endif
           unsigned int vb = v.iso_bits;
           int verdict = tc_verdict(tab, gr[h], kc[h], &vb);
           for (unsigned int sl = home[h]; verdict < 0;) {
