@@ -605,6 +605,13 @@ __global__ __launch_bounds__(1024) void spgemm_pivot_block_kernel(T* __restrict_
 #pragma unroll
           for (int h = 0; h < 4; ++h)
             if ((fw[h] & pat[h]) != pat[h]) kc[h] = kEmptyKey;     // not in the table: as if the slot were empty
+#if GRB_TC_EXP == 3   // isolating experiment: the filter's reads alone, nobody goes on to the table (results wrong)
+#pragma unroll
+          for (int h = 0; h < 4; ++h) {
+            if (kc[h] != kEmptyKey && (fw[h] & 1u)) acc = S::add(acc, (T)1);
+            kc[h] = kEmptyKey;
+          }
+#endif
         }
 #pragma unroll
         for (int h = 0; h < 4; ++h) {
