@@ -72,6 +72,12 @@ constexpr bool mxm_order_free() {
   }
 }
 
+template <int SR>
+constexpr bool mxm_plus_monoid() {
+  if constexpr (SR == GRB_RUNTIME_SR) return false;
+  else return MonoidTraits<SemiringTraits<SR>::monoid>::op == OP_PLUS;
+}
+
 template <int SR, typename T>
 __global__ __launch_bounds__(kBlock) void spgemm_masked_kernel(
     T* __restrict__ c_val, const Index* __restrict__ m_row, const Index* __restrict__ m_ind,
@@ -161,6 +167,9 @@ __global__ __launch_bounds__(kBlock) void spgemm_masked_kernel(
 // entry-driven kernel for its entries.
 #ifndef GRB_TC_EXP
 #define GRB_TC_EXP 0
+#endif
+#ifndef GRB_TC_COMPACT
+#define GRB_TC_COMPACT 1                   // the keys the filter lets through are queued and probed 64 at a time (0: each where it is found)
 #endif
 #ifndef GRB_TC_FILTER
 #define GRB_TC_FILTER 1                    // key-only tables: a 16 KiB Bloom filter in front of the table
@@ -456,6 +465,17 @@ __global__ __launch_bounds__(1024) void spgemm_pivot_block_kernel(T* __restrict_
   constexpr bool kFilter = GRB_TC_FILTER != 0;
   constexpr int kFiltWords = kFilter ? 4096 : 1;
   __shared__ unsigned int s_filt[kFiltWords];
+  // GRB_TC_COMPACT: one key in six passes the filter, and an LDS instruction with a sixth of its lanes active costs
+  // nearly what a full one costs (GRB_TC_EXP=3).  So the keys that pass are QUEUED per wave, with the partner they
+  // belong to, and probed 64 at a time with every lane active; a hit is one ds_add_u32 on the partner's counter.
+  // Key-only tables, an integer plus-monoid and a partner side that holds one value: an entry's result is then
+  // count x (the one product).
+  constexpr bool kCompact = GRB_TC_COMPACT != 0 && kFilter && std::is_same<Slot, KeySlot>::value && std::is_integral<T>::value &&
+                            mxm_plus_monoid<SR>();
+  constexpr int kCq = kCompact ? 2 * kWave : 1;
+  __shared__ unsigned int s_ckey[kCompact ? 16 : 1][kCq];
+  __shared__ unsigned char s_csrc[kCompact ? 16 : 1][kCq];
+  __shared__ unsigned int s_cnt[kCompact ? 16 : 1][kCompact ? kWave : 1];
   const int tid = threadIdx.x, lane = tid & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const T* __restrict__ par_val = reinterpret_cast<const T*>(v.par_val);
@@ -522,6 +542,29 @@ __global__ __launch_bounds__(1024) void spgemm_pivot_block_kernel(T* __restrict_
         pe = lower_bound_dev(v.par_ind, ps, pe, c_hi + 1);
       }
       T result = S::identity();
+      const bool compact = kCompact && v.par_iso != 0;       // wave-uniform
+      int qlen = 0;                                          // queued candidates (compact)
+      if constexpr (kCompact) {
+        if (compact) {
+          s_cnt[wave][lane] = 0u;
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+        }
+      }
+      // candidates [qlen - na, qlen) of the wave's queue, one per lane
+      auto probe_round = [&](int na) {
+        if constexpr (kCompact) {
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          const bool on = lane < na;
+          const unsigned int key = on ? s_ckey[wave][qlen - na + lane] : 0u;
+          const unsigned int src = on ? (unsigned int)s_csrc[wave][qlen - na + lane] : 0u;
+          if (on && tc_find(reinterpret_cast<const KeySlot*>(tab), tmask, key, nullptr)) atomicAdd(&s_cnt[wave][src], 1u);
+          qlen -= na;
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+        }
+      };
       // The partners' lists as one sequence of 256-element chunks, software-pipelined: the keys of the next chunk
       // (the same partner's, or the next partner's first) are in flight while the current chunk is probed -- a
       // partner is a couple of dependent memory steps otherwise, and a wave does hundreds of them one after the other.
@@ -605,6 +648,25 @@ __global__ __launch_bounds__(1024) void spgemm_pivot_block_kernel(T* __restrict_
 #pragma unroll
           for (int h = 0; h < 4; ++h)
             if ((fw[h] & pat[h]) != pat[h]) kc[h] = kEmptyKey;     // not in the table: as if the slot were empty
+          if constexpr (kCompact) {
+            if (compact) {
+#pragma unroll
+              for (int h = 0; h < 4; ++h) {
+                const bool pos = kc[h] != kEmptyKey;
+                const unsigned long long pm = __ballot(pos);
+                if (pm) {
+                  if (pos) {
+                    const int at = qlen + __popcll(pm & ((1ull << lane) - 1ull));
+                    s_ckey[wave][at] = kc[h];
+                    s_csrc[wave][at] = (unsigned char)src_c;
+                  }
+                  qlen += __popcll(pm);
+                  if (qlen >= kWave) probe_round(kWave);
+                }
+              }
+              continue;                                      // nothing per partner here: the counters hold the results
+            }
+          }
 #if GRB_TC_EXP == 3   // isolating experiment: the filter's reads alone, nobody goes on to the table (results wrong)
 #pragma unroll
           for (int h = 0; h < 4; ++h) {
@@ -646,6 +708,17 @@ __global__ __launch_bounds__(1024) void spgemm_pivot_block_kernel(T* __restrict_
           acc = wave_reduce(acc, [](T x, T y) { return S::add(x, y); });
           if (lane == src_c) result = acc;
           acc = S::identity();
+        }
+      }
+      if constexpr (kCompact) {
+        if (compact) {
+          if (qlen > 0) probe_round(qlen);
+          T pv;
+          const unsigned int vb = v.iso_bits;
+          memcpy(&pv, &vb, 4);
+          const T one = v.cols ? S::mul(par_one, pv) : S::mul(pv, par_one);
+          result = (T)s_cnt[wave][lane] * one;               // an integer sum of `count` equal products
+          __builtin_amdgcn_wave_barrier();
         }
       }
       if (mine) c_val[out] = (kSegments && seg > 0) ? S::add(result, c_val[out]) : result;
