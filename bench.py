@@ -492,14 +492,67 @@ def main():
         first = run_step(0)
         barrier()
         first_ms = (time.perf_counter() - t0p) * 1e3
-        for i in range(args.warmup):
-            run_step(i)
+        # The K timed steps are K traversals into K depth vectors, QUEUED back to back on the library's stream
+        # (grb_bfs_fused_enqueue) and waited for afterwards (grb_bfs_wait): nothing between two traversals waits for the
+        # host, so `value` is the device's rate, not the rate at which this interpreter gets scheduled.  The same K
+        # steps through the blocking call (one host round trip per traversal) are timed right after, as a sibling
+        # (`blocking_loop`), each step's wall time recorded.
+        vs = [g.Vector(n) for _ in range(args.steps)]
+
+        def run_queued(count, first=0, stamps=None):
+            tickets = []
+            for i in range(count):
+                info, t = g.bfs_enqueue(vs[i % len(vs)], A, sources[(first + i) % len(sources)], desc)
+                assert info == 0, info
+                tickets.append(t)
+            out = []
+            for t in tickets:
+                info, res = g.bfs_wait(t)
+                assert info == 0, info
+                if stamps is not None:
+                    stamps.append(time.perf_counter())
+                out.append(res)
+            return out
+
+        if args.warmup:
+            run_queued(args.warmup)
+        g.bfs_host_times(reset=True)
+        stamps = []
         barrier()
         t0 = time.perf_counter()
-        results = [run_step(i) for i in range(args.steps)]
+        results = run_queued(args.steps, stamps=stamps)
         barrier()
         elapsed = time.perf_counter() - t0
         edges = sum(r["edges_traversed"] for r in results)
+        ht = g.bfs_host_times(reset=True)
+        done_ms = np.diff(np.array([t0] + stamps)) * 1e3          # record k seen by the host: the first includes the queueing
+        extra["queued"] = {"what": "the timed region: K traversals queued (grb_bfs_fused_enqueue), then K waits (grb_bfs_wait)",
+                           "host_enqueue_us_per_step": round(ht["enqueue_us"] / max(ht["calls"], 1), 2),
+                           "host_wait_us_total": round(ht["wait_us"], 1),
+                           "record_arrival_gap_ms": {"min": round(float(done_ms[1:].min()), 4) if args.steps > 1 else None,
+                                                     "median": round(float(np.median(done_ms[1:])), 4) if args.steps > 1 else None,
+                                                     "max": round(float(done_ms[1:].max()), 4) if args.steps > 1 else None},
+                           "until_first_record_ms": round(float(done_ms[0]), 4)}
+        # the labels the queued steps left are checked below (parity block) through vs[...]; the blocking sibling:
+        for i in range(min(args.warmup, 2)):
+            run_step(i)
+        g.bfs_host_times(reset=True)
+        step_ms = []
+        barrier()
+        t0b = time.perf_counter()
+        for i in range(args.steps):
+            t1 = time.perf_counter()
+            run_step(i)
+            step_ms.append((time.perf_counter() - t1) * 1e3)
+        barrier()
+        el_block = time.perf_counter() - t0b
+        ht = g.bfs_host_times(reset=True)
+        extra["blocking_loop"] = {"what": "the same K steps through grb_bfs_fused, one host round trip per traversal",
+                                  "value": edges / el_block, "unit": "TEPS", "ms_per_step": round(el_block / args.steps * 1e3, 5),
+                                  "per_step_wall_ms": {"min": round(min(step_ms), 4), "median": round(float(np.median(step_ms)), 4),
+                                                       "max": round(max(step_ms), 4)},
+                                  "host_enqueue_us_per_step": round(ht["enqueue_us"] / max(ht["calls"], 1), 2),
+                                  "host_wait_us_per_step": round(ht["wait_us"] / max(ht["calls"], 1), 2)}
 
         # ---- roofline of the dominant kernel.  The traversal is ONE launch of
         #      bfs_persistent_kernel; its duration is measured with HIP events on the library's
@@ -789,11 +842,14 @@ def main():
                 for i in step_of.get(s, []):
                     if (results[i]["reached"], results[i]["edges_traversed"]) != (want_reached, want_edges):
                         mismatches.append(("timed step %d" % i, s))
+                    if not np.array_equal(vs[i].extractTuples()[1], depth):      # the vector the QUEUED timed step wrote
+                        mismatches.append(("labels of timed step %d" % i, s))
             extra["parity_checked_sources"] = nsamp
             extra["parity"] = {"checked_sources": nsamp, "mismatches": len(mismatches),
                                "checker": "oracle/_ref/libsimple_ref.so (the reference's SimpleReferenceBfs)" if use_ref
                                else "oracle/simple_reference.c (restatement)",
-                               "what": "depth labels bit-exact per source; reached / edges of every timed step from "
+                               "what": "depth labels bit-exact per source -- from a blocking call and from the vector every "
+                                       "queued timed step of that source wrote; reached / edges of every timed step from "
                                        "those sources"}
             if mismatches:
                 print(json.dumps({"error": "parity", "mismatches": mismatches[:10]}))

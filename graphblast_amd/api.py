@@ -471,6 +471,29 @@ def bfs(v, A, s, desc, fused=False, profile=False, max_levels=4096):
                       reached=res.reached, per_level=levels)
 
 
+def bfs_enqueue(v, A, s, desc):
+    """grb_bfs_fused_enqueue: queue the traversal on the library's stream and return (info, ticket) without waiting.
+    v, A and desc must stay alive until bfs_wait(ticket)."""
+    t = C.c_int64(0)
+    info = _lib.load().grb_bfs_fused_enqueue(_h(v), _h(A), int(s), _h(desc), C.byref(t))
+    return info, t.value
+
+
+def bfs_wait(ticket):
+    """grb_bfs_wait: (info, result dict) of a queued traversal; what bfs(..., fused=True) would have returned."""
+    res = BfsResult()
+    info = _lib.load().grb_bfs_wait(C.c_int64(ticket), C.byref(res))
+    return info, dict(levels=res.levels, tight_ms=res.tight_ms, edges_traversed=res.edges_traversed,
+                      reached=res.reached, per_level=[])
+
+
+def bfs_host_times(reset=False):
+    """Host microseconds spent queueing / waiting inside the one-launch traversal since the last reset, and the calls."""
+    e, w, n = C.c_double(0), C.c_double(0), C.c_longlong(0)
+    _lib.call("grb_bfs_host_times", C.byref(e), C.byref(w), C.byref(n), int(bool(reset)))
+    return dict(enqueue_us=e.value, wait_us=w.value, calls=n.value)
+
+
 def spmm(op, A, d_B, d_C, k, desc=None, tran=False):
     """C = A (+).(x) B with dense row-major device arrays B [ncols x k], C [nrows x k] (grb_spmm)."""
     return _lib.load().grb_spmm(_semiring_id(op), _h(A), int(bool(tran)), d_B, d_C, int(k), _h(desc))

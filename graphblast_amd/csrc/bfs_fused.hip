@@ -80,6 +80,116 @@ static grb_info bfs_tally_labels(const float* label, const Index* ptr, Index n, 
   return GRB_SUCCESS;
 }
 
+// what the host does with the record of a one-launch traversal: lastmxv_, the labels of a search that max_niter cut
+// short (the last frontier is never assigned by the reference loop), the result block, the vector's count
+static grb_info bfs_one_launch_finish(grb_vector v, grb_matrix A, grb_descriptor desc, int p_levels, int p_dir, long long p_reached,
+                                      unsigned long long p_edges, Index p_nf, bool p_cap, float p_ms, grb_bfs_result* result) {
+  hipStream_t s = ctx().stream;
+  const Index n = A->nrows;
+  desc->lastmxv = p_dir ? GRB_PULLONLY : GRB_PUSHONLY;
+  if (p_cap && p_nf > 0) {
+    hipLaunchKernelGGL(bfs_unlabel_kernel, dim3(stream_grid(n)), dim3(kBlock), 0, s, (float*)v->d_val, n,
+                       (float)(desc->max_niter + 1));
+    GRB_HIP_TRY(hipGetLastError());
+    int64_t e2 = 0; int32_t r2 = 0;
+    GRB_TRY(bfs_tally_labels((const float*)v->d_val, A->csr.ptr, n, &e2, &r2));
+    p_edges = (unsigned long long)e2; p_reached = r2;
+  }
+  if (result) {
+    result->levels = p_levels;
+    result->tight_ms = p_ms;
+    result->edges_traversed = (int64_t)p_edges;
+    result->reached = (int32_t)p_reached;
+  }
+  v->d_nnz = (Index)p_reached;
+  return GRB_SUCCESS;
+}
+
+static bool bfs_use_persistent() {
+  static const bool use = [] { const char* e = getenv("GRB_BFS_PERSISTENT"); return !e || atoi(e) != 0; }();
+  return use;
+}
+static int g_persistent_failures = 0;   // three barrier give-ups in a row (each costs seconds of bounded spinning): the device is
+                                        // evidently shared; stop trying for the rest of the process
+
+// ---- queue now, wait later (grb_hip.h) ------------------------------------------------------------------------------
+// K traversals into K vectors are K kernel pairs queued back to back on the library's stream, each with its own
+// record in pinned host memory; the host looks at the records when it wants the results.  Nothing between two
+// traversals waits for the host, so a host that is slow, descheduled or busy (the per-level host round trips of
+// bfs.hpp:42-88 are the extreme case) costs nothing as long as it queues faster than the device traverses.
+extern "C" grb_info grb_bfs_fused_enqueue(grb_vector v, grb_matrix A, grb_index source, grb_descriptor desc,
+                                          grb_bfs_ticket* ticket) { GRB_API_ENTER();
+  if (!ticket) return GRB_NULL_POINTER;
+  *ticket = 0;
+  if (!v || !A || !desc) return GRB_UNINITIALIZED_OBJECT;
+  if (!A->built || !A->csr.ptr || !A->csc.ptr) return GRB_UNINITIALIZED_OBJECT;
+  if (v->dtype != GRB_F32) return GRB_DOMAIN_MISMATCH;
+  if (A->nrows != A->ncols || v->nsize != A->nrows) return GRB_DIMENSION_MISMATCH;
+  if (source < 0 || source >= A->nrows) return GRB_INVALID_INDEX;
+  GRB_TRY(ctx_init());
+  int slot = 0, seq = 0;
+  GRB_TRY(bfs_ticket_take(&slot));
+  const bool one_launch = A->format == 0 && bfs_use_persistent() && g_persistent_failures < 3 && !bfs_queue_wanted(A, desc);
+  if (one_launch) {
+    hipStream_t s = ctx().stream;
+    GRB_TRY(ensure_empty_rows(&A->d_no_in_edges, A->csc, s));
+    GRB_TRY(ensure_pull_hint(&A->d_pull_hint, A->csc, A->csr.ptr, s));
+    GRB_TRY(grb_vector_set_storage(v, GRB_DENSE));
+    const grb_info li = bfs_persistent_enqueue(v, A, source, desc, slot, &seq);
+    if (li == GRB_SUCCESS) {
+      *ticket = ((grb_bfs_ticket)(unsigned int)seq << 8) | (grb_bfs_ticket)slot;
+      return GRB_SUCCESS;
+    }
+    if (li != GRB_NOT_IMPLEMENTED && li != GRB_PANIC) return li;
+  }
+  // a traversal the ring does not serve (road-network queues, CSR-only format, the host-driven fallback): run it now
+  // and park the result; the ticket behaves the same
+  grb_bfs_result res = {};
+  GRB_TRY(grb_bfs_fused(v, A, source, desc, &res, nullptr, 0, 0));
+  seq = ++ctx().mail_seq;
+  bfs_ticket_store(slot, seq, res);
+  *ticket = ((grb_bfs_ticket)(unsigned int)seq << 8) | (grb_bfs_ticket)slot;
+  return GRB_SUCCESS;
+}
+
+extern "C" grb_info grb_bfs_wait(grb_bfs_ticket ticket, grb_bfs_result* result) { GRB_API_ENTER();
+  const int slot = (int)(ticket & 0xff), seq = (int)(ticket >> 8);
+  grb_vector v = nullptr; grb_matrix A = nullptr; grb_descriptor desc = nullptr; grb_index source = 0;
+  grb_bfs_result parked = {};
+  const int state = bfs_ticket_state(slot, seq, &v, &A, &desc, &source, &parked);
+  if (state == 0) return GRB_INVALID_VALUE;                 // never issued, or waited for already
+  if (state == 2) {
+    if (result) *result = parked;
+    bfs_ticket_release(slot);
+    return GRB_SUCCESS;
+  }
+  int p_levels = 0, p_dir = 0;
+  long long p_reached = 0;
+  unsigned long long p_edges = 0;
+  Index p_nf = 0;
+  bool p_cap = false;
+  float p_ms = 0.f;
+  const grb_info pi = bfs_persistent_wait(slot, seq, &p_levels, &p_dir, &p_reached, &p_edges, &p_nf, &p_cap, &p_ms);
+  bfs_ticket_release(slot);
+  if (pi == GRB_PANIC) {
+    // the launch did not run to its end (its grid barrier gave up), or it was queued behind one that did not: the same
+    // traversal now, through grb_bfs_fused (which falls back to the host-driven level loop by itself)
+    ++g_persistent_failures;
+    GRB_HIP_TRY(hipStreamSynchronize(ctx().stream));
+    return grb_bfs_fused(v, A, source, desc, result, nullptr, 0, 0);
+  }
+  GRB_TRY(pi);
+  g_persistent_failures = 0;
+  return bfs_one_launch_finish(v, A, desc, p_levels, p_dir, p_reached, p_edges, p_nf, p_cap, p_ms, result);
+}
+
+// Host time spent inside the one-launch traversal's two halves since the last reset: queueing the launches
+// (argument block, two kernel launches) and waiting for / unpacking the record.  calls = traversals.
+extern "C" grb_info grb_bfs_host_times(double* enqueue_us, double* wait_us, long long* calls, int reset) { GRB_API_ENTER_HOST();
+  bfs_host_times(enqueue_us, wait_us, calls, reset != 0);
+  return GRB_SUCCESS;
+}
+
 extern "C" grb_info grb_bfs_fused(grb_vector v, grb_matrix A, grb_index source, grb_descriptor desc,
                                   grb_bfs_result* result, grb_bfs_level* levels_out, int max_levels, int profile) { GRB_API_ENTER();
   if (!v || !A || !desc) return GRB_UNINITIALIZED_OBJECT;
@@ -109,10 +219,8 @@ extern "C" grb_info grb_bfs_fused(grb_vector v, grb_matrix A, grb_index source, 
   GRB_TRY(ensure_empty_rows(&A->d_no_in_edges, A->csc, s));
   GRB_TRY(ensure_pull_hint(&A->d_pull_hint, A->csc, A->csr.ptr, s));
 
-  static const bool use_persistent = [] { const char* e = getenv("GRB_BFS_PERSISTENT"); return !e || atoi(e) != 0; }();
-  // three barrier give-ups in a row (each costs seconds of bounded spinning): the device is evidently shared;
-  // stop trying for the rest of the process
-  static int persistent_failures = 0;
+  const bool use_persistent = bfs_use_persistent();
+  int& persistent_failures = g_persistent_failures;
   if (use_persistent && persistent_failures < 3) {
     GRB_TRY(grb_vector_set_storage(v, GRB_DENSE));
     int p_levels = 0, p_dir = 0;
@@ -141,23 +249,7 @@ extern "C" grb_info grb_bfs_fused(grb_vector v, grb_matrix A, grb_index source, 
       goto host_loop;
     }
     GRB_TRY(pi);
-    desc->lastmxv = p_dir ? GRB_PULLONLY : GRB_PUSHONLY;
-    if (p_cap && p_nf > 0) {
-      hipLaunchKernelGGL(bfs_unlabel_kernel, dim3(stream_grid(n)), dim3(kBlock), 0, s, (float*)v->d_val, n,
-                         (float)(desc->max_niter + 1));
-      GRB_HIP_TRY(hipGetLastError());
-      int64_t e2 = 0; int32_t r2 = 0;
-      GRB_TRY(bfs_tally_labels((const float*)v->d_val, A->csr.ptr, n, &e2, &r2));
-      p_edges = (unsigned long long)e2; p_reached = r2;
-    }
-    if (result) {
-      result->levels = p_levels;
-      result->tight_ms = p_ms;
-      result->edges_traversed = (int64_t)p_edges;
-      result->reached = (int32_t)p_reached;
-    }
-    v->d_nnz = (Index)p_reached;
-    return GRB_SUCCESS;
+    return bfs_one_launch_finish(v, A, desc, p_levels, p_dir, p_reached, p_edges, p_nf, p_cap, p_ms, result);
   }
 
 host_loop:

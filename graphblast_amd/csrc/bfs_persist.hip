@@ -45,6 +45,31 @@ namespace grb {
 #ifndef GRB_BFS_SPARSE_FRESH
 #define GRB_BFS_SPARSE_FRESH 1
 #endif
+// the level totals ARE the level's barrier (see "level totals" in the kernel); 0: totals, then the counter barrier
+#ifndef GRB_BFS_TOTALS_BARRIER
+#define GRB_BFS_TOTALS_BARRIER 0
+#endif
+// the other barriers of the launch (big-vertex listing, pull-only start): 1 = grid_sync_flat, 0 = the hierarchical one
+#ifndef GRB_BFS_FLAT_BARRIER
+#define GRB_BFS_FLAT_BARRIER 0
+#endif
+// the big-vertex list: one global reservation per WORKGROUP and pass (waves reserve inside it through LDS) instead of one
+// per wave -- a heavy level's 3 000 appends to one address cost 15 us at the listing barrier
+#ifndef GRB_BFS_LIST_WG
+#define GRB_BFS_LIST_WG 1
+#endif
+// the depth vector written with write-through (sc1) stores: nothing dirty is left for the end-of-kernel write-back
+#ifndef GRB_BFS_LABEL_WT
+#define GRB_BFS_LABEL_WT 0
+#endif
+#if GRB_BFS_FLAT_BARRIER
+#define GRB_BFS_GRID_SYNC(bar, gen) grid_sync_flat(bar, gen)
+#else
+#define GRB_BFS_GRID_SYNC(bar, gen) grid_sync(bar, gen, false)
+#endif
+#if GRB_BFS_TOTALS_BARRIER
+constexpr int kTotShift = 40;     // level totals: a value lives in the low 40 bits of its word, the arrival count above
+#endif
 constexpr int kSmallDeg = 16;     // below: expanded inline by the discovering lane
 constexpr int kBigDeg = 512;      // from here: split into kBigChunk-edge entries for workgroups
 constexpr int kBigChunk = 1024;
@@ -102,6 +127,14 @@ struct PersistArgs {
   int seq;
   float ticks_to_ms;
   unsigned long long* trace;        // optional (GRB_BFS_TRACE): wall-clock stamps of workgroup 0
+  // Two state blocks [state | V0 | F0 .. F(kKeep + 2)] alternate between consecutive traversals: a launch runs on the
+  // clean one and clears what its predecessor dirtied in the other (the predecessor's level count is in *dev_levels),
+  // so consecutive launches need neither a memset nor a clean-up launch between them -- grb_bfs_fused_enqueue queues
+  // traversals back to back.  The stores are spread over the whole grid in front of the first level, which is
+  // latency-bound.
+  unsigned int* dev_levels;         // in: the previous traversal's level count; out (last instruction): this one's
+  uint4* clean;                     // the other block
+  unsigned long long st_bytes;      // size of the state part of a block
 };
 
 
@@ -133,6 +166,11 @@ __device__ inline void push_visit(const PersistArgs& a, unsigned int* V, unsigne
 __global__ __launch_bounds__(kPThreads) void bfs_persistent_kernel(PersistArgs a) {
   __shared__ unsigned long long s_red[kPWaves][4];
   __shared__ unsigned long long s_tot[4];
+#if GRB_BFS_TOTALS_BARRIER
+  __shared__ int s_lvl_ok;
+#endif
+  __shared__ int s_lcnt[2];                                        // big-vertex listing: this workgroup's entries of a pass
+  __shared__ unsigned s_lbase;                                     // ... and where its block starts in the global list
   __shared__ Index s_med[kMedCap];
   __shared__ int s_nmed;
   __shared__ PullLds s_pull[kPWaves];                              // one per wave: the pull levels' row queue
@@ -164,6 +202,16 @@ __global__ __launch_bounds__(kPThreads) void bfs_persistent_kernel(PersistArgs a
   int ntrace = 0;
   auto stamp = [&]() { if (a.trace && gtid == 0 && ntrace < 255) a.trace[1 + ntrace++] = wall_clock64() - t_start; };
 
+  // ---- the other state block: what the previous traversal dirtied there (its state, V0, the level bitmaps it wrote;
+  // every buffer when it went past the kept levels)
+  {
+    const unsigned int lv = *a.dev_levels;
+    const unsigned int used = lv + 2u >= (unsigned int)kKeep ? (unsigned int)kKeep + 3u : lv + 2u;
+    const long long n16 = (long long)((a.st_bytes + 4ull * (1ull + used) * (unsigned long long)nwords + 15ull) / 16ull);
+    const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+    for (long long i = gtid; i < n16; i += gthreads) a.clean[i] = z;
+  }
+
   // ---- the source.  The bitmaps arrive zeroed; unreached labels are written at the very end,
   // so the first level starts without a barrier (unless it is a pull, which must see the bit).
   const Index src_deg = a.optr[a.source + 1] - a.optr[a.source];
@@ -171,7 +219,7 @@ __global__ __launch_bounds__(kPThreads) void bfs_persistent_kernel(PersistArgs a
     atomicOr(&a.V[0][a.source >> 5], 1u << (a.source & 31));
     atomicOr(&a.F[0][a.source >> 5], 1u << (a.source & 31));
   }
-  if (a.mode == GRB_PULLONLY && !grid_sync(&st->bar, gen, false)) return;
+  if (a.mode == GRB_PULLONLY && !GRB_BFS_GRID_SYNC(&st->bar, gen)) return;
 
   // ---- level loop (all scalars below are identical in every workgroup)
   Index nf = 1;
@@ -235,7 +283,7 @@ __global__ __launch_bounds__(kPThreads) void bfs_persistent_kernel(PersistArgs a
         // A heavy level lists first and expands its small rows after the owners' phase (their racing atomics would
         // otherwise sit in front of the barrier every workgroup waits at); any other level does both in one scan.
         auto scan = [&](const bool do_list, const bool do_expand) {
-        if (tid == 0) s_nmed = 0;
+        if (tid == 0) { s_nmed = 0; s_lcnt[0] = 0; s_lcnt[1] = 0; }
         __syncthreads();
         for (long long base = 0; base < nwords; base += gthreads) {
           const long long i = (base / G + tid) * G + blockIdx.x;      // word index, stride G inside the WG
@@ -261,11 +309,30 @@ __global__ __launch_bounds__(kPThreads) void bfs_persistent_kernel(PersistArgs a
               if (lane >= o) incl += y;
             }
             const int total = __shfl(incl, kWave - 1, kWave);
+#if GRB_BFS_LIST_WG
+            // the waves reserve inside the workgroup's block (LDS), thread 0 reserves the block (one global atomic)
+            unsigned b0 = 0;
+            {
+              int* lcnt = &s_lcnt[(int)((base / gthreads) & 1)];
+              if (lane == 0 && total > 0) b0 = (unsigned)atomicAdd(lcnt, total);
+              __syncthreads();
+              if (tid == 0) {
+                const int wg_total = *lcnt;
+                s_lbase = wg_total > 0 ? atomicAdd(bcount, (unsigned)wg_total) : 0u;
+                s_lcnt[(int)((base / gthreads) & 1) ^ 1] = 0;   // the next pass's counter (nobody is on it now)
+              }
+              __syncthreads();
+              b0 = __shfl(b0, 0, kWave) + s_lbase;
+            }
+            if (total > 0) {
+              int at = (int)b0 + incl - mine;
+#else
             if (total > 0) {
               unsigned b0 = 0;
               if (lane == 0) b0 = atomicAdd(bcount, (unsigned)total);
               b0 = __shfl(b0, 0, kWave);
               int at = (int)b0 + incl - mine;
+#endif
               for (unsigned int t = w; t; t &= t - 1) {
                 const Index v = (Index)i * 32 + (__ffs((int)t) - 1);
                 const Index d = a.optr[v + 1] - a.optr[v];
@@ -292,7 +359,7 @@ __global__ __launch_bounds__(kPThreads) void bfs_persistent_kernel(PersistArgs a
         if (heavy) scan(true, false); else scan(nbig > 0, true);
         if (nbig > 0) {
           stamp();
-          if (!grid_sync(&st->bar, gen, false)) return;
+          if (!GRB_BFS_GRID_SYNC(&st->bar, gen)) return;
           stamp();
           int nent = (int)__hip_atomic_load(bcount, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           if (nent > a.big_cap) nent = a.big_cap;
@@ -424,7 +491,8 @@ __global__ __launch_bounds__(kPThreads) void bfs_persistent_kernel(PersistArgs a
             const Index hv = hint ? hint[v] : 0;
             const Index p = a.iptr[v], e = a.iptr[v + 1];
             bool found = false;
-            if (hint) found = on && ((probe_word<kF>(vin, hv >> 5) >> (hv & 31)) & 1u);
+            // off lanes carry v = 0, and hint[0] is -1 when vertex 0 has no in-edges: probe word 0 then, never word -1
+            if (hint) found = on && ((probe_word<kF>(vin, on ? (hv >> 5) : 0) >> (hv & 31)) & 1u);   // (an active vertex has in-edges: hv >= 0)
             const bool und = on && !found && p < e;
             const unsigned long long um = __ballot(und);
             if (um) {
@@ -584,14 +652,60 @@ __global__ __launch_bounds__(kPThreads) void bfs_persistent_kernel(PersistArgs a
     unsigned long long r0 = wave_reduce(c.found, add), r1 = wave_reduce(c.deg, add);
     unsigned long long r2 = wave_reduce(c.inspected, add), r3 = wave_reduce(c.big, add);
     if (lane == 0) { s_red[wave][0] = r0; s_red[wave][1] = r1; s_red[wave][2] = r2; s_red[wave][3] = r3; }
+#if GRB_BFS_TOTALS_BARRIER
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's write-through stores of the level have landed
+#endif
     __syncthreads();
     unsigned long long* acc = &st->acc[iter % 3][0][0];
+#if GRB_BFS_TOTALS_BARRIER
+    // The totals are the barrier.  Every workgroup adds its four values to its XCD group's line, each with a 1 above
+    // bit kTotShift: a word whose upper part equals the group's size holds every member's contribution, whatever the
+    // order in which the words of a line are served.  So nobody arrives anywhere: wave 0 polls the 8 x 4 words (one
+    // per lane) until every word is complete, and has the totals in hand when it is.  Against totals -> counter
+    // barrier -> read-back this takes the arrival's round trip, the top counter's and the read-back's out of every
+    // level.  (The write-through stores of the level have landed before the adds go out: vmcnt(0) above, then the
+    // workgroup barrier.  A value stays below 2^40: a level's out-degree sum is at most nnz.)
+    if (wave == 0) {
+      const unsigned groups = G < 8 ? (unsigned)G : 8u;
+      if (lane < 4 && (lane != 2 || a.count_inspected)) {
+        unsigned long long t = 1ull << kTotShift;
+        for (int w = 0; w < kPWaves; ++w) t += s_red[w][lane];
+        (void)__hip_atomic_fetch_add(&acc[(blockIdx.x & 7) * 16 + lane], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      const unsigned grp = (unsigned)lane >> 2;
+      const bool watch = lane < 32 && grp < groups && ((lane & 3) != 2 || a.count_inspected);
+      const unsigned long long want = watch ? (unsigned long long)(((unsigned)G - grp + 7u) / 8u) : 0ull;
+      unsigned long long q = 0;
+      unsigned spins = 0;
+      int ok = 1;
+      for (;;) {
+        if (watch) q = __hip_atomic_load(&acc[grp * 16 + (lane & 3)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (__all(!watch || (q >> kTotShift) == want)) break;
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > kSpinLimit ||
+            ((spins & 255u) == 0u && __hip_atomic_load(&st->bar.abort_flag[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+          if (lane == 0) __hip_atomic_store(&st->bar.abort_flag[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          ok = 0;
+          break;
+        }
+      }
+      q = watch ? (q & ((1ull << kTotShift) - 1ull)) : 0ull;
+      q += __shfl_xor(q, 4, kWave);
+      q += __shfl_xor(q, 8, kWave);
+      q += __shfl_xor(q, 16, kWave);
+      if (lane < 4) s_tot[lane] = q;
+      if (lane == 0) s_lvl_ok = ok;
+    }
+    __syncthreads();
+    if (!s_lvl_ok) return;
+    stamp();
+#else
     if (tid < 4) {
       unsigned long long t = 0;
       for (int w = 0; w < kPWaves; ++w) t += s_red[w][tid];
       if (t) __hip_atomic_fetch_add(&acc[(blockIdx.x & 7) * 16 + tid], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (!grid_sync(&st->bar, gen, false)) return;
+    if (!GRB_BFS_GRID_SYNC(&st->bar, gen)) return;
     stamp();
     if (wave == 0) {
       unsigned long long q = 0;
@@ -602,6 +716,7 @@ __global__ __launch_bounds__(kPThreads) void bfs_persistent_kernel(PersistArgs a
       if (lane < 4) s_tot[lane] = q;
     }
     __syncthreads();
+#endif
     const unsigned long long tot_found = s_tot[0], tot_deg = s_tot[1], tot_insp = s_tot[2], tot_big = s_tot[3];
     stamp();
     if (gtid == 0 && levels < a.rec_cap) {
@@ -671,7 +786,11 @@ __global__ __launch_bounds__(kPThreads) void bfs_persistent_kernel(PersistArgs a
             for (int k = 0; k < 6; ++k) lab |= ((pl[k] >> b) & 1u) << k;
             x[t] = (float)lab;
           }
+#if GRB_BFS_LABEL_WT
+          asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(out + q), "v"(make_float4(x[0], x[1], x[2], x[3])) : "memory");
+#else
           out[q] = make_float4(x[0], x[1], x[2], x[3]);
+#endif
         }
       } else {
         for (int b = 0; b < 32 && v0 + b < (long long)n; ++b) {
@@ -686,6 +805,7 @@ __global__ __launch_bounds__(kPThreads) void bfs_persistent_kernel(PersistArgs a
   stamp();
   if (a.trace && gtid == 0) a.trace[0] = (unsigned long long)ntrace;
   if (gtid == 0) {
+    publish(a.dev_levels, (unsigned int)levels);
     const unsigned long long tag = (unsigned long long)(unsigned int)a.seq << 32;
     const float ms = (float)(wall_clock64() - t_start) * a.ticks_to_ms;
     const unsigned int vals[8] = {(unsigned int)levels, (unsigned int)last_dir, (unsigned int)reached,
@@ -802,11 +922,76 @@ grb_info grb::oc_tables_build(const Index* d_ptr, const Index* d_ind, const std:
   return GRB_SUCCESS;
 }
 
-// Runs the persistent traversal.  Outputs mirror what the fused loop keeps on the host.
-grb_info bfs_persistent_run(grb_vector v, grb_matrix A, grb_index source, grb_descriptor desc, int profile,
-                            grb_bfs_level* levels_out, int max_levels, int* levels, int* last_dir,
-                            long long* reached, unsigned long long* edges, Index* nf_left, bool* hit_cap,
-                            float* tight_ms) {
+// ---- host side ---------------------------------------------------------------------------------------------------
+// A traversal is one launch queued on the library's stream and one 8-granule record in pinned host memory that the
+// kernel's last instruction writes.  Launching and
+// reading the record are separate steps (bfs_persistent_launch / bfs_persistent_collect): grb_bfs_fused does one after
+// the other, grb_bfs_fused_enqueue / grb_bfs_wait let the caller queue K traversals and wait once.
+namespace {
+constexpr int kRing = 256;                       // records (= traversals in flight) at most
+struct BfsTicket {
+  int state = 0;                                 // 0 free, 1 in flight, 2 already complete (ran synchronously)
+  int seq = 0;
+  grb_vector v = nullptr;
+  grb_matrix A = nullptr;
+  grb_descriptor desc = nullptr;
+  grb_index source = 0;
+  grb_bfs_result res = {};
+};
+struct BfsRing {
+  unsigned long long* h = nullptr;               // pinned, host-coherent: kRing x 8 granules {value, seq}
+  unsigned long long* d = nullptr;               // the device-side address of h
+  unsigned int* d_levels = nullptr;              // device word: the last traversal's level count (PersistArgs::dev_levels)
+  int block = 0;                                 // which of the two state blocks the next traversal runs on
+  BfsTicket t[kRing];
+  int next = 0;
+  int poisoned_upto = 0;                         // records with seq <= this were queued behind a traversal that failed
+  double enqueue_us = 0, wait_us = 0;
+  long long calls = 0;
+};
+BfsRing g_ring;
+grb_info ring_init() {
+  BfsRing& r = g_ring;
+  if (r.h) return GRB_SUCCESS;
+  GRB_TRY(ctx_init());
+  GRB_HIP_TRY(hipHostMalloc((void**)&r.h, sizeof(unsigned long long) * 8 * kRing, hipHostMallocMapped | hipHostMallocCoherent));
+  memset(r.h, 0, sizeof(unsigned long long) * 8 * kRing);
+  GRB_HIP_TRY(hipHostGetDevicePointer((void**)&r.d, r.h, 0));
+  GRB_HIP_TRY(hipMalloc((void**)&r.d_levels, 256));
+  GRB_HIP_TRY(hipMemset(r.d_levels, 0, 256));
+  return GRB_SUCCESS;
+}
+// the record in slot `slot` once it carries tag `seq`: spins, then (after 5 ms) waits for the stream and looks again
+grb_info ring_wait(int slot, int seq, unsigned int* out) {
+  const unsigned long long* hg = g_ring.h + 8 * (size_t)slot;
+  const auto t0 = std::chrono::steady_clock::now();
+  unsigned spins = 0;
+  bool synced = false;
+  for (;;) {
+    bool ok = true;
+    for (int k = 0; k < 8; ++k) {
+      const unsigned long long g = __atomic_load_n(&hg[k], __ATOMIC_ACQUIRE);
+      if ((int)(g >> 32) != seq) { ok = false; break; }
+      out[k] = (unsigned int)(g & 0xffffffffull);
+    }
+    if (ok) return GRB_SUCCESS;
+    if (synced) {
+      fprintf(stderr, "libgrb_hip: traversal record not published after stream sync\n");
+      return GRB_PANIC;
+    }
+    if ((++spins & 1023u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(5)) {
+      GRB_HIP_TRY(hipStreamSynchronize(ctx().stream));
+      synced = true;
+    }
+  }
+}
+}  // namespace
+
+// Queues one traversal on the library's stream; its record will appear in ring slot `slot` under
+// tag *seq_out.
+static grb_info bfs_persistent_launch(grb_vector v, grb_matrix A, grb_index source, grb_descriptor desc, int profile, int slot,
+                                      int* seq_out, void** p_rec_out, unsigned long long** trace_out) {
+  GRB_TRY(ring_init());
   Context& c = ctx();
   hipStream_t s = c.stream;
   const Index n = A->nrows;
@@ -823,16 +1008,25 @@ grb_info bfs_persistent_run(grb_vector v, grb_matrix A, grb_index source, grb_de
   const int rec_cap = 1 << 15;
   const int big_cap = (int)(A->nvals / kBigDeg) + 2;
 
-  // one allocation, one memset: [state | V0 | F0 .. F(kKeep + 2)]
+  // one allocation: two blocks [state | V0 | F0 .. F(kKeep + 2)], used in turn (PersistArgs::clean)
   const size_t st_bytes = (sizeof(PersistState) + 255) & ~(size_t)255;
-  const size_t zero_bytes = st_bytes + 4 * (size_t)(1 + kKeep + 3) * (size_t)nwords;
+  const size_t block_bytes = (st_bytes + 4 * (size_t)(1 + kKeep + 3) * (size_t)nwords + 255) & ~(size_t)255;
+  const size_t zero_bytes = 2 * block_bytes;
   void *p_zero, *p_v1, *p_big, *p_rec;
   GRB_TRY(scratch(7, zero_bytes, &p_zero));
   GRB_TRY(scratch(8, 4 * (size_t)nwords, &p_v1));
   GRB_TRY(scratch(2, sizeof(int2) * (size_t)big_cap, &p_big));
   GRB_TRY(scratch(11, sizeof(grb_bfs_level) * (size_t)rec_cap, &p_rec));
-  void* p_st = p_zero;
-  unsigned int* p_v0 = (unsigned int*)((char*)p_zero + st_bytes);
+  // both blocks are clear (and the level-count word says "nothing to clear") when somebody else has had the slot
+  if (c.bfs_prezero_ptr != p_zero || c.bfs_prezero_bytes != zero_bytes) {
+    GRB_HIP_TRY(hipMemsetAsync(p_zero, 0, zero_bytes, s));
+    GRB_HIP_TRY(hipMemsetAsync(g_ring.d_levels, 0, 4, s));
+    g_ring.block = 0;
+  }
+  c.bfs_prezero_ptr = nullptr;
+  char* p_block = (char*)p_zero + (size_t)g_ring.block * block_bytes;
+  void* p_st = p_block;
+  unsigned int* p_v0 = (unsigned int*)(p_block + st_bytes);
 
   static float ticks_to_ms = 0.f;
   if (ticks_to_ms == 0.f) {
@@ -901,26 +1095,25 @@ grb_info bfs_persistent_run(grb_vector v, grb_matrix A, grb_index source, grb_de
   a.st = (PersistState*)p_st;
   a.rec = (grb_bfs_level*)p_rec;
   a.rec_cap = rec_cap;
-  a.mail = c.d_hgran;
+  a.mail = g_ring.d + 8 * (size_t)slot;
   a.seq = ++c.mail_seq;
+  a.dev_levels = g_ring.d_levels;
+  a.clean = (uint4*)((char*)p_zero + (size_t)(g_ring.block ^ 1) * block_bytes);
+  a.st_bytes = (unsigned long long)st_bytes;
   a.ticks_to_ms = ticks_to_ms;
+  *seq_out = a.seq;
+  *p_rec_out = p_rec;
+  *trace_out = nullptr;
   static const bool want_trace = getenv("GRB_BFS_TRACE") != nullptr;
   a.trace = nullptr;
   if (want_trace) {
     void* p_tr;
     GRB_TRY(scratch(10, 256 * sizeof(unsigned long long), &p_tr));
     a.trace = (unsigned long long*)p_tr;
+    *trace_out = a.trace;
   }
 
-  static const bool host_timing = getenv("GRB_BFS_HOSTTIME") != nullptr;
-  static double acc_launch = 0, acc_wait = 0;
-  static int acc_n = 0;
-  const auto th0 = std::chrono::steady_clock::now();
-  // the block is normally already clear: the previous traversal queued the memset behind its own
-  // kernel, off the critical path of this call
-  if (c.bfs_prezero_ptr != p_zero || c.bfs_prezero_bytes != zero_bytes)
-    GRB_HIP_TRY(hipMemsetAsync(p_zero, 0, zero_bytes, s));
-  c.bfs_prezero_ptr = nullptr;
+
   if (profile & 1) GRB_HIP_TRY(hipEventRecord(c.ev0, s));
   // The grid barrier needs every workgroup resident at once.  GRB_BFS_COOPERATIVE=1 asks the runtime to
   // guarantee that (hipLaunchCooperativeKernel fails fast when it cannot); the default launch relies on the
@@ -941,22 +1134,32 @@ grb_info bfs_persistent_run(grb_vector v, grb_matrix A, grb_index source, grb_de
     GRB_HIP_TRY(hipGetLastError());
   }
   if (profile & 1) GRB_HIP_TRY(hipEventRecord(c.ev1, s));
-  const auto th1 = std::chrono::steady_clock::now();
+  // the next traversal runs on the other block and clears this one
+  g_ring.block ^= 1;
+  c.bfs_prezero_ptr = p_zero;
+  c.bfs_prezero_bytes = zero_bytes;
+  return GRB_SUCCESS;
+}
+
+// Waits for the record of a queued traversal and unpacks it.
+static grb_info bfs_persistent_collect(int slot, int seq, int profile, void* p_rec, unsigned long long* trace,
+                                       grb_bfs_level* levels_out, int max_levels, int* levels, int* last_dir,
+                                       long long* reached, unsigned long long* edges, Index* nf_left, bool* hit_cap,
+                                       float* tight_ms) {
+  Context& c = ctx();
+  hipStream_t s = c.stream;
+  const int rec_cap = 1 << 15;
   unsigned int gv[8];
-  GRB_TRY(wait_granules(a.seq, 8, gv));
+  if (seq <= g_ring.poisoned_upto) return GRB_PANIC;            // queued behind a traversal that did not finish
   {
-    // for the next traversal: clear what this one dirtied -- the state, V0 and the level bitmaps it wrote
-    // (every buffer when it went past the kept levels), queued now, off the critical path of this call
-    const int used = (int)gv[0] + 2 >= kKeep ? kKeep + 3 : (int)gv[0] + 2;
-    GRB_HIP_TRY(hipMemsetAsync(p_zero, 0, st_bytes + 4 * (size_t)(1 + used) * (size_t)nwords, s));
-    c.bfs_prezero_ptr = p_zero;
-    c.bfs_prezero_bytes = zero_bytes;
-  }
-  if (host_timing) {
-    const auto th2 = std::chrono::steady_clock::now();
-    acc_launch += std::chrono::duration<double, std::micro>(th1 - th0).count();
-    acc_wait += std::chrono::duration<double, std::micro>(th2 - th1).count();
-    if (++acc_n % 32 == 0) { fprintf(stderr, "bfs host: enqueue %.1f us, wait %.1f us (mean of 32)\n", acc_launch / 32, acc_wait / 32); acc_launch = acc_wait = 0; }
+    const grb_info wi = ring_wait(slot, seq, gv);
+    if (wi != GRB_SUCCESS) {
+      // the kernel left early (its barrier gave up) without leaving its level count: the next launch cleared too little
+      // of this block, and every traversal queued since ran on whatever that left
+      c.bfs_prezero_ptr = nullptr;
+      g_ring.poisoned_upto = c.mail_seq;
+      return wi;
+    }
   }
   *levels = (int)gv[0];
   *last_dir = (int)gv[1];
@@ -971,12 +1174,16 @@ grb_info bfs_persistent_run(grb_vector v, grb_matrix A, grb_index source, grb_de
     GRB_HIP_TRY(hipEventElapsedTime(&ms, c.ev0, c.ev1));
   }
   *tight_ms = ms;
-  if (a.trace) {
+  if (trace) {
     unsigned long long h[256];
-    GRB_HIP_TRY(hipMemcpyAsync(h, a.trace, sizeof(h), hipMemcpyDeviceToHost, s));
+    int khz = 0, dev = 0;
+    GRB_HIP_TRY(hipGetDevice(&dev));
+    GRB_HIP_TRY(hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev));
+    const double tick_us = khz > 0 ? 1e3 / (double)khz : 1e-2;
+    GRB_HIP_TRY(hipMemcpyAsync(h, trace, sizeof(h), hipMemcpyDeviceToHost, s));
     GRB_HIP_TRY(hipStreamSynchronize(s));
     fprintf(stderr, "bfs trace (us since kernel start; init, then per level: expanded / barrier / totals):");
-    for (unsigned long long i = 0; i < h[0] && i < 255; ++i) fprintf(stderr, " %.1f", (double)h[1 + i] * ticks_to_ms * 1e3);
+    for (unsigned long long i = 0; i < h[0] && i < 255; ++i) fprintf(stderr, " %.1f", (double)h[1 + i] * tick_us);
     fprintf(stderr, "\n");
   }
   if (levels_out && max_levels > 0) {
@@ -988,3 +1195,79 @@ grb_info bfs_persistent_run(grb_vector v, grb_matrix A, grb_index source, grb_de
   }
   return GRB_SUCCESS;
 }
+
+// ---- tickets: a traversal that has been queued and not yet waited for -----------------------------------------------
+// A free record of the ring (its previous traversal has been waited for); GRB_INSUFFICIENT_SPACE when kRing are in flight.
+grb_info grb::bfs_ticket_take(int* slot) {
+  GRB_TRY(ring_init());
+  for (int k = 0; k < kRing; ++k) {
+    const int i = (g_ring.next + k) % kRing;
+    if (g_ring.t[i].state == 0) { g_ring.next = (i + 1) % kRing; *slot = i; return GRB_SUCCESS; }
+  }
+  return GRB_INSUFFICIENT_SPACE;
+}
+grb_info grb::bfs_persistent_enqueue(grb_vector v, grb_matrix A, grb_index source, grb_descriptor desc, int slot, int* seq) {
+  void* p_rec = nullptr;
+  unsigned long long* trace = nullptr;
+  const auto t0 = std::chrono::steady_clock::now();
+  GRB_TRY(bfs_persistent_launch(v, A, source, desc, 0, slot, seq, &p_rec, &trace));
+  g_ring.enqueue_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+  ++g_ring.calls;
+  BfsTicket& t = g_ring.t[slot];
+  t.state = 1; t.seq = *seq; t.v = v; t.A = A; t.desc = desc; t.source = source;
+  return GRB_SUCCESS;
+}
+// A traversal that ran synchronously (a path the ring does not serve) parks its result in a ticket all the same.
+void grb::bfs_ticket_store(int slot, int seq, const grb_bfs_result& res) {
+  BfsTicket& t = g_ring.t[slot];
+  t.state = 2; t.seq = seq; t.res = res;
+}
+int grb::bfs_ticket_state(int slot, int seq, grb_vector* v, grb_matrix* A, grb_descriptor* desc, grb_index* source,
+                          grb_bfs_result* parked) {
+  if (slot < 0 || slot >= kRing || !g_ring.h) return 0;
+  const BfsTicket& t = g_ring.t[slot];
+  if (t.state == 0 || t.seq != seq) return 0;
+  if (v) *v = t.v;
+  if (A) *A = t.A;
+  if (desc) *desc = t.desc;
+  if (source) *source = t.source;
+  if (parked) *parked = t.res;
+  return t.state;
+}
+void grb::bfs_ticket_release(int slot) { g_ring.t[slot].state = 0; }
+grb_info grb::bfs_persistent_wait(int slot, int seq, int* levels, int* last_dir, long long* reached, unsigned long long* edges,
+                                  Index* nf_left, bool* hit_cap, float* tight_ms) {
+  const auto t0 = std::chrono::steady_clock::now();
+  const grb_info r = bfs_persistent_collect(slot, seq, 0, nullptr, nullptr, nullptr, 0, levels, last_dir, reached, edges, nf_left,
+                                            hit_cap, tight_ms);
+  g_ring.wait_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+  return r;
+}
+void grb::bfs_host_times(double* enqueue_us, double* wait_us, long long* calls, bool reset) {
+  if (enqueue_us) *enqueue_us = g_ring.enqueue_us;
+  if (wait_us) *wait_us = g_ring.wait_us;
+  if (calls) *calls = g_ring.calls;
+  if (reset) { g_ring.enqueue_us = g_ring.wait_us = 0; g_ring.calls = 0; }
+}
+
+// Runs the persistent traversal and waits for it.  Outputs mirror what the fused loop keeps on the host.
+grb_info bfs_persistent_run(grb_vector v, grb_matrix A, grb_index source, grb_descriptor desc, int profile,
+                            grb_bfs_level* levels_out, int max_levels, int* levels, int* last_dir,
+                            long long* reached, unsigned long long* edges, Index* nf_left, bool* hit_cap,
+                            float* tight_ms) {
+  int slot = 0, seq = 0;
+  GRB_TRY(bfs_ticket_take(&slot));
+  void* p_rec = nullptr;
+  unsigned long long* trace = nullptr;
+  const auto t0 = std::chrono::steady_clock::now();
+  GRB_TRY(bfs_persistent_launch(v, A, source, desc, profile, slot, &seq, &p_rec, &trace));
+  const auto t1 = std::chrono::steady_clock::now();
+  const grb_info r = bfs_persistent_collect(slot, seq, profile, p_rec, trace, levels_out, max_levels, levels, last_dir, reached,
+                                            edges, nf_left, hit_cap, tight_ms);
+  const auto t2 = std::chrono::steady_clock::now();
+  g_ring.enqueue_us += std::chrono::duration<double, std::micro>(t1 - t0).count();
+  g_ring.wait_us += std::chrono::duration<double, std::micro>(t2 - t1).count();
+  ++g_ring.calls;
+  return r;
+}
+

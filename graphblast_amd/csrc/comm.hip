@@ -201,7 +201,10 @@ static grb_info host_stage(size_t bytes) {
 grb_info grb_comm_set_host_transport(int rank, int world, grb_comm_host_fn fn, void* user) { GRB_API_ENTER();
   Comm& c = g_comm;
   if (c.comm) return GRB_OUTPUT_NOT_EMPTY;
-  if (!fn) {                                             // off
+  if (!fn) {                                             // off: the pinned staging block goes with it
+    if (c.h_stage) (void)hipHostFree(c.h_stage);
+    c.h_stage = nullptr;
+    c.h_cap = 0;
     c.host_fn = nullptr;
     c.host_user = nullptr;
     c.rank = 0;
@@ -315,8 +318,13 @@ grb_info grb_comm_allgatherv_inplace(void* d_buf, const long long* offsets, cons
     if (!offsets || !counts) return GRB_NULL_POINTER;
     hipStream_t s = grb::ctx().stream;
     long long extent = 0;
-    for (int r = 0; r < c.world; ++r)
-      if (counts[r] > 0 && offsets[r] + counts[r] > extent) extent = offsets[r] + counts[r];
+    for (int r = 0; r < c.world; ++r) {
+      if (counts[r] <= 0) continue;
+      if (offsets[r] < 0) return GRB_INVALID_VALUE;                    // a slice before the buffer
+      for (int q = 0; q < r; ++q)                                      // two ranks' slices must not overlap
+        if (counts[q] > 0 && offsets[r] < offsets[q] + counts[q] && offsets[q] < offsets[r] + counts[r]) return GRB_INVALID_VALUE;
+      if (offsets[r] + counts[r] > extent) extent = offsets[r] + counts[r];
+    }
     if (extent == 0) return GRB_SUCCESS;
     GRB_TRY(host_stage((size_t)extent));
     if (counts[c.rank] > 0)

@@ -492,6 +492,9 @@ struct grb_vector_s {
   void* d_val = nullptr;          // [nsize]
   grb::Index d_nnz = 0;
   bool d_owned = true;
+  // grb_vector_device_ptrs handed the raw storage out (torch / RCCL interop): from then on a caller may read or write it
+  // without an API call, so nothing that touches this vector is ever deferred (lazy.hip); sticky
+  bool exposed = false;
 };
 
 namespace grb {
@@ -528,6 +531,9 @@ grb_info k_apply_unary(int dtype, int unary, int op, double scalar, const void* 
 // GRB_API_ENTER flushes the queue (top-level calls only: depth 0 -> 1) before the function touches anything,
 // GRB_API_ENTER_QUEUE is for the functions that may append to it.
 enum { LZ_ADD_VV = 0, LZ_MULT_VV, LZ_ADD_VS, LZ_MULT_VS, LZ_DUP, LZ_ASSIGN /* u = the mask, sr = scmp, scalar = the value */ };
+// The ABI is serialised: every entry point holds one process-wide recursive lock for its duration (ctypes releases the
+// GIL, so two Python threads can be inside the library at once; the context's scratch slots, mailboxes and the queue
+// below are shared state).  depth counts the nesting of entry points on the thread that holds the lock.
 struct ApiScope {
   static int depth;
   bool entered_ = false;
@@ -673,6 +679,16 @@ grb_info oc_tables_build(const Index* d_ptr, const Index* d_ind, const std::vect
                          Index** d_bounds, Index** d_off, int** d_bigidx, int* nb, int* nbig);
 grb_info bfs_queue_run(grb_vector v, grb_matrix A, grb_index source, grb_descriptor desc, int* levels,
                        long long* reached, unsigned long long* edges, float* tight_ms);   // sssp_nearfar.hip
+bool bfs_queue_wanted(grb_matrix A, grb_descriptor desc);   // would bfs_queue_run take this traversal? (sssp_nearfar.hip)
+// bfs_persist.hip: traversals queued without waiting (grb_bfs_fused_enqueue / grb_bfs_wait, bfs_fused.hip)
+grb_info bfs_ticket_take(int* slot);
+grb_info bfs_persistent_enqueue(grb_vector v, grb_matrix A, grb_index source, grb_descriptor desc, int slot, int* seq);
+void bfs_ticket_store(int slot, int seq, const grb_bfs_result& res);
+int bfs_ticket_state(int slot, int seq, grb_vector* v, grb_matrix* A, grb_descriptor* desc, grb_index* source, grb_bfs_result* parked);
+void bfs_ticket_release(int slot);
+grb_info bfs_persistent_wait(int slot, int seq, int* levels, int* last_dir, long long* reached, unsigned long long* edges,
+                             Index* nf_left, bool* hit_cap, float* tight_ms);
+void bfs_host_times(double* enqueue_us, double* wait_us, long long* calls, bool reset);
 grb_info k_spmv_masked_or(int dtype, const CsrArrays& M, const void* u, double identity,
                           const void* mask, int mask_f32, int scmp, int earlyexit, int opreuse,
                           const Index* hint /* per-row best neighbour, may be null */, void* w);

@@ -17,6 +17,7 @@
 // may look at it, or rewrite an input, without asking the library --, registered semirings, calls made from inside a
 // driver (grb_pr, grb_cc, ...: depth > 1).  GRB_LAZY=0 / grb_set_lazy(0) switch the queue off.
 #include "common.hpp"
+#include <mutex>
 
 namespace grb {
 
@@ -37,6 +38,7 @@ struct LazyQueue {
 static LazyQueue g_lazy;
 static int g_lazy_on = -1;
 int ApiScope::depth = 0;
+static std::recursive_mutex g_api_lock;   // held by every entry point (ApiScope): depth and the queue are only touched under it
 
 bool lazy_enabled() {
   if (g_lazy_on < 0) { const char* e = getenv("GRB_LAZY"); g_lazy_on = (e && atoi(e) == 0) ? 0 : 1; }
@@ -180,12 +182,26 @@ static grb_info lazy_run_step(const LazyStep& st, int dtype, Index n) {
   }
 }
 
+static grb_info lazy_run_program(const LazyQueue& q);
+
 grb_info lazy_flush() {
   if (g_lazy.n == 0) return GRB_SUCCESS;
   LazyQueue q = g_lazy;             // the queue is empty while its steps run (they use internal kernels only)
   g_lazy.n = 0;
   if (q.nsize <= 0) return GRB_SUCCESS;
   if (q.n == 1) return lazy_run_step(q.s[0], q.dtype, q.nsize);
+  if (lazy_run_program(q) == GRB_SUCCESS) return GRB_SUCCESS;
+  // the fused program could not be built or launched: the calls were answered GRB_SUCCESS when they were queued, so
+  // their effect must still happen -- one step at a time through the kernels the eager path uses; only if THAT
+  // fails does the caller of the flushing entry point see an error
+  (void)hipGetLastError();
+  for (int s = 0; s < q.n; ++s) GRB_TRY(lazy_run_step(q.s[s], q.dtype, q.nsize));
+  return GRB_SUCCESS;
+}
+
+static grb_info lazy_run_program(const LazyQueue& q) {
+  // test hook: behave as if the fused program had been refused, so that lazy_flush's step-by-step fallback runs
+  if (const char* e = getenv("GRB_LAZY_FORCE_STEPWISE")) if (atoi(e) != 0) return GRB_PANIC;
   LzProg p;
   memset(&p, 0, sizeof(p));
   p.n = q.n;
@@ -254,9 +270,9 @@ bool lazy_try(int kind, int sr, grb_vector w, grb_vector u, grb_vector v, double
   const bool arithmetic = kind != LZ_DUP && kind != LZ_ASSIGN;
   bool ok = lazy_enabled() && ApiScope::depth == 1 && (!arithmetic || (sr >= 0 && sr < GRB_N_SEMIRINGS)) && w && u && (!two || v);
   if (ok) {
-    ok = u->vec_type == GRB_DENSE && u->d_owned && u->d_val && w->d_owned && w->d_val && w->vec_type == GRB_DENSE &&
-         u->dtype == w->dtype && u->nsize == w->nsize && u->nsize > 0;
-    if (ok && two) ok = v->vec_type == GRB_DENSE && v->d_owned && v->d_val && v->dtype == w->dtype && v->nsize == w->nsize;
+    ok = u->vec_type == GRB_DENSE && u->d_owned && !u->exposed && u->d_val && w->d_owned && !w->exposed && w->d_val &&
+         w->vec_type == GRB_DENSE && u->dtype == w->dtype && u->nsize == w->nsize && u->nsize > 0;
+    if (ok && two) ok = v->vec_type == GRB_DENSE && v->d_owned && !v->exposed && v->d_val && v->dtype == w->dtype && v->nsize == w->nsize;
   }
   if (ok && g_lazy.n > 0 && (g_lazy.dtype != w->dtype || g_lazy.nsize != w->nsize || g_lazy.n == kLazyMax)) {
     *flush_info = lazy_flush();
@@ -293,6 +309,7 @@ bool lazy_try(int kind, int sr, grb_vector w, grb_vector u, grb_vector v, double
 }
 
 grb_info ApiScope::enter(bool queue_aware) {
+  g_api_lock.lock();
   grb_info r = GRB_SUCCESS;
   if (depth == 0 && !queue_aware && g_lazy.n > 0) r = lazy_flush();
   ++depth;
@@ -300,7 +317,7 @@ grb_info ApiScope::enter(bool queue_aware) {
   return r;
 }
 ApiScope::~ApiScope() {
-  if (entered_) --depth;
+  if (entered_) { --depth; g_api_lock.unlock(); }
 }
 
 }  // namespace grb

@@ -788,6 +788,7 @@ grb_info grb_vector_convert(grb_vector v, double identity, float switchpoint, gr
 
 grb_info grb_vector_device_ptrs(grb_vector v, grb_index** d_sparse_ind, void** d_sparse_val, void** d_dense_val) { GRB_API_ENTER();
   if (!v) return GRB_UNINITIALIZED_OBJECT;
+  v->exposed = true;              // the caller may now look at the storage without telling the library: never deferred again
   if (d_sparse_ind) *d_sparse_ind = v->s_ind;
   if (d_sparse_val) *d_sparse_val = v->s_val;
   if (d_dense_val) *d_dense_val = v->d_val;

@@ -72,6 +72,43 @@ __device__ inline bool grid_sync(GridBarrier* st, unsigned& gen, bool invalidate
   return s_ok != 0;
 }
 
+// The same barrier without the second hop: the arrival is a NON-returning add on the workgroup's XCD counter (nothing
+// waits for its round trip), and wave 0 of every workgroup polls all eight counters at once, one per lane.  The
+// hierarchical form above costs the arrival's round trip, the last arriver's add on the top counter and the poll, one
+// after the other; this one costs the add's way to memory and the poll.  Eight lines are polled instead of one, by the
+// same 256 pollers each.  Same counters, same generations: the two forms can be mixed inside one launch.
+static __device__ __noinline__ bool grid_sync_flat(GridBarrier* st, unsigned& gen) {
+  __shared__ int s_ok_flat;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's write-through stores have landed
+  __syncthreads();
+  if (threadIdx.x < (unsigned)kWave) {
+    const unsigned g = gen + 1;
+    const unsigned G = gridDim.x;
+    const unsigned groups = G < 8u ? G : 8u;
+    const unsigned lane = threadIdx.x;
+    if (lane == 0) (void)__hip_atomic_fetch_add(&st->xcd_count[blockIdx.x & 7u][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const bool watch = lane < groups;
+    const unsigned want = watch ? ((G - lane + 7u) / 8u) * g : 0u;
+    unsigned spins = 0;
+    int ok = 1;
+    for (;;) {
+      const unsigned c = watch ? __hip_atomic_load(&st->xcd_count[lane][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+      if (__all(!watch || c >= want)) break;
+      __builtin_amdgcn_s_sleep(1);
+      if (++spins > kSpinLimit ||
+          ((spins & 255u) == 0u && __hip_atomic_load(&st->abort_flag[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+        if (lane == 0) __hip_atomic_store(&st->abort_flag[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ok = 0;
+        break;
+      }
+    }
+    if (lane == 0) s_ok_flat = ok;
+  }
+  __syncthreads();
+  ++gen;
+  return s_ok_flat != 0;
+}
+
 // The set bits of a wave's 64 bitmap words, one per lane per step.  A thread that walks its own word bit by bit
 // is fine while the frontier is a few scattered vertices; a road network's wave front fills whole words, and
 // then a handful of lanes each run 32 vertices' dependent memory chains one after the other while the rest of

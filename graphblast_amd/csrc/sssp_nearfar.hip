@@ -809,6 +809,15 @@ grb_info grb::sssp_nearfar_run(grb_vector v, grb_matrix A, grb_index source, grb
   return GRB_SUCCESS;
 }
 
+// a road network (few entries per row, many vertices) pushed level by level: the traversal bfs_queue_run serves
+bool grb::bfs_queue_wanted(grb_matrix A, grb_descriptor desc) {
+  static const int use = getenv("GRB_BFS_QUEUE") ? atoi(getenv("GRB_BFS_QUEUE")) : -1;   // -1 auto, 0 never, 1 whenever possible
+  if (use == 0 || g_barrier_failures >= 3) return false;
+  const Index n = A->nrows;
+  if (use < 0 && !(A->nvals < 8ll * (long long)n && n >= (1 << 16))) return false;
+  return desc->desc[GRB_MXVMODE] != GRB_PULLONLY;
+}
+
 // algorithm::bfs on a long-diameter, low-degree graph (a road network) through the same queues: with every weight 1
 // a pass IS a level, a vertex is queued exactly once, and a level of a few thousand vertices costs the 7.6 us of a
 // pass instead of the 26-31 us the bitmap kernel of bfs_persist.hip pays for walking and recycling 3 MB of bitmap
@@ -817,11 +826,8 @@ grb_info grb::sssp_nearfar_run(grb_vector v, grb_matrix A, grb_index source, grb
 // traversal would have been cut off by max_niter -- the caller runs the bitmap kernel.
 grb_info grb::bfs_queue_run(grb_vector v, grb_matrix A, grb_index source, grb_descriptor desc, int* levels,
                             long long* reached, unsigned long long* edges, float* tight_ms) {
-  static const int use = getenv("GRB_BFS_QUEUE") ? atoi(getenv("GRB_BFS_QUEUE")) : -1;   // -1 auto, 0 never, 1 whenever possible
-  if (use == 0 || g_barrier_failures >= 3) return GRB_NOT_IMPLEMENTED;
+  if (!bfs_queue_wanted(A, desc)) return GRB_NOT_IMPLEMENTED;
   const Index n = A->nrows;
-  if (use < 0 && !(A->nvals < 8ll * (long long)n && n >= (1 << 16))) return GRB_NOT_IMPLEMENTED;
-  if (desc->desc[GRB_MXVMODE] == GRB_PULLONLY) return GRB_NOT_IMPLEMENTED;
   Context& c = ctx();
   hipStream_t s = c.stream;
   static int max_per_cu = 0;

@@ -315,6 +315,23 @@ grb_info grb_bfs(grb_vector v, grb_matrix A, grb_index source, grb_descriptor de
 grb_info grb_bfs_fused(grb_vector v, grb_matrix A, grb_index source, grb_descriptor desc,
                        grb_bfs_result* result, grb_bfs_level* levels_out, int max_levels,
                        int profile);
+/* The same traversal, queued without waiting: the launch is put on the library's stream and the call returns; the
+ * result block is read by grb_bfs_wait.  K traversals into K vectors run back to back on the device with no host
+ * round trip between them (the reference's loop returns to the host several times per LEVEL, algorithm/bfs.hpp:42-88:
+ * `reduce` -> succ, `nvals`, the timing branches).  Traversals execute in the order they were queued; v, A and desc must
+ * stay alive and untouched by the caller until the ticket has been waited for (v's contents are undefined until then;
+ * any other entry point may be called meanwhile -- it is ordered behind the queued traversals on the stream).  At most
+ * 256 tickets may be outstanding (GRB_INSUFFICIENT_SPACE).  A traversal the one-launch kernel does not serve (road-network
+ * queues, GRB_SPARSE_MATRIX_FORMAT=1) runs to its end inside the enqueue call; its ticket waits like any other.
+ * grb_bfs_wait returns what grb_bfs_fused would have returned (a launch that could not finish is re-run through the
+ * host-driven level loop there); a ticket can be waited for once (GRB_INVALID_VALUE afterwards). */
+typedef int64_t grb_bfs_ticket;
+grb_info grb_bfs_fused_enqueue(grb_vector v, grb_matrix A, grb_index source, grb_descriptor desc,
+                               grb_bfs_ticket* ticket);
+grb_info grb_bfs_wait(grb_bfs_ticket ticket, grb_bfs_result* result);
+/* Host time (microseconds, summed since the last reset) inside the one-launch traversal's two halves -- queueing the
+ * launches / waiting for and unpacking the record -- and the number of traversals; any pointer may be NULL. */
+grb_info grb_bfs_host_times(double* enqueue_us, double* wait_us, long long* calls, int reset);
 
 /* ---- 1-D vertex-partitioned BFS level steps (one process per GPU).
  * The reference has no multi-GPU code (backend/cuda/descriptor.hpp:242,283-284 parse

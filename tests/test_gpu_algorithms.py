@@ -195,6 +195,106 @@ def test_bfs_max_niter_cap(hb, graphs):
             assert np.array_equal(got, np.where(full <= 5, full, 0)), (fused, mode)
 
 
+def test_bfs_queued_without_waiting(hb, graphs):
+    """grb_bfs_fused_enqueue / grb_bfs_wait: K traversals into K vectors queued back to back, waited for afterwards
+    (in any order), with unrelated calls in between -- labels and result blocks equal the blocking call's and the
+    oracle's; a ticket waits once; a graph the one-launch kernel does not serve (the road-like grid goes to the queue
+    kernel) behaves the same through a ticket."""
+    from oracle import simple_reference as sr
+    g = hb.g
+    for name, gr in graphs:
+        ptr, ind = gr["csr"]
+        A = build(hb, gr)
+        n = gr["n"]
+        srcs = [first_source(gr)] + g.graphgen.random_sources(ptr, 9, seed=3)
+        for mode, es, cap in ((0, 0.0, 0), (0, 0.05, 0), (2, 0.0, 0), (0, 0.0, 2)):
+            args = dict(mxvmode=mode, struconly=1, opreuse=1, edgeswitch=es)
+            if cap:
+                args["max_niter"] = cap                       # the search is cut: the wait runs the unlabel + tally pass
+            d = hb.descriptor(**args)
+            vs = [g.Vector(n) for _ in srcs]
+            tickets = []
+            for v, s_ in zip(vs, srcs):
+                info, t = g.bfs_enqueue(v, A, s_, d)
+                assert info == 0 and t != 0
+                tickets.append(t)
+            # the library stays usable while traversals are in flight (ordered behind them on the stream)
+            x = g.Vector(n)
+            assert x.fill(2.0) == 0
+            info, tot = g.reduce(None, "Plus", x, hb.descriptor())
+            assert info == 0 and tot == 2.0 * n
+            order = list(range(len(srcs)))[::-1] if mode == 2 else list(range(len(srcs)))
+            got = {}
+            for k in order:
+                info, res = g.bfs_wait(tickets[k])
+                assert info == 0
+                got[k] = res
+            assert g.bfs_wait(tickets[0])[0] == 3                 # GrB_INVALID_VALUE: a ticket is waited for once
+            for k, s_ in enumerate(srcs):
+                vb = g.Vector(n)
+                ib, rb = g.bfs(vb, A, s_, d, fused=True)
+                assert ib == 0
+                a, b = hb.dense_values(vs[k]), hb.dense_values(vb)
+                assert np.array_equal(a, b), (name, s_, mode, es, cap)
+                if not cap:
+                    assert np.array_equal(a, sr.bfs(ptr, ind, s_)[0]), (name, s_, mode, es)
+                for key in ("levels", "reached", "edges_traversed"):
+                    assert got[k][key] == rb[key], (name, s_, mode, es, cap, key)
+    assert g.bfs_wait(12345)[0] == 3                              # never issued
+    ht = g.bfs_host_times(reset=True)
+    assert ht["calls"] > 0 and ht["enqueue_us"] > 0
+    assert g.bfs_host_times()["calls"] == 0
+
+
+def test_bfs_more_tickets_than_the_ring_holds(hb, graphs):
+    """256 records: the 257th traversal queued without a wait is refused (GrB_INSUFFICIENT_SPACE), nothing is lost."""
+    g = hb.g
+    name, gr = graphs[3]
+    ptr, ind = gr["csr"]
+    A = build(hb, gr)
+    n = gr["n"]
+    d = hb.descriptor(mxvmode=0, struconly=1, opreuse=1)
+    vs = [g.Vector(n) for _ in range(4)]
+    srcs = g.graphgen.random_sources(ptr, 4, seed=9)
+    tickets = []
+    for i in range(256):
+        info, t = g.bfs_enqueue(vs[i % 4], A, srcs[i % 4], d)
+        assert info == 0
+        tickets.append(t)
+    assert g.bfs_enqueue(vs[0], A, srcs[0], d)[0] == 11           # GrB_INSUFFICIENT_SPACE
+    ref = {}
+    for i, t in enumerate(tickets):
+        info, res = g.bfs_wait(t)
+        assert info == 0
+        ref.setdefault(i % 4, res)
+        assert res["reached"] == ref[i % 4]["reached"] and res["levels"] == ref[i % 4]["levels"]
+    info, t = g.bfs_enqueue(vs[0], A, srcs[0], d)                  # room again
+    assert info == 0 and g.bfs_wait(t)[0] == 0
+
+
+def test_bfs_vertex_zero_without_in_edges(hb):
+    """Vertex 0 isolated (its pull hint is -1) on a graph whose later pull levels take the sparse-active-set path: the
+    idle lanes of that path carry vertex 0 and must not probe word -1 of the visited bitmap."""
+    from oracle import simple_reference as sr
+    from graphblast_amd.graphgen import finalize_edges, rmat_edges
+    g = hb.g
+    s, d_, n = rmat_edges(16, 16, seed=4)
+    s, d_ = np.asarray(s), np.asarray(d_)
+    keep = (s != 0) & (d_ != 0)
+    gr = finalize_edges(s[keep], d_[keep], n, symmetrize=True)
+    ptr, ind = gr["csr"]
+    assert ptr[1] == ptr[0]                                       # vertex 0 has no edges at all
+    A = build(hb, gr)
+    for src in [int(np.argmax(np.diff(ptr)))] + g.graphgen.random_sources(ptr, 3, seed=2):
+        for es in (0.0, 0.08):
+            d = hb.descriptor(mxvmode=0, struconly=1, opreuse=1, earlyexit=1, edgeswitch=es)
+            v = g.Vector(n)
+            info, res = g.bfs(v, A, src, d, fused=True, profile=1)
+            assert info == 0
+            assert any(L["direction"] == "pull" for L in res["per_level"])
+            assert np.array_equal(hb.dense_values(v), sr.bfs(ptr, ind, src)[0]), (src, es)
+
+
 def test_sssp(hb, graphs):
     """Distances equal lazy Dijkstra (integer weights 1..64: sums exact in f32, so exact;
     the bar written in BASELINE.md is 1e-5 relative)."""

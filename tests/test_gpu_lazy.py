@@ -174,3 +174,91 @@ def test_descriptor_toggles_do_not_cut_a_chain():
         assert np.array_equal(f2.extractTuples()[1], np.where(want_m == 0, np.float32(99), f2x))
     finally:
         g.set_lazy(before)
+
+
+def test_deferred_chains_against_the_oracle():
+    """Chains of length > 1, read back only at the END, against oracle/ops.py (the per-call fuzz reads every vector after
+    every call, so against the oracle the queue only ever held one step there).  Integer-valued data: bit for bit."""
+    import graphblast_amd as g
+    from backends import OracleBackend, HipBackend
+    ob, hb = OracleBackend(), HipBackend()
+    before = g.set_lazy(1)
+    try:
+        for dtype, seed in ((np.float32, 21), (np.int32, 22)):
+            rng = np.random.default_rng(seed)
+            deepest = 0
+            for trial in range(40):
+                npool = int(rng.integers(2, 10))
+                n = int(rng.choice([1, 64, 1000, 4097]))
+                init = [rng.integers(-3, 4, n).astype(dtype) for _ in range(npool)]
+                chain = _random_chain(rng, npool, int(rng.integers(2, 13)))
+                outs = []
+                for be in (ob, hb):
+                    d, ds = be.descriptor(), be.descriptor()
+                    assert be.toggle(ds, 0) == 0
+                    vecs = [be.vector(n, dtype) for _ in range(npool)]
+                    for v, x in zip(vecs, init):
+                        assert be.build_dense(v, x) == 0
+                    with np.errstate(all="ignore"):
+                        for kind, sr, w, u, v, s in chain:
+                            if kind == "add":
+                                assert be.eWiseAdd(vecs[w], None, None, sr, vecs[u], vecs[v], d) == 0
+                            elif kind == "mult":
+                                assert be.eWiseMult(vecs[w], None, None, sr, vecs[u], vecs[v], d) == 0
+                            elif kind == "add_scalar":
+                                assert be.eWiseAdd(vecs[w], None, None, sr, vecs[u], dtype(s), d) == 0
+                            elif kind in ("assign", "assign_scmp"):
+                                assert be.assign(vecs[w], vecs[u], dtype(s), ds if kind == "assign_scmp" else d) == 0
+                            else:
+                                assert vecs[w].dup(vecs[u]) == 0
+                            if be is hb:
+                                deepest = max(deepest, g.lazy_pending())
+                    outs.append([np.asarray(be.dense_values(v)).copy() for v in vecs])
+                for k, (a, b) in enumerate(zip(*outs)):
+                    same = (a == b) | (np.isnan(a.astype(np.float64)) & np.isnan(b.astype(np.float64)))
+                    assert same.all(), (dtype, trial, k, chain, a[~same][:4], b[~same][:4])
+            assert deepest >= 3                               # chains really were deferred
+    finally:
+        g.set_lazy(before)
+
+
+def test_exposed_storage_is_never_deferred():
+    """grb_vector_device_ptrs hands out the raw storage (torch / RCCL interop): a caller holding the pointer can read it
+    without an API call, so nothing that touches such a vector may wait in the queue (sticky)."""
+    import graphblast_amd as g
+    before = g.set_lazy(1)
+    try:
+        n = 4096
+        rng = np.random.default_rng(5)
+        d = g.Descriptor(); d.loadArgs()
+        a, b, c = (g.Vector(n) for _ in range(3))
+        xa, xb = rng.integers(0, 5, n).astype(np.float32), rng.integers(0, 5, n).astype(np.float32)
+        assert a.build(xa) == 0 and b.build(xb) == 0 and c.fill(0.0) == 0
+        assert g.eWiseAdd(c, None, None, "PlusMultiplies", a, b, d) == 0 and g.lazy_pending() == 1
+        ptr = c.device_ptrs()[2]                               # flushes, and marks c
+        assert g.lazy_pending() == 0 and ptr
+        assert g.eWiseAdd(c, None, None, "PlusMultiplies", c, b, d) == 0
+        assert g.lazy_pending() == 0                           # ran at once: c is exposed
+        import ctypes
+        host = np.empty(n, np.float32)
+        hip = ctypes.CDLL("libamdhip64.so")                    # read through the raw pointer, no library call in between
+        assert hip.hipMemcpy(ctypes.c_void_p(host.ctypes.data), ctypes.c_void_p(ptr), ctypes.c_size_t(4 * n), 2) == 0
+        assert np.array_equal(host, xa + xb + xb)
+        assert g.eWiseAdd(a, None, None, "PlusMultiplies", c, b, d) == 0 and g.lazy_pending() == 0   # as an operand too
+    finally:
+        g.set_lazy(before)
+
+
+def test_a_refused_program_still_runs_its_steps(monkeypatch):
+    """lazy_flush: the queued calls were answered GrB_SUCCESS; when the fused program cannot be launched their effect
+    must still happen (one step at a time through the eager kernels), not be dropped."""
+    import graphblast_amd as g
+    rng = np.random.default_rng(11)
+    init = [rng.integers(-3, 4, 5000).astype(np.float32) for _ in range(5)]
+    chain = _random_chain(rng, 5, 6)
+    want = _run(g, chain, init, np.float32, False)
+    monkeypatch.setenv("GRB_LAZY_FORCE_STEPWISE", "1")
+    depth = []
+    got = _run(g, chain, init, np.float32, True, depth)
+    monkeypatch.delenv("GRB_LAZY_FORCE_STEPWISE")
+    assert depth[0] >= 2 and _same(got, want)
