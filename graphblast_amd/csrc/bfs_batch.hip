@@ -234,11 +234,7 @@ __global__ __launch_bounds__(kBlock) void batch_pull_kernel(BatchArgs a) {
       if (__ballot(open) == 0ull) break;
       const Index cnt = open ? (e - p < quota ? e - p : quota) : 0;
       Index inc = cnt;
-#pragma unroll
-      for (int o = 1; o < kWave; o <<= 1) {
-        const Index t = __shfl_up(inc, o, kWave);
-        if (lane >= o) inc += t;
-      }
+inc = (Index)wave_incl_scan_u32((unsigned)inc);
       const Index total = __shfl(inc, kWave - 1, kWave);
       __builtin_amdgcn_wave_barrier();
       s_pre[w][lane] = inc - cnt;
@@ -365,11 +361,7 @@ __global__ __launch_bounds__(kBlock) void batch_push_kernel(BatchArgs a) {
     if (e - p >= a.big) p = e;                             // the slice kernel expands it
     const Index d = e - p;
     Index inc = d;
-#pragma unroll
-    for (int o = 1; o < kWave; o <<= 1) {
-      const Index t = __shfl_up(inc, o, kWave);
-      if (lane >= o) inc += t;
-    }
+inc = (Index)wave_incl_scan_u32((unsigned)inc);
     const Index total = __shfl(inc, kWave - 1, kWave);
     __builtin_amdgcn_wave_barrier();
     s_pre[w][lane] = inc - d;
@@ -501,11 +493,7 @@ __global__ __launch_bounds__(kThreads) void batch_push_owner_kernel(BatchArgs a,
     // does with rows): a wave pays one chain of memory latencies per 256 edges whatever the piece lengths are
     const Index len = o1 - o0;
     Index inc = len;
-#pragma unroll
-    for (int o = 1; o < kWave; o <<= 1) {
-      const Index t = __shfl_up(inc, o, kWave);
-      if (lane >= o) inc += t;
-    }
+inc = (Index)wave_incl_scan_u32((unsigned)inc);
     const Index total = __shfl(inc, kWave - 1, kWave);
     if (total == 0) continue;
     const int w = tid >> 6;
@@ -701,12 +689,8 @@ __global__ __launch_bounds__(kPThreads) void batch_tail_kernel(BatchArgs a, Tail
     }
     if (__ballot(mine != 0u) == 0ull) return;
     unsigned int inc = mine, ince = mine_edges;
-#pragma unroll
-    for (int o = 1; o < kWave; o <<= 1) {
-      const unsigned int tt = __shfl_up(inc, o, kWave);
-      const unsigned int te = __shfl_up(ince, o, kWave);
-      if (lane >= o) { inc += tt; ince += te; }
-    }
+inc = (unsigned int)wave_incl_scan_u32((unsigned)inc);
+ince = (unsigned int)wave_incl_scan_u32((unsigned)ince);
     unsigned int base = 0;
     unsigned long long before = 0;
     if (lane == kWave - 1) {
@@ -741,11 +725,7 @@ __global__ __launch_bounds__(kPThreads) void batch_tail_kernel(BatchArgs a, Tail
     for (int i = 0; i < N; ++i) mine += v[i] >= 0 ? 1u : 0u;
     if (__ballot(mine != 0u) == 0ull) return;
     unsigned int inc = mine;
-#pragma unroll
-    for (int o = 1; o < kWave; o <<= 1) {
-      const unsigned int tt = __shfl_up(inc, o, kWave);
-      if (lane >= o) inc += tt;
-    }
+inc = (unsigned int)wave_incl_scan_u32((unsigned)inc);
     unsigned int base = 0;
     if (lane == kWave - 1) base = atomicAdd(&s_nlist, inc);
     base = __shfl(base, kWave - 1, kWave);
@@ -779,12 +759,8 @@ __global__ __launch_bounds__(kPThreads) void batch_tail_kernel(BatchArgs a, Tail
       }
     }
     unsigned int inc = mine, ince = mine_e;
-#pragma unroll
-    for (int o = 1; o < kWave; o <<= 1) {
-      const unsigned int tt = __shfl_up(inc, o, kWave);
-      const unsigned int te = __shfl_up(ince, o, kWave);
-      if (lane >= o) { inc += tt; ince += te; }
-    }
+inc = (unsigned int)wave_incl_scan_u32((unsigned)inc);
+ince = (unsigned int)wave_incl_scan_u32((unsigned)ince);
     if (lane == kWave - 1) { s_wp[w] = inc; s_we[w] = ince; }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -905,11 +881,7 @@ __global__ __launch_bounds__(kPThreads) void batch_tail_kernel(BatchArgs a, Tail
       }
       const Index d = e - p;
       Index inc = d;
-#pragma unroll
-      for (int o = 1; o < kWave; o <<= 1) {
-        const Index tt = __shfl_up(inc, o, kWave);
-        if (lane >= o) inc += tt;
-      }
+inc = (Index)wave_incl_scan_u32((unsigned)inc);
       const Index total = __shfl(inc, kWave - 1, kWave);
       __builtin_amdgcn_wave_barrier();
       s_pre[w][lane] = inc - d;

@@ -223,12 +223,8 @@ __global__ __launch_bounds__(kPThreads) void bfs_part_level_kernel(PartArgs a) {
         }
         if (__ballot(ent > 0)) {                          // the owned big vertices as 1024-edge entries
           int incl = ent;
-#pragma unroll
-          for (int o = 1; o < kWave; o <<= 1) {
-            const int y = __shfl_up(incl, o, kWave);
-            if (lane >= o) incl += y;
-          }
-          const int total = __shfl(incl, kWave - 1, kWave);
+incl = (int)wave_incl_scan_u32((unsigned)incl);
+          const int total = (int)__builtin_amdgcn_readlane((int)incl, kWave - 1);
           unsigned b0 = 0;
           if (lane == 0) b0 = atomicAdd(bcount, (unsigned)total);
           b0 = __shfl(b0, 0, kWave);
@@ -246,8 +242,7 @@ __global__ __launch_bounds__(kPThreads) void bfs_part_level_kernel(PartArgs a) {
         }
       }
       // ---- totals: one atomic per value per workgroup into this XCD group's line
-      auto add = [](unsigned long long x, unsigned long long y) { return x + y; };
-      const unsigned long long r0 = wave_reduce(c_found, add), r1 = wave_reduce(c_deg, add), r2 = wave_reduce(c_big, add);
+      const unsigned long long r0 = wave_sum_u64(c_found), r1 = wave_sum_u64(c_deg), r2 = wave_sum_u64(c_big);
       if (lane == 0) { s_red[wave][0] = r0; s_red[wave][1] = r1; s_red[wave][2] = r2; }
       __syncthreads();
       unsigned long long* acc = &st->acc[iter % 3][0][0];
@@ -356,12 +351,8 @@ __global__ __launch_bounds__(kPThreads) void bfs_part_level_kernel(PartArgs a) {
                 }
                 const Index len = o1 - o0;
                 Index inc = len;
-#pragma unroll
-                for (int o = 1; o < kWave; o <<= 1) {
-                  const Index y = __shfl_up(inc, o, kWave);
-                  if (lane >= o) inc += y;
-                }
-                const Index total = __shfl(inc, kWave - 1, kWave);
+inc = (Index)wave_incl_scan_u32((unsigned)inc);
+                const Index total = (Index)__builtin_amdgcn_readlane((int)inc, kWave - 1);
                 if (total == 0) continue;
                 __builtin_amdgcn_wave_barrier();
                 s_pull[wave].row[lane] = make_int2(inc - len, o0);
@@ -532,12 +523,8 @@ __global__ __launch_bounds__(kPThreads) void bfs_part_level_kernel(PartArgs a) {
           if (lane < 2 * kPPullBlock) L.found[lane] = 0u;
           const int mine = __popc(und);
           int incl = mine;
-#pragma unroll
-          for (int o = 1; o < kWave; o <<= 1) {
-            const int y = __shfl_up(incl, o, kWave);
-            if (lane >= o) incl += y;
-          }
-          const int T = __shfl(incl, kWave - 1, kWave);
+incl = (int)wave_incl_scan_u32((unsigned)incl);
+          const int T = (int)__builtin_amdgcn_readlane((int)incl, kWave - 1);
           int at = incl - mine;
 #pragma unroll
           for (int j = 0; j < kPPullBlock; ++j)

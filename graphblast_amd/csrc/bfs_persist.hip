@@ -62,7 +62,24 @@ namespace grb {
 #ifndef GRB_BFS_LABEL_WT
 #define GRB_BFS_LABEL_WT 0
 #endif
-#if GRB_BFS_FLAT_BARRIER
+#ifndef GRB_BFS_GEN_BARRIER
+#define GRB_BFS_GEN_BARRIER 0
+#endif
+#ifndef GRB_BFS_DPP_TOTALS
+#define GRB_BFS_DPP_TOTALS 1       // the level totals' wave sums by DPP adds on 32-bit values (0: six 64-bit shuffle steps each)
+#endif
+#ifndef GRB_BFS_SCAN_CHUNKS
+#define GRB_BFS_SCAN_CHUNKS 1      // push levels read the frontier bitmap 64 consecutive words per wave (0: one word per lane, stride G)
+#endif
+#ifndef GRB_BFS_PULL_DYN
+#define GRB_BFS_PULL_DYN 1         // dense pull: a workgroup's blocks handed out to its waves dynamically (0: two fixed blocks per wave)
+#endif
+#ifndef GRB_BFS_FINE_TRACE
+#define GRB_BFS_FINE_TRACE 0       // 1: the level barrier stamped step by step (tools/bfs_trace.py; measurement builds only)
+#endif
+#if GRB_BFS_GEN_BARRIER
+#define GRB_BFS_GRID_SYNC(bar, gen) grid_sync_gen(bar, gen)
+#elif GRB_BFS_FLAT_BARRIER
 #define GRB_BFS_GRID_SYNC(bar, gen) grid_sync_flat(bar, gen)
 #else
 #define GRB_BFS_GRID_SYNC(bar, gen) grid_sync(bar, gen, false)
@@ -168,6 +185,9 @@ __global__ __launch_bounds__(kPThreads) void bfs_persistent_kernel(PersistArgs a
   __shared__ unsigned long long s_tot[4];
 #if GRB_BFS_TOTALS_BARRIER
   __shared__ int s_lvl_ok;
+#endif
+#if GRB_BFS_PULL_DYN
+  __shared__ int s_pull_next;                                      // dense pull: the next block of this workgroup's share
 #endif
   __shared__ int s_lcnt[2];                                        // big-vertex listing: this workgroup's entries of a pass
   __shared__ unsigned s_lbase;                                     // ... and where its block starts in the global list
@@ -286,7 +306,16 @@ __global__ __launch_bounds__(kPThreads) void bfs_persistent_kernel(PersistArgs a
         if (tid == 0) { s_nmed = 0; s_lcnt[0] = 0; s_lcnt[1] = 0; }
         __syncthreads();
         for (long long base = 0; base < nwords; base += gthreads) {
+#if GRB_BFS_SCAN_CHUNKS
+          // a wave reads 64 CONSECUTIVE words (two cache lines); consecutive 64-word chunks go to different workgroups, so
+          // a frontier that is contiguous in vertex order (a grid's wave front) is still spread over the grid.  (One word
+          // per lane with stride G, the first version, made every lane of a load a cache line of its own: 262 144 line
+          // requests for the 4 096 lines of RMAT-22's bitmap in every push level.)
+          const long long chunk = (base / kWave) + (long long)wave * G + blockIdx.x;
+          const long long i = chunk * kWave + lane;
+#else
           const long long i = (base / G + tid) * G + blockIdx.x;      // word index, stride G inside the WG
+#endif
           const unsigned int w = (i < nwords) ? fresh(&Fc[i]) : 0u;
           int mine = 0;
           for (unsigned int t = w; t; t &= t - 1) {
@@ -303,12 +332,8 @@ __global__ __launch_bounds__(kPThreads) void bfs_persistent_kernel(PersistArgs a
           }
           if (do_list) {
             int incl = mine;
-#pragma unroll
-            for (int o = 1; o < kWave; o <<= 1) {
-              const int y = __shfl_up(incl, o, kWave);
-              if (lane >= o) incl += y;
-            }
-            const int total = __shfl(incl, kWave - 1, kWave);
+incl = (int)wave_incl_scan_u32((unsigned)incl);
+            const int total = (int)__builtin_amdgcn_readlane((int)incl, kWave - 1);
 #if GRB_BFS_LIST_WG
             // the waves reserve inside the workgroup's block (LDS), thread 0 reserves the block (one global atomic)
             unsigned b0 = 0;
@@ -395,12 +420,8 @@ __global__ __launch_bounds__(kPThreads) void bfs_persistent_kernel(PersistArgs a
                 }
                 const Index len = o1 - o0;
                 Index inc = len;
-#pragma unroll
-                for (int o = 1; o < kWave; o <<= 1) {
-                  const Index y = __shfl_up(inc, o, kWave);
-                  if (lane >= o) inc += y;
-                }
-                const Index total = __shfl(inc, kWave - 1, kWave);
+inc = (Index)wave_incl_scan_u32((unsigned)inc);
+                const Index total = (Index)__builtin_amdgcn_readlane((int)inc, kWave - 1);
                 if (total == 0) continue;
                 __builtin_amdgcn_wave_barrier();
                 s_pull[wave].row[lane] = make_int2(inc - len, o0);
@@ -468,6 +489,12 @@ __global__ __launch_bounds__(kPThreads) void bfs_persistent_kernel(PersistArgs a
       // accounting.
       const bool sparse_act = GRB_BFS_SPARSE_PULL && a.n_in >= 0 &&
                               (a.n_in - reached) * GRB_BFS_SPARSE_DIV < (long long)n;
+#if GRB_BFS_PULL_DYN
+      const Index pull_per = (nblocks + (Index)G - 1) / (Index)G;
+      const Index pull_b0 = (Index)blockIdx.x * pull_per;
+      const Index pull_b1 = pull_b0 + pull_per < nblocks ? pull_b0 + pull_per : nblocks;
+      if (tid == 0) s_pull_next = 0;
+#endif
       if (!sparse_act || !GRB_BFS_SPARSE_FRESH) {
         if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         __syncthreads();
@@ -530,7 +557,18 @@ __global__ __launch_bounds__(kPThreads) void bfs_persistent_kernel(PersistArgs a
       // One wave owns a block of kPullBlock chunks of 64 vertices and runs every stage for all of them at once, so a
       // stage costs one memory latency per block instead of one per chunk:  words -> hint probe (the row pointers
       // travel with it) -> the rows it did not settle, queued and taken dense (pull_queue_run) -> outputs.
+#if GRB_BFS_PULL_DYN
+      // the blocks of a workgroup's share are handed out as its waves ask for them (an LDS counter): a wave that drew
+      // cheap blocks takes more of them, and the workgroup reaches the level's barrier when its work is done, not when
+      // the wave with the two dearest blocks is
+      for (;;) {
+        Index blk = 0;
+        if (lane == 0) blk = pull_b0 + (Index)atomicAdd(&s_pull_next, 1);
+        blk = (Index)__builtin_amdgcn_readfirstlane((int)blk);
+        if (blk >= pull_b1) break;
+#else
       for (Index blk = (Index)blockIdx.x * kPWaves + wave; blk < nblocks; blk += nwaves) {
+#endif
         // ---- stage 0: the block's words; a lane's vertices are vbase + 64 j
         const Index wi = blk * (2 * kPullBlock) + lane;
         const bool has_word = lane < 2 * kPullBlock && wi < nwords;
@@ -578,12 +616,8 @@ __global__ __launch_bounds__(kPThreads) void bfs_persistent_kernel(PersistArgs a
           if (lane < 2 * kPullBlock) L.found[lane] = 0u;
           const int mine = __popc(und);
           int incl = mine;
-#pragma unroll
-          for (int o = 1; o < kWave; o <<= 1) {
-            const int y = __shfl_up(incl, o, kWave);
-            if (lane >= o) incl += y;
-          }
-          const int T = __shfl(incl, kWave - 1, kWave);
+incl = (int)wave_incl_scan_u32((unsigned)incl);
+          const int T = (int)__builtin_amdgcn_readlane((int)incl, kWave - 1);
           int at = incl - mine;
 #pragma unroll
           for (int j = 0; j < kPullBlock; ++j)
@@ -646,11 +680,24 @@ __global__ __launch_bounds__(kPThreads) void bfs_persistent_kernel(PersistArgs a
     }
 
     stamp();
+    if (a.trace && tid == 0 && levels < 12 && blockIdx.x < 512) a.trace[256 + levels * 512 + blockIdx.x] = wall_clock64() - t_level;
     // ---- level totals: one atomic per value per workgroup into this XCD group's line
     GRB_PHASE_START();
+    // A wave's share of a level's totals fits 32 bits (every one of them is bounded by nnz, and Index is 32-bit); most
+    // waves of most levels have nothing to report at all and skip the sums (a wave-uniform branch).
+    unsigned long long r0 = 0, r1 = 0, r2 = 0, r3 = 0;
+#if GRB_BFS_DPP_TOTALS
+    if (__ballot((c.found | c.inspected) != 0ull)) {
+      r0 = wave_sum_u32((unsigned)c.found);
+      r1 = wave_sum_u32((unsigned)c.deg);
+      r2 = wave_sum_u32((unsigned)c.inspected);
+      r3 = wave_sum_u32((unsigned)c.big);
+    }
+#else
     auto add = [](unsigned long long x, unsigned long long y) { return x + y; };
-    unsigned long long r0 = wave_reduce(c.found, add), r1 = wave_reduce(c.deg, add);
-    unsigned long long r2 = wave_reduce(c.inspected, add), r3 = wave_reduce(c.big, add);
+    r0 = wave_reduce(c.found, add); r1 = wave_reduce(c.deg, add);
+    r2 = wave_reduce(c.inspected, add); r3 = wave_reduce(c.big, add);
+#endif
     if (lane == 0) { s_red[wave][0] = r0; s_red[wave][1] = r1; s_red[wave][2] = r2; s_red[wave][3] = r3; }
 #if GRB_BFS_TOTALS_BARRIER
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's write-through stores of the level have landed
@@ -700,12 +747,39 @@ __global__ __launch_bounds__(kPThreads) void bfs_persistent_kernel(PersistArgs a
     if (!s_lvl_ok) return;
     stamp();
 #else
+#if GRB_BFS_FINE_TRACE
+    stamp();                                             // reduced + workgroup barrier
+#endif
     if (tid < 4) {
       unsigned long long t = 0;
       for (int w = 0; w < kPWaves; ++w) t += s_red[w][tid];
       if (t) __hip_atomic_fetch_add(&acc[(blockIdx.x & 7) * 16 + tid], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+#if GRB_BFS_FINE_TRACE
+    {                                                    // grid_sync, stamped step by step (workgroup 0, thread 0)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      stamp();                                           // totals' adds have landed
+      __syncthreads();
+      stamp();                                           // every wave of this workgroup has arrived
+      if (tid == 0) {
+        const unsigned g = gen + 1;
+        const unsigned x = blockIdx.x & 7u;
+        const unsigned groups = G < 8 ? (unsigned)G : 8u;
+        const unsigned members = ((unsigned)G - x + 7u) / 8u;
+        const unsigned arr = __hip_atomic_fetch_add(&st->bar.xcd_count[x][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (arr + 1u == members * g) (void)__hip_atomic_fetch_add(&st->bar.top_count[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        stamp();                                         // own arrival returned
+        unsigned npoll = 0;
+        while (__hip_atomic_load(&st->bar.top_count[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < groups * g) { __builtin_amdgcn_s_sleep(1); ++npoll; if (npoll > kSpinLimit) break; }
+        stamp();                                         // released
+        if (a.trace && gtid == 0 && ntrace < 255) a.trace[1 + ntrace++] = npoll;   // (a count, not a time)
+      }
+      __syncthreads();
+      ++gen;
+    }
+#else
     if (!GRB_BFS_GRID_SYNC(&st->bar, gen)) return;
+#endif
     stamp();
     if (wave == 0) {
       unsigned long long q = 0;
@@ -1108,7 +1182,8 @@ static grb_info bfs_persistent_launch(grb_vector v, grb_matrix A, grb_index sour
   a.trace = nullptr;
   if (want_trace) {
     void* p_tr;
-    GRB_TRY(scratch(10, 256 * sizeof(unsigned long long), &p_tr));
+    GRB_TRY(scratch(10, (256 + 12 * 512) * sizeof(unsigned long long), &p_tr));
+    GRB_HIP_TRY(hipMemsetAsync(p_tr, 0, (256 + 12 * 512) * sizeof(unsigned long long), s));
     a.trace = (unsigned long long*)p_tr;
     *trace_out = a.trace;
   }
@@ -1185,6 +1260,21 @@ static grb_info bfs_persistent_collect(int slot, int seq, int profile, void* p_r
     fprintf(stderr, "bfs trace (us since kernel start; init, then per level: expanded / barrier / totals):");
     for (unsigned long long i = 0; i < h[0] && i < 255; ++i) fprintf(stderr, " %.1f", (double)h[1 + i] * tick_us);
     fprintf(stderr, "\n");
+    // when each workgroup had finished its share of a level (us since the level began): min / median / p90 / max
+    {
+      std::vector<unsigned long long> w((size_t)12 * 512);
+      GRB_HIP_TRY(hipMemcpyAsync(w.data(), trace + 256, w.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+      GRB_HIP_TRY(hipStreamSynchronize(s));
+      const int G = c.num_cu < 512 ? c.num_cu : 512;
+      fprintf(stderr, "bfs workgroup finish times per level (min/median/p90/max us):");
+      for (int L = 0; L < 12 && L < *levels; ++L) {
+        std::vector<double> t;
+        for (int b = 0; b < G; ++b) t.push_back((double)w[(size_t)L * 512 + b] * tick_us);
+        std::sort(t.begin(), t.end());
+        fprintf(stderr, " [%.1f %.1f %.1f %.1f]", t.front(), t[t.size() / 2], t[t.size() * 9 / 10], t.back());
+      }
+      fprintf(stderr, "\n");
+    }
   }
   if (levels_out && max_levels > 0) {
     const int k = *levels < max_levels ? (*levels < rec_cap ? *levels : rec_cap) : max_levels;

@@ -308,6 +308,62 @@ __device__ inline T wave_reduce(T v, F f) {
   return v;
 }
 
+// Sum of a wave's 64 values, in every lane.  Seven data-parallel-primitive adds (row shifts inside the 16-lane rows, two
+// row broadcasts) and one v_readlane instead of the twelve LDS-crossbar permutes of six 32-bit __shfl_xor steps: the
+// one-launch kernels reduce their level totals in EVERY level, sixteen waves of a workgroup at once.
+__device__ __forceinline__ unsigned wave_sum_u32(unsigned v) {
+  // update_dpp(old, src, ctrl, row_mask, bank_mask, bound_ctrl): lanes without a source (or masked out) read `old` = 0
+  unsigned t = v + __builtin_amdgcn_update_dpp(0u, v, 0x111, 0xf, 0xf, false)     // row_shr:1
+                 + __builtin_amdgcn_update_dpp(0u, v, 0x112, 0xf, 0xf, false)     // row_shr:2
+                 + __builtin_amdgcn_update_dpp(0u, v, 0x113, 0xf, 0xf, false);    // row_shr:3: lane i holds i-3 .. i of its row
+  t += __builtin_amdgcn_update_dpp(0u, t, 0x114, 0xf, 0xe, false);                // row_shr:4, banks 1-3: 8 lanes
+  t += __builtin_amdgcn_update_dpp(0u, t, 0x118, 0xf, 0xc, false);                // row_shr:8, banks 2-3: lane 15 of a row = the row
+  t += __builtin_amdgcn_update_dpp(0u, t, 0x142, 0xa, 0xf, false);                // row_bcast:15 into rows 1 and 3
+  t += __builtin_amdgcn_update_dpp(0u, t, 0x143, 0xc, 0xf, false);                // row_bcast:31 into rows 2 and 3: lane 63 = the wave
+  return (unsigned)__builtin_amdgcn_readlane((int)t, 63);
+}
+
+// Inclusive prefix sum over the wave's lanes by the same seven adds (after the row shifts every lane holds the prefix
+// inside its row; the two broadcasts add the totals of the rows before).  Every lane of the wave must be active.
+__device__ __forceinline__ unsigned wave_incl_scan_u32(unsigned v) {
+  unsigned t = v + __builtin_amdgcn_update_dpp(0u, v, 0x111, 0xf, 0xf, false)
+                 + __builtin_amdgcn_update_dpp(0u, v, 0x112, 0xf, 0xf, false)
+                 + __builtin_amdgcn_update_dpp(0u, v, 0x113, 0xf, 0xf, false);
+  t += __builtin_amdgcn_update_dpp(0u, t, 0x114, 0xf, 0xe, false);
+  t += __builtin_amdgcn_update_dpp(0u, t, 0x118, 0xf, 0xc, false);
+  t += __builtin_amdgcn_update_dpp(0u, t, 0x142, 0xa, 0xf, false);
+  t += __builtin_amdgcn_update_dpp(0u, t, 0x143, 0xc, 0xf, false);
+  return t;
+}
+// 64-bit sum of a wave: three 32-bit sums (the low word in two 16-bit halves, so that no partial sum can wrap)
+__device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v) {
+  const unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
+  return (unsigned long long)wave_sum_u32(lo & 0xffffu) + ((unsigned long long)wave_sum_u32(lo >> 16) << 16) +
+         ((unsigned long long)wave_sum_u32(hi) << 32);
+}
+// min / max of a wave's 64 values, in every lane: the same shifts with v_min / v_max (a lane without a source reads
+// the operation's identity)
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
+  auto mn = [](unsigned a, unsigned b) { return a < b ? a : b; };
+  unsigned t = mn(mn(v, __builtin_amdgcn_update_dpp(~0u, v, 0x111, 0xf, 0xf, false)),
+                  mn(__builtin_amdgcn_update_dpp(~0u, v, 0x112, 0xf, 0xf, false), __builtin_amdgcn_update_dpp(~0u, v, 0x113, 0xf, 0xf, false)));
+  t = mn(t, __builtin_amdgcn_update_dpp(~0u, t, 0x114, 0xf, 0xe, false));
+  t = mn(t, __builtin_amdgcn_update_dpp(~0u, t, 0x118, 0xf, 0xc, false));
+  t = mn(t, __builtin_amdgcn_update_dpp(~0u, t, 0x142, 0xa, 0xf, false));
+  t = mn(t, __builtin_amdgcn_update_dpp(~0u, t, 0x143, 0xc, 0xf, false));
+  return (unsigned)__builtin_amdgcn_readlane((int)t, 63);
+}
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
+  auto mx = [](unsigned a, unsigned b) { return a > b ? a : b; };
+  unsigned t = mx(mx(v, __builtin_amdgcn_update_dpp(0u, v, 0x111, 0xf, 0xf, false)),
+                  mx(__builtin_amdgcn_update_dpp(0u, v, 0x112, 0xf, 0xf, false), __builtin_amdgcn_update_dpp(0u, v, 0x113, 0xf, 0xf, false)));
+  t = mx(t, __builtin_amdgcn_update_dpp(0u, t, 0x114, 0xf, 0xe, false));
+  t = mx(t, __builtin_amdgcn_update_dpp(0u, t, 0x118, 0xf, 0xc, false));
+  t = mx(t, __builtin_amdgcn_update_dpp(0u, t, 0x142, 0xa, 0xf, false));
+  t = mx(t, __builtin_amdgcn_update_dpp(0u, t, 0x143, 0xc, 0xf, false));
+  return (unsigned)__builtin_amdgcn_readlane((int)t, 63);
+}
+
 // Reduce within aligned groups of L lanes (L power of two <= 64).
 template <typename T, typename F>
 __device__ inline T group_reduce(T v, int L, F f) {
@@ -338,12 +394,7 @@ __device__ inline bool last_workgroup_arrives(unsigned int* tickets) {
 // smem: at least kWavesPerBlock ints. Ends with a barrier, so smem may be reused.
 __device__ inline int block_exclusive_scan(int v, int* smem, int& total) {
   const int lane = lane_id(), wid = wave_id();
-  int x = v;
-#pragma unroll
-  for (int o = 1; o < kWave; o <<= 1) {
-    int y = __shfl_up(x, o, kWave);
-    if (lane >= o) x += y;
-  }
+  const int x = (int)wave_incl_scan_u32((unsigned)v);
   if (lane == kWave - 1) smem[wid] = x;
   __syncthreads();
   int wave_off = 0, tot = 0;

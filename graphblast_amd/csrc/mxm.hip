@@ -367,12 +367,8 @@ __global__ __launch_bounds__(kBlock) void spgemm_pivot_wave_kernel(T* __restrict
       const bool mine = t < ee && tc_entry_of(v, r, t, da, &ps, &pe, &out);
       const Index len = mine ? pe - ps : 0;
       Index incl = len;
-#pragma unroll
-      for (int o = 1; o < kWave; o <<= 1) {
-        const Index y = __shfl_up(incl, o, kWave);
-        if (lane >= o) incl += y;
-      }
-      const Index total = __shfl(incl, kWave - 1, kWave);
+incl = (Index)wave_incl_scan_u32((unsigned)incl);
+      const Index total = (Index)__builtin_amdgcn_readlane((int)incl, kWave - 1);
       if (__ballot(mine) == 0ull) continue;
       if (!built) {                                        // the pivot's table, once, and only if somebody needs it
         unsigned int slots = 64;

@@ -6,6 +6,10 @@
 #pragma once
 #include "common.hpp"
 
+#ifndef GRB_BARRIER_SLEEP
+#define GRB_BARRIER_SLEEP 1
+#endif
+
 namespace grb {
 
 constexpr int kPThreads = 1024;
@@ -16,6 +20,7 @@ struct GridBarrier {                // zeroed by the host before every launch
   unsigned xcd_count[8][32];        // one 128 B line per counter
   unsigned top_count[32];
   unsigned abort_flag[32];
+  unsigned gen_word[8][32];         // grid_sync_gen: the generation each XCD group's workgroups poll (one line per group)
 };
 
 // Everything one workgroup writes for another to read goes out as an agent-scope
@@ -56,7 +61,7 @@ __device__ inline bool grid_sync(GridBarrier* st, unsigned& gen, bool invalidate
     unsigned spins = 0;
     int ok = 1;
     while (__hip_atomic_load(&st->top_count[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < groups * g) {
-      __builtin_amdgcn_s_sleep(1);
+      __builtin_amdgcn_s_sleep(GRB_BARRIER_SLEEP);
       if (++spins > kSpinLimit ||
           __hip_atomic_load(&st->abort_flag[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
         __hip_atomic_store(&st->abort_flag[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -70,6 +75,43 @@ __device__ inline bool grid_sync(GridBarrier* st, unsigned& gen, bool invalidate
   __syncthreads();
   ++gen;
   return s_ok != 0;
+}
+
+// The same barrier with nobody polling a word that is also atomically updated: the leader that completes the top counter
+// stores the generation into one word per XCD group (its own 128 B line each), and a workgroup polls its group's word --
+// 32 pollers per line instead of 256 on the line the eight leaders' adds have to get through.
+static __device__ __noinline__ bool grid_sync_gen(GridBarrier* st, unsigned& gen) {
+  __shared__ int s_ok_gen;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's write-through stores have landed
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned g = gen + 1;
+    const unsigned G = gridDim.x;
+    const unsigned x = blockIdx.x & 7u;
+    const unsigned groups = G < 8u ? G : 8u;
+    const unsigned members = (G - x + 7u) / 8u;
+    const unsigned a = __hip_atomic_fetch_add(&st->xcd_count[x][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (a + 1u == members * g) {
+      const unsigned t = __hip_atomic_fetch_add(&st->top_count[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (t + 1u == groups * g)
+        for (unsigned k = 0; k < groups; ++k) __hip_atomic_store(&st->gen_word[k][0], g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    unsigned spins = 0;
+    int ok = 1;
+    while (__hip_atomic_load(&st->gen_word[x][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < g) {
+      __builtin_amdgcn_s_sleep(GRB_BARRIER_SLEEP);
+      if (++spins > kSpinLimit ||
+          ((spins & 255u) == 0u && __hip_atomic_load(&st->abort_flag[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+        __hip_atomic_store(&st->abort_flag[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ok = 0;
+        break;
+      }
+    }
+    s_ok_gen = ok;
+  }
+  __syncthreads();
+  ++gen;
+  return s_ok_gen != 0;
 }
 
 // The same barrier without the second hop: the arrival is a NON-returning add on the workgroup's XCD counter (nothing
@@ -124,12 +166,8 @@ template <typename F>
 __device__ inline void wave_for_each_bit(WaveBits* sb, unsigned int w, int lane, F f) {
   const int cnt = __popc(w);
   int incl = cnt;
-#pragma unroll
-  for (int o = 1; o < kWave; o <<= 1) {
-    const int y = __shfl_up(incl, o, kWave);
-    if (lane >= o) incl += y;
-  }
-  const int total = __shfl(incl, kWave - 1, kWave);
+incl = (int)wave_incl_scan_u32((unsigned)incl);
+  const int total = (int)__builtin_amdgcn_readlane((int)incl, kWave - 1);
   if (total == 0) return;
   __builtin_amdgcn_wave_barrier();
   sb->pre[lane] = incl - cnt;
@@ -170,12 +208,8 @@ __device__ inline void wave_for_each_bit4(WaveBits4* sb, const unsigned int (&w)
 #pragma unroll
   for (int k = 0; k < kBitsWords; ++k) cnt += __popc(w[k]);
   int incl = cnt;
-#pragma unroll
-  for (int o = 1; o < kWave; o <<= 1) {
-    const int y = __shfl_up(incl, o, kWave);
-    if (lane >= o) incl += y;
-  }
-  const int total = __shfl(incl, kWave - 1, kWave);
+incl = (int)wave_incl_scan_u32((unsigned)incl);
+  const int total = (int)__builtin_amdgcn_readlane((int)incl, kWave - 1);
   if (total == 0) return;
   __builtin_amdgcn_wave_barrier();
   {
@@ -311,12 +345,8 @@ __device__ __forceinline__ void pull_queue_run(const Index* __restrict__ iind, l
     while (__ballot(alive)) {
       const Index rem = alive ? (en - nx < cap ? en - nx : cap) : 0;
       Index incl = rem;
-#pragma unroll
-      for (int o = 1; o < kWave; o <<= 1) {
-        const Index y = __shfl_up(incl, o, kWave);
-        if (lane >= o) incl += y;
-      }
-      const Index total = __shfl(incl, kWave - 1, kWave);
+incl = (Index)wave_incl_scan_u32((unsigned)incl);
+      const Index total = (Index)__builtin_amdgcn_readlane((int)incl, kWave - 1);
       __builtin_amdgcn_wave_barrier();
       L.off[lane] = incl - rem;
       L.nxt[lane] = nx;

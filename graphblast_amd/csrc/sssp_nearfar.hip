@@ -173,10 +173,10 @@ __global__ __launch_bounds__(kPThreads) void sssp_nearfar_kernel(NfArgs a) {
     if (__ballot(expanded != expanded_before) == 0ull) break;
     }
     // ---- totals
-    auto add = [](u64 x, u64 y) { return x + y; };
-    const u64 r0 = wave_reduce((u64)expanded, add), r1 = wave_reduce((u64)far, add), r2 = wave_reduce((u64)made, add);
-    const u64 r3 = wave_reduce(relaxed, add);
-    const unsigned int rm = wave_reduce(mymin, [](unsigned int x, unsigned int y) { return x < y ? x : y; });
+    // (DPP sums, common.hpp: a pass of a road network is a few microseconds, and five shuffle reductions were one of them)
+    const u64 r0 = wave_sum_u64((u64)expanded), r1 = wave_sum_u64((u64)far), r2 = wave_sum_u64((u64)made);
+    const u64 r3 = wave_sum_u64(relaxed);
+    const unsigned int rm = wave_min_u32(mymin);
     if (lane == 0) { s_red[wave][0] = r0; s_red[wave][1] = r1; s_red[wave][2] = r2; s_red[wave][3] = r3; s_min[wave] = rm; }
     __syncthreads();
     u64* acc = &st->acc[pass % 3][0][0];
@@ -226,9 +226,8 @@ __global__ __launch_bounds__(kPThreads) void sssp_nearfar_kernel(NfArgs a) {
       md = (unsigned int)(key >> 32) > md ? (unsigned int)(key >> 32) : md;
     }
   }
-  auto umax = [](unsigned int x, unsigned int y) { return x > y ? x : y; };
-  mh = wave_reduce(mh, umax);
-  md = wave_reduce(md, umax);
+  mh = wave_max_u32(mh);
+  md = wave_max_u32(md);
   if (lane == 0 && mh) atomicMax(&st->maxhops[0], mh);
   if (lane == 0 && md) atomicMax(&st->maxdist[0], md);
   if (!grid_sync(&st->bar, gen, false)) return;
@@ -427,7 +426,7 @@ __global__ __launch_bounds__(kPThreads) void sssp_nfq_kernel(NfqArgs a) {
   auto stage_far = [&](bool jf, const NfqEntry& entry) {
     if (__ballot(jf) == 0ull) return;
     const unsigned int db = jf ? (unsigned int)(entry.vd >> 32) : 0xffffffffu;
-    const unsigned int rm = wave_reduce(db, [](unsigned int x, unsigned int y) { return x < y ? x : y; });
+    const unsigned int rm = wave_min_u32(db);
     if (lane == 0) atomicMin(&s_cnt[2], rm);
     stage(jf, entry, s_far, &s_cnt[1], kNfqStageFar, a.qf[ftarget], false);
   };
@@ -560,12 +559,10 @@ __global__ __launch_bounds__(kPThreads) void sssp_nfq_kernel(NfqArgs a) {
         md = (unsigned int)(key >> 32) > md ? (unsigned int)(key >> 32) : md;
       }
     }
-  auto umax = [](unsigned int x, unsigned int y) { return x > y ? x : y; };
-  auto add = [](u64 x, u64 y) { return x + y; };
-  mh = wave_reduce(mh, umax);
-  md = wave_reduce(md, umax);
-  const u64 w0 = wave_reduce(my_expanded, add), w1 = wave_reduce(my_relaxed, add), w2 = wave_reduce(my_queued, add);
-  const u64 r0 = a.as_bfs ? wave_reduce(n_reached, add) : 0ull, r1 = a.as_bfs ? wave_reduce(n_edges, add) : 0ull;
+  mh = wave_max_u32(mh);
+  md = wave_max_u32(md);
+  const u64 w0 = wave_sum_u64(my_expanded), w1 = wave_sum_u64(my_relaxed), w2 = wave_sum_u64(my_queued);
+  const u64 r0 = a.as_bfs ? wave_sum_u64(n_reached) : 0ull, r1 = a.as_bfs ? wave_sum_u64(n_edges) : 0ull;
   if (lane == 0) {
     if (mh) atomicMax(&st->maxhops[0], mh);
     if (md) atomicMax(&st->maxdist[0], md);

@@ -176,12 +176,8 @@ __global__ __launch_bounds__(kPThreads) void sssp_persistent_kernel(SsspArgs a) 
           if (d >= kSsspBig) mine += (d + kSsspChunk - 1) / kSsspChunk;
         }
         int incl = mine;
-#pragma unroll
-        for (int o = 1; o < kWave; o <<= 1) {
-          const int y = __shfl_up(incl, o, kWave);
-          if (lane >= o) incl += y;
-        }
-        const int total = __shfl(incl, kWave - 1, kWave);
+incl = (int)wave_incl_scan_u32((unsigned)incl);
+        const int total = (int)__builtin_amdgcn_readlane((int)incl, kWave - 1);
         if (total > 0) {
           unsigned b0 = 0;
           if (lane == 0) b0 = atomicAdd(bcount, (unsigned)total);
@@ -255,9 +251,8 @@ __global__ __launch_bounds__(kPThreads) void sssp_persistent_kernel(SsspArgs a) 
 
     // ---- totals
     const unsigned long long t_relax = wall_clock64();
-    auto add = [](unsigned long long x, unsigned long long y) { return x + y; };
-    const unsigned long long r0 = wave_reduce(c.improved, add), r1 = wave_reduce(c.big, add);
-    const unsigned long long r2 = wave_reduce(c.deg, add);
+    const unsigned long long r0 = wave_sum_u64(c.improved), r1 = wave_sum_u64(c.big);
+    const unsigned long long r2 = wave_sum_u64(c.deg);
     if (lane == 0) { s_red[wave][0] = r0; s_red[wave][1] = r1; s_red[wave][2] = r2; }
     __syncthreads();
     unsigned long long* acc = &st->acc[iter % 3][0][0];
