@@ -141,11 +141,28 @@ def other_workload(args):
         v = g.Vector(n)
         for i in range(args.warmup):
             g.bfs(v, A, sources[i % 64], desc, fused=True)
+        # the timed steps are queued back to back and waited for afterwards, as in the headline run
+        vs = [g.Vector(n) for _ in range(args.steps)]
+        g.bfs_host_times(reset=True)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        res = [g.bfs(v, A, sources[i % 64], desc, fused=True)[1] for i in range(args.steps)]
+        tickets = [g.bfs_enqueue(vs[i], A, sources[i % 64], desc)[1] for i in range(args.steps)]
+        res = [g.bfs_wait(t)[1] for t in tickets]
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
+        ht = g.bfs_host_times(reset=True)
+        torch.cuda.synchronize()
+        t0b = time.perf_counter()
+        for i in range(args.steps):
+            g.bfs(v, A, sources[i % 64], desc, fused=True)
+        torch.cuda.synchronize()
+        el_block = time.perf_counter() - t0b
+        htb = g.bfs_host_times(reset=True)
+        line["blocking_loop"] = {"ms_per_step": round(el_block / args.steps * 1e3, 5),
+                                 "host_enqueue_us_per_step": round(htb["enqueue_us"] / max(htb["calls"], 1), 2),
+                                 "host_wait_us_per_step": round(htb["wait_us"] / max(htb["calls"], 1), 2)}
+        line["queued"] = {"host_enqueue_us_per_step": round(ht["enqueue_us"] / max(ht["calls"], 1), 2)}
+        del vs
         ev = sum(g.bfs(v, A, sources[i % 64], desc, fused=True, profile=1)[1]["tight_ms"] for i in range(args.steps))
         acct = {s_: g.bfs(v, A, s_, desc, fused=True, profile=3)[1]["per_level"] for s_ in set(sources[i % 64] for i in range(args.steps))}
         tb = float(sum(sum(level_bytes(acct[sources[i % 64]], n)) for i in range(args.steps)))

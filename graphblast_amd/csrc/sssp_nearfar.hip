@@ -303,6 +303,7 @@ struct NfqArgs {
   int max_passes;
   int unit;                         // every weight is 1 (the value array is not read): the passes are BFS levels
   int as_bfs;                       // the result is algorithm::bfs's: depth labels (source 1, unreached 0), reached / edge totals
+  int inner;                        // sub-steps a workgroup runs on the near entries it staged itself before the pass's grid barrier
 };
 
 constexpr int kNfqSlots = 16;       // queue entries a wave takes per step
@@ -351,8 +352,10 @@ __device__ inline bool nfq_sync(NfqState* st, unsigned int b, unsigned int* lo) 
 }
 
 __global__ __launch_bounds__(kPThreads) void sssp_nfq_kernel(NfqArgs a) {
-  __shared__ NfqEntry s_near[kNfqStageNear];
+  __shared__ NfqEntry s_near2[2][kNfqStageNear];          // the staged near entries; two buffers in turn (sub-steps, below)
   __shared__ NfqEntry s_far[kNfqStageFar];
+  int nsel = 0;                                           // the buffer being staged into
+#define s_near (s_near2[nsel])
   __shared__ unsigned int s_cnt[4];                       // staged near, staged far, smallest far distance
   __shared__ unsigned int s_base[2];
   const int tid = threadIdx.x, lane = tid & (kWave - 1);
@@ -492,10 +495,8 @@ __global__ __launch_bounds__(kPThreads) void sssp_nfq_kernel(NfqArgs a) {
     // ---- a pass over the near queue
     const NfqEntry* qcur = a.qn[pass & 1];
     ftarget = fsel;
-    for (long long b = gwave * kNfqSlots; b < (long long)ncur; b += nwaves * kNfqSlots) {
-      const long long i = b + slot;
-      NfqEntry entry = {0ull, 0ull};
-      if (i < (long long)ncur) entry = nfq_get(&qcur[i]);            // (the 4 lanes of a slot read the same 16 bytes)
+    // one wave step: the entry of this lane's slot (an all-zero entry is an empty slot), its edges, what they lower
+    auto expand = [&](const NfqEntry& entry) {
       const Index s = (Index)(unsigned int)entry.se, e = (Index)(unsigned int)(entry.se >> 32);
       const u64 key = fresh(&a.K[(unsigned int)entry.vd]);           // in flight with the edges below
       const bool wide = e - s >= kNfWide;
@@ -533,6 +534,34 @@ __global__ __launch_bounds__(kPThreads) void sssp_nfq_kernel(NfqArgs a) {
         const float d2 = __shfl(du, src, kWave);
         const unsigned int h2 = __shfl(hu, src, kWave);
         for (Index p0 = s2; p0 < e2; p0 += kWave) relax(p0 + lane < e2, d2, h2, p0 + lane, qnext);
+      }
+    };
+    for (long long b = gwave * kNfqSlots; b < (long long)ncur; b += nwaves * kNfqSlots) {
+      const long long i = b + slot;
+      NfqEntry entry = {0ull, 0ull};
+      if (i < (long long)ncur) entry = nfq_get(&qcur[i]);            // (the 4 lanes of a slot read the same 16 bytes)
+      expand(entry);
+    }
+    // ---- sub-steps: the near entries this workgroup staged are expanded here and now, and what THEY stage too, a.inner
+    // times over, before anything goes to the global queue and the grid meets at the barrier.  Any order of relaxations
+    // reaches the same fixed point of (distance, hops); a pass's price is its chain of dependent steps plus the barrier,
+    // and a sub-step is the chain alone, its entries already in LDS.  (Not for a traversal -- unit weights, as_bfs: there
+    // a pass is a level and a vertex is queued once, which running ahead would give up.)
+    for (int subs = 0; subs < a.inner; ++subs) {
+      __syncthreads();
+      const unsigned int staged = s_cnt[0];
+      const unsigned int nloc = staged < (unsigned int)kNfqStageNear ? staged : (unsigned int)kNfqStageNear;
+      if (nloc == 0u) break;                                         // (the same for the whole workgroup)
+      __syncthreads();
+      const NfqEntry* mine = s_near2[nsel];
+      nsel ^= 1;
+      if (tid == 0) s_cnt[0] = 0u;
+      __syncthreads();
+      for (unsigned int b = (unsigned int)(tid >> 6) * kNfqSlots; b < nloc; b += kPWaves * kNfqSlots) {
+        const unsigned int i = b + (unsigned int)slot;
+        NfqEntry entry = {0ull, 0ull};
+        if (i < nloc) entry = mine[i];
+        expand(entry);
       }
     }
     flush(qnext);
@@ -590,6 +619,8 @@ __global__ __launch_bounds__(kPThreads) void sssp_nfq_kernel(NfqArgs a) {
       __hip_atomic_store(&a.mail[k], tag | vals[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
+
+#undef s_near
 
 __global__ void nfq_seed_kernel(NfqEntry* q1, NfqState* st, Index source, const Index* optr) {
   if (threadIdx.x == 0) {                                        // distance 0
@@ -746,6 +777,8 @@ grb_info grb::sssp_nearfar_run(grb_vector v, grb_matrix A, grb_index source, grb
     a.max_passes = max_passes;
     a.unit = 0;
     a.as_bfs = 0;
+    static const int nfq_inner = getenv("GRB_SSSP_SUBSTEPS") ? atoi(getenv("GRB_SSSP_SUBSTEPS")) : 16;
+    a.inner = nfq_inner < 0 ? 0 : nfq_inner;
     GRB_HIP_TRY(hipMemsetAsync(p_zero, 0, st_bytes, s));
     hipLaunchKernelGGL(nf_init_kernel, dim3(stream_grid(n, kBlock)), dim3(kBlock), 0, s, a.K, n, (Index)source);
     hipLaunchKernelGGL(nfq_seed_kernel, dim3(1), dim3(64), 0, s, a.qn[1], a.st, (Index)source, a.optr);
@@ -863,6 +896,7 @@ grb_info grb::bfs_queue_run(grb_vector v, grb_matrix A, grb_index source, grb_de
   a.max_passes = pass_cap > 0x7fffff00ll ? 0x7fffff00 : (int)pass_cap;
   a.unit = 1;
   a.as_bfs = 1;
+  a.inner = 0;                              // a pass is a level
   GRB_HIP_TRY(hipMemsetAsync(p_zero, 0, st_bytes, s));
   hipLaunchKernelGGL(nf_init_kernel, dim3(stream_grid(n, kBlock)), dim3(kBlock), 0, s, a.K, n, (Index)source);
   hipLaunchKernelGGL(nfq_seed_kernel, dim3(1), dim3(64), 0, s, a.qn[1], a.st, (Index)source, a.optr);
