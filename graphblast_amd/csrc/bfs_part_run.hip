@@ -394,7 +394,8 @@ inc = (Index)wave_incl_scan_u32((unsigned)inc);
         if (tid == 0) s_nmed = 0;
         __syncthreads();
         for (long long base = 0; base < local_words; base += gthreads) {
-          const long long i = (base / G + tid) * G + blockIdx.x;      // word index, stride G inside the workgroup
+          // 64 consecutive words per wave (two cache lines per load), consecutive chunks to different workgroups
+          const long long i = ((base / kWave) + (long long)wave * G + blockIdx.x) * kWave + lane;
           unsigned int w = (i < local_words) ? fresh(&Fcur[i]) : 0u;
           for (; w; w &= w - 1) {
             const Index vl = (Index)i * 32 + (__ffs((int)w) - 1);

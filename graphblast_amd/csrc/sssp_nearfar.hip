@@ -127,11 +127,13 @@ __global__ __launch_bounds__(kPThreads) void sssp_nearfar_kernel(NfArgs a) {
     for (int walk = 0; walk < a.inner; ++walk) {
     const unsigned int expanded_before = expanded;
     for (long long base = 0; base < nwords; base += kBitsWords * gthreads) {
-      const long long q0 = base / G + tid;               // workgroup b owns the words = b (mod G)
+      // a wave reads 64 consecutive words per load (two cache lines); consecutive 64-word chunks go to different
+      // workgroups.  (One word per lane with stride G, the first version, made every lane of a load a line of its own.)
+      const long long c0 = base / kWave + (long long)wave * G + blockIdx.x;     // word k of a lane: chunk c0 + k * kPWaves * G
       unsigned int w[kBitsWords];
 #pragma unroll
       for (int k = 0; k < kBitsWords; ++k) {
-        const long long i = (q0 + (long long)k * kPThreads) * G + blockIdx.x;
+        const long long i = (c0 + (long long)k * kPWaves * G) * kWave + lane;
         w[k] = (i < nwords) ? fresh(&a.dirty[i]) : 0u;
       }
       wave_for_each_bit4(&s_bits4[wave], w, lane, [&](int L, int k, int bit) {
@@ -139,7 +141,7 @@ __global__ __launch_bounds__(kPThreads) void sssp_nearfar_kernel(NfArgs a) {
         float du = 0.f;
         unsigned int hu = 0;
         if (L >= 0) {
-          const long long word = (q0 + (L - lane) + (long long)k * kPThreads) * G + blockIdx.x;
+          const long long word = (c0 + (long long)k * kPWaves * G) * kWave + L;
           v = (Index)word * 32 + bit;
           const unsigned int dbits = (unsigned int)(fresh(&a.K[v]) >> 32);
           if (__uint_as_float(dbits) < T) {
