@@ -333,10 +333,22 @@ __device__ inline bool tc_entry_of(const PivotView& v, Index r, Index t, Index d
 }
 
 // c = C's values; entries this pass does not own are left alone (the other pass, or the initialisation, has them)
-template <int SR, typename T>
+// kKeyOnly: the pivot side holds one value throughout (a pattern matrix): the table stores keys only -- twice the
+// slots in the same LDS -- and, with an integer plus-monoid and a one-valued partner side as well (triangle
+// counting), the keys that pass the filter are QUEUED per wave with the partner they belong to and probed 64 at a
+// time with every lane active, a hit being one ds_add_u32 on the partner's counter (as in the block kernel below):
+// no segmented scan per 64 elements, no table probe with a sixth of the lanes.
+template <int SR, typename T, bool kKeyOnly>
 __global__ __launch_bounds__(kBlock) void spgemm_pivot_wave_kernel(T* __restrict__ c_val, PivotView v, Index npivots) {
   typedef Semiring<SR, T> S;
-  __shared__ HashSlot s_tab[kWavesPerBlock][kWaveSlots];
+  typedef typename std::conditional<kKeyOnly, KeySlot, HashSlot>::type WSlot;
+  constexpr int kWSlots = kKeyOnly ? 2 * kWaveSlots : kWaveSlots;      // the same 8 KiB per wave
+  constexpr bool kCompactW = GRB_TC_COMPACT != 0 && GRB_TC_FILTER != 0 && kKeyOnly && std::is_integral<T>::value && mxm_plus_monoid<SR>();
+  constexpr int kCqW = kCompactW ? 2 * kWave : 1;
+  __shared__ unsigned int s_ckey[kCompactW ? kWavesPerBlock : 1][kCqW];
+  __shared__ unsigned char s_csrc[kCompactW ? kWavesPerBlock : 1][kCqW];
+  __shared__ unsigned int s_cnt[kCompactW ? kWavesPerBlock : 1][kCompactW ? kWave : 1];
+  __shared__ WSlot s_tab[kWavesPerBlock][kWSlots];
   constexpr bool kFilter = GRB_TC_FILTER != 0;             // a Bloom filter in front of the table, as in the block kernel
   constexpr int kFiltWords = kFilter ? kWaveCap / 2 : 1;   // 16 bits per key at capacity
   __shared__ unsigned int s_filt[kWavesPerBlock][kFiltWords];
@@ -344,7 +356,7 @@ __global__ __launch_bounds__(kBlock) void spgemm_pivot_wave_kernel(T* __restrict
   __shared__ Index s_start[kWavesPerBlock][kWave];
   __shared__ T s_acc[kWavesPerBlock][kWave];
   const int lane = lane_id(), wave = wave_id();
-  HashSlot* tab = s_tab[wave];
+  WSlot* tab = s_tab[wave];
   Index* off = s_off[wave];
   const T* __restrict__ par_val = reinterpret_cast<const T*>(v.par_val);
   const T* __restrict__ piv_val = reinterpret_cast<const T*>(v.piv_val);
@@ -372,7 +384,7 @@ incl = (Index)wave_incl_scan_u32((unsigned)incl);
       if (__ballot(mine) == 0ull) continue;
       if (!built) {                                        // the pivot's table, once, and only if somebody needs it
         unsigned int slots = 64;
-        while ((Index)slots < 2 * da) slots <<= 1;
+        while ((Index)slots < (kKeyOnly ? 4 : 2) * da) slots <<= 1;   // key-only: a quarter load (the block kernel's reasoning)
         tmask = slots - 1;
         for (unsigned int i = lane; i < slots; i += kWave) tab[i].key = kEmptyKey;
         if constexpr (kFilter) {
@@ -403,6 +415,59 @@ incl = (Index)wave_incl_scan_u32((unsigned)incl);
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       __builtin_amdgcn_wave_barrier();
       // ---- the partners' elements as one index space
+      if constexpr (kCompactW) {
+        if (v.par_iso != 0) {                                // (wave-uniform)
+          s_cnt[wave][lane] = 0u;
+          int qlen = 0;
+          auto probe_round = [&](int na) {                   // candidates [qlen - na, qlen) of the queue, one per lane
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const bool on = lane < na;
+            const unsigned int key = on ? s_ckey[wave][qlen - na + lane] : 0u;
+            const unsigned int src = on ? (unsigned int)s_csrc[wave][qlen - na + lane] : 0u;
+            if (on && tc_find(tab, tmask, key, nullptr)) atomicAdd(&s_cnt[wave][src], 1u);
+            qlen -= na;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+          };
+          for (Index x0 = 0; x0 < total; x0 += kWave) {
+            const Index x = x0 + lane;
+            const bool live = x < total;
+            int lo = 0;                                      // last partner whose offset is <= x
+            bool pass = false;
+            unsigned int col = 0u;
+            if (live) {
+#pragma unroll
+              for (int step = kWave / 2; step > 0; step >>= 1)
+                if (off[lo + step] <= x) lo += step;
+              col = (unsigned int)v.par_ind[s_start[wave][lo] + (x - off[lo])];
+              const unsigned int hh = tc_hash(col);
+              const unsigned int pat = (1u << (hh & 31u)) | (1u << ((hh >> 5) & 31u));
+              pass = (filt[(hh >> 12) & fmask] & pat) == pat;
+            }
+            const unsigned long long pm = __ballot(pass);
+            if (pm) {
+              if (pass) {
+                const int at = qlen + __popcll(pm & ((1ull << lane) - 1ull));
+                s_ckey[wave][at] = col;
+                s_csrc[wave][at] = (unsigned char)lo;
+              }
+              qlen += __popcll(pm);
+              if (qlen >= kWave) probe_round(kWave);
+            }
+          }
+          if (qlen > 0) probe_round(qlen);
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          T pv;
+          const unsigned int vb1 = v.iso_bits;
+          memcpy(&pv, &vb1, 4);
+          const T one = v.cols ? S::mul(par_one, pv) : S::mul(pv, par_one);
+          if (mine) c_val[out] = (T)s_cnt[wave][lane] * one;   // an integer sum of `count` equal products
+          __builtin_amdgcn_wave_barrier();
+          continue;
+        }
+      }
       for (Index x0 = 0; x0 < total; x0 += kWave) {
         const Index x = x0 + lane;
         const bool live = x < total;
@@ -421,6 +486,7 @@ incl = (Index)wave_incl_scan_u32((unsigned)incl);
             const unsigned int pat = (1u << (hh & 31u)) | (1u << ((hh >> 5) & 31u));
             maybe = (filt[(hh >> 12) & fmask] & pat) == pat;
           }
+          vb = v.iso_bits;                                   // (a key-only table stores no value: the pivot side's one)
           if (maybe && tc_find(tab, tmask, col, &vb)) {
             T pv;
             memcpy(&pv, &vb, 4);
@@ -445,7 +511,8 @@ struct PivotItem { Index pivot, e0, e1; };                // a run of a long piv
 template <int SR, typename T, bool kSegments, typename Slot, int kTableBytes>
 __global__ __launch_bounds__(1024) void spgemm_pivot_block_kernel(T* __restrict__ c_val, PivotView v,
                                                                   const PivotItem* __restrict__ big, int nbig,
-                                                                  Index min_len, unsigned long long* __restrict__ trace) {
+                                                                  Index min_len, Index max_len,
+                                                                  unsigned long long* __restrict__ trace) {
   typedef Semiring<SR, T> S;
   // kTableBytes of LDS table at half load: 64 KiB = two workgroups per CU; the 128 KiB instantiation takes the
   // pivots too long for that one, and with kSegments those too long for any LDS table
@@ -483,7 +550,7 @@ __global__ __launch_bounds__(1024) void spgemm_pivot_block_kernel(T* __restrict_
     const Index es = big[bi].e0, ee = big[bi].e1;
     const Index as = v.piv_ptr[r], ae = v.piv_ptr[r + 1];
     const Index da = ae - as;
-    if (kSegments ? da <= min_len : (da > kCap || da <= min_len)) continue;   // another instantiation's
+    if (da > max_len || (kSegments ? da <= min_len : (da > kCap || da <= min_len))) continue;   // another instantiation's / kernel's
     const unsigned long long t_item = wall_clock64();
     ++n_items;
     Slot* tab = s_tab;
@@ -730,6 +797,194 @@ __global__ __launch_bounds__(1024) void spgemm_pivot_block_kernel(T* __restrict_
   }
 }
 
+// ---- long pivots as BITMAPS (triangle counting: both sides one-valued, an integer plus-monoid) -------------------------
+// A hash table makes a probe a filter read, a queue write and -- for the one key in six that passes -- a 16-byte table
+// read; its size follows the pivot's length, so the longest pivots need 128 KiB tables or several table loads.  A
+// bitmap over a COLUMN RANGE needs none of that: kBytes of LDS hold 8 x kBytes columns (128 KiB: one Mi columns -- four
+// ranges cover RMAT-22 whatever the pivot's length), a probe is ONE 4-byte LDS read and exact, a hit is a bit.  The
+// pivot's entries inside the range set their bits; every partner list is cut to the range by two binary searches (it is
+// sorted), streamed through the same software pipeline as the block kernel's, and its hits are counted in registers,
+// folded once per partner and range (DPP sum).  An entry's result is the sum over the ranges.
+// What a partner costs before its first element is streamed -- its list bounds and output position (tc_entry_of: three
+// to twenty dependent loads) and two binary searches per range -- is paid ONCE per item: the first pass over an item's
+// entries writes each partner's cut points at all the range boundaries (the searches of one partner run side by side)
+// and its output position to a scratch block of the workgroup's, and every range reads them back with coalesced loads.
+constexpr int kBitsMaxSeg = 8;                             // ranges per pivot whose cut points are cached (more: searched per range)
+constexpr int kBitsItemEntries = 4 * 1024;                 // entries per item (run_pass cuts the lists so)
+constexpr int kBitsRec = kBitsMaxSeg + 2;                  // per entry: cut points [0 .. nseg], then the output position (-1: not this pass's)
+template <int SR, typename T, int kBytes>
+__global__ __launch_bounds__(1024) void spgemm_pivot_bitmap_kernel(T* __restrict__ c_val, PivotView v,
+                                                                   const PivotItem* __restrict__ big, int nbig, Index min_len,
+                                                                   Index* __restrict__ cuts_all) {
+  typedef Semiring<SR, T> S;
+  constexpr int kWords = kBytes / 4;
+  constexpr long long kCols = (long long)kWords * 32;
+  __shared__ unsigned int s_bits[kWords];
+  const int tid = threadIdx.x, lane = tid & (kWave - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  T par_one, pv;
+  memcpy(&par_one, &v.par_iso_bits, 4);
+  memcpy(&pv, &v.iso_bits, 4);
+  const T one = v.cols ? S::mul(par_one, pv) : S::mul(pv, par_one);       // every product of this launch
+  for (int bi = blockIdx.x; bi < nbig; bi += gridDim.x) {
+    const Index r = big[bi].pivot;
+    const Index es = big[bi].e0, ee = big[bi].e1;
+    const Index as = v.piv_ptr[r], ae = v.piv_ptr[r + 1];
+    const Index da = ae - as;
+    if (da <= min_len) continue;                           // the table kernels'
+    const long long seg_first = (long long)v.piv_ind[as] / kCols, seg_last = (long long)v.piv_ind[ae - 1] / kCols;
+    const int nseg = (int)(seg_last - seg_first + 1);
+    const bool cached = nseg <= kBitsMaxSeg && ee - es <= kBitsItemEntries && cuts_all != nullptr;
+    Index* cuts = cuts_all + (size_t)blockIdx.x * kBitsItemEntries * kBitsRec;
+    if (cached) {
+      __syncthreads();                                     // (the previous item's readers are done)
+      for (Index t0 = es + wave * kWave; t0 < ee; t0 += 1024) {
+        const Index t = t0 + lane;
+        Index ps = 0, pe = 0, out = 0;
+        const bool mine = t < ee && tc_entry_of(v, r, t, da, &ps, &pe, &out);
+        // cut k = the first element with a column >= (seg_first + k) * kCols, k = 0 .. nseg (elements outside the pivot's
+        // ranges belong to no range); the searches of one partner run side by side
+        Index lo[kBitsMaxSeg + 1], hi[kBitsMaxSeg + 1];
+#pragma unroll
+        for (int k = 0; k <= kBitsMaxSeg; ++k) { lo[k] = ps; hi[k] = (mine && k <= nseg) ? pe : ps; }
+        bool any = true;
+        while (any) {
+          any = false;
+#pragma unroll
+          for (int k = 0; k <= kBitsMaxSeg; ++k) {
+            if (lo[k] < hi[k]) {
+              const Index mid = lo[k] + (hi[k] - lo[k]) / 2;
+              const long long key = (seg_first + k) * kCols;
+              if ((long long)v.par_ind[mid] < key) lo[k] = mid + 1; else hi[k] = mid;
+              any = true;
+            }
+          }
+          any = __ballot(any) != 0ull;
+        }
+        if (t < ee) {
+          Index* rec = cuts + (size_t)(t - es) * kBitsRec;
+#pragma unroll
+          for (int k = 0; k <= kBitsMaxSeg; ++k) rec[k] = lo[k];
+          rec[kBitsMaxSeg + 1] = mine ? out : -1;
+        }
+      }
+      __syncthreads();
+    }
+    bool wrote = false;                                    // (the same for the whole workgroup)
+    for (long long seg = seg_first; seg <= seg_last; ++seg) {
+      const long long lo64 = seg * kCols, hi64 = lo64 + kCols;                  // columns [lo, hi)
+      const Index c_lo = (Index)lo64;
+      const Index c_end = hi64 > 0x7fffffffll ? 0x7fffffff : (Index)hi64;       // (no column id reaches 2^31 - 1)
+      const Index p0 = lower_bound_dev(v.piv_ind, as, ae, c_lo);
+      const Index p1 = lower_bound_dev(v.piv_ind, p0, ae, c_end);
+      if (p1 == p0) continue;
+      __syncthreads();
+      for (int i = tid; i < kWords / 4; i += 1024) reinterpret_cast<uint4*>(s_bits)[i] = make_uint4(0u, 0u, 0u, 0u);
+      __syncthreads();
+      for (Index p = p0 + tid; p < p1; p += 1024) {
+        const unsigned int c = (unsigned int)(v.piv_ind[p] - c_lo);
+        atomicOr(&s_bits[c >> 5], 1u << (c & 31u));
+      }
+      __syncthreads();
+      for (Index t0 = es + wave * kWave; t0 < ee; t0 += 1024) {
+        const Index t = t0 + lane;
+        Index ps = 0, pe = 0, out = 0;
+        bool mine = false;
+        if (cached) {
+          if (t < ee) {
+            const Index* rec = cuts + (size_t)(t - es) * kBitsRec;
+            const int k = (int)(seg - seg_first);
+            ps = rec[k];
+            pe = rec[k + 1];
+            out = rec[kBitsMaxSeg + 1];
+            mine = out >= 0;
+          }
+        } else {
+          mine = t < ee && tc_entry_of(v, r, t, da, &ps, &pe, &out);
+          if (mine) {                                        // the part of the partner inside this range
+            ps = lower_bound_dev(v.par_ind, ps, pe, c_lo);
+            pe = lower_bound_dev(v.par_ind, ps, pe, c_end);
+          }
+        }
+        unsigned int result = 0u;
+        unsigned long long todo = __ballot(mine && pe > ps);
+        struct Chunk { int src; Index q, ce; };
+        auto advance = [&](Chunk d) -> Chunk {
+          if (d.src < 0) return d;
+          if (d.q + 4 * kWave < d.ce) { d.q += 4 * kWave; return d; }
+          if (todo) {
+            d.src = __ffsll((long long)todo) - 1;
+            todo &= todo - 1;
+            d.q = __shfl(ps, d.src, kWave);
+            d.ce = __shfl(pe, d.src, kWave);
+          } else {
+            d.src = -1;
+          }
+          return d;
+        };
+        auto fetch = [&](const Chunk& d, unsigned int (&k)[4]) {
+#pragma unroll
+          for (int h = 0; h < 4; ++h) {
+            const Index q = d.q + h * kWave + lane;
+            k[h] = (d.src >= 0 && q < d.ce) ? (unsigned int)v.par_ind[q] : kEmptyKey;
+          }
+        };
+        Chunk d0 = {-1, 0, 0};
+        if (todo) {
+          d0.src = __ffsll((long long)todo) - 1;
+          todo &= todo - 1;
+          d0.q = __shfl(ps, d0.src, kWave);
+          d0.ce = __shfl(pe, d0.src, kWave);
+        }
+        constexpr int kDepth = GRB_TC_DEPTH;
+        Chunk dq[kDepth + 1];
+        unsigned int kq[kDepth + 1][4];
+        dq[0] = d0;
+        fetch(dq[0], kq[0]);
+#pragma unroll
+        for (int i = 1; i <= kDepth; ++i) {
+          dq[i] = advance(dq[i - 1]);
+          fetch(dq[i], kq[i]);
+        }
+        unsigned int acc = 0u;
+        while (dq[0].src >= 0) {
+          unsigned int kc[4];
+#pragma unroll
+          for (int h = 0; h < 4; ++h) kc[h] = kq[0][h];
+          const int src_c = dq[0].src;
+          const bool last_of_partner = dq[0].q + 4 * kWave >= dq[0].ce;
+#pragma unroll
+          for (int i = 0; i < kDepth; ++i) {
+            dq[i] = dq[i + 1];
+#pragma unroll
+            for (int h = 0; h < 4; ++h) kq[i][h] = kq[i + 1][h];
+          }
+          dq[kDepth] = advance(dq[kDepth]);
+          fetch(dq[kDepth], kq[kDepth]);
+          unsigned int w[4];
+#pragma unroll
+          for (int h = 0; h < 4; ++h) {
+            const unsigned int c = kc[h] != kEmptyKey ? kc[h] - (unsigned int)c_lo : 0u;
+            w[h] = s_bits[c >> 5] >> (c & 31u);
+          }
+#pragma unroll
+          for (int h = 0; h < 4; ++h) acc += (kc[h] != kEmptyKey) ? (w[h] & 1u) : 0u;
+          if (last_of_partner) {
+            const unsigned int tot = wave_sum_u32(acc);
+            if (lane == src_c) result = tot;
+            acc = 0u;
+          }
+        }
+        if (mine) {
+          const T add = (T)result * one;                     // an integer sum of `result` equal products
+          c_val[out] = wrote ? S::add(add, c_val[out]) : add;
+        }
+      }
+      wrote = true;
+    }
+  }
+}
+
 // min and max of the raw 4-byte values (out preset to {~0, 0}): equal = one value throughout
 __global__ __launch_bounds__(kBlock) void value_range_kernel(const unsigned int* __restrict__ val, Index n, unsigned int* __restrict__ out) {
   unsigned int lo = 0xffffffffu, hi = 0u;
@@ -934,8 +1189,12 @@ grb_info grb_mxm(grb_matrix C, grb_matrix mask, grb_accum accum, grb_semiring op
         const double cy = (double)(y.e1 - y.e0) * (double)(hp_piv[(size_t)y.pivot + 1] - hp_piv[y.pivot]);
         return cx > cy;
       });
-      hipLaunchKernelGGL((spgemm_pivot_wave_kernel<SR, T>), dim3(stream_grid((long long)npiv * kWave, kBlock)), dim3(kBlock), 0, s,
-                         (T*)C->csr.val, v, npiv);
+      if (piv_iso)
+        hipLaunchKernelGGL((spgemm_pivot_wave_kernel<SR, T, true>), dim3(stream_grid((long long)npiv * kWave, kBlock)), dim3(kBlock), 0, s,
+                           (T*)C->csr.val, v, npiv);
+      else
+        hipLaunchKernelGGL((spgemm_pivot_wave_kernel<SR, T, false>), dim3(stream_grid((long long)npiv * kWave, kBlock)), dim3(kBlock), 0, s,
+                           (T*)C->csr.val, v, npiv);
       GRB_HIP_TRY(hipGetLastError());
       if (big.empty()) return GRB_SUCCESS;
       // two workgroups per CU (64 KiB tables); is the pivot side one value throughout?  then the tables hold keys only
@@ -968,24 +1227,43 @@ grb_info grb_mxm(grb_matrix C, grb_matrix mask, grb_accum accum, grb_semiring op
           return GRB_SUCCESS;
         };
         const Index cap64 = 65536 / (Index)sizeof(Slot) / 2, cap128 = 131072 / (Index)sizeof(Slot) / 2;
+        // pivots longer than `bits_from` entries go to the bitmap kernel instead (key-only tables, an integer
+        // plus-monoid, a one-valued partner side: triangle counting); GRB_TC_BITMAP_MIN moves the line, 0 = never
+        Index max_tab = 0x7fffffff;
+        if constexpr (std::is_same<Slot, KeySlot>::value && std::is_integral<T>::value && mxm_plus_monoid<SR>()) {
+          static const long long bits_env = getenv("GRB_TC_BITMAP_MIN") ? atoll(getenv("GRB_TC_BITMAP_MIN")) : 2048;
+          if (vv.par_iso && bits_env > 0 && longest > (Index)bits_env) max_tab = (Index)bits_env;
+        }
         if (want_trace) GRB_HIP_TRY(hipMemsetAsync(d_trace, 0, 24 * (size_t)bgrid, s));
         hipLaunchKernelGGL((spgemm_pivot_block_kernel<SR, T, false, Slot, 65536>), dim3(bgrid), dim3(1024), 0, s, (T*)C->csr.val, vv,
-                           (const PivotItem*)p_big, (int)big.size(), (Index)0, d_trace);
+                           (const PivotItem*)p_big, (int)big.size(), (Index)0, max_tab, d_trace);
         GRB_HIP_TRY(hipGetLastError());
         GRB_TRY(dump("64 KiB LDS tables"));
-        if (longest > cap64) {
+        if (longest > cap64 && max_tab > cap64) {
           if (want_trace) GRB_HIP_TRY(hipMemsetAsync(d_trace, 0, 24 * (size_t)bgrid, s));
           hipLaunchKernelGGL((spgemm_pivot_block_kernel<SR, T, false, Slot, 131072>), dim3(bgrid), dim3(1024), 0, s, (T*)C->csr.val, vv,
-                             (const PivotItem*)p_big, (int)big.size(), cap64, d_trace);
+                             (const PivotItem*)p_big, (int)big.size(), cap64, max_tab, d_trace);
           GRB_HIP_TRY(hipGetLastError());
           GRB_TRY(dump("128 KiB LDS tables"));
         }
-        if (longest > cap128) {
+        if (longest > cap128 && max_tab > cap128) {
           if (want_trace) GRB_HIP_TRY(hipMemsetAsync(d_trace, 0, 24 * (size_t)bgrid, s));
           hipLaunchKernelGGL((spgemm_pivot_block_kernel<SR, T, true, Slot, 131072>), dim3(bgrid), dim3(1024), 0, s, (T*)C->csr.val, vv,
-                             (const PivotItem*)p_big, (int)big.size(), cap128, d_trace);
+                             (const PivotItem*)p_big, (int)big.size(), cap128, max_tab, d_trace);
           GRB_HIP_TRY(hipGetLastError());
           GRB_TRY(dump("128 KiB LDS tables, pivot in segments"));
+        }
+        if constexpr (std::is_same<Slot, KeySlot>::value && std::is_integral<T>::value && mxm_plus_monoid<SR>()) {
+          if (max_tab != 0x7fffffff) {
+            // 128 KiB of LDS: one workgroup per CU, four ranges on RMAT-22 (64 KiB -- two per CU, eight ranges -- measured
+            // 151 against 134 ms)
+            const int ggrid = (int)big.size() < ctx().num_cu ? (int)big.size() : ctx().num_cu;
+            void* p_cuts;
+            GRB_TRY(scratch(3, sizeof(Index) * (size_t)ggrid * kBitsItemEntries * kBitsRec, &p_cuts));
+            hipLaunchKernelGGL((spgemm_pivot_bitmap_kernel<SR, T, 131072>), dim3(ggrid), dim3(1024), 0, s, (T*)C->csr.val, vv,
+                               (const PivotItem*)p_big, (int)big.size(), max_tab, (Index*)p_cuts);
+            GRB_HIP_TRY(hipGetLastError());
+          }
         }
         return GRB_SUCCESS;
       };
