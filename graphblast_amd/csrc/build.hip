@@ -107,9 +107,20 @@ __global__ __launch_bounds__(kBlock) void radix_scatter_kernel(
   for (int k = threadIdx.x; k < kWavesPerBlock * 256; k += kBlock) (&wh[0][0])[k] = 0;
   __syncthreads();
   const long long wbase = (long long)blockIdx.x * kSortTile + (long long)wave * kWaveSpan;
-  for (int c = 0; c < kWaveSpan; c += kWave) {
-    const long long i = wbase + c + lane;
-    if (i < n) atomicAdd(&wh[wave][(unsigned)(keys[i] >> shift) & 255u], 1u);
+  // a lane's sixteen items, read ONCE and all at once (the ranking loop below is a chain of LDS updates behind a fence:
+  // a load inside it waits out a full memory latency per step, sixteen times per wave)
+  unsigned long long kreg[kWaveSpan / kWave];
+  unsigned int preg[kWaveSpan / kWave];
+#pragma unroll
+  for (int c = 0; c < kWaveSpan / kWave; ++c) {
+    const long long i = wbase + (long long)c * kWave + lane;
+    kreg[c] = i < n ? keys[i] : 0ull;
+    preg[c] = i < n ? pay[i] : 0u;
+  }
+#pragma unroll
+  for (int c = 0; c < kWaveSpan / kWave; ++c) {
+    const long long i = wbase + (long long)c * kWave + lane;
+    if (i < n) atomicAdd(&wh[wave][(unsigned)(kreg[c] >> shift) & 255u], 1u);
   }
   __syncthreads();
   {                                                    // thread d: start position of every wave for digit d
@@ -124,12 +135,13 @@ __global__ __launch_bounds__(kBlock) void radix_scatter_kernel(
   }
   __syncthreads();
   const unsigned long long lt = (1ull << lane) - 1ull;
-  for (int c = 0; c < kWaveSpan; c += kWave) {
-    const long long i = wbase + c + lane;
+#pragma unroll
+  for (int cc = 0; cc < kWaveSpan / kWave; ++cc) {
+    const long long i = wbase + (long long)cc * kWave + lane;
     const bool valid = i < n;
-    unsigned long long key = 0;
-    unsigned int p = 0, d = 0;
-    if (valid) { key = keys[i]; p = pay[i]; d = (unsigned)(key >> shift) & 255u; }
+    const unsigned long long key = kreg[cc];
+    const unsigned int p = preg[cc];
+    const unsigned int d = valid ? (unsigned)(key >> shift) & 255u : 0u;
     unsigned long long same = __ballot(valid);
 #pragma unroll
     for (int b = 0; b < 8; ++b) {
@@ -331,6 +343,43 @@ grb_info grb::device_sort_pairs(unsigned long long* d_keys, unsigned int* d_pay,
   b.totals = (unsigned int*)q;
   int cur = 0;
   GRB_TRY(radix_sort_pairs(b, &cur, n, lo_bits, hi_bits, s));
+  if (cur != 0) {
+    GRB_HIP_TRY(hipMemcpyAsync(d_keys, b.keys[1], 8 * (size_t)n, hipMemcpyDeviceToDevice, s));
+    GRB_HIP_TRY(hipMemcpyAsync(d_pay, b.pay[1], 4 * (size_t)n, hipMemcpyDeviceToDevice, s));
+  }
+  GRB_HIP_TRY(hipStreamSynchronize(s));
+  return GRB_SUCCESS;
+}
+
+// The same over the digit positions [first_bit, first_bit + nbits) only (whatever sits below first_bit rides along
+// unsorted: spmv_cband.hpp keeps an entry's row-in-band there).
+grb_info grb::device_sort_pairs_range(unsigned long long* d_keys, unsigned int* d_pay, long long n, int first_bit, int nbits) {
+  if (n <= 1 || nbits <= 0) return GRB_SUCCESS;
+  hipStream_t s = ctx().stream;
+  const int nblocks = (int)((n + kSortTile - 1) / kSortTile) + 1;
+  const size_t cnt_elems = 256 * (size_t)nblocks;
+  void* raw = nullptr;
+  GRB_HIP_TRY(hipMalloc(&raw, 12 * (size_t)n + 4 * cnt_elems + 4 * (cnt_elems / kScanTile + 2) + 64));
+  struct Free { void* p; ~Free() { (void)hipFree(p); } } guard{raw};
+  SortBuffers b;
+  char* q = (char*)raw;
+  b.keys[0] = d_keys;
+  b.keys[1] = (unsigned long long*)q; q += 8 * (size_t)n;
+  b.pay[0] = d_pay;
+  b.pay[1] = (unsigned int*)q; q += 4 * (size_t)n;
+  b.cnt = (unsigned int*)q; q += 4 * cnt_elems;
+  b.totals = (unsigned int*)q;
+  int cur = 0;
+  const int nb = (int)((n + kSortTile - 1) / kSortTile);
+  for (int sft = first_bit; sft < first_bit + nbits; sft += 8) {
+    const int src = cur, dst = 1 - cur;
+    hipLaunchKernelGGL(radix_hist_kernel, dim3(nb), dim3(kBlock), 0, s, (const unsigned long long*)b.keys[src], n, sft, nb, b.cnt);
+    GRB_TRY(exclusive_scan_u32(b.cnt, 256ll * nb, b.totals, s));
+    hipLaunchKernelGGL(radix_scatter_kernel, dim3(nb), dim3(kBlock), 0, s, (const unsigned long long*)b.keys[src],
+                       (const unsigned int*)b.pay[src], n, sft, nb, (const unsigned int*)b.cnt, b.keys[dst], b.pay[dst]);
+    GRB_HIP_TRY(hipGetLastError());
+    cur = dst;
+  }
   if (cur != 0) {
     GRB_HIP_TRY(hipMemcpyAsync(d_keys, b.keys[1], 8 * (size_t)n, hipMemcpyDeviceToDevice, s));
     GRB_HIP_TRY(hipMemcpyAsync(d_pay, b.pay[1], 4 * (size_t)n, hipMemcpyDeviceToDevice, s));

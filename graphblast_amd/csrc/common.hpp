@@ -707,6 +707,7 @@ void free_spmv_plan(SpmvPlan* plan);
 // orientation's pointer array, whose differences ARE the counts; nullptr: histogram of d_ind)
 grb_info device_exclusive_scan_u32(unsigned int* d, long long n);   // build.hip
 grb_info device_sort_pairs(unsigned long long* d_keys, unsigned int* d_pay, long long n, int lo_bits, int hi_bits);   // build.hip
+grb_info device_sort_pairs_range(unsigned long long* d_keys, unsigned int* d_pay, long long n, int first_bit, int nbits);
 grb_info device_rank_columns(const Index* d_ind, Index nvals, const Index* d_other_ptr, Index m, Index hot,
                              Index* d_order, Index* d_rank, long long* hot_refs, Index* nreferenced);
 // other_ptr: pointer array of the transposed orientation (length nminor + 1) or nullptr; only read by the

@@ -23,6 +23,7 @@
 //
 // Algorithmic bytes per launch of k_spmv: 8*nnz + 12*n + 4.
 #include "common.hpp"
+#include <chrono>
 
 namespace grb {
 
@@ -491,16 +492,47 @@ static grb_info prepare_cband(const CsrArrays& M, SpmvPlan& plan) {
     return d;
   };
 
+  // GRB_SPMV_PREP_TRACE: where the preparation's time goes (stderr; every mark waits for the stream)
+  static const bool prep_trace = getenv("GRB_SPMV_PREP_TRACE") != nullptr;
+  auto t_prev = std::chrono::steady_clock::now();
+  auto mark = [&](const char* what) {
+    if (!prep_trace) return;
+    (void)hipStreamSynchronize(st);
+    const auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "cband prep: %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_prev).count());
+    t_prev = now;
+  };
   // ---- host: hubs, bands
   std::vector<Index> ptr((size_t)n + 1);
   GRB_HIP_TRY(hipMemcpy(ptr.data(), M.ptr, 4 * ((size_t)n + 1), hipMemcpyDeviceToHost));
   Index hub_above = 0x7fffffff;                          // rows with more entries than this are hubs
   if (n > kCbRows) {
-    std::vector<Index> deg((size_t)n);
-    for (Index r = 0; r < n; ++r) deg[r] = ptr[(size_t)r + 1] - ptr[r];
-    std::nth_element(deg.begin(), deg.begin() + kCbRows, deg.end(), [](Index x, Index y) { return x > y; });
-    hub_above = deg[kCbRows] > 64 ? deg[kCbRows] : 64;   // at most kCbRows rows are strictly above the (kCbRows+1)-th largest
+    // the (kCbRows + 1)-th largest degree, from a histogram (one pass over the rows; degrees of 64 Ki and more share
+    // the last bin -- should the answer fall there, the selection is done on those rows alone)
+    constexpr int kDegBins = 65536;
+    std::vector<unsigned int> hist((size_t)kDegBins + 1, 0u);
+    for (Index r = 0; r < n; ++r) {
+      const Index d = ptr[(size_t)r + 1] - ptr[r];
+      ++hist[d < kDegBins ? d : kDegBins];
+    }
+    long long above = hist[kDegBins];
+    if (above > kCbRows) {
+      std::vector<Index> deg;
+      for (Index r = 0; r < n; ++r)
+        if (ptr[(size_t)r + 1] - ptr[r] >= kDegBins) deg.push_back(ptr[(size_t)r + 1] - ptr[r]);
+      std::nth_element(deg.begin(), deg.begin() + kCbRows, deg.end(), [](Index x, Index y) { return x > y; });
+      hub_above = deg[kCbRows];
+    } else {
+      int d = kDegBins - 1;
+      for (; d > 0; --d) {                                 // the largest d with (rows of degree >= d) >= kCbRows + 1
+        above += hist[d];
+        if (above > kCbRows) break;
+      }
+      hub_above = d;
+    }
+    if (hub_above < 64) hub_above = 64;                    // at most kCbRows rows are strictly above the (kCbRows+1)-th largest
   }
+  mark("row pointers + hub threshold");
   std::vector<unsigned int> row_band((size_t)n);
   std::vector<unsigned short> row_loc((size_t)n);
   std::vector<Index> hub_rows;
@@ -538,8 +570,11 @@ static grb_info prepare_cband(const CsrArrays& M, SpmvPlan& plan) {
     if (band_entries_max < 64 * kWave) band_entries_max = 64 * kWave;
   }
   {
+    // one pass over the rows: the light bands are cut, and every row learns its band and its place in it
     long long at = hub_entries, in_band = 0;
     Index r0 = 0;
+    int hub_i = 0;
+    unsigned int cur_band = (unsigned int)bands.size();   // the band being filled
     for (Index r = 0; r < n; ++r) {
       const bool hub = (hub_bits[r >> 5] >> (r & 31)) & 1u;
       const Index d = hub ? 0 : ptr[(size_t)r + 1] - ptr[r];
@@ -549,8 +584,11 @@ static grb_info prepare_cband(const CsrArrays& M, SpmvPlan& plan) {
         at += in_band;
         in_band = 0;
         r0 = r;
+        ++cur_band;
       }
       in_band += d;
+      row_band[r] = hub ? 0u : cur_band;
+      row_loc[r] = (unsigned short)(hub ? hub_i++ : r - r0);
     }
     bands.push_back(CbBand{r0, n - r0, 0});
     band_start.push_back(at);
@@ -559,17 +597,7 @@ static grb_info prepare_cband(const CsrArrays& M, SpmvPlan& plan) {
     if (at != nnz) return GRB_PANIC;
   }
   const int nbands = (int)bands.size();
-  {
-    int hub_i = 0;
-    for (int b = 0; b < nbands; ++b) {
-      if (bands[b].hub) continue;
-      for (Index r = bands[b].row0; r < bands[b].row0 + bands[b].nrows; ++r) {
-        const bool hub = (hub_bits[r >> 5] >> (r & 31)) & 1u;
-        row_band[r] = hub ? 0u : (unsigned int)b;
-        row_loc[r] = (unsigned short)(hub ? hub_i++ : r - bands[b].row0);
-      }
-    }
-  }
+  mark("bands (host pass)");
 
   // ---- device: keys, sort, segments
   // column codes: the hot prefix of the rank order (<= 512 Ki columns, packed per launch: 6 MB instead of the whole
@@ -590,22 +618,28 @@ static grb_info prepare_cband(const CsrArrays& M, SpmvPlan& plan) {
   unsigned short* d_row_loc = (unsigned short*)upload(row_loc.data(), 2 * (size_t)n, false);
   unsigned long long* d_keys = (unsigned long long*)dalloc(8 * (size_t)nnz, false);
   unsigned int* d_pay = (unsigned int*)dalloc(4 * (size_t)nnz, false);
-  unsigned short* d_eloc = (unsigned short*)dalloc(2 * (size_t)nnz, false);
   if (oom) return GRB_OUT_OF_MEMORY;
-  hipLaunchKernelGGL(cband_keys_kernel, dim3(stream_grid((long long)n * kWave, kBlock)), dim3(kBlock), 0, st, M.ptr, M.ind, n,
-                     (const unsigned int*)d_row_band, (const unsigned short*)d_row_loc, (const Index*)d_rank, d_keys, d_pay,
-                     d_eloc);
+  // key = ((band << colbits | column code) << 16) | row in band; sorted on the bits above the low 16 only
+  // (the column field also has to hold the end of the last 65536-column block: the segment search compares against it)
+  const long long col_span = ((ncols + 65535) / 65536) << 16;
+  const int colbits = cband_bits_for(col_span > ncols ? col_span : ncols), bandbits = cband_bits_for(nbands);
+  if (colbits + bandbits + kCbKeyLow > 64) return GRB_SUCCESS;
+  mark("ranks, uploads, allocations");
+  hipLaunchKernelGGL(cband_keys_kernel, dim3(stream_grid((long long)n * kWave, kBlock)), dim3(kBlock), 0, st, M.ptr, M.ind,
+                     (const unsigned int*)M.val, n, (const unsigned int*)d_row_band, (const unsigned short*)d_row_loc,
+                     (const Index*)d_rank, colbits, d_keys, d_pay);
   GRB_HIP_TRY(hipGetLastError());
   {
-    const grb_info si = device_sort_pairs(d_keys, d_pay, nnz, cband_bits_for(ncols), cband_bits_for(nbands));
+    const grb_info si = device_sort_pairs_range(d_keys, d_pay, nnz, kCbKeyLow, colbits + bandbits);
     if (si != GRB_SUCCESS) return si == GRB_PANIC ? GRB_OUT_OF_MEMORY : si;     // the sort's scratch did not fit
   }
+  mark("keys + sort");
   const int ncb = (int)((ncols + 65535) / 65536);
   long long* d_band_start = (long long*)upload(band_start.data(), 8 * band_start.size(), false);
   long long* d_seg = (long long*)dalloc(8 * (size_t)nbands * (size_t)(ncb + 1), false);
   if (oom) return GRB_OUT_OF_MEMORY;
   hipLaunchKernelGGL(cband_segments_kernel, dim3(ceil_div((long long)nbands * (ncb + 1), kBlock)), dim3(kBlock), 0, st,
-                     (const unsigned long long*)d_keys, (const long long*)d_band_start, nbands, ncb, d_seg);
+                     (const unsigned long long*)d_keys, (const long long*)d_band_start, nbands, ncb, colbits, d_seg);
   GRB_HIP_TRY(hipGetLastError());
   std::vector<long long> seg((size_t)nbands * (size_t)(ncb + 1));
   GRB_HIP_TRY(hipMemcpy(seg.data(), d_seg, 8 * seg.size(), hipMemcpyDeviceToHost));
@@ -646,6 +680,7 @@ static grb_info prepare_cband(const CsrArrays& M, SpmvPlan& plan) {
       }
   }
 
+  mark("segments (device + host)");
   // ---- iso?
   unsigned int iso_out[2] = {0xffffffffu, 0u};
   if (M.val) {
@@ -660,6 +695,7 @@ static grb_info prepare_cband(const CsrArrays& M, SpmvPlan& plan) {
   }
   C->iso = iso_out[0] == iso_out[1];
 
+  mark("iso test");
   // ---- device: the coded entries
   long long* d_seg_entry = (long long*)upload(seg_entry.data(), 8 * seg_entry.size(), false);
   long long* d_seg_group = (long long*)upload(seg_group.data(), 8 * seg_group.size(), false);
@@ -671,11 +707,12 @@ static grb_info prepare_cband(const CsrArrays& M, SpmvPlan& plan) {
   unsigned int* d_gbase = (unsigned int*)dalloc(4 * (size_t)ngroups, true);
   if (oom) return GRB_OUT_OF_MEMORY;
   hipLaunchKernelGGL(cband_emit_kernel, dim3(stream_grid(ngroups * kWave, kBlock)), dim3(kBlock), 0, st,
-                     (const unsigned long long*)d_keys, (const unsigned int*)d_pay, (const unsigned short*)d_eloc,
-                     (const unsigned int*)M.val, (const long long*)d_seg_entry, (const long long*)d_seg_group,
-                     (const unsigned int*)d_seg_base, (const long long*)d_seg_band_g0, nseg, ngroups, d_pack, d_val2, d_gbase);
+                     (const unsigned long long*)d_keys, (const unsigned int*)d_pay, (const long long*)d_seg_entry,
+                     (const long long*)d_seg_group, (const unsigned int*)d_seg_base, (const long long*)d_seg_band_g0, nseg, ngroups,
+                     colbits, d_pack, d_val2, d_gbase);
   GRB_HIP_TRY(hipGetLastError());
 
+  mark("emit");
   // ---- items: the bands' groups form one sequence (hub band first); it is cut into one piece of equal COST per
   // workgroup -- a light band's group costs more than the hub band's: its column-sorted list is sparser, so its
   // gathers touch more lines (GRB_SPMV_TRACE, ticks per group per workgroup: 3.3 against 2.0) -- so every
@@ -770,6 +807,7 @@ static grb_info prepare_cband(const CsrArrays& M, SpmvPlan& plan) {
   if (partial_elems >= (1ll << 31)) return GRB_SUCCESS;
   const int nslots = (int)fin_off.size();
 
+  mark("dealing (host)");
   CbArgs& A = C->args;
   A.bands = (const CbBand*)upload(bands.data(), sizeof(CbBand) * bands.size(), true);
   A.items = (const CbItem*)upload(dealt.data(), sizeof(CbItem) * dealt.size(), true);
@@ -790,6 +828,7 @@ static grb_info prepare_cband(const CsrArrays& M, SpmvPlan& plan) {
   C->partial_elems = partial_elems;
   if (oom) return GRB_OUT_OF_MEMORY;
   GRB_HIP_TRY(hipStreamSynchronize(st));
+  mark("uploads of the tables");
   C->grid = G;
   C->nhot = nhot;
   C->nbands = nbands;
@@ -993,7 +1032,16 @@ grb_info k_spmv(int sr, int dtype, const CsrArrays& M, SpmvPlan& plan, const voi
                 int mask_f32, int scmp, int accum, void* w, const Index* other_ptr) {
   if (plan.ntiles == 0 && M.nvals > 0) return GRB_INVALID_OBJECT;   // nonzeros but no plan: never a silent no-op
   if (plan.ntiles == 0 && plan.nrows == 0) return GRB_SUCCESS;       // nothing to write
-  if (M.nvals > 0 && !plan.hub_ready) GRB_TRY(prepare_hub_packing(M, plan, other_ptr));
+  if (M.nvals > 0 && !plan.hub_ready) {
+    static const bool trace = getenv("GRB_SPMV_PREP_TRACE") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
+    GRB_TRY(prepare_hub_packing(M, plan, other_ptr));
+    if (trace) {
+      (void)hipStreamSynchronize(ctx().stream);
+      fprintf(stderr, "hub packing (column ranks): %8.3f ms\n",
+              std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    }
+  }
   return dispatch_semiring(sr, dtype, [&](auto tag, auto t) -> grb_info {
     using T = decltype(t);
     constexpr int SR = decltype(tag)::value;
@@ -1007,7 +1055,14 @@ grb_info k_spmv(int sr, int dtype, const CsrArrays& M, SpmvPlan& plan, const voi
     if constexpr (cband_monoid_ok<SR>()) {
       if (fmt == 2 || (fmt == 1 && plan.d_order)) {
         if (!plan.cband && !plan.cband_tried && (fmt == 2 || plan.csr_launches >= spmv_reuse_threshold(-1))) {
+          static const bool trace = getenv("GRB_SPMV_PREP_TRACE") != nullptr;
+          const auto t0 = std::chrono::steady_clock::now();
           const grb_info pi = prepare_cband(M, plan);
+          if (trace) {
+            (void)hipStreamSynchronize(ctx().stream);
+            fprintf(stderr, "cband prep, all of it:      %8.3f ms\n",
+                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+          }
           if (pi != GRB_SUCCESS && pi != GRB_OUT_OF_MEMORY) return pi;     // no room for the second copy: CSR it is
           if (plan.cband && plan.d_ind2 && fmt == 1) {      // the CSR kernel's renamed column ids are not needed any more
             GRB_HIP_TRY(hipStreamSynchronize(ctx().stream));

@@ -97,39 +97,43 @@ inline void free_spmv_cband(SpmvCBand* b) {
 }
 
 // ---- preparation kernels ---------------------------------------------------------------------------------------
-// key of entry p: (band of its row) << 32 | rank of its column; payload p; and the row's position inside its band
+// The sort key of entry p:  ((band of its row) << colbits | code of its column) << 16 | the row's position inside its band.
+// Only the bits above the low 16 are sorted on; the position rides along, and the payload is the entry's VALUE -- what
+// the emit pass needs is then in the sorted arrays themselves, read front to back (the first version sorted entry
+// indices and gathered position and value through them afterwards: 16 GB of line fetches for RMAT-22).
+constexpr int kCbKeyLow = 16;
 __global__ __launch_bounds__(kBlock) void cband_keys_kernel(const Index* __restrict__ ptr, const Index* __restrict__ ind,
+                                                            const unsigned int* __restrict__ val /* nullable */,
                                                             Index n, const unsigned int* __restrict__ row_band,
                                                             const unsigned short* __restrict__ row_loc,
                                                             const Index* __restrict__ rank /* nullable: natural order */,
-                                                            unsigned long long* __restrict__ keys,
-                                                            unsigned int* __restrict__ pay, unsigned short* __restrict__ eloc) {
+                                                            int colbits, unsigned long long* __restrict__ keys,
+                                                            unsigned int* __restrict__ pay) {
   const int lane = lane_id();
   const Index nwaves = (Index)gridDim.x * kWavesPerBlock;
   for (Index r = (Index)blockIdx.x * kWavesPerBlock + wave_id(); r < n; r += nwaves) {
-    const unsigned long long hi = (unsigned long long)row_band[r] << 32;
-    const unsigned short loc = row_loc[r];
+    const unsigned long long hi = (unsigned long long)row_band[r] << colbits;
+    const unsigned long long loc = (unsigned long long)row_loc[r];
     const Index e = ptr[r + 1];
     for (Index p = ptr[r] + lane; p < e; p += kWave) {
       const Index c = ind[p];
-      keys[p] = hi | (unsigned long long)(unsigned int)(rank ? rank[c] : c);
-      pay[p] = (unsigned int)p;
-      eloc[p] = loc;
+      keys[p] = ((hi | (unsigned long long)(unsigned int)(rank ? rank[c] : c)) << kCbKeyLow) | loc;
+      pay[p] = val ? val[p] : 0u;
     }
   }
 }
 
 // first sorted position of every (band, 65536-column block): out[b * (ncb + 1) + cb]
 __global__ void cband_segments_kernel(const unsigned long long* __restrict__ keys, const long long* __restrict__ band_start,
-                                      int nbands, int ncb, long long* __restrict__ out) {
+                                      int nbands, int ncb, int colbits, long long* __restrict__ out) {
   const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= (long long)nbands * (ncb + 1)) return;
   const int b = (int)(t / (ncb + 1)), cb = (int)(t % (ncb + 1));
   long long lo = band_start[b], hi = band_start[b + 1];
-  const unsigned long long want = ((unsigned long long)(unsigned)b << 32) | ((unsigned long long)cb << 16);
+  const unsigned long long want = ((unsigned long long)(unsigned)b << colbits) + ((unsigned long long)cb << 16);
   while (lo < hi) {
     const long long mid = (lo + hi) >> 1;
-    if (keys[mid] < want) lo = mid + 1; else hi = mid;
+    if ((keys[mid] >> kCbKeyLow) < want) lo = mid + 1; else hi = mid;
   }
   out[t] = lo;
 }
@@ -140,16 +144,15 @@ __global__ void cband_segments_kernel(const unsigned long long* __restrict__ key
 // still covers the 64 consecutive entries of group k (few lines) and the group's base is wave-uniform.
 __global__ __launch_bounds__(kBlock) void cband_emit_kernel(const unsigned long long* __restrict__ keys,
                                                             const unsigned int* __restrict__ pay,
-                                                            const unsigned short* __restrict__ eloc,
-                                                            const unsigned int* __restrict__ val /* nullable */,
                                                             const long long* __restrict__ seg_entry /* [nseg + 1] */,
                                                             const long long* __restrict__ seg_group /* [nseg + 1] */,
                                                             const unsigned int* __restrict__ seg_base,
                                                             const long long* __restrict__ seg_band_g0 /* first group of the segment's band */,
-                                                            int nseg, long long ngroups, unsigned int* __restrict__ pack,
+                                                            int nseg, long long ngroups, int colbits, unsigned int* __restrict__ pack,
                                                             unsigned int* __restrict__ val2, unsigned int* __restrict__ gbase) {
   const int lane = lane_id();
   const long long nwaves = (long long)gridDim.x * kWavesPerBlock;
+  const unsigned long long colmask = (1ull << colbits) - 1ull;
   for (long long g = (long long)blockIdx.x * kWavesPerBlock + wave_id(); g < ngroups; g += nwaves) {
     int lo = 0, hi = nseg - 1;                         // last segment whose first group is <= g
     while (lo < hi) {
@@ -162,9 +165,9 @@ __global__ __launch_bounds__(kBlock) void cband_emit_kernel(const unsigned long 
     const bool valid = g - seg_group[lo] < seg_groups && q < seg_entry[lo + 1];
     unsigned int pk = kCbPad, v = 0;
     if (valid) {
-      const unsigned int p = pay[q];
-      pk = (((unsigned int)(keys[q] & 0xffffffffull) - seg_base[lo]) << 16) | (unsigned int)eloc[p];
-      if (val) v = val[p];
+      const unsigned long long key = keys[q];
+      pk = (((unsigned int)((key >> kCbKeyLow) & colmask) - seg_base[lo]) << 16) | (unsigned int)(key & 0xffffull);
+      if (val2) v = pay[q];
     }
     const long long rel = g - seg_band_g0[lo];
     const long long at = (seg_band_g0[lo] + (rel & ~3ll)) * kWave + (long long)lane * 4 + (rel & 3ll);
