@@ -14,7 +14,8 @@ if kept_w and os.path.exists(dst + '/other_workloads.jsonl'):
         for W, key in (("lj_bfs", "soc-L"), ("road_sssp", "road"), ("orkut_tc", "rkut")):
             if key in json.loads(ln).get("metric", "") + json.dumps(json.loads(ln).get("config", {})):
                 prev_lines.setdefault(W, ln)
-keep_prefixes = ("full_suite", "bfs_ab", "tests_") + tuple(kept_w) + tuple("pmc_%s_" % W for W in kept_w)
+keep_prefixes = ("full_suite", "bfs_", "tests_", "sssp_", "tc_", "spmv_", "orkut_tc_kernel_stats_before") + tuple(kept_w) + \
+    tuple("pmc_%s_" % W for W in kept_w)
 for f in os.listdir(dst):
     if not f.startswith(keep_prefixes):     # logs of test / A-B runs kept beside the profiles
         os.remove(os.path.join(dst, f))
@@ -45,11 +46,15 @@ if os.path.exists(trace):
                     "spmv_long_finalize_kernel"):
             if key in r["kernel"]:
                 spmv.setdefault(key, []).append(int(r["duration_ns"]))
+    # since round 5: the K timed (queued) steps are followed by min(warmup, 2) blocking warm-ups and the K steps of the
+    # blocking loop; the HIP-event pass comes after those
+    E = W + K + (min(line["warmup"], 2) + K if "blocking_loop" in line else 0)
     ph = {"source": "rocprofv3 --kernel-trace of the default `python bench.py` (same run as bench_kernel_stats_*.csv)",
           "warmup": W, "steps": K, "bfs_persistent_kernel_launches": len(bfs),
           "bfs_persistent_kernel_mean_us": {
               "timed_region_launches_W_to_W+K": round(sum(bfs[W:W + K]) / K / 1e3, 2),
-              "hip_event_pass_launches_W+K_to_W+2K": round(sum(bfs[W + K:W + 2 * K]) / K / 1e3, 2),
+              "hip_event_pass_launches": round(sum(bfs[E:E + K]) / K / 1e3, 2),
+              "hip_event_pass_first_launch_index": E,
               "all_launches_of_the_run": round(sum(bfs) / len(bfs) / 1e3, 2)},
           "hip_event_mean_us_reported_by_bench": round(line["roofline"]["avg_launch_ms"] * 1e3, 2),
           "spmv_kernels_mean_us": {k: round(sum(v) / len(v) / 1e3, 2) for k, v in spmv.items()},
