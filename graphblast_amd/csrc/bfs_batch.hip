@@ -75,11 +75,7 @@ struct LabelArgs {
   float* label[64];
 };
 
-__device__ inline u64 wave_or(u64 x) {
-#pragma unroll
-  for (int o = kWave / 2; o > 0; o >>= 1) x |= __shfl_xor(x, o, kWave);
-  return x;
-}
+__device__ inline u64 wave_or(u64 x) { return wave_or_u64(x); }   // DPP (common.hpp): twelve LDS-crossbar permutes otherwise
 
 struct BatchTotals {                  // per workgroup, in LDS
   u64 v[kBatchCounters];
@@ -132,8 +128,7 @@ __device__ inline void batch_commit_l(const BatchArgs& a, WaveTotals& acc, Index
   }
   acc.nf += (u64)__popcll(m);
   unsigned int dor = deg;
-#pragma unroll
-  for (int o = kWave / 2; o > 0; o >>= 1) dor |= __shfl_xor(dor, o, kWave);
+  dor = wave_or_u32(dor);
   for (unsigned int t = dor; t; t &= t - 1) {
     const int b = __builtin_amdgcn_readfirstlane(__ffs((int)t) - 1);
     const unsigned long long plane = __ballot((deg >> b) & 1u);
@@ -923,8 +918,7 @@ inc = (Index)wave_incl_scan_u32((unsigned)inc);
     totals_flush_to(st->slots[j % 3], &lds, tot);          // per source: read by workgroup 0 when the launch ends, by nobody else
     if (threadIdx.x < kWave) {                             // what everybody needs: the level's pairs and their out-edges
       u64 np = lds.v[2 + 2 * lane], ne = lds.v[3 + 2 * lane];
-#pragma unroll
-      for (int o = kWave / 2; o > 0; o >>= 1) { np += __shfl_xor(np, o, kWave); ne += __shfl_xor(ne, o, kWave); }
+      np = wave_sum_u64(np); ne = wave_sum_u64(ne);
       if (lane == 0 && np) {
         atomicAdd(&st->dec[j % 3][blockIdx.x & 7][0], np);
         atomicAdd(&st->dec[j % 3][blockIdx.x & 7][1], ne);

@@ -341,6 +341,19 @@ __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
   return (unsigned long long)wave_sum_u32(lo & 0xffffu) + ((unsigned long long)wave_sum_u32(lo >> 16) << 16) +
          ((unsigned long long)wave_sum_u32(hi) << 32);
 }
+// bitwise OR of a wave's 64 values, in every lane
+__device__ __forceinline__ unsigned wave_or_u32(unsigned v) {
+  unsigned t = v | __builtin_amdgcn_update_dpp(0u, v, 0x111, 0xf, 0xf, false) | __builtin_amdgcn_update_dpp(0u, v, 0x112, 0xf, 0xf, false) |
+               __builtin_amdgcn_update_dpp(0u, v, 0x113, 0xf, 0xf, false);
+  t |= __builtin_amdgcn_update_dpp(0u, t, 0x114, 0xf, 0xe, false);
+  t |= __builtin_amdgcn_update_dpp(0u, t, 0x118, 0xf, 0xc, false);
+  t |= __builtin_amdgcn_update_dpp(0u, t, 0x142, 0xa, 0xf, false);
+  t |= __builtin_amdgcn_update_dpp(0u, t, 0x143, 0xc, 0xf, false);
+  return (unsigned)__builtin_amdgcn_readlane((int)t, 63);
+}
+__device__ __forceinline__ unsigned long long wave_or_u64(unsigned long long v) {
+  return ((unsigned long long)wave_or_u32((unsigned)(v >> 32)) << 32) | (unsigned long long)wave_or_u32((unsigned)v);
+}
 // min / max of a wave's 64 values, in every lane: the same shifts with v_min / v_max (a lane without a source reads
 // the operation's identity)
 __device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
