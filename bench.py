@@ -421,6 +421,7 @@ def main():
     ap.add_argument("--extras", action="store_true",
                     help="also time the SpMV kernel on a road-like grid (launches the SpMV kernels of the main "
                          "measurement again: would mix into a rocprof average of this command)")
+    ap.add_argument("--no-lanes", action="store_true", help="skip the timing of the K steps with two traversals in flight")
     ap.add_argument("--no-batch", action="store_true",
                     help="skip the multi-frontier measurements (64-source sweep, sparse x dense mxm)")
     ap.add_argument("--partitioned", action="store_true",
@@ -550,6 +551,31 @@ def main():
                                                      "median": round(float(np.median(done_ms[1:])), 4) if args.steps > 1 else None,
                                                      "max": round(float(done_ms[1:].max()), 4) if args.steps > 1 else None},
                            "until_first_record_ms": round(float(done_ms[0]), 4)}
+        # ---- the same K steps with several traversals in flight (grb_bfs_set_lanes: n lanes of CUs / n workgroups each;
+        #      a traversal is two thirds barriers and latency chains that more CUs do not shorten).  A sibling of `value`,
+        #      not `value`: there every traversal has the whole device.  Labels of the last step compared below.
+        if not args.no_lanes:
+            lane_runs = {}
+            for nl in (2,):
+                g.bfs_set_lanes(nl)
+                run_queued(max(args.warmup, nl))
+                barrier()
+                t0l = time.perf_counter()
+                rl = run_queued(args.steps)
+                barrier()
+                ell = time.perf_counter() - t0l
+                assert [r_["reached"] for r_ in rl] == [r_["reached"] for r_ in results]
+                lane_runs[nl] = {"value": sum(r_["edges_traversed"] for r_ in rl) / ell, "ms_per_step": round(ell / args.steps * 1e3, 5),
+                                 "kernel_clock_ms_mean": round(float(np.mean([r_["tight_ms"] for r_ in rl])), 4)}
+            g.bfs_set_lanes(1)
+            extra["lanes"] = {"what": "K queued steps, two traversals in flight (grb_bfs_set_lanes(2): two streams, launches of CUs / 2 "
+                                      "workgroups); per-traversal results identical; unit TEPS.  Not `value`: there every traversal "
+                                      "has the whole device.  (Four lanes measured between 0.073 and 0.33 ms per step depending on how "
+                                      "the runtime maps streams to hardware queues: tools/bfs_lanes_bench.py)",
+                              "2": lane_runs[2]}
+            run_queued(2)                                         # back on one lane: the vectors hold single-lane results again
+            results_check = run_queued(args.steps)
+            assert [r_["reached"] for r_ in results_check] == [r_["reached"] for r_ in results]
         # the labels the queued steps left are checked below (parity block) through vs[...]; the blocking sibling:
         for i in range(min(args.warmup, 2)):
             run_step(i)

@@ -487,6 +487,11 @@ def bfs_wait(ticket):
                       reached=res.reached, per_level=[])
 
 
+def bfs_set_lanes(n=-1):
+    """grb_bfs_set_lanes: traversals in flight at once for bfs_enqueue (n < 1 only queries); returns the previous value."""
+    return int(_lib.load().grb_bfs_set_lanes(int(n)))
+
+
 def bfs_host_times(reset=False):
     """Host microseconds spent queueing / waiting inside the one-launch traversal since the last reset, and the calls."""
     e, w, n = C.c_double(0), C.c_double(0), C.c_longlong(0)

@@ -118,7 +118,7 @@ static int g_persistent_failures = 0;   // three barrier give-ups in a row (each
 // traversals waits for the host, so a host that is slow, descheduled or busy (the per-level host round trips of
 // bfs.hpp:42-88 are the extreme case) costs nothing as long as it queues faster than the device traverses.
 extern "C" grb_info grb_bfs_fused_enqueue(grb_vector v, grb_matrix A, grb_index source, grb_descriptor desc,
-                                          grb_bfs_ticket* ticket) { GRB_API_ENTER();
+                                          grb_bfs_ticket* ticket) { GRB_API_ENTER_BFSQ();
   if (!ticket) return GRB_NULL_POINTER;
   *ticket = 0;
   if (!v || !A || !desc) return GRB_UNINITIALIZED_OBJECT;
@@ -152,7 +152,7 @@ extern "C" grb_info grb_bfs_fused_enqueue(grb_vector v, grb_matrix A, grb_index 
   return GRB_SUCCESS;
 }
 
-extern "C" grb_info grb_bfs_wait(grb_bfs_ticket ticket, grb_bfs_result* result) { GRB_API_ENTER();
+extern "C" grb_info grb_bfs_wait(grb_bfs_ticket ticket, grb_bfs_result* result) { GRB_API_ENTER_BFSQ();
   const int slot = (int)(ticket & 0xff), seq = (int)(ticket >> 8);
   grb_vector v = nullptr; grb_matrix A = nullptr; grb_descriptor desc = nullptr; grb_index source = 0;
   grb_bfs_result parked = {};
@@ -181,6 +181,13 @@ extern "C" grb_info grb_bfs_wait(grb_bfs_ticket ticket, grb_bfs_result* result) 
   GRB_TRY(pi);
   g_persistent_failures = 0;
   return bfs_one_launch_finish(v, A, desc, p_levels, p_dir, p_reached, p_edges, p_nf, p_cap, p_ms, result);
+}
+
+// Traversals in flight at once: with n > 1 the traversals queued by grb_bfs_fused_enqueue go round n lanes, each lane a
+// stream of its own whose launches take num_cu / n workgroups, so that n launches are resident together.  n < 1 only
+// queries.  Returns the previous value.
+extern "C" int grb_bfs_set_lanes(int n) { GRB_API_ENTER_NOINFO();
+  return bfs_lanes_setting(n);
 }
 
 // Host time spent inside the one-launch traversal's two halves since the last reset: queueing the launches

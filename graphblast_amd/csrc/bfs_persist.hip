@@ -1006,13 +1006,34 @@ constexpr int kRing = 256;                       // records (= traversals in fli
 struct BfsTicket {
   int state = 0;                                 // 0 free, 1 in flight, 2 already complete (ran synchronously)
   int seq = 0;
+  int lane = 0;
   grb_vector v = nullptr;
   grb_matrix A = nullptr;
   grb_descriptor desc = nullptr;
   grb_index source = 0;
   grb_bfs_result res = {};
 };
+// A lane = what one traversal in flight needs for itself: a stream, the two state blocks, V1, the big-vertex list, the
+// level records, the level-count word.  Lane 0 is the library's own stream and scratch slots (the blocking call's path,
+// and the only lane unless grb_bfs_set_lanes asks for more); lanes 1.. own their memory.  With L lanes a queued
+// traversal runs on num_cu / L workgroups, and L of them are resident at once: a traversal is latency and barriers for
+// two thirds of its time (section 5 of DESIGN.md), so two on half the device each finish in 1.4 x the time of one on
+// all of it, four in 2 x.
+constexpr int kMaxLanes = 8;
+struct BfsLane {
+  hipStream_t stream = nullptr;
+  hipEvent_t ev_in = nullptr, ev_done = nullptr;
+  void *zero = nullptr, *v1 = nullptr, *big = nullptr, *rec = nullptr;
+  size_t zero_cap = 0, v1_cap = 0, big_cap = 0, rec_cap = 0;
+  size_t clean_bytes = 0;                        // zero_bytes the blocks were last cleared for (0: not clean)
+  unsigned int* d_levels = nullptr;
+  int block = 0;
+  unsigned long long fenced_epoch = ~0ull;       // ApiScope::epoch when this lane last fenced against the library's stream
+};
 struct BfsRing {
+  BfsLane lane[kMaxLanes + 1];                   // [0]: the library's stream (blocking calls, one lane); [1 ..]: the lanes proper
+  int lanes = 1, next_lane = 0;
+  bool lanes_active = false;                     // the launch being queued is one of several in flight (set around enqueue)
   unsigned long long* h = nullptr;               // pinned, host-coherent: kRing x 8 granules {value, seq}
   unsigned long long* d = nullptr;               // the device-side address of h
   unsigned int* d_levels = nullptr;              // device word: the last traversal's level count (PersistArgs::dev_levels)
@@ -1063,11 +1084,29 @@ grb_info ring_wait(int slot, int seq, unsigned int* out) {
 
 // Queues one traversal on the library's stream; its record will appear in ring slot `slot` under
 // tag *seq_out.
+static grb_info lane_buffer(void** p, size_t* cap, size_t bytes, hipStream_t s) {
+  if (*cap >= bytes) return GRB_SUCCESS;
+  if (*p) { GRB_HIP_TRY(hipStreamSynchronize(s)); (void)hipFree(*p); *p = nullptr; *cap = 0; }
+  const size_t want = (bytes + bytes / 4 + 255) & ~(size_t)255;
+  GRB_HIP_TRY(hipMalloc(p, want));
+  *cap = want;
+  return GRB_SUCCESS;
+}
+
 static grb_info bfs_persistent_launch(grb_vector v, grb_matrix A, grb_index source, grb_descriptor desc, int profile, int slot,
-                                      int* seq_out, void** p_rec_out, unsigned long long** trace_out) {
+                                      int* seq_out, void** p_rec_out, unsigned long long** trace_out, int lane_id = 0) {
   GRB_TRY(ring_init());
   Context& c = ctx();
-  hipStream_t s = c.stream;
+  BfsLane& ln = g_ring.lane[lane_id];
+  if (lane_id > 0 && !ln.stream) {
+    GRB_HIP_TRY(hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking));
+    GRB_HIP_TRY(hipEventCreateWithFlags(&ln.ev_in, hipEventDisableTiming));
+    GRB_HIP_TRY(hipEventCreateWithFlags(&ln.ev_done, hipEventDisableTiming));
+    GRB_HIP_TRY(hipMalloc((void**)&ln.d_levels, 256));
+    GRB_HIP_TRY(hipMemset(ln.d_levels, 0, 256));
+  }
+  hipStream_t s = lane_id > 0 ? ln.stream : c.stream;
+  unsigned int* d_levels = lane_id > 0 ? ln.d_levels : g_ring.d_levels;
   const Index n = A->nrows;
   const int nwords = 2 * ceil_div(n, 64);
   int wgs_per_cu = 1;
@@ -1078,7 +1117,9 @@ static grb_info bfs_persistent_launch(grb_vector v, grb_matrix A, grb_index sour
     if (max_per_cu < 1) return GRB_PANIC;
   }
   if (wgs_per_cu > max_per_cu) wgs_per_cu = max_per_cu;
-  const int G = c.num_cu * wgs_per_cu;
+  // lanes > 1: a queued traversal takes its share of the CUs (the blocking call, lane 0 alone, the whole device)
+  const int G = (g_ring.lanes > 1 && profile == 0 && lane_id >= 0 && g_ring.lanes_active) ? (c.num_cu / g_ring.lanes > 0 ? c.num_cu / g_ring.lanes : 1)
+                                                                                          : c.num_cu * wgs_per_cu;
   const int rec_cap = 1 << 15;
   const int big_cap = (int)(A->nvals / kBigDeg) + 2;
 
@@ -1087,18 +1128,34 @@ static grb_info bfs_persistent_launch(grb_vector v, grb_matrix A, grb_index sour
   const size_t block_bytes = (st_bytes + 4 * (size_t)(1 + kKeep + 3) * (size_t)nwords + 255) & ~(size_t)255;
   const size_t zero_bytes = 2 * block_bytes;
   void *p_zero, *p_v1, *p_big, *p_rec;
-  GRB_TRY(scratch(7, zero_bytes, &p_zero));
-  GRB_TRY(scratch(8, 4 * (size_t)nwords, &p_v1));
-  GRB_TRY(scratch(2, sizeof(int2) * (size_t)big_cap, &p_big));
-  GRB_TRY(scratch(11, sizeof(grb_bfs_level) * (size_t)rec_cap, &p_rec));
-  // both blocks are clear (and the level-count word says "nothing to clear") when somebody else has had the slot
-  if (c.bfs_prezero_ptr != p_zero || c.bfs_prezero_bytes != zero_bytes) {
-    GRB_HIP_TRY(hipMemsetAsync(p_zero, 0, zero_bytes, s));
-    GRB_HIP_TRY(hipMemsetAsync(g_ring.d_levels, 0, 4, s));
-    g_ring.block = 0;
+  int* p_blocksel = lane_id > 0 ? &ln.block : &g_ring.block;
+  if (lane_id == 0) {
+    GRB_TRY(scratch(7, zero_bytes, &p_zero));
+    GRB_TRY(scratch(8, 4 * (size_t)nwords, &p_v1));
+    GRB_TRY(scratch(2, sizeof(int2) * (size_t)big_cap, &p_big));
+    GRB_TRY(scratch(11, sizeof(grb_bfs_level) * (size_t)rec_cap, &p_rec));
+    // both blocks are clear (and the level-count word says "nothing to clear") when somebody else has had the slot
+    if (c.bfs_prezero_ptr != p_zero || c.bfs_prezero_bytes != zero_bytes) {
+      GRB_HIP_TRY(hipMemsetAsync(p_zero, 0, zero_bytes, s));
+      GRB_HIP_TRY(hipMemsetAsync(g_ring.d_levels, 0, 4, s));
+      g_ring.block = 0;
+    }
+    c.bfs_prezero_ptr = nullptr;
+  } else {
+    const size_t had = ln.zero_cap;
+    GRB_TRY(lane_buffer(&ln.zero, &ln.zero_cap, zero_bytes, s));
+    GRB_TRY(lane_buffer(&ln.v1, &ln.v1_cap, 4 * (size_t)nwords, s));
+    GRB_TRY(lane_buffer(&ln.big, &ln.big_cap, sizeof(int2) * (size_t)big_cap, s));
+    GRB_TRY(lane_buffer(&ln.rec, &ln.rec_cap, sizeof(grb_bfs_level) * (size_t)rec_cap, s));
+    p_zero = ln.zero; p_v1 = ln.v1; p_big = ln.big; p_rec = ln.rec;
+    if (had != ln.zero_cap || ln.clean_bytes != zero_bytes) {     // new memory, or a graph of another size: clear both blocks
+      GRB_HIP_TRY(hipMemsetAsync(p_zero, 0, zero_bytes, s));
+      GRB_HIP_TRY(hipMemsetAsync(ln.d_levels, 0, 4, s));
+      ln.block = 0;
+    }
+    ln.clean_bytes = 0;
   }
-  c.bfs_prezero_ptr = nullptr;
-  char* p_block = (char*)p_zero + (size_t)g_ring.block * block_bytes;
+  char* p_block = (char*)p_zero + (size_t)(*p_blocksel) * block_bytes;
   void* p_st = p_block;
   unsigned int* p_v0 = (unsigned int*)(p_block + st_bytes);
 
@@ -1149,21 +1206,48 @@ static grb_info bfs_persistent_launch(grb_vector v, grb_matrix A, grb_index sour
   {
     const char* e = getenv("GRB_BFS_OC_MIN");              // frontier out-edges from which a push level uses it; 0 = off
     const long long oc_min = e ? atoll(e) : 262144;
-    if (oc_min > 0 && A->oc_state == 0) {
-      A->oc_state = -1;
-      if (A->nvals > 0 && (Index)A->h_csr_ptr.size() == n + 1) {
-        GRB_TRY(oc_tables_build(A->csr.ptr, A->csr.ind, A->h_csr_ptr, n, n, G, &A->d_oc_bounds, &A->d_oc_off, &A->d_oc_bigidx,
-                                &A->oc_nb, &A->oc_nrows));
-        if (A->d_oc_off) A->oc_state = 1;
+    const bool narrow = G != c.num_cu * wgs_per_cu;        // a lane's grid: its own tables (the ranges are cut per workgroup)
+    if (!narrow) {
+      if (oc_min > 0 && A->oc_state == 0) {
+        A->oc_state = -1;
+        if (A->nvals > 0 && (Index)A->h_csr_ptr.size() == n + 1) {
+          GRB_TRY(oc_tables_build(A->csr.ptr, A->csr.ind, A->h_csr_ptr, n, n, G, &A->d_oc_bounds, &A->d_oc_off, &A->d_oc_bigidx,
+                                  &A->oc_nb, &A->oc_nrows));
+          if (A->d_oc_off) A->oc_state = 1;
+        }
       }
-    }
-    if (oc_min > 0 && A->oc_state == 1) {
-      a.oc_bounds = A->d_oc_bounds;
-      a.oc_off = A->d_oc_off;
-      a.oc_bigidx = A->d_oc_bigidx;
-      a.oc_nb = A->oc_nb;
-      a.oc_nrows = A->oc_nrows;
-      a.oc_min_edges = (unsigned long long)oc_min;
+      if (oc_min > 0 && A->oc_state == 1) {
+        a.oc_bounds = A->d_oc_bounds;
+        a.oc_off = A->d_oc_off;
+        a.oc_bigidx = A->d_oc_bigidx;
+        a.oc_nb = A->oc_nb;
+        a.oc_nrows = A->oc_nrows;
+        a.oc_min_edges = (unsigned long long)oc_min;
+      }
+    } else {
+      if (oc_min > 0 && (A->oc2_state == 0 || A->oc2_grid != G)) {
+        if (A->d_oc2_bounds || A->d_oc2_off || A->d_oc2_bigidx) {
+          GRB_HIP_TRY(hipDeviceSynchronize());               // (traversals of other lanes may be reading the old tables)
+          (void)hipFree(A->d_oc2_bounds); (void)hipFree(A->d_oc2_off); (void)hipFree(A->d_oc2_bigidx);
+          A->d_oc2_bounds = nullptr; A->d_oc2_off = nullptr; A->d_oc2_bigidx = nullptr;
+        }
+        A->oc2_state = -1;
+        A->oc2_grid = G;
+        if (A->nvals > 0 && (Index)A->h_csr_ptr.size() == n + 1) {
+          GRB_TRY(oc_tables_build(A->csr.ptr, A->csr.ind, A->h_csr_ptr, n, n, G, &A->d_oc2_bounds, &A->d_oc2_off, &A->d_oc2_bigidx,
+                                  &A->oc2_nb, &A->oc2_nrows));
+          if (A->d_oc2_off) A->oc2_state = 1;
+          GRB_HIP_TRY(hipStreamSynchronize(c.stream));       // (built on the library's stream; the lanes read them)
+        }
+      }
+      if (oc_min > 0 && A->oc2_state == 1) {
+        a.oc_bounds = A->d_oc2_bounds;
+        a.oc_off = A->d_oc2_off;
+        a.oc_bigidx = A->d_oc2_bigidx;
+        a.oc_nb = A->oc2_nb;
+        a.oc_nrows = A->oc2_nrows;
+        a.oc_min_edges = (unsigned long long)oc_min;
+      }
     }
   }
   a.st = (PersistState*)p_st;
@@ -1171,8 +1255,8 @@ static grb_info bfs_persistent_launch(grb_vector v, grb_matrix A, grb_index sour
   a.rec_cap = rec_cap;
   a.mail = g_ring.d + 8 * (size_t)slot;
   a.seq = ++c.mail_seq;
-  a.dev_levels = g_ring.d_levels;
-  a.clean = (uint4*)((char*)p_zero + (size_t)(g_ring.block ^ 1) * block_bytes);
+  a.dev_levels = d_levels;
+  a.clean = (uint4*)((char*)p_zero + (size_t)((*p_blocksel) ^ 1) * block_bytes);
   a.st_bytes = (unsigned long long)st_bytes;
   a.ticks_to_ms = ticks_to_ms;
   *seq_out = a.seq;
@@ -1189,6 +1273,13 @@ static grb_info bfs_persistent_launch(grb_vector v, grb_matrix A, grb_index sour
   }
 
 
+  // whatever OTHER entry points have queued on the library's stream since this lane last looked (a fill of v, a build of
+  // A) comes first; the traversal queue's own calls do not count -- lane 0's traversals live on that stream
+  if (lane_id > 0 && ln.fenced_epoch != ApiScope::epoch) {
+    GRB_HIP_TRY(hipEventRecord(ln.ev_in, c.stream));
+    GRB_HIP_TRY(hipStreamWaitEvent(s, ln.ev_in, 0));
+    ln.fenced_epoch = ApiScope::epoch;
+  }
   if (profile & 1) GRB_HIP_TRY(hipEventRecord(c.ev0, s));
   // The grid barrier needs every workgroup resident at once.  GRB_BFS_COOPERATIVE=1 asks the runtime to
   // guarantee that (hipLaunchCooperativeKernel fails fast when it cannot); the default launch relies on the
@@ -1209,10 +1300,15 @@ static grb_info bfs_persistent_launch(grb_vector v, grb_matrix A, grb_index sour
     GRB_HIP_TRY(hipGetLastError());
   }
   if (profile & 1) GRB_HIP_TRY(hipEventRecord(c.ev1, s));
-  // the next traversal runs on the other block and clears this one
-  g_ring.block ^= 1;
-  c.bfs_prezero_ptr = p_zero;
-  c.bfs_prezero_bytes = zero_bytes;
+  // the next traversal (of this lane) runs on the other block and clears this one
+  *p_blocksel ^= 1;
+  if (lane_id == 0) {
+    c.bfs_prezero_ptr = p_zero;
+    c.bfs_prezero_bytes = zero_bytes;
+  } else {
+    ln.clean_bytes = zero_bytes;
+    GRB_HIP_TRY(hipEventRecord(ln.ev_done, s));             // what the library's stream waits for before it touches v
+  }
   return GRB_SUCCESS;
 }
 
@@ -1232,6 +1328,7 @@ static grb_info bfs_persistent_collect(int slot, int seq, int profile, void* p_r
       // the kernel left early (its barrier gave up) without leaving its level count: the next launch cleared too little
       // of this block, and every traversal queued since ran on whatever that left
       c.bfs_prezero_ptr = nullptr;
+      for (int l = 1; l <= kMaxLanes; ++l) g_ring.lane[l].clean_bytes = 0;
       g_ring.poisoned_upto = c.mail_seq;
       return wi;
     }
@@ -1300,12 +1397,34 @@ grb_info grb::bfs_persistent_enqueue(grb_vector v, grb_matrix A, grb_index sourc
   void* p_rec = nullptr;
   unsigned long long* trace = nullptr;
   const auto t0 = std::chrono::steady_clock::now();
-  GRB_TRY(bfs_persistent_launch(v, A, source, desc, 0, slot, seq, &p_rec, &trace));
+  GRB_TRY(ring_init());
+  // lanes: the queued traversals go round the lanes, each lane's launches in order on its own stream
+  // (lane 0 is the library's stream -- measured: with it as one of the lanes four launches overlap, with four created
+  // streams only two or three do, whatever GPU_MAX_HW_QUEUES says)
+  int lane = 0;
+  if (g_ring.lanes > 1) { lane = g_ring.next_lane; g_ring.next_lane = (g_ring.next_lane + 1) % g_ring.lanes; }
+  g_ring.lanes_active = g_ring.lanes > 1;
+  const grb_info li = bfs_persistent_launch(v, A, source, desc, 0, slot, seq, &p_rec, &trace, lane);
+  g_ring.lanes_active = false;
+  GRB_TRY(li);
   g_ring.enqueue_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
   ++g_ring.calls;
   BfsTicket& t = g_ring.t[slot];
-  t.state = 1; t.seq = *seq; t.v = v; t.A = A; t.desc = desc; t.source = source;
+  t.state = 1; t.seq = *seq; t.lane = lane; t.v = v; t.A = A; t.desc = desc; t.source = source;
   return GRB_SUCCESS;
+}
+// Traversals in flight at once (1 .. 8): n lanes of num_cu / n workgroups each.  Everything queued so far is waited for
+// first (a launch needs its whole grid resident: lanes of different widths must not meet).  Returns the previous value.
+int grb::bfs_lanes_setting(int set) {
+  const int before = g_ring.lanes;
+  if (set >= 1 && set != before) {
+    (void)hipDeviceSynchronize();
+    int l = 1;
+    while (2 * l <= set && 2 * l <= kMaxLanes) l *= 2;     // powers of two: a grid of num_cu / 3 workgroups measured 3 x slower per launch
+    g_ring.lanes = l;
+    g_ring.next_lane = 0;
+  }
+  return before;
 }
 // A traversal that ran synchronously (a path the ring does not serve) parks its result in a ticket all the same.
 void grb::bfs_ticket_store(int slot, int seq, const grb_bfs_result& res) {
@@ -1330,6 +1449,11 @@ grb_info grb::bfs_persistent_wait(int slot, int seq, int* levels, int* last_dir,
   const auto t0 = std::chrono::steady_clock::now();
   const grb_info r = bfs_persistent_collect(slot, seq, 0, nullptr, nullptr, nullptr, 0, levels, last_dir, reached, edges, nf_left,
                                             hit_cap, tight_ms);
+  // a lane's launch is not ordered against the library's stream by itself: whatever is queued there from now on
+  // (reading the labels, say) waits for the lane's last launch -- the record is written by ONE workgroup's last
+  // instruction, others may still be storing labels
+  const int lane = g_ring.t[slot].lane;
+  if (r == GRB_SUCCESS && lane > 0 && g_ring.lane[lane].ev_done) (void)hipStreamWaitEvent(ctx().stream, g_ring.lane[lane].ev_done, 0);
   g_ring.wait_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
   return r;
 }

@@ -600,8 +600,10 @@ enum { LZ_ADD_VV = 0, LZ_MULT_VV, LZ_ADD_VS, LZ_MULT_VS, LZ_DUP, LZ_ASSIGN /* u 
 // below are shared state).  depth counts the nesting of entry points on the thread that holds the lock.
 struct ApiScope {
   static int depth;
+  static unsigned long long epoch;   // top-level entries so far, the traversal queue's own calls excepted (bfs_persist.hip:
+                                     // a lane fences against the library's stream only when something else has been called)
   bool entered_ = false;
-  grb_info enter(bool queue_aware);
+  grb_info enter(bool queue_aware, bool counts = true);
   ~ApiScope();
 };
 grb_info lazy_flush();
@@ -613,6 +615,13 @@ bool lazy_try(int kind, int sr, grb_vector_s* w, grb_vector_s* u, grb_vector_s* 
     if (api_fi__ != GRB_SUCCESS) return api_fi__;                               \
   } while (0)
 #define GRB_API_ENTER_NOINFO() grb::ApiScope api_scope__; (void)api_scope__.enter(false)
+// the traversal queue's own entry points (enqueue / wait / host times / lanes): flush like any other, not counted in epoch
+#define GRB_API_ENTER_BFSQ()                                                    \
+  grb::ApiScope api_scope__;                                                    \
+  do {                                                                          \
+    const grb_info api_fi__ = api_scope__.enter(false, false);                  \
+    if (api_fi__ != GRB_SUCCESS) return api_fi__;                               \
+  } while (0)
 #define GRB_API_ENTER_QUEUE() grb::ApiScope api_scope__; (void)api_scope__.enter(true)
 // host-only entry points that never look at a vector or a matrix (descriptor fields): no flush, so that the toggles an
 // application puts between two element-wise calls (sssp.hpp:77-81) do not cut its chain
@@ -649,6 +658,11 @@ struct grb_matrix_s {
   grb::Index* d_oc_off = nullptr;
   int* d_oc_bigidx = nullptr;
   int oc_nb = 0, oc_nrows = 0, oc_state = 0;
+  // the same tables for the narrower grid of concurrent traversals (grb_bfs_set_lanes: the ranges are cut per workgroup)
+  grb::Index* d_oc2_bounds = nullptr;
+  grb::Index* d_oc2_off = nullptr;
+  int* d_oc2_bigidx = nullptr;
+  int oc2_nb = 0, oc2_nrows = 0, oc2_state = 0, oc2_grid = 0;
   grb::BatchSlices batch_in, batch_out;          // bfs_batch.hip, built lazily
   grb::SpmmCore spmm_core_csr, spmm_core_csc;    // spmm.hip, built lazily when GRB_SPMM_CORE is set
 };
@@ -754,6 +768,7 @@ void bfs_ticket_release(int slot);
 grb_info bfs_persistent_wait(int slot, int seq, int* levels, int* last_dir, long long* reached, unsigned long long* edges,
                              Index* nf_left, bool* hit_cap, float* tight_ms);
 void bfs_host_times(double* enqueue_us, double* wait_us, long long* calls, bool reset);
+int bfs_lanes_setting(int set);                  // traversals in flight at once (grb_bfs_set_lanes); set < 1 only queries
 grb_info k_spmv_masked_or(int dtype, const CsrArrays& M, const void* u, double identity,
                           const void* mask, int mask_f32, int scmp, int earlyexit, int opreuse,
                           const Index* hint /* per-row best neighbour, may be null */, void* w);

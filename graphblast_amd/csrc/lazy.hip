@@ -38,6 +38,7 @@ struct LazyQueue {
 static LazyQueue g_lazy;
 static int g_lazy_on = -1;
 int ApiScope::depth = 0;
+unsigned long long ApiScope::epoch = 0;
 static std::recursive_mutex g_api_lock;   // held by every entry point (ApiScope): depth and the queue are only touched under it
 
 bool lazy_enabled() {
@@ -308,8 +309,9 @@ bool lazy_try(int kind, int sr, grb_vector w, grb_vector u, grb_vector v, double
   return true;
 }
 
-grb_info ApiScope::enter(bool queue_aware) {
+grb_info ApiScope::enter(bool queue_aware, bool counts) {
   g_api_lock.lock();
+  if (depth == 0 && counts) ++epoch;
   grb_info r = GRB_SUCCESS;
   if (depth == 0 && !queue_aware && g_lazy.n > 0) r = lazy_flush();
   ++depth;

@@ -832,6 +832,10 @@ void grb::matrix_release_device(grb_matrix A) {
   if (A->d_oc_off) { (void)hipFree(A->d_oc_off); A->d_oc_off = nullptr; }
   if (A->d_oc_bigidx) { (void)hipFree(A->d_oc_bigidx); A->d_oc_bigidx = nullptr; }
   A->oc_nb = A->oc_nrows = A->oc_state = 0;
+  if (A->d_oc2_bounds) { (void)hipFree(A->d_oc2_bounds); A->d_oc2_bounds = nullptr; }
+  if (A->d_oc2_off) { (void)hipFree(A->d_oc2_off); A->d_oc2_off = nullptr; }
+  if (A->d_oc2_bigidx) { (void)hipFree(A->d_oc2_bigidx); A->d_oc2_bigidx = nullptr; }
+  A->oc2_nb = A->oc2_nrows = A->oc2_state = A->oc2_grid = 0;
   for (BatchSlices* b : {&A->batch_in, &A->batch_out}) {
     if (b->d_slices) (void)hipFree(b->d_slices);
     if (b->d_rows) (void)hipFree(b->d_rows);

@@ -329,6 +329,13 @@ typedef int64_t grb_bfs_ticket;
 grb_info grb_bfs_fused_enqueue(grb_vector v, grb_matrix A, grb_index source, grb_descriptor desc,
                                grb_bfs_ticket* ticket);
 grb_info grb_bfs_wait(grb_bfs_ticket ticket, grb_bfs_result* result);
+/* Traversals in flight at once (1 .. 8; default 1).  With n > 1 the traversals queued by grb_bfs_fused_enqueue go round n
+ * lanes -- a stream each, launches of (CUs / n) workgroups -- so that n of them are resident together: a traversal spends
+ * two thirds of its time in barriers and latency chains that more CUs do not shorten, so two on half the device each
+ * finish in 1.4 x the time of one on all of it (RMAT-22), four in 2 x.  Per-traversal results are unchanged; the
+ * blocking grb_bfs_fused keeps the whole device (and, issued while lanes are busy, waits for their grids to drain).
+ * Changing the number waits for everything queued.  n < 1 only queries.  Returns the previous value. */
+int grb_bfs_set_lanes(int n);
 /* Host time (microseconds, summed since the last reset) inside the one-launch traversal's two halves -- queueing the
  * launches / waiting for and unpacking the record -- and the number of traversals; any pointer may be NULL. */
 grb_info grb_bfs_host_times(double* enqueue_us, double* wait_us, long long* calls, int reset);

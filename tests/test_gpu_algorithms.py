@@ -272,6 +272,47 @@ def test_bfs_more_tickets_than_the_ring_holds(hb, graphs):
     assert info == 0 and g.bfs_wait(t)[0] == 0
 
 
+def test_bfs_lanes(hb, graphs):
+    """grb_bfs_set_lanes: the queued traversals go round n lanes (a stream each, launches of CUs / n workgroups) and n of
+    them are resident at once.  Labels and result blocks are those of the blocking call, whatever the number of lanes,
+    with library calls on the vectors before (fill) and after (reduce, extractTuples) the traversals, and blocking
+    traversals in between."""
+    from oracle import simple_reference as sr
+    g = hb.g
+    before = g.bfs_set_lanes(-1)
+    try:
+        for lanes in (2, 3, 4, 8, 1):
+            assert g.bfs_set_lanes(lanes) in (before, 1, 2, 4, 8)
+            assert g.bfs_set_lanes(-1) == {2: 2, 3: 2, 4: 4, 8: 8, 1: 1}[lanes]      # powers of two
+            for name, gr in graphs[2:5]:
+                ptr, ind = gr["csr"]
+                A = build(hb, gr)
+                n = gr["n"]
+                srcs = [first_source(gr)] + g.graphgen.random_sources(ptr, 10, seed=7)
+                for es in (0.0, 0.05):
+                    d = hb.descriptor(mxvmode=0, struconly=1, opreuse=1, edgeswitch=es)
+                    vs = [g.Vector(n) for _ in srcs]
+                    for v in vs:
+                        assert v.fill(7.0) == 0                 # queued on the library's stream: the lane's launch comes after it
+                    tickets = [g.bfs_enqueue(v, A, s_, d) for v, s_ in zip(vs, srcs)]
+                    assert all(i == 0 for i, _ in tickets)
+                    vb = g.Vector(n)
+                    ib, rb0 = g.bfs(vb, A, srcs[0], d, fused=True)     # a blocking traversal while the lanes are busy
+                    assert ib == 0
+                    res = [g.bfs_wait(t) for _, t in tickets]
+                    assert all(i == 0 for i, _ in res)
+                    for k, s_ in enumerate(srcs):
+                        want = sr.bfs(ptr, ind, s_)[0]
+                        info, cnt = g.reduce(None, "Plus", vs[k], hb.descriptor())   # reads the labels on the library's stream
+                        assert info == 0 and cnt == float(want.astype(np.float64).sum()), (lanes, name, s_)
+                        assert np.array_equal(hb.dense_values(vs[k]), want), (lanes, name, s_, es)
+                        assert res[k][1]["reached"] == int(np.count_nonzero(want))
+                        assert res[k][1]["edges_traversed"] == int(np.diff(ptr)[want != 0].sum())
+                    assert np.array_equal(hb.dense_values(vb), sr.bfs(ptr, ind, srcs[0])[0])
+    finally:
+        g.bfs_set_lanes(before)
+
+
 def test_bfs_vertex_zero_without_in_edges(hb):
     """Vertex 0 isolated (its pull hint is -1) on a graph whose later pull levels take the sparse-active-set path: the
     idle lanes of that path carry vertex 0 and must not probe word -1 of the visited bitmap."""
