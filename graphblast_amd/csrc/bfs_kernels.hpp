@@ -212,45 +212,46 @@ static __global__ __launch_bounds__(kBlock) void bfs_level_tail_kernel(
   }
 }
 
-// hint[v] = the entry of row v whose own degree (deg_ptr) is largest, -1 for an empty row.
+// hint[v] = the entry of row v whose own degree (deg_ptr) is largest (the smallest such entry on ties), -1 for an empty
+// row.  A wave takes 64 consecutive rows: their entries are ONE contiguous piece of `ind`, streamed 64 at a time
+// (coalesced; the first version walked a row per lane, every load 64 lines); an entry's row is found by a 6-step search
+// of the 65 row starts in LDS and its (degree, entry) key folded into the row's slot with an LDS 64-bit max.
 static __global__ __launch_bounds__(kBlock) void bfs_hint_kernel(
     const Index* __restrict__ ptr, const Index* __restrict__ ind, Index n, const Index* __restrict__ deg_ptr,
     Index* __restrict__ hint) {
-  constexpr int kSerial = 16;
-  const int lane = lane_id();
+  __shared__ Index s_start[kWavesPerBlock][kWave + 1];
+  __shared__ unsigned long long s_best[kWavesPerBlock][kWave];
+  const int lane = lane_id(), wave = wave_id();
   const Index nchunks = (n + kWave - 1) / kWave;
   const Index nwaves = (Index)gridDim.x * kWavesPerBlock;
-  for (Index chunk = (Index)blockIdx.x * kWavesPerBlock + wave_id(); chunk < nchunks; chunk += nwaves) {
+  for (Index chunk = (Index)blockIdx.x * kWavesPerBlock + wave; chunk < nchunks; chunk += nwaves) {
     const Index v = chunk * kWave + lane;
-    Index p = 0, e = 0, best = -1;
-    int best_deg = -1;
-    if (v < n) { p = ptr[v]; e = ptr[v + 1]; }
-    const Index stop = (e - p > kSerial) ? p + kSerial : e;
-    for (; p < stop; ++p) {
-      const Index u = ind[p];
-      const int d = deg_ptr[u + 1] - deg_ptr[u];
-      if (d > best_deg) { best_deg = d; best = u; }
-    }
-    unsigned long long todo = __ballot(p < e);
-    while (todo) {
-      const int src = __ffsll((long long)todo) - 1;
-      todo &= todo - 1;
-      const Index rs = __shfl(p, src, kWave), re = __shfl(e, src, kWave);
-      Index wb = -1;
-      int wd = -1;
-      for (Index q = rs + lane; q < re; q += kWave) {
+    const Index vc = v < n ? v : n;                              // rows past the end: empty
+    s_start[wave][lane] = ptr[vc];
+    if (lane == kWave - 1) s_start[wave][kWave] = ptr[vc < n ? vc + 1 : n];
+    s_best[wave][lane] = 0ull;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const Index q0 = s_start[wave][0], q1 = s_start[wave][kWave];
+    for (Index q = q0 + lane; q - lane < q1; q += kWave) {
+      if (q < q1) {
         const Index u = ind[q];
-        const int d = deg_ptr[u + 1] - deg_ptr[u];
-        if (d > wd) { wd = d; wb = u; }
+        const unsigned int d = (unsigned int)(deg_ptr[u + 1] - deg_ptr[u]);
+        int r = 0;                                               // the last row whose start is <= q
+#pragma unroll
+        for (int step = kWave / 2; step > 0; step >>= 1)
+          if (s_start[wave][r + step] <= q) r += step;
+        // (degree + 1: an entry of degree 0 still beats "no entry"; ties go to the smaller entry)
+        atomicMax(&s_best[wave][r], ((unsigned long long)(d + 1u) << 32) | (unsigned long long)(0xffffffffu - (unsigned int)u));
       }
-      for (int o = kWave / 2; o > 0; o >>= 1) {
-        const int od = __shfl_xor(wd, o, kWave);
-        const Index ob = __shfl_xor(wb, o, kWave);
-        if (od > wd || (od == wd && ob < wb)) { wd = od; wb = ob; }
-      }
-      if (lane == src && wd > best_deg) { best_deg = wd; best = wb; }
     }
-    if (v < n) hint[v] = best;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (v < n) {
+      const unsigned long long b = s_best[wave][lane];
+      hint[v] = b ? (Index)(0xffffffffu - (unsigned int)b) : -1;
+    }
+    __builtin_amdgcn_wave_barrier();
   }
 }
 

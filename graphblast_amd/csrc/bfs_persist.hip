@@ -892,15 +892,32 @@ incl = (int)wave_incl_scan_u32((unsigned)incl);
   }
 }
 
-// destinations of the big rows' entries, counted in bins of kOcBin vertices (one wave per row)
-__global__ __launch_bounds__(kBlock) void oc_mass_kernel(const Index* __restrict__ optr, const Index* __restrict__ oind,
-                                                         const Index* __restrict__ rows, int nrows, unsigned int* __restrict__ bins) {
-  const int lane = lane_id();
-  const int nwaves = gridDim.x * kWavesPerBlock;
-  for (int r = blockIdx.x * kWavesPerBlock + wave_id(); r < nrows; r += nwaves) {
+// destinations of the big rows' entries, counted in bins of kOcBin vertices (one wave per row).  With at most kOcLdsBins
+// bins (RMAT-22: 16 Ki) a workgroup counts in LDS and adds its non-empty bins to memory once -- 55 M global atomics on
+// 16 Ki words were 3 ms of a matrix's first traversal.
+constexpr int kOcLdsBins = 16384;
+__global__ __launch_bounds__(1024) void oc_mass_kernel(const Index* __restrict__ optr, const Index* __restrict__ oind,
+                                                       const Index* __restrict__ rows, int nrows, int nbins, unsigned int* __restrict__ bins) {
+  __shared__ unsigned int h[kOcLdsBins];
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6, waves = blockDim.x >> 6;
+  const bool lds = nbins <= kOcLdsBins;
+  if (lds) {
+    for (int i = threadIdx.x; i < nbins; i += blockDim.x) h[i] = 0u;
+    __syncthreads();
+  }
+  const int nwaves = gridDim.x * waves;
+  for (int r = blockIdx.x * waves + wave; r < nrows; r += nwaves) {
     const Index u = rows[r];
     const Index e = optr[u + 1];
-    for (Index p = optr[u] + lane; p < e; p += kWave) atomicAdd(&bins[oind[p] / kOcBin], 1u);
+    for (Index p = optr[u] + lane; p < e; p += kWave) {
+      const int b = oind[p] / kOcBin;
+      if (lds) atomicAdd(&h[b], 1u); else atomicAdd(&bins[b], 1u);
+    }
+  }
+  if (lds) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < nbins; i += blockDim.x)
+      if (h[i]) atomicAdd(&bins[i], h[i]);
   }
 }
 
@@ -947,8 +964,14 @@ grb_info grb::oc_tables_build(const Index* d_ptr, const Index* d_ind, const std:
   GRB_HIP_TRY(hipMalloc(&p_bins, 4 * (size_t)nbins));
   GRB_HIP_TRY(hipMemsetAsync(p_bins, 0, 4 * (size_t)nbins, s));
   GRB_HIP_TRY(hipMemcpyAsync(p_rows, rows.data(), sizeof(Index) * rows.size(), hipMemcpyHostToDevice, s));
-  hipLaunchKernelGGL(oc_mass_kernel, dim3(stream_grid((long long)rows.size() * kWave, kBlock)), dim3(kBlock), 0, s, d_ptr, d_ind,
-                     (const Index*)p_rows, (int)rows.size(), (unsigned int*)p_bins);
+  {
+    const int waves_needed = (int)rows.size();
+    int mgrid = (waves_needed + 15) / 16;
+    if (mgrid > ctx().num_cu) mgrid = ctx().num_cu;
+    if (mgrid < 1) mgrid = 1;
+    hipLaunchKernelGGL(oc_mass_kernel, dim3(mgrid), dim3(1024), 0, s, d_ptr, d_ind, (const Index*)p_rows, (int)rows.size(), nbins,
+                       (unsigned int*)p_bins);
+  }
   GRB_HIP_TRY(hipGetLastError());
   GRB_HIP_TRY(hipMemcpyAsync(bins.data(), p_bins, 4 * (size_t)nbins, hipMemcpyDeviceToHost, s));
   GRB_HIP_TRY(hipStreamSynchronize(s));
