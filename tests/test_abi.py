@@ -183,7 +183,7 @@ def test_every_entry_point_flushes_the_lazy_queue():
             if not mm:
                 continue                                   # a declaration or a call, not the definition
             body = src[i + mm.end(): i + mm.end() + 400]
-            found[name] = bool(re.match(r"\s*(GRB_API_ENTER(_NOINFO|_QUEUE|_HOST)?\(\)|grb::ApiScope api_scope__)", body)) \
+            found[name] = bool(re.match(r"\s*(GRB_API_ENTER(_NOINFO|_QUEUE|_HOST|_BFSQ)?\(\)|grb::ApiScope api_scope__)", body)) \
                 or name == "grb_lazy_pending"              # reports the queue; must not flush it
     assert set(found) == names, sorted(names - set(found))
     assert all(found.values()), sorted(n for n, ok in found.items() if not ok)
