@@ -122,6 +122,7 @@ _SIGS = {
     "grb_spmv_set_reuse_threshold": [_i],
     "grb_set_lazy": [_i],
     "grb_lazy_pending": [],
+    "grb_lazy_fused_reductions": [],
     "grb_vector_apply": [_vp, _vp, _i, _i, _i, C.c_double, _vp, _vp],
     "grb_matrix_apply": [_vp, _vp, _i, _i, _i, C.c_double, _vp, _vp],
     "grb_comm_set_host_transport": [_i, _i, _vp, _vp],

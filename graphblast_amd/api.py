@@ -654,6 +654,11 @@ def lazy_pending():
     return int(_lib.load().grb_lazy_pending())
 
 
+def lazy_fused_reductions():
+    """reductions that ran inside a chain's launch so far (grb_lazy_fused_reductions)"""
+    return int(_lib.load().grb_lazy_fused_reductions())
+
+
 def spmv_set_reuse_threshold(launches=-1):
     """CSR-kernel products after which `auto` prepares the column-sorted format for an orientation
     (grb_spmv_set_reuse_threshold; 0 = at once); < 0 only queries.  Returns the previous value."""

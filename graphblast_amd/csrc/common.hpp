@@ -403,6 +403,50 @@ __device__ inline bool last_workgroup_arrives(unsigned int* tickets) {
   return true;
 }
 
+// The part of a one-launch reduction that follows every thread's private fold (elementwise.hip: reduce_kernel;
+// lazy.hip: a chain of element-wise calls whose last result is reduced in the same launch -- the SAME association
+// order, so the value does not depend on which of the two ran): butterfly inside the wave, the waves in order, the
+// workgroup's partial written through, an arrival ticket; the last workgroup to arrive folds the partials -- thread t
+// takes t, t + 256, ... -- the same way and writes {value, seq} into the pinned mailbox.  smem: kWavesPerBlock words.
+template <typename T, typename F>
+__device__ inline void reduce_finish(T acc, F add, T identity, unsigned int* partial, unsigned int* ticket,
+                                     unsigned long long* mail, int seq, unsigned int* smem, int* s_last) {
+  auto bits = [](T x) { unsigned int u; memcpy(&u, &x, 4); return u; };
+  auto from = [](unsigned int u) { T x; memcpy(&x, &u, 4); return x; };
+#pragma unroll
+  for (int o = kWave / 2; o > 0; o >>= 1) acc = add(acc, __shfl_xor(acc, o, kWave));
+  if (lane_id() == 0) smem[wave_id()] = bits(acc);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned int t = smem[0];
+    for (int w = 1; w < kWavesPerBlock; ++w) t = bits(add(from(t), from(smem[w])));
+    __hip_atomic_store(&partial[blockIdx.x], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    *s_last = last_workgroup_arrives(ticket) ? 1 : 0;
+  }
+  __syncthreads();
+  if (!*s_last) return;
+  unsigned int f = bits(identity);
+  for (int j = threadIdx.x; j < (int)gridDim.x; j += kBlock) {
+    const unsigned int pj = __hip_atomic_load(&partial[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    f = bits(add(from(f), from(pj)));
+  }
+  {
+    T fv = from(f);
+#pragma unroll
+    for (int o = kWave / 2; o > 0; o >>= 1) fv = add(fv, __shfl_xor(fv, o, kWave));
+    f = bits(fv);
+  }
+  __syncthreads();
+  if (lane_id() == 0) smem[wave_id()] = f;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned int t = smem[0];
+    for (int w = 1; w < kWavesPerBlock; ++w) t = bits(add(from(t), from(smem[w])));
+    __hip_atomic_store(&mail[0], ((unsigned long long)(unsigned int)seq << 32) | t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
 // Exclusive prefix sum of one int per thread over a 256-thread workgroup.
 // smem: at least kWavesPerBlock ints. Ends with a barrier, so smem may be reused.
 __device__ inline int block_exclusive_scan(int v, int* smem, int& total) {
@@ -607,6 +651,10 @@ struct ApiScope {
   ~ApiScope();
 };
 grb_info lazy_flush();
+// grb_reduce_vector on the result of a pending chain: the chain's launch also folds it (lazy.hip).  *done = false: not
+// this case -- the caller flushes and reduces as usual.
+grb_info lazy_flush_reduce(grb_vector_s* u, int monoid, double* out, bool* done);
+grb_info reduce_launch_prep(Index n, int* grid, unsigned int** d_partial, unsigned int** d_ticket);   // elementwise.hip
 bool lazy_try(int kind, int sr, grb_vector_s* w, grb_vector_s* u, grb_vector_s* v, double scalar, grb_info* flush_info);
 #define GRB_API_ENTER()                                                         \
   grb::ApiScope api_scope__;                                                    \

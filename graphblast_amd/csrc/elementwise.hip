@@ -284,6 +284,11 @@ __global__ __launch_bounds__(kBlock) void reduce_kernel(const T* __restrict__ d,
     if constexpr (kCountNeq) cnt += (x != cmp) ? 1 : 0;
     else acc = Mo::add(acc, x);
   }
+  if constexpr (!kCountNeq) {
+    // (the same tail as a chain of element-wise calls that ends in a reduction runs: common.hpp)
+    reduce_finish<T>(acc, [](T a, T b) { return Mo::add(a, b); }, Mo::identity(), partial, ticket, mail, seq, smem, &s_last);
+    return;
+  }
   unsigned int mine;
   if constexpr (kCountNeq) {
     cnt = wave_reduce(cnt, [](int a, int b) { return a + b; });
@@ -329,7 +334,7 @@ __global__ __launch_bounds__(kBlock) void reduce_kernel(const T* __restrict__ d,
   }
 }
 
-static grb_info reduce_launch_prep(Index n, int* grid, unsigned int** d_partial, unsigned int** d_ticket) {
+grb_info reduce_launch_prep(Index n, int* grid, unsigned int** d_partial, unsigned int** d_ticket) {
   *grid = stream_grid(n, kBlock * 4);
   void* p = nullptr;
   GRB_TRY(scratch(0, sizeof(int) * (size_t)(*grid), &p));

@@ -166,6 +166,60 @@ __global__ __launch_bounds__(kBlock) void lazy_chain_kernel(LzProg p, Index n) {
   }
 }
 
+// The same chain with a reduction of buffer `red` attached (grb_reduce_vector on a pending result): launched with the
+// reduce kernel's grid, a thread folds the elements it computes in the order the reduce kernel reads them -- the 16-byte
+// vectors i, i + stride, ... as add(add(acc, add(x, y)), add(z, w)), then its tail element -- and the launch ends with the
+// reduce kernel's own tail (common.hpp: reduce_finish): the value is bit for bit the one the separate launch gives.
+template <typename T>
+__device__ __forceinline__ T lz_scalar_op(int op, T a, T b) {
+  switch (op) {
+    case OP_PLUS: return binop<OP_PLUS, T>(a, b);
+    case OP_TIMES: return binop<OP_TIMES, T>(a, b);
+    case OP_MIN: return binop<OP_MIN, T>(a, b);
+    case OP_MAX: return binop<OP_MAX, T>(a, b);
+    case OP_LOR: return binop<OP_LOR, T>(a, b);
+    default: return binop<OP_LAND, T>(a, b);
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(kBlock) void lazy_chain_reduce_kernel(LzProg p, Index n, int red, int red_op, unsigned int ident_bits,
+                                                                   unsigned int* partial, unsigned int* ticket,
+                                                                   unsigned long long* mail, int seq) {
+  __shared__ LzVec<T> r[kLazyBufs][kBlock];
+  __shared__ unsigned int smem[kWavesPerBlock];
+  __shared__ int s_last;
+  const int me = threadIdx.x;
+  const Index nv = n / kLzVec;
+  T ident;
+  memcpy(&ident, &ident_bits, 4);
+  T acc = ident;
+  auto add = [red_op](T a, T b) { return lz_scalar_op<T>(red_op, a, b); };
+  for (Index i = blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += gridDim.x * blockDim.x) {
+    for (int b = 0; b < p.nbuf; ++b)
+      if ((p.load_mask >> b) & 1u) r[b][me] = reinterpret_cast<const LzVec<T>*>(p.buf[b])[i];
+    lz_steps<T>(p, r);
+    for (int b = 0; b < p.nbuf; ++b)
+      if ((p.store_mask >> b) & 1u) reinterpret_cast<LzVec<T>*>(p.buf[b])[i] = r[b][me];
+    const LzVec<T> q = r[red][me];
+    acc = add(add(acc, add(q.e[0], q.e[1])), add(q.e[2], q.e[3]));
+  }
+  const Index t = nv * kLzVec + (Index)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (t < n) {
+    for (int b = 0; b < p.nbuf; ++b) {
+      LzVec<T> x;
+#pragma unroll
+      for (int c = 0; c < kLzVec; ++c) x.e[c] = (T)0;
+      if ((p.load_mask >> b) & 1u) x.e[0] = reinterpret_cast<const T*>(p.buf[b])[t];
+      r[b][me] = x;
+    }
+    lz_steps<T>(p, r);
+    for (int b = 0; b < p.nbuf; ++b)
+      if ((p.store_mask >> b) & 1u) reinterpret_cast<T*>(p.buf[b])[t] = r[b][me].e[0];
+    acc = add(acc, r[red][me].e[0]);
+  }
+  reduce_finish<T>(acc, add, ident, partial, ticket, mail, seq, smem, &s_last);
+}
+
 // one step by the kernels the eager path uses (a queue of one step, or a step the program cannot hold)
 static grb_info lazy_run_step(const LazyStep& st, int dtype, Index n) {
   switch (st.kind) {
@@ -200,10 +254,66 @@ grb_info lazy_flush() {
   return GRB_SUCCESS;
 }
 
+static grb_info lazy_build_program(const LazyQueue& q, LzProg& p);
 static grb_info lazy_run_program(const LazyQueue& q) {
   // test hook: behave as if the fused program had been refused, so that lazy_flush's step-by-step fallback runs
   if (const char* e = getenv("GRB_LAZY_FORCE_STEPWISE")) if (atoi(e) != 0) return GRB_PANIC;
   LzProg p;
+  GRB_TRY(lazy_build_program(q, p));
+  if (q.dtype == GRB_F32)
+    hipLaunchKernelGGL(lazy_chain_kernel<float>, dim3(stream_grid(q.nsize / kLzVec + 1, kBlock)), dim3(kBlock), 0, ctx().stream, p, q.nsize);
+  else
+    hipLaunchKernelGGL(lazy_chain_kernel<int>, dim3(stream_grid(q.nsize / kLzVec + 1, kBlock)), dim3(kBlock), 0, ctx().stream, p, q.nsize);
+  GRB_HIP_TRY(hipGetLastError());
+  return GRB_SUCCESS;
+}
+
+static int g_fused_reductions = 0;
+// grb_reduce_vector(u) while a chain is pending that WRITES u: one launch runs the chain and folds u.
+grb_info lazy_flush_reduce(grb_vector u, int monoid, double* out, bool* done) {
+  *done = false;
+  if (g_lazy.n == 0 || !u || !out || u->vec_type != GRB_DENSE || !u->d_val) return GRB_SUCCESS;
+  if (monoid < 0 || monoid > GRB_LOGICAL_AND_MONOID) return GRB_SUCCESS;       // the order-sensitive "monoids" keep their own kernel
+  if (u->dtype != g_lazy.dtype || u->nsize != g_lazy.nsize || g_lazy.nsize <= 0) return GRB_SUCCESS;
+  if (const char* e = getenv("GRB_LAZY_FORCE_STEPWISE")) if (atoi(e) != 0) return GRB_SUCCESS;
+  bool written = false;
+  for (int s = 0; s < g_lazy.n; ++s) written = written || g_lazy.s[s].w == u;
+  if (!written) return GRB_SUCCESS;
+  LazyQueue q = g_lazy;
+  LzProg p;
+  if (lazy_build_program(q, p) != GRB_SUCCESS) return GRB_SUCCESS;            // (the ordinary flush deals with it)
+  int red = -1;
+  for (int b = 0; b < p.nbuf; ++b)
+    if (p.buf[b] == u->d_val) red = b;
+  if (red < 0) return GRB_SUCCESS;
+  g_lazy.n = 0;
+  int grid;
+  unsigned int *d_partial, *d_ticket;
+  GRB_TRY(reduce_launch_prep(q.nsize, &grid, &d_partial, &d_ticket));
+  Context& c = ctx();
+  const int seq = ++c.mail_seq;
+  static const int ops[6] = {OP_PLUS, OP_TIMES, OP_MIN, OP_MAX, OP_LOR, OP_LAND};
+  const double idv = monoid_identity(monoid, q.dtype);
+  unsigned int ident_bits;
+  if (q.dtype == GRB_F32) { const float f = (float)idv; memcpy(&ident_bits, &f, 4); }
+  else { const int iv = (int)idv; memcpy(&ident_bits, &iv, 4); }
+  if (q.dtype == GRB_F32)
+    hipLaunchKernelGGL(lazy_chain_reduce_kernel<float>, dim3(grid), dim3(kBlock), 0, c.stream, p, q.nsize, red, ops[monoid], ident_bits,
+                       d_partial, d_ticket, c.d_hgran, seq);
+  else
+    hipLaunchKernelGGL(lazy_chain_reduce_kernel<int>, dim3(grid), dim3(kBlock), 0, c.stream, p, q.nsize, red, ops[monoid], ident_bits,
+                       d_partial, d_ticket, c.d_hgran, seq);
+  GRB_HIP_TRY(hipGetLastError());
+  unsigned int raw = 0;
+  GRB_TRY(wait_granules(seq, 1, &raw));
+  if (q.dtype == GRB_F32) { float f; memcpy(&f, &raw, 4); *out = (double)f; }
+  else *out = (double)(int)raw;
+  *done = true;
+  ++g_fused_reductions;
+  return GRB_SUCCESS;
+}
+
+static grb_info lazy_build_program(const LazyQueue& q, LzProg& p) {
   memset(&p, 0, sizeof(p));
   p.n = q.n;
   unsigned int written = 0;
@@ -255,11 +365,6 @@ static grb_info lazy_run_program(const LazyQueue& q) {
     o.v = (signed char)sv;
     o.w = (signed char)sw;
   }
-  if (q.dtype == GRB_F32)
-    hipLaunchKernelGGL(lazy_chain_kernel<float>, dim3(stream_grid(q.nsize / kLzVec + 1, kBlock)), dim3(kBlock), 0, ctx().stream, p, q.nsize);
-  else
-    hipLaunchKernelGGL(lazy_chain_kernel<int>, dim3(stream_grid(q.nsize / kLzVec + 1, kBlock)), dim3(kBlock), 0, ctx().stream, p, q.nsize);
-  GRB_HIP_TRY(hipGetLastError());
   return GRB_SUCCESS;
 }
 
@@ -338,4 +443,6 @@ int grb_set_lazy(int on) {
 }
 // steps waiting in the queue (tests: a chain really was deferred).  Does not flush.
 int grb_lazy_pending(void) { return lazy_pending(); }
+// reductions that ran inside a chain's launch so far (tests).  Does not flush.
+int grb_lazy_fused_reductions(void) { return g_fused_reductions; }
 }

@@ -295,9 +295,16 @@ grb_info grb_eWiseAdd_scalar(grb_vector w, grb_vector mask, grb_accum accum, grb
 }
 
 // backend/cuda/operations.hpp:1004-1030 + reduce.hpp:13-76
-grb_info grb_reduce_vector(double* val, grb_accum accum, grb_monoid op, grb_vector u, grb_descriptor desc) { GRB_API_ENTER();
+grb_info grb_reduce_vector(double* val, grb_accum accum, grb_monoid op, grb_vector u, grb_descriptor desc) { GRB_API_ENTER_QUEUE();
   (void)accum;
-  if (!val || !u || !desc) return GRB_UNINITIALIZED_OBJECT;
+  if (!val || !u || !desc) { GRB_TRY(lazy_flush()); return GRB_UNINITIALIZED_OBJECT; }
+  // the result of a pending chain of element-wise calls (pr.hpp:72-80: ..., eWiseAdd, reduce): folded by the chain's own launch
+  if (u->vec_type == GRB_DENSE && grb::ApiScope::depth == 1) {
+    bool done = false;
+    GRB_TRY(lazy_flush_reduce(u, (int)op, val, &done));
+    if (done) return GRB_SUCCESS;
+  }
+  GRB_TRY(lazy_flush());
   if (u->vec_type == GRB_SPARSE) {
     if (desc->struconly) { *val = (double)u->s_nvals; return GRB_SUCCESS; }   // reduce.hpp:71-72
     return k_reduce(op, u->dtype, u->s_val, u->s_nvals, val);

@@ -253,6 +253,8 @@ grb_info grb_extractGather(grb_vector w, grb_vector mask, grb_accum accum, grb_v
  * returns the previous setting.  grb_lazy_pending(): steps waiting (does not flush). */
 int grb_set_lazy(int on);
 int grb_lazy_pending(void);
+/* reductions that ran inside a chain's launch so far (grb_reduce_vector on a pending result); does not flush */
+int grb_lazy_fused_reductions(void);
 
 /* apply on the device   operations.hpp:559-579 / :581-601 -> backend :878-957 (apply.hpp: host loops there).
  * Vector: w = f(u) on every stored element (dense: all of them; sparse: the nvals stored ones, indices copied), w takes

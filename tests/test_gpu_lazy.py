@@ -262,3 +262,56 @@ def test_a_refused_program_still_runs_its_steps(monkeypatch):
     got = _run(g, chain, init, np.float32, True, depth)
     monkeypatch.delenv("GRB_LAZY_FORCE_STEPWISE")
     assert depth[0] >= 2 and _same(got, want)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.int32])
+def test_a_reduction_at_the_end_of_a_chain_runs_in_its_launch(dtype):
+    """pr.hpp:72-80 ends eWiseMult, eWiseAdd, reduce: the reduction of a pending chain's result is folded by the chain's
+    own launch, in the reduce kernel's association order -- the value is bit for bit the separate launch's, every vector
+    is left as the calls would have left it, and a reduction of something the queue does not write is an ordinary one."""
+    import graphblast_amd as g
+    rng = np.random.default_rng(31 if dtype == np.float32 else 32)
+    monoids = ["PlusMonoid", "MultipliesMonoid", "MinimumMonoid", "MaximumMonoid", "LogicalOrMonoid", "LogicalAndMonoid"]
+    for trial in range(24):
+        n = int(rng.choice([1, 3, 64, 1000, 4097, 100003]))
+        npool = int(rng.integers(3, 7))
+        if dtype == np.float32:
+            init = [(rng.random(n, dtype=np.float32) * 2 - 1).astype(np.float32) for _ in range(npool)]
+        else:
+            init = [rng.integers(-3, 4, n).astype(np.int32) for _ in range(npool)]
+        chain = [c for c in _random_chain(rng, npool, int(rng.integers(1, 6)))]
+        target = chain[-1][2]                                  # the vector the last step writes
+        mono = monoids[trial % len(monoids)]
+        out = {}
+        for lazy in (True, False):
+            before = g.set_lazy(1 if lazy else 0)
+            try:
+                d = g.Descriptor(); d.loadArgs()
+                ds = g.Descriptor(); ds.loadArgs(); assert ds.toggle(0) == 0
+                vecs = []
+                for x in init:
+                    v = g.Vector(x.size, dtype); assert v.build(x) == 0; vecs.append(v)
+                fused0 = g.lazy_fused_reductions()
+                with np.errstate(all="ignore"):
+                    for kind, sr, w, u, v, s in chain:
+                        if kind == "add": assert g.eWiseAdd(vecs[w], None, None, sr, vecs[u], vecs[v], d) == 0
+                        elif kind == "mult": assert g.eWiseMult(vecs[w], None, None, sr, vecs[u], vecs[v], d) == 0
+                        elif kind == "add_scalar": assert g.eWiseAdd(vecs[w], None, None, sr, vecs[u], s, d) == 0
+                        elif kind in ("assign", "assign_scmp"): assert g.assign(vecs[w], vecs[u], None, s, None, None, ds if kind == "assign_scmp" else d) == 0
+                        else: assert vecs[w].dup(vecs[u]) == 0
+                    pending = g.lazy_pending()
+                    info, val = g.reduce(None, mono, vecs[target], d)
+                    assert info == 0 and g.lazy_pending() == 0
+                    other = (target + 1) % npool
+                    info2, val2 = g.reduce(None, "PlusMonoid", vecs[other], d)
+                    assert info2 == 0
+                if lazy and pending >= 1:
+                    assert g.lazy_fused_reductions() == fused0 + 1, (trial, chain)
+                out[lazy] = (np.float32(val) if dtype == np.float32 else np.int32(val), np.float32(val2) if dtype == np.float32 else np.int32(val2),
+                             [v.extractTuples()[1].copy() for v in vecs])
+            finally:
+                g.set_lazy(before)
+        a, b = out[True], out[False]
+        assert np.array([a[0]]).view(np.uint32)[0] == np.array([b[0]]).view(np.uint32)[0] or (np.isnan(a[0]) and np.isnan(b[0])), (trial, mono, a[0], b[0], chain)
+        assert np.array([a[1]]).view(np.uint32)[0] == np.array([b[1]]).view(np.uint32)[0] or (np.isnan(a[1]) and np.isnan(b[1]))
+        assert _same(a[2], b[2]), (trial, chain)
