@@ -49,6 +49,8 @@ if os.path.exists(trace):
     # since round 5: the K timed (queued) steps are followed by min(warmup, 2) blocking warm-ups and the K steps of the
     # blocking loop; the HIP-event pass comes after those
     E = W + K + (min(line["warmup"], 2) + K if "blocking_loop" in line else 0)
+    if "lanes" in line:                      # the two-lane sibling: max(warmup, 2) warm-ups + K steps, then 2 + K on one lane again
+        E += max(line["warmup"], 2) + K + 2 + K
     ph = {"source": "rocprofv3 --kernel-trace of the default `python bench.py` (same run as bench_kernel_stats_*.csv)",
           "warmup": W, "steps": K, "bfs_persistent_kernel_launches": len(bfs),
           "bfs_persistent_kernel_mean_us": {
