@@ -1074,7 +1074,7 @@ grb_info k_spmv(int sr, int dtype, const CsrArrays& M, SpmvPlan& plan, const voi
           SpmvCBand& C = *plan.cband;
           if (C.nhot > 0) {
             const Index np = plan.npacked < (Index)C.nhot ? plan.npacked : (Index)C.nhot;
-            hipLaunchKernelGGL((cband_pack_kernel<T>), dim3(ceil_div(np, kBlock)), dim3(kBlock), 0, ctx().stream, (const T*)u,
+            hipLaunchKernelGGL((cband_pack_kernel<T>), dim3(ceil_div(ceil_div(np, 4), kBlock)), dim3(kBlock), 0, ctx().stream, (const T*)u,
                                (const Index*)plan.d_order, np, (T*)plan.d_u2);
           }
           static const bool want_trace = getenv("GRB_SPMV_TRACE") != nullptr;
@@ -1092,7 +1092,7 @@ grb_info k_spmv(int sr, int dtype, const CsrArrays& M, SpmvPlan& plan, const voi
                                (const T*)plan.d_u2, (const T*)u, C.nhot, mask, mask_f32, scmp, accum, (T*)w, C.d_partials, d_trace);
           GRB_HIP_TRY(hipGetLastError());
           if (C.nfin > 0) {
-            hipLaunchKernelGGL((spmv_cband_fold_kernel<SR, T>), dim3(ceil_div(C.max_fin_rows, kWave), C.nfin), dim3(kBlock), 0,
+            hipLaunchKernelGGL((spmv_cband_fold_kernel<SR, T>), dim3(ceil_div(C.max_fin_rows, kWave), C.nfin), dim3(kCbFoldWaves * kWave), 0,
                                ctx().stream, C.args, (const void*)C.d_partials, mask, mask_f32, scmp, accum, (T*)w);
             GRB_HIP_TRY(hipGetLastError());
           }

@@ -381,12 +381,15 @@ __global__ __launch_bounds__(kCbThreads) void spmv_cband_kernel(CbArgs a, const 
   if (trace && tid == 0) trace[2 * blockIdx.x + 1] = wall_clock64();
 }
 
-// the rows of the bands several workgroups worked on: partial slices folded in slot order by four lanes per row,
-// then the epilogue.  blockIdx.y = shared band, blockIdx.x = 64 of its rows.
+// the rows of the bands several workgroups worked on: partial slices folded by sixteen lanes per row (wave q of a
+// 1024-thread workgroup takes slots s0 + q, s0 + q + 16, ..., four loads in flight each: the hub band of RMAT-22 has
+// ~210 slices, and with four waves per row block the kernel ran at 2.5 TB/s on 27 MB), then the epilogue.
+// blockIdx.y = shared band, blockIdx.x = 64 of its rows.
+constexpr int kCbFoldWaves = 16;
 template <int SR, typename T>
-__global__ __launch_bounds__(kBlock) void spmv_cband_fold_kernel(CbArgs a, const void* __restrict__ partials_raw,
-                                                                 const void* __restrict__ mask, int mask_f32, int scmp,
-                                                                 int accum, T* w) {
+__global__ __launch_bounds__(kCbFoldWaves * kWave) void spmv_cband_fold_kernel(CbArgs a, const void* __restrict__ partials_raw,
+                                                                             const void* __restrict__ mask, int mask_f32, int scmp,
+                                                                             int accum, T* w) {
   typedef Semiring<SR, T> S;
   typedef typename CbAcc<S::monoid, T>::type Acc;
   const Acc* __restrict__ partials = reinterpret_cast<const Acc*>(partials_raw);
@@ -394,9 +397,9 @@ __global__ __launch_bounds__(kBlock) void spmv_cband_fold_kernel(CbArgs a, const
   const CbBand B = a.bands[a.fin_band[f]];
   if ((int)blockIdx.x * kWave >= B.nrows) return;
   const int s0 = a.fin_ptr[f], s1 = a.fin_ptr[f + 1];
-  const int l = threadIdx.x & (kWave - 1), q = threadIdx.x >> 6;     // wave q takes slots s0 + q, s0 + q + 4, ...
+  const int l = threadIdx.x & (kWave - 1), q = threadIdx.x >> 6;     // wave q takes slots s0 + q, s0 + q + 16, ...
   const int i = blockIdx.x * kWave + l;
-  __shared__ unsigned long long s_part[kWavesPerBlock][kWave];
+  __shared__ unsigned long long s_part[kCbFoldWaves][kWave];
   Acc acc = (Acc)S::identity();
   if (i < B.nrows) {
     auto fold = [&](Acc p) {
@@ -404,20 +407,20 @@ __global__ __launch_bounds__(kBlock) void spmv_cband_fold_kernel(CbArgs a, const
       else acc += p;
     };
     int s = s0 + q;
-    for (; s + 3 * kWavesPerBlock < s1; s += 4 * kWavesPerBlock) {       // four slices in flight
+    for (; s + 3 * kCbFoldWaves < s1; s += 4 * kCbFoldWaves) {       // four slices in flight
       const Acc p0 = partials[(size_t)a.fin_off[s] + i];
-      const Acc p1 = partials[(size_t)a.fin_off[s + kWavesPerBlock] + i];
-      const Acc p2 = partials[(size_t)a.fin_off[s + 2 * kWavesPerBlock] + i];
-      const Acc p3 = partials[(size_t)a.fin_off[s + 3 * kWavesPerBlock] + i];
+      const Acc p1 = partials[(size_t)a.fin_off[s + kCbFoldWaves] + i];
+      const Acc p2 = partials[(size_t)a.fin_off[s + 2 * kCbFoldWaves] + i];
+      const Acc p3 = partials[(size_t)a.fin_off[s + 3 * kCbFoldWaves] + i];
       fold(p0); fold(p1); fold(p2); fold(p3);
     }
-    for (; s < s1; s += kWavesPerBlock) fold(partials[(size_t)a.fin_off[s] + i]);
+    for (; s < s1; s += kCbFoldWaves) fold(partials[(size_t)a.fin_off[s] + i]);
   }
   *reinterpret_cast<Acc*>(&s_part[q][l]) = acc;
   __syncthreads();
   if (q == 0 && i < B.nrows) {
     Acc tot = acc;
-    for (int k = 1; k < kWavesPerBlock; ++k) {
+    for (int k = 1; k < kCbFoldWaves; ++k) {
       const Acc p = *reinterpret_cast<Acc*>(&s_part[k][l]);
       if constexpr (std::is_same<Acc, T>::value) tot = S::add(tot, p);
       else tot += p;
@@ -428,10 +431,19 @@ __global__ __launch_bounds__(kBlock) void spmv_cband_fold_kernel(CbArgs a, const
 }
 
 // the hot prefix of the packed vector: u_hot[i] = u[order[i]] for the nhot most referenced columns
+// (four elements per lane: one 16-byte read of the order, four gathers in flight, one 16-byte store)
 template <typename T>
 __global__ void cband_pack_kernel(const T* __restrict__ u, const Index* __restrict__ order, Index nhot, T* __restrict__ u_hot) {
-  const Index i = (Index)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < nhot) u_hot[i] = u[order[i]];
+  const Index i4 = ((Index)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i4 + 3 < nhot) {
+    const int4 o = *reinterpret_cast<const int4*>(order + i4);
+    struct alignas(16) V4 { T x, y, z, w; };
+    V4 v;
+    v.x = u[o.x]; v.y = u[o.y]; v.z = u[o.z]; v.w = u[o.w];
+    *reinterpret_cast<V4*>(u_hot + i4) = v;
+  } else {
+    for (Index i = i4; i < nhot; ++i) u_hot[i] = u[order[i]];
+  }
 }
 
 // column -> code: its rank when that is below nhot, else nhot + the column itself
