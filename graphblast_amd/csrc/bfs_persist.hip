@@ -45,25 +45,10 @@ namespace grb {
 #ifndef GRB_BFS_SPARSE_FRESH
 #define GRB_BFS_SPARSE_FRESH 1
 #endif
-// the level totals ARE the level's barrier (see "level totals" in the kernel); 0: totals, then the counter barrier
-#ifndef GRB_BFS_TOTALS_BARRIER
-#define GRB_BFS_TOTALS_BARRIER 0
-#endif
-// the other barriers of the launch (big-vertex listing, pull-only start): 1 = grid_sync_flat, 0 = the hierarchical one
-#ifndef GRB_BFS_FLAT_BARRIER
-#define GRB_BFS_FLAT_BARRIER 0
-#endif
 // the big-vertex list: one global reservation per WORKGROUP and pass (waves reserve inside it through LDS) instead of one
 // per wave -- a heavy level's 3 000 appends to one address cost 15 us at the listing barrier
 #ifndef GRB_BFS_LIST_WG
 #define GRB_BFS_LIST_WG 1
-#endif
-// the depth vector written with write-through (sc1) stores: nothing dirty is left for the end-of-kernel write-back
-#ifndef GRB_BFS_LABEL_WT
-#define GRB_BFS_LABEL_WT 0
-#endif
-#ifndef GRB_BFS_GEN_BARRIER
-#define GRB_BFS_GEN_BARRIER 0
 #endif
 #ifndef GRB_BFS_DPP_TOTALS
 #define GRB_BFS_DPP_TOTALS 1       // the level totals' wave sums by DPP adds on 32-bit values (0: six 64-bit shuffle steps each)
@@ -77,16 +62,9 @@ namespace grb {
 #ifndef GRB_BFS_FINE_TRACE
 #define GRB_BFS_FINE_TRACE 0       // 1: the level barrier stamped step by step (tools/bfs_trace.py; measurement builds only)
 #endif
-#if GRB_BFS_GEN_BARRIER
-#define GRB_BFS_GRID_SYNC(bar, gen) grid_sync_gen(bar, gen)
-#elif GRB_BFS_FLAT_BARRIER
-#define GRB_BFS_GRID_SYNC(bar, gen) grid_sync_flat(bar, gen)
-#else
+// (the barrier's own variants -- the totals as the barrier, a flat poll of the eight group counters, a generation word per
+// group -- measured the same or slower: docs/experiments.md A.1)
 #define GRB_BFS_GRID_SYNC(bar, gen) grid_sync(bar, gen, false)
-#endif
-#if GRB_BFS_TOTALS_BARRIER
-constexpr int kTotShift = 40;     // level totals: a value lives in the low 40 bits of its word, the arrival count above
-#endif
 constexpr int kSmallDeg = 16;     // below: expanded inline by the discovering lane
 constexpr int kBigDeg = 512;      // from here: split into kBigChunk-edge entries for workgroups
 constexpr int kBigChunk = 1024;
@@ -183,9 +161,6 @@ __device__ inline void push_visit(const PersistArgs& a, unsigned int* V, unsigne
 __global__ __launch_bounds__(kPThreads) void bfs_persistent_kernel(PersistArgs a) {
   __shared__ unsigned long long s_red[kPWaves][4];
   __shared__ unsigned long long s_tot[4];
-#if GRB_BFS_TOTALS_BARRIER
-  __shared__ int s_lvl_ok;
-#endif
 #if GRB_BFS_PULL_DYN
   __shared__ int s_pull_next;                                      // dense pull: the next block of this workgroup's share
 #endif
@@ -699,54 +674,8 @@ incl = (int)wave_incl_scan_u32((unsigned)incl);
     r2 = wave_reduce(c.inspected, add); r3 = wave_reduce(c.big, add);
 #endif
     if (lane == 0) { s_red[wave][0] = r0; s_red[wave][1] = r1; s_red[wave][2] = r2; s_red[wave][3] = r3; }
-#if GRB_BFS_TOTALS_BARRIER
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's write-through stores of the level have landed
-#endif
     __syncthreads();
     unsigned long long* acc = &st->acc[iter % 3][0][0];
-#if GRB_BFS_TOTALS_BARRIER
-    // The totals are the barrier.  Every workgroup adds its four values to its XCD group's line, each with a 1 above
-    // bit kTotShift: a word whose upper part equals the group's size holds every member's contribution, whatever the
-    // order in which the words of a line are served.  So nobody arrives anywhere: wave 0 polls the 8 x 4 words (one
-    // per lane) until every word is complete, and has the totals in hand when it is.  Against totals -> counter
-    // barrier -> read-back this takes the arrival's round trip, the top counter's and the read-back's out of every
-    // level.  (The write-through stores of the level have landed before the adds go out: vmcnt(0) above, then the
-    // workgroup barrier.  A value stays below 2^40: a level's out-degree sum is at most nnz.)
-    if (wave == 0) {
-      const unsigned groups = G < 8 ? (unsigned)G : 8u;
-      if (lane < 4 && (lane != 2 || a.count_inspected)) {
-        unsigned long long t = 1ull << kTotShift;
-        for (int w = 0; w < kPWaves; ++w) t += s_red[w][lane];
-        (void)__hip_atomic_fetch_add(&acc[(blockIdx.x & 7) * 16 + lane], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-      const unsigned grp = (unsigned)lane >> 2;
-      const bool watch = lane < 32 && grp < groups && ((lane & 3) != 2 || a.count_inspected);
-      const unsigned long long want = watch ? (unsigned long long)(((unsigned)G - grp + 7u) / 8u) : 0ull;
-      unsigned long long q = 0;
-      unsigned spins = 0;
-      int ok = 1;
-      for (;;) {
-        if (watch) q = __hip_atomic_load(&acc[grp * 16 + (lane & 3)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (__all(!watch || (q >> kTotShift) == want)) break;
-        __builtin_amdgcn_s_sleep(1);
-        if (++spins > kSpinLimit ||
-            ((spins & 255u) == 0u && __hip_atomic_load(&st->bar.abort_flag[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
-          if (lane == 0) __hip_atomic_store(&st->bar.abort_flag[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          ok = 0;
-          break;
-        }
-      }
-      q = watch ? (q & ((1ull << kTotShift) - 1ull)) : 0ull;
-      q += __shfl_xor(q, 4, kWave);
-      q += __shfl_xor(q, 8, kWave);
-      q += __shfl_xor(q, 16, kWave);
-      if (lane < 4) s_tot[lane] = q;
-      if (lane == 0) s_lvl_ok = ok;
-    }
-    __syncthreads();
-    if (!s_lvl_ok) return;
-    stamp();
-#else
 #if GRB_BFS_FINE_TRACE
     stamp();                                             // reduced + workgroup barrier
 #endif
@@ -790,7 +719,6 @@ incl = (int)wave_incl_scan_u32((unsigned)incl);
       if (lane < 4) s_tot[lane] = q;
     }
     __syncthreads();
-#endif
     const unsigned long long tot_found = s_tot[0], tot_deg = s_tot[1], tot_insp = s_tot[2], tot_big = s_tot[3];
     stamp();
     if (gtid == 0 && levels < a.rec_cap) {
@@ -860,11 +788,7 @@ incl = (int)wave_incl_scan_u32((unsigned)incl);
             for (int k = 0; k < 6; ++k) lab |= ((pl[k] >> b) & 1u) << k;
             x[t] = (float)lab;
           }
-#if GRB_BFS_LABEL_WT
-          asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(out + q), "v"(make_float4(x[0], x[1], x[2], x[3])) : "memory");
-#else
           out[q] = make_float4(x[0], x[1], x[2], x[3]);
-#endif
         }
       } else {
         for (int b = 0; b < 32 && v0 + b < (long long)n; ++b) {

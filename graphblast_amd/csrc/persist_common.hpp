@@ -6,9 +6,6 @@
 #pragma once
 #include "common.hpp"
 
-#ifndef GRB_BARRIER_SLEEP
-#define GRB_BARRIER_SLEEP 1
-#endif
 
 namespace grb {
 
@@ -20,7 +17,6 @@ struct GridBarrier {                // zeroed by the host before every launch
   unsigned xcd_count[8][32];        // one 128 B line per counter
   unsigned top_count[32];
   unsigned abort_flag[32];
-  unsigned gen_word[8][32];         // grid_sync_gen: the generation each XCD group's workgroups poll (one line per group)
 };
 
 // Everything one workgroup writes for another to read goes out as an agent-scope
@@ -61,7 +57,7 @@ __device__ inline bool grid_sync(GridBarrier* st, unsigned& gen, bool invalidate
     unsigned spins = 0;
     int ok = 1;
     while (__hip_atomic_load(&st->top_count[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < groups * g) {
-      __builtin_amdgcn_s_sleep(GRB_BARRIER_SLEEP);
+      __builtin_amdgcn_s_sleep(1);
       if (++spins > kSpinLimit ||
           __hip_atomic_load(&st->abort_flag[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
         __hip_atomic_store(&st->abort_flag[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -75,80 +71,6 @@ __device__ inline bool grid_sync(GridBarrier* st, unsigned& gen, bool invalidate
   __syncthreads();
   ++gen;
   return s_ok != 0;
-}
-
-// The same barrier with nobody polling a word that is also atomically updated: the leader that completes the top counter
-// stores the generation into one word per XCD group (its own 128 B line each), and a workgroup polls its group's word --
-// 32 pollers per line instead of 256 on the line the eight leaders' adds have to get through.
-static __device__ __noinline__ bool grid_sync_gen(GridBarrier* st, unsigned& gen) {
-  __shared__ int s_ok_gen;
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's write-through stores have landed
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const unsigned g = gen + 1;
-    const unsigned G = gridDim.x;
-    const unsigned x = blockIdx.x & 7u;
-    const unsigned groups = G < 8u ? G : 8u;
-    const unsigned members = (G - x + 7u) / 8u;
-    const unsigned a = __hip_atomic_fetch_add(&st->xcd_count[x][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (a + 1u == members * g) {
-      const unsigned t = __hip_atomic_fetch_add(&st->top_count[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (t + 1u == groups * g)
-        for (unsigned k = 0; k < groups; ++k) __hip_atomic_store(&st->gen_word[k][0], g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    unsigned spins = 0;
-    int ok = 1;
-    while (__hip_atomic_load(&st->gen_word[x][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < g) {
-      __builtin_amdgcn_s_sleep(GRB_BARRIER_SLEEP);
-      if (++spins > kSpinLimit ||
-          ((spins & 255u) == 0u && __hip_atomic_load(&st->abort_flag[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
-        __hip_atomic_store(&st->abort_flag[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        ok = 0;
-        break;
-      }
-    }
-    s_ok_gen = ok;
-  }
-  __syncthreads();
-  ++gen;
-  return s_ok_gen != 0;
-}
-
-// The same barrier without the second hop: the arrival is a NON-returning add on the workgroup's XCD counter (nothing
-// waits for its round trip), and wave 0 of every workgroup polls all eight counters at once, one per lane.  The
-// hierarchical form above costs the arrival's round trip, the last arriver's add on the top counter and the poll, one
-// after the other; this one costs the add's way to memory and the poll.  Eight lines are polled instead of one, by the
-// same 256 pollers each.  Same counters, same generations: the two forms can be mixed inside one launch.
-static __device__ __noinline__ bool grid_sync_flat(GridBarrier* st, unsigned& gen) {
-  __shared__ int s_ok_flat;
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's write-through stores have landed
-  __syncthreads();
-  if (threadIdx.x < (unsigned)kWave) {
-    const unsigned g = gen + 1;
-    const unsigned G = gridDim.x;
-    const unsigned groups = G < 8u ? G : 8u;
-    const unsigned lane = threadIdx.x;
-    if (lane == 0) (void)__hip_atomic_fetch_add(&st->xcd_count[blockIdx.x & 7u][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const bool watch = lane < groups;
-    const unsigned want = watch ? ((G - lane + 7u) / 8u) * g : 0u;
-    unsigned spins = 0;
-    int ok = 1;
-    for (;;) {
-      const unsigned c = watch ? __hip_atomic_load(&st->xcd_count[lane][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-      if (__all(!watch || c >= want)) break;
-      __builtin_amdgcn_s_sleep(1);
-      if (++spins > kSpinLimit ||
-          ((spins & 255u) == 0u && __hip_atomic_load(&st->abort_flag[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
-        if (lane == 0) __hip_atomic_store(&st->abort_flag[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        ok = 0;
-        break;
-      }
-    }
-    if (lane == 0) s_ok_flat = ok;
-  }
-  __syncthreads();
-  ++gen;
-  return s_ok_flat != 0;
 }
 
 // The set bits of a wave's 64 bitmap words, one per lane per step.  A thread that walks its own word bit by bit
