@@ -180,7 +180,10 @@ __global__ __launch_bounds__(kBlock) void spgemm_masked_kernel(
 #ifndef GRB_TC_DEPTH
 #define GRB_TC_DEPTH 2                     // chunks of a partner stream in flight behind the one being probed
 #endif
-constexpr int kWaveCap = 512;              // pivot entries a wave's table holds (1024 slots x 8 B = 8 KiB per wave)
+#ifndef GRB_TC_WAVE_CAP
+#define GRB_TC_WAVE_CAP 256
+#endif
+constexpr int kWaveCap = GRB_TC_WAVE_CAP;  // pivot entries a wave's table holds (1024 slots x 8 B = 8 KiB per wave)
 constexpr int kWaveSlots = 2 * kWaveCap;
 constexpr unsigned int kEmptyKey = 0xffffffffu;
 
