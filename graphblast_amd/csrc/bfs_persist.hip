@@ -34,7 +34,7 @@ namespace grb {
 #define GRB_BFS_SPARSE_PULL 1
 #endif
 #ifndef GRB_BFS_SPARSE_DIV
-#define GRB_BFS_SPARSE_DIV 8
+#define GRB_BFS_SPARSE_DIV 4
 #endif
 #ifndef GRB_BFS_SYM
 #define GRB_BFS_SYM 1
@@ -65,8 +65,14 @@ namespace grb {
 // (the barrier's own variants -- the totals as the barrier, a flat poll of the eight group counters, a generation word per
 // group -- measured the same or slower: docs/experiments.md A.1)
 #define GRB_BFS_GRID_SYNC(bar, gen) grid_sync(bar, gen, false)
-constexpr int kSmallDeg = 16;     // below: expanded inline by the discovering lane
-constexpr int kBigDeg = 512;      // from here: split into kBigChunk-edge entries for workgroups
+#ifndef GRB_BFS_SMALL_DEG
+#define GRB_BFS_SMALL_DEG 8
+#endif
+#ifndef GRB_BFS_BIG_DEG
+#define GRB_BFS_BIG_DEG 256
+#endif
+constexpr int kSmallDeg = GRB_BFS_SMALL_DEG;  // below: expanded inline by the discovering lane
+constexpr int kBigDeg = GRB_BFS_BIG_DEG;      // from here: split into kBigChunk-edge entries for workgroups
 constexpr int kBigChunk = 1024;
 constexpr int kPullBlock = GRB_PULL_BLOCK;    // chunks (of 64 vertices) one wave carries through the pull stages together
 static_assert(kPullBlock * kWave <= kPullQueue, "a wave queues at most every vertex of its block");

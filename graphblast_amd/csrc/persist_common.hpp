@@ -167,7 +167,10 @@ incl = (int)wave_incl_scan_u32((unsigned)incl);
 
 
 struct __attribute__((packed, aligned(4))) Quad { Index x, y, z, w; };   // four consecutive column ids
-constexpr int kSparseWords = 32;  // bitmap words (of 32 vertices) a wave takes per step of a pull level with a sparse active set
+#ifndef GRB_SPARSE_WORDS
+#define GRB_SPARSE_WORDS 32
+#endif
+constexpr int kSparseWords = GRB_SPARSE_WORDS;  // bitmap words (of 32 vertices) a wave takes per step of a pull level with a sparse active set
 constexpr int kPullProbe4 = 4;
 
 // ---- pull levels: what a wave does with the rows its first probe (the hinted in-neighbour) did not settle --------
