@@ -33,6 +33,9 @@ namespace grb {
 #ifndef GRB_BFS_SPARSE_PULL
 #define GRB_BFS_SPARSE_PULL 1
 #endif
+#ifndef GRB_BFS_LABEL_COAL
+#define GRB_BFS_LABEL_COAL 1
+#endif
 #ifndef GRB_BFS_SPARSE_DIV
 #define GRB_BFS_SPARSE_DIV 4
 #endif
@@ -77,6 +80,7 @@ constexpr int kBigChunk = 1024;
 constexpr int kPullBlock = GRB_PULL_BLOCK;    // chunks (of 64 vertices) one wave carries through the pull stages together
 static_assert(kPullBlock * kWave <= kPullQueue, "a wave queues at most every vertex of its block");
 constexpr int kMedCap = 4096;     // LDS list of medium vertices per workgroup pass
+typedef float LabelQuad __attribute__((ext_vector_type(4)));
 constexpr int kKeep = 32;         // levels whose discovered-bitmaps are kept for the final label pass
 
 struct PersistState {               // zeroed by the host before every launch
@@ -757,6 +761,65 @@ incl = (int)wave_incl_scan_u32((unsigned)incl);
     const unsigned int* Vf = a.V[cur];
     const int kept = levels + 1 < kKeep ? levels + 1 : kKeep;      // F[0 .. kept)
     const bool label_aligned = (reinterpret_cast<unsigned long long>(a.label) & 15ull) == 0ull;
+#if GRB_BFS_LABEL_COAL
+    // 32 words per wave step (every wave of the grid has one at n = 4 Mi); a word's six planes are computed by the
+    // lane that loaded it and handed to the eight lanes that store its labels: a store instruction then writes
+    // 64 x 16 consecutive bytes (eight whole lines) instead of 16 bytes in each of 64 lines.
+    const long long nwave_all = (long long)G * (kPThreads / kWave);
+    for (long long wb = ((long long)blockIdx.x * (kPThreads / kWave) + wave) * 32; wb < nwords; wb += nwave_all * 32) {
+      const long long wi0 = wb + (lane & 31);
+      const bool have = wi0 < nwords;
+      const long long wi = have ? wi0 : (long long)nwords - 1;
+      const unsigned int vis = have ? fresh(&Vf[wi]) : 0u;
+      unsigned int f[kKeep];
+#pragma unroll
+      for (int L0 = 0; L0 < kKeep; L0 += 8) {
+        if (L0 < kept) {
+#pragma unroll
+          for (int u = 0; u < 8; ++u) f[L0 + u] = (L0 + u < kept && have) ? fresh(&a.F[L0 + u][wi]) : 0u;
+        } else {
+#pragma unroll
+          for (int u = 0; u < 8; ++u) f[L0 + u] = 0u;
+        }
+      }
+      unsigned int pl[6] = {0u, 0u, 0u, 0u, 0u, 0u};
+#pragma unroll
+      for (int L = 0; L < kKeep; ++L) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k)
+          if (((L + 1) >> k) & 1) pl[k] |= f[L];
+      }
+      const unsigned int keepm = vis & ~(pl[0] | pl[1] | pl[2] | pl[3] | pl[4] | pl[5]);
+      const bool whole = label_aligned && (wb + 32) * 32 <= (long long)n && __ballot(keepm != 0u) == 0ull;
+      if (whole) {
+        LabelQuad* out = reinterpret_cast<LabelQuad*>(a.label + wb * 32) + lane;
+        const int b0 = (lane & 7) * 4;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int src = q * 8 + (lane >> 3);
+          unsigned int lab[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+          for (int k = 0; k < 6; ++k) {
+            const unsigned int pk = (unsigned int)__shfl((int)pl[k], src, kWave) >> b0;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) lab[t] |= ((pk >> t) & 1u) << k;
+          }
+          LabelQuad x;
+          x.x = (float)lab[0]; x.y = (float)lab[1]; x.z = (float)lab[2]; x.w = (float)lab[3];
+          out[q * 64] = x;
+        }
+      } else if (have && lane < 32) {
+        const long long v0 = wi * 32;
+        for (int b = 0; b < 32 && v0 + b < (long long)n; ++b) {
+          unsigned int lab = 0u;
+#pragma unroll
+          for (int k = 0; k < 6; ++k) lab |= ((pl[k] >> b) & 1u) << k;
+          if (!((keepm >> b) & 1u)) a.label[v0 + b] = (float)lab;
+        }
+      }
+    }
+  }
+#else
     for (long long wi = gtid; wi < nwords; wi += gthreads) {
       const unsigned int vis = fresh(&Vf[wi]);
       unsigned int f[kKeep];
@@ -806,6 +869,7 @@ incl = (int)wave_incl_scan_u32((unsigned)incl);
       }
     }
   }
+#endif
   stamp();
   if (a.trace && gtid == 0) a.trace[0] = (unsigned long long)ntrace;
   if (gtid == 0) {
