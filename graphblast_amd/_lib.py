@@ -116,7 +116,6 @@ _SIGS = {
                         C.POINTER(_i)],
     "grb_semiring_register": [_i, _d, _i, C.POINTER(_i)],
     "grb_spmm": [_i, _vp, _i, _vp, _vp, _i, _vp],
-    "grb_spmm_core_info": [_vp, _i, C.POINTER(_i), C.POINTER(C.c_int64)],
     "grb_spmv_set_bands": [_i],
     "grb_spmv_set_format": [_i],
     "grb_spmv_set_reuse_threshold": [_i],

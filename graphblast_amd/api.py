@@ -504,12 +504,6 @@ def spmm(op, A, d_B, d_C, k, desc=None, tran=False):
     return _lib.load().grb_spmm(_semiring_id(op), _h(A), int(bool(tran)), d_B, d_C, int(k), _h(desc))
 
 
-def spmm_core_info(A, tran=False):
-    nt, nz = C.c_int(0), C.c_int64(0)
-    _lib.call("grb_spmm_core_info", _h(A), int(bool(tran)), C.byref(nt), C.byref(nz))
-    return nt.value, nz.value
-
-
 def bfs_batch(vs, A, sources, desc):
     """Up to 64 traversals at once (grb_bfs_batch): vs[i] receives the depth labels of sources[i]."""
     k = len(vs)

@@ -5,8 +5,8 @@
 // (backend/cuda/operations.hpp:52-70, spmm.hpp:15-27).  With k <= 64 a row of F is ONE 64-bit
 // word (bit s = "in the frontier of source s"), the semiring's add is a word-wide OR, its
 // multiply the AND with the edge's presence: one 8-byte gather per edge serves 64 traversals.
-// No tile of A is dense enough for a matrix core to beat that (multi-frontier): the
-// MFMA path of this library is the dense-core SpMM in spmm.hip.
+// No tile of A is dense enough for a matrix core to beat that (the dense-core SpMM path that
+// tried was measured slower and removed in round 5).
 //
 //   seen[v], W_L[v]  one 64-bit word per vertex; W_L = the bits discovered by level L, kept for
 //                    the first kStore levels (the frontier of level L + 1 IS W_L)

@@ -618,21 +618,6 @@ struct BatchSlices {
   int* d_range_ids = nullptr;        // the ranges of at most 2 Ki rows first (nsmall of them), then the wider ones
   int nsmall = 0;
 };
-// dense-core split of one orientation for the MFMA SpMM path (spmm.hip)
-struct SpmmCore {
-  bool built = false;
-  int H = 0;                      // rows / columns considered
-  int ntiles = 0, ntrows = 0;     // stored 16 x 16 tiles, tile rows
-  long long nnz_core = 0;         // entries moved into tiles
-  int* d_trow_ptr = nullptr;      // [ntrows + 1]
-  int* d_tcol = nullptr;          // [ntiles] tile column
-  float* d_tvals = nullptr;       // [ntiles][16][16], transposed ([kk][i])
-  Index* d_rows = nullptr;        // [ntrows * 16] core row -> matrix row (-1 padding)
-  Index* d_cols = nullptr;        // [ntcols * 16] core column -> matrix column (-1 padding)
-  CsrArrays rest;                 // the matrix without the entries of stored tiles
-  SpmvPlan rest_plan;
-};
-void free_spmm_core(SpmmCore* core);
 int spmv_reuse_threshold(int set);
 grb_info k_apply_unary(int dtype, int unary, int op, double scalar, const void* in, void* out, Index n);   // elementwise.hip
 // ---- lazy.hip: the queue of element-wise calls.  EVERY entry point of the C ABI starts with one of these macros:
@@ -712,16 +697,12 @@ struct grb_matrix_s {
   int* d_oc2_bigidx = nullptr;
   int oc2_nb = 0, oc2_nrows = 0, oc2_state = 0, oc2_grid = 0;
   grb::BatchSlices batch_in, batch_out;          // bfs_batch.hip, built lazily
-  grb::SpmmCore spmm_core_csr, spmm_core_csc;    // spmm.hip, built lazily when GRB_SPMM_CORE is set
 };
 
-// Every cache that holds a copy of the stored VALUES (not structure) is dropped: the SpMV band formats, the SpMM
-// dense-core tiles.  Called by whatever rewrites csr.val / csc.val in place.
+// Every cache that holds a copy of the stored VALUES (not structure) is dropped: the SpMV band formats.  Called by whatever rewrites csr.val / csc.val in place.
 inline void matrix_values_changed(grb_matrix_s* A) {
   grb::spmv_plan_values_changed(&A->plan_csr);
   grb::spmv_plan_values_changed(&A->plan_csc);
-  grb::free_spmm_core(&A->spmm_core_csr);
-  grb::free_spmm_core(&A->spmm_core_csc);
 }
 
 namespace grb {

@@ -845,8 +845,6 @@ void grb::matrix_release_device(grb_matrix A) {
     *b = BatchSlices();
   }
   A->nonneg_values = -1; A->mean_value = -1.0; A->small_int_values = -1;
-  free_spmm_core(&A->spmm_core_csr);
-  free_spmm_core(&A->spmm_core_csc);
   free_spmv_plan(&A->plan_csr);
   free_spmv_plan(&A->plan_csc);
   A->built = false;

@@ -447,15 +447,10 @@ typedef struct {
  * backend/cuda/operations.hpp:52-70 "SpMM and GEMM not implemented yet", spmm.hpp:15-27):
  *   C = A (+).(x) B   (tran = 0)      C = A^T (+).(x) B   (tran = 1)
  * B [ncols(A or A^T) x k] and C [nrows x k] dense row-major DEVICE arrays of A's element type, any of
- * the 17 semirings; no mask / accum (NULL in the reference's signature).  With GRB_SPMM_CORE=<H> in
- * the environment and PlusMultiplies f32, the dense 16 x 16 tiles among the top-H rows x top-H
- * columns are multiplied on the matrix cores (v_mfma_f32_16x16x4_f32); grb_spmm_core_info reports
- * how many tiles / entries that split holds.  That path multiplies the explicit zeros of a stored tile with
- * rows of B and sums duplicate entries into one cell: it is for FINITE B (0 x Inf = NaN would reach rows
- * that hold no entry in that column) and off unless the variable is set. */
+ * the 17 semirings; no mask / accum (NULL in the reference's signature).  Row sums in the stored order of a row's
+ * entries.  (The Boolean multi-frontier product -- many traversals at once -- is grb_bfs_batch, not this.) */
 grb_info grb_spmm(grb_semiring op, grb_matrix A, int tran, const void* d_B, void* d_C, grb_index k,
                   grb_descriptor desc);
-grb_info grb_spmm_core_info(grb_matrix A, int tran, int* ntiles, int64_t* nnz_in_tiles);
 
 /* How the generic SpMV (grb_k_spmv, the pull half of mxv / vxm) reads the input vector for this orientation:
  * `nhot` leading values of the rank-packed vector are staged in LDS; with `bands` > 1 the matrix is also split

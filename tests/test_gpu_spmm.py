@@ -1,7 +1,7 @@
 """GPU suite (-m gpu): grb_spmm -- mxm with a dense right-hand side, the product the reference declares and
 leaves a stub (backend/cuda/operations.hpp:52-70, spmm.hpp:15-27).  Checked column by column against the
-oracle's SpMV definition (oracle/ops.py follows backend/cuda/spmv.hpp), all 17 semirings, and -- for the
-MFMA dense-core path -- against the plain CSR path."""
+oracle's SpMV definition (oracle/ops.py follows backend/cuda/spmv.hpp), all 17 semirings, and against the
+library's own mxv column by column."""
 import os
 
 import numpy as np
@@ -98,39 +98,3 @@ def test_spmm_columns_equal_spmv(hb):
                 assert np.allclose(got[:, c], col, rtol=1e-5, atol=0), (op, c)     # mxv sums long rows slice-wise too
             else:
                 assert np.array_equal(got[:, c], col), (op, c)
-
-
-def test_spmm_mfma_core_path(hb, monkeypatch):
-    """GRB_SPMM_CORE=<H>: dense 16 x 16 tiles among the top-H rows x columns go through
-    v_mfma_f32_16x16x4_f32.  A graph with a planted dense block (so that tiles qualify): integer-valued
-    data -> exactly the CSR path's result; random floats -> within 1e-5 relative; with an ASYMMETRIC B."""
-    from graphblast_amd.graphgen import rmat_edges, finalize_edges
-    g = hb.g
-    rng = np.random.default_rng(12)
-    s, d, n = rmat_edges(12, 8, seed=3)
-    blk = rng.permutation(n)[:96]
-    bs, bd = np.meshgrid(blk, blk)
-    keep = rng.random(bs.size) < 0.6
-    src = np.concatenate([s, bs.ravel()[keep]])
-    dst = np.concatenate([d, bd.ravel()[keep]])
-    gr = finalize_edges(src, dst, n, symmetrize=False)
-    ptr, ind = gr["csr"]
-    for vals, exact in ((rng.integers(1, 5, ind.size).astype(F), True), (rng.random(ind.size).astype(F), False)):
-        A = g.Matrix(n, n)
-        assert A.build_csr(ptr, ind, vals) == 0
-        for k in (16, 64, 40):
-            B = (rng.integers(0, 7, (n, k)) + np.arange(k)[None, :] * 0.5).astype(F)
-            monkeypatch.delenv("GRB_SPMM_CORE", raising=False)
-            plain = run_spmm(g, A, "PlusMultiplies", B, n)
-            monkeypatch.setenv("GRB_SPMM_CORE", "256")
-            core = run_spmm(g, A, "PlusMultiplies", B, n)
-            ntiles, nnz_tiles = g.spmm_core_info(A)
-            assert ntiles >= 20 and nnz_tiles >= 20 * 24, (ntiles, nnz_tiles)
-            if exact:
-                assert np.array_equal(core, plain), k
-            else:
-                assert np.allclose(core, plain, rtol=1e-5, atol=1e-6), k
-            # other semirings ignore the switch
-            mp = run_spmm(g, A, "MinimumPlus", B, n)
-            monkeypatch.delenv("GRB_SPMM_CORE")
-            assert np.array_equal(mp, run_spmm(g, A, "MinimumPlus", B, n))

@@ -1,6 +1,5 @@
 #!/usr/bin/env python3
-"""grb_spmm on the bench graph: CSR wave-tile kernel alone vs with the MFMA dense-core split
-(GRB_SPMM_CORE=H), k right-hand sides.  python tools/spmm_bench.py [scale] [k] [H ...]"""
+"""grb_spmm on the bench graph, k right-hand sides.  python tools/spmm_bench.py [scale] [k]"""
 import os
 import sys
 
@@ -13,7 +12,6 @@ from graphblast_amd.graphgen import rmat_edges, finalize_edges
 
 scale = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 k = int(sys.argv[2]) if len(sys.argv) > 2 else 64
-Hs = [int(x) for x in sys.argv[3:]] or [0, 1024, 4096]
 dev = torch.device("cuda", 0)
 src, dst, n = rmat_edges(scale, 16, seed=1, device=dev)
 gr = finalize_edges(src, dst, n, symmetrize=True)
@@ -22,28 +20,16 @@ nnz = gr["nnz"]
 tval = torch.rand(nnz, dtype=torch.float32, device=dev)
 B = torch.rand((n, k), dtype=torch.float32, device=dev)
 C = torch.empty((n, k), dtype=torch.float32, device=dev)
-ref = None
-for H in Hs:
-    if H:
-        os.environ["GRB_SPMM_CORE"] = str(H)
-    else:
-        os.environ.pop("GRB_SPMM_CORE", None)
-    A = g.Matrix(n, n)
-    assert A.build_csr(tptr.cpu().numpy(), tind.cpu().numpy(), tval.cpu().numpy()) == 0
-    for _ in range(2):
-        assert g.spmm("PlusMultiplies", A, B.data_ptr(), C.data_ptr(), k) == 0
-    torch.cuda.synchronize()
-    reps = 5
-    g.timer_start()
-    for _ in range(reps):
-        g.spmm("PlusMultiplies", A, B.data_ptr(), C.data_ptr(), k)
-    ms = g.timer_stop() / reps
-    nt, nz = g.spmm_core_info(A)
-    out = C.cpu().numpy()
-    if ref is None:
-        ref = out.copy()
-    err = float(np.max(np.abs(out - ref) / np.maximum(np.abs(ref), 1e-20)))
-    alg = 8.0 * nnz + 4.0 * (n + 1) + 2 * 4.0 * n * k            # matrix + B once + C once
-    print("rmat%d k=%d H=%d: %.3f ms  %.1f GFLOP/s  %.2f TB/s algorithmic (%.2f TB/s of B gathers)  tiles %d holding %d entries (%.2f%%)  max rel diff vs H=0 %.2e"
-          % (scale, k, H, ms, 2.0 * nnz * k / ms / 1e6, alg / ms / 1e9, 4.0 * k * nnz / ms / 1e9, nt, nz, 100.0 * nz / nnz, err))
-    del A
+A = g.Matrix(n, n)
+assert A.build_csr(tptr.cpu().numpy(), tind.cpu().numpy(), tval.cpu().numpy()) == 0
+for _ in range(2):
+    assert g.spmm("PlusMultiplies", A, B.data_ptr(), C.data_ptr(), k) == 0
+torch.cuda.synchronize()
+reps = 5
+g.timer_start()
+for _ in range(reps):
+    g.spmm("PlusMultiplies", A, B.data_ptr(), C.data_ptr(), k)
+ms = g.timer_stop() / reps
+alg = 8.0 * nnz + 4.0 * (n + 1) + 2 * 4.0 * n * k            # matrix + B once + C once
+print("rmat%d k=%d: %.3f ms  %.1f GFLOP/s  %.2f TB/s algorithmic (%.2f TB/s of B gathers)"
+      % (scale, k, ms, 2.0 * nnz * k / ms / 1e6, alg / ms / 1e9, 4.0 * k * nnz / ms / 1e9))
