@@ -1073,8 +1073,9 @@ grb_info ring_init() {
   GRB_HIP_TRY(hipMemset(r.d_levels, 0, 256));
   return GRB_SUCCESS;
 }
-// the record in slot `slot` once it carries tag `seq`: spins, then (after 5 ms) waits for the stream and looks again
-grb_info ring_wait(int slot, int seq, unsigned int* out) {
+// the record in slot `slot` once it carries tag `seq`: spins, then (after 5 ms) waits for the stream the traversal was
+// queued on (its lane's) and looks again
+grb_info ring_wait(int slot, int seq, unsigned int* out, hipStream_t stream) {
   const unsigned long long* hg = g_ring.h + 8 * (size_t)slot;
   const auto t0 = std::chrono::steady_clock::now();
   unsigned spins = 0;
@@ -1092,7 +1093,7 @@ grb_info ring_wait(int slot, int seq, unsigned int* out) {
       return GRB_PANIC;
     }
     if ((++spins & 1023u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(5)) {
-      GRB_HIP_TRY(hipStreamSynchronize(ctx().stream));
+      GRB_HIP_TRY(hipStreamSynchronize(stream));
       synced = true;
     }
   }
@@ -1333,14 +1334,14 @@ static grb_info bfs_persistent_launch(grb_vector v, grb_matrix A, grb_index sour
 static grb_info bfs_persistent_collect(int slot, int seq, int profile, void* p_rec, unsigned long long* trace,
                                        grb_bfs_level* levels_out, int max_levels, int* levels, int* last_dir,
                                        long long* reached, unsigned long long* edges, Index* nf_left, bool* hit_cap,
-                                       float* tight_ms) {
+                                       float* tight_ms, int lane_id = 0) {
   Context& c = ctx();
-  hipStream_t s = c.stream;
+  hipStream_t s = lane_id > 0 && g_ring.lane[lane_id].stream ? g_ring.lane[lane_id].stream : c.stream;
   const int rec_cap = 1 << 15;
   unsigned int gv[8];
   if (seq <= g_ring.poisoned_upto) return GRB_PANIC;            // queued behind a traversal that did not finish
   {
-    const grb_info wi = ring_wait(slot, seq, gv);
+    const grb_info wi = ring_wait(slot, seq, gv, s);
     if (wi != GRB_SUCCESS) {
       // the kernel left early (its barrier gave up) without leaving its level count: the next launch cleared too little
       // of this block, and every traversal queued since ran on whatever that left
@@ -1464,12 +1465,12 @@ void grb::bfs_ticket_release(int slot) { g_ring.t[slot].state = 0; }
 grb_info grb::bfs_persistent_wait(int slot, int seq, int* levels, int* last_dir, long long* reached, unsigned long long* edges,
                                   Index* nf_left, bool* hit_cap, float* tight_ms) {
   const auto t0 = std::chrono::steady_clock::now();
+  const int lane = g_ring.t[slot].lane;
   const grb_info r = bfs_persistent_collect(slot, seq, 0, nullptr, nullptr, nullptr, 0, levels, last_dir, reached, edges, nf_left,
-                                            hit_cap, tight_ms);
+                                            hit_cap, tight_ms, lane);
   // a lane's launch is not ordered against the library's stream by itself: whatever is queued there from now on
   // (reading the labels, say) waits for the lane's last launch -- the record is written by ONE workgroup's last
   // instruction, others may still be storing labels
-  const int lane = g_ring.t[slot].lane;
   if (r == GRB_SUCCESS && lane > 0 && g_ring.lane[lane].ev_done) (void)hipStreamWaitEvent(ctx().stream, g_ring.lane[lane].ev_done, 0);
   g_ring.wait_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
   return r;

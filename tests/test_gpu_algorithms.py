@@ -313,6 +313,38 @@ def test_bfs_lanes(hb, graphs):
         g.bfs_set_lanes(before)
 
 
+def test_bfs_lanes_waited_for_in_reverse(hb, graphs, capfd):
+    """250 traversals queued over two lanes and waited for LAST ticket first: the wait outlasts its spin phase (5 ms) and
+    falls back to waiting for the stream -- the stream of the ticket's lane, not the library's (a wait on the wrong stream
+    saw no record and sent the whole queue through the host-driven loop)."""
+    from oracle import simple_reference as sr
+    g = hb.g
+    before = g.bfs_set_lanes(-1)
+    try:
+        g.bfs_set_lanes(2)
+        name, gr = max(graphs, key=lambda x: x[1]["nnz"])
+        ptr, ind = gr["csr"]
+        A = build(hb, gr)
+        n = gr["n"]
+        srcs = [first_source(gr)] + g.graphgen.random_sources(ptr, 9, seed=11)
+        d = hb.descriptor(mxvmode=0, struconly=1, opreuse=1, edgeswitch=0.05)
+        vs = [g.Vector(n) for _ in range(250)]
+        capfd.readouterr()
+        tickets = [g.bfs_enqueue(v, A, srcs[k % len(srcs)], d) for k, v in enumerate(vs)]
+        assert all(i == 0 for i, _ in tickets)
+        res = [g.bfs_wait(t) for _, t in reversed(tickets)][::-1]
+        assert all(i == 0 for i, _ in res)
+        err = capfd.readouterr().err
+        assert "not published" not in err and "host-driven" not in err, err
+        want = {s_: sr.bfs(ptr, ind, s_)[0] for s_ in srcs}
+        for k in (0, 1, 124, 125, 248, 249):
+            w = want[srcs[k % len(srcs)]]
+            assert np.array_equal(hb.dense_values(vs[k]), w), k
+            assert res[k][1]["reached"] == int(np.count_nonzero(w))
+    finally:
+        g.bfs_set_lanes(before)
+
+
 def test_bfs_vertex_zero_without_in_edges(hb):
     """Vertex 0 isolated (its pull hint is -1) on a graph whose later pull levels take the sparse-active-set path: the
     idle lanes of that path carry vertex 0 and must not probe word -1 of the visited bitmap."""
