@@ -677,6 +677,7 @@ struct grb_matrix_s {
   std::vector<uint32_t> h_csr_val, h_csc_val;   // raw 4-byte values of dtype
   grb::CsrArrays csr, csc;                       // device
   grb::SpmvPlan plan_csr, plan_csc;
+  bool plan_csr_pending = false;                 // the CSR side's plan is built at its first use (mxm results: most are never multiplied)
   unsigned int* d_no_in_edges = nullptr;         // bitmap: CSC column empty (built lazily by bfs_fused)
   unsigned int* d_empty_csr_rows = nullptr;      // bitmap: CSR row empty (built lazily by bfs_part)
   int nonneg_values = -1;                        // -1 unknown, else whether every stored value is >= 0 (sssp_persist)
@@ -758,6 +759,14 @@ grb_info k_gather_indexed(int dtype, void* w, Index w_n, const int* idx, Index n
 
 // spmv.hip
 grb_info build_spmv_plan(const std::vector<Index>& ptr, Index n, Index nminor, SpmvPlan* plan);
+}  // namespace grb
+// the plan of one orientation, built now if its construction was put off (grb_matrix_s::plan_csr_pending)
+inline grb_info matrix_ensure_plan(grb_matrix_s* A, bool tran) {
+  if (tran || !A->plan_csr_pending) return GRB_SUCCESS;
+  A->plan_csr_pending = false;
+  return grb::build_spmv_plan(A->h_csr_ptr, A->nrows, A->ncols, &A->plan_csr);
+}
+namespace grb {
 void free_spmv_plan(SpmvPlan* plan);
 // build.hip: columns ranked by descending reference count on the device (d_other_ptr: the transposed
 // orientation's pointer array, whose differences ARE the counts; nullptr: histogram of d_ind)

@@ -1116,13 +1116,27 @@ grb_info grb_mxm(grb_matrix C, grb_matrix mask, grb_accum accum, grb_semiring op
   // C takes the mask's structure (C->dup(&mask->sparse_), spgemm.hpp:78-79)
   // whatever C held before goes, with the per-graph side arrays that described it (skip bitmaps,
   // pull hint, plans): a later traversal of C must not see hints of another graph
+  // ... but its three arrays stay when C already holds a result of this shape (the same output matrix in a loop of
+  // products: three hipFree and three hipMalloc of 4 nvals bytes a call otherwise, each a trip through the driver)
+  CsrArrays kept;
+#ifndef GRB_MXM_EAGER_RESULT                     // (build flag for the A/B: the round-4 behaviour -- fresh arrays, plan built here)
+  if (C->built && C->owned && C != mask && C != A && C != B && !C->csc.ptr && C->csr.ptr && C->csr.ind && C->csr.val &&
+      C->nrows == mask->nrows && C->csr.nvals == mask->nvals) {
+    kept = C->csr;
+    C->csr = CsrArrays();
+  }
+#endif
   matrix_release_device(C);
   C->owned = true;
   C->nvals = mask->nvals;
   const size_t cap = mask->nvals > 0 ? (size_t)mask->nvals : 1;
-  GRB_HIP_TRY(hipMalloc((void**)&C->csr.ptr, 4 * ((size_t)mask->nrows + 1)));
-  GRB_HIP_TRY(hipMalloc((void**)&C->csr.ind, 4 * cap));
-  GRB_HIP_TRY(hipMalloc(&C->csr.val, 4 * cap));
+  if (kept.ptr) {
+    C->csr.ptr = kept.ptr; C->csr.ind = kept.ind; C->csr.val = kept.val;
+  } else {
+    GRB_HIP_TRY(hipMalloc((void**)&C->csr.ptr, 4 * ((size_t)mask->nrows + 1)));
+    GRB_HIP_TRY(hipMalloc((void**)&C->csr.ind, 4 * cap));
+    GRB_HIP_TRY(hipMalloc(&C->csr.val, 4 * cap));
+  }
   GRB_HIP_TRY(hipMemcpyAsync(C->csr.ptr, mask->csr.ptr, 4 * ((size_t)mask->nrows + 1), hipMemcpyDeviceToDevice, s));
   if (mask->nvals > 0)
     GRB_HIP_TRY(hipMemcpyAsync(C->csr.ind, mask->csr.ind, 4 * (size_t)mask->nvals, hipMemcpyDeviceToDevice, s));
@@ -1131,7 +1145,11 @@ grb_info grb_mxm(grb_matrix C, grb_matrix mask, grb_accum accum, grb_semiring op
   C->h_csr_ptr = mask->h_csr_ptr;
   C->h_csr_ind.clear(); C->h_csr_val.clear();
   C->h_csc_ptr.clear(); C->h_csc_ind.clear(); C->h_csc_val.clear();
-  GRB_TRY(build_spmv_plan(C->h_csr_ptr, C->nrows, C->ncols, &C->plan_csr));   // mxv on the result works;
+#ifdef GRB_MXM_EAGER_RESULT
+  GRB_TRY(build_spmv_plan(C->h_csr_ptr, C->nrows, C->ncols, &C->plan_csr));
+#else
+  C->plan_csr_pending = true;                    // mxv on the result works: its plan is built when one is asked for;
+#endif
   C->built = true;                               // no CSC is made (as little as the reference's C->dup has one):
   if (mask->nvals == 0) return GRB_SUCCESS;      // products on the transpose return GrB_INVALID_OBJECT
   // ---- pivot-driven passes when the host mirrors of the row pointers are there (they list the long pivots);
@@ -1171,11 +1189,17 @@ grb_info grb_mxm(grb_matrix C, grb_matrix mask, grb_accum accum, grb_semiring op
     hipLaunchKernelGGL((fill_value_kernel<T>), dim3(stream_grid(mask->nvals, kBlock)), dim3(kBlock), 0, s, (T*)C->csr.val,
                        mask->nvals, Semiring<SR, T>::identity());
     GRB_HIP_TRY(hipGetLastError());
-    std::vector<PivotItem> big;
+    // a pass's list is the source of an asynchronous copy: both lists live until the stream has been waited for, once, on
+    // the way out (the guard is destroyed first) -- the host's work for the second pass (4 M row lengths, a sort) then runs
+    // while the device is busy with the first, not after it
+    std::vector<PivotItem> big_store[2];
+    struct SyncOnExit { hipStream_t s; ~SyncOnExit() { (void)hipStreamSynchronize(s); } } sync_on_exit{s};
+    int pass_no = 0;
     auto run_pass = [&](const PivotView& v, Index npiv, bool piv_iso, const std::vector<Index>& hp_piv,
                         const std::vector<Index>& hp_ent, int scratch_list) -> grb_info {
       // the long pivots' entries in runs of <= 4 tiles, heaviest first (a run costs about entries x pivot length:
       // its partners are no longer than the pivot), dealt round-robin: the few giant rows do not become the tail
+      std::vector<PivotItem>& big = big_store[pass_no++ & 1];
       big.clear();
       Index longest = 0;
       for (Index r = 0; r < npiv; ++r) {
@@ -1272,7 +1296,9 @@ grb_info grb_mxm(grb_matrix C, grb_matrix mask, grb_accum accum, grb_semiring op
       };
       if (iso) GRB_TRY(launch(KeySlot{}));
       else GRB_TRY(launch(HashSlot{}));
-      GRB_HIP_TRY(hipStreamSynchronize(s));               // `big` is a host vector the copy above reads
+#ifdef GRB_MXM_EAGER_RESULT
+      GRB_HIP_TRY(hipStreamSynchronize(s));               // (round 4: the stream waited for after every pass)
+#endif
       return GRB_SUCCESS;
     };
     PivotView v1;

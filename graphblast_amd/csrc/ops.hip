@@ -20,6 +20,7 @@ static grb_info spmv_dispatch(grb_vector w, grb_vector mask, grb_accum accum, in
   const CsrArrays& M = use_tran ? A->csc : A->csr;
   SpmvPlan& plan = use_tran ? A->plan_csc : A->plan_csr;
   if (!M.ptr) return GRB_INVALID_OBJECT;
+  GRB_TRY(matrix_ensure_plan(A, use_tran));
   // "functor == 1": add_op(3, 5) == 1 selects the Boolean fused-mask kernel (spmv.hpp:84-96)
   const int functor = (int)semiring_add(op, w->dtype, 3, 5);
   if (use_mask && desc->fusedmask && functor == 1) {
@@ -457,6 +458,7 @@ grb_info grb_k_spmv(grb_matrix A, int tran, grb_semiring op, const void* d_u, co
   const CsrArrays& M = tran ? A->csc : A->csr;
   SpmvPlan& plan = tran ? A->plan_csc : A->plan_csr;
   if (!M.ptr) return GRB_INVALID_OBJECT;
+  GRB_TRY(matrix_ensure_plan(A, tran != 0));
   const CsrArrays& other = tran ? A->csr : A->csc;
   return k_spmv(op, A->dtype, M, plan, d_u, d_mask, A->dtype == GRB_F32, scmp, accum, d_w,
                 (other.ptr && other.n == plan.nminor && !A->csc_alias) ? other.ptr : nullptr);
@@ -469,6 +471,7 @@ int grb_spmv_set_reuse_threshold(int launches) { GRB_API_ENTER_NOINFO(); return 
 grb_info grb_spmv_format_info(grb_matrix A, int tran, int* in_use, int64_t* groups, int* bands, int* items, int* hub_rows,
                               int* iso, int64_t* bytes_per_launch) { GRB_API_ENTER();
   if (!A || !A->built) return GRB_UNINITIALIZED_OBJECT;
+  GRB_TRY(matrix_ensure_plan(A, tran != 0));
   SpmvPlan& plan = tran ? A->plan_csc : A->plan_csr;
   long long g = 0, by = 0;
   int b = 0, it = 0, h = 0, is = 0;
@@ -493,6 +496,7 @@ grb_info grb_spmv_plan_info(grb_matrix A, int tran, int warm, int* bands, int64_
   const CsrArrays& M = tran ? A->csc : A->csr;
   SpmvPlan& plan = tran ? A->plan_csc : A->plan_csr;
   if (!M.ptr) return GRB_INVALID_OBJECT;
+  GRB_TRY(matrix_ensure_plan(A, tran != 0));
   const CsrArrays& other = tran ? A->csr : A->csc;
   long long bn = 0, pc = 0;
   GRB_TRY(k_spmv_plan_info(M, plan, (other.ptr && other.n == plan.nminor && !A->csc_alias) ? other.ptr : nullptr, warm,

@@ -174,6 +174,7 @@ grb_info grb_spmm(grb_semiring op, grb_matrix A, int tran, const void* d_B, void
   const CsrArrays& M = tran ? A->csc : A->csr;
   SpmvPlan& plan = tran ? A->plan_csc : A->plan_csr;
   if (!M.ptr) return GRB_INVALID_OBJECT;
+  GRB_TRY(matrix_ensure_plan(A, tran != 0));
   GRB_TRY(ctx_init());
   GRB_TRY(dispatch_semiring(op, A->dtype, [&](auto tag, auto t) -> grb_info {
     using T = decltype(t);

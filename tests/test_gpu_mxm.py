@@ -107,3 +107,50 @@ def test_long_pivots_on_rmat_sampled_entries(hb, scale, values):
         T = g.Matrix(n, n, dt)
         info, ntris, _ = g.tc(L, T, hb.descriptor())
         assert info == 0 and ntris == total
+
+
+def test_result_matrix_reused_and_multiplied(hb):
+    """The output matrix of one product is handed to the next (its arrays stay when the shape allows: a second mask with
+    the same row lengths but other columns must still give ITS structure and values), and a product's result is usable in
+    mxv -- its SpMV plan is built when first asked for, not by mxm."""
+    from oracle import ops as oops
+    from oracle.semiring import Semiring
+    g = hb.g
+    dt = np.float32
+    rng = np.random.default_rng(9)
+    n = 700
+    (ap, ai), (bp, bi), (mp, mi) = _rand_csr(rng, n, 15000), _rand_csr(rng, n, 15000), _rand_csr(rng, n, 9000)
+    av = rng.integers(1, 4, ai.size).astype(dt)
+    bv = rng.integers(1, 4, bi.size).astype(dt)
+    # the second mask: every row's columns mirrored (n - 1 - c), re-sorted per row: same pointers, other columns
+    mi2 = np.concatenate([np.sort(n - 1 - mi[mp[r]:mp[r + 1]]) for r in range(n)]).astype(mi.dtype)
+    A, B = g.Matrix(n, n, dt), g.Matrix(n, n, dt)
+    assert A.build_csr(ap, ai, av) == 0 and B.build_csr(bp, bi, bv) == 0
+    Ao, Bo = oops.Matrix(n, n, dt), oops.Matrix(n, n, dt)
+    Ao.build_csr(ap, ai, av); Bo.build_csr(bp, bi, bv)
+    d = hb.descriptor()
+    assert d.toggle(g.GrB_INP1) == 0
+    do = oops.Descriptor(); do.loadArgs(); do.toggle(oops.GrB_INP1)
+    Cm = g.Matrix(n, n, dt)
+    u = rng.integers(0, 5, n).astype(dt)
+    for cols in (mi, mi2, mi):
+        M, Mo = g.Matrix(n, n, dt), oops.Matrix(n, n, dt)
+        ones = np.ones(cols.size, dtype=dt)
+        assert M.build_csr(mp, cols, ones) == 0
+        Mo.build_csr(mp, cols, ones)
+        assert g.mxm(Cm, M, None, "PlusMultiplies", A, B, d) == 0
+        cp, ci, cv = Cm.host_csr()
+        want = oops.mxm_masked(Mo, Semiring("PlusMultiplies", dt), Ao, Bo, do)
+        assert np.array_equal(cp, mp) and np.array_equal(ci, cols) and np.array_equal(cv, want)
+        # w = C u through the generic SpMV (small integers: exact in any order)
+        uv, w = g.Vector(n, dt), g.Vector(n, dt)
+        assert uv.build(u, n) == 0
+        # (pull: the result has no CSC side -- as little as the reference's C->dup has one -- so a pushed product on it
+        # reports GrB_INVALID_OBJECT, and parseArgs' default mxvmode is push)
+        info = g.mxv(w, None, None, "PlusMultiplies", Cm, uv, hb.descriptor(mxvmode=2))
+        assert info == 0, info
+        assert g.mxv(g.Vector(n, dt), None, None, "PlusMultiplies", Cm, uv, hb.descriptor(mxvmode=1)) == 12      # GrB_INVALID_OBJECT
+        dense = np.zeros((n, n), dtype=np.float64)
+        dense[np.repeat(np.arange(n), np.diff(cp)), ci] = cv
+        assert np.array_equal(hb.dense_values(w).astype(np.float64), dense @ u.astype(np.float64))
+
