@@ -502,99 +502,201 @@ static grb_info prepare_cband(const CsrArrays& M, SpmvPlan& plan) {
     fprintf(stderr, "cband prep: %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_prev).count());
     t_prev = now;
   };
-  // ---- host: hubs, bands
-  std::vector<Index> ptr((size_t)n + 1);
-  GRB_HIP_TRY(hipMemcpy(ptr.data(), M.ptr, 4 * ((size_t)n + 1), hipMemcpyDeviceToHost));
-  Index hub_above = 0x7fffffff;                          // rows with more entries than this are hubs
-  if (n > kCbRows) {
-    // the (kCbRows + 1)-th largest degree, from a histogram (one pass over the rows; degrees of 64 Ki and more share
-    // the last bin -- should the answer fall there, the selection is done on those rows alone)
-    constexpr int kDegBins = 65536;
-    std::vector<unsigned int> hist((size_t)kDegBins + 1, 0u);
-    for (Index r = 0; r < n; ++r) {
-      const Index d = ptr[(size_t)r + 1] - ptr[r];
-      ++hist[d < kDegBins ? d : kDegBins];
-    }
-    long long above = hist[kDegBins];
-    if (above > kCbRows) {
-      std::vector<Index> deg;
-      for (Index r = 0; r < n; ++r)
-        if (ptr[(size_t)r + 1] - ptr[r] >= kDegBins) deg.push_back(ptr[(size_t)r + 1] - ptr[r]);
-      std::nth_element(deg.begin(), deg.begin() + kCbRows, deg.end(), [](Index x, Index y) { return x > y; });
-      hub_above = deg[kCbRows];
-    } else {
-      int d = kDegBins - 1;
-      for (; d > 0; --d) {                                 // the largest d with (rows of degree >= d) >= kCbRows + 1
-        above += hist[d];
-        if (above > kCbRows) break;
-      }
-      hub_above = d;
-    }
-    if (hub_above < 64) hub_above = 64;                    // at most kCbRows rows are strictly above the (kCbRows+1)-th largest
-  }
-  mark("row pointers + hub threshold");
-  std::vector<unsigned int> row_band((size_t)n);
-  std::vector<unsigned short> row_loc((size_t)n);
-  std::vector<Index> hub_rows;
-  std::vector<unsigned int> hub_bits(((size_t)n + 31) / 32, 0u);
-  long long hub_entries = 0;
-  for (Index r = 0; r < n; ++r)
-    if (ptr[(size_t)r + 1] - ptr[r] > hub_above) {
-      hub_bits[r >> 5] |= 1u << (r & 31);
-      hub_rows.push_back(r);
-      hub_entries += ptr[(size_t)r + 1] - ptr[r];
-    }
-  const int nhub = (int)hub_rows.size();
+  // ---- hubs, bands, every row's place: on the device (spmv_cband.hpp); GRB_CB_PREP_HOST=1 keeps the host pass of rounds
+  // 3-5 (same tables: the tests run both), which is also where the two cases the device pass does not cover end up
+  static const bool host_pass_wanted = getenv("GRB_CB_PREP_HOST") != nullptr && atoi(getenv("GRB_CB_PREP_HOST")) != 0;
+  static const int light_weight = getenv("GRB_CB_LIGHT_WEIGHT") ? atoi(getenv("GRB_CB_LIGHT_WEIGHT")) : 14;   // hub = 10
   std::vector<CbBand> bands;
   std::vector<long long> band_start;                     // sorted position of every band's first entry
-  if (nhub > 0) {
-    bands.push_back(CbBand{0, nhub, 1});
-    band_start.push_back(0);
-  }
+  int nhub = 0;
+  unsigned int* d_row_band = nullptr;
+  unsigned short* d_row_loc = nullptr;
+  Index* d_hub_rows = nullptr;
+  unsigned int* d_hub_bits = nullptr;
   // Light bands are sized so that a whole number of them is one workgroup's share: the hub band gets the
   // workgroups its cost asks for (a light entry costs more than a hub entry, see the dealing below), the light
   // rows' entries are split evenly over the rest, and a share that does not fit kCbRows rows is cut into k equal
   // bands -- then the equal-cost cuts of the dealing fall on band boundaries and few bands need partial slices.
-  static const int light_weight = getenv("GRB_CB_LIGHT_WEIGHT") ? atoi(getenv("GRB_CB_LIGHT_WEIGHT")) : 14;   // hub = 10
-  long long band_entries_max = (long long)kCbLightGroups * kWave;
-  {
+  auto light_band_limit = [&](long long hub_entries, int nh) -> long long {
+    long long band_entries_max = (long long)kCbLightGroups * kWave;
     const long long light_entries = nnz - hub_entries;
     const double hub_cost = 10.0 * (double)hub_entries, light_cost = (double)light_weight * (double)light_entries;
-    int wg_hub = nhub > 0 ? (int)(G * hub_cost / (hub_cost + light_cost) + 0.5) : 0;
-    if (nhub > 0 && wg_hub < 1) wg_hub = 1;
+    int wg_hub = nh > 0 ? (int)(G * hub_cost / (hub_cost + light_cost) + 0.5) : 0;
+    if (nh > 0 && wg_hub < 1) wg_hub = 1;
     if (wg_hub > G - 1) wg_hub = G - 1;
     const long long share = light_entries / (G - wg_hub) + 1;                 // entries per light workgroup
-    const double rows_per_share = (double)share * (double)(n - nhub) / (double)(light_entries > 0 ? light_entries : 1);
+    const double rows_per_share = (double)share * (double)(n - nh) / (double)(light_entries > 0 ? light_entries : 1);
     const int k = (int)(rows_per_share / (0.97 * kCbRows)) + 1;
     if (share / k + 1 < band_entries_max) band_entries_max = share / k + 1;
     if (band_entries_max < 64 * kWave) band_entries_max = 64 * kWave;
-  }
-  {
-    // one pass over the rows: the light bands are cut, and every row learns its band and its place in it
-    long long at = hub_entries, in_band = 0;
-    Index r0 = 0;
-    int hub_i = 0;
-    unsigned int cur_band = (unsigned int)bands.size();   // the band being filled
-    for (Index r = 0; r < n; ++r) {
-      const bool hub = (hub_bits[r >> 5] >> (r & 31)) & 1u;
-      const Index d = hub ? 0 : ptr[(size_t)r + 1] - ptr[r];
-      if (r > r0 && (r - r0 == kCbRows || in_band + d > band_entries_max)) {
-        bands.push_back(CbBand{r0, r - r0, 0});
-        band_start.push_back(at);
-        at += in_band;
-        in_band = 0;
-        r0 = r;
-        ++cur_band;
+    return band_entries_max;
+  };
+  bool host_pass = host_pass_wanted;
+  if (!host_pass) {
+    constexpr int kBandCap = 1 << 20;
+    unsigned int* d_hist = (unsigned int*)dalloc(4 * ((size_t)kCbDegBins + 1), false);
+    unsigned int* d_light = (unsigned int*)dalloc(4 * ((size_t)n + 1), false);
+    unsigned int* d_flag = (unsigned int*)dalloc(4 * ((size_t)n + 1), false);
+    Index* d_next = (Index*)dalloc(4 * (size_t)n, false);
+    Index* d_starts = (Index*)dalloc(4 * ((size_t)kBandCap + 1), false);
+    int* d_count = (int*)dalloc(16, false);
+    d_row_band = (unsigned int*)dalloc(4 * (size_t)n, false);
+    d_row_loc = (unsigned short*)dalloc(2 * (size_t)n, false);
+    d_hub_bits = (unsigned int*)dalloc(4 * (((size_t)n + 31) / 32), true);
+    if (oom) return GRB_OUT_OF_MEMORY;
+    Index hub_above = 0x7fffffff;                          // rows with more entries than this are hubs
+    if (n > kCbRows) {
+      GRB_HIP_TRY(hipMemsetAsync(d_hist, 0, 4 * ((size_t)kCbDegBins + 1), st));
+      hipLaunchKernelGGL(cband_degree_hist_kernel, dim3(G), dim3(1024), 0, st, M.ptr, n, d_hist);
+      GRB_HIP_TRY(hipGetLastError());
+      std::vector<unsigned int> hist((size_t)kCbDegBins + 1);
+      GRB_HIP_TRY(hipMemcpyAsync(hist.data(), d_hist, 4 * hist.size(), hipMemcpyDeviceToHost, st));
+      GRB_HIP_TRY(hipStreamSynchronize(st));
+      long long above = hist[kCbDegBins];
+      if (above > kCbRows) {
+        host_pass = true;                                  // the threshold lies among rows of >= 65 536 entries: selected on the host
+      } else {
+        int d = kCbDegBins - 1;
+        for (; d > 0; --d) {                               // the largest d with (rows of degree >= d) >= kCbRows + 1
+          above += hist[d];
+          if (above > kCbRows) break;
+        }
+        hub_above = d;
+        if (hub_above < 64) hub_above = 64;                // at most kCbRows rows are strictly above the (kCbRows+1)-th largest
       }
-      in_band += d;
-      row_band[r] = hub ? 0u : cur_band;
-      row_loc[r] = (unsigned short)(hub ? hub_i++ : r - r0);
     }
-    bands.push_back(CbBand{r0, n - r0, 0});
-    band_start.push_back(at);
-    at += in_band;
-    band_start.push_back(at);
-    if (at != nnz) return GRB_PANIC;
+    mark("degree histogram + hub threshold");
+    if (!host_pass) {
+      hipLaunchKernelGGL(cband_light_kernel, dim3(stream_grid((long long)n + kWave, kBlock)), dim3(kBlock), 0, st, M.ptr, n, hub_above,
+                         d_light, d_flag, d_hub_bits);
+      GRB_HIP_TRY(hipGetLastError());
+      GRB_TRY(device_exclusive_scan_u32(d_light, (long long)n + 1));
+      GRB_TRY(device_exclusive_scan_u32(d_flag, (long long)n + 1));
+      unsigned int tot[2] = {0u, 0u};                      // light entries, hubs
+      GRB_HIP_TRY(hipMemcpyAsync(&tot[0], d_light + n, 4, hipMemcpyDeviceToHost, st));
+      GRB_HIP_TRY(hipMemcpyAsync(&tot[1], d_flag + n, 4, hipMemcpyDeviceToHost, st));
+      GRB_HIP_TRY(hipStreamSynchronize(st));
+      nhub = (int)tot[1];
+      const long long hub_entries = nnz - (long long)tot[0];
+      const long long band_entries_max = light_band_limit(hub_entries, nhub);
+      hipLaunchKernelGGL(cband_next_kernel, dim3(stream_grid(n, kBlock)), dim3(kBlock), 0, st, (const unsigned int*)d_light, n,
+                         (unsigned int)band_entries_max, kCbRows, d_next);
+      hipLaunchKernelGGL(cband_chase_kernel, dim3(1), dim3(64), 0, st, (const Index*)d_next, n, d_starts, kBandCap, d_count);
+      GRB_HIP_TRY(hipGetLastError());
+      int nlight = 0;
+      GRB_HIP_TRY(hipMemcpyAsync(&nlight, d_count, 4, hipMemcpyDeviceToHost, st));
+      GRB_HIP_TRY(hipStreamSynchronize(st));
+      if (nlight > kBandCap) return GRB_SUCCESS;           // a million bands: not a matrix for this format
+      d_hub_rows = (Index*)dalloc(4 * (size_t)(nhub > 0 ? nhub : 1), true);
+      long long* d_first = (long long*)dalloc(8 * ((size_t)nlight + 1), false);
+      if (oom) return GRB_OUT_OF_MEMORY;
+      const unsigned int band0 = nhub > 0 ? 1u : 0u;
+      hipLaunchKernelGGL(cband_place_kernel, dim3(stream_grid(n, kBlock)), dim3(kBlock), 0, st, (const Index*)d_starts, nlight, band0,
+                         (const unsigned int*)d_light, (const unsigned int*)d_flag, (const unsigned int*)d_hub_bits, n,
+                         (unsigned long long)hub_entries, d_row_band, d_row_loc, d_hub_rows, d_first);
+      GRB_HIP_TRY(hipGetLastError());
+      std::vector<Index> starts((size_t)nlight + 1);
+      std::vector<long long> first((size_t)nlight);
+      GRB_HIP_TRY(hipMemcpyAsync(starts.data(), d_starts, 4 * starts.size(), hipMemcpyDeviceToHost, st));
+      if (nlight > 0) GRB_HIP_TRY(hipMemcpyAsync(first.data(), d_first, 8 * first.size(), hipMemcpyDeviceToHost, st));
+      GRB_HIP_TRY(hipStreamSynchronize(st));
+      if (nhub > 0) {
+        bands.push_back(CbBand{0, nhub, 1});
+        band_start.push_back(0);
+      }
+      for (int b = 0; b < nlight; ++b) {
+        bands.push_back(CbBand{starts[b], starts[(size_t)b + 1] - starts[b], 0});
+        band_start.push_back(first[b]);
+      }
+      band_start.push_back(nnz);
+    }
+  }
+  if (host_pass) {
+    // ---- host: hubs, bands
+    std::vector<Index> ptr((size_t)n + 1);
+    GRB_HIP_TRY(hipMemcpy(ptr.data(), M.ptr, 4 * ((size_t)n + 1), hipMemcpyDeviceToHost));
+    Index hub_above = 0x7fffffff;                          // rows with more entries than this are hubs
+    if (n > kCbRows) {
+      // the (kCbRows + 1)-th largest degree, from a histogram (one pass over the rows; degrees of 64 Ki and more share
+      // the last bin -- should the answer fall there, the selection is done on those rows alone)
+      constexpr int kDegBins = 65536;
+      std::vector<unsigned int> hist((size_t)kDegBins + 1, 0u);
+      for (Index r = 0; r < n; ++r) {
+        const Index d = ptr[(size_t)r + 1] - ptr[r];
+        ++hist[d < kDegBins ? d : kDegBins];
+      }
+      long long above = hist[kDegBins];
+      if (above > kCbRows) {
+        std::vector<Index> deg;
+        for (Index r = 0; r < n; ++r)
+          if (ptr[(size_t)r + 1] - ptr[r] >= kDegBins) deg.push_back(ptr[(size_t)r + 1] - ptr[r]);
+        std::nth_element(deg.begin(), deg.begin() + kCbRows, deg.end(), [](Index x, Index y) { return x > y; });
+        hub_above = deg[kCbRows];
+      } else {
+        int d = kDegBins - 1;
+        for (; d > 0; --d) {                                 // the largest d with (rows of degree >= d) >= kCbRows + 1
+          above += hist[d];
+          if (above > kCbRows) break;
+        }
+        hub_above = d;
+      }
+      if (hub_above < 64) hub_above = 64;                    // at most kCbRows rows are strictly above the (kCbRows+1)-th largest
+    }
+    mark("row pointers + hub threshold");
+    std::vector<unsigned int> row_band((size_t)n);
+    std::vector<unsigned short> row_loc((size_t)n);
+    std::vector<Index> hub_rows;
+    std::vector<unsigned int> hub_bits(((size_t)n + 31) / 32, 0u);
+    long long hub_entries = 0;
+    for (Index r = 0; r < n; ++r)
+      if (ptr[(size_t)r + 1] - ptr[r] > hub_above) {
+        hub_bits[r >> 5] |= 1u << (r & 31);
+        hub_rows.push_back(r);
+        hub_entries += ptr[(size_t)r + 1] - ptr[r];
+      }
+    const int nhub_h = (int)hub_rows.size();
+    bands.clear();
+    band_start.clear();
+    if (nhub_h > 0) {
+      bands.push_back(CbBand{0, nhub_h, 1});
+      band_start.push_back(0);
+    }
+    const long long band_entries_max = light_band_limit(hub_entries, nhub_h);
+    {
+      // one pass over the rows: the light bands are cut, and every row learns its band and its place in it
+      long long at = hub_entries, in_band = 0;
+      Index r0 = 0;
+      int hub_i = 0;
+      unsigned int cur_band = (unsigned int)bands.size();   // the band being filled
+      for (Index r = 0; r < n; ++r) {
+        const bool hub = (hub_bits[r >> 5] >> (r & 31)) & 1u;
+        const Index d = hub ? 0 : ptr[(size_t)r + 1] - ptr[r];
+        if (r > r0 && (r - r0 == kCbRows || in_band + d > band_entries_max)) {
+          bands.push_back(CbBand{r0, r - r0, 0});
+          band_start.push_back(at);
+          at += in_band;
+          in_band = 0;
+          r0 = r;
+          ++cur_band;
+        }
+        in_band += d;
+        row_band[r] = hub ? 0u : cur_band;
+        row_loc[r] = (unsigned short)(hub ? hub_i++ : r - r0);
+      }
+      bands.push_back(CbBand{r0, n - r0, 0});
+      band_start.push_back(at);
+      at += in_band;
+      band_start.push_back(at);
+      if (at != nnz) return GRB_PANIC;
+    }
+
+    nhub = nhub_h;
+    d_row_band = (unsigned int*)upload(row_band.data(), 4 * (size_t)n, false);
+    d_row_loc = (unsigned short*)upload(row_loc.data(), 2 * (size_t)n, false);
+    d_hub_rows = (Index*)upload(hub_rows.data(), 4 * hub_rows.size(), true);
+    if (d_hub_bits) GRB_HIP_TRY(hipMemcpy(d_hub_bits, hub_bits.data(), 4 * hub_bits.size(), hipMemcpyHostToDevice));
+    else d_hub_bits = (unsigned int*)upload(hub_bits.data(), 4 * hub_bits.size(), true);
+    if (oom) return GRB_OUT_OF_MEMORY;
   }
   const int nbands = (int)bands.size();
   mark("bands (host pass)");
@@ -614,8 +716,6 @@ static grb_info prepare_cband(const CsrArrays& M, SpmvPlan& plan) {
     GRB_HIP_TRY(hipGetLastError());
   }
   const long long ncols = (long long)nhot + (long long)plan.nminor;
-  unsigned int* d_row_band = (unsigned int*)upload(row_band.data(), 4 * (size_t)n, false);
-  unsigned short* d_row_loc = (unsigned short*)upload(row_loc.data(), 2 * (size_t)n, false);
   unsigned long long* d_keys = (unsigned long long*)dalloc(8 * (size_t)nnz, false);
   unsigned int* d_pay = (unsigned int*)dalloc(4 * (size_t)nnz, false);
   if (oom) return GRB_OUT_OF_MEMORY;
@@ -818,8 +918,8 @@ static grb_info prepare_cband(const CsrArrays& M, SpmvPlan& plan) {
   A.pack = d_pack;
   A.val = d_val2;
   A.gbase = d_gbase;
-  A.hub_rows = (const Index*)upload(hub_rows.data(), 4 * hub_rows.size(), true);
-  A.hub_bits = (const unsigned int*)upload(hub_bits.data(), 4 * hub_bits.size(), true);
+  A.hub_rows = d_hub_rows;
+  A.hub_bits = d_hub_bits;
   A.iso_bits = iso_out[0];
   A.nhub = nhub;
   if (partial_elems > 0) C->d_partials = dalloc(8 * (size_t)partial_elems, true);   // accumulators of <= 8 bytes

@@ -97,6 +97,111 @@ inline void free_spmv_cband(SpmvCBand* b) {
 }
 
 // ---- preparation kernels ---------------------------------------------------------------------------------------
+// Rows -> hubs, bands, a place for every row: on the device (round 5; the host did this over a 17 MB copy of the row
+// pointers -- 10 of the preparation's 25 ms on a good day, 100 on a box whose host cores were busy).
+//   cband_degree_hist_kernel   degrees counted in 65 537 bins (>= 65 536 share the last): the hub threshold is the
+//                              (kCbRows + 1)-th largest degree, read off the histogram by the host (256 KB)
+//   cband_light_kernel         light[r] = the row's entries if it is no hub (else 0), flag[r] = hub; hub bitmap.
+//                              Exclusive scans of both (build.hip) give every row the light entries in front of it and
+//                              every hub its number
+//   cband_next_kernel          next[r] = where the band that starts at row r ends: kCbRows rows on, or in front of the first
+//                              row that takes the band's light entries past the limit (a search in the prefix sums)
+//   cband_chase_kernel         one thread follows next[] from row 0: the bands' first rows (a few hundred dependent loads)
+//   cband_place_kernel         band and place of every row; the hub list; the bands' first sorted positions
+constexpr int kCbDegBins = 65536;
+constexpr int kCbDegLds = 16384;          // bins counted in LDS (64 KiB); longer rows go to memory one atomic each
+__global__ __launch_bounds__(1024) void cband_degree_hist_kernel(const Index* __restrict__ ptr, Index n,
+                                                                 unsigned int* __restrict__ hist /* [kCbDegBins + 1], zeroed */) {
+  __shared__ unsigned int h[kCbDegLds];
+  for (int i = threadIdx.x; i < kCbDegLds; i += blockDim.x) h[i] = 0u;
+  __syncthreads();
+  const Index stride = (Index)gridDim.x * blockDim.x;
+  for (Index r = (Index)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += stride) {
+    const Index d = ptr[r + 1] - ptr[r];
+    if (d < kCbDegLds) atomicAdd(&h[d], 1u);
+    else atomicAdd(&hist[d < kCbDegBins ? d : kCbDegBins], 1u);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < kCbDegLds; i += blockDim.x)
+    if (h[i]) atomicAdd(&hist[i], h[i]);
+}
+
+__global__ __launch_bounds__(kBlock) void cband_light_kernel(const Index* __restrict__ ptr, Index n, Index hub_above,
+                                                             unsigned int* __restrict__ light /* [n + 1] */,
+                                                             unsigned int* __restrict__ flag /* [n + 1] */,
+                                                             unsigned int* __restrict__ hub_bits /* [(n + 31) / 32] */) {
+  // a wave takes 64 consecutive rows (two words of the bitmap); rows past n are no hubs
+  const Index nchunks = (n + kWave) / kWave;              // covers index n too (the scans' closing zero)
+  const Index nwaves = (Index)gridDim.x * kWavesPerBlock;
+  const int lane = lane_id();
+  for (Index c = (Index)blockIdx.x * kWavesPerBlock + wave_id(); c < nchunks; c += nwaves) {
+    const Index r = c * kWave + lane;
+    Index d = 0;
+    if (r < n) d = ptr[r + 1] - ptr[r];
+    const bool hub = r < n && d > hub_above;
+    if (r <= n) { light[r] = hub ? 0u : (unsigned int)d; flag[r] = hub ? 1u : 0u; }
+    const unsigned long long m = __ballot(hub);
+    const Index w = 2 * c + (lane == 32 ? 1 : 0);
+    if ((lane == 0 || lane == 32) && (long long)w * 32 < (long long)n)
+      hub_bits[w] = lane == 0 ? (unsigned int)(m & 0xffffffffull) : (unsigned int)(m >> 32);
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void cband_next_kernel(const unsigned int* __restrict__ P /* [n + 1] light entries in front */,
+                                                            Index n, unsigned int max_entries, int max_rows,
+                                                            Index* __restrict__ next) {
+  const Index stride = (Index)gridDim.x * blockDim.x;
+  for (Index r = (Index)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += stride) {
+    // the host's rule, row by row: a band that began at r is cut in front of row q > r when it holds max_rows rows or
+    // when row q's entries would take it past max_entries, i.e. P[q + 1] - P[r] > max_entries
+    const unsigned long long lim = (unsigned long long)P[r] + max_entries;
+    Index lo = r + 1, hi = r + max_rows < n ? r + max_rows : n;     // the answer lies in [lo, hi]
+    while (lo < hi) {
+      const Index mid = lo + ((hi - lo) >> 1);
+      if ((unsigned long long)P[mid + 1] > lim) hi = mid; else lo = mid + 1;
+    }
+    next[r] = lo;
+  }
+}
+
+__global__ void cband_chase_kernel(const Index* __restrict__ next, Index n, Index* __restrict__ starts, int cap,
+                                   int* __restrict__ count) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  int k = 0;
+  for (Index r = 0; r < n; r = next[r]) {
+    if (k < cap) starts[k] = r;
+    ++k;
+  }
+  if (k < cap) starts[k] = n;
+  *count = k;
+}
+
+__global__ __launch_bounds__(kBlock) void cband_place_kernel(const Index* __restrict__ starts, int nlight, unsigned int band0,
+                                                             const unsigned int* __restrict__ P, const unsigned int* __restrict__ H,
+                                                             const unsigned int* __restrict__ hub_bits, Index n,
+                                                             unsigned long long hub_entries,
+                                                             unsigned int* __restrict__ row_band, unsigned short* __restrict__ row_loc,
+                                                             Index* __restrict__ hub_rows, long long* __restrict__ band_first) {
+  const Index stride = (Index)gridDim.x * blockDim.x;
+  for (Index r = (Index)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += stride) {
+    if ((hub_bits[r >> 5] >> (r & 31)) & 1u) {
+      const unsigned int i = H[r];
+      row_band[r] = 0u;
+      row_loc[r] = (unsigned short)i;
+      hub_rows[i] = r;
+    } else {
+      int lo = 0, hi = nlight - 1;                         // the last band that starts at or in front of r
+      while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (starts[mid] <= r) lo = mid; else hi = mid - 1;
+      }
+      row_band[r] = band0 + (unsigned int)lo;
+      row_loc[r] = (unsigned short)(r - starts[lo]);
+    }
+    if (r < (Index)nlight) band_first[r] = (long long)hub_entries + (long long)P[starts[r]];
+  }
+}
+
 // The sort key of entry p:  ((band of its row) << colbits | code of its column) << 16 | the row's position inside its band.
 // Only the bits above the low 16 are sorted on; the position rides along, and the payload is the entry's VALUE -- what
 // the emit pass needs is then in the sorted arrays themselves, read front to back (the first version sorted entry

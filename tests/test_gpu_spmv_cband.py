@@ -313,3 +313,53 @@ def test_auto_waits_for_reuse_before_it_prepares_the_format(powerlaw):
     finally:
         g.spmv_set_reuse_threshold(before)
         g.spmv_set_format(fmt_before)
+
+
+_PREP_SCRIPT = r'''
+import json, sys, os
+import numpy as np, torch
+import graphblast_amd as g
+from graphblast_amd.graphgen import rmat_edges, finalize_edges
+dev = torch.device("cuda", 0)
+g.spmv_set_reuse_threshold(0)
+out = []
+for scale, ef, sym, forced in ((16, 16, True, False), (14, 8, False, True), (17, 4, True, True)):
+    g.spmv_set_format(2 if forced else 1)
+    s, d, n = rmat_edges(scale, ef, seed=3, device=dev)
+    gr = finalize_edges(s, d, n, symmetrize=sym)
+    tp, ti = gr["csr"]
+    rng = np.random.default_rng(scale)
+    vals = torch.from_numpy(rng.integers(1, 6, gr["nnz"]).astype(np.float32)).to(dev)
+    A = g.Matrix(n, n)
+    assert A.build_device_csr(tp.data_ptr(), ti.data_ptr(), vals.data_ptr(), gr["nnz"], keep=(tp, ti, vals)) == 0
+    u = torch.from_numpy(rng.integers(0, 4, n).astype(np.float32)).to(dev)
+    w = torch.zeros(n, dtype=torch.float32, device=dev)
+    assert g.k_spmv(A, 0, "PlusMultiplies", u.data_ptr(), None, 0, 0, w.data_ptr()) == 0
+    torch.cuda.synchronize()
+    info = g.spmv_format_info(A, 0)
+    out.append({"info": info, "sum": float(w.double().sum().item()), "w": w.cpu().numpy().astype(np.float64).tolist()[:2000]})
+print("RESULT" + json.dumps(out))
+'''
+
+
+def test_preparation_on_the_device_equals_the_host_pass():
+    """Hubs, bands and every row's place come from device kernels (degree histogram, scans, the band chase); the host
+    pass of the earlier rounds stays behind GRB_CB_PREP_HOST=1.  Both must cut the same bands, deal the same items and
+    give the same products (integer-valued data: exact) -- run in two fresh processes, the switch is read once."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for host in ("0", "1"):
+        env = dict(os.environ, GRB_CB_PREP_HOST=host, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+        p = subprocess.run([sys.executable, "-c", _PREP_SCRIPT], env=env, cwd=root, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        line = [l for l in p.stdout.splitlines() if l.startswith("RESULT")][-1]
+        res[host] = json.loads(line[len("RESULT"):])
+    assert len(res["0"]) == len(res["1"]) == 3
+    for a, b in zip(res["0"], res["1"]):
+        assert a["info"]["in_use"] == 1 and b["info"]["in_use"] == 1
+        assert a["info"] == b["info"], (a["info"], b["info"])
+        assert a["sum"] == b["sum"] and a["w"] == b["w"]
