@@ -707,13 +707,18 @@ static grb_info prepare_cband(const CsrArrays& M, SpmvPlan& plan) {
   // as in natural order, so packing the tail buys no locality
   unsigned int nhot = 0;
   Index* d_rank = nullptr;
+  const Index* d_ind2 = nullptr;                           // the CSR kernel's renamed column ids, when it has run already
   if (plan.d_order) {
-    GRB_TRY(column_ranks(plan, &d_rank));
-    temp.push_back(d_rank);
     const unsigned int want = ((unsigned int)plan.npacked + 65535u) & ~65535u;
     nhot = want < 8u * 65536u ? want : 8u * 65536u;
-    hipLaunchKernelGGL(cband_codes_kernel, dim3(ceil_div(plan.nminor, kBlock)), dim3(kBlock), 0, st, d_rank, plan.nminor, nhot);
-    GRB_HIP_TRY(hipGetLastError());
+    if (plan.d_ind2) {
+      d_ind2 = plan.d_ind2;                                // rank < nhot ? rank : nhot + column, formed per entry: no gather
+    } else {
+      GRB_TRY(column_ranks(plan, &d_rank));
+      temp.push_back(d_rank);
+      hipLaunchKernelGGL(cband_codes_kernel, dim3(ceil_div(plan.nminor, kBlock)), dim3(kBlock), 0, st, d_rank, plan.nminor, nhot);
+      GRB_HIP_TRY(hipGetLastError());
+    }
   }
   const long long ncols = (long long)nhot + (long long)plan.nminor;
   unsigned long long* d_keys = (unsigned long long*)dalloc(8 * (size_t)nnz, false);
@@ -725,9 +730,13 @@ static grb_info prepare_cband(const CsrArrays& M, SpmvPlan& plan) {
   const int colbits = cband_bits_for(col_span > ncols ? col_span : ncols), bandbits = cband_bits_for(nbands);
   if (colbits + bandbits + kCbKeyLow > 64) return GRB_SUCCESS;
   mark("ranks, uploads, allocations");
-  hipLaunchKernelGGL(cband_keys_kernel, dim3(stream_grid((long long)n * kWave, kBlock)), dim3(kBlock), 0, st, M.ptr, M.ind,
+  hipLaunchKernelGGL(cband_keys_kernel, dim3(stream_grid((long long)n, kBlock)), dim3(kBlock), 0, st, M.ptr, M.ind,
                      (const unsigned int*)M.val, n, (const unsigned int*)d_row_band, (const unsigned short*)d_row_loc,
-                     (const Index*)d_rank, colbits, d_keys, d_pay);
+                     (const unsigned int*)d_hub_bits, (const Index*)d_rank, d_ind2, nhot, colbits, d_keys, d_pay);
+  if (nhub > 0)
+    hipLaunchKernelGGL(cband_keys_hub_kernel, dim3(nhub < 4096 ? nhub : 4096), dim3(1024), 0, st, M.ptr, M.ind,
+                       (const unsigned int*)M.val, (const Index*)d_hub_rows, nhub, (const Index*)d_rank, d_ind2, nhot, colbits,
+                       d_keys, d_pay);
   GRB_HIP_TRY(hipGetLastError());
   {
     const grb_info si = device_sort_pairs_range(d_keys, d_pay, nnz, kCbKeyLow, colbits + bandbits);

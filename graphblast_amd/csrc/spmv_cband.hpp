@@ -207,24 +207,84 @@ __global__ __launch_bounds__(kBlock) void cband_place_kernel(const Index* __rest
 // the emit pass needs is then in the sorted arrays themselves, read front to back (the first version sorted entry
 // indices and gathered position and value through them afterwards: 16 GB of line fetches for RMAT-22).
 constexpr int kCbKeyLow = 16;
+// A wave takes 64 consecutive rows: their entries are one contiguous piece of the CSR arrays, walked 64 at a time
+// (coalesced, every lane busy; a wave per ROW -- the first version -- left most lanes idle on the short rows that make up
+// a power-law matrix).  A lane finds its entry's row among the wave's 65 row pointers (LDS).  Hub rows are stepped over
+// here and taken by cband_keys_hub_kernel, a 1024-thread workgroup per hub row: one wave walking a row of 300 000
+// entries was the whole kernel's time (3.5 of 4.4 ms on RMAT-22).
+// The column's code is its rank when that is below nhot, else nhot + the column: from the CSR kernel's renamed column
+// ids when they exist (ind2: no gather at all), else through the rank array (codes: one 4-byte gather per entry).
+__device__ inline void cband_key_store(Index p, const Index* __restrict__ ind, const unsigned int* __restrict__ val,
+                                       const Index* __restrict__ codes, const Index* __restrict__ ind2, unsigned int nhot,
+                                       int colbits, unsigned int band, unsigned int loc, unsigned long long* __restrict__ keys,
+                                       unsigned int* __restrict__ pay) {
+  const unsigned int col = (unsigned int)ind[p];
+  unsigned int code = col;
+  if (ind2) {
+    const unsigned int rk = (unsigned int)ind2[p];
+    code = rk < nhot ? rk : nhot + col;
+  } else if (codes) {
+    code = (unsigned int)codes[col];
+  }
+  keys[p] = ((((unsigned long long)band << colbits) | (unsigned long long)code) << kCbKeyLow) | (unsigned long long)loc;
+  pay[p] = val ? val[p] : 0u;
+}
+
 __global__ __launch_bounds__(kBlock) void cband_keys_kernel(const Index* __restrict__ ptr, const Index* __restrict__ ind,
                                                             const unsigned int* __restrict__ val /* nullable */,
                                                             Index n, const unsigned int* __restrict__ row_band,
                                                             const unsigned short* __restrict__ row_loc,
-                                                            const Index* __restrict__ rank /* nullable: natural order */,
+                                                            const unsigned int* __restrict__ hub_bits,
+                                                            const Index* __restrict__ codes /* nullable: natural order, or ind2 */,
+                                                            const Index* __restrict__ ind2 /* nullable */, unsigned int nhot,
                                                             int colbits, unsigned long long* __restrict__ keys,
                                                             unsigned int* __restrict__ pay) {
-  const int lane = lane_id();
+  __shared__ Index s_ptr[kWavesPerBlock][kWave + 1];
+  __shared__ unsigned int s_band[kWavesPerBlock][kWave];
+  __shared__ unsigned int s_loc[kWavesPerBlock][kWave];
+  const int lane = lane_id(), wv = wave_id();
+  const Index nchunks = (n + kWave - 1) / kWave;
   const Index nwaves = (Index)gridDim.x * kWavesPerBlock;
-  for (Index r = (Index)blockIdx.x * kWavesPerBlock + wave_id(); r < n; r += nwaves) {
-    const unsigned long long hi = (unsigned long long)row_band[r] << colbits;
-    const unsigned long long loc = (unsigned long long)row_loc[r];
-    const Index e = ptr[r + 1];
-    for (Index p = ptr[r] + lane; p < e; p += kWave) {
-      const Index c = ind[p];
-      keys[p] = ((hi | (unsigned long long)(unsigned int)(rank ? rank[c] : c)) << kCbKeyLow) | loc;
-      pay[p] = val ? val[p] : 0u;
+  for (Index c = (Index)blockIdx.x * kWavesPerBlock + wv; c < nchunks; c += nwaves) {
+    const Index r0 = c * kWave;
+    const bool have = r0 + lane < n;
+    const Index r = have ? r0 + lane : n;
+    __builtin_amdgcn_wave_barrier();
+    s_ptr[wv][lane] = ptr[r];                              // rows past n start where the matrix ends: never chosen
+    if (lane == 0) s_ptr[wv][kWave] = ptr[r0 + kWave < n ? r0 + kWave : n];
+    s_band[wv][lane] = have ? row_band[r] : 0u;
+    s_loc[wv][lane] = have ? (unsigned int)row_loc[r] : 0u;
+    const unsigned long long hubs = __ballot(have && ((hub_bits[r >> 5] >> (r & 31)) & 1u));
+    __builtin_amdgcn_wave_barrier();
+    const Index p1 = s_ptr[wv][kWave];
+    Index base = s_ptr[wv][0];
+    while (base < p1) {
+      const Index p = base + lane < p1 ? base + lane : p1 - 1;
+      int j = 0;                                           // the last row of the chunk that starts at or in front of p
+#pragma unroll
+      for (int step = kWave / 2; step > 0; step >>= 1)
+        if (s_ptr[wv][j + step] <= p) j += step;
+      const int j0 = __builtin_amdgcn_readfirstlane(j);    // the row this step begins in
+      if ((hubs >> j0) & 1ull) { base = s_ptr[wv][j0 + 1]; continue; }
+      if (base + lane < p1 && !((hubs >> j) & 1ull))
+        cband_key_store(p, ind, val, codes, ind2, nhot, colbits, s_band[wv][j], s_loc[wv][j], keys, pay);
+      base += kWave;
     }
+  }
+}
+
+// the hub rows' entries: hub i (row hub_rows[i]) is band 0, place i; a workgroup per hub, 1024 entries a step
+__global__ __launch_bounds__(1024) void cband_keys_hub_kernel(const Index* __restrict__ ptr, const Index* __restrict__ ind,
+                                                              const unsigned int* __restrict__ val /* nullable */,
+                                                              const Index* __restrict__ hub_rows, int nhub,
+                                                              const Index* __restrict__ codes, const Index* __restrict__ ind2,
+                                                              unsigned int nhot, int colbits, unsigned long long* __restrict__ keys,
+                                                              unsigned int* __restrict__ pay) {
+  for (int i = blockIdx.x; i < nhub; i += gridDim.x) {
+    const Index r = hub_rows[i];
+    const Index e = ptr[r + 1];
+    for (Index p = ptr[r] + (Index)threadIdx.x; p < e; p += (Index)blockDim.x)
+      cband_key_store(p, ind, val, codes, ind2, nhot, colbits, 0u, (unsigned int)i, keys, pay);
   }
 }
 
