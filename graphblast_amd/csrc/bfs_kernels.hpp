@@ -216,6 +216,14 @@ static __global__ __launch_bounds__(kBlock) void bfs_level_tail_kernel(
 // row.  A wave takes 64 consecutive rows: their entries are ONE contiguous piece of `ind`, streamed 64 at a time
 // (coalesced; the first version walked a row per lane, every load 64 lines); an entry's row is found by a 6-step search
 // of the 65 row starts in LDS and its (degree, entry) key folded into the row's slot with an LDS 64-bit max.
+// Rows of kHintLong entries and more are stepped over here and taken by bfs_hint_long_kernel, a whole workgroup each:
+// one wave walking the longest row of RMAT-22 alone (300 000 entries) was this kernel's whole time, 2.7 ms.
+constexpr Index kHintLong = 1024;
+__device__ inline unsigned long long hint_key(Index u, const Index* __restrict__ deg_ptr) {
+  // (degree + 1: an entry of degree 0 still beats "no entry"; ties go to the smaller entry)
+  const unsigned int d = (unsigned int)(deg_ptr[u + 1] - deg_ptr[u]);
+  return ((unsigned long long)(d + 1u) << 32) | (unsigned long long)(0xffffffffu - (unsigned int)u);
+}
 static __global__ __launch_bounds__(kBlock) void bfs_hint_kernel(
     const Index* __restrict__ ptr, const Index* __restrict__ ind, Index n, const Index* __restrict__ deg_ptr,
     Index* __restrict__ hint) {
@@ -227,31 +235,73 @@ static __global__ __launch_bounds__(kBlock) void bfs_hint_kernel(
   for (Index chunk = (Index)blockIdx.x * kWavesPerBlock + wave; chunk < nchunks; chunk += nwaves) {
     const Index v = chunk * kWave + lane;
     const Index vc = v < n ? v : n;                              // rows past the end: empty
-    s_start[wave][lane] = ptr[vc];
-    if (lane == kWave - 1) s_start[wave][kWave] = ptr[vc < n ? vc + 1 : n];
+    const Index my_start = ptr[vc], my_end = ptr[vc < n ? vc + 1 : n];
+    s_start[wave][lane] = my_start;
+    if (lane == kWave - 1) s_start[wave][kWave] = my_end;
     s_best[wave][lane] = 0ull;
+    const unsigned long long longs = __ballot(my_end - my_start >= kHintLong);
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    const Index q0 = s_start[wave][0], q1 = s_start[wave][kWave];
-    for (Index q = q0 + lane; q - lane < q1; q += kWave) {
-      if (q < q1) {
-        const Index u = ind[q];
-        const unsigned int d = (unsigned int)(deg_ptr[u + 1] - deg_ptr[u]);
-        int r = 0;                                               // the last row whose start is <= q
+    const Index q1 = s_start[wave][kWave];
+    Index base = s_start[wave][0];
+    while (base < q1) {
+      const Index q = base + lane < q1 ? base + lane : q1 - 1;
+      int r = 0;                                                 // the last row whose start is <= q
 #pragma unroll
-        for (int step = kWave / 2; step > 0; step >>= 1)
-          if (s_start[wave][r + step] <= q) r += step;
-        // (degree + 1: an entry of degree 0 still beats "no entry"; ties go to the smaller entry)
-        atomicMax(&s_best[wave][r], ((unsigned long long)(d + 1u) << 32) | (unsigned long long)(0xffffffffu - (unsigned int)u));
-      }
+      for (int step = kWave / 2; step > 0; step >>= 1)
+        if (s_start[wave][r + step] <= q) r += step;
+      const int r0 = __builtin_amdgcn_readfirstlane(r);          // the row this step begins in
+      if ((longs >> r0) & 1ull) { base = s_start[wave][r0 + 1]; continue; }
+      if (base + lane < q1 && !((longs >> r) & 1ull)) atomicMax(&s_best[wave][r], hint_key(ind[q], deg_ptr));
+      base += kWave;
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    if (v < n) {
+    if (v < n && !((longs >> lane) & 1ull)) {
       const unsigned long long b = s_best[wave][lane];
       hint[v] = b ? (Index)(0xffffffffu - (unsigned int)b) : -1;
     }
     __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// the rows of kHintLong entries and more: a workgroup looks at 1024 consecutive rows, lists the long ones, and walks
+// each of them with all its threads
+static __global__ __launch_bounds__(1024) void bfs_hint_long_kernel(
+    const Index* __restrict__ ptr, const Index* __restrict__ ind, Index n, const Index* __restrict__ deg_ptr,
+    Index* __restrict__ hint) {
+  __shared__ Index s_rows[1024];
+  __shared__ int s_n;
+  __shared__ unsigned long long s_max;
+  for (Index v0 = (Index)blockIdx.x * 1024; v0 < n; v0 += (Index)gridDim.x * 1024) {
+    __syncthreads();
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    const Index v = v0 + (Index)threadIdx.x;
+    if (v < n && ptr[v + 1] - ptr[v] >= kHintLong) s_rows[atomicAdd(&s_n, 1)] = v;
+    __syncthreads();
+    const int nl = s_n;
+    for (int k = 0; k < nl; ++k) {
+      const Index row = s_rows[k];
+      if (threadIdx.x == 0) s_max = 0ull;
+      __syncthreads();
+      unsigned long long best = 0ull;
+      const Index e = ptr[row + 1];
+      for (Index q = ptr[row] + (Index)threadIdx.x; q < e; q += 1024) {
+        const unsigned long long key = hint_key(ind[q], deg_ptr);
+        best = key > best ? key : best;
+      }
+      // wave maximum (a handful of LDS atomics per wave would do as well; sixteen of them per row is nothing)
+#pragma unroll
+      for (int off = kWave / 2; off > 0; off >>= 1) {
+        const unsigned long long o = __shfl_xor(best, off, kWave);
+        best = o > best ? o : best;
+      }
+      if ((threadIdx.x & (kWave - 1)) == 0) atomicMax(&s_max, best);
+      __syncthreads();
+      if (threadIdx.x == 0) hint[row] = (Index)(0xffffffffu - (unsigned int)s_max);      // (a long row is not empty)
+      __syncthreads();
+    }
   }
 }
 
@@ -262,6 +312,8 @@ static inline grb_info ensure_pull_hint(Index** cache, const CsrArrays& M, const
   if (M.n > 0) {
     hipLaunchKernelGGL(bfs_hint_kernel, dim3(stream_grid((long long)ceil_div(M.n, kWave) * kWave, kBlock)),
                        dim3(kBlock), 0, s, M.ptr, M.ind, M.n, deg_ptr, *cache);
+    hipLaunchKernelGGL(bfs_hint_long_kernel, dim3(stream_grid((long long)M.n, 1024)), dim3(1024), 0, s, M.ptr, M.ind, M.n, deg_ptr,
+                       *cache);
     GRB_HIP_TRY(hipGetLastError());
   }
   return GRB_SUCCESS;

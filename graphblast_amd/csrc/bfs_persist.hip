@@ -914,6 +914,7 @@ __global__ void ptr_differ_kernel(const Index* __restrict__ a, const Index* __re
 // bins (RMAT-22: 16 Ki) a workgroup counts in LDS and adds its non-empty bins to memory once -- 55 M global atomics on
 // 16 Ki words were 3 ms of a matrix's first traversal.
 constexpr int kOcLdsBins = 16384;
+constexpr Index kOcLongRow = 8192;
 __global__ __launch_bounds__(1024) void oc_mass_kernel(const Index* __restrict__ optr, const Index* __restrict__ oind,
                                                        const Index* __restrict__ rows, int nrows, int nbins, unsigned int* __restrict__ bins) {
   __shared__ unsigned int h[kOcLdsBins];
@@ -924,10 +925,22 @@ __global__ __launch_bounds__(1024) void oc_mass_kernel(const Index* __restrict__
     __syncthreads();
   }
   const int nwaves = gridDim.x * waves;
+  // a row of kOcLongRow entries and more is walked by a whole workgroup (one wave alone on RMAT-22's longest row was
+  // 1.2 ms, this kernel's whole time), any other by a wave
+  for (int r = blockIdx.x; r < nrows; r += gridDim.x) {
+    const Index u = rows[r];
+    const Index s0 = optr[u], e = optr[u + 1];
+    if (e - s0 < kOcLongRow) continue;
+    for (Index p = s0 + (Index)threadIdx.x; p < e; p += (Index)blockDim.x) {
+      const int b = oind[p] / kOcBin;
+      if (lds) atomicAdd(&h[b], 1u); else atomicAdd(&bins[b], 1u);
+    }
+  }
   for (int r = blockIdx.x * waves + wave; r < nrows; r += nwaves) {
     const Index u = rows[r];
-    const Index e = optr[u + 1];
-    for (Index p = optr[u] + lane; p < e; p += kWave) {
+    const Index s0 = optr[u], e = optr[u + 1];
+    if (e - s0 >= kOcLongRow) continue;
+    for (Index p = s0 + lane; p < e; p += kWave) {
       const int b = oind[p] / kOcBin;
       if (lds) atomicAdd(&h[b], 1u); else atomicAdd(&bins[b], 1u);
     }
@@ -944,11 +957,14 @@ __global__ void oc_range_off_kernel(const Index* __restrict__ optr, const Index*
                                     int nrows, int R, const Index* __restrict__ bounds, Index* __restrict__ off) {
   // a thread per big row walks the bounds in order, each search starting where the last one ended (a gallop, then a
   // bisection of the bracket): a row's entries are read about once, and a step's stores are consecutive over the rows.
-  // (A thread per (range, row) bisecting the whole row, the first version: 18 M independent searches, 3.6 ms.)
+  // (A thread per (range, row) bisecting the whole row, the first version: 18 M independent searches, 3.6 ms -- kept for
+  // the rows of kOcLongRow entries and more, oc_range_off_long_kernel: one thread walking 257 bounds through 300 000
+  // entries is a chain of 5 000 dependent loads.)
   for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < nrows; r += gridDim.x * blockDim.x) {
     const Index u = rows[r];
     const Index e = optr[u + 1];
     Index p = optr[u];
+    if (e - p >= kOcLongRow) continue;
     for (int b = 0; b <= R; ++b) {
       const Index key = bounds[b];
       Index lo = p, hi = p, step = 1;
@@ -960,6 +976,26 @@ __global__ void oc_range_off_kernel(const Index* __restrict__ optr, const Index*
       }
       p = lo;
       off[(long long)b * nrows + r] = p;
+    }
+  }
+}
+__global__ void oc_range_off_long_kernel(const Index* __restrict__ optr, const Index* __restrict__ oind, const Index* __restrict__ rows,
+                                         int nrows, int R, const Index* __restrict__ bounds, Index* __restrict__ off) {
+  // a wave per long row, a lane per bound (64 at a time): independent bisections of the whole row
+  const int lane = threadIdx.x & (kWave - 1);
+  const int nwaves = gridDim.x * (blockDim.x >> 6);
+  for (int r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); r < nrows; r += nwaves) {
+    const Index u = rows[r];
+    const Index s0 = optr[u], e = optr[u + 1];
+    if (e - s0 < kOcLongRow) continue;
+    for (int b = lane; b <= R; b += kWave) {
+      const Index key = bounds[b];
+      Index lo = s0, hi = e;
+      while (lo < hi) {
+        const Index mid = lo + (hi - lo) / 2;
+        if (oind[mid] < key) lo = mid + 1; else hi = mid;
+      }
+      off[(long long)b * nrows + r] = lo;
     }
   }
 }
@@ -1050,6 +1086,8 @@ grb_info grb::oc_tables_build(const Index* d_ptr, const Index* d_ind, const std:
   *d_bigidx = d_big;
   d_big = nullptr;                                         // (the caller's now)
   hipLaunchKernelGGL(oc_range_off_kernel, dim3(stream_grid((long long)nrows_big, 64)), dim3(64), 0, s, d_ptr, d_ind,
+                     (const Index*)p_rows, (int)nrows_big, (int)R, (const Index*)*d_bounds, *d_off);
+  hipLaunchKernelGGL(oc_range_off_long_kernel, dim3(stream_grid((long long)nrows_big * kWave, kBlock)), dim3(kBlock), 0, s, d_ptr, d_ind,
                      (const Index*)p_rows, (int)nrows_big, (int)R, (const Index*)*d_bounds, *d_off);
   GRB_HIP_TRY(hipGetLastError());
   GRB_HIP_TRY(hipStreamSynchronize(s));                    // the host vectors above go out of scope
