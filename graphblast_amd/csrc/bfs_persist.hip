@@ -1032,6 +1032,7 @@ grb_info grb::oc_tables_build(const Index* d_ptr, const Index* d_ind, const std:
   std::vector<unsigned int> bins((size_t)nbins, 0u);
   void *p_rows = nullptr, *p_bins = nullptr;
   int* d_big = nullptr;
+  struct FreeTemp { void** p; ~FreeTemp() { if (*p) (void)hipFree(*p); } } free_rows{&p_rows}, free_bins{&p_bins};   // on every way out
   GRB_HIP_TRY(hipMalloc(&p_rows, sizeof(Index) * nrows_big));
   GRB_HIP_TRY(hipMalloc((void**)&d_big, sizeof(int) * (size_t)nrows));
   struct FreeBig { int** p; ~FreeBig() { if (*p) (void)hipFree(*p); } } free_big{&d_big};   // (handed over on success)
@@ -1052,6 +1053,7 @@ grb_info grb::oc_tables_build(const Index* d_ptr, const Index* d_ind, const std:
   GRB_HIP_TRY(hipMemcpyAsync(bins.data(), p_bins, 4 * (size_t)nbins, hipMemcpyDeviceToHost, s));
   GRB_HIP_TRY(hipStreamSynchronize(s));
   (void)hipFree(p_bins);
+  p_bins = nullptr;
   long long total = 0;
   for (unsigned int x : bins) total += (long long)x;
   long long target = std::max<long long>(1, total / (1ll * G));
@@ -1079,7 +1081,7 @@ grb_info grb::oc_tables_build(const Index* d_ptr, const Index* d_ind, const std:
     target += std::max<long long>(1, target / 32);
   }
   const long long R = (long long)bounds.size() - 1;
-  if (R < 2 || (long long)nrows_big * (R + 1) > (64ll << 20)) { (void)hipFree(p_rows); return GRB_SUCCESS; }
+  if (R < 2 || (long long)nrows_big * (R + 1) > (64ll << 20)) return GRB_SUCCESS;
   GRB_HIP_TRY(hipMalloc((void**)d_bounds, sizeof(Index) * bounds.size()));
   GRB_HIP_TRY(hipMalloc((void**)d_off, sizeof(Index) * nrows_big * (size_t)(R + 1)));
   GRB_HIP_TRY(hipMemcpyAsync(*d_bounds, bounds.data(), sizeof(Index) * bounds.size(), hipMemcpyHostToDevice, s));
@@ -1091,7 +1093,6 @@ grb_info grb::oc_tables_build(const Index* d_ptr, const Index* d_ind, const std:
                      (const Index*)p_rows, (int)nrows_big, (int)R, (const Index*)*d_bounds, *d_off);
   GRB_HIP_TRY(hipGetLastError());
   GRB_HIP_TRY(hipStreamSynchronize(s));                    // the host vectors above go out of scope
-  (void)hipFree(p_rows);
   *nb = (int)R;
   *nbig = (int)nrows_big;
   return GRB_SUCCESS;
