@@ -169,3 +169,40 @@ def test_row_search_in_a_chunk_with_empty_rows_and_a_ragged_end():
         want = np.repeat(np.arange(rows_here), deg)
         got = np.array([row_of(starts, p) for p in range(ptr[0], ptr[-1])])
         assert np.array_equal(got, want), rows_here
+
+
+def test_label_pass_lane_mapping_covers_every_vertex_once():
+    """bfs_persist.hip's label pass: a wave takes 32 bitmap words; lane l < 32 loads word l and forms its six label planes
+    (bit b of plane k = bit k of the label of vertex 32 w + b); store q (0 .. 3) of lane l writes the four labels of
+    vertices 4 (l & 7) .. + 3 of word 8 q + (l >> 3), taking the planes from the lane that loaded that word -- at float
+    offset 256 q + 4 l of the wave's 1024 labels, i.e. 64 x 16 consecutive bytes per store instruction."""
+    rng = np.random.default_rng(6)
+    levels = 9
+    nwords = 32
+    # disjoint level bitmaps F[0 .. levels): every vertex in at most one
+    owner = rng.integers(-1, levels, nwords * 32)                   # -1: never reached
+    F = np.zeros((levels, nwords), dtype=np.uint64)
+    for v, L in enumerate(owner):
+        if L >= 0:
+            F[L, v // 32] |= np.uint64(1) << np.uint64(v % 32)
+    planes = np.zeros((nwords, 6), dtype=np.uint64)                  # what lane w (the loader of word w) holds
+    for L in range(levels):
+        for k in range(6):
+            if ((L + 1) >> k) & 1:
+                planes[:, k] |= F[L]
+    out = np.full(nwords * 32, -1.0)
+    written = np.zeros(nwords * 32, dtype=int)
+    for q in range(4):
+        for lane in range(64):
+            src = q * 8 + (lane >> 3)
+            b0 = (lane & 7) * 4
+            base = q * 256 + lane * 4                                 # float offset inside the wave's 1024 labels
+            for t in range(4):
+                lab = 0
+                for k in range(6):
+                    lab |= int((planes[src, k] >> np.uint64(b0 + t)) & np.uint64(1)) << k
+                out[base + t] = lab
+                written[base + t] += 1
+            assert base == src * 32 + b0                              # the address IS the vertex: word src, bit b0
+    assert np.all(written == 1)
+    assert np.array_equal(out, np.where(owner >= 0, owner + 1, 0).astype(float))
