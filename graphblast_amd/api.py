@@ -492,6 +492,11 @@ def bfs_set_lanes(n=-1):
     return int(_lib.load().grb_bfs_set_lanes(int(n)))
 
 
+def bfs_set_coschedule(k=-1):
+    """grb_bfs_set_coschedule: traversals per launch for bfs_enqueue (k < 1 only queries); returns the previous value."""
+    return int(_lib.load().grb_bfs_set_coschedule(int(k)))
+
+
 def bfs_host_times(reset=False):
     """Host microseconds spent queueing / waiting inside the one-launch traversal since the last reset, and the calls."""
     e, w, n = C.c_double(0), C.c_double(0), C.c_longlong(0)

@@ -88,6 +88,7 @@ static grb_info bfs_one_launch_finish(grb_vector v, grb_matrix A, grb_descriptor
   const Index n = A->nrows;
   desc->lastmxv = p_dir ? GRB_PULLONLY : GRB_PUSHONLY;
   if (p_cap && p_nf > 0) {
+    bfs_lanes_unfence();                                    // (a lane's next launch into v comes after this)
     hipLaunchKernelGGL(bfs_unlabel_kernel, dim3(stream_grid(n)), dim3(kBlock), 0, s, (float*)v->d_val, n,
                        (float)(desc->max_niter + 1));
     GRB_HIP_TRY(hipGetLastError());
@@ -132,8 +133,12 @@ extern "C" grb_info grb_bfs_fused_enqueue(grb_vector v, grb_matrix A, grb_index 
   const bool one_launch = A->format == 0 && bfs_use_persistent() && g_persistent_failures < 3 && !bfs_queue_wanted(A, desc);
   if (one_launch) {
     hipStream_t s = ctx().stream;
+    const bool first_use = !A->d_no_in_edges || !A->d_pull_hint;
     GRB_TRY(ensure_empty_rows(&A->d_no_in_edges, A->csc, s));
     GRB_TRY(ensure_pull_hint(&A->d_pull_hint, A->csc, A->csr.ptr, s));
+    // the matrix's skip bitmap and pull hint were just queued on the library's stream: a lane's stream is not ordered
+    // behind that (its fence looks at other entry points only), so wait here, once per matrix
+    if (first_use && bfs_lanes_setting(0) > 1) GRB_HIP_TRY(hipStreamSynchronize(s));
     GRB_TRY(grb_vector_set_storage(v, GRB_DENSE));
     const grb_info li = bfs_persistent_enqueue(v, A, source, desc, slot, &seq);
     if (li == GRB_SUCCESS) {
@@ -163,6 +168,16 @@ extern "C" grb_info grb_bfs_wait(grb_bfs_ticket ticket, grb_bfs_result* result) 
     bfs_ticket_release(slot);
     return GRB_SUCCESS;
   }
+  if (state == 3) {                                         // still waiting for its co-scheduled launch to fill: launch what there is
+    GRB_TRY(bfs_co_flush());
+    if (bfs_ticket_state(slot, seq, nullptr, nullptr, nullptr, nullptr, nullptr) == 4) {
+      bfs_ticket_release(slot);                             // the launch was refused: the same traversal, now
+      return grb_bfs_fused(v, A, source, desc, result, nullptr, 0, 0);
+    }
+  } else if (state == 4) {
+    bfs_ticket_release(slot);
+    return grb_bfs_fused(v, A, source, desc, result, nullptr, 0, 0);
+  }
   int p_levels = 0, p_dir = 0;
   long long p_reached = 0;
   unsigned long long p_edges = 0;
@@ -174,8 +189,11 @@ extern "C" grb_info grb_bfs_wait(grb_bfs_ticket ticket, grb_bfs_result* result) 
   if (pi == GRB_PANIC) {
     // the launch did not run to its end (its grid barrier gave up), or it was queued behind one that did not: the same
     // traversal now, through grb_bfs_fused (which falls back to the host-driven level loop by itself)
+    // (the whole device: the ticket may belong to a lane whose kernel is still writing v and its state blocks, and
+    // what the re-run queues on the library's stream must come before the lanes' next launches)
     ++g_persistent_failures;
-    GRB_HIP_TRY(hipStreamSynchronize(ctx().stream));
+    GRB_HIP_TRY(hipDeviceSynchronize());
+    bfs_lanes_unfence();
     return grb_bfs_fused(v, A, source, desc, result, nullptr, 0, 0);
   }
   GRB_TRY(pi);
@@ -188,6 +206,12 @@ extern "C" grb_info grb_bfs_wait(grb_bfs_ticket ticket, grb_bfs_result* result) 
 // queries.  Returns the previous value.
 extern "C" int grb_bfs_set_lanes(int n) { GRB_API_ENTER_NOINFO();
   return bfs_lanes_setting(n);
+}
+
+// Traversals per launch: with k > 1 the traversals queued by grb_bfs_fused_enqueue are launched k at a time, side by
+// side in one grid (bfs_persist.hip: bfs_co_kernel).  k < 1 only queries.  Returns the previous value.
+extern "C" int grb_bfs_set_coschedule(int k) { grb::ApiScope api_scope__; (void)api_scope__.enter(false, false);   // (one of the queue's own)
+  return bfs_co_setting(k);
 }
 
 // Host time spent inside the one-launch traversal's two halves since the last reset: queueing the launches

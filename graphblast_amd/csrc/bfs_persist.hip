@@ -79,7 +79,6 @@ constexpr int kBigDeg = GRB_BFS_BIG_DEG;      // from here: split into kBigChunk
 constexpr int kBigChunk = 1024;
 constexpr int kPullBlock = GRB_PULL_BLOCK;    // chunks (of 64 vertices) one wave carries through the pull stages together
 static_assert(kPullBlock * kWave <= kPullQueue, "a wave queues at most every vertex of its block");
-constexpr int kMedCap = 4096;     // LDS list of medium vertices per workgroup pass
 typedef float LabelQuad __attribute__((ext_vector_type(4)));
 constexpr int kKeep = 32;         // levels whose discovered-bitmaps are kept for the final label pass
 
@@ -150,7 +149,10 @@ struct LevelCounters {
 __device__ inline int fbuf(int level) { return level < kKeep ? level : kKeep + (level - kKeep) % 3; }
 
 // a vertex was discovered: account for it (and label it at once beyond the kept levels: new_label > 0)
-__device__ inline void discovered(const PersistArgs& a, Index v, float new_label, LevelCounters& c) {
+// (A = PersistArgs wherever it lives: the one-traversal kernel's by-value parameter, or one entry of the co-scheduled
+// kernel's argument table read through the kernarg segment pointer)
+template <typename A>
+__device__ inline void discovered(const A& a, Index v, float new_label, LevelCounters& c) {
   if (new_label > 0.f) a.label[v] = new_label;
   const Index d = a.optr[v + 1] - a.optr[v];
   ++c.found;
@@ -158,7 +160,8 @@ __device__ inline void discovered(const PersistArgs& a, Index v, float new_label
   if (d >= kBigDeg) ++c.big;
 }
 
-__device__ inline void push_visit(const PersistArgs& a, unsigned int* V, unsigned int* Fn, Index dst,
+template <typename A>
+__device__ inline void push_visit(const A& a, unsigned int* V, unsigned int* Fn, Index dst,
                                   float new_label, LevelCounters& c) {
   const unsigned int bit = 1u << (dst & 31);
   if (fresh(&V[dst >> 5]) & bit) return;
@@ -168,21 +171,38 @@ __device__ inline void push_visit(const PersistArgs& a, unsigned int* V, unsigne
   discovered(a, dst, new_label, c);
 }
 
-__global__ __launch_bounds__(kPThreads) void bfs_persistent_kernel(PersistArgs a) {
-  __shared__ unsigned long long s_red[kPWaves][4];
+// One traversal on a grid of G workgroups of T threads; `bid` is the workgroup's number inside that grid.  The
+// one-traversal kernel is this with T = 1024 on the launch's whole grid; the co-scheduled kernel (below) runs several
+// of these side by side in one launch, T = 512 or 256, each on its own sub-grid of G = CUs workgroups -- a CU then holds
+// one workgroup of every traversal, and the hardware's wave scheduler fills one traversal's barriers and latency chains
+// with the other's work.
+//
+// LDS: the pull levels' per-wave row queues and the owner-computes push's slice of the visited bitmap are never live
+// at the same time (a level is one or the other), so they share their bytes; at T = 256 four workgroups fit a CU.
+template <int T>
+struct PersistLds {
+  static constexpr int W = T / kWave;
+  struct OcView { int2 row[W][kWave]; unsigned int ocw[kOcWords]; };
+  union U { PullLds pull[W]; OcView oc; };
+};
+
+template <int T, typename AP>
+__device__ __forceinline__ void bfs_persistent_body(AP ap, const int bid, const int G) {
+  const auto& a = *ap;
+  constexpr int W = T / kWave;
+  constexpr int kMed = T >= 512 ? 4 * T : 512;                     // LDS list of medium vertices per workgroup pass
+  __shared__ unsigned long long s_red[W][4];
   __shared__ unsigned long long s_tot[4];
 #if GRB_BFS_PULL_DYN
   __shared__ int s_pull_next;                                      // dense pull: the next block of this workgroup's share
 #endif
   __shared__ int s_lcnt[2];                                        // big-vertex listing: this workgroup's entries of a pass
   __shared__ unsigned s_lbase;                                     // ... and where its block starts in the global list
-  __shared__ Index s_med[kMedCap];
+  __shared__ Index s_med[kMed];
   __shared__ int s_nmed;
-  __shared__ PullLds s_pull[kPWaves];                              // one per wave: the pull levels' row queue
-  __shared__ unsigned int s_ocw[kOcWords];
+  __shared__ typename PersistLds<T>::U s_u;                        // pull: one row queue per wave | heavy push: the range's slice
   int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
-  const int G = gridDim.x;
-  long long gtid = (long long)blockIdx.x * kPThreads + tid;
+  long long gtid = (long long)bid * T + tid;
   // The phases of a level are long and disjoint; left alone, the compiler computes every lane-derived index, mask and
   // LDS address of ALL of them once before the level loop and keeps them in registers for the whole kernel (the
   // kernel sits at its 128-register limit, so each such value is a spill somewhere else).  Each phase therefore
@@ -193,12 +213,12 @@ __global__ __launch_bounds__(kPThreads) void bfs_persistent_kernel(PersistArgs a
     asm volatile("" : "+v"(tid));                                 \
     lane = tid & (kWave - 1);                                     \
     wave = tid >> 6;                                              \
-    gtid = (long long)blockIdx.x * kPThreads + tid;               \
+    gtid = (long long)bid * T + tid;               \
   } while (0)
 #else
 #define GRB_PHASE_START() do { } while (0)
 #endif
-  const long long gthreads = (long long)G * kPThreads;
+  const long long gthreads = (long long)G * T;
   const Index n = a.n;
   const int nwords = 2 * ((n + 63) / 64);
   PersistState* st = a.st;
@@ -224,7 +244,7 @@ __global__ __launch_bounds__(kPThreads) void bfs_persistent_kernel(PersistArgs a
     atomicOr(&a.V[0][a.source >> 5], 1u << (a.source & 31));
     atomicOr(&a.F[0][a.source >> 5], 1u << (a.source & 31));
   }
-  if (a.mode == GRB_PULLONLY && !GRB_BFS_GRID_SYNC(&st->bar, gen)) return;
+  if (a.mode == GRB_PULLONLY && !grid_sync_at(&st->bar, gen, bid, G, false)) return;
 
   // ---- level loop (all scalars below are identical in every workgroup)
   Index nf = 1;
@@ -261,7 +281,7 @@ __global__ __launch_bounds__(kPThreads) void bfs_persistent_kernel(PersistArgs a
     if (iter + 1 >= kKeep + 3)                            // a rotating buffer about to be reused
       for (long long i = gtid; i < nwords; i += gthreads) publish(&a.F[fbuf(iter + 1)][i], 0u);
     if (gtid == 0) publish(&st->big_count[(iter + 1) & 1][0], 0u);
-    if (blockIdx.x == 0 && tid < 32) publish(&st->acc[(iter + 1) % 3][tid >> 2][tid & 3], 0ull);
+    if (bid == 0 && tid < 32) publish(&st->acc[(iter + 1) % 3][tid >> 2][tid & 3], 0ull);
     // A push level whose frontier carries many edges through few vertices runs at the rate of racing global
     // atomics (two per discovery, most attempts losers).  Such a level buckets its big vertices' edges by
     // destination range instead and lets the range's owner settle them in LDS: no global atomics at all.
@@ -296,10 +316,10 @@ __global__ __launch_bounds__(kPThreads) void bfs_persistent_kernel(PersistArgs a
           // a frontier that is contiguous in vertex order (a grid's wave front) is still spread over the grid.  (One word
           // per lane with stride G, the first version, made every lane of a load a cache line of its own: 262 144 line
           // requests for the 4 096 lines of RMAT-22's bitmap in every push level.)
-          const long long chunk = (base / kWave) + (long long)wave * G + blockIdx.x;
+          const long long chunk = (base / kWave) + (long long)wave * G + bid;
           const long long i = chunk * kWave + lane;
 #else
-          const long long i = (base / G + tid) * G + blockIdx.x;      // word index, stride G inside the WG
+          const long long i = (base / G + tid) * G + bid;      // word index, stride G inside the WG
 #endif
           const unsigned int w = (i < nwords) ? fresh(&Fc[i]) : 0u;
           int mine = 0;
@@ -311,7 +331,7 @@ __global__ __launch_bounds__(kPThreads) void bfs_persistent_kernel(PersistArgs a
             if (!do_expand) continue;
             if (d >= kSmallDeg) {
               const int slot = atomicAdd(&s_nmed, 1);
-              if (slot < kMedCap) { s_med[slot] = v; continue; }
+              if (slot < kMed) { s_med[slot] = v; continue; }
             }
             for (Index p = s; p < e; ++p) push_visit(a, V, Fn, a.oind[p], new_label, c);
           }
@@ -355,8 +375,8 @@ incl = (int)wave_incl_scan_u32((unsigned)incl);
           }
           if (!do_expand) continue;
           __syncthreads();
-          const int nm = s_nmed < kMedCap ? s_nmed : kMedCap;
-          for (int k = wave; k < nm; k += kPWaves) {
+          const int nm = s_nmed < kMed ? s_nmed : kMed;
+          for (int k = wave; k < nm; k += W) {
             const Index v = s_med[k];
             const Index e = a.optr[v + 1];
             for (Index p = a.optr[v] + lane; p < e; p += kWave) push_visit(a, V, Fn, a.oind[p], new_label, c);
@@ -369,16 +389,20 @@ incl = (int)wave_incl_scan_u32((unsigned)incl);
         if (heavy) scan(true, false); else scan(nbig > 0, true);
         if (nbig > 0) {
           stamp();
-          if (!GRB_BFS_GRID_SYNC(&st->bar, gen)) return;
+          if (!grid_sync_at(&st->bar, gen, bid, G, false)) return;
           stamp();
           int nent = (int)__hip_atomic_load(bcount, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           if (nent > a.big_cap) nent = a.big_cap;
           if (!heavy) {
-            for (int e = blockIdx.x; e < nent; e += G) {
+            for (int e = bid; e < nent; e += G) {
               const unsigned long long eb = fresh(reinterpret_cast<const unsigned long long*>(&a.big_list[e]));
               const int2 ent = make_int2((int)(eb & 0xffffffffull), (int)(eb >> 32));
-              const Index p = a.optr[ent.x] + ent.y * kBigChunk + tid;
-              if (p < a.optr[ent.x + 1]) push_visit(a, V, Fn, a.oind[p], new_label, c);
+              const Index pe = a.optr[ent.x + 1];
+#pragma unroll
+              for (int t = 0; t < kBigChunk / T; ++t) {
+                const Index p = a.optr[ent.x] + ent.y * kBigChunk + t * T + tid;
+                if (p < pe) push_visit(a, V, Fn, a.oind[p], new_label, c);
+              }
             }
           } else {
             // ---- owner-computes: this workgroup's ranges, one after the other.  The pieces of a wave's 64 list
@@ -386,15 +410,15 @@ incl = (int)wave_incl_scan_u32((unsigned)incl);
             // pull levels use for their leftovers), so a step costs one chain of memory latencies whatever the
             // piece lengths are; the range's new bits go out with one atomicOr per changed word -- the other
             // workgroups push the small vertices of the frontier with atomics meanwhile.
-            for (int b = blockIdx.x; b < a.oc_nb; b += G) {
+            for (int b = bid; b < a.oc_nb; b += G) {
               const Index v0 = a.oc_bounds[b];
               const int w0 = (int)(v0 >> 5);
               int nw = (int)((a.oc_bounds[b + 1] - v0 + 31) >> 5);
               if (w0 + nw > nwords) nw = nwords - w0;
               __syncthreads();
-              for (int i = tid; i < nw; i += kPThreads) s_ocw[i] = 0u;
+              for (int i = tid; i < nw; i += T) s_u.oc.ocw[i] = 0u;
               __syncthreads();
-              for (int e0 = 0; e0 < nent; e0 += kPThreads) {
+              for (int e0 = 0; e0 < nent; e0 += T) {
                 const int e = e0 + tid;
                 Index o0 = 0, o1 = 0;
                 if (e < nent) {
@@ -409,7 +433,7 @@ inc = (Index)wave_incl_scan_u32((unsigned)inc);
                 const Index total = (Index)__builtin_amdgcn_readlane((int)inc, kWave - 1);
                 if (total == 0) continue;
                 __builtin_amdgcn_wave_barrier();
-                s_pull[wave].row[lane] = make_int2(inc - len, o0);
+                s_u.oc.row[wave][lane] = make_int2(inc - len, o0);
                 __builtin_amdgcn_wave_barrier();
                 for (Index at0 = 0; at0 < total; at0 += 4 * kWave) {
                   Index q[4];
@@ -421,8 +445,8 @@ inc = (Index)wave_incl_scan_u32((unsigned)inc);
                       int r = 0;                           // the last entry whose first edge is <= at
 #pragma unroll
                       for (int step = kWave / 2; step > 0; step >>= 1)
-                        if (s_pull[wave].row[r + step].x <= at) r += step;
-                      q[j] = s_pull[wave].row[r].y + (at - s_pull[wave].row[r].x);
+                        if (s_u.oc.row[wave][r + step].x <= at) r += step;
+                      q[j] = s_u.oc.row[wave][r].y + (at - s_u.oc.row[wave][r].x);
                     }
                   }
                   Index d[4];
@@ -430,13 +454,13 @@ inc = (Index)wave_incl_scan_u32((unsigned)inc);
                   for (int j = 0; j < 4; ++j) d[j] = q[j] >= 0 ? a.oind[q[j]] : -1;
 #pragma unroll
                   for (int j = 0; j < 4; ++j)
-                    if (d[j] >= 0) atomicOr(&s_ocw[(d[j] >> 5) - w0], 1u << (d[j] & 31));
+                    if (d[j] >= 0) atomicOr(&s_u.oc.ocw[(d[j] >> 5) - w0], 1u << (d[j] & 31));
                 }
                 __builtin_amdgcn_wave_barrier();
               }
               __syncthreads();
-              for (int i = tid; i < nw; i += kPThreads) {
-                const unsigned int acc = s_ocw[i];
+              for (int i = tid; i < nw; i += T) {
+                const unsigned int acc = s_u.oc.ocw[i];
                 if (!acc) continue;
                 unsigned int newb = acc & ~fresh(&V[w0 + i]);
                 if (!newb) continue;
@@ -465,9 +489,9 @@ inc = (Index)wave_incl_scan_u32((unsigned)inc);
       const Index* hint = a.count_inspected ? nullptr : a.hint;
       const Index nchunks = (n + kWave - 1) / kWave;
       const Index nblocks = (nchunks + kPullBlock - 1) / kPullBlock;
-      const Index nwaves = (Index)G * kPWaves;
+      const Index nwaves = (Index)G * W;
       const unsigned long long lt_mask = (1ull << lane) - 1ull;
-      PullLds& L = s_pull[wave];
+      PullLds& L = s_u.pull[wave];
       // Few vertices are left to discover (the levels after the big one): the dense walk below would carry 512-vertex
       // blocks with a handful of live lanes through its stages.  Here a wave numbers the active bits of kSparseWords
       // bitmap words (wave_for_each_bit) and takes them 64 at a time, one vertex per lane.  Same discoveries, same
@@ -476,7 +500,7 @@ inc = (Index)wave_incl_scan_u32((unsigned)inc);
                               (a.n_in - reached) * GRB_BFS_SPARSE_DIV < (long long)n;
 #if GRB_BFS_PULL_DYN
       const Index pull_per = (nblocks + (Index)G - 1) / (Index)G;
-      const Index pull_b0 = (Index)blockIdx.x * pull_per;
+      const Index pull_b0 = (Index)bid * pull_per;
       const Index pull_b1 = pull_b0 + pull_per < nblocks ? pull_b0 + pull_per : nblocks;
       if (tid == 0) s_pull_next = 0;
 #endif
@@ -487,7 +511,7 @@ inc = (Index)wave_incl_scan_u32((unsigned)inc);
       if (sparse_act) {
         constexpr bool kF = GRB_BFS_SPARSE_FRESH != 0;     // few probes: agent-scope loads instead of the invalidate
         const Index ngroups = (Index)((nwords + kSparseWords - 1) / kSparseWords);
-        for (Index g = (Index)blockIdx.x * kPWaves + wave; g < ngroups; g += nwaves) {
+        for (Index g = (Index)bid * W + wave; g < ngroups; g += nwaves) {
           const Index wi = g * kSparseWords + lane;
           const bool has_word = lane < kSparseWords && wi < nwords;
           unsigned int vw = 0xffffffffu, act = 0u;
@@ -552,7 +576,7 @@ inc = (Index)wave_incl_scan_u32((unsigned)inc);
         blk = (Index)__builtin_amdgcn_readfirstlane((int)blk);
         if (blk >= pull_b1) break;
 #else
-      for (Index blk = (Index)blockIdx.x * kPWaves + wave; blk < nblocks; blk += nwaves) {
+      for (Index blk = (Index)bid * W + wave; blk < nblocks; blk += nwaves) {
 #endif
         // ---- stage 0: the block's words; a lane's vertices are vbase + 64 j
         const Index wi = blk * (2 * kPullBlock) + lane;
@@ -602,7 +626,7 @@ inc = (Index)wave_incl_scan_u32((unsigned)inc);
           const int mine = __popc(und);
           int incl = mine;
 incl = (int)wave_incl_scan_u32((unsigned)incl);
-          const int T = (int)__builtin_amdgcn_readlane((int)incl, kWave - 1);
+          const int Tq = (int)__builtin_amdgcn_readlane((int)incl, kWave - 1);
           int at = incl - mine;
 #pragma unroll
           for (int j = 0; j < kPullBlock; ++j)
@@ -612,7 +636,7 @@ incl = (int)wave_incl_scan_u32((unsigned)incl);
               ++at;
             }
           __builtin_amdgcn_wave_barrier();
-          pull_queue_run<false>(a.iind, a.nnz, vin, L, lane, T, c.inspected);
+          pull_queue_run<false>(a.iind, a.nnz, vin, L, lane, Tq, c.inspected);
 #pragma unroll
           for (int j = 0; j < kPullBlock; ++j) fnd |= ((L.found[2 * j + (lane >> 5)] >> (lane & 31)) & 1u) << j;
           __builtin_amdgcn_wave_barrier();
@@ -665,7 +689,7 @@ incl = (int)wave_incl_scan_u32((unsigned)incl);
     }
 
     stamp();
-    if (a.trace && tid == 0 && levels < 12 && blockIdx.x < 512) a.trace[256 + levels * 512 + blockIdx.x] = wall_clock64() - t_level;
+    if (a.trace && tid == 0 && levels < 12 && bid < 512) a.trace[256 + levels * 512 + bid] = wall_clock64() - t_level;
     // ---- level totals: one atomic per value per workgroup into this XCD group's line
     GRB_PHASE_START();
     // A wave's share of a level's totals fits 32 bits (every one of them is bounded by nnz, and Index is 32-bit); most
@@ -691,8 +715,8 @@ incl = (int)wave_incl_scan_u32((unsigned)incl);
 #endif
     if (tid < 4) {
       unsigned long long t = 0;
-      for (int w = 0; w < kPWaves; ++w) t += s_red[w][tid];
-      if (t) __hip_atomic_fetch_add(&acc[(blockIdx.x & 7) * 16 + tid], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int w = 0; w < W; ++w) t += s_red[w][tid];
+      if (t) __hip_atomic_fetch_add(&acc[(bid & 7) * 16 + tid], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 #if GRB_BFS_FINE_TRACE
     {                                                    // grid_sync, stamped step by step (workgroup 0, thread 0)
@@ -702,7 +726,7 @@ incl = (int)wave_incl_scan_u32((unsigned)incl);
       stamp();                                           // every wave of this workgroup has arrived
       if (tid == 0) {
         const unsigned g = gen + 1;
-        const unsigned x = blockIdx.x & 7u;
+        const unsigned x = bid & 7u;
         const unsigned groups = G < 8 ? (unsigned)G : 8u;
         const unsigned members = ((unsigned)G - x + 7u) / 8u;
         const unsigned arr = __hip_atomic_fetch_add(&st->bar.xcd_count[x][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -717,7 +741,7 @@ incl = (int)wave_incl_scan_u32((unsigned)incl);
       ++gen;
     }
 #else
-    if (!GRB_BFS_GRID_SYNC(&st->bar, gen)) return;
+    if (!grid_sync_at(&st->bar, gen, bid, G, false)) return;
 #endif
     stamp();
     if (wave == 0) {
@@ -765,8 +789,8 @@ incl = (int)wave_incl_scan_u32((unsigned)incl);
     // 32 words per wave step (every wave of the grid has one at n = 4 Mi); a word's six planes are computed by the
     // lane that loaded it and handed to the eight lanes that store its labels: a store instruction then writes
     // 64 x 16 consecutive bytes (eight whole lines) instead of 16 bytes in each of 64 lines.
-    const long long nwave_all = (long long)G * (kPThreads / kWave);
-    for (long long wb = ((long long)blockIdx.x * (kPThreads / kWave) + wave) * 32; wb < nwords; wb += nwave_all * 32) {
+    const long long nwave_all = (long long)G * (T / kWave);
+    for (long long wb = ((long long)bid * (T / kWave) + wave) * 32; wb < nwords; wb += nwave_all * 32) {
       const long long wi0 = wb + (lane & 31);
       const bool have = wi0 < nwords;
       const long long wi = have ? wi0 : (long long)nwords - 1;
@@ -884,6 +908,33 @@ incl = (int)wave_incl_scan_u32((unsigned)incl);
     for (int k = 0; k < 8; ++k)
       __hip_atomic_store(&a.mail[k], tag | vals[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
+}
+
+typedef const __attribute__((address_space(4))) PersistArgs* KernArgsPtr;
+__global__ __launch_bounds__(kPThreads) void bfs_persistent_kernel(PersistArgs a) {
+  bfs_persistent_body<kPThreads>((KernArgsPtr)__builtin_amdgcn_kernarg_segment_ptr(), (int)blockIdx.x, (int)gridDim.x);
+}
+
+// ---- several traversals in ONE launch ------------------------------------------------------------------------------
+// A traversal is barriers and dependent-load chains for half of its time (about 50 of 105 us move no
+// bytes), and none of that gets shorter with more CUs.  Here k queued traversals (2 .. 1024 / T) run side by side: the
+// launch is k sub-grids of G = CUs workgroups of T = 512 or 256 threads, workgroup b of the launch is workgroup b % G
+// of traversal b / G (so a traversal's workgroup keeps the XCD its number implies, and -- the dispatcher placing
+// workgroups in order -- a CU holds one workgroup of each traversal).  Every traversal has the whole device's CUs, L1s
+// and LDS bandwidth; its barriers, totals and latency chains are filled with the other traversals' waves by the
+// hardware scheduler.  Nothing depends on how the runtime maps streams to hardware queues (grb_bfs_set_lanes does).
+// The traversals are independent: private state blocks, bitmaps, lists, barrier counters and records (a lane's worth
+// each, BfsLane below); the argument blocks sit one after the other in the kernarg segment and a workgroup reads its
+// own through the segment pointer (scalar loads from constant memory, exactly what the one-traversal kernel's
+// by-value parameter compiles to -- a by-value table indexed at run time would be copied to scratch).
+constexpr int kCoMax = 4;
+struct CoArgs { PersistArgs t[kCoMax]; };
+template <int T>
+__global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void bfs_co_kernel(CoArgs ca, int G) {
+  const int j = (int)blockIdx.x / G;
+  const int bid = (int)blockIdx.x - j * G;
+  const KernArgsPtr base = (KernArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
+  bfs_persistent_body<T>(base + j, bid, G);
 }
 
 // which rows are big (>= kBigDeg entries), their numbers and their list, on the device (round 5: the host walked its
@@ -1106,7 +1157,8 @@ grb_info grb::oc_tables_build(const Index* d_ptr, const Index* d_ind, const std:
 namespace {
 constexpr int kRing = 256;                       // records (= traversals in flight) at most
 struct BfsTicket {
-  int state = 0;                                 // 0 free, 1 in flight, 2 already complete (ran synchronously)
+  int state = 0;                                 // 0 free, 1 in flight, 2 already complete (ran synchronously), 3 waiting for a
+                                                 // co-scheduled launch to fill, 4 could not be launched (the wait runs it)
   int seq = 0;
   int lane = 0;
   grb_vector v = nullptr;
@@ -1132,7 +1184,17 @@ struct BfsLane {
   int block = 0;
   unsigned long long fenced_epoch = ~0ull;       // ApiScope::epoch when this lane last fenced against the library's stream
 };
+struct CoPend {                                  // a traversal that has its ticket and waits for company (co-scheduling)
+  int slot = 0, seq = 0;
+  grb_vector v = nullptr;
+  grb_matrix A = nullptr;
+  grb_index source = 0;
+  grb_descriptor desc = nullptr;
+};
 struct BfsRing {
+  int co_width = 1;                              // traversals per launch (grb_bfs_set_coschedule); 1: every traversal its own launch
+  int co_n = 0;                                  // ... and the ones that wait for the launch to fill (ticket state 3)
+  CoPend co[kCoMax];
   BfsLane lane[kMaxLanes + 1];                   // [0]: the library's stream (blocking calls, one lane); [1 ..]: the lanes proper
   int lanes = 1, next_lane = 0;
   bool lanes_active = false;                     // the launch being queued is one of several in flight (set around enqueue)
@@ -1196,19 +1258,35 @@ static grb_info lane_buffer(void** p, size_t* cap, size_t bytes, hipStream_t s) 
   return GRB_SUCCESS;
 }
 
-static grb_info bfs_persistent_launch(grb_vector v, grb_matrix A, grb_index source, grb_descriptor desc, int profile, int slot,
-                                      int* seq_out, void** p_rec_out, unsigned long long** trace_out, int lane_id = 0) {
+// What a launch needs besides its argument block: whose buffers it runs on and what to note once it is queued.
+struct LaunchCtx {
+  int lane_id = 0;
+  bool co = false;               // one of several traversals of ONE launch on the library's stream (lane_id = its number there)
+  hipStream_t s = nullptr;
+  int G = 0;
+  void* p_zero = nullptr;
+  size_t zero_bytes = 0;
+  int* p_blocksel = nullptr;
+};
+
+// Fills the argument block of one traversal: the lane's buffers (lane 0: the library's scratch slots), the once-per-
+// matrix facts and tables, the record slot.  seq_in = 0 draws a new tag.  Queues at most memsets on lc->s.
+static grb_info bfs_persistent_args(grb_vector v, grb_matrix A, grb_index source, grb_descriptor desc, int profile, int slot,
+                                    int seq_in, int lane_id, bool co, PersistArgs* out, LaunchCtx* lc, void** p_rec_out,
+                                    unsigned long long** trace_out) {
   GRB_TRY(ring_init());
   Context& c = ctx();
   BfsLane& ln = g_ring.lane[lane_id];
-  if (lane_id > 0 && !ln.stream) {
-    GRB_HIP_TRY(hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking));
-    GRB_HIP_TRY(hipEventCreateWithFlags(&ln.ev_in, hipEventDisableTiming));
-    GRB_HIP_TRY(hipEventCreateWithFlags(&ln.ev_done, hipEventDisableTiming));
+  if (lane_id > 0 && !ln.d_levels) {
     GRB_HIP_TRY(hipMalloc((void**)&ln.d_levels, 256));
     GRB_HIP_TRY(hipMemset(ln.d_levels, 0, 256));
   }
-  hipStream_t s = lane_id > 0 ? ln.stream : c.stream;
+  if (lane_id > 0 && !co && !ln.stream) {
+    GRB_HIP_TRY(hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking));
+    GRB_HIP_TRY(hipEventCreateWithFlags(&ln.ev_in, hipEventDisableTiming));
+    GRB_HIP_TRY(hipEventCreateWithFlags(&ln.ev_done, hipEventDisableTiming));
+  }
+  hipStream_t s = (lane_id > 0 && !co) ? ln.stream : c.stream;
   unsigned int* d_levels = lane_id > 0 ? ln.d_levels : g_ring.d_levels;
   const Index n = A->nrows;
   const int nwords = 2 * ceil_div(n, 64);
@@ -1220,9 +1298,12 @@ static grb_info bfs_persistent_launch(grb_vector v, grb_matrix A, grb_index sour
     if (max_per_cu < 1) return GRB_PANIC;
   }
   if (wgs_per_cu > max_per_cu) wgs_per_cu = max_per_cu;
-  // lanes > 1: a queued traversal takes its share of the CUs (the blocking call, lane 0 alone, the whole device)
-  const int G = (g_ring.lanes > 1 && profile == 0 && lane_id >= 0 && g_ring.lanes_active) ? (c.num_cu / g_ring.lanes > 0 ? c.num_cu / g_ring.lanes : 1)
-                                                                                          : c.num_cu * wgs_per_cu;
+  const int G_full = c.num_cu * wgs_per_cu;
+  // lanes > 1: a queued traversal takes its share of the CUs (the blocking call, lane 0 alone, the whole device);
+  // a co-scheduled traversal has a workgroup on every CU
+  const int G = co ? c.num_cu
+                   : (g_ring.lanes > 1 && profile == 0 && g_ring.lanes_active) ? (c.num_cu / g_ring.lanes > 0 ? c.num_cu / g_ring.lanes : 1)
+                                                                               : G_full;
   const int rec_cap = 1 << 15;
   const int big_cap = (int)(A->nvals / kBigDeg) + 2;
 
@@ -1270,7 +1351,7 @@ static grb_info bfs_persistent_launch(grb_vector v, grb_matrix A, grb_index sour
     ticks_to_ms = khz > 0 ? 1.0f / (float)khz : 1e-5f;
   }
 
-  PersistArgs a;
+  PersistArgs& a = *out;
   a.optr = A->csr.ptr; a.oind = A->csr.ind;
   a.iptr = A->csc.ptr; a.iind = A->csc.ind;
   a.skip = A->d_no_in_edges;
@@ -1278,11 +1359,14 @@ static grb_info bfs_persistent_launch(grb_vector v, grb_matrix A, grb_index sour
   a.n = n;
   a.nnz = A->nvals;
   // once per matrix: how many vertices have in-edges at all (the complement of the skip bitmap), and whether the two
-  // pointer arrays hold the same numbers (the same array, or equal host mirrors)
+  // pointer arrays hold the same numbers (the same array, or equal host mirrors).  On the LIBRARY's stream, whatever
+  // lane the traversal goes to: the skip bitmap is made there (ensure_empty_rows), and waiting for it here also puts
+  // every other first-use preparation of this matrix (the pull hint) in front of the lane's launch.
   if (A->bfs_n_in < 0) {
+    hipStream_t sp = c.stream;
     std::vector<unsigned int> h_skip((size_t)nwords);
-    GRB_HIP_TRY(hipMemcpyAsync(h_skip.data(), A->d_no_in_edges, 4 * (size_t)nwords, hipMemcpyDeviceToHost, s));
-    GRB_HIP_TRY(hipStreamSynchronize(s));
+    GRB_HIP_TRY(hipMemcpyAsync(h_skip.data(), A->d_no_in_edges, 4 * (size_t)nwords, hipMemcpyDeviceToHost, sp));
+    GRB_HIP_TRY(hipStreamSynchronize(sp));
     long long empty = 0;
     for (unsigned int w : h_skip) empty += __builtin_popcount(w);
     A->bfs_n_in = (long long)nwords * 32 - empty;           // the padding bits beyond n are set in the skip bitmap
@@ -1291,12 +1375,12 @@ static grb_info bfs_persistent_launch(grb_vector v, grb_matrix A, grb_index sour
       // compared on the device (two 17 MB host mirrors were compared here: 2 ms, and mirrors need not exist)
       unsigned int* d_differ = nullptr;
       GRB_HIP_TRY(hipMalloc((void**)&d_differ, 4));
-      GRB_HIP_TRY(hipMemsetAsync(d_differ, 0, 4, s));
-      hipLaunchKernelGGL(ptr_differ_kernel, dim3(stream_grid((long long)n + 1, kBlock)), dim3(kBlock), 0, s, A->csr.ptr, A->csc.ptr,
+      GRB_HIP_TRY(hipMemsetAsync(d_differ, 0, 4, sp));
+      hipLaunchKernelGGL(ptr_differ_kernel, dim3(stream_grid((long long)n + 1, kBlock)), dim3(kBlock), 0, sp, A->csr.ptr, A->csc.ptr,
                          n + 1, d_differ);
       unsigned int differ = 1u;
-      const hipError_t e1 = hipMemcpyAsync(&differ, d_differ, 4, hipMemcpyDeviceToHost, s);
-      const hipError_t e2 = hipStreamSynchronize(s);
+      const hipError_t e1 = hipMemcpyAsync(&differ, d_differ, 4, hipMemcpyDeviceToHost, sp);
+      const hipError_t e2 = hipStreamSynchronize(sp);
       (void)hipFree(d_differ);
       GRB_HIP_TRY(e1);
       GRB_HIP_TRY(e2);
@@ -1322,7 +1406,7 @@ static grb_info bfs_persistent_launch(grb_vector v, grb_matrix A, grb_index sour
   {
     const char* e = getenv("GRB_BFS_OC_MIN");              // frontier out-edges from which a push level uses it; 0 = off
     const long long oc_min = e ? atoll(e) : 262144;
-    const bool narrow = G != c.num_cu * wgs_per_cu;        // a lane's grid: its own tables (the ranges are cut per workgroup)
+    const bool narrow = G != G_full;                       // a lane's grid: its own tables (the ranges are cut per workgroup)
     if (!narrow) {
       if (oc_min > 0 && A->oc_state == 0) {
         A->oc_state = -1;
@@ -1370,25 +1454,67 @@ static grb_info bfs_persistent_launch(grb_vector v, grb_matrix A, grb_index sour
   a.rec = (grb_bfs_level*)p_rec;
   a.rec_cap = rec_cap;
   a.mail = g_ring.d + 8 * (size_t)slot;
-  a.seq = ++c.mail_seq;
+  a.seq = seq_in ? seq_in : ++c.mail_seq;
   a.dev_levels = d_levels;
   a.clean = (uint4*)((char*)p_zero + (size_t)((*p_blocksel) ^ 1) * block_bytes);
   a.st_bytes = (unsigned long long)st_bytes;
   a.ticks_to_ms = ticks_to_ms;
-  *seq_out = a.seq;
   *p_rec_out = p_rec;
   *trace_out = nullptr;
   static const bool want_trace = getenv("GRB_BFS_TRACE") != nullptr;
   a.trace = nullptr;
-  if (want_trace) {
+  if (want_trace && lane_id == 0 && !co) {
     void* p_tr;
     GRB_TRY(scratch(10, (256 + 12 * 512) * sizeof(unsigned long long), &p_tr));
     GRB_HIP_TRY(hipMemsetAsync(p_tr, 0, (256 + 12 * 512) * sizeof(unsigned long long), s));
     a.trace = (unsigned long long*)p_tr;
     *trace_out = a.trace;
   }
+  lc->lane_id = lane_id; lc->co = co; lc->s = s; lc->G = G; lc->p_zero = p_zero; lc->zero_bytes = zero_bytes; lc->p_blocksel = p_blocksel;
+  return GRB_SUCCESS;
+}
+// the launch has been queued: the next traversal of this lane runs on the other block and clears this one
+static grb_info bfs_persistent_queued(const LaunchCtx& lc) {
+  Context& c = ctx();
+  *lc.p_blocksel ^= 1;
+  if (lc.lane_id == 0) {
+    c.bfs_prezero_ptr = lc.p_zero;
+    c.bfs_prezero_bytes = lc.zero_bytes;
+  } else {
+    BfsLane& ln = g_ring.lane[lc.lane_id];
+    ln.clean_bytes = lc.zero_bytes;
+    if (!lc.co) GRB_HIP_TRY(hipEventRecord(ln.ev_done, lc.s));   // what the library's stream waits for before it touches v
+  }
+  return GRB_SUCCESS;
+}
 
+// A launch that needs the whole device resident (the blocking traversal, a co-scheduled group; also the other one-launch
+// algorithms, through grb::bfs_lanes_fence) must not meet a lane's narrower grid half-way: both would spin at their
+// barriers until the bound.  It waits for what the lanes have in flight.
+grb_info grb::bfs_lanes_fence(hipStream_t s) {
+  if (g_ring.lanes <= 1) return GRB_SUCCESS;
+  for (int l = 1; l <= kMaxLanes; ++l) {
+    BfsLane& ln = g_ring.lane[l];
+    if (ln.stream && ln.ev_done && ln.stream != s) GRB_HIP_TRY(hipStreamWaitEvent(s, ln.ev_done, 0));
+  }
+  return GRB_SUCCESS;
+}
+// the library's stream has been given work that a lane's next launch must come after (the wait path's unlabel / re-run)
+void grb::bfs_lanes_unfence() {
+  for (int l = 1; l <= kMaxLanes; ++l) g_ring.lane[l].fenced_epoch = ~0ull;
+}
 
+// Queues one traversal (on the library's stream, or on its lane's); its record will appear in ring slot `slot` under
+// tag *seq_out.
+static grb_info bfs_persistent_launch(grb_vector v, grb_matrix A, grb_index source, grb_descriptor desc, int profile, int slot,
+                                      int* seq_out, void** p_rec_out, unsigned long long** trace_out, int lane_id = 0, int seq_in = 0) {
+  Context& c = ctx();
+  PersistArgs a;
+  LaunchCtx lc;
+  GRB_TRY(bfs_persistent_args(v, A, source, desc, profile, slot, seq_in, lane_id, false, &a, &lc, p_rec_out, trace_out));
+  *seq_out = a.seq;
+  hipStream_t s = lc.s;
+  BfsLane& ln = g_ring.lane[lane_id];
   // whatever OTHER entry points have queued on the library's stream since this lane last looked (a fill of v, a build of
   // A) comes first; the traversal queue's own calls do not count -- lane 0's traversals live on that stream
   if (lane_id > 0 && ln.fenced_epoch != ApiScope::epoch) {
@@ -1396,6 +1522,7 @@ static grb_info bfs_persistent_launch(grb_vector v, grb_matrix A, grb_index sour
     GRB_HIP_TRY(hipStreamWaitEvent(s, ln.ev_in, 0));
     ln.fenced_epoch = ApiScope::epoch;
   }
+  if (lane_id == 0 && !g_ring.lanes_active) GRB_TRY(bfs_lanes_fence(s));   // a whole-device grid
   if (profile & 1) GRB_HIP_TRY(hipEventRecord(c.ev0, s));
   // The grid barrier needs every workgroup resident at once.  GRB_BFS_COOPERATIVE=1 asks the runtime to
   // guarantee that (hipLaunchCooperativeKernel fails fast when it cannot); the default launch relies on the
@@ -1406,25 +1533,52 @@ static grb_info bfs_persistent_launch(grb_vector v, grb_matrix A, grb_index sour
   if (force_fallback) return GRB_NOT_IMPLEMENTED;            // test hook: behave as if the launch had been refused
   if (cooperative) {
     void* kargs[] = {&a};
-    if (hipLaunchCooperativeKernel(reinterpret_cast<void*>(bfs_persistent_kernel), dim3(G), dim3(kPThreads), kargs, 0, s) !=
+    if (hipLaunchCooperativeKernel(reinterpret_cast<void*>(bfs_persistent_kernel), dim3(lc.G), dim3(kPThreads), kargs, 0, s) !=
         hipSuccess) {
       (void)hipGetLastError();
       return GRB_NOT_IMPLEMENTED;
     }
   } else {
-    hipLaunchKernelGGL(bfs_persistent_kernel, dim3(G), dim3(kPThreads), 0, s, a);
+    hipLaunchKernelGGL(bfs_persistent_kernel, dim3(lc.G), dim3(kPThreads), 0, s, a);
     GRB_HIP_TRY(hipGetLastError());
   }
   if (profile & 1) GRB_HIP_TRY(hipEventRecord(c.ev1, s));
-  // the next traversal (of this lane) runs on the other block and clears this one
-  *p_blocksel ^= 1;
-  if (lane_id == 0) {
-    c.bfs_prezero_ptr = p_zero;
-    c.bfs_prezero_bytes = zero_bytes;
-  } else {
-    ln.clean_bytes = zero_bytes;
-    GRB_HIP_TRY(hipEventRecord(ln.ev_done, s));             // what the library's stream waits for before it touches v
+  return bfs_persistent_queued(lc);
+}
+
+// k traversals (2 .. kCoMax) in ONE launch on the library's stream: bfs_co_kernel, traversal j on lane j's buffers.
+template <int T>
+static grb_info co_kernel_fits(int k) {
+  static int per_cu = -1;
+  if (per_cu < 0) {
+    int m = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&m, bfs_co_kernel<T>, T, 0) != hipSuccess) { (void)hipGetLastError(); m = 0; }
+    per_cu = m;
   }
+  return per_cu >= k ? GRB_SUCCESS : GRB_NOT_IMPLEMENTED;
+}
+static grb_info bfs_co_launch(int k, const CoPend* pend) {
+  Context& c = ctx();
+  if (k < 2 || k > kCoMax) return GRB_INVALID_VALUE;
+  static const bool force_fallback = [] { const char* e = getenv("GRB_BFS_FORCE_FALLBACK"); return e && atoi(e) != 0; }();
+  if (force_fallback) return GRB_NOT_IMPLEMENTED;
+  const bool wide = k <= 2;                                  // two traversals: 512-thread workgroups; three or four: 256
+  GRB_TRY(wide ? co_kernel_fits<512>(k) : co_kernel_fits<256>(k));
+  CoArgs ca;
+  memset(&ca, 0, sizeof(ca));
+  LaunchCtx lc[kCoMax];
+  for (int j = 0; j < k; ++j) {
+    void* p_rec = nullptr;
+    unsigned long long* trace = nullptr;
+    GRB_TRY(bfs_persistent_args(pend[j].v, pend[j].A, pend[j].source, pend[j].desc, 0, pend[j].slot, pend[j].seq, j, true, &ca.t[j],
+                                &lc[j], &p_rec, &trace));
+  }
+  GRB_TRY(bfs_lanes_fence(c.stream));
+  const int G = lc[0].G;
+  if (wide) hipLaunchKernelGGL(bfs_co_kernel<512>, dim3(k * G), dim3(512), 0, c.stream, ca, G);
+  else hipLaunchKernelGGL(bfs_co_kernel<256>, dim3(k * G), dim3(256), 0, c.stream, ca, G);
+  GRB_HIP_TRY(hipGetLastError());
+  for (int j = 0; j < k; ++j) GRB_TRY(bfs_persistent_queued(lc[j]));
   return GRB_SUCCESS;
 }
 
@@ -1514,6 +1668,22 @@ grb_info grb::bfs_persistent_enqueue(grb_vector v, grb_matrix A, grb_index sourc
   unsigned long long* trace = nullptr;
   const auto t0 = std::chrono::steady_clock::now();
   GRB_TRY(ring_init());
+  BfsTicket& t = g_ring.t[slot];
+  if (g_ring.co_width > 1 && g_ring.lanes == 1) {
+    // co-scheduling: the traversal gets its ticket now and its launch when co_width of them have gathered (or when
+    // somebody waits for one of them, or any other entry point is called: bfs_co_flush).  One launch serves one matrix
+    // and one set of descriptor fields.
+    if (g_ring.co_n > 0 && (g_ring.co[0].A != A || g_ring.co[0].desc != desc)) GRB_TRY(bfs_co_flush());
+    *seq = ++ctx().mail_seq;
+    CoPend& p = g_ring.co[g_ring.co_n++];
+    p.slot = slot; p.seq = *seq; p.v = v; p.A = A; p.source = source; p.desc = desc;
+    t.state = 3; t.seq = *seq; t.lane = 0; t.v = v; t.A = A; t.desc = desc; t.source = source;
+    grb_info fi = GRB_SUCCESS;
+    if (g_ring.co_n >= g_ring.co_width) fi = bfs_co_flush();
+    g_ring.enqueue_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+    ++g_ring.calls;
+    return fi;
+  }
   // lanes: the queued traversals go round the lanes, each lane's launches in order on its own stream
   // (lane 0 is the library's stream -- measured: with it as one of the lanes four launches overlap, with four created
   // streams only two or three do, whatever GPU_MAX_HW_QUEUES says)
@@ -1525,15 +1695,53 @@ grb_info grb::bfs_persistent_enqueue(grb_vector v, grb_matrix A, grb_index sourc
   GRB_TRY(li);
   g_ring.enqueue_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
   ++g_ring.calls;
-  BfsTicket& t = g_ring.t[slot];
   t.state = 1; t.seq = *seq; t.lane = lane; t.v = v; t.A = A; t.desc = desc; t.source = source;
   return GRB_SUCCESS;
+}
+// Launches what waits: all of it in one launch when there are two or more (512-thread workgroups for two, 256 for three
+// or four), a lone one as an ordinary traversal.  A launch that is refused leaves its tickets in state 4: grb_bfs_wait
+// runs those traversals itself.
+bool grb::bfs_co_pending() { return g_ring.co_n > 0; }
+grb_info grb::bfs_co_flush() {
+  const int k = g_ring.co_n;
+  if (k == 0) return GRB_SUCCESS;
+  CoPend pend[kCoMax];
+  for (int j = 0; j < k; ++j) pend[j] = g_ring.co[j];
+  g_ring.co_n = 0;
+  grb_info li = GRB_NOT_IMPLEMENTED;
+  if (k >= 2) li = bfs_co_launch(k, pend);
+  if (li == GRB_SUCCESS) {
+    for (int j = 0; j < k; ++j) g_ring.t[pend[j].slot].state = 1;
+    return GRB_SUCCESS;
+  }
+  grb_info worst = GRB_SUCCESS;
+  for (int j = 0; j < k; ++j) {                            // one by one (a lone traversal, or the group launch was refused)
+    void* p_rec = nullptr;
+    unsigned long long* trace = nullptr;
+    int seq = 0;
+    const grb_info si = bfs_persistent_launch(pend[j].v, pend[j].A, pend[j].source, pend[j].desc, 0, pend[j].slot, &seq, &p_rec, &trace, 0,
+                                              pend[j].seq);
+    g_ring.t[pend[j].slot].state = si == GRB_SUCCESS ? 1 : 4;
+    if (si != GRB_SUCCESS && si != GRB_NOT_IMPLEMENTED && si != GRB_PANIC) worst = si;
+  }
+  return worst;
+}
+// Traversals per launch (1 .. kCoMax).  Everything queued so far is launched and waited for first.  Returns the previous value.
+int grb::bfs_co_setting(int set) {
+  const int before = g_ring.co_width;
+  if (set >= 1 && set != before) {
+    (void)bfs_co_flush();
+    (void)hipDeviceSynchronize();
+    g_ring.co_width = set > kCoMax ? kCoMax : set;
+  }
+  return before;
 }
 // Traversals in flight at once (1 .. 8): n lanes of num_cu / n workgroups each.  Everything queued so far is waited for
 // first (a launch needs its whole grid resident: lanes of different widths must not meet).  Returns the previous value.
 int grb::bfs_lanes_setting(int set) {
   const int before = g_ring.lanes;
   if (set >= 1 && set != before) {
+    (void)bfs_co_flush();
     (void)hipDeviceSynchronize();
     int l = 1;
     while (2 * l <= set && 2 * l <= kMaxLanes) l *= 2;     // powers of two: a grid of num_cu / 3 workgroups measured 3 x slower per launch

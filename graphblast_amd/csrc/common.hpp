@@ -807,6 +807,11 @@ grb_info bfs_persistent_wait(int slot, int seq, int* levels, int* last_dir, long
                              Index* nf_left, bool* hit_cap, float* tight_ms);
 void bfs_host_times(double* enqueue_us, double* wait_us, long long* calls, bool reset);
 int bfs_lanes_setting(int set);                  // traversals in flight at once (grb_bfs_set_lanes); set < 1 only queries
+int bfs_co_setting(int set);                     // traversals per launch (grb_bfs_set_coschedule); set < 1 only queries
+bool bfs_co_pending();                           // traversals that have a ticket and no launch yet
+grb_info bfs_co_flush();                         // ... launched now (every entry point but the queue's own does this first)
+grb_info bfs_lanes_fence(hipStream_t s);         // s waits for what the lanes have in flight (before a whole-device grid)
+void bfs_lanes_unfence();                        // the lanes' next launches wait for the library's stream again
 grb_info k_spmv_masked_or(int dtype, const CsrArrays& M, const void* u, double identity,
                           const void* mask, int mask_f32, int scmp, int earlyexit, int opreuse,
                           const Index* hint /* per-row best neighbour, may be null */, void* w);

@@ -419,6 +419,9 @@ grb_info ApiScope::enter(bool queue_aware, bool counts) {
   if (depth == 0 && counts) ++epoch;
   grb_info r = GRB_SUCCESS;
   if (depth == 0 && !queue_aware && g_lazy.n > 0) r = lazy_flush();
+  // traversals that wait for a co-scheduled launch to fill: any entry point but the traversal queue's own launches them
+  // first (it may read their labels' vector, free their matrix, or need the device for itself)
+  if (depth == 0 && counts && !queue_aware && bfs_co_pending()) { const grb_info ci = bfs_co_flush(); if (r == GRB_SUCCESS) r = ci; }
   ++depth;
   entered_ = true;
   return r;

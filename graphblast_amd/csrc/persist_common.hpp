@@ -40,14 +40,16 @@ __device__ inline V fresh(const V* p) {
 // ---- grid barrier ---------------------------------------------------------------------
 // Monotonic counters: generation g of a group of m arrivers completes when its counter
 // reaches m * g.  Returns false when the barrier was abandoned (spin bound hit somewhere).
-__device__ inline bool grid_sync(GridBarrier* st, unsigned& gen, bool invalidate = true) {
+// (bid, G): the workgroup's number and the number of workgroups of the grid the barrier is for -- the launch's own
+// (grid_sync) or one of the sub-grids that share a launch (bfs_persist.hip: co-scheduled traversals, each with its own
+// GridBarrier; bid & 7 is still the XCD the workgroup runs on there)
+__device__ inline bool grid_sync_at(GridBarrier* st, unsigned& gen, const unsigned bid, const unsigned G, bool invalidate = true) {
   __shared__ int s_ok;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's write-through stores have landed
   __syncthreads();
   if (threadIdx.x == 0) {
     const unsigned g = gen + 1;
-    const unsigned G = gridDim.x;
-    const unsigned x = blockIdx.x & 7u;
+    const unsigned x = bid & 7u;
     const unsigned groups = G < 8u ? G : 8u;
     const unsigned members = (G - x + 7u) / 8u;
     const unsigned a = __hip_atomic_fetch_add(&st->xcd_count[x][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -71,6 +73,9 @@ __device__ inline bool grid_sync(GridBarrier* st, unsigned& gen, bool invalidate
   __syncthreads();
   ++gen;
   return s_ok != 0;
+}
+__device__ inline bool grid_sync(GridBarrier* st, unsigned& gen, bool invalidate = true) {
+  return grid_sync_at(st, gen, blockIdx.x, gridDim.x, invalidate);
 }
 
 // The set bits of a wave's 64 bitmap words, one per lane per step.  A thread that walks its own word bit by bit

@@ -338,6 +338,18 @@ grb_info grb_bfs_wait(grb_bfs_ticket ticket, grb_bfs_result* result);
  * blocking grb_bfs_fused keeps the whole device (and, issued while lanes are busy, waits for their grids to drain).
  * Changing the number waits for everything queued.  n < 1 only queries.  Returns the previous value. */
 int grb_bfs_set_lanes(int n);
+/* Traversals per LAUNCH (1 .. 4; default 1).  With k > 1 the traversals queued by grb_bfs_fused_enqueue are launched k at
+ * a time, side by side in one grid: k sub-grids of one workgroup per CU each (512 threads for two traversals, 256 for
+ * three or four), every traversal with its own state, barrier counters and record.  A traversal is barriers and
+ * dependent-load chains for half of its time; the CU's wave scheduler fills them with the other traversals' work, and
+ * -- unlike lanes -- nothing depends on how the runtime maps streams to hardware queues: it is one launch on the
+ * library's stream.  A ticket is issued at once; its launch goes out when k tickets of the same matrix and descriptor
+ * have gathered, when one of them is waited for, or when any other entry point is called (so the ordering rules of
+ * grb_bfs_fused_enqueue hold unchanged).  Per-traversal labels and result blocks are those of grb_bfs_fused.  Ignored
+ * while grb_bfs_set_lanes is above 1.  Changing the number launches and waits for everything queued.  k < 1 only
+ * queries.  Returns the previous value.  (No counterpart in the reference, whose loop is one traversal with several
+ * host round trips per level: algorithm/bfs.hpp:42-88.) */
+int grb_bfs_set_coschedule(int k);
 /* Host time (microseconds, summed since the last reset) inside the one-launch traversal's two halves -- queueing the
  * launches / waiting for and unpacking the record -- and the number of traversals; any pointer may be NULL. */
 grb_info grb_bfs_host_times(double* enqueue_us, double* wait_us, long long* calls, int reset);

@@ -313,6 +313,80 @@ def test_bfs_lanes(hb, graphs):
         g.bfs_set_lanes(before)
 
 
+def test_bfs_coscheduled(hb, graphs, capfd):
+    """grb_bfs_set_coschedule: the queued traversals are launched k at a time, side by side in ONE grid (k sub-grids of a
+    workgroup per CU each; 512-thread workgroups for two, 256 for three or four).  Labels and result blocks are those of
+    the blocking call and the oracle for every k, with groups that never fill (eleven traversals; a wait, a library call
+    or a blocking traversal launches what has gathered), waits in reverse order, every direction mode, a search cut by
+    max_niter, and library calls on the vectors before and after."""
+    from oracle import simple_reference as sr
+    g = hb.g
+    before = g.bfs_set_coschedule(-1)
+    assert before == 1
+    try:
+        for k in (2, 3, 4, 9, 1):
+            assert g.bfs_set_coschedule(k) in (1, 2, 3, 4)
+            assert g.bfs_set_coschedule(-1) == min(k, 4)
+            for name, gr in graphs[2:5]:
+                ptr, ind = gr["csr"]
+                A = build(hb, gr)
+                n = gr["n"]
+                srcs = [first_source(gr)] + g.graphgen.random_sources(ptr, 10, seed=7)
+                want = {s_: sr.bfs(ptr, ind, s_)[0] for s_ in srcs}
+                for mode, es, cap in ((0, 0.0, 0), (0, 0.05, 0), (2, 0.0, 0), (1, 0.0, 0), (0, 0.0, 2)):
+                    args = dict(mxvmode=mode, struconly=1, opreuse=1, edgeswitch=es)
+                    if cap:
+                        args["max_niter"] = cap
+                    d = hb.descriptor(**args)
+                    vs = [g.Vector(n) for _ in srcs]
+                    for v in vs:
+                        assert v.fill(7.0) == 0
+                    capfd.readouterr()
+                    tickets = [g.bfs_enqueue(v, A, s_, d) for v, s_ in zip(vs[:6], srcs[:6])]
+                    vb = g.Vector(n)
+                    ib, rb0 = g.bfs(vb, A, srcs[0], d, fused=True)     # a blocking traversal: what has gathered goes first
+                    assert ib == 0
+                    tickets += [g.bfs_enqueue(v, A, s_, d) for v, s_ in zip(vs[6:], srcs[6:])]
+                    assert all(i == 0 and t != 0 for i, t in tickets)
+                    order = list(range(len(srcs)))
+                    if mode == 2:
+                        order = order[::-1]                            # the last ticket first: its group has not filled
+                    res = {}
+                    for i in order:
+                        res[i] = g.bfs_wait(tickets[i][1])
+                    assert all(i == 0 for i, _ in res.values())
+                    err = capfd.readouterr().err
+                    assert "not published" not in err and "host-driven" not in err, err
+                    assert g.bfs_wait(tickets[0][1])[0] == 3           # a ticket waits once
+                    for i, s_ in enumerate(srcs):
+                        w = want[s_] if not cap else np.where(want[s_] <= cap, want[s_], 0)
+                        if not cap:
+                            info, cnt = g.reduce(None, "Plus", vs[i], hb.descriptor())
+                            assert info == 0 and cnt == float(w.astype(np.float64).sum()), (k, name, s_)
+                        assert np.array_equal(hb.dense_values(vs[i]), w), (k, name, s_, mode, es, cap)
+                        assert res[i][1]["reached"] == int(np.count_nonzero(w)), (k, name, s_, mode, es, cap)
+                        assert res[i][1]["edges_traversed"] == int(np.diff(ptr)[w != 0].sum())
+                    w0 = want[srcs[0]] if not cap else np.where(want[srcs[0]] <= cap, want[srcs[0]], 0)
+                    assert np.array_equal(hb.dense_values(vb), w0)
+            # two matrices in turn: a launch serves one matrix, the group of the first goes out when the second arrives
+            (na, ga), (nb, gb) = graphs[2], graphs[3]
+            Aa, Ab = build(hb, ga), build(hb, gb)
+            d = hb.descriptor(mxvmode=0, struconly=1, opreuse=1)
+            sa, sb = first_source(ga), first_source(gb)
+            va, vb2 = [g.Vector(ga["n"]) for _ in range(3)], [g.Vector(gb["n"]) for _ in range(3)]
+            tk = []
+            for i in range(3):
+                tk.append(g.bfs_enqueue(va[i], Aa, sa, d))
+                tk.append(g.bfs_enqueue(vb2[i], Ab, sb, d))
+            assert all(i == 0 for i, _ in tk)
+            assert all(g.bfs_wait(t)[0] == 0 for _, t in tk)
+            for i in range(3):
+                assert np.array_equal(hb.dense_values(va[i]), sr.bfs(*ga["csr"], sa)[0])
+                assert np.array_equal(hb.dense_values(vb2[i]), sr.bfs(*gb["csr"], sb)[0])
+    finally:
+        g.bfs_set_coschedule(before)
+
+
 def test_bfs_lanes_waited_for_in_reverse(hb, graphs, capfd):
     """250 traversals queued over two lanes and waited for LAST ticket first: the wait outlasts its spin phase (5 ms) and
     falls back to waiting for the stream -- the stream of the ticket's lane, not the library's (a wait on the wrong stream
