@@ -86,8 +86,10 @@ struct PersistState {               // zeroed by the host before every launch
   GridBarrier bar;
   unsigned big_count[2][32];
   unsigned long long acc[3][8][16]; // level totals, one line per (set, XCD group): found, deg, inspected, big
+  unsigned next_idx[32];            // launches of several traversals: the one this sub-grid runs next (written before the end barrier)
 };
 
+// What every traversal of a (sub-)grid shares: the matrix, the rules, the grid's buffers.
 struct PersistArgs {
   const Index *optr, *oind;         // out-edges (CSR), walked by push
   const Index *iptr, *iind;         // in-edges (CSC), walked by pull
@@ -98,19 +100,32 @@ struct PersistArgs {
   long long n_in;                   // vertices with at least one in-edge (the only ones a pull level can discover); < 0 unknown
   int out_is_in;                    // optr and iptr hold the same numbers (a structurally symmetric matrix): a row's
                                     // out-degree is the difference of the in-edge pointers a pull level already holds
-  Index source;
   int mode;
   float switchpoint, edgeswitch;
   int max_niter;
   int count_inspected;
-  float* label;
-  unsigned int* V[2];               // V[0] and every F are zeroed by the host with the state
-  // F[L] = bitmap of the vertices discovered by level L (F[0] = the source), kept for L < kKeep: labels are
-  // NOT written while traversing -- one coalesced pass at the end turns the kept bitmaps into the depth vector
-  // (a scattered 4-byte label store costs a 32-byte memory write: 131 MB per traversal of RMAT-22 against
-  // 17 MB of labels).  Levels >= kKeep (long-diameter graphs, tiny frontiers) rotate through three more
-  // buffers and label directly.
-  unsigned int* F[kKeep + 3];
+  // State blocks [state | V0 | F0 .. F(kKeep + 2)] are used in rotation by the traversals of this grid: a traversal runs on
+  // a clean one and clears -- spread over the whole grid, in front of its latency-bound first level -- one that an
+  // earlier traversal dirtied (rot[1 + block] = that one's level count: how much of the block it dirtied), so
+  // consecutive traversals need neither a memset nor a clean-up launch between them.
+  //   one traversal per launch (T = 1024): two blocks, the host alternates them (TravArgs::block / ::clean, at fixed
+  //     places of the kernarg segment: the kernel re-reads them where it needs them instead of holding registers);
+  //     plain stores clear, the launch boundary publishes them
+  //   several per launch: three blocks; traversal number t of the sub-grid (rot[0], kept on the device: which
+  //     sub-grid runs how many traversals of a launch is decided on the device) runs on block t % 3 and clears block
+  //     (t + 1) % 3, which traversal t - 2 used, with write-through stores (the next traversal may be in this very
+  //     launch and its readers on other XCDs).  Nobody can still be inside traversal t - 2 -- its barrier counters
+  //     live in that block -- when t begins: t - 1 had barriers of its own.
+  //   V0      visited bitmap, the one a traversal starts on (arrives zeroed); v1 is its pull levels' other buffer
+  //   F[L]    bitmap of the vertices discovered by level L (F[0] = the source), kept for L < kKeep: labels are
+  //           NOT written while traversing -- one coalesced pass at the end turns the kept bitmaps into the depth vector
+  //           (a scattered 4-byte label store costs a 32-byte memory write: 131 MB per traversal of RMAT-22 against
+  //           17 MB of labels).  Levels >= kKeep (long-diameter graphs, tiny frontiers) rotate through three more
+  //           buffers and label directly.
+  char* blocks;
+  unsigned long long block_bytes, st_bytes;
+  unsigned int* v1;
+  unsigned int* rot;                // device words: [0] traversals this grid has run, [1 + b] level count of block b's last one
   int2* big_list;
   int big_cap;
   // owner-computes push for heavy sparse frontiers (oc_off == nullptr: off).  The vertices are cut into oc_nb ranges
@@ -124,21 +139,19 @@ struct PersistArgs {
   const int* oc_bigidx;
   int oc_nb, oc_nrows;
   unsigned long long oc_min_edges;
-  PersistState* st;
   grb_bfs_level* rec;
   int rec_cap;
-  unsigned long long* mail;         // pinned host granules {value, seq}
-  int seq;
   float ticks_to_ms;
   unsigned long long* trace;        // optional (GRB_BFS_TRACE): wall-clock stamps of workgroup 0
-  // Two state blocks [state | V0 | F0 .. F(kKeep + 2)] alternate between consecutive traversals: a launch runs on the
-  // clean one and clears what its predecessor dirtied in the other (the predecessor's level count is in *dev_levels),
-  // so consecutive launches need neither a memset nor a clean-up launch between them -- grb_bfs_fused_enqueue queues
-  // traversals back to back.  The stores are spread over the whole grid in front of the first level, which is
-  // latency-bound.
-  unsigned int* dev_levels;         // in: the previous traversal's level count; out (last instruction): this one's
-  uint4* clean;                     // the other block
-  unsigned long long st_bytes;      // size of the state part of a block
+};
+// ... and what is a traversal's own
+struct TravArgs {
+  float* label;
+  unsigned long long* mail;         // pinned host granules {value, seq}: the traversal's record
+  char* block;                      // one traversal per launch (the host keeps the rotation): the block it runs on ...
+  char* clean;                      // ... and the one it clears
+  Index source;
+  int seq;
 };
 
 
@@ -152,8 +165,8 @@ __device__ inline int fbuf(int level) { return level < kKeep ? level : kKeep + (
 // (A = PersistArgs wherever it lives: the one-traversal kernel's by-value parameter, or one entry of the co-scheduled
 // kernel's argument table read through the kernarg segment pointer)
 template <typename A>
-__device__ inline void discovered(const A& a, Index v, float new_label, LevelCounters& c) {
-  if (new_label > 0.f) a.label[v] = new_label;
+__device__ inline void discovered(const A& a, float* label, Index v, float new_label, LevelCounters& c) {
+  if (new_label > 0.f) label[v] = new_label;
   const Index d = a.optr[v + 1] - a.optr[v];
   ++c.found;
   c.deg += (unsigned long long)d;
@@ -161,14 +174,14 @@ __device__ inline void discovered(const A& a, Index v, float new_label, LevelCou
 }
 
 template <typename A>
-__device__ inline void push_visit(const A& a, unsigned int* V, unsigned int* Fn, Index dst,
+__device__ inline void push_visit(const A& a, float* label, unsigned int* V, unsigned int* Fn, Index dst,
                                   float new_label, LevelCounters& c) {
   const unsigned int bit = 1u << (dst & 31);
   if (fresh(&V[dst >> 5]) & bit) return;
   const unsigned int old = atomicOr(&V[dst >> 5], bit);
   if (old & bit) return;
   atomicOr(&Fn[dst >> 5], bit);
-  discovered(a, dst, new_label, c);
+  discovered(a, label, dst, new_label, c);
 }
 
 // One traversal on a grid of G workgroups of T threads; `bid` is the workgroup's number inside that grid.  The
@@ -178,19 +191,29 @@ __device__ inline void push_visit(const A& a, unsigned int* V, unsigned int* Fn,
 // with the other's work.
 //
 // LDS: the pull levels' per-wave row queues and the owner-computes push's slice of the visited bitmap are never live
-// at the same time (a level is one or the other), so they share their bytes; at T = 256 four workgroups fit a CU.
+// at the same time (a level is one or the other), so they share their bytes; at T = 256 four workgroups fit a CU, at
+// T = 128 (a narrower slice of the bitmap per range) eight.
 template <int T>
 struct PersistLds {
   static constexpr int W = T / kWave;
-  struct OcView { int2 row[W][kWave]; unsigned int ocw[kOcWords]; };
+  static constexpr int kOcW = T >= 256 ? kOcWords : kOcWords / 4;  // (eight workgroups per CU share its LDS: tables cut narrower)
+  struct OcView { int2 row[W][kWave]; unsigned int ocw[kOcW]; };
   union U { PullLds pull[W]; OcView oc; };
 };
 
-template <int T, typename AP>
-__device__ __forceinline__ void bfs_persistent_body(AP ap, const int bid, const int G) {
+// Returns the number (in the launch's table) of the traversal this grid runs next -- >= the table's size: none -- or -1
+// when a barrier gave up.  trot = how many traversals the grid has run before this one (PersistArgs::rot).  chained:
+// the launch carries more traversals than grids; a grid that finishes one draws the next from a counter (*ctr, which
+// stood at ctr_base when the launch began; the first n_grids traversals are dealt statically), so that a launch ends
+// when the work does, not when the grid with the longest traversals does.
+template <int T, typename AP, typename TP>
+__device__ __forceinline__ int bfs_persistent_body(AP ap, TP tp, const int bid, const int G, const unsigned trot, const bool chained,
+                                                   unsigned int* ctr, const unsigned ctr_base, const int n_grids) {
   const auto& a = *ap;
+#define label (tp->label)
+#define source (tp->source)
   constexpr int W = T / kWave;
-  constexpr int kMed = T >= 512 ? 4 * T : 512;                     // LDS list of medium vertices per workgroup pass
+  constexpr int kMed = T >= 512 ? 4 * T : T >= 256 ? 512 : 256;                     // LDS list of medium vertices per workgroup pass
   __shared__ unsigned long long s_red[W][4];
   __shared__ unsigned long long s_tot[4];
 #if GRB_BFS_PULL_DYN
@@ -221,30 +244,44 @@ __device__ __forceinline__ void bfs_persistent_body(AP ap, const int bid, const 
   const long long gthreads = (long long)G * T;
   const Index n = a.n;
   const int nwords = 2 * ((n + 63) / 64);
-  PersistState* st = a.st;
+  constexpr bool kHostRot = T == kPThreads;                        // one traversal per launch: the host keeps the rotation
+  const unsigned blk = kHostRot ? 0u : trot % 3u;
+  char* const pblock = kHostRot ? tp->block : a.blocks + (unsigned long long)blk * a.block_bytes;
+  PersistState* st = reinterpret_cast<PersistState*>(pblock);
+  unsigned int* const V0 = reinterpret_cast<unsigned int*>(pblock + a.st_bytes);
+  auto Vp = [&](int which) -> unsigned int* { return which ? a.v1 : V0; };
+  auto Fp = [&](int level) -> unsigned int* { return V0 + (size_t)(1 + fbuf(level)) * (size_t)nwords; };
   unsigned gen = 0;
   const unsigned long long t_start = wall_clock64();
   int ntrace = 0;
   auto stamp = [&]() { if (a.trace && gtid == 0 && ntrace < 255) a.trace[1 + ntrace++] = wall_clock64() - t_start; };
 
-  // ---- the other state block: what the previous traversal dirtied there (its state, V0, the level bitmaps it wrote;
-  // every buffer when it went past the kept levels)
-  {
-    const unsigned int lv = *a.dev_levels;
+  // ---- the block a later traversal will run on: what an earlier one dirtied there (its state, V0, the level bitmaps it
+  // wrote; every buffer when it went past the kept levels)
+  if constexpr (kHostRot) {
+    const unsigned int lv = *a.rot;
     const unsigned int used = lv + 2u >= (unsigned int)kKeep ? (unsigned int)kKeep + 3u : lv + 2u;
     const long long n16 = (long long)((a.st_bytes + 4ull * (1ull + used) * (unsigned long long)nwords + 15ull) / 16ull);
     const uint4 z = make_uint4(0u, 0u, 0u, 0u);
-    for (long long i = gtid; i < n16; i += gthreads) a.clean[i] = z;
+    uint4* clean = reinterpret_cast<uint4*>(tp->clean);
+    for (long long i = gtid; i < n16; i += gthreads) clean[i] = z;
+  } else {
+    const unsigned nb = (trot + 1u) % 3u;
+    const unsigned int lv = fresh(&a.rot[1 + nb]);
+    const unsigned int used = lv + 2u >= (unsigned int)kKeep ? (unsigned int)kKeep + 3u : lv + 2u;
+    const long long n8 = (long long)((a.st_bytes + 4ull * (1ull + used) * (unsigned long long)nwords + 7ull) / 8ull);
+    unsigned long long* clean = reinterpret_cast<unsigned long long*>(a.blocks + (unsigned long long)nb * a.block_bytes);
+    for (long long i = gtid; i < n8; i += gthreads) publish(&clean[i], 0ull);
   }
 
   // ---- the source.  The bitmaps arrive zeroed; unreached labels are written at the very end,
   // so the first level starts without a barrier (unless it is a pull, which must see the bit).
-  const Index src_deg = a.optr[a.source + 1] - a.optr[a.source];
+  const Index src_deg = a.optr[source + 1] - a.optr[source];
   if (gtid == 0) {
-    atomicOr(&a.V[0][a.source >> 5], 1u << (a.source & 31));
-    atomicOr(&a.F[0][a.source >> 5], 1u << (a.source & 31));
+    atomicOr(&V0[source >> 5], 1u << (source & 31));
+    atomicOr(&Fp(0)[source >> 5], 1u << (source & 31));
   }
-  if (a.mode == GRB_PULLONLY && !grid_sync_at(&st->bar, gen, bid, G, false)) return;
+  if (a.mode == GRB_PULLONLY && !grid_sync_at(&st->bar, gen, bid, G, false)) return -1;
 
   // ---- level loop (all scalars below are identical in every workgroup)
   Index nf = 1;
@@ -271,15 +308,15 @@ __device__ __forceinline__ void bfs_persistent_body(AP ap, const int bid, const 
     } else {
       f1_dense = (a.mode == GRB_PULLONLY);
     }
-    const unsigned int* Fc = a.F[fbuf(iter - 1)];
-    unsigned int* Fn = a.F[fbuf(iter)];
+    const unsigned int* Fc = Fp(iter - 1);
+    unsigned int* Fn = Fp(iter);
     const bool direct = iter >= kKeep;                    // this level's bitmap will be recycled: label now
     const float new_label = direct ? (float)(iter + 1) : 0.f;
     LevelCounters c;
     // recycle: the frontier buffer of two levels ahead, the entry counter and the totals of
     // the next level (nobody touches them during this one)
     if (iter + 1 >= kKeep + 3)                            // a rotating buffer about to be reused
-      for (long long i = gtid; i < nwords; i += gthreads) publish(&a.F[fbuf(iter + 1)][i], 0u);
+      for (long long i = gtid; i < nwords; i += gthreads) publish(&Fp(iter + 1)[i], 0u);
     if (gtid == 0) publish(&st->big_count[(iter + 1) & 1][0], 0u);
     if (bid == 0 && tid < 32) publish(&st->acc[(iter + 1) % 3][tid >> 2][tid & 3], 0ull);
     // A push level whose frontier carries many edges through few vertices runs at the rate of racing global
@@ -290,14 +327,14 @@ __device__ __forceinline__ void bfs_persistent_body(AP ap, const int bid, const 
     if (!f1_dense) {
       // ================= push =================
       GRB_PHASE_START();
-      unsigned int* V = a.V[cur];
+      unsigned int* V = Vp(cur);
       if (iter == 1) {
         // the frontier is the source alone: its edges spread over the whole grid
-        const Index e = a.optr[a.source + 1];
-        for (long long p = a.optr[a.source] + gtid; p < e; p += gthreads) {
+        const Index e = a.optr[source + 1];
+        for (long long p = a.optr[source] + gtid; p < e; p += gthreads) {
           const Index dst = a.oind[p];
-          if (dst == a.source) continue;
-          push_visit(a, V, Fn, dst, new_label, c);
+          if (dst == source) continue;
+          push_visit(a, label, V, Fn, dst, new_label, c);
         }
       } else {
         unsigned* bcount = &st->big_count[iter & 1][0];
@@ -333,7 +370,7 @@ __device__ __forceinline__ void bfs_persistent_body(AP ap, const int bid, const 
               const int slot = atomicAdd(&s_nmed, 1);
               if (slot < kMed) { s_med[slot] = v; continue; }
             }
-            for (Index p = s; p < e; ++p) push_visit(a, V, Fn, a.oind[p], new_label, c);
+            for (Index p = s; p < e; ++p) push_visit(a, label, V, Fn, a.oind[p], new_label, c);
           }
           if (do_list) {
             int incl = mine;
@@ -379,7 +416,7 @@ incl = (int)wave_incl_scan_u32((unsigned)incl);
           for (int k = wave; k < nm; k += W) {
             const Index v = s_med[k];
             const Index e = a.optr[v + 1];
-            for (Index p = a.optr[v] + lane; p < e; p += kWave) push_visit(a, V, Fn, a.oind[p], new_label, c);
+            for (Index p = a.optr[v] + lane; p < e; p += kWave) push_visit(a, label, V, Fn, a.oind[p], new_label, c);
           }
           __syncthreads();
           if (tid == 0) s_nmed = 0;
@@ -389,7 +426,7 @@ incl = (int)wave_incl_scan_u32((unsigned)incl);
         if (heavy) scan(true, false); else scan(nbig > 0, true);
         if (nbig > 0) {
           stamp();
-          if (!grid_sync_at(&st->bar, gen, bid, G, false)) return;
+          if (!grid_sync_at(&st->bar, gen, bid, G, false)) return -1;
           stamp();
           int nent = (int)__hip_atomic_load(bcount, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           if (nent > a.big_cap) nent = a.big_cap;
@@ -401,7 +438,7 @@ incl = (int)wave_incl_scan_u32((unsigned)incl);
 #pragma unroll
               for (int t = 0; t < kBigChunk / T; ++t) {
                 const Index p = a.optr[ent.x] + ent.y * kBigChunk + t * T + tid;
-                if (p < pe) push_visit(a, V, Fn, a.oind[p], new_label, c);
+                if (p < pe) push_visit(a, label, V, Fn, a.oind[p], new_label, c);
               }
             }
           } else {
@@ -468,7 +505,7 @@ inc = (Index)wave_incl_scan_u32((unsigned)inc);
                 if (newb) {
                   atomicOr(&Fn[w0 + i], newb);
                   for (; newb; newb &= newb - 1)
-                    discovered(a, (Index)((w0 + i) * 32) + (__ffs((int)newb) - 1), new_label, c);
+                    discovered(a, label, (Index)((w0 + i) * 32) + (__ffs((int)newb) - 1), new_label, c);
                 }
               }
             }
@@ -484,8 +521,8 @@ inc = (Index)wave_incl_scan_u32((unsigned)inc);
       // The barriers of this kernel do not invalidate; push levels read other workgroups' words
       // with fresh().  A pull level probes the visited bitmap millions of times, which is
       // faster through L1 with ordinary loads, so it pays the invalidate itself, once.
-      const unsigned int* vin = a.V[cur];
-      unsigned int* vout = a.V[cur ^ 1];
+      const unsigned int* vin = Vp(cur);
+      unsigned int* vout = Vp(cur ^ 1);
       const Index* hint = a.count_inspected ? nullptr : a.hint;
       const Index nchunks = (n + kWave - 1) / kWave;
       const Index nblocks = (nchunks + kPullBlock - 1) / kPullBlock;
@@ -551,7 +588,7 @@ inc = (Index)wave_incl_scan_u32((unsigned)inc);
               ++c.found;
               c.deg += (unsigned long long)d;
               if (d >= kBigDeg) ++c.big;
-              if (direct) a.label[v] = new_label;
+              if (direct) label[v] = new_label;
             }
           });
           __builtin_amdgcn_wave_barrier();
@@ -662,7 +699,7 @@ incl = (int)wave_incl_scan_u32((unsigned)incl);
                 ++c.found;
                 c.deg += (unsigned long long)d;
                 if (d >= kBigDeg) ++c.big;
-                if (direct) a.label[vbase + kWave * j] = new_label;
+                if (direct) label[vbase + kWave * j] = new_label;
               }
           } else {
             Index d0[kPullBlock], d1[kPullBlock];
@@ -672,7 +709,7 @@ incl = (int)wave_incl_scan_u32((unsigned)incl);
               const Index vj = f ? vbase + kWave * j : 0;
               d0[j] = a.optr[vj];
               d1[j] = a.optr[vj + 1];
-              if (f && direct) a.label[vj] = new_label;
+              if (f && direct) label[vj] = new_label;
             }
 #pragma unroll
             for (int j = 0; j < kPullBlock; ++j)
@@ -741,7 +778,7 @@ incl = (int)wave_incl_scan_u32((unsigned)incl);
       ++gen;
     }
 #else
-    if (!grid_sync_at(&st->bar, gen, bid, G, false)) return;
+    if (!grid_sync_at(&st->bar, gen, bid, G, false)) return -1;
 #endif
     stamp();
     if (wave == 0) {
@@ -782,9 +819,9 @@ incl = (int)wave_incl_scan_u32((unsigned)incl);
     // One bitmap word (32 vertices) per lane: the visited word and the word of every kept level go out together
     // (agent-scope loads: no invalidate to wait for), so the pass is one memory latency deep; a lane then writes its
     // 32 labels as eight 16-byte stores (a whole 128-byte line per lane).
-    const unsigned int* Vf = a.V[cur];
+    const unsigned int* Vf = Vp(cur);
     const int kept = levels + 1 < kKeep ? levels + 1 : kKeep;      // F[0 .. kept)
-    const bool label_aligned = (reinterpret_cast<unsigned long long>(a.label) & 15ull) == 0ull;
+    const bool label_aligned = (reinterpret_cast<unsigned long long>(label) & 15ull) == 0ull;
 #if GRB_BFS_LABEL_COAL
     // 32 words per wave step (every wave of the grid has one at n = 4 Mi); a word's six planes are computed by the
     // lane that loaded it and handed to the eight lanes that store its labels: a store instruction then writes
@@ -800,7 +837,7 @@ incl = (int)wave_incl_scan_u32((unsigned)incl);
       for (int L0 = 0; L0 < kKeep; L0 += 8) {
         if (L0 < kept) {
 #pragma unroll
-          for (int u = 0; u < 8; ++u) f[L0 + u] = (L0 + u < kept && have) ? fresh(&a.F[L0 + u][wi]) : 0u;
+          for (int u = 0; u < 8; ++u) f[L0 + u] = (L0 + u < kept && have) ? fresh(&Fp(L0 + u)[wi]) : 0u;
         } else {
 #pragma unroll
           for (int u = 0; u < 8; ++u) f[L0 + u] = 0u;
@@ -816,7 +853,7 @@ incl = (int)wave_incl_scan_u32((unsigned)incl);
       const unsigned int keepm = vis & ~(pl[0] | pl[1] | pl[2] | pl[3] | pl[4] | pl[5]);
       const bool whole = label_aligned && (wb + 32) * 32 <= (long long)n && __ballot(keepm != 0u) == 0ull;
       if (whole) {
-        LabelQuad* out = reinterpret_cast<LabelQuad*>(a.label + wb * 32) + lane;
+        LabelQuad* out = reinterpret_cast<LabelQuad*>(label + wb * 32) + lane;
         const int b0 = (lane & 7) * 4;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -838,7 +875,7 @@ incl = (int)wave_incl_scan_u32((unsigned)incl);
           unsigned int lab = 0u;
 #pragma unroll
           for (int k = 0; k < 6; ++k) lab |= ((pl[k] >> b) & 1u) << k;
-          if (!((keepm >> b) & 1u)) a.label[v0 + b] = (float)lab;
+          if (!((keepm >> b) & 1u)) label[v0 + b] = (float)lab;
         }
       }
     }
@@ -851,7 +888,7 @@ incl = (int)wave_incl_scan_u32((unsigned)incl);
       for (int L0 = 0; L0 < kKeep; L0 += 8) {
         if (L0 < kept) {
 #pragma unroll
-          for (int u = 0; u < 8; ++u) f[L0 + u] = L0 + u < kept ? fresh(&a.F[L0 + u][wi]) : 0u;
+          for (int u = 0; u < 8; ++u) f[L0 + u] = L0 + u < kept ? fresh(&Fp(L0 + u)[wi]) : 0u;
         } else {
 #pragma unroll
           for (int u = 0; u < 8; ++u) f[L0 + u] = 0u;
@@ -869,7 +906,7 @@ incl = (int)wave_incl_scan_u32((unsigned)incl);
       // a vertex that is visited but in no kept bitmap was labelled by a level >= kKeep: its label stays
       const unsigned int keepm = vis & ~(pl[0] | pl[1] | pl[2] | pl[3] | pl[4] | pl[5]);
       if (v0 + 32 <= (long long)n && keepm == 0u && label_aligned) {
-        float4* out = reinterpret_cast<float4*>(a.label + v0);
+        float4* out = reinterpret_cast<float4*>(label + v0);
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
           float x[4];
@@ -888,7 +925,7 @@ incl = (int)wave_incl_scan_u32((unsigned)incl);
           unsigned int lab = 0u;
 #pragma unroll
           for (int k = 0; k < 6; ++k) lab |= ((pl[k] >> b) & 1u) << k;
-          if (!((keepm >> b) & 1u)) a.label[v0 + b] = (float)lab;
+          if (!((keepm >> b) & 1u)) label[v0 + b] = (float)lab;
         }
       }
     }
@@ -896,45 +933,79 @@ incl = (int)wave_incl_scan_u32((unsigned)incl);
 #endif
   stamp();
   if (a.trace && gtid == 0) a.trace[0] = (unsigned long long)ntrace;
+  // ---- the end: this block's level count for whoever clears it, the next traversal's number, the record.  In a chained
+  // launch a barrier comes first -- the next traversal clears a block and must find nobody in this one's bitmaps -- and
+  // the record is written behind it: every workgroup's label stores have completed by then.
+  int next = 0x7fffffff;
+  if (gtid == 0) publish(&a.rot[kHostRot ? 0 : 1 + blk], (unsigned int)levels);
+  if (chained) {
+    if (gtid == 0) publish(&st->next_idx[0], (unsigned)n_grids + (atomicAdd(ctr, 1u) - ctr_base));
+    if (!grid_sync_at(&st->bar, gen, bid, G, false)) return -1;
+    next = (int)fresh(&st->next_idx[0]);
+  }
   if (gtid == 0) {
-    publish(a.dev_levels, (unsigned int)levels);
-    const unsigned long long tag = (unsigned long long)(unsigned int)a.seq << 32;
+    const unsigned long long tag = (unsigned long long)(unsigned int)tp->seq << 32;
     const float ms = (float)(wall_clock64() - t_start) * a.ticks_to_ms;
     const unsigned int vals[8] = {(unsigned int)levels, (unsigned int)last_dir, (unsigned int)reached,
                                   (unsigned int)(edges_cum & 0xffffffffull), (unsigned int)(edges_cum >> 32),
                                   (unsigned int)nf, (unsigned int)(iter > a.max_niter ? 1 : 0),
                                   __float_as_uint(ms)};
+    unsigned long long* mail = tp->mail;
 #pragma unroll
     for (int k = 0; k < 8; ++k)
-      __hip_atomic_store(&a.mail[k], tag | vals[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(&mail[k], tag | vals[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
+  return next;
+#undef label
+#undef source
 }
 
-typedef const __attribute__((address_space(4))) PersistArgs* KernArgsPtr;
-__global__ __launch_bounds__(kPThreads) void bfs_persistent_kernel(PersistArgs a) {
-  bfs_persistent_body<kPThreads>((KernArgsPtr)__builtin_amdgcn_kernarg_segment_ptr(), (int)blockIdx.x, (int)gridDim.x);
-}
-
-// ---- several traversals in ONE launch ------------------------------------------------------------------------------
+// ---- the launch: one grid per traversal in flight, several traversals per grid ---------------------------------------
 // A traversal is barriers and dependent-load chains for half of its time (about 50 of 105 us move no
-// bytes), and none of that gets shorter with more CUs.  Here k queued traversals (2 .. 1024 / T) run side by side: the
-// launch is k sub-grids of G = CUs workgroups of T = 512 or 256 threads, workgroup b of the launch is workgroup b % G
-// of traversal b / G (so a traversal's workgroup keeps the XCD its number implies, and -- the dispatcher placing
-// workgroups in order -- a CU holds one workgroup of each traversal).  Every traversal has the whole device's CUs, L1s
-// and LDS bandwidth; its barriers, totals and latency chains are filled with the other traversals' waves by the
-// hardware scheduler.  Nothing depends on how the runtime maps streams to hardware queues (grb_bfs_set_lanes does).
-// The traversals are independent: private state blocks, bitmaps, lists, barrier counters and records (a lane's worth
-// each, BfsLane below); the argument blocks sit one after the other in the kernarg segment and a workgroup reads its
-// own through the segment pointer (scalar loads from constant memory, exactly what the one-traversal kernel's
-// by-value parameter compiles to -- a by-value table indexed at run time would be copied to scratch).
-constexpr int kCoMax = 4;
-struct CoArgs { PersistArgs t[kCoMax]; };
+// bytes), and none of that gets shorter with more CUs.  A launch therefore carries up to kCoTrain queued traversals
+// and runs n_grids of them (1 .. kCoMax) side by side: the launch is n_grids sub-grids of G = CUs workgroups of
+// T = 1024 / 512 / 256 threads, workgroup b of the launch is workgroup b % G of sub-grid b / G (so a workgroup keeps the
+// XCD its number implies, and -- the dispatcher placing workgroups in order -- a CU holds one workgroup of every
+// sub-grid).  Every traversal has the whole device's CUs, L1s and LDS bandwidth; its barriers, totals and latency
+// chains are filled with the other traversals' waves by the hardware scheduler, and nothing depends on how the runtime
+// maps streams to hardware queues (grb_bfs_set_lanes does).  The sub-grids are independent: private state blocks,
+// bitmaps, lists, barrier counters (a lane's worth each, BfsLane below); a sub-grid that finishes a traversal draws
+// the next one from the launch's counter.  The argument blocks sit in the kernarg segment and a workgroup reads its own
+// through the segment pointer (scalar loads from constant memory, what a by-value parameter compiles to when it is
+// not indexed at run time -- a by-value table that is would be copied to scratch).
+constexpr int kCoMax = 8;
+constexpr int kCoTrain = 48;
+struct LaunchArgs {
+  PersistArgs g[kCoMax];
+  TravArgs t[kCoTrain];
+  unsigned int* ctr;                // the launch's counter (monotonic over launches; ctr_base: where it stood)
+  unsigned ctr_base;
+  int ntrav, n_grids, G;
+};
+static_assert(sizeof(LaunchArgs) <= 4096, "the kernarg segment holds 4 KiB");
+typedef const __attribute__((address_space(4))) LaunchArgs* LaunchArgsPtr;
 template <int T>
-__global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void bfs_co_kernel(CoArgs ca, int G) {
+__global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void bfs_persistent_kernel(LaunchArgs la_) {
+  const LaunchArgsPtr la = (LaunchArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
+  if constexpr (T == kPThreads) {
+    // one traversal on the launch's whole grid: every argument at a fixed place of the segment
+    (void)bfs_persistent_body<T>(&la->g[0], &la->t[0], (int)blockIdx.x, (int)gridDim.x, 0u, false, nullptr, 0u, 1);
+    return;
+  }
+  const int G = la->G;
   const int j = (int)blockIdx.x / G;
   const int bid = (int)blockIdx.x - j * G;
-  const KernArgsPtr base = (KernArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
-  bfs_persistent_body<T>(base + j, bid, G);
+  const auto* g = &la->g[j];
+  const int ntrav = la->ntrav;
+  const bool chained = ntrav > la->n_grids;
+  unsigned trot = fresh(&g->rot[0]);                     // (nobody writes it before the launch's last traversal of this grid ends)
+  int idx = j;
+  while (idx < ntrav) {
+    idx = bfs_persistent_body<T>(g, &la->t[idx], bid, G, trot, chained, la->ctr, la->ctr_base, la->n_grids);
+    if (idx < 0) return;
+    ++trot;
+  }
+  if (bid == 0 && threadIdx.x == 0) publish(&g->rot[0], trot);
 }
 
 // which rows are big (>= kBigDeg entries), their numbers and their list, on the device (round 5: the host walked its
@@ -1061,7 +1132,7 @@ using namespace grb;
 // row enters each range ([nb + 1][nbig]).  Leaves *d_off null when there is nothing to gain (no big rows, a table
 // beyond 64 M entries).  Also used by the partitioned traversal (bfs_part_run.hip) for a rank's out-edge shard.
 grb_info grb::oc_tables_build(const Index* d_ptr, const Index* d_ind, const std::vector<Index>& optr, Index nrows, Index ncols, int G,
-                              Index** d_bounds, Index** d_off, int** d_bigidx, int* nb, int* nbig) {
+                              Index** d_bounds, Index** d_off, int** d_bigidx, int* nb, int* nbig, int max_words) {
   hipStream_t s = ctx().stream;
   *d_bounds = nullptr; *d_off = nullptr; *d_bigidx = nullptr; *nb = 0; *nbig = 0;
   const Index n = ncols;
@@ -1115,7 +1186,7 @@ grb_info grb::oc_tables_build(const Index* d_ptr, const Index* d_ind, const std:
   for (int attempt = 0; attempt < 64; ++attempt) {
     bounds.assign(1, 0);
     static const int cap_env = getenv("GRB_BFS_OC_WIDTH") ? atoi(getenv("GRB_BFS_OC_WIDTH")) : 0;   // vertices per range at most
-    int max_bins = kOcWords * 32 / kOcBin;                 // a range's slice of the visited bitmap fits the LDS buffer
+    int max_bins = max_words * 32 / kOcBin;                // a range's slice of the visited bitmap fits the LDS buffer
     if (cap_env >= kOcBin && cap_env / kOcBin < max_bins) max_bins = cap_env / kOcBin;
     long long acc = 0;
     int first = 0;
@@ -1180,8 +1251,8 @@ struct BfsLane {
   void *zero = nullptr, *v1 = nullptr, *big = nullptr, *rec = nullptr;
   size_t zero_cap = 0, v1_cap = 0, big_cap = 0, rec_cap = 0;
   size_t clean_bytes = 0;                        // zero_bytes the blocks were last cleared for (0: not clean)
-  unsigned int* d_levels = nullptr;
-  int block = 0;
+  unsigned int* d_rot = nullptr;                  // PersistArgs::rot
+  int block = 0;                                  // one traversal per launch: which of the two blocks the next one runs on
   unsigned long long fenced_epoch = ~0ull;       // ApiScope::epoch when this lane last fenced against the library's stream
 };
 struct CoPend {                                  // a traversal that has its ticket and waits for company (co-scheduling)
@@ -1194,14 +1265,18 @@ struct CoPend {                                  // a traversal that has its tic
 struct BfsRing {
   int co_width = 1;                              // traversals per launch (grb_bfs_set_coschedule); 1: every traversal its own launch
   int co_n = 0;                                  // ... and the ones that wait for the launch to fill (ticket state 3)
-  CoPend co[kCoMax];
-  BfsLane lane[kMaxLanes + 1];                   // [0]: the library's stream (blocking calls, one lane); [1 ..]: the lanes proper
+  CoPend co[kCoTrain];
+  BfsLane lane[kMaxLanes + 1 + kCoMax];          // [0]: the library's stream (blocking calls, one lane); [1 ..]: the lanes proper;
+                                                 // [kMaxLanes + 1 ..]: the sub-grids of the launches of several traversals
   int lanes = 1, next_lane = 0;
   bool lanes_active = false;                     // the launch being queued is one of several in flight (set around enqueue)
   unsigned long long* h = nullptr;               // pinned, host-coherent: kRing x 8 granules {value, seq}
   unsigned long long* d = nullptr;               // the device-side address of h
-  unsigned int* d_levels = nullptr;              // device word: the last traversal's level count (PersistArgs::dev_levels)
-  int block = 0;                                 // which of the two state blocks the next traversal runs on
+  unsigned int* d_rot = nullptr;                 // PersistArgs::rot of lane 0 (the library's scratch slots)
+  int block = 0;                                 // ... and which of its two blocks the next traversal runs on
+  unsigned int* d_ctr = nullptr;                 // LaunchArgs::ctr: the chained launches' counter, and where it stands
+  unsigned ctr_base = 0;
+  bool ctr_dirty = false;                        // a chained launch did not finish: the counter is anywhere
   BfsTicket t[kRing];
   int next = 0;
   int poisoned_upto = 0;                         // records with seq <= this were queued behind a traversal that failed
@@ -1216,8 +1291,9 @@ grb_info ring_init() {
   GRB_HIP_TRY(hipHostMalloc((void**)&r.h, sizeof(unsigned long long) * 8 * kRing, hipHostMallocMapped | hipHostMallocCoherent));
   memset(r.h, 0, sizeof(unsigned long long) * 8 * kRing);
   GRB_HIP_TRY(hipHostGetDevicePointer((void**)&r.d, r.h, 0));
-  GRB_HIP_TRY(hipMalloc((void**)&r.d_levels, 256));
-  GRB_HIP_TRY(hipMemset(r.d_levels, 0, 256));
+  GRB_HIP_TRY(hipMalloc((void**)&r.d_rot, 512));
+  GRB_HIP_TRY(hipMemset(r.d_rot, 0, 512));
+  r.d_ctr = r.d_rot + 64;
   return GRB_SUCCESS;
 }
 // the record in slot `slot` once it carries tag `seq`: spins, then (after 5 ms) waits for the stream the traversal was
@@ -1261,25 +1337,24 @@ static grb_info lane_buffer(void** p, size_t* cap, size_t bytes, hipStream_t s) 
 // What a launch needs besides its argument block: whose buffers it runs on and what to note once it is queued.
 struct LaunchCtx {
   int lane_id = 0;
-  bool co = false;               // one of several traversals of ONE launch on the library's stream (lane_id = its number there)
+  bool co = false;               // one of the sub-grids of ONE launch on the library's stream (lane_id = its number there)
   hipStream_t s = nullptr;
   int G = 0;
   void* p_zero = nullptr;
-  size_t zero_bytes = 0;
-  int* p_blocksel = nullptr;
+  size_t zero_bytes = 0, block_bytes = 0;
+  int* p_blocksel = nullptr;     // one traversal per launch: the host's side of the rotation
 };
 
-// Fills the argument block of one traversal: the lane's buffers (lane 0: the library's scratch slots), the once-per-
-// matrix facts and tables, the record slot.  seq_in = 0 draws a new tag.  Queues at most memsets on lc->s.
-static grb_info bfs_persistent_args(grb_vector v, grb_matrix A, grb_index source, grb_descriptor desc, int profile, int slot,
-                                    int seq_in, int lane_id, bool co, PersistArgs* out, LaunchCtx* lc, void** p_rec_out,
-                                    unsigned long long** trace_out) {
+// Fills the argument block of one (sub-)grid: the lane's buffers (lane 0: the library's scratch slots), the once-per-
+// matrix facts and tables.  Queues at most memsets on lc->s.
+static grb_info bfs_persistent_args(grb_matrix A, grb_descriptor desc, int profile, int lane_id, bool co, PersistArgs* out,
+                                    LaunchCtx* lc, void** p_rec_out, unsigned long long** trace_out, int oc_words = kOcWords) {
   GRB_TRY(ring_init());
   Context& c = ctx();
   BfsLane& ln = g_ring.lane[lane_id];
-  if (lane_id > 0 && !ln.d_levels) {
-    GRB_HIP_TRY(hipMalloc((void**)&ln.d_levels, 256));
-    GRB_HIP_TRY(hipMemset(ln.d_levels, 0, 256));
+  if (lane_id > 0 && !ln.d_rot) {
+    GRB_HIP_TRY(hipMalloc((void**)&ln.d_rot, 256));
+    GRB_HIP_TRY(hipMemset(ln.d_rot, 0, 256));
   }
   if (lane_id > 0 && !co && !ln.stream) {
     GRB_HIP_TRY(hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking));
@@ -1287,30 +1362,30 @@ static grb_info bfs_persistent_args(grb_vector v, grb_matrix A, grb_index source
     GRB_HIP_TRY(hipEventCreateWithFlags(&ln.ev_done, hipEventDisableTiming));
   }
   hipStream_t s = (lane_id > 0 && !co) ? ln.stream : c.stream;
-  unsigned int* d_levels = lane_id > 0 ? ln.d_levels : g_ring.d_levels;
+  unsigned int* d_rot = lane_id > 0 ? ln.d_rot : g_ring.d_rot;
   const Index n = A->nrows;
   const int nwords = 2 * ceil_div(n, 64);
   int wgs_per_cu = 1;
   if (const char* e = getenv("GRB_BFS_WGS_PER_CU")) wgs_per_cu = atoi(e) >= 2 ? 2 : 1;
   static int max_per_cu = 0;
   if (!max_per_cu) {
-    GRB_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&max_per_cu, bfs_persistent_kernel, kPThreads, 0));
+    GRB_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&max_per_cu, bfs_persistent_kernel<kPThreads>, kPThreads, 0));
     if (max_per_cu < 1) return GRB_PANIC;
   }
   if (wgs_per_cu > max_per_cu) wgs_per_cu = max_per_cu;
   const int G_full = c.num_cu * wgs_per_cu;
   // lanes > 1: a queued traversal takes its share of the CUs (the blocking call, lane 0 alone, the whole device);
-  // a co-scheduled traversal has a workgroup on every CU
+  // a sub-grid of a co-scheduled launch has a workgroup on every CU
   const int G = co ? c.num_cu
                    : (g_ring.lanes > 1 && profile == 0 && g_ring.lanes_active) ? (c.num_cu / g_ring.lanes > 0 ? c.num_cu / g_ring.lanes : 1)
                                                                                : G_full;
   const int rec_cap = 1 << 15;
   const int big_cap = (int)(A->nvals / kBigDeg) + 2;
 
-  // one allocation: two blocks [state | V0 | F0 .. F(kKeep + 2)], used in turn (PersistArgs::clean)
+  // one allocation: three blocks [state | V0 | F0 .. F(kKeep + 2)], used in rotation (PersistArgs::blocks)
   const size_t st_bytes = (sizeof(PersistState) + 255) & ~(size_t)255;
   const size_t block_bytes = (st_bytes + 4 * (size_t)(1 + kKeep + 3) * (size_t)nwords + 255) & ~(size_t)255;
-  const size_t zero_bytes = 2 * block_bytes;
+  const size_t zero_bytes = (co ? 3 : 2) * block_bytes;
   void *p_zero, *p_v1, *p_big, *p_rec;
   int* p_blocksel = lane_id > 0 ? &ln.block : &g_ring.block;
   if (lane_id == 0) {
@@ -1318,10 +1393,10 @@ static grb_info bfs_persistent_args(grb_vector v, grb_matrix A, grb_index source
     GRB_TRY(scratch(8, 4 * (size_t)nwords, &p_v1));
     GRB_TRY(scratch(2, sizeof(int2) * (size_t)big_cap, &p_big));
     GRB_TRY(scratch(11, sizeof(grb_bfs_level) * (size_t)rec_cap, &p_rec));
-    // both blocks are clear (and the level-count word says "nothing to clear") when somebody else has had the slot
+    // every block is clear (and the rotation words say "nothing to clear") when somebody else has had the slot
     if (c.bfs_prezero_ptr != p_zero || c.bfs_prezero_bytes != zero_bytes) {
       GRB_HIP_TRY(hipMemsetAsync(p_zero, 0, zero_bytes, s));
-      GRB_HIP_TRY(hipMemsetAsync(g_ring.d_levels, 0, 4, s));
+      GRB_HIP_TRY(hipMemsetAsync(d_rot, 0, 16, s));
       g_ring.block = 0;
     }
     c.bfs_prezero_ptr = nullptr;
@@ -1332,16 +1407,13 @@ static grb_info bfs_persistent_args(grb_vector v, grb_matrix A, grb_index source
     GRB_TRY(lane_buffer(&ln.big, &ln.big_cap, sizeof(int2) * (size_t)big_cap, s));
     GRB_TRY(lane_buffer(&ln.rec, &ln.rec_cap, sizeof(grb_bfs_level) * (size_t)rec_cap, s));
     p_zero = ln.zero; p_v1 = ln.v1; p_big = ln.big; p_rec = ln.rec;
-    if (had != ln.zero_cap || ln.clean_bytes != zero_bytes) {     // new memory, or a graph of another size: clear both blocks
+    if (had != ln.zero_cap || ln.clean_bytes != zero_bytes) {     // new memory, or a graph of another size: clear every block
       GRB_HIP_TRY(hipMemsetAsync(p_zero, 0, zero_bytes, s));
-      GRB_HIP_TRY(hipMemsetAsync(ln.d_levels, 0, 4, s));
+      GRB_HIP_TRY(hipMemsetAsync(d_rot, 0, 16, s));
       ln.block = 0;
     }
     ln.clean_bytes = 0;
   }
-  char* p_block = (char*)p_zero + (size_t)(*p_blocksel) * block_bytes;
-  void* p_st = p_block;
-  unsigned int* p_v0 = (unsigned int*)(p_block + st_bytes);
 
   static float ticks_to_ms = 0.f;
   if (ticks_to_ms == 0.f) {
@@ -1389,15 +1461,16 @@ static grb_info bfs_persistent_args(grb_vector v, grb_matrix A, grb_index source
   }
   a.n_in = A->bfs_n_in;
   a.out_is_in = A->bfs_out_is_in ? 1 : 0;
-  a.source = source;
   a.mode = desc->desc[GRB_MXVMODE];
   a.switchpoint = desc->switchpoint;
   a.edgeswitch = desc->edgeswitch;
   a.max_niter = desc->max_niter;
   a.count_inspected = (profile & 2) ? 1 : 0;
-  a.label = (float*)v->d_val;
-  a.V[0] = p_v0; a.V[1] = (unsigned int*)p_v1;
-  for (int L = 0; L < kKeep + 3; ++L) a.F[L] = p_v0 + (size_t)(1 + L) * (size_t)nwords;
+  a.blocks = (char*)p_zero;
+  a.block_bytes = (unsigned long long)block_bytes;
+  a.st_bytes = (unsigned long long)st_bytes;
+  a.v1 = (unsigned int*)p_v1;
+  a.rot = d_rot;
   a.big_list = (int2*)p_big;
   a.big_cap = big_cap;
   // owner-computes push: the tables are made once per matrix (ranges of equal in-edge mass, at most kOcWords words
@@ -1406,7 +1479,8 @@ static grb_info bfs_persistent_args(grb_vector v, grb_matrix A, grb_index source
   {
     const char* e = getenv("GRB_BFS_OC_MIN");              // frontier out-edges from which a push level uses it; 0 = off
     const long long oc_min = e ? atoll(e) : 262144;
-    const bool narrow = G != G_full;                       // a lane's grid: its own tables (the ranges are cut per workgroup)
+    const bool narrow = G != G_full || oc_words != kOcWords;   // a lane's grid, or narrower slices: its own tables (the ranges are cut per workgroup)
+    const int oc2_key = G + (oc_words << 12);
     if (!narrow) {
       if (oc_min > 0 && A->oc_state == 0) {
         A->oc_state = -1;
@@ -1425,17 +1499,17 @@ static grb_info bfs_persistent_args(grb_vector v, grb_matrix A, grb_index source
         a.oc_min_edges = (unsigned long long)oc_min;
       }
     } else {
-      if (oc_min > 0 && (A->oc2_state == 0 || A->oc2_grid != G)) {
+      if (oc_min > 0 && (A->oc2_state == 0 || A->oc2_grid != oc2_key)) {
         if (A->d_oc2_bounds || A->d_oc2_off || A->d_oc2_bigidx) {
           GRB_HIP_TRY(hipDeviceSynchronize());               // (traversals of other lanes may be reading the old tables)
           (void)hipFree(A->d_oc2_bounds); (void)hipFree(A->d_oc2_off); (void)hipFree(A->d_oc2_bigidx);
           A->d_oc2_bounds = nullptr; A->d_oc2_off = nullptr; A->d_oc2_bigidx = nullptr;
         }
         A->oc2_state = -1;
-        A->oc2_grid = G;
+        A->oc2_grid = oc2_key;
         if (A->nvals > 0 && (Index)A->h_csr_ptr.size() == n + 1) {
           GRB_TRY(oc_tables_build(A->csr.ptr, A->csr.ind, A->h_csr_ptr, n, n, G, &A->d_oc2_bounds, &A->d_oc2_off, &A->d_oc2_bigidx,
-                                  &A->oc2_nb, &A->oc2_nrows));
+                                  &A->oc2_nb, &A->oc2_nrows, oc_words));
           if (A->d_oc2_off) A->oc2_state = 1;
           GRB_HIP_TRY(hipStreamSynchronize(c.stream));       // (built on the library's stream; the lanes read them)
         }
@@ -1450,14 +1524,8 @@ static grb_info bfs_persistent_args(grb_vector v, grb_matrix A, grb_index source
       }
     }
   }
-  a.st = (PersistState*)p_st;
   a.rec = (grb_bfs_level*)p_rec;
-  a.rec_cap = rec_cap;
-  a.mail = g_ring.d + 8 * (size_t)slot;
-  a.seq = seq_in ? seq_in : ++c.mail_seq;
-  a.dev_levels = d_levels;
-  a.clean = (uint4*)((char*)p_zero + (size_t)((*p_blocksel) ^ 1) * block_bytes);
-  a.st_bytes = (unsigned long long)st_bytes;
+  a.rec_cap = co ? 0 : rec_cap;                              // (per-level records: the blocking call's profiling runs read them)
   a.ticks_to_ms = ticks_to_ms;
   *p_rec_out = p_rec;
   *trace_out = nullptr;
@@ -1470,13 +1538,14 @@ static grb_info bfs_persistent_args(grb_vector v, grb_matrix A, grb_index source
     a.trace = (unsigned long long*)p_tr;
     *trace_out = a.trace;
   }
-  lc->lane_id = lane_id; lc->co = co; lc->s = s; lc->G = G; lc->p_zero = p_zero; lc->zero_bytes = zero_bytes; lc->p_blocksel = p_blocksel;
+  lc->lane_id = lane_id; lc->co = co; lc->s = s; lc->G = G; lc->p_zero = p_zero; lc->zero_bytes = zero_bytes;
+  lc->block_bytes = block_bytes; lc->p_blocksel = p_blocksel;
   return GRB_SUCCESS;
 }
-// the launch has been queued: the next traversal of this lane runs on the other block and clears this one
+// the launch has been queued: the lane's blocks are in the state the rotation words describe
 static grb_info bfs_persistent_queued(const LaunchCtx& lc) {
   Context& c = ctx();
-  *lc.p_blocksel ^= 1;
+  if (!lc.co) *lc.p_blocksel ^= 1;                          // the next traversal runs on the other block and clears this one
   if (lc.lane_id == 0) {
     c.bfs_prezero_ptr = lc.p_zero;
     c.bfs_prezero_bytes = lc.zero_bytes;
@@ -1509,10 +1578,19 @@ void grb::bfs_lanes_unfence() {
 static grb_info bfs_persistent_launch(grb_vector v, grb_matrix A, grb_index source, grb_descriptor desc, int profile, int slot,
                                       int* seq_out, void** p_rec_out, unsigned long long** trace_out, int lane_id = 0, int seq_in = 0) {
   Context& c = ctx();
-  PersistArgs a;
+  LaunchArgs la;
+  memset(&la, 0, sizeof(la));
   LaunchCtx lc;
-  GRB_TRY(bfs_persistent_args(v, A, source, desc, profile, slot, seq_in, lane_id, false, &a, &lc, p_rec_out, trace_out));
-  *seq_out = a.seq;
+  GRB_TRY(bfs_persistent_args(A, desc, profile, lane_id, false, &la.g[0], &lc, p_rec_out, trace_out));
+  la.t[0].label = (float*)v->d_val;
+  la.t[0].block = (char*)lc.p_zero + (size_t)(*lc.p_blocksel) * lc.block_bytes;
+  la.t[0].clean = (char*)lc.p_zero + (size_t)((*lc.p_blocksel) ^ 1) * lc.block_bytes;
+  la.t[0].mail = g_ring.d + 8 * (size_t)slot;
+  la.t[0].source = source;
+  la.t[0].seq = seq_in ? seq_in : ++c.mail_seq;
+  la.ctr = g_ring.d_ctr;
+  la.ntrav = 1; la.n_grids = 1; la.G = lc.G;
+  *seq_out = la.t[0].seq;
   hipStream_t s = lc.s;
   BfsLane& ln = g_ring.lane[lane_id];
   // whatever OTHER entry points have queued on the library's stream since this lane last looked (a fill of v, a build of
@@ -1532,53 +1610,72 @@ static grb_info bfs_persistent_launch(grb_vector v, grb_matrix A, grb_index sour
   static const bool force_fallback = [] { const char* e = getenv("GRB_BFS_FORCE_FALLBACK"); return e && atoi(e) != 0; }();
   if (force_fallback) return GRB_NOT_IMPLEMENTED;            // test hook: behave as if the launch had been refused
   if (cooperative) {
-    void* kargs[] = {&a};
-    if (hipLaunchCooperativeKernel(reinterpret_cast<void*>(bfs_persistent_kernel), dim3(lc.G), dim3(kPThreads), kargs, 0, s) !=
+    void* kargs[] = {&la};
+    if (hipLaunchCooperativeKernel(reinterpret_cast<void*>(bfs_persistent_kernel<kPThreads>), dim3(lc.G), dim3(kPThreads), kargs, 0, s) !=
         hipSuccess) {
       (void)hipGetLastError();
       return GRB_NOT_IMPLEMENTED;
     }
   } else {
-    hipLaunchKernelGGL(bfs_persistent_kernel, dim3(lc.G), dim3(kPThreads), 0, s, a);
+    hipLaunchKernelGGL(bfs_persistent_kernel<kPThreads>, dim3(lc.G), dim3(kPThreads), 0, s, la);
     GRB_HIP_TRY(hipGetLastError());
   }
   if (profile & 1) GRB_HIP_TRY(hipEventRecord(c.ev1, s));
   return bfs_persistent_queued(lc);
 }
 
-// k traversals (2 .. kCoMax) in ONE launch on the library's stream: bfs_co_kernel, traversal j on lane j's buffers.
+// ntrav traversals (2 .. kCoTrain) of one matrix under one descriptor in ONE launch on the library's stream: n_grids
+// sub-grids (sub-grid j on lane j's buffers) that draw the traversals from the launch's table.
 template <int T>
 static grb_info co_kernel_fits(int k) {
   static int per_cu = -1;
   if (per_cu < 0) {
     int m = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&m, bfs_co_kernel<T>, T, 0) != hipSuccess) { (void)hipGetLastError(); m = 0; }
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&m, bfs_persistent_kernel<T>, T, 0) != hipSuccess) { (void)hipGetLastError(); m = 0; }
     per_cu = m;
   }
   return per_cu >= k ? GRB_SUCCESS : GRB_NOT_IMPLEMENTED;
 }
-static grb_info bfs_co_launch(int k, const CoPend* pend) {
+static grb_info bfs_co_launch(int ntrav, const CoPend* pend, int width) {
   Context& c = ctx();
-  if (k < 2 || k > kCoMax) return GRB_INVALID_VALUE;
+  if (ntrav < 2 || ntrav > kCoTrain) return GRB_INVALID_VALUE;
   static const bool force_fallback = [] { const char* e = getenv("GRB_BFS_FORCE_FALLBACK"); return e && atoi(e) != 0; }();
   if (force_fallback) return GRB_NOT_IMPLEMENTED;
-  const bool wide = k <= 2;                                  // two traversals: 512-thread workgroups; three or four: 256
-  GRB_TRY(wide ? co_kernel_fits<512>(k) : co_kernel_fits<256>(k));
-  CoArgs ca;
-  memset(&ca, 0, sizeof(ca));
+  int n_grids = width < ntrav ? width : ntrav;
+  if (n_grids > kCoMax) n_grids = kCoMax;
+  // two sub-grids: 512-thread workgroups; three or four: 256; up to eight: 128
+  const int T = n_grids <= 2 ? 512 : n_grids <= 4 ? 256 : 128;
+  GRB_TRY(T == 512 ? co_kernel_fits<512>(n_grids) : T == 256 ? co_kernel_fits<256>(n_grids) : co_kernel_fits<128>(n_grids));
+  const int oc_words = T >= 256 ? kOcWords : kOcWords / 4;
+  LaunchArgs la;
+  memset(&la, 0, sizeof(la));
   LaunchCtx lc[kCoMax];
-  for (int j = 0; j < k; ++j) {
+  for (int j = 0; j < n_grids; ++j) {
     void* p_rec = nullptr;
     unsigned long long* trace = nullptr;
-    GRB_TRY(bfs_persistent_args(pend[j].v, pend[j].A, pend[j].source, pend[j].desc, 0, pend[j].slot, pend[j].seq, j, true, &ca.t[j],
-                                &lc[j], &p_rec, &trace));
+    GRB_TRY(bfs_persistent_args(pend[0].A, pend[0].desc, 0, kMaxLanes + 1 + j, true, &la.g[j], &lc[j], &p_rec, &trace, oc_words));
   }
+  for (int i = 0; i < ntrav; ++i) {
+    la.t[i].label = (float*)pend[i].v->d_val;
+    la.t[i].mail = g_ring.d + 8 * (size_t)pend[i].slot;
+    la.t[i].source = pend[i].source;
+    la.t[i].seq = pend[i].seq;
+  }
+  if (g_ring.ctr_dirty) {
+    GRB_HIP_TRY(hipMemsetAsync(g_ring.d_ctr, 0, 4, c.stream));
+    g_ring.ctr_base = 0;
+    g_ring.ctr_dirty = false;
+  }
+  la.ctr = g_ring.d_ctr;
+  la.ctr_base = g_ring.ctr_base;
+  la.ntrav = ntrav; la.n_grids = n_grids; la.G = lc[0].G;
   GRB_TRY(bfs_lanes_fence(c.stream));
-  const int G = lc[0].G;
-  if (wide) hipLaunchKernelGGL(bfs_co_kernel<512>, dim3(k * G), dim3(512), 0, c.stream, ca, G);
-  else hipLaunchKernelGGL(bfs_co_kernel<256>, dim3(k * G), dim3(256), 0, c.stream, ca, G);
+  if (T == 512) hipLaunchKernelGGL(bfs_persistent_kernel<512>, dim3(n_grids * la.G), dim3(512), 0, c.stream, la);
+  else if (T == 256) hipLaunchKernelGGL(bfs_persistent_kernel<256>, dim3(n_grids * la.G), dim3(256), 0, c.stream, la);
+  else hipLaunchKernelGGL(bfs_persistent_kernel<128>, dim3(n_grids * la.G), dim3(128), 0, c.stream, la);
   GRB_HIP_TRY(hipGetLastError());
-  for (int j = 0; j < k; ++j) GRB_TRY(bfs_persistent_queued(lc[j]));
+  if (ntrav > n_grids) g_ring.ctr_base += (unsigned)ntrav;   // a chained launch draws once per traversal
+  for (int j = 0; j < n_grids; ++j) GRB_TRY(bfs_persistent_queued(lc[j]));
   return GRB_SUCCESS;
 }
 
@@ -1598,8 +1695,9 @@ static grb_info bfs_persistent_collect(int slot, int seq, int profile, void* p_r
       // the kernel left early (its barrier gave up) without leaving its level count: the next launch cleared too little
       // of this block, and every traversal queued since ran on whatever that left
       c.bfs_prezero_ptr = nullptr;
-      for (int l = 1; l <= kMaxLanes; ++l) g_ring.lane[l].clean_bytes = 0;
+      for (int l = 1; l < kMaxLanes + 1 + kCoMax; ++l) g_ring.lane[l].clean_bytes = 0;
       g_ring.poisoned_upto = c.mail_seq;
+      g_ring.ctr_dirty = true;
       return wi;
     }
   }
@@ -1670,8 +1768,10 @@ grb_info grb::bfs_persistent_enqueue(grb_vector v, grb_matrix A, grb_index sourc
   GRB_TRY(ring_init());
   BfsTicket& t = g_ring.t[slot];
   if (g_ring.co_width > 1 && g_ring.lanes == 1) {
-    // co-scheduling: the traversal gets its ticket now and its launch when co_width of them have gathered (or when
-    // somebody waits for one of them, or any other entry point is called: bfs_co_flush).  One launch serves one matrix
+    // co-scheduling: the traversal gets its ticket now and its launch when somebody waits for a ticket, when any other
+    // entry point is called (bfs_co_flush), or when kCoTrain of them have gathered -- a launch runs co_width of them at a
+    // time and hands out the rest as its sub-grids come free, so the more it carries the less its tail weighs; the host
+    // queues a ticket in a microsecond, so gathering costs the device nothing it notices.  One launch serves one matrix
     // and one set of descriptor fields.
     if (g_ring.co_n > 0 && (g_ring.co[0].A != A || g_ring.co[0].desc != desc)) GRB_TRY(bfs_co_flush());
     *seq = ++ctx().mail_seq;
@@ -1679,7 +1779,7 @@ grb_info grb::bfs_persistent_enqueue(grb_vector v, grb_matrix A, grb_index sourc
     p.slot = slot; p.seq = *seq; p.v = v; p.A = A; p.source = source; p.desc = desc;
     t.state = 3; t.seq = *seq; t.lane = 0; t.v = v; t.A = A; t.desc = desc; t.source = source;
     grb_info fi = GRB_SUCCESS;
-    if (g_ring.co_n >= g_ring.co_width) fi = bfs_co_flush();
+    if (g_ring.co_n >= kCoTrain) fi = bfs_co_flush();       // the launch's table is full
     g_ring.enqueue_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
     ++g_ring.calls;
     return fi;
@@ -1698,18 +1798,18 @@ grb_info grb::bfs_persistent_enqueue(grb_vector v, grb_matrix A, grb_index sourc
   t.state = 1; t.seq = *seq; t.lane = lane; t.v = v; t.A = A; t.desc = desc; t.source = source;
   return GRB_SUCCESS;
 }
-// Launches what waits: all of it in one launch when there are two or more (512-thread workgroups for two, 256 for three
-// or four), a lone one as an ordinary traversal.  A launch that is refused leaves its tickets in state 4: grb_bfs_wait
+// Launches what waits: all of it in one launch when there are two or more (co_width sub-grids: 512-thread workgroups for
+// two, 256 for three or four), a lone one as an ordinary traversal.  A launch that is refused leaves its tickets in state 4: grb_bfs_wait
 // runs those traversals itself.
 bool grb::bfs_co_pending() { return g_ring.co_n > 0; }
 grb_info grb::bfs_co_flush() {
   const int k = g_ring.co_n;
   if (k == 0) return GRB_SUCCESS;
-  CoPend pend[kCoMax];
+  CoPend pend[kCoTrain];
   for (int j = 0; j < k; ++j) pend[j] = g_ring.co[j];
   g_ring.co_n = 0;
   grb_info li = GRB_NOT_IMPLEMENTED;
-  if (k >= 2) li = bfs_co_launch(k, pend);
+  if (k >= 2) li = bfs_co_launch(k, pend, g_ring.co_width);
   if (li == GRB_SUCCESS) {
     for (int j = 0; j < k; ++j) g_ring.t[pend[j].slot].state = 1;
     return GRB_SUCCESS;

@@ -793,7 +793,7 @@ grb_info sssp_nearfar_run(grb_vector v, grb_matrix A, grb_index source, grb_desc
 constexpr int kOcBin = 256;        // owner-computes push (bfs_persist.hip, bfs_part_run.hip): the ranges are cut on multiples of this many vertices
 constexpr int kOcWords = 8192;     // ... and a range's slice of the visited bitmap is at most this many words (32 KiB of LDS)
 grb_info oc_tables_build(const Index* d_ptr, const Index* d_ind, const std::vector<Index>& h_ptr, Index nrows, Index ncols, int G,
-                         Index** d_bounds, Index** d_off, int** d_bigidx, int* nb, int* nbig);
+                         Index** d_bounds, Index** d_off, int** d_bigidx, int* nb, int* nbig, int max_words = kOcWords);
 grb_info bfs_queue_run(grb_vector v, grb_matrix A, grb_index source, grb_descriptor desc, int* levels,
                        long long* reached, unsigned long long* edges, float* tight_ms);   // sssp_nearfar.hip
 bool bfs_queue_wanted(grb_matrix A, grb_descriptor desc);   // would bfs_queue_run take this traversal? (sssp_nearfar.hip)

@@ -314,19 +314,20 @@ def test_bfs_lanes(hb, graphs):
 
 
 def test_bfs_coscheduled(hb, graphs, capfd):
-    """grb_bfs_set_coschedule: the queued traversals are launched k at a time, side by side in ONE grid (k sub-grids of a
-    workgroup per CU each; 512-thread workgroups for two, 256 for three or four).  Labels and result blocks are those of
-    the blocking call and the oracle for every k, with groups that never fill (eleven traversals; a wait, a library call
-    or a blocking traversal launches what has gathered), waits in reverse order, every direction mode, a search cut by
-    max_niter, and library calls on the vectors before and after."""
+    """grb_bfs_set_coschedule: the queued traversals run k at a time, side by side in ONE launch (k sub-grids of a
+    workgroup per CU each; 512-thread workgroups for two, 256 up to four, 128 up to eight; a launch carries every
+    traversal that has gathered and its sub-grids draw them from a counter).  Labels and result blocks are those of
+    the blocking call and the oracle for every k, with launches of fewer traversals than sub-grids and of more (six and
+    five traversals; a wait, a library call or a blocking traversal launches what has gathered), waits in reverse order,
+    every direction mode, a search cut by max_niter, and library calls on the vectors before and after."""
     from oracle import simple_reference as sr
     g = hb.g
     before = g.bfs_set_coschedule(-1)
     assert before == 1
     try:
-        for k in (2, 3, 4, 9, 1):
-            assert g.bfs_set_coschedule(k) in (1, 2, 3, 4)
-            assert g.bfs_set_coschedule(-1) == min(k, 4)
+        for k in (2, 3, 4, 6, 9, 1):
+            assert g.bfs_set_coschedule(k) in range(1, 9)
+            assert g.bfs_set_coschedule(-1) == min(k, 8)
             for name, gr in graphs[2:5]:
                 ptr, ind = gr["csr"]
                 A = build(hb, gr)
