@@ -422,6 +422,8 @@ def main():
                     help="also time the SpMV kernel on a road-like grid (launches the SpMV kernels of the main "
                          "measurement again: would mix into a rocprof average of this command)")
     ap.add_argument("--no-lanes", action="store_true", help="skip the timing of the K steps with two traversals in flight")
+    ap.add_argument("--no-coschedule", action="store_true",
+                    help="skip the timing of the K steps with several traversals side by side in one launch")
     ap.add_argument("--no-batch", action="store_true",
                     help="skip the multi-frontier measurements (64-source sweep, sparse x dense mxm)")
     ap.add_argument("--partitioned", action="store_true",
@@ -576,6 +578,46 @@ def main():
             run_queued(2)                                         # back on one lane: the vectors hold single-lane results again
             results_check = run_queued(args.steps)
             assert [r_["reached"] for r_ in results_check] == [r_["reached"] for r_ in results]
+        # ---- the same K steps, several traversals side by side in ONE launch (grb_bfs_set_coschedule: k sub-grids of a
+        #      workgroup per CU each, one launch on the library's stream whatever the runtime does with streams).  A sibling
+        #      of `value` with a roofline block of its own; the labels of EVERY step are compared with the labels the
+        #      one-at-a-time steps wrote (which the parity block below compares with the reference's BFS).
+        if not args.no_coschedule:
+            solo_labels = [x.extractTuples()[1] for x in vs]
+            co_runs = {}
+            for k in (4, 8):
+                g.bfs_set_coschedule(k)
+                run_queued(max(args.warmup, 2 * k))
+                reps = []
+                for _ in range(3):
+                    barrier()
+                    t0c = time.perf_counter()
+                    rc = run_queued(args.steps)
+                    barrier()
+                    reps.append(time.perf_counter() - t0c)
+                elc = float(np.median(reps))
+                assert [(r_["reached"], r_["edges_traversed"], r_["levels"]) for r_ in rc] == \
+                       [(r_["reached"], r_["edges_traversed"], r_["levels"]) for r_ in results]
+                bad = sum(0 if np.array_equal(x.extractTuples()[1], w_) else 1 for x, w_ in zip(vs, solo_labels))
+                if bad:
+                    print(json.dumps({"error": "parity", "what": "co-scheduled labels differ", "k": k, "vectors": bad}))
+                    raise SystemExit(3)
+                g.bfs_coschedule_profile(True)                       # a second pass: HIP events around the launches
+                run_queued(args.steps)
+                prof = g.bfs_coschedule_profile(False)
+                co_runs[k] = {"value": sum(r_["edges_traversed"] for r_ in rc) / elc, "unit": "TEPS",
+                              "ms_per_step": round(elc / args.steps * 1e3, 5),
+                              "ms_per_step_runs": [round(x / args.steps * 1e3, 5) for x in reps],
+                              "kernel_clock_ms_mean": round(float(np.mean([r_["tight_ms"] for r_ in rc])), 4),
+                              "launches": prof["launches"], "launch_ms_total_by_hip_events": round(prof["ms_total"], 5),
+                              "labels": "all %d vectors equal to the one-at-a-time steps'" % len(vs)}
+            g.bfs_set_coschedule(1)
+            extra["coscheduled"] = {"what": "K queued steps with grb_bfs_set_coschedule(k): ONE launch carries the K traversals, k "
+                                            "sub-grids (a workgroup per CU each; 256 threads at k = 4, 128 at k = 8) run them side by "
+                                            "side and draw the next from a counter; per-traversal results and labels identical.  Not "
+                                            "`value`: there a traversal has the device to itself.  median of 3 runs",
+                                    "4": co_runs[4], "8": co_runs[8]}
+            run_queued(args.steps)                                   # (the vectors hold one-at-a-time results again)
         # the labels the queued steps left are checked below (parity block) through vs[...]; the blocking sibling:
         for i in range(min(args.warmup, 2)):
             run_step(i)
@@ -617,6 +659,32 @@ def main():
                     "traffic_source": pmc_traffic("bfs_persistent_kernel")[1], "launches": args.steps,
                     "avg_launch_ms": round(event_ms / args.steps, 5),
                     "algorithmic_bytes_per_launch": int(total_bytes / args.steps)}
+        # the design's floor for ONE traversal at a time: what a traversal of this many levels costs when its levels have
+        # next to no work (a level's barrier, totals and latency chain; measured here as the cheapest level the kernel
+        # itself clocked in the event pass -- a last level with a frontier of a few vertices) plus what HIP events see around
+        # the kernel's own clock (launch, the depth vector's write-back behind the last instruction)
+        lv_ms = [L["ms"] for r_ in timed for L in r_["per_level"] if L["ms"] > 0]
+        n_levels = float(np.mean([r_["levels"] for r_ in results]))
+        clock_ms = float(np.mean([r_["tight_ms"] for r_ in results]))
+        if lv_ms:
+            empty_level_ms = float(np.percentile(lv_ms, 5))
+            floor_ms = n_levels * empty_level_ms + max(event_ms / args.steps - clock_ms, 0.0)
+            roofline.update({"latency_floor_ms": round(floor_ms, 5),
+                             "latency_floor": "levels (%.2f) x a level with next to no work (%.2f us, the kernel's own clock) + launch "
+                                              "and write-back around the kernel (%.1f us): what one traversal at a time costs in this "
+                                              "design before a byte of the graph is read"
+                                              % (n_levels, empty_level_ms * 1e3, max(event_ms / args.steps - clock_ms, 0.0) * 1e3),
+                             "frac_if_the_rest_ran_at_peak": round(total_bytes / args.steps / ((floor_ms + total_bytes / args.steps / (HBM_PEAK_GBS * 1e9) * 1e3) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)})
+        if "coscheduled" in extra:
+            for k in ("4", "8"):
+                cr = extra["coscheduled"][k]
+                ach_k = total_bytes / (cr["launch_ms_total_by_hip_events"] * 1e-3) / 1e9
+                cr["roofline"] = {"bound": "hbm", "kernel": "bfs_persistent_kernel<%d>" % (256 if k == "4" else 128),
+                                  "achieved": round(ach_k, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach_k / HBM_PEAK_GBS, 4),
+                                  "launches": cr["launches"], "traversals_per_launch": round(args.steps / max(cr["launches"], 1), 2),
+                                  "avg_launch_ms": round(cr["launch_ms_total_by_hip_events"] / max(cr["launches"], 1), 5),
+                                  "algorithmic_bytes_per_launch": int(total_bytes / max(cr["launches"], 1)),
+                                  "traffic": None}
         tight_ms = sum(r["tight_ms"] for r in results)
         one = account[sources[0]]
         ob = level_bytes(one, n)
@@ -1049,12 +1117,13 @@ def main():
         if world > 1 or os.environ.get("GRB_BENCH_TEST_REPLICAS"):
             mine = [sources[(rank * args.steps + i) % len(sources)] for i in range(args.steps)]
             # the N = 1 run's timed region on every rank: K traversals queued, then K waits (labels into K vectors)
-            vq = [g.Vector(n) for _ in range(min(args.steps, 8))]
+            # (one vector per outstanding ticket: the API's contract -- a vector is untouched until its ticket has been waited for)
+            vq = [g.Vector(n) for _ in range(args.steps)]
 
             def queued_pass(srcs_):
                 tk = []
                 for i, s_ in enumerate(srcs_):
-                    info, t_ = g.bfs_enqueue(vq[i % len(vq)], A, s_, desc)
+                    info, t_ = g.bfs_enqueue(vq[i], A, s_, desc)
                     assert info == 0, info
                     tk.append(t_)
                 tot = 0
@@ -1070,6 +1139,13 @@ def main():
             my_edges = queued_pass(mine)
             barrier()
             el = time.perf_counter() - t0
+            # the labels a queued timed step wrote, on every rank: the first and the last step against a blocking traversal
+            # of the same source (which the partitioned parity block above has compared with the reference)
+            for i_ in sorted({0, len(mine) - 1}):
+                assert g.bfs(v, A, mine[i_], desc, fused=True)[0] == 0
+                if not np.array_equal(vq[i_].extractTuples()[1], v.extractTuples()[1]):
+                    print(json.dumps({"error": "parity (replica leg)", "rank": rank, "step": i_}))
+                    sys.exit(3)
             t = torch.tensor([el, float(my_edges)], dtype=torch.float64, device=sdev)
             tm, te = t[:1].clone(), t[1:].clone()
             if world > 1:

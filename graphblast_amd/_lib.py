@@ -153,6 +153,7 @@ _SIGS = {
     "grb_bfs_host_times": [C.POINTER(_d), C.POINTER(_d), C.POINTER(C.c_longlong), _i],
     "grb_bfs_set_lanes": [_i],
     "grb_bfs_set_coschedule": [_i],
+    "grb_bfs_coschedule_profile": [_i, C.POINTER(C.c_double), C.POINTER(_i), C.POINTER(_i)],
     "grb_bfs_part_pull": [_vp, _i, _i, _vp, _vp, _vp, _f],
     "grb_bfs_part_push": [_vp, _i, _i, _vp, _vp, _vp, _vp, C.POINTER(C.c_int64)],
     "grb_bfs_part_apply": [_vp, _vp, _i, _i, _i, _vp, _f, C.POINTER(C.c_int32)],

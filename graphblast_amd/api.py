@@ -497,6 +497,15 @@ def bfs_set_coschedule(k=-1):
     return int(_lib.load().grb_bfs_set_coschedule(int(k)))
 
 
+def bfs_coschedule_profile(on):
+    """grb_bfs_coschedule_profile: on=True starts HIP events around the launches of several traversals; on=False stops and
+    returns dict(ms_total, launches, traversals)."""
+    ms, nl, nt = C.c_double(0), C.c_int(0), C.c_int(0)
+    info = _lib.load().grb_bfs_coschedule_profile(1 if on else 0, C.byref(ms), C.byref(nl), C.byref(nt))
+    assert info == 0, info
+    return dict(ms_total=ms.value, launches=nl.value, traversals=nt.value)
+
+
 def bfs_host_times(reset=False):
     """Host microseconds spent queueing / waiting inside the one-launch traversal since the last reset, and the calls."""
     e, w, n = C.c_double(0), C.c_double(0), C.c_longlong(0)

@@ -214,6 +214,12 @@ extern "C" int grb_bfs_set_coschedule(int k) { grb::ApiScope api_scope__; (void)
   return bfs_co_setting(k);
 }
 
+// Measurement passes: HIP events (on the library's stream) around the launches of several traversals.  on != 0 starts
+// collecting; on == 0 stops and reports the launches' summed duration, their number and the traversals they ran.
+extern "C" grb_info grb_bfs_coschedule_profile(int on, double* launch_ms_total, int* launches, int* traversals) { GRB_API_ENTER_BFSQ();
+  return bfs_co_profile(on, launch_ms_total, launches, traversals);
+}
+
 // Host time spent inside the one-launch traversal's two halves since the last reset: queueing the launches
 // (argument block, two kernel launches) and waiting for / unpacking the record.  calls = traversals.
 extern "C" grb_info grb_bfs_host_times(double* enqueue_us, double* wait_us, long long* calls, int reset) { GRB_API_ENTER_HOST();

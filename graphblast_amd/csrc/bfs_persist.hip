@@ -89,7 +89,7 @@ struct PersistState {               // zeroed by the host before every launch
   unsigned next_idx[32];            // launches of several traversals: the one this sub-grid runs next (written before the end barrier)
 };
 
-// What every traversal of a (sub-)grid shares: the matrix, the rules, the grid's buffers.
+// What every traversal of a launch shares: the matrix, the rules, the tables.
 struct PersistArgs {
   const Index *optr, *oind;         // out-edges (CSR), walked by push
   const Index *iptr, *iind;         // in-edges (CSC), walked by pull
@@ -122,11 +122,7 @@ struct PersistArgs {
   //           (a scattered 4-byte label store costs a 32-byte memory write: 131 MB per traversal of RMAT-22 against
   //           17 MB of labels).  Levels >= kKeep (long-diameter graphs, tiny frontiers) rotate through three more
   //           buffers and label directly.
-  char* blocks;
   unsigned long long block_bytes, st_bytes;
-  unsigned int* v1;
-  unsigned int* rot;                // device words: [0] traversals this grid has run, [1 + b] level count of block b's last one
-  int2* big_list;
   int big_cap;
   // owner-computes push for heavy sparse frontiers (oc_off == nullptr: off).  The vertices are cut into oc_nb ranges
   // [oc_bounds[b], oc_bounds[b + 1]) of about equal in-edge mass (word-aligned, at most kOcWords words); a row of
@@ -139,10 +135,18 @@ struct PersistArgs {
   const int* oc_bigidx;
   int oc_nb, oc_nrows;
   unsigned long long oc_min_edges;
-  grb_bfs_level* rec;
   int rec_cap;
   float ticks_to_ms;
   unsigned long long* trace;        // optional (GRB_BFS_TRACE): wall-clock stamps of workgroup 0
+};
+// ... what is a (sub-)grid's own: the buffers its traversals run on, one after the other
+struct GridArgs {
+  char* blocks;                     // the state blocks
+  unsigned int* v1;
+  unsigned int* rot;                // device words: [0] traversals this grid has run, [1 + b] level count of block b's last one
+                                    // (one traversal per launch: [0] = the last traversal's level count)
+  int2* big_list;
+  grb_bfs_level* rec;
 };
 // ... and what is a traversal's own
 struct TravArgs {
@@ -206,12 +210,16 @@ struct PersistLds {
 // the launch carries more traversals than grids; a grid that finishes one draws the next from a counter (*ctr, which
 // stood at ctr_base when the launch began; the first n_grids traversals are dealt statically), so that a launch ends
 // when the work does, not when the grid with the longest traversals does.
-template <int T, typename AP, typename TP>
-__device__ __forceinline__ int bfs_persistent_body(AP ap, TP tp, const int bid, const int G, const unsigned trot, const bool chained,
+template <int T, typename AP, typename GP, typename TP>
+__device__ __forceinline__ int bfs_persistent_body(AP ap, GP gp, TP tp, const int bid, const int G, const unsigned trot, const bool chained,
                                                    unsigned int* ctr, const unsigned ctr_base, const int n_grids) {
   const auto& a = *ap;
-#define label (tp->label)
-#define source (tp->source)
+  constexpr bool kHostRot = T == kPThreads;                        // one traversal per launch: the host keeps the rotation
+  // A sub-grid's and a traversal's own arguments sit at a run-time place of the kernarg segment.  What is read from there
+  // cannot be re-read for free where it is needed (the shared block's fields, at fixed places, can), so the compiler
+  // would read all of it once and hold it in registers for the whole kernel -- which has none to spare.  Every phase
+  // therefore reads what it needs through a pointer the optimiser cannot see through (one scalar load per phase).
+  auto ph = [](auto q) { if constexpr (!kHostRot) asm volatile("" : "+s"(q)); return q; };
   constexpr int W = T / kWave;
   constexpr int kMed = T >= 512 ? 4 * T : T >= 256 ? 512 : 256;                     // LDS list of medium vertices per workgroup pass
   __shared__ unsigned long long s_red[W][4];
@@ -244,12 +252,16 @@ __device__ __forceinline__ int bfs_persistent_body(AP ap, TP tp, const int bid, 
   const long long gthreads = (long long)G * T;
   const Index n = a.n;
   const int nwords = 2 * ((n + 63) / 64);
-  constexpr bool kHostRot = T == kPThreads;                        // one traversal per launch: the host keeps the rotation
   const unsigned blk = kHostRot ? 0u : trot % 3u;
-  char* const pblock = kHostRot ? tp->block : a.blocks + (unsigned long long)blk * a.block_bytes;
-  PersistState* st = reinterpret_cast<PersistState*>(pblock);
-  unsigned int* const V0 = reinterpret_cast<unsigned int*>(pblock + a.st_bytes);
-  auto Vp = [&](int which) -> unsigned int* { return which ? a.v1 : V0; };
+  // (the block's address is worked out again wherever it is needed -- a scalar load and a multiply-add per use, a few per
+  // level -- instead of living in registers)
+  auto pblock = [&]() -> char* {
+    if constexpr (kHostRot) return tp->block;
+    else return ph(gp)->blocks + (unsigned long long)blk * a.block_bytes;
+  };
+#define st (reinterpret_cast<PersistState*>(pblock()))
+#define V0 (reinterpret_cast<unsigned int*>(pblock() + a.st_bytes))
+  auto Vp = [&](int which) -> unsigned int* { return which ? ph(gp)->v1 : V0; };
   auto Fp = [&](int level) -> unsigned int* { return V0 + (size_t)(1 + fbuf(level)) * (size_t)nwords; };
   unsigned gen = 0;
   const unsigned long long t_start = wall_clock64();
@@ -259,7 +271,7 @@ __device__ __forceinline__ int bfs_persistent_body(AP ap, TP tp, const int bid, 
   // ---- the block a later traversal will run on: what an earlier one dirtied there (its state, V0, the level bitmaps it
   // wrote; every buffer when it went past the kept levels)
   if constexpr (kHostRot) {
-    const unsigned int lv = *a.rot;
+    const unsigned int lv = *ph(gp)->rot;
     const unsigned int used = lv + 2u >= (unsigned int)kKeep ? (unsigned int)kKeep + 3u : lv + 2u;
     const long long n16 = (long long)((a.st_bytes + 4ull * (1ull + used) * (unsigned long long)nwords + 15ull) / 16ull);
     const uint4 z = make_uint4(0u, 0u, 0u, 0u);
@@ -267,19 +279,23 @@ __device__ __forceinline__ int bfs_persistent_body(AP ap, TP tp, const int bid, 
     for (long long i = gtid; i < n16; i += gthreads) clean[i] = z;
   } else {
     const unsigned nb = (trot + 1u) % 3u;
-    const unsigned int lv = fresh(&a.rot[1 + nb]);
+    const unsigned int lv = fresh(&ph(gp)->rot[1 + nb]);
     const unsigned int used = lv + 2u >= (unsigned int)kKeep ? (unsigned int)kKeep + 3u : lv + 2u;
     const long long n8 = (long long)((a.st_bytes + 4ull * (1ull + used) * (unsigned long long)nwords + 7ull) / 8ull);
-    unsigned long long* clean = reinterpret_cast<unsigned long long*>(a.blocks + (unsigned long long)nb * a.block_bytes);
+    unsigned long long* clean = reinterpret_cast<unsigned long long*>(ph(gp)->blocks + (unsigned long long)nb * a.block_bytes);
     for (long long i = gtid; i < n8; i += gthreads) publish(&clean[i], 0ull);
   }
 
   // ---- the source.  The bitmaps arrive zeroed; unreached labels are written at the very end,
   // so the first level starts without a barrier (unless it is a pull, which must see the bit).
-  const Index src_deg = a.optr[source + 1] - a.optr[source];
-  if (gtid == 0) {
-    atomicOr(&V0[source >> 5], 1u << (source & 31));
-    atomicOr(&Fp(0)[source >> 5], 1u << (source & 31));
+  Index src_deg;
+  {
+    const Index source = ph(tp)->source;
+    src_deg = a.optr[source + 1] - a.optr[source];
+    if (gtid == 0) {
+      atomicOr(&Vp(0)[source >> 5], 1u << (source & 31));
+      atomicOr(&Fp(0)[source >> 5], 1u << (source & 31));
+    }
   }
   if (a.mode == GRB_PULLONLY && !grid_sync_at(&st->bar, gen, bid, G, false)) return -1;
 
@@ -328,7 +344,10 @@ __device__ __forceinline__ int bfs_persistent_body(AP ap, TP tp, const int bid, 
       // ================= push =================
       GRB_PHASE_START();
       unsigned int* V = Vp(cur);
+      float* const label = ph(tp)->label;
+      int2* const big_list = ph(gp)->big_list;
       if (iter == 1) {
+        const Index source = ph(tp)->source;
         // the frontier is the source alone: its edges spread over the whole grid
         const Index e = a.optr[source + 1];
         for (long long p = a.optr[source] + gtid; p < e; p += gthreads) {
@@ -405,7 +424,7 @@ incl = (int)wave_incl_scan_u32((unsigned)incl);
                 const Index d = a.optr[v + 1] - a.optr[v];
                 if (d >= kBigDeg)
                   for (int k = 0; k < (heavy ? 1 : (d + kBigChunk - 1) / kBigChunk); ++k, ++at)
-                    if (at < a.big_cap) publish(reinterpret_cast<unsigned long long*>(&a.big_list[at]),
+                    if (at < a.big_cap) publish(reinterpret_cast<unsigned long long*>(&big_list[at]),
                                                 ((unsigned long long)(unsigned)k << 32) | (unsigned)v);
               }
             }
@@ -432,7 +451,7 @@ incl = (int)wave_incl_scan_u32((unsigned)incl);
           if (nent > a.big_cap) nent = a.big_cap;
           if (!heavy) {
             for (int e = bid; e < nent; e += G) {
-              const unsigned long long eb = fresh(reinterpret_cast<const unsigned long long*>(&a.big_list[e]));
+              const unsigned long long eb = fresh(reinterpret_cast<const unsigned long long*>(&big_list[e]));
               const int2 ent = make_int2((int)(eb & 0xffffffffull), (int)(eb >> 32));
               const Index pe = a.optr[ent.x + 1];
 #pragma unroll
@@ -459,7 +478,7 @@ incl = (int)wave_incl_scan_u32((unsigned)incl);
                 const int e = e0 + tid;
                 Index o0 = 0, o1 = 0;
                 if (e < nent) {
-                  const Index u = (Index)(fresh(reinterpret_cast<const unsigned long long*>(&a.big_list[e])) & 0xffffffffull);
+                  const Index u = (Index)(fresh(reinterpret_cast<const unsigned long long*>(&big_list[e])) & 0xffffffffull);
                   const int r = a.oc_bigidx[u];
                   o0 = a.oc_off[(size_t)b * a.oc_nrows + r];
                   o1 = a.oc_off[(size_t)(b + 1) * a.oc_nrows + r];
@@ -523,6 +542,7 @@ inc = (Index)wave_incl_scan_u32((unsigned)inc);
       // faster through L1 with ordinary loads, so it pays the invalidate itself, once.
       const unsigned int* vin = Vp(cur);
       unsigned int* vout = Vp(cur ^ 1);
+      float* const label = ph(tp)->label;
       const Index* hint = a.count_inspected ? nullptr : a.hint;
       const Index nchunks = (n + kWave - 1) / kWave;
       const Index nblocks = (nchunks + kPullBlock - 1) / kPullBlock;
@@ -766,11 +786,12 @@ incl = (int)wave_incl_scan_u32((unsigned)incl);
         const unsigned x = bid & 7u;
         const unsigned groups = G < 8 ? (unsigned)G : 8u;
         const unsigned members = ((unsigned)G - x + 7u) / 8u;
-        const unsigned arr = __hip_atomic_fetch_add(&st->bar.xcd_count[x][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (arr + 1u == members * g) (void)__hip_atomic_fetch_add(&st->bar.top_count[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        PersistState* const stl = st;
+        const unsigned arr = __hip_atomic_fetch_add(&stl->bar.xcd_count[x][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (arr + 1u == members * g) (void)__hip_atomic_fetch_add(&stl->bar.top_count[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         stamp();                                         // own arrival returned
         unsigned npoll = 0;
-        while (__hip_atomic_load(&st->bar.top_count[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < groups * g) { __builtin_amdgcn_s_sleep(1); ++npoll; if (npoll > kSpinLimit) break; }
+        while (__hip_atomic_load(&stl->bar.top_count[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < groups * g) { __builtin_amdgcn_s_sleep(1); ++npoll; if (npoll > kSpinLimit) break; }
         stamp();                                         // released
         if (a.trace && gtid == 0 && ntrace < 255) a.trace[1 + ntrace++] = npoll;   // (a count, not a time)
       }
@@ -793,7 +814,7 @@ incl = (int)wave_incl_scan_u32((unsigned)incl);
     const unsigned long long tot_found = s_tot[0], tot_deg = s_tot[1], tot_insp = s_tot[2], tot_big = s_tot[3];
     stamp();
     if (gtid == 0 && levels < a.rec_cap) {
-      grb_bfs_level& L = a.rec[levels];
+      grb_bfs_level& L = ph(gp)->rec[levels];
       L.direction = f1_dense ? 1 : 0;
       L.frontier = nf;
       L.frontier_edges = f1_dense ? (a.count_inspected ? (int64_t)tot_insp : 0) : (int64_t)mf;
@@ -820,6 +841,7 @@ incl = (int)wave_incl_scan_u32((unsigned)incl);
     // (agent-scope loads: no invalidate to wait for), so the pass is one memory latency deep; a lane then writes its
     // 32 labels as eight 16-byte stores (a whole 128-byte line per lane).
     const unsigned int* Vf = Vp(cur);
+    float* const label = ph(tp)->label;
     const int kept = levels + 1 < kKeep ? levels + 1 : kKeep;      // F[0 .. kept)
     const bool label_aligned = (reinterpret_cast<unsigned long long>(label) & 15ull) == 0ull;
 #if GRB_BFS_LABEL_COAL
@@ -937,27 +959,27 @@ incl = (int)wave_incl_scan_u32((unsigned)incl);
   // launch a barrier comes first -- the next traversal clears a block and must find nobody in this one's bitmaps -- and
   // the record is written behind it: every workgroup's label stores have completed by then.
   int next = 0x7fffffff;
-  if (gtid == 0) publish(&a.rot[kHostRot ? 0 : 1 + blk], (unsigned int)levels);
+  if (gtid == 0) publish(&ph(gp)->rot[kHostRot ? 0 : 1 + blk], (unsigned int)levels);
   if (chained) {
     if (gtid == 0) publish(&st->next_idx[0], (unsigned)n_grids + (atomicAdd(ctr, 1u) - ctr_base));
     if (!grid_sync_at(&st->bar, gen, bid, G, false)) return -1;
     next = (int)fresh(&st->next_idx[0]);
   }
   if (gtid == 0) {
-    const unsigned long long tag = (unsigned long long)(unsigned int)tp->seq << 32;
+    const unsigned long long tag = (unsigned long long)(unsigned int)ph(tp)->seq << 32;
     const float ms = (float)(wall_clock64() - t_start) * a.ticks_to_ms;
     const unsigned int vals[8] = {(unsigned int)levels, (unsigned int)last_dir, (unsigned int)reached,
                                   (unsigned int)(edges_cum & 0xffffffffull), (unsigned int)(edges_cum >> 32),
                                   (unsigned int)nf, (unsigned int)(iter > a.max_niter ? 1 : 0),
                                   __float_as_uint(ms)};
-    unsigned long long* mail = tp->mail;
+    unsigned long long* mail = ph(tp)->mail;
 #pragma unroll
     for (int k = 0; k < 8; ++k)
       __hip_atomic_store(&mail[k], tag | vals[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
   return next;
-#undef label
-#undef source
+#undef st
+#undef V0
 }
 
 // ---- the launch: one grid per traversal in flight, several traversals per grid ---------------------------------------
@@ -976,7 +998,8 @@ incl = (int)wave_incl_scan_u32((unsigned)incl);
 constexpr int kCoMax = 8;
 constexpr int kCoTrain = 48;
 struct LaunchArgs {
-  PersistArgs g[kCoMax];
+  PersistArgs a;
+  GridArgs g[kCoMax];
   TravArgs t[kCoTrain];
   unsigned int* ctr;                // the launch's counter (monotonic over launches; ctr_base: where it stood)
   unsigned ctr_base;
@@ -989,7 +1012,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
   const LaunchArgsPtr la = (LaunchArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
   if constexpr (T == kPThreads) {
     // one traversal on the launch's whole grid: every argument at a fixed place of the segment
-    (void)bfs_persistent_body<T>(&la->g[0], &la->t[0], (int)blockIdx.x, (int)gridDim.x, 0u, false, nullptr, 0u, 1);
+    (void)bfs_persistent_body<T>(&la->a, &la->g[0], &la->t[0], (int)blockIdx.x, (int)gridDim.x, 0u, false, nullptr, 0u, 1);
     return;
   }
   const int G = la->G;
@@ -1001,7 +1024,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
   unsigned trot = fresh(&g->rot[0]);                     // (nobody writes it before the launch's last traversal of this grid ends)
   int idx = j;
   while (idx < ntrav) {
-    idx = bfs_persistent_body<T>(g, &la->t[idx], bid, G, trot, chained, la->ctr, la->ctr_base, la->n_grids);
+    idx = bfs_persistent_body<T>(&la->a, g, &la->t[idx], bid, G, trot, chained, la->ctr, la->ctr_base, la->n_grids);
     if (idx < 0) return;
     ++trot;
   }
@@ -1277,6 +1300,11 @@ struct BfsRing {
   unsigned int* d_ctr = nullptr;                 // LaunchArgs::ctr: the chained launches' counter, and where it stands
   unsigned ctr_base = 0;
   bool ctr_dirty = false;                        // a chained launch did not finish: the counter is anywhere
+  // grb_bfs_coschedule_profile: HIP events around the launches of several traversals (measurement passes only)
+  bool co_profile = false;
+  std::vector<hipEvent_t> co_ev;                 // pairs
+  size_t co_ev_used = 0;
+  int co_prof_trav = 0;
   BfsTicket t[kRing];
   int next = 0;
   int poisoned_upto = 0;                         // records with seq <= this were queued behind a traversal that failed
@@ -1348,7 +1376,7 @@ struct LaunchCtx {
 // Fills the argument block of one (sub-)grid: the lane's buffers (lane 0: the library's scratch slots), the once-per-
 // matrix facts and tables.  Queues at most memsets on lc->s.
 static grb_info bfs_persistent_args(grb_matrix A, grb_descriptor desc, int profile, int lane_id, bool co, PersistArgs* out,
-                                    LaunchCtx* lc, void** p_rec_out, unsigned long long** trace_out, int oc_words = kOcWords) {
+                                    GridArgs* gout, LaunchCtx* lc, void** p_rec_out, unsigned long long** trace_out, int oc_words = kOcWords) {
   GRB_TRY(ring_init());
   Context& c = ctx();
   BfsLane& ln = g_ring.lane[lane_id];
@@ -1466,12 +1494,12 @@ static grb_info bfs_persistent_args(grb_matrix A, grb_descriptor desc, int profi
   a.edgeswitch = desc->edgeswitch;
   a.max_niter = desc->max_niter;
   a.count_inspected = (profile & 2) ? 1 : 0;
-  a.blocks = (char*)p_zero;
+  gout->blocks = (char*)p_zero;
   a.block_bytes = (unsigned long long)block_bytes;
   a.st_bytes = (unsigned long long)st_bytes;
-  a.v1 = (unsigned int*)p_v1;
-  a.rot = d_rot;
-  a.big_list = (int2*)p_big;
+  gout->v1 = (unsigned int*)p_v1;
+  gout->rot = d_rot;
+  gout->big_list = (int2*)p_big;
   a.big_cap = big_cap;
   // owner-computes push: the tables are made once per matrix (ranges of equal in-edge mass, at most kOcWords words
   // wide, about two per workgroup; the big rows; where each big row enters each range)
@@ -1524,7 +1552,7 @@ static grb_info bfs_persistent_args(grb_matrix A, grb_descriptor desc, int profi
       }
     }
   }
-  a.rec = (grb_bfs_level*)p_rec;
+  gout->rec = (grb_bfs_level*)p_rec;
   a.rec_cap = co ? 0 : rec_cap;                              // (per-level records: the blocking call's profiling runs read them)
   a.ticks_to_ms = ticks_to_ms;
   *p_rec_out = p_rec;
@@ -1581,7 +1609,7 @@ static grb_info bfs_persistent_launch(grb_vector v, grb_matrix A, grb_index sour
   LaunchArgs la;
   memset(&la, 0, sizeof(la));
   LaunchCtx lc;
-  GRB_TRY(bfs_persistent_args(A, desc, profile, lane_id, false, &la.g[0], &lc, p_rec_out, trace_out));
+  GRB_TRY(bfs_persistent_args(A, desc, profile, lane_id, false, &la.a, &la.g[0], &lc, p_rec_out, trace_out));
   la.t[0].label = (float*)v->d_val;
   la.t[0].block = (char*)lc.p_zero + (size_t)(*lc.p_blocksel) * lc.block_bytes;
   la.t[0].clean = (char*)lc.p_zero + (size_t)((*lc.p_blocksel) ^ 1) * lc.block_bytes;
@@ -1653,7 +1681,7 @@ static grb_info bfs_co_launch(int ntrav, const CoPend* pend, int width) {
   for (int j = 0; j < n_grids; ++j) {
     void* p_rec = nullptr;
     unsigned long long* trace = nullptr;
-    GRB_TRY(bfs_persistent_args(pend[0].A, pend[0].desc, 0, kMaxLanes + 1 + j, true, &la.g[j], &lc[j], &p_rec, &trace, oc_words));
+    GRB_TRY(bfs_persistent_args(pend[0].A, pend[0].desc, 0, kMaxLanes + 1 + j, true, &la.a, &la.g[j], &lc[j], &p_rec, &trace, oc_words));
   }
   for (int i = 0; i < ntrav; ++i) {
     la.t[i].label = (float*)pend[i].v->d_val;
@@ -1670,10 +1698,23 @@ static grb_info bfs_co_launch(int ntrav, const CoPend* pend, int width) {
   la.ctr_base = g_ring.ctr_base;
   la.ntrav = ntrav; la.n_grids = n_grids; la.G = lc[0].G;
   GRB_TRY(bfs_lanes_fence(c.stream));
+  if (g_ring.co_profile) {
+    while (g_ring.co_ev.size() < g_ring.co_ev_used + 2) {
+      hipEvent_t e;
+      GRB_HIP_TRY(hipEventCreate(&e));
+      g_ring.co_ev.push_back(e);
+    }
+    GRB_HIP_TRY(hipEventRecord(g_ring.co_ev[g_ring.co_ev_used], c.stream));
+  }
   if (T == 512) hipLaunchKernelGGL(bfs_persistent_kernel<512>, dim3(n_grids * la.G), dim3(512), 0, c.stream, la);
   else if (T == 256) hipLaunchKernelGGL(bfs_persistent_kernel<256>, dim3(n_grids * la.G), dim3(256), 0, c.stream, la);
   else hipLaunchKernelGGL(bfs_persistent_kernel<128>, dim3(n_grids * la.G), dim3(128), 0, c.stream, la);
   GRB_HIP_TRY(hipGetLastError());
+  if (g_ring.co_profile) {
+    GRB_HIP_TRY(hipEventRecord(g_ring.co_ev[g_ring.co_ev_used + 1], c.stream));
+    g_ring.co_ev_used += 2;
+    g_ring.co_prof_trav += ntrav;
+  }
   if (ntrav > n_grids) g_ring.ctr_base += (unsigned)ntrav;   // a chained launch draws once per traversal
   for (int j = 0; j < n_grids; ++j) GRB_TRY(bfs_persistent_queued(lc[j]));
   return GRB_SUCCESS;
@@ -1825,6 +1866,33 @@ grb_info grb::bfs_co_flush() {
     if (si != GRB_SUCCESS && si != GRB_NOT_IMPLEMENTED && si != GRB_PANIC) worst = si;
   }
   return worst;
+}
+// HIP events around the launches of several traversals: on != 0 starts collecting (and forgets what was collected);
+// on == 0 stops, waits for the launches and reports their summed duration, their number and the traversals they ran.
+grb_info grb::bfs_co_profile(int on, double* ms_total, int* launches, int* traversals) {
+  GRB_TRY(ring_init());
+  if (on) {
+    GRB_TRY(bfs_co_flush());
+    g_ring.co_profile = true;
+    g_ring.co_ev_used = 0;
+    g_ring.co_prof_trav = 0;
+    return GRB_SUCCESS;
+  }
+  GRB_TRY(bfs_co_flush());
+  g_ring.co_profile = false;
+  double tot = 0;
+  for (size_t i = 0; i + 1 < g_ring.co_ev_used; i += 2) {
+    float ms = 0.f;
+    GRB_HIP_TRY(hipEventSynchronize(g_ring.co_ev[i + 1]));
+    GRB_HIP_TRY(hipEventElapsedTime(&ms, g_ring.co_ev[i], g_ring.co_ev[i + 1]));
+    tot += (double)ms;
+  }
+  if (ms_total) *ms_total = tot;
+  if (launches) *launches = (int)(g_ring.co_ev_used / 2);
+  if (traversals) *traversals = g_ring.co_prof_trav;
+  g_ring.co_ev_used = 0;
+  g_ring.co_prof_trav = 0;
+  return GRB_SUCCESS;
 }
 // Traversals per launch (1 .. kCoMax).  Everything queued so far is launched and waited for first.  Returns the previous value.
 int grb::bfs_co_setting(int set) {

@@ -808,6 +808,7 @@ grb_info bfs_persistent_wait(int slot, int seq, int* levels, int* last_dir, long
 void bfs_host_times(double* enqueue_us, double* wait_us, long long* calls, bool reset);
 int bfs_lanes_setting(int set);                  // traversals in flight at once (grb_bfs_set_lanes); set < 1 only queries
 int bfs_co_setting(int set);                     // traversals per launch (grb_bfs_set_coschedule); set < 1 only queries
+grb_info bfs_co_profile(int on, double* ms_total, int* launches, int* traversals);   // HIP events around those launches
 bool bfs_co_pending();                           // traversals that have a ticket and no launch yet
 grb_info bfs_co_flush();                         // ... launched now (every entry point but the queue's own does this first)
 grb_info bfs_lanes_fence(hipStream_t s);         // s waits for what the lanes have in flight (before a whole-device grid)

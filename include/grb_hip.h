@@ -338,18 +338,24 @@ grb_info grb_bfs_wait(grb_bfs_ticket ticket, grb_bfs_result* result);
  * blocking grb_bfs_fused keeps the whole device (and, issued while lanes are busy, waits for their grids to drain).
  * Changing the number waits for everything queued.  n < 1 only queries.  Returns the previous value. */
 int grb_bfs_set_lanes(int n);
-/* Traversals per LAUNCH (1 .. 4; default 1).  With k > 1 the traversals queued by grb_bfs_fused_enqueue are launched k at
- * a time, side by side in one grid: k sub-grids of one workgroup per CU each (512 threads for two traversals, 256 for
- * three or four), every traversal with its own state, barrier counters and record.  A traversal is barriers and
- * dependent-load chains for half of its time; the CU's wave scheduler fills them with the other traversals' work, and
- * -- unlike lanes -- nothing depends on how the runtime maps streams to hardware queues: it is one launch on the
- * library's stream.  A ticket is issued at once; its launch goes out when k tickets of the same matrix and descriptor
- * have gathered, when one of them is waited for, or when any other entry point is called (so the ordering rules of
- * grb_bfs_fused_enqueue hold unchanged).  Per-traversal labels and result blocks are those of grb_bfs_fused.  Ignored
- * while grb_bfs_set_lanes is above 1.  Changing the number launches and waits for everything queued.  k < 1 only
- * queries.  Returns the previous value.  (No counterpart in the reference, whose loop is one traversal with several
- * host round trips per level: algorithm/bfs.hpp:42-88.) */
+/* Traversals side by side in one LAUNCH (1 .. 8; default 1).  With k > 1 the traversals queued by grb_bfs_fused_enqueue
+ * share launches: a launch is k sub-grids of one workgroup per CU each (512 threads for two, 256 up to four, 128 up to
+ * eight), every sub-grid runs one traversal at a time on state, barrier counters and bitmaps of its own, and when it has
+ * finished one it draws the next of the launch's traversals (up to 48 per launch) from a counter.  A traversal is
+ * barriers and dependent-load chains for half of its time; the CU's wave scheduler fills them with the other
+ * traversals' work, and -- unlike lanes -- nothing depends on how the runtime maps streams to hardware queues: it is one
+ * launch on the library's stream.  A ticket is issued at once; the launch goes out when one of the gathered tickets is
+ * waited for, when any other entry point is called (so the ordering rules of grb_bfs_fused_enqueue hold unchanged),
+ * when a traversal of another matrix or descriptor is queued, or when 48 have gathered.  Per-traversal labels and
+ * result blocks are those of grb_bfs_fused; a traversal's record is written after a barrier of its sub-grid, i.e. when
+ * every label store has completed.  Ignored while grb_bfs_set_lanes is above 1.  Changing the number launches and waits
+ * for everything queued.  k < 1 only queries.  Returns the previous value.  (No counterpart in the reference, whose loop
+ * is one traversal with several host round trips per level: algorithm/bfs.hpp:42-88.) */
 int grb_bfs_set_coschedule(int k);
+/* Measurement: HIP events on the library's stream around every launch of several traversals.  on != 0 starts collecting
+ * (what has gathered is launched first); on == 0 stops, waits for the launches and reports their summed duration, their
+ * number and the traversals they ran (bench.py's roofline block of the co-scheduled sibling). */
+grb_info grb_bfs_coschedule_profile(int on, double* launch_ms_total, int* launches, int* traversals);
 /* Host time (microseconds, summed since the last reset) inside the one-launch traversal's two halves -- queueing the
  * launches / waiting for and unpacking the record -- and the number of traversals; any pointer may be NULL. */
 grb_info grb_bfs_host_times(double* enqueue_us, double* wait_us, long long* calls, int reset);
