@@ -1302,7 +1302,8 @@ struct BfsRing {
   bool ctr_dirty = false;                        // a chained launch did not finish: the counter is anywhere
   // grb_bfs_coschedule_profile: HIP events around the launches of several traversals (measurement passes only)
   bool co_profile = false;
-  std::vector<hipEvent_t> co_ev;                 // pairs
+  std::vector<hipEvent_t>* co_ev = nullptr;      // pairs (on the heap, never freed: the ring stays trivially destructible --
+                                                 // nothing of it may run at exit, when the HIP runtime may be gone)
   size_t co_ev_used = 0;
   int co_prof_trav = 0;
   BfsTicket t[kRing];
@@ -1699,19 +1700,20 @@ static grb_info bfs_co_launch(int ntrav, const CoPend* pend, int width) {
   la.ntrav = ntrav; la.n_grids = n_grids; la.G = lc[0].G;
   GRB_TRY(bfs_lanes_fence(c.stream));
   if (g_ring.co_profile) {
-    while (g_ring.co_ev.size() < g_ring.co_ev_used + 2) {
+    if (!g_ring.co_ev) g_ring.co_ev = new std::vector<hipEvent_t>();
+    while (g_ring.co_ev->size() < g_ring.co_ev_used + 2) {
       hipEvent_t e;
       GRB_HIP_TRY(hipEventCreate(&e));
-      g_ring.co_ev.push_back(e);
+      g_ring.co_ev->push_back(e);
     }
-    GRB_HIP_TRY(hipEventRecord(g_ring.co_ev[g_ring.co_ev_used], c.stream));
+    GRB_HIP_TRY(hipEventRecord((*g_ring.co_ev)[g_ring.co_ev_used], c.stream));
   }
   if (T == 512) hipLaunchKernelGGL(bfs_persistent_kernel<512>, dim3(n_grids * la.G), dim3(512), 0, c.stream, la);
   else if (T == 256) hipLaunchKernelGGL(bfs_persistent_kernel<256>, dim3(n_grids * la.G), dim3(256), 0, c.stream, la);
   else hipLaunchKernelGGL(bfs_persistent_kernel<128>, dim3(n_grids * la.G), dim3(128), 0, c.stream, la);
   GRB_HIP_TRY(hipGetLastError());
   if (g_ring.co_profile) {
-    GRB_HIP_TRY(hipEventRecord(g_ring.co_ev[g_ring.co_ev_used + 1], c.stream));
+    GRB_HIP_TRY(hipEventRecord((*g_ring.co_ev)[g_ring.co_ev_used + 1], c.stream));
     g_ring.co_ev_used += 2;
     g_ring.co_prof_trav += ntrav;
   }
@@ -1883,8 +1885,8 @@ grb_info grb::bfs_co_profile(int on, double* ms_total, int* launches, int* trave
   double tot = 0;
   for (size_t i = 0; i + 1 < g_ring.co_ev_used; i += 2) {
     float ms = 0.f;
-    GRB_HIP_TRY(hipEventSynchronize(g_ring.co_ev[i + 1]));
-    GRB_HIP_TRY(hipEventElapsedTime(&ms, g_ring.co_ev[i], g_ring.co_ev[i + 1]));
+    GRB_HIP_TRY(hipEventSynchronize((*g_ring.co_ev)[i + 1]));
+    GRB_HIP_TRY(hipEventElapsedTime(&ms, (*g_ring.co_ev)[i], (*g_ring.co_ev)[i + 1]));
     tot += (double)ms;
   }
   if (ms_total) *ms_total = tot;
