@@ -33,6 +33,12 @@ class AlgoResult(C.Structure):
     _fields_ = [("iterations", C.c_int), ("tight_ms", C.c_float), ("last_value", C.c_double)]
 
 
+class TcCoreResult(C.Structure):
+    _fields_ = [("core_rows", C.c_int32), ("min_row_length", C.c_int32), ("core_entries", C.c_int64), ("count", C.c_int64),
+                ("checksum", C.c_uint64), ("build_ms", C.c_float), ("product_ms", C.c_float), ("tiles", C.c_int32),
+                ("tiles_mfma", C.c_int32), ("tiles_by_density", C.c_int32 * 10)]
+
+
 class BfsLevel(C.Structure):
     _fields_ = [("direction", C.c_int32), ("frontier", C.c_int32), ("frontier_edges", C.c_int64),
                 ("discovered", C.c_int32), ("ms", C.c_float)]
@@ -165,6 +171,7 @@ _SIGS = {
     "grb_reduce_matrix_scalar": [C.POINTER(_d), _i, _i, _vp, _vp],
     "grb_matrix_tril": [_vp, _vp, _vp],
     "grb_tc": [C.POINTER(C.c_int64), _vp, _vp, _vp, C.POINTER(AlgoResult)],
+    "grb_tc_dense_core": [_vp, _i, _i, _i, C.POINTER(TcCoreResult)],
     "grb_sssp": [_vp, _vp, _i, _vp, C.POINTER(AlgoResult)],
     "grb_pr": [_vp, _vp, _f, _f, _vp, C.POINTER(AlgoResult)],
     "grb_k_spmv": [_vp, _i, _i, _vp, _vp, _i, _i, _vp],

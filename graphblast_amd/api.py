@@ -561,6 +561,16 @@ def tc(A, B, desc):
     return info, n.value, dict(tight_ms=res.tight_ms)
 
 
+def tc_dense_core(L, k_want, method=0, dense_from=0):
+    """grb_tc_dense_core: the product C<L> = L (+.x) L^T restricted to the k_want longest rows of L, as K x K bit rows.
+    method 0 popcount, 1 MFMA (v_mfma_i32_16x16x64_i8), 2 MFMA for tiles of >= dense_from mask entries.  Returns (info, dict)."""
+    res = _lib.TcCoreResult()
+    info = _lib.load().grb_tc_dense_core(_h(L), int(k_want), int(method), int(dense_from), C.byref(res))
+    return info, dict(core_rows=res.core_rows, min_row_length=res.min_row_length, core_entries=res.core_entries, count=res.count,
+                      checksum=res.checksum, build_ms=res.build_ms, product_ms=res.product_ms, tiles=res.tiles,
+                      tiles_mfma=res.tiles_mfma, tiles_by_density=list(res.tiles_by_density))
+
+
 def traceMxmTranspose(op, A, B, desc):
     out = C.c_double(0)
     info = _lib.load().grb_trace_mxm_transpose(C.byref(out), _semiring_id(op), _h(A), _h(B), _h(desc))

@@ -1,0 +1,427 @@
+// mxm_core.hip -- the DENSE CORE of the masked product C<L> = L (+.x) L^T (triangle counting, algorithm/tc.hpp:15-54;
+// the reference's kernel: backend/cuda/kernels/spgemm.hpp:17-79, one sorted-list intersection per mask entry).
+//
+// In a power-law graph most of that product's work sits between a few thousand rows: on the RMAT ef-28 stand-in of
+// config 5 the 16 Ki longest rows of L hold 5 % of the vertices' ... and 80 % of the list elements the pivot kernels of
+// mxm.hip stream.  Among those rows the lists are dense enough to be BIT rows: H[r][c] = 1 when the r-th core row has
+// the c-th core row's vertex as an entry (ranks follow the vertex order, so H is strictly lower triangular like L).
+// The product restricted to the core is then
+//       C_H(i, j) = sum_k H[i][k] * H[j][k]        for the mask's entries (i, j) = the set bits of H itself,
+// which is a dense K x K x K problem with two ways to run it on a CU:
+//   popcount   a lane per MASK ENTRY, 32 columns of k per AND + v_bcnt: work = entries x K / 32, nothing is computed
+//              for the pairs (i, j) that are not entries
+//   MFMA       v_mfma_i32_16x16x64_i8 on 0/1 bytes expanded from the bit rows in registers: every pair of a 128 x 128
+//              tile is computed, 16 384 multiply-adds per instruction, and the mask is applied to the finished tile
+// The first wins where the mask is sparse, the second where it is dense; a tile's entry count decides (method 2).
+// Both read the same bit rows through the same LDS staging and write the same per-entry results, so the A/B is a
+// matter of calling grb_tc_dense_core twice (tools/tc_core_ab.py; tests/test_gpu_mxm.py compares both with numpy).
+#include "common.hpp"
+
+namespace grb {
+
+constexpr int kCoreTile = 128;        // rows (and columns) of an output tile: a 256-thread workgroup, 2 x 2 waves of 64 x 64
+constexpr int kCoreChunkW = 32;       // words of a bit row staged per step: 1024 values of k
+constexpr int kCorePitch = kCoreChunkW + 1;   // (odd pitch: the 16 rows a wave instruction touches fall into 16 banks)
+constexpr int kCoreBatch = 4096;      // mask entries of a tile the popcount kernel carries at once (16 per thread)
+typedef int CoreV4 __attribute__((ext_vector_type(4)));
+
+// row lengths, capped, as a histogram (LDS-private per workgroup): the host reads the threshold that leaves <= K rows
+__global__ __launch_bounds__(1024) void core_len_hist_kernel(const Index* __restrict__ ptr, Index n, unsigned int* __restrict__ hist) {
+  __shared__ unsigned int h[16384];
+  for (int i = threadIdx.x; i < 16384; i += blockDim.x) h[i] = 0u;
+  __syncthreads();
+  for (Index v = (Index)blockIdx.x * blockDim.x + threadIdx.x; v < n; v += (Index)gridDim.x * blockDim.x) {
+    const Index d = ptr[v + 1] - ptr[v];
+    atomicAdd(&h[d < 16383 ? d : 16383], 1u);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 16384; i += blockDim.x)
+    if (h[i]) atomicAdd(&hist[i], h[i]);
+}
+__global__ void core_flag_kernel(const Index* __restrict__ ptr, Index n, Index theta, unsigned int* __restrict__ flag /* [n + 1] */) {
+  for (Index v = (Index)blockIdx.x * blockDim.x + threadIdx.x; v <= n; v += (Index)gridDim.x * blockDim.x)
+    flag[v] = (v < n && ptr[v + 1] - ptr[v] >= theta) ? 1u : 0u;
+}
+__global__ void core_rank_kernel(const Index* __restrict__ ptr, Index n, Index theta, const unsigned int* __restrict__ before,
+                                 int* __restrict__ rank, Index* __restrict__ rows) {
+  for (Index v = (Index)blockIdx.x * blockDim.x + threadIdx.x; v < n; v += (Index)gridDim.x * blockDim.x) {
+    const bool core = ptr[v + 1] - ptr[v] >= theta;
+    rank[v] = core ? (int)before[v] : -1;
+    if (core) rows[before[v]] = v;
+  }
+}
+// the bit rows: a wave per core row walks the row's entries, an entry that is a core vertex sets its bit
+__global__ __launch_bounds__(kBlock) void core_fill_kernel(const Index* __restrict__ ptr, const Index* __restrict__ ind,
+                                                           const Index* __restrict__ rows, int K, const int* __restrict__ rank,
+                                                           unsigned int* __restrict__ H, int Wr) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int nw = gridDim.x * (blockDim.x >> 6);
+  for (int r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); r < K; r += nw) {
+    const Index x = rows[r];
+    const Index e = ptr[x + 1];
+    for (Index p = ptr[x] + lane; p < e; p += kWave) {
+      const int c = rank[ind[p]];
+      if (c >= 0) atomicOr(&H[(size_t)r * Wr + (c >> 5)], 1u << (c & 31));
+    }
+  }
+}
+// per row: how many bits stand before each word (the per-entry results are stored in row-major order of the set bits)
+__global__ __launch_bounds__(kBlock) void core_prefix_kernel(const unsigned int* __restrict__ H, int K, int Wr,
+                                                             unsigned short* __restrict__ pre, unsigned int* __restrict__ rowcnt /* [K + 1] */) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int nw = gridDim.x * (blockDim.x >> 6);
+  for (int r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); r <= K; r += nw) {
+    if (r == K) { if (lane == 0) rowcnt[K] = 0u; continue; }
+    unsigned int run = 0u;
+    for (int w0 = 0; w0 < Wr; w0 += kWave) {
+      const int w = w0 + lane;
+      const unsigned int c = w < Wr ? (unsigned int)__popc(H[(size_t)r * Wr + w]) : 0u;
+      const unsigned int incl = wave_incl_scan_u32(c);
+      if (w < Wr) pre[(size_t)r * Wr + w] = (unsigned short)(run + incl - c);
+      run += (unsigned int)__builtin_amdgcn_readlane((int)incl, kWave - 1);
+    }
+    if (lane == 0) rowcnt[r] = run;
+  }
+}
+// mask entries per 128 x 128 tile (bi >= bj), tile t = bi (bi + 1) / 2 + bj
+__global__ __launch_bounds__(kBlock) void core_tile_count_kernel(const unsigned int* __restrict__ H, int K, int Wr, int nt,
+                                                                 unsigned int* __restrict__ tile_cnt) {
+  const int ntile = nt * (nt + 1) / 2;
+  for (int t = blockIdx.x; t < ntile; t += gridDim.x) {
+    int bi = (int)((sqrtf(8.f * (float)t + 1.f) - 1.f) * 0.5f);
+    while (bi * (bi + 1) / 2 > t) --bi;
+    while ((bi + 1) * (bi + 2) / 2 <= t) ++bi;
+    const int bj = t - bi * (bi + 1) / 2;
+    unsigned int c = 0u;
+    for (int q = threadIdx.x; q < kCoreTile * (kCoreTile / 32); q += blockDim.x) {
+      const int row = bi * kCoreTile + (q >> 2), w = bj * (kCoreTile / 32) + (q & 3);
+      if (row < K) c += (unsigned int)__popc(H[(size_t)row * Wr + w]);
+    }
+    c = wave_sum_u32(c);
+    if ((threadIdx.x & (kWave - 1)) == 0 && c) atomicAdd(&tile_cnt[t], c);
+  }
+}
+
+struct CoreTile { unsigned short bi, bj; };
+
+// where the result of entry (row i, column j) goes
+__device__ inline unsigned int core_out_pos(const unsigned int* __restrict__ H, const unsigned short* __restrict__ pre,
+                                            const unsigned int* __restrict__ rowstart, int Wr, int i, int j) {
+  const size_t at = (size_t)i * Wr + (j >> 5);
+  return rowstart[i] + (unsigned int)pre[at] + (unsigned int)__popc(H[at] & ((1u << (j & 31)) - 1u));
+}
+
+// stages `nrows` bit rows starting at row0, words [w0, w0 + kCoreChunkW), into s[row][kCorePitch]
+__device__ inline void core_stage(unsigned int* s, const unsigned int* __restrict__ H, int K, int Wr, int row0, int w0, int tid) {
+  for (int q = tid; q < kCoreTile * kCoreChunkW; q += 256) {
+    const int r = q / kCoreChunkW, w = q % kCoreChunkW;
+    const int row = row0 + r;
+    s[r * kCorePitch + w] = (row < K && w0 + w < Wr) ? H[(size_t)row * Wr + w0 + w] : 0u;
+  }
+}
+
+// ---- popcount: a thread per mask entry of the tile, 16 entries per thread at a time
+__global__ __launch_bounds__(256) void core_popc_kernel(const unsigned int* __restrict__ H, const unsigned short* __restrict__ pre,
+                                                        const unsigned int* __restrict__ rowstart, int K, int Wr,
+                                                        const CoreTile* __restrict__ tiles, int ntiles, int* __restrict__ out,
+                                                        unsigned long long* __restrict__ total) {
+  __shared__ unsigned int sA[kCoreTile * kCorePitch], sB[kCoreTile * kCorePitch];
+  __shared__ unsigned int sM[kCoreTile][kCoreTile / 32];
+  __shared__ unsigned int sStart[kCoreTile + 1];
+  __shared__ unsigned short sEnt[kCoreBatch];
+  const int tid = threadIdx.x;
+  unsigned long long mine = 0ull;
+  for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    const int bi = tiles[t].bi, bj = tiles[t].bj;
+    const int row0 = bi * kCoreTile, col0 = bj * kCoreTile;
+    __syncthreads();
+    for (int q = tid; q < kCoreTile * (kCoreTile / 32); q += 256) {
+      const int row = row0 + (q >> 2);
+      sM[q >> 2][q & 3] = row < K ? H[(size_t)row * Wr + (col0 >> 5) + (q & 3)] : 0u;
+    }
+    __syncthreads();
+    if (tid < kWave) {                                       // the tile's entries numbered row-major: row starts by one wave
+      unsigned int run = 0u;
+      for (int r0 = 0; r0 < kCoreTile; r0 += kWave) {
+        const int r = r0 + tid;
+        const unsigned int c = (unsigned int)(__popc(sM[r][0]) + __popc(sM[r][1]) + __popc(sM[r][2]) + __popc(sM[r][3]));
+        const unsigned int incl = wave_incl_scan_u32(c);
+        sStart[r] = run + incl - c;
+        run += (unsigned int)__builtin_amdgcn_readlane((int)incl, kWave - 1);
+      }
+      if (tid == 0) sStart[kCoreTile] = run;
+    }
+    __syncthreads();
+    const int E = (int)sStart[kCoreTile];
+    const int nchunk = (col0 + kCoreTile + 32 * kCoreChunkW - 1) / (32 * kCoreChunkW);   // bits of row j stand below column j
+    for (int e0 = 0; e0 < E; e0 += kCoreBatch) {
+      __syncthreads();
+      if (tid < kCoreTile) {                                 // this batch's entries, (row << 8 | column) inside the tile
+        int at = (int)sStart[tid] - e0;
+#pragma unroll
+        for (int w = 0; w < kCoreTile / 32; ++w)
+          for (unsigned int b = sM[tid][w]; b; b &= b - 1u, ++at)
+            if (at >= 0 && at < kCoreBatch) sEnt[at] = (unsigned short)((tid << 8) | (w * 32 + __ffs((int)b) - 1));
+      }
+      __syncthreads();
+      const int nb = E - e0 < kCoreBatch ? E - e0 : kCoreBatch;
+      unsigned int acc[kCoreBatch / 256];
+#pragma unroll
+      for (int q = 0; q < kCoreBatch / 256; ++q) acc[q] = 0u;
+      for (int c = 0; c < nchunk; ++c) {
+        __syncthreads();
+        core_stage(sA, H, K, Wr, row0, c * kCoreChunkW, tid);
+        core_stage(sB, H, K, Wr, col0, c * kCoreChunkW, tid);
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < kCoreBatch / 256; ++q) {
+          const int e = q * 256 + tid;
+          if (e < nb) {
+            const unsigned int ij = sEnt[e];
+            const unsigned int* a = &sA[(ij >> 8) * kCorePitch];
+            const unsigned int* b = &sB[(ij & 255u) * kCorePitch];
+            unsigned int s = acc[q];
+#pragma unroll
+            for (int w = 0; w < kCoreChunkW; ++w) s += (unsigned int)__popc(a[w] & b[w]);
+            acc[q] = s;
+          }
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < kCoreBatch / 256; ++q) {
+        const int e = q * 256 + tid;
+        if (e < nb) {
+          const unsigned int ij = sEnt[e];
+          out[core_out_pos(H, pre, rowstart, Wr, row0 + (int)(ij >> 8), col0 + (int)(ij & 255u))] = (int)acc[q];
+          mine += acc[q];
+        }
+      }
+    }
+  }
+  mine = wave_sum_u64(mine);
+  if ((tid & (kWave - 1)) == 0 && mine) atomicAdd(total, mine);
+}
+
+// ---- MFMA: sixteen 0/1 bytes from sixteen bits (four bits to four bytes by one multiply: n + (n << 7) + (n << 14) +
+// (n << 21) puts bit b of the nibble at bit 8 b)
+__device__ __forceinline__ CoreV4 core_expand16(unsigned int h) {
+  CoreV4 d;
+  d.x = (int)(((h & 0xfu) * 0x00204081u) & 0x01010101u);
+  d.y = (int)((((h >> 4) & 0xfu) * 0x00204081u) & 0x01010101u);
+  d.z = (int)((((h >> 8) & 0xfu) * 0x00204081u) & 0x01010101u);
+  d.w = (int)((((h >> 12) & 0xfu) * 0x00204081u) & 0x01010101u);
+  return d;
+}
+// v_mfma_i32_16x16x64_i8: lane l holds, of A (16 x 64), row l % 16 and the sixteen values k = 16 (l / 16) .. + 15; of B
+// (64 x 16) column l % 16 and the same sixteen k; of C / D (16 x 16) column l % 16 and rows 4 (l / 16) .. + 3
+// (tests/test_gpu_mxm.py::test_dense_core checks the kernel built on this against numpy).
+__global__ __launch_bounds__(256) void core_mfma_kernel(const unsigned int* __restrict__ H, const unsigned short* __restrict__ pre,
+                                                        const unsigned int* __restrict__ rowstart, int K, int Wr,
+                                                        const CoreTile* __restrict__ tiles, int ntiles, int* __restrict__ out,
+                                                        unsigned long long* __restrict__ total) {
+  __shared__ unsigned int sA[kCoreTile * kCorePitch], sB[kCoreTile * kCorePitch];
+  const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
+  const int wi = wave >> 1, wj = wave & 1;                   // this wave's 64 x 64 quarter of the tile
+  const int l16 = lane & 15, kq = lane >> 4;                 // row / column inside a 16 x 16 block; which sixteen of the 64 k
+  unsigned long long mine = 0ull;
+  for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    const int bi = tiles[t].bi, bj = tiles[t].bj;
+    const int row0 = bi * kCoreTile, col0 = bj * kCoreTile;
+    const int nchunk = (col0 + kCoreTile + 32 * kCoreChunkW - 1) / (32 * kCoreChunkW);
+    CoreV4 acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) acc[a][b] = CoreV4{0, 0, 0, 0};
+    for (int c = 0; c < nchunk; ++c) {
+      __syncthreads();
+      core_stage(sA, H, K, Wr, row0, c * kCoreChunkW, tid);
+      core_stage(sB, H, K, Wr, col0, c * kCoreChunkW, tid);
+      __syncthreads();
+#pragma unroll 2
+      for (int ks = 0; ks < kCoreChunkW / 2; ++ks) {         // 64 values of k per step: two words of every row
+        const int w = 2 * ks + (kq >> 1), sh = 16 * (kq & 1);
+        CoreV4 fa[4], fb[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) fa[a] = core_expand16((sA[(wi * 64 + a * 16 + l16) * kCorePitch + w] >> sh) & 0xffffu);
+#pragma unroll
+        for (int b = 0; b < 4; ++b) fb[b] = core_expand16((sB[(wj * 64 + b * 16 + l16) * kCorePitch + w] >> sh) & 0xffffu);
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+          for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[a], fb[b], acc[a][b], 0, 0, 0);
+      }
+    }
+    // the mask: only the pairs that are entries of L are results
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const int j = col0 + wj * 64 + b * 16 + l16;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = row0 + wi * 64 + a * 16 + 4 * kq + r;
+          if (i < K && j < K) {
+            const size_t at = (size_t)i * Wr + (j >> 5);
+            const unsigned int word = H[at];
+            if ((word >> (j & 31)) & 1u) {
+              const int val = acc[a][b][r];
+              out[rowstart[i] + (unsigned int)pre[at] + (unsigned int)__popc(word & ((1u << (j & 31)) - 1u))] = val;
+              mine += (unsigned long long)(unsigned int)val;
+            }
+          }
+        }
+      }
+  }
+  mine = wave_sum_u64(mine);
+  if (lane == 0 && mine) atomicAdd(total, mine);
+}
+
+// position-weighted sum of the per-entry results: equal for two runs only if (almost surely) every entry is
+__global__ __launch_bounds__(kBlock) void core_checksum_kernel(const int* __restrict__ out, long long n, unsigned long long* __restrict__ sum) {
+  unsigned long long s = 0ull;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    s += (unsigned long long)(unsigned int)out[i] * (unsigned long long)((unsigned int)i * 2654435761u | 1u);
+  s = wave_sum_u64(s);
+  if ((threadIdx.x & (kWave - 1)) == 0 && s) atomicAdd(sum, s);
+}
+
+}  // namespace grb
+
+using namespace grb;
+
+extern "C" grb_info grb_tc_dense_core(grb_matrix L, int k_want, int method, int dense_from, grb_tc_core_result* res) { GRB_API_ENTER();
+  if (!L || !res) return GRB_NULL_POINTER;
+  if (!L->built || !L->csr.ptr) return GRB_UNINITIALIZED_OBJECT;
+  if (L->nrows != L->ncols) return GRB_DIMENSION_MISMATCH;
+  if (k_want < 1 || method < 0 || method > 2) return GRB_INVALID_VALUE;
+  memset(res, 0, sizeof(*res));
+  GRB_TRY(ctx_init());
+  Context& c = ctx();
+  hipStream_t s = c.stream;
+  const Index n = L->nrows;
+  if (k_want > 65535) k_want = 65535;                       // (the per-word prefix counts are 16-bit)
+  hipEvent_t ev[3];
+  for (auto& e : ev) GRB_HIP_TRY(hipEventCreate(&e));
+  struct EvFree { hipEvent_t* e; ~EvFree() { for (int i = 0; i < 3; ++i) (void)hipEventDestroy(e[i]); } } ev_free{ev};
+  struct DevFree { std::vector<void*> p; ~DevFree() { for (void* q : p) (void)hipFree(q); } } mem;
+  auto dmalloc = [&](void** p, size_t bytes) -> grb_info {
+    GRB_HIP_TRY(hipMalloc(p, bytes ? bytes : 4));
+    mem.p.push_back(*p);
+    return GRB_SUCCESS;
+  };
+  GRB_HIP_TRY(hipEventRecord(ev[0], s));
+  // ---- the core rows: the k_want longest (all rows of a length are taken or none: theta is a length)
+  unsigned int* d_hist = nullptr;
+  GRB_TRY(dmalloc((void**)&d_hist, 4 * 16384));
+  GRB_HIP_TRY(hipMemsetAsync(d_hist, 0, 4 * 16384, s));
+  hipLaunchKernelGGL(core_len_hist_kernel, dim3(c.num_cu), dim3(1024), 0, s, L->csr.ptr, n, d_hist);
+  GRB_HIP_TRY(hipGetLastError());
+  std::vector<unsigned int> hist(16384);
+  GRB_HIP_TRY(hipMemcpyAsync(hist.data(), d_hist, 4 * 16384, hipMemcpyDeviceToHost, s));
+  GRB_HIP_TRY(hipStreamSynchronize(s));
+  Index theta = 16383;
+  long long have = hist[16383];
+  if (have > k_want) return GRB_NOT_IMPLEMENTED;             // more than k_want rows beyond the histogram's last bin
+  while (theta > 1 && have + (long long)hist[theta - 1] <= (long long)k_want) { --theta; have += hist[theta]; }
+  const int K = (int)have;
+  res->core_rows = K;
+  res->min_row_length = theta;
+  if (K < 2) return GRB_SUCCESS;
+  unsigned int* d_flag = nullptr;
+  int* d_rank = nullptr;
+  Index* d_rows = nullptr;
+  GRB_TRY(dmalloc((void**)&d_flag, 4 * ((size_t)n + 1)));
+  GRB_TRY(dmalloc((void**)&d_rank, 4 * (size_t)n));
+  GRB_TRY(dmalloc((void**)&d_rows, 4 * (size_t)K));
+  hipLaunchKernelGGL(core_flag_kernel, dim3(stream_grid((long long)n + 1)), dim3(kBlock), 0, s, L->csr.ptr, n, theta, d_flag);
+  GRB_HIP_TRY(hipGetLastError());
+  GRB_TRY(device_exclusive_scan_u32(d_flag, (long long)n + 1));
+  hipLaunchKernelGGL(core_rank_kernel, dim3(stream_grid(n)), dim3(kBlock), 0, s, L->csr.ptr, n, theta, (const unsigned int*)d_flag, d_rank,
+                     d_rows);
+  GRB_HIP_TRY(hipGetLastError());
+  // ---- the bit rows (padded to whole staging chunks), the per-word prefix counts, the rows' first result
+  const int nt = (K + kCoreTile - 1) / kCoreTile;
+  const int Wr = ((nt * kCoreTile / 32 + kCoreChunkW - 1) / kCoreChunkW) * kCoreChunkW;
+  unsigned int* d_H = nullptr;
+  unsigned short* d_pre = nullptr;
+  unsigned int* d_rowstart = nullptr;
+  GRB_TRY(dmalloc((void**)&d_H, 4 * (size_t)K * Wr));
+  GRB_TRY(dmalloc((void**)&d_pre, 2 * (size_t)K * Wr));
+  GRB_TRY(dmalloc((void**)&d_rowstart, 4 * ((size_t)K + 1)));
+  GRB_HIP_TRY(hipMemsetAsync(d_H, 0, 4 * (size_t)K * Wr, s));
+  hipLaunchKernelGGL(core_fill_kernel, dim3(stream_grid((long long)K * kWave)), dim3(kBlock), 0, s, L->csr.ptr, L->csr.ind,
+                     (const Index*)d_rows, K, (const int*)d_rank, d_H, Wr);
+  hipLaunchKernelGGL(core_prefix_kernel, dim3(stream_grid((long long)(K + 1) * kWave)), dim3(kBlock), 0, s, (const unsigned int*)d_H, K, Wr,
+                     d_pre, d_rowstart);
+  GRB_HIP_TRY(hipGetLastError());
+  GRB_TRY(device_exclusive_scan_u32(d_rowstart, (long long)K + 1));
+  unsigned int nent = 0;
+  GRB_HIP_TRY(hipMemcpyAsync(&nent, d_rowstart + K, 4, hipMemcpyDeviceToHost, s));
+  // ---- the tiles: entry counts decide who takes a tile; heaviest (most columns of k) first
+  const int ntile_all = nt * (nt + 1) / 2;
+  unsigned int* d_tcnt = nullptr;
+  GRB_TRY(dmalloc((void**)&d_tcnt, 4 * (size_t)ntile_all));
+  GRB_HIP_TRY(hipMemsetAsync(d_tcnt, 0, 4 * (size_t)ntile_all, s));
+  hipLaunchKernelGGL(core_tile_count_kernel, dim3(ntile_all < 4096 ? ntile_all : 4096), dim3(kBlock), 0, s, (const unsigned int*)d_H, K, Wr, nt,
+                     d_tcnt);
+  GRB_HIP_TRY(hipGetLastError());
+  std::vector<unsigned int> tcnt((size_t)ntile_all);
+  GRB_HIP_TRY(hipMemcpyAsync(tcnt.data(), d_tcnt, 4 * (size_t)ntile_all, hipMemcpyDeviceToHost, s));
+  GRB_HIP_TRY(hipStreamSynchronize(s));
+  res->core_entries = (int64_t)nent;
+  std::vector<CoreTile> t_popc, t_mfma;
+  const unsigned int from = method == 0 ? 0xffffffffu : method == 1 ? 1u : (unsigned int)(dense_from > 0 ? dense_from : 1);
+  for (int bi = nt - 1; bi >= 0; --bi)
+    for (int bj = bi; bj >= 0; --bj) {                       // (columns of k a tile needs grow with bj)
+      const unsigned int e = tcnt[(size_t)bi * (bi + 1) / 2 + bj];
+      if (!e) continue;
+      ++res->tiles;
+      const int decile = (int)((unsigned long long)e * 10ull / (unsigned long long)(kCoreTile * kCoreTile));
+      ++res->tiles_by_density[decile > 9 ? 9 : decile];
+      (e >= from ? t_mfma : t_popc).push_back(CoreTile{(unsigned short)bi, (unsigned short)bj});
+    }
+  auto by_work = [](const CoreTile& x, const CoreTile& y) { return x.bj > y.bj; };
+  std::stable_sort(t_popc.begin(), t_popc.end(), by_work);
+  std::stable_sort(t_mfma.begin(), t_mfma.end(), by_work);
+  res->tiles_mfma = (int)t_mfma.size();
+  CoreTile *d_tp = nullptr, *d_tm = nullptr;
+  GRB_TRY(dmalloc((void**)&d_tp, sizeof(CoreTile) * t_popc.size()));
+  GRB_TRY(dmalloc((void**)&d_tm, sizeof(CoreTile) * t_mfma.size()));
+  if (!t_popc.empty()) GRB_HIP_TRY(hipMemcpyAsync(d_tp, t_popc.data(), sizeof(CoreTile) * t_popc.size(), hipMemcpyHostToDevice, s));
+  if (!t_mfma.empty()) GRB_HIP_TRY(hipMemcpyAsync(d_tm, t_mfma.data(), sizeof(CoreTile) * t_mfma.size(), hipMemcpyHostToDevice, s));
+  int* d_out = nullptr;
+  unsigned long long* d_tot = nullptr;
+  GRB_TRY(dmalloc((void**)&d_out, 4 * (size_t)nent));
+  GRB_TRY(dmalloc((void**)&d_tot, 16));
+  GRB_HIP_TRY(hipMemsetAsync(d_out, 0xff, 4 * (size_t)nent, s));   // (an entry nobody wrote shows in the checksum)
+  GRB_HIP_TRY(hipMemsetAsync(d_tot, 0, 16, s));
+  GRB_HIP_TRY(hipEventRecord(ev[1], s));
+  // ---- the product
+  const int wg = 2 * c.num_cu;
+  if (!t_popc.empty()) {
+    hipLaunchKernelGGL(core_popc_kernel, dim3((int)t_popc.size() < wg ? (int)t_popc.size() : wg), dim3(256), 0, s, (const unsigned int*)d_H,
+                       (const unsigned short*)d_pre, (const unsigned int*)d_rowstart, K, Wr, (const CoreTile*)d_tp, (int)t_popc.size(), d_out,
+                       d_tot);
+    GRB_HIP_TRY(hipGetLastError());
+  }
+  if (!t_mfma.empty()) {
+    hipLaunchKernelGGL(core_mfma_kernel, dim3((int)t_mfma.size() < wg ? (int)t_mfma.size() : wg), dim3(256), 0, s, (const unsigned int*)d_H,
+                       (const unsigned short*)d_pre, (const unsigned int*)d_rowstart, K, Wr, (const CoreTile*)d_tm, (int)t_mfma.size(), d_out,
+                       d_tot);
+    GRB_HIP_TRY(hipGetLastError());
+  }
+  GRB_HIP_TRY(hipEventRecord(ev[2], s));
+  if (nent) {
+    hipLaunchKernelGGL(core_checksum_kernel, dim3(stream_grid((long long)nent)), dim3(kBlock), 0, s, (const int*)d_out, (long long)nent, d_tot + 1);
+    GRB_HIP_TRY(hipGetLastError());
+  }
+  unsigned long long tot[2] = {0ull, 0ull};
+  GRB_HIP_TRY(hipMemcpyAsync(tot, d_tot, 16, hipMemcpyDeviceToHost, s));
+  GRB_HIP_TRY(hipStreamSynchronize(s));
+  res->count = (int64_t)tot[0];
+  res->checksum = tot[1];
+  GRB_HIP_TRY(hipEventElapsedTime(&res->build_ms, ev[0], ev[1]));
+  GRB_HIP_TRY(hipEventElapsedTime(&res->product_ms, ev[1], ev[2]));
+  return GRB_SUCCESS;
+}

@@ -565,6 +565,28 @@ int grb_cc_set_fused(int on);
 /* algorithm::tc (algorithm/tc.hpp:15-54): A = lower triangle (int), B = buffer matrix. */
 grb_info grb_tc(int64_t* ntris, grb_matrix A, grb_matrix B, grb_descriptor desc, grb_algo_result* result);
 
+/* The DENSE CORE of that product (csrc/mxm_core.hip): the k_want longest rows of the lower triangle L (all rows of a
+ * length or none) as K x K bit rows H, and C_H(i, j) = sum_k H[i][k] H[j][k] for the entries (i, j) of L between core
+ * rows -- the part of C<L> = L (+.x) L^T (algorithm/tc.hpp:15-54, kernels/spgemm.hpp:17-79) in which the lists are
+ * dense enough to be bit rows.  method 0: a lane per mask entry, AND + popcount over 32 columns at a time; method 1:
+ * v_mfma_i32_16x16x64_i8 on 0/1 bytes expanded from the bit rows, every pair of a 128 x 128 tile computed and the mask
+ * applied to the finished tile; method 2: MFMA for the tiles with at least dense_from mask entries (of 16 384), popcount
+ * for the others.  count = sum of C_H over those entries; checksum = position-weighted sum of the per-entry results (equal
+ * across methods only if every entry is).  No counterpart in the reference (SURVEY.md 8(f)2 sketches it). */
+typedef struct {
+  int32_t  core_rows;          /* K */
+  int32_t  min_row_length;     /* rows of at least this many entries are core rows */
+  int64_t  core_entries;       /* entries of L between core rows = results */
+  int64_t  count;
+  uint64_t checksum;
+  float    build_ms;           /* HIP events: ranks, bit rows, prefix counts, tile list */
+  float    product_ms;         /* HIP events: the product kernels alone */
+  int32_t  tiles;              /* 128 x 128 tiles with at least one entry */
+  int32_t  tiles_mfma;         /* ... of which the MFMA kernel took */
+  int32_t  tiles_by_density[10];   /* those tiles by tenths of 16 384 entries */
+} grb_tc_core_result;
+grb_info grb_tc_dense_core(grb_matrix L, int k_want, int method, int dense_from, grb_tc_core_result* res);
+
 /* ---- The remaining drivers of graphblas/algorithm/  and the two extension
  * operations only they use. */
 /* scatter   operations.hpp:748-761 -> backend :1110-1142 (scatter.hpp:10-82): w[(Index)u[k]] = val

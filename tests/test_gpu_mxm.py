@@ -154,3 +154,52 @@ def test_result_matrix_reused_and_multiplied(hb):
         dense[np.repeat(np.arange(n), np.diff(cp)), ci] = cv
         assert np.array_equal(hb.dense_values(w).astype(np.float64), dense @ u.astype(np.float64))
 
+
+
+@pytest.mark.parametrize("scale,k_want", [(11, 200), (13, 700), (14, 2100)])
+def test_dense_core(hb, scale, k_want):
+    """grb_tc_dense_core (csrc/mxm_core.hip): the product C<L> = L (+.x) L^T restricted to the longest rows of L, as bit
+    rows -- by AND + popcount per mask entry, by v_mfma_i32_16x16x64_i8 on expanded 0/1 bytes with the mask applied to
+    the finished tile, and by both (MFMA for the denser tiles).  All three against numpy's dense product on the same
+    core: the count, the number of entries, and a position-weighted checksum of the per-entry results."""
+    from graphblast_amd.graphgen import rmat_edges, finalize_edges
+    g = hb.g
+    s, d, n = rmat_edges(scale, 24, seed=11)
+    gr = finalize_edges(s, d, n, symmetrize=True)
+    ptr, ind = gr["csr"]
+    rows = np.repeat(np.arange(n), np.diff(ptr))
+    keep = ind < rows
+    li, lj = rows[keep], ind[keep]
+    lptr = np.zeros(n + 1, dtype=np.int32)
+    np.cumsum(np.bincount(li, minlength=n), out=lptr[1:])
+    L = g.Matrix(n, n, np.int32)
+    assert L.build_csr(lptr, lj.astype(np.int32), np.ones(lj.size, dtype=np.int32)) == 0
+    got = {}
+    for method, dense_from in ((0, 0), (1, 0), (2, 600), (2, 3000)):
+        info, r = g.tc_dense_core(L, k_want, method, dense_from)
+        assert info == 0, (method, info)
+        got[(method, dense_from)] = r
+    r0 = got[(0, 0)]
+    K, theta = r0["core_rows"], r0["min_row_length"]
+    dl = np.diff(lptr)
+    core = np.nonzero(dl >= theta)[0]
+    assert K == core.size and 2 <= K <= k_want
+    assert np.count_nonzero(dl >= theta - 1) > k_want or theta == 1       # the threshold is the lowest that fits
+    rank = np.full(n, -1)
+    rank[core] = np.arange(K)
+    H = np.zeros((K, K), dtype=np.int64)
+    cc = (rank[li] >= 0) & (rank[lj] >= 0)
+    H[rank[li[cc]], rank[lj[cc]]] = 1
+    P = (H @ H.T) * H                                                      # the mask: L's own entries between core rows
+    ent_r, ent_c = np.nonzero(H)                                           # row-major = the order of the stored results
+    vals = P[ent_r, ent_c].astype(np.uint64)
+    pos = np.arange(vals.size, dtype=np.uint64)
+    weight = ((pos * np.uint64(2654435761)) & np.uint64(0xffffffff)) | np.uint64(1)
+    want_sum = int((vals * weight).sum() & np.uint64(0xffffffffffffffff))
+    for key, r in got.items():
+        assert r["core_entries"] == int(H.sum()), key
+        assert r["count"] == int(P.sum()), key
+        assert r["checksum"] == want_sum, key
+        assert sum(r["tiles_by_density"]) == r["tiles"]
+    assert got[(1, 0)]["tiles_mfma"] == got[(1, 0)]["tiles"] and got[(0, 0)]["tiles_mfma"] == 0
+    assert 0 <= got[(2, 3000)]["tiles_mfma"] <= got[(2, 600)]["tiles_mfma"] <= got[(1, 0)]["tiles"]
