@@ -792,6 +792,34 @@ grb_info sssp_nearfar_run(grb_vector v, grb_matrix A, grb_index source, grb_desc
                           double* succ, float* tight_ms, int* passes);
 constexpr int kOcBin = 256;        // owner-computes push (bfs_persist.hip, bfs_part_run.hip): the ranges are cut on multiples of this many vertices
 constexpr int kOcWords = 8192;     // ... and a range's slice of the visited bitmap is at most this many words (32 KiB of LDS)
+// ---- the dense core of the masked product C<L> = L (+.x) L^T (mxm_core.hip; used by grb_tc_dense_core and by grb_mxm)
+struct TcCoreDev {
+  int K = 0, Wr = 0, nt = 0;
+  Index n = 0, theta = 0;
+  unsigned int nent = 0, nt_elems = 0;               // entries between core rows; elements of the core rows' T-lists
+  int* rank = nullptr;                               // [n]: a vertex's number among the core rows, -1 outside
+  Index* rows = nullptr;                             // [K]
+  unsigned int* H = nullptr;                         // [K][Wr] bit rows
+  unsigned short* pre = nullptr;                     // [K][Wr] bits of the row before the word
+  unsigned int* rowstart = nullptr;                  // [K + 1] first entry of a row = the core mask's CSR pointers
+  Index *pos = nullptr, *ccind = nullptr;            // [nent] an entry's position in the whole mask's CSR; its column (a rank)
+  unsigned int *tptr = nullptr, *cscptr = nullptr;   // [K + 1]
+  Index *tind = nullptr, *cscind = nullptr;
+  void *tiles_popc = nullptr, *tiles_mfma = nullptr;
+  int n_popc = 0, n_mfma = 0;
+  std::vector<Index> h_mptr, h_tptr, h_cscptr;
+  std::vector<void*> owned;
+  TcCoreDev() = default;
+  TcCoreDev(const TcCoreDev&) = delete;
+  ~TcCoreDev();
+};
+grb_info tc_core_rows(const Index* ptr, Index n, int k_want, TcCoreDev* d);
+grb_info tc_core_bits(const Index* ptr, const Index* ind, TcCoreDev* d, bool split);
+grb_info tc_core_tiles(TcCoreDev* d, int method, int dense_from, grb_tc_core_result* res);
+grb_info tc_core_hproduct(const TcCoreDev* d, int* out, unsigned long long* total);
+grb_info tc_core_split(const Index* ptr, const Index* ind, TcCoreDev* d, unsigned int* mval2);
+grb_info tc_core_combine(int dtype, void* c_val, const TcCoreDev* d, const int* ch, const void* ct, unsigned int one_bits, const void* m_val,
+                         int mask_f32);
 grb_info oc_tables_build(const Index* d_ptr, const Index* d_ind, const std::vector<Index>& h_ptr, Index nrows, Index ncols, int G,
                          Index** d_bounds, Index** d_off, int** d_bigidx, int* nb, int* nbig, int max_words = kOcWords);
 grb_info bfs_queue_run(grb_vector v, grb_matrix A, grb_index source, grb_descriptor desc, int* levels,

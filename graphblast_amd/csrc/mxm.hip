@@ -1192,14 +1192,16 @@ grb_info grb_mxm(grb_matrix C, grb_matrix mask, grb_accum accum, grb_semiring op
     // a pass's list is the source of an asynchronous copy: both lists live until the stream has been waited for, once, on
     // the way out (the guard is destroyed first) -- the host's work for the second pass (4 M row lengths, a sort) then runs
     // while the device is busy with the first, not after it
-    std::vector<PivotItem> big_store[2];
+    TcCoreDev core;                                        // (declared first: freed after the stream has been waited for)
+    std::vector<PivotItem> big_store[4];
     struct SyncOnExit { hipStream_t s; ~SyncOnExit() { (void)hipStreamSynchronize(s); } } sync_on_exit{s};
     int pass_no = 0;
+    T* c_out = (T*)C->csr.val;                             // where a pass writes (the dense core's T-part: a buffer of its own)
     auto run_pass = [&](const PivotView& v, Index npiv, bool piv_iso, const std::vector<Index>& hp_piv,
                         const std::vector<Index>& hp_ent, int scratch_list) -> grb_info {
       // the long pivots' entries in runs of <= 4 tiles, heaviest first (a run costs about entries x pivot length:
       // its partners are no longer than the pivot), dealt round-robin: the few giant rows do not become the tail
-      std::vector<PivotItem>& big = big_store[pass_no++ & 1];
+      std::vector<PivotItem>& big = big_store[pass_no++ & 3];
       big.clear();
       Index longest = 0;
       for (Index r = 0; r < npiv; ++r) {
@@ -1218,10 +1220,10 @@ grb_info grb_mxm(grb_matrix C, grb_matrix mask, grb_accum accum, grb_semiring op
       });
       if (piv_iso)
         hipLaunchKernelGGL((spgemm_pivot_wave_kernel<SR, T, true>), dim3(stream_grid((long long)npiv * kWave, kBlock)), dim3(kBlock), 0, s,
-                           (T*)C->csr.val, v, npiv);
+                           c_out, v, npiv);
       else
         hipLaunchKernelGGL((spgemm_pivot_wave_kernel<SR, T, false>), dim3(stream_grid((long long)npiv * kWave, kBlock)), dim3(kBlock), 0, s,
-                           (T*)C->csr.val, v, npiv);
+                           c_out, v, npiv);
       GRB_HIP_TRY(hipGetLastError());
       if (big.empty()) return GRB_SUCCESS;
       // two workgroups per CU (64 KiB tables); is the pivot side one value throughout?  then the tables hold keys only
@@ -1262,20 +1264,20 @@ grb_info grb_mxm(grb_matrix C, grb_matrix mask, grb_accum accum, grb_semiring op
           if (vv.par_iso && bits_env > 0 && longest > (Index)bits_env) max_tab = (Index)bits_env;
         }
         if (want_trace) GRB_HIP_TRY(hipMemsetAsync(d_trace, 0, 24 * (size_t)bgrid, s));
-        hipLaunchKernelGGL((spgemm_pivot_block_kernel<SR, T, false, Slot, 65536>), dim3(bgrid), dim3(1024), 0, s, (T*)C->csr.val, vv,
+        hipLaunchKernelGGL((spgemm_pivot_block_kernel<SR, T, false, Slot, 65536>), dim3(bgrid), dim3(1024), 0, s, c_out, vv,
                            (const PivotItem*)p_big, (int)big.size(), (Index)0, max_tab, d_trace);
         GRB_HIP_TRY(hipGetLastError());
         GRB_TRY(dump("64 KiB LDS tables"));
         if (longest > cap64 && max_tab > cap64) {
           if (want_trace) GRB_HIP_TRY(hipMemsetAsync(d_trace, 0, 24 * (size_t)bgrid, s));
-          hipLaunchKernelGGL((spgemm_pivot_block_kernel<SR, T, false, Slot, 131072>), dim3(bgrid), dim3(1024), 0, s, (T*)C->csr.val, vv,
+          hipLaunchKernelGGL((spgemm_pivot_block_kernel<SR, T, false, Slot, 131072>), dim3(bgrid), dim3(1024), 0, s, c_out, vv,
                              (const PivotItem*)p_big, (int)big.size(), cap64, max_tab, d_trace);
           GRB_HIP_TRY(hipGetLastError());
           GRB_TRY(dump("128 KiB LDS tables"));
         }
         if (longest > cap128 && max_tab > cap128) {
           if (want_trace) GRB_HIP_TRY(hipMemsetAsync(d_trace, 0, 24 * (size_t)bgrid, s));
-          hipLaunchKernelGGL((spgemm_pivot_block_kernel<SR, T, true, Slot, 131072>), dim3(bgrid), dim3(1024), 0, s, (T*)C->csr.val, vv,
+          hipLaunchKernelGGL((spgemm_pivot_block_kernel<SR, T, true, Slot, 131072>), dim3(bgrid), dim3(1024), 0, s, c_out, vv,
                              (const PivotItem*)p_big, (int)big.size(), cap128, max_tab, d_trace);
           GRB_HIP_TRY(hipGetLastError());
           GRB_TRY(dump("128 KiB LDS tables, pivot in segments"));
@@ -1287,7 +1289,7 @@ grb_info grb_mxm(grb_matrix C, grb_matrix mask, grb_accum accum, grb_semiring op
             const int ggrid = (int)big.size() < ctx().num_cu ? (int)big.size() : ctx().num_cu;
             void* p_cuts;
             GRB_TRY(scratch(3, sizeof(Index) * (size_t)ggrid * kBitsItemEntries * kBitsRec, &p_cuts));
-            hipLaunchKernelGGL((spgemm_pivot_bitmap_kernel<SR, T, 131072>), dim3(ggrid), dim3(1024), 0, s, (T*)C->csr.val, vv,
+            hipLaunchKernelGGL((spgemm_pivot_bitmap_kernel<SR, T, 131072>), dim3(ggrid), dim3(1024), 0, s, c_out, vv,
                                (const PivotItem*)p_big, (int)big.size(), max_tab, (Index*)p_cuts);
             GRB_HIP_TRY(hipGetLastError());
           }
@@ -1326,6 +1328,78 @@ grb_info grb_mxm(grb_matrix C, grb_matrix mask, grb_accum accum, grb_semiring op
     v1.iso_bits = rng[0];
     v1.par_iso = iso_b ? 1 : 0;
     v1.par_iso_bits = rng[2];
+    // ---- the dense core (mxm_core.hip), for the triangle count's product C<L> = L (+.x) L^T: among the longest rows the
+    // lists are dense enough to be bit rows.  An entry (i, j) between two core rows is taken out of the passes over the
+    // whole mask (its copy of the mask value is zeroed) and computed as
+    //     hits among the core's columns  (the bit rows: AND + popcount per entry, or MFMA on the denser tiles)
+    //   + hits outside them              (the same pivot passes, on the two rows' lists WITHOUT the core vertices)
+    // -- on the config-5 stand-in the 32 Ki longest rows carry 0.8 % of the vertices, 20 % of the mask's entries and most
+    // of the list elements the passes stream.  GRB_TC_CORE_K=0 switches it off; GRB_TC_CORE_MFMA_FROM moves the line
+    // between the two bit-row kernels (entries per 128 x 128 tile; 0 = popcount only, 1 = MFMA only).
+    bool use_core = false;
+    if constexpr (std::is_same<T, int>::value && mxm_plus_monoid<SR>()) {
+      // (read per call, as the reference reads its own environment switches per call: tests move them)
+      const int core_k = getenv("GRB_TC_CORE_K") ? atoi(getenv("GRB_TC_CORE_K")) : 32768;
+      const int core_from = getenv("GRB_TC_CORE_MFMA_FROM") ? atoi(getenv("GRB_TC_CORE_MFMA_FROM")) : 2048;
+      const long long core_min = getenv("GRB_TC_CORE_MIN_NVALS") ? atoll(getenv("GRB_TC_CORE_MIN_NVALS")) : (1ll << 22);
+      if (core_k > 0 && iso_a && iso_b && have_csc && mask == A && A == B && !tran_a && tran_b && mask->nrows == mask->ncols &&
+          mask->dtype == GRB_I32 && (long long)mask->nvals >= core_min) {
+        GRB_TRY(tc_core_rows(Aa.ptr, Aa.n, core_k, &core));
+        if (core.K >= 2 * 128) {
+          void* p_mv;
+          GRB_TRY(scratch(4, 4 * (size_t)mask->nvals, &p_mv));
+          GRB_HIP_TRY(hipMemcpyAsync(p_mv, mask->csr.val, 4 * (size_t)mask->nvals, hipMemcpyDeviceToDevice, s));
+          GRB_TRY(tc_core_bits(Aa.ptr, Aa.ind, &core, true));
+          if (core.nent > 0) {
+            GRB_TRY(tc_core_tiles(&core, core_from == 0 ? 0 : core_from == 1 ? 1 : 2, core_from, nullptr));
+            GRB_TRY(tc_core_split(Aa.ptr, Aa.ind, &core, (unsigned int*)p_mv));
+            v1.m_val = p_mv;                               // the passes over the whole mask skip the entries between core rows
+            use_core = true;
+          }
+        }
+      }
+    }
+    auto core_part = [&]() -> grb_info {
+      if (!use_core) return GRB_SUCCESS;
+      if constexpr (std::is_same<T, int>::value && mxm_plus_monoid<SR>()) {
+        const size_t ne = ((size_t)core.nent + 63) & ~(size_t)63;
+        void* p_cw;
+        GRB_TRY(scratch(5, 4 * 3 * ne + 64, &p_cw));
+        int* ch = (int*)p_cw;
+        T* ct = (T*)p_cw + ne;
+        T* ones = (T*)p_cw + 2 * ne;
+        unsigned long long* tot = (unsigned long long*)((T*)p_cw + 3 * ne);
+        GRB_HIP_TRY(hipMemsetAsync(ct, 0, 4 * ne, s));       // (the plus-monoid's identity)
+        GRB_HIP_TRY(hipMemsetAsync(tot, 0, 16, s));
+        hipLaunchKernelGGL((fill_value_kernel<T>), dim3(stream_grid((long long)core.nent, kBlock)), dim3(kBlock), 0, s, ones, (Index)core.nent, (T)1);
+        GRB_HIP_TRY(hipGetLastError());
+        GRB_TRY(tc_core_hproduct(&core, ch, tot));
+        // the lists without the core vertices, the entries between core rows as the mask: the same two passes
+        PivotView t1 = v1;
+        t1.piv_ptr = (const Index*)core.tptr; t1.piv_ind = core.tind;
+        t1.par_ptr = (const Index*)core.tptr; t1.par_ind = core.tind;
+        t1.ent_ptr = (const Index*)core.rowstart; t1.ent_ind = core.ccind;
+        t1.m_ptr = (const Index*)core.rowstart; t1.m_ind = core.ccind; t1.m_val = ones;
+        t1.mask_f32 = 0;
+        c_out = ct;
+        GRB_TRY(run_pass(t1, (Index)core.K, true, core.h_tptr, core.h_mptr, 6));
+        PivotView t2 = t1;
+        t2.ent_ptr = (const Index*)core.cscptr; t2.ent_ind = core.cscind;
+        t2.cols = 1;
+        t2.iso_bits = rng[2];
+        t2.par_iso_bits = rng[0];
+        GRB_TRY(run_pass(t2, (Index)core.K, true, core.h_tptr, core.h_cscptr, 6));
+        c_out = (T*)C->csr.val;
+        T a_one, b_one;
+        memcpy(&a_one, &rng[0], 4);
+        memcpy(&b_one, &rng[2], 4);
+        const T one = Semiring<SR, T>::mul(a_one, b_one);
+        unsigned int one_bits;
+        memcpy(&one_bits, &one, 4);
+        GRB_TRY(tc_core_combine(GRB_I32, C->csr.val, &core, ch, ct, one_bits, mask->csr.val, mask->dtype == GRB_F32));
+      }
+      return GRB_SUCCESS;
+    };
     GRB_TRY(run_pass(v1, Aa.n, iso_a, hpa, mask->h_csr_ptr, 6));
     if (!have_csc) return entry_driven(1);                // the entries whose row of B is the longer list
     PivotView v2 = v1;
@@ -1336,7 +1410,8 @@ grb_info grb_mxm(grb_matrix C, grb_matrix mask, grb_accum accum, grb_semiring op
     v2.iso_bits = rng[2];
     v2.par_iso = iso_a ? 1 : 0;
     v2.par_iso_bits = rng[0];
-    return run_pass(v2, Bb.n, iso_b, hpb, mask->h_csc_ptr, 6);
+    GRB_TRY(run_pass(v2, Bb.n, iso_b, hpb, mask->h_csc_ptr, 6));
+    return core_part();
   });
 }
 

@@ -53,7 +53,7 @@ __global__ void core_rank_kernel(const Index* __restrict__ ptr, Index n, Index t
 // the bit rows: a wave per core row walks the row's entries, an entry that is a core vertex sets its bit
 __global__ __launch_bounds__(kBlock) void core_fill_kernel(const Index* __restrict__ ptr, const Index* __restrict__ ind,
                                                            const Index* __restrict__ rows, int K, const int* __restrict__ rank,
-                                                           unsigned int* __restrict__ H, int Wr) {
+                                                           unsigned int* __restrict__ H, int Wr, unsigned int* __restrict__ colcnt /* nullable */) {
   const int lane = threadIdx.x & (kWave - 1);
   const int nw = gridDim.x * (blockDim.x >> 6);
   for (int r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); r < K; r += nw) {
@@ -61,17 +61,22 @@ __global__ __launch_bounds__(kBlock) void core_fill_kernel(const Index* __restri
     const Index e = ptr[x + 1];
     for (Index p = ptr[x] + lane; p < e; p += kWave) {
       const int c = rank[ind[p]];
-      if (c >= 0) atomicOr(&H[(size_t)r * Wr + (c >> 5)], 1u << (c & 31));
+      if (c >= 0) {
+        atomicOr(&H[(size_t)r * Wr + (c >> 5)], 1u << (c & 31));
+        if (colcnt) atomicAdd(&colcnt[c], 1u);
+      }
     }
   }
 }
 // per row: how many bits stand before each word (the per-entry results are stored in row-major order of the set bits)
 __global__ __launch_bounds__(kBlock) void core_prefix_kernel(const unsigned int* __restrict__ H, int K, int Wr,
-                                                             unsigned short* __restrict__ pre, unsigned int* __restrict__ rowcnt /* [K + 1] */) {
+                                                             unsigned short* __restrict__ pre, unsigned int* __restrict__ rowcnt /* [K + 1] */,
+                                                             const Index* __restrict__ ptr, const Index* __restrict__ rows,
+                                                             unsigned int* __restrict__ tcnt /* [K + 1], nullable: entries outside the core */) {
   const int lane = threadIdx.x & (kWave - 1);
   const int nw = gridDim.x * (blockDim.x >> 6);
   for (int r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); r <= K; r += nw) {
-    if (r == K) { if (lane == 0) rowcnt[K] = 0u; continue; }
+    if (r == K) { if (lane == 0) { rowcnt[K] = 0u; if (tcnt) tcnt[K] = 0u; } continue; }
     unsigned int run = 0u;
     for (int w0 = 0; w0 < Wr; w0 += kWave) {
       const int w = w0 + lane;
@@ -80,7 +85,10 @@ __global__ __launch_bounds__(kBlock) void core_prefix_kernel(const unsigned int*
       if (w < Wr) pre[(size_t)r * Wr + w] = (unsigned short)(run + incl - c);
       run += (unsigned int)__builtin_amdgcn_readlane((int)incl, kWave - 1);
     }
-    if (lane == 0) rowcnt[r] = run;
+    if (lane == 0) {
+      rowcnt[r] = run;
+      if (tcnt) tcnt[r] = (unsigned int)(ptr[rows[r] + 1] - ptr[rows[r]]) - run;
+    }
   }
 }
 // mask entries per 128 x 128 tile (bi >= bj), tile t = bi (bi + 1) / 2 + bj
@@ -286,36 +294,79 @@ __global__ __launch_bounds__(kBlock) void core_checksum_kernel(const int* __rest
   if ((threadIdx.x & (kWave - 1)) == 0 && s) atomicAdd(sum, s);
 }
 
+
+// The second walk over the core rows' lists, when the core is one part of a whole product (mxm.hip): an entry that is a
+// core vertex is a MASK ENTRY BETWEEN CORE ROWS -- its result comes from the bit rows, so it is noted (where it sits in
+// the mask, its column, its place in the column's list) and its copy of the mask value is zeroed, which takes it out of
+// the pivot kernels' passes over the whole mask; every other entry goes to the row's T-list (the list without the core
+// vertices, in order), against which the same pivot kernels intersect the T-lists of the entries noted here.
+__global__ __launch_bounds__(kBlock) void core_split_kernel(const Index* __restrict__ ptr, const Index* __restrict__ ind,
+                                                            const Index* __restrict__ rows, int K, const int* __restrict__ rank,
+                                                            const unsigned int* __restrict__ H, const unsigned short* __restrict__ pre,
+                                                            const unsigned int* __restrict__ rowstart, int Wr,
+                                                            Index* __restrict__ pos, Index* __restrict__ ccind,
+                                                            const unsigned int* __restrict__ tptr, Index* __restrict__ tind,
+                                                            const unsigned int* __restrict__ cscptr, unsigned int* __restrict__ cscfill,
+                                                            Index* __restrict__ cscind, unsigned int* __restrict__ mval2) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int nw = gridDim.x * (blockDim.x >> 6);
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  for (int r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); r < K; r += nw) {
+    const Index x = rows[r];
+    const Index s0 = ptr[x], e = ptr[x + 1];
+    unsigned int tat = tptr[r];
+    for (Index p0 = s0; p0 < e; p0 += kWave) {
+      const Index p = p0 + lane;
+      const bool have = p < e;
+      const Index col = have ? ind[p] : 0;
+      const int c = have ? rank[col] : -1;
+      const bool isT = have && c < 0;
+      const unsigned long long tm = __ballot(isT);
+      if (isT) tind[tat + (unsigned int)__popcll(tm & lt)] = col;
+      tat += (unsigned int)__popcll(tm);
+      if (have && c >= 0) {
+        const unsigned int en = core_out_pos(H, pre, rowstart, Wr, r, c);
+        pos[en] = p;
+        ccind[en] = (Index)c;
+        cscind[cscptr[c] + atomicAdd(&cscfill[c], 1u)] = (Index)r;
+        if (mval2) mval2[p] = 0u;
+      }
+    }
+  }
+}
+// C at a core entry = (hits among the core's columns + hits outside them) x the one product
+template <typename T>
+__global__ __launch_bounds__(kBlock) void core_combine_kernel(T* __restrict__ c_val, const Index* __restrict__ pos, const int* __restrict__ ch,
+                                                              const T* __restrict__ ct, unsigned int nent, T one,
+                                                              const void* __restrict__ m_val, int mask_f32) {
+  for (unsigned int en = blockIdx.x * blockDim.x + threadIdx.x; en < nent; en += gridDim.x * blockDim.x) {
+    const Index p = pos[en];
+    if (!mask_nonzero(m_val, mask_f32, p)) continue;        // (an entry the mask's own value switches off stays the identity)
+    c_val[p] = (T)ch[en] * one + ct[en];
+  }
+}
+
 }  // namespace grb
 
 using namespace grb;
 
-extern "C" grb_info grb_tc_dense_core(grb_matrix L, int k_want, int method, int dense_from, grb_tc_core_result* res) { GRB_API_ENTER();
-  if (!L || !res) return GRB_NULL_POINTER;
-  if (!L->built || !L->csr.ptr) return GRB_UNINITIALIZED_OBJECT;
-  if (L->nrows != L->ncols) return GRB_DIMENSION_MISMATCH;
-  if (k_want < 1 || method < 0 || method > 2) return GRB_INVALID_VALUE;
-  memset(res, 0, sizeof(*res));
-  GRB_TRY(ctx_init());
+TcCoreDev::~TcCoreDev() { for (void* q : owned) (void)hipFree(q); }
+static grb_info core_malloc(TcCoreDev* d, void** p, size_t bytes) {
+  GRB_HIP_TRY(hipMalloc(p, bytes ? bytes : 4));
+  d->owned.push_back(*p);
+  return GRB_SUCCESS;
+}
+
+// the core rows: the k_want longest (all rows of a length are taken or none: theta is a length), ranked in vertex order
+grb_info grb::tc_core_rows(const Index* ptr, Index n, int k_want, TcCoreDev* d) {
   Context& c = ctx();
   hipStream_t s = c.stream;
-  const Index n = L->nrows;
+  d->K = 0; d->n = n;
   if (k_want > 65535) k_want = 65535;                       // (the per-word prefix counts are 16-bit)
-  hipEvent_t ev[3];
-  for (auto& e : ev) GRB_HIP_TRY(hipEventCreate(&e));
-  struct EvFree { hipEvent_t* e; ~EvFree() { for (int i = 0; i < 3; ++i) (void)hipEventDestroy(e[i]); } } ev_free{ev};
-  struct DevFree { std::vector<void*> p; ~DevFree() { for (void* q : p) (void)hipFree(q); } } mem;
-  auto dmalloc = [&](void** p, size_t bytes) -> grb_info {
-    GRB_HIP_TRY(hipMalloc(p, bytes ? bytes : 4));
-    mem.p.push_back(*p);
-    return GRB_SUCCESS;
-  };
-  GRB_HIP_TRY(hipEventRecord(ev[0], s));
-  // ---- the core rows: the k_want longest (all rows of a length are taken or none: theta is a length)
   unsigned int* d_hist = nullptr;
-  GRB_TRY(dmalloc((void**)&d_hist, 4 * 16384));
+  GRB_TRY(core_malloc(d, (void**)&d_hist, 4 * 16384));
   GRB_HIP_TRY(hipMemsetAsync(d_hist, 0, 4 * 16384, s));
-  hipLaunchKernelGGL(core_len_hist_kernel, dim3(c.num_cu), dim3(1024), 0, s, L->csr.ptr, n, d_hist);
+  hipLaunchKernelGGL(core_len_hist_kernel, dim3(c.num_cu), dim3(1024), 0, s, ptr, n, d_hist);
   GRB_HIP_TRY(hipGetLastError());
   std::vector<unsigned int> hist(16384);
   GRB_HIP_TRY(hipMemcpyAsync(hist.data(), d_hist, 4 * 16384, hipMemcpyDeviceToHost, s));
@@ -324,96 +375,179 @@ extern "C" grb_info grb_tc_dense_core(grb_matrix L, int k_want, int method, int 
   long long have = hist[16383];
   if (have > k_want) return GRB_NOT_IMPLEMENTED;             // more than k_want rows beyond the histogram's last bin
   while (theta > 1 && have + (long long)hist[theta - 1] <= (long long)k_want) { --theta; have += hist[theta]; }
-  const int K = (int)have;
-  res->core_rows = K;
-  res->min_row_length = theta;
-  if (K < 2) return GRB_SUCCESS;
+  d->K = (int)have;
+  d->theta = theta;
+  if (d->K < 2) return GRB_SUCCESS;
   unsigned int* d_flag = nullptr;
-  int* d_rank = nullptr;
-  Index* d_rows = nullptr;
-  GRB_TRY(dmalloc((void**)&d_flag, 4 * ((size_t)n + 1)));
-  GRB_TRY(dmalloc((void**)&d_rank, 4 * (size_t)n));
-  GRB_TRY(dmalloc((void**)&d_rows, 4 * (size_t)K));
-  hipLaunchKernelGGL(core_flag_kernel, dim3(stream_grid((long long)n + 1)), dim3(kBlock), 0, s, L->csr.ptr, n, theta, d_flag);
+  GRB_TRY(core_malloc(d, (void**)&d_flag, 4 * ((size_t)n + 1)));
+  GRB_TRY(core_malloc(d, (void**)&d->rank, 4 * (size_t)n));
+  GRB_TRY(core_malloc(d, (void**)&d->rows, 4 * (size_t)d->K));
+  hipLaunchKernelGGL(core_flag_kernel, dim3(stream_grid((long long)n + 1)), dim3(kBlock), 0, s, ptr, n, theta, d_flag);
   GRB_HIP_TRY(hipGetLastError());
   GRB_TRY(device_exclusive_scan_u32(d_flag, (long long)n + 1));
-  hipLaunchKernelGGL(core_rank_kernel, dim3(stream_grid(n)), dim3(kBlock), 0, s, L->csr.ptr, n, theta, (const unsigned int*)d_flag, d_rank,
-                     d_rows);
+  hipLaunchKernelGGL(core_rank_kernel, dim3(stream_grid(n)), dim3(kBlock), 0, s, ptr, n, theta, (const unsigned int*)d_flag, d->rank, d->rows);
   GRB_HIP_TRY(hipGetLastError());
-  // ---- the bit rows (padded to whole staging chunks), the per-word prefix counts, the rows' first result
-  const int nt = (K + kCoreTile - 1) / kCoreTile;
-  const int Wr = ((nt * kCoreTile / 32 + kCoreChunkW - 1) / kCoreChunkW) * kCoreChunkW;
-  unsigned int* d_H = nullptr;
-  unsigned short* d_pre = nullptr;
-  unsigned int* d_rowstart = nullptr;
-  GRB_TRY(dmalloc((void**)&d_H, 4 * (size_t)K * Wr));
-  GRB_TRY(dmalloc((void**)&d_pre, 2 * (size_t)K * Wr));
-  GRB_TRY(dmalloc((void**)&d_rowstart, 4 * ((size_t)K + 1)));
-  GRB_HIP_TRY(hipMemsetAsync(d_H, 0, 4 * (size_t)K * Wr, s));
-  hipLaunchKernelGGL(core_fill_kernel, dim3(stream_grid((long long)K * kWave)), dim3(kBlock), 0, s, L->csr.ptr, L->csr.ind,
-                     (const Index*)d_rows, K, (const int*)d_rank, d_H, Wr);
-  hipLaunchKernelGGL(core_prefix_kernel, dim3(stream_grid((long long)(K + 1) * kWave)), dim3(kBlock), 0, s, (const unsigned int*)d_H, K, Wr,
-                     d_pre, d_rowstart);
+  return GRB_SUCCESS;
+}
+// the bit rows (padded to whole staging chunks), the per-word prefix counts, the rows' first result; with split: the
+// entries outside the core per row and the entries per core column as well
+grb_info grb::tc_core_bits(const Index* ptr, const Index* ind, TcCoreDev* d, bool split) {
+  hipStream_t s = ctx().stream;
+  const int K = d->K;
+  d->nt = (K + kCoreTile - 1) / kCoreTile;
+  d->Wr = ((d->nt * kCoreTile / 32 + kCoreChunkW - 1) / kCoreChunkW) * kCoreChunkW;
+  const int Wr = d->Wr;
+  GRB_TRY(core_malloc(d, (void**)&d->H, 4 * (size_t)K * Wr));
+  GRB_TRY(core_malloc(d, (void**)&d->pre, 2 * (size_t)K * Wr));
+  GRB_TRY(core_malloc(d, (void**)&d->rowstart, 4 * ((size_t)K + 1)));
+  if (split) {
+    GRB_TRY(core_malloc(d, (void**)&d->tptr, 4 * ((size_t)K + 1)));
+    GRB_TRY(core_malloc(d, (void**)&d->cscptr, 4 * ((size_t)K + 1)));
+    GRB_HIP_TRY(hipMemsetAsync(d->cscptr, 0, 4 * ((size_t)K + 1), s));
+  }
+  GRB_HIP_TRY(hipMemsetAsync(d->H, 0, 4 * (size_t)K * Wr, s));
+  hipLaunchKernelGGL(core_fill_kernel, dim3(stream_grid((long long)K * kWave)), dim3(kBlock), 0, s, ptr, ind, (const Index*)d->rows, K,
+                     (const int*)d->rank, d->H, Wr, split ? d->cscptr : nullptr);
+  hipLaunchKernelGGL(core_prefix_kernel, dim3(stream_grid((long long)(K + 1) * kWave)), dim3(kBlock), 0, s, (const unsigned int*)d->H, K, Wr,
+                     d->pre, d->rowstart, ptr, (const Index*)d->rows, split ? d->tptr : nullptr);
   GRB_HIP_TRY(hipGetLastError());
-  GRB_TRY(device_exclusive_scan_u32(d_rowstart, (long long)K + 1));
-  unsigned int nent = 0;
-  GRB_HIP_TRY(hipMemcpyAsync(&nent, d_rowstart + K, 4, hipMemcpyDeviceToHost, s));
-  // ---- the tiles: entry counts decide who takes a tile; heaviest (most columns of k) first
+  GRB_TRY(device_exclusive_scan_u32(d->rowstart, (long long)K + 1));
+  if (split) {
+    GRB_TRY(device_exclusive_scan_u32(d->tptr, (long long)K + 1));
+    GRB_TRY(device_exclusive_scan_u32(d->cscptr, (long long)K + 1));
+  }
+  GRB_HIP_TRY(hipMemcpyAsync(&d->nent, d->rowstart + K, 4, hipMemcpyDeviceToHost, s));
+  if (split) GRB_HIP_TRY(hipMemcpyAsync(&d->nt_elems, d->tptr + K, 4, hipMemcpyDeviceToHost, s));
+  GRB_HIP_TRY(hipStreamSynchronize(s));
+  return GRB_SUCCESS;
+}
+// the tiles: entry counts decide who takes a tile; heaviest (most columns of k) first
+grb_info grb::tc_core_tiles(TcCoreDev* d, int method, int dense_from, grb_tc_core_result* res) {
+  hipStream_t s = ctx().stream;
+  const int nt = d->nt;
   const int ntile_all = nt * (nt + 1) / 2;
   unsigned int* d_tcnt = nullptr;
-  GRB_TRY(dmalloc((void**)&d_tcnt, 4 * (size_t)ntile_all));
+  GRB_TRY(core_malloc(d, (void**)&d_tcnt, 4 * (size_t)ntile_all));
   GRB_HIP_TRY(hipMemsetAsync(d_tcnt, 0, 4 * (size_t)ntile_all, s));
-  hipLaunchKernelGGL(core_tile_count_kernel, dim3(ntile_all < 4096 ? ntile_all : 4096), dim3(kBlock), 0, s, (const unsigned int*)d_H, K, Wr, nt,
-                     d_tcnt);
+  hipLaunchKernelGGL(core_tile_count_kernel, dim3(ntile_all < 4096 ? ntile_all : 4096), dim3(kBlock), 0, s, (const unsigned int*)d->H, d->K, d->Wr,
+                     nt, d_tcnt);
   GRB_HIP_TRY(hipGetLastError());
   std::vector<unsigned int> tcnt((size_t)ntile_all);
   GRB_HIP_TRY(hipMemcpyAsync(tcnt.data(), d_tcnt, 4 * (size_t)ntile_all, hipMemcpyDeviceToHost, s));
   GRB_HIP_TRY(hipStreamSynchronize(s));
-  res->core_entries = (int64_t)nent;
   std::vector<CoreTile> t_popc, t_mfma;
   const unsigned int from = method == 0 ? 0xffffffffu : method == 1 ? 1u : (unsigned int)(dense_from > 0 ? dense_from : 1);
   for (int bi = nt - 1; bi >= 0; --bi)
     for (int bj = bi; bj >= 0; --bj) {                       // (columns of k a tile needs grow with bj)
       const unsigned int e = tcnt[(size_t)bi * (bi + 1) / 2 + bj];
       if (!e) continue;
-      ++res->tiles;
-      const int decile = (int)((unsigned long long)e * 10ull / (unsigned long long)(kCoreTile * kCoreTile));
-      ++res->tiles_by_density[decile > 9 ? 9 : decile];
+      if (res) {
+        ++res->tiles;
+        const int decile = (int)((unsigned long long)e * 10ull / (unsigned long long)(kCoreTile * kCoreTile));
+        ++res->tiles_by_density[decile > 9 ? 9 : decile];
+      }
       (e >= from ? t_mfma : t_popc).push_back(CoreTile{(unsigned short)bi, (unsigned short)bj});
     }
   auto by_work = [](const CoreTile& x, const CoreTile& y) { return x.bj > y.bj; };
   std::stable_sort(t_popc.begin(), t_popc.end(), by_work);
   std::stable_sort(t_mfma.begin(), t_mfma.end(), by_work);
-  res->tiles_mfma = (int)t_mfma.size();
-  CoreTile *d_tp = nullptr, *d_tm = nullptr;
-  GRB_TRY(dmalloc((void**)&d_tp, sizeof(CoreTile) * t_popc.size()));
-  GRB_TRY(dmalloc((void**)&d_tm, sizeof(CoreTile) * t_mfma.size()));
-  if (!t_popc.empty()) GRB_HIP_TRY(hipMemcpyAsync(d_tp, t_popc.data(), sizeof(CoreTile) * t_popc.size(), hipMemcpyHostToDevice, s));
-  if (!t_mfma.empty()) GRB_HIP_TRY(hipMemcpyAsync(d_tm, t_mfma.data(), sizeof(CoreTile) * t_mfma.size(), hipMemcpyHostToDevice, s));
+  d->n_popc = (int)t_popc.size();
+  d->n_mfma = (int)t_mfma.size();
+  if (res) res->tiles_mfma = d->n_mfma;
+  GRB_TRY(core_malloc(d, &d->tiles_popc, sizeof(CoreTile) * t_popc.size()));
+  GRB_TRY(core_malloc(d, &d->tiles_mfma, sizeof(CoreTile) * t_mfma.size()));
+  // (pageable host vectors: the copies complete before the calls return)
+  if (!t_popc.empty()) GRB_HIP_TRY(hipMemcpy(d->tiles_popc, t_popc.data(), sizeof(CoreTile) * t_popc.size(), hipMemcpyHostToDevice));
+  if (!t_mfma.empty()) GRB_HIP_TRY(hipMemcpy(d->tiles_mfma, t_mfma.data(), sizeof(CoreTile) * t_mfma.size(), hipMemcpyHostToDevice));
+  return GRB_SUCCESS;
+}
+// out[e] = sum_k H[i][k] H[j][k] for every entry e = (i, j) between core rows; *total += their sum
+grb_info grb::tc_core_hproduct(const TcCoreDev* d, int* out, unsigned long long* total) {
+  Context& c = ctx();
+  hipStream_t s = c.stream;
+  const int wg = 2 * c.num_cu;
+  if (d->n_popc) {
+    hipLaunchKernelGGL(core_popc_kernel, dim3(d->n_popc < wg ? d->n_popc : wg), dim3(256), 0, s, (const unsigned int*)d->H,
+                       (const unsigned short*)d->pre, (const unsigned int*)d->rowstart, d->K, d->Wr, (const CoreTile*)d->tiles_popc, d->n_popc, out,
+                       total);
+    GRB_HIP_TRY(hipGetLastError());
+  }
+  if (d->n_mfma) {
+    hipLaunchKernelGGL(core_mfma_kernel, dim3(d->n_mfma < wg ? d->n_mfma : wg), dim3(256), 0, s, (const unsigned int*)d->H,
+                       (const unsigned short*)d->pre, (const unsigned int*)d->rowstart, d->K, d->Wr, (const CoreTile*)d->tiles_mfma, d->n_mfma, out,
+                       total);
+    GRB_HIP_TRY(hipGetLastError());
+  }
+  return GRB_SUCCESS;
+}
+// the entries between core rows as a mask of their own (CSR: rowstart / ccind, CSC: cscptr / cscind), where each sits in
+// the whole mask (pos), the core rows' lists without the core vertices (tptr / tind); mval2 (nullable): a copy of the
+// whole mask's values in which those entries are zeroed
+grb_info grb::tc_core_split(const Index* ptr, const Index* ind, TcCoreDev* d, unsigned int* mval2) {
+  hipStream_t s = ctx().stream;
+  const int K = d->K;
+  unsigned int* d_fill = nullptr;
+  GRB_TRY(core_malloc(d, (void**)&d->pos, 4 * (size_t)d->nent));
+  GRB_TRY(core_malloc(d, (void**)&d->ccind, 4 * (size_t)d->nent));
+  GRB_TRY(core_malloc(d, (void**)&d->cscind, 4 * (size_t)d->nent));
+  GRB_TRY(core_malloc(d, (void**)&d->tind, 4 * (size_t)d->nt_elems));
+  GRB_TRY(core_malloc(d, (void**)&d_fill, 4 * ((size_t)K + 1)));
+  GRB_HIP_TRY(hipMemsetAsync(d_fill, 0, 4 * ((size_t)K + 1), s));
+  hipLaunchKernelGGL(core_split_kernel, dim3(stream_grid((long long)K * kWave)), dim3(kBlock), 0, s, ptr, ind, (const Index*)d->rows, K,
+                     (const int*)d->rank, (const unsigned int*)d->H, (const unsigned short*)d->pre, (const unsigned int*)d->rowstart, d->Wr, d->pos,
+                     d->ccind, (const unsigned int*)d->tptr, d->tind, (const unsigned int*)d->cscptr, d_fill, d->cscind, mval2);
+  GRB_HIP_TRY(hipGetLastError());
+  d->h_mptr.resize((size_t)K + 1); d->h_tptr.resize((size_t)K + 1); d->h_cscptr.resize((size_t)K + 1);
+  GRB_HIP_TRY(hipMemcpyAsync(d->h_mptr.data(), d->rowstart, 4 * ((size_t)K + 1), hipMemcpyDeviceToHost, s));
+  GRB_HIP_TRY(hipMemcpyAsync(d->h_tptr.data(), d->tptr, 4 * ((size_t)K + 1), hipMemcpyDeviceToHost, s));
+  GRB_HIP_TRY(hipMemcpyAsync(d->h_cscptr.data(), d->cscptr, 4 * ((size_t)K + 1), hipMemcpyDeviceToHost, s));
+  GRB_HIP_TRY(hipStreamSynchronize(s));
+  return GRB_SUCCESS;
+}
+grb_info grb::tc_core_combine(int dtype, void* c_val, const TcCoreDev* d, const int* ch, const void* ct, unsigned int one_bits, const void* m_val,
+                              int mask_f32) {
+  hipStream_t s = ctx().stream;
+  if (!d->nent) return GRB_SUCCESS;
+  if (dtype != GRB_I32) return GRB_NOT_IMPLEMENTED;
+  int one;
+  memcpy(&one, &one_bits, 4);
+  hipLaunchKernelGGL((core_combine_kernel<int>), dim3(stream_grid((long long)d->nent)), dim3(kBlock), 0, s, (int*)c_val, (const Index*)d->pos, ch,
+                     (const int*)ct, d->nent, one, m_val, mask_f32);
+  GRB_HIP_TRY(hipGetLastError());
+  return GRB_SUCCESS;
+}
+
+extern "C" grb_info grb_tc_dense_core(grb_matrix L, int k_want, int method, int dense_from, grb_tc_core_result* res) { GRB_API_ENTER();
+  if (!L || !res) return GRB_NULL_POINTER;
+  if (!L->built || !L->csr.ptr) return GRB_UNINITIALIZED_OBJECT;
+  if (L->nrows != L->ncols) return GRB_DIMENSION_MISMATCH;
+  if (k_want < 1 || method < 0 || method > 2) return GRB_INVALID_VALUE;
+  memset(res, 0, sizeof(*res));
+  GRB_TRY(ctx_init());
+  hipStream_t s = ctx().stream;
+  hipEvent_t ev[3];
+  for (auto& e : ev) GRB_HIP_TRY(hipEventCreate(&e));
+  struct EvFree { hipEvent_t* e; ~EvFree() { for (int i = 0; i < 3; ++i) (void)hipEventDestroy(e[i]); } } ev_free{ev};
+  TcCoreDev d;
+  GRB_HIP_TRY(hipEventRecord(ev[0], s));
+  GRB_TRY(tc_core_rows(L->csr.ptr, L->nrows, k_want, &d));
+  res->core_rows = d.K;
+  res->min_row_length = d.theta;
+  if (d.K < 2) return GRB_SUCCESS;
+  GRB_TRY(tc_core_bits(L->csr.ptr, L->csr.ind, &d, false));
+  res->core_entries = (int64_t)d.nent;
+  GRB_TRY(tc_core_tiles(&d, method, dense_from, res));
   int* d_out = nullptr;
   unsigned long long* d_tot = nullptr;
-  GRB_TRY(dmalloc((void**)&d_out, 4 * (size_t)nent));
-  GRB_TRY(dmalloc((void**)&d_tot, 16));
-  GRB_HIP_TRY(hipMemsetAsync(d_out, 0xff, 4 * (size_t)nent, s));   // (an entry nobody wrote shows in the checksum)
+  GRB_TRY(core_malloc(&d, (void**)&d_out, 4 * (size_t)d.nent));
+  GRB_TRY(core_malloc(&d, (void**)&d_tot, 16));
+  GRB_HIP_TRY(hipMemsetAsync(d_out, 0xff, 4 * (size_t)d.nent, s));   // (an entry nobody wrote shows in the checksum)
   GRB_HIP_TRY(hipMemsetAsync(d_tot, 0, 16, s));
   GRB_HIP_TRY(hipEventRecord(ev[1], s));
-  // ---- the product
-  const int wg = 2 * c.num_cu;
-  if (!t_popc.empty()) {
-    hipLaunchKernelGGL(core_popc_kernel, dim3((int)t_popc.size() < wg ? (int)t_popc.size() : wg), dim3(256), 0, s, (const unsigned int*)d_H,
-                       (const unsigned short*)d_pre, (const unsigned int*)d_rowstart, K, Wr, (const CoreTile*)d_tp, (int)t_popc.size(), d_out,
-                       d_tot);
-    GRB_HIP_TRY(hipGetLastError());
-  }
-  if (!t_mfma.empty()) {
-    hipLaunchKernelGGL(core_mfma_kernel, dim3((int)t_mfma.size() < wg ? (int)t_mfma.size() : wg), dim3(256), 0, s, (const unsigned int*)d_H,
-                       (const unsigned short*)d_pre, (const unsigned int*)d_rowstart, K, Wr, (const CoreTile*)d_tm, (int)t_mfma.size(), d_out,
-                       d_tot);
-    GRB_HIP_TRY(hipGetLastError());
-  }
+  GRB_TRY(tc_core_hproduct(&d, d_out, d_tot));
   GRB_HIP_TRY(hipEventRecord(ev[2], s));
-  if (nent) {
-    hipLaunchKernelGGL(core_checksum_kernel, dim3(stream_grid((long long)nent)), dim3(kBlock), 0, s, (const int*)d_out, (long long)nent, d_tot + 1);
+  if (d.nent) {
+    hipLaunchKernelGGL(core_checksum_kernel, dim3(stream_grid((long long)d.nent)), dim3(kBlock), 0, s, (const int*)d_out, (long long)d.nent, d_tot + 1);
     GRB_HIP_TRY(hipGetLastError());
   }
   unsigned long long tot[2] = {0ull, 0ull};

@@ -203,3 +203,46 @@ def test_dense_core(hb, scale, k_want):
         assert sum(r["tiles_by_density"]) == r["tiles"]
     assert got[(1, 0)]["tiles_mfma"] == got[(1, 0)]["tiles"] and got[(0, 0)]["tiles_mfma"] == 0
     assert 0 <= got[(2, 3000)]["tiles_mfma"] <= got[(2, 600)]["tiles_mfma"] <= got[(1, 0)]["tiles"]
+
+
+@pytest.mark.parametrize("mfma_from", ["0", "1", "600"])
+def test_triangle_count_with_the_dense_core(hb, mfma_from):
+    """grb_mxm's dense-core path (C<L> = L (+.x) L^T through grb_tc): the entries between the longest rows come from the
+    bit rows (popcount only, MFMA only, both) plus the pivot passes on the lists without the core vertices; everything
+    else from the passes over the whole mask with those entries switched off.  Every stored value of the product equals
+    the product computed with the core off, and the count the reference's SimpleReferenceTc."""
+    import os
+    from graphblast_amd.graphgen import rmat_edges, finalize_edges
+    from oracle import simple_reference as sr
+    g = hb.g
+    s, d, n = rmat_edges(14, 24, seed=3)
+    gr = finalize_edges(s, d, n, symmetrize=True)
+    ptr, ind = gr["csr"]
+    A = g.Matrix(n, n, np.int32)
+    assert A.build_csr(ptr, ind, np.ones(ind.size, dtype=np.int32)) == 0
+    L = g.Matrix(n, n, np.int32)
+    assert g.tril(L, A, hb.descriptor()) == 0
+    lp, li, lv = L.host_csr()
+    saved = {k: os.environ.get(k) for k in ("GRB_TC_CORE_K", "GRB_TC_CORE_MIN_NVALS", "GRB_TC_CORE_MFMA_FROM")}
+    try:
+        os.environ["GRB_TC_CORE_K"] = "0"
+        B0 = g.Matrix(n, n, np.int32)
+        info, want_n, _ = g.tc(L, B0, hb.descriptor())
+        assert info == 0 and want_n == sr.tc(lp, li)[0] and want_n > 0
+        _, _, want = B0.host_csr()
+        for k in ("300", "1500"):
+            os.environ.update(GRB_TC_CORE_K=k, GRB_TC_CORE_MIN_NVALS="0", GRB_TC_CORE_MFMA_FROM=mfma_from)
+            B1 = g.Matrix(n, n, np.int32)
+            info, got_n, _ = g.tc(L, B1, hb.descriptor())
+            assert info == 0 and got_n == want_n, (k, got_n, want_n)
+            bp, bi, bv = B1.host_csr()
+            assert np.array_equal(bp, lp) and np.array_equal(bi, li)
+            assert np.array_equal(bv, want), (k, int(np.count_nonzero(bv != want)))
+            info, got_n, _ = g.tc(L, B1, hb.descriptor())             # the same output matrix again (its arrays are kept)
+            assert info == 0 and got_n == want_n
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
