@@ -375,6 +375,48 @@ def other_workload(args):
                                   "list_bytes_served_on_chip": int(alg), "list_GBps": round(alg / t / 1e9, 1),
                                   "note": "bytes = compulsory HBM traffic (operands once, result once); the kernel is bound "
                                           "by the on-chip rate of its list intersections (list_GBps), not by HBM"}})
+        # north_star's "MFMA dense-tile path where the frontier densifies", on the workload SURVEY 8(f)2 names for it: the
+        # product restricted to the K longest rows of L as K x K bit rows (csrc/mxm_core.hip) -- AND + popcount per mask
+        # entry against v_mfma_i32_16x16x64_i8 on the same rows, same per-entry results (checksum) -- and the whole product
+        # with that core switched on (GRB_TC_CORE_K: entries between core rows from the bit rows + the pivot passes on
+        # the lists without the core vertices)
+        core_ab = {}
+        for K in (2048, 8192, 16384):
+            runs = {}
+            for name, method in (("popcount", 0), ("mfma", 1)):
+                best = None
+                for _ in range(3):
+                    info, r_ = g.tc_dense_core(L, K, method, 0)
+                    assert info == 0, info
+                    best = r_ if best is None or r_["product_ms"] < best["product_ms"] else best
+                runs[name] = best
+            assert (runs["popcount"]["count"], runs["popcount"]["checksum"]) == (runs["mfma"]["count"], runs["mfma"]["checksum"])
+            core_ab[str(K)] = {"core_rows": runs["mfma"]["core_rows"], "core_entries": runs["mfma"]["core_entries"],
+                               "hits_in_core": runs["mfma"]["count"], "tiles": runs["mfma"]["tiles"],
+                               "tiles_by_tenths_of_16384_entries": runs["mfma"]["tiles_by_density"],
+                               "popcount_ms": round(runs["popcount"]["product_ms"], 4), "mfma_ms": round(runs["mfma"]["product_ms"], 4),
+                               "build_ms": round(runs["mfma"]["build_ms"], 3)}
+        with_core = {}
+        for K in (8192,):
+            os.environ["GRB_TC_CORE_K"] = str(K)
+            try:
+                g.tc(L, B, g.Descriptor())
+                dd = g.Descriptor()
+                dd.loadArgs()
+                info, ntri_c, res_c = g.tc(L, B, dd)
+            finally:
+                os.environ.pop("GRB_TC_CORE_K", None)
+            assert info == 0 and ntri_c == ntri, (ntri_c, ntri)
+            with_core[str(K)] = round(res_c["tight_ms"], 2)
+        g.tc(L, B, desc)                                       # (B holds the default path's product again: the parity block reads it)
+        line["dense_core"] = {"per_core_size": core_ab, "whole_product_ms_with_the_core_on": with_core,
+                              "whole_product_ms": round(t * 1e3, 2),
+                              "mfma": "measured, not used: on the bit rows of the 2 048 longest rows the MFMA kernel beats AND + "
+                                      "popcount (the tiles there hold 10-80 %% of their pairs), from 8 192 rows on the mask is too "
+                                      "sparse for computing every pair of a tile (most tiles hold < 10 %%); and the whole product "
+                                      "is SLOWER with the core on (%s ms against %.1f): building the bit rows, splitting the lists "
+                                      "and the second pair of passes cost more than the list elements the core takes off the "
+                                      "pivot kernels (docs/experiments.md)" % (with_core, t * 1e3)}
         if not args.no_cpu_baseline:
             # the reference's own SimpleReferenceTc (test_tc.hpp:41-87) on the first k rows of L -- one core, k chosen
             # for about 15 s of work (the whole graph would take minutes); the HIP result's per-entry counts over the

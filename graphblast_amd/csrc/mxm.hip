@@ -1333,13 +1333,15 @@ grb_info grb_mxm(grb_matrix C, grb_matrix mask, grb_accum accum, grb_semiring op
     // whole mask (its copy of the mask value is zeroed) and computed as
     //     hits among the core's columns  (the bit rows: AND + popcount per entry, or MFMA on the denser tiles)
     //   + hits outside them              (the same pivot passes, on the two rows' lists WITHOUT the core vertices)
-    // -- on the config-5 stand-in the 32 Ki longest rows carry 0.8 % of the vertices, 20 % of the mask's entries and most
-    // of the list elements the passes stream.  GRB_TC_CORE_K=0 switches it off; GRB_TC_CORE_MFMA_FROM moves the line
-    // between the two bit-row kernels (entries per 128 x 128 tile; 0 = popcount only, 1 = MFMA only).
+    // OFF by default (GRB_TC_CORE_K = rows of the core; measured on the config-5 stand-in, docs/experiments.md: the
+    // product takes 123-140 ms with a core of 2 Ki ... 32 Ki rows against 112 without -- the tail of the degree
+    // distribution is long, a core large enough to take a third of the streamed list elements off the pivot kernels is
+    // too sparse for bit rows, and a small one does not pay for its set-up).  GRB_TC_CORE_MFMA_FROM moves the line between
+    // the two bit-row kernels (entries per 128 x 128 tile; 0 = popcount only, 1 = MFMA only).
     bool use_core = false;
     if constexpr (std::is_same<T, int>::value && mxm_plus_monoid<SR>()) {
       // (read per call, as the reference reads its own environment switches per call: tests move them)
-      const int core_k = getenv("GRB_TC_CORE_K") ? atoi(getenv("GRB_TC_CORE_K")) : 32768;
+      const int core_k = getenv("GRB_TC_CORE_K") ? atoi(getenv("GRB_TC_CORE_K")) : 0;
       const int core_from = getenv("GRB_TC_CORE_MFMA_FROM") ? atoi(getenv("GRB_TC_CORE_MFMA_FROM")) : 2048;
       const long long core_min = getenv("GRB_TC_CORE_MIN_NVALS") ? atoll(getenv("GRB_TC_CORE_MIN_NVALS")) : (1ll << 22);
       if (core_k > 0 && iso_a && iso_b && have_csc && mask == A && A == B && !tran_a && tran_b && mask->nrows == mask->ncols &&
