@@ -505,10 +505,23 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if shared_gpu:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=dev)
+        # a rendezvous or an RCCL bring-up that cannot complete ends the run inside ten minutes with ONE line and a
+        # non-zero exit code (the default is thirty minutes of silence)
+        import datetime
+        try:
+            if shared_gpu:
+                dist.init_process_group("gloo", timeout=datetime.timedelta(minutes=5))
+            else:
+                dist.init_process_group("nccl", device_id=dev, timeout=datetime.timedelta(minutes=5))
+                probe = torch.ones(1, device=dev)
+                dist.all_reduce(probe)                          # the communicator is created lazily: create it now
+                torch.cuda.synchronize()
+                assert int(probe.item()) == world, "all-reduce over %d ranks returned %r" % (world, probe.item())
+        except Exception as exc:                                # noqa: BLE001 -- whatever the launcher / RCCL raised
+            if rank == 0:
+                print(json.dumps({"error": "collectives unavailable: %s: %s" % (type(exc).__name__, str(exc)[:300]),
+                                  "n_gpus": world}), flush=True)
+            sys.exit(4)
 
     import graphblast_amd as g
     from graphblast_amd.graphgen import rmat_edges, finalize_edges, random_sources
@@ -1215,6 +1228,29 @@ def main():
                 "steps_per_gpu": args.steps, "ms_per_step_per_gpu": float(tm.item()) / args.steps * 1e3,
                 "note": "every rank traverses its own sources on a full replica of the graph, queued as in the N = 1 run "
                         "(grb_bfs_fused_enqueue / grb_bfs_wait); no collective"}
+            # the same leg with eight traversals side by side per launch on every rank (grb_bfs_set_coschedule(8))
+            g.bfs_set_coschedule(8)
+            queued_pass(mine[:max(args.warmup, 8)])
+            barrier()
+            t0 = time.perf_counter()
+            my_edges_co = queued_pass(mine)
+            barrier()
+            el_co = time.perf_counter() - t0
+            g.bfs_set_coschedule(1)
+            for i_ in sorted({0, len(mine) - 1}):
+                assert g.bfs(v, A, mine[i_], desc, fused=True)[0] == 0
+                if not np.array_equal(vq[i_].extractTuples()[1], v.extractTuples()[1]):
+                    print(json.dumps({"error": "parity (replica leg, co-scheduled)", "rank": rank, "step": i_}))
+                    sys.exit(3)
+            t = torch.tensor([el_co, float(my_edges_co)], dtype=torch.float64, device=sdev)
+            tm2, te2 = t[:1].clone(), t[1:].clone()
+            if world > 1:
+                dist.all_reduce(tm2, op=dist.ReduceOp.MAX)
+                dist.all_reduce(te2, op=dist.ReduceOp.SUM)
+            extra["source_sharded_replicas"]["coscheduled_8"] = {
+                "value": float(te2.item()) / float(tm2.item()), "unit": "TEPS", "scaling": "weak",
+                "ms_per_step_per_gpu": float(tm2.item()) / args.steps * 1e3,
+                "note": "the same, eight traversals side by side in one launch on every rank"}
 
     if rank == 0:
         line = {
@@ -1227,6 +1263,12 @@ def main():
                        "sources": len(sources), "parallelism": parallelism},
             "roofline": roofline,
         }
+        if world > 1 or args.partitioned:
+            line["scaling_note"] = ("`value` is the 1-D vertex-partitioned traversal north_star names: ONE traversal at a time over all "
+                                    "N GPUs, a launch and an all-gather per level -- STRONG scaling of a 1 GB graph whose traversal "
+                                    "is latency-bound on one GPU already (N = 1 of this line's metric is the one-launch kernel, "
+                                    "`python bench.py --gpus 1`), so it falls with N.  `source_sharded_replicas` is the WEAK-scaling "
+                                    "leg: every GPU traverses its own sources on a replica, no collective.")
         line.update(extra)
         # whatever C libraries still hold in their stdio buffers (RCCL's version banner) goes out first: the JSON
         # line is the last line of stdout
