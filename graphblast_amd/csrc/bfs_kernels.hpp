@@ -219,13 +219,28 @@ static __global__ __launch_bounds__(kBlock) void bfs_level_tail_kernel(
 // Rows of kHintLong entries and more are stepped over here and taken by bfs_hint_long_kernel, a whole workgroup each:
 // one wave walking the longest row of RMAT-22 alone (300 000 entries) was this kernel's whole time, 2.7 ms.
 constexpr Index kHintLong = 1024;
-__device__ inline unsigned long long hint_key(Index u, const Index* __restrict__ deg_ptr) {
-  // (degree + 1: an entry of degree 0 still beats "no entry"; ties go to the smaller entry)
-  const unsigned int d = (unsigned int)(deg_ptr[u + 1] - deg_ptr[u]);
-  return ((unsigned long long)(d + 1u) << 32) | (unsigned long long)(0xffffffffu - (unsigned int)u);
+// The degrees are looked up once per ENTRY, at random: two 4-byte reads of a 16 MB pointer array per entry were 9.1 GB
+// of line fetches for the 1 GB graph of RMAT-22 (profiles/r05/pmc_traffic.json), most of the 5.3 ms a matrix's first
+// traversal paid.  The hint only has to be a GOOD in-neighbour -- any in-neighbour is a correct one -- so the kernels
+// compare degree CLASSES, one byte per vertex (exact below 128, then sixteen steps per doubling: monotone, so "largest
+// class, smallest entry on ties" is still a maximum-degree neighbour up to 4 % of its degree): 4 MB at RMAT-22, which
+// the L2s hold.
+__device__ inline unsigned char hint_degree_class(unsigned int d) {
+  if (d < 128u) return (unsigned char)d;
+  const int e = 31 - __clz((int)d);                            // d in [2^e, 2^(e+1)), e >= 7
+  const unsigned int c = 128u + (unsigned int)(e - 7) * 16u + ((d >> (e - 4)) & 15u);
+  return (unsigned char)(c > 255u ? 255u : c);
+}
+static __global__ void bfs_degree_class_kernel(const Index* __restrict__ deg_ptr, Index n, unsigned char* __restrict__ cls) {
+  for (Index v = (Index)blockIdx.x * blockDim.x + threadIdx.x; v < n; v += (Index)gridDim.x * blockDim.x)
+    cls[v] = hint_degree_class((unsigned int)(deg_ptr[v + 1] - deg_ptr[v]));
+}
+__device__ inline unsigned long long hint_key(Index u, const unsigned char* __restrict__ cls) {
+  // (class + 1: an entry of degree 0 still beats "no entry"; ties go to the smaller entry)
+  return ((unsigned long long)((unsigned int)cls[u] + 1u) << 32) | (unsigned long long)(0xffffffffu - (unsigned int)u);
 }
 static __global__ __launch_bounds__(kBlock) void bfs_hint_kernel(
-    const Index* __restrict__ ptr, const Index* __restrict__ ind, Index n, const Index* __restrict__ deg_ptr,
+    const Index* __restrict__ ptr, const Index* __restrict__ ind, Index n, const unsigned char* __restrict__ deg_ptr,
     Index* __restrict__ hint) {
   __shared__ Index s_start[kWavesPerBlock][kWave + 1];
   __shared__ unsigned long long s_best[kWavesPerBlock][kWave];
@@ -268,7 +283,7 @@ static __global__ __launch_bounds__(kBlock) void bfs_hint_kernel(
 // the rows of kHintLong entries and more: a workgroup looks at 1024 consecutive rows, lists the long ones, and walks
 // each of them with all its threads
 static __global__ __launch_bounds__(1024) void bfs_hint_long_kernel(
-    const Index* __restrict__ ptr, const Index* __restrict__ ind, Index n, const Index* __restrict__ deg_ptr,
+    const Index* __restrict__ ptr, const Index* __restrict__ ind, Index n, const unsigned char* __restrict__ deg_ptr,
     Index* __restrict__ hint) {
   __shared__ Index s_rows[1024];
   __shared__ int s_n;
@@ -310,11 +325,16 @@ static inline grb_info ensure_pull_hint(Index** cache, const CsrArrays& M, const
   if (*cache) return GRB_SUCCESS;
   GRB_HIP_TRY(hipMalloc((void**)cache, 4 * (size_t)(M.n > 0 ? M.n : 1)));
   if (M.n > 0) {
+    unsigned char* d_cls = nullptr;                              // (stream-ordered: freed when the kernels below have run)
+    GRB_HIP_TRY(hipMallocAsync((void**)&d_cls, (size_t)M.n, s));
+    hipLaunchKernelGGL(bfs_degree_class_kernel, dim3(stream_grid(M.n)), dim3(kBlock), 0, s, deg_ptr, M.n, d_cls);
     hipLaunchKernelGGL(bfs_hint_kernel, dim3(stream_grid((long long)ceil_div(M.n, kWave) * kWave, kBlock)),
-                       dim3(kBlock), 0, s, M.ptr, M.ind, M.n, deg_ptr, *cache);
-    hipLaunchKernelGGL(bfs_hint_long_kernel, dim3(stream_grid((long long)M.n, 1024)), dim3(1024), 0, s, M.ptr, M.ind, M.n, deg_ptr,
-                       *cache);
-    GRB_HIP_TRY(hipGetLastError());
+                       dim3(kBlock), 0, s, M.ptr, M.ind, M.n, (const unsigned char*)d_cls, *cache);
+    hipLaunchKernelGGL(bfs_hint_long_kernel, dim3(stream_grid((long long)M.n, 1024)), dim3(1024), 0, s, M.ptr, M.ind, M.n,
+                       (const unsigned char*)d_cls, *cache);
+    const hipError_t le = hipGetLastError();
+    GRB_HIP_TRY(hipFreeAsync(d_cls, s));
+    GRB_HIP_TRY(le);
   }
   return GRB_SUCCESS;
 }

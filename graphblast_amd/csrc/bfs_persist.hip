@@ -1948,6 +1948,13 @@ grb_info grb::bfs_persistent_wait(int slot, int seq, int* levels, int* last_dir,
   // (reading the labels, say) waits for the lane's last launch -- the record is written by ONE workgroup's last
   // instruction, others may still be storing labels
   if (r == GRB_SUCCESS && lane > 0 && g_ring.lane[lane].ev_done) (void)hipStreamWaitEvent(ctx().stream, g_ring.lane[lane].ev_done, 0);
+  // ... and a caller who has taken the vector's storage (grb_vector_device_ptrs: zero-copy interop) may read it on a stream
+  // the library knows nothing about: for such a vector the wait is for the LAUNCH, whose end also writes the labels back
+  // from the L2s they were stored through
+  if (r == GRB_SUCCESS && g_ring.t[slot].v && g_ring.t[slot].v->exposed) {
+    hipStream_t ts = lane > 0 && g_ring.lane[lane].stream ? g_ring.lane[lane].stream : ctx().stream;
+    if (hipStreamSynchronize(ts) != hipSuccess) return GRB_PANIC;
+  }
   g_ring.wait_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
   return r;
 }

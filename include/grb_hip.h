@@ -326,7 +326,12 @@ grb_info grb_bfs_fused(grb_vector v, grb_matrix A, grb_index source, grb_descrip
  * 256 tickets may be outstanding (GRB_INSUFFICIENT_SPACE).  A traversal the one-launch kernel does not serve (road-network
  * queues, GRB_SPARSE_MATRIX_FORMAT=1) runs to its end inside the enqueue call; its ticket waits like any other.
  * grb_bfs_wait returns what grb_bfs_fused would have returned (a launch that could not finish is re-run through the
- * host-driven level loop there); a ticket can be waited for once (GRB_INVALID_VALUE afterwards). */
+ * host-driven level loop there); a ticket can be waited for once (GRB_INVALID_VALUE afterwards).
+ * Ordering of the labels: grb_bfs_wait returns when the traversal's RECORD has arrived; the library's own stream is
+ * ordered behind the launch, so every entry point called afterwards sees the complete depth vector.  A caller that reads
+ * v's storage itself (grb_vector_device_ptrs) on a stream of its own gets the same guarantee a different way: for a
+ * vector whose storage has been handed out, grb_bfs_wait waits for the launch itself
+ * (tests/test_gpu_algorithms.py::test_bfs_wait_on_a_vector_read_through_its_device_pointer). */
 typedef int64_t grb_bfs_ticket;
 grb_info grb_bfs_fused_enqueue(grb_vector v, grb_matrix A, grb_index source, grb_descriptor desc,
                                grb_bfs_ticket* ticket);

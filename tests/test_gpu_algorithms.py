@@ -388,6 +388,51 @@ def test_bfs_coscheduled(hb, graphs, capfd):
         g.bfs_set_coschedule(before)
 
 
+def test_bfs_wait_on_a_vector_read_through_its_device_pointer(hb, graphs):
+    """Zero-copy interop: the caller takes a vector's device storage (grb_vector_device_ptrs) and reads it on a stream the
+    library knows nothing about, right after grb_bfs_wait.  The record a wait looks at is written by ONE workgroup while
+    others may still be storing labels, so for such a vector the wait is for the launch itself: the copy below (a torch
+    tensor over the raw pointer, copied on torch's own stream) must hold the complete depth vector -- one traversal per
+    launch, lanes, and several traversals per launch."""
+    import torch
+    from oracle import simple_reference as sr
+    g = hb.g
+    name, gr = max(graphs, key=lambda x: x[1]["nnz"])
+    ptr, ind = gr["csr"]
+    A = build(hb, gr)
+    n = gr["n"]
+    srcs = [first_source(gr)] + g.graphgen.random_sources(ptr, 11, seed=13)
+    want = {s_: sr.bfs(ptr, ind, s_)[0] for s_ in srcs}
+    d = hb.descriptor(mxvmode=0, struconly=1, opreuse=1, edgeswitch=0.05)
+
+    def view(v):
+        p = v.device_ptrs()[2]
+        class _Iface:                                           # a tensor over the library's device memory, no copy
+            __cuda_array_interface__ = {"shape": (n,), "typestr": "<f4", "data": (int(p), False), "version": 2}
+        return torch.as_tensor(_Iface(), device="cuda")
+
+    side = torch.cuda.Stream()
+    for lanes, co in ((1, 1), (2, 1), (1, 4)):
+        g.bfs_set_lanes(lanes)
+        g.bfs_set_coschedule(co)
+        try:
+            for rep in range(6):
+                vs = [g.Vector(n) for _ in srcs]
+                for v in vs:
+                    assert v.fill(-1.0) == 0
+                views = [view(v) for v in vs]                   # (marks the storage as handed out)
+                tickets = [g.bfs_enqueue(v, A, s_, d) for v, s_ in zip(vs, srcs)]
+                assert all(i == 0 for i, _ in tickets)
+                for (i_, t), s_, vw in zip(tickets, srcs, views):
+                    assert g.bfs_wait(t)[0] == 0
+                    with torch.cuda.stream(side):
+                        got = vw.to("cpu", non_blocking=False).numpy()
+                    assert np.array_equal(got, want[s_]), (lanes, co, rep, s_, int(np.count_nonzero(got != want[s_])))
+        finally:
+            g.bfs_set_lanes(1)
+            g.bfs_set_coschedule(1)
+
+
 def test_bfs_lanes_waited_for_in_reverse(hb, graphs, capfd):
     """250 traversals queued over two lanes and waited for LAST ticket first: the wait outlasts its spin phase (5 ms) and
     falls back to waiting for the stream -- the stream of the ticket's lane, not the library's (a wait on the wrong stream
