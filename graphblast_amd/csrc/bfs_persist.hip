@@ -1162,9 +1162,11 @@ grb_info grb::oc_tables_build(const Index* d_ptr, const Index* d_ind, const std:
   (void)optr;
   if (nrows <= 0 || n < 2 * kOcBin) return GRB_SUCCESS;
   // the big rows: flags, their exclusive scan (= a big row's number), the list
+  // (temporaries from the stream-ordered allocator: a hipFree waits for the whole device, three of them were 0.2 ms of a
+  // matrix's first traversal)
   unsigned int* d_flag = nullptr;
-  GRB_HIP_TRY(hipMalloc((void**)&d_flag, 4 * ((size_t)nrows + 1)));
-  struct FreeFlag { void* p; ~FreeFlag() { (void)hipFree(p); } } free_flag{d_flag};
+  GRB_HIP_TRY(hipMallocAsync((void**)&d_flag, 4 * ((size_t)nrows + 1), s));
+  struct FreeFlag { void* p; hipStream_t s; ~FreeFlag() { (void)hipFreeAsync(p, s); } } free_flag{d_flag, s};
   hipLaunchKernelGGL(oc_big_flag_kernel, dim3(stream_grid((long long)nrows + 1, kBlock)), dim3(kBlock), 0, s, d_ptr, nrows, d_flag);
   GRB_HIP_TRY(hipGetLastError());
   GRB_TRY(device_exclusive_scan_u32(d_flag, (long long)nrows + 1));
@@ -1177,11 +1179,11 @@ grb_info grb::oc_tables_build(const Index* d_ptr, const Index* d_ind, const std:
   std::vector<unsigned int> bins((size_t)nbins, 0u);
   void *p_rows = nullptr, *p_bins = nullptr;
   int* d_big = nullptr;
-  struct FreeTemp { void** p; ~FreeTemp() { if (*p) (void)hipFree(*p); } } free_rows{&p_rows}, free_bins{&p_bins};   // on every way out
-  GRB_HIP_TRY(hipMalloc(&p_rows, sizeof(Index) * nrows_big));
+  struct FreeTemp { void** p; hipStream_t s; ~FreeTemp() { if (*p) (void)hipFreeAsync(*p, s); } } free_rows{&p_rows, s}, free_bins{&p_bins, s};   // on every way out
+  GRB_HIP_TRY(hipMallocAsync(&p_rows, sizeof(Index) * nrows_big, s));
   GRB_HIP_TRY(hipMalloc((void**)&d_big, sizeof(int) * (size_t)nrows));
   struct FreeBig { int** p; ~FreeBig() { if (*p) (void)hipFree(*p); } } free_big{&d_big};   // (handed over on success)
-  GRB_HIP_TRY(hipMalloc(&p_bins, 4 * (size_t)nbins));
+  GRB_HIP_TRY(hipMallocAsync(&p_bins, 4 * (size_t)nbins, s));
   GRB_HIP_TRY(hipMemsetAsync(p_bins, 0, 4 * (size_t)nbins, s));
   hipLaunchKernelGGL(oc_big_place_kernel, dim3(stream_grid(nrows, kBlock)), dim3(kBlock), 0, s, d_ptr, nrows, (const unsigned int*)d_flag,
                      d_big, (Index*)p_rows);
@@ -1197,7 +1199,7 @@ grb_info grb::oc_tables_build(const Index* d_ptr, const Index* d_ind, const std:
   GRB_HIP_TRY(hipGetLastError());
   GRB_HIP_TRY(hipMemcpyAsync(bins.data(), p_bins, 4 * (size_t)nbins, hipMemcpyDeviceToHost, s));
   GRB_HIP_TRY(hipStreamSynchronize(s));
-  (void)hipFree(p_bins);
+  (void)hipFreeAsync(p_bins, s);
   p_bins = nullptr;
   long long total = 0;
   for (unsigned int x : bins) total += (long long)x;
