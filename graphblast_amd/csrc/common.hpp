@@ -813,6 +813,7 @@ struct TcCoreDev {
   TcCoreDev(const TcCoreDev&) = delete;
   ~TcCoreDev();
 };
+grb_info tc_core_alloc(TcCoreDev* d, void** p, size_t bytes);   // device memory that lives as long as d
 grb_info tc_core_rows(const Index* ptr, Index n, int k_want, TcCoreDev* d);
 grb_info tc_core_bits(const Index* ptr, const Index* ind, TcCoreDev* d, bool split);
 grb_info tc_core_tiles(TcCoreDev* d, int method, int dense_from, grb_tc_core_result* res);

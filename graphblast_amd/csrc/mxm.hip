@@ -1349,7 +1349,7 @@ grb_info grb_mxm(grb_matrix C, grb_matrix mask, grb_accum accum, grb_semiring op
         GRB_TRY(tc_core_rows(Aa.ptr, Aa.n, core_k, &core));
         if (core.K >= 2 * 128) {
           void* p_mv;
-          GRB_TRY(scratch(4, 4 * (size_t)mask->nvals, &p_mv));
+          GRB_TRY(tc_core_alloc(&core, &p_mv, 4 * (size_t)mask->nvals));   // (not a scratch slot: the push path keeps state in those)
           GRB_HIP_TRY(hipMemcpyAsync(p_mv, mask->csr.val, 4 * (size_t)mask->nvals, hipMemcpyDeviceToDevice, s));
           GRB_TRY(tc_core_bits(Aa.ptr, Aa.ind, &core, true));
           if (core.nent > 0) {
@@ -1366,7 +1366,7 @@ grb_info grb_mxm(grb_matrix C, grb_matrix mask, grb_accum accum, grb_semiring op
       if constexpr (std::is_same<T, int>::value && mxm_plus_monoid<SR>()) {
         const size_t ne = ((size_t)core.nent + 63) & ~(size_t)63;
         void* p_cw;
-        GRB_TRY(scratch(5, 4 * 3 * ne + 64, &p_cw));
+        GRB_TRY(tc_core_alloc(&core, &p_cw, 4 * 3 * ne + 64));
         int* ch = (int*)p_cw;
         T* ct = (T*)p_cw + ne;
         T* ones = (T*)p_cw + 2 * ne;

@@ -352,6 +352,8 @@ __global__ __launch_bounds__(kBlock) void core_combine_kernel(T* __restrict__ c_
 using namespace grb;
 
 TcCoreDev::~TcCoreDev() { for (void* q : owned) (void)hipFree(q); }
+static grb_info core_malloc(TcCoreDev* d, void** p, size_t bytes);
+grb_info grb::tc_core_alloc(TcCoreDev* d, void** p, size_t bytes) { return core_malloc(d, p, bytes); }
 static grb_info core_malloc(TcCoreDev* d, void** p, size_t bytes) {
   GRB_HIP_TRY(hipMalloc(p, bytes ? bytes : 4));
   d->owned.push_back(*p);
