@@ -740,6 +740,7 @@ grb_info part_bfs_run(grb_part* ps, int nranks, grb_index source, int mode, floa
     if (w != world || r != p0->rank) return GRB_UNINITIALIZED_OBJECT;
   }
   if (world > 1 || levels_per_launch < 1) levels_per_launch = 1;
+  GRB_TRY(bfs_lanes_fence(ctx().stream));   // a whole-device grid must not meet a BFS lane's narrower one half-way (bfs_persist.hip)
   static int max_per_cu = 0;
   if (!max_per_cu) {
     GRB_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&max_per_cu, bfs_part_level_kernel, kPThreads, 0));

@@ -286,10 +286,12 @@ grb_info lazy_flush_reduce(grb_vector u, int monoid, double* out, bool* done) {
   for (int b = 0; b < p.nbuf; ++b)
     if (p.buf[b] == u->d_val) red = b;
   if (red < 0) return GRB_SUCCESS;
-  g_lazy.n = 0;
+  // The queue is cleared only once the fused launch is out: the queued steps have been answered GRB_SUCCESS already, so if
+  // the preparation or the launch fails they stay queued -- the caller's ordinary flush (which has a step-by-step
+  // fallback) runs them, and the reduction takes its own kernel.
   int grid;
   unsigned int *d_partial, *d_ticket;
-  GRB_TRY(reduce_launch_prep(q.nsize, &grid, &d_partial, &d_ticket));
+  if (reduce_launch_prep(q.nsize, &grid, &d_partial, &d_ticket) != GRB_SUCCESS) return GRB_SUCCESS;
   Context& c = ctx();
   const int seq = ++c.mail_seq;
   static const int ops[6] = {OP_PLUS, OP_TIMES, OP_MIN, OP_MAX, OP_LOR, OP_LAND};
@@ -303,7 +305,8 @@ grb_info lazy_flush_reduce(grb_vector u, int monoid, double* out, bool* done) {
   else
     hipLaunchKernelGGL(lazy_chain_reduce_kernel<int>, dim3(grid), dim3(kBlock), 0, c.stream, p, q.nsize, red, ops[monoid], ident_bits,
                        d_partial, d_ticket, c.d_hgran, seq);
-  GRB_HIP_TRY(hipGetLastError());
+  if (hipGetLastError() != hipSuccess) return GRB_SUCCESS;   // (not launched: the steps are still queued, *done is false)
+  g_lazy.n = 0;
   unsigned int raw = 0;
   GRB_TRY(wait_granules(seq, 1, &raw));
   if (q.dtype == GRB_F32) { float f; memcpy(&f, &raw, 4); *out = (double)f; }

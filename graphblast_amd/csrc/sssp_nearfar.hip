@@ -718,6 +718,7 @@ grb_info grb::sssp_nearfar_run(grb_vector v, grb_matrix A, grb_index source, grb
     A->mean_value = A->nvals > 0 ? sum / (double)A->nvals : 0.0;
   }
   const int nwords = 2 * ceil_div(n, 64);
+  GRB_TRY(bfs_lanes_fence(ctx().stream));   // a whole-device grid must not meet a BFS lane's narrower one half-way (bfs_persist.hip)
   static int max_per_cu = 0;
   if (!max_per_cu) {
     int m2 = 0;
@@ -862,6 +863,7 @@ grb_info grb::bfs_queue_run(grb_vector v, grb_matrix A, grb_index source, grb_de
   const Index n = A->nrows;
   Context& c = ctx();
   hipStream_t s = c.stream;
+  GRB_TRY(bfs_lanes_fence(ctx().stream));   // a whole-device grid must not meet a BFS lane's narrower one half-way (bfs_persist.hip)
   static int max_per_cu = 0;
   if (!max_per_cu) {
     GRB_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&max_per_cu, sssp_nfq_kernel, kPThreads, 0));

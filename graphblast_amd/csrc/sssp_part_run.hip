@@ -450,6 +450,7 @@ grb_info part_sssp_run(grb_part_sssp* ps, int nranks, grb_index source, int max_
     if (w != world || r != p0->rank) return GRB_UNINITIALIZED_OBJECT;
   }
   if (world > 1 || rounds_per_launch < 1) rounds_per_launch = 1;
+  GRB_TRY(bfs_lanes_fence(ctx().stream));   // a whole-device grid must not meet a BFS lane's narrower one half-way (bfs_persist.hip)
   static int max_per_cu = 0;
   if (!max_per_cu) {
     GRB_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&max_per_cu, sssp_part_kernel, kPThreads, 0));

@@ -363,6 +363,7 @@ grb_info sssp_persistent_run(grb_vector v, grb_matrix A, grb_index source, grb_d
   }
 
   const int nwords = 2 * ceil_div(n, 64);
+  GRB_TRY(bfs_lanes_fence(ctx().stream));   // a whole-device grid must not meet a BFS lane's narrower one half-way (bfs_persist.hip)
   static int max_per_cu = 0;
   if (!max_per_cu) {
     GRB_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&max_per_cu, sssp_persistent_kernel, kPThreads, 0));
