@@ -68,6 +68,21 @@ def pmc_traffic(kernel_key, workload="rmat22_bfs"):
     return best, where
 
 
+def pmc_per_traversal(kernel_key):
+    """(HBM bytes per TRAVERSAL of a launch of several, source): the launches of a PMC pass carry different numbers of
+    traversals, so tools/summarize_profiles.py divides their summed counters by the traversals they ran"""
+    best, where = None, None
+    pdir = os.path.join(ROOT, "profiles")
+    for d in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
+        f = os.path.join(pdir, d, "pmc_traffic.json")
+        if os.path.exists(f):
+            for name, rec in json.load(open(f)).get("kernels", {}).items():
+                if kernel_key in name and rec.get("hbm_bytes_per_traversal"):
+                    best = rec["hbm_bytes_per_traversal"]
+                    where = "profiles/%s/pmc_traffic.json (separate rocprofv3 --pmc passes, not this run)" % d
+    return best, where
+
+
 def pmc_group(name, workload=None):
     """(HBM bytes per unit of a group of kernels -- e.g. all batch_* launches of one 64-source sweep -- , source)"""
     best, where = None, None
@@ -722,8 +737,9 @@ def main():
         ach = total_bytes / (event_ms * 1e-3) / 1e9
         roofline = {"bound": "hbm", "kernel": "bfs_persistent_kernel", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-                    "traffic": pmc_traffic("bfs_persistent_kernel")[0],
-                    "traffic_source": pmc_traffic("bfs_persistent_kernel")[1], "launches": args.steps,
+                    "traffic": pmc_traffic("bfs_persistent_kernel<1024>")[0] or pmc_traffic("bfs_persistent_kernel")[0],
+                    "traffic_source": pmc_traffic("bfs_persistent_kernel<1024>")[1] or pmc_traffic("bfs_persistent_kernel")[1],
+                    "launches": args.steps,
                     "avg_launch_ms": round(event_ms / args.steps, 5),
                     "algorithmic_bytes_per_launch": int(total_bytes / args.steps)}
         # the design's floor for ONE traversal at a time: what a traversal of this many levels costs when its levels have
@@ -751,7 +767,10 @@ def main():
                                   "launches": cr["launches"], "traversals_per_launch": round(args.steps / max(cr["launches"], 1), 2),
                                   "avg_launch_ms": round(cr["launch_ms_total_by_hip_events"] / max(cr["launches"], 1), 5),
                                   "algorithmic_bytes_per_launch": int(total_bytes / max(cr["launches"], 1)),
-                                  "traffic": None}
+                                  "traffic": (int(pmc_per_traversal("bfs_persistent_kernel<%d>" % (256 if k == "4" else 128))[0] *
+                                                  args.steps / max(cr["launches"], 1))
+                                              if pmc_per_traversal("bfs_persistent_kernel<%d>" % (256 if k == "4" else 128))[0] else None),
+                                  "traffic_source": pmc_per_traversal("bfs_persistent_kernel<%d>" % (256 if k == "4" else 128))[1]}
         tight_ms = sum(r["tight_ms"] for r in results)
         one = account[sources[0]]
         ob = level_bytes(one, n)
@@ -1230,8 +1249,9 @@ def main():
                 ach = total_bytes / (event_ms * 1e-3) / 1e9
                 roofline = {"bound": "hbm", "kernel": "bfs_persistent_kernel", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS,
                             "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-                            "traffic": pmc_traffic("bfs_persistent_kernel")[0],
-                            "traffic_source": pmc_traffic("bfs_persistent_kernel")[1], "launches": len(mine),
+                            "traffic": pmc_traffic("bfs_persistent_kernel<1024>")[0] or pmc_traffic("bfs_persistent_kernel")[0],
+                            "traffic_source": pmc_traffic("bfs_persistent_kernel<1024>")[1] or pmc_traffic("bfs_persistent_kernel")[1],
+                            "launches": len(mine),
                             "avg_launch_ms": round(event_ms / len(mine), 5),
                             "algorithmic_bytes_per_launch": int(total_bytes / len(mine)),
                             "note": "per-GPU kernel of the source_sharded_replicas leg, rank 0"}

@@ -14,7 +14,7 @@ if kept_w and os.path.exists(dst + '/other_workloads.jsonl'):
         for W, key in (("lj_bfs", "soc-L"), ("road_sssp", "road"), ("orkut_tc", "rkut")):
             if key in json.loads(ln).get("metric", "") + json.dumps(json.loads(ln).get("config", {})):
                 prev_lines.setdefault(W, ln)
-keep_prefixes = ("full_suite", "bfs_", "tests_", "sssp_", "tc_", "spmv_", "bench_spread", "orkut_tc_kernel_stats_before") + tuple(kept_w) + \
+keep_prefixes = ("full_suite", "bfs_", "tests_", "sssp_", "tc_", "spmv_", "bench_spread", "orkut_tc_kernel_stats_before", "core_", "co", "prep", "driver_", "README") + tuple(kept_w) + \
     tuple("pmc_%s_" % W for W in kept_w)
 for f in os.listdir(dst):
     if not f.startswith(keep_prefixes):     # logs of test / A-B runs kept beside the profiles
@@ -39,7 +39,14 @@ if os.path.exists(trace):
     if "bfs_prep" in line:                   # since round 4 the bench times a matrix's FIRST traversal before the warm-up
         W += 1
     tr = [r for r in csv.DictReader(open(trace))]
-    bfs = [int(r["duration_ns"]) for r in tr if r["kernel"].startswith("grb::bfs_persistent_kernel")]
+    # (since round 6 the kernel is a template on the workgroup's width: <1024> one traversal per launch, <512> / <256> /
+    # <128> the launches of several traversals)
+    bfs = [int(r["duration_ns"]) for r in tr if r["kernel"].startswith("grb::bfs_persistent_kernel<1024>")]
+    co = {}
+    for r in tr:
+        for wdt in ("512", "256", "128"):
+            if r["kernel"].startswith("grb::bfs_persistent_kernel<%s>" % wdt):
+                co.setdefault(wdt, []).append(int(r["duration_ns"]))
     spmv = {}
     for r in tr:
         for key in ("spmv_cband_kernel", "cband_pack_kernel", "spmv_cband_fold_kernel", "spmv_hub_kernel", "pack_vector_kernel",
@@ -51,6 +58,8 @@ if os.path.exists(trace):
     E = W + K + (min(line["warmup"], 2) + K if "blocking_loop" in line else 0)
     if "lanes" in line:                      # the two-lane sibling: max(warmup, 2) warm-ups + K steps, then 2 + K on one lane again
         E += max(line["warmup"], 2) + K + 2 + K
+    if "coscheduled" in line:                # ... its launches are other kernels, but K one-at-a-time steps follow it
+        E += K
     ph = {"source": "rocprofv3 --kernel-trace of the default `python bench.py` (same run as bench_kernel_stats_*.csv)",
           "warmup": W, "steps": K, "bfs_persistent_kernel_launches": len(bfs),
           "bfs_persistent_kernel_mean_us": {
@@ -58,6 +67,10 @@ if os.path.exists(trace):
               "hip_event_pass_launches": round(sum(bfs[E:E + K]) / K / 1e3, 2),
               "hip_event_pass_first_launch_index": E,
               "all_launches_of_the_run": round(sum(bfs) / len(bfs) / 1e3, 2)},
+          "coscheduled_launches": {("bfs_persistent_kernel<%s>" % k_): {"launches": len(v_), "durations_us": [round(x / 1e3, 1) for x in v_]}
+                                   for k_, v_ in co.items()},
+          "coscheduled_hip_event_ms_reported_by_bench": {k_: line["coscheduled"][k_]["launch_ms_total_by_hip_events"]
+                                                         for k_ in ("4", "8")} if "coscheduled" in line else None,
           "hip_event_mean_us_reported_by_bench": round(line["roofline"]["avg_launch_ms"] * 1e3, 2),
           "spmv_kernels_mean_us": {k: round(sum(v) / len(v) / 1e3, 2) for k, v in spmv.items()},
           "spmv_hip_event_mean_us_reported_by_bench": round(line["spmv"]["avg_launch_ms"] * 1e3, 2)}
@@ -87,6 +100,23 @@ def pmc_tables(prefix, csv_prefix):
         f_, w_ = v.get("FETCH_SIZE_KB_mean", 0), v.get("WRITE_SIZE_KB_mean", 0)
         v["hbm_bytes_per_launch_raw"] = int((f_ + w_) * 1024)
         v["hbm_bytes_per_launch"] = int((2 * f_ + w_) * 1024)
+    # the launches of several traversals carry different numbers of them (warm-up, timed, profiled passes): per TRAVERSAL,
+    # from the command's own step / warm-up counts (bench.py: max(warmup, 2 k) warm-up + 3 x steps timed + steps profiled)
+    plog = src + '/%sFETCH_SIZE.log' % prefix
+    if os.path.exists(plog):
+        try:
+            pl = json.loads([x for x in open(plog).read().strip().splitlines() if x.startswith("{")][-1])
+            for wdt, kk in (("256", 4), ("128", 8)):
+                name = "grb::bfs_persistent_kernel<%s>" % wdt
+                if name in out and "coscheduled" in pl:
+                    trav = max(pl["warmup"], 2 * kk) + 4 * pl["steps"]
+                    v = out[name]
+                    tot = 1024.0 * (2 * v.get("FETCH_SIZE_KB_mean", 0) * v.get("launches_FETCH_SIZE", 0) +
+                                    v.get("WRITE_SIZE_KB_mean", 0) * v.get("launches_WRITE_SIZE", 0))
+                    v["traversals_in_these_launches"] = trav
+                    v["hbm_bytes_per_traversal"] = int(tot / trav)
+        except Exception as exc:                # noqa: BLE001
+            print("co-scheduled traffic not derived:", exc)
     return out
 
 
@@ -148,7 +178,7 @@ doc = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes
                "reported at exactly 1/2; WRITE_SIZE matches the written 262144 KB).  hbm_bytes_per_launch_raw is the uncorrected sum.",
        "calibration": cal, "kernels": out, "groups": groups, "workloads": workloads}
 json.dump(doc, open(dst + '/pmc_traffic.json', 'w'), indent=1, sort_keys=True)
-for k in ("grb::bfs_persistent_kernel", "grb::spmv_cband_kernel<1, float, false>", "grb::spmv_cband_kernel<1, float, true>", "grb::cband_pack_kernel<float>"):
+for k in ("grb::bfs_persistent_kernel<1024>", "grb::bfs_persistent_kernel<256>", "grb::bfs_persistent_kernel<128>", "grb::spmv_cband_kernel<1, float, false>", "grb::spmv_cband_kernel<1, float, true>", "grb::cband_pack_kernel<float>"):
     print(k, out.get(k, {}).get("hbm_bytes_per_launch"))
 print("groups", groups)
 for W, d in workloads.items():
