@@ -956,7 +956,14 @@ def main():
                                  "achieved": round(sp_bytes / (sp_ms * 1e-3) / 1e9, 1), "unit": "GB/s",
                                  "frac": round(sp_bytes / (sp_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                  "gathered_B_rows_GBps": round(4.0 * kk * nnz / (sp_ms * 1e-3) / 1e9, 1),
-                                 "vs_64_spmv_launches": round(64 * ms / sp_ms, 2)}
+                                 "vs_64_spmv_launches": round(64 * ms / sp_ms, 2),
+                                 "note": "a convenience path (the reference stops at a stub here, backend/cuda/operations.hpp:52-70), "
+                                         "not a tuned one: every nonzero gathers a whole row of B (4 k bytes) from the L2s, and the "
+                                         "kernel runs at the rate of those gathers (gathered_B_rows_GBps), whatever HBM does.  What "
+                                         "would change that is reuse of B's rows on the CU -- row bands with their sums in LDS and "
+                                         "entries sorted by column, as the SpMV band format has -- which a wave-per-tile kernel with "
+                                         "k-wide rows cannot hold (DESIGN.md 5.3); not built.  `frac` prices it on the reference "
+                                         "format's compulsory bytes all the same"}
             del tB, tC
 
         # ---- the same SpMV kernel where the gathers are local (a road-like 4096^2 grid in natural
