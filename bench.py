@@ -177,7 +177,25 @@ def other_workload(args):
                                  "host_enqueue_us_per_step": round(htb["enqueue_us"] / max(htb["calls"], 1), 2),
                                  "host_wait_us_per_step": round(htb["wait_us"] / max(htb["calls"], 1), 2)}
         line["queued"] = {"host_enqueue_us_per_step": round(ht["enqueue_us"] / max(ht["calls"], 1), 2)}
-        del vs
+        # the same steps, eight traversals side by side per launch (grb_bfs_set_coschedule, as in the headline run); every
+        # vector's labels against the one-at-a-time steps'
+        solo_labels = [x.extractTuples()[1] for x in vs]
+        g.bfs_set_coschedule(8)
+        for t_ in [g.bfs_enqueue(vs[i], A, sources[i % 64], desc)[1] for i in range(min(args.steps, 16))]:
+            g.bfs_wait(t_)
+        torch.cuda.synchronize()
+        t0c = time.perf_counter()
+        tickets = [g.bfs_enqueue(vs[i], A, sources[i % 64], desc)[1] for i in range(args.steps)]
+        res_c = [g.bfs_wait(t)[1] for t in tickets]
+        torch.cuda.synchronize()
+        el_c = time.perf_counter() - t0c
+        g.bfs_set_coschedule(1)
+        assert [r_["reached"] for r_ in res_c] == [r_["reached"] for r_ in res]
+        assert all(np.array_equal(x.extractTuples()[1], w_) for x, w_ in zip(vs, solo_labels)), "co-scheduled labels differ"
+        line["coscheduled_8"] = {"value": sum(r_["edges_traversed"] for r_ in res_c) / el_c, "unit": "TEPS",
+                                 "ms_per_step": round(el_c / args.steps * 1e3, 5),
+                                 "labels": "all %d vectors equal to the one-at-a-time steps'" % len(vs)}
+        del vs, solo_labels
         ev = sum(g.bfs(v, A, sources[i % 64], desc, fused=True, profile=1)[1]["tight_ms"] for i in range(args.steps))
         acct = {s_: g.bfs(v, A, s_, desc, fused=True, profile=3)[1]["per_level"] for s_ in set(sources[i % 64] for i in range(args.steps))}
         tb = float(sum(sum(level_bytes(acct[sources[i % 64]], n)) for i in range(args.steps)))
@@ -188,7 +206,8 @@ def other_workload(args):
                                                "n": n, "nnz": nnz},
                      "roofline": {"bound": "hbm", "kernel": kern, "achieved": round(tb / (ev * 1e-3) / 1e9, 2),
                                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(tb / (ev * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                  "traffic": pmc_traffic(kern, "lj_bfs")[0], "traffic_source": pmc_traffic(kern, "lj_bfs")[1],
+                                  "traffic": pmc_traffic(kern + "<1024>", "lj_bfs")[0] or pmc_traffic(kern, "lj_bfs")[0],
+                                  "traffic_source": pmc_traffic(kern + "<1024>", "lj_bfs")[1] or pmc_traffic(kern, "lj_bfs")[1],
                                   "avg_launch_ms": round(ev / args.steps, 5),
                                   "algorithmic_bytes_per_launch": int(tb / args.steps)}})
         if not args.no_cpu_baseline:
