@@ -37,8 +37,14 @@
 namespace grb {
 
 constexpr int kPKeep = 32;          // levels whose discovered-bitmaps are kept for the final label pass
-constexpr int kPSmallDeg = 16;      // push: below, expanded by the lane that found the vertex
-constexpr int kPBigDeg = 512;       // push: from here, cut into kPBigChunk-edge entries for whole workgroups
+#ifndef GRB_PART_SMALL_DEG
+#define GRB_PART_SMALL_DEG 16
+#endif
+#ifndef GRB_PART_BIG_DEG
+#define GRB_PART_BIG_DEG 512
+#endif
+constexpr int kPSmallDeg = GRB_PART_SMALL_DEG;      // push: below, expanded by the lane that found the vertex
+constexpr int kPBigDeg = GRB_PART_BIG_DEG;          // push: from here, cut into kPBigChunk-edge entries for whole workgroups
 constexpr int kPBigChunk = 1024;
 constexpr int kPPullBlock = 8;      // 64-vertex chunks a wave carries through the pull stages together
 constexpr int kPMedCap = 4096;
@@ -210,15 +216,32 @@ __global__ __launch_bounds__(kPThreads) void bfs_part_level_kernel(PartArgs a) {
           }
         }
         int ent = 0;
-        for (unsigned int t = f; t; t &= t - 1) {
-          const Index vtx = (Index)i * 32 + (__ffs((int)t) - 1);
-          const int d = a.deg[vtx];
-          ++c_found;
-          c_deg += (unsigned long long)d;
-          if (owned && count_only) a.label[vtx - a.lo] = 0.f;   // found by the level that ended the loop: never assigned (bfs.hpp:48-66)
-          if (owned && !count_only) {
-            if (direct) a.label[vtx - a.lo] = lab;
-            if (d >= kPBigDeg) { ++c_big; ent += a.oc_off ? 1 : (d + kPBigChunk - 1) / kPBigChunk; }
+        // the word's vertices eight at a time: their out-degrees are eight independent random reads of the replicated
+        // degree array, and a bit-by-bit loop waits for each before it asks for the next -- a word of the big level holds
+        // up to 32 discoveries, i.e. 32 memory latencies on the level's critical path (the apply pass of that level was
+        // ~20 us of the traversal's 0.2 ms)
+        for (unsigned int t = f; t;) {
+          Index vt[8];
+          int dd[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            vt[j] = t ? (Index)i * 32 + (__ffs((int)t) - 1) : -1;
+            t &= t - 1;                                      // (0 stays 0)
+          }
+#pragma unroll
+          for (int j = 0; j < 8; ++j) dd[j] = vt[j] >= 0 ? a.deg[vt[j]] : 0;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            if (vt[j] < 0) continue;
+            const Index vtx = vt[j];
+            const int d = dd[j];
+            ++c_found;
+            c_deg += (unsigned long long)d;
+            if (owned && count_only) a.label[vtx - a.lo] = 0.f;   // found by the level that ended the loop: never assigned (bfs.hpp:48-66)
+            if (owned && !count_only) {
+              if (direct) a.label[vtx - a.lo] = lab;
+              if (d >= kPBigDeg) { ++c_big; ent += a.oc_off ? 1 : (d + kPBigChunk - 1) / kPBigChunk; }
+            }
           }
         }
         if (__ballot(ent > 0)) {                          // the owned big vertices as 1024-edge entries
