@@ -181,3 +181,64 @@ def test_config5_triangle_count_on_orkut_or_standin(hb):
             print("config 5 stand-in: n %d nnz(L) %d triangles %d, %.1f ms" % (n, li.size, ntri, res["tight_ms"]))
         del L, B
     assert counts[0] == counts[1], counts
+
+
+def test_config4_pagerank_on_the_partition_at_rmat22(hb):
+    """config 4 at its own size: PageRank (PlusMultiplies mxv, pr.hpp:15-94) on RMAT-22 through the 1-D partition's device
+    loop (grb_pr_part_run: row chunks, a chunk's slice of the next vector gathered on the communication stream while the
+    next chunk is multiplied, the residual all-reduced) with the library's RCCL communicator -- a world of one rank is what
+    one GPU allows -- and the partitioned BFS on the same partition; within 1e-5 relative (north_star's bar for float
+    PageRank) of the exact iteration, within its own rounding of the CPU reference, and the single-GPU fused iteration
+    held to the same."""
+    from graphblast_amd.graphgen import rmat_edges, finalize_edges
+    from graphblast_amd.dist import Partition1D, RcclComm, bitmap_words
+    from oracle import ref_simple, simple_reference as sr
+    g = hb.g
+    dev = torch.device("cuda", 0)
+    s, d, n = rmat_edges(22, 16, seed=1, device=dev)
+    gr = finalize_edges(s, d, n, symmetrize=True)
+    del s, d
+    tptr, tind = gr["csr"]
+    ptr, ind = tptr.cpu().numpy(), tind.cpu().numpy()
+    comm = RcclComm(0, 1, bitmap_words(n), dev)
+    if True:
+        part = Partition1D(n, tptr.long(), tind.long(), 0, 1, dev, comm=comm, edgeswitch=0.08)
+        deg = torch.from_numpy(np.maximum(np.diff(ptr), 1).astype(F)).to(dev)
+        pvec, info = part.pagerank(deg, alpha=0.85, eps=0.0, max_niter=10)
+        assert info["iterations"] == 10 and info.get("overlapped_chunks", 0) == 2
+        got = pvec.cpu().numpy()
+        # With in-degrees above 1e5 the float32 reference's own sequential sums are only good to ~1e-4 relative, so at this
+        # size the 1e-5 bar is checked against the same ten power iterations in float64 and the reference is held to what
+        # its rounding allows (as tests/test_gpu_algorithms.py does for the single-GPU iteration)
+        import scipy.sparse as sp
+        outdeg = np.diff(ptr).astype(np.float64)
+        M = sp.csr_matrix((np.ones(ind.size), ind, ptr), shape=(n, n)).T.tocsr()
+        want = np.full(n, 1.0 / n)
+        for _ in range(10):
+            want = 0.85 * (M @ np.divide(want, outdeg, out=np.zeros(n), where=outdeg > 0)) + (1.0 - 0.85) / n
+        del M
+        rel = np.abs(got - want) / np.maximum(np.abs(want), 1e-30)
+        assert rel.max() <= 1e-5, float(rel.max())
+        ref32 = (ref_simple.pr(ptr, ind, 0.85, 0.0, 10)[0] if ref_simple.available() else sr.pr(ptr, ind, 0.85, 0.0, 10)[0])
+        assert (np.abs(got - ref32) / np.maximum(np.abs(ref32), 1e-30)).max() <= 5e-4
+        # the single-GPU fused iteration on the same graph: the same vector to the same tolerance
+        # (the driver's matrix is alpha / outdeg(row) on every stored entry, gpr.cu:67-90; symmetric structure: the CSC side's
+        # entry (column c, row r) carries alpha / outdeg(r) as well)
+        dgf = (tptr[1:] - tptr[:-1]).to(torch.float32).clamp_(min=1.0)
+        rows = torch.repeat_interleave(torch.arange(n, device=dev), (tptr[1:] - tptr[:-1]).long())
+        pv = (torch.tensor(0.85, dtype=torch.float32, device=dev) / dgf)[rows].contiguous()
+        pc = (torch.tensor(0.85, dtype=torch.float32, device=dev) / dgf)[tind.long()].contiguous()
+        A = g.Matrix(n, n)
+        assert A.build_device_csr(tptr.data_ptr(), tind.data_ptr(), pv.data_ptr(), gr["nnz"], tptr.data_ptr(), tind.data_ptr(),
+                                  pc.data_ptr(), keep=(tptr, tind, pv, pc)) == 0
+        p1 = g.Vector(n)
+        info1 = g.pr(p1, A, 0.85, 0.0, hb.descriptor(mxvmode=2, max_niter=10))
+        assert info1[0] == 0
+        rel1 = np.abs(hb.dense_values(p1) - want) / np.maximum(np.abs(want), 1e-30)
+        assert rel1.max() <= 1e-5, float(rel1.max())
+        # ... and a traversal on the same partition, labels bit-exact
+        src = int(np.argmax(np.diff(ptr)))
+        res = part.bfs(src)
+        depth = cpu_bfs(ptr, ind, src)
+        assert np.array_equal(part.gather_labels().cpu().numpy(), depth)
+        assert res["edges_traversed"] == int(np.diff(ptr)[depth != 0].sum())
