@@ -83,14 +83,16 @@ static grb_info bfs_tally_labels(const float* label, const Index* ptr, Index n, 
 // what the host does with the record of a one-launch traversal: lastmxv_, the labels of a search that max_niter cut
 // short (the last frontier is never assigned by the reference loop), the result block, the vector's count
 static grb_info bfs_one_launch_finish(grb_vector v, grb_matrix A, grb_descriptor desc, int p_levels, int p_dir, long long p_reached,
-                                      unsigned long long p_edges, Index p_nf, bool p_cap, float p_ms, grb_bfs_result* result) {
+                                      unsigned long long p_edges, Index p_nf, bool p_cap, float p_ms, grb_bfs_result* result,
+                                      int max_niter_queued = -1) {
   hipStream_t s = ctx().stream;
   const Index n = A->nrows;
+  const int cap_niter = max_niter_queued >= 0 ? max_niter_queued : desc->max_niter;   // (a queued traversal: the cap it ran under)
   desc->lastmxv = p_dir ? GRB_PULLONLY : GRB_PUSHONLY;
   if (p_cap && p_nf > 0) {
     bfs_lanes_unfence();                                    // (a lane's next launch into v comes after this)
     hipLaunchKernelGGL(bfs_unlabel_kernel, dim3(stream_grid(n)), dim3(kBlock), 0, s, (float*)v->d_val, n,
-                       (float)(desc->max_niter + 1));
+                       (float)(cap_niter + 1));
     GRB_HIP_TRY(hipGetLastError());
     int64_t e2 = 0; int32_t r2 = 0;
     GRB_TRY(bfs_tally_labels((const float*)v->d_val, A->csr.ptr, n, &e2, &r2));
@@ -161,7 +163,8 @@ extern "C" grb_info grb_bfs_wait(grb_bfs_ticket ticket, grb_bfs_result* result) 
   const int slot = (int)(ticket & 0xff), seq = (int)(ticket >> 8);
   grb_vector v = nullptr; grb_matrix A = nullptr; grb_descriptor desc = nullptr; grb_index source = 0;
   grb_bfs_result parked = {};
-  const int state = bfs_ticket_state(slot, seq, &v, &A, &desc, &source, &parked);
+  int max_niter_queued = -1;
+  const int state = bfs_ticket_state(slot, seq, &v, &A, &desc, &source, &parked, &max_niter_queued);
   if (state == 0) return GRB_INVALID_VALUE;                 // never issued, or waited for already
   if (state == 2) {
     if (result) *result = parked;
@@ -198,7 +201,7 @@ extern "C" grb_info grb_bfs_wait(grb_bfs_ticket ticket, grb_bfs_result* result) 
   }
   GRB_TRY(pi);
   g_persistent_failures = 0;
-  return bfs_one_launch_finish(v, A, desc, p_levels, p_dir, p_reached, p_edges, p_nf, p_cap, p_ms, result);
+  return bfs_one_launch_finish(v, A, desc, p_levels, p_dir, p_reached, p_edges, p_nf, p_cap, p_ms, result, max_niter_queued);
 }
 
 // Traversals in flight at once: with n > 1 the traversals queued by grb_bfs_fused_enqueue go round n lanes, each lane a

@@ -1261,6 +1261,7 @@ struct BfsTicket {
   grb_matrix A = nullptr;
   grb_descriptor desc = nullptr;
   grb_index source = 0;
+  int max_niter = 0;                             // as the descriptor stood when the traversal was queued (the wait's unlabel pass)
   grb_bfs_result res = {};
 };
 // A lane = what one traversal in flight needs for itself: a stream, the two state blocks, V1, the big-vertex list, the
@@ -1280,12 +1281,26 @@ struct BfsLane {
   int block = 0;                                  // one traversal per launch: which of the two blocks the next one runs on
   unsigned long long fenced_epoch = ~0ull;       // ApiScope::epoch when this lane last fenced against the library's stream
 };
+struct BfsRules {                                // the descriptor fields a traversal runs under, as they stood when it was queued
+  int mode = 0, max_niter = 0;
+  float switchpoint = 0.f, edgeswitch = 0.f;
+  bool operator==(const BfsRules& o) const {
+    return mode == o.mode && max_niter == o.max_niter && switchpoint == o.switchpoint && edgeswitch == o.edgeswitch;
+  }
+};
+static BfsRules bfs_rules_of(grb_descriptor desc) {
+  BfsRules r;
+  r.mode = desc->desc[GRB_MXVMODE]; r.max_niter = desc->max_niter; r.switchpoint = desc->switchpoint; r.edgeswitch = desc->edgeswitch;
+  return r;
+}
 struct CoPend {                                  // a traversal that has its ticket and waits for company (co-scheduling)
   int slot = 0, seq = 0;
   grb_vector v = nullptr;
   grb_matrix A = nullptr;
   grb_index source = 0;
   grb_descriptor desc = nullptr;
+  BfsRules rules;                                // (the descriptor's setters do not launch what has gathered: a traversal keeps
+                                                 // the rules it was queued under, and one launch serves one set of rules)
 };
 struct BfsRing {
   int co_width = 1;                              // traversals per launch (grb_bfs_set_coschedule); 1: every traversal its own launch
@@ -1378,7 +1393,7 @@ struct LaunchCtx {
 
 // Fills the argument block of one (sub-)grid: the lane's buffers (lane 0: the library's scratch slots), the once-per-
 // matrix facts and tables.  Queues at most memsets on lc->s.
-static grb_info bfs_persistent_args(grb_matrix A, grb_descriptor desc, int profile, int lane_id, bool co, PersistArgs* out,
+static grb_info bfs_persistent_args(grb_matrix A, const BfsRules& rules, int profile, int lane_id, bool co, PersistArgs* out,
                                     GridArgs* gout, LaunchCtx* lc, void** p_rec_out, unsigned long long** trace_out, int oc_words = kOcWords) {
   GRB_TRY(ring_init());
   Context& c = ctx();
@@ -1492,10 +1507,10 @@ static grb_info bfs_persistent_args(grb_matrix A, grb_descriptor desc, int profi
   }
   a.n_in = A->bfs_n_in;
   a.out_is_in = A->bfs_out_is_in ? 1 : 0;
-  a.mode = desc->desc[GRB_MXVMODE];
-  a.switchpoint = desc->switchpoint;
-  a.edgeswitch = desc->edgeswitch;
-  a.max_niter = desc->max_niter;
+  a.mode = rules.mode;
+  a.switchpoint = rules.switchpoint;
+  a.edgeswitch = rules.edgeswitch;
+  a.max_niter = rules.max_niter;
   a.count_inspected = (profile & 2) ? 1 : 0;
   gout->blocks = (char*)p_zero;
   a.block_bytes = (unsigned long long)block_bytes;
@@ -1607,12 +1622,13 @@ void grb::bfs_lanes_unfence() {
 // Queues one traversal (on the library's stream, or on its lane's); its record will appear in ring slot `slot` under
 // tag *seq_out.
 static grb_info bfs_persistent_launch(grb_vector v, grb_matrix A, grb_index source, grb_descriptor desc, int profile, int slot,
-                                      int* seq_out, void** p_rec_out, unsigned long long** trace_out, int lane_id = 0, int seq_in = 0) {
+                                      int* seq_out, void** p_rec_out, unsigned long long** trace_out, int lane_id = 0, int seq_in = 0,
+                                      const BfsRules* rules_in = nullptr) {
   Context& c = ctx();
   LaunchArgs la;
   memset(&la, 0, sizeof(la));
   LaunchCtx lc;
-  GRB_TRY(bfs_persistent_args(A, desc, profile, lane_id, false, &la.a, &la.g[0], &lc, p_rec_out, trace_out));
+  GRB_TRY(bfs_persistent_args(A, rules_in ? *rules_in : bfs_rules_of(desc), profile, lane_id, false, &la.a, &la.g[0], &lc, p_rec_out, trace_out));
   la.t[0].label = (float*)v->d_val;
   la.t[0].block = (char*)lc.p_zero + (size_t)(*lc.p_blocksel) * lc.block_bytes;
   la.t[0].clean = (char*)lc.p_zero + (size_t)((*lc.p_blocksel) ^ 1) * lc.block_bytes;
@@ -1684,7 +1700,7 @@ static grb_info bfs_co_launch(int ntrav, const CoPend* pend, int width) {
   for (int j = 0; j < n_grids; ++j) {
     void* p_rec = nullptr;
     unsigned long long* trace = nullptr;
-    GRB_TRY(bfs_persistent_args(pend[0].A, pend[0].desc, 0, kMaxLanes + 1 + j, true, &la.a, &la.g[j], &lc[j], &p_rec, &trace, oc_words));
+    GRB_TRY(bfs_persistent_args(pend[0].A, pend[0].rules, 0, kMaxLanes + 1 + j, true, &la.a, &la.g[j], &lc[j], &p_rec, &trace, oc_words));
   }
   for (int i = 0; i < ntrav; ++i) {
     la.t[i].label = (float*)pend[i].v->d_val;
@@ -1818,11 +1834,12 @@ grb_info grb::bfs_persistent_enqueue(grb_vector v, grb_matrix A, grb_index sourc
     // time and hands out the rest as its sub-grids come free, so the more it carries the less its tail weighs; the host
     // queues a ticket in a microsecond, so gathering costs the device nothing it notices.  One launch serves one matrix
     // and one set of descriptor fields.
-    if (g_ring.co_n > 0 && (g_ring.co[0].A != A || g_ring.co[0].desc != desc)) GRB_TRY(bfs_co_flush());
+    const BfsRules rules = bfs_rules_of(desc);
+    if (g_ring.co_n > 0 && (g_ring.co[0].A != A || !(g_ring.co[0].rules == rules))) GRB_TRY(bfs_co_flush());
     *seq = ++ctx().mail_seq;
     CoPend& p = g_ring.co[g_ring.co_n++];
-    p.slot = slot; p.seq = *seq; p.v = v; p.A = A; p.source = source; p.desc = desc;
-    t.state = 3; t.seq = *seq; t.lane = 0; t.v = v; t.A = A; t.desc = desc; t.source = source;
+    p.slot = slot; p.seq = *seq; p.v = v; p.A = A; p.source = source; p.desc = desc; p.rules = rules;
+    t.state = 3; t.seq = *seq; t.lane = 0; t.v = v; t.A = A; t.desc = desc; t.source = source; t.max_niter = rules.max_niter;
     grb_info fi = GRB_SUCCESS;
     if (g_ring.co_n >= kCoTrain) fi = bfs_co_flush();       // the launch's table is full
     g_ring.enqueue_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
@@ -1840,7 +1857,7 @@ grb_info grb::bfs_persistent_enqueue(grb_vector v, grb_matrix A, grb_index sourc
   GRB_TRY(li);
   g_ring.enqueue_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
   ++g_ring.calls;
-  t.state = 1; t.seq = *seq; t.lane = lane; t.v = v; t.A = A; t.desc = desc; t.source = source;
+  t.state = 1; t.seq = *seq; t.lane = lane; t.v = v; t.A = A; t.desc = desc; t.source = source; t.max_niter = desc->max_niter;
   return GRB_SUCCESS;
 }
 // Launches what waits: all of it in one launch when there are two or more (co_width sub-grids: 512-thread workgroups for
@@ -1865,7 +1882,7 @@ grb_info grb::bfs_co_flush() {
     unsigned long long* trace = nullptr;
     int seq = 0;
     const grb_info si = bfs_persistent_launch(pend[j].v, pend[j].A, pend[j].source, pend[j].desc, 0, pend[j].slot, &seq, &p_rec, &trace, 0,
-                                              pend[j].seq);
+                                              pend[j].seq, &pend[j].rules);
     g_ring.t[pend[j].slot].state = si == GRB_SUCCESS ? 1 : 4;
     if (si != GRB_SUCCESS && si != GRB_NOT_IMPLEMENTED && si != GRB_PANIC) worst = si;
   }
@@ -1928,7 +1945,7 @@ void grb::bfs_ticket_store(int slot, int seq, const grb_bfs_result& res) {
   t.state = 2; t.seq = seq; t.res = res;
 }
 int grb::bfs_ticket_state(int slot, int seq, grb_vector* v, grb_matrix* A, grb_descriptor* desc, grb_index* source,
-                          grb_bfs_result* parked) {
+                          grb_bfs_result* parked, int* max_niter) {
   if (slot < 0 || slot >= kRing || !g_ring.h) return 0;
   const BfsTicket& t = g_ring.t[slot];
   if (t.state == 0 || t.seq != seq) return 0;
@@ -1937,6 +1954,7 @@ int grb::bfs_ticket_state(int slot, int seq, grb_vector* v, grb_matrix* A, grb_d
   if (desc) *desc = t.desc;
   if (source) *source = t.source;
   if (parked) *parked = t.res;
+  if (max_niter) *max_niter = t.max_niter;
   return t.state;
 }
 void grb::bfs_ticket_release(int slot) { g_ring.t[slot].state = 0; }

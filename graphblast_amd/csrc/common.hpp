@@ -830,7 +830,8 @@ bool bfs_queue_wanted(grb_matrix A, grb_descriptor desc);   // would bfs_queue_r
 grb_info bfs_ticket_take(int* slot);
 grb_info bfs_persistent_enqueue(grb_vector v, grb_matrix A, grb_index source, grb_descriptor desc, int slot, int* seq);
 void bfs_ticket_store(int slot, int seq, const grb_bfs_result& res);
-int bfs_ticket_state(int slot, int seq, grb_vector* v, grb_matrix* A, grb_descriptor* desc, grb_index* source, grb_bfs_result* parked);
+int bfs_ticket_state(int slot, int seq, grb_vector* v, grb_matrix* A, grb_descriptor* desc, grb_index* source, grb_bfs_result* parked,
+                     int* max_niter = nullptr);
 void bfs_ticket_release(int slot);
 grb_info bfs_persistent_wait(int slot, int seq, int* levels, int* last_dir, long long* reached, unsigned long long* edges,
                              Index* nf_left, bool* hit_cap, float* tight_ms);

@@ -353,7 +353,9 @@ int grb_bfs_set_lanes(int n);
  * waited for, when any other entry point is called (so the ordering rules of grb_bfs_fused_enqueue hold unchanged),
  * when a traversal of another matrix or descriptor is queued, or when 48 have gathered.  Per-traversal labels and
  * result blocks are those of grb_bfs_fused; a traversal's record is written after a barrier of its sub-grid, i.e. when
- * every label store has completed.  Ignored while grb_bfs_set_lanes is above 1.  Changing the number launches and waits
+ * every label store has completed.  A traversal runs under the descriptor fields (mxvmode, switchpoint, edgeswitch,
+ * max_niter) as they stood when it was QUEUED -- the descriptor's setters launch nothing, and one launch serves one set of
+ * rules (a traversal queued under other rules starts a new launch).  Ignored while grb_bfs_set_lanes is above 1.  Changing the number launches and waits
  * for everything queued.  k < 1 only queries.  Returns the previous value.  (No counterpart in the reference, whose loop
  * is one traversal with several host round trips per level: algorithm/bfs.hpp:42-88.) */
 int grb_bfs_set_coschedule(int k);

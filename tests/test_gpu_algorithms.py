@@ -388,6 +388,42 @@ def test_bfs_coscheduled(hb, graphs, capfd):
         g.bfs_set_coschedule(before)
 
 
+def test_bfs_coscheduled_keeps_the_rules_it_was_queued_under(hb, graphs):
+    """A descriptor that is changed between two grb_bfs_fused_enqueue calls (loadArgs: max_niter, mxvmode) while the first
+    traversal still waits for its launch to fill: the descriptor's setters launch nothing, so every traversal carries the
+    rules it was queued under -- one launch serves one set of rules, the wait's unlabel pass uses the cap the traversal ran
+    under -- and the results are those of blocking calls under the respective rules."""
+    from oracle import simple_reference as sr
+    g = hb.g
+    name, gr = graphs[3]
+    ptr, ind = gr["csr"]
+    A = build(hb, gr)
+    n = gr["n"]
+    srcs = [first_source(gr)] + g.graphgen.random_sources(ptr, 5, seed=21)
+    full = {s_: sr.bfs(ptr, ind, s_)[0] for s_ in srcs}
+    g.bfs_set_coschedule(4)
+    try:
+        d = hb.descriptor(mxvmode=0, struconly=1, opreuse=1)
+        vs = [g.Vector(n) for _ in srcs]
+        tickets, caps = [], []
+        for i, (v, s_) in enumerate(zip(vs, srcs)):
+            cap = (10000, 2, 3)[i % 3]
+            assert d.loadArgs(mxvmode=(0, 2, 1)[i % 3], struconly=1, opreuse=1, max_niter=cap) == 0   # the SAME descriptor object
+            info, t = g.bfs_enqueue(v, A, s_, d)
+            assert info == 0
+            tickets.append(t)
+            caps.append(cap)
+        assert d.loadArgs(mxvmode=0, struconly=1, opreuse=1, max_niter=1) == 0                        # ... and once more before any wait
+        for v, s_, t, cap in zip(vs, srcs, tickets, caps):
+            info, res = g.bfs_wait(t)
+            assert info == 0
+            want = np.where(full[s_] <= cap, full[s_], 0)
+            assert np.array_equal(hb.dense_values(v), want), (s_, cap)
+            assert res["reached"] == int(np.count_nonzero(want))
+    finally:
+        g.bfs_set_coschedule(1)
+
+
 def test_bfs_wait_on_a_vector_read_through_its_device_pointer(hb, graphs):
     """Zero-copy interop: the caller takes a vector's device storage (grb_vector_device_ptrs) and reads it on a stream the
     library knows nothing about, right after grb_bfs_wait.  The record a wait looks at is written by ONE workgroup while
