@@ -1,5 +1,6 @@
 /* The C ABI from plain C: build a graph from a coordinate list, run the direction-optimised BFS as one
- * launch (grb_bfs_fused) and the reference's op-by-op loop (grb_bfs), print the depth labels.
+ * launch (grb_bfs_fused) and the reference's op-by-op loop (grb_bfs), print the depth labels; then six traversals queued and
+ * run four side by side per launch.
  *   gcc -std=c99 -Iinclude examples/bfs_c_abi.c -Lgraphblast_amd -lgrb_hip -Wl,-rpath,$PWD/graphblast_amd -o bfs_c_abi
  *   ./bfs_c_abi            # a 3 x 4 grid, source 0
  */
@@ -62,6 +63,31 @@ int main(void) {
       printf("MISMATCH at %d\n", i);
       return 2;
     }
+  /* many traversals, one wait: queued (grb_bfs_fused_enqueue), four side by side per launch (grb_bfs_set_coschedule),
+   * waited for afterwards -- every source's labels are the grid distances from it */
+  enum { K = 6 };
+  grb_vector vk[K];
+  grb_bfs_ticket tk[K];
+  grb_bfs_set_coschedule(4);
+  for (int s = 0; s < K; ++s) {
+    CHECK(grb_vector_new(&vk[s], GRB_F32, N));
+    CHECK(grb_bfs_fused_enqueue(vk[s], A, 2 * s, desc, &tk[s]));
+  }
+  for (int s = 0; s < K; ++s) {
+    float got[N];
+    CHECK(grb_bfs_wait(tk[s], &res));
+    n = N;
+    CHECK(grb_vector_extract_tuples_dense(vk[s], got, &n));
+    const int sx = (2 * s) % W, sy = (2 * s) / W;
+    for (int i = 0; i < N; ++i)
+      if (got[i] != (float)(1 + abs(i % W - sx) + abs(i / W - sy))) {
+        printf("MISMATCH at %d of queued traversal %d\n", i, s);
+        return 3;
+      }
+    grb_vector_free(vk[s]);
+  }
+  grb_bfs_set_coschedule(1);
+  printf("queued, four per launch: %d traversals\n", K);
   printf("CORRECT\n");
   grb_descriptor_free(desc);
   grb_vector_free(v);
