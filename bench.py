@@ -177,10 +177,10 @@ def other_workload(args):
                                  "host_enqueue_us_per_step": round(htb["enqueue_us"] / max(htb["calls"], 1), 2),
                                  "host_wait_us_per_step": round(htb["wait_us"] / max(htb["calls"], 1), 2)}
         line["queued"] = {"host_enqueue_us_per_step": round(ht["enqueue_us"] / max(ht["calls"], 1), 2)}
-        # the same steps, eight traversals side by side per launch (grb_bfs_set_coschedule, as in the headline run); every
+        # the same steps, twelve traversals side by side per launch (grb_bfs_set_coschedule, as in the headline run); every
         # vector's labels against the one-at-a-time steps'
         solo_labels = [x.extractTuples()[1] for x in vs]
-        g.bfs_set_coschedule(8)
+        g.bfs_set_coschedule(12)
         for t_ in [g.bfs_enqueue(vs[i], A, sources[i % 64], desc)[1] for i in range(min(args.steps, 16))]:
             g.bfs_wait(t_)
         torch.cuda.synchronize()
@@ -192,7 +192,7 @@ def other_workload(args):
         g.bfs_set_coschedule(1)
         assert [r_["reached"] for r_ in res_c] == [r_["reached"] for r_ in res]
         assert all(np.array_equal(x.extractTuples()[1], w_) for x, w_ in zip(vs, solo_labels)), "co-scheduled labels differ"
-        line["coscheduled_8"] = {"value": sum(r_["edges_traversed"] for r_ in res_c) / el_c, "unit": "TEPS",
+        line["coscheduled_12"] = {"value": sum(r_["edges_traversed"] for r_ in res_c) / el_c, "unit": "TEPS",
                                  "ms_per_step": round(el_c / args.steps * 1e3, 5),
                                  "labels": "all %d vectors equal to the one-at-a-time steps'" % len(vs)}
         del vs, solo_labels
@@ -686,7 +686,7 @@ def main():
         if not args.no_coschedule:
             solo_labels = [x.extractTuples()[1] for x in vs]
             co_runs = {}
-            for k in (4, 8):
+            for k in (4, 8, 12):
                 g.bfs_set_coschedule(k)
                 run_queued(max(args.warmup, 2 * k))
                 reps = []
@@ -714,10 +714,11 @@ def main():
                               "labels": "all %d vectors equal to the one-at-a-time steps'" % len(vs)}
             g.bfs_set_coschedule(1)
             extra["coscheduled"] = {"what": "K queued steps with grb_bfs_set_coschedule(k): ONE launch carries the K traversals, k "
-                                            "sub-grids (a workgroup per CU each; 256 threads at k = 4, 128 at k = 8) run them side by "
-                                            "side and draw the next from a counter; per-traversal results and labels identical.  Not "
-                                            "`value`: there a traversal has the device to itself.  median of 3 runs",
-                                    "4": co_runs[4], "8": co_runs[8]}
+                                            "sub-grids (a workgroup per CU each; 256 threads at k = 4, 128 at k = 8 and 12 -- that "
+                                            "instance is built for six waves per SIMD) run them side by side and draw the next from a "
+                                            "counter; per-traversal results and labels identical.  Not `value`: there a traversal has "
+                                            "the device to itself.  median of 3 runs",
+                                    "4": co_runs[4], "8": co_runs[8], "12": co_runs[12]}
             run_queued(args.steps)                                   # (the vectors hold one-at-a-time results again)
         # the labels the queued steps left are checked below (parity block) through vs[...]; the blocking sibling:
         for i in range(min(args.warmup, 2)):
@@ -778,7 +779,7 @@ def main():
                                               % (n_levels, empty_level_ms * 1e3, max(event_ms / args.steps - clock_ms, 0.0) * 1e3),
                              "frac_if_the_rest_ran_at_peak": round(total_bytes / args.steps / ((floor_ms + total_bytes / args.steps / (HBM_PEAK_GBS * 1e9) * 1e3) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)})
         if "coscheduled" in extra:
-            for k in ("4", "8"):
+            for k in ("4", "8", "12"):
                 cr = extra["coscheduled"][k]
                 ach_k = total_bytes / (cr["launch_ms_total_by_hip_events"] * 1e-3) / 1e9
                 cr["roofline"] = {"bound": "hbm", "kernel": "bfs_persistent_kernel<%d>" % (256 if k == "4" else 128),
@@ -1286,9 +1287,9 @@ def main():
                 "steps_per_gpu": args.steps, "ms_per_step_per_gpu": float(tm.item()) / args.steps * 1e3,
                 "note": "every rank traverses its own sources on a full replica of the graph, queued as in the N = 1 run "
                         "(grb_bfs_fused_enqueue / grb_bfs_wait); no collective"}
-            # the same leg with eight traversals side by side per launch on every rank (grb_bfs_set_coschedule(8))
-            g.bfs_set_coschedule(8)
-            queued_pass(mine[:max(args.warmup, 8)])
+            # the same leg with twelve traversals side by side per launch on every rank (grb_bfs_set_coschedule(12))
+            g.bfs_set_coschedule(12)
+            queued_pass(mine[:max(args.warmup, 12)])
             barrier()
             t0 = time.perf_counter()
             my_edges_co = queued_pass(mine)
@@ -1305,10 +1306,10 @@ def main():
             if world > 1:
                 dist.all_reduce(tm2, op=dist.ReduceOp.MAX)
                 dist.all_reduce(te2, op=dist.ReduceOp.SUM)
-            extra["source_sharded_replicas"]["coscheduled_8"] = {
+            extra["source_sharded_replicas"]["coscheduled_12"] = {
                 "value": float(te2.item()) / float(tm2.item()), "unit": "TEPS", "scaling": "weak",
                 "ms_per_step_per_gpu": float(tm2.item()) / args.steps * 1e3,
-                "note": "the same, eight traversals side by side in one launch on every rank"}
+                "note": "the same, twelve traversals side by side in one launch on every rank"}
 
     if rank == 0:
         line = {

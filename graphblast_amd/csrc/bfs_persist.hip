@@ -62,6 +62,17 @@ namespace grb {
 #ifndef GRB_BFS_PULL_DYN
 #define GRB_BFS_PULL_DYN 1         // dense pull: a workgroup's blocks handed out to its waves dynamically (0: two fixed blocks per wave)
 #endif
+// the 128-thread instance (launches of five to twelve traversals): waves per SIMD it is built for, and the shape of its
+// pull queue (rows per lane and round / entries per lane and step) -- tools/bfs_co_bench.py, docs/experiments.md R6.1
+#ifndef GRB_CO_LEAN_WPE
+#define GRB_CO_LEAN_WPE 6
+#endif
+#ifndef GRB_CO_LEAN_R
+#define GRB_CO_LEAN_R 1
+#endif
+#ifndef GRB_CO_LEAN_D
+#define GRB_CO_LEAN_D 1
+#endif
 #ifndef GRB_BFS_FINE_TRACE
 #define GRB_BFS_FINE_TRACE 0       // 1: the level barrier stamped step by step (tools/bfs_trace.py; measurement builds only)
 #endif
@@ -200,9 +211,11 @@ __device__ inline void push_visit(const A& a, float* label, unsigned int* V, uns
 template <int T>
 struct PersistLds {
   static constexpr int W = T / kWave;
-  static constexpr int kOcW = T >= 256 ? kOcWords : kOcWords / 4;  // (eight workgroups per CU share its LDS: tables cut narrower)
+  static constexpr int kPB = T >= 256 ? kPullBlock : (kPullBlock < 4 ? kPullBlock : 4);   // chunks a wave carries through a dense pull
+  typedef PullLdsT<kPB * kWave> Pull;
+  static constexpr int kOcW = T >= 256 ? kOcWords : kOcWords / 4;  // (up to twelve workgroups per CU share its LDS: tables cut narrower)
   struct OcView { int2 row[W][kWave]; unsigned int ocw[kOcW]; };
-  union U { PullLds pull[W]; OcView oc; };
+  union U { Pull pull[W]; OcView oc; };
 };
 
 // Returns the number (in the launch's table) of the traversal this grid runs next -- >= the table's size: none -- or -1
@@ -221,6 +234,12 @@ __device__ __forceinline__ int bfs_persistent_body(AP ap, GP gp, TP tp, const in
   // therefore reads what it needs through a pointer the optimiser cannot see through (one scalar load per phase).
   auto ph = [](auto q) { if constexpr (!kHostRot) asm volatile("" : "+s"(q)); return q; };
   constexpr int W = T / kWave;
+  // The 128-thread instance is built for SIX waves per SIMD (80 registers: up to twelve workgroups = 24 waves on a CU
+  // instead of 16): the pull levels' row queue is where the kernel is fattest (docs/experiments.md R6.1: without it the
+  // kernel fits 74 registers), so there a wave carries 4 chunks instead of 8 and the queue takes one row per lane and round
+  // and one entry per lane and step instead of 4 and 4 -- and its LDS halves with the block.
+  constexpr int kPB = PersistLds<T>::kPB;
+  constexpr int kQR = T >= 256 ? kPullR : GRB_CO_LEAN_R, kQD = T >= 256 ? 4 : GRB_CO_LEAN_D;
   constexpr int kMed = T >= 512 ? 4 * T : T >= 256 ? 512 : 256;                     // LDS list of medium vertices per workgroup pass
   __shared__ unsigned long long s_red[W][4];
   __shared__ unsigned long long s_tot[4];
@@ -545,10 +564,10 @@ inc = (Index)wave_incl_scan_u32((unsigned)inc);
       float* const label = ph(tp)->label;
       const Index* hint = a.count_inspected ? nullptr : a.hint;
       const Index nchunks = (n + kWave - 1) / kWave;
-      const Index nblocks = (nchunks + kPullBlock - 1) / kPullBlock;
+      const Index nblocks = (nchunks + kPB - 1) / kPB;
       const Index nwaves = (Index)G * W;
       const unsigned long long lt_mask = (1ull << lane) - 1ull;
-      PullLds& L = s_u.pull[wave];
+      typename PersistLds<T>::Pull& L = s_u.pull[wave];
       // Few vertices are left to discover (the levels after the big one): the dense walk below would carry 512-vertex
       // blocks with a handful of live lanes through its stages.  Here a wave numbers the active bits of kSparseWords
       // bitmap words (wave_for_each_bit) and takes them 64 at a time, one vertex per lane.  Same discoveries, same
@@ -596,7 +615,7 @@ inc = (Index)wave_incl_scan_u32((unsigned)inc);
                 L.id[slot] = (unsigned short)lane;
               }
               __builtin_amdgcn_wave_barrier();
-              pull_queue_run<kF>(a.iind, a.nnz, vin, L, lane, __popcll(um), c.inspected);
+              pull_queue_run<kF, kQR, kQD>(a.iind, a.nnz, vin, L, lane, __popcll(um), c.inspected);
               if (und && ((L.found[lane >> 5] >> (lane & 31)) & 1u)) found = true;
               __builtin_amdgcn_wave_barrier();
             }
@@ -620,7 +639,7 @@ inc = (Index)wave_incl_scan_u32((unsigned)inc);
           __builtin_amdgcn_wave_barrier();
         }
       } else
-      // One wave owns a block of kPullBlock chunks of 64 vertices and runs every stage for all of them at once, so a
+      // One wave owns a block of kPB chunks of 64 vertices and runs every stage for all of them at once, so a
       // stage costs one memory latency per block instead of one per chunk:  words -> hint probe (the row pointers
       // travel with it) -> the rows it did not settle, queued and taken dense (pull_queue_run) -> outputs.
 #if GRB_BFS_PULL_DYN
@@ -636,13 +655,13 @@ inc = (Index)wave_incl_scan_u32((unsigned)inc);
       for (Index blk = (Index)bid * W + wave; blk < nblocks; blk += nwaves) {
 #endif
         // ---- stage 0: the block's words; a lane's vertices are vbase + 64 j
-        const Index wi = blk * (2 * kPullBlock) + lane;
-        const bool has_word = lane < 2 * kPullBlock && wi < nwords;
+        const Index wi = blk * (2 * kPB) + lane;
+        const bool has_word = lane < 2 * kPB && wi < nwords;
         unsigned int vw = 0xffffffffu, inact = 0xffffffffu;
         if (has_word) { vw = vin[wi]; inact = vw | a.skip[wi]; }
         unsigned int act = 0;
 #pragma unroll
-        for (int j = 0; j < kPullBlock; ++j) {
+        for (int j = 0; j < kPB; ++j) {
           const unsigned int wj = __shfl(inact, 2 * j + (lane >> 5), kWave);
           act |= ((~wj >> (lane & 31)) & 1u) << j;
         }
@@ -650,15 +669,15 @@ inc = (Index)wave_incl_scan_u32((unsigned)inc);
           if (has_word) publish(&vout[wi], vw);
           continue;
         }
-        const Index vbase = blk * (kPullBlock * kWave) + lane;
+        const Index vbase = blk * (kPB * kWave) + lane;
         unsigned int fnd = 0;
         // ---- stage 1: the hinted in-neighbour of every active vertex; the row pointers travel
         // with it (coalesced, and needed by whoever the hint does not settle)
-        Index p[kPullBlock], e[kPullBlock];
+        Index p[kPB], e[kPB];
         {
-          Index hv[kPullBlock];
+          Index hv[kPB];
 #pragma unroll
-          for (int j = 0; j < kPullBlock; ++j) {
+          for (int j = 0; j < kPB; ++j) {
             const Index vj = ((act >> j) & 1u) ? vbase + kWave * j : 0;
             hv[j] = hint ? hint[vj] : 0;
             p[j] = a.iptr[vj];
@@ -666,7 +685,7 @@ inc = (Index)wave_incl_scan_u32((unsigned)inc);
           }
           if (hint) {
 #pragma unroll
-            for (int j = 0; j < kPullBlock; ++j) {
+            for (int j = 0; j < kPB; ++j) {
               const unsigned int on = (act >> j) & 1u;
               const unsigned int w = vin[on ? (hv[j] >> 5) : 0];
               fnd |= (on & (w >> (hv[j] & 31)) & 1u) << j;
@@ -675,33 +694,33 @@ inc = (Index)wave_incl_scan_u32((unsigned)inc);
         }
         unsigned int und = act & ~fnd;
 #pragma unroll
-        for (int j = 0; j < kPullBlock; ++j)
+        for (int j = 0; j < kPB; ++j)
           if (p[j] >= e[j]) und &= ~(1u << j);
         if (__ballot(und != 0u)) {
           // ---- the undecided rows, queued in lane order
-          if (lane < 2 * kPullBlock) L.found[lane] = 0u;
+          if (lane < 2 * kPB) L.found[lane] = 0u;
           const int mine = __popc(und);
           int incl = mine;
 incl = (int)wave_incl_scan_u32((unsigned)incl);
           const int Tq = (int)__builtin_amdgcn_readlane((int)incl, kWave - 1);
           int at = incl - mine;
 #pragma unroll
-          for (int j = 0; j < kPullBlock; ++j)
+          for (int j = 0; j < kPB; ++j)
             if ((und >> j) & 1u) {
               L.row[at] = make_int2(p[j], e[j]);
               L.id[at] = (unsigned short)(j * kWave + lane);
               ++at;
             }
           __builtin_amdgcn_wave_barrier();
-          pull_queue_run<false>(a.iind, a.nnz, vin, L, lane, Tq, c.inspected);
+          pull_queue_run<false, kQR, kQD>(a.iind, a.nnz, vin, L, lane, Tq, c.inspected);
 #pragma unroll
-          for (int j = 0; j < kPullBlock; ++j) fnd |= ((L.found[2 * j + (lane >> 5)] >> (lane & 31)) & 1u) << j;
+          for (int j = 0; j < kPB; ++j) fnd |= ((L.found[2 * j + (lane >> 5)] >> (lane & 31)) & 1u) << j;
           __builtin_amdgcn_wave_barrier();
         }
         // ---- outputs: new words, labels, accounting
         unsigned int nb = 0;
 #pragma unroll
-        for (int j = 0; j < kPullBlock; ++j) {
+        for (int j = 0; j < kPB; ++j) {
           const unsigned long long fb = __ballot((fnd >> j) & 1u);
           if ((lane >> 1) == j) nb = (lane & 1) ? (unsigned int)(fb >> 32) : (unsigned int)(fb & 0xffffffffull);
         }
@@ -713,7 +732,7 @@ incl = (int)wave_incl_scan_u32((unsigned)incl);
           if (GRB_BFS_SYM && a.out_is_in) {
             // the out-degree is the in-degree: no second pair of row pointers, no dependent load at the end of the step
 #pragma unroll
-            for (int j = 0; j < kPullBlock; ++j)
+            for (int j = 0; j < kPB; ++j)
               if ((fnd >> j) & 1u) {
                 const Index d = e[j] - p[j];
                 ++c.found;
@@ -722,9 +741,9 @@ incl = (int)wave_incl_scan_u32((unsigned)incl);
                 if (direct) label[vbase + kWave * j] = new_label;
               }
           } else {
-            Index d0[kPullBlock], d1[kPullBlock];
+            Index d0[kPB], d1[kPB];
 #pragma unroll
-            for (int j = 0; j < kPullBlock; ++j) {
+            for (int j = 0; j < kPB; ++j) {
               const bool f = (fnd >> j) & 1u;
               const Index vj = f ? vbase + kWave * j : 0;
               d0[j] = a.optr[vj];
@@ -732,7 +751,7 @@ incl = (int)wave_incl_scan_u32((unsigned)incl);
               if (f && direct) label[vj] = new_label;
             }
 #pragma unroll
-            for (int j = 0; j < kPullBlock; ++j)
+            for (int j = 0; j < kPB; ++j)
               if ((fnd >> j) & 1u) {
                 const Index d = d1[j] - d0[j];
                 ++c.found;
@@ -995,7 +1014,7 @@ incl = (int)wave_incl_scan_u32((unsigned)incl);
 // the next one from the launch's counter.  The argument blocks sit in the kernarg segment and a workgroup reads its own
 // through the segment pointer (scalar loads from constant memory, what a by-value parameter compiles to when it is
 // not indexed at run time -- a by-value table that is would be copied to scratch).
-constexpr int kCoMax = 8;
+constexpr int kCoMax = 12;
 constexpr int kCoTrain = 48;
 struct LaunchArgs {
   PersistArgs a;
@@ -1008,7 +1027,7 @@ struct LaunchArgs {
 static_assert(sizeof(LaunchArgs) <= 4096, "the kernarg segment holds 4 KiB");
 typedef const __attribute__((address_space(4))) LaunchArgs* LaunchArgsPtr;
 template <int T>
-__global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void bfs_persistent_kernel(LaunchArgs la_) {
+__global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(T >= 256 ? 4 : GRB_CO_LEAN_WPE, T >= 256 ? 4 : GRB_CO_LEAN_WPE))) void bfs_persistent_kernel(LaunchArgs la_) {
   const LaunchArgsPtr la = (LaunchArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
   if constexpr (T == kPThreads) {
     // one traversal on the launch's whole grid: every argument at a fixed place of the segment
@@ -1690,7 +1709,7 @@ static grb_info bfs_co_launch(int ntrav, const CoPend* pend, int width) {
   if (force_fallback) return GRB_NOT_IMPLEMENTED;
   int n_grids = width < ntrav ? width : ntrav;
   if (n_grids > kCoMax) n_grids = kCoMax;
-  // two sub-grids: 512-thread workgroups; three or four: 256; up to eight: 128
+  // two sub-grids: 512-thread workgroups; three or four: 256; up to twelve: 128 (built for six waves per SIMD)
   const int T = n_grids <= 2 ? 512 : n_grids <= 4 ? 256 : 128;
   GRB_TRY(T == 512 ? co_kernel_fits<512>(n_grids) : T == 256 ? co_kernel_fits<256>(n_grids) : co_kernel_fits<128>(n_grids));
   const int oc_words = T >= 256 ? kOcWords : kOcWords / 4;

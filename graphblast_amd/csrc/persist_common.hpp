@@ -189,14 +189,16 @@ constexpr int kPullProbe4 = 4;
 // sequential early-exit count of the oracle: entries up to and including the first hit, or all of them.
 constexpr int kPullQueue = 8 * kWave;               // rows a wave can queue: every vertex of an 8-chunk block
 constexpr int kPullR = 4;                           // rows per lane and round of the first-entries stage
-struct PullLds {
-  int2 row[kPullQueue];                             // {next entry, end}
-  unsigned short id[kPullQueue];
+template <int kQueue>
+struct PullLdsT {
+  int2 row[kQueue];                                 // {next entry, end}
+  unsigned short id[kQueue];
   unsigned int found[32];                           // bit id: the row had a hit
   int off[kWave], nxt[kWave], hit[kWave];           // dealing a pass: first slot / first entry / smallest hitting offset
   WaveBits bits;                                    // sparse active sets: the active bits numbered (wave_for_each_bit)
   unsigned int fresh_bits[kSparseWords];            // ... and what they discovered, by word
 };
+typedef PullLdsT<kPullQueue> PullLds;
 
 // T rows are queued; afterwards found[] has the bit of every queued row with an in-neighbour in vin.
 // kFresh: the bitmap is probed with agent-scope loads (a level with few probes skips the L1 invalidate instead).
@@ -204,35 +206,37 @@ template <bool kFresh>
 __device__ __forceinline__ unsigned int probe_word(const unsigned int* vin, Index w) {
   return kFresh ? fresh(&vin[w]) : vin[w];
 }
-template <bool kFresh>
+// kR rows per lane and round in the first stage, kD entries per lane and step in the second (4 and 4 where the kernel has
+// the registers; the sub-grid kernels built for six waves per SIMD take 2 and 2: 34 registers less at their fattest point)
+template <bool kFresh, int kR = kPullR, int kD = 4, typename LDS = PullLds>
 __device__ __forceinline__ void pull_queue_run(const Index* __restrict__ iind, long long innz, const unsigned int* vin,
-                                               PullLds& L, int lane, int T, unsigned long long& inspected) {
+                                               LDS& L, int lane, int T, unsigned long long& inspected) {
   const unsigned long long lt_mask = (1ull << lane) - 1ull;
   int S = 0;                                                       // survivors, compacted to the front of the queue
   if (innz >= kPullProbe4) {
     const Index last = (Index)innz - kPullProbe4;
-    for (int q0 = 0; q0 < T; q0 += kWave * kPullR) {
-      int2 it[kPullR];
-      int id[kPullR];
-      Quad cq[kPullR];
+    for (int q0 = 0; q0 < T; q0 += kWave * kR) {
+      int2 it[kR];
+      int id[kR];
+      Quad cq[kR];
 #pragma unroll
-      for (int k = 0; k < kPullR; ++k) {
+      for (int k = 0; k < kR; ++k) {
         const int qi = q0 + k * kWave + lane;
         const bool valid = qi < T;
         it[k] = valid ? L.row[qi] : make_int2(0, 0);
         id[k] = valid ? (int)L.id[qi] : 0;
       }
 #pragma unroll
-      for (int k = 0; k < kPullR; ++k) {
+      for (int k = 0; k < kR; ++k) {
         Index at = it[k].x;
         const int shift = at > last ? at - last : 0;               // only the final entries of the array
         at -= shift;
         cq[k] = *reinterpret_cast<const Quad*>(iind + at);
         for (int t = 0; t < shift; ++t) { cq[k].x = cq[k].y; cq[k].y = cq[k].z; cq[k].z = cq[k].w; }
       }
-      unsigned int wq[kPullR][kPullProbe4];
+      unsigned int wq[kR][kPullProbe4];
 #pragma unroll
-      for (int k = 0; k < kPullR; ++k) {
+      for (int k = 0; k < kR; ++k) {
         const Index len = it[k].y - it[k].x;
         const Index c4[kPullProbe4] = {cq[k].x, cq[k].y, cq[k].z, cq[k].w};
 #pragma unroll
@@ -240,7 +244,7 @@ __device__ __forceinline__ void pull_queue_run(const Index* __restrict__ iind, l
       }
       __builtin_amdgcn_wave_barrier();
 #pragma unroll
-      for (int k = 0; k < kPullR; ++k) {
+      for (int k = 0; k < kR; ++k) {
         const Index len = it[k].y - it[k].x;
         const Index c4[kPullProbe4] = {cq[k].x, cq[k].y, cq[k].z, cq[k].w};
         int first = -1;
@@ -282,11 +286,11 @@ incl = (Index)wave_incl_scan_u32((unsigned)incl);
       L.nxt[lane] = nx;
       L.hit[lane] = 0x7fffffff;
       __builtin_amdgcn_wave_barrier();
-      for (Index t0 = 0; t0 < total; t0 += 4 * kWave) {
-        int r[4];
-        Index o[4], col[4];
+      for (Index t0 = 0; t0 < total; t0 += kD * kWave) {
+        int r[kD];
+        Index o[kD], col[kD];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < kD; ++j) {
           const Index t = t0 + j * kWave + lane;
           r[j] = -1;
           o[j] = 0;
@@ -301,11 +305,11 @@ incl = (Index)wave_incl_scan_u32((unsigned)incl);
             col[j] = iind[L.nxt[x] + o[j]];
           }
         }
-        unsigned int w[4];
+        unsigned int w[kD];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) w[j] = probe_word<kFresh>(vin, col[j] >> 5);
+        for (int j = 0; j < kD; ++j) w[j] = probe_word<kFresh>(vin, col[j] >> 5);
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < kD; ++j)
           if (r[j] >= 0 && ((w[j] >> (col[j] & 31)) & 1u)) atomicMin(&L.hit[r[j]], (int)o[j]);
       }
       __builtin_amdgcn_wave_barrier();

@@ -343,10 +343,10 @@ grb_info grb_bfs_wait(grb_bfs_ticket ticket, grb_bfs_result* result);
  * blocking grb_bfs_fused keeps the whole device (and, issued while lanes are busy, waits for their grids to drain).
  * Changing the number waits for everything queued.  n < 1 only queries.  Returns the previous value. */
 int grb_bfs_set_lanes(int n);
-/* Traversals side by side in one LAUNCH (1 .. 8; default 1).  With k > 1 the traversals queued by grb_bfs_fused_enqueue
+/* Traversals side by side in one LAUNCH (1 .. 12; default 1).  With k > 1 the traversals queued by grb_bfs_fused_enqueue
  * share launches: a launch is k sub-grids of one workgroup per CU each (512 threads for two, 256 up to four, 128 up to
- * eight), every sub-grid runs one traversal at a time on state, barrier counters and bitmaps of its own, and when it has
- * finished one it draws the next of the launch's traversals (up to 48 per launch) from a counter.  A traversal is
+ * twelve -- that instance is built for six waves per SIMD), every sub-grid runs one traversal at a time on state,
+ * barrier counters and bitmaps of its own, and when it has finished one it draws the next of the launch's traversals (up to 48 per launch) from a counter.  A traversal is
  * barriers and dependent-load chains for half of its time; the CU's wave scheduler fills them with the other
  * traversals' work, and -- unlike lanes -- nothing depends on how the runtime maps streams to hardware queues: it is one
  * launch on the library's stream.  A ticket is issued at once; the launch goes out when one of the gathered tickets is

@@ -325,9 +325,9 @@ def test_bfs_coscheduled(hb, graphs, capfd):
     before = g.bfs_set_coschedule(-1)
     assert before == 1
     try:
-        for k in (2, 3, 4, 6, 9, 1):
-            assert g.bfs_set_coschedule(k) in range(1, 9)
-            assert g.bfs_set_coschedule(-1) == min(k, 8)
+        for k in (2, 3, 4, 6, 9, 12, 40, 1):
+            assert g.bfs_set_coschedule(k) in range(1, 13)
+            assert g.bfs_set_coschedule(-1) == min(k, 12)
             for name, gr in graphs[2:5]:
                 ptr, ind = gr["csr"]
                 A = build(hb, gr)

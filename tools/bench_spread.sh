@@ -20,7 +20,8 @@ for i in range(1, N + 1):
                  "per_step_wall_ms_blocking": d["blocking_loop"]["per_step_wall_ms"],
                  "coscheduled_4_ms_per_step": d.get("coscheduled", {}).get("4", {}).get("ms_per_step"),
                  "coscheduled_8_ms_per_step": d.get("coscheduled", {}).get("8", {}).get("ms_per_step"),
-                 "coscheduled_8_frac": d.get("coscheduled", {}).get("8", {}).get("roofline", {}).get("frac")})
+                 "coscheduled_12_ms_per_step": d.get("coscheduled", {}).get("12", {}).get("ms_per_step"),
+                 "coscheduled_12_frac": d.get("coscheduled", {}).get("12", {}).get("roofline", {}).get("frac")})
 with open(O + "/spread.jsonl", "w") as f:
     for r in rows: f.write(json.dumps(r) + "\n")
 v = [r["ms_per_step"] for r in rows]; b = [r["blocking_ms_per_step"] for r in rows]; k = [r["kernel_ms_by_hip_events"] for r in rows]
@@ -28,7 +29,7 @@ print("command: python bench.py --gpus 1 --steps 20 --warmup 5 (fresh process ea
 print("queued   ms_per_step min %.4f median %.4f max %.4f   TEPS median %.4g" % (min(v), st.median(v), max(v), st.median([r["value"] for r in rows])))
 print("blocking ms_per_step min %.4f median %.4f max %.4f" % (min(b), st.median(b), max(b)))
 print("kernel by HIP events  min %.4f median %.4f max %.4f" % (min(k), st.median(k), max(k)))
-for key in ("coscheduled_4_ms_per_step", "coscheduled_8_ms_per_step"):
+for key in ("coscheduled_4_ms_per_step", "coscheduled_8_ms_per_step", "coscheduled_12_ms_per_step"):
     c = [r[key] for r in rows if r.get(key) is not None]
     if c: print("%s min %.4f median %.4f max %.4f" % (key, min(c), st.median(c), max(c)))
 PY

@@ -70,7 +70,7 @@ if os.path.exists(trace):
           "coscheduled_launches": {("bfs_persistent_kernel<%s>" % k_): {"launches": len(v_), "durations_us": [round(x / 1e3, 1) for x in v_]}
                                    for k_, v_ in co.items()},
           "coscheduled_hip_event_ms_reported_by_bench": {k_: line["coscheduled"][k_]["launch_ms_total_by_hip_events"]
-                                                         for k_ in ("4", "8")} if "coscheduled" in line else None,
+                                                         for k_ in ("4", "8", "12") if k_ in line["coscheduled"]} if "coscheduled" in line else None,
           "hip_event_mean_us_reported_by_bench": round(line["roofline"]["avg_launch_ms"] * 1e3, 2),
           "spmv_kernels_mean_us": {k: round(sum(v) / len(v) / 1e3, 2) for k, v in spmv.items()},
           "spmv_hip_event_mean_us_reported_by_bench": round(line["spmv"]["avg_launch_ms"] * 1e3, 2)}
@@ -106,10 +106,10 @@ def pmc_tables(prefix, csv_prefix):
     if os.path.exists(plog):
         try:
             pl = json.loads([x for x in open(plog).read().strip().splitlines() if x.startswith("{")][-1])
-            for wdt, kk in (("256", 4), ("128", 8)):
+            for wdt, kks in (("256", (4,)), ("128", (8, 12))):
                 name = "grb::bfs_persistent_kernel<%s>" % wdt
                 if name in out and "coscheduled" in pl:
-                    trav = max(pl["warmup"], 2 * kk) + 4 * pl["steps"]
+                    trav = sum(max(pl["warmup"], 2 * kk) + 4 * pl["steps"] for kk in kks if str(kk) in pl["coscheduled"])
                     v = out[name]
                     tot = 1024.0 * (2 * v.get("FETCH_SIZE_KB_mean", 0) * v.get("launches_FETCH_SIZE", 0) +
                                     v.get("WRITE_SIZE_KB_mean", 0) * v.get("launches_WRITE_SIZE", 0))
