@@ -1014,7 +1014,10 @@ incl = (int)wave_incl_scan_u32((unsigned)incl);
 // the next one from the launch's counter.  The argument blocks sit in the kernarg segment and a workgroup reads its own
 // through the segment pointer (scalar loads from constant memory, what a by-value parameter compiles to when it is
 // not indexed at run time -- a by-value table that is would be copied to scratch).
-constexpr int kCoMax = 12;
+#ifndef GRB_CO_MAX
+#define GRB_CO_MAX 12
+#endif
+constexpr int kCoMax = GRB_CO_MAX;            // sub-grids per launch at most (two waves each on a CU: GRB_CO_LEAN_WPE x 4 / 2)
 constexpr int kCoTrain = 48;
 struct LaunchArgs {
   PersistArgs a;
@@ -1710,7 +1713,7 @@ static grb_info bfs_co_launch(int ntrav, const CoPend* pend, int width) {
   int n_grids = width < ntrav ? width : ntrav;
   if (n_grids > kCoMax) n_grids = kCoMax;
   // two sub-grids: 512-thread workgroups; three or four: 256; up to twelve: 128 (built for six waves per SIMD)
-  const int T = n_grids <= 2 ? 512 : n_grids <= 4 ? 256 : 128;
+  const int T = n_grids <= 2 ? 512 : n_grids <= 4 ? 256 : 128;   // (a launch the CU cannot hold is refused: co_kernel_fits)
   GRB_TRY(T == 512 ? co_kernel_fits<512>(n_grids) : T == 256 ? co_kernel_fits<256>(n_grids) : co_kernel_fits<128>(n_grids));
   const int oc_words = T >= 256 ? kOcWords : kOcWords / 4;
   LaunchArgs la;
