@@ -67,6 +67,9 @@ namespace grb {
 #ifndef GRB_CO_LEAN_WPE
 #define GRB_CO_LEAN_WPE 6
 #endif
+#ifndef GRB_CO_LEAN_FROM
+#define GRB_CO_LEAN_FROM 128       // workgroup widths up to this one are built that way
+#endif
 #ifndef GRB_CO_LEAN_R
 #define GRB_CO_LEAN_R 1
 #endif
@@ -211,7 +214,8 @@ __device__ inline void push_visit(const A& a, float* label, unsigned int* V, uns
 template <int T>
 struct PersistLds {
   static constexpr int W = T / kWave;
-  static constexpr int kPB = T >= 256 ? kPullBlock : (kPullBlock < 4 ? kPullBlock : 4);   // chunks a wave carries through a dense pull
+  static constexpr bool kLean = T <= GRB_CO_LEAN_FROM;                     // built for GRB_CO_LEAN_WPE waves per SIMD
+  static constexpr int kPB = !kLean ? kPullBlock : (kPullBlock < 4 ? kPullBlock : 4);   // chunks a wave carries through a dense pull
   typedef PullLdsT<kPB * kWave> Pull;
   static constexpr int kOcW = T >= 256 ? kOcWords : kOcWords / 4;  // (up to twelve workgroups per CU share its LDS: tables cut narrower)
   struct OcView { int2 row[W][kWave]; unsigned int ocw[kOcW]; };
@@ -239,7 +243,7 @@ __device__ __forceinline__ int bfs_persistent_body(AP ap, GP gp, TP tp, const in
   // kernel fits 74 registers), so there a wave carries 4 chunks instead of 8 and the queue takes one row per lane and round
   // and one entry per lane and step instead of 4 and 4 -- and its LDS halves with the block.
   constexpr int kPB = PersistLds<T>::kPB;
-  constexpr int kQR = T >= 256 ? kPullR : GRB_CO_LEAN_R, kQD = T >= 256 ? 4 : GRB_CO_LEAN_D;
+  constexpr int kQR = !PersistLds<T>::kLean ? kPullR : GRB_CO_LEAN_R, kQD = !PersistLds<T>::kLean ? 4 : GRB_CO_LEAN_D;
   constexpr int kMed = T >= 512 ? 4 * T : T >= 256 ? 512 : 256;                     // LDS list of medium vertices per workgroup pass
   __shared__ unsigned long long s_red[W][4];
   __shared__ unsigned long long s_tot[4];
@@ -1030,7 +1034,7 @@ struct LaunchArgs {
 static_assert(sizeof(LaunchArgs) <= 4096, "the kernarg segment holds 4 KiB");
 typedef const __attribute__((address_space(4))) LaunchArgs* LaunchArgsPtr;
 template <int T>
-__global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(T >= 256 ? 4 : GRB_CO_LEAN_WPE, T >= 256 ? 4 : GRB_CO_LEAN_WPE))) void bfs_persistent_kernel(LaunchArgs la_) {
+__global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(T > GRB_CO_LEAN_FROM ? 4 : GRB_CO_LEAN_WPE, T > GRB_CO_LEAN_FROM ? 4 : GRB_CO_LEAN_WPE))) void bfs_persistent_kernel(LaunchArgs la_) {
   const LaunchArgsPtr la = (LaunchArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
   if constexpr (T == kPThreads) {
     // one traversal on the launch's whole grid: every argument at a fixed place of the segment
@@ -1416,7 +1420,8 @@ struct LaunchCtx {
 // Fills the argument block of one (sub-)grid: the lane's buffers (lane 0: the library's scratch slots), the once-per-
 // matrix facts and tables.  Queues at most memsets on lc->s.
 static grb_info bfs_persistent_args(grb_matrix A, const BfsRules& rules, int profile, int lane_id, bool co, PersistArgs* out,
-                                    GridArgs* gout, LaunchCtx* lc, void** p_rec_out, unsigned long long** trace_out, int oc_words = kOcWords) {
+                                    GridArgs* gout, LaunchCtx* lc, void** p_rec_out, unsigned long long** trace_out, int oc_words = kOcWords,
+                                    int g_mult = 1) {
   GRB_TRY(ring_init());
   Context& c = ctx();
   BfsLane& ln = g_ring.lane[lane_id];
@@ -1444,7 +1449,7 @@ static grb_info bfs_persistent_args(grb_matrix A, const BfsRules& rules, int pro
   const int G_full = c.num_cu * wgs_per_cu;
   // lanes > 1: a queued traversal takes its share of the CUs (the blocking call, lane 0 alone, the whole device);
   // a sub-grid of a co-scheduled launch has a workgroup on every CU
-  const int G = co ? c.num_cu
+  const int G = co ? c.num_cu * g_mult
                    : (g_ring.lanes > 1 && profile == 0 && g_ring.lanes_active) ? (c.num_cu / g_ring.lanes > 0 ? c.num_cu / g_ring.lanes : 1)
                                                                                : G_full;
   const int rec_cap = 1 << 15;
@@ -1705,16 +1710,16 @@ static grb_info co_kernel_fits(int k) {
   }
   return per_cu >= k ? GRB_SUCCESS : GRB_NOT_IMPLEMENTED;
 }
-static grb_info bfs_co_launch(int ntrav, const CoPend* pend, int width) {
+static grb_info bfs_co_launch(int ntrav, const CoPend* pend, int width, int g_mult = 1) {
   Context& c = ctx();
-  if (ntrav < 2 || ntrav > kCoTrain) return GRB_INVALID_VALUE;
+  if (ntrav < (g_mult > 1 ? 1 : 2) || ntrav > kCoTrain) return GRB_INVALID_VALUE;
   static const bool force_fallback = [] { const char* e = getenv("GRB_BFS_FORCE_FALLBACK"); return e && atoi(e) != 0; }();
   if (force_fallback) return GRB_NOT_IMPLEMENTED;
   int n_grids = width < ntrav ? width : ntrav;
   if (n_grids > kCoMax) n_grids = kCoMax;
   // two sub-grids: 512-thread workgroups; three or four: 256; up to twelve: 128 (built for six waves per SIMD)
   const int T = n_grids <= 2 ? 512 : n_grids <= 4 ? 256 : 128;   // (a launch the CU cannot hold is refused: co_kernel_fits)
-  GRB_TRY(T == 512 ? co_kernel_fits<512>(n_grids) : T == 256 ? co_kernel_fits<256>(n_grids) : co_kernel_fits<128>(n_grids));
+  GRB_TRY(T == 512 ? co_kernel_fits<512>(n_grids * g_mult) : T == 256 ? co_kernel_fits<256>(n_grids * g_mult) : co_kernel_fits<128>(n_grids * g_mult));
   const int oc_words = T >= 256 ? kOcWords : kOcWords / 4;
   LaunchArgs la;
   memset(&la, 0, sizeof(la));
@@ -1722,7 +1727,7 @@ static grb_info bfs_co_launch(int ntrav, const CoPend* pend, int width) {
   for (int j = 0; j < n_grids; ++j) {
     void* p_rec = nullptr;
     unsigned long long* trace = nullptr;
-    GRB_TRY(bfs_persistent_args(pend[0].A, pend[0].rules, 0, kMaxLanes + 1 + j, true, &la.a, &la.g[j], &lc[j], &p_rec, &trace, oc_words));
+    GRB_TRY(bfs_persistent_args(pend[0].A, pend[0].rules, 0, kMaxLanes + 1 + j, true, &la.a, &la.g[j], &lc[j], &p_rec, &trace, oc_words, g_mult));
   }
   for (int i = 0; i < ntrav; ++i) {
     la.t[i].label = (float*)pend[i].v->d_val;
@@ -1893,7 +1898,12 @@ grb_info grb::bfs_co_flush() {
   for (int j = 0; j < k; ++j) pend[j] = g_ring.co[j];
   g_ring.co_n = 0;
   grb_info li = GRB_NOT_IMPLEMENTED;
+  // (GRB_BFS_SINGLE_WIDE=m, a measurement hook: a lone traversal on m workgroups of 512 threads per CU -- needs a build
+  // whose 512-thread instance fits m per CU, -DGRB_CO_LEAN_FROM=512; tools/bfs_single_wide_probe.py.  Three per CU, 24
+  // waves, measured 0.111 ms against 0.098 for the 1024-thread kernel: one traversal is not short of waves)
+  static const int single_wide = getenv("GRB_BFS_SINGLE_WIDE") ? atoi(getenv("GRB_BFS_SINGLE_WIDE")) : 0;
   if (k >= 2) li = bfs_co_launch(k, pend, g_ring.co_width);
+  else if (single_wide > 1) li = bfs_co_launch(1, pend, 1, single_wide);
   if (li == GRB_SUCCESS) {
     for (int j = 0; j < k; ++j) g_ring.t[pend[j].slot].state = 1;
     return GRB_SUCCESS;
