@@ -474,7 +474,7 @@ static grb_info prepare_cband(const CsrArrays& M, SpmvPlan& plan) {
   const long long nnz = M.nvals;
   if (n <= 0 || nnz <= 0) return GRB_SUCCESS;
   hipStream_t st = ctx().stream;
-  const int G = ctx().num_cu;
+  const int G = ctx().num_cu * kCbWgPerCu;
   SpmvCBand* C = new SpmvCBand();
   struct Guard { SpmvCBand* c; ~Guard() { free_spmv_cband(c); } } guard{C};
   std::vector<void*> temp;

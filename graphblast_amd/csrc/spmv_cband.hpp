@@ -36,9 +36,23 @@
 
 namespace grb {
 
-constexpr int kCbThreads = 1024;
+// (build flags for the A/B of band size against waves per CU: tools/spmv_cband_occupancy.sh, docs/experiments.md R6.6)
+#ifndef GRB_CB_THREADS
+#define GRB_CB_THREADS 1024
+#endif
+#ifndef GRB_CB_ROWS
+#define GRB_CB_ROWS 16384
+#endif
+#ifndef GRB_CB_WG_PER_CU
+#define GRB_CB_WG_PER_CU 1
+#endif
+constexpr int kCbThreads = GRB_CB_THREADS;
 constexpr int kCbWaves = kCbThreads / kWave;
-constexpr int kCbRows = 16384;            // rows per band: 16 Ki accumulators of <= 8 bytes = 128 KiB of LDS
+constexpr int kCbRows = GRB_CB_ROWS;      // rows per band: 16 Ki accumulators of <= 8 bytes = 128 KiB of LDS
+constexpr int kCbWgPerCu = GRB_CB_WG_PER_CU;   // persistent workgroups per CU the groups are dealt to
+#ifndef GRB_CB_WPE
+#define GRB_CB_WPE 4                      // waves per SIMD the product kernel is built for (= kCbWgPerCu x kCbWaves / 4)
+#endif
 #ifndef GRB_CB_ITEM_GROUPS
 #define GRB_CB_ITEM_GROUPS 4096
 #endif
@@ -424,7 +438,7 @@ constexpr int kCbStage = GRB_CB_STAGE;    // chunks per pipeline stage of a wave
 typedef unsigned int CbWord4 __attribute__((ext_vector_type(4)));
 
 template <int SR, typename T, bool kIso>
-__global__ __launch_bounds__(kCbThreads) void spmv_cband_kernel(CbArgs a, const T* __restrict__ u_hot,
+__global__ __launch_bounds__(kCbThreads) __attribute__((amdgpu_waves_per_eu(GRB_CB_WPE, GRB_CB_WPE))) void spmv_cband_kernel(CbArgs a, const T* __restrict__ u_hot,
                                                                 const T* __restrict__ u_nat, unsigned int nhot,
                                                                 const void* __restrict__ mask, int mask_f32, int scmp,
                                                                 int accum, T* w, void* __restrict__ partials_raw,
