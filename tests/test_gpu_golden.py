@@ -346,6 +346,19 @@ for case in ("rmat14.d2", "rmat14.d0", "grid48.d0"):
         v2 = g.Vector(n)
         assert g.sssp(v2, W, int(src), d2)[0] == 0
         assert np.array_equal(v2.extractTuples()[1], fx["%s/sssp_%d" % (case, k)]), (case, k)
+    # the same through tickets, one traversal per launch and four side by side: a launch that is refused leaves its
+    # tickets to the wait, which runs the traversal itself
+    for co in (1, 4):
+        g.bfs_set_coschedule(co)
+        d = g.Descriptor(); assert d.loadArgs(mxvmode=0, struconly=1, opreuse=1) == 0
+        srcs = [int(x) for x in fx[case + "/sources"]]
+        vs = [g.Vector(n) for _ in srcs]
+        tk = [g.bfs_enqueue(x, A, s_, d) for x, s_ in zip(vs, srcs)]
+        assert all(i == 0 for i, _ in tk)
+        for k, ((_, t), x) in enumerate(zip(tk, vs)):
+            assert g.bfs_wait(t)[0] == 0
+            assert np.array_equal(x.extractTuples()[1], fx["%s/bfs_%d" % (case, k)]), (case, k, co)
+    g.bfs_set_coschedule(1)
 print("OK")
 '''
     for env, note in (({"GRB_BFS_FORCE_FALLBACK": "1", "GRB_SSSP_FORCE_FALLBACK": "1"}, True),
