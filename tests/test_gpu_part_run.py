@@ -363,3 +363,5 @@ def test_bench_n_greater_than_one_path_with_two_ranks_on_one_gpu():
     assert line["collectives"]["collectives_per_traversal"] >= 2
     assert line["pagerank_partitioned"]["iterations"] == 10
     assert line["source_sharded_replicas"]["value"] > 0
+    assert line["source_sharded_replicas"]["coscheduled_12"]["value"] > 0      # the replica leg, several traversals per launch
+    assert "STRONG" in line["scaling_note"] and "WEAK" in line["scaling_note"]
