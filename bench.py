@@ -377,38 +377,92 @@ def other_workload(args):
         steps = max(1, min(args.steps, 3))
         desc = g.Descriptor()
         desc.loadArgs()
-        g.tc(L, B, desc)
-        ms = []
-        for _ in range(steps):
-            dd = g.Descriptor()
-            dd.loadArgs()
-            info, ntri, res = g.tc(L, B, dd)
-            assert info == 0
-            ms.append(res["tight_ms"])
         dl = np.diff(lp).astype(np.float64)
         erow = np.repeat(np.arange(n, dtype=np.int64), np.diff(lp))
         # every mask entry (i, j) intersects rows i and j of L: the algorithmic bytes are both lists + the entry
         alg = float(4.0 * (np.sum(dl * dl) + np.sum(dl[li])) + 12.0 * li.size)
         # what the pivot kernels stream past their LDS tables: the SHORTER list of every mask entry
         shorter = float(np.minimum(dl[erow], dl[li]).sum())
-        del erow
+        # ---- grb_tc as it is by default: the count on the degree-ordered orientation of the same edges, no product in B
+        # (csrc/tc_count.hip; tc.hpp:17 calls B the buffer matrix).  The first call on a matrix prepares the orientation,
+        # the matrix keeps it: `value` is a call on a matrix that has it, first_call_ms one that does not.
+        g.tc_set_product(0)
+        info, ntri, res = g.tc(L, B, desc)
+        assert info == 0
+        first_ms, first = res["tight_ms"], g.tc_last()[1]
+        counted = first["path"] == 1
+        ms, kern_ms = [], []
+        for _ in range(steps):
+            dd = g.Descriptor()
+            dd.loadArgs()
+            info, again, res = g.tc(L, B, dd)
+            assert info == 0 and again == ntri
+            ms.append(res["tight_ms"])
+            kern_ms.append(g.tc_last()[1]["count_ms"])
         t = float(np.mean(ms)) * 1e-3
-        kern = "spgemm_pivot_block_kernel / spgemm_pivot_wave_kernel"
-        # compulsory HBM bytes: L's structure read (as the left operand, the right operand and the mask: one copy in
-        # memory), the result's values written, its structure copied; the intersections themselves re-read adjacency
+        # ---- the reference's two calls (mxm into B, reduce B): what grb_tc does for any other matrix or descriptor, and
+        # after grb_tc_set_product(1)
+        g.tc_set_product(1)
+        g.tc(L, B, desc)
+        pms = []
+        for _ in range(steps):
+            dd = g.Descriptor()
+            dd.loadArgs()
+            info, ntri_p, res = g.tc(L, B, dd)
+            assert info == 0 and ntri_p == ntri, (ntri_p, ntri)
+            pms.append(res["tight_ms"])
+        tp = float(np.mean(pms)) * 1e-3
+        del erow
+        # compulsory HBM bytes of the product: L's structure read (as the left operand, the right operand and the mask: one
+        # copy in memory), the result's values written, its structure copied; the intersections themselves re-read adjacency
         # lists that the L2 serves (alg: both lists of every mask entry)
         compulsory = float(4.0 * (n + 1) + 4.0 * li.size + 4.0 * li.size + 4.0 * (n + 1) + 4.0 * li.size)
-        line.update({"metric": "triangle count (masked SpGEMM L*L^T .* L) time on a graph of com-Orkut's size",
-                     "value": t * 1e3, "unit": "ms", "higher_is_better": False, "ms_per_step": t * 1e3, "dtype": "i32",
-                     "steps": steps, "config": {"workload": "orkut_tc" if path else "rmat22_ef28_sym_tc (stand-in)", "n": n, "shorter_list_elements": shorter,
-                                                "nnz_L": int(li.size), "triangles": int(ntri)},
-                     "roofline": {"bound": "hbm", "kernel": kern, "achieved": round(compulsory / t / 1e9, 2),
-                                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(compulsory / t / 1e9 / HBM_PEAK_GBS, 5),
-                                  "traffic": pmc_group("masked_spgemm_call", "orkut_tc")[0], "traffic_source": pmc_group("masked_spgemm_call", "orkut_tc")[1],
-                                  "algorithmic_bytes_per_launch": int(compulsory),
-                                  "list_bytes_served_on_chip": int(alg), "list_GBps": round(alg / t / 1e9, 1),
-                                  "note": "bytes = compulsory HBM traffic (operands once, result once); the kernel is bound "
-                                          "by the on-chip rate of its list intersections (list_GBps), not by HBM"}})
+        product = {"ms": round(tp * 1e3, 3), "shorter_list_elements": shorter,
+                   "roofline": {"bound": "hbm", "kernel": "spgemm_pivot_block_kernel / spgemm_pivot_wave_kernel",
+                                "achieved": round(compulsory / tp / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                "frac": round(compulsory / tp / 1e9 / HBM_PEAK_GBS, 5),
+                                "traffic": pmc_group("masked_spgemm_call", "orkut_tc")[0], "traffic_source": pmc_group("masked_spgemm_call", "orkut_tc")[1],
+                                "algorithmic_bytes_per_launch": int(compulsory),
+                                "list_bytes_served_on_chip": int(alg), "list_GBps": round(alg / tp / 1e9, 1),
+                                "note": "bytes = compulsory HBM traffic (operands once, result once); the kernel is bound "
+                                        "by the on-chip rate of its list intersections (list_GBps), not by HBM"}}
+        if counted:
+            # the oriented lists: every vertex keeps its neighbours of higher degree; an edge is intersected once, the list
+            # of the end with the shorter list streamed past an LDS bitmap (or hash table) of the other end's list
+            key = np.diff(ptr).astype(np.int64) * n + (n - 1 - np.arange(n, dtype=np.int64))   # the library's order: degree, then id
+            allrows = np.repeat(np.arange(n, dtype=np.int64), np.diff(ptr))
+            up = key[ind] > key[allrows]
+            olen = np.bincount(allrows[up], minlength=n).astype(np.float64)
+            streamed = float(np.minimum(olen[allrows[up]], olen[ind[up]]).sum())
+            del allrows, up, key
+            # compulsory bytes of the count: the lists once (4 B an edge), a partner descriptor an edge (8 B), the row pointers
+            comp_c = float(4.0 * li.size + 8.0 * li.size + 4.0 * (n + 1))
+            tk = float(np.mean(kern_ms)) * 1e-3
+            line.update({"metric": "triangle count time on a graph of com-Orkut's size (grb_tc; the count on the degree-ordered "
+                                   "orientation, the orientation kept by the matrix)",
+                         "value": t * 1e3, "unit": "ms", "higher_is_better": False, "ms_per_step": t * 1e3, "dtype": "i32", "steps": steps,
+                         "first_call_ms": round(first_ms, 3), "first_call_preparation_ms": round(first["prep_ms"], 3),
+                         "config": {"workload": "orkut_tc" if path else "rmat22_ef28_sym_tc (stand-in)", "n": n, "nnz_L": int(li.size),
+                                    "triangles": int(ntri), "longest_oriented_list": int(first["longest_list"]),
+                                    "longest_row_of_L": int(dl.max()), "streamed_list_elements": streamed,
+                                    "workgroups": {"wave_hash": first["tasks"][0], "bitmap": first["tasks"][1], "hash": first["tasks"][2]}},
+                         "roofline": {"bound": "hbm", "kernel": "tc_count_bitmap_kernel + tc_count_pivot_kernel",
+                                      "achieved": round(comp_c / tk / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                      "frac": round(comp_c / tk / 1e9 / HBM_PEAK_GBS, 5),
+                                      "traffic": pmc_group("tc_count_call", "orkut_tc")[0], "traffic_source": pmc_group("tc_count_call", "orkut_tc")[1],
+                                      "algorithmic_bytes_per_launch": int(comp_c), "kernels_ms": round(tk * 1e3, 3),
+                                      "streamed_list_bytes": int(4.0 * streamed), "streamed_GBps": round(4.0 * streamed / tk / 1e9, 1),
+                                      "note": "bytes = compulsory HBM traffic (the oriented lists and the partner descriptors once); "
+                                              "what the kernels actually move is the shorter list of every edge once per edge "
+                                              "(streamed_list_bytes), from HBM and the caches between them: streamed_GBps"},
+                         "product_in_B": product})
+        else:
+            line.update({"metric": "triangle count (masked SpGEMM L*L^T .* L) time on a graph of com-Orkut's size",
+                         "value": tp * 1e3, "unit": "ms", "higher_is_better": False, "ms_per_step": tp * 1e3, "dtype": "i32",
+                         "steps": steps, "config": {"workload": "orkut_tc" if path else "rmat22_ef28_sym_tc (stand-in)", "n": n, "shorter_list_elements": shorter,
+                                                    "nnz_L": int(li.size), "triangles": int(ntri)},
+                         "roofline": product["roofline"]})
+        t = tp                                                 # (the dense-core block below compares products)
         # north_star's "MFMA dense-tile path where the frontier densifies", on the workload SURVEY 8(f)2 names for it: the
         # product restricted to the K longest rows of L as K x K bit rows (csrc/mxm_core.hip) -- AND + popcount per mask
         # entry against v_mfma_i32_16x16x64_i8 on the same rows, same per-entry results (checksum) -- and the whole product
@@ -442,7 +496,7 @@ def other_workload(args):
                 os.environ.pop("GRB_TC_CORE_K", None)
             assert info == 0 and ntri_c == ntri, (ntri_c, ntri)
             with_core[str(K)] = round(res_c["tight_ms"], 2)
-        g.tc(L, B, desc)                                       # (B holds the default path's product again: the parity block reads it)
+        g.tc(L, B, desc)                                       # (B holds the product path's result again: the parity block reads it)
         line["dense_core"] = {"per_core_size": core_ab, "whole_product_ms_with_the_core_on": with_core,
                               "whole_product_ms": round(t * 1e3, 2),
                               "mfma": "measured, not used: on the bit rows of the 2 048 longest rows the MFMA kernel beats AND + "
@@ -470,10 +524,12 @@ def other_workload(args):
                                               "intersection work)" % (k_rows, int(lp[k_rows]), int(li.size), 100.0 * work[k_rows - 1] / work[-1]),
                                     "triangles_in_sample": int(want)}
             line["parity"] = {"checked_rows": k_rows, "mismatches": 0 if got == int(want) else 1,
-                              "what": "per-entry counts of the HIP result summed over the sampled rows == the CPU reference's count"}
+                              "what": "per-entry counts of the product (grb_tc_set_product(1)) summed over the sampled rows == the CPU "
+                                      "reference's count on those rows; the count without the product == the product's sum (%d)" % int(ntri)}
             if got != int(want):
                 print(json.dumps({"error": "parity", "workload": args.workload, "got": got, "want": int(want)}))
                 sys.exit(3)
+        g.tc_set_product(0)
     print(json.dumps(line))
 
 

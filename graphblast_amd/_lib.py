@@ -39,6 +39,11 @@ class TcCoreResult(C.Structure):
                 ("tiles_mfma", C.c_int32), ("tiles_by_density", C.c_int32 * 10)]
 
 
+class TcInfo(C.Structure):
+    _fields_ = [("path", C.c_int32), ("prep_ms", C.c_float), ("count_ms", C.c_float), ("longest_list", C.c_int32),
+                ("tasks", C.c_int32 * 3)]
+
+
 class BfsLevel(C.Structure):
     _fields_ = [("direction", C.c_int32), ("frontier", C.c_int32), ("frontier_edges", C.c_int64),
                 ("discovered", C.c_int32), ("ms", C.c_float)]
@@ -172,6 +177,8 @@ _SIGS = {
     "grb_matrix_tril": [_vp, _vp, _vp],
     "grb_tc": [C.POINTER(C.c_int64), _vp, _vp, _vp, C.POINTER(AlgoResult)],
     "grb_tc_dense_core": [_vp, _i, _i, _i, C.POINTER(TcCoreResult)],
+    "grb_tc_set_product": [_i],
+    "grb_tc_last": [C.POINTER(TcInfo)],
     "grb_sssp": [_vp, _vp, _i, _vp, C.POINTER(AlgoResult)],
     "grb_pr": [_vp, _vp, _f, _f, _vp, C.POINTER(AlgoResult)],
     "grb_k_spmv": [_vp, _i, _i, _vp, _vp, _i, _i, _vp],

@@ -561,6 +561,18 @@ def tc(A, B, desc):
     return info, n.value, dict(tight_ms=res.tight_ms)
 
 
+def tc_set_product(on):
+    """grb_tc_set_product: 1 = grb_tc always forms the product in B, 0 = it counts without it where it can; < 0 queries."""
+    return _lib.load().grb_tc_set_product(int(on))
+
+
+def tc_last():
+    """grb_tc_last: which way the last tc went and what it cost."""
+    t = _lib.TcInfo()
+    info = _lib.load().grb_tc_last(C.byref(t))
+    return info, dict(path=t.path, prep_ms=t.prep_ms, count_ms=t.count_ms, longest_list=t.longest_list, tasks=list(t.tasks))
+
+
 def tc_dense_core(L, k_want, method=0, dense_from=0):
     """grb_tc_dense_core: the product C<L> = L (+.x) L^T restricted to the k_want longest rows of L, as K x K bit rows.
     method 0 popcount, 1 MFMA (v_mfma_i32_16x16x64_i8), 2 MFMA for tiles of >= dense_from mask entries.  Returns (info, dict)."""

@@ -698,12 +698,15 @@ struct grb_matrix_s {
   int* d_oc2_bigidx = nullptr;
   int oc2_nb = 0, oc2_nrows = 0, oc2_state = 0, oc2_grid = 0;
   grb::BatchSlices batch_in, batch_out;          // bfs_batch.hip, built lazily
+  void* tc_prep = nullptr;                       // tc_count.hip: the degree-oriented lists of a lower triangle (built by the first count)
 };
 
+namespace grb { void tc_prep_free(grb_matrix_s* A); }   // tc_count.hip
 // Every cache that holds a copy of the stored VALUES (not structure) is dropped: the SpMV band formats.  Called by whatever rewrites csr.val / csc.val in place.
 inline void matrix_values_changed(grb_matrix_s* A) {
   grb::spmv_plan_values_changed(&A->plan_csr);
   grb::spmv_plan_values_changed(&A->plan_csc);
+  grb::tc_prep_free(A);                          // (whether every value is 1 is part of what it found)
 }
 
 namespace grb {
@@ -785,6 +788,8 @@ int k_spmv_cband_info(const SpmvPlan& plan, long long* groups, int* bands, int* 
 int spmv_format_setting(int set);  // spmv.hip: < 0 = query; 0 CSR kernel, 1 auto, 2 column-sorted bands wherever allowed
 grb_info k_spmv_plan_info(const CsrArrays& M, SpmvPlan& plan, const Index* other_ptr, int warm, int* bands,
                           long long* band_nnz, long long* pieces, int* nhot);
+grb_info tc_count_try(grb_matrix_s* A, long long* count, bool* done);   // tc_count.hip
+int tc_product_setting(int set);                 // tc_count.hip: < 0 queries
 int sssp_nearfar_setting(int set, bool apply);   // sssp_nearfar.hip
 int sssp_last_order(int set);                    // set < 0 queries
 void sssp_last_work(long long* out3);            // near / far: vertices expanded, out-edges relaxed, vertices marked, all passes

@@ -1498,10 +1498,20 @@ grb_info grb_tc(int64_t* ntris, grb_matrix A, grb_matrix B, grb_descriptor desc,
   float ms = 0.f;
   grb_descriptor_toggle(desc, GRB_INP1);
   grb_info info = grb_timer_start();
-  if (info == GRB_SUCCESS) info = grb_mxm(B, A, GRB_ACCUM_NULL, GRB_PLUS_MULTIPLIES, A, A, desc);
   double sum = 0;
   long long wide = 0;
-  if (info == GRB_SUCCESS && B->dtype == GRB_I32 && !desc->struconly) {
+  // the count without the product (tc_count.hip), when grb_mxm would have accepted the call and A is what tc.hpp says it is
+  bool counted = false;
+  if (info == GRB_SUCCESS && A->built && A != B && A->dtype == B->dtype && desc->desc[GRB_INP0] != GRB_TRAN &&
+      desc->desc[GRB_INP1] == GRB_TRAN && A->csr.ptr && A->csc.ptr && B->nrows == A->nrows && B->ncols == A->ncols)
+    info = tc_count_try(A, &wide, &counted);
+  if (counted) {
+    sum = (double)wide;
+  } else if (info == GRB_SUCCESS) {
+    info = grb_mxm(B, A, GRB_ACCUM_NULL, GRB_PLUS_MULTIPLIES, A, A, desc);
+  }
+  if (counted) {
+  } else if (info == GRB_SUCCESS && B->dtype == GRB_I32 && !desc->struconly) {
     // reduce<int, int>(ntris, ...) in the reference (tc.hpp:41-42) wraps beyond 2^31 triangles; this entry
     // point returns the count in 64 bits (the frontend's int* overload keeps the reference's int)
     void* p_sum;

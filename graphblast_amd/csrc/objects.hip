@@ -845,6 +845,7 @@ void grb::matrix_release_device(grb_matrix A) {
     *b = BatchSlices();
   }
   A->nonneg_values = -1; A->mean_value = -1.0; A->small_int_values = -1;
+  tc_prep_free(A);
   free_spmv_plan(&A->plan_csr);
   free_spmv_plan(&A->plan_csc);
   A->plan_csr_pending = false;

@@ -569,8 +569,27 @@ grb_info grb_pr(grb_vector p, grb_matrix A, float alpha, float eps, grb_descript
 grb_info grb_cc(grb_vector v, grb_matrix A, int seed, grb_descriptor desc, grb_algo_result* result);
 int grb_cc_set_fused(int on);
 
-/* algorithm::tc (algorithm/tc.hpp:15-54): A = lower triangle (int), B = buffer matrix. */
+/* algorithm::tc (algorithm/tc.hpp:15-54): A = lower triangle (int), B = buffer matrix.
+ * The reference forms B<A> = A (+.x) A^T and reduces it (tc.hpp:38-43); B is its "buffer matrix" (tc.hpp:17) and is not
+ * read again.  When A is a STRICTLY lower triangle whose stored values are all 1 -- the matrix the reference's driver
+ * builds (example/gtc.cu) -- that sum is the number of triangles, which does not depend on which way the edges point:
+ * the library then counts on the degree-ordered orientation of the same edges (csrc/tc_count.hip: every vertex keeps
+ * the neighbours of higher degree, the lists are short, one end of every edge is looked up in an LDS bitmap of the other)
+ * and LEAVES B AS IT WAS.  The orientation is prepared by the first count on a matrix and kept with it.  Any other
+ * matrix or descriptor (INP0 transposed, ...), and every matrix after grb_tc_set_product(1) (or GRB_TC_PRODUCT=1 in the
+ * environment), runs the reference's two calls with the product in B.  ntris is the same number either way. */
 grb_info grb_tc(int64_t* ntris, grb_matrix A, grb_matrix B, grb_descriptor desc, grb_algo_result* result);
+/* 1: grb_tc always forms the product in B; 0: counts without it where it can (default); < 0: query.  Returns the
+ * previous setting. */
+int grb_tc_set_product(int on);
+typedef struct {
+  int32_t path;           /* of the last grb_tc: 0 = product + reduce, 1 = counted on the oriented lists            */
+  float   prep_ms;        /* the orientation, when that call had to build it (0 when the matrix brought it along)    */
+  float   count_ms;       /* the counting kernels                                                                  */
+  int32_t longest_list;   /* the longest list of the orientation                                                   */
+  int32_t tasks[3];       /* workgroups launched: a wave + hash table, 512 threads + bitmap, 512 threads + hash table */
+} grb_tc_info;
+grb_info grb_tc_last(grb_tc_info* out);
 
 /* The DENSE CORE of that product (csrc/mxm_core.hip): the k_want longest rows of the lower triangle L (all rows of a
  * length or none) as K x K bit rows H, and C_H(i, j) = sum_k H[i][k] H[j][k] for the entries (i, j) of L between core

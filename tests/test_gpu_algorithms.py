@@ -672,6 +672,10 @@ def test_triangle_count(hb, graphs):
         info, ntris, res = g.tc(L, B, d)
         assert info == 0 and ntris == sr.tc(lp, li)[0], name
         if n <= 5000:
+            was = g.tc_set_product(1)                                   # the reference's two calls: the product in B
+            info, ntris, res = g.tc(L, B, hb.descriptor())
+            g.tc_set_product(was)
+            assert info == 0 and ntris == sr.tc(lp, li)[0], name
             Lo = oops.Matrix(n, n, np.int32); Lo.build_csr(lp, li, lv)
             do = oops.Descriptor(); do.loadArgs(); do.toggle(oops.GrB_INP1)
             from oracle.semiring import Semiring

@@ -224,6 +224,7 @@ def test_triangle_count_with_the_dense_core(hb, mfma_from):
     assert g.tril(L, A, hb.descriptor()) == 0
     lp, li, lv = L.host_csr()
     saved = {k: os.environ.get(k) for k in ("GRB_TC_CORE_K", "GRB_TC_CORE_MIN_NVALS", "GRB_TC_CORE_MFMA_FROM")}
+    was = g.tc_set_product(1)                                   # (the product in B is what this test is about)
     try:
         os.environ["GRB_TC_CORE_K"] = "0"
         B0 = g.Matrix(n, n, np.int32)
@@ -241,8 +242,122 @@ def test_triangle_count_with_the_dense_core(hb, mfma_from):
             info, got_n, _ = g.tc(L, B1, hb.descriptor())             # the same output matrix again (its arrays are kept)
             assert info == 0 and got_n == want_n
     finally:
+        g.tc_set_product(was)
         for k, v in saved.items():
             if v is None:
                 os.environ.pop(k, None)
             else:
                 os.environ[k] = v
+
+
+def _lower(ptr, ind, n, strict=True):
+    rows = np.repeat(np.arange(n, dtype=np.int32), np.diff(ptr))
+    keep = ind < rows if strict else ind <= rows
+    lp = np.zeros(n + 1, dtype=np.int32)
+    np.cumsum(np.bincount(rows[keep], minlength=n), out=lp[1:])
+    return lp, ind[keep].astype(np.int32)
+
+
+def _tc_graphs():
+    from graphblast_amd.graphgen import rmat_edges, grid_edges, finalize_edges
+    rng = np.random.default_rng(11)
+    out = []
+    s, d, n = rmat_edges(13, 24, seed=5)                                    # hubs: lists of several hundred
+    out.append(("rmat13", finalize_edges(s, d, n, symmetrize=True)))
+    s, d, n = grid_edges(60, keep=0.7, seed=2)                              # road-like: nothing but short lists
+    out.append(("grid", finalize_edges(s, d, n, symmetrize=True)))
+    n = 900                                                                 # dense: every list long, ties in the degrees
+    out.append(("dense", finalize_edges(rng.integers(0, n, 300000), rng.integers(0, n, 300000), n, symmetrize=True)))
+    n = 640                                                                 # complete graph: the ranking is the ids alone
+    a, b = np.meshgrid(np.arange(n), np.arange(n))
+    out.append(("complete", finalize_edges(a.ravel(), b.ravel(), n, symmetrize=True)))
+    n = 3000                                                                # a star, a path and isolated vertices
+    src = np.concatenate([np.zeros(1500, dtype=np.int64), np.arange(1600, 2500)])
+    dst = np.concatenate([np.arange(1, 1501), np.arange(1601, 2501)])
+    out.append(("star+path", finalize_edges(src, dst, n, symmetrize=True)))
+    return out
+
+
+@pytest.mark.parametrize("bitmap_upto", [None, "100"])
+def test_triangle_count_without_the_product(hb, bitmap_upto):
+    """grb_tc on a strictly lower triangle of ones counts on the degree-ordered orientation (csrc/tc_count.hip) and leaves
+    the buffer matrix alone; the number is SimpleReferenceTc's and the product path's, for hub graphs, road-like graphs,
+    dense graphs (bitmap kernel; with GRB_TC_BITMAP_UPTO=100 the hash-table kernel of the pivots numbered beyond the
+    bitmap), f32 and i32.  Whatever is not such a matrix -- a diagonal entry, a value that is not 1, a transposed first
+    operand -- goes through the reference's two calls, as does everything after grb_tc_set_product(1)."""
+    import os
+    from oracle import simple_reference as sr
+    g = hb.g
+    saved = os.environ.get("GRB_TC_BITMAP_UPTO")
+    if bitmap_upto is not None:
+        os.environ["GRB_TC_BITMAP_UPTO"] = bitmap_upto
+    was = g.tc_set_product(0)
+    try:
+        seen = [0, 0, 0]
+        for name, gr in _tc_graphs():
+            ptr, ind = np.asarray(gr["csr"][0]), np.asarray(gr["csr"][1])
+            n = gr["n"]
+            lp, li = _lower(ptr, ind, n)
+            want = sr.tc(lp, li)[0]
+            for dt in (np.int32, np.float32):
+                L, B = g.Matrix(n, n, dt), g.Matrix(n, n, dt)
+                assert L.build_csr(lp, li, np.ones(li.size, dtype=dt)) == 0
+                for rep in range(2):                                        # the second count finds the orientation with the matrix
+                    info, ntris, _ = g.tc(L, B, hb.descriptor())
+                    last = g.tc_last()[1]
+                    assert info == 0 and ntris == want, (name, dt, rep, ntris, want)
+                    assert last["path"] == 1 and (rep == 0 or last["prep_ms"] < 1.0), (name, last)
+                    assert B.nvals() == 0                                   # the buffer matrix was not touched
+                for k in range(3):
+                    seen[k] += last["tasks"][k]
+                # the reference's two calls on the same matrix: the same number, the product in B
+                g.tc_set_product(1)
+                info, ntris, _ = g.tc(L, B, hb.descriptor())
+                assert info == 0 and g.tc_last()[1]["path"] == 0
+                # (the reduction of an f32 product is an f32 sum: exact up to 2^24 only; the count path's is an integer)
+                assert ntris == want if dt == np.int32 else abs(ntris - want) <= 2e-7 * want, (name, dt, ntris, want)
+                assert int(B.host_csr()[2].astype(np.int64).sum()) == want
+                g.tc_set_product(0)
+                # values changed in place: the kept orientation goes with them (4 = 2 x 2 per common neighbour now)
+                if name == "rmat13" and dt == np.int32:
+                    assert g.apply(L, None, None, "bind_second", L, hb.descriptor(), binop="multiplies", scalar=2) == 0
+                    info, ntris, _ = g.tc(L, B, hb.descriptor())
+                    assert info == 0 and g.tc_last()[1]["path"] == 0 and ntris == 4 * want
+        assert seen[0] > 0 and (seen[1] > 0 if bitmap_upto is None else seen[2] > 0), seen
+        # not such a matrix
+        name, gr = _tc_graphs()[0]
+        ptr, ind = np.asarray(gr["csr"][0]), np.asarray(gr["csr"][1])
+        n = gr["n"]
+        lp, li = _lower(ptr, ind, n)
+        want = sr.tc(lp, li)[0]
+        vals = np.ones(li.size, dtype=np.int32)
+        vals[li.size // 2] = 3
+        L, B = g.Matrix(n, n, np.int32), g.Matrix(n, n, np.int32)
+        assert L.build_csr(lp, li, vals) == 0
+        info, ntris, _ = g.tc(L, B, hb.descriptor())
+        assert info == 0 and g.tc_last()[1]["path"] == 0 and ntris == int(B.host_csr()[2].astype(np.int64).sum()) != want
+        info, again, _ = g.tc(L, B, hb.descriptor())                        # (the verdict is kept with the matrix too)
+        assert info == 0 and again == ntris and g.tc_last()[1]["path"] == 0
+        dp, di = _lower(ptr, np.asarray(ind), n)                            # a diagonal entry: row 5 gets (5, 5)
+        rows = np.repeat(np.arange(n, dtype=np.int32), np.diff(dp))
+        r2, c2 = np.concatenate([rows, [5]]), np.concatenate([di, [5]])
+        o = np.lexsort((c2, r2))
+        p2 = np.zeros(n + 1, dtype=np.int32)
+        np.cumsum(np.bincount(r2, minlength=n), out=p2[1:])
+        L2, B2 = g.Matrix(n, n, np.int32), g.Matrix(n, n, np.int32)
+        assert L2.build_csr(p2, c2[o].astype(np.int32), np.ones(c2.size, dtype=np.int32)) == 0
+        info, ntris, _ = g.tc(L2, B2, hb.descriptor())
+        assert info == 0 and g.tc_last()[1]["path"] == 0 and ntris == sr.tc(p2, c2[o].astype(np.int32))[0]
+        # the first operand transposed: grb_mxm's business
+        L3, B3 = g.Matrix(n, n, np.int32), g.Matrix(n, n, np.int32)
+        assert L3.build_csr(lp, li, np.ones(li.size, dtype=np.int32)) == 0
+        d = hb.descriptor()
+        d.toggle(g.GrB_INP0)
+        info, ntris, _ = g.tc(L3, B3, d)
+        assert info == 0 and g.tc_last()[1]["path"] == 0
+    finally:
+        g.tc_set_product(was)
+        if saved is None:
+            os.environ.pop("GRB_TC_BITMAP_UPTO", None)
+        else:
+            os.environ["GRB_TC_BITMAP_UPTO"] = saved

@@ -4,7 +4,7 @@ timeout 300 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/r2k/kt -o
 f=$(find gpurun_out/r2k/kt -name "b_kernel_trace.csv" | head -1)
 python - "$f" <<'PY'
 import csv, sys
-rows = [r for r in csv.DictReader(open(sys.argv[1])) if "grb::batch" in r["Kernel_Name"]]
+rows = [r for r in csv.DictReader(open(sys.argv[1]))]         # every kernel (memsets and copies show up as fill / copy kernels)
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 # last sweep: find the last batch_seed_kernel
 idx = max(i for i, r in enumerate(rows) if "batch_seed" in r["Kernel_Name"])
