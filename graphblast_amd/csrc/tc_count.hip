@@ -229,9 +229,11 @@ __global__ __launch_bounds__(kBlock) void tc_degree_kernel(const Index* __restri
   pay[v] = (unsigned)v;
 }
 
-__global__ __launch_bounds__(kBlock) void tc_number_kernel(const unsigned* __restrict__ order, Index n, int* __restrict__ number) {
+// (pbase: the degree of the vertex numbered r -- room for its partners, whoever they turn out to be; scanned afterwards)
+__global__ __launch_bounds__(kBlock) void tc_number_kernel(const unsigned* __restrict__ order, const unsigned long long* __restrict__ key,
+                                                           Index n, int* __restrict__ number, unsigned* __restrict__ pbase) {
   const Index r = (Index)blockIdx.x * kBlock + threadIdx.x;
-  if (r < n) number[order[r]] = (int)r;
+  if (r < n) { number[order[r]] = (int)r; pbase[r] = 0xffffffffu - (unsigned)key[r]; }
 }
 
 // pass A: every entry (i, j) as {lower-ranked end, higher-ranked end} in the new numbers; the lower end's list grows by one.
@@ -272,30 +274,20 @@ __device__ __forceinline__ void tc_roles(int lo, int hi, const int* __restrict__
   *plen = lo_is_pivot ? lhi : llo;
 }
 
-// pass B: the lists themselves (in whatever order the atomics hand out: they are looked up, never merged) and the number
-// of partners per pivot
+// pass B: the lists themselves (in whatever order the atomics hand out: they are looked up, never merged) and every
+// pivot's partners as {first element of the list in D, length}, in the room its degree reserves (dcur / pcur start as
+// copies of Dptr / pbase: the atomics hand out absolute positions)
 __global__ __launch_bounds__(kBlock) void tc_lists_kernel(const int* __restrict__ elo, const int* __restrict__ ehi, long long nnz,
                                                           const unsigned* __restrict__ Dptr, const int* __restrict__ len,
-                                                          unsigned* __restrict__ cur, int* __restrict__ D, unsigned* __restrict__ pcnt) {
+                                                          unsigned* __restrict__ dcur, int* __restrict__ D,
+                                                          unsigned* __restrict__ pcur, int2* __restrict__ P) {
   const long long stride = (long long)gridDim.x * kBlock;
   for (long long e = (long long)blockIdx.x * kBlock + threadIdx.x; e < nnz; e += stride) {
     const int lo = elo[e], hi = ehi[e];
-    D[Dptr[lo] + atomicAdd(&cur[lo], 1u)] = hi;
+    D[atomicAdd(&dcur[lo], 1u)] = hi;
     int pivot, partner, plen;
     tc_roles(lo, hi, len, &pivot, &partner, &plen);
-    if (plen > 0) atomicAdd(&pcnt[pivot], 1u);
-  }
-}
-
-// pass C: a pivot's partners as {first element of the list in D, length}
-__global__ __launch_bounds__(kBlock) void tc_partners_kernel(const int* __restrict__ elo, const int* __restrict__ ehi, long long nnz,
-                                                             const unsigned* __restrict__ Dptr, const int* __restrict__ len,
-                                                             const unsigned* __restrict__ Pptr, unsigned* __restrict__ cur, int2* __restrict__ P) {
-  const long long stride = (long long)gridDim.x * kBlock;
-  for (long long e = (long long)blockIdx.x * kBlock + threadIdx.x; e < nnz; e += stride) {
-    int pivot, partner, plen;
-    tc_roles(elo[e], ehi[e], len, &pivot, &partner, &plen);
-    if (plen > 0) P[Pptr[pivot] + atomicAdd(&cur[pivot], 1u)] = make_int2((int)Dptr[partner], plen);
+    if (plen > 0) P[atomicAdd(&pcur[pivot], 1u)] = make_int2((int)Dptr[partner], plen);
   }
 }
 
@@ -305,23 +297,25 @@ __device__ __forceinline__ int tc_class(int p, int len, unsigned np, int bitmap_
   if (len <= kTcWaveLen) return 0;
   return p <= bitmap_upto ? 1 : 2;
 }
-__global__ __launch_bounds__(kBlock) void tc_task_count_kernel(const int* __restrict__ len, const unsigned* __restrict__ Pptr, Index n, int bitmap_upto,
+__global__ __launch_bounds__(kBlock) void tc_task_count_kernel(const int* __restrict__ len, const unsigned* __restrict__ pbase,
+                                                               const unsigned* __restrict__ pcur, Index n, int bitmap_upto,
                                                                unsigned* __restrict__ c0, unsigned* __restrict__ c1, unsigned* __restrict__ c2) {
   const Index p = (Index)blockIdx.x * kBlock + threadIdx.x;
   if (p >= n) return;
-  const unsigned np = Pptr[p + 1] - Pptr[p];
+  const unsigned np = pcur[p] - pbase[p];
   const int c = tc_class((int)p, len[p], np, bitmap_upto);
   c0[p] = c == 0 ? (np + kTcChunk[0] - 1) / kTcChunk[0] : 0u;
   c1[p] = c == 1 ? (np + kTcChunk[1] - 1) / kTcChunk[1] : 0u;
   c2[p] = c == 2 ? (np + kTcChunk[2] - 1) / kTcChunk[2] : 0u;
 }
-__global__ __launch_bounds__(kBlock) void tc_task_fill_kernel(const int* __restrict__ len, const unsigned* __restrict__ Pptr, Index n, int bitmap_upto,
+__global__ __launch_bounds__(kBlock) void tc_task_fill_kernel(const int* __restrict__ len, const unsigned* __restrict__ pbase,
+                                                              const unsigned* __restrict__ pcur, Index n, int bitmap_upto,
                                                               const unsigned* __restrict__ c0, const unsigned* __restrict__ c1,
                                                               const unsigned* __restrict__ c2, int4* __restrict__ t0, int4* __restrict__ t1,
                                                               int4* __restrict__ t2) {
   const Index p = (Index)blockIdx.x * kBlock + threadIdx.x;
   if (p >= n) return;
-  const unsigned first = Pptr[p], np = Pptr[p + 1] - first;
+  const unsigned first = pbase[p], np = pcur[p] - first;
   const int c = tc_class((int)p, len[p], np, bitmap_upto);
   if (c < 0) return;
   int4* const t = c == 0 ? t0 : c == 1 ? t1 : t2;
@@ -390,7 +384,7 @@ static grb_info tc_prepare(grb_matrix_s* A, TcPrep* t) {
   TcTemps tmp;
   int *erow, *number, *elo, *ehi, *len, *flags;
   unsigned long long* key;
-  unsigned *order, *cur, *pptr, *c0, *c1, *c2;
+  unsigned *order, *cur, *pptr, *pcur, *c0, *c1, *c2;
   GRB_TRY(tmp.get(&erow, (size_t)nnz));
   GRB_TRY(tmp.get(&elo, (size_t)nnz));
   GRB_TRY(tmp.get(&ehi, (size_t)nnz));
@@ -400,6 +394,7 @@ static grb_info tc_prepare(grb_matrix_s* A, TcPrep* t) {
   GRB_TRY(tmp.get(&order, (size_t)n));
   GRB_TRY(tmp.get(&cur, (size_t)n));
   GRB_TRY(tmp.get(&pptr, (size_t)n + 1));
+  GRB_TRY(tmp.get(&pcur, (size_t)n));
   GRB_TRY(tmp.get(&c0, (size_t)n + 1));
   GRB_TRY(tmp.get(&c1, (size_t)n + 1));
   GRB_TRY(tmp.get(&c2, (size_t)n + 1));
@@ -411,7 +406,8 @@ static grb_info tc_prepare(grb_matrix_s* A, TcPrep* t) {
   hipLaunchKernelGGL(tc_degree_kernel, dim3(vgrid), dim3(kBlock), 0, s, (const Index*)A->csr.ptr, (const Index*)A->csc.ptr, n, key, order);
   GRB_HIP_TRY(hipGetLastError());
   GRB_TRY(device_sort_pairs(key, order, n, 32, 0));
-  hipLaunchKernelGGL(tc_number_kernel, dim3(vgrid), dim3(kBlock), 0, s, (const unsigned*)order, n, number);
+  GRB_HIP_TRY(hipMemsetAsync(pptr + n, 0, 4, s));
+  hipLaunchKernelGGL(tc_number_kernel, dim3(vgrid), dim3(kBlock), 0, s, (const unsigned*)order, (const unsigned long long*)key, n, number, pptr);
   hipLaunchKernelGGL(tc_rows_kernel, dim3(stream_grid((long long)n * 16, kBlock)), dim3(kBlock), 0, s, (const Index*)A->csr.ptr, n, erow);
   GRB_HIP_TRY(hipGetLastError());
   GRB_HIP_TRY(hipMemsetAsync(dptr, 0, 4 * ((size_t)n + 1), s));
@@ -421,6 +417,7 @@ static grb_info tc_prepare(grb_matrix_s* A, TcPrep* t) {
                      (const unsigned*)A->csr.val, one, nnz, (const int*)number, elo, ehi, dptr, flags);
   GRB_HIP_TRY(hipGetLastError());
   GRB_TRY(device_exclusive_scan_u32(dptr, (long long)n + 1));
+  GRB_TRY(device_exclusive_scan_u32(pptr, (long long)n + 1));
   hipLaunchKernelGGL(tc_lengths_kernel, dim3(vgrid), dim3(kBlock), 0, s, (const unsigned*)dptr, n, len, flags + 1);
   GRB_HIP_TRY(hipGetLastError());
   int h_flags[2] = {0, 0};
@@ -429,26 +426,18 @@ static grb_info tc_prepare(grb_matrix_s* A, TcPrep* t) {
   if (h_flags[0]) return GRB_SUCCESS;         // not a strictly lower triangle of ones
   t->longest = h_flags[1];
   GRB_HIP_TRY(hipMalloc((void**)&t->D, 4 * ((size_t)nnz + 8)));
+  GRB_HIP_TRY(hipMalloc((void**)&t->P, 8 * (2 * (size_t)nnz + 1)));          // (a vertex's room: its degree)
   GRB_HIP_TRY(hipMemsetAsync(t->D + nnz, 0, 32, s));
-  GRB_HIP_TRY(hipMemsetAsync(cur, 0, 4 * (size_t)n, s));
-  GRB_HIP_TRY(hipMemsetAsync(pptr, 0, 4 * ((size_t)n + 1), s));
+  GRB_HIP_TRY(hipMemcpyAsync(cur, dptr, 4 * (size_t)n, hipMemcpyDeviceToDevice, s));
+  GRB_HIP_TRY(hipMemcpyAsync(pcur, pptr, 4 * (size_t)n, hipMemcpyDeviceToDevice, s));
   hipLaunchKernelGGL(tc_lists_kernel, dim3(egrid), dim3(kBlock), 0, s, (const int*)elo, (const int*)ehi, nnz, (const unsigned*)dptr,
-                     (const int*)len, cur, t->D, pptr);
-  GRB_HIP_TRY(hipGetLastError());
-  GRB_TRY(device_exclusive_scan_u32(pptr, (long long)n + 1));
-  unsigned npart = 0;
-  GRB_HIP_TRY(hipMemcpyAsync(&npart, pptr + n, 4, hipMemcpyDeviceToHost, s));
-  GRB_HIP_TRY(hipStreamSynchronize(s));
-  GRB_HIP_TRY(hipMalloc((void**)&t->P, 8 * ((size_t)npart + 1)));
-  GRB_HIP_TRY(hipMemsetAsync(cur, 0, 4 * (size_t)n, s));
-  hipLaunchKernelGGL(tc_partners_kernel, dim3(egrid), dim3(kBlock), 0, s, (const int*)elo, (const int*)ehi, nnz, (const unsigned*)dptr,
-                     (const int*)len, (const unsigned*)pptr, cur, t->P);
+                     (const int*)len, cur, t->D, pcur, t->P);
   GRB_HIP_TRY(hipGetLastError());
   // the tasks (GRB_TC_BITMAP_UPTO: tests send the pivots beyond a smaller number to the hash-table kernel)
   int bitmap_upto = kTcBits;
   if (const char* e = getenv("GRB_TC_BITMAP_UPTO")) { const int v = atoi(e); if (v >= 0 && v < kTcBits) bitmap_upto = v; }
   for (unsigned* c : {c0, c1, c2}) GRB_HIP_TRY(hipMemsetAsync(c + n, 0, 4, s));
-  hipLaunchKernelGGL(tc_task_count_kernel, dim3(vgrid), dim3(kBlock), 0, s, (const int*)len, (const unsigned*)pptr, n, bitmap_upto, c0, c1, c2);
+  hipLaunchKernelGGL(tc_task_count_kernel, dim3(vgrid), dim3(kBlock), 0, s, (const int*)len, (const unsigned*)pptr, (const unsigned*)pcur, n, bitmap_upto, c0, c1, c2);
   GRB_HIP_TRY(hipGetLastError());
   unsigned nt[3] = {0, 0, 0};
   int k = 0;
@@ -462,7 +451,7 @@ static grb_info tc_prepare(grb_matrix_s* A, TcPrep* t) {
     t->ntasks[k] = (int)nt[k];
     GRB_HIP_TRY(hipMalloc((void**)&t->tasks[k], 16 * ((size_t)nt[k] + 1)));
   }
-  hipLaunchKernelGGL(tc_task_fill_kernel, dim3(vgrid), dim3(kBlock), 0, s, (const int*)len, (const unsigned*)pptr, n, bitmap_upto, (const unsigned*)c0,
+  hipLaunchKernelGGL(tc_task_fill_kernel, dim3(vgrid), dim3(kBlock), 0, s, (const int*)len, (const unsigned*)pptr, (const unsigned*)pcur, n, bitmap_upto, (const unsigned*)c0,
                      (const unsigned*)c1, (const unsigned*)c2, t->tasks[0], t->tasks[1], t->tasks[2]);
   GRB_HIP_TRY(hipGetLastError());
   GRB_HIP_TRY(hipStreamSynchronize(s));
@@ -507,6 +496,7 @@ grb_info tc_count_try(grb_matrix_s* A, long long* count, bool* done) {
   GRB_TRY(scratch(10, 8 * (kTcSlots + 1), &p_slots));
   unsigned long long* slots = (unsigned long long*)p_slots;
   GRB_HIP_TRY(hipMemsetAsync(slots, 0, 8 * (kTcSlots + 1), s));
+  // (the short pivots' kernel on a second stream beside the long pivots' was measured: the same 23.5 ms, docs/experiments.md R6.8)
   if (t->ntasks[1] > 0)
     hipLaunchKernelGGL((tc_count_bitmap_kernel<512, kTcBits>), dim3(t->ntasks[1]), dim3(512), 0, s, (const int*)t->D, (const int*)t->Dptr,
                        (const int2*)t->P, (const int4*)t->tasks[1], slots);
