@@ -222,6 +222,20 @@ def test_reference_mains_both_driver_paths_and_timing_lines(rmat_mtx, exe, args,
             assert a[3] == b[3], (a, b)           # pr: the fused loop always pulls; the printed mode is lastmxv_
 
 
+def test_reference_gtc_main_three_ways(rmat_mtx):
+    """example/gtc.cu, unchanged, on RMAT-15: through the shadow of algorithm/tc.hpp with the library counting on the
+    degree-ordered orientation (no product in the buffer matrix), with GRB_TC_PRODUCT=1 (the reference's two calls inside
+    the library) and with GRB_FRONTEND_FUSED=0 (the reference's own text, op by op) -- CORRECT against the reference's CPU
+    count each time, and the one line tc.hpp prints under --timing 1 each time."""
+    import re
+    for env in ({}, {"GRB_TC_PRODUCT": "1"}, {"GRB_FRONTEND_FUSED": "0"}):
+        out = _run_env("gtc_ref", env, "--niter", "1", "--timing", "1", rmat_mtx)
+        assert "INCORRECT" not in out, (env, out[-1500:])
+        assert out.count("CORRECT") >= 1, (env, out[-1500:])
+        rows = [ln for ln in out.splitlines() if re.match(r"^0, 1/\d+, (push|pull), [-+0-9.e]+$", ln.strip())]
+        assert len(rows) >= 2, (env, out[-1500:])          # the warm-up call and the timed one
+
+
 def test_reference_gbfs_main_at_scale_is_the_fast_path(tmp_path):
     """example/gbfs.cu, unchanged, on RMAT-20 (n = 1 Mi, ~31 M edges) handed over through the reference's own
     binary cache (a .mtx stub with banner + size line next to `.stub.mtx.ud.nosl.bin`, which readMtx finds

@@ -168,6 +168,17 @@ for W in ALL_W:
                           for k, v in ow.items() if "spgemm_" in k or "fill_value_kernel" in k)
                 workloads[W]["groups"] = {"masked_spgemm_call": {"hbm_bytes_per_unit": int(tot / ncall), "units": ncall,
                                                                  "what": "every spgemm_* kernel + fill_value_kernel, per mxm call"}}
+            # one count without the product = one tc_total_kernel launch + the counting kernels (the preparation's
+            # kernels run once per matrix and are not in the sum)
+            calls = [v for k, v in ow.items() if "tc_total_kernel" in k]
+            ncall = min(calls[0].get("launches_FETCH_SIZE", 0), calls[0].get("launches_WRITE_SIZE", 0)) if calls else 0
+            if ncall > 0:
+                tot = sum(1024.0 * (2 * v.get("FETCH_SIZE_KB_mean", 0) * v.get("launches_FETCH_SIZE", 0)
+                                    + v.get("WRITE_SIZE_KB_mean", 0) * v.get("launches_WRITE_SIZE", 0))
+                          for k, v in ow.items() if "tc_count_" in k or "tc_total_kernel" in k)
+                workloads[W].setdefault("groups", {})["tc_count_call"] = {
+                    "hbm_bytes_per_unit": int(tot / ncall), "units": ncall,
+                    "what": "tc_count_bitmap_kernel + tc_count_pivot_kernel + tc_total_kernel, per grb_tc call on a prepared matrix"}
 if lines:
     open(dst + '/other_workloads.jsonl', 'w').write("\n".join(lines) + "\n")
 doc = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, each with --kernel-trace only) over "

@@ -1,0 +1,25 @@
+import os, sys, torch
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+from graphblast_amd.graphgen import rmat_edges, finalize_edges
+dev = torch.device("cuda", 0)
+s, d, n = rmat_edges(22, 28, seed=6, device=dev)
+gr = finalize_edges(s, d, n, symmetrize=True)
+ptr, ind = gr["csr"]
+deg = (ptr[1:] - ptr[:-1]).to(torch.int64)
+rows = torch.repeat_interleave(torch.arange(n, device=dev, dtype=torch.int64), deg)
+cols = ind.to(torch.int64)
+ids = torch.arange(n, device=dev, dtype=torch.int64)
+key = deg * n + (n - 1 - ids)
+number = torch.empty(n, dtype=torch.int64, device=dev)
+number[torch.sort(key, descending=True).indices] = ids
+r2, c2 = number[rows], number[cols]
+up = c2 < r2
+lo, hi = r2[up], c2[up]
+dL = torch.bincount(lo, minlength=n)
+for bits in (14, 15, 16, 17, 18):
+    small = (hi < (1 << bits))
+    c16 = torch.bincount(lo[small], minlength=n)
+    piv_is_lo = dL[hi] <= dL[lo]
+    par = torch.where(piv_is_lo, hi, lo)
+    tot = float(dL[par].sum()); s16 = float(c16[par].sum())
+    print("numbers below 2^%d: %.4f of the list entries, %.4f of the streamed elements" % (bits, float(small.float().mean()), s16 / tot))
