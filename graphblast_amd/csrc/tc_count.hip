@@ -17,6 +17,7 @@
 namespace grb {
 
 constexpr unsigned kTcEmpty = 0xffffffffu;
+constexpr unsigned kTcPad = 0x7fffffffu;       // fills a list up to a multiple of four entries: no vertex has this number
 constexpr int kTcSlots = 1024;               // partial sums (one address would serialise a million atomics)
 #ifndef GRB_TC_SLOTS
 #define GRB_TC_SLOTS 4
@@ -26,48 +27,43 @@ constexpr int kTcSlots = 1024;               // partial sums (one address would 
 #define GRB_TC_DEPTH 2
 #endif
 
+// Every list starts at a multiple of four entries of D and is filled up to one with kTcPad, a number no list holds: a
+// lane's 16 bytes are four entries of ONE list or four to skip, and no entry needs a range check of its own (the kernels
+// are bound by their vector instructions as much as by the stream: 4 cycles of a SIMD per instruction and wave, ~20
+// instructions per element before this).
+//
 // A wave streams the lists of up to 64 partners (lane l holds partner l's {first element, length}): 64 lanes x 16 bytes a
 // step, kDepth steps' loads in flight -- the same partner's next 256 elements or the next partner's first ones, whichever
 // follows -- before the oldest step's elements are looked up: a wave's chain is its look-ups, not its loads.
-// look(x, first, e0, e1): the lane's four elements x[0..4) are elements first .. first + 3 of D; those in [e0, e1) count.
+// look(x): one entry of a partner's list (or kTcPad).
 template <int kDepth, typename F>
 __device__ __forceinline__ void tc_stream_batch(const int* __restrict__ D, const int2 my, const int nb, const int lane, F&& look) {
-  int gi = 0;                                   // the step to issue next: partner gi, elements gk .. gk + 255 of [ge0, ge1)
-  int ge0 = __builtin_amdgcn_readfirstlane(my.x), ge1 = ge0 + __builtin_amdgcn_readfirstlane(my.y);
-  int gk = ge0 & ~3;
-  bool more = nb > 0;
+  // the batch's steps, counted once: the loop below is a counted loop whose control is the scalar unit's alone
+  const int total = (int)wave_sum_u32((unsigned)(my.y + 4 * kWave - 1) / (4u * kWave));
+  int gi = -1, gk = 0, ge1 = 0;                 // the generator: partner gi, the step after the last issued starts at gk (of [.., ge1))
   int4 v[kDepth];
-  int se0[kDepth], se1[kDepth], sk[kDepth];
-  bool live[kDepth];
-  auto issue = [&](int d) {
-    live[d] = more;
-    if (!more) return;
-    se0[d] = ge0; se1[d] = ge1; sk[d] = gk;
-    if (gk + 4 * lane < ge1) v[d] = *reinterpret_cast<const int4*>(D + gk + 4 * lane);
-    gk += 4 * kWave;
+  int se1[kDepth], sk[kDepth];
+  auto issue = [&](int d) {                     // (only called while a step is left: partners have at least one element)
     if (gk >= ge1) {
       ++gi;
-      if (gi < nb) {
-        ge0 = __builtin_amdgcn_readlane(my.x, gi);
-        ge1 = ge0 + __builtin_amdgcn_readlane(my.y, gi);
-        gk = ge0 & ~3;
-      } else {
-        more = false;
-      }
+      gk = __builtin_amdgcn_readlane(my.x, gi);
+      ge1 = gk + __builtin_amdgcn_readlane(my.y, gi);
     }
+    se1[d] = ge1; sk[d] = gk;
+    if (gk + 4 * lane < ge1) v[d] = *reinterpret_cast<const int4*>(D + gk + 4 * lane);
+    gk += 4 * kWave;
   };
 #pragma unroll
-  for (int d = 0; d < kDepth; ++d) issue(d);
-  while (live[0]) {
+  for (int d = 0; d < kDepth; ++d)
+    if (d < total) issue(d);
+  for (int st = 0; st < total; st += kDepth) {
 #pragma unroll
     for (int d = 0; d < kDepth; ++d) {
-      if (!live[d]) break;                      // (steps are issued in slot order: a dead slot ends the batch)
-      const int first = sk[d] + 4 * lane;
-      if (first < se1[d]) {
-        const unsigned x[4] = {(unsigned)v[d].x, (unsigned)v[d].y, (unsigned)v[d].z, (unsigned)v[d].w};
-        look(x, first, se0[d], se1[d]);
+      if (st + d >= total) break;
+      if (sk[d] + 4 * lane < se1[d]) {
+        look((unsigned)v[d].x); look((unsigned)v[d].y); look((unsigned)v[d].z); look((unsigned)v[d].w);
       }
-      issue(d);
+      if (st + d + kDepth < total) issue(d);
     }
   }
 }
@@ -98,6 +94,7 @@ __global__ __launch_bounds__(kThreads) void tc_count_pivot_kernel(const int* __r
   __syncthreads();
   for (int i = tid; i < len; i += kThreads) {
     const unsigned x = (unsigned)D[s + i];
+    if (x == kTcPad) continue;                  // (len counts the list's room: up to three entries of filling)
     unsigned slot = (x * 0x9E3779B1u) >> shift;
     while (atomicCAS(&table[slot], kTcEmpty, x) != kTcEmpty) slot = (slot + 1) & mask;
   }
@@ -108,27 +105,11 @@ __global__ __launch_bounds__(kThreads) void tc_count_pivot_kernel(const int* __r
   while (b < nbatch) {
     const int nb = task.z - b * kWave < kWave ? task.z - b * kWave : kWave;
     const int2 my = lane < nb ? P[task.y + b * kWave + lane] : make_int2(0, 0);
-    tc_stream_batch<GRB_TC_DEPTH>(D, my, nb, lane, [&](const unsigned (&x)[4], int first, int e0, int e1) {
-      unsigned slot[4], tv[4];
-#pragma unroll
-      for (int c = 0; c < 4; ++c) { slot[c] = (x[c] * 0x9E3779B1u) >> shift; tv[c] = table[slot[c]]; }
-      unsigned pend = 0;
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        if (first + c < e0 || first + c >= e1) continue;
-        count += tv[c] == x[c];
-        pend |= (tv[c] != x[c] && tv[c] != kTcEmpty) ? 1u << c : 0u;
-      }
-      while (pend) {                          // the look-ups that met somebody else: all four walk on together
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          if (!(pend >> c & 1u)) continue;
-          slot[c] = (slot[c] + 1) & mask;
-          const unsigned t = table[slot[c]];
-          count += t == x[c];
-          if (t == x[c] || t == kTcEmpty) pend &= ~(1u << c);
-        }
-      }
+    tc_stream_batch<GRB_TC_DEPTH>(D, my, nb, lane, [&](unsigned x) {
+      unsigned slot = (x * 0x9E3779B1u) >> shift;
+      unsigned t = table[slot];
+      while (t != x && t != kTcEmpty) { slot = (slot + 1) & mask; t = table[slot]; }
+      count += t == x;
     });
     if (kWaves > 1) {
       if (lane == 0) b = atomicAdd(&next, 1);
@@ -158,7 +139,7 @@ template <int kThreads, int kBits>
 __global__ __launch_bounds__(kThreads) void tc_count_bitmap_kernel(const int* __restrict__ D, const int* __restrict__ Dptr,
                                                                     const int2* __restrict__ P, const int4* __restrict__ tasks,
                                                                     unsigned long long* total) {
-  __shared__ unsigned bits[kBits / 32];
+  __shared__ unsigned bits[kBits / 32 + 1];
   __shared__ int next;
   __shared__ unsigned part[kThreads / kWave];
   constexpr int kWaves = kThreads / kWave;
@@ -166,28 +147,24 @@ __global__ __launch_bounds__(kThreads) void tc_count_bitmap_kernel(const int* __
   const int4 task = tasks[blockIdx.x];
   const int s = Dptr[task.x], len = Dptr[task.x + 1] - s;
   const int nwords = (task.x + 31) / 32;        // task.x <= kBits
-  for (int i = tid; i < nwords; i += kThreads) bits[i] = 0u;
+  for (int i = tid; i <= nwords; i += kThreads) bits[i] = 0u;     // word nwords stays zero: every number from 32 nwords on looks there
   if (tid == 0) next = kWaves;
   __syncthreads();
   for (int i = tid; i < len; i += kThreads) {
     const unsigned x = (unsigned)D[s + i];
-    atomicOr(&bits[x >> 5], 1u << (x & 31));
+    if (x != kTcPad) atomicOr(&bits[x >> 5], 1u << (x & 31));     // (len counts the list's room: up to three entries of filling)
   }
   __syncthreads();
-  const unsigned top = (unsigned)nwords * 32u;  // a streamed number from here on is not in the list
+  const unsigned top = (unsigned)nwords;
   unsigned count = 0;
   const int nbatch = (task.z + kWave - 1) / kWave;
   int b = wave_id();
   while (b < nbatch) {
     const int nb = task.z - b * kWave < kWave ? task.z - b * kWave : kWave;
     const int2 my = lane < nb ? P[task.y + b * kWave + lane] : make_int2(0, 0);
-    tc_stream_batch<GRB_TC_DEPTH>(D, my, nb, lane, [&](const unsigned (&x)[4], int first, int e0, int e1) {
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const bool in = first + c >= e0 && first + c < e1 && x[c] < top;
-        const unsigned w = bits[in ? x[c] >> 5 : 0];
-        count += in ? (w >> (x[c] & 31)) & 1u : 0u;
-      }
+    tc_stream_batch<GRB_TC_DEPTH>(D, my, nb, lane, [&](unsigned x) {
+      const unsigned w = x >> 5;
+      count += (bits[w < top ? w : top] >> (x & 31)) & 1u;
     });
     if (lane == 0) b = atomicAdd(&next, 1);
     b = __builtin_amdgcn_readfirstlane(b);
@@ -255,10 +232,11 @@ __global__ __launch_bounds__(kBlock) void tc_orient_kernel(const int* __restrict
   if (__any(wrong) && lane_id() == 0) atomicOr(bad, 1);
 }
 
-__global__ __launch_bounds__(kBlock) void tc_lengths_kernel(const unsigned* __restrict__ Dptr, Index n, int* __restrict__ len, int* __restrict__ longest) {
+// a list's length, and its room in D: the next multiple of four entries (before the scan that makes the counts positions)
+__global__ __launch_bounds__(kBlock) void tc_lengths_kernel(unsigned* __restrict__ cnt, Index n, int* __restrict__ len, int* __restrict__ longest) {
   const Index v = (Index)blockIdx.x * kBlock + threadIdx.x;
   int l = 0;
-  if (v < n) { l = (int)(Dptr[v + 1] - Dptr[v]); len[v] = l; }
+  if (v < n) { l = (int)cnt[v]; len[v] = l; cnt[v] = (unsigned)(l + 3) & ~3u; }
 #pragma unroll
   for (int off = kWave / 2; off; off >>= 1) { const int o = __shfl_down(l, off); l = o > l ? o : l; }
   if (lane_id() == 0 && l > 0) atomicMax(longest, l);
@@ -416,18 +394,20 @@ static grb_info tc_prepare(grb_matrix_s* A, TcPrep* t) {
   hipLaunchKernelGGL(tc_orient_kernel, dim3(egrid), dim3(kBlock), 0, s, (const int*)erow, (const Index*)A->csr.ind,
                      (const unsigned*)A->csr.val, one, nnz, (const int*)number, elo, ehi, dptr, flags);
   GRB_HIP_TRY(hipGetLastError());
+  hipLaunchKernelGGL(tc_lengths_kernel, dim3(vgrid), dim3(kBlock), 0, s, dptr, n, len, flags + 1);
+  GRB_HIP_TRY(hipGetLastError());
   GRB_TRY(device_exclusive_scan_u32(dptr, (long long)n + 1));
   GRB_TRY(device_exclusive_scan_u32(pptr, (long long)n + 1));
-  hipLaunchKernelGGL(tc_lengths_kernel, dim3(vgrid), dim3(kBlock), 0, s, (const unsigned*)dptr, n, len, flags + 1);
-  GRB_HIP_TRY(hipGetLastError());
   int h_flags[2] = {0, 0};
+  unsigned room = 0;
   GRB_HIP_TRY(hipMemcpyAsync(h_flags, flags, 8, hipMemcpyDeviceToHost, s));
+  GRB_HIP_TRY(hipMemcpyAsync(&room, dptr + n, 4, hipMemcpyDeviceToHost, s));
   GRB_HIP_TRY(hipStreamSynchronize(s));
   if (h_flags[0]) return GRB_SUCCESS;         // not a strictly lower triangle of ones
   t->longest = h_flags[1];
-  GRB_HIP_TRY(hipMalloc((void**)&t->D, 4 * ((size_t)nnz + 8)));
+  GRB_HIP_TRY(hipMalloc((void**)&t->D, 4 * ((size_t)room + 8)));
   GRB_HIP_TRY(hipMalloc((void**)&t->P, 8 * (2 * (size_t)nnz + 1)));          // (a vertex's room: its degree)
-  GRB_HIP_TRY(hipMemsetAsync(t->D + nnz, 0, 32, s));
+  GRB_HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)t->D, (int)kTcPad, (size_t)room + 8, s));
   GRB_HIP_TRY(hipMemcpyAsync(cur, dptr, 4 * (size_t)n, hipMemcpyDeviceToDevice, s));
   GRB_HIP_TRY(hipMemcpyAsync(pcur, pptr, 4 * (size_t)n, hipMemcpyDeviceToDevice, s));
   hipLaunchKernelGGL(tc_lists_kernel, dim3(egrid), dim3(kBlock), 0, s, (const int*)elo, (const int*)ehi, nnz, (const unsigned*)dptr,

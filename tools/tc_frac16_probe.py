@@ -23,3 +23,15 @@ for bits in (14, 15, 16, 17, 18):
     par = torch.where(piv_is_lo, hi, lo)
     tot = float(dL[par].sum()); s16 = float(c16[par].sum())
     print("numbers below 2^%d: %.4f of the list entries, %.4f of the streamed elements" % (bits, float(small.float().mean()), s16 / tot))
+# elements of a partner's list that are not below the pivot's number cannot be in the pivot's list (it holds numbers below
+# the pivot): how much of the stream belongs to pivots numbered below 2^b, and how much of THAT lies below 2^b
+piv_is_lo = dL[hi] <= dL[lo]
+piv = torch.where(piv_is_lo, lo, hi)
+par = torch.where(piv_is_lo, hi, lo)
+tot = float(dL[par].sum())
+for bits in (14, 15, 16, 17, 18):
+    small = (hi < (1 << bits))
+    c16 = torch.bincount(lo[small], minlength=n)
+    sel = piv < (1 << bits)
+    print("pivots numbered below 2^%d: %.4f of the edges, %.4f of the streamed elements (%.4f of the total lies in their partners' parts below 2^%d)"
+          % (bits, float(sel.float().mean()), float(dL[par][sel].sum()) / tot, float(c16[par][sel].sum()) / tot, bits))
