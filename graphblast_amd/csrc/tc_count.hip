@@ -10,8 +10,9 @@
 //
 //     sum over edges {p, q}, p the endpoint with the LONGER list, of | list(p) ^ list(q) |
 //
-// with list(p) in an LDS hash table of the workgroup that owns the pivot p and the lists of p's partners streamed past it
-// a wave to a list, 16 bytes per lane per step.
+// with list(p) as an LDS bitmap (the vertices are numbered by rank: list(p) holds numbers below p) or hash table of the
+// workgroup that owns the pivot p, and the lists of p's partners streamed past it a wave to a list, 16 bytes per lane per
+// step.  DESIGN.md 5.4a; docs/experiments.md R6.8 for how it got here.
 #include "common.hpp"
 
 namespace grb {
@@ -27,31 +28,43 @@ constexpr int kTcSlots = 1024;               // partial sums (one address would 
 #define GRB_TC_DEPTH 2
 #endif
 
-// Every list starts at a multiple of four entries of D and is filled up to one with kTcPad, a number no list holds: a
-// lane's 16 bytes are four entries of ONE list or four to skip, and no entry needs a range check of its own (the kernels
-// are bound by their vector instructions as much as by the stream: 4 cycles of a SIMD per instruction and wave, ~20
-// instructions per element before this).
+// A list is kept in two parts: the numbers below 65 535 as 16-bit entries of D16, the others as 32-bit entries of D32
+// (no vertex is numbered 65 535: the 16-bit code is the filling).  The numbering is by rank, so a list is mostly hubs:
+// 86 % of the entries of the bench's graph are below 2^16.  And a list holds numbers BELOW its owner's: a pivot
+// numbered below 65 536 has nothing to find in the 32-bit part of a partner, and does not stream it -- those pivots
+// carry 93 % of the streamed elements, so nine tenths of the stream is two bytes an element, 512 elements a step.
+// Every part starts at a multiple of 16 bytes and is filled up to one (0xffff / kTcPad, numbers no list holds): a
+// lane's 16 bytes are entries of ONE part or nothing, and no entry needs a range check of its own -- the kernels are
+// bound by their vector instructions (4 cycles of a SIMD per instruction and wave) as much as by the stream.
 //
-// A wave streams the lists of up to 64 partners (lane l holds partner l's {first element, length}): 64 lanes x 16 bytes a
-// step, kDepth steps' loads in flight -- the same partner's next 256 elements or the next partner's first ones, whichever
-// follows -- before the oldest step's elements are looked up: a wave's chain is its look-ups, not its loads.
-// look(x): one entry of a partner's list (or kTcPad).
-template <int kDepth, typename F>
-__device__ __forceinline__ void tc_stream_batch(const int* __restrict__ D, const int2 my, const int nb, const int lane, F&& look) {
-  // the batch's steps, counted once: the loop below is a counted loop whose control is the scalar unit's alone
-  const int total = (int)wave_sum_u32((unsigned)(my.y + 4 * kWave - 1) / (4u * kWave));
-  int gi = -1, gk = 0, ge1 = 0;                 // the generator: partner gi, the step after the last issued starts at gk (of [.., ge1))
+// A wave streams the lists of up to 64 partners (lane l holds partner l's {first 16-bit entry, entries, first 32-bit
+// entry, entries}): 64 lanes x 16 bytes a step, kDepth steps' loads in flight -- the same part's next bytes, the
+// partner's other part or the next partner's first bytes, whichever follows -- before the oldest step's elements are
+// looked up.  The batch's steps are counted first: the loop is a counted loop whose control is the scalar unit's alone.
+// pair(w): two 16-bit entries of a partner's list (or fillings) as they lie in a 32-bit word; look(x): one 32-bit entry.
+// wide: the 32-bit parts are streamed too (wave-uniform).
+template <int kDepth, typename F2, typename F>
+__device__ __forceinline__ void tc_stream_batch(const unsigned short* __restrict__ D16, const int* __restrict__ D32, const int4 my,
+                                                const bool wide, const int lane, F2&& pair, F&& look) {
+  const unsigned mine = ((unsigned)my.y + 8 * kWave - 1) / (8u * kWave) + (wide ? ((unsigned)my.w + 4 * kWave - 1) / (4u * kWave) : 0u);
+  const int total = (int)wave_sum_u32(mine);
+  int gi = -1, gs = 1, gk = 0, ge1 = 0;         // the generator: partner gi, part gs (0: 16-bit), the next step starts at gk (of [.., ge1))
   int4 v[kDepth];
-  int se1[kDepth], sk[kDepth];
-  auto issue = [&](int d) {                     // (only called while a step is left: partners have at least one element)
-    if (gk >= ge1) {
-      ++gi;
-      gk = __builtin_amdgcn_readlane(my.x, gi);
-      ge1 = gk + __builtin_amdgcn_readlane(my.y, gi);
+  int se1[kDepth], sk[kDepth], sw[kDepth];
+  auto issue = [&](int d) {                     // (only called while a step is left)
+    while (gk >= ge1) {                         // the next part that holds anything
+      if (gs == 0 && wide) { gs = 1; } else { gs = 0; ++gi; }
+      gk = __builtin_amdgcn_readlane(gs ? my.z : my.x, gi);
+      ge1 = gk + __builtin_amdgcn_readlane(gs ? my.w : my.y, gi);
     }
-    se1[d] = ge1; sk[d] = gk;
-    if (gk + 4 * lane < ge1) v[d] = *reinterpret_cast<const int4*>(D + gk + 4 * lane);
-    gk += 4 * kWave;
+    se1[d] = ge1; sk[d] = gk; sw[d] = gs;
+    if (gs) {
+      if (gk + 4 * lane < ge1) v[d] = *reinterpret_cast<const int4*>(D32 + gk + 4 * lane);
+      gk += 4 * kWave;
+    } else {
+      if (gk + 8 * lane < ge1) v[d] = *reinterpret_cast<const int4*>(D16 + gk + 8 * lane);
+      gk += 8 * kWave;
+    }
   };
 #pragma unroll
   for (int d = 0; d < kDepth; ++d)
@@ -60,62 +73,82 @@ __device__ __forceinline__ void tc_stream_batch(const int* __restrict__ D, const
 #pragma unroll
     for (int d = 0; d < kDepth; ++d) {
       if (st + d >= total) break;
-      if (sk[d] + 4 * lane < se1[d]) {
-        look((unsigned)v[d].x); look((unsigned)v[d].y); look((unsigned)v[d].z); look((unsigned)v[d].w);
+      const unsigned w[4] = {(unsigned)v[d].x, (unsigned)v[d].y, (unsigned)v[d].z, (unsigned)v[d].w};
+      if (sw[d]) {
+        if (sk[d] + 4 * lane < se1[d]) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) look(w[c]);
+        }
+      } else {
+        if (sk[d] + 8 * lane < se1[d]) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) pair(w[c]);
+        }
       }
       if (st + d + kDepth < total) issue(d);
     }
   }
 }
 
+// the numbers of a pivot's own list, one by one (both parts, fillings skipped)
+template <int kThreads, typename F>
+__device__ __forceinline__ void tc_own_list(const unsigned short* __restrict__ D16, const int* __restrict__ D32, const int4 own, const int tid, F&& put) {
+  for (int i = tid; i < own.y; i += kThreads) put((unsigned)D16[own.x + i]);
+  for (int i = tid; i < own.w; i += kThreads) put((unsigned)D32[own.z + i]);
+}
+
 // One task = a pivot and up to a few hundred of its partners: {pivot, first partner, partners, -}.  A pivot with many
 // partners is cut into tasks that each build the table again (<= 2 len LDS operations against thousands of streamed
-// elements).  A WAVE streams a partner: 64 lanes x 16 bytes a step, the load of the following step -- the same partner's
-// or the next one's, the 64 partner descriptors of a batch sit in the lanes' registers -- issued before this step's
-// elements are looked up, so a wave's chain is its look-ups, not its loads.
+// elements).  The waves of a workgroup draw batches of 64 partners from an LDS counter.
 template <int kThreads, int kTable>
-__global__ __launch_bounds__(kThreads) void tc_count_pivot_kernel(const int* __restrict__ D, const int* __restrict__ Dptr,
-                                                                   const int2* __restrict__ P, const int4* __restrict__ tasks,
-                                                                   unsigned long long* total) {
+__global__ __launch_bounds__(kThreads) void tc_count_pivot_kernel(const unsigned short* __restrict__ D16, const int* __restrict__ D32,
+                                                                   const int4* __restrict__ lists, const int4* __restrict__ P,
+                                                                   const int4* __restrict__ tasks, int ntasks, unsigned long long* total) {
   __shared__ unsigned table[kTable];
   __shared__ int next;
   __shared__ unsigned part[kThreads / kWave];
   constexpr int kWaves = kThreads / kWave;
   const int tid = threadIdx.x, lane = lane_id();
-  const int4 task = tasks[blockIdx.x];
-  const int s = Dptr[task.x], len = Dptr[task.x + 1] - s;
-  int need = len * GRB_TC_SLOTS - 1 > 63 ? len * GRB_TC_SLOTS - 1 : 63;
-  if (need > kTable - 1) need = kTable - 1;
-  const int lg = 32 - __clz(need);             // a table of 2^lg >= 4 len slots (2 len for the longest lists), at least 64
-  const unsigned mask = (1u << lg) - 1u;
-  const int shift = 32 - lg;
-  for (unsigned i = tid; i <= mask; i += kThreads) table[i] = kTcEmpty;
-  if (tid == 0) next = kWaves;
-  __syncthreads();
-  for (int i = tid; i < len; i += kThreads) {
-    const unsigned x = (unsigned)D[s + i];
-    if (x == kTcPad) continue;                  // (len counts the list's room: up to three entries of filling)
-    unsigned slot = (x * 0x9E3779B1u) >> shift;
-    while (atomicCAS(&table[slot], kTcEmpty, x) != kTcEmpty) slot = (slot + 1) & mask;
-  }
-  __syncthreads();
   unsigned count = 0;
-  const int nbatch = (task.z + kWave - 1) / kWave;
-  int b = kWaves > 1 ? wave_id() : 0;
-  while (b < nbatch) {
-    const int nb = task.z - b * kWave < kWave ? task.z - b * kWave : kWave;
-    const int2 my = lane < nb ? P[task.y + b * kWave + lane] : make_int2(0, 0);
-    tc_stream_batch<GRB_TC_DEPTH>(D, my, nb, lane, [&](unsigned x) {
+  // (GRB_TC_WAVE_GRID: the one-wave instance with fewer workgroups than tasks -- measured, no gain: 8 192 workgroups 17.9 ms
+  // per count, 65 536 16.7, one per task 16.6)
+  for (int ti = blockIdx.x; ti < ntasks; ti += gridDim.x) {
+    const int4 task = tasks[ti];
+    const int4 own = lists[task.x];
+    const int len = own.y + own.w;
+    int need = len * GRB_TC_SLOTS - 1 > 63 ? len * GRB_TC_SLOTS - 1 : 63;
+    if (need > kTable - 1) need = kTable - 1;
+    const int lg = 32 - __clz(need);           // a table of 2^lg >= 4 len slots (2 len for the longest lists), at least 64
+    const unsigned mask = (1u << lg) - 1u;
+    const int shift = 32 - lg;
+    if (kWaves > 1) __syncthreads();
+    for (unsigned i = tid; i <= mask; i += kThreads) table[i] = kTcEmpty;
+    if (tid == 0) next = kWaves;
+    __syncthreads();
+    tc_own_list<kThreads>(D16, D32, own, tid, [&](unsigned x) {
       unsigned slot = (x * 0x9E3779B1u) >> shift;
-      unsigned t = table[slot];
-      while (t != x && t != kTcEmpty) { slot = (slot + 1) & mask; t = table[slot]; }
-      count += t == x;
+      while (atomicCAS(&table[slot], kTcEmpty, x) != kTcEmpty) slot = (slot + 1) & mask;
     });
-    if (kWaves > 1) {
-      if (lane == 0) b = atomicAdd(&next, 1);
-      b = __builtin_amdgcn_readfirstlane(b);
-    } else {
-      ++b;
+    __syncthreads();
+    const bool wide = task.x > 65536;           // the pivot's list reaches beyond the 16-bit numbers
+    const int nbatch = (task.z + kWave - 1) / kWave;
+    int b = kWaves > 1 ? wave_id() : 0;
+    while (b < nbatch) {
+      const int nb = task.z - b * kWave < kWave ? task.z - b * kWave : kWave;
+      const int4 my = lane < nb ? P[task.y + b * kWave + lane] : make_int4(0, 0, 0, 0);
+      auto look = [&](unsigned x) {
+        unsigned slot = (x * 0x9E3779B1u) >> shift;
+        unsigned t = table[slot];
+        while (t != x && t != kTcEmpty) { slot = (slot + 1) & mask; t = table[slot]; }
+        count += t == x;
+      };
+      tc_stream_batch<GRB_TC_DEPTH>(D16, D32, my, wide, lane, [&](unsigned w) { look(w & 0xffffu); look(w >> 16); }, look);
+      if (kWaves > 1) {
+        if (lane == 0) b = atomicAdd(&next, 1);
+        b = __builtin_amdgcn_readfirstlane(b);
+      } else {
+        ++b;
+      }
     }
   }
 #pragma unroll
@@ -136,36 +169,43 @@ __global__ __launch_bounds__(kThreads) void tc_count_pivot_kernel(const int* __r
 // The pivots numbered up to kBits (vertices are NUMBERED BY RANK, 0 = the highest degree, so list(p) holds numbers below
 // p): the pivot's list is a BITMAP of p bits -- one LDS read and a bit test per streamed element, no hashing, no walk.
 template <int kThreads, int kBits>
-__global__ __launch_bounds__(kThreads) void tc_count_bitmap_kernel(const int* __restrict__ D, const int* __restrict__ Dptr,
-                                                                    const int2* __restrict__ P, const int4* __restrict__ tasks,
-                                                                    unsigned long long* total) {
+__global__ __launch_bounds__(kThreads) void tc_count_bitmap_kernel(const unsigned short* __restrict__ D16, const int* __restrict__ D32,
+                                                                    const int4* __restrict__ lists, const int4* __restrict__ P,
+                                                                    const int4* __restrict__ tasks, unsigned long long* total) {
   __shared__ unsigned bits[kBits / 32 + 1];
   __shared__ int next;
   __shared__ unsigned part[kThreads / kWave];
   constexpr int kWaves = kThreads / kWave;
   const int tid = threadIdx.x, lane = lane_id();
   const int4 task = tasks[blockIdx.x];
-  const int s = Dptr[task.x], len = Dptr[task.x + 1] - s;
-  const int nwords = (task.x + 31) / 32;        // task.x <= kBits
-  for (int i = tid; i <= nwords; i += kThreads) bits[i] = 0u;     // word nwords stays zero: every number from 32 nwords on looks there
+  const int4 own = lists[task.x];
+  // the bitmap: task.x bits (task.x <= kBits) and never fewer than 65 536 -- a 16-bit entry is looked up without a bound
+  // check -- and one word more that stays zero: every 32-bit entry from 32 nwords on looks there
+  const int nwords = task.x > 65536 ? (task.x + 31) / 32 : 2048;
+  for (int i = tid; i <= nwords; i += kThreads) bits[i] = 0u;
   if (tid == 0) next = kWaves;
   __syncthreads();
-  for (int i = tid; i < len; i += kThreads) {
-    const unsigned x = (unsigned)D[s + i];
-    if (x != kTcPad) atomicOr(&bits[x >> 5], 1u << (x & 31));     // (len counts the list's room: up to three entries of filling)
-  }
+  tc_own_list<kThreads>(D16, D32, own, tid, [&](unsigned x) { atomicOr(&bits[x >> 5], 1u << (x & 31)); });
   __syncthreads();
   const unsigned top = (unsigned)nwords;
+  const bool wide = task.x > 65536;
   unsigned count = 0;
   const int nbatch = (task.z + kWave - 1) / kWave;
   int b = wave_id();
   while (b < nbatch) {
     const int nb = task.z - b * kWave < kWave ? task.z - b * kWave : kWave;
-    const int2 my = lane < nb ? P[task.y + b * kWave + lane] : make_int2(0, 0);
-    tc_stream_batch<GRB_TC_DEPTH>(D, my, nb, lane, [&](unsigned x) {
-      const unsigned w = x >> 5;
-      count += (bits[w < top ? w : top] >> (x & 31)) & 1u;
-    });
+    const int4 my = lane < nb ? P[task.y + b * kWave + lane] : make_int4(0, 0, 0, 0);
+    // (the fillings: bit 65 535 is nobody's, kTcPad looks at word `top`; v_bfe_u32 takes the low five bits of its offset)
+    tc_stream_batch<GRB_TC_DEPTH>(D16, D32, my, wide, lane,
+      [&](unsigned w) {
+        const unsigned lo = *reinterpret_cast<const unsigned*>(reinterpret_cast<const char*>(bits) + ((w >> 3) & 0x1ffcu));
+        const unsigned hi = *reinterpret_cast<const unsigned*>(reinterpret_cast<const char*>(bits) + ((w >> 19) & 0x1ffcu));
+        count += __builtin_amdgcn_ubfe(lo, w, 1u) + __builtin_amdgcn_ubfe(hi, w >> 16, 1u);
+      },
+      [&](unsigned x) {
+        const unsigned w = x >> 5;
+        count += __builtin_amdgcn_ubfe(bits[w < top ? w : top], x, 1u);
+      });
     if (lane == 0) b = atomicAdd(&next, 1);
     b = __builtin_amdgcn_readfirstlane(b);
   }
@@ -206,19 +246,24 @@ __global__ __launch_bounds__(kBlock) void tc_degree_kernel(const Index* __restri
   pay[v] = (unsigned)v;
 }
 
-// (pbase: the degree of the vertex numbered r -- room for its partners, whoever they turn out to be; scanned afterwards)
+// The number of the vertex of rank r: r, but nobody is numbered 65 535 (the 16-bit parts' filling).
+// (pbase: the degree of the vertex of a number -- room for its partners, whoever they turn out to be; scanned afterwards)
 __global__ __launch_bounds__(kBlock) void tc_number_kernel(const unsigned* __restrict__ order, const unsigned long long* __restrict__ key,
                                                            Index n, int* __restrict__ number, unsigned* __restrict__ pbase) {
   const Index r = (Index)blockIdx.x * kBlock + threadIdx.x;
-  if (r < n) { number[order[r]] = (int)r; pbase[r] = 0xffffffffu - (unsigned)key[r]; }
+  if (r >= n) return;
+  const int num = (int)r + (r >= 65535 ? 1 : 0);
+  number[order[r]] = num;
+  pbase[num] = 0xffffffffu - (unsigned)key[r];
 }
 
-// pass A: every entry (i, j) as {lower-ranked end, higher-ranked end} in the new numbers; the lower end's list grows by one.
+// pass A: every entry (i, j) as {lower-ranked end, higher-ranked end} in the new numbers; the lower end's list grows by one
+// -- its 16-bit part or its 32-bit part.
 // bad: an entry on or above the diagonal, or a value that is not 1 -- the sum of the product is then not a count
 __global__ __launch_bounds__(kBlock) void tc_orient_kernel(const int* __restrict__ erow, const Index* __restrict__ ind,
                                                            const unsigned* __restrict__ val, unsigned one, long long nnz,
                                                            const int* __restrict__ number, int* __restrict__ elo, int* __restrict__ ehi,
-                                                           unsigned* __restrict__ cnt, int* __restrict__ bad) {
+                                                           unsigned* __restrict__ c16, unsigned* __restrict__ c32, int* __restrict__ bad) {
   const long long stride = (long long)gridDim.x * kBlock;
   bool wrong = false;
   for (long long e = (long long)blockIdx.x * kBlock + threadIdx.x; e < nnz; e += stride) {
@@ -227,19 +272,34 @@ __global__ __launch_bounds__(kBlock) void tc_orient_kernel(const int* __restrict
     const int a = number[i], b = number[j];
     const int lo = a > b ? a : b, hi = a > b ? b : a;
     elo[e] = lo; ehi[e] = hi;
-    atomicAdd(&cnt[lo], 1u);
+    atomicAdd(hi < 65535 ? &c16[lo] : &c32[lo], 1u);
   }
   if (__any(wrong) && lane_id() == 0) atomicOr(bad, 1);
 }
 
-// a list's length, and its room in D: the next multiple of four entries (before the scan that makes the counts positions)
-__global__ __launch_bounds__(kBlock) void tc_lengths_kernel(unsigned* __restrict__ cnt, Index n, int* __restrict__ len, int* __restrict__ longest) {
+// the two parts' lengths of every list, and their rooms: the next multiple of 16 bytes (before the scans that make the
+// rooms positions)
+__global__ __launch_bounds__(kBlock) void tc_lengths_kernel(unsigned* __restrict__ c16, unsigned* __restrict__ c32, Index nn,
+                                                            int* __restrict__ len16, int* __restrict__ len32, int* __restrict__ len,
+                                                            int* __restrict__ longest) {
   const Index v = (Index)blockIdx.x * kBlock + threadIdx.x;
   int l = 0;
-  if (v < n) { l = (int)cnt[v]; len[v] = l; cnt[v] = (unsigned)(l + 3) & ~3u; }
+  if (v < nn) {
+    const int a = (int)c16[v], b = (int)c32[v];
+    len16[v] = a; len32[v] = b; l = a + b; len[v] = l;
+    c16[v] = (unsigned)(a + 7) & ~7u;
+    c32[v] = (unsigned)(b + 3) & ~3u;
+  }
 #pragma unroll
   for (int off = kWave / 2; off; off >>= 1) { const int o = __shfl_down(l, off); l = o > l ? o : l; }
   if (lane_id() == 0 && l > 0) atomicMax(longest, l);
+}
+
+__global__ __launch_bounds__(kBlock) void tc_describe_kernel(const unsigned* __restrict__ ptr16, const unsigned* __restrict__ ptr32,
+                                                             const int* __restrict__ len16, const int* __restrict__ len32, Index nn,
+                                                             int4* __restrict__ lists) {
+  const Index v = (Index)blockIdx.x * kBlock + threadIdx.x;
+  if (v < nn) lists[v] = make_int4((int)ptr16[v], len16[v], (int)ptr32[v], len32[v]);
 }
 
 // who intersects an edge: the end with the longer list streams nothing, it is the PIVOT (the lower-ranked end on a tie);
@@ -253,19 +313,21 @@ __device__ __forceinline__ void tc_roles(int lo, int hi, const int* __restrict__
 }
 
 // pass B: the lists themselves (in whatever order the atomics hand out: they are looked up, never merged) and every
-// pivot's partners as {first element of the list in D, length}, in the room its degree reserves (dcur / pcur start as
-// copies of Dptr / pbase: the atomics hand out absolute positions)
+// pivot's partners -- their lists' descriptors -- in the room its degree reserves (cur16 / cur32 / pcur start as copies of
+// the position arrays: the atomics hand out absolute positions)
 __global__ __launch_bounds__(kBlock) void tc_lists_kernel(const int* __restrict__ elo, const int* __restrict__ ehi, long long nnz,
-                                                          const unsigned* __restrict__ Dptr, const int* __restrict__ len,
-                                                          unsigned* __restrict__ dcur, int* __restrict__ D,
-                                                          unsigned* __restrict__ pcur, int2* __restrict__ P) {
+                                                          const int4* __restrict__ lists, const int* __restrict__ len,
+                                                          unsigned* __restrict__ cur16, unsigned* __restrict__ cur32,
+                                                          unsigned short* __restrict__ D16, int* __restrict__ D32,
+                                                          unsigned* __restrict__ pcur, int4* __restrict__ P) {
   const long long stride = (long long)gridDim.x * kBlock;
   for (long long e = (long long)blockIdx.x * kBlock + threadIdx.x; e < nnz; e += stride) {
     const int lo = elo[e], hi = ehi[e];
-    D[atomicAdd(&dcur[lo], 1u)] = hi;
+    if (hi < 65535) D16[atomicAdd(&cur16[lo], 1u)] = (unsigned short)hi;
+    else D32[atomicAdd(&cur32[lo], 1u)] = hi;
     int pivot, partner, plen;
     tc_roles(lo, hi, len, &pivot, &partner, &plen);
-    if (plen > 0) P[atomicAdd(&pcur[pivot], 1u)] = make_int2((int)Dptr[partner], plen);
+    if (plen > 0) P[atomicAdd(&pcur[pivot], 1u)] = lists[partner];
   }
 }
 
@@ -319,14 +381,19 @@ __global__ __launch_bounds__(kTcSlots) void tc_total_kernel(unsigned long long* 
 
 struct TcPrep {
   int state = 0;                              // 0 not tried, 1 ready, -1 the sum of this matrix's product is not such a count
-  int* D = nullptr;                           // the lists, end to end (+ 8 entries: a step reads whole 16-byte groups)
-  int* Dptr = nullptr;                        // [n + 1]
-  int2* P = nullptr;                          // the partners, pivot by pivot
+  unsigned short* D16 = nullptr;              // the lists' numbers below 65 535, part by part (+ 16 entries: a step reads whole 16-byte groups)
+  int* D32 = nullptr;                         // ... and the others (+ 8)
+  int4* lists = nullptr;                      // [n + 1] by number: {first entry in D16, entries, first entry in D32, entries}
+  int4* P = nullptr;                          // the partners' lists (copies of their descriptors), pivot by pivot
   int4* tasks[3] = {nullptr, nullptr, nullptr};
   int ntasks[3] = {0, 0, 0};
   int longest = 0;
   float prep_ms = 0.f;
 };
+static void tc_prep_release(TcPrep* t) {
+  for (void** q : {(void**)&t->D16, (void**)&t->D32, (void**)&t->lists, (void**)&t->P, (void**)&t->tasks[0], (void**)&t->tasks[1], (void**)&t->tasks[2]})
+    if (*q) { (void)hipFree(*q); *q = nullptr; }
+}
 
 static int g_tc_product = -1;                 // grb_tc_set_product
 static struct { int path; float prep_ms, count_ms; int longest; int ntasks[3]; } g_tc_last = {0, 0.f, 0.f, 0, {0, 0, 0}};
@@ -334,8 +401,7 @@ static struct { int path; float prep_ms, count_ms; int longest; int ntasks[3]; }
 void tc_prep_free(grb_matrix_s* A) {
   TcPrep* t = (TcPrep*)A->tc_prep;
   if (!t) return;
-  for (void* q : {(void*)t->D, (void*)t->Dptr, (void*)t->P, (void*)t->tasks[0], (void*)t->tasks[1], (void*)t->tasks[2]})
-    if (q) (void)hipFree(q);
+  tc_prep_release(t);
   delete t;
   A->tc_prep = nullptr;
 }
@@ -356,74 +422,87 @@ struct TcTemps {
 static grb_info tc_prepare(grb_matrix_s* A, TcPrep* t) {
   hipStream_t s = ctx().stream;
   const Index n = A->nrows;
+  const Index nn = n + 1;                     // numbers: 0 .. n, 65 535 left out
   const long long nnz = A->nvals;
   t->state = -1;
   if (A->csc_alias || !A->csc.ptr || !A->csr.val || n != A->ncols || nnz < 1 || nnz > 0x7ffffff0ll) return GRB_SUCCESS;
   TcTemps tmp;
-  int *erow, *number, *elo, *ehi, *len, *flags;
+  int *erow, *number, *elo, *ehi, *len, *len16, *len32, *flags;
   unsigned long long* key;
-  unsigned *order, *cur, *pptr, *pcur, *c0, *c1, *c2;
+  unsigned *order, *ptr16, *ptr32, *cur16, *cur32, *pptr, *pcur, *c0, *c1, *c2;
   GRB_TRY(tmp.get(&erow, (size_t)nnz));
   GRB_TRY(tmp.get(&elo, (size_t)nnz));
   GRB_TRY(tmp.get(&ehi, (size_t)nnz));
   GRB_TRY(tmp.get(&number, (size_t)n));
-  GRB_TRY(tmp.get(&len, (size_t)n));
+  GRB_TRY(tmp.get(&len, (size_t)nn));
+  GRB_TRY(tmp.get(&len16, (size_t)nn));
+  GRB_TRY(tmp.get(&len32, (size_t)nn));
   GRB_TRY(tmp.get(&key, (size_t)n));
   GRB_TRY(tmp.get(&order, (size_t)n));
-  GRB_TRY(tmp.get(&cur, (size_t)n));
-  GRB_TRY(tmp.get(&pptr, (size_t)n + 1));
-  GRB_TRY(tmp.get(&pcur, (size_t)n));
-  GRB_TRY(tmp.get(&c0, (size_t)n + 1));
-  GRB_TRY(tmp.get(&c1, (size_t)n + 1));
-  GRB_TRY(tmp.get(&c2, (size_t)n + 1));
+  GRB_TRY(tmp.get(&ptr16, (size_t)nn + 1));
+  GRB_TRY(tmp.get(&ptr32, (size_t)nn + 1));
+  GRB_TRY(tmp.get(&cur16, (size_t)nn));
+  GRB_TRY(tmp.get(&cur32, (size_t)nn));
+  GRB_TRY(tmp.get(&pptr, (size_t)nn + 1));
+  GRB_TRY(tmp.get(&pcur, (size_t)nn));
+  GRB_TRY(tmp.get(&c0, (size_t)nn + 1));
+  GRB_TRY(tmp.get(&c1, (size_t)nn + 1));
+  GRB_TRY(tmp.get(&c2, (size_t)nn + 1));
   GRB_TRY(tmp.get(&flags, 2));                // {bad, longest list}
-  GRB_HIP_TRY(hipMalloc((void**)&t->Dptr, 4 * ((size_t)n + 1)));
-  unsigned* const dptr = (unsigned*)t->Dptr;
-  const int vgrid = (int)((n + kBlock - 1) / kBlock), egrid = stream_grid(nnz, kBlock * 4);
+  GRB_HIP_TRY(hipMalloc((void**)&t->lists, 16 * (size_t)nn));
+  const int vgrid = (int)((n + kBlock - 1) / kBlock), ngrid = (int)((nn + kBlock - 1) / kBlock), egrid = stream_grid(nnz, kBlock * 4);
   // the numbering: by degree, the highest first, ties by the caller's number (the sort is stable)
   hipLaunchKernelGGL(tc_degree_kernel, dim3(vgrid), dim3(kBlock), 0, s, (const Index*)A->csr.ptr, (const Index*)A->csc.ptr, n, key, order);
   GRB_HIP_TRY(hipGetLastError());
   GRB_TRY(device_sort_pairs(key, order, n, 32, 0));
-  GRB_HIP_TRY(hipMemsetAsync(pptr + n, 0, 4, s));
+  GRB_HIP_TRY(hipMemsetAsync(pptr, 0, 4 * ((size_t)nn + 1), s));
   hipLaunchKernelGGL(tc_number_kernel, dim3(vgrid), dim3(kBlock), 0, s, (const unsigned*)order, (const unsigned long long*)key, n, number, pptr);
   hipLaunchKernelGGL(tc_rows_kernel, dim3(stream_grid((long long)n * 16, kBlock)), dim3(kBlock), 0, s, (const Index*)A->csr.ptr, n, erow);
   GRB_HIP_TRY(hipGetLastError());
-  GRB_HIP_TRY(hipMemsetAsync(dptr, 0, 4 * ((size_t)n + 1), s));
+  GRB_HIP_TRY(hipMemsetAsync(ptr16, 0, 4 * ((size_t)nn + 1), s));
+  GRB_HIP_TRY(hipMemsetAsync(ptr32, 0, 4 * ((size_t)nn + 1), s));
   GRB_HIP_TRY(hipMemsetAsync(flags, 0, 8, s));
   const unsigned one = A->dtype == GRB_F32 ? 0x3f800000u : 1u;
   hipLaunchKernelGGL(tc_orient_kernel, dim3(egrid), dim3(kBlock), 0, s, (const int*)erow, (const Index*)A->csr.ind,
-                     (const unsigned*)A->csr.val, one, nnz, (const int*)number, elo, ehi, dptr, flags);
+                     (const unsigned*)A->csr.val, one, nnz, (const int*)number, elo, ehi, ptr16, ptr32, flags);
+  hipLaunchKernelGGL(tc_lengths_kernel, dim3(ngrid), dim3(kBlock), 0, s, ptr16, ptr32, nn, len16, len32, len, flags + 1);
   GRB_HIP_TRY(hipGetLastError());
-  hipLaunchKernelGGL(tc_lengths_kernel, dim3(vgrid), dim3(kBlock), 0, s, dptr, n, len, flags + 1);
+  GRB_TRY(device_exclusive_scan_u32(ptr16, (long long)nn + 1));
+  GRB_TRY(device_exclusive_scan_u32(ptr32, (long long)nn + 1));
+  GRB_TRY(device_exclusive_scan_u32(pptr, (long long)nn + 1));
+  hipLaunchKernelGGL(tc_describe_kernel, dim3(ngrid), dim3(kBlock), 0, s, (const unsigned*)ptr16, (const unsigned*)ptr32, (const int*)len16,
+                     (const int*)len32, nn, t->lists);
   GRB_HIP_TRY(hipGetLastError());
-  GRB_TRY(device_exclusive_scan_u32(dptr, (long long)n + 1));
-  GRB_TRY(device_exclusive_scan_u32(pptr, (long long)n + 1));
   int h_flags[2] = {0, 0};
-  unsigned room = 0;
+  unsigned room16 = 0, room32 = 0;
   GRB_HIP_TRY(hipMemcpyAsync(h_flags, flags, 8, hipMemcpyDeviceToHost, s));
-  GRB_HIP_TRY(hipMemcpyAsync(&room, dptr + n, 4, hipMemcpyDeviceToHost, s));
+  GRB_HIP_TRY(hipMemcpyAsync(&room16, ptr16 + nn, 4, hipMemcpyDeviceToHost, s));
+  GRB_HIP_TRY(hipMemcpyAsync(&room32, ptr32 + nn, 4, hipMemcpyDeviceToHost, s));
   GRB_HIP_TRY(hipStreamSynchronize(s));
   if (h_flags[0]) return GRB_SUCCESS;         // not a strictly lower triangle of ones
   t->longest = h_flags[1];
-  GRB_HIP_TRY(hipMalloc((void**)&t->D, 4 * ((size_t)room + 8)));
-  GRB_HIP_TRY(hipMalloc((void**)&t->P, 8 * (2 * (size_t)nnz + 1)));          // (a vertex's room: its degree)
-  GRB_HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)t->D, (int)kTcPad, (size_t)room + 8, s));
-  GRB_HIP_TRY(hipMemcpyAsync(cur, dptr, 4 * (size_t)n, hipMemcpyDeviceToDevice, s));
-  GRB_HIP_TRY(hipMemcpyAsync(pcur, pptr, 4 * (size_t)n, hipMemcpyDeviceToDevice, s));
-  hipLaunchKernelGGL(tc_lists_kernel, dim3(egrid), dim3(kBlock), 0, s, (const int*)elo, (const int*)ehi, nnz, (const unsigned*)dptr,
-                     (const int*)len, cur, t->D, pcur, t->P);
+  GRB_HIP_TRY(hipMalloc((void**)&t->D16, 2 * ((size_t)room16 + 16)));
+  GRB_HIP_TRY(hipMalloc((void**)&t->D32, 4 * ((size_t)room32 + 8)));
+  GRB_HIP_TRY(hipMalloc((void**)&t->P, 16 * (2 * (size_t)nnz + 1)));         // (a vertex's room: its degree)
+  GRB_HIP_TRY(hipMemsetAsync(t->D16, 0xff, 2 * ((size_t)room16 + 16), s));
+  GRB_HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)t->D32, (int)kTcPad, (size_t)room32 + 8, s));
+  GRB_HIP_TRY(hipMemcpyAsync(cur16, ptr16, 4 * (size_t)nn, hipMemcpyDeviceToDevice, s));
+  GRB_HIP_TRY(hipMemcpyAsync(cur32, ptr32, 4 * (size_t)nn, hipMemcpyDeviceToDevice, s));
+  GRB_HIP_TRY(hipMemcpyAsync(pcur, pptr, 4 * (size_t)nn, hipMemcpyDeviceToDevice, s));
+  hipLaunchKernelGGL(tc_lists_kernel, dim3(egrid), dim3(kBlock), 0, s, (const int*)elo, (const int*)ehi, nnz, (const int4*)t->lists,
+                     (const int*)len, cur16, cur32, t->D16, t->D32, pcur, t->P);
   GRB_HIP_TRY(hipGetLastError());
   // the tasks (GRB_TC_BITMAP_UPTO: tests send the pivots beyond a smaller number to the hash-table kernel)
   int bitmap_upto = kTcBits;
   if (const char* e = getenv("GRB_TC_BITMAP_UPTO")) { const int v = atoi(e); if (v >= 0 && v < kTcBits) bitmap_upto = v; }
-  for (unsigned* c : {c0, c1, c2}) GRB_HIP_TRY(hipMemsetAsync(c + n, 0, 4, s));
-  hipLaunchKernelGGL(tc_task_count_kernel, dim3(vgrid), dim3(kBlock), 0, s, (const int*)len, (const unsigned*)pptr, (const unsigned*)pcur, n, bitmap_upto, c0, c1, c2);
+  for (unsigned* c : {c0, c1, c2}) GRB_HIP_TRY(hipMemsetAsync(c + nn, 0, 4, s));
+  hipLaunchKernelGGL(tc_task_count_kernel, dim3(ngrid), dim3(kBlock), 0, s, (const int*)len, (const unsigned*)pptr, (const unsigned*)pcur, nn, bitmap_upto, c0, c1, c2);
   GRB_HIP_TRY(hipGetLastError());
   unsigned nt[3] = {0, 0, 0};
   int k = 0;
   for (unsigned* c : {c0, c1, c2}) {
-    GRB_TRY(device_exclusive_scan_u32(c, (long long)n + 1));
-    GRB_HIP_TRY(hipMemcpyAsync(&nt[k++], c + n, 4, hipMemcpyDeviceToHost, s));
+    GRB_TRY(device_exclusive_scan_u32(c, (long long)nn + 1));
+    GRB_HIP_TRY(hipMemcpyAsync(&nt[k++], c + nn, 4, hipMemcpyDeviceToHost, s));
   }
   GRB_HIP_TRY(hipStreamSynchronize(s));
   if (nt[2] > 0 && t->longest > kTcHashLen) return GRB_SUCCESS;     // a list no table here holds
@@ -431,7 +510,7 @@ static grb_info tc_prepare(grb_matrix_s* A, TcPrep* t) {
     t->ntasks[k] = (int)nt[k];
     GRB_HIP_TRY(hipMalloc((void**)&t->tasks[k], 16 * ((size_t)nt[k] + 1)));
   }
-  hipLaunchKernelGGL(tc_task_fill_kernel, dim3(vgrid), dim3(kBlock), 0, s, (const int*)len, (const unsigned*)pptr, (const unsigned*)pcur, n, bitmap_upto, (const unsigned*)c0,
+  hipLaunchKernelGGL(tc_task_fill_kernel, dim3(ngrid), dim3(kBlock), 0, s, (const int*)len, (const unsigned*)pptr, (const unsigned*)pcur, nn, bitmap_upto, (const unsigned*)c0,
                      (const unsigned*)c1, (const unsigned*)c2, t->tasks[0], t->tasks[1], t->tasks[2]);
   GRB_HIP_TRY(hipGetLastError());
   GRB_HIP_TRY(hipStreamSynchronize(s));
@@ -464,9 +543,7 @@ grb_info tc_count_try(grb_matrix_s* A, long long* count, bool* done) {
     A->tc_prep = t;
     const grb_info info = tc_prepare(A, t);
     if (info != GRB_SUCCESS || t->state != 1) {
-      // (whatever was allocated goes; the verdict stays: the next call does not try again)
-      for (void** q : {(void**)&t->D, (void**)&t->Dptr, (void**)&t->P, (void**)&t->tasks[0], (void**)&t->tasks[1], (void**)&t->tasks[2]})
-        if (*q) { (void)hipFree(*q); *q = nullptr; }
+      tc_prep_release(t);                     // (whatever was allocated goes; the verdict stays: the next call does not try again)
       if (info != GRB_SUCCESS) { delete t; A->tc_prep = nullptr; return info; }
     }
   }
@@ -478,14 +555,17 @@ grb_info tc_count_try(grb_matrix_s* A, long long* count, bool* done) {
   GRB_HIP_TRY(hipMemsetAsync(slots, 0, 8 * (kTcSlots + 1), s));
   // (the short pivots' kernel on a second stream beside the long pivots' was measured: the same 23.5 ms, docs/experiments.md R6.8)
   if (t->ntasks[1] > 0)
-    hipLaunchKernelGGL((tc_count_bitmap_kernel<512, kTcBits>), dim3(t->ntasks[1]), dim3(512), 0, s, (const int*)t->D, (const int*)t->Dptr,
-                       (const int2*)t->P, (const int4*)t->tasks[1], slots);
+    hipLaunchKernelGGL((tc_count_bitmap_kernel<512, kTcBits>), dim3(t->ntasks[1]), dim3(512), 0, s, (const unsigned short*)t->D16, (const int*)t->D32,
+                       (const int4*)t->lists, (const int4*)t->P, (const int4*)t->tasks[1], slots);
   if (t->ntasks[2] > 0)
-    hipLaunchKernelGGL((tc_count_pivot_kernel<512, 2 * kTcHashLen>), dim3(t->ntasks[2]), dim3(512), 0, s, (const int*)t->D, (const int*)t->Dptr,
-                       (const int2*)t->P, (const int4*)t->tasks[2], slots);
-  if (t->ntasks[0] > 0)
-    hipLaunchKernelGGL((tc_count_pivot_kernel<64, 2 * kTcWaveLen>), dim3(t->ntasks[0]), dim3(64), 0, s, (const int*)t->D, (const int*)t->Dptr,
-                       (const int2*)t->P, (const int4*)t->tasks[0], slots);
+    hipLaunchKernelGGL((tc_count_pivot_kernel<512, 2 * kTcHashLen>), dim3(t->ntasks[2]), dim3(512), 0, s, (const unsigned short*)t->D16, (const int*)t->D32,
+                       (const int4*)t->lists, (const int4*)t->P, (const int4*)t->tasks[2], t->ntasks[2], slots);
+  if (t->ntasks[0] > 0) {
+    static const int wave_grid = [] { const char* e = getenv("GRB_TC_WAVE_GRID"); return e && atoi(e) > 0 ? atoi(e) : (1 << 20); }();
+    hipLaunchKernelGGL((tc_count_pivot_kernel<64, 2 * kTcWaveLen>), dim3(t->ntasks[0] < wave_grid ? t->ntasks[0] : wave_grid), dim3(64), 0, s,
+                       (const unsigned short*)t->D16, (const int*)t->D32, (const int4*)t->lists, (const int4*)t->P, (const int4*)t->tasks[0],
+                       t->ntasks[0], slots);
+  }
   hipLaunchKernelGGL(tc_total_kernel, dim3(1), dim3(kTcSlots), 0, s, slots);
   GRB_HIP_TRY(hipGetLastError());
   GRB_HIP_TRY(hipEventRecord(ev[2], s));
