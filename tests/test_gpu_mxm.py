@@ -361,3 +361,50 @@ def test_triangle_count_without_the_product(hb, bitmap_upto):
             os.environ.pop("GRB_TC_BITMAP_UPTO", None)
         else:
             os.environ["GRB_TC_BITMAP_UPTO"] = saved
+
+
+@pytest.mark.parametrize("bitmap_upto", [None, "66000"])
+def test_triangle_count_numbers_beyond_16_bits(hb, bitmap_upto):
+    """The oriented lists keep the numbers below 65 535 as 16-bit entries and the others as 32-bit entries, nobody is numbered
+    65 535, and a pivot numbered below 65 536 does not stream its partners' 32-bit parts: graphs with more than 65 536
+    vertices whose low-ranked vertices have long lists -- a sparse one (every pivot a wave's, most of them beyond 65 536)
+    and a dense one (pivots beyond 65 536 with lists of several hundred entries: the bitmap kernel's wide path, and with
+    GRB_TC_BITMAP_UPTO=66000 the 512-thread hash-table kernel's).  The count equals the product path's sum, and the CPU
+    reference's on the sparse graph."""
+    import os
+    from graphblast_amd.graphgen import finalize_edges
+    from oracle import simple_reference as sr
+    g = hb.g
+    saved = os.environ.get("GRB_TC_BITMAP_UPTO")
+    if bitmap_upto is not None:
+        os.environ["GRB_TC_BITMAP_UPTO"] = bitmap_upto
+    was = g.tc_set_product(0)
+    try:
+        rng = np.random.default_rng(23)
+        seen = [0, 0, 0]
+        for name, n, m in (("sparse", 150000, 1500000), ("dense", 67000, 14000000)):
+            gr = finalize_edges(rng.integers(0, n, m), rng.integers(0, n, m), n, symmetrize=True)
+            lp, li = _lower(np.asarray(gr["csr"][0]), np.asarray(gr["csr"][1]), n)
+            del gr
+            L, B = g.Matrix(n, n, np.int32), g.Matrix(n, n, np.int32)
+            assert L.build_csr(lp, li, np.ones(li.size, dtype=np.int32)) == 0
+            info, ntris, _ = g.tc(L, B, hb.descriptor())
+            last = g.tc_last()[1]
+            assert info == 0 and last["path"] == 1 and B.nvals() == 0, (name, last)
+            for k in range(3):
+                seen[k] += last["tasks"][k]
+            if name == "sparse":
+                assert ntris == sr.tc(lp, li)[0], name
+            else:
+                assert last["longest_list"] > 256, last
+            g.tc_set_product(1)
+            info, want, _ = g.tc(L, B, hb.descriptor())
+            g.tc_set_product(0)
+            assert info == 0 and g.tc_last()[1]["path"] == 0 and ntris == want > 0, (name, ntris, want)
+        assert seen[0] > 0 and (seen[1] > 0 if bitmap_upto is None else seen[2] > 0), seen
+    finally:
+        g.tc_set_product(was)
+        if saved is None:
+            os.environ.pop("GRB_TC_BITMAP_UPTO", None)
+        else:
+            os.environ["GRB_TC_BITMAP_UPTO"] = saved
