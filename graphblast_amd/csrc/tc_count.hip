@@ -14,6 +14,7 @@
 // workgroup that owns the pivot p, and the lists of p's partners streamed past it a wave to a list, 16 bytes per lane per
 // step.  DESIGN.md 5.4a; docs/experiments.md R6.8 for how it got here.
 #include "common.hpp"
+#include <chrono>
 
 namespace grb {
 
@@ -426,6 +427,17 @@ static grb_info tc_prepare(grb_matrix_s* A, TcPrep* t) {
   const long long nnz = A->nvals;
   t->state = -1;
   if (A->csc_alias || !A->csc.ptr || !A->csr.val || n != A->ncols || nnz < 1 || nnz > 0x7ffffff0ll) return GRB_SUCCESS;
+  // GRB_TC_TRACE=1: the host's clock after every stage (each with a stream wait), to stderr
+  static const bool trace = [] { const char* e = getenv("GRB_TC_TRACE"); return e && atoi(e) != 0; }();
+  auto now_us = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  double t_last = trace ? now_us() : 0.0;
+  auto stage = [&](const char* what) {
+    if (!trace) return;
+    (void)hipStreamSynchronize(s);
+    const double t = now_us();
+    fprintf(stderr, "tc_prepare: %-28s %9.1f us\n", what, t - t_last);
+    t_last = t;
+  };
   TcTemps tmp;
   int *erow, *number, *elo, *ehi, *len, *len16, *len32, *flags;
   unsigned long long* key;
@@ -450,11 +462,13 @@ static grb_info tc_prepare(grb_matrix_s* A, TcPrep* t) {
   GRB_TRY(tmp.get(&c2, (size_t)nn + 1));
   GRB_TRY(tmp.get(&flags, 2));                // {bad, longest list}
   GRB_HIP_TRY(hipMalloc((void**)&t->lists, 16 * (size_t)nn));
+  stage("temporaries allocated");
   const int vgrid = (int)((n + kBlock - 1) / kBlock), ngrid = (int)((nn + kBlock - 1) / kBlock), egrid = stream_grid(nnz, kBlock * 4);
   // the numbering: by degree, the highest first, ties by the caller's number (the sort is stable)
   hipLaunchKernelGGL(tc_degree_kernel, dim3(vgrid), dim3(kBlock), 0, s, (const Index*)A->csr.ptr, (const Index*)A->csc.ptr, n, key, order);
   GRB_HIP_TRY(hipGetLastError());
   GRB_TRY(device_sort_pairs(key, order, n, 32, 0));
+  stage("degrees sorted");
   GRB_HIP_TRY(hipMemsetAsync(pptr, 0, 4 * ((size_t)nn + 1), s));
   hipLaunchKernelGGL(tc_number_kernel, dim3(vgrid), dim3(kBlock), 0, s, (const unsigned*)order, (const unsigned long long*)key, n, number, pptr);
   hipLaunchKernelGGL(tc_rows_kernel, dim3(stream_grid((long long)n * 16, kBlock)), dim3(kBlock), 0, s, (const Index*)A->csr.ptr, n, erow);
@@ -467,6 +481,7 @@ static grb_info tc_prepare(grb_matrix_s* A, TcPrep* t) {
                      (const unsigned*)A->csr.val, one, nnz, (const int*)number, elo, ehi, ptr16, ptr32, flags);
   hipLaunchKernelGGL(tc_lengths_kernel, dim3(ngrid), dim3(kBlock), 0, s, ptr16, ptr32, nn, len16, len32, len, flags + 1);
   GRB_HIP_TRY(hipGetLastError());
+  stage("rows, pass A, lengths");
   GRB_TRY(device_exclusive_scan_u32(ptr16, (long long)nn + 1));
   GRB_TRY(device_exclusive_scan_u32(ptr32, (long long)nn + 1));
   GRB_TRY(device_exclusive_scan_u32(pptr, (long long)nn + 1));
@@ -479,11 +494,13 @@ static grb_info tc_prepare(grb_matrix_s* A, TcPrep* t) {
   GRB_HIP_TRY(hipMemcpyAsync(&room16, ptr16 + nn, 4, hipMemcpyDeviceToHost, s));
   GRB_HIP_TRY(hipMemcpyAsync(&room32, ptr32 + nn, 4, hipMemcpyDeviceToHost, s));
   GRB_HIP_TRY(hipStreamSynchronize(s));
+  stage("scans");
   if (h_flags[0]) return GRB_SUCCESS;         // not a strictly lower triangle of ones
   t->longest = h_flags[1];
   GRB_HIP_TRY(hipMalloc((void**)&t->D16, 2 * ((size_t)room16 + 16)));
   GRB_HIP_TRY(hipMalloc((void**)&t->D32, 4 * ((size_t)room32 + 8)));
   GRB_HIP_TRY(hipMalloc((void**)&t->P, 16 * (2 * (size_t)nnz + 1)));         // (a vertex's room: its degree)
+  stage("lists and partners allocated");
   GRB_HIP_TRY(hipMemsetAsync(t->D16, 0xff, 2 * ((size_t)room16 + 16), s));
   GRB_HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)t->D32, (int)kTcPad, (size_t)room32 + 8, s));
   GRB_HIP_TRY(hipMemcpyAsync(cur16, ptr16, 4 * (size_t)nn, hipMemcpyDeviceToDevice, s));
@@ -492,6 +509,7 @@ static grb_info tc_prepare(grb_matrix_s* A, TcPrep* t) {
   hipLaunchKernelGGL(tc_lists_kernel, dim3(egrid), dim3(kBlock), 0, s, (const int*)elo, (const int*)ehi, nnz, (const int4*)t->lists,
                      (const int*)len, cur16, cur32, t->D16, t->D32, pcur, t->P);
   GRB_HIP_TRY(hipGetLastError());
+  stage("pass B");
   // the tasks (GRB_TC_BITMAP_UPTO: tests send the pivots beyond a smaller number to the hash-table kernel)
   int bitmap_upto = kTcBits;
   if (const char* e = getenv("GRB_TC_BITMAP_UPTO")) { const int v = atoi(e); if (v >= 0 && v < kTcBits) bitmap_upto = v; }
@@ -514,6 +532,7 @@ static grb_info tc_prepare(grb_matrix_s* A, TcPrep* t) {
                      (const unsigned*)c1, (const unsigned*)c2, t->tasks[0], t->tasks[1], t->tasks[2]);
   GRB_HIP_TRY(hipGetLastError());
   GRB_HIP_TRY(hipStreamSynchronize(s));
+  stage("tasks");
   t->state = 1;
   return GRB_SUCCESS;
 }

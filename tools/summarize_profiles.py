@@ -14,7 +14,7 @@ if kept_w and os.path.exists(dst + '/other_workloads.jsonl'):
         for W, key in (("lj_bfs", "soc-L"), ("road_sssp", "road"), ("orkut_tc", "rkut")):
             if key in json.loads(ln).get("metric", "") + json.dumps(json.loads(ln).get("config", {})):
                 prev_lines.setdefault(W, ln)
-keep_prefixes = ("full_suite", "bfs_", "tests_", "sssp_", "tc_", "spmv_", "bench_spread", "orkut_tc_kernel_stats_before", "core_", "co", "prep", "driver_", "README") + tuple(kept_w) + \
+keep_prefixes = ("full_suite", "smoke", "batch", "bfs_", "tests_", "sssp_", "tc_", "spmv_", "bench_spread", "orkut_tc_kernel_stats_before", "core_", "co", "prep", "driver_", "README") + tuple(kept_w) + \
     tuple("pmc_%s_" % W for W in kept_w)
 for f in os.listdir(dst):
     if not f.startswith(keep_prefixes):     # logs of test / A-B runs kept beside the profiles
