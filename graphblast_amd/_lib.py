@@ -178,6 +178,7 @@ _SIGS = {
     "grb_tc": [C.POINTER(C.c_int64), _vp, _vp, _vp, C.POINTER(AlgoResult)],
     "grb_tc_dense_core": [_vp, _i, _i, _i, C.POINTER(TcCoreResult)],
     "grb_tc_set_product": [_i],
+    "grb_tc_release": [_vp],
     "grb_tc_last": [C.POINTER(TcInfo)],
     "grb_sssp": [_vp, _vp, _i, _vp, C.POINTER(AlgoResult)],
     "grb_pr": [_vp, _vp, _f, _f, _vp, C.POINTER(AlgoResult)],

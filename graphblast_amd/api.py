@@ -566,6 +566,11 @@ def tc_set_product(on):
     return _lib.load().grb_tc_set_product(int(on))
 
 
+def tc_release(A):
+    """grb_tc_release: drops the orientation the matrix keeps after its first count."""
+    return _lib.load().grb_tc_release(_h(A))
+
+
 def tc_last():
     """grb_tc_last: which way the last tc went and what it cost."""
     t = _lib.TcInfo()

@@ -610,6 +610,13 @@ using namespace grb;
 
 extern "C" int grb_tc_set_product(int on) { GRB_API_ENTER_HOST(); return tc_product_setting(on); }
 
+extern "C" grb_info grb_tc_release(grb_matrix A) { GRB_API_ENTER();
+  if (!A) return GRB_NULL_POINTER;
+  GRB_HIP_TRY(hipStreamSynchronize(ctx().stream));
+  tc_prep_free(A);
+  return GRB_SUCCESS;
+}
+
 extern "C" grb_info grb_tc_last(grb_tc_info* out) { GRB_API_ENTER_HOST();
   if (!out) return GRB_NULL_POINTER;
   out->path = g_tc_last.path;

@@ -582,6 +582,10 @@ grb_info grb_tc(int64_t* ntris, grb_matrix A, grb_matrix B, grb_descriptor desc,
 /* 1: grb_tc always forms the product in B; 0: counts without it where it can (default); < 0: query.  Returns the
  * previous setting. */
 int grb_tc_set_product(int on);
+/* The orientation a matrix keeps after its first count (about 34 bytes per stored entry: the lists, a 16-byte descriptor
+ * per edge end, the task lists) is released by grb_matrix_free and by whatever rewrites the matrix; this releases it
+ * at once -- the next count prepares it again. */
+grb_info grb_tc_release(grb_matrix A);
 typedef struct {
   int32_t path;           /* of the last grb_tc: 0 = product + reduce, 1 = counted on the oriented lists            */
   float   prep_ms;        /* the orientation, when that call had to build it (0 when the matrix brought it along)    */
