@@ -412,3 +412,36 @@ def test_triangle_count_numbers_beyond_16_bits(hb, bitmap_upto):
             os.environ.pop("GRB_TC_BITMAP_UPTO", None)
         else:
             os.environ["GRB_TC_BITMAP_UPTO"] = saved
+
+
+def test_triangle_count_random_graphs(hb):
+    """Forty random graphs -- a single vertex, no edges, paths, cliques, power-law and uniform ones, up to 20 000 vertices --
+    counted on the orientation and through the product: both equal SimpleReferenceTc."""
+    from graphblast_amd.graphgen import finalize_edges
+    from oracle import simple_reference as sr
+    g = hb.g
+    rng = np.random.default_rng(77)
+    was = g.tc_set_product(0)
+    try:
+        paths = [0, 0]
+        for trial in range(40):
+            n = int(rng.choice([1, 2, 3, 17, 64, 65, 300, 2000, 20000]))
+            m = int(rng.choice([0, 1, n, 4 * n, 30 * n]))
+            if trial % 4 == 0:                                   # skewed endpoints: a few hubs
+                s_ = (rng.random(m) ** 3 * n).astype(np.int64)
+                d_ = rng.integers(0, n, m)
+            else:
+                s_, d_ = rng.integers(0, n, m), rng.integers(0, n, m)
+            gr = finalize_edges(s_, d_, n, symmetrize=True)
+            lp, li = _lower(np.asarray(gr["csr"][0]), np.asarray(gr["csr"][1]), n)
+            want = sr.tc(lp, li)[0] if li.size else 0
+            L, B = g.Matrix(n, n, np.int32), g.Matrix(n, n, np.int32)
+            assert L.build_csr(lp, li, np.ones(li.size, dtype=np.int32)) == 0
+            for product in (0, 1):
+                g.tc_set_product(product)
+                info, ntris, _ = g.tc(L, B, hb.descriptor())
+                assert info == 0 and ntris == want, (trial, n, m, product, ntris, want)
+                paths[g.tc_last()[1]["path"]] += 1
+        assert paths[1] >= 20, paths
+    finally:
+        g.tc_set_product(was)
