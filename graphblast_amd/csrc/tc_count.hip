@@ -167,12 +167,63 @@ __global__ __launch_bounds__(kThreads) void tc_count_pivot_kernel(const unsigned
   }
 }
 
+// The pivots with short lists (<= 256 entries: 851 506 of the bench's graph, 2 % of the streamed elements): their partners'
+// lists are no longer than theirs -- a dozen entries, two parts -- and a wave step per part leaves sixty lanes idle.  Here a
+// LANE walks a partner: 16 bytes (eight 16-bit or four 32-bit entries) per step, 64 partners of the task at a time, the
+// pivot's list in the wave's 512-slot hash table.  One wave per task, no barriers but the wave's own.
+__global__ __launch_bounds__(kWave) void tc_count_small_kernel(const unsigned short* __restrict__ D16, const int* __restrict__ D32,
+                                                               const int4* __restrict__ lists, const int4* __restrict__ P,
+                                                               const int4* __restrict__ tasks, unsigned long long* total) {
+  constexpr int kTable = 512;
+  __shared__ unsigned table[kTable];
+  const int lane = lane_id();
+  const int4 task = tasks[blockIdx.x];
+  const int4 own = lists[task.x];
+  const int len = own.y + own.w;
+  const int need = len * GRB_TC_SLOTS - 1 > 63 ? (len * GRB_TC_SLOTS - 1 < kTable - 1 ? len * GRB_TC_SLOTS - 1 : kTable - 1) : 63;
+  const int lg = 32 - __clz(need);
+  const unsigned mask = (1u << lg) - 1u;
+  const int shift = 32 - lg;
+  for (unsigned i = lane; i <= mask; i += kWave) table[i] = kTcEmpty;
+  __syncthreads();
+  tc_own_list<kWave>(D16, D32, own, lane, [&](unsigned x) {
+    unsigned slot = (x * 0x9E3779B1u) >> shift;
+    while (atomicCAS(&table[slot], kTcEmpty, x) != kTcEmpty) slot = (slot + 1) & mask;
+  });
+  __syncthreads();
+  const bool wide = task.x > 65536;
+  unsigned count = 0;
+  auto look = [&](unsigned x) {
+    unsigned slot = (x * 0x9E3779B1u) >> shift;
+    unsigned t = table[slot];
+    while (t != x && t != kTcEmpty) { slot = (slot + 1) & mask; t = table[slot]; }
+    count += t == x;
+  };
+  for (int q = lane; q < task.z; q += kWave) {
+    const int4 my = P[task.y + q];
+    for (int k = my.x; k < my.x + my.y; k += 8) {
+      const int4 v = *reinterpret_cast<const int4*>(D16 + k);
+      const unsigned w[4] = {(unsigned)v.x, (unsigned)v.y, (unsigned)v.z, (unsigned)v.w};
+#pragma unroll
+      for (int c = 0; c < 4; ++c) { look(w[c] & 0xffffu); look(w[c] >> 16); }
+    }
+    if (wide)
+      for (int k = my.z; k < my.z + my.w; k += 4) {
+        const int4 v = *reinterpret_cast<const int4*>(D32 + k);
+        look((unsigned)v.x); look((unsigned)v.y); look((unsigned)v.z); look((unsigned)v.w);
+      }
+  }
+#pragma unroll
+  for (int off = kWave / 2; off; off >>= 1) count += __shfl_down(count, off);
+  if (lane == 0 && count) atomicAdd(&total[blockIdx.x & (kTcSlots - 1)], (unsigned long long)count);
+}
+
 // The pivots numbered up to kBits (vertices are NUMBERED BY RANK, 0 = the highest degree, so list(p) holds numbers below
 // p): the pivot's list is a BITMAP of p bits -- one LDS read and a bit test per streamed element, no hashing, no walk.
 template <int kThreads, int kBits>
 __global__ __launch_bounds__(kThreads) void tc_count_bitmap_kernel(const unsigned short* __restrict__ D16, const int* __restrict__ D32,
                                                                     const int4* __restrict__ lists, const int4* __restrict__ P,
-                                                                    const int4* __restrict__ tasks, unsigned long long* total) {
+                                                                    const int4* __restrict__ tasks, int short_upto, unsigned long long* total) {
   __shared__ unsigned bits[kBits / 32 + 1];
   __shared__ int next;
   __shared__ unsigned part[kThreads / kWave];
@@ -195,7 +246,32 @@ __global__ __launch_bounds__(kThreads) void tc_count_bitmap_kernel(const unsigne
   int b = wave_id();
   while (b < nbatch) {
     const int nb = task.z - b * kWave < kWave ? task.z - b * kWave : kWave;
-    const int4 my = lane < nb ? P[task.y + b * kWave + lane] : make_int4(0, 0, 0, 0);
+    int4 my = lane < nb ? P[task.y + b * kWave + lane] : make_int4(0, 0, 0, 0);
+    // the batch's SHORT partners are walked by their lanes, 16 bytes a step, all of them at once -- a wave step for a
+    // list of twenty entries would leave sixty lanes idle; the wave then streams the others
+    if (my.y + my.w > 0 && my.y <= short_upto && my.w <= short_upto / 2) {
+      for (int k = my.x; k < my.x + my.y; k += 8) {
+        const int4 v = *reinterpret_cast<const int4*>(D16 + k);
+        const unsigned w[4] = {(unsigned)v.x, (unsigned)v.y, (unsigned)v.z, (unsigned)v.w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const unsigned lo = *reinterpret_cast<const unsigned*>(reinterpret_cast<const char*>(bits) + ((w[c] >> 3) & 0x1ffcu));
+          const unsigned hi = *reinterpret_cast<const unsigned*>(reinterpret_cast<const char*>(bits) + ((w[c] >> 19) & 0x1ffcu));
+          count += __builtin_amdgcn_ubfe(lo, w[c], 1u) + __builtin_amdgcn_ubfe(hi, w[c] >> 16, 1u);
+        }
+      }
+      if (wide)
+        for (int k = my.z; k < my.z + my.w; k += 4) {
+          const int4 v = *reinterpret_cast<const int4*>(D32 + k);
+          const unsigned w[4] = {(unsigned)v.x, (unsigned)v.y, (unsigned)v.z, (unsigned)v.w};
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const unsigned i = w[c] >> 5;
+            count += __builtin_amdgcn_ubfe(bits[i < top ? i : top], w[c], 1u);
+          }
+        }
+      my = make_int4(0, 0, 0, 0);
+    }
     // (the fillings: bit 65 535 is nobody's, kTcPad looks at word `top`; v_bfe_u32 takes the low five bits of its offset)
     tc_stream_batch<GRB_TC_DEPTH>(D16, D32, my, wide, lane,
       [&](unsigned w) {
@@ -573,17 +649,24 @@ grb_info tc_count_try(grb_matrix_s* A, long long* count, bool* done) {
   unsigned long long* slots = (unsigned long long*)p_slots;
   GRB_HIP_TRY(hipMemsetAsync(slots, 0, 8 * (kTcSlots + 1), s));
   // (the short pivots' kernel on a second stream beside the long pivots' was measured: the same 23.5 ms, docs/experiments.md R6.8)
+  // GRB_TC_SHORT: partners of the bitmap kernel with at most this many 16-bit entries (half as many 32-bit ones) are walked by a lane
+  static const int short_upto = [] { const char* e = getenv("GRB_TC_SHORT"); return e ? atoi(e) : 128; }();
   if (t->ntasks[1] > 0)
     hipLaunchKernelGGL((tc_count_bitmap_kernel<512, kTcBits>), dim3(t->ntasks[1]), dim3(512), 0, s, (const unsigned short*)t->D16, (const int*)t->D32,
-                       (const int4*)t->lists, (const int4*)t->P, (const int4*)t->tasks[1], slots);
+                       (const int4*)t->lists, (const int4*)t->P, (const int4*)t->tasks[1], short_upto, slots);
   if (t->ntasks[2] > 0)
     hipLaunchKernelGGL((tc_count_pivot_kernel<512, 2 * kTcHashLen>), dim3(t->ntasks[2]), dim3(512), 0, s, (const unsigned short*)t->D16, (const int*)t->D32,
                        (const int4*)t->lists, (const int4*)t->P, (const int4*)t->tasks[2], t->ntasks[2], slots);
   if (t->ntasks[0] > 0) {
-    static const int wave_grid = [] { const char* e = getenv("GRB_TC_WAVE_GRID"); return e && atoi(e) > 0 ? atoi(e) : (1 << 20); }();
-    hipLaunchKernelGGL((tc_count_pivot_kernel<64, 2 * kTcWaveLen>), dim3(t->ntasks[0] < wave_grid ? t->ntasks[0] : wave_grid), dim3(64), 0, s,
-                       (const unsigned short*)t->D16, (const int*)t->D32, (const int4*)t->lists, (const int4*)t->P, (const int4*)t->tasks[0],
-                       t->ntasks[0], slots);
+    // GRB_TC_SMALL=0: the wave-per-partner kernel for the short pivots too (the A/B of docs/experiments.md R6.8)
+    static const bool small = [] { const char* e = getenv("GRB_TC_SMALL"); return !e || atoi(e) != 0; }();
+    if (small)
+      hipLaunchKernelGGL(tc_count_small_kernel, dim3(t->ntasks[0]), dim3(kWave), 0, s, (const unsigned short*)t->D16, (const int*)t->D32,
+                         (const int4*)t->lists, (const int4*)t->P, (const int4*)t->tasks[0], slots);
+    else
+      hipLaunchKernelGGL((tc_count_pivot_kernel<64, 2 * kTcWaveLen>), dim3(t->ntasks[0]), dim3(64), 0, s,
+                         (const unsigned short*)t->D16, (const int*)t->D32, (const int4*)t->lists, (const int4*)t->P, (const int4*)t->tasks[0],
+                         t->ntasks[0], slots);
   }
   hipLaunchKernelGGL(tc_total_kernel, dim3(1), dim3(kTcSlots), 0, s, slots);
   GRB_HIP_TRY(hipGetLastError());
