@@ -301,7 +301,10 @@ __global__ __launch_bounds__(kThreads) void tc_count_bitmap_kernel(const unsigne
 constexpr int kTcWaveLen = 256;               // lists up to here: a wave and a hash table of 512 slots
 constexpr int kTcBits = 1 << 18;              // pivots numbered up to here: the bitmap kernel
 constexpr int kTcHashLen = 4096;              // longer lists than this (of a pivot beyond kTcBits): not handled, the product runs
-constexpr int kTcChunk[3] = {256, 2048, 2048};   // partners per task, by kernel
+#ifndef GRB_TC_CHUNK
+#define GRB_TC_CHUNK 2048
+#endif
+constexpr int kTcChunk[3] = {256, GRB_TC_CHUNK, 2048};   // partners per task, by kernel
 
 // the row of every entry (a wave per row: stores only, a hub row is a few hundred of them)
 __global__ __launch_bounds__(kBlock) void tc_rows_kernel(const Index* __restrict__ ptr, Index n, int* __restrict__ erow) {
