@@ -456,7 +456,7 @@ def other_workload(args):
                                     "triangles": int(ntri), "longest_oriented_list": int(first["longest_list"]),
                                     "longest_row_of_L": int(dl.max()), "streamed_list_elements": streamed,
                                     "workgroups": {"wave_hash": first["tasks"][0], "bitmap": first["tasks"][1], "hash": first["tasks"][2]}},
-                         "roofline": {"bound": "hbm", "kernel": "tc_count_bitmap_kernel + tc_count_pivot_kernel",
+                         "roofline": {"bound": "hbm", "kernel": "tc_count_bitmap_kernel + tc_count_small_kernel",
                                       "achieved": round(comp_c / tk / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                       "frac": round(comp_c / tk / 1e9 / HBM_PEAK_GBS, 5),
                                       "traffic": pmc_group("tc_count_call", "orkut_tc")[0], "traffic_source": pmc_group("tc_count_call", "orkut_tc")[1],

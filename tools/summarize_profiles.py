@@ -178,7 +178,7 @@ for W in ALL_W:
                           for k, v in ow.items() if "tc_count_" in k or "tc_total_kernel" in k)
                 workloads[W].setdefault("groups", {})["tc_count_call"] = {
                     "hbm_bytes_per_unit": int(tot / ncall), "units": ncall,
-                    "what": "tc_count_bitmap_kernel + tc_count_pivot_kernel + tc_total_kernel, per grb_tc call on a prepared matrix"}
+                    "what": "tc_count_bitmap_kernel + tc_count_small_kernel (+ tc_count_pivot_kernel) + tc_total_kernel, per grb_tc call on a prepared matrix"}
 if lines:
     open(dst + '/other_workloads.jsonl', 'w').write("\n".join(lines) + "\n")
 doc = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, each with --kernel-trace only) over "
