@@ -562,7 +562,8 @@ def tc(A, B, desc):
 
 
 def tc_set_product(on):
-    """grb_tc_set_product: 1 = grb_tc always forms the product in B, 0 = it counts without it where it can; < 0 queries."""
+    """grb_tc_set_product: 0 = grb_tc counts without the product where that is a count and pays (default), 1 = always the
+    product in B, 2 = the count wherever it is a count; < 0 queries."""
     return _lib.load().grb_tc_set_product(int(on))
 
 

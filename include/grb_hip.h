@@ -579,8 +579,10 @@ int grb_cc_set_fused(int on);
  * matrix or descriptor (INP0 transposed, ...), and every matrix after grb_tc_set_product(1) (or GRB_TC_PRODUCT=1 in the
  * environment), runs the reference's two calls with the product in B.  ntris is the same number either way. */
 grb_info grb_tc(int64_t* ntris, grb_matrix A, grb_matrix B, grb_descriptor desc, grb_algo_result* result);
-/* 1: grb_tc always forms the product in B; 0: counts without it where it can (default); < 0: query.  Returns the
- * previous setting. */
+/* 0 (default): the count without the product where it is a count AND pays -- the first count asked of a matrix without
+ * long rows (squared row lengths summing to at most 256 per entry: road networks, uniform random graphs, whose product is
+ * cheap) goes through the product, the second prepares the orientation; 1: always the product in B; 2: the count wherever
+ * it is a count; < 0: query.  Returns the previous setting.  GRB_TC_PRODUCT=<0|1|2> in the environment sets the start. */
 int grb_tc_set_product(int on);
 /* The orientation a matrix keeps after its first count (about 34 bytes per stored entry: the lists, a 16-byte descriptor
  * per edge end, the task lists) is released by grb_matrix_free and by whatever rewrites the matrix; this releases it

@@ -291,7 +291,7 @@ def test_triangle_count_without_the_product(hb, bitmap_upto):
     saved = os.environ.get("GRB_TC_BITMAP_UPTO")
     if bitmap_upto is not None:
         os.environ["GRB_TC_BITMAP_UPTO"] = bitmap_upto
-    was = g.tc_set_product(0)
+    was = g.tc_set_product(2)                                   # the count wherever it is a count (0 would send the first count on a hub-free graph through the product)
     try:
         seen = [0, 0, 0]
         for name, gr in _tc_graphs():
@@ -321,7 +321,7 @@ def test_triangle_count_without_the_product(hb, bitmap_upto):
                 # (the reduction of an f32 product is an f32 sum: exact up to 2^24 only; the count path's is an integer)
                 assert ntris == want if dt == np.int32 else abs(ntris - want) <= 2e-7 * want, (name, dt, ntris, want)
                 assert int(B.host_csr()[2].astype(np.int64).sum()) == want
-                g.tc_set_product(0)
+                g.tc_set_product(2)
                 # values changed in place: the kept orientation goes with them (4 = 2 x 2 per common neighbour now)
                 if name == "rmat13" and dt == np.int32:
                     assert g.apply(L, None, None, "bind_second", L, hb.descriptor(), binop="multiplies", scalar=2) == 0
@@ -382,7 +382,7 @@ def test_triangle_count_numbers_beyond_16_bits(hb, bitmap_upto):
     saved = os.environ.get("GRB_TC_BITMAP_UPTO")
     if bitmap_upto is not None:
         os.environ["GRB_TC_BITMAP_UPTO"] = bitmap_upto
-    was = g.tc_set_product(0)
+    was = g.tc_set_product(2)
     try:
         rng = np.random.default_rng(23)
         seen = [0, 0, 0]
@@ -403,7 +403,7 @@ def test_triangle_count_numbers_beyond_16_bits(hb, bitmap_upto):
                 assert last["longest_list"] > 256, last
             g.tc_set_product(1)
             info, want, _ = g.tc(L, B, hb.descriptor())
-            g.tc_set_product(0)
+            g.tc_set_product(2)
             assert info == 0 and g.tc_last()[1]["path"] == 0 and ntris == want > 0, (name, ntris, want)
         assert seen[0] > 0 and (seen[1] > 0 if bitmap_upto is None else seen[2] > 0), seen
     finally:
@@ -437,11 +437,44 @@ def test_triangle_count_random_graphs(hb):
             want = sr.tc(lp, li)[0] if li.size else 0
             L, B = g.Matrix(n, n, np.int32), g.Matrix(n, n, np.int32)
             assert L.build_csr(lp, li, np.ones(li.size, dtype=np.int32)) == 0
-            for product in (0, 1):
+            for product in (2, 1, 0, 0):
                 g.tc_set_product(product)
                 info, ntris, _ = g.tc(L, B, hb.descriptor())
                 assert info == 0 and ntris == want, (trial, n, m, product, ntris, want)
                 paths[g.tc_last()[1]["path"]] += 1
         assert paths[1] >= 20, paths
+    finally:
+        g.tc_set_product(was)
+
+
+def test_triangle_count_first_count_on_a_matrix_without_long_rows(hb):
+    """The default (grb_tc_set_product(0)): a matrix whose rows are all short is cheap for the product and the orientation's
+    preparation is not -- its FIRST count goes through the reference's two calls, the second prepares the orientation, the
+    third finds it with the matrix; a hub graph prepares at once.  The same number every time."""
+    from graphblast_amd.graphgen import rmat_edges, finalize_edges
+    from oracle import simple_reference as sr
+    g = hb.g
+    rng = np.random.default_rng(3)
+    was = g.tc_set_product(0)
+    try:
+        n = 30000
+        gr = finalize_edges(rng.integers(0, n, 300000), rng.integers(0, n, 300000), n, symmetrize=True)
+        lp, li = _lower(np.asarray(gr["csr"][0]), np.asarray(gr["csr"][1]), n)
+        want = sr.tc(lp, li)[0]
+        L, B = g.Matrix(n, n, np.int32), g.Matrix(n, n, np.int32)
+        assert L.build_csr(lp, li, np.ones(li.size, dtype=np.int32)) == 0
+        trace = []
+        for rep in range(3):
+            info, ntris, _ = g.tc(L, B, hb.descriptor())
+            assert info == 0 and ntris == want
+            trace.append((g.tc_last()[1]["path"], g.tc_last()[1]["prep_ms"] > 0.05))
+        assert trace == [(0, False), (1, True), (1, False)], trace
+        s_, d_, n = rmat_edges(14, 24, seed=3)
+        gr = finalize_edges(s_, d_, n, symmetrize=True)
+        lp, li = _lower(np.asarray(gr["csr"][0]), np.asarray(gr["csr"][1]), n)
+        L, B = g.Matrix(n, n, np.int32), g.Matrix(n, n, np.int32)
+        assert L.build_csr(lp, li, np.ones(li.size, dtype=np.int32)) == 0
+        info, ntris, _ = g.tc(L, B, hb.descriptor())
+        assert info == 0 and ntris == sr.tc(lp, li)[0] and g.tc_last()[1]["path"] == 1
     finally:
         g.tc_set_product(was)
