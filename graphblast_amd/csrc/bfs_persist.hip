@@ -1123,6 +1123,10 @@ __global__ __launch_bounds__(1024) void oc_mass_kernel(const Index* __restrict__
   }
 }
 
+#ifndef GRB_OC_PARTS
+#define GRB_OC_PARTS 8
+#endif
+constexpr int kOcParts = GRB_OC_PARTS;
 // where big row rows[r] enters range b: off[b * nrows + r] = the first entry of the row with a destination >= bounds[b]
 __global__ void oc_range_off_kernel(const Index* __restrict__ optr, const Index* __restrict__ oind, const Index* __restrict__ rows,
                                     int nrows, int R, const Index* __restrict__ bounds, Index* __restrict__ off) {
@@ -1131,16 +1135,25 @@ __global__ void oc_range_off_kernel(const Index* __restrict__ optr, const Index*
   // (A thread per (range, row) bisecting the whole row, the first version: 18 M independent searches, 3.6 ms -- kept for
   // the rows of kOcLongRow entries and more, oc_range_off_long_kernel: one thread walking 257 bounds through 300 000
   // entries is a chain of 5 000 dependent loads.)
-  for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < nrows; r += gridDim.x * blockDim.x) {
+  // (round 6: kOcParts threads per row, each walking its share of the bounds -- the first of them found by a bisection of
+  // the whole row: a chain an eighth as long, 0.91 -> see docs/experiments.md R6.3)
+  const int per = (R + 1 + kOcParts - 1) / kOcParts;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nrows * kOcParts; i += gridDim.x * blockDim.x) {
+    const int r = i % nrows, part = i / nrows;                 // (neighbouring threads: neighbouring rows, the same bounds -- their stores stay consecutive)
     const Index u = rows[r];
     const Index e = optr[u + 1];
     Index p = optr[u];
     if (e - p >= kOcLongRow) continue;
-    for (int b = 0; b <= R; ++b) {
+    const int b0 = part * per, b1 = b0 + per < R + 1 ? b0 + per : R + 1;
+    for (int b = b0; b < b1; ++b) {
       const Index key = bounds[b];
       Index lo = p, hi = p, step = 1;
-      while (hi < e && oind[hi] < key) { lo = hi + 1; hi += step; step <<= 1; }
-      if (hi > e) hi = e;
+      if (b == b0 && part > 0) {
+        hi = e;                                                // this thread's first bound: anywhere in the row
+      } else {
+        while (hi < e && oind[hi] < key) { lo = hi + 1; hi += step; step <<= 1; }
+        if (hi > e) hi = e;
+      }
       while (lo < hi) {
         const Index mid = lo + (hi - lo) / 2;
         if (oind[mid] < key) lo = mid + 1; else hi = mid;
@@ -1260,7 +1273,7 @@ grb_info grb::oc_tables_build(const Index* d_ptr, const Index* d_ind, const std:
   GRB_HIP_TRY(hipMemcpyAsync(*d_bounds, bounds.data(), sizeof(Index) * bounds.size(), hipMemcpyHostToDevice, s));
   *d_bigidx = d_big;
   d_big = nullptr;                                         // (the caller's now)
-  hipLaunchKernelGGL(oc_range_off_kernel, dim3(stream_grid((long long)nrows_big, 64)), dim3(64), 0, s, d_ptr, d_ind,
+  hipLaunchKernelGGL(oc_range_off_kernel, dim3(stream_grid((long long)nrows_big * kOcParts, 64)), dim3(64), 0, s, d_ptr, d_ind,
                      (const Index*)p_rows, (int)nrows_big, (int)R, (const Index*)*d_bounds, *d_off);
   hipLaunchKernelGGL(oc_range_off_long_kernel, dim3(stream_grid((long long)nrows_big * kWave, kBlock)), dim3(kBlock), 0, s, d_ptr, d_ind,
                      (const Index*)p_rows, (int)nrows_big, (int)R, (const Index*)*d_bounds, *d_off);
