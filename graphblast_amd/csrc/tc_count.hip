@@ -515,7 +515,10 @@ static grb_info tc_prepare(grb_matrix_s* A, TcPrep* t) {
   const Index nn = n + 1;                     // numbers: 0 .. n, 65 535 left out
   const long long nnz = A->nvals;
   t->state = -1;
-  if (A->csc_alias || !A->csc.ptr || !A->csr.val || n != A->ncols || nnz < 1 || nnz > 0x7ffffff0ll) return GRB_SUCCESS;
+  // (positions are 32-bit: the entries, two descriptors an edge, the parts' rooms with up to seven fillings a vertex)
+  if (A->csc_alias || !A->csc.ptr || !A->csr.val || n != A->ncols || nnz < 1 || nnz > 0x7ffffff0ll || n >= 0x7ffffff0 ||
+      nnz + 8ll * ((long long)n + 1) >= 0xfffffff0ll)
+    return GRB_SUCCESS;
   // GRB_TC_TRACE=1: the host's clock after every stage (each with a stream wait), to stderr
   static const bool trace = [] { const char* e = getenv("GRB_TC_TRACE"); return e && atoi(e) != 0; }();
   auto now_us = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
