@@ -35,3 +35,13 @@ for bits in (14, 15, 16, 17, 18):
     sel = piv < (1 << bits)
     print("pivots numbered below 2^%d: %.4f of the edges, %.4f of the streamed elements (%.4f of the total lies in their partners' parts below 2^%d)"
           % (bits, float(sel.float().mean()), float(dL[par][sel].sum()) / tot, float(c16[par][sel].sum()) / tot, bits))
+# a partner's entries that are not below the PIVOT's number cannot hit either: with sorted lists and a cut per (pivot, partner)
+# only the entries below the pivot's number would be streamed -- how much of the stream is that?
+keys = torch.sort(lo * n + hi).values                       # list entries, owner-major, ascending inside a list
+start = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+start[1:] = torch.cumsum(dL, 0)
+useful = torch.searchsorted(keys, par * n + piv) - start[par]
+print("entries of the streamed lists that are below their pivot's number: %.4f of the streamed elements" % (float(useful.sum()) / tot))
+for bits in (16,):
+    sel = piv < (1 << bits)
+    print("   of pivots numbered below 2^16: %.4f of their stream" % (float(useful[sel].sum()) / float(dL[par][sel].sum())))
