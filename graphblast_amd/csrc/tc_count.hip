@@ -339,22 +339,27 @@ __global__ __launch_bounds__(kBlock) void tc_number_kernel(const unsigned* __res
 
 // pass A: every entry (i, j) as {lower-ranked end, higher-ranked end} in the new numbers; the lower end's list grows by one
 // -- its 16-bit part or its 32-bit part.
-// bad: an entry on or above the diagonal, or a value that is not 1 -- the sum of the product is then not a count
+// bad: bit 0 an entry on the diagonal or a value that is not 1, bits 1 / 2 entries below / above the diagonal (both: the sum
+// of the product is not a count)
 __global__ __launch_bounds__(kBlock) void tc_orient_kernel(const int* __restrict__ erow, const Index* __restrict__ ind,
                                                            const unsigned* __restrict__ val, unsigned one, long long nnz,
                                                            const int* __restrict__ number, int* __restrict__ elo, int* __restrict__ ehi,
                                                            unsigned* __restrict__ c16, unsigned* __restrict__ c32, int* __restrict__ bad) {
   const long long stride = (long long)gridDim.x * kBlock;
-  bool wrong = false;
+  bool wrong = false, below = false, above = false;
   for (long long e = (long long)blockIdx.x * kBlock + threadIdx.x; e < nnz; e += stride) {
     const int i = erow[e], j = (int)ind[e];
-    wrong |= j >= i || val[e] != one;
+    wrong |= j == i || val[e] != one;
+    below |= j < i;
+    above |= j > i;
     const int a = number[i], b = number[j];
     const int lo = a > b ? a : b, hi = a > b ? b : a;
     elo[e] = lo; ehi[e] = hi;
     atomicAdd(hi < 65535 ? &c16[lo] : &c32[lo], 1u);
   }
-  if (__any(wrong) && lane_id() == 0) atomicOr(bad, 1);
+  // (a strictly UPPER triangle of ones sums to the same count: every edge once, either way round; entries on both sides do not)
+  const int f = (__any(wrong) ? 1 : 0) | (__any(below) ? 2 : 0) | (__any(above) ? 4 : 0);
+  if (lane_id() == 0) atomicOr(bad, f);
 }
 
 // the two parts' lengths of every list, and their rooms: the next multiple of 16 bytes (before the scans that make the
@@ -587,7 +592,7 @@ static grb_info tc_prepare(grb_matrix_s* A, TcPrep* t) {
   GRB_HIP_TRY(hipMemcpyAsync(&room32, ptr32 + nn, 4, hipMemcpyDeviceToHost, s));
   GRB_HIP_TRY(hipStreamSynchronize(s));
   stage("scans");
-  if (h_flags[0]) return GRB_SUCCESS;         // not a strictly lower triangle of ones
+  if ((h_flags[0] & 1) || (h_flags[0] & 6) == 6) return GRB_SUCCESS;   // not a strict triangle of ones
   t->longest = h_flags[1];
   GRB_HIP_TRY(hipMalloc((void**)&t->D16, 2 * ((size_t)room16 + 16)));
   GRB_HIP_TRY(hipMalloc((void**)&t->D32, 4 * ((size_t)room32 + 8)));

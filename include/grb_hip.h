@@ -571,8 +571,8 @@ int grb_cc_set_fused(int on);
 
 /* algorithm::tc (algorithm/tc.hpp:15-54): A = lower triangle (int), B = buffer matrix.
  * The reference forms B<A> = A (+.x) A^T and reduces it (tc.hpp:38-43); B is its "buffer matrix" (tc.hpp:17) and is not
- * read again.  When A is a STRICTLY lower triangle whose stored values are all 1 -- the matrix the reference's driver
- * builds (example/gtc.cu) -- that sum is the number of triangles, which does not depend on which way the edges point:
+ * read again.  When A is a STRICTLY lower (or strictly upper) triangle whose stored values are all 1 -- the matrix the
+ * reference's driver builds (example/gtc.cu) -- that sum is the number of triangles, which does not depend on which way the edges point:
  * the library then counts on the degree-ordered orientation of the same edges (csrc/tc_count.hip: every vertex keeps
  * the neighbours of higher degree, the lists are short, one end of every edge is looked up in an LDS bitmap of the other)
  * and LEAVES B AS IT WAS.  The orientation is prepared by the first count on a matrix and kept with it.  Any other

@@ -352,6 +352,19 @@ def test_triangle_count_without_the_product(hb, bitmap_upto):
         assert L2.build_csr(p2, c2[o].astype(np.int32), np.ones(c2.size, dtype=np.int32)) == 0
         info, ntris, _ = g.tc(L2, B2, hb.descriptor())
         assert info == 0 and g.tc_last()[1]["path"] == 0 and ntris == sr.tc(p2, c2[o].astype(np.int32))[0]
+        # a strictly UPPER triangle of ones: the same count, on the orientation as well
+        up_rows = np.repeat(np.arange(n, dtype=np.int32), np.diff(lp))
+        o = np.lexsort((up_rows, li))
+        upp = np.zeros(n + 1, dtype=np.int32)
+        np.cumsum(np.bincount(li, minlength=n), out=upp[1:])
+        U, BU = g.Matrix(n, n, np.int32), g.Matrix(n, n, np.int32)
+        assert U.build_csr(upp, up_rows[o].astype(np.int32), np.ones(li.size, dtype=np.int32)) == 0
+        info, ntris, _ = g.tc(U, BU, hb.descriptor())
+        assert info == 0 and ntris == want and g.tc_last()[1]["path"] == 1
+        g.tc_set_product(1)
+        info, ntris, _ = g.tc(U, BU, hb.descriptor())
+        g.tc_set_product(2)
+        assert info == 0 and ntris == want and g.tc_last()[1]["path"] == 0
         # the first operand transposed: grb_mxm's business
         L3, B3 = g.Matrix(n, n, np.int32), g.Matrix(n, n, np.int32)
         assert L3.build_csr(lp, li, np.ones(li.size, dtype=np.int32)) == 0
